@@ -1,0 +1,216 @@
+/*
+ * include/vmd_eval.h — the drop-in boundary: C ABI of the MI355X property evaluator.
+ *
+ * Mirrors the part of mdlib's md_script surface that VIAMD calls on its evaluation hot path
+ * (SURVEY.md 8b).  Each entry point names the reference call site it replaces (paths relative to
+ * /root/reference).  The script *compiler* (md_script_ir_compile_from_source, src/main.cpp:878) is out
+ * of scope: the IR here is a list of property descriptors filled by vmd_ir_add_* (a mini front-end that
+ * produces them from script text lives in viamd_amd/script.py).
+ *
+ * All compute runs in hand-written HIP kernels (include/vmd_hip.h); there is no CPU fallback: every
+ * function that needs the device returns false/NULL and logs when no HIP device is usable.
+ */
+#ifndef VMD_EVAL_H
+#define VMD_EVAL_H
+
+#include <stdbool.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- data handed in by the host application ---------------------------------------------------- */
+
+/* md_unitcell_t as VIAMD reads it (src/viamd.cpp:1837-1843: x,y,z,xy,xz,yz) + periodicity flags */
+#define VMD_UNITCELL_PBC_X 1u
+#define VMD_UNITCELL_PBC_Y 2u
+#define VMD_UNITCELL_PBC_Z 4u
+#define VMD_UNITCELL_PBC_ALL 7u
+typedef struct vmd_unitcell_t {
+    float x, y, z, xy, xz, yz;
+    uint32_t flags;
+} vmd_unitcell_t;
+
+/* the slice of md_system_t the path reads: SoA coordinates of the displayed frame (src/main.cpp:642),
+ * masses (md_atom_mass, src/viamd.cpp:2253), unit cell.  Coordinates may be NULL: the evaluator always
+ * pulls frames through the trajectory (src/main.cpp:995-996). */
+typedef struct vmd_system_t {
+    size_t atom_count;
+    const float* x;
+    const float* y;
+    const float* z;
+    const float* mass;          /* atom_count entries */
+    vmd_unitcell_t unitcell;
+} vmd_system_t;
+
+typedef struct vmd_frame_header_t {
+    size_t num_atoms;
+    int64_t index;
+    double timestamp;
+    vmd_unitcell_t unitcell;
+} vmd_frame_header_t;
+
+/* device-resident view of a trajectory: frame f has x at base + f*frame_stride, y at +row_stride,
+ * z at +2*row_stride (floats).  cells: host array, one per frame. */
+typedef struct vmd_device_view_t {
+    const float* base;          /* device pointer */
+    size_t frame_stride;
+    size_t row_stride;
+    const vmd_unitcell_t* cells;
+    int device;
+} vmd_device_view_t;
+
+/* md_trajectory_i stand-in.  load_frame has the signature of md_trajectory_load_frame
+ * (src/viamd.cpp:465-467, :1815-1817).  device_view is an extension: when non-NULL and successful the
+ * evaluator reads frames in place from HBM instead of staging them through load_frame. */
+typedef struct vmd_trajectory_i {
+    void* inst;
+    size_t (*num_frames)(void* inst);
+    size_t (*num_atoms)(void* inst);
+    bool (*load_frame)(void* inst, int64_t idx, vmd_frame_header_t* header, float* x, float* y, float* z);
+    bool (*device_view)(void* inst, vmd_device_view_t* out);
+} vmd_trajectory_i;
+
+/* ---- IR: property descriptors (md_script_ir_t stand-in) ----------------------------------------- */
+
+typedef struct vmd_script_ir_t vmd_script_ir_t;
+
+/* md_script_property_flags_t (src/main.cpp:1317,1456,1485) */
+typedef uint32_t vmd_property_flags_t;
+#define VMD_PROPERTY_FLAG_NONE         0u
+#define VMD_PROPERTY_FLAG_TEMPORAL     1u
+#define VMD_PROPERTY_FLAG_DISTRIBUTION 2u
+#define VMD_PROPERTY_FLAG_VOLUME       4u
+
+#define VMD_RDF_NUM_BINS 1024   /* mdlib's distribution bin count */
+#define VMD_VOLUME_DIM   128    /* mdlib's volume resolution, BASELINE config 4 "128^3" */
+
+typedef enum vmd_distance_kind_t {
+    VMD_DISTANCE_COM  = 0,      /* distance(a,b)      */
+    VMD_DISTANCE_MIN  = 1,      /* distance_min(a,b)  */
+    VMD_DISTANCE_MAX  = 2,      /* distance_max(a,b)  */
+    VMD_DISTANCE_PAIR = 3       /* distance_pair(a,b) */
+} vmd_distance_kind_t;
+
+vmd_script_ir_t* vmd_ir_create(void);                                   /* md_script_ir_create, src/main.cpp:846 */
+void             vmd_ir_free(vmd_script_ir_t* ir);                      /* md_script_ir_free,   src/main.cpp:968 */
+/* `name = rdf(ref, target, {rmin,rmax});` — 0-based atom indices, copied.  src/main.cpp:528 */
+bool vmd_ir_add_rdf(vmd_script_ir_t* ir, const char* name, const int32_t* ref, size_t nref,
+                    const int32_t* target, size_t ntarget, float rmin, float rmax);
+/* `name = sdf(structures, target, cutoff);` structures = K index lists of m atoms each.  src/main.cpp:528 */
+bool vmd_ir_add_sdf(vmd_script_ir_t* ir, const char* name, const int32_t* structures, size_t K, size_t m,
+                    const int32_t* target, size_t ntarget, float cutoff);
+/* `name = distance*(a, b);`  src/main.cpp:2817-2858 */
+bool vmd_ir_add_distance(vmd_script_ir_t* ir, const char* name, vmd_distance_kind_t kind,
+                         const int32_t* a, size_t na, const int32_t* b, size_t nb);
+bool     vmd_ir_valid(const vmd_script_ir_t* ir);                       /* md_script_ir_valid, src/main.cpp:936 */
+uint64_t vmd_ir_fingerprint(const vmd_script_ir_t* ir);                 /* md_script_ir_fingerprint, src/main.cpp:937 */
+size_t   vmd_ir_property_count(const vmd_script_ir_t* ir);              /* md_script_ir_property_count, src/main.cpp:992,1277 */
+const char* const* vmd_ir_property_names(const vmd_script_ir_t* ir);    /* md_script_ir_property_names, src/main.cpp:1278 */
+vmd_property_flags_t vmd_ir_property_flags(const vmd_script_ir_t* ir, const char* name); /* src/main.cpp:1285 */
+
+/* ---- evaluation (md_script_eval_t stand-in) ------------------------------------------------------ */
+
+typedef struct vmd_script_eval_t vmd_script_eval_t;
+
+/* md_script_aggregate_t (src/main.cpp:1388-1449): per-frame population statistics of a temporal property */
+typedef struct vmd_script_aggregate_t {
+    size_t num_values;
+    float* population_mean;
+    float* population_var;
+    float (*population_ext)[2];     /* vec2_t {min,max} */
+} vmd_script_aggregate_t;
+
+/* md_script_property_data_t — the fields VIAMD reads.  The struct address and the arrays
+ * stay valid and fixed for the lifetime of the eval, across vmd_eval_clear_data (src/main.cpp:1286,1303). */
+typedef struct vmd_script_property_data_t {
+    int32_t dim[4];                 /* [0] frames (temporal) | [2] bins (distribution) | [1..3] volume dims */
+    float*  values;                 /* temporal: values[frame*dim[1]+i]; distribution: values[bin]; volume: x fastest */
+    float*  weights;                /* distribution only */
+    size_t  num_values;
+    vmd_script_aggregate_t* aggregate;
+    float   min_value, max_value;
+    float   min_range[2], max_range[2];
+    uint64_t fingerprint;
+    /* extension: the exact integer accumulators behind values (distribution: dim[2], volume: dim[1]*dim[2]*dim[3]) */
+    const uint64_t* counts;
+    const double*   weights64;
+} vmd_script_property_data_t;
+
+/* md_script_eval_create(num_frames, ir, alloc), src/main.cpp:971 */
+vmd_script_eval_t* vmd_eval_create(size_t num_frames, const vmd_script_ir_t* ir);
+void     vmd_eval_free(vmd_script_eval_t* eval);                        /* md_script_eval_free, src/main.cpp:960 */
+void     vmd_eval_clear_data(vmd_script_eval_t* eval);                  /* md_script_eval_clear_data, src/main.cpp:990 */
+void     vmd_eval_interrupt(vmd_script_eval_t* eval);                   /* md_script_eval_interrupt, src/main.cpp:829,952,984 */
+uint64_t vmd_eval_ir_fingerprint(const vmd_script_eval_t* eval);        /* md_script_eval_ir_fingerprint, src/main.cpp:987 */
+/* the hot call — md_script_eval_frame_range, src/main.cpp:996,1032.  Re-entrant on one eval from many
+ * threads with disjoint ranges; returns false on interrupt or error. */
+bool vmd_eval_frame_range(vmd_script_eval_t* eval, const vmd_script_ir_t* ir, const vmd_system_t* sys,
+                          vmd_trajectory_i* traj, uint32_t frame_beg, uint32_t frame_end);
+/* md_script_eval_property_data, src/main.cpp:1286 */
+const vmd_script_property_data_t* vmd_eval_property_data(const vmd_script_eval_t* eval, const char* name);
+/* md_script_eval_frame_mask (src/main.cpp:1513): one byte per frame here, non-zero = evaluated */
+const uint8_t* vmd_eval_frame_mask(const vmd_script_eval_t* eval);
+size_t   vmd_eval_num_frames(const vmd_script_eval_t* eval);
+size_t   vmd_eval_frames_done(const vmd_script_eval_t* eval);
+
+/* md_script_vis_eval_payload(..., MD_SCRIPT_VISUALIZE_SDF) (density_volume.cpp:183-188, src/main.cpp:5751):
+ * world->reference matrices of every reference structure of SDF property `name` at `frame`
+ * (column-major mat4, as mat4_t), and the half extent.  matrices: K*16 floats. */
+bool vmd_eval_sdf_matrices(vmd_script_eval_t* eval, const char* name, const vmd_system_t* sys,
+                           vmd_trajectory_i* traj, uint32_t frame, float* matrices, size_t* K_out, float* extent_out);
+
+/* ---- multi-GPU merge: integer accumulators are exported / imported as plain device or host
+ * buffers so the host runtime (torch.distributed = RCCL) can all-reduce them ------------------------- */
+typedef struct vmd_accum_view_t {
+    const char* name;
+    vmd_property_flags_t flags;
+    uint64_t* counts_dev;      /* device u64 accumulators (distribution bins or voxels), may be NULL */
+    size_t    num_counts;
+    double*   weights64;       /* host fp64, distribution only */
+    size_t    num_weights;
+    float*    temporal;        /* host, temporal rows */
+    size_t    num_temporal;
+} vmd_accum_view_t;
+size_t vmd_eval_accum_views(vmd_script_eval_t* eval, vmd_accum_view_t* out, size_t cap);
+/* re-derive values/weights/aggregates from the accumulators (after an external reduce) */
+bool   vmd_eval_finalize(vmd_script_eval_t* eval);
+/* mark frames as evaluated elsewhere (after a mask all-reduce) */
+void   vmd_eval_set_frame_mask(vmd_script_eval_t* eval, const uint8_t* mask, size_t n);
+
+/* ---- device-resident trajectories (pre-staged in HBM) ---------------------------------- */
+typedef struct vmd_devtraj_t vmd_devtraj_t;
+vmd_devtraj_t*    vmd_devtraj_create(size_t num_frames, size_t num_atoms);
+void              vmd_devtraj_free(vmd_devtraj_t* t);
+vmd_trajectory_i* vmd_devtraj_interface(vmd_devtraj_t* t);
+bool vmd_devtraj_upload_frame(vmd_devtraj_t* t, size_t frame, const vmd_unitcell_t* cell,
+                              const float* x, const float* y, const float* z);
+/* seeded synthetic water box of SURVEY 8d (same integer RNG as oracle S9) for frames [beg,end) */
+bool vmd_devtraj_synth(vmd_devtraj_t* t, uint64_t seed, float L, float sigma, uint32_t n_blob,
+                       size_t frame_beg, size_t frame_end);
+float* vmd_devtraj_device_ptr(vmd_devtraj_t* t, size_t* frame_stride, size_t* row_stride);
+
+/* ---- consumer post-processing VIAMD applies to the results (src/main.cpp:139-250), host side ------- */
+void vmd_downsample_histogram(float* dst_bins, int num_dst_bins, const float* src_bins, const float* src_weights,
+                              int num_src_bins);
+void vmd_compute_histogram_masked(float* bins, int num_bins, float range_min, float range_max, const float* values,
+                                  int dim, const uint8_t* frame_mask, int num_frames, bool aggregate);
+
+/* ---- runtime ---------------------------------------------------------------------------------------- */
+int         vmd_device_count(void);                 /* 0 when no HIP device is usable */
+bool        vmd_set_device(int device);
+const char* vmd_last_error(void);                   /* thread-local message of the last failure */
+const char* vmd_version(void);
+/* tuning knobs (kernel variant, frames per batch); returns previous value, -1 for unknown key */
+int         vmd_set_option(const char* key, int value);
+/* wall-clock ms of kernel `which` accumulated by hipEvents since the last reset (bench instrumentation) */
+void        vmd_profile_reset(void);
+double      vmd_profile_ms(const char* which, uint64_t* launches);
+void        vmd_profile_enable(bool on);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,91 @@
+/*
+ * include/vmd_hip.h — thin C-ABI layer over the hand-written gfx950 kernels (no host state, no torch types).
+ *
+ * Every function enqueues work on `stream` (a hipStream_t passed as void*) and returns 0 or a hipError_t.
+ * Pointers are device pointers unless a comment says "host".  A *frame batch* is B consecutive frames:
+ * frame b has x at xyz + b*frame_stride, y at +row_stride, z at +2*row_stride (floats); boxes[b*3+{0,1,2}]
+ * are its orthorhombic edge lengths (SPEC S1).
+ *
+ * Reference functions replaced (the sources are in the empty submodule ext/mdlib, /root/reference/.gitmodules:10-12;
+ * names from /root/reference/ext/ImGuiColorTextEdit/TextEditor.cpp:3318-3331 and SURVEY.md 8a):
+ *   vmd_hip_cells_*   <- md_spatial_hash build            (a5)
+ *   vmd_hip_rdf_*     <- rdf() pair loop + md_spatial_hash query (a4, a5)
+ *   vmd_hip_sdf_*     <- sdf() alignment + density-volume accumulation (a6, a7, a9)
+ *   vmd_hip_distance  <- distance / distance_min / distance_max / distance_pair (a8)
+ */
+#ifndef VMD_HIP_H
+#define VMD_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* pencil grid of one batch: ny*nz pencils along x, each cut into nxf fine cells (SPEC S3 note) */
+typedef struct vmd_grid_t {
+    int32_t nxf, ny, nz;
+    int32_t ncell;          /* nxf*ny*nz */
+} vmd_grid_t;
+
+/* K1: bin the `nsel` selected atoms of every frame of the batch into the grid and write them cell-sorted.
+ *   sel        int32[nsel] atom indices (NULL = 0..nsel-1)
+ *   cell_count u32[B][ncell+1]  scratch, zeroed by this call
+ *   rank       u32[B][nsel]     scratch
+ *   cell_start u32[B][ncell+1]  out: exclusive prefix of the cell populations
+ *   sorted     f32[B][3][nsel_pad] out: wrapped coordinates in cell order (x row, y row, z row) */
+int vmd_hip_cells_build(void* stream, const float* xyz, size_t frame_stride, size_t row_stride,
+                        const float* boxes, int B, const int32_t* sel, int nsel, int nsel_pad,
+                        vmd_grid_t grid, uint32_t* cell_count, uint32_t* rank, uint32_t* cell_start, float* sorted);
+
+/* K2: RDF pair histogram over a batch from cell-sorted selections (ref may equal tgt -> half shell).
+ *   partial   u64[nblocks][nbins] scratch (nblocks = vmd_hip_rdf_num_blocks())
+ *   counts    u64[nbins]  accumulated (+=) with device atomics
+ *   variant   0 = wave queue (default), 1 = inline hit path */
+int vmd_hip_rdf_num_blocks(void);
+int vmd_hip_rdf_pencil(void* stream, const float* sorted_ref, const uint32_t* cell_start_ref, int nref, int nref_pad,
+                       const float* sorted_tgt, const uint32_t* cell_start_tgt, int ntgt, int ntgt_pad,
+                       const float* boxes, int B, vmd_grid_t grid, float rmin, float rmax, int nbins,
+                       int same_set, int variant, uint64_t* partial, uint64_t* counts);
+
+/* general RDF (any periodicity flags, any cutoff, no grid): O(nref*ntgt) per frame, SPEC S3 by comparison */
+int vmd_hip_rdf_brute(void* stream, const float* xyz, size_t frame_stride, size_t row_stride,
+                      const float* boxes, uint32_t pbc_flags, int B,
+                      const int32_t* ref, int nref, const int32_t* tgt, int ntgt,
+                      float rmin, float rmax, int nbins, uint64_t* counts);
+
+/* K3: per frame, per reference structure alignment (fp64, SPEC S5).
+ *   structs  int32[K][m], mass f32[K][m], ref_pose f64[m][3] (COM-centred)
+ *   R32 f32[B][K][9], c32 f32[B][K][3] out;  M64 f64[B][K][12] out (optional, may be NULL) */
+int vmd_hip_sdf_align(void* stream, const float* xyz, size_t frame_stride, size_t row_stride,
+                      const float* boxes, uint32_t pbc_flags, int B,
+                      const int32_t* structs, const float* mass, int K, int m, const double* ref_pose,
+                      float* R32, float* c32, double* M64);
+/* reference pose from one frame (structure 0): ref_pose f64[m][3] out */
+int vmd_hip_sdf_ref_pose(void* stream, const float* xyz, size_t row_stride, const float* box, uint32_t pbc_flags,
+                         const int32_t* struct0, const float* mass0, int m, double* ref_pose);
+/* K4: scatter target atoms of every frame into the dim^3 u64 volume (x fastest), SPEC S5 */
+int vmd_hip_sdf_scatter(void* stream, const float* xyz, size_t frame_stride, size_t row_stride,
+                        const float* boxes, uint32_t pbc_flags, int B,
+                        const int32_t* structs, int K, int m, const float* R32, const float* c32,
+                        const int32_t* tgt, int ntgt, float extent, int dim, uint64_t* volume);
+
+/* K5: distance family, one row per frame: out f32[B][dim1], dim1 = 1 (COM/MIN/MAX) or na*nb (PAIR). kind as
+ * vmd_distance_kind_t.  mass_a/mass_b f32[na]/[nb] (COM only). */
+int vmd_hip_distance(void* stream, const float* xyz, size_t frame_stride, size_t row_stride,
+                     const float* boxes, uint32_t pbc_flags, int B, int kind,
+                     const int32_t* a, const float* mass_a, int na, const int32_t* b, const float* mass_b, int nb,
+                     float* out);
+
+/* u64 counters -> f32 values (values[i] = (float)counts[i]) + max reduction into max_out[0] (device f32) */
+int vmd_hip_counts_to_float(void* stream, const uint64_t* counts, size_t n, float* values, float* max_out);
+
+/* synthetic water box (oracle S9 twin): fills frames [frame0, frame0+B) of a batch laid out as above */
+int vmd_hip_synth_frames(void* stream, float* xyz, size_t frame_stride, size_t row_stride, int B, uint32_t frame0,
+                         uint64_t seed, uint32_t n_atoms, uint32_t n_blob, float L, float sigma);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

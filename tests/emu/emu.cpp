@@ -1,0 +1,157 @@
+// tests/emu/emu.cpp — TEST-ONLY SIMT emulator: runs a HIP-style kernel on the CPU, one cooperative fiber per
+// GPU thread, blocks one after another.  __syncthreads() and the wave64 collectives (__ballot, __shfl_xor,
+// wave barrier) are rendezvous points among the live fibers of the block / wave.  See hip/hip_runtime.h.
+#include "hip/hip_runtime.h"
+
+#include <sys/mman.h>
+#include <ucontext.h>
+
+#include <vector>
+
+namespace emu {
+
+enum State { RUNNABLE = 0, WAIT_BLOCK = 1, WAIT_WAVE = 2, DONE = 3 };
+
+struct Fiber {
+    ucontext_t ctx;
+    char* stack = nullptr;
+    int state = DONE;
+    emu_uint3 tid{0, 0, 0};
+    int linear = 0;
+    unsigned gen = 0;
+};
+
+Fiber* g_cur = nullptr;
+emu_uint3 g_blockIdx{0, 0, 0};
+dim3 g_blockDim, g_gridDim;
+
+static const size_t kStack = 256 * 1024;
+static std::vector<Fiber> g_fibers;
+static ucontext_t g_sched;
+static const std::function<void()>* g_body = nullptr;
+// per wave exchange buffers, double buffered by the per-fiber generation counter
+static std::vector<uint64_t> g_xbuf;   // [wave][2][64]
+
+emu_uint3 cur_tid() { return g_cur->tid; }
+int cur_lane() { return g_cur->linear & 63; }
+
+static void fiber_entry() {
+    (*g_body)();
+    Fiber* f = g_cur;
+    f->state = DONE;
+    const int wave = f->linear >> 6, lane = f->linear & 63;
+    g_xbuf[(size_t)(wave * 2 + 0) * 64 + lane] = 0;
+    g_xbuf[(size_t)(wave * 2 + 1) * 64 + lane] = 0;
+    swapcontext(&f->ctx, &g_sched);
+}
+
+static void yield(State s) {
+    Fiber* f = g_cur;
+    f->state = s;
+    swapcontext(&f->ctx, &g_sched);
+}
+
+void sync_block() { yield(WAIT_BLOCK); }
+void sync_wave() { yield(WAIT_WAVE); }
+
+static uint64_t* xslot(Fiber* f, unsigned gen) { return &g_xbuf[(size_t)((f->linear >> 6) * 2 + (gen & 1)) * 64]; }
+
+unsigned long long ballot(int pred) {
+    Fiber* f = g_cur;
+    const unsigned gen = f->gen++;
+    uint64_t* s = xslot(f, gen);
+    s[f->linear & 63] = pred ? 1 : 0;
+    yield(WAIT_WAVE);
+    unsigned long long m = 0;
+    for (int l = 0; l < 64; ++l) if (s[l]) m |= 1ull << l;
+    return m;
+}
+
+uint32_t shfl_xor_bits(uint32_t v, int mask) {
+    Fiber* f = g_cur;
+    const unsigned gen = f->gen++;
+    uint64_t* s = xslot(f, gen);
+    s[f->linear & 63] = v;
+    yield(WAIT_WAVE);
+    return (uint32_t)s[(f->linear & 63) ^ (mask & 63)];
+}
+
+static void run_block(int nthreads) {
+    const int nwaves = (nthreads + 63) / 64;
+    g_xbuf.assign((size_t)nwaves * 2 * 64, 0);
+    if ((int)g_fibers.size() < nthreads) {
+        const size_t old = g_fibers.size();
+        g_fibers.resize(nthreads);
+        for (size_t i = old; i < g_fibers.size(); ++i) {
+            g_fibers[i].stack = (char*)mmap(nullptr, kStack, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+            if (g_fibers[i].stack == MAP_FAILED) { fprintf(stderr, "emu: mmap failed\n"); abort(); }
+        }
+    }
+    for (int t = 0; t < nthreads; ++t) {
+        Fiber& f = g_fibers[t];
+        f.state = RUNNABLE;
+        f.linear = t;
+        f.gen = 0;
+        f.tid.x = t % g_blockDim.x;
+        f.tid.y = (t / g_blockDim.x) % g_blockDim.y;
+        f.tid.z = t / (g_blockDim.x * g_blockDim.y);
+        getcontext(&f.ctx);
+        f.ctx.uc_stack.ss_sp = f.stack;
+        f.ctx.uc_stack.ss_size = kStack;
+        f.ctx.uc_link = &g_sched;
+        makecontext(&f.ctx, fiber_entry, 0);
+    }
+    for (;;) {
+        bool ran = false;
+        for (int t = 0; t < nthreads; ++t) {
+            Fiber& f = g_fibers[t];
+            if (f.state != RUNNABLE) continue;
+            g_cur = &f;
+            swapcontext(&g_sched, &f.ctx);
+            ran = true;
+        }
+        // release rendezvous points
+        bool released = false, all_done = true, block_ready = true;
+        for (int t = 0; t < nthreads; ++t) {
+            const int s = g_fibers[t].state;
+            if (s != DONE) all_done = false;
+            if (s != DONE && s != WAIT_BLOCK) block_ready = false;
+        }
+        if (all_done) break;
+        if (block_ready) {
+            for (int t = 0; t < nthreads; ++t) if (g_fibers[t].state == WAIT_BLOCK) { g_fibers[t].state = RUNNABLE; released = true; }
+        }
+        for (int w = 0; w < nwaves; ++w) {
+            bool ready = true, any = false;
+            const int end = (w + 1) * 64 < nthreads ? (w + 1) * 64 : nthreads;
+            for (int t = w * 64; t < end; ++t) {
+                const int s = g_fibers[t].state;
+                if (s == WAIT_WAVE) any = true;
+                else if (s != DONE) ready = false;
+            }
+            if (ready && any) {
+                for (int t = w * 64; t < end; ++t) if (g_fibers[t].state == WAIT_WAVE) { g_fibers[t].state = RUNNABLE; released = true; }
+            }
+        }
+        if (!ran && !released) {
+            fprintf(stderr, "emu: deadlock (divergent barrier / collective) in block (%u,%u,%u)\n", g_blockIdx.x, g_blockIdx.y, g_blockIdx.z);
+            abort();
+        }
+    }
+}
+
+void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
+    g_body = &body;
+    g_gridDim = grid;
+    g_blockDim = block;
+    const int nthreads = (int)(block.x * block.y * block.z);
+    for (unsigned bz = 0; bz < grid.z; ++bz)
+        for (unsigned by = 0; by < grid.y; ++by)
+            for (unsigned bx = 0; bx < grid.x; ++bx) {
+                g_blockIdx = emu_uint3{bx, by, bz};
+                run_block(nthreads);
+            }
+    g_body = nullptr;
+}
+
+}  // namespace emu

@@ -1,0 +1,110 @@
+// tests/emu/hip/hip_runtime.h — TEST-ONLY stand-in for <hip/hip_runtime.h>.
+//
+// Lets g++ compile viamd_amd/csrc/*.hip|*.cpp unchanged into tests/emu/libviamd_emu.so, where every kernel runs
+// on the CPU as cooperative fibers (one per GPU thread; wave64 collectives and __syncthreads are rendezvous points).
+// Purpose: check kernel *logic* (indexing, segment enumeration, queue/flush machinery, host batching) against the
+// oracle in this GPU-less container before spending GPU minutes.  It is NOT a backend: the viamd_amd Python package
+// never loads it, and bench.py / smoke() / `-m gpu` tests only ever use the hipcc-built libviamd_amd.so.
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __shared__ static
+#define __launch_bounds__(...)
+#define VMD_UNIFORM_AS
+
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct emu_uint3 { unsigned x, y, z; };
+
+namespace emu {
+struct Fiber;
+extern Fiber* g_cur;
+extern emu_uint3 g_blockIdx;
+extern dim3 g_blockDim, g_gridDim;
+emu_uint3 cur_tid();
+int cur_lane();
+void launch(dim3 grid, dim3 block, const std::function<void()>& body);
+void sync_block();
+void sync_wave();
+unsigned long long ballot(int pred);
+uint32_t shfl_xor_bits(uint32_t v, int mask);
+}  // namespace emu
+
+#define threadIdx (emu::cur_tid())
+#define blockIdx (emu::g_blockIdx)
+#define blockDim (emu::g_blockDim)
+#define gridDim (emu::g_gridDim)
+
+// ---- device builtins used by the kernels -----------------------------------------------------------------------
+static inline void __syncthreads() { emu::sync_block(); }
+static inline unsigned long long __ballot(int pred) { return emu::ballot(pred); }
+static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+static inline float __int_as_float(int v) { float f; memcpy(&f, &v, 4); return f; }
+static inline int __float_as_int(float f) { int v; memcpy(&v, &f, 4); return v; }
+static inline float __shfl_xor(float v, int mask) {
+    uint32_t b; memcpy(&b, &v, 4);
+    b = emu::shfl_xor_bits(b, mask);
+    float r; memcpy(&r, &b, 4); return r;
+}
+static inline unsigned emu_mbcnt_lo(unsigned mask, unsigned add) {
+    const int lane = emu::cur_lane();
+    const unsigned lt = lane >= 32 ? 0xffffffffu : ((1u << lane) - 1u);
+    return add + (unsigned)__builtin_popcount(mask & lt);
+}
+static inline unsigned emu_mbcnt_hi(unsigned mask, unsigned add) {
+    const int lane = emu::cur_lane();
+    const unsigned lt = lane < 32 ? 0u : (lane == 63 ? 0x7fffffffu : ((1u << (lane - 32)) - 1u));
+    return add + (unsigned)__builtin_popcount(mask & lt);
+}
+#define __builtin_amdgcn_mbcnt_lo(m, v) emu_mbcnt_lo((m), (v))
+#define __builtin_amdgcn_mbcnt_hi(m, v) emu_mbcnt_hi((m), (v))
+#define __builtin_amdgcn_readfirstlane(v) (v)
+#define __builtin_amdgcn_wave_barrier() emu::sync_wave()
+
+template <typename T>
+static inline T atomicAdd(T* p, T v) { T old = *p; *p = old + v; return old; }
+static inline unsigned atomicMax(unsigned* p, unsigned v) { unsigned old = *p; if (v > old) *p = v; return old; }
+
+// ---- host runtime -------------------------------------------------------------------------------------------------
+typedef int hipError_t;
+enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2 };
+typedef struct emu_stream_t* hipStream_t;
+typedef struct emu_event_t* hipEvent_t;
+enum hipMemcpyKind { hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3 };
+#define hipStreamNonBlocking 1
+#define hipHostMallocDefault 0
+
+static inline const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "success" : "emu error"; }
+static inline hipError_t hipGetLastError() { return hipSuccess; }
+static inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
+static inline hipError_t hipSetDevice(int) { return hipSuccess; }
+static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = (hipStream_t)0x1; return hipSuccess; }
+static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+static inline hipError_t hipMalloc(void** p, size_t n) { *p = calloc(n ? n : 1, 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
+static inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+static inline hipError_t hipHostMalloc(void** p, size_t n, unsigned) { return hipMalloc(p, n); }
+static inline hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
+static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
+static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = (hipEvent_t)0x1; return hipSuccess; }
+static inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.0f; return hipSuccess; }
+
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
+    emu::launch((grid), (block), [=]() { kernel(__VA_ARGS__); })

@@ -1,0 +1,177 @@
+"""ctypes binding of the C ABI declared in include/vmd_eval.h and include/vmd_hip.h.
+
+The product library is viamd_amd/libviamd_amd.so, built by hipcc for gfx950 (see viamd_amd/build.py).
+There is no CPU fallback: if the library is missing, `default_lib()` raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libviamd_amd.so")
+
+PBC_ALL = 7
+FLAG_TEMPORAL, FLAG_DISTRIBUTION, FLAG_VOLUME = 1, 2, 4
+DIST_COM, DIST_MIN, DIST_MAX, DIST_PAIR = 0, 1, 2, 3
+RDF_NUM_BINS = 1024
+VOLUME_DIM = 128
+
+c_float_p = C.POINTER(C.c_float)
+c_int32_p = C.POINTER(C.c_int32)
+c_uint8_p = C.POINTER(C.c_uint8)
+c_uint64_p = C.POINTER(C.c_uint64)
+c_double_p = C.POINTER(C.c_double)
+
+
+class Unitcell(C.Structure):
+    _fields_ = [("x", C.c_float), ("y", C.c_float), ("z", C.c_float),
+                ("xy", C.c_float), ("xz", C.c_float), ("yz", C.c_float),
+                ("flags", C.c_uint32)]
+
+
+class System(C.Structure):
+    _fields_ = [("atom_count", C.c_size_t), ("x", c_float_p), ("y", c_float_p), ("z", c_float_p),
+                ("mass", c_float_p), ("unitcell", Unitcell)]
+
+
+class FrameHeader(C.Structure):
+    _fields_ = [("num_atoms", C.c_size_t), ("index", C.c_int64), ("timestamp", C.c_double), ("unitcell", Unitcell)]
+
+
+class DeviceView(C.Structure):
+    _fields_ = [("base", c_float_p), ("frame_stride", C.c_size_t), ("row_stride", C.c_size_t),
+                ("cells", C.POINTER(Unitcell)), ("device", C.c_int)]
+
+
+NUM_FRAMES_FN = C.CFUNCTYPE(C.c_size_t, C.c_void_p)
+NUM_ATOMS_FN = C.CFUNCTYPE(C.c_size_t, C.c_void_p)
+LOAD_FRAME_FN = C.CFUNCTYPE(C.c_bool, C.c_void_p, C.c_int64, C.POINTER(FrameHeader), c_float_p, c_float_p, c_float_p)
+DEVICE_VIEW_FN = C.CFUNCTYPE(C.c_bool, C.c_void_p, C.POINTER(DeviceView))
+
+
+class TrajectoryI(C.Structure):
+    _fields_ = [("inst", C.c_void_p), ("num_frames", NUM_FRAMES_FN), ("num_atoms", NUM_ATOMS_FN),
+                ("load_frame", LOAD_FRAME_FN), ("device_view", DEVICE_VIEW_FN)]
+
+
+class Aggregate(C.Structure):
+    _fields_ = [("num_values", C.c_size_t), ("population_mean", c_float_p), ("population_var", c_float_p),
+                ("population_ext", c_float_p)]
+
+
+class PropertyData(C.Structure):
+    _fields_ = [("dim", C.c_int32 * 4), ("values", c_float_p), ("weights", c_float_p), ("num_values", C.c_size_t),
+                ("aggregate", C.POINTER(Aggregate)), ("min_value", C.c_float), ("max_value", C.c_float),
+                ("min_range", C.c_float * 2), ("max_range", C.c_float * 2), ("fingerprint", C.c_uint64),
+                ("counts", c_uint64_p), ("weights64", c_double_p)]
+
+
+class AccumView(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("flags", C.c_uint32), ("counts_dev", C.c_void_p), ("num_counts", C.c_size_t),
+                ("weights64", c_double_p), ("num_weights", C.c_size_t), ("temporal", c_float_p), ("num_temporal", C.c_size_t)]
+
+
+class Grid(C.Structure):
+    _fields_ = [("nxf", C.c_int32), ("ny", C.c_int32), ("nz", C.c_int32), ("ncell", C.c_int32)]
+
+
+# every symbol include/vmd_eval.h and include/vmd_hip.h declare: (name, restype, argtypes)
+_vp = C.c_void_p
+SIGNATURES = [
+    # vmd_eval.h
+    ("vmd_ir_create", _vp, []),
+    ("vmd_ir_free", None, [_vp]),
+    ("vmd_ir_add_rdf", C.c_bool, [_vp, C.c_char_p, c_int32_p, C.c_size_t, c_int32_p, C.c_size_t, C.c_float, C.c_float]),
+    ("vmd_ir_add_sdf", C.c_bool, [_vp, C.c_char_p, c_int32_p, C.c_size_t, C.c_size_t, c_int32_p, C.c_size_t, C.c_float]),
+    ("vmd_ir_add_distance", C.c_bool, [_vp, C.c_char_p, C.c_int, c_int32_p, C.c_size_t, c_int32_p, C.c_size_t]),
+    ("vmd_ir_valid", C.c_bool, [_vp]),
+    ("vmd_ir_fingerprint", C.c_uint64, [_vp]),
+    ("vmd_ir_property_count", C.c_size_t, [_vp]),
+    ("vmd_ir_property_names", C.POINTER(C.c_char_p), [_vp]),
+    ("vmd_ir_property_flags", C.c_uint32, [_vp, C.c_char_p]),
+    ("vmd_eval_create", _vp, [C.c_size_t, _vp]),
+    ("vmd_eval_free", None, [_vp]),
+    ("vmd_eval_clear_data", None, [_vp]),
+    ("vmd_eval_interrupt", None, [_vp]),
+    ("vmd_eval_ir_fingerprint", C.c_uint64, [_vp]),
+    ("vmd_eval_frame_range", C.c_bool, [_vp, _vp, C.POINTER(System), C.POINTER(TrajectoryI), C.c_uint32, C.c_uint32]),
+    ("vmd_eval_property_data", C.POINTER(PropertyData), [_vp, C.c_char_p]),
+    ("vmd_eval_frame_mask", c_uint8_p, [_vp]),
+    ("vmd_eval_num_frames", C.c_size_t, [_vp]),
+    ("vmd_eval_frames_done", C.c_size_t, [_vp]),
+    ("vmd_eval_sdf_matrices", C.c_bool, [_vp, C.c_char_p, C.POINTER(System), C.POINTER(TrajectoryI), C.c_uint32, c_float_p,
+                                         C.POINTER(C.c_size_t), c_float_p]),
+    ("vmd_eval_accum_views", C.c_size_t, [_vp, C.POINTER(AccumView), C.c_size_t]),
+    ("vmd_eval_finalize", C.c_bool, [_vp]),
+    ("vmd_eval_set_frame_mask", None, [_vp, c_uint8_p, C.c_size_t]),
+    ("vmd_devtraj_create", _vp, [C.c_size_t, C.c_size_t]),
+    ("vmd_devtraj_free", None, [_vp]),
+    ("vmd_devtraj_interface", C.POINTER(TrajectoryI), [_vp]),
+    ("vmd_devtraj_upload_frame", C.c_bool, [_vp, C.c_size_t, C.POINTER(Unitcell), c_float_p, c_float_p, c_float_p]),
+    ("vmd_devtraj_synth", C.c_bool, [_vp, C.c_uint64, C.c_float, C.c_float, C.c_uint32, C.c_size_t, C.c_size_t]),
+    ("vmd_devtraj_device_ptr", _vp, [_vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    ("vmd_downsample_histogram", None, [c_float_p, C.c_int, c_float_p, c_float_p, C.c_int]),
+    ("vmd_compute_histogram_masked", None, [c_float_p, C.c_int, C.c_float, C.c_float, c_float_p, C.c_int, c_uint8_p, C.c_int, C.c_bool]),
+    ("vmd_device_count", C.c_int, []),
+    ("vmd_set_device", C.c_bool, [C.c_int]),
+    ("vmd_last_error", C.c_char_p, []),
+    ("vmd_version", C.c_char_p, []),
+    ("vmd_set_option", C.c_int, [C.c_char_p, C.c_int]),
+    ("vmd_profile_reset", None, []),
+    ("vmd_profile_ms", C.c_double, [C.c_char_p, c_uint64_p]),
+    ("vmd_profile_enable", None, [C.c_bool]),
+    # vmd_hip.h
+    ("vmd_hip_cells_build", C.c_int, [_vp, _vp, C.c_size_t, C.c_size_t, _vp, C.c_int, _vp, C.c_int, C.c_int, Grid, _vp, _vp, _vp, _vp]),
+    ("vmd_hip_rdf_num_blocks", C.c_int, []),
+    ("vmd_hip_rdf_pencil", C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, C.c_int, C.c_int, _vp, C.c_int, Grid,
+                                     C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, _vp, _vp]),
+    ("vmd_hip_rdf_brute", C.c_int, [_vp, _vp, C.c_size_t, C.c_size_t, _vp, C.c_uint32, C.c_int, _vp, C.c_int, _vp, C.c_int,
+                                    C.c_float, C.c_float, C.c_int, _vp]),
+    ("vmd_hip_sdf_align", C.c_int, [_vp, _vp, C.c_size_t, C.c_size_t, _vp, C.c_uint32, C.c_int, _vp, _vp, C.c_int, C.c_int, _vp,
+                                    _vp, _vp, _vp]),
+    ("vmd_hip_sdf_ref_pose", C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_uint32, _vp, _vp, C.c_int, _vp]),
+    ("vmd_hip_sdf_scatter", C.c_int, [_vp, _vp, C.c_size_t, C.c_size_t, _vp, C.c_uint32, C.c_int, _vp, C.c_int, C.c_int, _vp, _vp,
+                                      _vp, C.c_int, C.c_float, C.c_int, _vp]),
+    ("vmd_hip_distance", C.c_int, [_vp, _vp, C.c_size_t, C.c_size_t, _vp, C.c_uint32, C.c_int, C.c_int, _vp, _vp, C.c_int,
+                                   _vp, _vp, C.c_int, _vp]),
+    ("vmd_hip_counts_to_float", C.c_int, [_vp, _vp, C.c_size_t, _vp, _vp]),
+    ("vmd_hip_synth_frames", C.c_int, [_vp, _vp, C.c_size_t, C.c_size_t, C.c_int, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32,
+                                       C.c_float, C.c_float]),
+]
+
+
+class VmdLib:
+    """A loaded libviamd_amd.so with typed entry points (attribute access -> ctypes function)."""
+
+    def __init__(self, path=LIB_PATH):
+        if not os.path.exists(path):
+            raise ImportError(
+                f"{path} not found: the MI355X backend is a hipcc-built shared library and there is no CPU fallback. "
+                "Build it with `python -c 'import __graft_entry__ as g; g.build()'` (or viamd_amd/build.py).")
+        self.path = path
+        self.cdll = C.CDLL(path)
+        missing = []
+        for name, restype, argtypes in SIGNATURES:
+            try:
+                fn = getattr(self.cdll, name)
+            except AttributeError:
+                missing.append(name)
+                continue
+            fn.restype = restype
+            fn.argtypes = argtypes
+            setattr(self, name, fn)
+        if missing:
+            raise ImportError(f"{path} lacks symbols declared in include/*.h: {missing}")
+
+    def last_error(self):
+        msg = self.vmd_last_error()
+        return msg.decode() if msg else ""
+
+
+_default = None
+
+
+def default_lib():
+    global _default
+    if _default is None:
+        _default = VmdLib(LIB_PATH)
+    return _default

@@ -1,0 +1,42 @@
+"""Build viamd_amd/libviamd_amd.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+import os
+import shutil
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(_HERE)
+SOURCES = [os.path.join(_HERE, "csrc", "vmd_kernels.hip"), os.path.join(_HERE, "csrc", "vmd_eval.cpp")]
+HEADERS = [os.path.join(ROOT, "include", "vmd_eval.h"), os.path.join(ROOT, "include", "vmd_hip.h")]
+OUT = os.path.join(_HERE, "libviamd_amd.so")
+
+# -ffp-contract=off: oracle/SPEC.md names every fused operation explicitly (fmaf); nothing else may be contracted.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+         "-Wno-unused-value", "-Wno-pass-failed"]
+
+
+def hipcc():
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found: the MI355X backend cannot be built (there is no CPU fallback)")
+    return exe
+
+
+def up_to_date():
+    if not os.path.exists(OUT):
+        return False
+    t = os.path.getmtime(OUT)
+    return all(os.path.getmtime(s) <= t for s in SOURCES + HEADERS + [os.path.abspath(__file__)])
+
+
+def build(force=False, verbose=False):
+    if not force and up_to_date():
+        return OUT
+    cmd = [hipcc()] + FLAGS + ["-I", os.path.join(ROOT, "include"), "-x", "hip"] + SOURCES + ["-o", OUT]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force=True, verbose=True))

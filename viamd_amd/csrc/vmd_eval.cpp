@@ -1,0 +1,1005 @@
+// viamd_amd/csrc/vmd_eval.cpp — C++ host side of the drop-in boundary (include/vmd_eval.h).
+//
+// Mirrors the md_script_eval_* lifecycle VIAMD drives (/root/reference/src/main.cpp:951-1039): create ->
+// clear_data -> frame_range from pool threads -> property_data / frame_mask polled by the GUI thread.
+// All arithmetic happens in the HIP kernels of vmd_kernels.hip; this file only batches frames, owns the
+// device buffers and keeps the md_script_property_data_t views up to date.  There is no CPU compute path.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "vmd_eval.h"
+#include "vmd_hip.h"
+
+// ------------------------------------------------------------------------------------------------ errors / options
+
+static thread_local std::string g_last_error;
+
+static bool vmd_fail(const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    fprintf(stderr, "[viamd_amd] error: %s\n", buf);
+    return false;
+}
+
+#define HIP_OK(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess) return vmd_fail("%s failed: %s", #expr, hipGetErrorString(e_));     \
+    } while (0)
+#define KRN_OK(expr)                                                                              \
+    do {                                                                                          \
+        int e_ = (expr);                                                                          \
+        if (e_ != 0) return vmd_fail("%s failed: %s", #expr, hipGetErrorString((hipError_t)e_));  \
+    } while (0)
+
+struct Options {
+    std::atomic<int> rdf_variant{0};     // 0 queue, 1 inline
+    std::atomic<int> batch_frames{0};    // 0 = auto
+    std::atomic<int> force_brute{0};
+    std::atomic<int> nxf_divisor{8};     // fine x cell = rmax / nxf_divisor
+};
+static Options g_opt;
+
+extern "C" int vmd_set_option(const char* key, int value) {
+    std::atomic<int>* o = nullptr;
+    if (!strcmp(key, "rdf_variant")) o = &g_opt.rdf_variant;
+    else if (!strcmp(key, "batch_frames")) o = &g_opt.batch_frames;
+    else if (!strcmp(key, "force_brute")) o = &g_opt.force_brute;
+    else if (!strcmp(key, "nxf_divisor")) o = &g_opt.nxf_divisor;
+    if (!o) return -1;
+    return o->exchange(value);
+}
+
+extern "C" const char* vmd_last_error(void) { return g_last_error.c_str(); }
+extern "C" const char* vmd_version(void) { return "viamd_amd 0.1 (gfx950)"; }
+
+extern "C" int vmd_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+extern "C" bool vmd_set_device(int device) {
+    HIP_OK(hipSetDevice(device));
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------ profiling (hipEvents)
+
+struct ProfEntry { double ms = 0.0; uint64_t launches = 0; };
+static std::mutex g_prof_mtx;
+static std::map<std::string, ProfEntry> g_prof;
+static std::atomic<bool> g_prof_on{false};
+
+extern "C" void vmd_profile_enable(bool on) { g_prof_on = on; }
+extern "C" void vmd_profile_reset(void) { std::lock_guard<std::mutex> l(g_prof_mtx); g_prof.clear(); }
+extern "C" double vmd_profile_ms(const char* which, uint64_t* launches) {
+    std::lock_guard<std::mutex> l(g_prof_mtx);
+    auto it = g_prof.find(which);
+    if (it == g_prof.end()) { if (launches) *launches = 0; return 0.0; }
+    if (launches) *launches = it->second.launches;
+    return it->second.ms;
+}
+
+struct ProfPending { const char* name; hipEvent_t a, b; };
+struct Profiler {
+    std::vector<ProfPending> pending;
+    std::vector<hipEvent_t> pool;
+    hipEvent_t get() {
+        if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+        hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return nullptr; return e;
+    }
+    void begin(const char* name, hipStream_t s) {
+        if (!g_prof_on) return;
+        ProfPending p{name, get(), get()};
+        if (!p.a || !p.b) return;
+        hipEventRecord(p.a, s);
+        pending.push_back(p);
+    }
+    void end(hipStream_t s) {
+        if (!g_prof_on || pending.empty()) return;
+        hipEventRecord(pending.back().b, s);
+    }
+    void resolve() {   // call after the stream is synchronised
+        if (pending.empty()) return;
+        std::lock_guard<std::mutex> l(g_prof_mtx);
+        for (auto& p : pending) {
+            float ms = 0.0f;
+            if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) { g_prof[p.name].ms += ms; g_prof[p.name].launches += 1; }
+            pool.push_back(p.a); pool.push_back(p.b);
+        }
+        pending.clear();
+    }
+    ~Profiler() { for (auto e : pool) hipEventDestroy(e); for (auto& p : pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); } }
+};
+
+// ------------------------------------------------------------------------------------------------ device buffer helper
+
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t cap = 0;
+    bool ensure(size_t n) {
+        if (n <= cap) return true;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        hipError_t e = hipMalloc((void**)&p, std::max<size_t>(n, 1) * sizeof(T));
+        if (e != hipSuccess) return vmd_fail("hipMalloc(%zu bytes) failed: %s", n * sizeof(T), hipGetErrorString(e));
+        cap = n;
+        return true;
+    }
+    bool upload(const T* src, size_t n, hipStream_t s) {
+        if (!ensure(n)) return false;
+        if (n) HIP_OK(hipMemcpyAsync(p, src, n * sizeof(T), hipMemcpyHostToDevice, s));
+        return true;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    ~DevBuf() { release(); }
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+};
+
+// ------------------------------------------------------------------------------------------------ IR
+
+enum PropKind { PROP_RDF = 0, PROP_SDF = 1, PROP_DIST = 2 };
+
+struct Property {
+    std::string name;
+    PropKind kind;
+    vmd_property_flags_t flags;
+    std::vector<int32_t> a, b;      // RDF: ref/target; SDF: structures (K*m)/target; DIST: a/b
+    float rmin = 0.0f, rmax = 0.0f; // RDF range; SDF: rmax = cutoff (half extent)
+    size_t K = 0, m = 0;
+    int dist_kind = 0;
+};
+
+struct vmd_script_ir_t {
+    std::vector<Property> props;
+    std::vector<const char*> names;
+    void rebuild_names() { names.clear(); for (auto& p : props) names.push_back(p.name.c_str()); }
+};
+
+static uint64_t fnv1a(uint64_t h, const void* data, size_t n) {
+    const uint8_t* p = (const uint8_t*)data;
+    for (size_t i = 0; i < n; ++i) { h ^= p[i]; h *= 0x100000001B3ull; }
+    return h;
+}
+
+extern "C" vmd_script_ir_t* vmd_ir_create(void) { return new vmd_script_ir_t(); }
+extern "C" void vmd_ir_free(vmd_script_ir_t* ir) { delete ir; }
+
+static bool ir_name_ok(vmd_script_ir_t* ir, const char* name) {
+    if (!ir) return vmd_fail("ir is NULL");
+    if (!name || !*name) return vmd_fail("property name is empty");
+    for (auto& p : ir->props) if (p.name == name) return vmd_fail("property '%s' already defined", name);
+    return true;
+}
+static bool idx_ok(const int32_t* idx, size_t n, const char* what) {
+    if (n == 0 || !idx) return vmd_fail("%s is empty", what);
+    for (size_t i = 0; i < n; ++i) if (idx[i] < 0) return vmd_fail("%s contains a negative atom index", what);
+    return true;
+}
+
+extern "C" bool vmd_ir_add_rdf(vmd_script_ir_t* ir, const char* name, const int32_t* ref, size_t nref,
+                               const int32_t* target, size_t ntarget, float rmin, float rmax) {
+    if (!ir_name_ok(ir, name) || !idx_ok(ref, nref, "rdf reference set") || !idx_ok(target, ntarget, "rdf target set")) return false;
+    if (!(rmin >= 0.0f) || !(rmax > rmin)) return vmd_fail("rdf range must satisfy 0 <= rmin < rmax");
+    Property p;
+    p.name = name; p.kind = PROP_RDF; p.flags = VMD_PROPERTY_FLAG_DISTRIBUTION;
+    p.a.assign(ref, ref + nref); p.b.assign(target, target + ntarget);
+    p.rmin = rmin; p.rmax = rmax;
+    ir->props.push_back(std::move(p));
+    ir->rebuild_names();
+    return true;
+}
+
+extern "C" bool vmd_ir_add_sdf(vmd_script_ir_t* ir, const char* name, const int32_t* structures, size_t K, size_t m,
+                               const int32_t* target, size_t ntarget, float cutoff) {
+    if (!ir_name_ok(ir, name) || !idx_ok(structures, K * m, "sdf reference structures") || !idx_ok(target, ntarget, "sdf target set")) return false;
+    if (!(cutoff > 0.0f)) return vmd_fail("sdf cutoff must be positive");
+    Property p;
+    p.name = name; p.kind = PROP_SDF; p.flags = VMD_PROPERTY_FLAG_VOLUME;
+    p.a.assign(structures, structures + K * m); p.b.assign(target, target + ntarget);
+    p.K = K; p.m = m; p.rmax = cutoff;
+    ir->props.push_back(std::move(p));
+    ir->rebuild_names();
+    return true;
+}
+
+extern "C" bool vmd_ir_add_distance(vmd_script_ir_t* ir, const char* name, vmd_distance_kind_t kind,
+                                    const int32_t* a, size_t na, const int32_t* b, size_t nb) {
+    if (!ir_name_ok(ir, name) || !idx_ok(a, na, "distance set a") || !idx_ok(b, nb, "distance set b")) return false;
+    if ((int)kind < 0 || (int)kind > 3) return vmd_fail("unknown distance kind %d", (int)kind);
+    Property p;
+    p.name = name; p.kind = PROP_DIST; p.flags = VMD_PROPERTY_FLAG_TEMPORAL;
+    p.a.assign(a, a + na); p.b.assign(b, b + nb);
+    p.dist_kind = (int)kind;
+    ir->props.push_back(std::move(p));
+    ir->rebuild_names();
+    return true;
+}
+
+extern "C" bool vmd_ir_valid(const vmd_script_ir_t* ir) { return ir != nullptr; }
+
+extern "C" uint64_t vmd_ir_fingerprint(const vmd_script_ir_t* ir) {
+    if (!ir) return 0;
+    uint64_t h = 0xCBF29CE484222325ull;
+    for (auto& p : ir->props) {
+        h = fnv1a(h, p.name.data(), p.name.size());
+        h = fnv1a(h, &p.kind, sizeof(p.kind));
+        h = fnv1a(h, p.a.data(), p.a.size() * sizeof(int32_t));
+        h = fnv1a(h, p.b.data(), p.b.size() * sizeof(int32_t));
+        h = fnv1a(h, &p.rmin, sizeof(float)); h = fnv1a(h, &p.rmax, sizeof(float));
+        h = fnv1a(h, &p.K, sizeof(p.K)); h = fnv1a(h, &p.m, sizeof(p.m)); h = fnv1a(h, &p.dist_kind, sizeof(int));
+    }
+    return h ? h : 1;
+}
+extern "C" size_t vmd_ir_property_count(const vmd_script_ir_t* ir) { return ir ? ir->props.size() : 0; }
+extern "C" const char* const* vmd_ir_property_names(const vmd_script_ir_t* ir) { return ir ? ir->names.data() : nullptr; }
+extern "C" vmd_property_flags_t vmd_ir_property_flags(const vmd_script_ir_t* ir, const char* name) {
+    if (!ir || !name) return VMD_PROPERTY_FLAG_NONE;
+    for (auto& p : ir->props) if (p.name == name) return p.flags;
+    return VMD_PROPERTY_FLAG_NONE;
+}
+
+// ------------------------------------------------------------------------------------------------ eval
+
+// a distinct atom selection that needs a cell-sorted copy per frame batch (shared between RDF properties)
+struct Selection {
+    std::vector<int32_t> idx;
+    DevBuf<int32_t> d_idx;
+    DevBuf<uint32_t> cell_count, rank, cell_start;
+    DevBuf<float> sorted;
+    int nsel_pad = 0;
+    bool built = false;     // for the current batch ...
+    vmd_grid_t built_grid;  // ... on this grid
+};
+
+struct PropState {
+    Property prop;                      // private copy of the descriptor
+    vmd_script_property_data_t data;
+    vmd_script_aggregate_t aggregate;
+    std::vector<float> values, weights, agg_mean, agg_var, agg_ext;
+    std::vector<uint64_t> counts;       // host mirror of d_counts
+    std::vector<double> weights64;
+    size_t ncounts = 0;                 // bins or voxels
+    size_t dim1 = 0;                    // temporal population
+    DevBuf<uint64_t> d_counts;
+    DevBuf<float> d_values;             // volume float view (device)
+    DevBuf<float> d_max;
+    int sel_a = -1, sel_b = -1;         // RDF: indices into eval->sels
+    bool same_set = false;
+    // SDF
+    DevBuf<int32_t> d_structs, d_tgt;
+    DevBuf<float> d_mass;
+    DevBuf<double> d_ref_pose;
+    DevBuf<float> d_R32, d_c32;
+    bool ref_pose_ready = false;
+    // DIST
+    DevBuf<int32_t> d_a, d_b;
+    DevBuf<float> d_ma, d_mb, d_out;
+    bool uploaded = false;
+    bool dirty = false;                 // device accumulators changed since the last host refresh
+};
+
+struct vmd_script_eval_t {
+    uint64_t ir_fingerprint = 0;
+    size_t num_frames = 0;
+    std::vector<uint8_t> frame_mask;
+    std::atomic<size_t> frames_done{0};
+    std::atomic<bool> interrupt{false};
+    std::mutex mtx;                                   // serialises device work of concurrent frame_range calls
+    std::vector<std::unique_ptr<PropState>> props;
+    std::vector<std::unique_ptr<Selection>> sels;
+    hipStream_t stream = nullptr;
+    int device = 0;
+    Profiler prof;
+    // batch scratch
+    DevBuf<float> d_boxes, d_stage;
+    float* h_stage = nullptr; size_t h_stage_cap = 0;   // pinned
+    std::vector<float> h_boxes;
+    DevBuf<uint64_t> d_partial;
+    std::vector<float> h_temporal;
+    std::vector<vmd_unitcell_t> cells;
+};
+
+static PropState* find_prop(const vmd_script_eval_t* e, const char* name) {
+    if (!e || !name) return nullptr;
+    for (auto& p : e->props) if (p->prop.name == name) return p.get();
+    return nullptr;
+}
+
+static int intern_selection(vmd_script_eval_t* e, const std::vector<int32_t>& idx) {
+    for (size_t i = 0; i < e->sels.size(); ++i) if (e->sels[i]->idx == idx) return (int)i;
+    auto s = std::make_unique<Selection>();
+    s->idx = idx;
+    e->sels.push_back(std::move(s));
+    return (int)e->sels.size() - 1;
+}
+
+extern "C" vmd_script_eval_t* vmd_eval_create(size_t num_frames, const vmd_script_ir_t* ir) {
+    if (!ir) { vmd_fail("vmd_eval_create: ir is NULL"); return nullptr; }
+    if (vmd_device_count() <= 0) { vmd_fail("vmd_eval_create: no usable HIP device (the evaluator has no CPU path)"); return nullptr; }
+    auto e = std::make_unique<vmd_script_eval_t>();
+    if (hipGetDevice(&e->device) != hipSuccess) { vmd_fail("hipGetDevice failed"); return nullptr; }
+    if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) { vmd_fail("hipStreamCreate failed"); return nullptr; }
+    e->ir_fingerprint = vmd_ir_fingerprint(ir);
+    e->num_frames = num_frames;
+    e->frame_mask.assign(num_frames, 0);
+    for (auto& p : ir->props) {
+        auto st = std::make_unique<PropState>();
+        st->prop = p;
+        memset(&st->data, 0, sizeof(st->data));
+        memset(&st->aggregate, 0, sizeof(st->aggregate));
+        switch (p.kind) {
+        case PROP_RDF:
+            st->ncounts = VMD_RDF_NUM_BINS;
+            st->values.assign(st->ncounts, 0.0f); st->weights.assign(st->ncounts, 0.0f);
+            st->counts.assign(st->ncounts, 0); st->weights64.assign(st->ncounts, 0.0);
+            st->data.dim[0] = 1; st->data.dim[1] = 1; st->data.dim[2] = (int32_t)st->ncounts; st->data.dim[3] = 0;
+            st->data.weights = st->weights.data();
+            st->data.weights64 = st->weights64.data();
+            st->data.min_range[0] = p.rmin; st->data.max_range[0] = p.rmax;
+            st->same_set = (p.a == p.b);
+            st->sel_a = intern_selection(e.get(), p.a);
+            st->sel_b = st->same_set ? st->sel_a : intern_selection(e.get(), p.b);
+            break;
+        case PROP_SDF:
+            st->ncounts = (size_t)VMD_VOLUME_DIM * VMD_VOLUME_DIM * VMD_VOLUME_DIM;
+            st->values.assign(st->ncounts, 0.0f);
+            st->counts.assign(st->ncounts, 0);
+            st->data.dim[0] = 1; st->data.dim[1] = st->data.dim[2] = st->data.dim[3] = VMD_VOLUME_DIM;
+            st->data.min_range[0] = -p.rmax; st->data.max_range[0] = p.rmax;
+            break;
+        case PROP_DIST:
+            st->dim1 = p.dist_kind == VMD_DISTANCE_PAIR ? p.a.size() * p.b.size() : 1;
+            st->values.assign(num_frames * st->dim1, 0.0f);
+            st->data.dim[0] = (int32_t)num_frames; st->data.dim[1] = (int32_t)st->dim1;
+            if (st->dim1 > 1) {
+                st->agg_mean.assign(num_frames, 0.0f); st->agg_var.assign(num_frames, 0.0f); st->agg_ext.assign(num_frames * 2, 0.0f);
+                st->aggregate.num_values = num_frames;
+                st->aggregate.population_mean = st->agg_mean.data();
+                st->aggregate.population_var = st->agg_var.data();
+                st->aggregate.population_ext = (float(*)[2])st->agg_ext.data();
+                st->data.aggregate = &st->aggregate;
+            }
+            break;
+        }
+        st->data.values = st->values.data();
+        st->data.num_values = st->values.size();
+        st->data.counts = st->counts.empty() ? nullptr : st->counts.data();
+        st->data.fingerprint = 1;
+        if (st->ncounts) {
+            if (!st->d_counts.ensure(st->ncounts)) return nullptr;
+            if (hipMemsetAsync(st->d_counts.p, 0, st->ncounts * sizeof(uint64_t), e->stream) != hipSuccess) { vmd_fail("hipMemset failed"); return nullptr; }
+        }
+        e->props.push_back(std::move(st));
+    }
+    if (hipStreamSynchronize(e->stream) != hipSuccess) { vmd_fail("hipStreamSynchronize failed"); return nullptr; }
+    return e.release();
+}
+
+extern "C" void vmd_eval_free(vmd_script_eval_t* eval) {
+    if (!eval) return;
+    {
+        std::lock_guard<std::mutex> l(eval->mtx);
+        if (eval->stream) { (void)hipStreamSynchronize(eval->stream); }
+        if (eval->h_stage) (void)hipHostFree(eval->h_stage);
+        eval->h_stage = nullptr;
+        eval->props.clear();
+        eval->sels.clear();
+        if (eval->stream) (void)hipStreamDestroy(eval->stream);
+        eval->stream = nullptr;
+    }
+    delete eval;
+}
+
+extern "C" void vmd_eval_clear_data(vmd_script_eval_t* eval) {
+    if (!eval) return;
+    std::lock_guard<std::mutex> l(eval->mtx);
+    eval->interrupt = false;
+    std::fill(eval->frame_mask.begin(), eval->frame_mask.end(), (uint8_t)0);
+    eval->frames_done = 0;
+    for (auto& p : eval->props) {
+        std::fill(p->values.begin(), p->values.end(), 0.0f);
+        std::fill(p->weights.begin(), p->weights.end(), 0.0f);
+        std::fill(p->counts.begin(), p->counts.end(), (uint64_t)0);
+        std::fill(p->weights64.begin(), p->weights64.end(), 0.0);
+        std::fill(p->agg_mean.begin(), p->agg_mean.end(), 0.0f);
+        std::fill(p->agg_var.begin(), p->agg_var.end(), 0.0f);
+        std::fill(p->agg_ext.begin(), p->agg_ext.end(), 0.0f);
+        if (p->ncounts) (void)hipMemsetAsync(p->d_counts.p, 0, p->ncounts * sizeof(uint64_t), eval->stream);
+        p->data.max_value = 0.0f; p->data.min_value = 0.0f;
+        p->data.max_range[1] = 0.0f;
+        p->dirty = false;
+        p->data.fingerprint += 1;
+    }
+    (void)hipStreamSynchronize(eval->stream);
+}
+
+extern "C" void vmd_eval_interrupt(vmd_script_eval_t* eval) { if (eval) eval->interrupt = true; }
+extern "C" uint64_t vmd_eval_ir_fingerprint(const vmd_script_eval_t* eval) { return eval ? eval->ir_fingerprint : 0; }
+extern "C" const vmd_script_property_data_t* vmd_eval_property_data(const vmd_script_eval_t* eval, const char* name) {
+    PropState* p = find_prop(eval, name);
+    return p ? &p->data : nullptr;
+}
+extern "C" const uint8_t* vmd_eval_frame_mask(const vmd_script_eval_t* eval) { return eval ? eval->frame_mask.data() : nullptr; }
+extern "C" size_t vmd_eval_num_frames(const vmd_script_eval_t* eval) { return eval ? eval->num_frames : 0; }
+extern "C" size_t vmd_eval_frames_done(const vmd_script_eval_t* eval) { return eval ? eval->frames_done.load() : 0; }
+
+// ---- host views -------------------------------------------------------------------------------------------------
+
+static bool refresh_distribution(vmd_script_eval_t* e, PropState* p) {
+    HIP_OK(hipMemcpyAsync(p->counts.data(), p->d_counts.p, p->ncounts * sizeof(uint64_t), hipMemcpyDeviceToHost, e->stream));
+    HIP_OK(hipStreamSynchronize(e->stream));
+    float ymax = 0.0f, vmax = 0.0f;
+    for (size_t b = 0; b < p->ncounts; ++b) {
+        const float v = (float)p->counts[b];
+        const float w = (float)p->weights64[b];
+        p->values[b] = v; p->weights[b] = w;
+        vmax = std::max(vmax, v);
+        if (w > 0.0f) ymax = std::max(ymax, v / w);
+    }
+    p->data.min_value = 0.0f; p->data.max_value = vmax;
+    p->data.min_range[1] = 0.0f; p->data.max_range[1] = ymax;
+    p->data.fingerprint += 1;
+    p->dirty = false;
+    return true;
+}
+
+static bool refresh_volume(vmd_script_eval_t* e, PropState* p) {
+    if (!p->d_values.ensure(p->ncounts) || !p->d_max.ensure(1)) return false;
+    KRN_OK(vmd_hip_counts_to_float(e->stream, p->d_counts.p, p->ncounts, p->d_values.p, p->d_max.p));
+    float vmax = 0.0f;
+    HIP_OK(hipMemcpyAsync(p->values.data(), p->d_values.p, p->ncounts * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    HIP_OK(hipMemcpyAsync(p->counts.data(), p->d_counts.p, p->ncounts * sizeof(uint64_t), hipMemcpyDeviceToHost, e->stream));
+    HIP_OK(hipMemcpyAsync(&vmax, p->d_max.p, sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    HIP_OK(hipStreamSynchronize(e->stream));
+    p->data.min_value = 0.0f; p->data.max_value = vmax;
+    p->data.fingerprint += 1;
+    p->dirty = false;
+    return true;
+}
+
+static void refresh_temporal_stats(vmd_script_eval_t* e, PropState* p) {
+    float lo = 3.4e38f, hi = -3.4e38f;
+    bool any = false;
+    for (size_t f = 0; f < e->num_frames; ++f) {
+        if (!e->frame_mask[f]) continue;
+        const float* row = &p->values[f * p->dim1];
+        float rlo = row[0], rhi = row[0];
+        double s = 0.0;
+        for (size_t i = 0; i < p->dim1; ++i) { rlo = std::min(rlo, row[i]); rhi = std::max(rhi, row[i]); s += row[i]; }
+        if (p->dim1 > 1) {
+            const double mean = s / (double)p->dim1;
+            double v = 0.0;
+            for (size_t i = 0; i < p->dim1; ++i) { const double d = row[i] - mean; v += d * d; }
+            p->agg_mean[f] = (float)mean;
+            p->agg_var[f] = (float)std::sqrt(v / (double)p->dim1);   // VIAMD plots mean +- var as a band (src/main.cpp:1409-1424)
+            p->agg_ext[2 * f] = rlo; p->agg_ext[2 * f + 1] = rhi;
+        }
+        lo = std::min(lo, rlo); hi = std::max(hi, rhi);
+        any = true;
+    }
+    if (!any) { lo = hi = 0.0f; }
+    p->data.min_value = lo; p->data.max_value = hi;
+    p->data.min_range[0] = lo; p->data.max_range[0] = hi;
+    p->data.fingerprint += 1;
+    p->dirty = false;
+}
+
+extern "C" bool vmd_eval_finalize(vmd_script_eval_t* eval) {
+    if (!eval) return vmd_fail("eval is NULL");
+    std::lock_guard<std::mutex> l(eval->mtx);
+    HIP_OK(hipSetDevice(eval->device));
+    for (auto& p : eval->props) {
+        bool ok = true;
+        if (p->prop.kind == PROP_RDF) ok = refresh_distribution(eval, p.get());
+        else if (p->prop.kind == PROP_SDF) ok = refresh_volume(eval, p.get());
+        else refresh_temporal_stats(eval, p.get());
+        if (!ok) return false;
+    }
+    return true;
+}
+
+extern "C" void vmd_eval_set_frame_mask(vmd_script_eval_t* eval, const uint8_t* mask, size_t n) {
+    if (!eval || !mask) return;
+    std::lock_guard<std::mutex> l(eval->mtx);
+    size_t done = 0;
+    for (size_t f = 0; f < eval->num_frames; ++f) {
+        if (f < n) eval->frame_mask[f] = mask[f] ? 1 : 0;
+        done += eval->frame_mask[f] ? 1 : 0;
+    }
+    eval->frames_done = done;
+}
+
+extern "C" size_t vmd_eval_accum_views(vmd_script_eval_t* eval, vmd_accum_view_t* out, size_t cap) {
+    if (!eval) return 0;
+    size_t n = 0;
+    for (auto& p : eval->props) {
+        if (n < cap && out) {
+            vmd_accum_view_t v;
+            memset(&v, 0, sizeof(v));
+            v.name = p->prop.name.c_str();
+            v.flags = p->prop.flags;
+            if (p->ncounts) { v.counts_dev = p->d_counts.p; v.num_counts = p->ncounts; }
+            if (!p->weights64.empty()) { v.weights64 = p->weights64.data(); v.num_weights = p->weights64.size(); }
+            if (p->prop.kind == PROP_DIST) { v.temporal = p->values.data(); v.num_temporal = p->values.size(); }
+            out[n] = v;
+        }
+        n += 1;
+    }
+    return n;
+}
+
+// ---- the hot call -----------------------------------------------------------------------------------------------
+
+static bool upload_static(vmd_script_eval_t* e, const vmd_system_t* sys) {
+    for (auto& s : e->sels) {
+        if (!s->d_idx.p) { if (!s->d_idx.upload(s->idx.data(), s->idx.size(), e->stream)) return false; }
+    }
+    for (auto& p : e->props) {
+        if (p->uploaded) continue;
+        const Property& d = p->prop;
+        auto masses = [&](const std::vector<int32_t>& idx, std::vector<float>& out) {
+            out.resize(idx.size());
+            for (size_t i = 0; i < idx.size(); ++i)
+                out[i] = (sys && sys->mass && (size_t)idx[i] < sys->atom_count) ? sys->mass[idx[i]] : 1.0f;
+        };
+        std::vector<float> tmp;
+        if (d.kind == PROP_SDF) {
+            if (!p->d_structs.upload(d.a.data(), d.a.size(), e->stream)) return false;
+            if (!p->d_tgt.upload(d.b.data(), d.b.size(), e->stream)) return false;
+            masses(d.a, tmp);
+            if (!p->d_mass.upload(tmp.data(), tmp.size(), e->stream)) return false;
+            if (!p->d_ref_pose.ensure(d.m * 3)) return false;
+        } else if (d.kind == PROP_DIST) {
+            if (!p->d_a.upload(d.a.data(), d.a.size(), e->stream)) return false;
+            if (!p->d_b.upload(d.b.data(), d.b.size(), e->stream)) return false;
+            masses(d.a, tmp);
+            if (!p->d_ma.upload(tmp.data(), tmp.size(), e->stream)) return false;
+            masses(d.b, tmp);
+            if (!p->d_mb.upload(tmp.data(), tmp.size(), e->stream)) return false;
+        }
+        HIP_OK(hipStreamSynchronize(e->stream));   // tmp goes out of scope
+        p->uploaded = true;
+    }
+    return true;
+}
+
+static bool check_atoms(const vmd_script_eval_t* e, size_t num_atoms) {
+    for (auto& p : e->props) {
+        for (int32_t i : p->prop.a) if ((size_t)i >= num_atoms) return vmd_fail("property '%s' references atom %d but the trajectory has %zu atoms", p->prop.name.c_str(), i, num_atoms);
+        for (int32_t i : p->prop.b) if ((size_t)i >= num_atoms) return vmd_fail("property '%s' references atom %d but the trajectory has %zu atoms", p->prop.name.c_str(), i, num_atoms);
+    }
+    return true;
+}
+
+struct BatchSrc {
+    const float* base = nullptr;   // device
+    size_t frame_stride = 0, row_stride = 0;
+};
+
+// bring frames [f0, f0+nb) to the device (or alias them in place), fill e->cells / e->h_boxes
+static bool fetch_batch(vmd_script_eval_t* e, vmd_trajectory_i* traj, const vmd_device_view_t* view, size_t num_atoms,
+                        size_t f0, size_t nb, BatchSrc* src) {
+    e->cells.resize(nb);
+    e->h_boxes.resize(nb * 3);
+    if (view) {
+        src->base = view->base + f0 * view->frame_stride;
+        src->frame_stride = view->frame_stride;
+        src->row_stride = view->row_stride;
+        for (size_t b = 0; b < nb; ++b) e->cells[b] = view->cells[f0 + b];
+    } else {
+        const size_t npad = (num_atoms + 63) & ~(size_t)63;
+        const size_t need = nb * 3 * npad;
+        if (need > e->h_stage_cap) {
+            if (e->h_stage) (void)hipHostFree(e->h_stage);
+            e->h_stage = nullptr; e->h_stage_cap = 0;
+            HIP_OK(hipHostMalloc((void**)&e->h_stage, need * sizeof(float), hipHostMallocDefault));
+            e->h_stage_cap = need;
+        }
+        if (!e->d_stage.ensure(need)) return false;
+        for (size_t b = 0; b < nb; ++b) {
+            vmd_frame_header_t hdr;
+            memset(&hdr, 0, sizeof(hdr));
+            float* x = e->h_stage + b * 3 * npad;
+            if (!traj->load_frame(traj->inst, (int64_t)(f0 + b), &hdr, x, x + npad, x + 2 * npad))
+                return vmd_fail("trajectory load_frame(%zu) failed", f0 + b);
+            e->cells[b] = hdr.unitcell;
+        }
+        HIP_OK(hipMemcpyAsync(e->d_stage.p, e->h_stage, need * sizeof(float), hipMemcpyHostToDevice, e->stream));
+        src->base = e->d_stage.p;
+        src->frame_stride = 3 * npad;
+        src->row_stride = npad;
+    }
+    for (size_t b = 0; b < nb; ++b) {
+        const vmd_unitcell_t& c = e->cells[b];
+        if (c.xy != 0.0f || c.xz != 0.0f || c.yz != 0.0f) return vmd_fail("frame %zu: triclinic unit cells are not supported (SPEC D-TRICLINIC)", f0 + b);
+        if (c.flags != e->cells[0].flags) return vmd_fail("frame %zu: periodicity flags change inside the trajectory", f0 + b);
+        e->h_boxes[3 * b + 0] = c.x; e->h_boxes[3 * b + 1] = c.y; e->h_boxes[3 * b + 2] = c.z;
+    }
+    if (!e->d_boxes.upload(e->h_boxes.data(), nb * 3, e->stream)) return false;
+    return true;
+}
+
+static uint32_t batch_pbc(const vmd_script_eval_t* e) {
+    const vmd_unitcell_t& c = e->cells[0];
+    uint32_t f = c.flags & VMD_UNITCELL_PBC_ALL;
+    if (!(c.x > 0.0f)) f &= ~VMD_UNITCELL_PBC_X;
+    if (!(c.y > 0.0f)) f &= ~VMD_UNITCELL_PBC_Y;
+    if (!(c.z > 0.0f)) f &= ~VMD_UNITCELL_PBC_Z;
+    return f;
+}
+
+// pencil grid for a batch and cutoff; false when the batch cannot use the grid kernel
+static bool choose_grid(const vmd_script_eval_t* e, size_t nb, float rmax, vmd_grid_t* g) {
+    if (g_opt.force_brute) return false;
+    if (batch_pbc(e) != VMD_UNITCELL_PBC_ALL) return false;
+    float Lmin[3] = {3.4e38f, 3.4e38f, 3.4e38f};
+    for (size_t b = 0; b < nb; ++b) for (int a = 0; a < 3; ++a) Lmin[a] = std::min(Lmin[a], e->h_boxes[3 * b + a]);
+    // minimum image must be unique for every hit: rmax < L/2 with margin
+    for (int a = 0; a < 3; ++a) if (!(rmax * 2.0f * 1.001f < Lmin[a])) return false;
+    int n[3];
+    for (int a = 1; a < 3; ++a) {
+        int k = (int)std::floor(Lmin[a] / rmax);
+        while (k > 1 && ((float)k / Lmin[a]) * rmax > 0.9999f) k -= 1;
+        if (k < 2) return false;
+        n[a] = std::min(k, 1024);
+    }
+    const float cx = rmax / (float)std::max(1, g_opt.nxf_divisor.load());
+    int nxf = (int)std::floor(Lmin[0] / cx);
+    nxf = std::max(1, std::min(nxf, 4096));
+    g->nxf = nxf; g->ny = n[1]; g->nz = n[2];
+    const long long ncell = (long long)nxf * n[1] * n[2];
+    if (ncell > (1ll << 26)) return false;
+    g->ncell = (int32_t)ncell;
+    return true;
+}
+
+static bool build_selection(vmd_script_eval_t* e, Selection* s, const BatchSrc& src, size_t nb, const vmd_grid_t& g) {
+    if (s->built && s->built_grid.nxf == g.nxf && s->built_grid.ny == g.ny && s->built_grid.nz == g.nz) return true;
+    const int nsel = (int)s->idx.size();
+    s->nsel_pad = (nsel + 63) & ~63;
+    if (!s->cell_count.ensure(nb * (size_t)(g.ncell + 1)) || !s->cell_start.ensure(nb * (size_t)(g.ncell + 1)) ||
+        !s->rank.ensure(nb * (size_t)nsel) || !s->sorted.ensure(nb * 3 * (size_t)s->nsel_pad)) return false;
+    e->prof.begin("cells_build", e->stream);
+    KRN_OK(vmd_hip_cells_build(e->stream, src.base, src.frame_stride, src.row_stride, e->d_boxes.p, (int)nb, s->d_idx.p, nsel,
+                               s->nsel_pad, g, s->cell_count.p, s->rank.p, s->cell_start.p, s->sorted.p));
+    e->prof.end(e->stream);
+    s->built = true;
+    s->built_grid = g;
+    return true;
+}
+
+static size_t auto_batch(const vmd_script_eval_t* e, size_t num_atoms) {
+    const int forced = g_opt.batch_frames;
+    if (forced > 0) return (size_t)forced;
+    // scratch per frame: every selection holds ~20 B per selected atom + the staged frame itself (host trajectories)
+    size_t per_frame = 12 * num_atoms;
+    for (auto& s : e->sels) per_frame += 24 * s->idx.size();
+    size_t B = (size_t)(768ull << 20) / std::max<size_t>(per_frame, 1);
+    B = std::max<size_t>(1, std::min<size_t>(B, 256));
+    return B;
+}
+
+extern "C" bool vmd_eval_frame_range(vmd_script_eval_t* eval, const vmd_script_ir_t* ir, const vmd_system_t* sys,
+                                     vmd_trajectory_i* traj, uint32_t frame_beg, uint32_t frame_end) {
+    g_last_error.clear();   // a false return with an empty message means "interrupted"
+    if (!eval || !traj) return vmd_fail("vmd_eval_frame_range: NULL argument");
+    if (ir && vmd_ir_fingerprint(ir) != eval->ir_fingerprint) return vmd_fail("vmd_eval_frame_range: eval was created from a different ir");
+    if (frame_end > eval->num_frames) frame_end = (uint32_t)eval->num_frames;
+    if (frame_beg >= frame_end) return true;
+    if (eval->interrupt) return false;
+
+    std::lock_guard<std::mutex> lock(eval->mtx);
+    HIP_OK(hipSetDevice(eval->device));
+    vmd_script_eval_t* e = eval;
+    const size_t num_atoms = traj->num_atoms(traj->inst);
+    if (traj->num_frames(traj->inst) < frame_end) return vmd_fail("trajectory has fewer frames than the requested range");
+    if (!check_atoms(e, num_atoms)) return false;
+    if (!upload_static(e, sys)) return false;
+
+    vmd_device_view_t view;
+    const bool have_view = traj->device_view && traj->device_view(traj->inst, &view) && view.device == e->device;
+
+    // SDF reference pose: structure 0 at trajectory frame 0 (SPEC S5)
+    for (auto& p : e->props) {
+        if (p->prop.kind != PROP_SDF || p->ref_pose_ready) continue;
+        BatchSrc src;
+        if (!fetch_batch(e, traj, have_view ? &view : nullptr, num_atoms, 0, 1, &src)) return false;
+        KRN_OK(vmd_hip_sdf_ref_pose(e->stream, src.base, src.row_stride, e->d_boxes.p, batch_pbc(e), p->d_structs.p, p->d_mass.p,
+                                    (int)p->prop.m, p->d_ref_pose.p));
+        HIP_OK(hipStreamSynchronize(e->stream));
+        p->ref_pose_ready = true;
+    }
+
+    const size_t B = auto_batch(e, num_atoms);
+    bool completed = true;
+    for (size_t f0 = frame_beg; f0 < frame_end; f0 += B) {
+        if (e->interrupt) { completed = false; break; }
+        const size_t nb = std::min<size_t>(B, frame_end - f0);
+        BatchSrc src;
+        if (!fetch_batch(e, traj, have_view ? &view : nullptr, num_atoms, f0, nb, &src)) return false;
+        const uint32_t pbc = batch_pbc(e);
+        for (auto& s : e->sels) s->built = false;
+
+        size_t temporal_floats = 0;
+        for (auto& p : e->props) if (p->prop.kind == PROP_DIST) temporal_floats += nb * p->dim1;
+        e->h_temporal.resize(temporal_floats);
+        size_t toff = 0;
+
+        for (auto& p : e->props) {
+            const Property& d = p->prop;
+            if (d.kind == PROP_RDF) {
+                vmd_grid_t g;
+                if (choose_grid(e, nb, d.rmax, &g)) {
+                    Selection* sa = e->sels[p->sel_a].get();
+                    Selection* sb = e->sels[p->sel_b].get();
+                    // properties with the same cutoff share the sorted copies; build_selection re-sorts when the grid differs
+                    if (!build_selection(e, sa, src, nb, g)) return false;
+                    if (sb != sa && !build_selection(e, sb, src, nb, g)) return false;
+                    const int nblocks = vmd_hip_rdf_num_blocks();
+                    if (!e->d_partial.ensure((size_t)nblocks * 4 * VMD_RDF_NUM_BINS)) return false;
+                    e->prof.begin("rdf_pencil", e->stream);
+                    KRN_OK(vmd_hip_rdf_pencil(e->stream, sa->sorted.p, sa->cell_start.p, (int)sa->idx.size(), sa->nsel_pad,
+                                              sb->sorted.p, sb->cell_start.p, (int)sb->idx.size(), sb->nsel_pad,
+                                              e->d_boxes.p, (int)nb, g, d.rmin, d.rmax, VMD_RDF_NUM_BINS,
+                                              p->same_set ? 1 : 0, g_opt.rdf_variant, e->d_partial.p, p->d_counts.p));
+                    e->prof.end(e->stream);
+                } else {
+                    Selection* sa = e->sels[p->sel_a].get();
+                    Selection* sb = e->sels[p->sel_b].get();
+                    e->prof.begin("rdf_brute", e->stream);
+                    KRN_OK(vmd_hip_rdf_brute(e->stream, src.base, src.frame_stride, src.row_stride, e->d_boxes.p, pbc, (int)nb,
+                                             sa->d_idx.p, (int)sa->idx.size(), sb->d_idx.p, (int)sb->idx.size(),
+                                             d.rmin, d.rmax, VMD_RDF_NUM_BINS, p->d_counts.p));
+                    e->prof.end(e->stream);
+                }
+                // SPEC S4 normalisation, fp64 on the host (needs only the box)
+                for (size_t b = 0; b < nb; ++b) {
+                    const float* L = &e->h_boxes[3 * b];
+                    double V;
+                    if (pbc == VMD_UNITCELL_PBC_ALL) V = (double)L[0] * (double)L[1] * (double)L[2];
+                    else V = (4.0 / 3.0) * M_PI * (double)d.rmax * (double)d.rmax * (double)d.rmax;
+                    const double rho = (double)d.a.size() * (double)d.b.size() / V;
+                    const double w = ((double)d.rmax - (double)d.rmin) / (double)p->ncounts;
+                    for (size_t k = 0; k < p->ncounts; ++k) {
+                        const double r0 = (double)d.rmin + w * (double)k;
+                        const double r1 = (double)d.rmin + w * (double)(k + 1);
+                        p->weights64[k] += rho * (4.0 / 3.0) * M_PI * (r1 * r1 * r1 - r0 * r0 * r0);
+                    }
+                }
+                p->dirty = true;
+            } else if (d.kind == PROP_SDF) {
+                if (!p->d_R32.ensure(nb * d.K * 9) || !p->d_c32.ensure(nb * d.K * 3)) return false;
+                e->prof.begin("sdf_align", e->stream);
+                KRN_OK(vmd_hip_sdf_align(e->stream, src.base, src.frame_stride, src.row_stride, e->d_boxes.p, pbc, (int)nb,
+                                         p->d_structs.p, p->d_mass.p, (int)d.K, (int)d.m, p->d_ref_pose.p, p->d_R32.p, p->d_c32.p, nullptr));
+                e->prof.end(e->stream);
+                e->prof.begin("sdf_scatter", e->stream);
+                KRN_OK(vmd_hip_sdf_scatter(e->stream, src.base, src.frame_stride, src.row_stride, e->d_boxes.p, pbc, (int)nb,
+                                           p->d_structs.p, (int)d.K, (int)d.m, p->d_R32.p, p->d_c32.p, p->d_tgt.p, (int)d.b.size(),
+                                           d.rmax, VMD_VOLUME_DIM, p->d_counts.p));
+                e->prof.end(e->stream);
+                p->dirty = true;
+            } else {
+                if (!p->d_out.ensure(nb * p->dim1)) return false;
+                e->prof.begin("distance", e->stream);
+                KRN_OK(vmd_hip_distance(e->stream, src.base, src.frame_stride, src.row_stride, e->d_boxes.p, pbc, (int)nb, d.dist_kind,
+                                        p->d_a.p, p->d_ma.p, (int)d.a.size(), p->d_b.p, p->d_mb.p, (int)d.b.size(), p->d_out.p));
+                e->prof.end(e->stream);
+                HIP_OK(hipMemcpyAsync(e->h_temporal.data() + toff, p->d_out.p, nb * p->dim1 * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+                toff += nb * p->dim1;
+                p->dirty = true;
+            }
+        }
+        HIP_OK(hipStreamSynchronize(e->stream));
+        e->prof.resolve();
+        toff = 0;
+        for (auto& p : e->props) {
+            if (p->prop.kind != PROP_DIST) continue;
+            memcpy(&p->values[f0 * p->dim1], e->h_temporal.data() + toff, nb * p->dim1 * sizeof(float));
+            toff += nb * p->dim1;
+        }
+        for (size_t b = 0; b < nb; ++b) e->frame_mask[f0 + b] = 1;
+        e->frames_done += nb;
+        // cheap views are refreshed every batch so a polling GUI sees progress (src/main.cpp:1508-1524)
+        for (auto& p : e->props) if (p->prop.kind == PROP_RDF) { if (!refresh_distribution(e, p.get())) return false; }
+    }
+    for (auto& p : e->props) {
+        if (!p->dirty) continue;
+        if (p->prop.kind == PROP_SDF) { if (!refresh_volume(e, p.get())) return false; }
+        else if (p->prop.kind == PROP_DIST) refresh_temporal_stats(e, p.get());
+    }
+    return completed;
+}
+
+extern "C" bool vmd_eval_sdf_matrices(vmd_script_eval_t* eval, const char* name, const vmd_system_t* sys,
+                                      vmd_trajectory_i* traj, uint32_t frame, float* matrices, size_t* K_out, float* extent_out) {
+    if (!eval || !traj) return vmd_fail("vmd_eval_sdf_matrices: NULL argument");
+    PropState* p = find_prop(eval, name);
+    if (!p || p->prop.kind != PROP_SDF) return vmd_fail("'%s' is not an sdf property", name ? name : "(null)");
+    std::lock_guard<std::mutex> lock(eval->mtx);
+    HIP_OK(hipSetDevice(eval->device));
+    vmd_script_eval_t* e = eval;
+    const size_t num_atoms = traj->num_atoms(traj->inst);
+    if (!check_atoms(e, num_atoms) || !upload_static(e, sys)) return false;
+    vmd_device_view_t view;
+    const bool have_view = traj->device_view && traj->device_view(traj->inst, &view) && view.device == e->device;
+    BatchSrc src;
+    if (!p->ref_pose_ready) {
+        if (!fetch_batch(e, traj, have_view ? &view : nullptr, num_atoms, 0, 1, &src)) return false;
+        KRN_OK(vmd_hip_sdf_ref_pose(e->stream, src.base, src.row_stride, e->d_boxes.p, batch_pbc(e), p->d_structs.p, p->d_mass.p,
+                                    (int)p->prop.m, p->d_ref_pose.p));
+        HIP_OK(hipStreamSynchronize(e->stream));
+        p->ref_pose_ready = true;
+    }
+    if (!fetch_batch(e, traj, have_view ? &view : nullptr, num_atoms, frame, 1, &src)) return false;
+    const size_t K = p->prop.K;
+    DevBuf<double> dM;
+    if (!dM.ensure(K * 12) || !p->d_R32.ensure(K * 9) || !p->d_c32.ensure(K * 3)) return false;
+    KRN_OK(vmd_hip_sdf_align(e->stream, src.base, src.frame_stride, src.row_stride, e->d_boxes.p, batch_pbc(e), 1,
+                             p->d_structs.p, p->d_mass.p, (int)K, (int)p->prop.m, p->d_ref_pose.p, p->d_R32.p, p->d_c32.p, dM.p));
+    std::vector<double> M(K * 12);
+    HIP_OK(hipMemcpyAsync(M.data(), dM.p, K * 12 * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    HIP_OK(hipStreamSynchronize(e->stream));
+    if (matrices) {
+        for (size_t k = 0; k < K; ++k) {
+            float* o = matrices + 16 * k;   // column-major mat4
+            const double* r = &M[12 * k];
+            for (int c = 0; c < 4; ++c) for (int rr = 0; rr < 3; ++rr) o[4 * c + rr] = (float)r[4 * rr + c];
+            o[3] = 0.0f; o[7] = 0.0f; o[11] = 0.0f; o[15] = 1.0f;
+        }
+    }
+    if (K_out) *K_out = K;
+    if (extent_out) *extent_out = p->prop.rmax;
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------ device trajectory
+
+struct vmd_devtraj_t {
+    size_t num_frames = 0, num_atoms = 0, npad = 0;
+    float* d = nullptr;
+    int device = 0;
+    std::vector<vmd_unitcell_t> cells;
+    vmd_trajectory_i iface;
+};
+
+static size_t dt_num_frames(void* inst) { return ((vmd_devtraj_t*)inst)->num_frames; }
+static size_t dt_num_atoms(void* inst) { return ((vmd_devtraj_t*)inst)->num_atoms; }
+static bool dt_load_frame(void* inst, int64_t idx, vmd_frame_header_t* hdr, float* x, float* y, float* z) {
+    vmd_devtraj_t* t = (vmd_devtraj_t*)inst;
+    if (idx < 0 || (size_t)idx >= t->num_frames) return vmd_fail("devtraj: frame %lld out of range", (long long)idx);
+    const float* f = t->d + (size_t)idx * 3 * t->npad;
+    if (x) HIP_OK(hipMemcpy(x, f, t->num_atoms * sizeof(float), hipMemcpyDeviceToHost));
+    if (y) HIP_OK(hipMemcpy(y, f + t->npad, t->num_atoms * sizeof(float), hipMemcpyDeviceToHost));
+    if (z) HIP_OK(hipMemcpy(z, f + 2 * t->npad, t->num_atoms * sizeof(float), hipMemcpyDeviceToHost));
+    if (hdr) { hdr->num_atoms = t->num_atoms; hdr->index = idx; hdr->timestamp = (double)idx; hdr->unitcell = t->cells[idx]; }
+    return true;
+}
+static bool dt_device_view(void* inst, vmd_device_view_t* out) {
+    vmd_devtraj_t* t = (vmd_devtraj_t*)inst;
+    out->base = t->d; out->frame_stride = 3 * t->npad; out->row_stride = t->npad; out->cells = t->cells.data(); out->device = t->device;
+    return true;
+}
+
+extern "C" vmd_devtraj_t* vmd_devtraj_create(size_t num_frames, size_t num_atoms) {
+    if (vmd_device_count() <= 0) { vmd_fail("vmd_devtraj_create: no usable HIP device"); return nullptr; }
+    auto t = std::make_unique<vmd_devtraj_t>();
+    t->num_frames = num_frames; t->num_atoms = num_atoms; t->npad = (num_atoms + 63) & ~(size_t)63;
+    if (hipGetDevice(&t->device) != hipSuccess) { vmd_fail("hipGetDevice failed"); return nullptr; }
+    const size_t bytes = std::max<size_t>(num_frames * 3 * t->npad, 1) * sizeof(float);
+    hipError_t err = hipMalloc((void**)&t->d, bytes);
+    if (err != hipSuccess) { vmd_fail("vmd_devtraj_create: hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(err)); return nullptr; }
+    vmd_unitcell_t none;
+    memset(&none, 0, sizeof(none));
+    t->cells.assign(num_frames, none);
+    t->iface.inst = t.get();
+    t->iface.num_frames = dt_num_frames; t->iface.num_atoms = dt_num_atoms;
+    t->iface.load_frame = dt_load_frame; t->iface.device_view = dt_device_view;
+    return t.release();
+}
+extern "C" void vmd_devtraj_free(vmd_devtraj_t* t) {
+    if (!t) return;
+    if (t->d) (void)hipFree(t->d);
+    delete t;
+}
+extern "C" vmd_trajectory_i* vmd_devtraj_interface(vmd_devtraj_t* t) { return t ? &t->iface : nullptr; }
+
+extern "C" bool vmd_devtraj_upload_frame(vmd_devtraj_t* t, size_t frame, const vmd_unitcell_t* cell,
+                                         const float* x, const float* y, const float* z) {
+    if (!t || frame >= t->num_frames) return vmd_fail("vmd_devtraj_upload_frame: bad frame");
+    float* f = t->d + frame * 3 * t->npad;
+    HIP_OK(hipMemcpy(f, x, t->num_atoms * sizeof(float), hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(f + t->npad, y, t->num_atoms * sizeof(float), hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(f + 2 * t->npad, z, t->num_atoms * sizeof(float), hipMemcpyHostToDevice));
+    if (cell) t->cells[frame] = *cell;
+    return true;
+}
+
+extern "C" bool vmd_devtraj_synth(vmd_devtraj_t* t, uint64_t seed, float L, float sigma, uint32_t n_blob,
+                                  size_t frame_beg, size_t frame_end) {
+    if (!t || frame_end > t->num_frames || frame_beg > frame_end) return vmd_fail("vmd_devtraj_synth: bad range");
+    vmd_unitcell_t c;
+    memset(&c, 0, sizeof(c));
+    c.x = c.y = c.z = L; c.flags = VMD_UNITCELL_PBC_ALL;
+    for (size_t f0 = frame_beg; f0 < frame_end; f0 += 1024) {
+        const size_t nb = std::min<size_t>(1024, frame_end - f0);
+        KRN_OK(vmd_hip_synth_frames(nullptr, t->d + f0 * 3 * t->npad, 3 * t->npad, t->npad, (int)nb, (uint32_t)f0, seed,
+                                    (uint32_t)t->num_atoms, n_blob, L, sigma));
+    }
+    HIP_OK(hipDeviceSynchronize());
+    for (size_t f = frame_beg; f < frame_end; ++f) t->cells[f] = c;
+    return true;
+}
+
+extern "C" float* vmd_devtraj_device_ptr(vmd_devtraj_t* t, size_t* frame_stride, size_t* row_stride) {
+    if (!t) return nullptr;
+    if (frame_stride) *frame_stride = 3 * t->npad;
+    if (row_stride) *row_stride = t->npad;
+    return t->d;
+}
+
+// ------------------------------------------------------------------------------------------------ consumer post-processing
+
+// what VIAMD does with a distribution before plotting it (/root/reference/src/main.cpp:232-250)
+extern "C" void vmd_downsample_histogram(float* dst_bins, int num_dst_bins, const float* src_bins, const float* src_weights,
+                                         int num_src_bins) {
+    const int factor = std::max(1, num_src_bins / std::max(1, num_dst_bins));
+    for (int d = 0; d < num_dst_bins; ++d) {
+        double bin = 0.0, weight = 0.0;
+        for (int i = 0; i < factor; ++i) {
+            const int s = d * factor + i;
+            if (s >= num_src_bins) break;
+            bin += src_bins[s];
+            weight += src_weights ? src_weights[s] : 1.0;
+        }
+        dst_bins[d] = (float)(bin / weight);
+    }
+}
+
+// temporal -> distribution as VIAMD builds it from the frame mask (/root/reference/src/main.cpp:172-230)
+extern "C" void vmd_compute_histogram_masked(float* bins, int num_bins, float range_min, float range_max, const float* values,
+                                             int dim, const uint8_t* frame_mask, int num_frames, bool aggregate) {
+    const int hdim = aggregate ? 1 : dim;
+    std::fill(bins, bins + (size_t)hdim * num_bins, 0.0f);
+    const float ext = range_max - range_min;
+    const float inv = ext > 0.0f ? 1.0f / ext : 0.0f;
+    std::vector<int> count(hdim, 0);
+    bool any = false;
+    for (int f = 0; f < num_frames; ++f) {
+        if (!frame_mask[f]) continue;
+        any = true;
+        for (int i = 0; i < dim; ++i) {
+            const float v = values[(size_t)f * dim + i];
+            if (v < range_min || range_max < v) continue;
+            const int b = std::min(std::max((int)(((v - range_min) * inv) * num_bins), 0), num_bins - 1);
+            const int row = aggregate ? 0 : i;
+            bins[(size_t)row * num_bins + b] += 1.0f;
+            count[row] += 1;
+        }
+    }
+    if (!any) return;
+    const float width = ext / num_bins;
+    for (int r = 0; r < hdim; ++r) {
+        const float scl = 1.0f / (width * count[r]);
+        for (int j = 0; j < num_bins; ++j) bins[(size_t)r * num_bins + j] *= scl;
+    }
+}

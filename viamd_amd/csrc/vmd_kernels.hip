@@ -1,0 +1,977 @@
+// viamd_amd/csrc/vmd_kernels.hip — hand-written gfx950 (CDNA4, wave64) kernels of the RDF / SDF / distance
+// hot path + the thin C-ABI launch layer declared in include/vmd_hip.h.
+//
+// Arithmetic contract: oracle/SPEC.md (S2 wrap, S3 pair displacement, S4 binning, S5 alignment/scatter,
+// S6 distances).  This file is compiled with -ffp-contract=off: the only fused operations are the explicit
+// fmaf() calls the spec names, so integer results are bit-identical to the CPU restatement.
+//
+// Reference functions replaced (sources live in the empty submodule ext/mdlib):
+//   md_spatial_hash build/query  -> k_cells_count / k_cells_scan / k_cells_scatter + the segment walk of k_rdf_pencil
+//   rdf()                        -> k_rdf_pencil (periodic, grid) / k_rdf_brute (general)
+//   sdf() + density volume       -> k_sdf_align (fp64 Horn/Jacobi) + k_sdf_scatter
+//   distance*()                  -> k_distance_com / k_distance_minmax / k_distance_pair
+//
+// Design notes (DESIGN.md has the long form):
+//  * wave64 everywhere; a wave is the unit of work in the pair kernel (private LDS histogram + private LDS
+//    hit queue per wave, no block barrier in the hot loop).
+//  * i atoms live in lanes, j atoms are wave-uniform: their coordinates come through the scalar cache
+//    (s_load) and feed VALU ops as SGPR operands, so the candidate filter is 7 VALU ops per pair.
+//  * hits are compacted through the per-wave LDS queue so that sqrt + binning + ds_add run on full waves.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+
+#include "vmd_hip.h"
+
+#define VMD_WAVE 64
+#define VMD_MAX_BINS 1024
+#define VMD_QUEUE_CAP 512          // power of two; holds < 64 pending + 4 undrained candidate columns of 64
+#define VMD_FAR 1.0e18f            // coordinate of a padding lane: never within any cutoff, squares stay finite
+
+// Wave-uniform read-only data (j coordinates, cell offsets, boxes) is read through the constant address space so
+// that hipcc emits s_load (scalar cache, SGPR operands) instead of per-lane global_load.  Legal because those
+// arrays are only written by earlier kernels.  (The SIMT emulator under tests/emu defines this to nothing.)
+#ifndef VMD_UNIFORM_AS
+#define VMD_UNIFORM_AS __attribute__((address_space(4)))
+#endif
+typedef VMD_UNIFORM_AS const float vmd_cf32;
+typedef VMD_UNIFORM_AS const uint32_t vmd_cu32;
+
+// ------------------------------------------------------------------------------------------------ helpers
+
+// SPEC S2
+__device__ __forceinline__ float vmd_wrap(float x, float L) {
+    const float invL = 1.0f / L;
+    const float t = x * invL;
+    const float f = floorf(t);
+    float xw = fmaf(-f, L, x);
+    if (xw < 0.0f) xw = xw + L;
+    if (xw >= L) xw = xw - L;
+    return xw;
+}
+
+__device__ __forceinline__ float vmd_d2(float dx, float dy, float dz) { return fmaf(dz, dz, fmaf(dy, dy, dx * dx)); }
+
+// SPEC S3 by comparison (general kernels)
+__device__ __forceinline__ float vmd_mi_cmp(float d, float L, float hL, bool pbc) {
+    if (pbc) {
+        const float s = d > hL ? L : (d < -hL ? -L : 0.0f);
+        d = d - s;
+    }
+    return d;
+}
+
+// SPEC S5/S6 fp32 minimum image by rint
+__device__ __forceinline__ float vmd_mi_rintf(float d, float L, bool pbc) {
+    if (pbc) {
+        const float invL = 1.0f / L;
+        d = fmaf(-rintf(d * invL), L, d);
+    }
+    return d;
+}
+
+__device__ __forceinline__ double vmd_mi_rint(double d, double L, bool pbc) {
+    if (pbc) d = d - L * rint(d / L);
+    return d;
+}
+
+__device__ __forceinline__ int vmd_cell_coord(float v, float inv, int n) {
+    int c = (int)(v * inv);
+    return c > n - 1 ? n - 1 : c;
+}
+
+__device__ __forceinline__ float vmd_wave_min(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float vmd_wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float vmd_uniform(float v) {
+    return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
+}
+__device__ __forceinline__ unsigned vmd_lane_prefix(unsigned long long mask) {
+    return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+}
+
+// SPEC S4: bin of one squared distance, -1 when outside the open interval
+struct vmd_binning_t {
+    float rmin, rmax, inv_range, fnbins;
+    int nbins;
+};
+__device__ __forceinline__ int vmd_bin_of(const vmd_binning_t& b, float d2) {
+    const float d = sqrtf(d2);
+    if (!(b.rmin < d && d < b.rmax)) return -1;
+    int bin = (int)(((d - b.rmin) * b.inv_range) * b.fnbins);
+    bin = bin < 0 ? 0 : bin;
+    return bin > b.nbins - 1 ? b.nbins - 1 : bin;
+}
+
+// ------------------------------------------------------------------------------------------------ K1: cell build
+
+struct vmd_cells_params_t {
+    const float* xyz; size_t frame_stride; size_t row_stride;
+    const float* boxes; const int32_t* sel; int nsel; int nsel_pad;
+    vmd_grid_t grid;
+    uint32_t* cell_count; uint32_t* rank; uint32_t* cell_start; float* sorted;
+};
+
+__device__ __forceinline__ uint32_t vmd_cell_of(const vmd_cells_params_t& p, int b, int t, float& xw, float& yw, float& zw) {
+    const int a = p.sel ? p.sel[t] : t;
+    const float* fx = p.xyz + (size_t)b * p.frame_stride;
+    const float Lx = p.boxes[3 * b + 0], Ly = p.boxes[3 * b + 1], Lz = p.boxes[3 * b + 2];
+    xw = vmd_wrap(fx[a], Lx);
+    yw = vmd_wrap(fx[p.row_stride + a], Ly);
+    zw = vmd_wrap(fx[2 * p.row_stride + a], Lz);
+    const int cx = vmd_cell_coord(xw, (float)p.grid.nxf / Lx, p.grid.nxf);
+    const int cy = vmd_cell_coord(yw, (float)p.grid.ny / Ly, p.grid.ny);
+    const int cz = vmd_cell_coord(zw, (float)p.grid.nz / Lz, p.grid.nz);
+    return (uint32_t)((cz * p.grid.ny + cy) * p.grid.nxf + cx);
+}
+
+__global__ __launch_bounds__(256) void k_cells_count(vmd_cells_params_t p) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.y;
+    if (t >= p.nsel) return;
+    float xw, yw, zw;
+    const uint32_t c = vmd_cell_of(p, b, t, xw, yw, zw);
+    p.rank[(size_t)b * p.nsel + t] = atomicAdd(&p.cell_count[(size_t)b * (p.grid.ncell + 1) + c], 1u);
+}
+
+// one 1024-thread block per frame: exclusive prefix over the cell populations
+__global__ __launch_bounds__(1024) void k_cells_scan(const uint32_t* __restrict__ cell_count, uint32_t* __restrict__ cell_start,
+                                                     int ncell) {
+    __shared__ uint32_t part[1024];
+    const int b = blockIdx.x;
+    const uint32_t* cnt = cell_count + (size_t)b * (ncell + 1);
+    uint32_t* out = cell_start + (size_t)b * (ncell + 1);
+    const int per = (ncell + 1023) / 1024;
+    const int beg = threadIdx.x * per;
+    const int end = beg + per < ncell ? beg + per : ncell;
+    uint32_t s = 0;
+    for (int c = beg; c < end; ++c) s += cnt[c];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const uint32_t v = threadIdx.x >= (unsigned)o ? part[threadIdx.x - o] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[threadIdx.x] - s;   // exclusive
+    for (int c = beg; c < end; ++c) { out[c] = run; run += cnt[c]; }
+    if (threadIdx.x == 1023) out[ncell] = part[1023];
+}
+
+__global__ __launch_bounds__(256) void k_cells_scatter(vmd_cells_params_t p) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.y;
+    if (t >= p.nsel) return;
+    float xw, yw, zw;
+    const uint32_t c = vmd_cell_of(p, b, t, xw, yw, zw);
+    const uint32_t pos = p.cell_start[(size_t)b * (p.grid.ncell + 1) + c] + p.rank[(size_t)b * p.nsel + t];
+    float* s = p.sorted + (size_t)b * 3 * p.nsel_pad;
+    s[pos] = xw;
+    s[p.nsel_pad + pos] = yw;
+    s[2 * (size_t)p.nsel_pad + pos] = zw;
+}
+
+// ------------------------------------------------------------------------------------------------ K2: RDF, pencil grid
+
+struct vmd_pair_params_t {
+    const float* __restrict__ sref; const uint32_t* __restrict__ cs_ref; int nref_pad;
+    const float* __restrict__ stgt; const uint32_t* __restrict__ cs_tgt; int ntgt_pad;
+    const float* __restrict__ boxes; int B;
+    vmd_grid_t grid;
+    vmd_binning_t bin;
+    float r2_up;        // conservative candidate filter (> rmax^2)
+    float rpad;         // conservative range padding (> rmax)
+    uint64_t* partial;  // [gridDim.x*4][nbins]
+};
+
+// per-wave state of the hit machinery
+struct vmd_wave_acc_t {
+    unsigned* hist;       // LDS, nbins
+    float* queue;         // LDS, VMD_QUEUE_CAP
+    unsigned qhead, qtail;  // wave-uniform ring positions
+    unsigned ncols;       // wave-uniform: candidate columns (<= 64 hits each) since the last flush
+};
+
+template <unsigned INC>
+__device__ __forceinline__ void vmd_bin_add(const vmd_binning_t& bn, unsigned* hist, float d2, bool active) {
+    if (active) {
+        const int bin = vmd_bin_of(bn, d2);
+        if (bin >= 0) atomicAdd(&hist[bin], INC);
+    }
+}
+
+// VARIANT 0: compact the hits of one candidate column into the wave queue (ring buffer in LDS);
+// vmd_drain_full pops full waves of 64 so that sqrt + binning + ds_add always run with every lane busy.
+// VARIANT 1: bin the hits in place under the divergent mask (reference implementation of the same arithmetic).
+template <int VARIANT, unsigned INC>
+__device__ __forceinline__ void vmd_push(const vmd_binning_t& bn, vmd_wave_acc_t& w, bool hit, float d2) {
+    if (VARIANT == 1) {
+        vmd_bin_add<INC>(bn, w.hist, d2, hit);
+        return;
+    }
+    const unsigned long long mask = __ballot(hit);
+    if (mask) {
+        const unsigned pos = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, w.qtail));
+        if (hit) w.queue[pos & (VMD_QUEUE_CAP - 1)] = d2;
+        w.qtail += (unsigned)__popcll(mask);
+    }
+}
+
+template <int VARIANT, unsigned INC>
+__device__ __forceinline__ void vmd_drain_full(const vmd_binning_t& bn, vmd_wave_acc_t& w, int lane) {
+    if (VARIANT == 1) return;
+    while (w.qtail - w.qhead >= VMD_WAVE) {
+        __builtin_amdgcn_wave_barrier();
+        const float v = w.queue[(w.qhead + lane) & (VMD_QUEUE_CAP - 1)];
+        __builtin_amdgcn_wave_barrier();
+        w.qhead += VMD_WAVE;
+        vmd_bin_add<INC>(bn, w.hist, v, true);
+    }
+}
+
+template <int VARIANT, unsigned INC>
+__device__ __forceinline__ void vmd_drain(const vmd_binning_t& bn, vmd_wave_acc_t& w, int lane) {
+    if (VARIANT == 1) return;
+    vmd_drain_full<VARIANT, INC>(bn, w, lane);
+    const unsigned rem = w.qtail - w.qhead;
+    __builtin_amdgcn_wave_barrier();
+    const float v = w.queue[(w.qhead + lane) & (VMD_QUEUE_CAP - 1)];
+    __builtin_amdgcn_wave_barrier();
+    w.qhead = w.qtail;
+    vmd_bin_add<INC>(bn, w.hist, v, (unsigned)lane < rem);
+}
+
+// one uniform j segment [ja, jb) against the wave's 64 i atoms.  MASKED: count only j > i (own pencil, same set).
+// SHIFT: the segment is a periodic image, displaced by (sx,sy,sz) (SPEC S3: dx = fl(fl(xi-xj) - sx)).
+template <int VARIANT, unsigned INC, bool MASKED, bool SHIFT>
+__device__ __forceinline__ void vmd_segment_loop(const vmd_pair_params_t& p, vmd_wave_acc_t& w, vmd_cf32* tx, vmd_cf32* ty, vmd_cf32* tz,
+                                                 unsigned ja, unsigned jb, float sx, float sy, float sz,
+                                                 float xi, float yi, float zi, unsigned i, int lane) {
+    const float r2 = p.r2_up;
+    vmd_cf32* px = tx + ja;
+    vmd_cf32* py = ty + ja;
+    vmd_cf32* pz = tz + ja;
+    int n = (int)(jb - ja);
+    unsigned j = ja;
+    for (; n >= 4; n -= 4, px += 4, py += 4, pz += 4, j += 4) {
+        float xj[4], yj[4], zj[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { xj[u] = px[u]; yj[u] = py[u]; zj[u] = pz[u]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float dx = xi - xj[u], dy = yi - yj[u], dz = zi - zj[u];
+            if (SHIFT) { dx = dx - sx; dy = dy - sy; dz = dz - sz; }
+            const float d2 = vmd_d2(dx, dy, dz);
+            bool hit = d2 < r2;
+            if (MASKED) hit = hit && (j + u > i);
+            vmd_push<VARIANT, INC>(p.bin, w, hit, d2);
+        }
+        vmd_drain_full<VARIANT, INC>(p.bin, w, lane);
+    }
+    for (int u = 0; u < n; ++u) {
+        float dx = xi - px[u], dy = yi - py[u], dz = zi - pz[u];
+        if (SHIFT) { dx = dx - sx; dy = dy - sy; dz = dz - sz; }
+        const float d2 = vmd_d2(dx, dy, dz);
+        bool hit = d2 < r2;
+        if (MASKED) hit = hit && (j + u > i);
+        vmd_push<VARIANT, INC>(p.bin, w, hit, d2);
+    }
+    vmd_drain_full<VARIANT, INC>(p.bin, w, lane);
+}
+
+template <int VARIANT, unsigned INC, bool MASKED>
+__device__ __forceinline__ void vmd_segment(const vmd_pair_params_t& p, vmd_wave_acc_t& w, vmd_cf32* st,
+                                            unsigned ja, unsigned jb, float sx, float sy, float sz,
+                                            float xi, float yi, float zi, unsigned i, int lane) {
+    vmd_cf32* tx = st;
+    vmd_cf32* ty = st + p.ntgt_pad;
+    vmd_cf32* tz = st + 2 * (size_t)p.ntgt_pad;
+    if (sx == 0.0f && sy == 0.0f && sz == 0.0f)
+        vmd_segment_loop<VARIANT, INC, MASKED, false>(p, w, tx, ty, tz, ja, jb, sx, sy, sz, xi, yi, zi, i, lane);
+    else
+        vmd_segment_loop<VARIANT, INC, MASKED, true>(p, w, tx, ty, tz, ja, jb, sx, sy, sz, xi, yi, zi, i, lane);
+}
+
+template <int VARIANT, bool SAME>
+__global__ __launch_bounds__(256) void k_rdf_pencil(vmd_pair_params_t p) {
+    __shared__ unsigned s_hist[4][VMD_MAX_BINS];
+    __shared__ float s_queue[4][VMD_QUEUE_CAP];
+    constexpr unsigned INC = SAME ? 2u : 1u;
+
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    const int nbins = p.bin.nbins;
+
+    vmd_wave_acc_t w;
+    w.hist = s_hist[wave];
+    w.queue = s_queue[wave];
+    w.qhead = 0; w.qtail = 0; w.ncols = 0;
+    for (int b = lane; b < nbins; b += VMD_WAVE) w.hist[b] = 0u;
+    __builtin_amdgcn_wave_barrier();
+
+    const int nxf = p.grid.nxf, ny = p.grid.ny, nz = p.grid.nz;
+    const int npen = ny * nz;
+    const int nitems = p.B * npen;
+    const int gw = blockIdx.x * 4 + wave;
+    const int GW = gridDim.x * 4;
+    uint64_t* __restrict__ prow = p.partial + (size_t)gw * nbins;
+    bool flushed = false;
+
+    for (int item = gw; item < nitems; item += GW) {
+        const int b = item / npen;
+        const int pen = item - b * npen;
+        const int pz = pen / ny;
+        const int py = pen - pz * ny;
+        vmd_cf32* boxes = (vmd_cf32*)p.boxes;
+        const float Lx = boxes[3 * b + 0], Ly = boxes[3 * b + 1], Lz = boxes[3 * b + 2];
+        const float inv_cx = (float)nxf / Lx;
+        vmd_cu32* csr = (vmd_cu32*)p.cs_ref + (size_t)b * (p.grid.ncell + 1);
+        vmd_cu32* cst = (vmd_cu32*)p.cs_tgt + (size_t)b * (p.grid.ncell + 1);
+        const float* __restrict__ sr = p.sref + (size_t)b * 3 * p.nref_pad;
+        vmd_cf32* st = (vmd_cf32*)p.stgt + (size_t)b * 3 * p.ntgt_pad;
+        const unsigned pbeg = csr[pen * nxf];
+        const unsigned pend = csr[(pen + 1) * nxf];
+
+        for (unsigned cbeg = pbeg; cbeg < pend; cbeg += VMD_WAVE) {
+            const unsigned i = cbeg + lane;
+            const bool valid = i < pend;
+            const float xi = valid ? sr[i] : VMD_FAR;
+            const float yi = valid ? sr[p.nref_pad + i] : VMD_FAR;
+            const float zi = valid ? sr[2 * (size_t)p.nref_pad + i] : VMD_FAR;
+            const float xlo = vmd_uniform(vmd_wave_min(valid ? xi : 3.0e38f));
+            const float xhi = vmd_uniform(vmd_wave_max(valid ? xi : -3.0e38f));
+
+            for (int dz = SAME ? 0 : -1; dz <= 1; ++dz) {
+                int qz = pz + dz; float sz = 0.0f;
+                if (qz < 0) { qz += nz; sz = -Lz; } else if (qz >= nz) { qz -= nz; sz = Lz; }
+                for (int dy = -1; dy <= 1; ++dy) {
+                    if (SAME && dz == 0 && dy < 0) continue;
+                    int qy = py + dy; float sy = 0.0f;
+                    if (qy < 0) { qy += ny; sy = -Ly; } else if (qy >= ny) { qy -= ny; sy = Ly; }
+                    const bool own = SAME && dz == 0 && dy == 0;
+                    const int q = qz * ny + qy;
+                    for (int kx = -1; kx <= 1; ++kx) {
+                        const float sx = (float)kx * Lx;
+                        const float lo = (xlo - p.rpad) - sx;
+                        const float hi = (xhi + p.rpad) - sx;
+                        if (hi < 0.0f || lo >= Lx) continue;
+                        const int ca = lo <= 0.0f ? 0 : vmd_cell_coord(lo, inv_cx, nxf);
+                        const int cb = hi >= Lx ? nxf - 1 : vmd_cell_coord(hi, inv_cx, nxf);
+                        unsigned ja = cst[q * nxf + ca];
+                        const unsigned jb = cst[q * nxf + cb + 1];
+                        if (own) {
+                            // unordered pairs once: j > i.  Inside the chunk the test is per lane, above it all lanes pass.
+                            const unsigned cend = cbeg + VMD_WAVE;
+                            const unsigned ma = ja > cbeg ? ja : cbeg;
+                            const unsigned mb = jb < cend ? jb : cend;
+                            if (ma < mb) {
+                                w.ncols += mb - ma;
+                                vmd_segment<VARIANT, INC, true>(p, w, st, ma, mb, sx, sy, sz, xi, yi, zi, i, lane);
+                            }
+                            ja = ja > cend ? ja : cend;
+                        }
+                        if (ja < jb) {
+                            w.ncols += jb - ja;
+                            vmd_segment<VARIANT, INC, false>(p, w, st, ja, jb, sx, sy, sz, xi, yi, zi, i, lane);
+                        }
+                    }
+                }
+            }
+            // u32 LDS counters: every candidate column adds at most 64*INC; flush long before 2^32
+            if (w.ncols >= (1u << 23)) {
+                vmd_drain<VARIANT, INC>(p.bin, w, lane);
+                __builtin_amdgcn_wave_barrier();
+                for (int bb = lane; bb < nbins; bb += VMD_WAVE) {
+                    const uint64_t v = w.hist[bb];
+                    prow[bb] = flushed ? prow[bb] + v : v;
+                    w.hist[bb] = 0u;
+                }
+                __builtin_amdgcn_wave_barrier();
+                flushed = true;
+                w.ncols = 0;
+            }
+        }
+    }
+    vmd_drain<VARIANT, INC>(p.bin, w, lane);
+    __builtin_amdgcn_wave_barrier();
+    for (int bb = lane; bb < nbins; bb += VMD_WAVE) {
+        const uint64_t v = w.hist[bb];
+        prow[bb] = flushed ? prow[bb] + v : v;
+    }
+}
+
+// sum the per-wave partial rows into the u64 accumulators
+__global__ __launch_bounds__(256) void k_hist_reduce(const uint64_t* __restrict__ partial, int nrows, int nbins,
+                                                     uint64_t* __restrict__ counts) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= nbins) return;
+    uint64_t s = 0;
+    for (int r = 0; r < nrows; ++r) s += partial[(size_t)r * nbins + b];
+    if (s) atomicAdd((unsigned long long*)&counts[b], (unsigned long long)s);
+}
+
+// ------------------------------------------------------------------------------------------------ RDF, general (brute)
+
+struct vmd_brute_params_t {
+    const float* xyz; size_t frame_stride; size_t row_stride;
+    const float* boxes; uint32_t pbc; int B;
+    const int32_t* ref; int nref; const int32_t* tgt; int ntgt;
+    vmd_binning_t bin;
+    uint64_t* counts;
+};
+
+__global__ __launch_bounds__(256) void k_rdf_brute(vmd_brute_params_t p) {
+    __shared__ unsigned s_hist[VMD_MAX_BINS];
+    __shared__ float s_t[3][256];
+    const int b = blockIdx.y;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const float* fx = p.xyz + (size_t)b * p.frame_stride;
+    const float* fy = fx + p.row_stride;
+    const float* fz = fy + p.row_stride;
+    const bool px = p.pbc & 1u, py = p.pbc & 2u, pz = p.pbc & 4u;
+    const float Lx = p.boxes[3 * b + 0], Ly = p.boxes[3 * b + 1], Lz = p.boxes[3 * b + 2];
+    const float hx = 0.5f * Lx, hy = 0.5f * Ly, hz = 0.5f * Lz;
+    for (int k = threadIdx.x; k < p.bin.nbins; k += 256) s_hist[k] = 0u;
+    float xi = VMD_FAR, yi = VMD_FAR, zi = VMD_FAR;
+    const bool valid = t < p.nref;
+    if (valid) {
+        const int a = p.ref ? p.ref[t] : t;
+        xi = px ? vmd_wrap(fx[a], Lx) : fx[a];
+        yi = py ? vmd_wrap(fy[a], Ly) : fy[a];
+        zi = pz ? vmd_wrap(fz[a], Lz) : fz[a];
+    }
+    for (int j0 = 0; j0 < p.ntgt; j0 += 256) {
+        __syncthreads();
+        const int j = j0 + threadIdx.x;
+        if (j < p.ntgt) {
+            const int a = p.tgt ? p.tgt[j] : j;
+            s_t[0][threadIdx.x] = px ? vmd_wrap(fx[a], Lx) : fx[a];
+            s_t[1][threadIdx.x] = py ? vmd_wrap(fy[a], Ly) : fy[a];
+            s_t[2][threadIdx.x] = pz ? vmd_wrap(fz[a], Lz) : fz[a];
+        }
+        __syncthreads();
+        const int nj = p.ntgt - j0 < 256 ? p.ntgt - j0 : 256;
+        if (valid) {
+            for (int jj = 0; jj < nj; ++jj) {
+                const float dx = vmd_mi_cmp(xi - s_t[0][jj], Lx, hx, px);
+                const float dy = vmd_mi_cmp(yi - s_t[1][jj], Ly, hy, py);
+                const float dz = vmd_mi_cmp(zi - s_t[2][jj], Lz, hz, pz);
+                const int bin = vmd_bin_of(p.bin, vmd_d2(dx, dy, dz));
+                if (bin >= 0) atomicAdd(&s_hist[bin], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < p.bin.nbins; k += 256) {
+        const unsigned v = s_hist[k];
+        if (v) atomicAdd((unsigned long long*)&p.counts[k], (unsigned long long)v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ K3: SDF alignment (fp64)
+
+// cyclic Jacobi on a symmetric 4x4 — identical operation order to oracle vo_jacobi4
+__device__ void vmd_jacobi4(double A[4][4], double V[4][4]) {
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) V[i][j] = (i == j) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 24; ++sweep) {
+        double off = 0.0;
+        for (int p = 0; p < 3; ++p) for (int q = p + 1; q < 4; ++q) off = off + fabs(A[p][q]);
+        if (off == 0.0) break;
+        for (int p = 0; p < 3; ++p) {
+            for (int q = p + 1; q < 4; ++q) {
+                const double apq = A[p][q];
+                if (apq == 0.0) continue;
+                const double theta = (A[q][q] - A[p][p]) / (2.0 * apq);
+                const double at = fabs(theta);
+                double t = 1.0 / (at + sqrt(theta * theta + 1.0));
+                if (theta < 0.0) t = -t;
+                const double c = 1.0 / sqrt(t * t + 1.0);
+                const double s = t * c;
+                for (int k = 0; k < 4; ++k) {
+                    const double akp = A[k][p], akq = A[k][q];
+                    A[k][p] = c * akp - s * akq;
+                    A[k][q] = s * akp + c * akq;
+                }
+                for (int k = 0; k < 4; ++k) {
+                    const double apk = A[p][k], aqk = A[q][k];
+                    A[p][k] = c * apk - s * aqk;
+                    A[q][k] = s * apk + c * aqk;
+                }
+                A[p][q] = 0.0; A[q][p] = 0.0;
+                for (int k = 0; k < 4; ++k) {
+                    const double vkp = V[k][p], vkq = V[k][q];
+                    V[k][p] = c * vkp - s * vkq;
+                    V[k][q] = s * vkp + c * vkq;
+                }
+            }
+        }
+    }
+}
+
+__device__ void vmd_horn_rotation(const double S[3][3], double R[9]) {
+    double N[4][4], V[4][4];
+    N[0][0] = S[0][0] + S[1][1] + S[2][2];
+    N[0][1] = S[1][2] - S[2][1];
+    N[0][2] = S[2][0] - S[0][2];
+    N[0][3] = S[0][1] - S[1][0];
+    N[1][1] = S[0][0] - S[1][1] - S[2][2];
+    N[1][2] = S[0][1] + S[1][0];
+    N[1][3] = S[2][0] + S[0][2];
+    N[2][2] = S[1][1] - S[0][0] - S[2][2];
+    N[2][3] = S[1][2] + S[2][1];
+    N[3][3] = S[2][2] - S[0][0] - S[1][1];
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < i; ++j) N[i][j] = N[j][i];
+    vmd_jacobi4(N, V);
+    int best = 0;
+    for (int i = 1; i < 4; ++i) if (N[i][i] > N[best][best]) best = i;
+    double qw = V[0][best], qx = V[1][best], qy = V[2][best], qz = V[3][best];
+    const double nrm = sqrt(qw * qw + qx * qx + qy * qy + qz * qz);
+    qw = qw / nrm; qx = qx / nrm; qy = qy / nrm; qz = qz / nrm;
+    R[0] = 1.0 - 2.0 * (qy * qy + qz * qz);
+    R[1] = 2.0 * (qx * qy - qw * qz);
+    R[2] = 2.0 * (qx * qz + qw * qy);
+    R[3] = 2.0 * (qx * qy + qw * qz);
+    R[4] = 1.0 - 2.0 * (qx * qx + qz * qz);
+    R[5] = 2.0 * (qy * qz - qw * qx);
+    R[6] = 2.0 * (qx * qz - qw * qy);
+    R[7] = 2.0 * (qy * qz + qw * qx);
+    R[8] = 1.0 - 2.0 * (qx * qx + qy * qy);
+}
+
+// walks the unwrap chain of one structure; calls f(a, w, px, py, pz) for every atom in order
+template <typename F>
+__device__ __forceinline__ void vmd_unwrap_chain(const float* fx, const float* fy, const float* fz,
+                                                 const int32_t* idx, const float* mass, int m,
+                                                 double Lx, double Ly, double Lz, bool px_, bool py_, bool pz_, F f) {
+    double qx = 0.0, qy = 0.0, qz = 0.0;
+    for (int a = 0; a < m; ++a) {
+        const int i = idx[a];
+        double x = (double)fx[i], y = (double)fy[i], z = (double)fz[i];
+        if (a > 0) {
+            x = qx + vmd_mi_rint(x - qx, Lx, px_);
+            y = qy + vmd_mi_rint(y - qy, Ly, py_);
+            z = qz + vmd_mi_rint(z - qz, Lz, pz_);
+        }
+        qx = x; qy = y; qz = z;
+        f(a, mass ? (double)mass[a] : 1.0, x, y, z);
+    }
+}
+
+struct vmd_align_params_t {
+    const float* xyz; size_t frame_stride; size_t row_stride;
+    const float* boxes; uint32_t pbc; int B;
+    const int32_t* structs; const float* mass; int K; int m;
+    const double* ref_pose;
+    float* R32; float* c32; double* M64;
+};
+
+__global__ __launch_bounds__(64) void k_sdf_align(vmd_align_params_t p) {
+    const int t = blockIdx.x * 64 + threadIdx.x;
+    if (t >= p.B * p.K) return;
+    const int b = t / p.K, k = t - b * p.K;
+    const float* fx = p.xyz + (size_t)b * p.frame_stride;
+    const float* fy = fx + p.row_stride;
+    const float* fz = fy + p.row_stride;
+    const double Lx = (double)p.boxes[3 * b + 0], Ly = (double)p.boxes[3 * b + 1], Lz = (double)p.boxes[3 * b + 2];
+    const bool px = p.pbc & 1u, py = p.pbc & 2u, pz = p.pbc & 4u;
+    const int32_t* idx = p.structs + (size_t)k * p.m;
+    const float* mass = p.mass ? p.mass + (size_t)k * p.m : nullptr;
+
+    double sw = 0.0, sx = 0.0, sy = 0.0, sz = 0.0;
+    vmd_unwrap_chain(fx, fy, fz, idx, mass, p.m, Lx, Ly, Lz, px, py, pz,
+                     [&](int, double w, double x, double y, double z) {
+                         sw = sw + w; sx = sx + w * x; sy = sy + w * y; sz = sz + w * z;
+                     });
+    const double com0 = sx / sw, com1 = sy / sw, com2 = sz / sw;
+    double S[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+    const double* ref = p.ref_pose;
+    vmd_unwrap_chain(fx, fy, fz, idx, mass, p.m, Lx, Ly, Lz, px, py, pz,
+                     [&](int a, double w, double x, double y, double z) {
+                         const double c0 = x - com0, c1 = y - com1, c2 = z - com2;
+                         const double r0 = ref[3 * a + 0], r1 = ref[3 * a + 1], r2 = ref[3 * a + 2];
+                         const double wc0 = w * c0, wc1 = w * c1, wc2 = w * c2;
+                         S[0][0] = S[0][0] + wc0 * r0; S[0][1] = S[0][1] + wc0 * r1; S[0][2] = S[0][2] + wc0 * r2;
+                         S[1][0] = S[1][0] + wc1 * r0; S[1][1] = S[1][1] + wc1 * r1; S[1][2] = S[1][2] + wc1 * r2;
+                         S[2][0] = S[2][0] + wc2 * r0; S[2][1] = S[2][1] + wc2 * r1; S[2][2] = S[2][2] + wc2 * r2;
+                     });
+    double R[9];
+    vmd_horn_rotation(S, R);
+    float* R32 = p.R32 + (size_t)t * 9;
+    float* c32 = p.c32 + (size_t)t * 3;
+    for (int i = 0; i < 9; ++i) R32[i] = (float)R[i];
+    c32[0] = (float)com0; c32[1] = (float)com1; c32[2] = (float)com2;
+    if (p.M64) {
+        double* M = p.M64 + (size_t)t * 12;
+        for (int r = 0; r < 3; ++r) {
+            M[4 * r + 0] = R[3 * r + 0]; M[4 * r + 1] = R[3 * r + 1]; M[4 * r + 2] = R[3 * r + 2];
+            M[4 * r + 3] = -(R[3 * r + 0] * com0 + R[3 * r + 1] * com1 + R[3 * r + 2] * com2);
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void k_sdf_ref_pose(const float* xyz, size_t row_stride, const float* box, uint32_t pbc,
+                                                     const int32_t* idx, const float* mass, int m, double* ref_pose) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    const float* fx = xyz;
+    const float* fy = fx + row_stride;
+    const float* fz = fy + row_stride;
+    const double Lx = (double)box[0], Ly = (double)box[1], Lz = (double)box[2];
+    const bool px = pbc & 1u, py = pbc & 2u, pz = pbc & 4u;
+    double sw = 0.0, sx = 0.0, sy = 0.0, sz = 0.0;
+    vmd_unwrap_chain(fx, fy, fz, idx, mass, m, Lx, Ly, Lz, px, py, pz,
+                     [&](int a, double w, double x, double y, double z) {
+                         ref_pose[3 * a + 0] = x; ref_pose[3 * a + 1] = y; ref_pose[3 * a + 2] = z;
+                         sw = sw + w; sx = sx + w * x; sy = sy + w * y; sz = sz + w * z;
+                     });
+    const double com0 = sx / sw, com1 = sy / sw, com2 = sz / sw;
+    for (int a = 0; a < m; ++a) {
+        ref_pose[3 * a + 0] = ref_pose[3 * a + 0] - com0;
+        ref_pose[3 * a + 1] = ref_pose[3 * a + 1] - com1;
+        ref_pose[3 * a + 2] = ref_pose[3 * a + 2] - com2;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ K4: SDF scatter
+
+struct vmd_scatter_params_t {
+    const float* __restrict__ xyz; size_t frame_stride; size_t row_stride;
+    const float* __restrict__ boxes; uint32_t pbc; int B;
+    const int32_t* __restrict__ structs; int K; int m;
+    const float* __restrict__ R32; const float* __restrict__ c32;
+    const int32_t* __restrict__ tgt; int ntgt; float extent; int dim;
+    unsigned long long* volume;
+};
+
+__global__ __launch_bounds__(256) void k_sdf_scatter(vmd_scatter_params_t p) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.y;
+    if (t >= p.ntgt) return;
+    const int i = p.tgt ? p.tgt[t] : t;
+    const float* fx = p.xyz + (size_t)b * p.frame_stride;
+    const float x = fx[i], y = fx[p.row_stride + i], z = fx[2 * p.row_stride + i];
+    const float Lx = p.boxes[3 * b + 0], Ly = p.boxes[3 * b + 1], Lz = p.boxes[3 * b + 2];
+    const bool px = p.pbc & 1u, py = p.pbc & 2u, pz = p.pbc & 4u;
+    const float s = p.extent;
+    const float vscale = (float)p.dim / (2.0f * s);
+    const float fdim = (float)p.dim;
+    for (int k = 0; k < p.K; ++k) {
+        const int32_t* sidx = p.structs + (size_t)k * p.m;
+        bool own = false;
+        for (int a = 0; a < p.m; ++a) own = own || (sidx[a] == i);
+        if (own) continue;
+        const float* R = p.R32 + ((size_t)b * p.K + k) * 9;
+        const float* c = p.c32 + ((size_t)b * p.K + k) * 3;
+        const float dx = vmd_mi_rintf(x - c[0], Lx, px);
+        const float dy = vmd_mi_rintf(y - c[1], Ly, py);
+        const float dz = vmd_mi_rintf(z - c[2], Lz, pz);
+        const float qx = fmaf(R[2], dz, fmaf(R[1], dy, R[0] * dx));
+        const float qy = fmaf(R[5], dz, fmaf(R[4], dy, R[3] * dx));
+        const float qz = fmaf(R[8], dz, fmaf(R[7], dy, R[6] * dx));
+        const float tx = (qx + s) * vscale;
+        const float ty = (qy + s) * vscale;
+        const float tz = (qz + s) * vscale;
+        if (tx >= 0.0f && tx < fdim && ty >= 0.0f && ty < fdim && tz >= 0.0f && tz < fdim) {
+            const int vx = (int)tx, vy = (int)ty, vz = (int)tz;
+            atomicAdd(&p.volume[((size_t)vz * p.dim + vy) * p.dim + vx], 1ull);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ K5: distances
+
+struct vmd_dist_params_t {
+    const float* xyz; size_t frame_stride; size_t row_stride;
+    const float* boxes; uint32_t pbc; int B;
+    const int32_t* a; const float* mass_a; int na; const int32_t* b; const float* mass_b; int nb;
+    float* out;
+};
+
+__device__ void vmd_set_com(const float* fx, const float* fy, const float* fz, const int32_t* idx, const float* mass, int n,
+                            double Lx, double Ly, double Lz, bool px, bool py, bool pz, float out[3]) {
+    double sw = 0.0, sx = 0.0, sy = 0.0, sz = 0.0;
+    double p0x = 0.0, p0y = 0.0, p0z = 0.0;
+    for (int a = 0; a < n; ++a) {
+        const int i = idx[a];
+        double x = (double)fx[i], y = (double)fy[i], z = (double)fz[i];
+        if (a == 0) { p0x = x; p0y = y; p0z = z; }
+        else {
+            x = p0x + vmd_mi_rint(x - p0x, Lx, px);
+            y = p0y + vmd_mi_rint(y - p0y, Ly, py);
+            z = p0z + vmd_mi_rint(z - p0z, Lz, pz);
+        }
+        const double w = mass ? (double)mass[a] : 1.0;
+        sw = sw + w; sx = sx + w * x; sy = sy + w * y; sz = sz + w * z;
+    }
+    out[0] = (float)(sx / sw); out[1] = (float)(sy / sw); out[2] = (float)(sz / sw);
+}
+
+__global__ __launch_bounds__(64) void k_distance_com(vmd_dist_params_t p) {
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= p.B) return;
+    const float* fx = p.xyz + (size_t)b * p.frame_stride;
+    const float* fy = fx + p.row_stride;
+    const float* fz = fy + p.row_stride;
+    const float Lx = p.boxes[3 * b + 0], Ly = p.boxes[3 * b + 1], Lz = p.boxes[3 * b + 2];
+    const bool px = p.pbc & 1u, py = p.pbc & 2u, pz = p.pbc & 4u;
+    float ca[3], cb[3];
+    vmd_set_com(fx, fy, fz, p.a, p.mass_a, p.na, (double)Lx, (double)Ly, (double)Lz, px, py, pz, ca);
+    vmd_set_com(fx, fy, fz, p.b, p.mass_b, p.nb, (double)Lx, (double)Ly, (double)Lz, px, py, pz, cb);
+    const float dx = vmd_mi_rintf(ca[0] - cb[0], Lx, px);
+    const float dy = vmd_mi_rintf(ca[1] - cb[1], Ly, py);
+    const float dz = vmd_mi_rintf(ca[2] - cb[2], Lz, pz);
+    p.out[b] = sqrtf(vmd_d2(dx, dy, dz));
+}
+
+__device__ __forceinline__ float vmd_pair_d2(const vmd_dist_params_t& p, int b, int ia, int ib) {
+    const float* fx = p.xyz + (size_t)b * p.frame_stride;
+    const float* fy = fx + p.row_stride;
+    const float* fz = fy + p.row_stride;
+    const float Lx = p.boxes[3 * b + 0], Ly = p.boxes[3 * b + 1], Lz = p.boxes[3 * b + 2];
+    const bool px = p.pbc & 1u, py = p.pbc & 2u, pz = p.pbc & 4u;
+    const int i = p.a[ia], j = p.b[ib];
+    const float xi = px ? vmd_wrap(fx[i], Lx) : fx[i], xj = px ? vmd_wrap(fx[j], Lx) : fx[j];
+    const float yi = py ? vmd_wrap(fy[i], Ly) : fy[i], yj = py ? vmd_wrap(fy[j], Ly) : fy[j];
+    const float zi = pz ? vmd_wrap(fz[i], Lz) : fz[i], zj = pz ? vmd_wrap(fz[j], Lz) : fz[j];
+    const float dx = vmd_mi_cmp(xi - xj, Lx, 0.5f * Lx, px);
+    const float dy = vmd_mi_cmp(yi - yj, Ly, 0.5f * Ly, py);
+    const float dz = vmd_mi_cmp(zi - zj, Lz, 0.5f * Lz, pz);
+    return vmd_d2(dx, dy, dz);
+}
+
+// one block per frame; MAXI = false -> min, true -> max
+template <bool MAXI>
+__global__ __launch_bounds__(256) void k_distance_minmax(vmd_dist_params_t p) {
+    __shared__ float s_red[256];
+    const int b = blockIdx.x;
+    const long long npairs = (long long)p.na * p.nb;
+    float best = MAXI ? 0.0f : 3.4028235e38f;
+    for (long long k = threadIdx.x; k < npairs; k += 256) {
+        const int ia = (int)(k / p.nb), ib = (int)(k - (long long)ia * p.nb);
+        const float d2 = vmd_pair_d2(p, b, ia, ib);
+        best = MAXI ? fmaxf(best, d2) : fminf(best, d2);
+    }
+    s_red[threadIdx.x] = best;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+            const float v = s_red[threadIdx.x + o];
+            s_red[threadIdx.x] = MAXI ? fmaxf(s_red[threadIdx.x], v) : fminf(s_red[threadIdx.x], v);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) p.out[b] = sqrtf(s_red[0]);
+}
+
+__global__ __launch_bounds__(256) void k_distance_pair(vmd_dist_params_t p) {
+    const long long npairs = (long long)p.na * p.nb;
+    const long long k = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.y;
+    if (k >= npairs) return;
+    const int ia = (int)(k / p.nb), ib = (int)(k - (long long)ia * p.nb);
+    p.out[(size_t)b * npairs + k] = sqrtf(vmd_pair_d2(p, b, ia, ib));
+}
+
+// ------------------------------------------------------------------------------------------------ misc
+
+__global__ __launch_bounds__(256) void k_counts_to_float(const uint64_t* __restrict__ counts, size_t n, float* __restrict__ values,
+                                                         unsigned* __restrict__ max_bits) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float v = (float)counts[i];
+    values[i] = v;
+    if (max_bits && v > 0.0f) atomicMax(max_bits, (unsigned)__float_as_int(v));
+}
+
+__device__ __forceinline__ uint64_t vmd_mix64(uint64_t z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__device__ __forceinline__ float vmd_synth_uniform(uint64_t seed, uint32_t stream, uint32_t frame, uint32_t atom) {
+    const uint64_t key = vmd_mix64(seed * 0x9E3779B97F4A7C15ull + (uint64_t)stream);
+    const uint64_t h = vmd_mix64(key ^ (((uint64_t)frame << 32) | (uint64_t)atom));
+    return (float)(uint32_t)(h >> 40) * (1.0f / 16777216.0f);
+}
+
+struct vmd_synth_params_t {
+    float* xyz; size_t frame_stride; size_t row_stride; int B; uint32_t frame0;
+    uint64_t seed; uint32_t n_atoms; uint32_t n_blob; float L; float sigma;
+};
+
+// oracle S9 twin: integer RNG, explicit rounding steps -> bit-identical to vo_synth_frame
+__global__ __launch_bounds__(256) void k_synth(vmd_synth_params_t p) {
+    const uint32_t i = p.n_blob + blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.y;
+    if (i >= p.n_atoms) return;
+    const uint32_t frame = p.frame0 + (uint32_t)b;
+    const float sig = (float)((double)p.sigma * sqrt((double)frame));
+    const uint32_t w = i - p.n_blob;
+    const uint32_t mol = w / 3u, site = w % 3u;
+    float* f = p.xyz + (size_t)b * p.frame_stride;
+    for (uint32_t c = 0; c < 3; ++c) {
+        float p0 = vmd_synth_uniform(p.seed, 1u + c, 0u, mol) * p.L;
+        if (site) {
+            const float off = (vmd_synth_uniform(p.seed, 4u + 3u * (site - 1u) + c, 0u, mol) - 0.5f) * 1.1f;
+            p0 = p0 + off;
+        }
+        const float g = (((vmd_synth_uniform(p.seed, 10u + c, frame, i) + vmd_synth_uniform(p.seed, 13u + c, frame, i)) +
+                          (vmd_synth_uniform(p.seed, 16u + c, frame, i) + vmd_synth_uniform(p.seed, 19u + c, frame, i))) - 2.0f) * 1.7320508f;
+        const float t = sig * g;
+        f[(size_t)c * p.row_stride + i] = vmd_wrap(p0 + t, p.L);
+    }
+}
+
+// ================================================================================================ C ABI
+
+#define VMD_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)
+
+extern "C" int vmd_hip_cells_build(void* stream, const float* xyz, size_t frame_stride, size_t row_stride,
+                                   const float* boxes, int B, const int32_t* sel, int nsel, int nsel_pad,
+                                   vmd_grid_t grid, uint32_t* cell_count, uint32_t* rank, uint32_t* cell_start, float* sorted) {
+    hipStream_t s = (hipStream_t)stream;
+    if (B <= 0 || nsel <= 0) return 0;
+    hipError_t e = hipMemsetAsync(cell_count, 0, sizeof(uint32_t) * (size_t)B * (grid.ncell + 1), s);
+    if (e != hipSuccess) return (int)e;
+    vmd_cells_params_t p{xyz, frame_stride, row_stride, boxes, sel, nsel, nsel_pad, grid, cell_count, rank, cell_start, sorted};
+    const dim3 g((nsel + 255) / 256, B);
+    hipLaunchKernelGGL(k_cells_count, g, dim3(256), 0, s, p);
+    VMD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_cells_scan, dim3(B), dim3(1024), 0, s, (const uint32_t*)cell_count, cell_start, (int)grid.ncell);
+    VMD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_cells_scatter, g, dim3(256), 0, s, p);
+    VMD_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int vmd_hip_rdf_num_blocks(void) { return 1024; }
+
+extern "C" int vmd_hip_rdf_pencil(void* stream, const float* sorted_ref, const uint32_t* cell_start_ref, int nref, int nref_pad,
+                                  const float* sorted_tgt, const uint32_t* cell_start_tgt, int ntgt, int ntgt_pad,
+                                  const float* boxes, int B, vmd_grid_t grid, float rmin, float rmax, int nbins,
+                                  int same_set, int variant, uint64_t* partial, uint64_t* counts) {
+    hipStream_t s = (hipStream_t)stream;
+    if (nbins <= 0 || nbins > VMD_MAX_BINS) return (int)hipErrorInvalidValue;
+    if (B <= 0 || nref <= 0 || ntgt <= 0) return 0;
+    vmd_pair_params_t p;
+    p.sref = sorted_ref; p.cs_ref = cell_start_ref; p.nref_pad = nref_pad;
+    p.stgt = sorted_tgt; p.cs_tgt = cell_start_tgt; p.ntgt_pad = ntgt_pad;
+    p.boxes = boxes; p.B = B; p.grid = grid;
+    p.bin.rmin = rmin; p.bin.rmax = rmax; p.bin.inv_range = 1.0f / (rmax - rmin); p.bin.fnbins = (float)nbins; p.bin.nbins = nbins;
+    p.r2_up = nextafterf(rmax * rmax, 3.0e38f) * 1.0001f;
+    p.rpad = rmax * 1.0001f + 1.0e-4f;
+    p.partial = partial;
+    const int nitems = B * grid.ny * grid.nz;
+    int nblocks = (nitems + 3) / 4;
+    if (nblocks > vmd_hip_rdf_num_blocks()) nblocks = vmd_hip_rdf_num_blocks();
+    const dim3 g(nblocks), blk(256);
+    if (same_set) {
+        if (variant == 1) hipLaunchKernelGGL((k_rdf_pencil<1, true>), g, blk, 0, s, p);
+        else hipLaunchKernelGGL((k_rdf_pencil<0, true>), g, blk, 0, s, p);
+    } else {
+        if (variant == 1) hipLaunchKernelGGL((k_rdf_pencil<1, false>), g, blk, 0, s, p);
+        else hipLaunchKernelGGL((k_rdf_pencil<0, false>), g, blk, 0, s, p);
+    }
+    VMD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_hist_reduce, dim3((nbins + 255) / 256), dim3(256), 0, s, (const uint64_t*)partial, nblocks * 4, nbins, counts);
+    VMD_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int vmd_hip_rdf_brute(void* stream, const float* xyz, size_t frame_stride, size_t row_stride,
+                                 const float* boxes, uint32_t pbc_flags, int B,
+                                 const int32_t* ref, int nref, const int32_t* tgt, int ntgt,
+                                 float rmin, float rmax, int nbins, uint64_t* counts) {
+    hipStream_t s = (hipStream_t)stream;
+    if (nbins <= 0 || nbins > VMD_MAX_BINS) return (int)hipErrorInvalidValue;
+    if (B <= 0 || nref <= 0 || ntgt <= 0) return 0;
+    vmd_brute_params_t p{xyz, frame_stride, row_stride, boxes, pbc_flags, B, ref, nref, tgt, ntgt, {}, counts};
+    p.bin.rmin = rmin; p.bin.rmax = rmax; p.bin.inv_range = 1.0f / (rmax - rmin); p.bin.fnbins = (float)nbins; p.bin.nbins = nbins;
+    hipLaunchKernelGGL(k_rdf_brute, dim3((nref + 255) / 256, B), dim3(256), 0, s, p);
+    VMD_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int vmd_hip_sdf_align(void* stream, const float* xyz, size_t frame_stride, size_t row_stride,
+                                 const float* boxes, uint32_t pbc_flags, int B,
+                                 const int32_t* structs, const float* mass, int K, int m, const double* ref_pose,
+                                 float* R32, float* c32, double* M64) {
+    hipStream_t s = (hipStream_t)stream;
+    if (B <= 0 || K <= 0 || m <= 0) return 0;
+    vmd_align_params_t p{xyz, frame_stride, row_stride, boxes, pbc_flags, B, structs, mass, K, m, ref_pose, R32, c32, M64};
+    hipLaunchKernelGGL(k_sdf_align, dim3((B * K + 63) / 64), dim3(64), 0, s, p);
+    VMD_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int vmd_hip_sdf_ref_pose(void* stream, const float* xyz, size_t row_stride, const float* box, uint32_t pbc_flags,
+                                    const int32_t* struct0, const float* mass0, int m, double* ref_pose) {
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_sdf_ref_pose, dim3(1), dim3(64), 0, s, xyz, row_stride, box, pbc_flags, struct0, mass0, m, ref_pose);
+    VMD_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int vmd_hip_sdf_scatter(void* stream, const float* xyz, size_t frame_stride, size_t row_stride,
+                                   const float* boxes, uint32_t pbc_flags, int B,
+                                   const int32_t* structs, int K, int m, const float* R32, const float* c32,
+                                   const int32_t* tgt, int ntgt, float extent, int dim, uint64_t* volume) {
+    hipStream_t s = (hipStream_t)stream;
+    if (B <= 0 || K <= 0 || ntgt <= 0) return 0;
+    vmd_scatter_params_t p{xyz, frame_stride, row_stride, boxes, pbc_flags, B, structs, K, m, R32, c32, tgt, ntgt, extent, dim,
+                           (unsigned long long*)volume};
+    hipLaunchKernelGGL(k_sdf_scatter, dim3((ntgt + 255) / 256, B), dim3(256), 0, s, p);
+    VMD_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int vmd_hip_distance(void* stream, const float* xyz, size_t frame_stride, size_t row_stride,
+                                const float* boxes, uint32_t pbc_flags, int B, int kind,
+                                const int32_t* a, const float* mass_a, int na, const int32_t* b, const float* mass_b, int nb,
+                                float* out) {
+    hipStream_t s = (hipStream_t)stream;
+    if (B <= 0 || na <= 0 || nb <= 0) return 0;
+    vmd_dist_params_t p{xyz, frame_stride, row_stride, boxes, pbc_flags, B, a, mass_a, na, b, mass_b, nb, out};
+    switch (kind) {
+    case 0: hipLaunchKernelGGL(k_distance_com, dim3((B + 63) / 64), dim3(64), 0, s, p); break;
+    case 1: hipLaunchKernelGGL((k_distance_minmax<false>), dim3(B), dim3(256), 0, s, p); break;
+    case 2: hipLaunchKernelGGL((k_distance_minmax<true>), dim3(B), dim3(256), 0, s, p); break;
+    case 3: {
+        const long long npairs = (long long)na * nb;
+        hipLaunchKernelGGL(k_distance_pair, dim3((unsigned)((npairs + 255) / 256), B), dim3(256), 0, s, p);
+        break;
+    }
+    default: return (int)hipErrorInvalidValue;
+    }
+    VMD_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int vmd_hip_counts_to_float(void* stream, const uint64_t* counts, size_t n, float* values, float* max_out) {
+    hipStream_t s = (hipStream_t)stream;
+    if (n == 0) return 0;
+    if (max_out) {
+        hipError_t e = hipMemsetAsync(max_out, 0, sizeof(float), s);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(k_counts_to_float, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, counts, n, values, (unsigned*)max_out);
+    VMD_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int vmd_hip_synth_frames(void* stream, float* xyz, size_t frame_stride, size_t row_stride, int B, uint32_t frame0,
+                                    uint64_t seed, uint32_t n_atoms, uint32_t n_blob, float L, float sigma) {
+    hipStream_t s = (hipStream_t)stream;
+    if (B <= 0 || n_atoms <= n_blob) return 0;
+    vmd_synth_params_t p{xyz, frame_stride, row_stride, B, frame0, seed, n_atoms, n_blob, L, sigma};
+    hipLaunchKernelGGL(k_synth, dim3((n_atoms - n_blob + 255) / 256, B), dim3(256), 0, s, p);
+    VMD_LAUNCH_CHECK();
+    return 0;
+}

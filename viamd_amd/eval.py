@@ -1,0 +1,282 @@
+"""Host-side mirror of the md_script evaluation surface VIAMD uses, over the C ABI.
+
+Names follow the reference: ScriptIR ~ md_script_ir_t, ScriptEval ~ md_script_eval_t (create / clear_data /
+frame_range / interrupt / property_data / frame_mask), see /root/reference/src/main.cpp:951-1039, :1286, :1513.
+Everything here is plumbing: the arithmetic runs in the HIP kernels behind libviamd_amd.so.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+
+def _idx(a):
+    a = np.ascontiguousarray(a, dtype=np.int32).reshape(-1)
+    return a, a.ctypes.data_as(L.c_int32_p)
+
+
+def make_unitcell(box, flags=L.PBC_ALL):
+    """box: None (no cell), scalar (cubic) or (x,y,z)."""
+    if box is None:
+        return L.Unitcell(0, 0, 0, 0, 0, 0, 0)
+    if np.isscalar(box):
+        box = (box, box, box)
+    return L.Unitcell(float(box[0]), float(box[1]), float(box[2]), 0, 0, 0, flags)
+
+
+class VmdError(RuntimeError):
+    pass
+
+
+class MolSystem:
+    """The slice of md_system_t the evaluator reads: atom count, masses, unit cell (src/main.cpp:642)."""
+
+    def __init__(self, num_atoms, mass=None, unitcell=None):
+        self.num_atoms = int(num_atoms)
+        self.mass = np.ascontiguousarray(mass if mass is not None else np.ones(num_atoms), dtype=np.float32)
+        assert self.mass.size == self.num_atoms
+        self.c = L.System()
+        self.c.atom_count = self.num_atoms
+        self.c.mass = self.mass.ctypes.data_as(L.c_float_p)
+        self.c.unitcell = unitcell if unitcell is not None else make_unitcell(None)
+
+
+class ScriptIR:
+    """Property descriptors (md_script_ir_t stand-in)."""
+
+    def __init__(self, lib=None):
+        self.lib = lib or L.default_lib()
+        self.h = self.lib.vmd_ir_create()
+        if not self.h:
+            raise VmdError("vmd_ir_create failed")
+
+    def close(self):
+        if self.h:
+            self.lib.vmd_ir_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, ok):
+        if not ok:
+            raise VmdError(self.lib.last_error())
+
+    def add_rdf(self, name, ref, target, cutoff, rmin=0.0):
+        """`name = rdf(ref, target, cutoff)` (src/main.cpp:528); cutoff may be (rmin, rmax)."""
+        if not np.isscalar(cutoff):
+            rmin, cutoff = cutoff
+        r, rp = _idx(ref)
+        t, tp = _idx(target)
+        self._check(self.lib.vmd_ir_add_rdf(self.h, name.encode(), rp, r.size, tp, t.size, float(rmin), float(cutoff)))
+
+    def add_sdf(self, name, structures, target, cutoff):
+        """`name = sdf(structures, target, cutoff)`; structures: [K, m] atom indices."""
+        s = np.ascontiguousarray(structures, dtype=np.int32)
+        if s.ndim != 2:
+            raise ValueError("structures must be a [K, m] index array")
+        t, tp = _idx(target)
+        self._check(self.lib.vmd_ir_add_sdf(self.h, name.encode(), s.ctypes.data_as(L.c_int32_p), s.shape[0], s.shape[1],
+                                            tp, t.size, float(cutoff)))
+
+    def add_distance(self, name, a, b, kind=L.DIST_COM):
+        """`name = distance|distance_min|distance_max|distance_pair(a, b)` (src/main.cpp:2817-2858)."""
+        a_, ap = _idx(a)
+        b_, bp = _idx(b)
+        self._check(self.lib.vmd_ir_add_distance(self.h, name.encode(), int(kind), ap, a_.size, bp, b_.size))
+
+    def valid(self):
+        return bool(self.lib.vmd_ir_valid(self.h))
+
+    def fingerprint(self):
+        return int(self.lib.vmd_ir_fingerprint(self.h))
+
+    def property_count(self):
+        return int(self.lib.vmd_ir_property_count(self.h))
+
+    def property_names(self):
+        n = self.property_count()
+        p = self.lib.vmd_ir_property_names(self.h)
+        return [p[i].decode() for i in range(n)]
+
+    def property_flags(self, name):
+        return int(self.lib.vmd_ir_property_flags(self.h, name.encode()))
+
+
+class PropertyDataView:
+    """Zero-copy numpy views of one md_script_property_data_t."""
+
+    def __init__(self, c):
+        self.c = c  # ctypes PropertyData (owned by the eval)
+
+    @property
+    def dim(self):
+        return tuple(self.c.dim)
+
+    @property
+    def fingerprint(self):
+        return int(self.c.fingerprint)
+
+    def _arr(self, ptr, n, dtype):
+        if not ptr or n == 0:
+            return None
+        return np.ctypeslib.as_array(ptr, shape=(n,)).view(dtype)
+
+    @property
+    def values(self):
+        return self._arr(self.c.values, self.c.num_values, np.float32)
+
+    @property
+    def weights(self):
+        return self._arr(self.c.weights, self.c.dim[2], np.float32) if self.c.weights else None
+
+    @property
+    def counts(self):
+        if not self.c.counts:
+            return None
+        n = self.c.dim[2] if self.c.weights else self.c.dim[1] * self.c.dim[2] * self.c.dim[3]
+        return self._arr(self.c.counts, n, np.uint64)
+
+    @property
+    def weights64(self):
+        return self._arr(self.c.weights64, self.c.dim[2], np.float64) if self.c.weights64 else None
+
+    @property
+    def min_range(self):
+        return tuple(self.c.min_range)
+
+    @property
+    def max_range(self):
+        return tuple(self.c.max_range)
+
+    @property
+    def max_value(self):
+        return float(self.c.max_value)
+
+    @property
+    def min_value(self):
+        return float(self.c.min_value)
+
+    @property
+    def aggregate(self):
+        if not self.c.aggregate:
+            return None
+        a = self.c.aggregate.contents
+        n = a.num_values
+        return {"mean": np.ctypeslib.as_array(a.population_mean, shape=(n,)),
+                "var": np.ctypeslib.as_array(a.population_var, shape=(n,)),
+                "ext": np.ctypeslib.as_array(a.population_ext, shape=(n * 2,)).reshape(n, 2)}
+
+
+class ScriptEval:
+    """md_script_eval_t stand-in: owns the accumulators, evaluates frame ranges on the GPU."""
+
+    def __init__(self, num_frames, ir):
+        self.lib = ir.lib
+        self.ir = ir
+        self.h = self.lib.vmd_eval_create(int(num_frames), ir.h)
+        if not self.h:
+            raise VmdError(self.lib.last_error())
+
+    def close(self):
+        if self.h:
+            self.lib.vmd_eval_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def clear_data(self):
+        self.lib.vmd_eval_clear_data(self.h)
+
+    def interrupt(self):
+        self.lib.vmd_eval_interrupt(self.h)
+
+    def ir_fingerprint(self):
+        return int(self.lib.vmd_eval_ir_fingerprint(self.h))
+
+    def frame_range(self, sys, traj, frame_beg, frame_end):
+        """md_script_eval_frame_range(eval, ir, &sys, traj, beg, end); False on interrupt; raises on error."""
+        sysp = C.byref(sys.c) if sys is not None else None
+        ok = self.lib.vmd_eval_frame_range(self.h, self.ir.h, sysp, traj.interface(), int(frame_beg), int(frame_end))
+        if not ok:
+            if self.lib.vmd_eval_frames_done(self.h) < self.num_frames() and self._interrupted():
+                return False
+            raise VmdError(self.lib.last_error())
+        return True
+
+    def _interrupted(self):
+        # an interrupt leaves no error message behind
+        return True if not self.lib.last_error() else False
+
+    def property_data(self, name):
+        p = self.lib.vmd_eval_property_data(self.h, name.encode())
+        if not p:
+            return None
+        return PropertyDataView(p.contents)
+
+    def num_frames(self):
+        return int(self.lib.vmd_eval_num_frames(self.h))
+
+    def frames_done(self):
+        return int(self.lib.vmd_eval_frames_done(self.h))
+
+    def frame_mask(self):
+        n = self.num_frames()
+        return np.ctypeslib.as_array(self.lib.vmd_eval_frame_mask(self.h), shape=(n,))
+
+    def set_frame_mask(self, mask):
+        m = np.ascontiguousarray(mask, dtype=np.uint8)
+        self.lib.vmd_eval_set_frame_mask(self.h, m.ctypes.data_as(L.c_uint8_p), m.size)
+
+    def finalize(self):
+        if not self.lib.vmd_eval_finalize(self.h):
+            raise VmdError(self.lib.last_error())
+
+    def accum_views(self):
+        n = self.lib.vmd_eval_accum_views(self.h, None, 0)
+        arr = (L.AccumView * n)()
+        self.lib.vmd_eval_accum_views(self.h, arr, n)
+        return list(arr)
+
+    def sdf_matrices(self, name, sys, traj, frame):
+        """vis.sdf.matrices / vis.sdf.extent of md_script_vis_eval_payload (density_volume.cpp:183-204)."""
+        K = C.c_size_t(0)
+        ext = C.c_float(0)
+        sysp = C.byref(sys.c) if sys is not None else None
+        if not self.lib.vmd_eval_sdf_matrices(self.h, name.encode(), sysp, traj.interface(), int(frame), None, C.byref(K), C.byref(ext)):
+            raise VmdError(self.lib.last_error())
+        mats = np.zeros((K.value, 16), np.float32)
+        if not self.lib.vmd_eval_sdf_matrices(self.h, name.encode(), sysp, traj.interface(), int(frame),
+                                              mats.ctypes.data_as(L.c_float_p), C.byref(K), C.byref(ext)):
+            raise VmdError(self.lib.last_error())
+        # column-major mat4 -> numpy [K,4,4] with M[k] @ [x,y,z,1]
+        return mats.reshape(-1, 4, 4).transpose(0, 2, 1).copy(), float(ext.value)
+
+
+def downsample_histogram(values, weights, num_bins, lib=None):
+    """What VIAMD plots for a distribution property: g = sum(values)/sum(weights) per display bin (src/main.cpp:232-250)."""
+    lib = lib or L.default_lib()
+    v = np.ascontiguousarray(values, np.float32)
+    w = None if weights is None else np.ascontiguousarray(weights, np.float32)
+    out = np.zeros(num_bins, np.float32)
+    lib.vmd_downsample_histogram(out.ctypes.data_as(L.c_float_p), num_bins, v.ctypes.data_as(L.c_float_p),
+                                 w.ctypes.data_as(L.c_float_p) if w is not None else None, v.size)
+    return out
+
+
+def compute_histogram_masked(values, dim, mask, num_bins, rmin, rmax, aggregate=False, lib=None):
+    lib = lib or L.default_lib()
+    v = np.ascontiguousarray(values, np.float32)
+    m = np.ascontiguousarray(mask, np.uint8)
+    out = np.zeros((1 if aggregate else dim) * num_bins, np.float32)
+    lib.vmd_compute_histogram_masked(out.ctypes.data_as(L.c_float_p), num_bins, float(rmin), float(rmax),
+                                     v.ctypes.data_as(L.c_float_p), dim, m.ctypes.data_as(L.c_uint8_p), m.size, bool(aggregate))
+    return out
