@@ -1,0 +1,188 @@
+"""Shared parity scenarios: the same checks run against the SIMT emulator build (CPU, small sizes, `-m "not gpu"`)
+and against the hipcc-built product library on a real MI355X (`-m gpu`).  The checker is always the oracle."""
+import numpy as np
+
+import viamd_amd as V
+from viamd_amd import _lib as L
+
+
+def water_box(O, seed, n_atoms, box, frames, sigma=0.05):
+    """[F,3,N] seeded synthetic O,H,H box (oracle S9)."""
+    return np.stack([O.synth_frame(seed, n_atoms, box, sigma, f) for f in range(frames)])
+
+
+def oxygen(n_atoms):
+    return np.arange(0, n_atoms, 3, dtype=np.int32)
+
+
+def hydrogen(n_atoms):
+    return np.array([i for i in range(n_atoms) if i % 3], dtype=np.int32)
+
+
+def cell_pair(O, box, flags=L.PBC_ALL):
+    """(oracle cell, product unitcell) for the same box"""
+    return O.make_cell(box, flags if box is not None else 0), V.make_unitcell(box, flags)
+
+
+def oracle_rdf(O, coords, ocell, ref, tgt, rmin, rmax, frames=None, method="cells"):
+    counts = np.zeros(1024, np.uint64)
+    weights = np.zeros(1024, np.float64)
+    frames = range(coords.shape[0]) if frames is None else frames
+    for f in frames:
+        O.rdf_frame(coords[f, 0], coords[f, 1], coords[f, 2], ocell, ref, tgt, rmin, rmax, counts=counts, method=method)
+        O.rdf_weights(ocell, len(ref), len(tgt), rmin, rmax, weights=weights)
+    return counts, weights
+
+
+def make_traj(lib, coords, vcell, device):
+    if device:
+        t = V.DeviceTrajectory(coords.shape[0], coords.shape[2], lib=lib)
+        t.upload(coords, vcell)
+        return t
+    return V.HostTrajectory(coords, vcell)
+
+
+def check_rdf(lib, O, coords, box, props, flags=L.PBC_ALL, device=False, ranges=None, variant=0, oracle_method="cells"):
+    """props: list of (name, ref, tgt, rmin, rmax).  Bit-exact counts, 1e-12 weights, 1e-5 normalised g(r)."""
+    ocell, vcell = cell_pair(O, box, flags)
+    F, _, N = coords.shape
+    ir = V.ScriptIR(lib)
+    for name, ref, tgt, rmin, rmax in props:
+        ir.add_rdf(name, ref, tgt, (rmin, rmax))
+    ev = V.ScriptEval(F, ir)
+    traj = make_traj(lib, coords, vcell, device)
+    sysm = V.MolSystem(N, unitcell=vcell)
+    old = lib.vmd_set_option(b"rdf_variant", variant)
+    try:
+        for beg, end in (ranges or [(0, F)]):
+            assert ev.frame_range(sysm, traj, beg, end)
+    finally:
+        lib.vmd_set_option(b"rdf_variant", old)
+    assert ev.frame_mask().all() and ev.frames_done() == F
+    for name, ref, tgt, rmin, rmax in props:
+        pd = ev.property_data(name)
+        counts, weights = oracle_rdf(O, coords, ocell, ref, tgt, rmin, rmax, method=oracle_method)
+        assert pd.dim[2] == 1024
+        np.testing.assert_array_equal(pd.counts, counts, err_msg=f"{name}: integer histogram differs from the oracle")
+        np.testing.assert_allclose(pd.weights64, weights, rtol=1e-12)
+        np.testing.assert_array_equal(pd.values, counts.astype(np.float32))
+        g_dev = V.downsample_histogram(pd.values, pd.weights, 128, lib=lib)
+        g_ref = O.downsample_histogram(counts.astype(np.float32), weights.astype(np.float32), 128)
+        np.testing.assert_allclose(g_dev, g_ref, rtol=1e-5, atol=0)   # tolerance stated by BASELINE.json north_star
+        assert pd.min_range[0] == np.float32(rmin) and pd.max_range[0] == np.float32(rmax)
+    return ev
+
+
+# ---- SDF scenario: K rigid-ish structures of m atoms tumbling in a water box -------------------------------------------
+
+def sdf_system(O, seed, n_water_atoms, box, frames, K=4, m=6):
+    """Returns coords [F,3,N], structures [K,m], masses [N].  Atoms [0, K*m) are the structures, the rest water."""
+    rng = np.random.default_rng(seed)
+    n_s = K * m
+    N = n_s + n_water_atoms
+    water = np.stack([O.synth_frame(seed, N, box, 0.05, f, n_blob=n_s) for f in range(frames)])  # [F,3,N], blob rows zero
+    template = rng.normal(0, 1.6, (m, 3))
+    centers = rng.uniform(0, box, (K, 3))
+    coords = water.copy()
+
+    def rot(axis, ang):
+        axis = axis / np.linalg.norm(axis)
+        Kx = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+        return np.eye(3) + np.sin(ang) * Kx + (1 - np.cos(ang)) * Kx @ Kx
+
+    Rk = [rot(rng.normal(size=3), rng.uniform(0, np.pi)) for _ in range(K)]
+    for f in range(frames):
+        for k in range(K):
+            Rk[k] = rot(rng.normal(size=3), np.deg2rad(4.0)) @ Rk[k]
+            centers[k] += rng.normal(0, 0.3, 3)
+            pts = template @ Rk[k].T + centers[k] + rng.normal(0, 0.05, (m, 3))
+            pts = np.mod(pts, box)     # wrapped: structures straddle the periodic boundary now and then
+            coords[f, :, k * m:(k + 1) * m] = pts.T.astype(np.float32)
+    structures = np.arange(n_s, dtype=np.int32).reshape(K, m)
+    mass = np.ones(N, np.float32)
+    mass[:n_s] = rng.choice([12.011, 14.007, 15.999, 1.008], n_s).astype(np.float32)
+    w = np.arange(N - n_s)
+    mass[n_s:] = np.where(w % 3 == 0, 15.999, 1.008).astype(np.float32)
+    return coords, structures, mass
+
+
+def oracle_sdf(O, coords, ocell, structures, mass, tgt, cutoff, dim=128):
+    K, m = structures.shape
+    smass = mass[structures]
+    ref_pose = O.sdf_ref_pose(coords[0, 0], coords[0, 1], coords[0, 2], ocell, structures[0], smass[0])
+    vol = np.zeros(dim ** 3, np.uint64)
+    mats = []
+    for f in range(coords.shape[0]):
+        M, R32, c32 = O.sdf_frame_align(coords[f, 0], coords[f, 1], coords[f, 2], ocell, structures, smass, ref_pose)
+        O.sdf_frame_scatter(coords[f, 0], coords[f, 1], coords[f, 2], ocell, structures, R32, c32, tgt, cutoff, dim, vol)
+        mats.append(M)
+    return vol, np.stack(mats)
+
+
+def check_sdf(lib, O, coords, box, structures, mass, tgt, cutoff, flags=L.PBC_ALL, device=False, ranges=None):
+    ocell, vcell = cell_pair(O, box, flags)
+    F, _, N = coords.shape
+    ir = V.ScriptIR(lib)
+    ir.add_sdf("v", structures, tgt, cutoff)
+    ev = V.ScriptEval(F, ir)
+    traj = make_traj(lib, coords, vcell, device)
+    sysm = V.MolSystem(N, mass=mass, unitcell=vcell)
+    for beg, end in (ranges or [(0, F)]):
+        assert ev.frame_range(sysm, traj, beg, end)
+    pd = ev.property_data("v")
+    vol, mats = oracle_sdf(O, coords, ocell, structures, mass, tgt, cutoff)
+    assert pd.dim[1:] == (128, 128, 128)
+    np.testing.assert_array_equal(pd.counts, vol, err_msg="SDF voxel counts differ from the oracle")
+    np.testing.assert_array_equal(pd.values, vol.astype(np.float32))
+    assert pd.max_value == float(vol.max())
+    assert vol.sum() > 0
+    # vis payload: world->reference matrices of a frame (density_volume.cpp:263)
+    f = F - 1
+    M4, ext = ev.sdf_matrices("v", sysm, traj, f)
+    assert ext == np.float32(cutoff)
+    np.testing.assert_allclose(M4[:, :3, :], mats[f].astype(np.float32), rtol=0, atol=0)
+    return ev, vol
+
+
+def oracle_distance(O, coords, ocell, mass, a, b, kind):
+    F = coords.shape[0]
+    dim1 = len(a) * len(b) if kind == L.DIST_PAIR else 1
+    out = np.zeros((F, dim1), np.float32)
+    for f in range(F):
+        x, y, z = coords[f]
+        if kind == L.DIST_COM:
+            out[f, 0] = O.distance_com(x, y, z, ocell, a, mass[a], b, mass[b])
+        elif kind == L.DIST_MIN:
+            out[f, 0] = O.distance_minmax(x, y, z, ocell, a, b, "min")
+        elif kind == L.DIST_MAX:
+            out[f, 0] = O.distance_minmax(x, y, z, ocell, a, b, "max")
+        else:
+            out[f] = O.distance_pair(x, y, z, ocell, a, b)
+    return out
+
+
+def check_distances(lib, O, coords, box, mass, specs, flags=L.PBC_ALL, device=False, ranges=None):
+    """specs: list of (name, a, b, kind).  Temporal rows must equal the oracle bit for bit (fp32)."""
+    ocell, vcell = cell_pair(O, box, flags)
+    F, _, N = coords.shape
+    ir = V.ScriptIR(lib)
+    for name, a, b, kind in specs:
+        ir.add_distance(name, a, b, kind)
+    ev = V.ScriptEval(F, ir)
+    traj = make_traj(lib, coords, vcell, device)
+    sysm = V.MolSystem(N, mass=mass, unitcell=vcell)
+    for beg, end in (ranges or [(0, F)]):
+        assert ev.frame_range(sysm, traj, beg, end)
+    for name, a, b, kind in specs:
+        pd = ev.property_data(name)
+        ref = oracle_distance(O, coords, ocell, mass, np.asarray(a, np.int32), np.asarray(b, np.int32), kind)
+        assert pd.dim[0] == F and pd.dim[1] == ref.shape[1]
+        got = pd.values.reshape(F, -1)
+        np.testing.assert_array_equal(got, ref, err_msg=f"{name}: temporal values differ from the oracle")
+        if ref.shape[1] > 1:
+            agg = pd.aggregate
+            np.testing.assert_allclose(agg["mean"], ref.mean(axis=1), rtol=1e-6)
+            np.testing.assert_array_equal(agg["ext"][:, 0], ref.min(axis=1))
+            np.testing.assert_array_equal(agg["ext"][:, 1], ref.max(axis=1))
+        assert pd.min_range[0] == ref.min() and pd.max_range[0] == ref.max()
+    return ev

@@ -1,0 +1,58 @@
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    """CPU restatement (test infrastructure, parity unpinned — oracle/SPEC.md)."""
+    from oracle import oracle as O
+    O.build()
+    O.lib()
+    return O
+
+
+EMU_DIR = os.path.join(ROOT, "tests", "emu")
+EMU_LIB = os.path.join(EMU_DIR, "libviamd_emu.so")
+EMU_SOURCES = [os.path.join(ROOT, "viamd_amd", "csrc", "vmd_kernels.hip"),
+               os.path.join(ROOT, "viamd_amd", "csrc", "vmd_eval.cpp"),
+               os.path.join(EMU_DIR, "emu.cpp")]
+EMU_DEPS = EMU_SOURCES + [os.path.join(EMU_DIR, "hip", "hip_runtime.h"),
+                          os.path.join(ROOT, "include", "vmd_eval.h"), os.path.join(ROOT, "include", "vmd_hip.h")]
+
+
+def build_emu():
+    """g++ build of the *same* kernel + host sources against the test-only SIMT emulator (tests/emu)."""
+    if os.path.exists(EMU_LIB) and all(os.path.getmtime(EMU_LIB) >= os.path.getmtime(s) for s in EMU_DEPS):
+        return EMU_LIB
+    cmd = ["g++", "-O2", "-g", "-shared", "-fPIC", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-mavx2", "-mfma",
+           "-I" + EMU_DIR, "-I" + os.path.join(ROOT, "include"), "-x", "c++"] + EMU_SOURCES + ["-o", EMU_LIB]
+    subprocess.check_call(cmd)
+    return EMU_LIB
+
+
+@pytest.fixture(scope="session")
+def emu_lib():
+    """Kernels + host code compiled for the CPU SIMT emulator: logic checks only, never the product path."""
+    from viamd_amd import VmdLib
+    return VmdLib(build_emu())
+
+
+@pytest.fixture(scope="session")
+def gpu_lib():
+    """The product: hipcc-built libviamd_amd.so on a real GPU.  Fails (not skips) when the library or GPU is missing."""
+    from viamd_amd import default_lib
+    lib = default_lib()
+    assert lib.vmd_device_count() > 0, "no HIP device visible: -m gpu tests must run on the MI355X box"
+    return lib

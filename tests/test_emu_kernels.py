@@ -1,0 +1,111 @@
+"""Kernel + host logic on the CPU SIMT emulator (tests/emu) against the oracle — small sizes, no GPU needed.
+
+These run the *same* .hip/.cpp sources as the product, compiled by g++ against a fake hip_runtime.h; they prove the
+indexing / segment enumeration / queue machinery / batching logic, not device numerics (that is `-m gpu`)."""
+import numpy as np
+import pytest
+
+import cases
+from viamd_amd import _lib as L
+
+
+@pytest.fixture(scope="module")
+def box3k(oracle):
+    return cases.water_box(oracle, 7, 3000, 60.0, 3)
+
+
+def test_rdf_same_set_half_shell(emu_lib, oracle, box3k):
+    o = cases.oxygen(3000)
+    cases.check_rdf(emu_lib, oracle, box3k, 60.0, [("goo", o, o, 0.0, 12.0)])
+
+
+def test_rdf_two_sets_full_shell_and_range(emu_lib, oracle, box3k):
+    o, h = cases.oxygen(3000), cases.hydrogen(3000)
+    cases.check_rdf(emu_lib, oracle, box3k[:2], 60.0, [("goh", o, h, 0.0, 10.0), ("ring", h, o, 2.5, 9.0)])
+
+
+def test_rdf_inline_variant_matches(emu_lib, oracle, box3k):
+    o = cases.oxygen(3000)
+    cases.check_rdf(emu_lib, oracle, box3k[:1], 60.0, [("goo", o, o, 0.0, 12.0)], variant=1)
+
+
+def test_rdf_two_pencils_per_axis(emu_lib, oracle):
+    # L = 26, rc = 12 -> ny = nz = 2: both neighbour offsets map to the same pencil with different images
+    c = cases.water_box(oracle, 11, 1500, 26.0, 2)
+    o = cases.oxygen(1500)
+    cases.check_rdf(emu_lib, oracle, c, 26.0, [("goo", o, o, 0.0, 12.0), ("gall", o, np.arange(1500), 0.0, 12.0)],
+                    oracle_method="brute")
+
+
+def test_rdf_noncubic_box_and_unwrapped_input(emu_lib, oracle):
+    rng = np.random.default_rng(5)
+    box = (50.0, 38.0, 64.0)
+    c = (rng.uniform(-1.0, 2.0, (2, 3, 2400)) * np.array(box)[None, :, None]).astype(np.float32)  # outside the cell too
+    a = np.arange(0, 2400, 2)
+    cases.check_rdf(emu_lib, oracle, c, box, [("g", a, a, 0.0, 9.0)])
+
+
+def test_rdf_brute_nonperiodic_and_large_cutoff(emu_lib, oracle):
+    rng = np.random.default_rng(3)
+    c = rng.uniform(0, 20, (3, 3, 300)).astype(np.float32)
+    a, b = np.arange(0, 300, 2), np.arange(300)
+    cases.check_rdf(emu_lib, oracle, c, None, [("g", a, b, 0.0, 10.0)], oracle_method="brute")          # no cell (C1-like)
+    cases.check_rdf(emu_lib, oracle, c, 20.0, [("g", a, a, 0.0, 10.0)], oracle_method="brute")          # rc = L/2 -> brute + PBC
+    cases.check_rdf(emu_lib, oracle, c, 20.0, [("g", a, b, 1.0, 6.0)], flags=3,
+                    oracle_method="brute")                                                               # slab periodicity
+
+
+def test_rdf_sharding_and_device_trajectory(emu_lib, oracle, box3k):
+    o = cases.oxygen(3000)
+    cases.check_rdf(emu_lib, oracle, box3k, 60.0, [("goo", o, o, 0.0, 12.0)], device=True, ranges=[(2, 3), (0, 1), (1, 2)])
+
+
+def test_sdf_volume_and_matrices(emu_lib, oracle):
+    coords, structures, mass = cases.sdf_system(oracle, 4, 1500, 40.0, 3)
+    n_s = structures.size
+    tgt = np.arange(n_s, coords.shape[2], 3, dtype=np.int32)                # water oxygens
+    cases.check_sdf(emu_lib, oracle, coords, 40.0, structures, mass, tgt, 10.0)
+    # targets that include the structures' own atoms exercise the exclusion rule (SPEC D-SDF-EXCL)
+    cases.check_sdf(emu_lib, oracle, coords[:2], 40.0, structures, mass, np.arange(coords.shape[2], dtype=np.int32), 6.0,
+                    ranges=[(1, 2), (0, 1)])
+
+
+def test_distance_family(emu_lib, oracle):
+    coords, structures, mass = cases.sdf_system(oracle, 9, 600, 30.0, 4)
+    specs = [("d", [3], [40], L.DIST_COM), ("dcom", structures[0], structures[1], L.DIST_COM),
+             ("dmin", structures[0], structures[2], L.DIST_MIN), ("dmax", structures[1], structures[3], L.DIST_MAX),
+             ("dpair", structures[0][:3], structures[1][:4], L.DIST_PAIR)]
+    cases.check_distances(emu_lib, oracle, coords, 30.0, mass, specs, ranges=[(0, 2), (2, 4)])
+
+
+def test_synth_kernel_matches_oracle_generator(emu_lib, oracle):
+    import viamd_amd as V
+    t = V.DeviceTrajectory(3, 999, lib=emu_lib)
+    t.synth(42, 50.0, 0.05)
+    for f in range(3):
+        got, cell = t.download_frame(f)
+        ref = oracle.synth_frame(42, 999, 50.0, 0.05, f)
+        np.testing.assert_array_equal(got, ref)
+        assert cell.x == 50.0 and cell.flags == 7
+
+
+def test_interrupt_and_clear(emu_lib, oracle, box3k):
+    import viamd_amd as V
+    o = cases.oxygen(3000)
+    ir = V.ScriptIR(emu_lib)
+    ir.add_rdf("goo", o, o, 12.0)
+    ev = V.ScriptEval(3, ir)
+    traj = V.HostTrajectory(box3k, V.make_unitcell(60.0))
+    ev.interrupt()
+    assert ev.frame_range(V.MolSystem(3000), traj, 0, 3) is False      # returns promptly, nothing evaluated
+    assert ev.frames_done() == 0 and not ev.frame_mask().any()
+    ev.clear_data()                                                    # clears the interrupt flag too (src/main.cpp:990)
+    assert ev.frame_range(V.MolSystem(3000), traj, 0, 1)
+    fp = ev.property_data("goo").fingerprint
+    first = ev.property_data("goo").counts.copy()
+    assert first.sum() > 0
+    ev.clear_data()
+    assert ev.property_data("goo").counts.sum() == 0 and ev.property_data("goo").fingerprint != fp
+    assert ev.frame_range(V.MolSystem(3000), traj, 0, 1)
+    np.testing.assert_array_equal(ev.property_data("goo").counts, first)
+    assert ev.ir_fingerprint() == ir.fingerprint()
