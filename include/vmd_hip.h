@@ -40,10 +40,11 @@ int vmd_hip_cells_build(void* stream, const float* xyz, size_t frame_stride, siz
                         vmd_grid_t grid, uint32_t* cell_count, uint32_t* rank, uint32_t* cell_start, float* sorted);
 
 /* K2: RDF pair histogram over a batch from cell-sorted selections (ref may equal tgt -> half shell).
- *   partial   u64[nblocks][nbins] scratch (nblocks = vmd_hip_rdf_num_blocks())
+ *   partial   u64[vmd_hip_rdf_partial_words()] scratch (per-wave rows + the work counter)
  *   counts    u64[nbins]  accumulated (+=) with device atomics
  *   variant   0 = wave queue (default), 1 = inline hit path */
 int vmd_hip_rdf_num_blocks(void);
+size_t vmd_hip_rdf_partial_words(void);
 int vmd_hip_rdf_pencil(void* stream, const float* sorted_ref, const uint32_t* cell_start_ref, int nref, int nref_pad,
                        const float* sorted_tgt, const uint32_t* cell_start_tgt, int ntgt, int ntgt_pad,
                        const float* boxes, int B, vmd_grid_t grid, float rmin, float rmax, int nbins,

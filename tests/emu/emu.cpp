@@ -76,6 +76,18 @@ uint32_t shfl_xor_bits(uint32_t v, int mask) {
     return (uint32_t)s[(f->linear & 63) ^ (mask & 63)];
 }
 
+uint32_t readfirstlane_bits(uint32_t v) {
+    Fiber* f = g_cur;
+    const unsigned gen = f->gen++;
+    uint64_t* s = xslot(f, gen);
+    s[f->linear & 63] = (uint64_t)v | (1ull << 63);      // bit 63 marks a live, participating lane
+    yield(WAIT_WAVE);
+    uint32_t r = v;
+    for (int l = 0; l < 64; ++l) if (s[l] >> 63) { r = (uint32_t)s[l]; break; }
+    // the slot is reused two collectives later; ballots/shuffles overwrite their own lane before reading
+    return r;
+}
+
 static void run_block(int nthreads) {
     const int nwaves = (nthreads + 63) / 64;
     g_xbuf.assign((size_t)nwaves * 2 * 64, 0);

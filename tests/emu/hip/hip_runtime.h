@@ -39,6 +39,7 @@ void sync_block();
 void sync_wave();
 unsigned long long ballot(int pred);
 uint32_t shfl_xor_bits(uint32_t v, int mask);
+uint32_t readfirstlane_bits(uint32_t v);
 }  // namespace emu
 
 #define threadIdx (emu::cur_tid())
@@ -69,7 +70,7 @@ static inline unsigned emu_mbcnt_hi(unsigned mask, unsigned add) {
 }
 #define __builtin_amdgcn_mbcnt_lo(m, v) emu_mbcnt_lo((m), (v))
 #define __builtin_amdgcn_mbcnt_hi(m, v) emu_mbcnt_hi((m), (v))
-#define __builtin_amdgcn_readfirstlane(v) (v)
+#define __builtin_amdgcn_readfirstlane(v) ((int)emu::readfirstlane_bits((uint32_t)(v)))
 #define __builtin_amdgcn_wave_barrier() emu::sync_wave()
 
 template <typename T>

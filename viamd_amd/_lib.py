@@ -122,6 +122,7 @@ SIGNATURES = [
     # vmd_hip.h
     ("vmd_hip_cells_build", C.c_int, [_vp, _vp, C.c_size_t, C.c_size_t, _vp, C.c_int, _vp, C.c_int, C.c_int, Grid, _vp, _vp, _vp, _vp]),
     ("vmd_hip_rdf_num_blocks", C.c_int, []),
+    ("vmd_hip_rdf_partial_words", C.c_size_t, []),
     ("vmd_hip_rdf_pencil", C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, C.c_int, C.c_int, _vp, C.c_int, Grid,
                                      C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     ("vmd_hip_rdf_brute", C.c_int, [_vp, _vp, C.c_size_t, C.c_size_t, _vp, C.c_uint32, C.c_int, _vp, C.c_int, _vp, C.c_int,

@@ -693,8 +693,8 @@ static size_t auto_batch(const vmd_script_eval_t* e, size_t num_atoms) {
     // scratch per frame: every selection holds ~20 B per selected atom + the staged frame itself (host trajectories)
     size_t per_frame = 12 * num_atoms;
     for (auto& s : e->sels) per_frame += 24 * s->idx.size();
-    size_t B = (size_t)(768ull << 20) / std::max<size_t>(per_frame, 1);
-    B = std::max<size_t>(1, std::min<size_t>(B, 256));
+    size_t B = (size_t)(1536ull << 20) / std::max<size_t>(per_frame, 1);
+    B = std::max<size_t>(1, std::min<size_t>(B, 1024));
     return B;
 }
 
@@ -754,8 +754,7 @@ extern "C" bool vmd_eval_frame_range(vmd_script_eval_t* eval, const vmd_script_i
                     // properties with the same cutoff share the sorted copies; build_selection re-sorts when the grid differs
                     if (!build_selection(e, sa, src, nb, g)) return false;
                     if (sb != sa && !build_selection(e, sb, src, nb, g)) return false;
-                    const int nblocks = vmd_hip_rdf_num_blocks();
-                    if (!e->d_partial.ensure((size_t)nblocks * 4 * VMD_RDF_NUM_BINS)) return false;
+                    if (!e->d_partial.ensure(vmd_hip_rdf_partial_words())) return false;
                     e->prof.begin("rdf_pencil", e->stream);
                     KRN_OK(vmd_hip_rdf_pencil(e->stream, sa->sorted.p, sa->cell_start.p, (int)sa->idx.size(), sa->nsel_pad,
                                               sb->sorted.p, sb->cell_start.p, (int)sb->idx.size(), sb->nsel_pad,

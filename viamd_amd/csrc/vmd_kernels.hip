@@ -190,6 +190,7 @@ struct vmd_pair_params_t {
     float r2_up;        // conservative candidate filter (> rmax^2)
     float rpad;         // conservative range padding (> rmax)
     uint64_t* partial;  // [gridDim.x*4][nbins]
+    unsigned* work_counter;  // zeroed before launch: next (frame, pencil) item to hand out
 };
 
 // per-wave state of the hit machinery
@@ -325,7 +326,11 @@ __global__ __launch_bounds__(256) void k_rdf_pencil(vmd_pair_params_t p) {
     uint64_t* __restrict__ prow = p.partial + (size_t)gw * nbins;
     bool flushed = false;
 
-    for (int item = gw; item < nitems; item += GW) {
+    // work items are handed out dynamically (one returning atomic per item, fetched one item ahead)
+    int item = gw;
+    int next_item = 0;
+    for (; item < nitems; item = next_item) {
+        if (lane == 0) next_item = (int)atomicAdd(p.work_counter, 1u) + GW;
         const int b = item / npen;
         const int pen = item - b * npen;
         const int pz = pen / ny;
@@ -399,6 +404,7 @@ __global__ __launch_bounds__(256) void k_rdf_pencil(vmd_pair_params_t p) {
                 w.ncols = 0;
             }
         }
+        next_item = __builtin_amdgcn_readfirstlane(next_item);
     }
     vmd_drain<VARIANT, INC>(p.bin, w, lane);
     __builtin_amdgcn_wave_barrier();
@@ -408,13 +414,16 @@ __global__ __launch_bounds__(256) void k_rdf_pencil(vmd_pair_params_t p) {
     }
 }
 
-// sum the per-wave partial rows into the u64 accumulators
+// sum the per-wave partial rows into the u64 accumulators: block (x = 256 bins, y = slice of 32 rows), coalesced
+// row reads, one atomicAdd(u64) per bin and slice
 __global__ __launch_bounds__(256) void k_hist_reduce(const uint64_t* __restrict__ partial, int nrows, int nbins,
                                                      uint64_t* __restrict__ counts) {
     const int b = blockIdx.x * 256 + threadIdx.x;
     if (b >= nbins) return;
+    const int r0 = blockIdx.y * 32;
+    const int r1 = r0 + 32 < nrows ? r0 + 32 : nrows;
     uint64_t s = 0;
-    for (int r = 0; r < nrows; ++r) s += partial[(size_t)r * nbins + b];
+    for (int r = r0; r < r1; ++r) s += partial[(size_t)r * nbins + b];
     if (s) atomicAdd((unsigned long long*)&counts[b], (unsigned long long)s);
 }
 
@@ -852,6 +861,7 @@ extern "C" int vmd_hip_cells_build(void* stream, const float* xyz, size_t frame_
 }
 
 extern "C" int vmd_hip_rdf_num_blocks(void) { return 1024; }
+extern "C" size_t vmd_hip_rdf_partial_words(void) { return (size_t)vmd_hip_rdf_num_blocks() * 4 * VMD_MAX_BINS + 1; }
 
 extern "C" int vmd_hip_rdf_pencil(void* stream, const float* sorted_ref, const uint32_t* cell_start_ref, int nref, int nref_pad,
                                   const float* sorted_tgt, const uint32_t* cell_start_tgt, int ntgt, int ntgt_pad,
@@ -860,7 +870,14 @@ extern "C" int vmd_hip_rdf_pencil(void* stream, const float* sorted_ref, const u
     hipStream_t s = (hipStream_t)stream;
     if (nbins <= 0 || nbins > VMD_MAX_BINS) return (int)hipErrorInvalidValue;
     if (B <= 0 || nref <= 0 || ntgt <= 0) return 0;
+    // the work counter lives behind the partial rows (see vmd_hip_rdf_partial_words)
+    unsigned* work_counter = (unsigned*)(partial + (size_t)vmd_hip_rdf_num_blocks() * 4 * VMD_MAX_BINS);
+    {
+        hipError_t e = hipMemsetAsync(work_counter, 0, sizeof(uint64_t), s);
+        if (e != hipSuccess) return (int)e;
+    }
     vmd_pair_params_t p;
+    p.work_counter = work_counter;
     p.sref = sorted_ref; p.cs_ref = cell_start_ref; p.nref_pad = nref_pad;
     p.stgt = sorted_tgt; p.cs_tgt = cell_start_tgt; p.ntgt_pad = ntgt_pad;
     p.boxes = boxes; p.B = B; p.grid = grid;
@@ -880,7 +897,7 @@ extern "C" int vmd_hip_rdf_pencil(void* stream, const float* sorted_ref, const u
         else hipLaunchKernelGGL((k_rdf_pencil<0, false>), g, blk, 0, s, p);
     }
     VMD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_hist_reduce, dim3((nbins + 255) / 256), dim3(256), 0, s, (const uint64_t*)partial, nblocks * 4, nbins, counts);
+    hipLaunchKernelGGL(k_hist_reduce, dim3((nbins + 255) / 256, (nblocks * 4 + 31) / 32), dim3(256), 0, s, (const uint64_t*)partial, nblocks * 4, nbins, counts);
     VMD_LAUNCH_CHECK();
     return 0;
 }
