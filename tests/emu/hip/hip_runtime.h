@@ -73,6 +73,19 @@ static inline unsigned emu_mbcnt_hi(unsigned mask, unsigned add) {
 #define __builtin_amdgcn_readfirstlane(v) ((int)emu::readfirstlane_bits((uint32_t)(v)))
 #define __builtin_amdgcn_wave_barrier() emu::sync_wave()
 
+// v_sqrt_f32 stand-in with a deliberate +-1 ulp error on half of the inputs: exercises the exactness fix-up of vmd_bin_add
+static inline float emu_approx_sqrtf(float x) {
+    float r = sqrtf(x);
+    uint32_t b; memcpy(&b, &x, 4);
+    if (!(r > 0.0f) || !std::isfinite(r)) return r;
+    if ((b >> 3) & 1u) r = nextafterf(r, (b & 1u) ? INFINITY : 0.0f);
+    return r;
+}
+#define __builtin_amdgcn_sqrtf(x) emu_approx_sqrtf(x)
+typedef float emu_f2 __attribute__((vector_size(8)));
+static inline emu_f2 emu_fma2(emu_f2 a, emu_f2 b, emu_f2 c) { emu_f2 r = {fmaf(a[0], b[0], c[0]), fmaf(a[1], b[1], c[1])}; return r; }
+#define __builtin_elementwise_fma(a, b, c) emu_fma2((a), (b), (c))
+
 template <typename T>
 static inline T atomicAdd(T* p, T v) { T old = *p; *p = old + v; return old; }
 static inline unsigned atomicMax(unsigned* p, unsigned v) { unsigned old = *p; if (v > old) *p = v; return old; }

@@ -25,7 +25,7 @@
 
 #define VMD_WAVE 64
 #define VMD_MAX_BINS 1024
-#define VMD_QUEUE_CAP 512          // power of two; holds < 64 pending + 4 undrained candidate columns of 64
+#define VMD_QUEUE_CAP 320          // < 64 pending + 4 undrained candidate columns of 64
 #define VMD_FAR 1.0e18f            // coordinate of a padding lane: never within any cutoff, squares stay finite
 
 // Wave-uniform read-only data (j coordinates, cell offsets, boxes) is read through the constant address space so
@@ -36,6 +36,7 @@
 #endif
 typedef VMD_UNIFORM_AS const float vmd_cf32;
 typedef VMD_UNIFORM_AS const uint32_t vmd_cu32;
+typedef float vmd_f2 __attribute__((vector_size(8)));   // two fp32 lanes of one VGPR/SGPR pair (v_pk_*_f32)
 
 // ------------------------------------------------------------------------------------------------ helpers
 
@@ -101,7 +102,19 @@ __device__ __forceinline__ unsigned vmd_lane_prefix(unsigned long long mask) {
 struct vmd_binning_t {
     float rmin, rmax, inv_range, fnbins;
     int nbins;
+    // fast path of vmd_bin_fast: v_sqrt_f32 (1 ulp) is trusted when the distance is safely inside (fast_lo, fast_hi)
+    // and the scaled value is at least fast_delta away from a bin edge; everything else takes the exact path
+    float fast_lo, fast_hi, fast_delta;
 };
+__host__ __device__ inline vmd_binning_t vmd_make_binning(float rmin, float rmax, int nbins) {
+    vmd_binning_t b;
+    b.rmin = rmin; b.rmax = rmax; b.inv_range = 1.0f / (rmax - rmin); b.fnbins = (float)nbins; b.nbins = nbins;
+    b.fast_lo = rmin * (1.0f + 1.0e-6f) + 1.0e-30f;
+    b.fast_hi = rmax * (1.0f - 1.0e-6f);
+    b.fast_delta = 1.0e-3f + 1.0e-6f * rmax * b.inv_range * b.fnbins;
+    if (!(b.fast_delta < 0.25f)) { b.fast_lo = 3.0e38f; b.fast_hi = -3.0e38f; }   // degenerate range: exact path only
+    return b;
+}
 __device__ __forceinline__ int vmd_bin_of(const vmd_binning_t& b, float d2) {
     const float d = sqrtf(d2);
     if (!(b.rmin < d && d < b.rmax)) return -1;
@@ -197,21 +210,35 @@ struct vmd_pair_params_t {
 struct vmd_wave_acc_t {
     unsigned* hist;       // LDS, nbins
     float* queue;         // LDS, VMD_QUEUE_CAP
-    unsigned qhead, qtail;  // wave-uniform ring positions
+    unsigned qtail;       // wave-uniform stack height
     unsigned ncols;       // wave-uniform: candidate columns (<= 64 hits each) since the last flush
 };
 
+// Bin `d2` of every `active` lane into the LDS histogram.  Must be called by all lanes of the wave.
+// Result is exactly vmd_bin_of(d2) (SPEC S4): the 1-ulp hardware sqrt is only used where it provably cannot change the
+// bin or the open-interval test; the (rare) uncertain lanes re-do the computation with the correctly rounded sqrtf.
 template <unsigned INC>
 __device__ __forceinline__ void vmd_bin_add(const vmd_binning_t& bn, unsigned* hist, float d2, bool active) {
-    if (active) {
-        const int bin = vmd_bin_of(bn, d2);
-        if (bin >= 0) atomicAdd(&hist[bin], INC);
+    const float s = __builtin_amdgcn_sqrtf(d2);
+    const float t = ((s - bn.rmin) * bn.inv_range) * bn.fnbins;
+    const float fl = floorf(t);
+    const float fr = t - fl;
+    const bool sure = s > bn.fast_lo && s < bn.fast_hi && fr > bn.fast_delta && fr < 1.0f - bn.fast_delta;
+    int bin = (int)fl;
+    bool add = active && sure;
+    if (__ballot(active && !sure)) {
+        if (active && !sure) {
+            bin = vmd_bin_of(bn, d2);
+            add = bin >= 0;
+        }
     }
+    if (add) atomicAdd(&hist[bin], INC);
 }
 
-// VARIANT 0: compact the hits of one candidate column into the wave queue (ring buffer in LDS);
-// vmd_drain_full pops full waves of 64 so that sqrt + binning + ds_add always run with every lane busy.
-// VARIANT 1: bin the hits in place under the divergent mask (reference implementation of the same arithmetic).
+// VARIANT 0: compact the hits of one candidate column onto the wave's LDS stack (order is irrelevant for a
+// histogram, so LIFO: no head pointer, no wrap-around); vmd_drain_full pops full waves of 64 so that
+// sqrt + binning + ds_add always run with every lane busy.
+// VARIANT 1: bin the hits in place under the divergent mask (same arithmetic; A/B baseline and cross-check).
 template <int VARIANT, unsigned INC>
 __device__ __forceinline__ void vmd_push(const vmd_binning_t& bn, vmd_wave_acc_t& w, bool hit, float d2) {
     if (VARIANT == 1) {
@@ -220,8 +247,8 @@ __device__ __forceinline__ void vmd_push(const vmd_binning_t& bn, vmd_wave_acc_t
     }
     const unsigned long long mask = __ballot(hit);
     if (mask) {
-        const unsigned pos = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, w.qtail));
-        if (hit) w.queue[pos & (VMD_QUEUE_CAP - 1)] = d2;
+        const unsigned pre = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+        if (hit) (w.queue + w.qtail)[pre] = d2;
         w.qtail += (unsigned)__popcll(mask);
     }
 }
@@ -229,11 +256,11 @@ __device__ __forceinline__ void vmd_push(const vmd_binning_t& bn, vmd_wave_acc_t
 template <int VARIANT, unsigned INC>
 __device__ __forceinline__ void vmd_drain_full(const vmd_binning_t& bn, vmd_wave_acc_t& w, int lane) {
     if (VARIANT == 1) return;
-    while (w.qtail - w.qhead >= VMD_WAVE) {
+    while (w.qtail >= VMD_WAVE) {
+        w.qtail -= VMD_WAVE;
         __builtin_amdgcn_wave_barrier();
-        const float v = w.queue[(w.qhead + lane) & (VMD_QUEUE_CAP - 1)];
+        const float v = (w.queue + w.qtail)[lane];
         __builtin_amdgcn_wave_barrier();
-        w.qhead += VMD_WAVE;
         vmd_bin_add<INC>(bn, w.hist, v, true);
     }
 }
@@ -242,11 +269,11 @@ template <int VARIANT, unsigned INC>
 __device__ __forceinline__ void vmd_drain(const vmd_binning_t& bn, vmd_wave_acc_t& w, int lane) {
     if (VARIANT == 1) return;
     vmd_drain_full<VARIANT, INC>(bn, w, lane);
-    const unsigned rem = w.qtail - w.qhead;
+    const unsigned rem = w.qtail;
     __builtin_amdgcn_wave_barrier();
-    const float v = w.queue[(w.qhead + lane) & (VMD_QUEUE_CAP - 1)];
+    const float v = w.queue[lane];
     __builtin_amdgcn_wave_barrier();
-    w.qhead = w.qtail;
+    w.qtail = 0;
     vmd_bin_add<INC>(bn, w.hist, v, (unsigned)lane < rem);
 }
 
@@ -262,18 +289,26 @@ __device__ __forceinline__ void vmd_segment_loop(const vmd_pair_params_t& p, vmd
     vmd_cf32* pz = tz + ja;
     int n = (int)(jb - ja);
     unsigned j = ja;
+    // two j columns per VALU instruction: v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32 are IEEE per element, so the
+    // arithmetic is still SPEC S3 exactly; the j pair sits in an SGPR pair straight from s_load_dwordx4
+    const vmd_f2 xi2 = {xi, xi}, yi2 = {yi, yi}, zi2 = {zi, zi};
+    const vmd_f2 sx2 = {sx, sx}, sy2 = {sy, sy}, sz2 = {sz, sz};
     for (; n >= 4; n -= 4, px += 4, py += 4, pz += 4, j += 4) {
         float xj[4], yj[4], zj[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) { xj[u] = px[u]; yj[u] = py[u]; zj[u] = pz[u]; }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            float dx = xi - xj[u], dy = yi - yj[u], dz = zi - zj[u];
-            if (SHIFT) { dx = dx - sx; dy = dy - sy; dz = dz - sz; }
-            const float d2 = vmd_d2(dx, dy, dz);
-            bool hit = d2 < r2;
-            if (MASKED) hit = hit && (j + u > i);
-            vmd_push<VARIANT, INC>(p.bin, w, hit, d2);
+        for (int h = 0; h < 2; ++h) {
+            const vmd_f2 xj2 = {xj[2 * h], xj[2 * h + 1]}, yj2 = {yj[2 * h], yj[2 * h + 1]}, zj2 = {zj[2 * h], zj[2 * h + 1]};
+            vmd_f2 dx = xi2 - xj2, dy = yi2 - yj2, dz = zi2 - zj2;
+            if (SHIFT) { dx = dx - sx2; dy = dy - sy2; dz = dz - sz2; }
+            const vmd_f2 d2 = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                bool hit = d2[u] < r2;
+                if (MASKED) hit = hit && (j + 2 * h + u > i);
+                vmd_push<VARIANT, INC>(p.bin, w, hit, d2[u]);
+            }
         }
         vmd_drain_full<VARIANT, INC>(p.bin, w, lane);
     }
@@ -314,7 +349,7 @@ __global__ __launch_bounds__(256) void k_rdf_pencil(vmd_pair_params_t p) {
     vmd_wave_acc_t w;
     w.hist = s_hist[wave];
     w.queue = s_queue[wave];
-    w.qhead = 0; w.qtail = 0; w.ncols = 0;
+    w.qtail = 0; w.ncols = 0;
     for (int b = lane; b < nbins; b += VMD_WAVE) w.hist[b] = 0u;
     __builtin_amdgcn_wave_barrier();
 
@@ -860,7 +895,7 @@ extern "C" int vmd_hip_cells_build(void* stream, const float* xyz, size_t frame_
     return 0;
 }
 
-extern "C" int vmd_hip_rdf_num_blocks(void) { return 1024; }
+extern "C" int vmd_hip_rdf_num_blocks(void) { return 2048; }   // 8 blocks x 4 waves per CU: 8 waves per SIMD
 extern "C" size_t vmd_hip_rdf_partial_words(void) { return (size_t)vmd_hip_rdf_num_blocks() * 4 * VMD_MAX_BINS + 1; }
 
 extern "C" int vmd_hip_rdf_pencil(void* stream, const float* sorted_ref, const uint32_t* cell_start_ref, int nref, int nref_pad,
@@ -881,7 +916,7 @@ extern "C" int vmd_hip_rdf_pencil(void* stream, const float* sorted_ref, const u
     p.sref = sorted_ref; p.cs_ref = cell_start_ref; p.nref_pad = nref_pad;
     p.stgt = sorted_tgt; p.cs_tgt = cell_start_tgt; p.ntgt_pad = ntgt_pad;
     p.boxes = boxes; p.B = B; p.grid = grid;
-    p.bin.rmin = rmin; p.bin.rmax = rmax; p.bin.inv_range = 1.0f / (rmax - rmin); p.bin.fnbins = (float)nbins; p.bin.nbins = nbins;
+    p.bin = vmd_make_binning(rmin, rmax, nbins);
     p.r2_up = nextafterf(rmax * rmax, 3.0e38f) * 1.0001f;
     p.rpad = rmax * 1.0001f + 1.0e-4f;
     p.partial = partial;
@@ -910,7 +945,7 @@ extern "C" int vmd_hip_rdf_brute(void* stream, const float* xyz, size_t frame_st
     if (nbins <= 0 || nbins > VMD_MAX_BINS) return (int)hipErrorInvalidValue;
     if (B <= 0 || nref <= 0 || ntgt <= 0) return 0;
     vmd_brute_params_t p{xyz, frame_stride, row_stride, boxes, pbc_flags, B, ref, nref, tgt, ntgt, {}, counts};
-    p.bin.rmin = rmin; p.bin.rmax = rmax; p.bin.inv_range = 1.0f / (rmax - rmin); p.bin.fnbins = (float)nbins; p.bin.nbins = nbins;
+    p.bin = vmd_make_binning(rmin, rmax, nbins);
     hipLaunchKernelGGL(k_rdf_brute, dim3((nref + 255) / 256, B), dim3(256), 0, s, p);
     VMD_LAUNCH_CHECK();
     return 0;
