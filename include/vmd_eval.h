@@ -187,6 +187,10 @@ void              vmd_devtraj_free(vmd_devtraj_t* t);
 vmd_trajectory_i* vmd_devtraj_interface(vmd_devtraj_t* t);
 bool vmd_devtraj_upload_frame(vmd_devtraj_t* t, size_t frame, const vmd_unitcell_t* cell,
                               const float* x, const float* y, const float* z);
+/* overwrite atoms [first_atom, first_atom+atom_count) of frames [frame_beg, frame_beg+frame_count): xyz is
+ * host float[frame_count][3][atom_count] */
+bool vmd_devtraj_upload_atoms(vmd_devtraj_t* t, size_t frame_beg, size_t frame_count, size_t first_atom, size_t atom_count,
+                              const float* xyz);
 /* seeded synthetic water box of SURVEY 8d (same integer RNG as oracle S9) for frames [beg,end) */
 bool vmd_devtraj_synth(vmd_devtraj_t* t, uint64_t seed, float L, float sigma, uint32_t n_blob,
                        size_t frame_beg, size_t frame_end);

@@ -66,11 +66,13 @@ int vmd_hip_sdf_align(void* stream, const float* xyz, size_t frame_stride, size_
 /* reference pose from one frame (structure 0): ref_pose f64[m][3] out */
 int vmd_hip_sdf_ref_pose(void* stream, const float* xyz, size_t row_stride, const float* box, uint32_t pbc_flags,
                          const int32_t* struct0, const float* mass0, int m, double* ref_pose);
-/* K4: scatter target atoms of every frame into the dim^3 u64 volume (x fastest), SPEC S5 */
+/* K4: scatter target atoms of every frame into the dim^3 u64 volume (x fastest), SPEC S5.
+ *   owner  int8[ntgt]: index of the structure target t belongs to, -1 if none (NULL: membership is searched in structs;
+ *          an atom listed in several structures needs NULL) */
 int vmd_hip_sdf_scatter(void* stream, const float* xyz, size_t frame_stride, size_t row_stride,
                         const float* boxes, uint32_t pbc_flags, int B,
                         const int32_t* structs, int K, int m, const float* R32, const float* c32,
-                        const int32_t* tgt, int ntgt, float extent, int dim, uint64_t* volume);
+                        const int32_t* tgt, const int8_t* owner, int ntgt, float extent, int dim, uint64_t* volume);
 
 /* K5: distance family, one row per frame: out f32[B][dim1], dim1 = 1 (COM/MIN/MAX) or na*nb (PAIR). kind as
  * vmd_distance_kind_t.  mass_a/mass_b f32[na]/[nb] (COM only). */

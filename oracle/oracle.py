@@ -67,6 +67,9 @@ def lib():
         L.vo_sdf_frame_scatter.restype = C.c_uint64
         L.vo_sdf_frame_scatter.argtypes = [fp, fp, fp, cp, ip, C.c_size_t, C.c_size_t, fp, fp, ip, C.c_size_t,
                                            C.c_float, C.c_int, u64p]
+        L.vo_sdf_run.restype = C.c_uint64
+        L.vo_sdf_run.argtypes = [fp, cp, C.c_size_t, C.c_size_t, ip, fp, C.c_size_t, C.c_size_t, ip, C.c_size_t,
+                                 C.c_float, C.c_int, C.c_int, u64p]
         L.vo_set_com.restype = None
         L.vo_set_com.argtypes = [fp, fp, fp, cp, ip, fp, C.c_size_t, fp]
         L.vo_distance_com.restype = C.c_float
@@ -191,6 +194,21 @@ def sdf_frame_scatter(x, y, z, cell, struct_idx, R32, c32, tgt, s, dim=128, vol=
     c32 = np.ascontiguousarray(c32, np.float32)
     hits = lib().vo_sdf_frame_scatter(_f(x), _f(y), _f(z), C.byref(cell), _i(struct_idx), K, m, _f(R32), _f(c32),
                                       _i(tgt), tgt.size, s, dim, _u64(vol))
+    return vol, hits
+
+
+def sdf_run(traj, cells, struct_idx, struct_mass, tgt, s, dim=128, nthreads=1):
+    """traj float32 [F,3,npad]; returns vol u64[dim^3], hits"""
+    traj = np.ascontiguousarray(traj, np.float32)
+    F, _, npad = traj.shape
+    carr = (Cell * F)(*cells)
+    struct_idx = _as_idx(struct_idx)
+    K, m = struct_idx.shape
+    struct_mass = np.ascontiguousarray(struct_mass, np.float32)
+    tgt = _as_idx(tgt)
+    vol = np.zeros(dim ** 3, np.uint64)
+    hits = lib().vo_sdf_run(_f(traj), carr, F, npad, _i(struct_idx), _f(struct_mass), K, m, _i(tgt), tgt.size, s, dim, nthreads,
+                            _u64(vol))
     return vol, hits
 
 

@@ -471,6 +471,71 @@ uint64_t vo_sdf_frame_scatter(const float* x, const float* y, const float* z, co
     return hits;
 }
 
+/* Multi-threaded SDF driver (same threading model as vo_rdf_run): per frame alignment + scatter into a private
+ * hit list, merged into the shared volume at frame end.  ref pose is taken from frame 0 of `traj`. */
+uint64_t vo_sdf_run(const float* traj, const vo_cell_t* cells, size_t nframes, size_t npad,
+                    const int32_t* struct_idx, const float* struct_mass, size_t K, size_t m,
+                    const int32_t* tgt_idx, size_t ntgt, float s, int dim, int nthreads, uint64_t* vol) {
+    uint64_t total = 0;
+    if (nthreads < 1) nthreads = 1;
+    double* ref_pose = (double*)malloc(sizeof(double) * 3 * m);
+    vo_sdf_ref_pose(traj, traj + npad, traj + 2 * npad, &cells[0], struct_idx, struct_mass, m, ref_pose);
+#ifdef _OPENMP
+#pragma omp parallel num_threads(nthreads)
+#endif
+    {
+        float* R32 = (float*)malloc(sizeof(float) * 9 * K);
+        float* c32 = (float*)malloc(sizeof(float) * 3 * K);
+        size_t cap = 1 << 16, nh = 0;
+        uint32_t* hitlist = (uint32_t*)malloc(sizeof(uint32_t) * cap);
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 1)
+#endif
+        for (long f = 0; f < (long)nframes; ++f) {
+            const float* x = traj + (size_t)f * 3 * npad;
+            const float* y = x + npad;
+            const float* z = y + npad;
+            vo_sdf_frame_align(x, y, z, &cells[f], struct_idx, struct_mass, K, m, ref_pose, NULL, R32, c32);
+            const vo_box_t bx = vo_box(&cells[f]);
+            const float vscale = (float)dim / (2.0f * s);
+            const float fdim = (float)dim;
+            nh = 0;
+            for (size_t k = 0; k < K; ++k) {
+                const float* R = R32 + 9 * k;
+                const float* c = c32 + 3 * k;
+                const int32_t* sidx = struct_idx + k * m;
+                for (size_t t = 0; t < ntgt; ++t) {
+                    const int32_t i = tgt_idx ? tgt_idx[t] : (int32_t)t;
+                    const float dx = vo_mi_rintf(x[i] - c[0], bx.L[0], bx.pbc[0]);
+                    const float dy = vo_mi_rintf(y[i] - c[1], bx.L[1], bx.pbc[1]);
+                    const float dz = vo_mi_rintf(z[i] - c[2], bx.L[2], bx.pbc[2]);
+                    const float qx = fmaf(R[2], dz, fmaf(R[1], dy, R[0] * dx));
+                    const float qy = fmaf(R[5], dz, fmaf(R[4], dy, R[3] * dx));
+                    const float qz = fmaf(R[8], dz, fmaf(R[7], dy, R[6] * dx));
+                    const float tx = (qx + s) * vscale, ty = (qy + s) * vscale, tz = (qz + s) * vscale;
+                    if (tx >= 0.0f && tx < fdim && ty >= 0.0f && ty < fdim && tz >= 0.0f && tz < fdim) {
+                        int own = 0;
+                        for (size_t a = 0; a < m; ++a) if (sidx[a] == i) { own = 1; break; }
+                        if (own) continue;
+                        if (nh == cap) { cap *= 2; hitlist = (uint32_t*)realloc(hitlist, sizeof(uint32_t) * cap); }
+                        hitlist[nh++] = (uint32_t)(((size_t)(int)tz * dim + (int)ty) * dim + (int)tx);
+                    }
+                }
+            }
+#ifdef _OPENMP
+#pragma omp critical
+#endif
+            {
+                for (size_t h = 0; h < nh; ++h) vol[hitlist[h]] += 1;
+                total += nh;
+            }
+        }
+        free(hitlist); free(R32); free(c32);
+    }
+    free(ref_pose);
+    return total;
+}
+
 /* ------------------------------------------------------------------------------------------------ S6 */
 void vo_set_com(const float* x, const float* y, const float* z, const vo_cell_t* cell,
                 const int32_t* idx, const float* mass, size_t n, float out[3]) {

@@ -74,6 +74,11 @@ uint64_t vo_sdf_frame_scatter(const float* x, const float* y, const float* z, co
                               const float* R32, const float* c32,
                               const int32_t* tgt_idx, size_t ntgt, float s, int dim, uint64_t* vol);
 
+/* multi-threaded SDF driver over a trajectory float[F][3][npad] (threading as vo_rdf_run); returns #voxel hits */
+uint64_t vo_sdf_run(const float* traj, const vo_cell_t* cells, size_t nframes, size_t npad,
+                    const int32_t* struct_idx, const float* struct_mass, size_t K, size_t m,
+                    const int32_t* tgt_idx, size_t ntgt, float s, int dim, int nthreads, uint64_t* vol);
+
 /* S6 distance family, one frame */
 void  vo_set_com(const float* x, const float* y, const float* z, const vo_cell_t* cell,
                  const int32_t* idx, const float* mass, size_t n, float out[3]);

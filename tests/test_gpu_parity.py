@@ -248,3 +248,24 @@ def test_nccl_single_rank_reduce_is_identity(gpu_lib, oracle, box30k):
     finally:
         dist.destroy_process_group()
     np.testing.assert_array_equal(ev.property_data("goo").counts, ref)
+
+
+def test_synthetic_blob_system_device_equals_host_and_script_eval(gpu_lib, oracle):
+    """BASELINE config 4 in miniature through the script front-end: device-generated waters + uploaded blob rows."""
+    from viamd_amd import script, synth
+    n_blob, n_atoms, box, F = 200, 200 + 30000, 70.0, 5
+    topo = synth.water_box_topology(n_atoms, n_blob)
+    traj = synth.make_device_trajectory(V, 12, n_atoms, box, F, n_blob)
+    coords = synth.host_frames(oracle, 12, n_atoms, box, F, n_blob)
+    for f in (0, F - 1):
+        got, _ = traj.download_frame(f)
+        np.testing.assert_array_equal(got, coords[f])
+    ir, info = script.compile_script("s = residue(5:11); v = sdf(s, element('O') and water, 10.0);"
+                                     "g = rdf(element('O') and water, element('O') and water, 12.0);", topo)
+    ev = V.ScriptEval(F, ir)
+    assert ev.frame_range(V.MolSystem(n_atoms, mass=topo.mass, unitcell=V.make_unitcell(box)), traj, 0, F)
+    ocell = oracle.make_cell(box)
+    vol, _ = cases.oracle_sdf(oracle, coords, ocell, info["v"]["structures"], topo.mass, info["v"]["target"], 10.0)
+    np.testing.assert_array_equal(ev.property_data("v").counts, vol)
+    ref, _ = cases.oracle_rdf(oracle, coords, ocell, info["g"]["ref"], info["g"]["target"], 0.0, 12.0)
+    np.testing.assert_array_equal(ev.property_data("g").counts, ref)

@@ -1,0 +1,73 @@
+"""Mini script front-end: BASELINE config strings -> property descriptors."""
+import numpy as np
+import pytest
+
+import viamd_amd as V
+from viamd_amd import script, synth
+
+
+@pytest.fixture(scope="module")
+def topo():
+    return synth.water_box_topology(2000 + 3000, n_blob=2000)
+
+
+def test_topology(topo):
+    assert topo.num_atoms == 5000 and topo.num_residues == 200 + 1000
+    assert topo.residue_name(0) == "ALA" and topo.residue_name(200) == "HOH"
+    assert list(topo.residue_atoms(3)) == list(range(30, 40))
+    assert topo.mass[2000] == np.float32(15.999) and topo.mass[2001] == np.float32(1.008)
+
+
+def test_baseline_config_scripts_compile(emu_lib, topo):
+    ir, info = script.compile_script("g = rdf(element('O') and water, element('O') and water, 12.0);", topo, lib=emu_lib)
+    assert ir.property_names() == ["g"] and ir.property_flags("g") == V.FLAG_DISTRIBUTION
+    np.testing.assert_array_equal(info["g"]["ref"], np.arange(2000, 5000, 3))
+    ir, info = script.compile_script("""
+        # default script shape of src/main.cpp:528
+        s1 = resname("ALA")[2:8];
+        r = rdf(element('C'), element('H'), 10.0);
+        v = sdf(s1, element('H'), 10.0);
+        d1 = distance(10, 30);
+        d2 = distance_min(residue(3), water and element('O'));
+        h = rdf(not element('H'), not element('H'), {2.0, 9.0});
+    """, topo, lib=emu_lib)
+    assert ir.property_names() == ["r", "v", "d1", "d2", "h"]
+    assert info["v"]["structures"].shape == (7, 10) and info["v"]["structures"][0, 0] == 10      # residues 2..8, 1-based
+    assert info["d1"]["a"].tolist() == [9] and info["d1"]["b"].tolist() == [29]                  # 1-based script indices
+    assert info["d2"]["kind"] == "distance_min" and info["d2"]["a"].tolist() == list(range(20, 30))
+    assert (info["h"]["rmin"], info["h"]["rmax"]) == (2.0, 9.0)
+    assert [ir.property_flags(n) for n in ir.property_names()] == [V.FLAG_DISTRIBUTION, V.FLAG_VOLUME, V.FLAG_TEMPORAL,
+                                                                   V.FLAG_TEMPORAL, V.FLAG_DISTRIBUTION]
+    ir, info = script.compile_script("s = residue(5:11); v = sdf(s, element('O') and water, 10.0);", topo, lib=emu_lib)
+    assert info["v"]["structures"].shape == (7, 10) and info["v"]["structures"][0, 0] == 40
+
+
+def test_script_errors(emu_lib, topo):
+    for bad in ("g = rdf(element('X'), all, 5.0);", "v = sdf(all[1:2], all, 5.0);", "d = distance(1, 999999);",
+                "d = distance(1, 2) in residue(3);", "g = rdf(all, all 5.0);", "x = frobnicate(3);", "g = rdf(residue(0), all, 5.0);"):
+        with pytest.raises((script.ScriptError, V.VmdError)):
+            script.compile_script(bad, topo, lib=emu_lib)
+
+
+def test_script_driven_evaluation_matches_oracle(emu_lib, oracle):
+    """config-4/5 style script end to end on the emulator build: blob + waters, sdf + rdf + distances."""
+    import cases
+    from viamd_amd import _lib as L
+    n_blob, n_atoms, box, F = 60, 60 + 900, 30.0, 3
+    topo = synth.water_box_topology(n_atoms, n_blob)
+    coords = synth.host_frames(oracle, 12, n_atoms, box, F, n_blob)
+    ir, info = script.compile_script(
+        "s = residue(2:4); v = sdf(s, element('O') and water, 8.0); g = rdf(element('O') and water, not element('H'), 9.0);"
+        "d = distance(residue(1), residue(6)); m = distance_max(residue(2), residue(3));", topo, lib=emu_lib)
+    ev = V.ScriptEval(F, ir)
+    vcell = V.make_unitcell(box)
+    assert ev.frame_range(V.MolSystem(n_atoms, mass=topo.mass, unitcell=vcell), V.HostTrajectory(coords, vcell), 0, F)
+    ocell = oracle.make_cell(box)
+    vol, _ = cases.oracle_sdf(oracle, coords, ocell, info["v"]["structures"], topo.mass, info["v"]["target"], 8.0)
+    np.testing.assert_array_equal(ev.property_data("v").counts, vol)
+    ref, _ = cases.oracle_rdf(oracle, coords, ocell, info["g"]["ref"], info["g"]["target"], 0.0, 9.0)
+    np.testing.assert_array_equal(ev.property_data("g").counts, ref)
+    d = cases.oracle_distance(oracle, coords, ocell, topo.mass, info["d"]["a"], info["d"]["b"], L.DIST_COM)
+    np.testing.assert_array_equal(ev.property_data("d").values.reshape(F, -1), d)
+    m = cases.oracle_distance(oracle, coords, ocell, topo.mass, info["m"]["a"], info["m"]["b"], L.DIST_MAX)
+    np.testing.assert_array_equal(ev.property_data("m").values.reshape(F, -1), m)

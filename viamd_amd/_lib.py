@@ -107,6 +107,7 @@ SIGNATURES = [
     ("vmd_devtraj_free", None, [_vp]),
     ("vmd_devtraj_interface", C.POINTER(TrajectoryI), [_vp]),
     ("vmd_devtraj_upload_frame", C.c_bool, [_vp, C.c_size_t, C.POINTER(Unitcell), c_float_p, c_float_p, c_float_p]),
+    ("vmd_devtraj_upload_atoms", C.c_bool, [_vp, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, c_float_p]),
     ("vmd_devtraj_synth", C.c_bool, [_vp, C.c_uint64, C.c_float, C.c_float, C.c_uint32, C.c_size_t, C.c_size_t]),
     ("vmd_devtraj_device_ptr", _vp, [_vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     ("vmd_downsample_histogram", None, [c_float_p, C.c_int, c_float_p, c_float_p, C.c_int]),
@@ -131,7 +132,7 @@ SIGNATURES = [
                                     _vp, _vp, _vp]),
     ("vmd_hip_sdf_ref_pose", C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_uint32, _vp, _vp, C.c_int, _vp]),
     ("vmd_hip_sdf_scatter", C.c_int, [_vp, _vp, C.c_size_t, C.c_size_t, _vp, C.c_uint32, C.c_int, _vp, C.c_int, C.c_int, _vp, _vp,
-                                      _vp, C.c_int, C.c_float, C.c_int, _vp]),
+                                      _vp, _vp, C.c_int, C.c_float, C.c_int, _vp]),
     ("vmd_hip_distance", C.c_int, [_vp, _vp, C.c_size_t, C.c_size_t, _vp, C.c_uint32, C.c_int, C.c_int, _vp, _vp, C.c_int,
                                    _vp, _vp, C.c_int, _vp]),
     ("vmd_hip_counts_to_float", C.c_int, [_vp, _vp, C.c_size_t, _vp, _vp]),

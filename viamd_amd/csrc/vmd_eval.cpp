@@ -286,6 +286,8 @@ struct PropState {
     bool same_set = false;
     // SDF
     DevBuf<int32_t> d_structs, d_tgt;
+    DevBuf<int8_t> d_owner;
+    bool have_owner = false;
     DevBuf<float> d_mass;
     DevBuf<double> d_ref_pose;
     DevBuf<float> d_R32, d_c32;
@@ -568,6 +570,22 @@ static bool upload_static(vmd_script_eval_t* e, const vmd_system_t* sys) {
             masses(d.a, tmp);
             if (!p->d_mass.upload(tmp.data(), tmp.size(), e->stream)) return false;
             if (!p->d_ref_pose.ensure(d.m * 3)) return false;
+            // owner[t]: the structure target t is a member of (exclusion rule); only valid when memberships are unique
+            std::vector<int8_t> owner(d.b.size(), (int8_t)-1);
+            bool unique = d.K <= 127;
+            if (unique) {
+                std::map<int32_t, int> where;
+                for (size_t k = 0; k < d.K && unique; ++k)
+                    for (size_t a = 0; a < d.m; ++a) {
+                        auto it = where.find(d.a[k * d.m + a]);
+                        if (it != where.end() && it->second != (int)k) { unique = false; break; }
+                        where[d.a[k * d.m + a]] = (int)k;
+                    }
+                if (unique) for (size_t t = 0; t < d.b.size(); ++t) { auto it = where.find(d.b[t]); if (it != where.end()) owner[t] = (int8_t)it->second; }
+            }
+            p->have_owner = unique;
+            if (unique && !p->d_owner.upload(owner.data(), owner.size(), e->stream)) return false;
+            HIP_OK(hipStreamSynchronize(e->stream));
         } else if (d.kind == PROP_DIST) {
             if (!p->d_a.upload(d.a.data(), d.a.size(), e->stream)) return false;
             if (!p->d_b.upload(d.b.data(), d.b.size(), e->stream)) return false;
@@ -793,7 +811,7 @@ extern "C" bool vmd_eval_frame_range(vmd_script_eval_t* eval, const vmd_script_i
                 e->prof.end(e->stream);
                 e->prof.begin("sdf_scatter", e->stream);
                 KRN_OK(vmd_hip_sdf_scatter(e->stream, src.base, src.frame_stride, src.row_stride, e->d_boxes.p, pbc, (int)nb,
-                                           p->d_structs.p, (int)d.K, (int)d.m, p->d_R32.p, p->d_c32.p, p->d_tgt.p, (int)d.b.size(),
+                                           p->d_structs.p, (int)d.K, (int)d.m, p->d_R32.p, p->d_c32.p, p->d_tgt.p, p->have_owner ? p->d_owner.p : nullptr, (int)d.b.size(),
                                            d.rmax, VMD_VOLUME_DIM, p->d_counts.p));
                 e->prof.end(e->stream);
                 p->dirty = true;
@@ -930,6 +948,17 @@ extern "C" bool vmd_devtraj_upload_frame(vmd_devtraj_t* t, size_t frame, const v
     HIP_OK(hipMemcpy(f + t->npad, y, t->num_atoms * sizeof(float), hipMemcpyHostToDevice));
     HIP_OK(hipMemcpy(f + 2 * t->npad, z, t->num_atoms * sizeof(float), hipMemcpyHostToDevice));
     if (cell) t->cells[frame] = *cell;
+    return true;
+}
+
+extern "C" bool vmd_devtraj_upload_atoms(vmd_devtraj_t* t, size_t frame_beg, size_t frame_count, size_t first_atom, size_t atom_count,
+                                        const float* xyz /* [frame_count][3][atom_count] */) {
+    if (!t || frame_beg + frame_count > t->num_frames || first_atom + atom_count > t->num_atoms) return vmd_fail("vmd_devtraj_upload_atoms: bad range");
+    for (size_t f = 0; f < frame_count; ++f)
+        for (int c = 0; c < 3; ++c)
+            HIP_OK(hipMemcpyAsync(t->d + (frame_beg + f) * 3 * t->npad + (size_t)c * t->npad + first_atom,
+                                  xyz + (f * 3 + c) * atom_count, atom_count * sizeof(float), hipMemcpyHostToDevice, nullptr));
+    HIP_OK(hipDeviceSynchronize());
     return true;
 }
 

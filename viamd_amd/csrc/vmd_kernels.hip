@@ -25,7 +25,7 @@
 
 #define VMD_WAVE 64
 #define VMD_MAX_BINS 1024
-#define VMD_QUEUE_CAP 320          // < 64 pending + 4 undrained candidate columns of 64
+#define VMD_QUEUE_CAP 384          // < 64 pending + 4 undrained candidate columns of 64, + 64 per-lane dump slots
 #define VMD_FAR 1.0e18f            // coordinate of a padding lane: never within any cutoff, squares stay finite
 
 // Wave-uniform read-only data (j coordinates, cell offsets, boxes) is read through the constant address space so
@@ -37,6 +37,11 @@
 typedef VMD_UNIFORM_AS const float vmd_cf32;
 typedef VMD_UNIFORM_AS const uint32_t vmd_cu32;
 typedef float vmd_f2 __attribute__((vector_size(8)));   // two fp32 lanes of one VGPR/SGPR pair (v_pk_*_f32)
+typedef float vmd_f4 __attribute__((vector_size(16), aligned(4)));
+// four consecutive wave-uniform floats at byte offset `off` (32-bit: s_load_dwordx4 sdst, sbase, soffset)
+__device__ __forceinline__ vmd_f4 vmd_uniform_load4(vmd_cf32* base, unsigned off) {
+    return *(VMD_UNIFORM_AS const vmd_f4*)((VMD_UNIFORM_AS const char*)base + off);
+}
 
 // ------------------------------------------------------------------------------------------------ helpers
 
@@ -209,8 +214,9 @@ struct vmd_pair_params_t {
 // per-wave state of the hit machinery
 struct vmd_wave_acc_t {
     unsigned* hist;       // LDS, nbins
-    float* queue;         // LDS, VMD_QUEUE_CAP
-    unsigned qtail;       // wave-uniform stack height
+    char* qbase;          // LDS, VMD_QUEUE_CAP floats: the wave's hit stack
+    char* qptr;           // wave-uniform top of the stack (byte address)
+    float* dump;          // per-lane scratch slot: where the non-hit lanes of a push write
     unsigned ncols;       // wave-uniform: candidate columns (<= 64 hits each) since the last flush
 };
 
@@ -247,19 +253,21 @@ __device__ __forceinline__ void vmd_push(const vmd_binning_t& bn, vmd_wave_acc_t
     }
     const unsigned long long mask = __ballot(hit);
     if (mask) {
+        // every lane stores (no exec-mask juggling): hit lanes to their compacted slot, the others to a private dump slot
         const unsigned pre = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-        if (hit) (w.queue + w.qtail)[pre] = d2;
-        w.qtail += (unsigned)__popcll(mask);
+        float* slot = hit ? (float*)(w.qptr + 4u * pre) : w.dump;
+        *slot = d2;
+        w.qptr += 4u * (unsigned)__popcll(mask);
     }
 }
 
 template <int VARIANT, unsigned INC>
 __device__ __forceinline__ void vmd_drain_full(const vmd_binning_t& bn, vmd_wave_acc_t& w, int lane) {
     if (VARIANT == 1) return;
-    while (w.qtail >= VMD_WAVE) {
-        w.qtail -= VMD_WAVE;
+    while (w.qptr - w.qbase >= 4 * VMD_WAVE) {
+        w.qptr -= 4 * VMD_WAVE;
         __builtin_amdgcn_wave_barrier();
-        const float v = (w.queue + w.qtail)[lane];
+        const float v = ((const float*)w.qptr)[lane];
         __builtin_amdgcn_wave_barrier();
         vmd_bin_add<INC>(bn, w.hist, v, true);
     }
@@ -269,11 +277,11 @@ template <int VARIANT, unsigned INC>
 __device__ __forceinline__ void vmd_drain(const vmd_binning_t& bn, vmd_wave_acc_t& w, int lane) {
     if (VARIANT == 1) return;
     vmd_drain_full<VARIANT, INC>(bn, w, lane);
-    const unsigned rem = w.qtail;
+    const unsigned rem = (unsigned)(w.qptr - w.qbase) / 4u;
     __builtin_amdgcn_wave_barrier();
-    const float v = w.queue[lane];
+    const float v = ((const float*)w.qbase)[lane];
     __builtin_amdgcn_wave_barrier();
-    w.qtail = 0;
+    w.qptr = w.qbase;
     vmd_bin_add<INC>(bn, w.hist, v, (unsigned)lane < rem);
 }
 
@@ -287,16 +295,14 @@ __device__ __forceinline__ void vmd_segment_loop(const vmd_pair_params_t& p, vmd
     vmd_cf32* px = tx + ja;
     vmd_cf32* py = ty + ja;
     vmd_cf32* pz = tz + ja;
-    int n = (int)(jb - ja);
-    unsigned j = ja;
+    const unsigned n = jb - ja;
     // two j columns per VALU instruction: v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32 are IEEE per element, so the
     // arithmetic is still SPEC S3 exactly; the j pair sits in an SGPR pair straight from s_load_dwordx4
     const vmd_f2 xi2 = {xi, xi}, yi2 = {yi, yi}, zi2 = {zi, zi};
     const vmd_f2 sx2 = {sx, sx}, sy2 = {sy, sy}, sz2 = {sz, sz};
-    for (; n >= 4; n -= 4, px += 4, py += 4, pz += 4, j += 4) {
-        float xj[4], yj[4], zj[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) { xj[u] = px[u]; yj[u] = py[u]; zj[u] = pz[u]; }
+    unsigned k = 0;
+    for (; k + 4 <= n; k += 4) {
+        const vmd_f4 xj = vmd_uniform_load4(px, 4u * k), yj = vmd_uniform_load4(py, 4u * k), zj = vmd_uniform_load4(pz, 4u * k);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const vmd_f2 xj2 = {xj[2 * h], xj[2 * h + 1]}, yj2 = {yj[2 * h], yj[2 * h + 1]}, zj2 = {zj[2 * h], zj[2 * h + 1]};
@@ -306,18 +312,18 @@ __device__ __forceinline__ void vmd_segment_loop(const vmd_pair_params_t& p, vmd
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 bool hit = d2[u] < r2;
-                if (MASKED) hit = hit && (j + 2 * h + u > i);
+                if (MASKED) hit = hit && (ja + k + 2 * h + u > i);
                 vmd_push<VARIANT, INC>(p.bin, w, hit, d2[u]);
             }
         }
         vmd_drain_full<VARIANT, INC>(p.bin, w, lane);
     }
-    for (int u = 0; u < n; ++u) {
-        float dx = xi - px[u], dy = yi - py[u], dz = zi - pz[u];
+    for (; k < n; ++k) {
+        float dx = xi - px[k], dy = yi - py[k], dz = zi - pz[k];
         if (SHIFT) { dx = dx - sx; dy = dy - sy; dz = dz - sz; }
         const float d2 = vmd_d2(dx, dy, dz);
         bool hit = d2 < r2;
-        if (MASKED) hit = hit && (j + u > i);
+        if (MASKED) hit = hit && (ja + k > i);
         vmd_push<VARIANT, INC>(p.bin, w, hit, d2);
     }
     vmd_drain_full<VARIANT, INC>(p.bin, w, lane);
@@ -348,8 +354,10 @@ __global__ __launch_bounds__(256) void k_rdf_pencil(vmd_pair_params_t p) {
 
     vmd_wave_acc_t w;
     w.hist = s_hist[wave];
-    w.queue = s_queue[wave];
-    w.qtail = 0; w.ncols = 0;
+    w.qbase = (char*)s_queue[wave];
+    w.qptr = w.qbase;
+    w.dump = &s_queue[wave][VMD_QUEUE_CAP - VMD_WAVE + lane];
+    w.ncols = 0;
     for (int b = lane; b < nbins; b += VMD_WAVE) w.hist[b] = 0u;
     __builtin_amdgcn_wave_barrier();
 
@@ -690,7 +698,7 @@ struct vmd_scatter_params_t {
     const float* __restrict__ boxes; uint32_t pbc; int B;
     const int32_t* __restrict__ structs; int K; int m;
     const float* __restrict__ R32; const float* __restrict__ c32;
-    const int32_t* __restrict__ tgt; int ntgt; float extent; int dim;
+    const int32_t* __restrict__ tgt; const int8_t* __restrict__ owner; int ntgt; float extent; int dim;
     unsigned long long* volume;
 };
 
@@ -706,11 +714,17 @@ __global__ __launch_bounds__(256) void k_sdf_scatter(vmd_scatter_params_t p) {
     const float s = p.extent;
     const float vscale = (float)p.dim / (2.0f * s);
     const float fdim = (float)p.dim;
+    // SPEC D-SDF-EXCL: a target atom is skipped for the structure it belongs to.  owner[t] (structure index or -1) is
+    // precomputed on the host for K <= 127; without it the membership test walks the structure's index list.
+    const int own_k = p.owner ? (int)p.owner[t] : -2;
     for (int k = 0; k < p.K; ++k) {
-        const int32_t* sidx = p.structs + (size_t)k * p.m;
-        bool own = false;
-        for (int a = 0; a < p.m; ++a) own = own || (sidx[a] == i);
-        if (own) continue;
+        if (own_k == k) continue;
+        if (own_k == -2) {
+            const int32_t* sidx = p.structs + (size_t)k * p.m;
+            bool own = false;
+            for (int a = 0; a < p.m; ++a) own = own || (sidx[a] == i);
+            if (own) continue;
+        }
         const float* R = p.R32 + ((size_t)b * p.K + k) * 9;
         const float* c = p.c32 + ((size_t)b * p.K + k) * 3;
         const float dx = vmd_mi_rintf(x - c[0], Lx, px);
@@ -974,10 +988,10 @@ extern "C" int vmd_hip_sdf_ref_pose(void* stream, const float* xyz, size_t row_s
 extern "C" int vmd_hip_sdf_scatter(void* stream, const float* xyz, size_t frame_stride, size_t row_stride,
                                    const float* boxes, uint32_t pbc_flags, int B,
                                    const int32_t* structs, int K, int m, const float* R32, const float* c32,
-                                   const int32_t* tgt, int ntgt, float extent, int dim, uint64_t* volume) {
+                                   const int32_t* tgt, const int8_t* owner, int ntgt, float extent, int dim, uint64_t* volume) {
     hipStream_t s = (hipStream_t)stream;
     if (B <= 0 || K <= 0 || ntgt <= 0) return 0;
-    vmd_scatter_params_t p{xyz, frame_stride, row_stride, boxes, pbc_flags, B, structs, K, m, R32, c32, tgt, ntgt, extent, dim,
+    vmd_scatter_params_t p{xyz, frame_stride, row_stride, boxes, pbc_flags, B, structs, K, m, R32, c32, tgt, owner, ntgt, extent, dim,
                            (unsigned long long*)volume};
     hipLaunchKernelGGL(k_sdf_scatter, dim3((ntgt + 255) / 256, B), dim3(256), 0, s, p);
     VMD_LAUNCH_CHECK();

@@ -1,0 +1,271 @@
+"""Mini front-end for the subset of the VIAMD script language the hot path needs.
+
+Stands in for md_script_ir_compile_from_source (/root/reference/src/main.cpp:878) for scripts of the forms VIAMD itself
+generates or ships as defaults (src/main.cpp:528, :2817-2858):
+
+    s1 = resname("ALA")[2:8];
+    r  = rdf(element('C'), element('H'), 10.0);
+    v  = sdf(s1, element('H'), 10.0);
+    d1 = distance(10, 30);          # 1-based atom indices (src/main.cpp:2817)
+    d2 = distance_min(residue(3), water);
+
+Selections: element('X') | type/name('X') | resname("X") | residue(a:b) | resid(a:b) | atom(a:b) | integer | all | water |
+protein, combined with `and`, `or`, `not`, parentheses; `sel[a:b]` slices an array of structures (1-based, inclusive).
+The output is a ScriptIR of property descriptors (vmd_ir_add_rdf/_sdf/_distance); nothing is evaluated here.
+"""
+import re
+
+import numpy as np
+
+from . import _lib as L
+from .eval import ScriptIR
+
+WATER_RESNAMES = {"HOH", "WAT", "SOL", "TIP3", "TIP4", "SPC", "H2O"}
+PROTEIN_RESNAMES = {"ALA", "ARG", "ASN", "ASP", "CYS", "GLN", "GLU", "GLY", "HIS", "ILE", "LEU", "LYS", "MET", "PHE", "PRO",
+                    "SER", "THR", "TRP", "TYR", "VAL"}
+
+
+class ScriptError(ValueError):
+    pass
+
+
+class Topology:
+    """What selections are resolved against: per-atom element / name / residue name / residue index (0-based, contiguous)."""
+
+    def __init__(self, elements, resnames=None, residue_index=None, names=None, mass=None):
+        self.elements = np.asarray(elements)
+        n = self.elements.size
+        self.resnames = np.asarray(resnames) if resnames is not None else np.array(["UNK"] * n)
+        self.residue_index = np.asarray(residue_index, dtype=np.int64) if residue_index is not None else np.zeros(n, np.int64)
+        self.names = np.asarray(names) if names is not None else self.elements
+        self.mass = mass
+        self.num_atoms = n
+        self.num_residues = int(self.residue_index.max()) + 1 if n else 0
+        # atom range of every residue (residues are contiguous runs of atoms)
+        order = np.argsort(self.residue_index, kind="stable")
+        self._res_atoms = np.split(order, np.cumsum(np.bincount(self.residue_index, minlength=self.num_residues))[:-1])
+
+    def residue_atoms(self, r):
+        return np.sort(self._res_atoms[r])
+
+    def residue_name(self, r):
+        return str(self.resnames[self._res_atoms[r][0]])
+
+
+class Sel:
+    """A selection value: a boolean atom mask plus, when it came from a per-residue construct, the list of structures."""
+
+    def __init__(self, mask, structures=None):
+        self.mask = mask
+        self.structures = structures      # list of index arrays, or None
+
+    def indices(self):
+        return np.nonzero(self.mask)[0].astype(np.int32)
+
+
+_TOKEN = re.compile(r"""\s*(?:(?P<num>\d+\.\d*(?:[eE][-+]?\d+)?|\.\d+|\d+)|(?P<str>'[^']*'|"[^"]*")|(?P<id>[A-Za-z_]\w*)|(?P<op>[=(),;:\[\]{}]))""")
+
+
+def _tokenize(text):
+    text = re.sub(r"#[^\n]*", "", text)
+    pos, out = 0, []
+    while pos < len(text):
+        m = _TOKEN.match(text, pos)
+        if not m:
+            if text[pos:].strip() == "":
+                break
+            raise ScriptError(f"unexpected character {text[pos:].strip()[0]!r} at offset {pos}")
+        pos = m.end()
+        kind = m.lastgroup
+        out.append((kind, m.group(kind)))
+    return out
+
+
+class _Parser:
+    def __init__(self, tokens, topo, env):
+        self.t, self.i, self.topo, self.env = tokens, 0, topo, env
+
+    def peek(self):
+        return self.t[self.i] if self.i < len(self.t) else (None, None)
+
+    def take(self, value=None, kind=None):
+        k, v = self.peek()
+        if k is None or (value is not None and v != value) or (kind is not None and k != kind):
+            raise ScriptError(f"expected {value or kind}, found {v!r}")
+        self.i += 1
+        return v
+
+    def accept(self, value):
+        if self.peek()[1] == value:
+            self.i += 1
+            return True
+        return False
+
+    # range a[:b], 1-based inclusive -> python slice bounds (0-based, exclusive)
+    def range_(self):
+        a = int(self.take(kind="num"))
+        b = a
+        if self.accept(":"):
+            b = int(self.take(kind="num"))
+        if a < 1 or b < a:
+            raise ScriptError(f"bad range {a}:{b} (script indices are 1-based)")
+        return a - 1, b
+
+    def sel_or(self):
+        s = self.sel_and()
+        while self.accept("or"):
+            s = Sel(s.mask | self.sel_and().mask)
+        return s
+
+    def sel_and(self):
+        s = self.sel_not()
+        while self.accept("and"):
+            r = self.sel_not()
+            structs = None
+            if s.structures is not None:      # per-structure intersection keeps the array shape
+                structs = [st[r.mask[st]] for st in s.structures]
+            s = Sel(s.mask & r.mask, structs)
+        return s
+
+    def sel_not(self):
+        if self.accept("not"):
+            return Sel(~self.sel_not().mask)
+        return self.sel_postfix()
+
+    def sel_postfix(self):
+        s = self.sel_atom()
+        while self.accept("["):
+            a, b = self.range_()
+            self.take("]")
+            if s.structures is None:
+                raise ScriptError("[a:b] applies to an array of structures (resname(...), residue(...))")
+            if b > len(s.structures):
+                raise ScriptError(f"slice [{a + 1}:{b}] exceeds the {len(s.structures)} structures of the selection")
+            st = s.structures[a:b]
+            mask = np.zeros(self.topo.num_atoms, bool)
+            for x in st:
+                mask[x] = True
+            s = Sel(mask, st)
+        return s
+
+    def _residues(self, pred):
+        topo = self.topo
+        st = [topo.residue_atoms(r) for r in range(topo.num_residues) if pred(r)]
+        mask = np.zeros(topo.num_atoms, bool)
+        for x in st:
+            mask[x] = True
+        return Sel(mask, st)
+
+    def sel_atom(self):
+        k, v = self.peek()
+        topo = self.topo
+        if v == "(":
+            self.take("(")
+            s = self.sel_or()
+            self.take(")")
+            return s
+        if k == "num":
+            a, b = self.range_()
+            if b > topo.num_atoms:
+                raise ScriptError(f"atom index {b} out of range (system has {topo.num_atoms} atoms)")
+            mask = np.zeros(topo.num_atoms, bool)
+            mask[a:b] = True
+            return Sel(mask)
+        if k != "id":
+            raise ScriptError(f"unexpected token {v!r} in selection")
+        self.i += 1
+        if v in self.env and isinstance(self.env[v], Sel):
+            return self.env[v]
+        if v == "all":
+            return Sel(np.ones(topo.num_atoms, bool))
+        if v == "water":
+            return self._residues(lambda r: topo.residue_name(r).upper() in WATER_RESNAMES)
+        if v == "protein":
+            return self._residues(lambda r: topo.residue_name(r).upper() in PROTEIN_RESNAMES)
+        if v in ("element", "type", "name", "label", "resname"):
+            self.take("(")
+            names = [self.take(kind="str")[1:-1]]
+            while self.accept(","):
+                names.append(self.take(kind="str")[1:-1])
+            self.take(")")
+            if v == "resname":
+                return self._residues(lambda r: topo.residue_name(r) in names)
+            arr = topo.elements if v == "element" else topo.names
+            return Sel(np.isin(arr, names))
+        if v in ("residue", "resid", "atom"):
+            self.take("(")
+            a, b = self.range_()
+            self.take(")")
+            if v == "atom":
+                if b > topo.num_atoms:
+                    raise ScriptError(f"atom({b}) out of range")
+                mask = np.zeros(topo.num_atoms, bool)
+                mask[a:b] = True
+                return Sel(mask)
+            if b > topo.num_residues:
+                raise ScriptError(f"{v}({b}) out of range (system has {topo.num_residues} residues)")
+            return self._residues(lambda r: a <= r < b)
+        raise ScriptError(f"unknown identifier {v!r}")
+
+    def number(self):
+        return float(self.take(kind="num"))
+
+
+_FUNCS = {"rdf", "sdf", "distance", "distance_min", "distance_max", "distance_pair"}
+_DIST_KIND = {"distance": L.DIST_COM, "distance_min": L.DIST_MIN, "distance_max": L.DIST_MAX, "distance_pair": L.DIST_PAIR}
+
+
+def compile_script(text, topo, lib=None):
+    """Returns (ScriptIR, info) where info[name] = dict(kind=..., plus the resolved index arrays)."""
+    ir = ScriptIR(lib)
+    env, info = {}, {}
+    p = _Parser(_tokenize(text), topo, env)
+    while p.peek()[0] is not None:
+        if p.accept(";"):
+            continue
+        name = p.take(kind="id")
+        p.take("=")
+        k, v = p.peek()
+        if k == "id" and v in _FUNCS:
+            p.i += 1
+            p.take("(")
+            if v == "rdf":
+                ref = p.sel_or(); p.take(",")
+                tgt = p.sel_or(); p.take(",")
+                if p.accept("{"):
+                    rmin = p.number(); p.take(","); rmax = p.number(); p.take("}")
+                else:
+                    rmin, rmax = 0.0, p.number()
+                    if p.accept(":"):
+                        rmin, rmax = rmax, p.number()
+                p.take(")")
+                a, b = ref.indices(), tgt.indices()
+                if a.size == 0 or b.size == 0:
+                    raise ScriptError(f"{name}: empty selection")
+                ir.add_rdf(name, a, b, (rmin, rmax))
+                info[name] = dict(kind="rdf", ref=a, target=b, rmin=rmin, rmax=rmax)
+            elif v == "sdf":
+                ref = p.sel_or(); p.take(",")
+                tgt = p.sel_or(); p.take(",")
+                cutoff = p.number()
+                p.take(")")
+                structs = ref.structures if ref.structures is not None else [ref.indices()]
+                sizes = {len(s) for s in structs}
+                if len(sizes) != 1 or 0 in sizes:
+                    raise ScriptError(f"{name}: sdf reference structures must be non-empty and of equal size, got sizes {sorted(sizes)}")
+                st = np.stack([np.asarray(s, np.int32) for s in structs])
+                ir.add_sdf(name, st, tgt.indices(), cutoff)
+                info[name] = dict(kind="sdf", structures=st, target=tgt.indices(), cutoff=cutoff)
+            else:
+                a = p.sel_or(); p.take(",")
+                b = p.sel_or()
+                p.take(")")
+                if p.peek()[1] == "in":
+                    raise ScriptError(f"{name}: `in <context>` populations are not supported by this front-end")
+                ir.add_distance(name, a.indices(), b.indices(), _DIST_KIND[v])
+                info[name] = dict(kind=v, a=a.indices(), b=b.indices())
+        else:
+            env[name] = p.sel_or()
+        if p.peek()[0] is not None:
+            p.take(";")
+    return ir, info

@@ -100,6 +100,13 @@ class DeviceTrajectory:
         for f in range(coords.shape[0]):
             self.upload_frame(f, cells[f], coords[f, 0], coords[f, 1], coords[f, 2])
 
+    def upload_atoms(self, frame_beg, first_atom, xyz):
+        """Overwrite a block of atoms in consecutive frames: xyz float32 [F, 3, n]."""
+        xyz = np.ascontiguousarray(xyz, np.float32)
+        if not self.lib.vmd_devtraj_upload_atoms(self.h, int(frame_beg), xyz.shape[0], int(first_atom), xyz.shape[2],
+                                                 xyz.ctypes.data_as(L.c_float_p)):
+            raise VmdError(self.lib.last_error())
+
     def synth(self, seed, L_box, sigma=0.05, n_blob=0, frame_beg=0, frame_end=None):
         """Fill frames with the seeded synthetic water box of SURVEY.md 8d (generated on the device)."""
         frame_end = self._num_frames if frame_end is None else frame_end
