@@ -98,6 +98,7 @@ typedef struct emu_event_t* hipEvent_t;
 enum hipMemcpyKind { hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3 };
 #define hipStreamNonBlocking 1
 #define hipHostMallocDefault 0
+#define hipHostRegisterDefault 0
 
 static inline const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "success" : "emu error"; }
 static inline hipError_t hipGetLastError() { return hipSuccess; }
@@ -112,6 +113,8 @@ static inline hipError_t hipMalloc(void** p, size_t n) { *p = calloc(n ? n : 1, 
 static inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
 static inline hipError_t hipHostMalloc(void** p, size_t n, unsigned) { return hipMalloc(p, n); }
 static inline hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
+static inline hipError_t hipHostRegister(void*, size_t, unsigned) { return hipSuccess; }
+static inline hipError_t hipHostUnregister(void*) { return hipSuccess; }
 static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }

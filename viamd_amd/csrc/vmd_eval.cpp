@@ -296,6 +296,8 @@ struct PropState {
     DevBuf<int32_t> d_a, d_b;
     DevBuf<float> d_ma, d_mb, d_out;
     bool uploaded = false;
+    bool pinned = false;
+    ~PropState() { if (pinned) { (void)hipHostUnregister(values.data()); (void)hipHostUnregister(counts.data()); } }
     bool dirty = false;                 // device accumulators changed since the last host refresh
 };
 
@@ -365,6 +367,10 @@ extern "C" vmd_script_eval_t* vmd_eval_create(size_t num_frames, const vmd_scrip
             st->ncounts = (size_t)VMD_VOLUME_DIM * VMD_VOLUME_DIM * VMD_VOLUME_DIM;
             st->values.assign(st->ncounts, 0.0f);
             st->counts.assign(st->ncounts, 0);
+            // the 8 + 17 MB host views of a volume are pinned: their D2H refresh runs at PCIe speed
+            st->pinned = hipHostRegister(st->values.data(), st->ncounts * sizeof(float), hipHostRegisterDefault) == hipSuccess &&
+                         hipHostRegister(st->counts.data(), st->ncounts * sizeof(uint64_t), hipHostRegisterDefault) == hipSuccess;
+            if (!st->pinned) (void)hipGetLastError();
             st->data.dim[0] = 1; st->data.dim[1] = st->data.dim[2] = st->data.dim[3] = VMD_VOLUME_DIM;
             st->data.min_range[0] = -p.rmax; st->data.max_range[0] = p.rmax;
             break;
@@ -617,7 +623,7 @@ struct BatchSrc {
 static bool fetch_batch(vmd_script_eval_t* e, vmd_trajectory_i* traj, const vmd_device_view_t* view, size_t num_atoms,
                         size_t f0, size_t nb, BatchSrc* src) {
     e->cells.resize(nb);
-    e->h_boxes.resize(nb * 3);
+    e->h_boxes.resize(nb * 6);
     if (view) {
         src->base = view->base + f0 * view->frame_stride;
         src->frame_stride = view->frame_stride;
@@ -650,9 +656,11 @@ static bool fetch_batch(vmd_script_eval_t* e, vmd_trajectory_i* traj, const vmd_
         const vmd_unitcell_t& c = e->cells[b];
         if (c.xy != 0.0f || c.xz != 0.0f || c.yz != 0.0f) return vmd_fail("frame %zu: triclinic unit cells are not supported (SPEC D-TRICLINIC)", f0 + b);
         if (c.flags != e->cells[0].flags) return vmd_fail("frame %zu: periodicity flags change inside the trajectory", f0 + b);
-        e->h_boxes[3 * b + 0] = c.x; e->h_boxes[3 * b + 1] = c.y; e->h_boxes[3 * b + 2] = c.z;
+        float* hb = &e->h_boxes[6 * b];
+        hb[0] = c.x; hb[1] = c.y; hb[2] = c.z;
+        hb[3] = 1.0f / c.x; hb[4] = 1.0f / c.y; hb[5] = 1.0f / c.z;      // SPEC S2: invL = fl(1.0f / L)
     }
-    if (!e->d_boxes.upload(e->h_boxes.data(), nb * 3, e->stream)) return false;
+    if (!e->d_boxes.upload(e->h_boxes.data(), nb * 6, e->stream)) return false;
     return true;
 }
 
@@ -670,7 +678,7 @@ static bool choose_grid(const vmd_script_eval_t* e, size_t nb, float rmax, vmd_g
     if (g_opt.force_brute) return false;
     if (batch_pbc(e) != VMD_UNITCELL_PBC_ALL) return false;
     float Lmin[3] = {3.4e38f, 3.4e38f, 3.4e38f};
-    for (size_t b = 0; b < nb; ++b) for (int a = 0; a < 3; ++a) Lmin[a] = std::min(Lmin[a], e->h_boxes[3 * b + a]);
+    for (size_t b = 0; b < nb; ++b) for (int a = 0; a < 3; ++a) Lmin[a] = std::min(Lmin[a], e->h_boxes[6 * b + a]);
     // minimum image must be unique for every hit: rmax < L/2 with margin
     for (int a = 0; a < 3; ++a) if (!(rmax * 2.0f * 1.001f < Lmin[a])) return false;
     int n[3];
@@ -790,7 +798,7 @@ extern "C" bool vmd_eval_frame_range(vmd_script_eval_t* eval, const vmd_script_i
                 }
                 // SPEC S4 normalisation, fp64 on the host (needs only the box)
                 for (size_t b = 0; b < nb; ++b) {
-                    const float* L = &e->h_boxes[3 * b];
+                    const float* L = &e->h_boxes[6 * b];
                     double V;
                     if (pbc == VMD_UNITCELL_PBC_ALL) V = (double)L[0] * (double)L[1] * (double)L[2];
                     else V = (4.0 / 3.0) * M_PI * (double)d.rmax * (double)d.rmax * (double)d.rmax;

@@ -46,8 +46,8 @@ __device__ __forceinline__ vmd_f4 vmd_uniform_load4(vmd_cf32* base, unsigned off
 // ------------------------------------------------------------------------------------------------ helpers
 
 // SPEC S2
-__device__ __forceinline__ float vmd_wrap(float x, float L) {
-    const float invL = 1.0f / L;
+// invL = fl(1.0f / L), computed once per frame on the host (IEEE division, identical to the device's)
+__device__ __forceinline__ float vmd_wrap(float x, float L, float invL) {
     const float t = x * invL;
     const float f = floorf(t);
     float xw = fmaf(-f, L, x);
@@ -68,11 +68,8 @@ __device__ __forceinline__ float vmd_mi_cmp(float d, float L, float hL, bool pbc
 }
 
 // SPEC S5/S6 fp32 minimum image by rint
-__device__ __forceinline__ float vmd_mi_rintf(float d, float L, bool pbc) {
-    if (pbc) {
-        const float invL = 1.0f / L;
-        d = fmaf(-rintf(d * invL), L, d);
-    }
+__device__ __forceinline__ float vmd_mi_rintf(float d, float L, float invL, bool pbc) {
+    if (pbc) d = fmaf(-rintf(d * invL), L, d);
     return d;
 }
 
@@ -140,13 +137,14 @@ struct vmd_cells_params_t {
 __device__ __forceinline__ uint32_t vmd_cell_of(const vmd_cells_params_t& p, int b, int t, float& xw, float& yw, float& zw) {
     const int a = p.sel ? p.sel[t] : t;
     const float* fx = p.xyz + (size_t)b * p.frame_stride;
-    const float Lx = p.boxes[3 * b + 0], Ly = p.boxes[3 * b + 1], Lz = p.boxes[3 * b + 2];
-    xw = vmd_wrap(fx[a], Lx);
-    yw = vmd_wrap(fx[p.row_stride + a], Ly);
-    zw = vmd_wrap(fx[2 * p.row_stride + a], Lz);
-    const int cx = vmd_cell_coord(xw, (float)p.grid.nxf / Lx, p.grid.nxf);
-    const int cy = vmd_cell_coord(yw, (float)p.grid.ny / Ly, p.grid.ny);
-    const int cz = vmd_cell_coord(zw, (float)p.grid.nz / Lz, p.grid.nz);
+    const float Lx = p.boxes[6 * b + 0], Ly = p.boxes[6 * b + 1], Lz = p.boxes[6 * b + 2];
+    const float iLx = p.boxes[6 * b + 3], iLy = p.boxes[6 * b + 4], iLz = p.boxes[6 * b + 5];
+    xw = vmd_wrap(fx[a], Lx, iLx);
+    yw = vmd_wrap(fx[p.row_stride + a], Ly, iLy);
+    zw = vmd_wrap(fx[2 * p.row_stride + a], Lz, iLz);
+    const int cx = vmd_cell_coord(xw, (float)p.grid.nxf * iLx, p.grid.nxf);
+    const int cy = vmd_cell_coord(yw, (float)p.grid.ny * iLy, p.grid.ny);
+    const int cz = vmd_cell_coord(zw, (float)p.grid.nz * iLz, p.grid.nz);
     return (uint32_t)((cz * p.grid.ny + cy) * p.grid.nxf + cx);
 }
 
@@ -379,8 +377,8 @@ __global__ __launch_bounds__(256) void k_rdf_pencil(vmd_pair_params_t p) {
         const int pz = pen / ny;
         const int py = pen - pz * ny;
         vmd_cf32* boxes = (vmd_cf32*)p.boxes;
-        const float Lx = boxes[3 * b + 0], Ly = boxes[3 * b + 1], Lz = boxes[3 * b + 2];
-        const float inv_cx = (float)nxf / Lx;
+        const float Lx = boxes[6 * b + 0], Ly = boxes[6 * b + 1], Lz = boxes[6 * b + 2];
+        const float inv_cx = (float)nxf * boxes[6 * b + 3];
         vmd_cu32* csr = (vmd_cu32*)p.cs_ref + (size_t)b * (p.grid.ncell + 1);
         vmd_cu32* cst = (vmd_cu32*)p.cs_tgt + (size_t)b * (p.grid.ncell + 1);
         const float* __restrict__ sr = p.sref + (size_t)b * 3 * p.nref_pad;
@@ -489,25 +487,26 @@ __global__ __launch_bounds__(256) void k_rdf_brute(vmd_brute_params_t p) {
     const float* fy = fx + p.row_stride;
     const float* fz = fy + p.row_stride;
     const bool px = p.pbc & 1u, py = p.pbc & 2u, pz = p.pbc & 4u;
-    const float Lx = p.boxes[3 * b + 0], Ly = p.boxes[3 * b + 1], Lz = p.boxes[3 * b + 2];
+    const float Lx = p.boxes[6 * b + 0], Ly = p.boxes[6 * b + 1], Lz = p.boxes[6 * b + 2];
+    const float iLx = p.boxes[6 * b + 3], iLy = p.boxes[6 * b + 4], iLz = p.boxes[6 * b + 5];
     const float hx = 0.5f * Lx, hy = 0.5f * Ly, hz = 0.5f * Lz;
     for (int k = threadIdx.x; k < p.bin.nbins; k += 256) s_hist[k] = 0u;
     float xi = VMD_FAR, yi = VMD_FAR, zi = VMD_FAR;
     const bool valid = t < p.nref;
     if (valid) {
         const int a = p.ref ? p.ref[t] : t;
-        xi = px ? vmd_wrap(fx[a], Lx) : fx[a];
-        yi = py ? vmd_wrap(fy[a], Ly) : fy[a];
-        zi = pz ? vmd_wrap(fz[a], Lz) : fz[a];
+        xi = px ? vmd_wrap(fx[a], Lx, iLx) : fx[a];
+        yi = py ? vmd_wrap(fy[a], Ly, iLy) : fy[a];
+        zi = pz ? vmd_wrap(fz[a], Lz, iLz) : fz[a];
     }
     for (int j0 = 0; j0 < p.ntgt; j0 += 256) {
         __syncthreads();
         const int j = j0 + threadIdx.x;
         if (j < p.ntgt) {
             const int a = p.tgt ? p.tgt[j] : j;
-            s_t[0][threadIdx.x] = px ? vmd_wrap(fx[a], Lx) : fx[a];
-            s_t[1][threadIdx.x] = py ? vmd_wrap(fy[a], Ly) : fy[a];
-            s_t[2][threadIdx.x] = pz ? vmd_wrap(fz[a], Lz) : fz[a];
+            s_t[0][threadIdx.x] = px ? vmd_wrap(fx[a], Lx, iLx) : fx[a];
+            s_t[1][threadIdx.x] = py ? vmd_wrap(fy[a], Ly, iLy) : fy[a];
+            s_t[2][threadIdx.x] = pz ? vmd_wrap(fz[a], Lz, iLz) : fz[a];
         }
         __syncthreads();
         const int nj = p.ntgt - j0 < 256 ? p.ntgt - j0 : 256;
@@ -632,7 +631,7 @@ __global__ __launch_bounds__(64) void k_sdf_align(vmd_align_params_t p) {
     const float* fx = p.xyz + (size_t)b * p.frame_stride;
     const float* fy = fx + p.row_stride;
     const float* fz = fy + p.row_stride;
-    const double Lx = (double)p.boxes[3 * b + 0], Ly = (double)p.boxes[3 * b + 1], Lz = (double)p.boxes[3 * b + 2];
+    const double Lx = (double)p.boxes[6 * b + 0], Ly = (double)p.boxes[6 * b + 1], Lz = (double)p.boxes[6 * b + 2];
     const bool px = p.pbc & 1u, py = p.pbc & 2u, pz = p.pbc & 4u;
     const int32_t* idx = p.structs + (size_t)k * p.m;
     const float* mass = p.mass ? p.mass + (size_t)k * p.m : nullptr;
@@ -709,11 +708,13 @@ __global__ __launch_bounds__(256) void k_sdf_scatter(vmd_scatter_params_t p) {
     const int i = p.tgt ? p.tgt[t] : t;
     const float* fx = p.xyz + (size_t)b * p.frame_stride;
     const float x = fx[i], y = fx[p.row_stride + i], z = fx[2 * p.row_stride + i];
-    const float Lx = p.boxes[3 * b + 0], Ly = p.boxes[3 * b + 1], Lz = p.boxes[3 * b + 2];
+    const float Lx = p.boxes[6 * b + 0], Ly = p.boxes[6 * b + 1], Lz = p.boxes[6 * b + 2];
+    const float iLx = p.boxes[6 * b + 3], iLy = p.boxes[6 * b + 4], iLz = p.boxes[6 * b + 5];
     const bool px = p.pbc & 1u, py = p.pbc & 2u, pz = p.pbc & 4u;
     const float s = p.extent;
     const float vscale = (float)p.dim / (2.0f * s);
     const float fdim = (float)p.dim;
+    const float r2_skip = 3.0f * s * s * 1.001f + 1.0e-3f;
     // SPEC D-SDF-EXCL: a target atom is skipped for the structure it belongs to.  owner[t] (structure index or -1) is
     // precomputed on the host for K <= 127; without it the membership test walks the structure's index list.
     const int own_k = p.owner ? (int)p.owner[t] : -2;
@@ -727,9 +728,11 @@ __global__ __launch_bounds__(256) void k_sdf_scatter(vmd_scatter_params_t p) {
         }
         const float* R = p.R32 + ((size_t)b * p.K + k) * 9;
         const float* c = p.c32 + ((size_t)b * p.K + k) * 3;
-        const float dx = vmd_mi_rintf(x - c[0], Lx, px);
-        const float dy = vmd_mi_rintf(y - c[1], Ly, py);
-        const float dz = vmd_mi_rintf(z - c[2], Lz, pz);
+        const float dx = vmd_mi_rintf(x - c[0], Lx, iLx, px);
+        const float dy = vmd_mi_rintf(y - c[1], Ly, iLy, py);
+        const float dz = vmd_mi_rintf(z - c[2], Lz, iLz, pz);
+        // a voxel hit needs |q|_inf < s, hence |d|^2 = |q|^2 < 3 s^2: skip the rotation for everything outside that sphere
+        if (vmd_d2(dx, dy, dz) > r2_skip) continue;
         const float qx = fmaf(R[2], dz, fmaf(R[1], dy, R[0] * dx));
         const float qy = fmaf(R[5], dz, fmaf(R[4], dy, R[3] * dx));
         const float qz = fmaf(R[8], dz, fmaf(R[7], dy, R[6] * dx));
@@ -777,14 +780,15 @@ __global__ __launch_bounds__(64) void k_distance_com(vmd_dist_params_t p) {
     const float* fx = p.xyz + (size_t)b * p.frame_stride;
     const float* fy = fx + p.row_stride;
     const float* fz = fy + p.row_stride;
-    const float Lx = p.boxes[3 * b + 0], Ly = p.boxes[3 * b + 1], Lz = p.boxes[3 * b + 2];
+    const float Lx = p.boxes[6 * b + 0], Ly = p.boxes[6 * b + 1], Lz = p.boxes[6 * b + 2];
+    const float iLx = p.boxes[6 * b + 3], iLy = p.boxes[6 * b + 4], iLz = p.boxes[6 * b + 5];
     const bool px = p.pbc & 1u, py = p.pbc & 2u, pz = p.pbc & 4u;
     float ca[3], cb[3];
     vmd_set_com(fx, fy, fz, p.a, p.mass_a, p.na, (double)Lx, (double)Ly, (double)Lz, px, py, pz, ca);
     vmd_set_com(fx, fy, fz, p.b, p.mass_b, p.nb, (double)Lx, (double)Ly, (double)Lz, px, py, pz, cb);
-    const float dx = vmd_mi_rintf(ca[0] - cb[0], Lx, px);
-    const float dy = vmd_mi_rintf(ca[1] - cb[1], Ly, py);
-    const float dz = vmd_mi_rintf(ca[2] - cb[2], Lz, pz);
+    const float dx = vmd_mi_rintf(ca[0] - cb[0], Lx, iLx, px);
+    const float dy = vmd_mi_rintf(ca[1] - cb[1], Ly, iLy, py);
+    const float dz = vmd_mi_rintf(ca[2] - cb[2], Lz, iLz, pz);
     p.out[b] = sqrtf(vmd_d2(dx, dy, dz));
 }
 
@@ -792,12 +796,13 @@ __device__ __forceinline__ float vmd_pair_d2(const vmd_dist_params_t& p, int b, 
     const float* fx = p.xyz + (size_t)b * p.frame_stride;
     const float* fy = fx + p.row_stride;
     const float* fz = fy + p.row_stride;
-    const float Lx = p.boxes[3 * b + 0], Ly = p.boxes[3 * b + 1], Lz = p.boxes[3 * b + 2];
+    const float Lx = p.boxes[6 * b + 0], Ly = p.boxes[6 * b + 1], Lz = p.boxes[6 * b + 2];
+    const float iLx = p.boxes[6 * b + 3], iLy = p.boxes[6 * b + 4], iLz = p.boxes[6 * b + 5];
     const bool px = p.pbc & 1u, py = p.pbc & 2u, pz = p.pbc & 4u;
     const int i = p.a[ia], j = p.b[ib];
-    const float xi = px ? vmd_wrap(fx[i], Lx) : fx[i], xj = px ? vmd_wrap(fx[j], Lx) : fx[j];
-    const float yi = py ? vmd_wrap(fy[i], Ly) : fy[i], yj = py ? vmd_wrap(fy[j], Ly) : fy[j];
-    const float zi = pz ? vmd_wrap(fz[i], Lz) : fz[i], zj = pz ? vmd_wrap(fz[j], Lz) : fz[j];
+    const float xi = px ? vmd_wrap(fx[i], Lx, iLx) : fx[i], xj = px ? vmd_wrap(fx[j], Lx, iLx) : fx[j];
+    const float yi = py ? vmd_wrap(fy[i], Ly, iLy) : fy[i], yj = py ? vmd_wrap(fy[j], Ly, iLy) : fy[j];
+    const float zi = pz ? vmd_wrap(fz[i], Lz, iLz) : fz[i], zj = pz ? vmd_wrap(fz[j], Lz, iLz) : fz[j];
     const float dx = vmd_mi_cmp(xi - xj, Lx, 0.5f * Lx, px);
     const float dy = vmd_mi_cmp(yi - yj, Ly, 0.5f * Ly, py);
     const float dz = vmd_mi_cmp(zi - zj, Lz, 0.5f * Lz, pz);
@@ -883,7 +888,7 @@ __global__ __launch_bounds__(256) void k_synth(vmd_synth_params_t p) {
         const float g = (((vmd_synth_uniform(p.seed, 10u + c, frame, i) + vmd_synth_uniform(p.seed, 13u + c, frame, i)) +
                           (vmd_synth_uniform(p.seed, 16u + c, frame, i) + vmd_synth_uniform(p.seed, 19u + c, frame, i))) - 2.0f) * 1.7320508f;
         const float t = sig * g;
-        f[(size_t)c * p.row_stride + i] = vmd_wrap(p0 + t, p.L);
+        f[(size_t)c * p.row_stride + i] = vmd_wrap(p0 + t, p.L, 1.0f / p.L);
     }
 }
 

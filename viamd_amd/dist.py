@@ -44,8 +44,7 @@ def reduce_eval(ev, group=None):
     import torch.distributed as dist
 
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
-        ev.finalize()
-        return
+        return          # nothing to merge; frame_range already refreshed the host views
     on_gpu = dist.get_backend(group) == "nccl"
     dev = "cuda" if on_gpu else "cpu"
     keep = []
