@@ -206,7 +206,7 @@ struct vmd_pair_params_t {
     float r2_up;        // conservative candidate filter (> rmax^2)
     float rpad;         // conservative range padding (> rmax)
     uint64_t* partial;  // [gridDim.x*4][nbins]
-    unsigned* work_counter;  // zeroed before launch: next (frame, pencil) item to hand out
+    unsigned* work_counter;  // [8], zeroed before launch: one dynamic work queue per XCD (frames f = q mod 8)
 };
 
 // per-wave state of the hit machinery
@@ -340,6 +340,24 @@ __device__ __forceinline__ void vmd_segment(const vmd_pair_params_t& p, vmd_wave
         vmd_segment_loop<VARIANT, INC, MASKED, true>(p, w, tx, ty, tz, ja, jb, sx, sy, sz, xi, yi, zi, i, lane);
 }
 
+// Work distribution: the (frame, pencil) items are split into 8 queues by frame index modulo 8.  A wave first drains the
+// queue of its "home" XCD (blockIdx % 8 — the observed block->XCD placement; affinity only, never correctness) so that all
+// pencils of one frame are pulled through ONE XCD's L2, then steals from the other queues.  Returns the global item id
+// (b * npen + pen) or -1 when every queue is empty.  Called by lane 0 only.
+__device__ __forceinline__ int vmd_next_item(unsigned* counters, int& q, int& tries, int B, int npen) {
+    while (tries < 8) {
+        const int nframes_q = (B - q + 7) >> 3;                 // frames q, q+8, ... < B
+        const unsigned t = atomicAdd(&counters[q], 1u);
+        if (nframes_q > 0 && t < (unsigned)(nframes_q * npen)) {
+            const int fq = (int)t / npen;
+            return (q + 8 * fq) * npen + ((int)t - fq * npen);
+        }
+        q = (q + 1) & 7;
+        tries += 1;
+    }
+    return -1;
+}
+
 template <int VARIANT, bool SAME>
 __global__ __launch_bounds__(256) void k_rdf_pencil(vmd_pair_params_t p) {
     __shared__ unsigned s_hist[4][VMD_MAX_BINS];
@@ -361,17 +379,17 @@ __global__ __launch_bounds__(256) void k_rdf_pencil(vmd_pair_params_t p) {
 
     const int nxf = p.grid.nxf, ny = p.grid.ny, nz = p.grid.nz;
     const int npen = ny * nz;
-    const int nitems = p.B * npen;
     const int gw = blockIdx.x * 4 + wave;
-    const int GW = gridDim.x * 4;
     uint64_t* __restrict__ prow = p.partial + (size_t)gw * nbins;
     bool flushed = false;
 
     // work items are handed out dynamically (one returning atomic per item, fetched one item ahead)
-    int item = gw;
-    int next_item = 0;
-    for (; item < nitems; item = next_item) {
-        if (lane == 0) next_item = (int)atomicAdd(p.work_counter, 1u) + GW;
+    int q = blockIdx.x & 7, tries = 0;
+    int item = -1, next_item = -1;
+    if (lane == 0) item = vmd_next_item(p.work_counter, q, tries, p.B, npen);
+    item = __builtin_amdgcn_readfirstlane(item);
+    for (; item >= 0; item = next_item) {
+        if (lane == 0) next_item = vmd_next_item(p.work_counter, q, tries, p.B, npen);
         const int b = item / npen;
         const int pen = item - b * npen;
         const int pz = pen / ny;
@@ -915,7 +933,7 @@ extern "C" int vmd_hip_cells_build(void* stream, const float* xyz, size_t frame_
 }
 
 extern "C" int vmd_hip_rdf_num_blocks(void) { return 2048; }   // 8 blocks x 4 waves per CU: 8 waves per SIMD
-extern "C" size_t vmd_hip_rdf_partial_words(void) { return (size_t)vmd_hip_rdf_num_blocks() * 4 * VMD_MAX_BINS + 1; }
+extern "C" size_t vmd_hip_rdf_partial_words(void) { return (size_t)vmd_hip_rdf_num_blocks() * 4 * VMD_MAX_BINS + 4; }
 
 extern "C" int vmd_hip_rdf_pencil(void* stream, const float* sorted_ref, const uint32_t* cell_start_ref, int nref, int nref_pad,
                                   const float* sorted_tgt, const uint32_t* cell_start_tgt, int ntgt, int ntgt_pad,
@@ -927,7 +945,7 @@ extern "C" int vmd_hip_rdf_pencil(void* stream, const float* sorted_ref, const u
     // the work counter lives behind the partial rows (see vmd_hip_rdf_partial_words)
     unsigned* work_counter = (unsigned*)(partial + (size_t)vmd_hip_rdf_num_blocks() * 4 * VMD_MAX_BINS);
     {
-        hipError_t e = hipMemsetAsync(work_counter, 0, sizeof(uint64_t), s);
+        hipError_t e = hipMemsetAsync(work_counter, 0, 8 * sizeof(unsigned), s);
         if (e != hipSuccess) return (int)e;
     }
     vmd_pair_params_t p;
@@ -941,6 +959,7 @@ extern "C" int vmd_hip_rdf_pencil(void* stream, const float* sorted_ref, const u
     p.partial = partial;
     const int nitems = B * grid.ny * grid.nz;
     int nblocks = (nitems + 3) / 4;
+    if (nblocks < 8) nblocks = 8;
     if (nblocks > vmd_hip_rdf_num_blocks()) nblocks = vmd_hip_rdf_num_blocks();
     const dim3 g(nblocks), blk(256);
     if (same_set) {
