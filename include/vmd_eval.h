@@ -62,6 +62,15 @@ typedef struct vmd_device_view_t {
     int device;
 } vmd_device_view_t;
 
+/* host-resident view of a trajectory with the same SoA frame layout (e.g. a frame cache in pinned memory): lets the
+ * evaluator DMA frames straight from it instead of copying them through load_frame first. */
+typedef struct vmd_host_view_t {
+    const float* base;          /* host pointer */
+    size_t frame_stride;
+    size_t row_stride;
+    const vmd_unitcell_t* cells;
+} vmd_host_view_t;
+
 /* md_trajectory_i stand-in.  load_frame has the signature of md_trajectory_load_frame
  * (src/viamd.cpp:465-467, :1815-1817).  device_view is an extension: when non-NULL and successful the
  * evaluator reads frames in place from HBM instead of staging them through load_frame. */
@@ -71,6 +80,7 @@ typedef struct vmd_trajectory_i {
     size_t (*num_atoms)(void* inst);
     bool (*load_frame)(void* inst, int64_t idx, vmd_frame_header_t* header, float* x, float* y, float* z);
     bool (*device_view)(void* inst, vmd_device_view_t* out);
+    bool (*host_view)(void* inst, vmd_host_view_t* out);     /* extension, may be NULL */
 } vmd_trajectory_i;
 
 /* ---- IR: property descriptors (md_script_ir_t stand-in) ----------------------------------------- */
@@ -195,6 +205,16 @@ bool vmd_devtraj_upload_atoms(vmd_devtraj_t* t, size_t frame_beg, size_t frame_c
 bool vmd_devtraj_synth(vmd_devtraj_t* t, uint64_t seed, float L, float sigma, uint32_t n_blob,
                        size_t frame_beg, size_t frame_end);
 float* vmd_devtraj_device_ptr(vmd_devtraj_t* t, size_t* frame_stride, size_t* row_stride);
+
+/* host-resident trajectory in pinned memory, float[F][3][npad] (the PCIe-inclusive path: frames cross the bus per batch) */
+typedef struct vmd_hosttraj_t vmd_hosttraj_t;
+vmd_hosttraj_t*   vmd_hosttraj_create(size_t num_frames, size_t num_atoms);
+void              vmd_hosttraj_free(vmd_hosttraj_t* t);
+vmd_trajectory_i* vmd_hosttraj_interface(vmd_hosttraj_t* t);
+float*            vmd_hosttraj_frame_ptr(vmd_hosttraj_t* t, size_t frame, size_t* row_stride);   /* x row; y at +row_stride, z at +2*row_stride */
+bool              vmd_hosttraj_set_cell(vmd_hosttraj_t* t, size_t frame, const vmd_unitcell_t* cell);
+/* copy frames [frame_beg, frame_end) of a device trajectory into the host trajectory (same atom count) */
+bool              vmd_hosttraj_copy_from_device(vmd_hosttraj_t* t, vmd_devtraj_t* src, size_t frame_beg, size_t frame_end);
 
 /* ---- consumer post-processing VIAMD applies to the results (src/main.cpp:139-250), host side ------- */
 void vmd_downsample_histogram(float* dst_bins, int num_dst_bins, const float* src_bins, const float* src_weights,

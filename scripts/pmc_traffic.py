@@ -1,0 +1,35 @@
+"""Turn a scripts/gpu_pmc.sh output directory into profiles/pmc_traffic.json (HBM-side traffic per kernel launch).
+
+FETCH_SIZE / WRITE_SIZE are in KiB (rocprofv3), collected in separate --pmc passes (MI355X_MICROARCH.md, rocprofv3 PMC slots).
+gfx950 note from the same guide: FETCH_SIZE under-reports wide coalesced streaming reads by exactly 2x; other access widths are
+uncalibrated, so both the raw value and the 2x-corrected read figure are stored."""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+src, workload, frames_per_launch, out = sys.argv[1], sys.argv[2], float(sys.argv[3]), sys.argv[4]
+acc = defaultdict(lambda: defaultdict(list))
+for f in sorted(glob.glob(os.path.join(src, "p*", "**", "*counter_collection.csv"), recursive=True)):
+    per = defaultdict(float)
+    with open(f) as fh:
+        for row in csv.DictReader(fh):
+            if row.get("Counter_Name") not in ("FETCH_SIZE", "WRITE_SIZE"):
+                continue
+            k = row["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]
+            per[(k, row["Dispatch_Id"], row["Counter_Name"])] += float(row["Counter_Value"] or 0)
+    for (k, d, c), v in per.items():
+        acc[k][c].append(v)
+res = json.load(open(out)) if os.path.exists(out) else {}
+res[workload] = {"frames_per_launch": frames_per_launch, "source": os.path.basename(src.rstrip("/")), "kernels": {}}
+for k in sorted(acc):
+    f = acc[k].get("FETCH_SIZE", [0]); w = acc[k].get("WRITE_SIZE", [0])
+    fetch, write = sum(f) / len(f) * 1024, sum(w) / len(w) * 1024
+    res[workload]["kernels"][k] = {"fetch_bytes_per_launch_raw": fetch, "write_bytes_per_launch": write,
+                                   "hbm_bytes_per_launch_raw": fetch + write,
+                                   "hbm_bytes_per_launch_read_x2": 2 * fetch + write,
+                                   "hbm_bytes_per_frame_raw": (fetch + write) / frames_per_launch}
+json.dump(res, open(out, "w"), indent=1)
+print(json.dumps(res[workload]["kernels"].get("k_rdf_pencil", {}), indent=1))

@@ -35,6 +35,10 @@ def oracle_rdf(O, coords, ocell, ref, tgt, rmin, rmax, frames=None, method="cell
 
 
 def make_traj(lib, coords, vcell, device):
+    if device == "pinned":
+        t = V.PinnedHostTrajectory(coords.shape[0], coords.shape[2], lib=lib)
+        t.upload(coords, vcell)
+        return t
     if device:
         t = V.DeviceTrajectory(coords.shape[0], coords.shape[2], lib=lib)
         t.upload(coords, vcell)

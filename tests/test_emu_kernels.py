@@ -60,6 +60,16 @@ def test_rdf_sharding_and_device_trajectory(emu_lib, oracle, box3k):
     cases.check_rdf(emu_lib, oracle, box3k, 60.0, [("goo", o, o, 0.0, 12.0)], device=True, ranges=[(2, 3), (0, 1), (1, 2)])
 
 
+def test_pinned_host_trajectory_and_small_batches(emu_lib, oracle, box3k):
+    o = cases.oxygen(3000)
+    old = emu_lib.vmd_set_option(b"batch_frames", 1)          # every frame its own batch: exercises the two-stage pipeline
+    try:
+        cases.check_rdf(emu_lib, oracle, box3k, 60.0, [("goo", o, o, 0.0, 12.0)], device="pinned")
+        cases.check_rdf(emu_lib, oracle, box3k, 60.0, [("goo", o, o, 0.0, 12.0)], device=False)
+    finally:
+        emu_lib.vmd_set_option(b"batch_frames", old)
+
+
 def test_sdf_volume_and_matrices(emu_lib, oracle):
     coords, structures, mass = cases.sdf_system(oracle, 4, 1500, 40.0, 3)
     n_s = structures.size

@@ -41,6 +41,18 @@ def test_rdf_inline_variant_and_host_staging(gpu_lib, oracle, box30k):
     cases.check_rdf(gpu_lib, oracle, box30k[:2], 80.0, [("goo", o, o, 0.0, 12.0)], variant=1, device=False)
 
 
+def test_staged_host_trajectories_overlap_pipeline(gpu_lib, oracle, box30k):
+    """load_frame staging and the pinned host view, with tiny batches so that both pipeline stages are used many times"""
+    o, h = cases.oxygen(30000), cases.hydrogen(30000)
+    old = gpu_lib.vmd_set_option(b"batch_frames", 1)
+    try:
+        cases.check_rdf(gpu_lib, oracle, box30k, 80.0, [("goo", o, o, 0.0, 12.0), ("goh", o, h, 0.0, 8.0)], device="pinned")
+        cases.check_rdf(gpu_lib, oracle, box30k, 80.0, [("goo", o, o, 0.0, 12.0)], device=False)
+    finally:
+        gpu_lib.vmd_set_option(b"batch_frames", old)
+    cases.check_rdf(gpu_lib, oracle, box30k, 80.0, [("goo", o, o, 0.0, 12.0)], device="pinned")
+
+
 def test_rdf_small_boxes_and_unwrapped_input(gpu_lib, oracle):
     c = cases.water_box(oracle, 11, 3000, 26.0, 3)                    # ny = nz = 2
     o = cases.oxygen(3000)

@@ -48,9 +48,16 @@ LOAD_FRAME_FN = C.CFUNCTYPE(C.c_bool, C.c_void_p, C.c_int64, C.POINTER(FrameHead
 DEVICE_VIEW_FN = C.CFUNCTYPE(C.c_bool, C.c_void_p, C.POINTER(DeviceView))
 
 
+class HostView(C.Structure):
+    _fields_ = [("base", c_float_p), ("frame_stride", C.c_size_t), ("row_stride", C.c_size_t), ("cells", C.POINTER(Unitcell))]
+
+
+HOST_VIEW_FN = C.CFUNCTYPE(C.c_bool, C.c_void_p, C.POINTER(HostView))
+
+
 class TrajectoryI(C.Structure):
     _fields_ = [("inst", C.c_void_p), ("num_frames", NUM_FRAMES_FN), ("num_atoms", NUM_ATOMS_FN),
-                ("load_frame", LOAD_FRAME_FN), ("device_view", DEVICE_VIEW_FN)]
+                ("load_frame", LOAD_FRAME_FN), ("device_view", DEVICE_VIEW_FN), ("host_view", HOST_VIEW_FN)]
 
 
 class Aggregate(C.Structure):
@@ -110,6 +117,12 @@ SIGNATURES = [
     ("vmd_devtraj_upload_atoms", C.c_bool, [_vp, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, c_float_p]),
     ("vmd_devtraj_synth", C.c_bool, [_vp, C.c_uint64, C.c_float, C.c_float, C.c_uint32, C.c_size_t, C.c_size_t]),
     ("vmd_devtraj_device_ptr", _vp, [_vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    ("vmd_hosttraj_create", _vp, [C.c_size_t, C.c_size_t]),
+    ("vmd_hosttraj_free", None, [_vp]),
+    ("vmd_hosttraj_interface", C.POINTER(TrajectoryI), [_vp]),
+    ("vmd_hosttraj_frame_ptr", c_float_p, [_vp, C.c_size_t, C.POINTER(C.c_size_t)]),
+    ("vmd_hosttraj_set_cell", C.c_bool, [_vp, C.c_size_t, C.POINTER(Unitcell)]),
+    ("vmd_hosttraj_copy_from_device", C.c_bool, [_vp, _vp, C.c_size_t, C.c_size_t]),
     ("vmd_downsample_histogram", None, [c_float_p, C.c_int, c_float_p, c_float_p, C.c_int]),
     ("vmd_compute_histogram_masked", None, [c_float_p, C.c_int, C.c_float, C.c_float, c_float_p, C.c_int, c_uint8_p, C.c_int, C.c_bool]),
     ("vmd_device_count", C.c_int, []),

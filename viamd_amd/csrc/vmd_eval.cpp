@@ -313,14 +313,24 @@ struct vmd_script_eval_t {
     hipStream_t stream = nullptr;
     int device = 0;
     Profiler prof;
-    // batch scratch
-    DevBuf<float> d_boxes, d_stage;
-    float* h_stage = nullptr; size_t h_stage_cap = 0;   // pinned
-    std::vector<float> h_boxes;
+    // batch scratch.  Two stages: while the kernels of batch k run, the host loads batch k+1 through load_frame into
+    // the other pinned buffer and its H2D copy runs on copy_stream (trajectory staging).
+    struct Stage {
+        float* h = nullptr; size_t hcap = 0;     // pinned host frames [nb][3][npad]
+        DevBuf<float> d;                         // their device copy
+        DevBuf<float> d_boxes;
+        std::vector<float> h_boxes;              // [nb][6]: L, 1/L
+        std::vector<vmd_unitcell_t> cells;
+        hipEvent_t ready = nullptr;
+        const float* base = nullptr; size_t frame_stride = 0, row_stride = 0;   // where the kernels read the batch
+        size_t f0 = 0, nb = 0;
+    };
+    Stage stages[2];
+    hipStream_t copy_stream = nullptr;
     DevBuf<uint64_t> d_partial;
     std::vector<float> h_temporal;
-    std::vector<vmd_unitcell_t> cells;
 };
+typedef vmd_script_eval_t::Stage Stage;
 
 static PropState* find_prop(const vmd_script_eval_t* e, const char* name) {
     if (!e || !name) return nullptr;
@@ -342,6 +352,8 @@ extern "C" vmd_script_eval_t* vmd_eval_create(size_t num_frames, const vmd_scrip
     auto e = std::make_unique<vmd_script_eval_t>();
     if (hipGetDevice(&e->device) != hipSuccess) { vmd_fail("hipGetDevice failed"); return nullptr; }
     if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) { vmd_fail("hipStreamCreate failed"); return nullptr; }
+    if (hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking) != hipSuccess) { vmd_fail("hipStreamCreate failed"); return nullptr; }
+    for (auto& st : e->stages) if (hipEventCreate(&st.ready) != hipSuccess) { vmd_fail("hipEventCreate failed"); return nullptr; }
     e->ir_fingerprint = vmd_ir_fingerprint(ir);
     e->num_frames = num_frames;
     e->frame_mask.assign(num_frames, 0);
@@ -407,8 +419,16 @@ extern "C" void vmd_eval_free(vmd_script_eval_t* eval) {
     {
         std::lock_guard<std::mutex> l(eval->mtx);
         if (eval->stream) { (void)hipStreamSynchronize(eval->stream); }
-        if (eval->h_stage) (void)hipHostFree(eval->h_stage);
-        eval->h_stage = nullptr;
+        if (eval->copy_stream) { (void)hipStreamSynchronize(eval->copy_stream); }
+        for (auto& st : eval->stages) {
+            if (st.h) (void)hipHostFree(st.h);
+            st.h = nullptr;
+            st.d.release(); st.d_boxes.release();
+            if (st.ready) (void)hipEventDestroy(st.ready);
+            st.ready = nullptr;
+        }
+        if (eval->copy_stream) (void)hipStreamDestroy(eval->copy_stream);
+        eval->copy_stream = nullptr;
         eval->props.clear();
         eval->sels.clear();
         if (eval->stream) (void)hipStreamDestroy(eval->stream);
@@ -619,53 +639,77 @@ struct BatchSrc {
     size_t frame_stride = 0, row_stride = 0;
 };
 
-// bring frames [f0, f0+nb) to the device (or alias them in place), fill e->cells / e->h_boxes
-static bool fetch_batch(vmd_script_eval_t* e, vmd_trajectory_i* traj, const vmd_device_view_t* view, size_t num_atoms,
-                        size_t f0, size_t nb, BatchSrc* src) {
-    e->cells.resize(nb);
-    e->h_boxes.resize(nb * 6);
+// bring frames [f0, f0+nb) to the device (or alias them in place) through stage `st`: fills st.cells / st.h_boxes, queues
+// the copies on copy_stream and records st.ready
+static bool fetch_stage(vmd_script_eval_t* e, Stage& st, vmd_trajectory_i* traj, const vmd_device_view_t* view, size_t num_atoms,
+                        size_t f0, size_t nb) {
+    vmd_host_view_t hv;
+    const vmd_host_view_t* hview = (!view && traj->host_view && traj->host_view(traj->inst, &hv)) ? &hv : nullptr;
+    st.f0 = f0; st.nb = nb;
+    st.cells.resize(nb);
+    st.h_boxes.resize(nb * 6);
     if (view) {
-        src->base = view->base + f0 * view->frame_stride;
-        src->frame_stride = view->frame_stride;
-        src->row_stride = view->row_stride;
-        for (size_t b = 0; b < nb; ++b) e->cells[b] = view->cells[f0 + b];
+        st.base = view->base + f0 * view->frame_stride;
+        st.frame_stride = view->frame_stride;
+        st.row_stride = view->row_stride;
+        for (size_t b = 0; b < nb; ++b) st.cells[b] = view->cells[f0 + b];
+    } else if (hview) {
+        // frames already sit in host memory in our layout: DMA them as one block, no load_frame copies
+        const size_t need = nb * hview->frame_stride;
+        if (!st.d.ensure(need)) return false;
+        HIP_OK(hipMemcpyAsync(st.d.p, hview->base + f0 * hview->frame_stride, need * sizeof(float), hipMemcpyHostToDevice, e->copy_stream));
+        st.base = st.d.p;
+        st.frame_stride = hview->frame_stride;
+        st.row_stride = hview->row_stride;
+        for (size_t b = 0; b < nb; ++b) st.cells[b] = hview->cells[f0 + b];
     } else {
         const size_t npad = (num_atoms + 63) & ~(size_t)63;
         const size_t need = nb * 3 * npad;
-        if (need > e->h_stage_cap) {
-            if (e->h_stage) (void)hipHostFree(e->h_stage);
-            e->h_stage = nullptr; e->h_stage_cap = 0;
-            HIP_OK(hipHostMalloc((void**)&e->h_stage, need * sizeof(float), hipHostMallocDefault));
-            e->h_stage_cap = need;
+        if (need > st.hcap) {
+            if (st.h) (void)hipHostFree(st.h);
+            st.h = nullptr; st.hcap = 0;
+            HIP_OK(hipHostMalloc((void**)&st.h, need * sizeof(float), hipHostMallocDefault));
+            st.hcap = need;
         }
-        if (!e->d_stage.ensure(need)) return false;
+        if (!st.d.ensure(need)) return false;
         for (size_t b = 0; b < nb; ++b) {
             vmd_frame_header_t hdr;
             memset(&hdr, 0, sizeof(hdr));
-            float* x = e->h_stage + b * 3 * npad;
+            float* x = st.h + b * 3 * npad;
             if (!traj->load_frame(traj->inst, (int64_t)(f0 + b), &hdr, x, x + npad, x + 2 * npad))
                 return vmd_fail("trajectory load_frame(%zu) failed", f0 + b);
-            e->cells[b] = hdr.unitcell;
+            st.cells[b] = hdr.unitcell;
         }
-        HIP_OK(hipMemcpyAsync(e->d_stage.p, e->h_stage, need * sizeof(float), hipMemcpyHostToDevice, e->stream));
-        src->base = e->d_stage.p;
-        src->frame_stride = 3 * npad;
-        src->row_stride = npad;
+        HIP_OK(hipMemcpyAsync(st.d.p, st.h, need * sizeof(float), hipMemcpyHostToDevice, e->copy_stream));
+        st.base = st.d.p;
+        st.frame_stride = 3 * npad;
+        st.row_stride = npad;
     }
     for (size_t b = 0; b < nb; ++b) {
-        const vmd_unitcell_t& c = e->cells[b];
+        const vmd_unitcell_t& c = st.cells[b];
         if (c.xy != 0.0f || c.xz != 0.0f || c.yz != 0.0f) return vmd_fail("frame %zu: triclinic unit cells are not supported (SPEC D-TRICLINIC)", f0 + b);
-        if (c.flags != e->cells[0].flags) return vmd_fail("frame %zu: periodicity flags change inside the trajectory", f0 + b);
-        float* hb = &e->h_boxes[6 * b];
+        if (c.flags != st.cells[0].flags) return vmd_fail("frame %zu: periodicity flags change inside the trajectory", f0 + b);
+        float* hb = &st.h_boxes[6 * b];
         hb[0] = c.x; hb[1] = c.y; hb[2] = c.z;
         hb[3] = 1.0f / c.x; hb[4] = 1.0f / c.y; hb[5] = 1.0f / c.z;      // SPEC S2: invL = fl(1.0f / L)
     }
-    if (!e->d_boxes.upload(e->h_boxes.data(), nb * 6, e->stream)) return false;
+    if (!st.d_boxes.upload(st.h_boxes.data(), nb * 6, e->copy_stream)) return false;
+    HIP_OK(hipEventRecord(st.ready, e->copy_stream));
     return true;
 }
 
-static uint32_t batch_pbc(const vmd_script_eval_t* e) {
-    const vmd_unitcell_t& c = e->cells[0];
+// synchronous variant used for single frames (reference pose, vis payload)
+static bool fetch_batch(vmd_script_eval_t* e, vmd_trajectory_i* traj, const vmd_device_view_t* view, size_t num_atoms,
+                        size_t f0, size_t nb, BatchSrc* src) {
+    Stage& st = e->stages[0];
+    if (!fetch_stage(e, st, traj, view, num_atoms, f0, nb)) return false;
+    HIP_OK(hipStreamSynchronize(e->copy_stream));
+    src->base = st.base; src->frame_stride = st.frame_stride; src->row_stride = st.row_stride;
+    return true;
+}
+
+static uint32_t batch_pbc(const Stage& st) {
+    const vmd_unitcell_t& c = st.cells[0];
     uint32_t f = c.flags & VMD_UNITCELL_PBC_ALL;
     if (!(c.x > 0.0f)) f &= ~VMD_UNITCELL_PBC_X;
     if (!(c.y > 0.0f)) f &= ~VMD_UNITCELL_PBC_Y;
@@ -674,11 +718,11 @@ static uint32_t batch_pbc(const vmd_script_eval_t* e) {
 }
 
 // pencil grid for a batch and cutoff; false when the batch cannot use the grid kernel
-static bool choose_grid(const vmd_script_eval_t* e, size_t nb, float rmax, vmd_grid_t* g) {
+static bool choose_grid(const Stage& st, size_t nb, float rmax, vmd_grid_t* g) {
     if (g_opt.force_brute) return false;
-    if (batch_pbc(e) != VMD_UNITCELL_PBC_ALL) return false;
+    if (batch_pbc(st) != VMD_UNITCELL_PBC_ALL) return false;
     float Lmin[3] = {3.4e38f, 3.4e38f, 3.4e38f};
-    for (size_t b = 0; b < nb; ++b) for (int a = 0; a < 3; ++a) Lmin[a] = std::min(Lmin[a], e->h_boxes[6 * b + a]);
+    for (size_t b = 0; b < nb; ++b) for (int a = 0; a < 3; ++a) Lmin[a] = std::min(Lmin[a], st.h_boxes[6 * b + a]);
     // minimum image must be unique for every hit: rmax < L/2 with margin
     for (int a = 0; a < 3; ++a) if (!(rmax * 2.0f * 1.001f < Lmin[a])) return false;
     int n[3];
@@ -698,14 +742,14 @@ static bool choose_grid(const vmd_script_eval_t* e, size_t nb, float rmax, vmd_g
     return true;
 }
 
-static bool build_selection(vmd_script_eval_t* e, Selection* s, const BatchSrc& src, size_t nb, const vmd_grid_t& g) {
+static bool build_selection(vmd_script_eval_t* e, Selection* s, const Stage& src, size_t nb, const vmd_grid_t& g) {
     if (s->built && s->built_grid.nxf == g.nxf && s->built_grid.ny == g.ny && s->built_grid.nz == g.nz) return true;
     const int nsel = (int)s->idx.size();
     s->nsel_pad = (nsel + 63) & ~63;
     if (!s->cell_count.ensure(nb * (size_t)(g.ncell + 1)) || !s->cell_start.ensure(nb * (size_t)(g.ncell + 1)) ||
         !s->rank.ensure(nb * (size_t)nsel) || !s->sorted.ensure(nb * 3 * (size_t)s->nsel_pad)) return false;
     e->prof.begin("cells_build", e->stream);
-    KRN_OK(vmd_hip_cells_build(e->stream, src.base, src.frame_stride, src.row_stride, e->d_boxes.p, (int)nb, s->d_idx.p, nsel,
+    KRN_OK(vmd_hip_cells_build(e->stream, src.base, src.frame_stride, src.row_stride, src.d_boxes.p, (int)nb, s->d_idx.p, nsel,
                                s->nsel_pad, g, s->cell_count.p, s->rank.p, s->cell_start.p, s->sorted.p));
     e->prof.end(e->stream);
     s->built = true;
@@ -749,20 +793,31 @@ extern "C" bool vmd_eval_frame_range(vmd_script_eval_t* eval, const vmd_script_i
         if (p->prop.kind != PROP_SDF || p->ref_pose_ready) continue;
         BatchSrc src;
         if (!fetch_batch(e, traj, have_view ? &view : nullptr, num_atoms, 0, 1, &src)) return false;
-        KRN_OK(vmd_hip_sdf_ref_pose(e->stream, src.base, src.row_stride, e->d_boxes.p, batch_pbc(e), p->d_structs.p, p->d_mass.p,
+        KRN_OK(vmd_hip_sdf_ref_pose(e->stream, src.base, src.row_stride, e->stages[0].d_boxes.p, batch_pbc(e->stages[0]), p->d_structs.p, p->d_mass.p,
                                     (int)p->prop.m, p->d_ref_pose.p));
         HIP_OK(hipStreamSynchronize(e->stream));
         p->ref_pose_ready = true;
     }
 
-    const size_t B = auto_batch(e, num_atoms);
+    // frames per launch: as many as the scratch budget allows, split evenly so that no small tail batch is left
+    size_t B = auto_batch(e, num_atoms);
+    {
+        const size_t total = frame_end - frame_beg;
+        const size_t nbatch = (total + B - 1) / B;
+        B = (total + nbatch - 1) / nbatch;
+    }
     bool completed = true;
-    for (size_t f0 = frame_beg; f0 < frame_end; f0 += B) {
+    const vmd_device_view_t* vw = have_view ? &view : nullptr;
+    // host trajectories are staged in smaller batches so that load_frame of batch k+1 overlaps the kernels of batch k
+    if (!have_view && g_opt.batch_frames <= 0) B = std::min<size_t>(B, 128);
+    int cur = 0;
+    if (!fetch_stage(e, e->stages[cur], traj, vw, num_atoms, frame_beg, std::min<size_t>(B, frame_end - frame_beg))) return false;
+    for (size_t f0 = frame_beg; f0 < frame_end; f0 += B, cur ^= 1) {
         if (e->interrupt) { completed = false; break; }
         const size_t nb = std::min<size_t>(B, frame_end - f0);
-        BatchSrc src;
-        if (!fetch_batch(e, traj, have_view ? &view : nullptr, num_atoms, f0, nb, &src)) return false;
-        const uint32_t pbc = batch_pbc(e);
+        Stage& src = e->stages[cur];
+        HIP_OK(hipStreamWaitEvent(e->stream, src.ready, 0));
+        const uint32_t pbc = batch_pbc(src);
         for (auto& s : e->sels) s->built = false;
 
         size_t temporal_floats = 0;
@@ -774,7 +829,7 @@ extern "C" bool vmd_eval_frame_range(vmd_script_eval_t* eval, const vmd_script_i
             const Property& d = p->prop;
             if (d.kind == PROP_RDF) {
                 vmd_grid_t g;
-                if (choose_grid(e, nb, d.rmax, &g)) {
+                if (choose_grid(src, nb, d.rmax, &g)) {
                     Selection* sa = e->sels[p->sel_a].get();
                     Selection* sb = e->sels[p->sel_b].get();
                     // properties with the same cutoff share the sorted copies; build_selection re-sorts when the grid differs
@@ -784,21 +839,21 @@ extern "C" bool vmd_eval_frame_range(vmd_script_eval_t* eval, const vmd_script_i
                     e->prof.begin("rdf_pencil", e->stream);
                     KRN_OK(vmd_hip_rdf_pencil(e->stream, sa->sorted.p, sa->cell_start.p, (int)sa->idx.size(), sa->nsel_pad,
                                               sb->sorted.p, sb->cell_start.p, (int)sb->idx.size(), sb->nsel_pad,
-                                              e->d_boxes.p, (int)nb, g, d.rmin, d.rmax, VMD_RDF_NUM_BINS,
+                                              src.d_boxes.p, (int)nb, g, d.rmin, d.rmax, VMD_RDF_NUM_BINS,
                                               p->same_set ? 1 : 0, g_opt.rdf_variant, e->d_partial.p, p->d_counts.p));
                     e->prof.end(e->stream);
                 } else {
                     Selection* sa = e->sels[p->sel_a].get();
                     Selection* sb = e->sels[p->sel_b].get();
                     e->prof.begin("rdf_brute", e->stream);
-                    KRN_OK(vmd_hip_rdf_brute(e->stream, src.base, src.frame_stride, src.row_stride, e->d_boxes.p, pbc, (int)nb,
+                    KRN_OK(vmd_hip_rdf_brute(e->stream, src.base, src.frame_stride, src.row_stride, src.d_boxes.p, pbc, (int)nb,
                                              sa->d_idx.p, (int)sa->idx.size(), sb->d_idx.p, (int)sb->idx.size(),
                                              d.rmin, d.rmax, VMD_RDF_NUM_BINS, p->d_counts.p));
                     e->prof.end(e->stream);
                 }
                 // SPEC S4 normalisation, fp64 on the host (needs only the box)
                 for (size_t b = 0; b < nb; ++b) {
-                    const float* L = &e->h_boxes[6 * b];
+                    const float* L = &src.h_boxes[6 * b];
                     double V;
                     if (pbc == VMD_UNITCELL_PBC_ALL) V = (double)L[0] * (double)L[1] * (double)L[2];
                     else V = (4.0 / 3.0) * M_PI * (double)d.rmax * (double)d.rmax * (double)d.rmax;
@@ -814,11 +869,11 @@ extern "C" bool vmd_eval_frame_range(vmd_script_eval_t* eval, const vmd_script_i
             } else if (d.kind == PROP_SDF) {
                 if (!p->d_R32.ensure(nb * d.K * 9) || !p->d_c32.ensure(nb * d.K * 3)) return false;
                 e->prof.begin("sdf_align", e->stream);
-                KRN_OK(vmd_hip_sdf_align(e->stream, src.base, src.frame_stride, src.row_stride, e->d_boxes.p, pbc, (int)nb,
+                KRN_OK(vmd_hip_sdf_align(e->stream, src.base, src.frame_stride, src.row_stride, src.d_boxes.p, pbc, (int)nb,
                                          p->d_structs.p, p->d_mass.p, (int)d.K, (int)d.m, p->d_ref_pose.p, p->d_R32.p, p->d_c32.p, nullptr));
                 e->prof.end(e->stream);
                 e->prof.begin("sdf_scatter", e->stream);
-                KRN_OK(vmd_hip_sdf_scatter(e->stream, src.base, src.frame_stride, src.row_stride, e->d_boxes.p, pbc, (int)nb,
+                KRN_OK(vmd_hip_sdf_scatter(e->stream, src.base, src.frame_stride, src.row_stride, src.d_boxes.p, pbc, (int)nb,
                                            p->d_structs.p, (int)d.K, (int)d.m, p->d_R32.p, p->d_c32.p, p->d_tgt.p, p->have_owner ? p->d_owner.p : nullptr, (int)d.b.size(),
                                            d.rmax, VMD_VOLUME_DIM, p->d_counts.p));
                 e->prof.end(e->stream);
@@ -826,13 +881,17 @@ extern "C" bool vmd_eval_frame_range(vmd_script_eval_t* eval, const vmd_script_i
             } else {
                 if (!p->d_out.ensure(nb * p->dim1)) return false;
                 e->prof.begin("distance", e->stream);
-                KRN_OK(vmd_hip_distance(e->stream, src.base, src.frame_stride, src.row_stride, e->d_boxes.p, pbc, (int)nb, d.dist_kind,
+                KRN_OK(vmd_hip_distance(e->stream, src.base, src.frame_stride, src.row_stride, src.d_boxes.p, pbc, (int)nb, d.dist_kind,
                                         p->d_a.p, p->d_ma.p, (int)d.a.size(), p->d_b.p, p->d_mb.p, (int)d.b.size(), p->d_out.p));
                 e->prof.end(e->stream);
                 HIP_OK(hipMemcpyAsync(e->h_temporal.data() + toff, p->d_out.p, nb * p->dim1 * sizeof(float), hipMemcpyDeviceToHost, e->stream));
                 toff += nb * p->dim1;
                 p->dirty = true;
             }
+        }
+        // the kernels of this batch are queued: load the next batch on the host while they run
+        if (f0 + B < frame_end && !e->interrupt) {
+            if (!fetch_stage(e, e->stages[cur ^ 1], traj, vw, num_atoms, f0 + B, std::min<size_t>(B, frame_end - (f0 + B)))) return false;
         }
         HIP_OK(hipStreamSynchronize(e->stream));
         e->prof.resolve();
@@ -870,7 +929,7 @@ extern "C" bool vmd_eval_sdf_matrices(vmd_script_eval_t* eval, const char* name,
     BatchSrc src;
     if (!p->ref_pose_ready) {
         if (!fetch_batch(e, traj, have_view ? &view : nullptr, num_atoms, 0, 1, &src)) return false;
-        KRN_OK(vmd_hip_sdf_ref_pose(e->stream, src.base, src.row_stride, e->d_boxes.p, batch_pbc(e), p->d_structs.p, p->d_mass.p,
+        KRN_OK(vmd_hip_sdf_ref_pose(e->stream, src.base, src.row_stride, e->stages[0].d_boxes.p, batch_pbc(e->stages[0]), p->d_structs.p, p->d_mass.p,
                                     (int)p->prop.m, p->d_ref_pose.p));
         HIP_OK(hipStreamSynchronize(e->stream));
         p->ref_pose_ready = true;
@@ -879,7 +938,7 @@ extern "C" bool vmd_eval_sdf_matrices(vmd_script_eval_t* eval, const char* name,
     const size_t K = p->prop.K;
     DevBuf<double> dM;
     if (!dM.ensure(K * 12) || !p->d_R32.ensure(K * 9) || !p->d_c32.ensure(K * 3)) return false;
-    KRN_OK(vmd_hip_sdf_align(e->stream, src.base, src.frame_stride, src.row_stride, e->d_boxes.p, batch_pbc(e), 1,
+    KRN_OK(vmd_hip_sdf_align(e->stream, src.base, src.frame_stride, src.row_stride, e->stages[0].d_boxes.p, batch_pbc(e->stages[0]), 1,
                              p->d_structs.p, p->d_mass.p, (int)K, (int)p->prop.m, p->d_ref_pose.p, p->d_R32.p, p->d_c32.p, dM.p));
     std::vector<double> M(K * 12);
     HIP_OK(hipMemcpyAsync(M.data(), dM.p, K * 12 * sizeof(double), hipMemcpyDeviceToHost, e->stream));
@@ -938,7 +997,7 @@ extern "C" vmd_devtraj_t* vmd_devtraj_create(size_t num_frames, size_t num_atoms
     t->cells.assign(num_frames, none);
     t->iface.inst = t.get();
     t->iface.num_frames = dt_num_frames; t->iface.num_atoms = dt_num_atoms;
-    t->iface.load_frame = dt_load_frame; t->iface.device_view = dt_device_view;
+    t->iface.load_frame = dt_load_frame; t->iface.device_view = dt_device_view; t->iface.host_view = nullptr;
     return t.release();
 }
 extern "C" void vmd_devtraj_free(vmd_devtraj_t* t) {
@@ -991,6 +1050,64 @@ extern "C" float* vmd_devtraj_device_ptr(vmd_devtraj_t* t, size_t* frame_stride,
     if (frame_stride) *frame_stride = 3 * t->npad;
     if (row_stride) *row_stride = t->npad;
     return t->d;
+}
+
+// ------------------------------------------------------------------------------------------------ host trajectory (pinned)
+
+struct vmd_hosttraj_t {
+    size_t num_frames = 0, num_atoms = 0, npad = 0;
+    float* h = nullptr;
+    std::vector<vmd_unitcell_t> cells;
+    vmd_trajectory_i iface;
+};
+static size_t ht_num_frames(void* inst) { return ((vmd_hosttraj_t*)inst)->num_frames; }
+static size_t ht_num_atoms(void* inst) { return ((vmd_hosttraj_t*)inst)->num_atoms; }
+static bool ht_load_frame(void* inst, int64_t idx, vmd_frame_header_t* hdr, float* x, float* y, float* z) {
+    vmd_hosttraj_t* t = (vmd_hosttraj_t*)inst;
+    if (idx < 0 || (size_t)idx >= t->num_frames) return vmd_fail("hosttraj: frame %lld out of range", (long long)idx);
+    const float* f = t->h + (size_t)idx * 3 * t->npad;
+    if (x) memcpy(x, f, t->num_atoms * sizeof(float));
+    if (y) memcpy(y, f + t->npad, t->num_atoms * sizeof(float));
+    if (z) memcpy(z, f + 2 * t->npad, t->num_atoms * sizeof(float));
+    if (hdr) { hdr->num_atoms = t->num_atoms; hdr->index = idx; hdr->timestamp = (double)idx; hdr->unitcell = t->cells[idx]; }
+    return true;
+}
+static bool ht_host_view(void* inst, vmd_host_view_t* out) {
+    vmd_hosttraj_t* t = (vmd_hosttraj_t*)inst;
+    out->base = t->h; out->frame_stride = 3 * t->npad; out->row_stride = t->npad; out->cells = t->cells.data();
+    return true;
+}
+extern "C" vmd_hosttraj_t* vmd_hosttraj_create(size_t num_frames, size_t num_atoms) {
+    auto t = std::make_unique<vmd_hosttraj_t>();
+    t->num_frames = num_frames; t->num_atoms = num_atoms; t->npad = (num_atoms + 63) & ~(size_t)63;
+    const size_t bytes = std::max<size_t>(num_frames * 3 * t->npad, 1) * sizeof(float);
+    if (hipHostMalloc((void**)&t->h, bytes, hipHostMallocDefault) != hipSuccess) { vmd_fail("vmd_hosttraj_create: hipHostMalloc(%zu) failed", bytes); return nullptr; }
+    vmd_unitcell_t none;
+    memset(&none, 0, sizeof(none));
+    t->cells.assign(num_frames, none);
+    t->iface.inst = t.get();
+    t->iface.num_frames = ht_num_frames; t->iface.num_atoms = ht_num_atoms; t->iface.load_frame = ht_load_frame;
+    t->iface.device_view = nullptr; t->iface.host_view = ht_host_view;
+    return t.release();
+}
+extern "C" void vmd_hosttraj_free(vmd_hosttraj_t* t) { if (!t) return; if (t->h) (void)hipHostFree(t->h); delete t; }
+extern "C" vmd_trajectory_i* vmd_hosttraj_interface(vmd_hosttraj_t* t) { return t ? &t->iface : nullptr; }
+extern "C" float* vmd_hosttraj_frame_ptr(vmd_hosttraj_t* t, size_t frame, size_t* row_stride) {
+    if (!t || frame >= t->num_frames) return nullptr;
+    if (row_stride) *row_stride = t->npad;
+    return t->h + frame * 3 * t->npad;
+}
+extern "C" bool vmd_hosttraj_set_cell(vmd_hosttraj_t* t, size_t frame, const vmd_unitcell_t* cell) {
+    if (!t || !cell || frame >= t->num_frames) return vmd_fail("vmd_hosttraj_set_cell: bad frame");
+    t->cells[frame] = *cell;
+    return true;
+}
+extern "C" bool vmd_hosttraj_copy_from_device(vmd_hosttraj_t* t, vmd_devtraj_t* src, size_t frame_beg, size_t frame_end) {
+    if (!t || !src || frame_end > t->num_frames || frame_end > src->num_frames || src->num_atoms != t->num_atoms) return vmd_fail("vmd_hosttraj_copy_from_device: shape mismatch");
+    if (frame_beg >= frame_end) return true;
+    HIP_OK(hipMemcpy(t->h + frame_beg * 3 * t->npad, src->d + frame_beg * 3 * src->npad, (frame_end - frame_beg) * 3 * t->npad * sizeof(float), hipMemcpyDeviceToHost));
+    for (size_t f = frame_beg; f < frame_end; ++f) t->cells[f] = src->cells[f];
+    return true;
 }
 
 // ------------------------------------------------------------------------------------------------ consumer post-processing

@@ -205,7 +205,8 @@ struct vmd_pair_params_t {
     vmd_binning_t bin;
     float r2_up;        // conservative candidate filter (> rmax^2)
     float rpad;         // conservative range padding (> rmax)
-    uint64_t* partial;  // [gridDim.x*4][nbins]
+    uint64_t* partial;  // [gridDim.x][nbins]: one row per block, written once at the end
+    unsigned long long* counts;  // the accumulators: target of the (rare) overflow flush
     unsigned* work_counter;  // [8], zeroed before launch: one dynamic work queue per XCD (frames f = q mod 8)
 };
 
@@ -379,9 +380,6 @@ __global__ __launch_bounds__(256) void k_rdf_pencil(vmd_pair_params_t p) {
 
     const int nxf = p.grid.nxf, ny = p.grid.ny, nz = p.grid.nz;
     const int npen = ny * nz;
-    const int gw = blockIdx.x * 4 + wave;
-    uint64_t* __restrict__ prow = p.partial + (size_t)gw * nbins;
-    bool flushed = false;
 
     // work items are handed out dynamically (one returning atomic per item, fetched one item ahead)
     int q = blockIdx.x & 7, tries = 0;
@@ -449,31 +447,31 @@ __global__ __launch_bounds__(256) void k_rdf_pencil(vmd_pair_params_t p) {
                     }
                 }
             }
-            // u32 LDS counters: every candidate column adds at most 64*INC; flush long before 2^32
+            // u32 LDS counters: every candidate column adds at most 64*INC; flush long before 2^32 (rare: straight to the
+            // device accumulators with atomics)
             if (w.ncols >= (1u << 23)) {
                 vmd_drain<VARIANT, INC>(p.bin, w, lane);
                 __builtin_amdgcn_wave_barrier();
                 for (int bb = lane; bb < nbins; bb += VMD_WAVE) {
-                    const uint64_t v = w.hist[bb];
-                    prow[bb] = flushed ? prow[bb] + v : v;
+                    const unsigned v = w.hist[bb];
+                    if (v) atomicAdd(&p.counts[bb], (unsigned long long)v);
                     w.hist[bb] = 0u;
                 }
                 __builtin_amdgcn_wave_barrier();
-                flushed = true;
                 w.ncols = 0;
             }
         }
         next_item = __builtin_amdgcn_readfirstlane(next_item);
     }
     vmd_drain<VARIANT, INC>(p.bin, w, lane);
-    __builtin_amdgcn_wave_barrier();
-    for (int bb = lane; bb < nbins; bb += VMD_WAVE) {
-        const uint64_t v = w.hist[bb];
-        prow[bb] = flushed ? prow[bb] + v : v;
-    }
+    // one row per block: the four wave histograms are summed through LDS and stored with plain, coalesced writes
+    __syncthreads();
+    uint64_t* __restrict__ prow = p.partial + (size_t)blockIdx.x * nbins;
+    for (int bb = threadIdx.x; bb < nbins; bb += 256)
+        prow[bb] = (uint64_t)s_hist[0][bb] + s_hist[1][bb] + s_hist[2][bb] + s_hist[3][bb];
 }
 
-// sum the per-wave partial rows into the u64 accumulators: block (x = 256 bins, y = slice of 32 rows), coalesced
+// sum the per-block partial rows into the u64 accumulators: block (x = 256 bins, y = slice of 32 rows), coalesced
 // row reads, one atomicAdd(u64) per bin and slice
 __global__ __launch_bounds__(256) void k_hist_reduce(const uint64_t* __restrict__ partial, int nrows, int nbins,
                                                      uint64_t* __restrict__ counts) {
@@ -933,7 +931,7 @@ extern "C" int vmd_hip_cells_build(void* stream, const float* xyz, size_t frame_
 }
 
 extern "C" int vmd_hip_rdf_num_blocks(void) { return 2048; }   // 8 blocks x 4 waves per CU: 8 waves per SIMD
-extern "C" size_t vmd_hip_rdf_partial_words(void) { return (size_t)vmd_hip_rdf_num_blocks() * 4 * VMD_MAX_BINS + 4; }
+extern "C" size_t vmd_hip_rdf_partial_words(void) { return (size_t)vmd_hip_rdf_num_blocks() * VMD_MAX_BINS + 4; }
 
 extern "C" int vmd_hip_rdf_pencil(void* stream, const float* sorted_ref, const uint32_t* cell_start_ref, int nref, int nref_pad,
                                   const float* sorted_tgt, const uint32_t* cell_start_tgt, int ntgt, int ntgt_pad,
@@ -943,7 +941,7 @@ extern "C" int vmd_hip_rdf_pencil(void* stream, const float* sorted_ref, const u
     if (nbins <= 0 || nbins > VMD_MAX_BINS) return (int)hipErrorInvalidValue;
     if (B <= 0 || nref <= 0 || ntgt <= 0) return 0;
     // the work counter lives behind the partial rows (see vmd_hip_rdf_partial_words)
-    unsigned* work_counter = (unsigned*)(partial + (size_t)vmd_hip_rdf_num_blocks() * 4 * VMD_MAX_BINS);
+    unsigned* work_counter = (unsigned*)(partial + (size_t)vmd_hip_rdf_num_blocks() * VMD_MAX_BINS);
     {
         hipError_t e = hipMemsetAsync(work_counter, 0, 8 * sizeof(unsigned), s);
         if (e != hipSuccess) return (int)e;
@@ -957,6 +955,7 @@ extern "C" int vmd_hip_rdf_pencil(void* stream, const float* sorted_ref, const u
     p.r2_up = nextafterf(rmax * rmax, 3.0e38f) * 1.0001f;
     p.rpad = rmax * 1.0001f + 1.0e-4f;
     p.partial = partial;
+    p.counts = (unsigned long long*)counts;
     const int nitems = B * grid.ny * grid.nz;
     int nblocks = (nitems + 3) / 4;
     if (nblocks < 8) nblocks = 8;
@@ -970,7 +969,7 @@ extern "C" int vmd_hip_rdf_pencil(void* stream, const float* sorted_ref, const u
         else hipLaunchKernelGGL((k_rdf_pencil<0, false>), g, blk, 0, s, p);
     }
     VMD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_hist_reduce, dim3((nbins + 255) / 256, (nblocks * 4 + 31) / 32), dim3(256), 0, s, (const uint64_t*)partial, nblocks * 4, nbins, counts);
+    hipLaunchKernelGGL(k_hist_reduce, dim3((nbins + 255) / 256, (nblocks + 31) / 32), dim3(256), 0, s, (const uint64_t*)partial, nblocks, nbins, counts);
     VMD_LAUNCH_CHECK();
     return 0;
 }

@@ -44,7 +44,7 @@ class HostTrajectory:
             return True
 
         self._cb = (L.NUM_FRAMES_FN(num_frames), L.NUM_ATOMS_FN(num_atoms), L.LOAD_FRAME_FN(load_frame))
-        self.c = L.TrajectoryI(None, self._cb[0], self._cb[1], self._cb[2], L.DEVICE_VIEW_FN())
+        self.c = L.TrajectoryI(None, self._cb[0], self._cb[1], self._cb[2], L.DEVICE_VIEW_FN(), L.HOST_VIEW_FN())
 
     def interface(self):
         return C.byref(self.c)
@@ -54,6 +54,57 @@ class HostTrajectory:
 
     def num_atoms(self):
         return self.coords.shape[2]
+
+
+class PinnedHostTrajectory:
+    """Frames in pinned host memory in the evaluator's own SoA layout (a frame cache): every batch crosses PCIe once,
+    DMA'd directly, overlapped with the kernels of the previous batch."""
+
+    def __init__(self, num_frames, num_atoms, lib=None):
+        self.lib = lib or L.default_lib()
+        self.h = self.lib.vmd_hosttraj_create(int(num_frames), int(num_atoms))
+        if not self.h:
+            raise VmdError(self.lib.last_error())
+        self._num_frames, self._num_atoms = int(num_frames), int(num_atoms)
+
+    def close(self):
+        if self.h:
+            self.lib.vmd_hosttraj_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def interface(self):
+        return self.lib.vmd_hosttraj_interface(self.h)
+
+    def num_frames(self):
+        return self._num_frames
+
+    def num_atoms(self):
+        return self._num_atoms
+
+    def frame(self, f):
+        """numpy view [3, num_atoms] of frame f (writable)"""
+        rs = C.c_size_t(0)
+        p = self.lib.vmd_hosttraj_frame_ptr(self.h, int(f), C.byref(rs))
+        return np.ctypeslib.as_array(p, shape=(3, rs.value))[:, :self._num_atoms]
+
+    def upload(self, coords, cells):
+        coords = np.asarray(coords, np.float32)
+        if isinstance(cells, L.Unitcell):
+            cells = [cells] * coords.shape[0]
+        for f in range(coords.shape[0]):
+            self.frame(f)[:] = coords[f]
+            self.lib.vmd_hosttraj_set_cell(self.h, f, C.byref(cells[f]))
+
+    def copy_from_device(self, dev, frame_beg=0, frame_end=None):
+        frame_end = self._num_frames if frame_end is None else frame_end
+        if not self.lib.vmd_hosttraj_copy_from_device(self.h, dev.h, int(frame_beg), int(frame_end)):
+            raise VmdError(self.lib.last_error())
 
 
 class DeviceTrajectory:
