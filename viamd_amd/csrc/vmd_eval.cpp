@@ -763,7 +763,8 @@ static size_t auto_batch(const vmd_script_eval_t* e, size_t num_atoms) {
     // scratch per frame: every selection holds ~20 B per selected atom + the staged frame itself (host trajectories)
     size_t per_frame = 12 * num_atoms;
     for (auto& s : e->sels) per_frame += 24 * s->idx.size();
-    size_t B = (size_t)(1536ull << 20) / std::max<size_t>(per_frame, 1);
+    // 288 GB of HBM: a 12 GB scratch budget keeps whole 1k-frame trajectories of the 1M-atom configs in one or two launches
+    size_t B = (size_t)(12ull << 30) / std::max<size_t>(per_frame, 1);
     B = std::max<size_t>(1, std::min<size_t>(B, 1024));
     return B;
 }

@@ -104,17 +104,21 @@ __device__ __forceinline__ unsigned vmd_lane_prefix(unsigned long long mask) {
 struct vmd_binning_t {
     float rmin, rmax, inv_range, fnbins;
     int nbins;
-    // fast path of vmd_bin_fast: v_sqrt_f32 (1 ulp) is trusted when the distance is safely inside (fast_lo, fast_hi)
-    // and the scaled value is at least fast_delta away from a bin edge; everything else takes the exact path
-    float fast_lo, fast_hi, fast_delta;
+    // fast path of vmd_bin_add: t' = fma(v_sqrt_f32(d2), fast_k, fast_c) approximates the spec's scaled distance to within
+    // fast_delta/4; it is trusted when it lies at least fast_delta away from every integer (bin edge, and through bins 0 and
+    // nbins-1 also from r_min / r_max); everything else takes the exact path
+    float fast_k, fast_c, fast_half;   // fast_half = 0.5 - fast_delta
 };
 __host__ __device__ inline vmd_binning_t vmd_make_binning(float rmin, float rmax, int nbins) {
     vmd_binning_t b;
     b.rmin = rmin; b.rmax = rmax; b.inv_range = 1.0f / (rmax - rmin); b.fnbins = (float)nbins; b.nbins = nbins;
-    b.fast_lo = rmin * (1.0f + 1.0e-6f) + 1.0e-30f;
-    b.fast_hi = rmax * (1.0f - 1.0e-6f);
-    b.fast_delta = 1.0e-3f + 1.0e-6f * rmax * b.inv_range * b.fnbins;
-    if (!(b.fast_delta < 0.25f)) { b.fast_lo = 3.0e38f; b.fast_hi = -3.0e38f; }   // degenerate range: exact path only
+    // error budget of t' against the spec value ((d - rmin) * inv_range) * nbins: v_sqrt_f32 1 ulp and three roundings on each
+    // side, all relative to rmax * inv_range * nbins -> 1e-6 * that is > 8 ulp; plus 1e-3 absolute head room
+    const float delta = 1.0e-3f + 1.0e-6f * rmax * b.inv_range * b.fnbins;
+    b.fast_k = b.inv_range * b.fnbins;
+    b.fast_c = -rmin * b.fast_k;
+    b.fast_half = 0.5f - delta;
+    if (!(delta < 0.25f)) b.fast_half = -1.0f;      // degenerate range: nothing is ever "sure", exact path only
     return b;
 }
 __device__ __forceinline__ int vmd_bin_of(const vmd_binning_t& b, float d2) {
@@ -224,12 +228,11 @@ struct vmd_wave_acc_t {
 // bin or the open-interval test; the (rare) uncertain lanes re-do the computation with the correctly rounded sqrtf.
 template <unsigned INC>
 __device__ __forceinline__ void vmd_bin_add(const vmd_binning_t& bn, unsigned* hist, float d2, bool active) {
-    const float s = __builtin_amdgcn_sqrtf(d2);
-    const float t = ((s - bn.rmin) * bn.inv_range) * bn.fnbins;
-    const float fl = floorf(t);
-    const float fr = t - fl;
-    const bool sure = s > bn.fast_lo && s < bn.fast_hi && fr > bn.fast_delta && fr < 1.0f - bn.fast_delta;
-    int bin = (int)fl;
+    const float t = fmaf(__builtin_amdgcn_sqrtf(d2), bn.fast_k, bn.fast_c);
+    int bin = (int)t;                                   // truncation: floor for the t > 0 that can be "sure"
+    const float fr = t - truncf(t);
+    // sure <=> t is inside bin `bin` with margin delta on both sides and the bin exists (negative t wraps to a huge unsigned)
+    const bool sure = fabsf(fr - 0.5f) < bn.fast_half && (unsigned)bin < (unsigned)bn.nbins;
     bool add = active && sure;
     if (__ballot(active && !sure)) {
         if (active && !sure) {
