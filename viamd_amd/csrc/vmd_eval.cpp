@@ -747,7 +747,7 @@ static bool build_selection(vmd_script_eval_t* e, Selection* s, const Stage& src
     const int nsel = (int)s->idx.size();
     s->nsel_pad = (nsel + 63) & ~63;
     if (!s->cell_count.ensure(nb * (size_t)(g.ncell + 1)) || !s->cell_start.ensure(nb * (size_t)(g.ncell + 1)) ||
-        !s->rank.ensure(nb * (size_t)nsel) || !s->sorted.ensure(nb * 3 * (size_t)s->nsel_pad)) return false;
+        !s->rank.ensure(nb * (size_t)nsel) || !s->sorted.ensure(nb * 3 * (size_t)s->nsel_pad + 64)) return false;   // +64: the pair kernel prefetches past a segment
     e->prof.begin("cells_build", e->stream);
     KRN_OK(vmd_hip_cells_build(e->stream, src.base, src.frame_stride, src.row_stride, src.d_boxes.p, (int)nb, s->d_idx.p, nsel,
                                s->nsel_pad, g, s->cell_count.p, s->rank.p, s->cell_start.p, s->sorted.p));

@@ -302,9 +302,8 @@ __device__ __forceinline__ void vmd_segment_loop(const vmd_pair_params_t& p, vmd
     // arithmetic is still SPEC S3 exactly; the j pair sits in an SGPR pair straight from s_load_dwordx4
     const vmd_f2 xi2 = {xi, xi}, yi2 = {yi, yi}, zi2 = {zi, zi};
     const vmd_f2 sx2 = {sx, sx}, sy2 = {sy, sy}, sz2 = {sz, sz};
-    unsigned k = 0;
-    for (; k + 4 <= n; k += 4) {
-        const vmd_f4 xj = vmd_uniform_load4(px, 4u * k), yj = vmd_uniform_load4(py, 4u * k), zj = vmd_uniform_load4(pz, 4u * k);
+    // four columns (two packed pairs) from one s_load_dwordx4 per coordinate
+    auto group = [&](const vmd_f4& xj, const vmd_f4& yj, const vmd_f4& zj, unsigned k0) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const vmd_f2 xj2 = {xj[2 * h], xj[2 * h + 1]}, yj2 = {yj[2 * h], yj[2 * h + 1]}, zj2 = {zj[2 * h], zj[2 * h + 1]};
@@ -314,11 +313,24 @@ __device__ __forceinline__ void vmd_segment_loop(const vmd_pair_params_t& p, vmd
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 bool hit = d2[u] < r2;
-                if (MASKED) hit = hit && (ja + k + 2 * h + u > i);
+                if (MASKED) hit = hit && (ja + k0 + 2 * h + u > i);
                 vmd_push<VARIANT, INC>(p.bin, w, hit, d2[u]);
             }
         }
         vmd_drain_full<VARIANT, INC>(p.bin, w, lane);
+    };
+    // software pipeline: the scalar loads of the next group are issued before the current group is processed (two register
+    // sets, no copies).  Loads may run up to 16 bytes past the segment: the sorted rows carry that much slack.
+    unsigned k = 0;
+    if (n >= 4) {
+        vmd_f4 xa = vmd_uniform_load4(px, 0), ya = vmd_uniform_load4(py, 0), za = vmd_uniform_load4(pz, 0);
+        for (; k + 8 <= n; k += 8) {
+            const vmd_f4 xb = vmd_uniform_load4(px, 4u * k + 16u), yb = vmd_uniform_load4(py, 4u * k + 16u), zb = vmd_uniform_load4(pz, 4u * k + 16u);
+            group(xa, ya, za, k);
+            xa = vmd_uniform_load4(px, 4u * k + 32u); ya = vmd_uniform_load4(py, 4u * k + 32u); za = vmd_uniform_load4(pz, 4u * k + 32u);
+            group(xb, yb, zb, k + 4);
+        }
+        if (k + 4 <= n) { group(xa, ya, za, k); k += 4; }
     }
     for (; k < n; ++k) {
         float dx = xi - px[k], dy = yi - py[k], dz = zi - pz[k];
