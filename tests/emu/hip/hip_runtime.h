@@ -20,6 +20,7 @@
 #define __shared__ static
 #define __launch_bounds__(...)
 #define VMD_UNIFORM_AS
+#define VMD_NO_INLINE_ASM
 
 struct dim3 {
     unsigned x, y, z;

@@ -217,8 +217,9 @@ struct vmd_pair_params_t {
 // per-wave state of the hit machinery
 struct vmd_wave_acc_t {
     unsigned* hist;       // LDS, nbins
-    char* qbase;          // LDS, VMD_QUEUE_CAP floats: the wave's hit stack
-    char* qptr;           // wave-uniform top of the stack (byte address)
+    float* queue;         // LDS, VMD_QUEUE_CAP floats: the wave's hit stack
+    unsigned qbase;       // LDS byte address of queue[0] (0 in the emulator build, where qtop is a plain offset)
+    unsigned qtop;        // wave-uniform: LDS byte address of the top of the stack
     float* dump;          // per-lane scratch slot: where the non-hit lanes of a push write
     unsigned ncols;       // wave-uniform: candidate columns (<= 64 hits each) since the last flush
 };
@@ -255,21 +256,21 @@ __device__ __forceinline__ void vmd_push(const vmd_binning_t& bn, vmd_wave_acc_t
     }
     const unsigned long long mask = __ballot(hit);
     if (mask) {
-        // every lane stores (no exec-mask juggling): hit lanes to their compacted slot, the others to a private dump slot
+        // every lane stores: hit lanes to their compacted slot, the others to a private dump slot
         const unsigned pre = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-        float* slot = hit ? (float*)(w.qptr + 4u * pre) : w.dump;
+        float* slot = hit ? (float*)((char*)w.queue + ((w.qtop - w.qbase) + 4u * pre)) : w.dump;
         *slot = d2;
-        w.qptr += 4u * (unsigned)__popcll(mask);
+        w.qtop += 4u * (unsigned)__popcll(mask);
     }
 }
 
 template <int VARIANT, unsigned INC>
 __device__ __forceinline__ void vmd_drain_full(const vmd_binning_t& bn, vmd_wave_acc_t& w, int lane) {
     if (VARIANT == 1) return;
-    while (w.qptr - w.qbase >= 4 * VMD_WAVE) {
-        w.qptr -= 4 * VMD_WAVE;
+    while (w.qtop - w.qbase >= 4u * VMD_WAVE) {
+        w.qtop -= 4u * VMD_WAVE;
         __builtin_amdgcn_wave_barrier();
-        const float v = ((const float*)w.qptr)[lane];
+        const float v = *(const float*)((const char*)w.queue + ((w.qtop - w.qbase) + 4u * (unsigned)lane));
         __builtin_amdgcn_wave_barrier();
         vmd_bin_add<INC>(bn, w.hist, v, true);
     }
@@ -279,13 +280,44 @@ template <int VARIANT, unsigned INC>
 __device__ __forceinline__ void vmd_drain(const vmd_binning_t& bn, vmd_wave_acc_t& w, int lane) {
     if (VARIANT == 1) return;
     vmd_drain_full<VARIANT, INC>(bn, w, lane);
-    const unsigned rem = (unsigned)(w.qptr - w.qbase) / 4u;
+    const unsigned rem = (w.qtop - w.qbase) / 4u;
     __builtin_amdgcn_wave_barrier();
-    const float v = ((const float*)w.qbase)[lane];
+    const float v = w.queue[lane];
     __builtin_amdgcn_wave_barrier();
-    w.qptr = w.qbase;
+    w.qtop = w.qbase;
     vmd_bin_add<INC>(bn, w.hist, v, (unsigned)lane < rem);
 }
+
+// The push of the hot loop, hand-scheduled (hipcc spends 8 SALU + 5 VALU per column on the same thing): compare, and if
+// any lane hit, prefix the hit lanes (v_mbcnt), store their d2 on the LDS stack under EXEC = hit mask, advance the stack.
+// Requires EXEC = all 64 lanes on entry (true in the segment loops: padding lanes carry far-away coordinates instead of
+// being masked off).  The SIMT emulator build (tests/emu) has no inline asm and takes the plain C++ vmd_push instead.
+#ifndef VMD_NO_INLINE_ASM
+#define VMD_LDS_ADDRESS(p) ((unsigned)(size_t)(__attribute__((address_space(3))) void*)(p))
+__device__ __forceinline__ void vmd_push_hot(vmd_wave_acc_t& w, float d2, float r2) {
+    unsigned t, n;
+    // s_nop: d2 usually comes straight out of a v_pk_fma_f32; the hazard recogniser cannot see into this block and the
+    // VOP3P result needs one wait state before a dependent VALU read on gfx940-class parts
+    asm volatile(
+        "s_nop 0\n\t"
+        "v_cmp_gt_f32 vcc, %[r2], %[d2]\n\t"
+        "s_cbranch_vccz .Lvmd_nohit%=\n\t"
+        "v_mbcnt_lo_u32_b32 %[t], vcc_lo, 0\n\t"
+        "v_mbcnt_hi_u32_b32 %[t], vcc_hi, %[t]\n\t"
+        "v_lshl_add_u32 %[t], %[t], 2, %[q]\n\t"
+        "s_mov_b64 exec, vcc\n\t"
+        "ds_write_b32 %[t], %[d2]\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        "s_bcnt1_i32_b64 %[n], vcc\n\t"
+        "s_lshl2_add_u32 %[q], %[n], %[q]\n"
+        ".Lvmd_nohit%=:"
+        : [q] "+s"(w.qtop), [t] "=&v"(t), [n] "=&s"(n)
+        : [d2] "v"(d2), [r2] "s"(r2)
+        : "vcc", "scc", "memory");
+}
+#else
+#define VMD_LDS_ADDRESS(p) 0u
+#endif
 
 // one uniform j segment [ja, jb) against the wave's 64 i atoms.  MASKED: count only j > i (own pencil, same set).
 // SHIFT: the segment is a periodic image, displaced by (sx,sy,sz) (SPEC S3: dx = fl(fl(xi-xj) - sx)).
@@ -312,6 +344,9 @@ __device__ __forceinline__ void vmd_segment_loop(const vmd_pair_params_t& p, vmd
             const vmd_f2 d2 = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
+#ifndef VMD_NO_INLINE_ASM
+                if (VARIANT == 0 && !MASKED) { vmd_push_hot(w, d2[u], r2); continue; }
+#endif
                 bool hit = d2[u] < r2;
                 if (MASKED) hit = hit && (ja + k0 + 2 * h + u > i);
                 vmd_push<VARIANT, INC>(p.bin, w, hit, d2[u]);
@@ -386,8 +421,9 @@ __global__ __launch_bounds__(256) void k_rdf_pencil(vmd_pair_params_t p) {
 
     vmd_wave_acc_t w;
     w.hist = s_hist[wave];
-    w.qbase = (char*)s_queue[wave];
-    w.qptr = w.qbase;
+    w.queue = s_queue[wave];
+    w.qbase = VMD_LDS_ADDRESS(s_queue[wave]);
+    w.qtop = w.qbase;
     w.dump = &s_queue[wave][VMD_QUEUE_CAP - VMD_WAVE + lane];
     w.ncols = 0;
     for (int b = lane; b < nbins; b += VMD_WAVE) w.hist[b] = 0u;
