@@ -36,6 +36,10 @@ typedef struct vmd_grid_t {
  *   rank       u32[B][nsel]     scratch
  *   cell_start u32[B][ncell+1]  out: exclusive prefix of the cell populations
  *   sorted     f32[B][3][nsel_pad] out: wrapped coordinates in cell order (x row, y row, z row) */
+/* selections of <= 65536 atoms on grids with ncell + 1 <= 24576 are built by one block per frame entirely in LDS
+ * (count -> scan -> scatter); larger ones take the three-kernel path with global atomics */
+int vmd_hip_cells_fused_ok(vmd_grid_t grid, int nsel);
+int vmd_hip_set_cells_fused(int on);   /* tuning / A-B switch, returns the previous value */
 int vmd_hip_cells_build(void* stream, const float* xyz, size_t frame_stride, size_t row_stride,
                         const float* boxes, int B, const int32_t* sel, int nsel, int nsel_pad,
                         vmd_grid_t grid, uint32_t* cell_count, uint32_t* rank, uint32_t* cell_start, float* sorted);

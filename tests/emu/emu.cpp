@@ -152,7 +152,11 @@ static void run_block(int nthreads) {
     }
 }
 
-void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
+static std::vector<uint64_t> g_dynshm;
+void* dyn_shared() { return g_dynshm.data(); }
+
+void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body) {
+    g_dynshm.assign(shmem / 8 + 2, 0);
     g_body = &body;
     g_gridDim = grid;
     g_blockDim = block;

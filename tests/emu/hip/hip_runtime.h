@@ -19,6 +19,8 @@
 #define __forceinline__ inline __attribute__((always_inline))
 #define __shared__ static
 #define __launch_bounds__(...)
+#define HIP_DYNAMIC_SHARED(type, var) type* var = (type*)emu::dyn_shared();
+#define hipFuncAttributeMaxDynamicSharedMemorySize 8
 #define VMD_UNIFORM_AS
 #define VMD_NO_INLINE_ASM
 
@@ -35,7 +37,8 @@ extern emu_uint3 g_blockIdx;
 extern dim3 g_blockDim, g_gridDim;
 emu_uint3 cur_tid();
 int cur_lane();
-void launch(dim3 grid, dim3 block, const std::function<void()>& body);
+void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body);
+void* dyn_shared();
 void sync_block();
 void sync_wave();
 unsigned long long ballot(int pred);
@@ -119,6 +122,7 @@ static inline hipError_t hipHostUnregister(void*) { return hipSuccess; }
 static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
+static inline hipError_t hipFuncSetAttribute(const void*, int, int) { return hipSuccess; }
 static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = (hipEvent_t)0x1; return hipSuccess; }
 static inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
 static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
@@ -126,4 +130,4 @@ static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) {
 static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.0f; return hipSuccess; }
 
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
-    emu::launch((grid), (block), [=]() { kernel(__VA_ARGS__); })
+    emu::launch((grid), (block), (shmem), [=]() { kernel(__VA_ARGS__); })

@@ -61,6 +61,7 @@ extern "C" int vmd_set_option(const char* key, int value) {
     else if (!strcmp(key, "batch_frames")) o = &g_opt.batch_frames;
     else if (!strcmp(key, "force_brute")) o = &g_opt.force_brute;
     else if (!strcmp(key, "nxf_divisor")) o = &g_opt.nxf_divisor;
+    else if (!strcmp(key, "cells_fused")) return vmd_hip_set_cells_fused(value);
     if (!o) return -1;
     return o->exchange(value);
 }
@@ -735,6 +736,9 @@ static bool choose_grid(const Stage& st, size_t nb, float rmax, vmd_grid_t* g) {
     const float cx = rmax / (float)std::max(1, g_opt.nxf_divisor.load());
     int nxf = (int)std::floor(Lmin[0] / cx);
     nxf = std::max(1, std::min(nxf, 4096));
+    // keep the cell table small enough for the LDS-resident build (24576 counters) as long as the fine cells stay <= rmax/3
+    const int nxf_lds = 24575 / (n[1] * n[2]);
+    if (nxf > nxf_lds && nxf_lds >= (int)std::ceil(3.0f * Lmin[0] / rmax)) nxf = nxf_lds;
     g->nxf = nxf; g->ny = n[1]; g->nz = n[2];
     const long long ncell = (long long)nxf * n[1] * n[2];
     if (ncell > (1ll << 26)) return false;

@@ -199,6 +199,50 @@ __global__ __launch_bounds__(256) void k_cells_scatter(vmd_cells_params_t p) {
     s[2 * (size_t)p.nsel_pad + pos] = zw;
 }
 
+// Fused build for grids whose cell table fits in LDS: ONE 1024-thread block per frame does count (LDS atomics) ->
+// exclusive scan (in LDS) -> scatter (LDS cursors).  No global atomics, no rank array, no separate scan launch.
+// LDS: (ncell + 1) counters + 1024 scan partials.
+__global__ __launch_bounds__(1024) void k_cells_fused(vmd_cells_params_t p) {
+    HIP_DYNAMIC_SHARED(uint32_t, s_dyn)
+    uint32_t* s_cnt = s_dyn;                       // [ncell + 1]
+    uint32_t* s_part = s_dyn + p.grid.ncell + 1;   // [1024]
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int ncell = p.grid.ncell;
+    for (int c = tid; c <= ncell; c += 1024) s_cnt[c] = 0u;
+    __syncthreads();
+    float xw, yw, zw;
+    for (int t = tid; t < p.nsel; t += 1024) atomicAdd(&s_cnt[vmd_cell_of(p, b, t, xw, yw, zw)], 1u);
+    __syncthreads();
+    // exclusive scan, same scheme as k_cells_scan
+    const int per = (ncell + 1023) / 1024;
+    const int beg = tid * per;
+    const int end = beg + per < ncell ? beg + per : ncell;
+    uint32_t sum = 0;
+    for (int c = beg; c < end; ++c) sum += s_cnt[c];
+    s_part[tid] = sum;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const uint32_t v = tid >= o ? s_part[tid - o] : 0u;
+        __syncthreads();
+        s_part[tid] += v;
+        __syncthreads();
+    }
+    uint32_t run = s_part[tid] - sum;
+    uint32_t* out = p.cell_start + (size_t)b * (ncell + 1);
+    for (int c = beg; c < end; ++c) { const uint32_t n = s_cnt[c]; s_cnt[c] = run; out[c] = run; run += n; }
+    if (tid == 1023) out[ncell] = s_part[1023];
+    __syncthreads();
+    float* srt = p.sorted + (size_t)b * 3 * p.nsel_pad;
+    for (int t = tid; t < p.nsel; t += 1024) {
+        const uint32_t c = vmd_cell_of(p, b, t, xw, yw, zw);
+        const uint32_t pos = atomicAdd(&s_cnt[c], 1u);
+        srt[pos] = xw;
+        srt[p.nsel_pad + pos] = yw;
+        srt[2 * (size_t)p.nsel_pad + pos] = zw;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ K2: RDF, pencil grid
 
 struct vmd_pair_params_t {
@@ -963,11 +1007,30 @@ __global__ __launch_bounds__(256) void k_synth(vmd_synth_params_t p) {
 
 #define VMD_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)
 
+static int g_cells_fused = 1;
+extern "C" int vmd_hip_set_cells_fused(int on) { const int old = g_cells_fused; g_cells_fused = on; return old; }
+// the fused single-block-per-frame build needs the cell table in LDS (<= 96 KB of counters)
+// ... and pays off while one block per frame still has enough parallelism (measured: 33k atoms/frame 1.5x faster, 333k slower)
+extern "C" int vmd_hip_cells_fused_ok(vmd_grid_t grid, int nsel) { return g_cells_fused && grid.ncell + 1 <= 24576 && nsel <= 65536; }
+
 extern "C" int vmd_hip_cells_build(void* stream, const float* xyz, size_t frame_stride, size_t row_stride,
                                    const float* boxes, int B, const int32_t* sel, int nsel, int nsel_pad,
                                    vmd_grid_t grid, uint32_t* cell_count, uint32_t* rank, uint32_t* cell_start, float* sorted) {
     hipStream_t s = (hipStream_t)stream;
     if (B <= 0 || nsel <= 0) return 0;
+    if (vmd_hip_cells_fused_ok(grid, nsel)) {
+        vmd_cells_params_t pf{xyz, frame_stride, row_stride, boxes, sel, nsel, nsel_pad, grid, cell_count, rank, cell_start, sorted};
+        const size_t shm = sizeof(uint32_t) * ((size_t)grid.ncell + 1 + 1024);
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t ea = hipFuncSetAttribute((const void*)k_cells_fused, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+            if (ea != hipSuccess) return (int)ea;
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(k_cells_fused, dim3(B), dim3(1024), shm, s, pf);
+        VMD_LAUNCH_CHECK();
+        return 0;
+    }
     hipError_t e = hipMemsetAsync(cell_count, 0, sizeof(uint32_t) * (size_t)B * (grid.ncell + 1), s);
     if (e != hipSuccess) return (int)e;
     vmd_cells_params_t p{xyz, frame_stride, row_stride, boxes, sel, nsel, nsel_pad, grid, cell_count, rank, cell_start, sorted};
