@@ -11,6 +11,16 @@ def water_box(O, seed, n_atoms, box, frames, sigma=0.05):
     return np.stack([O.synth_frame(seed, n_atoms, box, sigma, f) for f in range(frames)])
 
 
+def host_frames(O, seed, n_atoms, box, frames, n_blob=0, sigma=0.05):
+    """The synthetic system of viamd_amd.synth on the host (oracle generator for the waters), float32 [F, 3, n_atoms]."""
+    from viamd_amd import synth
+    out = np.stack([O.synth_frame(seed, n_atoms, box, sigma, f, n_blob=n_blob) for f in range(frames)])
+    if n_blob:
+        for f0, xyz in synth.blob_trajectory(seed, n_blob, box, frames):
+            out[f0:f0 + xyz.shape[0], :, :n_blob] = xyz
+    return out
+
+
 def oxygen(n_atoms):
     return np.arange(0, n_atoms, 3, dtype=np.int32)
 

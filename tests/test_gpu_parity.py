@@ -111,6 +111,33 @@ def test_rdf_sharding_threads_and_reevaluation(gpu_lib, oracle, box30k):
     np.testing.assert_array_equal(ev.property_data("goo").counts, ref)
 
 
+def test_full_and_filtered_eval_run_concurrently(gpu_lib, oracle, box30k):
+    """VIAMD's "Eval Full" + "Eval Filt" (src/main.cpp:982-1039): two evals from ONE ir, the filtered one over a sub-range,
+    both running at the same time from different pool threads."""
+    o = cases.oxygen(30000)
+    ir = V.ScriptIR(); ir.add_rdf("goo", o, o, 12.0)
+    full, filt = V.ScriptEval(4, ir), V.ScriptEval(4, ir)
+    assert full.ir_fingerprint() == filt.ir_fingerprint() == ir.fingerprint()
+    vcell = V.make_unitcell(80.0)
+    traj = V.DeviceTrajectory(4, 30000); traj.upload(box30k, vcell)
+    sysm = V.MolSystem(30000, unitcell=vcell)
+    ths = [threading.Thread(target=lambda: full.frame_range(sysm, traj, 0, 4)),
+           threading.Thread(target=lambda: filt.frame_range(sysm, traj, 1, 3))]
+    [t.start() for t in ths]; [t.join() for t in ths]
+    ocell = oracle.make_cell(80.0)
+    ref_full, _ = cases.oracle_rdf(oracle, box30k, ocell, o, o, 0.0, 12.0)
+    ref_filt, wf = cases.oracle_rdf(oracle, box30k, ocell, o, o, 0.0, 12.0, frames=(1, 2))
+    np.testing.assert_array_equal(full.property_data("goo").counts, ref_full)
+    np.testing.assert_array_equal(filt.property_data("goo").counts, ref_filt)
+    np.testing.assert_allclose(filt.property_data("goo").weights64, wf, rtol=1e-12)
+    assert list(filt.frame_mask()) == [0, 1, 1, 0] and filt.frames_done() == 2
+    # moving the filter window: clear + re-evaluate only the new sub-range (what the timeline slider triggers)
+    filt.clear_data()
+    assert filt.frame_range(sysm, traj, 2, 4)
+    ref2, _ = cases.oracle_rdf(oracle, box30k, ocell, o, o, 0.0, 12.0, frames=(2, 3))
+    np.testing.assert_array_equal(filt.property_data("goo").counts, ref2)
+
+
 def test_synth_kernel_matches_oracle_generator(gpu_lib, oracle):
     t = V.DeviceTrajectory(3, 100002)
     t.synth(2, 100.0, 0.05)
@@ -278,7 +305,7 @@ def test_synthetic_blob_system_device_equals_host_and_script_eval(gpu_lib, oracl
     n_blob, n_atoms, box, F = 200, 200 + 30000, 70.0, 5
     topo = synth.water_box_topology(n_atoms, n_blob)
     traj = synth.make_device_trajectory(V, 12, n_atoms, box, F, n_blob)
-    coords = synth.host_frames(oracle, 12, n_atoms, box, F, n_blob)
+    coords = cases.host_frames(oracle, 12, n_atoms, box, F, n_blob)
     for f in (0, F - 1):
         got, _ = traj.download_frame(f)
         np.testing.assert_array_equal(got, coords[f])

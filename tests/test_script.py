@@ -55,7 +55,7 @@ def test_script_driven_evaluation_matches_oracle(emu_lib, oracle):
     from viamd_amd import _lib as L
     n_blob, n_atoms, box, F = 60, 60 + 900, 30.0, 3
     topo = synth.water_box_topology(n_atoms, n_blob)
-    coords = synth.host_frames(oracle, 12, n_atoms, box, F, n_blob)
+    coords = cases.host_frames(oracle, 12, n_atoms, box, F, n_blob)
     ir, info = script.compile_script(
         "s = residue(2:4); v = sdf(s, element('O') and water, 8.0); g = rdf(element('O') and water, not element('H'), 9.0);"
         "d = distance(residue(1), residue(6)); m = distance_max(residue(2), residue(3));", topo, lib=emu_lib)

@@ -152,13 +152,24 @@ __device__ __forceinline__ uint32_t vmd_cell_of(const vmd_cells_params_t& p, int
     return (uint32_t)((cz * p.grid.ny + cy) * p.grid.nxf + cx);
 }
 
+// atoms per thread.  Measured on the 333k-atom selection of config 3: 4 independent gathers per thread are ~10 % SLOWER than
+// 1 (the kernels are bound by scattered 4-byte write / atomic transactions, not by latency), so this stays at 1.
+#define VMD_CELLS_ILP 1
 __global__ __launch_bounds__(256) void k_cells_count(vmd_cells_params_t p) {
-    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int t0 = blockIdx.x * (256 * VMD_CELLS_ILP) + threadIdx.x;
     const int b = blockIdx.y;
-    if (t >= p.nsel) return;
+    uint32_t c[VMD_CELLS_ILP];
     float xw, yw, zw;
-    const uint32_t c = vmd_cell_of(p, b, t, xw, yw, zw);
-    p.rank[(size_t)b * p.nsel + t] = atomicAdd(&p.cell_count[(size_t)b * (p.grid.ncell + 1) + c], 1u);
+#pragma unroll
+    for (int u = 0; u < VMD_CELLS_ILP; ++u) {
+        const int t = t0 + 256 * u;
+        c[u] = t < p.nsel ? vmd_cell_of(p, b, t, xw, yw, zw) : 0xffffffffu;
+    }
+#pragma unroll
+    for (int u = 0; u < VMD_CELLS_ILP; ++u) {
+        const int t = t0 + 256 * u;
+        if (c[u] != 0xffffffffu) p.rank[(size_t)b * p.nsel + t] = atomicAdd(&p.cell_count[(size_t)b * (p.grid.ncell + 1) + c[u]], 1u);
+    }
 }
 
 // one 1024-thread block per frame: exclusive prefix over the cell populations
@@ -187,16 +198,27 @@ __global__ __launch_bounds__(1024) void k_cells_scan(const uint32_t* __restrict_
 }
 
 __global__ __launch_bounds__(256) void k_cells_scatter(vmd_cells_params_t p) {
-    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int t0 = blockIdx.x * (256 * VMD_CELLS_ILP) + threadIdx.x;
     const int b = blockIdx.y;
-    if (t >= p.nsel) return;
-    float xw, yw, zw;
-    const uint32_t c = vmd_cell_of(p, b, t, xw, yw, zw);
-    const uint32_t pos = p.cell_start[(size_t)b * (p.grid.ncell + 1) + c] + p.rank[(size_t)b * p.nsel + t];
+    float xw[VMD_CELLS_ILP], yw[VMD_CELLS_ILP], zw[VMD_CELLS_ILP];
+    uint32_t pos[VMD_CELLS_ILP];
+#pragma unroll
+    for (int u = 0; u < VMD_CELLS_ILP; ++u) {
+        const int t = t0 + 256 * u;
+        pos[u] = 0xffffffffu;
+        if (t < p.nsel) {
+            const uint32_t c = vmd_cell_of(p, b, t, xw[u], yw[u], zw[u]);
+            pos[u] = p.cell_start[(size_t)b * (p.grid.ncell + 1) + c] + p.rank[(size_t)b * p.nsel + t];
+        }
+    }
     float* s = p.sorted + (size_t)b * 3 * p.nsel_pad;
-    s[pos] = xw;
-    s[p.nsel_pad + pos] = yw;
-    s[2 * (size_t)p.nsel_pad + pos] = zw;
+#pragma unroll
+    for (int u = 0; u < VMD_CELLS_ILP; ++u) {
+        if (pos[u] == 0xffffffffu) continue;
+        s[pos[u]] = xw[u];
+        s[p.nsel_pad + pos[u]] = yw[u];
+        s[2 * (size_t)p.nsel_pad + pos[u]] = zw[u];
+    }
 }
 
 // Fused build for grids whose cell table fits in LDS: ONE 1024-thread block per frame does count (LDS atomics) ->
@@ -1034,7 +1056,7 @@ extern "C" int vmd_hip_cells_build(void* stream, const float* xyz, size_t frame_
     hipError_t e = hipMemsetAsync(cell_count, 0, sizeof(uint32_t) * (size_t)B * (grid.ncell + 1), s);
     if (e != hipSuccess) return (int)e;
     vmd_cells_params_t p{xyz, frame_stride, row_stride, boxes, sel, nsel, nsel_pad, grid, cell_count, rank, cell_start, sorted};
-    const dim3 g((nsel + 255) / 256, B);
+    const dim3 g((nsel + 256 * VMD_CELLS_ILP - 1) / (256 * VMD_CELLS_ILP), B);
     hipLaunchKernelGGL(k_cells_count, g, dim3(256), 0, s, p);
     VMD_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_cells_scan, dim3(B), dim3(1024), 0, s, (const uint32_t*)cell_count, cell_start, (int)grid.ncell);

@@ -68,12 +68,3 @@ def make_device_trajectory(V, seed, n_atoms, box, frames, n_blob=0, sigma=0.05, 
         for f0, xyz in blob_trajectory(seed, n_blob, box, frames):
             traj.upload_atoms(f0, 0, xyz)
     return traj
-
-
-def host_frames(O, seed, n_atoms, box, frames, n_blob=0, sigma=0.05):
-    """The same system on the host (oracle generator for the waters), float32 [F, 3, n_atoms] — used by the CPU baseline."""
-    out = np.stack([O.synth_frame(seed, n_atoms, box, sigma, f, n_blob=n_blob) for f in range(frames)])
-    if n_blob:
-        for f0, xyz in blob_trajectory(seed, n_blob, box, frames):
-            out[f0:f0 + xyz.shape[0], :, :n_blob] = xyz
-    return out
