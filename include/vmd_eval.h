@@ -115,6 +115,11 @@ bool vmd_ir_add_sdf(vmd_script_ir_t* ir, const char* name, const int32_t* struct
 /* `name = distance*(a, b);`  src/main.cpp:2817-2858 */
 bool vmd_ir_add_distance(vmd_script_ir_t* ir, const char* name, vmd_distance_kind_t kind,
                          const int32_t* a, size_t na, const int32_t* b, size_t nb);
+/* `name = distance*(a, b) in <contexts>;` (src/main.cpp:2840-2858): a population of P contexts, one value (or pair block)
+ * per context and frame -> dim[1] = P (x |a||b| for distance_pair).  a/b hold the absolute atom indices of all contexts
+ * back to back; context c owns a[a_offsets[c] .. a_offsets[c+1]) and b[b_offsets[c] .. b_offsets[c+1]). */
+bool vmd_ir_add_distance_population(vmd_script_ir_t* ir, const char* name, vmd_distance_kind_t kind, size_t P,
+                                    const int32_t* a, const int32_t* a_offsets, const int32_t* b, const int32_t* b_offsets);
 bool     vmd_ir_valid(const vmd_script_ir_t* ir);                       /* md_script_ir_valid, src/main.cpp:936 */
 uint64_t vmd_ir_fingerprint(const vmd_script_ir_t* ir);                 /* md_script_ir_fingerprint, src/main.cpp:937 */
 size_t   vmd_ir_property_count(const vmd_script_ir_t* ir);              /* md_script_ir_property_count, src/main.cpp:992,1277 */

@@ -79,12 +79,13 @@ int vmd_hip_sdf_scatter(void* stream, const float* xyz, size_t frame_stride, siz
                         const int32_t* structs, int K, int m, const float* R32, const float* c32,
                         const int32_t* tgt, const int8_t* owner, int ntgt, float extent, int dim, uint64_t* volume);
 
-/* K5: distance family, one row per frame: out f32[B][dim1], dim1 = 1 (COM/MIN/MAX) or na*nb (PAIR). kind as
- * vmd_distance_kind_t.  mass_a/mass_b f32[na]/[nb] (COM only). */
+/* K5: distance family, one row per frame: out f32[B][P*per].  kind as vmd_distance_kind_t; P contexts (population);
+ * context c uses a[aoff[c]..aoff[c+1]) and b[boff[c]..boff[c+1]); per = 1 (COM/MIN/MAX) or |a_c|*|b_c| (PAIR, equal
+ * for all contexts).  mass_a/mass_b parallel to a/b (COM only). */
 int vmd_hip_distance(void* stream, const float* xyz, size_t frame_stride, size_t row_stride,
-                     const float* boxes, uint32_t pbc_flags, int B, int kind,
-                     const int32_t* a, const float* mass_a, int na, const int32_t* b, const float* mass_b, int nb,
-                     float* out);
+                     const float* boxes, uint32_t pbc_flags, int B, int kind, int P, int per,
+                     const int32_t* a, const float* mass_a, const int32_t* aoff,
+                     const int32_t* b, const float* mass_b, const int32_t* boff, float* out);
 
 /* u64 counters -> f32 values (values[i] = (float)counts[i]) + max reduction into max_out[0] (device f32) */
 int vmd_hip_counts_to_float(void* stream, const uint64_t* counts, size_t n, float* values, float* max_out);

@@ -175,21 +175,34 @@ def oracle_distance(O, coords, ocell, mass, a, b, kind):
     return out
 
 
+def oracle_distance_population(O, coords, ocell, mass, a_sets, b_sets, kind):
+    cols = [oracle_distance(O, coords, ocell, mass, np.asarray(a, np.int32), np.asarray(b, np.int32), kind) for a, b in zip(a_sets, b_sets)]
+    return np.concatenate(cols, axis=1)
+
+
 def check_distances(lib, O, coords, box, mass, specs, flags=L.PBC_ALL, device=False, ranges=None):
-    """specs: list of (name, a, b, kind).  Temporal rows must equal the oracle bit for bit (fp32)."""
+    """specs: list of (name, a, b, kind) — or (name, a_sets, b_sets, kind, "pop") for a population of contexts.
+    Temporal rows must equal the oracle bit for bit (fp32)."""
     ocell, vcell = cell_pair(O, box, flags)
     F, _, N = coords.shape
     ir = V.ScriptIR(lib)
-    for name, a, b, kind in specs:
-        ir.add_distance(name, a, b, kind)
+    for sp in specs:
+        if len(sp) == 5:
+            ir.add_distance_population(sp[0], sp[1], sp[2], sp[3])
+        else:
+            ir.add_distance(*sp[:3], sp[3])
     ev = V.ScriptEval(F, ir)
     traj = make_traj(lib, coords, vcell, device)
     sysm = V.MolSystem(N, mass=mass, unitcell=vcell)
     for beg, end in (ranges or [(0, F)]):
         assert ev.frame_range(sysm, traj, beg, end)
-    for name, a, b, kind in specs:
+    for sp in specs:
+        name, a, b, kind = sp[:4]
         pd = ev.property_data(name)
-        ref = oracle_distance(O, coords, ocell, mass, np.asarray(a, np.int32), np.asarray(b, np.int32), kind)
+        if len(sp) == 5:
+            ref = oracle_distance_population(O, coords, ocell, mass, a, b, kind)
+        else:
+            ref = oracle_distance(O, coords, ocell, mass, np.asarray(a, np.int32), np.asarray(b, np.int32), kind)
         assert pd.dim[0] == F and pd.dim[1] == ref.shape[1]
         got = pd.values.reshape(F, -1)
         np.testing.assert_array_equal(got, ref, err_msg=f"{name}: temporal values differ from the oracle")

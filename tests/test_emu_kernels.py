@@ -94,7 +94,11 @@ def test_distance_family(emu_lib, oracle):
     coords, structures, mass = cases.sdf_system(oracle, 9, 600, 30.0, 4)
     specs = [("d", [3], [40], L.DIST_COM), ("dcom", structures[0], structures[1], L.DIST_COM),
              ("dmin", structures[0], structures[2], L.DIST_MIN), ("dmax", structures[1], structures[3], L.DIST_MAX),
-             ("dpair", structures[0][:3], structures[1][:4], L.DIST_PAIR)]
+             ("dpair", structures[0][:3], structures[1][:4], L.DIST_PAIR),
+             # populations: `distance(1, 4) in residue(:)`, `distance_min(...) in ...`, `distance_pair(1:2, 4:6) in ...`
+             ("pcom", [s[:1] for s in structures], [s[3:4] for s in structures], L.DIST_COM, "pop"),
+             ("pmin", [s[:2] for s in structures], [s[2:] for s in structures], L.DIST_MIN, "pop"),
+             ("ppair", [s[:2] for s in structures], [s[3:6] for s in structures], L.DIST_PAIR, "pop")]
     cases.check_distances(emu_lib, oracle, coords, 30.0, mass, specs, ranges=[(0, 2), (2, 4)])
 
 

@@ -229,7 +229,10 @@ def test_distance_family_and_coevaluation(gpu_lib, oracle):
     specs = [("d", [3], [40], L.DIST_COM), ("dcom", structures[0], structures[1], L.DIST_COM),
              ("dmin", structures[0], structures[2], L.DIST_MIN), ("dmax", structures[1], structures[3], L.DIST_MAX),
              ("dpair", structures[0][:3], structures[1][:4], L.DIST_PAIR)]
-    cases.check_distances(gpu_lib, oracle, coords, 50.0, mass, specs, device=True, ranges=[(0, 5), (5, 12)])
+    pops = [("pcom", [s[:1] for s in structures], [s[3:4] for s in structures], L.DIST_COM, "pop"),
+            ("pmax", [s[:2] for s in structures], [s[2:] for s in structures], L.DIST_MAX, "pop"),
+            ("ppair", [s[:2] for s in structures], [s[3:6] for s in structures], L.DIST_PAIR, "pop")]
+    cases.check_distances(gpu_lib, oracle, coords, 50.0, mass, specs + pops, device=True, ranges=[(0, 5), (5, 12)])
     # BASELINE config 5 in miniature: 3 RDF + 1 SDF + 4 distance properties on one eval, one pass over the frames
     N = coords.shape[2]
     n_s = structures.size

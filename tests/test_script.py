@@ -42,9 +42,20 @@ def test_baseline_config_scripts_compile(emu_lib, topo):
     assert info["v"]["structures"].shape == (7, 10) and info["v"]["structures"][0, 0] == 40
 
 
+def test_distance_in_context_population(emu_lib, topo):
+    """`distance(i, j) in residue(k)` uses indices local to the residue (src/main.cpp:2836-2840); an array of contexts gives a population"""
+    ir, info = script.compile_script("d = distance(1, 5) in residue(3); p = distance_min(1:2, element('O')) in resname(\"ALA\")[2:4];",
+                                     topo, lib=emu_lib)
+    assert info["d"]["a_sets"][0].tolist() == [20] and info["d"]["b_sets"][0].tolist() == [24]
+    assert len(info["p"]["a_sets"]) == 3 and info["p"]["a_sets"][1].tolist() == [20, 21]
+    assert info["p"]["b_sets"][1].tolist() == [23]                       # the one O of residue 3 (N C C O C H H H C H)
+    ev = V.ScriptEval(2, ir)
+    assert ev.property_data("d").dim[:2] == (2, 1) and ev.property_data("p").dim[:2] == (2, 3)
+
+
 def test_script_errors(emu_lib, topo):
     for bad in ("g = rdf(element('X'), all, 5.0);", "v = sdf(all[1:2], all, 5.0);", "d = distance(1, 999999);",
-                "d = distance(1, 2) in residue(3);", "g = rdf(all, all 5.0);", "x = frobnicate(3);", "g = rdf(residue(0), all, 5.0);"):
+                "d = distance(1, 2) in all;", "d = distance(1, 99) in residue(3);", "g = rdf(all, all 5.0);", "x = frobnicate(3);", "g = rdf(residue(0), all, 5.0);"):
         with pytest.raises((script.ScriptError, V.VmdError)):
             script.compile_script(bad, topo, lib=emu_lib)
 

@@ -90,6 +90,7 @@ SIGNATURES = [
     ("vmd_ir_add_rdf", C.c_bool, [_vp, C.c_char_p, c_int32_p, C.c_size_t, c_int32_p, C.c_size_t, C.c_float, C.c_float]),
     ("vmd_ir_add_sdf", C.c_bool, [_vp, C.c_char_p, c_int32_p, C.c_size_t, C.c_size_t, c_int32_p, C.c_size_t, C.c_float]),
     ("vmd_ir_add_distance", C.c_bool, [_vp, C.c_char_p, C.c_int, c_int32_p, C.c_size_t, c_int32_p, C.c_size_t]),
+    ("vmd_ir_add_distance_population", C.c_bool, [_vp, C.c_char_p, C.c_int, C.c_size_t, c_int32_p, c_int32_p, c_int32_p, c_int32_p]),
     ("vmd_ir_valid", C.c_bool, [_vp]),
     ("vmd_ir_fingerprint", C.c_uint64, [_vp]),
     ("vmd_ir_property_count", C.c_size_t, [_vp]),
@@ -148,8 +149,8 @@ SIGNATURES = [
     ("vmd_hip_sdf_ref_pose", C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_uint32, _vp, _vp, C.c_int, _vp]),
     ("vmd_hip_sdf_scatter", C.c_int, [_vp, _vp, C.c_size_t, C.c_size_t, _vp, C.c_uint32, C.c_int, _vp, C.c_int, C.c_int, _vp, _vp,
                                       _vp, _vp, C.c_int, C.c_float, C.c_int, _vp]),
-    ("vmd_hip_distance", C.c_int, [_vp, _vp, C.c_size_t, C.c_size_t, _vp, C.c_uint32, C.c_int, C.c_int, _vp, _vp, C.c_int,
-                                   _vp, _vp, C.c_int, _vp]),
+    ("vmd_hip_distance", C.c_int, [_vp, _vp, C.c_size_t, C.c_size_t, _vp, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int,
+                                   _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     ("vmd_hip_counts_to_float", C.c_int, [_vp, _vp, C.c_size_t, _vp, _vp]),
     ("vmd_hip_synth_frames", C.c_int, [_vp, _vp, C.c_size_t, C.c_size_t, C.c_int, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32,
                                        C.c_float, C.c_float]),

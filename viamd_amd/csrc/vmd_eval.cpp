@@ -167,6 +167,7 @@ struct Property {
     float rmin = 0.0f, rmax = 0.0f; // RDF range; SDF: rmax = cutoff (half extent)
     size_t K = 0, m = 0;
     int dist_kind = 0;
+    std::vector<int32_t> aoff, boff;   // DIST: context offsets into a / b (population), size P + 1
 };
 
 struct vmd_script_ir_t {
@@ -229,6 +230,29 @@ extern "C" bool vmd_ir_add_distance(vmd_script_ir_t* ir, const char* name, vmd_d
     Property p;
     p.name = name; p.kind = PROP_DIST; p.flags = VMD_PROPERTY_FLAG_TEMPORAL;
     p.a.assign(a, a + na); p.b.assign(b, b + nb);
+    p.aoff = {0, (int32_t)na}; p.boff = {0, (int32_t)nb};
+    p.dist_kind = (int)kind;
+    ir->props.push_back(std::move(p));
+    ir->rebuild_names();
+    return true;
+}
+
+extern "C" bool vmd_ir_add_distance_population(vmd_script_ir_t* ir, const char* name, vmd_distance_kind_t kind, size_t P,
+                                               const int32_t* a, const int32_t* a_offsets, const int32_t* b, const int32_t* b_offsets) {
+    if (!ir_name_ok(ir, name)) return false;
+    if (P == 0 || !a_offsets || !b_offsets) return vmd_fail("distance population is empty");
+    if ((int)kind < 0 || (int)kind > 3) return vmd_fail("unknown distance kind %d", (int)kind);
+    if (a_offsets[0] != 0 || b_offsets[0] != 0) return vmd_fail("context offsets must start at 0");
+    for (size_t c = 0; c < P; ++c) {
+        if (a_offsets[c + 1] <= a_offsets[c] || b_offsets[c + 1] <= b_offsets[c]) return vmd_fail("distance context %zu has an empty set", c);
+        if (kind == VMD_DISTANCE_PAIR && ((a_offsets[c + 1] - a_offsets[c]) != a_offsets[1] || (b_offsets[c + 1] - b_offsets[c]) != b_offsets[1]))
+            return vmd_fail("distance_pair needs contexts of equal size");
+    }
+    if (!idx_ok(a, (size_t)a_offsets[P], "distance set a") || !idx_ok(b, (size_t)b_offsets[P], "distance set b")) return false;
+    Property p;
+    p.name = name; p.kind = PROP_DIST; p.flags = VMD_PROPERTY_FLAG_TEMPORAL;
+    p.a.assign(a, a + a_offsets[P]); p.b.assign(b, b + b_offsets[P]);
+    p.aoff.assign(a_offsets, a_offsets + P + 1); p.boff.assign(b_offsets, b_offsets + P + 1);
     p.dist_kind = (int)kind;
     ir->props.push_back(std::move(p));
     ir->rebuild_names();
@@ -247,6 +271,7 @@ extern "C" uint64_t vmd_ir_fingerprint(const vmd_script_ir_t* ir) {
         h = fnv1a(h, p.b.data(), p.b.size() * sizeof(int32_t));
         h = fnv1a(h, &p.rmin, sizeof(float)); h = fnv1a(h, &p.rmax, sizeof(float));
         h = fnv1a(h, &p.K, sizeof(p.K)); h = fnv1a(h, &p.m, sizeof(p.m)); h = fnv1a(h, &p.dist_kind, sizeof(int));
+        h = fnv1a(h, p.aoff.data(), p.aoff.size() * sizeof(int32_t)); h = fnv1a(h, p.boff.data(), p.boff.size() * sizeof(int32_t));
     }
     return h ? h : 1;
 }
@@ -280,6 +305,7 @@ struct PropState {
     std::vector<double> weights64;
     size_t ncounts = 0;                 // bins or voxels
     size_t dim1 = 0;                    // temporal population
+    size_t dist_P = 1, dist_per = 1;    // DIST: contexts x values per context
     DevBuf<uint64_t> d_counts;
     DevBuf<float> d_values;             // volume float view (device)
     DevBuf<float> d_max;
@@ -294,7 +320,7 @@ struct PropState {
     DevBuf<float> d_R32, d_c32;
     bool ref_pose_ready = false;
     // DIST
-    DevBuf<int32_t> d_a, d_b;
+    DevBuf<int32_t> d_a, d_b, d_aoff, d_boff;
     DevBuf<float> d_ma, d_mb, d_out;
     bool uploaded = false;
     bool pinned = false;
@@ -388,7 +414,9 @@ extern "C" vmd_script_eval_t* vmd_eval_create(size_t num_frames, const vmd_scrip
             st->data.min_range[0] = -p.rmax; st->data.max_range[0] = p.rmax;
             break;
         case PROP_DIST:
-            st->dim1 = p.dist_kind == VMD_DISTANCE_PAIR ? p.a.size() * p.b.size() : 1;
+            st->dist_P = p.aoff.size() - 1;
+            st->dist_per = p.dist_kind == VMD_DISTANCE_PAIR ? (size_t)p.aoff[1] * (size_t)p.boff[1] : 1;
+            st->dim1 = st->dist_P * st->dist_per;
             st->values.assign(num_frames * st->dim1, 0.0f);
             st->data.dim[0] = (int32_t)num_frames; st->data.dim[1] = (int32_t)st->dim1;
             if (st->dim1 > 1) {
@@ -616,6 +644,8 @@ static bool upload_static(vmd_script_eval_t* e, const vmd_system_t* sys) {
         } else if (d.kind == PROP_DIST) {
             if (!p->d_a.upload(d.a.data(), d.a.size(), e->stream)) return false;
             if (!p->d_b.upload(d.b.data(), d.b.size(), e->stream)) return false;
+            if (!p->d_aoff.upload(d.aoff.data(), d.aoff.size(), e->stream)) return false;
+            if (!p->d_boff.upload(d.boff.data(), d.boff.size(), e->stream)) return false;
             masses(d.a, tmp);
             if (!p->d_ma.upload(tmp.data(), tmp.size(), e->stream)) return false;
             masses(d.b, tmp);
@@ -887,7 +917,8 @@ extern "C" bool vmd_eval_frame_range(vmd_script_eval_t* eval, const vmd_script_i
                 if (!p->d_out.ensure(nb * p->dim1)) return false;
                 e->prof.begin("distance", e->stream);
                 KRN_OK(vmd_hip_distance(e->stream, src.base, src.frame_stride, src.row_stride, src.d_boxes.p, pbc, (int)nb, d.dist_kind,
-                                        p->d_a.p, p->d_ma.p, (int)d.a.size(), p->d_b.p, p->d_mb.p, (int)d.b.size(), p->d_out.p));
+                                        (int)p->dist_P, (int)p->dist_per, p->d_a.p, p->d_ma.p, p->d_aoff.p, p->d_b.p, p->d_mb.p, p->d_boff.p,
+                                        p->d_out.p));
                 e->prof.end(e->stream);
                 HIP_OK(hipMemcpyAsync(e->h_temporal.data() + toff, p->d_out.p, nb * p->dim1 * sizeof(float), hipMemcpyDeviceToHost, e->stream));
                 toff += nb * p->dim1;

@@ -884,8 +884,10 @@ __global__ __launch_bounds__(256) void k_sdf_scatter(vmd_scatter_params_t p) {
 struct vmd_dist_params_t {
     const float* xyz; size_t frame_stride; size_t row_stride;
     const float* boxes; uint32_t pbc; int B;
-    const int32_t* a; const float* mass_a; int na; const int32_t* b; const float* mass_b; int nb;
-    float* out;
+    // population of P contexts (`... in residue(:)`): context c uses a[aoff[c]..aoff[c+1]) and b[boff[c]..boff[c+1])
+    const int32_t* a; const float* mass_a; const int32_t* aoff; const int32_t* b; const float* mass_b; const int32_t* boff; int P;
+    int per;      // values per context: 1, or |a_c|*|b_c| for distance_pair (equal for all contexts)
+    float* out;   // [B][P*per]
 };
 
 __device__ void vmd_set_com(const float* fx, const float* fy, const float* fz, const int32_t* idx, const float* mass, int n,
@@ -908,31 +910,32 @@ __device__ void vmd_set_com(const float* fx, const float* fy, const float* fz, c
 }
 
 __global__ __launch_bounds__(64) void k_distance_com(vmd_dist_params_t p) {
-    const int b = blockIdx.x * 64 + threadIdx.x;
-    if (b >= p.B) return;
+    const int t = blockIdx.x * 64 + threadIdx.x;
+    if (t >= p.B * p.P) return;
+    const int b = t / p.P, c = t - b * p.P;
     const float* fx = p.xyz + (size_t)b * p.frame_stride;
     const float* fy = fx + p.row_stride;
     const float* fz = fy + p.row_stride;
     const float Lx = p.boxes[6 * b + 0], Ly = p.boxes[6 * b + 1], Lz = p.boxes[6 * b + 2];
     const float iLx = p.boxes[6 * b + 3], iLy = p.boxes[6 * b + 4], iLz = p.boxes[6 * b + 5];
     const bool px = p.pbc & 1u, py = p.pbc & 2u, pz = p.pbc & 4u;
+    const int a0 = p.aoff[c], na = p.aoff[c + 1] - a0, b0 = p.boff[c], nb = p.boff[c + 1] - b0;
     float ca[3], cb[3];
-    vmd_set_com(fx, fy, fz, p.a, p.mass_a, p.na, (double)Lx, (double)Ly, (double)Lz, px, py, pz, ca);
-    vmd_set_com(fx, fy, fz, p.b, p.mass_b, p.nb, (double)Lx, (double)Ly, (double)Lz, px, py, pz, cb);
+    vmd_set_com(fx, fy, fz, p.a + a0, p.mass_a ? p.mass_a + a0 : nullptr, na, (double)Lx, (double)Ly, (double)Lz, px, py, pz, ca);
+    vmd_set_com(fx, fy, fz, p.b + b0, p.mass_b ? p.mass_b + b0 : nullptr, nb, (double)Lx, (double)Ly, (double)Lz, px, py, pz, cb);
     const float dx = vmd_mi_rintf(ca[0] - cb[0], Lx, iLx, px);
     const float dy = vmd_mi_rintf(ca[1] - cb[1], Ly, iLy, py);
     const float dz = vmd_mi_rintf(ca[2] - cb[2], Lz, iLz, pz);
-    p.out[b] = sqrtf(vmd_d2(dx, dy, dz));
+    p.out[t] = sqrtf(vmd_d2(dx, dy, dz));
 }
 
-__device__ __forceinline__ float vmd_pair_d2(const vmd_dist_params_t& p, int b, int ia, int ib) {
+__device__ __forceinline__ float vmd_pair_d2(const vmd_dist_params_t& p, int b, int i, int j) {
     const float* fx = p.xyz + (size_t)b * p.frame_stride;
     const float* fy = fx + p.row_stride;
     const float* fz = fy + p.row_stride;
     const float Lx = p.boxes[6 * b + 0], Ly = p.boxes[6 * b + 1], Lz = p.boxes[6 * b + 2];
     const float iLx = p.boxes[6 * b + 3], iLy = p.boxes[6 * b + 4], iLz = p.boxes[6 * b + 5];
     const bool px = p.pbc & 1u, py = p.pbc & 2u, pz = p.pbc & 4u;
-    const int i = p.a[ia], j = p.b[ib];
     const float xi = px ? vmd_wrap(fx[i], Lx, iLx) : fx[i], xj = px ? vmd_wrap(fx[j], Lx, iLx) : fx[j];
     const float yi = py ? vmd_wrap(fy[i], Ly, iLy) : fy[i], yj = py ? vmd_wrap(fy[j], Ly, iLy) : fy[j];
     const float zi = pz ? vmd_wrap(fz[i], Lz, iLz) : fz[i], zj = pz ? vmd_wrap(fz[j], Lz, iLz) : fz[j];
@@ -942,16 +945,17 @@ __device__ __forceinline__ float vmd_pair_d2(const vmd_dist_params_t& p, int b, 
     return vmd_d2(dx, dy, dz);
 }
 
-// one block per frame; MAXI = false -> min, true -> max
+// one block per (frame, context); MAXI = false -> min, true -> max
 template <bool MAXI>
 __global__ __launch_bounds__(256) void k_distance_minmax(vmd_dist_params_t p) {
     __shared__ float s_red[256];
-    const int b = blockIdx.x;
-    const long long npairs = (long long)p.na * p.nb;
+    const int b = blockIdx.x / p.P, c = blockIdx.x - b * p.P;
+    const int a0 = p.aoff[c], na = p.aoff[c + 1] - a0, b0 = p.boff[c], nb = p.boff[c + 1] - b0;
+    const long long npairs = (long long)na * nb;
     float best = MAXI ? 0.0f : 3.4028235e38f;
     for (long long k = threadIdx.x; k < npairs; k += 256) {
-        const int ia = (int)(k / p.nb), ib = (int)(k - (long long)ia * p.nb);
-        const float d2 = vmd_pair_d2(p, b, ia, ib);
+        const int ia = (int)(k / nb), ib = (int)(k - (long long)ia * nb);
+        const float d2 = vmd_pair_d2(p, b, p.a[a0 + ia], p.b[b0 + ib]);
         best = MAXI ? fmaxf(best, d2) : fminf(best, d2);
     }
     s_red[threadIdx.x] = best;
@@ -963,16 +967,17 @@ __global__ __launch_bounds__(256) void k_distance_minmax(vmd_dist_params_t p) {
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) p.out[b] = sqrtf(s_red[0]);
+    if (threadIdx.x == 0) p.out[blockIdx.x] = sqrtf(s_red[0]);
 }
 
+// grid (ceil(per/256), B*P): all |a_c| x |b_c| pairs of context c, row-major
 __global__ __launch_bounds__(256) void k_distance_pair(vmd_dist_params_t p) {
-    const long long npairs = (long long)p.na * p.nb;
     const long long k = (long long)blockIdx.x * 256 + threadIdx.x;
-    const int b = blockIdx.y;
-    if (k >= npairs) return;
-    const int ia = (int)(k / p.nb), ib = (int)(k - (long long)ia * p.nb);
-    p.out[(size_t)b * npairs + k] = sqrtf(vmd_pair_d2(p, b, ia, ib));
+    const int b = blockIdx.y / p.P, c = blockIdx.y - b * p.P;
+    if (k >= p.per) return;
+    const int a0 = p.aoff[c], b0 = p.boff[c], nb = p.boff[c + 1] - b0;
+    const int ia = (int)(k / nb), ib = (int)(k - (long long)ia * nb);
+    p.out[((size_t)b * p.P + c) * p.per + k] = sqrtf(vmd_pair_d2(p, b, p.a[a0 + ia], p.b[b0 + ib]));
 }
 
 // ------------------------------------------------------------------------------------------------ misc
@@ -1158,21 +1163,17 @@ extern "C" int vmd_hip_sdf_scatter(void* stream, const float* xyz, size_t frame_
 }
 
 extern "C" int vmd_hip_distance(void* stream, const float* xyz, size_t frame_stride, size_t row_stride,
-                                const float* boxes, uint32_t pbc_flags, int B, int kind,
-                                const int32_t* a, const float* mass_a, int na, const int32_t* b, const float* mass_b, int nb,
-                                float* out) {
+                                const float* boxes, uint32_t pbc_flags, int B, int kind, int P, int per,
+                                const int32_t* a, const float* mass_a, const int32_t* aoff,
+                                const int32_t* b, const float* mass_b, const int32_t* boff, float* out) {
     hipStream_t s = (hipStream_t)stream;
-    if (B <= 0 || na <= 0 || nb <= 0) return 0;
-    vmd_dist_params_t p{xyz, frame_stride, row_stride, boxes, pbc_flags, B, a, mass_a, na, b, mass_b, nb, out};
+    if (B <= 0 || P <= 0 || per <= 0) return 0;
+    vmd_dist_params_t p{xyz, frame_stride, row_stride, boxes, pbc_flags, B, a, mass_a, aoff, b, mass_b, boff, P, per, out};
     switch (kind) {
-    case 0: hipLaunchKernelGGL(k_distance_com, dim3((B + 63) / 64), dim3(64), 0, s, p); break;
-    case 1: hipLaunchKernelGGL((k_distance_minmax<false>), dim3(B), dim3(256), 0, s, p); break;
-    case 2: hipLaunchKernelGGL((k_distance_minmax<true>), dim3(B), dim3(256), 0, s, p); break;
-    case 3: {
-        const long long npairs = (long long)na * nb;
-        hipLaunchKernelGGL(k_distance_pair, dim3((unsigned)((npairs + 255) / 256), B), dim3(256), 0, s, p);
-        break;
-    }
+    case 0: hipLaunchKernelGGL(k_distance_com, dim3((B * P + 63) / 64), dim3(64), 0, s, p); break;
+    case 1: hipLaunchKernelGGL((k_distance_minmax<false>), dim3(B * P), dim3(256), 0, s, p); break;
+    case 2: hipLaunchKernelGGL((k_distance_minmax<true>), dim3(B * P), dim3(256), 0, s, p); break;
+    case 3: hipLaunchKernelGGL(k_distance_pair, dim3((unsigned)((per + 255) / 256), B * P), dim3(256), 0, s, p); break;
     default: return (int)hipErrorInvalidValue;
     }
     VMD_LAUNCH_CHECK();

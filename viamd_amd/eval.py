@@ -89,6 +89,17 @@ class ScriptIR:
         b_, bp = _idx(b)
         self._check(self.lib.vmd_ir_add_distance(self.h, name.encode(), int(kind), ap, a_.size, bp, b_.size))
 
+    def add_distance_population(self, name, a_sets, b_sets, kind=L.DIST_COM):
+        """`name = distance*(a, b) in <contexts>`: one (a, b) pair of index sets per context -> dim[1] = number of contexts."""
+        assert len(a_sets) == len(b_sets) and len(a_sets) > 0
+        a = np.concatenate([np.asarray(x, np.int32).reshape(-1) for x in a_sets]).astype(np.int32)
+        b = np.concatenate([np.asarray(x, np.int32).reshape(-1) for x in b_sets]).astype(np.int32)
+        ao = np.concatenate([[0], np.cumsum([len(x) for x in a_sets])]).astype(np.int32)
+        bo = np.concatenate([[0], np.cumsum([len(x) for x in b_sets])]).astype(np.int32)
+        self._check(self.lib.vmd_ir_add_distance_population(self.h, name.encode(), int(kind), len(a_sets),
+                                                            a.ctypes.data_as(L.c_int32_p), ao.ctypes.data_as(L.c_int32_p),
+                                                            b.ctypes.data_as(L.c_int32_p), bo.ctypes.data_as(L.c_int32_p)))
+
     def valid(self):
         return bool(self.lib.vmd_ir_valid(self.h))
 

@@ -82,8 +82,14 @@ def _tokenize(text):
 
 
 class _Parser:
-    def __init__(self, tokens, topo, env):
-        self.t, self.i, self.topo, self.env = tokens, 0, topo, env
+    def __init__(self, tokens, topo, env, ctx=None):
+        # ctx: atom indices of the evaluation context (`... in residue(3)`): integer / atom() indices are then relative to it
+        # (src/main.cpp:2836-2840: `distance(i, j) in residue(k)` uses indices local to the residue) and every mask is clipped to it
+        self.t, self.i, self.topo, self.env, self.ctx = tokens, 0, topo, env, ctx
+        self.ctx_mask = None
+        if ctx is not None:
+            self.ctx_mask = np.zeros(topo.num_atoms, bool)
+            self.ctx_mask[ctx] = True
 
     def peek(self):
         return self.t[self.i] if self.i < len(self.t) else (None, None)
@@ -156,7 +162,27 @@ class _Parser:
             mask[x] = True
         return Sel(mask, st)
 
+    def _atom_range(self, a, b):
+        topo = self.topo
+        mask = np.zeros(topo.num_atoms, bool)
+        if self.ctx is not None:
+            if b > len(self.ctx):
+                raise ScriptError(f"atom index {b} out of range (the context has {len(self.ctx)} atoms)")
+            mask[self.ctx[a:b]] = True
+        else:
+            if b > topo.num_atoms:
+                raise ScriptError(f"atom index {b} out of range (system has {topo.num_atoms} atoms)")
+            mask[a:b] = True
+        return mask
+
     def sel_atom(self):
+        s = self._sel_atom()
+        if self.ctx_mask is not None and self.peek()[1] != "[":
+            structs = None if s.structures is None else [st[self.ctx_mask[st]] for st in s.structures]
+            s = Sel(s.mask & self.ctx_mask, structs)
+        return s
+
+    def _sel_atom(self):
         k, v = self.peek()
         topo = self.topo
         if v == "(":
@@ -166,11 +192,7 @@ class _Parser:
             return s
         if k == "num":
             a, b = self.range_()
-            if b > topo.num_atoms:
-                raise ScriptError(f"atom index {b} out of range (system has {topo.num_atoms} atoms)")
-            mask = np.zeros(topo.num_atoms, bool)
-            mask[a:b] = True
-            return Sel(mask)
+            return Sel(self._atom_range(a, b))
         if k != "id":
             raise ScriptError(f"unexpected token {v!r} in selection")
         self.i += 1
@@ -197,11 +219,7 @@ class _Parser:
             a, b = self.range_()
             self.take(")")
             if v == "atom":
-                if b > topo.num_atoms:
-                    raise ScriptError(f"atom({b}) out of range")
-                mask = np.zeros(topo.num_atoms, bool)
-                mask[a:b] = True
-                return Sel(mask)
+                return Sel(self._atom_range(a, b))
             if b > topo.num_residues:
                 raise ScriptError(f"{v}({b}) out of range (system has {topo.num_residues} residues)")
             return self._residues(lambda r: a <= r < b)
@@ -257,13 +275,36 @@ def compile_script(text, topo, lib=None):
                 ir.add_sdf(name, st, tgt.indices(), cutoff)
                 info[name] = dict(kind="sdf", structures=st, target=tgt.indices(), cutoff=cutoff)
             else:
-                a = p.sel_or(); p.take(",")
-                b = p.sel_or()
-                p.take(")")
-                if p.peek()[1] == "in":
-                    raise ScriptError(f"{name}: `in <context>` populations are not supported by this front-end")
-                ir.add_distance(name, a.indices(), b.indices(), _DIST_KIND[v])
-                info[name] = dict(kind=v, a=a.indices(), b=b.indices())
+                # the arguments may be followed by `in <contexts>`: find the closing parenthesis first
+                start, depth, j = p.i, 1, p.i
+                while depth:
+                    if j >= len(p.t):
+                        raise ScriptError(f"{name}: missing ')'")
+                    depth += {"(": 1, ")": -1}.get(p.t[j][1], 0)
+                    j += 1
+                if j < len(p.t) and p.t[j][1] == "in":
+                    q = _Parser(p.t, topo, env)
+                    q.i = j + 1
+                    ctx = q.sel_or()
+                    if ctx.structures is None or not ctx.structures:
+                        raise ScriptError(f"{name}: `in` needs an array of structures (residue(...), resname(...))")
+                    a_sets, b_sets = [], []
+                    for st in ctx.structures:
+                        r = _Parser(p.t, topo, env, ctx=np.asarray(st))
+                        r.i = start
+                        a = r.sel_or(); r.take(","); b = r.sel_or(); r.take(")")
+                        if a.indices().size == 0 or b.indices().size == 0:
+                            raise ScriptError(f"{name}: empty selection inside a context")
+                        a_sets.append(a.indices()); b_sets.append(b.indices())
+                    p.i = q.i
+                    ir.add_distance_population(name, a_sets, b_sets, _DIST_KIND[v])
+                    info[name] = dict(kind=v, a_sets=a_sets, b_sets=b_sets)
+                else:
+                    a = p.sel_or(); p.take(",")
+                    b = p.sel_or()
+                    p.take(")")
+                    ir.add_distance(name, a.indices(), b.indices(), _DIST_KIND[v])
+                    info[name] = dict(kind=v, a=a.indices(), b=b.indices())
         else:
             env[name] = p.sel_or()
         if p.peek()[0] is not None:
