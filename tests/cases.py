@@ -39,8 +39,9 @@ def oracle_rdf(O, coords, ocell, ref, tgt, rmin, rmax, frames=None, method="cell
     weights = np.zeros(1024, np.float64)
     frames = range(coords.shape[0]) if frames is None else frames
     for f in frames:
-        O.rdf_frame(coords[f, 0], coords[f, 1], coords[f, 2], ocell, ref, tgt, rmin, rmax, counts=counts, method=method)
-        O.rdf_weights(ocell, len(ref), len(tgt), rmin, rmax, weights=weights)
+        oc = ocell[f] if isinstance(ocell, list) else ocell
+        O.rdf_frame(coords[f, 0], coords[f, 1], coords[f, 2], oc, ref, tgt, rmin, rmax, counts=counts, method=method)
+        O.rdf_weights(oc, len(ref), len(tgt), rmin, rmax, weights=weights)
     return counts, weights
 
 
@@ -57,15 +58,20 @@ def make_traj(lib, coords, vcell, device):
 
 
 def check_rdf(lib, O, coords, box, props, flags=L.PBC_ALL, device=False, ranges=None, variant=0, oracle_method="cells"):
-    """props: list of (name, ref, tgt, rmin, rmax).  Bit-exact counts, 1e-12 weights, 1e-5 normalised g(r)."""
-    ocell, vcell = cell_pair(O, box, flags)
+    """props: list of (name, ref, tgt, rmin, rmax).  Bit-exact counts, 1e-12 weights, 1e-5 normalised g(r).
+    box may be a list with one box per frame (NPT trajectories)."""
     F, _, N = coords.shape
+    if isinstance(box, list):
+        pairs = [cell_pair(O, b, flags) for b in box]
+        ocell, vcell = [p[0] for p in pairs], [p[1] for p in pairs]
+    else:
+        ocell, vcell = cell_pair(O, box, flags)
     ir = V.ScriptIR(lib)
     for name, ref, tgt, rmin, rmax in props:
         ir.add_rdf(name, ref, tgt, (rmin, rmax))
     ev = V.ScriptEval(F, ir)
     traj = make_traj(lib, coords, vcell, device)
-    sysm = V.MolSystem(N, unitcell=vcell)
+    sysm = V.MolSystem(N, unitcell=vcell[0] if isinstance(vcell, list) else vcell)
     old = lib.vmd_set_option(b"rdf_variant", variant)
     try:
         for beg, end in (ranges or [(0, F)]):

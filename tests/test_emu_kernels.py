@@ -55,6 +55,15 @@ def test_rdf_noncubic_box_and_unwrapped_input(emu_lib, oracle):
     cases.check_rdf(emu_lib, oracle, c, box, [("g", a, a, 0.0, 9.0)])
 
 
+def test_rdf_box_changes_every_frame(emu_lib, oracle):
+    """NPT-like trajectory: the grid of a batch comes from its smallest box, cell coordinates are scaled per frame"""
+    rng = np.random.default_rng(8)
+    boxes = [40.0, 43.5, 38.2, (41.0, 39.0, 44.0)]
+    c = np.stack([(rng.uniform(0, 1, (3, 1500)) * np.array(b if not np.isscalar(b) else (b,) * 3)[:, None]).astype(np.float32) for b in boxes])
+    a = np.arange(0, 1500, 2)
+    cases.check_rdf(emu_lib, oracle, c, boxes, [("g", a, a, 0.0, 11.0), ("gx", a, np.arange(1, 1500, 2), 0.0, 9.0)])
+
+
 def test_rdf_brute_nonperiodic_and_large_cutoff(emu_lib, oracle):
     rng = np.random.default_rng(3)
     c = rng.uniform(0, 20, (3, 3, 300)).astype(np.float32)

@@ -74,6 +74,14 @@ def test_rdf_small_boxes_and_unwrapped_input(gpu_lib, oracle):
     cases.check_rdf(gpu_lib, oracle, c, box, [("g", a, a, 0.0, 9.0), ("gx", a, np.arange(1, 9000, 2), 0.5, 11.0)])
 
 
+def test_rdf_box_changes_every_frame(gpu_lib, oracle):
+    rng = np.random.default_rng(8)
+    boxes = [60.0, 63.5, 58.2, (61.0, 59.0, 64.0), 60.5]
+    c = np.stack([(rng.uniform(0, 1, (3, 12000)) * np.array(b if not np.isscalar(b) else (b,) * 3)[:, None]).astype(np.float32) for b in boxes])
+    a = np.arange(0, 12000, 2)
+    cases.check_rdf(gpu_lib, oracle, c, boxes, [("g", a, a, 0.0, 11.0), ("gx", a, np.arange(1, 12000, 2), 0.0, 9.0)], device=True)
+
+
 def test_rdf_brute_paths(gpu_lib, oracle):
     rng = np.random.default_rng(3)
     c = rng.uniform(0, 20, (5, 3, 700)).astype(np.float32)
