@@ -75,7 +75,9 @@ int main(int argc, char** argv) {
     run_pool(8, true);                                       // interrupted run: some frames only
     const size_t partial = vmd_eval_frames_done(eval);
     if (partial >= F && F >= 32) fail("interrupt had no effect");
+    const auto t0 = std::chrono::steady_clock::now();
     auto pc = run_pool(8, false);                            // restart from scratch (src/main.cpp:990)
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if (vmd_eval_frames_done(eval) != F) fail("not all frames evaluated");
     const uint8_t* mask = vmd_eval_frame_mask(eval);
     for (size_t f = 0; f < F; ++f) if (!mask[f]) fail("frame mask hole");
@@ -94,7 +96,8 @@ int main(int argc, char** argv) {
     if (g[100] < 0.9f || g[100] > 1.1f) fail("g(r) not ~1 at large r");
     for (size_t f = 0; f < F; ++f) if (!(pdd->values[f] > 0.0f && pdd->values[f] < 0.87f * L)) fail("distance row");
 
-    std::printf("OK frames=%zu hits=%llu polls=%d fingerprint_changes=%d interrupted_at=%zu\n", F, hits, pc.first, pc.second, partial);
+    std::printf("OK frames=%zu hits=%llu polls=%d fingerprint_changes=%d interrupted_at=%zu eval_ms=%.2f frames_per_s=%.0f\n", F, hits,
+                pc.first, pc.second, partial, ms, F / ms * 1e3);
     vmd_eval_free(eval);
     vmd_ir_free(ir);
     vmd_devtraj_free(dt);

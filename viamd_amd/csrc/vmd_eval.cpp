@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -328,13 +329,26 @@ struct PropState {
     bool dirty = false;                 // device accumulators changed since the last host refresh
 };
 
+// one pending vmd_eval_frame_range call (lives on the caller's stack)
+struct RangeRequest {
+    uint32_t beg = 0, end = 0;
+    const vmd_system_t* sys = nullptr;
+    vmd_trajectory_i* traj = nullptr;
+    bool done = false, ok = true;
+    std::string error;
+};
+
 struct vmd_script_eval_t {
     uint64_t ir_fingerprint = 0;
     size_t num_frames = 0;
     std::vector<uint8_t> frame_mask;
     std::atomic<size_t> frames_done{0};
     std::atomic<bool> interrupt{false};
-    std::mutex mtx;                                   // serialises device work of concurrent frame_range calls
+    std::mutex mtx;                                   // serialises device work (frame ranges, finalize, clear, vis payloads)
+    std::mutex queue_mtx;                             // combining queue of concurrent frame_range calls
+    std::condition_variable queue_cv;
+    std::vector<RangeRequest*> queue;
+    bool leader_active = false;
     std::vector<std::unique_ptr<PropState>> props;
     std::vector<std::unique_ptr<Selection>> sels;
     hipStream_t stream = nullptr;
@@ -803,15 +817,10 @@ static size_t auto_batch(const vmd_script_eval_t* e, size_t num_atoms) {
     return B;
 }
 
-extern "C" bool vmd_eval_frame_range(vmd_script_eval_t* eval, const vmd_script_ir_t* ir, const vmd_system_t* sys,
-                                     vmd_trajectory_i* traj, uint32_t frame_beg, uint32_t frame_end) {
-    g_last_error.clear();   // a false return with an empty message means "interrupted"
-    if (!eval || !traj) return vmd_fail("vmd_eval_frame_range: NULL argument");
-    if (ir && vmd_ir_fingerprint(ir) != eval->ir_fingerprint) return vmd_fail("vmd_eval_frame_range: eval was created from a different ir");
-    if (frame_end > eval->num_frames) frame_end = (uint32_t)eval->num_frames;
-    if (frame_beg >= frame_end) return true;
+// evaluates frames [frame_beg, frame_end) in large batches; returns false on interrupt (empty error) or failure
+static bool process_range(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_trajectory_i* traj, uint32_t frame_beg, uint32_t frame_end) {
+    g_last_error.clear();
     if (eval->interrupt) return false;
-
     std::lock_guard<std::mutex> lock(eval->mtx);
     HIP_OK(hipSetDevice(eval->device));
     vmd_script_eval_t* e = eval;
@@ -948,6 +957,56 @@ extern "C" bool vmd_eval_frame_range(vmd_script_eval_t* eval, const vmd_script_i
         else if (p->prop.kind == PROP_DIST) refresh_temporal_stats(e, p.get());
     }
     return completed;
+}
+
+// The hot call.  VIAMD invokes it from N pool threads with small disjoint ranges (grain 1, src/main.cpp:993-997,
+// src/task_system.cpp:73-81).  Launching kernels per call would drown the GPU in tiny batches, so calls COMBINE: the first
+// caller becomes the leader, later callers queue their range and sleep; the leader repeatedly takes everything queued so far,
+// merges adjacent ranges into long runs and evaluates those in large frame batches, then wakes the owners.
+extern "C" bool vmd_eval_frame_range(vmd_script_eval_t* eval, const vmd_script_ir_t* ir, const vmd_system_t* sys,
+                                     vmd_trajectory_i* traj, uint32_t frame_beg, uint32_t frame_end) {
+    g_last_error.clear();   // a false return with an empty message means "interrupted"
+    if (!eval || !traj) return vmd_fail("vmd_eval_frame_range: NULL argument");
+    if (ir && vmd_ir_fingerprint(ir) != eval->ir_fingerprint) return vmd_fail("vmd_eval_frame_range: eval was created from a different ir");
+    if (frame_end > eval->num_frames) frame_end = (uint32_t)eval->num_frames;
+    if (frame_beg >= frame_end) return true;
+    if (eval->interrupt) return false;
+
+    RangeRequest me;
+    me.beg = frame_beg; me.end = frame_end; me.sys = sys; me.traj = traj;
+    std::unique_lock<std::mutex> ql(eval->queue_mtx);
+    eval->queue.push_back(&me);
+    if (eval->leader_active) {
+        eval->queue_cv.wait(ql, [&] { return me.done; });
+        if (!me.ok) g_last_error = me.error;
+        return me.ok;
+    }
+    eval->leader_active = true;
+    while (!eval->queue.empty()) {
+        std::vector<RangeRequest*> taken;
+        taken.swap(eval->queue);
+        ql.unlock();
+        // requests for the same trajectory, sorted by first frame; touching ranges fuse into one run
+        std::sort(taken.begin(), taken.end(), [](const RangeRequest* a, const RangeRequest* b) {
+            return a->traj != b->traj ? a->traj < b->traj : a->beg < b->beg; });
+        size_t i = 0;
+        while (i < taken.size()) {
+            size_t j = i + 1;
+            uint32_t run_end = taken[i]->end;
+            while (j < taken.size() && taken[j]->traj == taken[i]->traj && taken[j]->beg == run_end) { run_end = taken[j]->end; ++j; }
+            const bool ok = process_range(eval, taken[i]->sys, taken[i]->traj, taken[i]->beg, run_end);
+            const std::string err = ok ? std::string() : g_last_error;
+            for (size_t k = i; k < j; ++k) { taken[k]->ok = ok; taken[k]->error = err; }
+            i = j;
+        }
+        ql.lock();
+        for (RangeRequest* r : taken) r->done = true;
+        eval->queue_cv.notify_all();
+    }
+    eval->leader_active = false;
+    ql.unlock();
+    if (!me.ok) g_last_error = me.error;
+    return me.ok;
 }
 
 extern "C" bool vmd_eval_sdf_matrices(vmd_script_eval_t* eval, const char* name, const vmd_system_t* sys,
