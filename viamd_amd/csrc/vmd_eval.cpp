@@ -63,6 +63,7 @@ extern "C" int vmd_set_option(const char* key, int value) {
     else if (!strcmp(key, "force_brute")) o = &g_opt.force_brute;
     else if (!strcmp(key, "nxf_divisor")) o = &g_opt.nxf_divisor;
     else if (!strcmp(key, "cells_fused")) return vmd_hip_set_cells_fused(value);
+    else if (!strcmp(key, "rdf_blocks")) return vmd_hip_set_rdf_blocks(value);
     if (!o) return -1;
     return o->exchange(value);
 }

@@ -1071,7 +1071,9 @@ extern "C" int vmd_hip_cells_build(void* stream, const float* xyz, size_t frame_
     return 0;
 }
 
-extern "C" int vmd_hip_rdf_num_blocks(void) { return 2048; }   // 8 blocks x 4 waves per CU: 8 waves per SIMD
+static int g_rdf_blocks = 2048;   // 8 blocks x 4 waves per CU requested; 6 fit (SGPR budget)
+extern "C" int vmd_hip_rdf_num_blocks(void) { return 2048; }   // capacity of the partial-row scratch
+extern "C" int vmd_hip_set_rdf_blocks(int n) { const int old = g_rdf_blocks; if (n >= 8 && n <= 2048) g_rdf_blocks = n; return old; }
 extern "C" size_t vmd_hip_rdf_partial_words(void) { return (size_t)vmd_hip_rdf_num_blocks() * VMD_MAX_BINS + 4; }
 
 extern "C" int vmd_hip_rdf_pencil(void* stream, const float* sorted_ref, const uint32_t* cell_start_ref, int nref, int nref_pad,
@@ -1100,7 +1102,7 @@ extern "C" int vmd_hip_rdf_pencil(void* stream, const float* sorted_ref, const u
     const int nitems = B * grid.ny * grid.nz;
     int nblocks = (nitems + 3) / 4;
     if (nblocks < 8) nblocks = 8;
-    if (nblocks > vmd_hip_rdf_num_blocks()) nblocks = vmd_hip_rdf_num_blocks();
+    if (nblocks > g_rdf_blocks) nblocks = g_rdf_blocks;
     const dim3 g(nblocks), blk(256);
     if (same_set) {
         if (variant == 1) hipLaunchKernelGGL((k_rdf_pencil<1, true>), g, blk, 0, s, p);
