@@ -3,9 +3,10 @@
  *
  * Every function enqueues work on `stream` (a hipStream_t passed as void*) and returns 0 or a hipError_t.
  * Pointers are device pointers unless a comment says "host".  A *frame batch* is B consecutive frames:
- * frame b has x at xyz + b*frame_stride, y at +row_stride, z at +2*row_stride (floats); boxes[b*6+{0,1,2}]
- * are its orthorhombic edge lengths (SPEC S1) and boxes[b*6+{3,4,5}] their reciprocals fl(1.0f/L) (SPEC S2), both
- * filled by the host.
+ * frame b has x at xyz + b*frame_stride, y at +row_stride, z at +2*row_stride (floats); boxes[b*9+{0,1,2}]
+ * are its cell edge lengths (SPEC S1), boxes[b*9+{3,4,5}] their reciprocals fl(1.0f/L) (SPEC S2) and boxes[b*9+{6,7,8}]
+ * the tilt factors xy, xz, yz, all filled by the host.  pbc_flags: bits 0-2 periodic axes, bit 3 triclinic (SPEC S3t;
+ * brute / sdf / distance kernels only — the pencil grid is orthorhombic).
  *
  * Reference functions replaced (the sources are in the empty submodule ext/mdlib, /root/reference/.gitmodules:10-12;
  * names from /root/reference/ext/ImGuiColorTextEdit/TextEditor.cpp:3318-3331 and SURVEY.md 8a):

@@ -109,12 +109,12 @@ def _u64(a):
     return a.ctypes.data_as(C.POINTER(C.c_uint64))
 
 
-def make_cell(L, flags=PBC_ALL):
+def make_cell(L, flags=PBC_ALL, tilt=(0.0, 0.0, 0.0)):
     if L is None:
         return Cell(0, 0, 0, 0, 0, 0, 0)
     if np.isscalar(L):
         L = (L, L, L)
-    return Cell(float(L[0]), float(L[1]), float(L[2]), 0, 0, 0, flags)
+    return Cell(float(L[0]), float(L[1]), float(L[2]), float(tilt[0]), float(tilt[1]), float(tilt[2]), flags)
 
 
 def _as_idx(a):

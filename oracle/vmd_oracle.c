@@ -31,6 +31,9 @@ typedef struct {
     float L[3];
     float hL[3];
     int pbc[3];
+    int tri;            /* triclinic: tilt factors non-zero (needs all three axes periodic) */
+    float xy, xz, yz;   /* basis: a = (x,0,0), b = (xy,y,0), c = (xz,yz,z)  (src/viamd.cpp:1837-1843) */
+    float iL[3];        /* fl(1/L) */
 } vo_box_t;
 
 static vo_box_t vo_box(const vo_cell_t* c) {
@@ -41,9 +44,49 @@ static vo_box_t vo_box(const vo_cell_t* c) {
         for (int a = 0; a < 3; ++a) {
             b.pbc[a] = ((c->flags >> a) & 1u) && b.L[a] > 0.0f;
             b.hL[a] = 0.5f * b.L[a];
+            b.iL[a] = 1.0f / b.L[a];
         }
+        b.tri = vo_triclinic(c);
+        b.xy = c->xy; b.xz = c->xz; b.yz = c->yz;
     }
     return b;
+}
+
+/* SPEC S3t (triclinic): fractional coordinates and back, fp32 */
+static inline void vo_frac(const vo_box_t* b, float x, float y, float z, float s[3]) {
+    s[2] = z * b->iL[2];
+    s[1] = fmaf(-b->yz, s[2], y) * b->iL[1];
+    s[0] = fmaf(-b->xz, s[2], fmaf(-b->xy, s[1], x)) * b->iL[0];
+}
+static inline void vo_cart(const vo_box_t* b, const float s[3], float d[3]) {
+    d[2] = s[2] * b->L[2];
+    d[1] = fmaf(b->yz, s[2], s[1] * b->L[1]);
+    d[0] = fmaf(b->xz, s[2], fmaf(b->xy, s[1], s[0] * b->L[0]));
+}
+/* minimum image of a Cartesian displacement in a triclinic cell: round in fractional space (valid for |d| below half the
+ * smallest cell width, the usual restriction) */
+static inline void vo_mi_tri(const vo_box_t* b, float d[3]) {
+    float s[3];
+    vo_frac(b, d[0], d[1], d[2], s);
+    s[0] = s[0] - rintf(s[0]); s[1] = s[1] - rintf(s[1]); s[2] = s[2] - rintf(s[2]);
+    vo_cart(b, s, d);
+}
+static inline void vo_mi_tri_d(const vo_box_t* b, double d[3]) {
+    double s[3];
+    s[2] = d[2] / (double)b->L[2];
+    s[1] = (d[1] - (double)b->yz * s[2]) / (double)b->L[1];
+    s[0] = (d[0] - (double)b->xy * s[1] - (double)b->xz * s[2]) / (double)b->L[0];
+    s[0] = s[0] - rint(s[0]); s[1] = s[1] - rint(s[1]); s[2] = s[2] - rint(s[2]);
+    d[2] = s[2] * (double)b->L[2];
+    d[1] = s[1] * (double)b->L[1] + (double)b->yz * s[2];
+    d[0] = s[0] * (double)b->L[0] + (double)b->xy * s[1] + (double)b->xz * s[2];
+}
+/* pair displacement on fractional coordinates (triclinic S3t): d = cart(ds - rint(ds)) */
+static inline float vo_pair_d2_tri(const vo_box_t* b, const float si[3], const float sj[3]) {
+    float ds[3], d[3];
+    for (int a = 0; a < 3; ++a) { ds[a] = si[a] - sj[a]; ds[a] = ds[a] - rintf(ds[a]); }
+    vo_cart(b, ds, d);
+    return fmaf(d[2], d[2], fmaf(d[1], d[1], d[0] * d[0]));
 }
 
 /* S3 on one axis */
@@ -84,6 +127,12 @@ static void vo_gather_wrapped(const float* x, const float* y, const float* z, co
                               const int32_t* idx, size_t n, float* ox, float* oy, float* oz) {
     for (size_t i = 0; i < n; ++i) {
         const int32_t a = idx ? idx[i] : (int32_t)i;
+        if (bx->tri) {          /* S3t works on fractional coordinates */
+            float sfr[3];
+            vo_frac(bx, x[a], y[a], z[a], sfr);
+            ox[i] = sfr[0]; oy[i] = sfr[1]; oz[i] = sfr[2];
+            continue;
+        }
         ox[i] = bx->pbc[0] ? vo_wrap(x[a], bx->L[0]) : x[a];
         oy[i] = bx->pbc[1] ? vo_wrap(y[a], bx->L[1]) : y[a];
         oz[i] = bx->pbc[2] ? vo_wrap(z[a], bx->L[2]) : z[a];
@@ -94,8 +143,8 @@ static void vo_gather_wrapped(const float* x, const float* y, const float* z, co
 uint64_t vo_rdf_frame_brute(const float* x, const float* y, const float* z, const vo_cell_t* cell,
                             const int32_t* ref_idx, size_t nref, const int32_t* tgt_idx, size_t ntgt,
                             float rmin, float rmax, int nbins, uint64_t* counts) {
-    if (vo_triclinic(cell)) return UINT64_MAX;
     const vo_box_t bx = vo_box(cell);
+    if (bx.tri && !(bx.pbc[0] && bx.pbc[1] && bx.pbc[2])) return UINT64_MAX;
     const vo_bin_t bn = vo_bin_setup(rmin, rmax, nbins);
     float* buf = (float*)malloc(sizeof(float) * 3 * (nref + ntgt) + 64);
     float *rx = buf, *ry = rx + nref, *rz = ry + nref, *tx = rz + nref, *ty = tx + ntgt, *tz = ty + ntgt;
@@ -105,10 +154,17 @@ uint64_t vo_rdf_frame_brute(const float* x, const float* y, const float* z, cons
     for (size_t i = 0; i < nref; ++i) {
         const float xi = rx[i], yi = ry[i], zi = rz[i];
         for (size_t j = 0; j < ntgt; ++j) {
-            const float dx = vo_mi(xi - tx[j], bx.L[0], bx.hL[0], bx.pbc[0]);
-            const float dy = vo_mi(yi - ty[j], bx.L[1], bx.hL[1], bx.pbc[1]);
-            const float dz = vo_mi(zi - tz[j], bx.L[2], bx.hL[2], bx.pbc[2]);
-            const int bin = vo_bin_of(&bn, vo_d2(dx, dy, dz));
+            float d2;
+            if (bx.tri) {
+                const float si[3] = {xi, yi, zi}, sj[3] = {tx[j], ty[j], tz[j]};
+                d2 = vo_pair_d2_tri(&bx, si, sj);
+            } else {
+                const float dx = vo_mi(xi - tx[j], bx.L[0], bx.hL[0], bx.pbc[0]);
+                const float dy = vo_mi(yi - ty[j], bx.L[1], bx.hL[1], bx.pbc[1]);
+                const float dz = vo_mi(zi - tz[j], bx.L[2], bx.hL[2], bx.pbc[2]);
+                d2 = vo_d2(dx, dy, dz);
+            }
+            const int bin = vo_bin_of(&bn, d2);
             if (bin >= 0) { counts[bin] += 1; hits += 1; }
         }
     }
@@ -133,7 +189,7 @@ static inline int vo_cell_coord(float v, float org, float inv, int n) {
 uint64_t vo_rdf_frame_cells(const float* x, const float* y, const float* z, const vo_cell_t* cell,
                             const int32_t* ref_idx, size_t nref, const int32_t* tgt_idx, size_t ntgt,
                             float rmin, float rmax, int nbins, uint64_t* counts) {
-    if (vo_triclinic(cell)) return UINT64_MAX;
+    if (vo_triclinic(cell)) return UINT64_MAX;       /* the grid is orthorhombic only: callers fall back to brute */
     const vo_box_t bx = vo_box(cell);
     const vo_bin_t bn = vo_bin_setup(rmin, rmax, nbins);
     if (nref == 0 || ntgt == 0) return 0;
@@ -296,7 +352,11 @@ static void vo_unwrap_com(const float* x, const float* y, const float* z, const 
     for (size_t a = 0; a < m; ++a) {
         const int32_t i = idx[a];
         double px = (double)x[i], py = (double)y[i], pz = (double)z[i];
-        if (a > 0) {
+        if (a > 0 && bx->tri) {
+            double d[3] = {px - p[3 * (a - 1) + 0], py - p[3 * (a - 1) + 1], pz - p[3 * (a - 1) + 2]};
+            vo_mi_tri_d(bx, d);
+            px = p[3 * (a - 1) + 0] + d[0]; py = p[3 * (a - 1) + 1] + d[1]; pz = p[3 * (a - 1) + 2] + d[2];
+        } else if (a > 0) {
             px = p[3 * (a - 1) + 0] + vo_mi_rint(px - p[3 * (a - 1) + 0], (double)bx->L[0], bx->pbc[0]);
             py = p[3 * (a - 1) + 1] + vo_mi_rint(py - p[3 * (a - 1) + 1], (double)bx->L[1], bx->pbc[1]);
             pz = p[3 * (a - 1) + 2] + vo_mi_rint(pz - p[3 * (a - 1) + 2], (double)bx->L[2], bx->pbc[2]);
@@ -427,6 +487,14 @@ void vo_sdf_frame_align(const float* x, const float* y, const float* z, const vo
     free(p);
 }
 
+static inline float vo_mi_rintf(float d, float L, int pbc);
+/* SPEC S5/S6 fp32 minimum image of a Cartesian displacement (orthorhombic: per axis by rint; triclinic: S3t) */
+static inline void vo_mi3_rintf(const vo_box_t* bx, float d[3]) {
+    if (bx->tri) { vo_mi_tri(bx, d); return; }
+    d[0] = vo_mi_rintf(d[0], bx->L[0], bx->pbc[0]);
+    d[1] = vo_mi_rintf(d[1], bx->L[1], bx->pbc[1]);
+    d[2] = vo_mi_rintf(d[2], bx->L[2], bx->pbc[2]);
+}
 static inline float vo_mi_rintf(float d, float L, int pbc) {
     if (pbc) {
         const float invL = 1.0f / L;
@@ -452,9 +520,9 @@ uint64_t vo_sdf_frame_scatter(const float* x, const float* y, const float* z, co
             int own = 0;
             for (size_t a = 0; a < m; ++a) if (sidx[a] == i) { own = 1; break; }
             if (own) continue;
-            const float dx = vo_mi_rintf(x[i] - c[0], bx.L[0], bx.pbc[0]);
-            const float dy = vo_mi_rintf(y[i] - c[1], bx.L[1], bx.pbc[1]);
-            const float dz = vo_mi_rintf(z[i] - c[2], bx.L[2], bx.pbc[2]);
+            float dv[3] = {x[i] - c[0], y[i] - c[1], z[i] - c[2]};
+            vo_mi3_rintf(&bx, dv);
+            const float dx = dv[0], dy = dv[1], dz = dv[2];
             const float qx = fmaf(R[2], dz, fmaf(R[1], dy, R[0] * dx));
             const float qy = fmaf(R[5], dz, fmaf(R[4], dy, R[3] * dx));
             const float qz = fmaf(R[8], dz, fmaf(R[7], dy, R[6] * dx));
@@ -506,9 +574,9 @@ uint64_t vo_sdf_run(const float* traj, const vo_cell_t* cells, size_t nframes, s
                 const int32_t* sidx = struct_idx + k * m;
                 for (size_t t = 0; t < ntgt; ++t) {
                     const int32_t i = tgt_idx ? tgt_idx[t] : (int32_t)t;
-                    const float dx = vo_mi_rintf(x[i] - c[0], bx.L[0], bx.pbc[0]);
-                    const float dy = vo_mi_rintf(y[i] - c[1], bx.L[1], bx.pbc[1]);
-                    const float dz = vo_mi_rintf(z[i] - c[2], bx.L[2], bx.pbc[2]);
+                    float dv[3] = {x[i] - c[0], y[i] - c[1], z[i] - c[2]};
+                    vo_mi3_rintf(&bx, dv);
+                    const float dx = dv[0], dy = dv[1], dz = dv[2];
                     const float qx = fmaf(R[2], dz, fmaf(R[1], dy, R[0] * dx));
                     const float qy = fmaf(R[5], dz, fmaf(R[4], dy, R[3] * dx));
                     const float qz = fmaf(R[8], dz, fmaf(R[7], dy, R[6] * dx));
@@ -546,7 +614,11 @@ void vo_set_com(const float* x, const float* y, const float* z, const vo_cell_t*
         const int32_t i = idx[a];
         double px = (double)x[i], py = (double)y[i], pz = (double)z[i];
         if (a == 0) { p0[0] = px; p0[1] = py; p0[2] = pz; }
-        else {
+        else if (bx.tri) {
+            double d[3] = {px - p0[0], py - p0[1], pz - p0[2]};
+            vo_mi_tri_d(&bx, d);
+            px = p0[0] + d[0]; py = p0[1] + d[1]; pz = p0[2] + d[2];
+        } else {
             px = p0[0] + vo_mi_rint(px - p0[0], (double)bx.L[0], bx.pbc[0]);
             py = p0[1] + vo_mi_rint(py - p0[1], (double)bx.L[1], bx.pbc[1]);
             pz = p0[2] + vo_mi_rint(pz - p0[2], (double)bx.L[2], bx.pbc[2]);
@@ -563,13 +635,18 @@ float vo_distance_com(const float* x, const float* y, const float* z, const vo_c
     float ca[3], cb[3];
     vo_set_com(x, y, z, cell, a, ma, na, ca);
     vo_set_com(x, y, z, cell, b, mb, nb, cb);
-    const float dx = vo_mi_rintf(ca[0] - cb[0], bx.L[0], bx.pbc[0]);
-    const float dy = vo_mi_rintf(ca[1] - cb[1], bx.L[1], bx.pbc[1]);
-    const float dz = vo_mi_rintf(ca[2] - cb[2], bx.L[2], bx.pbc[2]);
-    return sqrtf(vo_d2(dx, dy, dz));
+    float dv[3] = {ca[0] - cb[0], ca[1] - cb[1], ca[2] - cb[2]};
+    vo_mi3_rintf(&bx, dv);
+    return sqrtf(vo_d2(dv[0], dv[1], dv[2]));
 }
 
 static float vo_pair_d2(const float* x, const float* y, const float* z, const vo_box_t* bx, int32_t i, int32_t j) {
+    if (bx->tri) {
+        float si[3], sj[3];
+        vo_frac(bx, x[i], y[i], z[i], si);
+        vo_frac(bx, x[j], y[j], z[j], sj);
+        return vo_pair_d2_tri(bx, si, sj);
+    }
     const float xi = bx->pbc[0] ? vo_wrap(x[i], bx->L[0]) : x[i];
     const float yi = bx->pbc[1] ? vo_wrap(y[i], bx->L[1]) : y[i];
     const float zi = bx->pbc[2] ? vo_wrap(z[i], bx->L[2]) : z[i];

@@ -30,8 +30,11 @@ def hydrogen(n_atoms):
 
 
 def cell_pair(O, box, flags=L.PBC_ALL):
-    """(oracle cell, product unitcell) for the same box"""
-    return O.make_cell(box, flags if box is not None else 0), V.make_unitcell(box, flags)
+    """(oracle cell, product unitcell) for the same box; box = (x, y, z, xy, xz, yz) is a triclinic cell"""
+    tilt = (0.0, 0.0, 0.0)
+    if box is not None and not np.isscalar(box) and len(box) == 6:
+        box, tilt = tuple(box[:3]), tuple(box[3:])
+    return O.make_cell(box, flags if box is not None else 0, tilt), V.make_unitcell(box, flags, tilt)
 
 
 def oracle_rdf(O, coords, ocell, ref, tgt, rmin, rmax, frames=None, method="cells"):
@@ -91,6 +94,33 @@ def check_rdf(lib, O, coords, box, props, flags=L.PBC_ALL, device=False, ranges=
         np.testing.assert_allclose(g_dev, g_ref, rtol=1e-5, atol=0)   # tolerance stated by BASELINE.json north_star
         assert pd.min_range[0] == np.float32(rmin) and pd.max_range[0] == np.float32(rmax)
     return ev
+
+
+def rdf_edge_cases(lib, O, device=False):
+    """Inputs the reference's spatial hash has to survive: atoms exactly on cell faces / box faces, coincident atoms, far
+    outside the cell, a single pair, selections of one atom, atom counts that are not a multiple of the wave size."""
+    rng = np.random.default_rng(17)
+    box = 50.0
+    n = 1237                                              # not a multiple of 64
+    c = rng.uniform(0, box, (2, 3, n)).astype(np.float32)
+    c[:, :, 0] = 0.0                                      # on the origin
+    c[:, 0, 1] = box                                      # exactly on the far face (wraps to 0)
+    c[:, :, 2] = c[:, :, 3]                               # two coincident atoms: d = 0 never counts (open interval)
+    c[:, :, 4] = np.float32(-0.0)
+    c[:, 0, 5] = np.nextafter(np.float32(box), np.float32(0))
+    c[:, :, 6] = c[:, :, 7] + np.float32(1e6 * box)      # far outside the cell: same image as atom 7 after wrapping
+    c[:, 1, 8] = 12.5 * 2                                 # exactly on a pencil boundary (ny = 4 -> edge 12.5)
+    c[:, 2, 9] = 12.5 * 3
+    c[0, :, 10:40] = c[0, :, 40:70] + np.float32(12.0)   # pairs at (about) the cutoff along every axis
+    everything = np.arange(n)
+    check_rdf(lib, O, c, box, [("all", everything, everything, 0.0, 12.0), ("one", [11], everything, 0.0, 12.0),
+                               ("to_one", everything, [12], 0.5, 11.0), ("pair", [2], [3], 0.0, 5.0),
+                               ("shell", everything[::2], everything[1::2], 11.9, 12.0)], device=device)
+    # a selection that leaves most pencils empty, and a target far denser than the reference
+    c2 = rng.uniform(0, box, (1, 3, 4000)).astype(np.float32)
+    c2[:, :, :50] = rng.uniform(20, 24, (1, 3, 50))
+    check_rdf(lib, O, c2, box, [("blob", np.arange(50), np.arange(50), 0.0, 10.0), ("blob_all", np.arange(50), np.arange(4000), 0.0, 12.0)],
+              device=device)
 
 
 # ---- SDF scenario: K rigid-ish structures of m atoms tumbling in a water box -------------------------------------------
@@ -219,3 +249,29 @@ def check_distances(lib, O, coords, box, mass, specs, flags=L.PBC_ALL, device=Fa
             np.testing.assert_array_equal(agg["ext"][:, 1], ref.max(axis=1))
         assert pd.min_range[0] == ref.min() and pd.max_range[0] == ref.max()
     return ev
+
+
+def triclinic_cases(lib, O, n_water, device=False):
+    """SPEC S3t: triclinic cells go through the general (brute) RDF kernel and the rint-in-fractional-space minimum image of
+    SDF / distance; everything must still equal the oracle bit for bit."""
+    box = (30.0, 28.0, 26.0, 6.0, -4.0, 5.0)
+    A = np.array([[box[0], box[3], box[4]], [0, box[1], box[5]], [0, 0, box[2]]])
+    coords, structures, mass = sdf_system(O, 31, n_water, 26.0, 3)
+    F, _, N = coords.shape
+    # spread the orthorhombic test system over the triclinic cell (and beyond: atoms up to half a cell outside)
+    frac = coords.astype(np.float64) / 26.0 * 1.4 - 0.2
+    coords = np.einsum("ij,fjn->fin", A, frac).astype(np.float32)
+    n_s = structures.size
+    # keep every structure compact (the alignment needs whole structures): shrink the blob atoms towards their centre
+    for f in range(F):
+        for k in range(structures.shape[0]):
+            idx = structures[k]
+            c0 = coords[f][:, idx[:1]]
+            coords[f][:, idx] = c0 + 0.15 * (coords[f][:, idx] - c0)
+    o = np.arange(n_s, N, 3, dtype=np.int32)
+    h = np.array([i for i in range(n_s, N) if (i - n_s) % 3], np.int32)
+    check_rdf(lib, O, coords, box, [("goo", o, o, 0.0, 9.0), ("goh", o, h, 0.5, 8.0)], device=device, oracle_method="brute")
+    check_sdf(lib, O, coords, box, structures, mass, o, 6.0, device=device)
+    check_distances(lib, O, coords, box, mass, [("d", structures[0], structures[1], L.DIST_COM), ("m", structures[0], structures[2], L.DIST_MIN),
+                                               ("x", structures[1], structures[2], L.DIST_MAX), ("p", structures[0][:2], o[:3], L.DIST_PAIR)],
+                    device=device)

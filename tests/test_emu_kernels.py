@@ -64,6 +64,10 @@ def test_rdf_box_changes_every_frame(emu_lib, oracle):
     cases.check_rdf(emu_lib, oracle, c, boxes, [("g", a, a, 0.0, 11.0), ("gx", a, np.arange(1, 1500, 2), 0.0, 9.0)])
 
 
+def test_rdf_edge_cases(emu_lib, oracle):
+    cases.rdf_edge_cases(emu_lib, oracle)
+
+
 def test_rdf_brute_nonperiodic_and_large_cutoff(emu_lib, oracle):
     rng = np.random.default_rng(3)
     c = rng.uniform(0, 20, (3, 3, 300)).astype(np.float32)
@@ -142,3 +146,7 @@ def test_interrupt_and_clear(emu_lib, oracle, box3k):
     assert ev.frame_range(V.MolSystem(3000), traj, 0, 1)
     np.testing.assert_array_equal(ev.property_data("goo").counts, first)
     assert ev.ir_fingerprint() == ir.fingerprint()
+
+
+def test_triclinic_cell_all_property_kinds(emu_lib, oracle):
+    cases.triclinic_cases(emu_lib, oracle, n_water=900)

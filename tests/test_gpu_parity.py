@@ -82,6 +82,10 @@ def test_rdf_box_changes_every_frame(gpu_lib, oracle):
     cases.check_rdf(gpu_lib, oracle, c, boxes, [("g", a, a, 0.0, 11.0), ("gx", a, np.arange(1, 12000, 2), 0.0, 9.0)], device=True)
 
 
+def test_rdf_edge_cases(gpu_lib, oracle):
+    cases.rdf_edge_cases(gpu_lib, oracle, device=True)
+
+
 def test_rdf_brute_paths(gpu_lib, oracle):
     rng = np.random.default_rng(3)
     c = rng.uniform(0, 20, (5, 3, 700)).astype(np.float32)
@@ -329,3 +333,7 @@ def test_synthetic_blob_system_device_equals_host_and_script_eval(gpu_lib, oracl
     np.testing.assert_array_equal(ev.property_data("v").counts, vol)
     ref, _ = cases.oracle_rdf(oracle, coords, ocell, info["g"]["ref"], info["g"]["target"], 0.0, 12.0)
     np.testing.assert_array_equal(ev.property_data("g").counts, ref)
+
+
+def test_triclinic_cell_all_property_kinds(gpu_lib, oracle):
+    cases.triclinic_cases(gpu_lib, oracle, n_water=9000, device=True)

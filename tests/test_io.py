@@ -60,3 +60,12 @@ def test_pdb_periodic_cell(tmp_path):
     c, t, cell = pdb.read_pdb(tmp_path / "w.pdb")
     assert (cell.x, cell.y, cell.z, cell.flags) == (20.0, 20.0, 20.0, 7)
     assert t.residue_name(0) == "HOH" and t.num_residues == 10
+
+
+def test_pdb_triclinic_cell_roundtrip(tmp_path):
+    topo = synth.water_box_topology(30)
+    coords = np.random.default_rng(0).uniform(0, 20, (1, 3, 30))
+    pdb.write_pdb(tmp_path / "t.pdb", coords, topo, box=(30.0, 28.0, 26.0), tilt=(6.0, -4.0, 5.0))
+    c, t, cell = pdb.read_pdb(tmp_path / "t.pdb")
+    np.testing.assert_allclose([cell.x, cell.y, cell.z, cell.xy, cell.xz, cell.yz], [30.0, 28.0, 26.0, 6.0, -4.0, 5.0], atol=2e-2)
+    assert cell.flags == 7

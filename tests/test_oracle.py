@@ -175,3 +175,34 @@ def test_synth_is_deterministic_and_in_box(oracle):
     oh = f0[:, 1::3] - f0[:, 0::3]
     oh -= 100.0 * np.round(oh / 100.0)
     assert np.abs(oh).max() <= 0.5501            # O-H offsets of frame 0 stay below 1 Angstrom
+
+
+def test_triclinic_minimum_image_against_27_image_search(oracle):
+    """SPEC S3t (round in fractional space) against an fp64 search over all 27 neighbouring images."""
+    rng = np.random.default_rng(9)
+    x, y, z, xy, xz, yz = 30.0, 28.0, 26.0, 6.0, -4.0, 5.0
+    A = np.array([[x, xy, xz], [0, y, yz], [0, 0, z]])
+    n = 600
+    pts = (A @ rng.uniform(-0.5, 1.5, (3, n))).astype(np.float32)        # inside and outside the cell
+    cell = oracle.make_cell((x, y, z), 7, (xy, xz, yz))
+    idx = np.arange(n)
+    counts, hits = oracle.rdf_frame(pts[0], pts[1], pts[2], cell, idx, idx, 0.0, 10.0)     # 10 < half the smallest width
+    d = pts.astype(np.float64)[:, :, None] - pts.astype(np.float64)[:, None, :]
+    best = np.full((n, n), np.inf)
+    for i in (-1, 0, 1):
+        for j in (-1, 0, 1):
+            for k in (-1, 0, 1):
+                s = A @ np.array([i, j, k], float)
+                # fold the difference by whole cell vectors first (points lie up to 1.5 cells out)
+                dd = d - (A @ np.round(np.linalg.solve(A, d.reshape(3, -1)))).reshape(3, n, n) + s[:, None, None]
+                best = np.minimum(best, np.sqrt((dd ** 2).sum(axis=0)))
+    sel = (best > 0) & (best < 10.0)
+    ref = np.bincount((best[sel] / 10.0 * 1024).astype(int), minlength=1024)[:1024]
+    assert abs(int(hits) - int(sel.sum())) <= 2
+    assert np.abs(counts.astype(np.int64) - ref).sum() <= max(4, 2e-3 * hits)        # fp32 vs fp64 at bin edges only
+    # distances use the same arithmetic
+    a, b = [3], [77]
+    dmin = oracle.distance_minmax(pts[0], pts[1], pts[2], cell, a, b, "min")
+    assert abs(dmin - best[3, 77]) < 1e-4
+    dcom = oracle.distance_com(pts[0], pts[1], pts[2], cell, a, None, b, None)
+    assert abs(dcom - best[3, 77]) < 1e-4

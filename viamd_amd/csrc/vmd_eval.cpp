@@ -693,7 +693,7 @@ static bool fetch_stage(vmd_script_eval_t* e, Stage& st, vmd_trajectory_i* traj,
     const vmd_host_view_t* hview = (!view && traj->host_view && traj->host_view(traj->inst, &hv)) ? &hv : nullptr;
     st.f0 = f0; st.nb = nb;
     st.cells.resize(nb);
-    st.h_boxes.resize(nb * 6);
+    st.h_boxes.resize(nb * 9);
     if (view) {
         st.base = view->base + f0 * view->frame_stride;
         st.frame_stride = view->frame_stride;
@@ -733,13 +733,18 @@ static bool fetch_stage(vmd_script_eval_t* e, Stage& st, vmd_trajectory_i* traj,
     }
     for (size_t b = 0; b < nb; ++b) {
         const vmd_unitcell_t& c = st.cells[b];
-        if (c.xy != 0.0f || c.xz != 0.0f || c.yz != 0.0f) return vmd_fail("frame %zu: triclinic unit cells are not supported (SPEC D-TRICLINIC)", f0 + b);
-        if (c.flags != st.cells[0].flags) return vmd_fail("frame %zu: periodicity flags change inside the trajectory", f0 + b);
-        float* hb = &st.h_boxes[6 * b];
+        const bool tri = c.xy != 0.0f || c.xz != 0.0f || c.yz != 0.0f;
+        if (tri && ((c.flags & VMD_UNITCELL_PBC_ALL) != VMD_UNITCELL_PBC_ALL || !(c.x > 0.0f && c.y > 0.0f && c.z > 0.0f)))
+            return vmd_fail("frame %zu: a triclinic unit cell must be periodic along all three axes (SPEC S3t)", f0 + b);
+        const vmd_unitcell_t& c0 = st.cells[0];
+        if (c.flags != c0.flags || tri != (c0.xy != 0.0f || c0.xz != 0.0f || c0.yz != 0.0f))
+            return vmd_fail("frame %zu: periodicity / cell type changes inside the trajectory", f0 + b);
+        float* hb = &st.h_boxes[9 * b];
         hb[0] = c.x; hb[1] = c.y; hb[2] = c.z;
         hb[3] = 1.0f / c.x; hb[4] = 1.0f / c.y; hb[5] = 1.0f / c.z;      // SPEC S2: invL = fl(1.0f / L)
+        hb[6] = c.xy; hb[7] = c.xz; hb[8] = c.yz;
     }
-    if (!st.d_boxes.upload(st.h_boxes.data(), nb * 6, e->copy_stream)) return false;
+    if (!st.d_boxes.upload(st.h_boxes.data(), nb * 9, e->copy_stream)) return false;
     HIP_OK(hipEventRecord(st.ready, e->copy_stream));
     return true;
 }
@@ -760,6 +765,7 @@ static uint32_t batch_pbc(const Stage& st) {
     if (!(c.x > 0.0f)) f &= ~VMD_UNITCELL_PBC_X;
     if (!(c.y > 0.0f)) f &= ~VMD_UNITCELL_PBC_Y;
     if (!(c.z > 0.0f)) f &= ~VMD_UNITCELL_PBC_Z;
+    if (c.xy != 0.0f || c.xz != 0.0f || c.yz != 0.0f) f |= 8u;         // triclinic (kernels: VMD_PBC_TRICLINIC)
     return f;
 }
 
@@ -768,7 +774,7 @@ static bool choose_grid(const Stage& st, size_t nb, float rmax, vmd_grid_t* g) {
     if (g_opt.force_brute) return false;
     if (batch_pbc(st) != VMD_UNITCELL_PBC_ALL) return false;
     float Lmin[3] = {3.4e38f, 3.4e38f, 3.4e38f};
-    for (size_t b = 0; b < nb; ++b) for (int a = 0; a < 3; ++a) Lmin[a] = std::min(Lmin[a], st.h_boxes[6 * b + a]);
+    for (size_t b = 0; b < nb; ++b) for (int a = 0; a < 3; ++a) Lmin[a] = std::min(Lmin[a], st.h_boxes[9 * b + a]);
     // minimum image must be unique for every hit: rmax < L/2 with margin
     for (int a = 0; a < 3; ++a) if (!(rmax * 2.0f * 1.001f < Lmin[a])) return false;
     int n[3];
@@ -898,9 +904,9 @@ static bool process_range(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
                 }
                 // SPEC S4 normalisation, fp64 on the host (needs only the box)
                 for (size_t b = 0; b < nb; ++b) {
-                    const float* L = &src.h_boxes[6 * b];
+                    const float* L = &src.h_boxes[9 * b];
                     double V;
-                    if (pbc == VMD_UNITCELL_PBC_ALL) V = (double)L[0] * (double)L[1] * (double)L[2];
+                    if ((pbc & VMD_UNITCELL_PBC_ALL) == VMD_UNITCELL_PBC_ALL) V = (double)L[0] * (double)L[1] * (double)L[2];   // also the triclinic volume
                     else V = (4.0 / 3.0) * M_PI * (double)d.rmax * (double)d.rmax * (double)d.rmax;
                     const double rho = (double)d.a.size() * (double)d.b.size() / V;
                     const double w = ((double)d.rmax - (double)d.rmin) / (double)p->ncounts;

@@ -78,6 +78,83 @@ __device__ __forceinline__ double vmd_mi_rint(double d, double L, bool pbc) {
     return d;
 }
 
+// One frame's unit cell as the kernels see it.  boxes[b*9 + ...] = {Lx,Ly,Lz, 1/Lx,1/Ly,1/Lz, xy,xz,yz}; pbc bit 3 = triclinic
+// (basis a = (x,0,0), b = (xy,y,0), c = (xz,yz,z), all three axes periodic; SPEC S3t).
+#define VMD_BOX_STRIDE 9
+#define VMD_PBC_TRICLINIC 8u
+struct vmd_box_t {
+    float Lx, Ly, Lz, iLx, iLy, iLz, xy, xz, yz;
+    bool px, py, pz, tri;
+};
+__device__ __forceinline__ vmd_box_t vmd_load_box(const float* boxes, int b, uint32_t pbc) {
+    const float* q = boxes + (size_t)VMD_BOX_STRIDE * b;
+    vmd_box_t bx;
+    bx.Lx = q[0]; bx.Ly = q[1]; bx.Lz = q[2]; bx.iLx = q[3]; bx.iLy = q[4]; bx.iLz = q[5]; bx.xy = q[6]; bx.xz = q[7]; bx.yz = q[8];
+    bx.px = pbc & 1u; bx.py = pbc & 2u; bx.pz = pbc & 4u; bx.tri = pbc & VMD_PBC_TRICLINIC;
+    return bx;
+}
+// SPEC S3t: Cartesian -> fractional and back, fp32
+__device__ __forceinline__ void vmd_frac(const vmd_box_t& b, float x, float y, float z, float& sx, float& sy, float& sz) {
+    sz = z * b.iLz;
+    sy = fmaf(-b.yz, sz, y) * b.iLy;
+    sx = fmaf(-b.xz, sz, fmaf(-b.xy, sy, x)) * b.iLx;
+}
+__device__ __forceinline__ void vmd_cart(const vmd_box_t& b, float sx, float sy, float sz, float& dx, float& dy, float& dz) {
+    dz = sz * b.Lz;
+    dy = fmaf(b.yz, sz, sy * b.Ly);
+    dx = fmaf(b.xz, sz, fmaf(b.xy, sy, sx * b.Lx));
+}
+// squared minimum-image distance of two atoms given by fractional coordinates (triclinic)
+__device__ __forceinline__ float vmd_pair_d2_tri(const vmd_box_t& b, float six, float siy, float siz, float sjx, float sjy, float sjz) {
+    float dsx = six - sjx, dsy = siy - sjy, dsz = siz - sjz;
+    dsx = dsx - rintf(dsx); dsy = dsy - rintf(dsy); dsz = dsz - rintf(dsz);
+    float dx, dy, dz;
+    vmd_cart(b, dsx, dsy, dsz, dx, dy, dz);
+    return vmd_d2(dx, dy, dz);
+}
+// the coordinates pair kernels work on: wrapped Cartesian (S2) for orthorhombic / open cells, fractional for triclinic
+__device__ __forceinline__ void vmd_pair_coords(const vmd_box_t& b, float x, float y, float z, float& ox, float& oy, float& oz) {
+    if (b.tri) { vmd_frac(b, x, y, z, ox, oy, oz); return; }
+    ox = b.px ? vmd_wrap(x, b.Lx, b.iLx) : x;
+    oy = b.py ? vmd_wrap(y, b.Ly, b.iLy) : y;
+    oz = b.pz ? vmd_wrap(z, b.Lz, b.iLz) : z;
+}
+__device__ __forceinline__ float vmd_pair_d2_general(const vmd_box_t& b, float xi, float yi, float zi, float xj, float yj, float zj) {
+    if (b.tri) return vmd_pair_d2_tri(b, xi, yi, zi, xj, yj, zj);
+    const float dx = vmd_mi_cmp(xi - xj, b.Lx, 0.5f * b.Lx, b.px);
+    const float dy = vmd_mi_cmp(yi - yj, b.Ly, 0.5f * b.Ly, b.py);
+    const float dz = vmd_mi_cmp(zi - zj, b.Lz, 0.5f * b.Lz, b.pz);
+    return vmd_d2(dx, dy, dz);
+}
+// SPEC S5/S6 minimum image of a Cartesian displacement by rounding (fp32 / fp64)
+__device__ __forceinline__ void vmd_mi3_rintf(const vmd_box_t& b, float& dx, float& dy, float& dz) {
+    if (b.tri) {
+        float sx, sy, sz;
+        vmd_frac(b, dx, dy, dz, sx, sy, sz);
+        sx = sx - rintf(sx); sy = sy - rintf(sy); sz = sz - rintf(sz);
+        vmd_cart(b, sx, sy, sz, dx, dy, dz);
+        return;
+    }
+    dx = vmd_mi_rintf(dx, b.Lx, b.iLx, b.px);
+    dy = vmd_mi_rintf(dy, b.Ly, b.iLy, b.py);
+    dz = vmd_mi_rintf(dz, b.Lz, b.iLz, b.pz);
+}
+__device__ __forceinline__ void vmd_mi3_rint(const vmd_box_t& b, double& dx, double& dy, double& dz) {
+    if (b.tri) {
+        double sz = dz / (double)b.Lz;
+        double sy = (dy - (double)b.yz * sz) / (double)b.Ly;
+        double sx = (dx - (double)b.xy * sy - (double)b.xz * sz) / (double)b.Lx;
+        sx = sx - rint(sx); sy = sy - rint(sy); sz = sz - rint(sz);
+        dz = sz * (double)b.Lz;
+        dy = sy * (double)b.Ly + (double)b.yz * sz;
+        dx = sx * (double)b.Lx + (double)b.xy * sy + (double)b.xz * sz;
+        return;
+    }
+    dx = vmd_mi_rint(dx, (double)b.Lx, b.px);
+    dy = vmd_mi_rint(dy, (double)b.Ly, b.py);
+    dz = vmd_mi_rint(dz, (double)b.Lz, b.pz);
+}
+
 __device__ __forceinline__ int vmd_cell_coord(float v, float inv, int n) {
     int c = (int)(v * inv);
     return c > n - 1 ? n - 1 : c;
@@ -141,8 +218,8 @@ struct vmd_cells_params_t {
 __device__ __forceinline__ uint32_t vmd_cell_of(const vmd_cells_params_t& p, int b, int t, float& xw, float& yw, float& zw) {
     const int a = p.sel ? p.sel[t] : t;
     const float* fx = p.xyz + (size_t)b * p.frame_stride;
-    const float Lx = p.boxes[6 * b + 0], Ly = p.boxes[6 * b + 1], Lz = p.boxes[6 * b + 2];
-    const float iLx = p.boxes[6 * b + 3], iLy = p.boxes[6 * b + 4], iLz = p.boxes[6 * b + 5];
+    const float* bq = p.boxes + (size_t)VMD_BOX_STRIDE * b;
+    const float Lx = bq[0], Ly = bq[1], Lz = bq[2], iLx = bq[3], iLy = bq[4], iLz = bq[5];
     xw = vmd_wrap(fx[a], Lx, iLx);
     yw = vmd_wrap(fx[p.row_stride + a], Ly, iLy);
     zw = vmd_wrap(fx[2 * p.row_stride + a], Lz, iLz);
@@ -510,8 +587,8 @@ __global__ __launch_bounds__(256) void k_rdf_pencil(vmd_pair_params_t p) {
         const int pz = pen / ny;
         const int py = pen - pz * ny;
         vmd_cf32* boxes = (vmd_cf32*)p.boxes;
-        const float Lx = boxes[6 * b + 0], Ly = boxes[6 * b + 1], Lz = boxes[6 * b + 2];
-        const float inv_cx = (float)nxf * boxes[6 * b + 3];
+        const float Lx = boxes[VMD_BOX_STRIDE * b + 0], Ly = boxes[VMD_BOX_STRIDE * b + 1], Lz = boxes[VMD_BOX_STRIDE * b + 2];
+        const float inv_cx = (float)nxf * boxes[VMD_BOX_STRIDE * b + 3];
         vmd_cu32* csr = (vmd_cu32*)p.cs_ref + (size_t)b * (p.grid.ncell + 1);
         vmd_cu32* cst = (vmd_cu32*)p.cs_tgt + (size_t)b * (p.grid.ncell + 1);
         const float* __restrict__ sr = p.sref + (size_t)b * 3 * p.nref_pad;
@@ -619,36 +696,26 @@ __global__ __launch_bounds__(256) void k_rdf_brute(vmd_brute_params_t p) {
     const float* fx = p.xyz + (size_t)b * p.frame_stride;
     const float* fy = fx + p.row_stride;
     const float* fz = fy + p.row_stride;
-    const bool px = p.pbc & 1u, py = p.pbc & 2u, pz = p.pbc & 4u;
-    const float Lx = p.boxes[6 * b + 0], Ly = p.boxes[6 * b + 1], Lz = p.boxes[6 * b + 2];
-    const float iLx = p.boxes[6 * b + 3], iLy = p.boxes[6 * b + 4], iLz = p.boxes[6 * b + 5];
-    const float hx = 0.5f * Lx, hy = 0.5f * Ly, hz = 0.5f * Lz;
+    const vmd_box_t bx = vmd_load_box(p.boxes, b, p.pbc);
     for (int k = threadIdx.x; k < p.bin.nbins; k += 256) s_hist[k] = 0u;
     float xi = VMD_FAR, yi = VMD_FAR, zi = VMD_FAR;
     const bool valid = t < p.nref;
     if (valid) {
         const int a = p.ref ? p.ref[t] : t;
-        xi = px ? vmd_wrap(fx[a], Lx, iLx) : fx[a];
-        yi = py ? vmd_wrap(fy[a], Ly, iLy) : fy[a];
-        zi = pz ? vmd_wrap(fz[a], Lz, iLz) : fz[a];
+        vmd_pair_coords(bx, fx[a], fy[a], fz[a], xi, yi, zi);
     }
     for (int j0 = 0; j0 < p.ntgt; j0 += 256) {
         __syncthreads();
         const int j = j0 + threadIdx.x;
         if (j < p.ntgt) {
             const int a = p.tgt ? p.tgt[j] : j;
-            s_t[0][threadIdx.x] = px ? vmd_wrap(fx[a], Lx, iLx) : fx[a];
-            s_t[1][threadIdx.x] = py ? vmd_wrap(fy[a], Ly, iLy) : fy[a];
-            s_t[2][threadIdx.x] = pz ? vmd_wrap(fz[a], Lz, iLz) : fz[a];
+            vmd_pair_coords(bx, fx[a], fy[a], fz[a], s_t[0][threadIdx.x], s_t[1][threadIdx.x], s_t[2][threadIdx.x]);
         }
         __syncthreads();
         const int nj = p.ntgt - j0 < 256 ? p.ntgt - j0 : 256;
         if (valid) {
             for (int jj = 0; jj < nj; ++jj) {
-                const float dx = vmd_mi_cmp(xi - s_t[0][jj], Lx, hx, px);
-                const float dy = vmd_mi_cmp(yi - s_t[1][jj], Ly, hy, py);
-                const float dz = vmd_mi_cmp(zi - s_t[2][jj], Lz, hz, pz);
-                const int bin = vmd_bin_of(p.bin, vmd_d2(dx, dy, dz));
+                const int bin = vmd_bin_of(p.bin, vmd_pair_d2_general(bx, xi, yi, zi, s_t[0][jj], s_t[1][jj], s_t[2][jj]));
                 if (bin >= 0) atomicAdd(&s_hist[bin], 1u);
             }
         }
@@ -733,16 +800,15 @@ __device__ void vmd_horn_rotation(const double S[3][3], double R[9]) {
 // walks the unwrap chain of one structure; calls f(a, w, px, py, pz) for every atom in order
 template <typename F>
 __device__ __forceinline__ void vmd_unwrap_chain(const float* fx, const float* fy, const float* fz,
-                                                 const int32_t* idx, const float* mass, int m,
-                                                 double Lx, double Ly, double Lz, bool px_, bool py_, bool pz_, F f) {
+                                                 const int32_t* idx, const float* mass, int m, const vmd_box_t& bx, F f) {
     double qx = 0.0, qy = 0.0, qz = 0.0;
     for (int a = 0; a < m; ++a) {
         const int i = idx[a];
         double x = (double)fx[i], y = (double)fy[i], z = (double)fz[i];
         if (a > 0) {
-            x = qx + vmd_mi_rint(x - qx, Lx, px_);
-            y = qy + vmd_mi_rint(y - qy, Ly, py_);
-            z = qz + vmd_mi_rint(z - qz, Lz, pz_);
+            double dx = x - qx, dy = y - qy, dz = z - qz;
+            vmd_mi3_rint(bx, dx, dy, dz);
+            x = qx + dx; y = qy + dy; z = qz + dz;
         }
         qx = x; qy = y; qz = z;
         f(a, mass ? (double)mass[a] : 1.0, x, y, z);
@@ -764,20 +830,19 @@ __global__ __launch_bounds__(64) void k_sdf_align(vmd_align_params_t p) {
     const float* fx = p.xyz + (size_t)b * p.frame_stride;
     const float* fy = fx + p.row_stride;
     const float* fz = fy + p.row_stride;
-    const double Lx = (double)p.boxes[6 * b + 0], Ly = (double)p.boxes[6 * b + 1], Lz = (double)p.boxes[6 * b + 2];
-    const bool px = p.pbc & 1u, py = p.pbc & 2u, pz = p.pbc & 4u;
+    const vmd_box_t bx = vmd_load_box(p.boxes, b, p.pbc);
     const int32_t* idx = p.structs + (size_t)k * p.m;
     const float* mass = p.mass ? p.mass + (size_t)k * p.m : nullptr;
 
     double sw = 0.0, sx = 0.0, sy = 0.0, sz = 0.0;
-    vmd_unwrap_chain(fx, fy, fz, idx, mass, p.m, Lx, Ly, Lz, px, py, pz,
+    vmd_unwrap_chain(fx, fy, fz, idx, mass, p.m, bx,
                      [&](int, double w, double x, double y, double z) {
                          sw = sw + w; sx = sx + w * x; sy = sy + w * y; sz = sz + w * z;
                      });
     const double com0 = sx / sw, com1 = sy / sw, com2 = sz / sw;
     double S[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
     const double* ref = p.ref_pose;
-    vmd_unwrap_chain(fx, fy, fz, idx, mass, p.m, Lx, Ly, Lz, px, py, pz,
+    vmd_unwrap_chain(fx, fy, fz, idx, mass, p.m, bx,
                      [&](int a, double w, double x, double y, double z) {
                          const double c0 = x - com0, c1 = y - com1, c2 = z - com2;
                          const double r0 = ref[3 * a + 0], r1 = ref[3 * a + 1], r2 = ref[3 * a + 2];
@@ -807,10 +872,9 @@ __global__ __launch_bounds__(64) void k_sdf_ref_pose(const float* xyz, size_t ro
     const float* fx = xyz;
     const float* fy = fx + row_stride;
     const float* fz = fy + row_stride;
-    const double Lx = (double)box[0], Ly = (double)box[1], Lz = (double)box[2];
-    const bool px = pbc & 1u, py = pbc & 2u, pz = pbc & 4u;
+    const vmd_box_t bx = vmd_load_box(box, 0, pbc);
     double sw = 0.0, sx = 0.0, sy = 0.0, sz = 0.0;
-    vmd_unwrap_chain(fx, fy, fz, idx, mass, m, Lx, Ly, Lz, px, py, pz,
+    vmd_unwrap_chain(fx, fy, fz, idx, mass, m, bx,
                      [&](int a, double w, double x, double y, double z) {
                          ref_pose[3 * a + 0] = x; ref_pose[3 * a + 1] = y; ref_pose[3 * a + 2] = z;
                          sw = sw + w; sx = sx + w * x; sy = sy + w * y; sz = sz + w * z;
@@ -841,9 +905,7 @@ __global__ __launch_bounds__(256) void k_sdf_scatter(vmd_scatter_params_t p) {
     const int i = p.tgt ? p.tgt[t] : t;
     const float* fx = p.xyz + (size_t)b * p.frame_stride;
     const float x = fx[i], y = fx[p.row_stride + i], z = fx[2 * p.row_stride + i];
-    const float Lx = p.boxes[6 * b + 0], Ly = p.boxes[6 * b + 1], Lz = p.boxes[6 * b + 2];
-    const float iLx = p.boxes[6 * b + 3], iLy = p.boxes[6 * b + 4], iLz = p.boxes[6 * b + 5];
-    const bool px = p.pbc & 1u, py = p.pbc & 2u, pz = p.pbc & 4u;
+    const vmd_box_t bx = vmd_load_box(p.boxes, b, p.pbc);
     const float s = p.extent;
     const float vscale = (float)p.dim / (2.0f * s);
     const float fdim = (float)p.dim;
@@ -861,9 +923,8 @@ __global__ __launch_bounds__(256) void k_sdf_scatter(vmd_scatter_params_t p) {
         }
         const float* R = p.R32 + ((size_t)b * p.K + k) * 9;
         const float* c = p.c32 + ((size_t)b * p.K + k) * 3;
-        const float dx = vmd_mi_rintf(x - c[0], Lx, iLx, px);
-        const float dy = vmd_mi_rintf(y - c[1], Ly, iLy, py);
-        const float dz = vmd_mi_rintf(z - c[2], Lz, iLz, pz);
+        float dx = x - c[0], dy = y - c[1], dz = z - c[2];
+        vmd_mi3_rintf(bx, dx, dy, dz);
         // a voxel hit needs |q|_inf < s, hence |d|^2 = |q|^2 < 3 s^2: skip the rotation for everything outside that sphere
         if (vmd_d2(dx, dy, dz) > r2_skip) continue;
         const float qx = fmaf(R[2], dz, fmaf(R[1], dy, R[0] * dx));
@@ -891,7 +952,7 @@ struct vmd_dist_params_t {
 };
 
 __device__ void vmd_set_com(const float* fx, const float* fy, const float* fz, const int32_t* idx, const float* mass, int n,
-                            double Lx, double Ly, double Lz, bool px, bool py, bool pz, float out[3]) {
+                            const vmd_box_t& bx, float out[3]) {
     double sw = 0.0, sx = 0.0, sy = 0.0, sz = 0.0;
     double p0x = 0.0, p0y = 0.0, p0z = 0.0;
     for (int a = 0; a < n; ++a) {
@@ -899,9 +960,9 @@ __device__ void vmd_set_com(const float* fx, const float* fy, const float* fz, c
         double x = (double)fx[i], y = (double)fy[i], z = (double)fz[i];
         if (a == 0) { p0x = x; p0y = y; p0z = z; }
         else {
-            x = p0x + vmd_mi_rint(x - p0x, Lx, px);
-            y = p0y + vmd_mi_rint(y - p0y, Ly, py);
-            z = p0z + vmd_mi_rint(z - p0z, Lz, pz);
+            double dx = x - p0x, dy = y - p0y, dz = z - p0z;
+            vmd_mi3_rint(bx, dx, dy, dz);
+            x = p0x + dx; y = p0y + dy; z = p0z + dz;
         }
         const double w = mass ? (double)mass[a] : 1.0;
         sw = sw + w; sx = sx + w * x; sy = sy + w * y; sz = sz + w * z;
@@ -916,16 +977,13 @@ __global__ __launch_bounds__(64) void k_distance_com(vmd_dist_params_t p) {
     const float* fx = p.xyz + (size_t)b * p.frame_stride;
     const float* fy = fx + p.row_stride;
     const float* fz = fy + p.row_stride;
-    const float Lx = p.boxes[6 * b + 0], Ly = p.boxes[6 * b + 1], Lz = p.boxes[6 * b + 2];
-    const float iLx = p.boxes[6 * b + 3], iLy = p.boxes[6 * b + 4], iLz = p.boxes[6 * b + 5];
-    const bool px = p.pbc & 1u, py = p.pbc & 2u, pz = p.pbc & 4u;
+    const vmd_box_t bx = vmd_load_box(p.boxes, b, p.pbc);
     const int a0 = p.aoff[c], na = p.aoff[c + 1] - a0, b0 = p.boff[c], nb = p.boff[c + 1] - b0;
     float ca[3], cb[3];
-    vmd_set_com(fx, fy, fz, p.a + a0, p.mass_a ? p.mass_a + a0 : nullptr, na, (double)Lx, (double)Ly, (double)Lz, px, py, pz, ca);
-    vmd_set_com(fx, fy, fz, p.b + b0, p.mass_b ? p.mass_b + b0 : nullptr, nb, (double)Lx, (double)Ly, (double)Lz, px, py, pz, cb);
-    const float dx = vmd_mi_rintf(ca[0] - cb[0], Lx, iLx, px);
-    const float dy = vmd_mi_rintf(ca[1] - cb[1], Ly, iLy, py);
-    const float dz = vmd_mi_rintf(ca[2] - cb[2], Lz, iLz, pz);
+    vmd_set_com(fx, fy, fz, p.a + a0, p.mass_a ? p.mass_a + a0 : nullptr, na, bx, ca);
+    vmd_set_com(fx, fy, fz, p.b + b0, p.mass_b ? p.mass_b + b0 : nullptr, nb, bx, cb);
+    float dx = ca[0] - cb[0], dy = ca[1] - cb[1], dz = ca[2] - cb[2];
+    vmd_mi3_rintf(bx, dx, dy, dz);
     p.out[t] = sqrtf(vmd_d2(dx, dy, dz));
 }
 
@@ -933,16 +991,11 @@ __device__ __forceinline__ float vmd_pair_d2(const vmd_dist_params_t& p, int b, 
     const float* fx = p.xyz + (size_t)b * p.frame_stride;
     const float* fy = fx + p.row_stride;
     const float* fz = fy + p.row_stride;
-    const float Lx = p.boxes[6 * b + 0], Ly = p.boxes[6 * b + 1], Lz = p.boxes[6 * b + 2];
-    const float iLx = p.boxes[6 * b + 3], iLy = p.boxes[6 * b + 4], iLz = p.boxes[6 * b + 5];
-    const bool px = p.pbc & 1u, py = p.pbc & 2u, pz = p.pbc & 4u;
-    const float xi = px ? vmd_wrap(fx[i], Lx, iLx) : fx[i], xj = px ? vmd_wrap(fx[j], Lx, iLx) : fx[j];
-    const float yi = py ? vmd_wrap(fy[i], Ly, iLy) : fy[i], yj = py ? vmd_wrap(fy[j], Ly, iLy) : fy[j];
-    const float zi = pz ? vmd_wrap(fz[i], Lz, iLz) : fz[i], zj = pz ? vmd_wrap(fz[j], Lz, iLz) : fz[j];
-    const float dx = vmd_mi_cmp(xi - xj, Lx, 0.5f * Lx, px);
-    const float dy = vmd_mi_cmp(yi - yj, Ly, 0.5f * Ly, py);
-    const float dz = vmd_mi_cmp(zi - zj, Lz, 0.5f * Lz, pz);
-    return vmd_d2(dx, dy, dz);
+    const vmd_box_t bx = vmd_load_box(p.boxes, b, p.pbc);
+    float xi, yi, zi, xj, yj, zj;
+    vmd_pair_coords(bx, fx[i], fy[i], fz[i], xi, yi, zi);
+    vmd_pair_coords(bx, fx[j], fy[j], fz[j], xj, yj, zj);
+    return vmd_pair_d2_general(bx, xi, yi, zi, xj, yj, zj);
 }
 
 // one block per (frame, context); MAXI = false -> min, true -> max

@@ -16,13 +16,14 @@ def _idx(a):
     return a, a.ctypes.data_as(L.c_int32_p)
 
 
-def make_unitcell(box, flags=L.PBC_ALL):
-    """box: None (no cell), scalar (cubic) or (x,y,z)."""
+def make_unitcell(box, flags=L.PBC_ALL, tilt=(0.0, 0.0, 0.0)):
+    """box: None (no cell), scalar (cubic) or (x,y,z); tilt = (xy, xz, yz) of a triclinic cell
+    (basis a=(x,0,0), b=(xy,y,0), c=(xz,yz,z), as VIAMD reads md_unitcell_t, src/viamd.cpp:1837-1843)."""
     if box is None:
         return L.Unitcell(0, 0, 0, 0, 0, 0, 0)
     if np.isscalar(box):
         box = (box, box, box)
-    return L.Unitcell(float(box[0]), float(box[1]), float(box[2]), 0, 0, 0, flags)
+    return L.Unitcell(float(box[0]), float(box[1]), float(box[2]), float(tilt[0]), float(tilt[1]), float(tilt[2]), flags)
 
 
 class VmdError(RuntimeError):
