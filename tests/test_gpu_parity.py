@@ -279,7 +279,7 @@ def test_interrupt_and_errors(gpu_lib, oracle, box30k):
     assert ev.frame_range(V.MolSystem(30000), traj, 0, 4) is False and ev.frames_done() == 0
     ev.clear_data()
     assert ev.frame_range(V.MolSystem(30000), traj, 0, 4) and ev.frames_done() == 4
-    tri = V.make_unitcell(80.0); tri.xy = 5.0
+    tri = V.make_unitcell(80.0, flags=3); tri.xy = 5.0                   # tilted but not periodic along z: rejected
     with pytest.raises(V.VmdError, match="triclinic"):
         ev2 = V.ScriptEval(4, ir)
         ev2.frame_range(V.MolSystem(30000), V.HostTrajectory(box30k, tri), 0, 1)
