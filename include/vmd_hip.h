@@ -36,14 +36,17 @@ typedef struct vmd_grid_t {
  *   cell_count u32[B][ncell+1]  scratch, zeroed by this call
  *   rank       u32[B][nsel]     scratch
  *   cell_start u32[B][ncell+1]  out: exclusive prefix of the cell populations
- *   sorted     f32[B][3][nsel_pad] out: wrapped coordinates in cell order (x row, y row, z row) */
+ *   sorted     f32[B][3][nsel_pad] out: wrapped coordinates in cell order (x row, y row, z row)
+ *   aos        f32[B][nsel_pad][4] scratch or NULL: when given, the sort scatters one 16-byte record per atom and a
+ *              coalesced repack pass produces `sorted` (fewer scattered L2 transactions) */
 /* selections of <= 65536 atoms on grids with ncell + 1 <= 24576 are built by one block per frame entirely in LDS
  * (count -> scan -> scatter); larger ones take the three-kernel path with global atomics */
 int vmd_hip_cells_fused_ok(vmd_grid_t grid, int nsel);
 int vmd_hip_set_cells_fused(int on);   /* tuning / A-B switch, returns the previous value */
 int vmd_hip_cells_build(void* stream, const float* xyz, size_t frame_stride, size_t row_stride,
                         const float* boxes, int B, const int32_t* sel, int nsel, int nsel_pad,
-                        vmd_grid_t grid, uint32_t* cell_count, uint32_t* rank, uint32_t* cell_start, float* sorted);
+                        vmd_grid_t grid, uint32_t* cell_count, uint32_t* rank, uint32_t* cell_start, float* sorted,
+                        float* aos);
 
 /* K2: RDF pair histogram over a batch from cell-sorted selections (ref may equal tgt -> half shell).
  *   partial   u64[vmd_hip_rdf_partial_words()] scratch (per-wave rows + the work counter)

@@ -135,7 +135,7 @@ SIGNATURES = [
     ("vmd_profile_ms", C.c_double, [C.c_char_p, c_uint64_p]),
     ("vmd_profile_enable", None, [C.c_bool]),
     # vmd_hip.h
-    ("vmd_hip_cells_build", C.c_int, [_vp, _vp, C.c_size_t, C.c_size_t, _vp, C.c_int, _vp, C.c_int, C.c_int, Grid, _vp, _vp, _vp, _vp]),
+    ("vmd_hip_cells_build", C.c_int, [_vp, _vp, C.c_size_t, C.c_size_t, _vp, C.c_int, _vp, C.c_int, C.c_int, Grid, _vp, _vp, _vp, _vp, _vp]),
     ("vmd_hip_cells_fused_ok", C.c_int, [Grid, C.c_int]),
     ("vmd_hip_set_cells_fused", C.c_int, [C.c_int]),
     ("vmd_hip_rdf_num_blocks", C.c_int, []),

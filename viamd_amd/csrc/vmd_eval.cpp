@@ -53,6 +53,7 @@ struct Options {
     std::atomic<int> batch_frames{0};    // 0 = auto
     std::atomic<int> force_brute{0};
     std::atomic<int> nxf_divisor{8};     // fine x cell = rmax / nxf_divisor
+    std::atomic<int> cells_aos{1};       // sort through 16-byte records + repack
 };
 static Options g_opt;
 
@@ -62,6 +63,7 @@ extern "C" int vmd_set_option(const char* key, int value) {
     else if (!strcmp(key, "batch_frames")) o = &g_opt.batch_frames;
     else if (!strcmp(key, "force_brute")) o = &g_opt.force_brute;
     else if (!strcmp(key, "nxf_divisor")) o = &g_opt.nxf_divisor;
+    else if (!strcmp(key, "cells_aos")) o = &g_opt.cells_aos;
     else if (!strcmp(key, "cells_fused")) return vmd_hip_set_cells_fused(value);
     else if (!strcmp(key, "rdf_blocks")) return vmd_hip_set_rdf_blocks(value);
     if (!o) return -1;
@@ -292,7 +294,7 @@ struct Selection {
     std::vector<int32_t> idx;
     DevBuf<int32_t> d_idx;
     DevBuf<uint32_t> cell_count, rank, cell_start;
-    DevBuf<float> sorted;
+    DevBuf<float> sorted, aos;
     int nsel_pad = 0;
     bool built = false;     // for the current batch ...
     vmd_grid_t built_grid;  // ... on this grid
@@ -803,9 +805,11 @@ static bool build_selection(vmd_script_eval_t* e, Selection* s, const Stage& src
     s->nsel_pad = (nsel + 63) & ~63;
     if (!s->cell_count.ensure(nb * (size_t)(g.ncell + 1)) || !s->cell_start.ensure(nb * (size_t)(g.ncell + 1)) ||
         !s->rank.ensure(nb * (size_t)nsel) || !s->sorted.ensure(nb * 3 * (size_t)s->nsel_pad + 64)) return false;   // +64: the pair kernel prefetches past a segment
+    const bool use_aos = g_opt.cells_aos != 0;
+    if (use_aos && !s->aos.ensure(nb * 4 * (size_t)s->nsel_pad)) return false;
     e->prof.begin("cells_build", e->stream);
     KRN_OK(vmd_hip_cells_build(e->stream, src.base, src.frame_stride, src.row_stride, src.d_boxes.p, (int)nb, s->d_idx.p, nsel,
-                               s->nsel_pad, g, s->cell_count.p, s->rank.p, s->cell_start.p, s->sorted.p));
+                               s->nsel_pad, g, s->cell_count.p, s->rank.p, s->cell_start.p, s->sorted.p, use_aos ? s->aos.p : nullptr));
     e->prof.end(e->stream);
     s->built = true;
     s->built_grid = g;
@@ -817,7 +821,7 @@ static size_t auto_batch(const vmd_script_eval_t* e, size_t num_atoms) {
     if (forced > 0) return (size_t)forced;
     // scratch per frame: every selection holds ~20 B per selected atom + the staged frame itself (host trajectories)
     size_t per_frame = 12 * num_atoms;
-    for (auto& s : e->sels) per_frame += 24 * s->idx.size();
+    for (auto& s : e->sels) per_frame += 40 * s->idx.size();
     // 288 GB of HBM: a 12 GB scratch budget keeps whole 1k-frame trajectories of the 1M-atom configs in one or two launches
     size_t B = (size_t)(12ull << 30) / std::max<size_t>(per_frame, 1);
     B = std::max<size_t>(1, std::min<size_t>(B, 1024));

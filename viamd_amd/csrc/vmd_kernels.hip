@@ -213,6 +213,7 @@ struct vmd_cells_params_t {
     const float* boxes; const int32_t* sel; int nsel; int nsel_pad;
     vmd_grid_t grid;
     uint32_t* cell_count; uint32_t* rank; uint32_t* cell_start; float* sorted;
+    float* aos;   // optional f32[B][nsel_pad][4] staging: scatter ONE 16-byte record per atom, k_cells_repack makes the SoA rows
 };
 
 __device__ __forceinline__ uint32_t vmd_cell_of(const vmd_cells_params_t& p, int b, int t, float& xw, float& yw, float& zw) {
@@ -227,6 +228,24 @@ __device__ __forceinline__ uint32_t vmd_cell_of(const vmd_cells_params_t& p, int
     const int cy = vmd_cell_coord(yw, (float)p.grid.ny * iLy, p.grid.ny);
     const int cz = vmd_cell_coord(zw, (float)p.grid.nz * iLz, p.grid.nz);
     return (uint32_t)((cz * p.grid.ny + cy) * p.grid.nxf + cx);
+}
+
+// a scattered 4-byte store costs the L2 as much as a scattered 16-byte one: the sort writes ONE float4 record per atom and
+// k_cells_repack turns the records into the SoA rows with coalesced traffic
+typedef float vmd_f4a __attribute__((vector_size(16)));
+__device__ __forceinline__ void vmd_store_aos(float* aos, size_t slot, float x, float y, float z) {
+    const vmd_f4a v = {x, y, z, 0.0f};
+    *(vmd_f4a*)(aos + 4 * slot) = v;
+}
+__global__ __launch_bounds__(256) void k_cells_repack(const float* __restrict__ aos, float* __restrict__ sorted, int nsel, int nsel_pad) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.y;
+    if (t >= nsel) return;
+    const vmd_f4a v = *(const vmd_f4a*)(aos + 4 * ((size_t)b * nsel_pad + t));
+    float* s = sorted + (size_t)b * 3 * nsel_pad;
+    s[t] = v[0];
+    s[nsel_pad + t] = v[1];
+    s[2 * (size_t)nsel_pad + t] = v[2];
 }
 
 // atoms per thread.  Measured on the 333k-atom selection of config 3: 4 independent gathers per thread are ~10 % SLOWER than
@@ -292,6 +311,7 @@ __global__ __launch_bounds__(256) void k_cells_scatter(vmd_cells_params_t p) {
 #pragma unroll
     for (int u = 0; u < VMD_CELLS_ILP; ++u) {
         if (pos[u] == 0xffffffffu) continue;
+        if (p.aos) { vmd_store_aos(p.aos, (size_t)b * p.nsel_pad + pos[u], xw[u], yw[u], zw[u]); continue; }
         s[pos[u]] = xw[u];
         s[p.nsel_pad + pos[u]] = yw[u];
         s[2 * (size_t)p.nsel_pad + pos[u]] = zw[u];
@@ -336,6 +356,7 @@ __global__ __launch_bounds__(1024) void k_cells_fused(vmd_cells_params_t p) {
     for (int t = tid; t < p.nsel; t += 1024) {
         const uint32_t c = vmd_cell_of(p, b, t, xw, yw, zw);
         const uint32_t pos = atomicAdd(&s_cnt[c], 1u);
+        if (p.aos) { vmd_store_aos(p.aos, (size_t)b * p.nsel_pad + pos, xw, yw, zw); continue; }
         srt[pos] = xw;
         srt[p.nsel_pad + pos] = yw;
         srt[2 * (size_t)p.nsel_pad + pos] = zw;
@@ -1095,11 +1116,13 @@ extern "C" int vmd_hip_cells_fused_ok(vmd_grid_t grid, int nsel) { return g_cell
 
 extern "C" int vmd_hip_cells_build(void* stream, const float* xyz, size_t frame_stride, size_t row_stride,
                                    const float* boxes, int B, const int32_t* sel, int nsel, int nsel_pad,
-                                   vmd_grid_t grid, uint32_t* cell_count, uint32_t* rank, uint32_t* cell_start, float* sorted) {
+                                   vmd_grid_t grid, uint32_t* cell_count, uint32_t* rank, uint32_t* cell_start, float* sorted,
+                                   float* aos) {
     hipStream_t s = (hipStream_t)stream;
     if (B <= 0 || nsel <= 0) return 0;
+    const dim3 grp((nsel + 255) / 256, B);
     if (vmd_hip_cells_fused_ok(grid, nsel)) {
-        vmd_cells_params_t pf{xyz, frame_stride, row_stride, boxes, sel, nsel, nsel_pad, grid, cell_count, rank, cell_start, sorted};
+        vmd_cells_params_t pf{xyz, frame_stride, row_stride, boxes, sel, nsel, nsel_pad, grid, cell_count, rank, cell_start, sorted, aos};
         const size_t shm = sizeof(uint32_t) * ((size_t)grid.ncell + 1 + 1024);
         static bool attr_set = false;
         if (!attr_set) {
@@ -1109,11 +1132,12 @@ extern "C" int vmd_hip_cells_build(void* stream, const float* xyz, size_t frame_
         }
         hipLaunchKernelGGL(k_cells_fused, dim3(B), dim3(1024), shm, s, pf);
         VMD_LAUNCH_CHECK();
+        if (aos) { hipLaunchKernelGGL(k_cells_repack, grp, dim3(256), 0, s, (const float*)aos, sorted, nsel, nsel_pad); VMD_LAUNCH_CHECK(); }
         return 0;
     }
     hipError_t e = hipMemsetAsync(cell_count, 0, sizeof(uint32_t) * (size_t)B * (grid.ncell + 1), s);
     if (e != hipSuccess) return (int)e;
-    vmd_cells_params_t p{xyz, frame_stride, row_stride, boxes, sel, nsel, nsel_pad, grid, cell_count, rank, cell_start, sorted};
+    vmd_cells_params_t p{xyz, frame_stride, row_stride, boxes, sel, nsel, nsel_pad, grid, cell_count, rank, cell_start, sorted, aos};
     const dim3 g((nsel + 256 * VMD_CELLS_ILP - 1) / (256 * VMD_CELLS_ILP), B);
     hipLaunchKernelGGL(k_cells_count, g, dim3(256), 0, s, p);
     VMD_LAUNCH_CHECK();
@@ -1121,6 +1145,7 @@ extern "C" int vmd_hip_cells_build(void* stream, const float* xyz, size_t frame_
     VMD_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_cells_scatter, g, dim3(256), 0, s, p);
     VMD_LAUNCH_CHECK();
+    if (aos) { hipLaunchKernelGGL(k_cells_repack, grp, dim3(256), 0, s, (const float*)aos, sorted, nsel, nsel_pad); VMD_LAUNCH_CHECK(); }
     return 0;
 }
 
