@@ -149,7 +149,8 @@ typedef struct vmd_script_property_data_t {
     float   min_value, max_value;
     float   min_range[2], max_range[2];
     uint64_t fingerprint;
-    /* extension: the exact integer accumulators behind values (distribution: dim[2], volume: dim[1]*dim[2]*dim[3]) */
+    /* extension: the exact integer accumulators behind values (distribution: dim[2], volume: dim[1]*dim[2]*dim[3]).
+     * Distributions keep it current; for volumes (17 MB) call vmd_eval_refresh_counts before reading it. */
     const uint64_t* counts;
     const double*   weights64;
 } vmd_script_property_data_t;
@@ -190,6 +191,8 @@ typedef struct vmd_accum_view_t {
     size_t    num_temporal;
 } vmd_accum_view_t;
 size_t vmd_eval_accum_views(vmd_script_eval_t* eval, vmd_accum_view_t* out, size_t cap);
+/* bring the host u64 mirror (`counts`) of a property up to date with the device accumulators */
+bool   vmd_eval_refresh_counts(vmd_script_eval_t* eval, const char* name);
 /* re-derive values/weights/aggregates from the accumulators (after an external reduce) */
 bool   vmd_eval_finalize(vmd_script_eval_t* eval);
 /* mark frames as evaluated elsewhere (after a mask all-reduce) */

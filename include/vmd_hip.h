@@ -68,11 +68,12 @@ int vmd_hip_rdf_brute(void* stream, const float* xyz, size_t frame_stride, size_
 
 /* K3: per frame, per reference structure alignment (fp64, SPEC S5).
  *   structs  int32[K][m], mass f32[K][m], ref_pose f64[m][3] (COM-centred)
- *   R32 f32[B][K][9], c32 f32[B][K][3] out;  M64 f64[B][K][12] out (optional, may be NULL) */
+ *   R32 f32[B][K][9], c32 f32[B][K][3] out;  M64 f64[B][K][12] out (optional, may be NULL)
+ *   group f32[B][4] out (optional): centre + radius of the set of structure COMs, the scatter's one-test pre-filter */
 int vmd_hip_sdf_align(void* stream, const float* xyz, size_t frame_stride, size_t row_stride,
                       const float* boxes, uint32_t pbc_flags, int B,
                       const int32_t* structs, const float* mass, int K, int m, const double* ref_pose,
-                      float* R32, float* c32, double* M64);
+                      float* R32, float* c32, double* M64, float* group);
 /* reference pose from one frame (structure 0): ref_pose f64[m][3] out */
 int vmd_hip_sdf_ref_pose(void* stream, const float* xyz, size_t row_stride, const float* box, uint32_t pbc_flags,
                          const int32_t* struct0, const float* mass0, int m, double* ref_pose);
@@ -82,7 +83,10 @@ int vmd_hip_sdf_ref_pose(void* stream, const float* xyz, size_t row_stride, cons
 int vmd_hip_sdf_scatter(void* stream, const float* xyz, size_t frame_stride, size_t row_stride,
                         const float* boxes, uint32_t pbc_flags, int B,
                         const int32_t* structs, int K, int m, const float* R32, const float* c32,
-                        const int32_t* tgt, const int8_t* owner, int ntgt, float extent, int dim, uint64_t* volume);
+                        const int32_t* tgt, const int8_t* owner, int ntgt, float extent, int dim, uint64_t* volume,
+                        const float* group /* from vmd_hip_sdf_align, or NULL */,
+                        const uint8_t* atom_tag /* u8[row_stride] or NULL: dense-target path, one tag per ATOM: 255 = not a
+                                                   target, 254 = target, k <= 253 = target that belongs to structure k */);
 
 /* K5: distance family, one row per frame: out f32[B][P*per].  kind as vmd_distance_kind_t; P contexts (population);
  * context c uses a[aoff[c]..aoff[c+1]) and b[boff[c]..boff[c+1]); per = 1 (COM/MIN/MAX) or |a_c|*|b_c| (PAIR, equal

@@ -103,6 +103,21 @@ def test_sdf_volume_and_matrices(emu_lib, oracle):
                     ranges=[(1, 2), (0, 1)])
 
 
+def test_sdf_sparse_and_dense_target_paths(emu_lib, oracle):
+    coords, structures, mass = cases.sdf_system(oracle, 14, 1200, 36.0, 2)
+    n_s, N = structures.size, coords.shape[2]
+    dense = np.arange(n_s, N, 3, dtype=np.int32)                  # a third of all atoms -> streamed with tags
+    sparse = np.arange(n_s, N, 30, dtype=np.int32)                # a few percent -> index-list gather
+    for flag in (0, 1):
+        old = emu_lib.vmd_set_option(b"sdf_dense", flag)
+        try:
+            cases.check_sdf(emu_lib, oracle, coords, 36.0, structures, mass, dense, 8.0)
+            cases.check_sdf(emu_lib, oracle, coords, 36.0, structures, mass, np.arange(N, dtype=np.int32), 5.0)   # owners among the targets
+            cases.check_sdf(emu_lib, oracle, coords, 36.0, structures, mass, sparse, 9.0)
+        finally:
+            emu_lib.vmd_set_option(b"sdf_dense", old)
+
+
 def test_distance_family(emu_lib, oracle):
     coords, structures, mass = cases.sdf_system(oracle, 9, 600, 30.0, 4)
     specs = [("d", [3], [40], L.DIST_COM), ("dcom", structures[0], structures[1], L.DIST_COM),

@@ -212,6 +212,21 @@ def test_sdf_volume_matrices_and_sharding(gpu_lib, oracle):
                     ranges=[(1, 3), (0, 1)])
 
 
+def test_sdf_sparse_and_dense_target_paths(gpu_lib, oracle):
+    coords, structures, mass = cases.sdf_system(oracle, 14, 30000, 70.0, 3, K=7, m=10)
+    n_s, N = structures.size, coords.shape[2]
+    dense = np.arange(n_s, N, 3, dtype=np.int32)
+    sparse = np.arange(n_s, N, 30, dtype=np.int32)
+    for flag in (0, 1):
+        old = gpu_lib.vmd_set_option(b"sdf_dense", flag)
+        try:
+            cases.check_sdf(gpu_lib, oracle, coords, 70.0, structures, mass, dense, 10.0, device=True)
+            cases.check_sdf(gpu_lib, oracle, coords, 70.0, structures, mass, np.arange(N, dtype=np.int32), 6.0, device=True)
+            cases.check_sdf(gpu_lib, oracle, coords, 70.0, structures, mass, sparse, 10.0)
+        finally:
+            gpu_lib.vmd_set_option(b"sdf_dense", old)
+
+
 def test_sdf_rigid_motion_invariance(gpu_lib, oracle):
     """frame 1 = frame 0 rigidly rotated + translated (no cell) -> the same volume twice."""
     rng = np.random.default_rng(6)

@@ -109,6 +109,7 @@ SIGNATURES = [
     ("vmd_eval_sdf_matrices", C.c_bool, [_vp, C.c_char_p, C.POINTER(System), C.POINTER(TrajectoryI), C.c_uint32, c_float_p,
                                          C.POINTER(C.c_size_t), c_float_p]),
     ("vmd_eval_accum_views", C.c_size_t, [_vp, C.POINTER(AccumView), C.c_size_t]),
+    ("vmd_eval_refresh_counts", C.c_bool, [_vp, C.c_char_p]),
     ("vmd_eval_finalize", C.c_bool, [_vp]),
     ("vmd_eval_set_frame_mask", None, [_vp, c_uint8_p, C.c_size_t]),
     ("vmd_devtraj_create", _vp, [C.c_size_t, C.c_size_t]),
@@ -146,10 +147,10 @@ SIGNATURES = [
     ("vmd_hip_rdf_brute", C.c_int, [_vp, _vp, C.c_size_t, C.c_size_t, _vp, C.c_uint32, C.c_int, _vp, C.c_int, _vp, C.c_int,
                                     C.c_float, C.c_float, C.c_int, _vp]),
     ("vmd_hip_sdf_align", C.c_int, [_vp, _vp, C.c_size_t, C.c_size_t, _vp, C.c_uint32, C.c_int, _vp, _vp, C.c_int, C.c_int, _vp,
-                                    _vp, _vp, _vp]),
+                                    _vp, _vp, _vp, _vp]),
     ("vmd_hip_sdf_ref_pose", C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_uint32, _vp, _vp, C.c_int, _vp]),
     ("vmd_hip_sdf_scatter", C.c_int, [_vp, _vp, C.c_size_t, C.c_size_t, _vp, C.c_uint32, C.c_int, _vp, C.c_int, C.c_int, _vp, _vp,
-                                      _vp, _vp, C.c_int, C.c_float, C.c_int, _vp]),
+                                      _vp, _vp, C.c_int, C.c_float, C.c_int, _vp, _vp, _vp]),
     ("vmd_hip_distance", C.c_int, [_vp, _vp, C.c_size_t, C.c_size_t, _vp, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int,
                                    _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     ("vmd_hip_counts_to_float", C.c_int, [_vp, _vp, C.c_size_t, _vp, _vp]),

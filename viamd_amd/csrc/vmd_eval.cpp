@@ -54,6 +54,7 @@ struct Options {
     std::atomic<int> force_brute{0};
     std::atomic<int> nxf_divisor{8};     // fine x cell = rmax / nxf_divisor
     std::atomic<int> cells_aos{1};       // sort through 16-byte records + repack
+    std::atomic<int> sdf_dense{0};       // dense-target SDF scatter (stream whole frames, select by tag): measured slower, off
 };
 static Options g_opt;
 
@@ -64,6 +65,7 @@ extern "C" int vmd_set_option(const char* key, int value) {
     else if (!strcmp(key, "force_brute")) o = &g_opt.force_brute;
     else if (!strcmp(key, "nxf_divisor")) o = &g_opt.nxf_divisor;
     else if (!strcmp(key, "cells_aos")) o = &g_opt.cells_aos;
+    else if (!strcmp(key, "sdf_dense")) o = &g_opt.sdf_dense;
     else if (!strcmp(key, "cells_fused")) return vmd_hip_set_cells_fused(value);
     else if (!strcmp(key, "rdf_blocks")) return vmd_hip_set_rdf_blocks(value);
     if (!o) return -1;
@@ -319,9 +321,12 @@ struct PropState {
     DevBuf<int32_t> d_structs, d_tgt;
     DevBuf<int8_t> d_owner;
     bool have_owner = false;
+    DevBuf<uint8_t> d_tag;              // dense-target path: one tag per atom
+    bool have_tag = false;
+    size_t tag_len = 0;
     DevBuf<float> d_mass;
     DevBuf<double> d_ref_pose;
-    DevBuf<float> d_R32, d_c32;
+    DevBuf<float> d_R32, d_c32, d_group;
     bool ref_pose_ready = false;
     // DIST
     DevBuf<int32_t> d_a, d_b, d_aoff, d_boff;
@@ -330,6 +335,7 @@ struct PropState {
     bool pinned = false;
     ~PropState() { if (pinned) { (void)hipHostUnregister(values.data()); (void)hipHostUnregister(counts.data()); } }
     bool dirty = false;                 // device accumulators changed since the last host refresh
+    bool counts_stale = false;          // volume: host u64 mirror older than the device accumulators
 };
 
 // one pending vmd_eval_frame_range call (lives on the caller's stack)
@@ -501,6 +507,7 @@ extern "C" void vmd_eval_clear_data(vmd_script_eval_t* eval) {
         p->data.max_value = 0.0f; p->data.min_value = 0.0f;
         p->data.max_range[1] = 0.0f;
         p->dirty = false;
+        p->counts_stale = false;
         p->data.fingerprint += 1;
     }
     (void)hipStreamSynchronize(eval->stream);
@@ -541,7 +548,9 @@ static bool refresh_volume(vmd_script_eval_t* e, PropState* p) {
     KRN_OK(vmd_hip_counts_to_float(e->stream, p->d_counts.p, p->ncounts, p->d_values.p, p->d_max.p));
     float vmax = 0.0f;
     HIP_OK(hipMemcpyAsync(p->values.data(), p->d_values.p, p->ncounts * sizeof(float), hipMemcpyDeviceToHost, e->stream));
-    HIP_OK(hipMemcpyAsync(p->counts.data(), p->d_counts.p, p->ncounts * sizeof(uint64_t), hipMemcpyDeviceToHost, e->stream));
+    // the 17 MB u64 mirror behind `counts` is an extension VIAMD never reads: it is synchronised on demand
+    // (vmd_eval_refresh_counts), only the float view travels after every range
+    p->counts_stale = true;
     HIP_OK(hipMemcpyAsync(&vmax, p->d_max.p, sizeof(float), hipMemcpyDeviceToHost, e->stream));
     HIP_OK(hipStreamSynchronize(e->stream));
     p->data.min_value = 0.0f; p->data.max_value = vmax;
@@ -588,6 +597,18 @@ extern "C" bool vmd_eval_finalize(vmd_script_eval_t* eval) {
         else refresh_temporal_stats(eval, p.get());
         if (!ok) return false;
     }
+    return true;
+}
+
+extern "C" bool vmd_eval_refresh_counts(vmd_script_eval_t* eval, const char* name) {
+    PropState* p = find_prop(eval, name);
+    if (!p) return vmd_fail("vmd_eval_refresh_counts: no property '%s'", name ? name : "(null)");
+    std::lock_guard<std::mutex> l(eval->mtx);
+    if (!p->counts_stale || !p->ncounts) return true;
+    HIP_OK(hipSetDevice(eval->device));
+    HIP_OK(hipMemcpyAsync(p->counts.data(), p->d_counts.p, p->ncounts * sizeof(uint64_t), hipMemcpyDeviceToHost, eval->stream));
+    HIP_OK(hipStreamSynchronize(eval->stream));
+    p->counts_stale = false;
     return true;
 }
 
@@ -657,6 +678,16 @@ static bool upload_static(vmd_script_eval_t* e, const vmd_system_t* sys) {
             }
             p->have_owner = unique;
             if (unique && !p->d_owner.upload(owner.data(), owner.size(), e->stream)) return false;
+            // dense targets: stream whole frames and select by a per-atom tag instead of gathering through the index list
+            const size_t natoms = sys ? sys->atom_count : 0;
+            p->have_tag = unique && d.K <= 253 && natoms > 0 && d.b.size() * 8 >= natoms && g_opt.sdf_dense != 0;
+            if (p->have_tag) {
+                p->tag_len = (natoms + 63) & ~(size_t)63;
+                std::vector<uint8_t> tag(p->tag_len, (uint8_t)255);
+                for (size_t t = 0; t < d.b.size(); ++t) tag[d.b[t]] = owner[t] < 0 ? (uint8_t)254 : (uint8_t)owner[t];
+                if (!p->d_tag.upload(tag.data(), tag.size(), e->stream)) return false;
+                HIP_OK(hipStreamSynchronize(e->stream));
+            }
             HIP_OK(hipStreamSynchronize(e->stream));
         } else if (d.kind == PROP_DIST) {
             if (!p->d_a.upload(d.a.data(), d.a.size(), e->stream)) return false;
@@ -922,15 +953,16 @@ static bool process_range(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
                 }
                 p->dirty = true;
             } else if (d.kind == PROP_SDF) {
-                if (!p->d_R32.ensure(nb * d.K * 9) || !p->d_c32.ensure(nb * d.K * 3)) return false;
+                if (!p->d_R32.ensure(nb * d.K * 9) || !p->d_c32.ensure(nb * d.K * 3) || !p->d_group.ensure(nb * 4)) return false;
                 e->prof.begin("sdf_align", e->stream);
                 KRN_OK(vmd_hip_sdf_align(e->stream, src.base, src.frame_stride, src.row_stride, src.d_boxes.p, pbc, (int)nb,
-                                         p->d_structs.p, p->d_mass.p, (int)d.K, (int)d.m, p->d_ref_pose.p, p->d_R32.p, p->d_c32.p, nullptr));
+                                         p->d_structs.p, p->d_mass.p, (int)d.K, (int)d.m, p->d_ref_pose.p, p->d_R32.p, p->d_c32.p, nullptr, p->d_group.p));
                 e->prof.end(e->stream);
                 e->prof.begin("sdf_scatter", e->stream);
                 KRN_OK(vmd_hip_sdf_scatter(e->stream, src.base, src.frame_stride, src.row_stride, src.d_boxes.p, pbc, (int)nb,
                                            p->d_structs.p, (int)d.K, (int)d.m, p->d_R32.p, p->d_c32.p, p->d_tgt.p, p->have_owner ? p->d_owner.p : nullptr, (int)d.b.size(),
-                                           d.rmax, VMD_VOLUME_DIM, p->d_counts.p));
+                                           d.rmax, VMD_VOLUME_DIM, p->d_counts.p, p->d_group.p,
+                                           (p->have_tag && p->tag_len == src.row_stride) ? p->d_tag.p : nullptr));
                 e->prof.end(e->stream);
                 p->dirty = true;
             } else {
@@ -1045,7 +1077,7 @@ extern "C" bool vmd_eval_sdf_matrices(vmd_script_eval_t* eval, const char* name,
     DevBuf<double> dM;
     if (!dM.ensure(K * 12) || !p->d_R32.ensure(K * 9) || !p->d_c32.ensure(K * 3)) return false;
     KRN_OK(vmd_hip_sdf_align(e->stream, src.base, src.frame_stride, src.row_stride, e->stages[0].d_boxes.p, batch_pbc(e->stages[0]), 1,
-                             p->d_structs.p, p->d_mass.p, (int)K, (int)p->prop.m, p->d_ref_pose.p, p->d_R32.p, p->d_c32.p, dM.p));
+                             p->d_structs.p, p->d_mass.p, (int)K, (int)p->prop.m, p->d_ref_pose.p, p->d_R32.p, p->d_c32.p, dM.p, nullptr));
     std::vector<double> M(K * 12);
     HIP_OK(hipMemcpyAsync(M.data(), dM.p, K * 12 * sizeof(double), hipMemcpyDeviceToHost, e->stream));
     HIP_OK(hipStreamSynchronize(e->stream));

@@ -908,6 +908,26 @@ __global__ __launch_bounds__(64) void k_sdf_ref_pose(const float* xyz, size_t ro
     }
 }
 
+// Per frame: C = COM of structure 0 and R = max_k |mi(c_k - C)| (padded).  An atom farther than r + R from C is farther than r
+// from every c_k (triangle inequality of the minimum-image metric), so the scatter can drop it with ONE test instead of K.
+__global__ __launch_bounds__(64) void k_sdf_group(const float* __restrict__ c32, const float* __restrict__ boxes, uint32_t pbc,
+                                                  int B, int K, float* __restrict__ group) {
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= B) return;
+    const vmd_box_t bx = vmd_load_box(boxes, b, pbc);
+    const float* c0 = c32 + (size_t)b * K * 3;
+    float r2max = 0.0f;
+    for (int k = 1; k < K; ++k) {
+        const float* c = c0 + 3 * k;
+        float dx = c[0] - c0[0], dy = c[1] - c0[1], dz = c[2] - c0[2];
+        vmd_mi3_rintf(bx, dx, dy, dz);
+        r2max = fmaxf(r2max, vmd_d2(dx, dy, dz));
+    }
+    float* g = group + 4 * (size_t)b;
+    g[0] = c0[0]; g[1] = c0[1]; g[2] = c0[2];
+    g[3] = sqrtf(r2max) * 1.0005f + 1.0e-2f;
+}
+
 // ------------------------------------------------------------------------------------------------ K4: SDF scatter
 
 struct vmd_scatter_params_t {
@@ -917,47 +937,113 @@ struct vmd_scatter_params_t {
     const float* __restrict__ R32; const float* __restrict__ c32;
     const int32_t* __restrict__ tgt; const int8_t* __restrict__ owner; int ntgt; float extent; int dim;
     unsigned long long* volume;
+    const float* __restrict__ group;   // f32[B][4] from k_sdf_group, or NULL
 };
 
-__global__ __launch_bounds__(256) void k_sdf_scatter(vmd_scatter_params_t p) {
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    const int b = blockIdx.y;
-    if (t >= p.ntgt) return;
-    const int i = p.tgt ? p.tgt[t] : t;
-    const float* fx = p.xyz + (size_t)b * p.frame_stride;
-    const float x = fx[i], y = fx[p.row_stride + i], z = fx[2 * p.row_stride + i];
-    const vmd_box_t bx = vmd_load_box(p.boxes, b, p.pbc);
+// one target atom against structure k of frame b (SPEC S5 scatter).  own_k: structure the atom belongs to (-1 none,
+// -2 unknown: search the index list)
+__device__ __forceinline__ void vmd_sdf_atom_k(const vmd_scatter_params_t& p, const vmd_box_t& bx, int b, int k, float x, float y, float z,
+                                               int own_k, int i) {
+    // SPEC D-SDF-EXCL: a target atom is skipped for the structure it belongs to
+    if (own_k == k) return;
+    if (own_k == -2) {
+        const int32_t* sidx = p.structs + (size_t)k * p.m;
+        bool own = false;
+        for (int a = 0; a < p.m; ++a) own = own || (sidx[a] == i);
+        if (own) return;
+    }
     const float s = p.extent;
+    const float* R = p.R32 + ((size_t)b * p.K + k) * 9;
+    const float* c = p.c32 + ((size_t)b * p.K + k) * 3;
+    float dx = x - c[0], dy = y - c[1], dz = z - c[2];
+    vmd_mi3_rintf(bx, dx, dy, dz);
+    const float qx = fmaf(R[2], dz, fmaf(R[1], dy, R[0] * dx));
+    const float qy = fmaf(R[5], dz, fmaf(R[4], dy, R[3] * dx));
+    const float qz = fmaf(R[8], dz, fmaf(R[7], dy, R[6] * dx));
     const float vscale = (float)p.dim / (2.0f * s);
     const float fdim = (float)p.dim;
-    const float r2_skip = 3.0f * s * s * 1.001f + 1.0e-3f;
-    // SPEC D-SDF-EXCL: a target atom is skipped for the structure it belongs to.  owner[t] (structure index or -1) is
-    // precomputed on the host for K <= 127; without it the membership test walks the structure's index list.
-    const int own_k = p.owner ? (int)p.owner[t] : -2;
-    for (int k = 0; k < p.K; ++k) {
-        if (own_k == k) continue;
-        if (own_k == -2) {
-            const int32_t* sidx = p.structs + (size_t)k * p.m;
-            bool own = false;
-            for (int a = 0; a < p.m; ++a) own = own || (sidx[a] == i);
-            if (own) continue;
+    const float tx = (qx + s) * vscale;
+    const float ty = (qy + s) * vscale;
+    const float tz = (qz + s) * vscale;
+    if (tx >= 0.0f && tx < fdim && ty >= 0.0f && ty < fdim && tz >= 0.0f && tz < fdim) {
+        const int vx = (int)tx, vy = (int)ty, vz = (int)tz;
+        atomicAdd(&p.volume[((size_t)vz * p.dim + vy) * p.dim + vx], 1ull);
+    }
+}
+
+// group pre-filter (k_sdf_group): can this atom reach ANY structure's cube?  A voxel hit needs |q|_inf < s, hence
+// |d| = |q| < sqrt(3) s; with the group sphere (centre g, radius g[3]) one distance test replaces K.
+__device__ __forceinline__ bool vmd_sdf_near(const vmd_scatter_params_t& p, const vmd_box_t& bx, int b, float x, float y, float z) {
+    if (!p.group) return true;
+    const float* g = p.group + 4 * (size_t)b;
+    float dx = x - g[0], dy = y - g[1], dz = z - g[2];
+    vmd_mi3_rintf(bx, dx, dy, dz);
+    const float reach = (1.7320508f * p.extent * 1.0005f + 1.0e-3f) + g[3];
+    return vmd_d2(dx, dy, dz) <= reach * reach;
+}
+
+// Target atoms come in index order, i.e. spatially random: nearly every wave holds a few atoms near the structures, so
+// running the K transforms under the divergent mask would cost every wave the full loop at ~5 % lane use.  Instead a block
+// first compacts the atoms that pass the group test into LDS (1024 candidates per block, all gathers in flight at once),
+// then spreads the (atom, structure) pairs evenly over its threads.
+#define VMD_SDF_ILP 4
+__global__ __launch_bounds__(256) void k_sdf_scatter(vmd_scatter_params_t p) {
+    __shared__ float s_x[256 * VMD_SDF_ILP], s_y[256 * VMD_SDF_ILP], s_z[256 * VMD_SDF_ILP];
+    __shared__ int s_own[256 * VMD_SDF_ILP], s_idx[256 * VMD_SDF_ILP];
+    __shared__ unsigned s_n;
+    const int t0 = blockIdx.x * (256 * VMD_SDF_ILP) + threadIdx.x;
+    const int b = blockIdx.y;
+    const vmd_box_t bx = vmd_load_box(p.boxes, b, p.pbc);
+    const float* fx = p.xyz + (size_t)b * p.frame_stride;
+    if (threadIdx.x == 0) s_n = 0u;
+    int idx[VMD_SDF_ILP], own[VMD_SDF_ILP];
+    float x[VMD_SDF_ILP], y[VMD_SDF_ILP], z[VMD_SDF_ILP];
+#pragma unroll
+    for (int u = 0; u < VMD_SDF_ILP; ++u) {
+        const int t = t0 + 256 * u;
+        idx[u] = -1; own[u] = -2;
+        if (t < p.ntgt) { idx[u] = p.tgt ? p.tgt[t] : t; own[u] = p.owner ? (int)p.owner[t] : -2; }
+    }
+#pragma unroll
+    for (int u = 0; u < VMD_SDF_ILP; ++u) {
+        x[u] = y[u] = z[u] = 0.0f;
+        if (idx[u] >= 0) { x[u] = fx[idx[u]]; y[u] = fx[p.row_stride + idx[u]]; z[u] = fx[2 * p.row_stride + idx[u]]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < VMD_SDF_ILP; ++u) {
+        if (idx[u] >= 0 && vmd_sdf_near(p, bx, b, x[u], y[u], z[u])) {
+            const unsigned slot = atomicAdd(&s_n, 1u);
+            s_x[slot] = x[u]; s_y[slot] = y[u]; s_z[slot] = z[u]; s_own[slot] = own[u]; s_idx[slot] = idx[u];
         }
-        const float* R = p.R32 + ((size_t)b * p.K + k) * 9;
-        const float* c = p.c32 + ((size_t)b * p.K + k) * 3;
-        float dx = x - c[0], dy = y - c[1], dz = z - c[2];
-        vmd_mi3_rintf(bx, dx, dy, dz);
-        // a voxel hit needs |q|_inf < s, hence |d|^2 = |q|^2 < 3 s^2: skip the rotation for everything outside that sphere
-        if (vmd_d2(dx, dy, dz) > r2_skip) continue;
-        const float qx = fmaf(R[2], dz, fmaf(R[1], dy, R[0] * dx));
-        const float qy = fmaf(R[5], dz, fmaf(R[4], dy, R[3] * dx));
-        const float qz = fmaf(R[8], dz, fmaf(R[7], dy, R[6] * dx));
-        const float tx = (qx + s) * vscale;
-        const float ty = (qy + s) * vscale;
-        const float tz = (qz + s) * vscale;
-        if (tx >= 0.0f && tx < fdim && ty >= 0.0f && ty < fdim && tz >= 0.0f && tz < fdim) {
-            const int vx = (int)tx, vy = (int)ty, vz = (int)tz;
-            atomicAdd(&p.volume[((size_t)vz * p.dim + vy) * p.dim + vx], 1ull);
-        }
+    }
+    __syncthreads();
+    const int nwork = (int)s_n * p.K;
+    for (int w = threadIdx.x; w < nwork; w += 256) {
+        const int a = w / p.K, k = w - a * p.K;
+        vmd_sdf_atom_k(p, bx, b, k, s_x[a], s_y[a], s_z[a], s_own[a], s_idx[a]);
+    }
+}
+
+// dense targets (a sizeable fraction of all atoms, e.g. every water oxygen): stream the WHOLE frame with 16-byte loads per
+// lane and pick the targets by a per-atom tag byte (255 = not a target, 254 = target, k <= 253 = target owned by structure k)
+// instead of gathering 4 bytes per lane through an index list.  Same arithmetic, same result.
+__global__ __launch_bounds__(256) void k_sdf_scatter_dense(vmd_scatter_params_t p, const uint8_t* __restrict__ tag, int natoms4) {
+    const int t4 = blockIdx.x * 256 + threadIdx.x;       // group of 4 consecutive atoms
+    const int b = blockIdx.y;
+    if (t4 >= natoms4) return;
+    const uint32_t tg = ((const uint32_t*)tag)[t4];
+    if (tg == 0xffffffffu) return;
+    const vmd_box_t bx = vmd_load_box(p.boxes, b, p.pbc);
+    const float* fx = p.xyz + (size_t)b * p.frame_stride;
+    const vmd_f4a x4 = *(const vmd_f4a*)(fx + 4 * (size_t)t4);
+    const vmd_f4a y4 = *(const vmd_f4a*)(fx + p.row_stride + 4 * (size_t)t4);
+    const vmd_f4a z4 = *(const vmd_f4a*)(fx + 2 * p.row_stride + 4 * (size_t)t4);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int tu = (int)((tg >> (8 * u)) & 255u);
+        if (tu == 255 || !vmd_sdf_near(p, bx, b, x4[u], y4[u], z4[u])) continue;
+        for (int k = 0; k < p.K; ++k) vmd_sdf_atom_k(p, bx, b, k, x4[u], y4[u], z4[u], tu == 254 ? -1 : tu, 4 * t4 + u);
     }
 }
 
@@ -1212,12 +1298,16 @@ extern "C" int vmd_hip_rdf_brute(void* stream, const float* xyz, size_t frame_st
 extern "C" int vmd_hip_sdf_align(void* stream, const float* xyz, size_t frame_stride, size_t row_stride,
                                  const float* boxes, uint32_t pbc_flags, int B,
                                  const int32_t* structs, const float* mass, int K, int m, const double* ref_pose,
-                                 float* R32, float* c32, double* M64) {
+                                 float* R32, float* c32, double* M64, float* group) {
     hipStream_t s = (hipStream_t)stream;
     if (B <= 0 || K <= 0 || m <= 0) return 0;
     vmd_align_params_t p{xyz, frame_stride, row_stride, boxes, pbc_flags, B, structs, mass, K, m, ref_pose, R32, c32, M64};
     hipLaunchKernelGGL(k_sdf_align, dim3((B * K + 63) / 64), dim3(64), 0, s, p);
     VMD_LAUNCH_CHECK();
+    if (group) {
+        hipLaunchKernelGGL(k_sdf_group, dim3((B + 63) / 64), dim3(64), 0, s, (const float*)c32, boxes, pbc_flags, B, K, group);
+        VMD_LAUNCH_CHECK();
+    }
     return 0;
 }
 
@@ -1232,12 +1322,19 @@ extern "C" int vmd_hip_sdf_ref_pose(void* stream, const float* xyz, size_t row_s
 extern "C" int vmd_hip_sdf_scatter(void* stream, const float* xyz, size_t frame_stride, size_t row_stride,
                                    const float* boxes, uint32_t pbc_flags, int B,
                                    const int32_t* structs, int K, int m, const float* R32, const float* c32,
-                                   const int32_t* tgt, const int8_t* owner, int ntgt, float extent, int dim, uint64_t* volume) {
+                                   const int32_t* tgt, const int8_t* owner, int ntgt, float extent, int dim, uint64_t* volume,
+                                   const float* group, const uint8_t* atom_tag) {
     hipStream_t s = (hipStream_t)stream;
     if (B <= 0 || K <= 0 || ntgt <= 0) return 0;
     vmd_scatter_params_t p{xyz, frame_stride, row_stride, boxes, pbc_flags, B, structs, K, m, R32, c32, tgt, owner, ntgt, extent, dim,
-                           (unsigned long long*)volume};
-    hipLaunchKernelGGL(k_sdf_scatter, dim3((ntgt + 255) / 256, B), dim3(256), 0, s, p);
+                           (unsigned long long*)volume, group};
+    if (atom_tag) {
+        const int natoms4 = (int)(row_stride / 4);       // rows are padded to a multiple of 64 floats; the tag array covers the padding
+        hipLaunchKernelGGL(k_sdf_scatter_dense, dim3((natoms4 + 255) / 256, B), dim3(256), 0, s, p, atom_tag, natoms4);
+        VMD_LAUNCH_CHECK();
+        return 0;
+    }
+    hipLaunchKernelGGL(k_sdf_scatter, dim3((ntgt + 256 * VMD_SDF_ILP - 1) / (256 * VMD_SDF_ILP), B), dim3(256), 0, s, p);
     VMD_LAUNCH_CHECK();
     return 0;
 }

@@ -122,8 +122,9 @@ class ScriptIR:
 class PropertyDataView:
     """Zero-copy numpy views of one md_script_property_data_t."""
 
-    def __init__(self, c):
+    def __init__(self, c, ev=None, name=None):
         self.c = c  # ctypes PropertyData (owned by the eval)
+        self._ev, self._name = ev, name
 
     @property
     def dim(self):
@@ -150,6 +151,8 @@ class PropertyDataView:
     def counts(self):
         if not self.c.counts:
             return None
+        if self._ev is not None and not self._ev.lib.vmd_eval_refresh_counts(self._ev.h, self._name.encode()):
+            raise VmdError(self._ev.lib.last_error())
         n = self.c.dim[2] if self.c.weights else self.c.dim[1] * self.c.dim[2] * self.c.dim[3]
         return self._arr(self.c.counts, n, np.uint64)
 
@@ -232,7 +235,7 @@ class ScriptEval:
         p = self.lib.vmd_eval_property_data(self.h, name.encode())
         if not p:
             return None
-        return PropertyDataView(p.contents)
+        return PropertyDataView(p.contents, self, name)
 
     def num_frames(self):
         return int(self.lib.vmd_eval_num_frames(self.h))
