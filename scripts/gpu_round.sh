@@ -32,3 +32,6 @@ find $OUT/prof_c2 -name "*kernel_trace.csv" -size +20M -delete
 echo "== PMC"
 bash $R/scripts/gpu_pmc.sh ${TAG}_pmc > $OUT/pmc.log 2>&1
 python $R/scripts/pmc_traffic.py $R/gpurun_out/${TAG}_pmc c2 500 $OUT/pmc_traffic.json
+echo "== PMC (c4: SDF scatter)"
+bash $R/scripts/gpu_pmc.sh ${TAG}_pmc_c4 --workload c4 > $OUT/pmc_c4.log 2>&1
+python $R/scripts/pmc_traffic.py $R/gpurun_out/${TAG}_pmc_c4 c4 500 $OUT/pmc_traffic.json | tail -3

@@ -22,6 +22,7 @@
 #define HIP_DYNAMIC_SHARED(type, var) type* var = (type*)emu::dyn_shared();
 #define hipFuncAttributeMaxDynamicSharedMemorySize 8
 #define VMD_UNIFORM_AS
+#define VMD_SGPR_CAP(n)
 #define VMD_NO_INLINE_ASM
 
 struct dim3 {

@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libviamd_amd.so")
+# VIAMD_AMD_LIB selects another build of the same library (A/B builds, out-of-tree installs); never a CPU substitute.
+LIB_PATH = os.environ.get("VIAMD_AMD_LIB") or os.path.join(_HERE, "libviamd_amd.so")
 
 PBC_ALL = 7
 FLAG_TEMPORAL, FLAG_DISTRIBUTION, FLAG_VOLUME = 1, 2, 4

@@ -31,6 +31,9 @@
 // Wave-uniform read-only data (j coordinates, cell offsets, boxes) is read through the constant address space so
 // that hipcc emits s_load (scalar cache, SGPR operands) instead of per-lane global_load.  Legal because those
 // arrays are only written by earlier kernels.  (The SIMT emulator under tests/emu defines this to nothing.)
+#ifndef VMD_SGPR_CAP
+#define VMD_SGPR_CAP(n) __attribute__((amdgpu_num_sgpr(n)))
+#endif
 #ifndef VMD_UNIFORM_AS
 #define VMD_UNIFORM_AS __attribute__((address_space(4)))
 #endif
@@ -573,8 +576,10 @@ __device__ __forceinline__ int vmd_next_item(unsigned* counters, int& q, int& tr
     return -1;
 }
 
+// SGPR cap: the kernel wants 106 SGPRs (6 waves/SIMD); at 96 a 7th wave fits and the extra spills land in the outer
+// (per work item / per segment) loops.  Measured +1.7 % on c2 (profiles/r01s_ab.txt); a cap of 80 (8 waves) gives it back.
 template <int VARIANT, bool SAME>
-__global__ __launch_bounds__(256) void k_rdf_pencil(vmd_pair_params_t p) {
+__global__ __launch_bounds__(256) VMD_SGPR_CAP(96) void k_rdf_pencil(vmd_pair_params_t p) {
     __shared__ unsigned s_hist[4][VMD_MAX_BINS];
     __shared__ float s_queue[4][VMD_QUEUE_CAP];
     constexpr unsigned INC = SAME ? 2u : 1u;
