@@ -53,6 +53,7 @@ int vmd_hip_cells_build(void* stream, const float* xyz, size_t frame_stride, siz
  *   counts    u64[nbins]  accumulated (+=) with device atomics
  *   variant   0 = wave queue (default), 1 = inline hit path */
 int vmd_hip_rdf_num_blocks(void);
+int vmd_hip_set_rdf_nsub(int n);       /* tuning knob: work items per pencil (1..64, 0 = automatic), returns the previous value */
 int vmd_hip_set_rdf_blocks(int n);     /* tuning knob: persistent grid size (8..2048), returns the previous value */
 size_t vmd_hip_rdf_partial_words(void);
 int vmd_hip_rdf_pencil(void* stream, const float* sorted_ref, const uint32_t* cell_start_ref, int nref, int nref_pad,

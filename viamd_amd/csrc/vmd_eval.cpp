@@ -68,6 +68,7 @@ extern "C" int vmd_set_option(const char* key, int value) {
     else if (!strcmp(key, "sdf_dense")) o = &g_opt.sdf_dense;
     else if (!strcmp(key, "cells_fused")) return vmd_hip_set_cells_fused(value);
     else if (!strcmp(key, "rdf_blocks")) return vmd_hip_set_rdf_blocks(value);
+    else if (!strcmp(key, "rdf_nsub")) return vmd_hip_set_rdf_nsub(value);
     if (!o) return -1;
     return o->exchange(value);
 }

@@ -378,8 +378,10 @@ struct vmd_pair_params_t {
     float rpad;         // conservative range padding (> rmax)
     uint64_t* partial;  // [gridDim.x][nbins]: one row per block, written once at the end
     unsigned long long* counts;  // the accumulators: target of the (rare) overflow flush
-    unsigned* work_counter;  // [8], zeroed before launch: one dynamic work queue per XCD (frames f = q mod 8)
+    unsigned* work_counter;  // [8 * VMD_COUNTER_STRIDE], zeroed before launch: one dynamic work queue per XCD (frames f = q mod 8)
+    int nsub;                // work items per pencil (i-chunks are dealt round-robin to the items)
 };
+#define VMD_COUNTER_STRIDE 32    // one 128-byte line per queue counter
 
 // per-wave state of the hit machinery
 struct vmd_wave_acc_t {
@@ -558,17 +560,19 @@ __device__ __forceinline__ void vmd_segment(const vmd_pair_params_t& p, vmd_wave
         vmd_segment_loop<VARIANT, INC, MASKED, true>(p, w, tx, ty, tz, ja, jb, sx, sy, sz, xi, yi, zi, i, lane);
 }
 
-// Work distribution: the (frame, pencil) items are split into 8 queues by frame index modulo 8.  A wave first drains the
-// queue of its "home" XCD (blockIdx % 8 — the observed block->XCD placement; affinity only, never correctness) so that all
-// pencils of one frame are pulled through ONE XCD's L2, then steals from the other queues.  Returns the global item id
-// (b * npen + pen) or -1 when every queue is empty.  Called by lane 0 only.
-__device__ __forceinline__ int vmd_next_item(unsigned* counters, int& q, int& tries, int B, int npen) {
+// Work distribution: an item is (frame, pencil, sub): the i-chunks sub, sub + nsub, ... of one pencil.  Items are split into
+// 8 queues by frame index modulo 8.  A wave first drains the queue of its "home" XCD (blockIdx % 8 — the observed block->XCD
+// placement; affinity only, never correctness) so that all pencils of one frame are pulled through ONE XCD's L2, then steals
+// from the other queues.  Splitting pencils (nsub > 1) shrinks the number of frames an XCD has in flight (waves / (npen *
+// nsub)) so the j streams of the running items stay inside its 4 MiB L2.  Returns the global item id
+// ((b * npen + pen) * nsub + sub) or -1 when every queue is empty.  Called by lane 0 only.
+__device__ __forceinline__ int vmd_next_item(unsigned* counters, int& q, int& tries, int B, int nitem_frame) {
     while (tries < 8) {
         const int nframes_q = (B - q + 7) >> 3;                 // frames q, q+8, ... < B
-        const unsigned t = atomicAdd(&counters[q], 1u);
-        if (nframes_q > 0 && t < (unsigned)(nframes_q * npen)) {
-            const int fq = (int)t / npen;
-            return (q + 8 * fq) * npen + ((int)t - fq * npen);
+        const unsigned t = atomicAdd(&counters[q * VMD_COUNTER_STRIDE], 1u);
+        if (nframes_q > 0 && t < (unsigned)(nframes_q * nitem_frame)) {
+            const int fq = (int)t / nitem_frame;
+            return (q + 8 * fq) * nitem_frame + ((int)t - fq * nitem_frame);
         }
         q = (q + 1) & 7;
         tries += 1;
@@ -604,12 +608,16 @@ __global__ __launch_bounds__(256) VMD_SGPR_CAP(96) void k_rdf_pencil(vmd_pair_pa
     // work items are handed out dynamically (one returning atomic per item, fetched one item ahead)
     int q = blockIdx.x & 7, tries = 0;
     int item = -1, next_item = -1;
-    if (lane == 0) item = vmd_next_item(p.work_counter, q, tries, p.B, npen);
+    const int nsub = p.nsub;
+    const int nitem_frame = npen * nsub;
+    if (lane == 0) item = vmd_next_item(p.work_counter, q, tries, p.B, nitem_frame);
     item = __builtin_amdgcn_readfirstlane(item);
     for (; item >= 0; item = next_item) {
-        if (lane == 0) next_item = vmd_next_item(p.work_counter, q, tries, p.B, npen);
-        const int b = item / npen;
-        const int pen = item - b * npen;
+        if (lane == 0) next_item = vmd_next_item(p.work_counter, q, tries, p.B, nitem_frame);
+        const int b = item / nitem_frame;
+        const int rem = item - b * nitem_frame;
+        const int pen = rem / nsub;
+        const int sub = rem - pen * nsub;
         const int pz = pen / ny;
         const int py = pen - pz * ny;
         vmd_cf32* boxes = (vmd_cf32*)p.boxes;
@@ -622,7 +630,7 @@ __global__ __launch_bounds__(256) VMD_SGPR_CAP(96) void k_rdf_pencil(vmd_pair_pa
         const unsigned pbeg = csr[pen * nxf];
         const unsigned pend = csr[(pen + 1) * nxf];
 
-        for (unsigned cbeg = pbeg; cbeg < pend; cbeg += VMD_WAVE) {
+        for (unsigned cbeg = pbeg + (unsigned)sub * VMD_WAVE; cbeg < pend; cbeg += (unsigned)nsub * VMD_WAVE) {
             const unsigned i = cbeg + lane;
             const bool valid = i < pend;
             const float xi = valid ? sr[i] : VMD_FAR;
@@ -1240,10 +1248,14 @@ extern "C" int vmd_hip_cells_build(void* stream, const float* xyz, size_t frame_
     return 0;
 }
 
+static int g_rdf_nsub = 0;   // 0 = automatic: about one i-chunk per item
+extern "C" int vmd_hip_set_rdf_nsub(int n) { const int old = g_rdf_nsub; if (n >= 0 && n <= 64) g_rdf_nsub = n; return old; }
 static int g_rdf_blocks = 2048;   // 8 blocks x 4 waves per CU requested; 6 fit (SGPR budget)
 extern "C" int vmd_hip_rdf_num_blocks(void) { return 2048; }   // capacity of the partial-row scratch
 extern "C" int vmd_hip_set_rdf_blocks(int n) { const int old = g_rdf_blocks; if (n >= 8 && n <= 2048) g_rdf_blocks = n; return old; }
-extern "C" size_t vmd_hip_rdf_partial_words(void) { return (size_t)vmd_hip_rdf_num_blocks() * VMD_MAX_BINS + 4; }
+extern "C" size_t vmd_hip_rdf_partial_words(void) {
+    return (size_t)vmd_hip_rdf_num_blocks() * VMD_MAX_BINS + 8 * VMD_COUNTER_STRIDE * sizeof(unsigned) / sizeof(uint64_t);
+}
 
 extern "C" int vmd_hip_rdf_pencil(void* stream, const float* sorted_ref, const uint32_t* cell_start_ref, int nref, int nref_pad,
                                   const float* sorted_tgt, const uint32_t* cell_start_tgt, int ntgt, int ntgt_pad,
@@ -1255,7 +1267,7 @@ extern "C" int vmd_hip_rdf_pencil(void* stream, const float* sorted_ref, const u
     // the work counter lives behind the partial rows (see vmd_hip_rdf_partial_words)
     unsigned* work_counter = (unsigned*)(partial + (size_t)vmd_hip_rdf_num_blocks() * VMD_MAX_BINS);
     {
-        hipError_t e = hipMemsetAsync(work_counter, 0, 8 * sizeof(unsigned), s);
+        hipError_t e = hipMemsetAsync(work_counter, 0, 8 * VMD_COUNTER_STRIDE * sizeof(unsigned), s);
         if (e != hipSuccess) return (int)e;
     }
     vmd_pair_params_t p;
@@ -1268,7 +1280,16 @@ extern "C" int vmd_hip_rdf_pencil(void* stream, const float* sorted_ref, const u
     p.rpad = rmax * 1.0001f + 1.0e-4f;
     p.partial = partial;
     p.counts = (unsigned long long*)counts;
-    const int nitems = B * grid.ny * grid.nz;
+    // items per pencil: the mean number of 64-atom i-chunks in a pencil, so that an XCD's waves in flight cover as few frames
+    // as possible (profiles/r01t_ab.txt: c2 +11 %, c3 +8.5 % over whole-pencil items)
+    p.nsub = g_rdf_nsub;
+    if (p.nsub == 0) {
+        const long long per_chunk = (long long)grid.ny * grid.nz * VMD_WAVE;
+        p.nsub = (int)((nref + per_chunk - 1) / per_chunk);
+        if (p.nsub < 1) p.nsub = 1;
+        if (p.nsub > 64) p.nsub = 64;
+    }
+    const int nitems = B * grid.ny * grid.nz * p.nsub;
     int nblocks = (nitems + 3) / 4;
     if (nblocks < 8) nblocks = 8;
     if (nblocks > g_rdf_blocks) nblocks = g_rdf_blocks;
