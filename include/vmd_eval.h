@@ -198,6 +198,22 @@ bool   vmd_eval_finalize(vmd_script_eval_t* eval);
 /* mark frames as evaluated elsewhere (after a mask all-reduce) */
 void   vmd_eval_set_frame_mask(vmd_script_eval_t* eval, const uint8_t* mask, size_t n);
 
+/* ---- filtered evaluation (VIAMD: the "Eval Filt" task, src/main.cpp:1014-1039) ----------
+ * VIAMD answers a timeline sub-range by re-running md_script_eval_frame_range over it on a second eval object
+ * every time the range slider moves.  With frame blocks the full evaluation additionally keeps one partial
+ * accumulator per block of `block_frames` frames in HBM (distribution: 8 KB, volume: 16 MB per block); a second
+ * eval that names the first as its source then serves every whole block of a requested range with one u64 add
+ * per bin / voxel and evaluates only the ragged frames at the two ends.  Results are bit-identical to a plain
+ * evaluation of the same range (integer counts; fp64 weights to the last bits of a different summation order). */
+/* keep block partials from now on (0 = off).  Call before the first frame_range or right after clear_data.
+ * A block is stored when one frame_range call (or one merged group of concurrent calls) covers it entirely. */
+bool   vmd_eval_set_block_frames(vmd_script_eval_t* eval, size_t block_frames);
+/* let `eval` reuse the block partials of `source` (same IR fingerprint, same num_frames, same device); NULL detaches.
+ * `source` must outlive the attachment and must not be cleared while `eval` evaluates. */
+bool   vmd_eval_set_source(vmd_script_eval_t* eval, vmd_script_eval_t* source);
+/* frames evaluated by kernels / frames served from block partials since the last clear_data */
+void   vmd_eval_frame_stats(const vmd_script_eval_t* eval, size_t* frames_computed, size_t* frames_reused);
+
 /* ---- device-resident trajectories (pre-staged in HBM) ---------------------------------- */
 typedef struct vmd_devtraj_t vmd_devtraj_t;
 vmd_devtraj_t*    vmd_devtraj_create(size_t num_frames, size_t num_atoms);

@@ -97,6 +97,8 @@ int vmd_hip_distance(void* stream, const float* xyz, size_t frame_stride, size_t
                      const int32_t* a, const float* mass_a, const int32_t* aoff,
                      const int32_t* b, const float* mass_b, const int32_t* boff, float* out);
 
+/* dst[i] += src[i] (u64): merges a frame block's partial accumulator into the totals */
+int vmd_hip_add_u64(void* stream, uint64_t* dst, const uint64_t* src, size_t n);
 /* u64 counters -> f32 values (values[i] = (float)counts[i]) + max reduction into max_out[0] (device f32) */
 int vmd_hip_counts_to_float(void* stream, const uint64_t* counts, size_t n, float* values, float* max_out);
 

@@ -156,13 +156,13 @@ def sdf_system(O, seed, n_water_atoms, box, frames, K=4, m=6):
     return coords, structures, mass
 
 
-def oracle_sdf(O, coords, ocell, structures, mass, tgt, cutoff, dim=128):
+def oracle_sdf(O, coords, ocell, structures, mass, tgt, cutoff, dim=128, frames=None):
     K, m = structures.shape
     smass = mass[structures]
     ref_pose = O.sdf_ref_pose(coords[0, 0], coords[0, 1], coords[0, 2], ocell, structures[0], smass[0])
     vol = np.zeros(dim ** 3, np.uint64)
     mats = []
-    for f in range(coords.shape[0]):
+    for f in (range(coords.shape[0]) if frames is None else frames):
         M, R32, c32 = O.sdf_frame_align(coords[f, 0], coords[f, 1], coords[f, 2], ocell, structures, smass, ref_pose)
         O.sdf_frame_scatter(coords[f, 0], coords[f, 1], coords[f, 2], ocell, structures, R32, c32, tgt, cutoff, dim, vol)
         mats.append(M)
@@ -275,3 +275,79 @@ def triclinic_cases(lib, O, n_water, device=False):
     check_distances(lib, O, coords, box, mass, [("d", structures[0], structures[1], L.DIST_COM), ("m", structures[0], structures[2], L.DIST_MIN),
                                                ("x", structures[1], structures[2], L.DIST_MAX), ("p", structures[0][:2], o[:3], L.DIST_PAIR)],
                     device=device)
+
+
+def filtered_cases(lib, O, n_water, device=False):
+    """a full evaluation that keeps per-block partials, and "Eval Filt" evaluations (src/main.cpp:1014-1039)
+    that reuse them.  Every sub-range result must equal a plain evaluation of that range by the oracle, bit for bit."""
+    box, F, S = 34.0, 11, 4
+    coords, structures, mass = sdf_system(O, 23, n_water, box, F)
+    n_s, N = structures.size, coords.shape[2]
+    ocell, vcell = cell_pair(O, box)
+    ox = np.arange(n_s, N, 3, dtype=np.int32)
+    ir = V.ScriptIR(lib)
+    ir.add_rdf("g", ox, ox, (0.0, 9.0))
+    ir.add_sdf("v", structures, ox, 7.0)
+    ir.add_distance("d", structures[0], structures[1], L.DIST_MIN)
+    traj = make_traj(lib, coords, vcell, device)
+    sysm = V.MolSystem(N, mass=mass, unitcell=vcell)
+    dref = oracle_distance(O, coords, ocell, mass, structures[0], structures[1], L.DIST_MIN)
+
+    def verify(ev, frames):
+        frames = list(frames)
+        counts, weights = oracle_rdf(O, coords, ocell, ox, ox, 0.0, 9.0, frames=frames)
+        pd = ev.property_data("g")
+        np.testing.assert_array_equal(pd.counts, counts)
+        np.testing.assert_allclose(pd.weights64, weights, rtol=1e-12)
+        vol, _ = oracle_sdf(O, coords, ocell, structures, mass, ox, 7.0, frames=frames)
+        np.testing.assert_array_equal(ev.property_data("v").counts, vol)
+        assert vol.sum() > 0
+        got = ev.property_data("d").values.reshape(F, -1)
+        np.testing.assert_array_equal(got[frames], dref[frames])
+        mask = np.zeros(F, bool); mask[frames] = True
+        np.testing.assert_array_equal(ev.frame_mask().astype(bool), mask)
+
+    # full evaluation in one call: blocks [0,4) [4,8) [8,11) are all kept
+    full = V.ScriptEval(F, ir)
+    full.set_block_frames(S)
+    assert full.frame_range(sysm, traj, 0, F)
+    verify(full, range(F))
+    assert full.frame_stats() == (F, 0)
+
+    filt = V.ScriptEval(F, ir)
+    filt.set_source(full)
+    assert filt.frame_range(sysm, traj, 1, 10)            # ragged 1-3, block [4,8), ragged 8-9
+    verify(filt, range(1, 10))
+    assert filt.frame_stats() == (5, 4)
+    filt.clear_data()
+    assert filt.frame_range(sysm, traj, 0, F)             # answered entirely from the partials
+    verify(filt, range(F))
+    assert filt.frame_stats() == (0, F)
+    filt.clear_data()
+    assert filt.frame_range(sysm, traj, 5, 7)             # inside one block: plain evaluation
+    verify(filt, range(5, 7))
+    assert filt.frame_stats() == (2, 0)
+
+    # a full evaluation fed in unaligned ranges keeps only the blocks a single call covered: [0,4) and [8,11)
+    full.clear_data()
+    assert full.frame_range(sysm, traj, 6, F) and full.frame_range(sysm, traj, 0, 6)
+    verify(full, range(F))
+    filt.clear_data()
+    assert filt.frame_range(sysm, traj, 0, F)
+    verify(filt, range(F))
+    assert filt.frame_stats() == (4, 7)
+    filt.set_source(None)
+    filt.clear_data()
+    assert filt.frame_range(sysm, traj, 2, 9)
+    verify(filt, range(2, 9))
+    assert filt.frame_stats() == (7, 0)
+
+    # guard rails
+    other = V.ScriptIR(lib); other.add_rdf("g", ox, ox, (0.0, 8.0))
+    import pytest
+    with pytest.raises(V.VmdError):
+        V.ScriptEval(F, other).set_source(full)
+    with pytest.raises(V.VmdError):
+        V.ScriptEval(F, ir).set_source(V.ScriptEval(F, ir))     # source keeps no blocks
+    with pytest.raises(V.VmdError):
+        full.set_block_frames(2)                                  # not after frames were evaluated

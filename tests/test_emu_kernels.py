@@ -165,3 +165,7 @@ def test_interrupt_and_clear(emu_lib, oracle, box3k):
 
 def test_triclinic_cell_all_property_kinds(emu_lib, oracle):
     cases.triclinic_cases(emu_lib, oracle, n_water=900)
+
+
+def test_filtered_evaluation_reuses_block_partials(emu_lib, oracle):
+    cases.filtered_cases(emu_lib, oracle, 900)

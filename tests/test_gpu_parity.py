@@ -352,3 +352,36 @@ def test_synthetic_blob_system_device_equals_host_and_script_eval(gpu_lib, oracl
 
 def test_triclinic_cell_all_property_kinds(gpu_lib, oracle):
     cases.triclinic_cases(gpu_lib, oracle, n_water=9000, device=True)
+
+
+def test_filtered_evaluation_reuses_block_partials(gpu_lib, oracle):
+    cases.filtered_cases(gpu_lib, oracle, n_water=6000, device=True)
+    cases.filtered_cases(gpu_lib, oracle, n_water=3000, device=False)
+
+
+def test_filtered_evaluation_at_config2_shape(gpu_lib, oracle):
+    """Size-independent property at the bench shape: the sum over any partition of the timeline into sub-ranges, each answered
+    by a filtered eval (block partials + ragged ends), equals the full evaluation; a sub-range equals its plain evaluation."""
+    N, box, F, S = 100002, 100.0, 96, 16
+    traj = V.DeviceTrajectory(F, N)
+    traj.synth(2, box, 0.05)
+    ox = cases.oxygen(N)
+    ir = V.ScriptIR(); ir.add_rdf("g", ox, ox, 12.0)
+    sysm = V.MolSystem(N, unitcell=V.make_unitcell(box))
+    full = V.ScriptEval(F, ir); full.set_block_frames(S)
+    assert full.frame_range(sysm, traj, 0, F)
+    total = full.property_data("g").counts.copy()
+    filt = V.ScriptEval(F, ir); filt.set_source(full)
+    plain = V.ScriptEval(F, ir)
+    acc = np.zeros_like(total)
+    for beg, end in [(0, 7), (7, 50), (50, 81), (81, 96)]:
+        filt.clear_data(); plain.clear_data()
+        assert filt.frame_range(sysm, traj, beg, end) and plain.frame_range(sysm, traj, beg, end)
+        np.testing.assert_array_equal(filt.property_data("g").counts, plain.property_data("g").counts)
+        np.testing.assert_allclose(filt.property_data("g").weights64, plain.property_data("g").weights64, rtol=1e-12)
+        acc += filt.property_data("g").counts
+    np.testing.assert_array_equal(acc, total)
+    assert filt.frame_stats() == (15, 0)            # [81,96) lies inside block [80,96): plain evaluation
+    filt.clear_data()
+    assert filt.frame_range(sysm, traj, 7, 50)
+    assert filt.frame_stats() == (9 + 2, 32)       # frames 7-15 and 48-49 computed, blocks [16,32) [32,48) reused

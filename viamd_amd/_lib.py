@@ -113,6 +113,9 @@ SIGNATURES = [
     ("vmd_eval_refresh_counts", C.c_bool, [_vp, C.c_char_p]),
     ("vmd_eval_finalize", C.c_bool, [_vp]),
     ("vmd_eval_set_frame_mask", None, [_vp, c_uint8_p, C.c_size_t]),
+    ("vmd_eval_set_block_frames", C.c_bool, [_vp, C.c_size_t]),
+    ("vmd_eval_set_source", C.c_bool, [_vp, _vp]),
+    ("vmd_eval_frame_stats", None, [_vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     ("vmd_devtraj_create", _vp, [C.c_size_t, C.c_size_t]),
     ("vmd_devtraj_free", None, [_vp]),
     ("vmd_devtraj_interface", C.POINTER(TrajectoryI), [_vp]),
@@ -155,6 +158,7 @@ SIGNATURES = [
                                       _vp, _vp, C.c_int, C.c_float, C.c_int, _vp, _vp, _vp]),
     ("vmd_hip_distance", C.c_int, [_vp, _vp, C.c_size_t, C.c_size_t, _vp, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int,
                                    _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    ("vmd_hip_add_u64", C.c_int, [_vp, _vp, _vp, C.c_size_t]),
     ("vmd_hip_counts_to_float", C.c_int, [_vp, _vp, C.c_size_t, _vp, _vp]),
     ("vmd_hip_synth_frames", C.c_int, [_vp, _vp, C.c_size_t, C.c_size_t, C.c_int, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32,
                                        C.c_float, C.c_float]),

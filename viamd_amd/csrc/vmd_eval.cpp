@@ -314,6 +314,8 @@ struct PropState {
     size_t dim1 = 0;                    // temporal population
     size_t dist_P = 1, dist_per = 1;    // DIST: contexts x values per context
     DevBuf<uint64_t> d_counts;
+    DevBuf<uint64_t> d_blocks;          // [nblocks][ncounts]: per-frame-block partial accumulators (filtered evaluation)
+    std::vector<double> block_weights64; // [nblocks][ncounts], distributions only
     DevBuf<float> d_values;             // volume float view (device)
     DevBuf<float> d_max;
     int sel_a = -1, sel_b = -1;         // RDF: indices into eval->sels
@@ -380,6 +382,12 @@ struct vmd_script_eval_t {
     hipStream_t copy_stream = nullptr;
     DevBuf<uint64_t> d_partial;
     std::vector<float> h_temporal;
+    // filtered evaluation: per-block partial accumulators and the eval whose blocks this one may reuse
+    size_t block_frames = 0;
+    std::unique_ptr<std::atomic<uint8_t>[]> block_ready;
+    size_t num_blocks = 0;
+    vmd_script_eval_t* source = nullptr;
+    std::atomic<size_t> frames_computed{0}, frames_reused{0};
 };
 typedef vmd_script_eval_t::Stage Stage;
 
@@ -496,6 +504,8 @@ extern "C" void vmd_eval_clear_data(vmd_script_eval_t* eval) {
     eval->interrupt = false;
     std::fill(eval->frame_mask.begin(), eval->frame_mask.end(), (uint8_t)0);
     eval->frames_done = 0;
+    eval->frames_computed = 0; eval->frames_reused = 0;
+    for (size_t b = 0; b < eval->num_blocks; ++b) eval->block_ready[b] = 0;
     for (auto& p : eval->props) {
         std::fill(p->values.begin(), p->values.end(), 0.0f);
         std::fill(p->weights.begin(), p->weights.end(), 0.0f);
@@ -611,6 +621,49 @@ extern "C" bool vmd_eval_refresh_counts(vmd_script_eval_t* eval, const char* nam
     HIP_OK(hipStreamSynchronize(eval->stream));
     p->counts_stale = false;
     return true;
+}
+
+extern "C" bool vmd_eval_set_block_frames(vmd_script_eval_t* eval, size_t block_frames) {
+    if (!eval) return vmd_fail("eval is NULL");
+    std::lock_guard<std::mutex> l(eval->mtx);
+    HIP_OK(hipSetDevice(eval->device));
+    if (eval->frames_done.load() != 0) return vmd_fail("vmd_eval_set_block_frames: call before the first frame_range or right after clear_data");
+    eval->block_frames = 0; eval->num_blocks = 0; eval->block_ready.reset();
+    for (auto& p : eval->props) { p->d_blocks.release(); p->block_weights64.clear(); }
+    if (block_frames == 0) return true;
+    const size_t nblocks = (eval->num_frames + block_frames - 1) / block_frames;
+    size_t bytes = 0;
+    for (auto& p : eval->props) bytes += nblocks * p->ncounts * sizeof(uint64_t);
+    if (bytes > ((size_t)96 << 30))
+        return vmd_fail("vmd_eval_set_block_frames: %zu blocks need %.1f GB of block partials; use larger blocks", nblocks, (double)bytes / 1073741824.0);
+    for (auto& p : eval->props) {
+        if (!p->ncounts) continue;
+        if (!p->d_blocks.ensure(nblocks * p->ncounts)) return false;
+        if (p->prop.kind == PROP_RDF) p->block_weights64.assign(nblocks * p->ncounts, 0.0);
+    }
+    eval->block_ready.reset(new std::atomic<uint8_t>[nblocks]);
+    for (size_t b = 0; b < nblocks; ++b) eval->block_ready[b] = 0;
+    eval->num_blocks = nblocks;
+    eval->block_frames = block_frames;
+    return true;
+}
+
+extern "C" bool vmd_eval_set_source(vmd_script_eval_t* eval, vmd_script_eval_t* source) {
+    if (!eval) return vmd_fail("eval is NULL");
+    std::lock_guard<std::mutex> l(eval->mtx);
+    if (!source) { eval->source = nullptr; return true; }
+    if (source == eval) return vmd_fail("vmd_eval_set_source: an eval cannot be its own source");
+    if (source->ir_fingerprint != eval->ir_fingerprint || source->num_frames != eval->num_frames || source->props.size() != eval->props.size())
+        return vmd_fail("vmd_eval_set_source: source was created from a different script or frame count");
+    if (source->device != eval->device) return vmd_fail("vmd_eval_set_source: source lives on another device");
+    if (source->block_frames == 0) return vmd_fail("vmd_eval_set_source: source keeps no block partials (vmd_eval_set_block_frames)");
+    eval->source = source;
+    return true;
+}
+
+extern "C" void vmd_eval_frame_stats(const vmd_script_eval_t* eval, size_t* frames_computed, size_t* frames_reused) {
+    if (frames_computed) *frames_computed = eval ? eval->frames_computed.load() : 0;
+    if (frames_reused) *frames_reused = eval ? eval->frames_reused.load() : 0;
 }
 
 extern "C" void vmd_eval_set_frame_mask(vmd_script_eval_t* eval, const uint8_t* mask, size_t n) {
@@ -860,6 +913,77 @@ static size_t auto_batch(const vmd_script_eval_t* e, size_t num_atoms) {
     return B;
 }
 
+// one kernel batch: frames [f0, f0 + nb); blk >= 0 when the batch is exactly frame block `blk` of this eval
+struct Batch { size_t f0, nb; long blk; };
+
+static void plan_batches(const vmd_script_eval_t* e, size_t beg, size_t end, size_t Bmax, std::vector<Batch>* out) {
+    auto even = [&](size_t a, size_t b) {
+        const size_t total = b - a;
+        if (!total) return;
+        const size_t nbatch = (total + Bmax - 1) / Bmax;
+        const size_t B = (total + nbatch - 1) / nbatch;
+        for (size_t f = a; f < b; f += B) out->push_back({f, std::min(B, b - f), -1});
+    };
+    const size_t S = e->block_frames;
+    if (S == 0) { even(beg, end); return; }
+    // whole blocks that fit one batch become their own batch (their partial is kept), everything else is a plain piece
+    size_t run = beg;                          // start of the pending plain piece
+    for (size_t f = beg; f < end;) {
+        const size_t blk = f / S;
+        const size_t bend = std::min((blk + 1) * S, e->num_frames);
+        if (f == blk * S && bend <= end && bend - f <= Bmax) {
+            even(run, f);
+            out->push_back({f, bend - f, (long)blk});
+            f = bend; run = f;
+        } else {
+            f = std::min(bend, end);
+        }
+    }
+    even(run, end);
+}
+
+// filtered evaluation: merge every ready block of the source eval that lies inside [beg, end) into this eval's accumulators
+// and return the sub-ranges that still have to be computed
+static bool reuse_blocks(vmd_script_eval_t* e, size_t beg, size_t end, std::vector<std::pair<size_t, size_t>>* todo) {
+    vmd_script_eval_t* src = e->source;
+    if (!src || src->block_frames == 0) { todo->push_back({beg, end}); return true; }
+    std::lock_guard<std::mutex> lock(src->mtx);   // order: own mutex, then the source's (a source never locks its users)
+    const size_t S = src->block_frames;
+    size_t run = beg, reused = 0;
+    for (size_t f = beg; f < end;) {
+        const size_t blk = f / S;
+        const size_t bend = std::min((blk + 1) * S, e->num_frames);
+        if (f == blk * S && bend <= end && blk < src->num_blocks && src->block_ready[blk]) {
+            if (run < f) todo->push_back({run, f});
+            for (size_t i = 0; i < e->props.size(); ++i) {
+                PropState* p = e->props[i].get();
+                const PropState* q = src->props[i].get();
+                if (p->ncounts) {
+                    KRN_OK(vmd_hip_add_u64(e->stream, p->d_counts.p, q->d_blocks.p + blk * p->ncounts, p->ncounts));
+                    if (p->prop.kind == PROP_RDF)
+                        for (size_t k = 0; k < p->ncounts; ++k) p->weights64[k] += q->block_weights64[blk * p->ncounts + k];
+                } else {
+                    memcpy(&p->values[f * p->dim1], &q->values[f * p->dim1], (bend - f) * p->dim1 * sizeof(float));
+                }
+                p->dirty = true;
+            }
+            for (size_t g = f; g < bend; ++g) e->frame_mask[g] = 1;
+            reused += bend - f;
+            f = bend; run = f;
+        } else {
+            f = std::min(bend, end);
+        }
+    }
+    if (run < end) todo->push_back({run, end});
+    if (reused) {
+        HIP_OK(hipStreamSynchronize(e->stream));   // the source's partials are read before its mutex is released
+        e->frames_done += reused;
+        e->frames_reused += reused;
+        for (auto& p : e->props) if (p->prop.kind == PROP_RDF) { if (!refresh_distribution(e, p.get())) return false; }
+    }
+    return true;
+}
+
 // evaluates frames [frame_beg, frame_end) in large batches; returns false on interrupt (empty error) or failure
 static bool process_range(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_trajectory_i* traj, uint32_t frame_beg, uint32_t frame_end) {
     g_last_error.clear();
@@ -886,22 +1010,25 @@ static bool process_range(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
         p->ref_pose_ready = true;
     }
 
+    // frames served from the block partials of the source eval (filtered evaluation), the rest is computed
+    std::vector<std::pair<size_t, size_t>> segments;
+    if (!reuse_blocks(e, frame_beg, frame_end, &segments)) return false;
+
     // frames per launch: as many as the scratch budget allows, split evenly so that no small tail batch is left
-    size_t B = auto_batch(e, num_atoms);
-    {
-        const size_t total = frame_end - frame_beg;
-        const size_t nbatch = (total + B - 1) / B;
-        B = (total + nbatch - 1) / nbatch;
-    }
-    bool completed = true;
+    size_t Bmax = auto_batch(e, num_atoms);
     const vmd_device_view_t* vw = have_view ? &view : nullptr;
     // host trajectories are staged in smaller batches so that load_frame of batch k+1 overlaps the kernels of batch k
-    if (!have_view && g_opt.batch_frames <= 0) B = std::min<size_t>(B, 128);
+    if (!have_view && g_opt.batch_frames <= 0) Bmax = std::min<size_t>(Bmax, 128);
+    std::vector<Batch> batches;
+    for (auto& sg : segments) plan_batches(e, sg.first, sg.second, Bmax, &batches);
+
+    bool completed = true;
     int cur = 0;
-    if (!fetch_stage(e, e->stages[cur], traj, vw, num_atoms, frame_beg, std::min<size_t>(B, frame_end - frame_beg))) return false;
-    for (size_t f0 = frame_beg; f0 < frame_end; f0 += B, cur ^= 1) {
+    if (!batches.empty() && !fetch_stage(e, e->stages[cur], traj, vw, num_atoms, batches[0].f0, batches[0].nb)) return false;
+    for (size_t bi = 0; bi < batches.size(); ++bi, cur ^= 1) {
         if (e->interrupt) { completed = false; break; }
-        const size_t nb = std::min<size_t>(B, frame_end - f0);
+        const Batch& bt = batches[bi];
+        const size_t f0 = bt.f0, nb = bt.nb;
         Stage& src = e->stages[cur];
         HIP_OK(hipStreamWaitEvent(e->stream, src.ready, 0));
         const uint32_t pbc = batch_pbc(src);
@@ -914,6 +1041,12 @@ static bool process_range(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
 
         for (auto& p : e->props) {
             const Property& d = p->prop;
+            // a whole frame block accumulates into its own partial first and is merged into the totals afterwards
+            uint64_t* acc = p->d_counts.p;
+            if (bt.blk >= 0 && p->ncounts) {
+                acc = p->d_blocks.p + (size_t)bt.blk * p->ncounts;
+                HIP_OK(hipMemsetAsync(acc, 0, p->ncounts * sizeof(uint64_t), e->stream));
+            }
             if (d.kind == PROP_RDF) {
                 vmd_grid_t g;
                 if (choose_grid(src, nb, d.rmax, &g)) {
@@ -927,7 +1060,7 @@ static bool process_range(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
                     KRN_OK(vmd_hip_rdf_pencil(e->stream, sa->sorted.p, sa->cell_start.p, (int)sa->idx.size(), sa->nsel_pad,
                                               sb->sorted.p, sb->cell_start.p, (int)sb->idx.size(), sb->nsel_pad,
                                               src.d_boxes.p, (int)nb, g, d.rmin, d.rmax, VMD_RDF_NUM_BINS,
-                                              p->same_set ? 1 : 0, g_opt.rdf_variant, e->d_partial.p, p->d_counts.p));
+                                              p->same_set ? 1 : 0, g_opt.rdf_variant, e->d_partial.p, acc));
                     e->prof.end(e->stream);
                 } else {
                     Selection* sa = e->sels[p->sel_a].get();
@@ -935,10 +1068,12 @@ static bool process_range(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
                     e->prof.begin("rdf_brute", e->stream);
                     KRN_OK(vmd_hip_rdf_brute(e->stream, src.base, src.frame_stride, src.row_stride, src.d_boxes.p, pbc, (int)nb,
                                              sa->d_idx.p, (int)sa->idx.size(), sb->d_idx.p, (int)sb->idx.size(),
-                                             d.rmin, d.rmax, VMD_RDF_NUM_BINS, p->d_counts.p));
+                                             d.rmin, d.rmax, VMD_RDF_NUM_BINS, acc));
                     e->prof.end(e->stream);
                 }
                 // SPEC S4 normalisation, fp64 on the host (needs only the box)
+                double* bw = bt.blk >= 0 ? &p->block_weights64[(size_t)bt.blk * p->ncounts] : nullptr;
+                if (bw) std::fill(bw, bw + p->ncounts, 0.0);
                 for (size_t b = 0; b < nb; ++b) {
                     const float* L = &src.h_boxes[9 * b];
                     double V;
@@ -949,7 +1084,9 @@ static bool process_range(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
                     for (size_t k = 0; k < p->ncounts; ++k) {
                         const double r0 = (double)d.rmin + w * (double)k;
                         const double r1 = (double)d.rmin + w * (double)(k + 1);
-                        p->weights64[k] += rho * (4.0 / 3.0) * M_PI * (r1 * r1 * r1 - r0 * r0 * r0);
+                        const double wk = rho * (4.0 / 3.0) * M_PI * (r1 * r1 * r1 - r0 * r0 * r0);
+                        p->weights64[k] += wk;
+                        if (bw) bw[k] += wk;
                     }
                 }
                 p->dirty = true;
@@ -962,7 +1099,7 @@ static bool process_range(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
                 e->prof.begin("sdf_scatter", e->stream);
                 KRN_OK(vmd_hip_sdf_scatter(e->stream, src.base, src.frame_stride, src.row_stride, src.d_boxes.p, pbc, (int)nb,
                                            p->d_structs.p, (int)d.K, (int)d.m, p->d_R32.p, p->d_c32.p, p->d_tgt.p, p->have_owner ? p->d_owner.p : nullptr, (int)d.b.size(),
-                                           d.rmax, VMD_VOLUME_DIM, p->d_counts.p, p->d_group.p,
+                                           d.rmax, VMD_VOLUME_DIM, acc, p->d_group.p,
                                            (p->have_tag && p->tag_len == src.row_stride) ? p->d_tag.p : nullptr));
                 e->prof.end(e->stream);
                 p->dirty = true;
@@ -977,10 +1114,11 @@ static bool process_range(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
                 toff += nb * p->dim1;
                 p->dirty = true;
             }
+            if (acc != p->d_counts.p) KRN_OK(vmd_hip_add_u64(e->stream, p->d_counts.p, acc, p->ncounts));
         }
         // the kernels of this batch are queued: load the next batch on the host while they run
-        if (f0 + B < frame_end && !e->interrupt) {
-            if (!fetch_stage(e, e->stages[cur ^ 1], traj, vw, num_atoms, f0 + B, std::min<size_t>(B, frame_end - (f0 + B)))) return false;
+        if (bi + 1 < batches.size() && !e->interrupt) {
+            if (!fetch_stage(e, e->stages[cur ^ 1], traj, vw, num_atoms, batches[bi + 1].f0, batches[bi + 1].nb)) return false;
         }
         HIP_OK(hipStreamSynchronize(e->stream));
         e->prof.resolve();
@@ -992,6 +1130,8 @@ static bool process_range(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
         }
         for (size_t b = 0; b < nb; ++b) e->frame_mask[f0 + b] = 1;
         e->frames_done += nb;
+        e->frames_computed += nb;
+        if (bt.blk >= 0) e->block_ready[bt.blk] = 1;
         // cheap views are refreshed every batch so a polling GUI sees progress (src/main.cpp:1508-1524)
         for (auto& p : e->props) if (p->prop.kind == PROP_RDF) { if (!refresh_distribution(e, p.get())) return false; }
     }

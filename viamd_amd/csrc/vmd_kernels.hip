@@ -1383,6 +1383,18 @@ extern "C" int vmd_hip_distance(void* stream, const float* xyz, size_t frame_str
     return 0;
 }
 
+// dst[i] += src[i]: merges one frame block's partial accumulator into another (block partials, filtered evaluation)
+__global__ __launch_bounds__(256) void k_add_u64(uint64_t* __restrict__ dst, const uint64_t* __restrict__ src, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) { const uint64_t v = src[i]; if (v) dst[i] += v; }
+}
+extern "C" int vmd_hip_add_u64(void* stream, uint64_t* dst, const uint64_t* src, size_t n) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_add_u64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dst, src, n);
+    VMD_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int vmd_hip_counts_to_float(void* stream, const uint64_t* counts, size_t n, float* values, float* max_out) {
     hipStream_t s = (hipStream_t)stream;
     if (n == 0) return 0;

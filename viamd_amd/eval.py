@@ -237,6 +237,24 @@ class ScriptEval:
             return None
         return PropertyDataView(p.contents, self, name)
 
+    def set_block_frames(self, block_frames):
+        """Keep one partial accumulator per block of `block_frames` frames in HBM (filtered evaluation)."""
+        if not self.lib.vmd_eval_set_block_frames(self.h, int(block_frames)):
+            raise VmdError(self.lib.last_error())
+
+    def set_source(self, source):
+        """Serve whole frame blocks of later frame_range calls from `source`'s block partials (None detaches).
+        The VIAMD "Eval Filt" pattern: a second eval over a timeline sub-range (src/main.cpp:1014-1039)."""
+        if not self.lib.vmd_eval_set_source(self.h, source.h if source is not None else None):
+            raise VmdError(self.lib.last_error())
+        self._source = source          # keep it alive
+
+    def frame_stats(self):
+        """(frames evaluated by kernels, frames served from block partials) since the last clear_data."""
+        a, b = C.c_size_t(0), C.c_size_t(0)
+        self.lib.vmd_eval_frame_stats(self.h, C.byref(a), C.byref(b))
+        return int(a.value), int(b.value)
+
     def num_frames(self):
         return int(self.lib.vmd_eval_num_frames(self.h))
 
