@@ -43,6 +43,11 @@ typedef struct vmd_grid_t {
  * (count -> scan -> scatter); larger ones take the three-kernel path with global atomics */
 int vmd_hip_cells_fused_ok(vmd_grid_t grid, int nsel);
 int vmd_hip_set_cells_fused(int on);   /* tuning / A-B switch, returns the previous value */
+/* selections above 64k atoms: G blocks per frame, each with the cell table in LDS (no global atomics); 0 = not applicable */
+int vmd_hip_cells_split_blocks(vmd_grid_t grid, int nsel);
+int vmd_hip_set_cells_split(int on);   /* A-B switch, returns the previous value */
+/* u32 words per frame the `rank` scratch of vmd_hip_cells_build must hold for this grid and selection */
+size_t vmd_hip_cells_scratch_words(vmd_grid_t grid, int nsel);
 int vmd_hip_cells_build(void* stream, const float* xyz, size_t frame_stride, size_t row_stride,
                         const float* boxes, int B, const int32_t* sel, int nsel, int nsel_pad,
                         vmd_grid_t grid, uint32_t* cell_count, uint32_t* rank, uint32_t* cell_start, float* sorted,

@@ -36,14 +36,15 @@ def test_rdf_two_sets_ranges_shared_grid(gpu_lib, oracle, box30k):
                     [("goh", o, h, 0.0, 12.0), ("goo", o, o, 0.0, 12.0), ("ring", h, o, 2.5, 9.0)], device=True)
 
 
-def test_both_cell_build_paths(gpu_lib, oracle, box30k):
+def test_all_cell_build_paths(gpu_lib, oracle, box30k):
+    """atomic 3-kernel build, LDS-fused single-block build, split build (G blocks per frame, forced with 2048-atom slices)"""
     o, h = cases.oxygen(30000), cases.hydrogen(30000)
-    for fused in (0, 1):
-        old = gpu_lib.vmd_set_option(b"cells_fused", fused)
+    for fused, split in ((0, 1), (1, 1), (1, 2)):
+        old = gpu_lib.vmd_set_option(b"cells_fused", fused), gpu_lib.vmd_set_option(b"cells_split", split)
         try:
             cases.check_rdf(gpu_lib, oracle, box30k[:2], 80.0, [("goo", o, o, 0.0, 12.0), ("goh", o, h, 0.0, 9.0)], device=True)
         finally:
-            gpu_lib.vmd_set_option(b"cells_fused", old)
+            gpu_lib.vmd_set_option(b"cells_fused", old[0]); gpu_lib.vmd_set_option(b"cells_split", old[1])
 
 
 def test_rdf_inline_variant_and_host_staging(gpu_lib, oracle, box30k):

@@ -146,6 +146,9 @@ SIGNATURES = [
     ("vmd_hip_rdf_num_blocks", C.c_int, []),
     ("vmd_hip_set_rdf_blocks", C.c_int, [C.c_int]),
     ("vmd_hip_set_rdf_nsub", C.c_int, [C.c_int]),
+    ("vmd_hip_cells_split_blocks", C.c_int, [Grid, C.c_int]),
+    ("vmd_hip_set_cells_split", C.c_int, [C.c_int]),
+    ("vmd_hip_cells_scratch_words", C.c_size_t, [Grid, C.c_int]),
     ("vmd_hip_rdf_partial_words", C.c_size_t, []),
     ("vmd_hip_rdf_pencil", C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, C.c_int, C.c_int, _vp, C.c_int, Grid,
                                      C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, _vp, _vp]),

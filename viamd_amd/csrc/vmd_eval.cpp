@@ -67,6 +67,7 @@ extern "C" int vmd_set_option(const char* key, int value) {
     else if (!strcmp(key, "cells_aos")) o = &g_opt.cells_aos;
     else if (!strcmp(key, "sdf_dense")) o = &g_opt.sdf_dense;
     else if (!strcmp(key, "cells_fused")) return vmd_hip_set_cells_fused(value);
+    else if (!strcmp(key, "cells_split")) return vmd_hip_set_cells_split(value);
     else if (!strcmp(key, "rdf_blocks")) return vmd_hip_set_rdf_blocks(value);
     else if (!strcmp(key, "rdf_nsub")) return vmd_hip_set_rdf_nsub(value);
     if (!o) return -1;
@@ -889,7 +890,7 @@ static bool build_selection(vmd_script_eval_t* e, Selection* s, const Stage& src
     const int nsel = (int)s->idx.size();
     s->nsel_pad = (nsel + 63) & ~63;
     if (!s->cell_count.ensure(nb * (size_t)(g.ncell + 1)) || !s->cell_start.ensure(nb * (size_t)(g.ncell + 1)) ||
-        !s->rank.ensure(nb * (size_t)nsel) || !s->sorted.ensure(nb * 3 * (size_t)s->nsel_pad + 64)) return false;   // +64: the pair kernel prefetches past a segment
+        !s->rank.ensure(nb * vmd_hip_cells_scratch_words(g, nsel)) || !s->sorted.ensure(nb * 3 * (size_t)s->nsel_pad + 64)) return false;   // +64: the pair kernel prefetches past a segment
     const bool use_aos = g_opt.cells_aos != 0;
     if (use_aos && !s->aos.ensure(nb * 4 * (size_t)s->nsel_pad)) return false;
     e->prof.begin("cells_build", e->stream);

@@ -366,6 +366,81 @@ __global__ __launch_bounds__(1024) void k_cells_fused(vmd_cells_params_t p) {
     }
 }
 
+// Split build for selections too large for one block per frame: G blocks share a frame, each owns a contiguous slice of the
+// selection.  count: LDS histogram of the slice -> global table [frame][g][cell]; scan: per frame, exclusive prefix over
+// cells of the column sums + running offset over g (in place: the table becomes each block's first slot per cell);
+// scatter: LDS cursors initialised from the table.  No global atomics, no rank array; the only scattered traffic is the
+// 16-byte record store.  The order of atoms inside a cell differs from the other builds (it is arbitrary in all of them).
+struct vmd_cells_split_t {
+    vmd_cells_params_t c;
+    uint32_t* table;     // [B][G][ncell]
+    int G; int slice;    // atoms per block (multiple of 1024)
+};
+
+__global__ __launch_bounds__(1024) void k_cells_split_count(vmd_cells_split_t q) {
+    HIP_DYNAMIC_SHARED(uint32_t, s_dyn)
+    const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int ncell = q.c.grid.ncell;
+    for (int c = tid; c < ncell; c += 1024) s_dyn[c] = 0u;
+    __syncthreads();
+    const int t1 = (g + 1) * q.slice < q.c.nsel ? (g + 1) * q.slice : q.c.nsel;
+    float xw, yw, zw;
+    for (int t = g * q.slice + tid; t < t1; t += 1024) atomicAdd(&s_dyn[vmd_cell_of(q.c, b, t, xw, yw, zw)], 1u);
+    __syncthreads();
+    uint32_t* out = q.table + ((size_t)b * q.G + g) * ncell;
+    for (int c = tid; c < ncell; c += 1024) out[c] = s_dyn[c];
+}
+
+__global__ __launch_bounds__(1024) void k_cells_split_scan(uint32_t* __restrict__ table, uint32_t* __restrict__ cell_start, int ncell, int G) {
+    __shared__ uint32_t part[1024];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    uint32_t* tb = table + (size_t)b * G * ncell;
+    uint32_t* out = cell_start + (size_t)b * (ncell + 1);
+    uint32_t carry = 0;
+    // rows of 1024 consecutive cells: thread = cell, so every table access is coalesced
+    for (int base = 0; base < ncell; base += 1024) {
+        const int c = base + tid;
+        uint32_t s = 0;
+        if (c < ncell) for (int g = 0; g < G; ++g) s += tb[(size_t)g * ncell + c];
+        part[tid] = s;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {
+            const uint32_t v = tid >= o ? part[tid - o] : 0u;
+            __syncthreads();
+            part[tid] += v;
+            __syncthreads();
+        }
+        if (c < ncell) {
+            uint32_t run = carry + part[tid] - s;   // exclusive
+            out[c] = run;
+            for (int g = 0; g < G; ++g) { const uint32_t n = tb[(size_t)g * ncell + c]; tb[(size_t)g * ncell + c] = run; run += n; }
+        }
+        carry += part[1023];
+        __syncthreads();
+    }
+    if (tid == 0) out[ncell] = carry;
+}
+
+__global__ __launch_bounds__(1024) void k_cells_split_scatter(vmd_cells_split_t q) {
+    HIP_DYNAMIC_SHARED(uint32_t, s_dyn)
+    const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int ncell = q.c.grid.ncell;
+    const uint32_t* first = q.table + ((size_t)b * q.G + g) * ncell;
+    for (int c = tid; c < ncell; c += 1024) s_dyn[c] = first[c];
+    __syncthreads();
+    const int t1 = (g + 1) * q.slice < q.c.nsel ? (g + 1) * q.slice : q.c.nsel;
+    float* srt = q.c.sorted + (size_t)b * 3 * q.c.nsel_pad;
+    float xw, yw, zw;
+    for (int t = g * q.slice + tid; t < t1; t += 1024) {
+        const uint32_t c = vmd_cell_of(q.c, b, t, xw, yw, zw);
+        const uint32_t pos = atomicAdd(&s_dyn[c], 1u);
+        if (q.c.aos) { vmd_store_aos(q.c.aos, (size_t)b * q.c.nsel_pad + pos, xw, yw, zw); continue; }
+        srt[pos] = xw;
+        srt[q.c.nsel_pad + pos] = yw;
+        srt[2 * (size_t)q.c.nsel_pad + pos] = zw;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ K2: RDF, pencil grid
 
 struct vmd_pair_params_t {
@@ -1209,9 +1284,28 @@ __global__ __launch_bounds__(256) void k_synth(vmd_synth_params_t p) {
 
 static int g_cells_fused = 1;
 extern "C" int vmd_hip_set_cells_fused(int on) { const int old = g_cells_fused; g_cells_fused = on; return old; }
+static int g_cells_split = 1;
+extern "C" int vmd_hip_set_cells_split(int on) { const int old = g_cells_split; g_cells_split = on; return old; }
 // the fused single-block-per-frame build needs the cell table in LDS (<= 96 KB of counters)
 // ... and pays off while one block per frame still has enough parallelism (measured: 33k atoms/frame 1.5x faster, 333k slower)
-extern "C" int vmd_hip_cells_fused_ok(vmd_grid_t grid, int nsel) { return g_cells_fused && grid.ncell + 1 <= 24576 && nsel <= 65536; }
+extern "C" int vmd_hip_cells_fused_ok(vmd_grid_t grid, int nsel) { return g_cells_fused && g_cells_split < 2 && grid.ncell + 1 <= 24576 && nsel <= 65536; }
+// larger selections: G blocks per frame with LDS tables (k_cells_split_*); 0 = not applicable
+// (cells_split = 2 forces this path with 2048-atom slices whatever the selection size, >= 1024 forces it with that slice
+// size: test / tuning hook)
+static int vmd_split_slice(void) { return g_cells_split == 2 ? 2048 : g_cells_split >= 1024 ? (g_cells_split & ~1023) : 32768; }
+extern "C" int vmd_hip_cells_split_blocks(vmd_grid_t grid, int nsel) {
+    if (!g_cells_fused || !g_cells_split || grid.ncell + 1 > 24576 || (nsel <= 65536 && g_cells_split < 2)) return 0;
+    return (nsel + vmd_split_slice() - 1) / vmd_split_slice();
+}
+// u32 words of `rank` scratch per frame that vmd_hip_cells_build needs for this grid and selection
+extern "C" size_t vmd_hip_cells_scratch_words(vmd_grid_t grid, int nsel) {
+    const size_t split = (size_t)vmd_hip_cells_split_blocks(grid, nsel) * (size_t)grid.ncell;
+    return split > (size_t)nsel ? split : (size_t)nsel;
+}
+
+static int vmd_lds_opt_in(const void* kernel) {
+    return (int)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+}
 
 extern "C" int vmd_hip_cells_build(void* stream, const float* xyz, size_t frame_stride, size_t row_stride,
                                    const float* boxes, int B, const int32_t* sel, int nsel, int nsel_pad,
@@ -1220,30 +1314,36 @@ extern "C" int vmd_hip_cells_build(void* stream, const float* xyz, size_t frame_
     hipStream_t s = (hipStream_t)stream;
     if (B <= 0 || nsel <= 0) return 0;
     const dim3 grp((nsel + 255) / 256, B);
-    if (vmd_hip_cells_fused_ok(grid, nsel)) {
-        vmd_cells_params_t pf{xyz, frame_stride, row_stride, boxes, sel, nsel, nsel_pad, grid, cell_count, rank, cell_start, sorted, aos};
-        const size_t shm = sizeof(uint32_t) * ((size_t)grid.ncell + 1 + 1024);
-        static bool attr_set = false;
-        if (!attr_set) {
-            hipError_t ea = hipFuncSetAttribute((const void*)k_cells_fused, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
-            if (ea != hipSuccess) return (int)ea;
-            attr_set = true;
-        }
-        hipLaunchKernelGGL(k_cells_fused, dim3(B), dim3(1024), shm, s, pf);
-        VMD_LAUNCH_CHECK();
-        if (aos) { hipLaunchKernelGGL(k_cells_repack, grp, dim3(256), 0, s, (const float*)aos, sorted, nsel, nsel_pad); VMD_LAUNCH_CHECK(); }
-        return 0;
-    }
-    hipError_t e = hipMemsetAsync(cell_count, 0, sizeof(uint32_t) * (size_t)B * (grid.ncell + 1), s);
-    if (e != hipSuccess) return (int)e;
     vmd_cells_params_t p{xyz, frame_stride, row_stride, boxes, sel, nsel, nsel_pad, grid, cell_count, rank, cell_start, sorted, aos};
-    const dim3 g((nsel + 256 * VMD_CELLS_ILP - 1) / (256 * VMD_CELLS_ILP), B);
-    hipLaunchKernelGGL(k_cells_count, g, dim3(256), 0, s, p);
-    VMD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_cells_scan, dim3(B), dim3(1024), 0, s, (const uint32_t*)cell_count, cell_start, (int)grid.ncell);
-    VMD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_cells_scatter, g, dim3(256), 0, s, p);
-    VMD_LAUNCH_CHECK();
+    if (vmd_hip_cells_fused_ok(grid, nsel)) {
+        const size_t shm = sizeof(uint32_t) * ((size_t)grid.ncell + 1 + 1024);
+        int ea = vmd_lds_opt_in((const void*)k_cells_fused);
+        if (ea) return ea;
+        hipLaunchKernelGGL(k_cells_fused, dim3(B), dim3(1024), shm, s, p);
+        VMD_LAUNCH_CHECK();
+    } else if (const int G = vmd_hip_cells_split_blocks(grid, nsel)) {
+        vmd_cells_split_t q{p, rank, G, vmd_split_slice()};
+        const size_t shm = sizeof(uint32_t) * (size_t)grid.ncell;
+        int ea = vmd_lds_opt_in((const void*)k_cells_split_count);
+        if (!ea) ea = vmd_lds_opt_in((const void*)k_cells_split_scatter);
+        if (ea) return ea;
+        hipLaunchKernelGGL(k_cells_split_count, dim3(G, B), dim3(1024), shm, s, q);
+        VMD_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_cells_split_scan, dim3(B), dim3(1024), 0, s, rank, cell_start, (int)grid.ncell, G);
+        VMD_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_cells_split_scatter, dim3(G, B), dim3(1024), shm, s, q);
+        VMD_LAUNCH_CHECK();
+    } else {
+        hipError_t e = hipMemsetAsync(cell_count, 0, sizeof(uint32_t) * (size_t)B * (grid.ncell + 1), s);
+        if (e != hipSuccess) return (int)e;
+        const dim3 g((nsel + 256 * VMD_CELLS_ILP - 1) / (256 * VMD_CELLS_ILP), B);
+        hipLaunchKernelGGL(k_cells_count, g, dim3(256), 0, s, p);
+        VMD_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_cells_scan, dim3(B), dim3(1024), 0, s, (const uint32_t*)cell_count, cell_start, (int)grid.ncell);
+        VMD_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_cells_scatter, g, dim3(256), 0, s, p);
+        VMD_LAUNCH_CHECK();
+    }
     if (aos) { hipLaunchKernelGGL(k_cells_repack, grp, dim3(256), 0, s, (const float*)aos, sorted, nsel, nsel_pad); VMD_LAUNCH_CHECK(); }
     return 0;
 }
