@@ -25,7 +25,7 @@
 
 #define VMD_WAVE 64
 #define VMD_MAX_BINS 1024
-#define VMD_QUEUE_CAP 384          // < 64 pending + 4 undrained candidate columns of 64, + 64 per-lane dump slots
+#define VMD_QUEUE_CAP 384          // < 64 pending + 4 undrained candidate columns of 64, + the 64-entry slow stack
 #define VMD_FAR 1.0e18f            // coordinate of a padding lane: never within any cutoff, squares stay finite
 
 // Wave-uniform read-only data (j coordinates, cell offsets, boxes) is read through the constant address space so
@@ -192,9 +192,11 @@ struct vmd_binning_t {
 __host__ __device__ inline vmd_binning_t vmd_make_binning(float rmin, float rmax, int nbins) {
     vmd_binning_t b;
     b.rmin = rmin; b.rmax = rmax; b.inv_range = 1.0f / (rmax - rmin); b.fnbins = (float)nbins; b.nbins = nbins;
-    // error budget of t' against the spec value ((d - rmin) * inv_range) * nbins: v_sqrt_f32 1 ulp and three roundings on each
-    // side, all relative to rmax * inv_range * nbins -> 1e-6 * that is > 8 ulp; plus 1e-3 absolute head room
-    const float delta = 1.0e-3f + 1.0e-6f * rmax * b.inv_range * b.fnbins;
+    // error budget of t' = fma(v_sqrt(d2), k, c) against the spec value ((d - rmin) * inv_range) * nbins, in ulps of
+    // T = rmax * inv_range * nbins (the largest intermediate): v_sqrt_f32 1 + fma 0.5 on our side, sqrtf 0.5 + subtraction
+    // 0.5 + product 0.5 on the spec's (the factor nbins = 2^k is exact), the rounding of c = -rmin*k 0.5: 3.5 ulp
+    // = 4.2e-7 * T.  delta = 6e-7 * T (5 ulp) + 2.5e-4 absolute head room.
+    const float delta = 2.5e-4f + 6.0e-7f * rmax * b.inv_range * b.fnbins;
     b.fast_k = b.inv_range * b.fnbins;
     b.fast_c = -rmin * b.fast_k;
     b.fast_half = 0.5f - delta;
@@ -464,7 +466,8 @@ struct vmd_wave_acc_t {
     float* queue;         // LDS, VMD_QUEUE_CAP floats: the wave's hit stack
     unsigned qbase;       // LDS byte address of queue[0] (0 in the emulator build, where qtop is a plain offset)
     unsigned qtop;        // wave-uniform: LDS byte address of the top of the stack
-    float* dump;          // per-lane scratch slot: where the non-hit lanes of a push write
+    float* slow;          // LDS, 64 floats behind the stack: hits whose fast binning was not provably exact, waiting for
+    unsigned nslow;       // (wave-uniform count) a full wave of them to go through the exact path together
     unsigned ncols;       // wave-uniform: candidate columns (<= 64 hits each) since the last flush
 };
 
@@ -488,6 +491,38 @@ __device__ __forceinline__ void vmd_bin_add(const vmd_binning_t& bn, unsigned* h
     if (add) atomicAdd(&hist[bin], INC);
 }
 
+// The exact path of vmd_bin_add costs ~25 VALU instructions and used to run for 1-2 lanes at a time in every fifth pop.
+// The drain therefore parks uncertain hits on a second, 64-entry LDS stack and sends them through vmd_bin_of a full wave at
+// a time.  Both functions must be called by all lanes of the wave.
+template <unsigned INC>
+__device__ __forceinline__ void vmd_slow_flush(const vmd_binning_t& bn, vmd_wave_acc_t& w, int lane) {
+    __builtin_amdgcn_wave_barrier();
+    const float v = w.slow[lane];
+    __builtin_amdgcn_wave_barrier();
+    if ((unsigned)lane < w.nslow) {
+        const int bin = vmd_bin_of(bn, v);
+        if (bin >= 0) atomicAdd(&w.hist[bin], INC);
+    }
+    w.nslow = 0;
+}
+template <unsigned INC>
+__device__ __forceinline__ void vmd_bin_add_deferred(const vmd_binning_t& bn, vmd_wave_acc_t& w, float d2, bool active, int lane) {
+    const float t = fmaf(__builtin_amdgcn_sqrtf(d2), bn.fast_k, bn.fast_c);
+    const int bin = (int)t;
+    const float fr = t - truncf(t);
+    const bool sure = fabsf(fr - 0.5f) < bn.fast_half && (unsigned)bin < (unsigned)bn.nbins;
+    if (active && sure) atomicAdd(&w.hist[bin], INC);
+    const bool unsure = active && !sure;
+    const unsigned long long m = __ballot(unsure);
+    if (m) {
+        const unsigned cnt = (unsigned)__popcll(m);
+        if (w.nslow + cnt > VMD_WAVE) vmd_slow_flush<INC>(bn, w, lane);
+        const unsigned pre = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+        if (unsure) w.slow[w.nslow + pre] = d2;
+        w.nslow += cnt;
+    }
+}
+
 // VARIANT 0: compact the hits of one candidate column onto the wave's LDS stack (order is irrelevant for a
 // histogram, so LIFO: no head pointer, no wrap-around); vmd_drain_full pops full waves of 64 so that
 // sqrt + binning + ds_add always run with every lane busy.
@@ -500,10 +535,8 @@ __device__ __forceinline__ void vmd_push(const vmd_binning_t& bn, vmd_wave_acc_t
     }
     const unsigned long long mask = __ballot(hit);
     if (mask) {
-        // every lane stores: hit lanes to their compacted slot, the others to a private dump slot
         const unsigned pre = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-        float* slot = hit ? (float*)((char*)w.queue + ((w.qtop - w.qbase) + 4u * pre)) : w.dump;
-        *slot = d2;
+        if (hit) *(float*)((char*)w.queue + ((w.qtop - w.qbase) + 4u * pre)) = d2;
         w.qtop += 4u * (unsigned)__popcll(mask);
     }
 }
@@ -516,7 +549,7 @@ __device__ __forceinline__ void vmd_drain_full(const vmd_binning_t& bn, vmd_wave
         __builtin_amdgcn_wave_barrier();
         const float v = *(const float*)((const char*)w.queue + ((w.qtop - w.qbase) + 4u * (unsigned)lane));
         __builtin_amdgcn_wave_barrier();
-        vmd_bin_add<INC>(bn, w.hist, v, true);
+        vmd_bin_add_deferred<INC>(bn, w, v, true, lane);
     }
 }
 
@@ -529,7 +562,8 @@ __device__ __forceinline__ void vmd_drain(const vmd_binning_t& bn, vmd_wave_acc_
     const float v = w.queue[lane];
     __builtin_amdgcn_wave_barrier();
     w.qtop = w.qbase;
-    vmd_bin_add<INC>(bn, w.hist, v, (unsigned)lane < rem);
+    vmd_bin_add_deferred<INC>(bn, w, v, (unsigned)lane < rem, lane);
+    vmd_slow_flush<INC>(bn, w, lane);
 }
 
 // The push of the hot loop, hand-scheduled (hipcc spends 8 SALU + 5 VALU per column on the same thing): compare, and if
@@ -672,7 +706,8 @@ __global__ __launch_bounds__(256) VMD_SGPR_CAP(96) void k_rdf_pencil(vmd_pair_pa
     w.queue = s_queue[wave];
     w.qbase = VMD_LDS_ADDRESS(s_queue[wave]);
     w.qtop = w.qbase;
-    w.dump = &s_queue[wave][VMD_QUEUE_CAP - VMD_WAVE + lane];
+    w.slow = &s_queue[wave][VMD_QUEUE_CAP - VMD_WAVE];
+    w.nslow = 0;
     w.ncols = 0;
     for (int b = lane; b < nbins; b += VMD_WAVE) w.hist[b] = 0u;
     __builtin_amdgcn_wave_barrier();
