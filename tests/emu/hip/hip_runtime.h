@@ -23,6 +23,7 @@
 #define hipFuncAttributeMaxDynamicSharedMemorySize 8
 #define VMD_UNIFORM_AS
 #define VMD_SGPR_CAP(n)
+#define VMD_BALLOT(pred) __ballot(pred)
 #define VMD_NO_INLINE_ASM
 
 struct dim3 {

@@ -34,6 +34,22 @@
 #ifndef VMD_SGPR_CAP
 #define VMD_SGPR_CAP(n) __attribute__((amdgpu_num_sgpr(n)))
 #endif
+// wave-wide predicate mask straight from the compare (HIP's __ballot goes through a 0/1 VGPR and a second v_cmp)
+#ifndef VMD_BALLOT
+#define VMD_BALLOT(pred) __builtin_amdgcn_ballot_w64(pred)
+#endif
+// floor-to-int and fractional part in one instruction each (v_cvt_flr_i32_f32, v_fract_f32)
+#ifndef VMD_NO_INLINE_ASM
+__device__ __forceinline__ int vmd_floor_to_int(float t) { int b; asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(b) : "v"(t)); return b; }
+__device__ __forceinline__ float vmd_fract(float t) { return __builtin_amdgcn_fractf(t); }
+// keeps a wave-uniform value in a VGPR (a VOP3 instruction takes only one SGPR operand; without this the compiler
+// re-materialises the second one with a v_mov in the inner loop)
+__device__ __forceinline__ float vmd_in_vgpr(float v) { float r; asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "s"(v)); return r; }
+#else
+__device__ __forceinline__ int vmd_floor_to_int(float t) { return (int)floorf(t); }
+__device__ __forceinline__ float vmd_fract(float t) { return t - floorf(t); }
+__device__ __forceinline__ float vmd_in_vgpr(float v) { return v; }
+#endif
 #ifndef VMD_UNIFORM_AS
 #define VMD_UNIFORM_AS __attribute__((address_space(4)))
 #endif
@@ -465,7 +481,9 @@ struct vmd_wave_acc_t {
     unsigned* hist;       // LDS, nbins
     float* queue;         // LDS, VMD_QUEUE_CAP floats: the wave's hit stack
     unsigned qbase;       // LDS byte address of queue[0] (0 in the emulator build, where qtop is a plain offset)
+    unsigned hbase;       // LDS byte address of hist[0] (product build only)
     unsigned qtop;        // wave-uniform: LDS byte address of the top of the stack
+    float fast_c;         // bn.fast_c held in a VGPR
     float* slow;          // LDS, 64 floats behind the stack: hits whose fast binning was not provably exact, waiting for
     unsigned nslow;       // (wave-uniform count) a full wave of them to go through the exact path together
     unsigned ncols;       // wave-uniform: candidate columns (<= 64 hits each) since the last flush
@@ -482,7 +500,7 @@ __device__ __forceinline__ void vmd_bin_add(const vmd_binning_t& bn, unsigned* h
     // sure <=> t is inside bin `bin` with margin delta on both sides and the bin exists (negative t wraps to a huge unsigned)
     const bool sure = fabsf(fr - 0.5f) < bn.fast_half && (unsigned)bin < (unsigned)bn.nbins;
     bool add = active && sure;
-    if (__ballot(active && !sure)) {
+    if (VMD_BALLOT(active && !sure)) {
         if (active && !sure) {
             bin = vmd_bin_of(bn, d2);
             add = bin >= 0;
@@ -505,23 +523,62 @@ __device__ __forceinline__ void vmd_slow_flush(const vmd_binning_t& bn, vmd_wave
     }
     w.nslow = 0;
 }
+// parks the lanes of mask `m` (hits whose fast binning was not provably exact) on the slow stack
+template <unsigned INC>
+__device__ __forceinline__ void vmd_slow_park(const vmd_binning_t& bn, vmd_wave_acc_t& w, float d2, unsigned long long m, bool unsure, int lane) {
+    const unsigned cnt = (unsigned)__popcll(m);
+    if (w.nslow + cnt > VMD_WAVE) vmd_slow_flush<INC>(bn, w, lane);
+    const unsigned pre = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+    if (unsure) w.slow[w.nslow + pre] = d2;
+    w.nslow += cnt;
+}
 template <unsigned INC>
 __device__ __forceinline__ void vmd_bin_add_deferred(const vmd_binning_t& bn, vmd_wave_acc_t& w, float d2, bool active, int lane) {
-    const float t = fmaf(__builtin_amdgcn_sqrtf(d2), bn.fast_k, bn.fast_c);
-    const int bin = (int)t;
-    const float fr = t - truncf(t);
+    const float t = fmaf(__builtin_amdgcn_sqrtf(d2), bn.fast_k, w.fast_c);
+    const int bin = vmd_floor_to_int(t);                // floor: a negative t (d < rmin) can never pass the range test below
+    const float fr = vmd_fract(t);                      // t - floor(t), exact
     const bool sure = fabsf(fr - 0.5f) < bn.fast_half && (unsigned)bin < (unsigned)bn.nbins;
     if (active && sure) atomicAdd(&w.hist[bin], INC);
     const bool unsure = active && !sure;
-    const unsigned long long m = __ballot(unsure);
-    if (m) {
-        const unsigned cnt = (unsigned)__popcll(m);
-        if (w.nslow + cnt > VMD_WAVE) vmd_slow_flush<INC>(bn, w, lane);
-        const unsigned pre = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-        if (unsure) w.slow[w.nslow + pre] = d2;
-        w.nslow += cnt;
-    }
+    const unsigned long long m = VMD_BALLOT(unsure);
+    if (m) vmd_slow_park<INC>(bn, w, d2, m, unsure, lane);
 }
+#ifndef VMD_NO_INLINE_ASM
+// The pop of the hot loop, hand-scheduled: read one full wave of hits from the top of the stack (w.qtop already lowered),
+// fast-bin them (same arithmetic as vmd_bin_add_deferred) and ds_add under EXEC = sure mask; returns the mask of the lanes
+// that must take the exact path.  9 VALU instructions; hipcc needs 14 for the same C++ (two address adds, a v_mov for the
+// second uniform operand of the fma, trunc + sub instead of fract, and a v_cndmask + v_cmp round trip for the ballot).
+// Requires EXEC = all lanes.
+template <unsigned INC>
+__device__ __forceinline__ unsigned long long vmd_pop_hot(const vmd_binning_t& bn, vmd_wave_acc_t& w, unsigned lane4, unsigned inc, float& d2) {
+    unsigned long long m;
+    float t;
+    int b;
+    asm volatile(
+        "v_add_u32 %[b], %[q], %[l4]\n\t"
+        "ds_read_b32 %[d2], %[b]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_sqrt_f32 %[t], %[d2]\n\t"
+        "s_nop 0\n\t"
+        "v_fma_f32 %[t], %[k], %[t], %[c]\n\t"
+        "v_cvt_flr_i32_f32 %[b], %[t]\n\t"
+        "v_fract_f32 %[t], %[t]\n\t"
+        "v_add_f32 %[t], -0.5, %[t]\n\t"
+        "v_cmp_lt_f32 %[m], |%[t]|, %[half]\n\t"
+        "v_cmp_gt_u32 vcc, %[nb], %[b]\n\t"
+        "s_and_b64 vcc, vcc, %[m]\n\t"
+        "v_lshl_add_u32 %[b], %[b], 2, %[hb]\n\t"
+        "s_mov_b64 exec, vcc\n\t"
+        "ds_add_u32 %[b], %[inc]\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        "s_not_b64 %[m], vcc\n\t"
+        : [m] "=&s"(m), [t] "=&v"(t), [b] "=&v"(b), [d2] "=&v"(d2)
+        : [q] "s"(w.qtop), [l4] "v"(lane4), [k] "s"(bn.fast_k), [c] "v"(w.fast_c), [half] "s"(bn.fast_half),
+          [nb] "s"(bn.nbins), [hb] "s"(w.hbase), [inc] "v"(inc)
+        : "vcc", "scc", "memory");
+    return m;
+}
+#endif
 
 // VARIANT 0: compact the hits of one candidate column onto the wave's LDS stack (order is irrelevant for a
 // histogram, so LIFO: no head pointer, no wrap-around); vmd_drain_full pops full waves of 64 so that
@@ -533,7 +590,7 @@ __device__ __forceinline__ void vmd_push(const vmd_binning_t& bn, vmd_wave_acc_t
         vmd_bin_add<INC>(bn, w.hist, d2, hit);
         return;
     }
-    const unsigned long long mask = __ballot(hit);
+    const unsigned long long mask = VMD_BALLOT(hit);
     if (mask) {
         const unsigned pre = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
         if (hit) *(float*)((char*)w.queue + ((w.qtop - w.qbase) + 4u * pre)) = d2;
@@ -546,10 +603,16 @@ __device__ __forceinline__ void vmd_drain_full(const vmd_binning_t& bn, vmd_wave
     if (VARIANT == 1) return;
     while (w.qtop - w.qbase >= 4u * VMD_WAVE) {
         w.qtop -= 4u * VMD_WAVE;
+#ifndef VMD_NO_INLINE_ASM
+        float v;
+        const unsigned long long m = vmd_pop_hot<INC>(bn, w, 4u * (unsigned)lane, INC, v);
+        if (m) vmd_slow_park<INC>(bn, w, v, m, (m >> lane) & 1ull, lane);
+#else
         __builtin_amdgcn_wave_barrier();
         const float v = *(const float*)((const char*)w.queue + ((w.qtop - w.qbase) + 4u * (unsigned)lane));
         __builtin_amdgcn_wave_barrier();
         vmd_bin_add_deferred<INC>(bn, w, v, true, lane);
+#endif
     }
 }
 
@@ -593,6 +656,29 @@ __device__ __forceinline__ void vmd_push_hot(vmd_wave_acc_t& w, float d2, float 
         : [d2] "v"(d2), [r2] "s"(r2)
         : "vcc", "scc", "memory");
 }
+// same with the own-pencil condition j > i folded in (j wave-uniform, i per lane)
+__device__ __forceinline__ void vmd_push_hot_masked(vmd_wave_acc_t& w, float d2, float r2, unsigned j, unsigned i) {
+    unsigned t, n;
+    unsigned long long m;
+    asm volatile(
+        "s_nop 0\n\t"
+        "v_cmp_gt_f32 vcc, %[r2], %[d2]\n\t"
+        "v_cmp_gt_u32 %[m], %[j], %[i]\n\t"
+        "s_and_b64 vcc, vcc, %[m]\n\t"
+        "s_cbranch_scc0 .Lvmd_nohitm%=\n\t"
+        "v_mbcnt_lo_u32_b32 %[t], vcc_lo, 0\n\t"
+        "v_mbcnt_hi_u32_b32 %[t], vcc_hi, %[t]\n\t"
+        "v_lshl_add_u32 %[t], %[t], 2, %[q]\n\t"
+        "s_mov_b64 exec, vcc\n\t"
+        "ds_write_b32 %[t], %[d2]\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        "s_bcnt1_i32_b64 %[n], vcc\n\t"
+        "s_lshl2_add_u32 %[q], %[n], %[q]\n"
+        ".Lvmd_nohitm%=:"
+        : [q] "+s"(w.qtop), [t] "=&v"(t), [n] "=&s"(n), [m] "=&s"(m)
+        : [d2] "v"(d2), [r2] "s"(r2), [j] "s"(j), [i] "v"(i)
+        : "vcc", "scc", "memory");
+}
 #else
 #define VMD_LDS_ADDRESS(p) 0u
 #endif
@@ -624,6 +710,7 @@ __device__ __forceinline__ void vmd_segment_loop(const vmd_pair_params_t& p, vmd
             for (int u = 0; u < 2; ++u) {
 #ifndef VMD_NO_INLINE_ASM
                 if (VARIANT == 0 && !MASKED) { vmd_push_hot(w, d2[u], r2); continue; }
+                if (VARIANT == 0 && MASKED) { vmd_push_hot_masked(w, d2[u], r2, ja + k0 + 2 * h + u, i); continue; }
 #endif
                 bool hit = d2[u] < r2;
                 if (MASKED) hit = hit && (ja + k0 + 2 * h + u > i);
@@ -705,9 +792,11 @@ __global__ __launch_bounds__(256) VMD_SGPR_CAP(96) void k_rdf_pencil(vmd_pair_pa
     w.hist = s_hist[wave];
     w.queue = s_queue[wave];
     w.qbase = VMD_LDS_ADDRESS(s_queue[wave]);
+    w.hbase = VMD_LDS_ADDRESS(s_hist[wave]);
     w.qtop = w.qbase;
     w.slow = &s_queue[wave][VMD_QUEUE_CAP - VMD_WAVE];
     w.nslow = 0;
+    w.fast_c = vmd_in_vgpr(p.bin.fast_c);
     w.ncols = 0;
     for (int b = lane; b < nbins; b += VMD_WAVE) w.hist[b] = 0u;
     __builtin_amdgcn_wave_barrier();
