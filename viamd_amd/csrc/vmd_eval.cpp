@@ -510,7 +510,9 @@ extern "C" void vmd_eval_clear_data(vmd_script_eval_t* eval) {
     for (auto& p : eval->props) {
         std::fill(p->values.begin(), p->values.end(), 0.0f);
         std::fill(p->weights.begin(), p->weights.end(), 0.0f);
-        std::fill(p->counts.begin(), p->counts.end(), (uint64_t)0);
+        // the 17 MB u64 mirror of a volume is only ever read after vmd_eval_refresh_counts: mark it stale instead of zeroing it
+        if (p->prop.kind == PROP_SDF) p->counts_stale = true;
+        else std::fill(p->counts.begin(), p->counts.end(), (uint64_t)0);
         std::fill(p->weights64.begin(), p->weights64.end(), 0.0);
         std::fill(p->agg_mean.begin(), p->agg_mean.end(), 0.0f);
         std::fill(p->agg_var.begin(), p->agg_var.end(), 0.0f);
@@ -519,7 +521,7 @@ extern "C" void vmd_eval_clear_data(vmd_script_eval_t* eval) {
         p->data.max_value = 0.0f; p->data.min_value = 0.0f;
         p->data.max_range[1] = 0.0f;
         p->dirty = false;
-        p->counts_stale = false;
+        if (p->prop.kind != PROP_SDF) p->counts_stale = false;
         p->data.fingerprint += 1;
     }
     (void)hipStreamSynchronize(eval->stream);
