@@ -16,7 +16,7 @@ for f in sorted(glob.glob(os.path.join(src, "p*", "**", "*counter_collection.csv
     per = defaultdict(float)
     with open(f) as fh:
         for row in csv.DictReader(fh):
-            if row.get("Counter_Name") not in ("FETCH_SIZE", "WRITE_SIZE"):
+            if row.get("Counter_Name") not in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU", "SQ_INSTS_SALU"):
                 continue
             k = row["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]
             per[(k, row["Dispatch_Id"], row["Counter_Name"])] += float(row["Counter_Value"] or 0)
@@ -31,5 +31,9 @@ for k in sorted(acc):
                                    "hbm_bytes_per_launch_raw": fetch + write,
                                    "hbm_bytes_per_launch_read_x2": 2 * fetch + write,
                                    "hbm_bytes_per_frame_raw": (fetch + write) / frames_per_launch}
+    for cname, key in (("SQ_INSTS_VALU", "valu_insts_per_launch"), ("SQ_INSTS_SALU", "salu_insts_per_launch")):
+        v = acc[k].get(cname)
+        if v:
+            res[workload]["kernels"][k][key] = sum(v) / len(v)     # wave-level instructions
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps(res[workload]["kernels"].get("k_rdf_pencil", {}), indent=1))
