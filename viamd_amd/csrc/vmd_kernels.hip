@@ -679,6 +679,125 @@ __device__ __forceinline__ void vmd_push_hot_masked(vmd_wave_acc_t& w, float d2,
         : [d2] "v"(d2), [r2] "s"(r2), [j] "s"(j), [i] "v"(i)
         : "vcc", "scc", "memory");
 }
+// Four columns per asm block: consecutive blocks each drew a hazard nop from the compiler (which cannot see inside) on top
+// of their own, and pinned the order of the packed chains around them; one block per s_load group needs a single wait
+// state and lets hipcc interleave the two packed d2 chains in front of it.
+__device__ __forceinline__ void vmd_push_hot4(vmd_wave_acc_t& w, float d0, float d1, float d2, float d3, float r2) {
+    unsigned t, n;
+    asm volatile(
+        "s_nop 0\n\t"
+        "v_cmp_gt_f32 vcc, %[r2], %[d0]\n\t"
+        "s_cbranch_vccz .Lvmd_p4_0_%=\n\t"
+        "v_mbcnt_lo_u32_b32 %[t], vcc_lo, 0\n\t"
+        "v_mbcnt_hi_u32_b32 %[t], vcc_hi, %[t]\n\t"
+        "v_lshl_add_u32 %[t], %[t], 2, %[q]\n\t"
+        "s_mov_b64 exec, vcc\n\t"
+        "ds_write_b32 %[t], %[d0]\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        "s_bcnt1_i32_b64 %[n], vcc\n\t"
+        "s_lshl2_add_u32 %[q], %[n], %[q]\n"
+        ".Lvmd_p4_0_%=:\n\t"
+        "v_cmp_gt_f32 vcc, %[r2], %[d1]\n\t"
+        "s_cbranch_vccz .Lvmd_p4_1_%=\n\t"
+        "v_mbcnt_lo_u32_b32 %[t], vcc_lo, 0\n\t"
+        "v_mbcnt_hi_u32_b32 %[t], vcc_hi, %[t]\n\t"
+        "v_lshl_add_u32 %[t], %[t], 2, %[q]\n\t"
+        "s_mov_b64 exec, vcc\n\t"
+        "ds_write_b32 %[t], %[d1]\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        "s_bcnt1_i32_b64 %[n], vcc\n\t"
+        "s_lshl2_add_u32 %[q], %[n], %[q]\n"
+        ".Lvmd_p4_1_%=:\n\t"
+        "v_cmp_gt_f32 vcc, %[r2], %[d2]\n\t"
+        "s_cbranch_vccz .Lvmd_p4_2_%=\n\t"
+        "v_mbcnt_lo_u32_b32 %[t], vcc_lo, 0\n\t"
+        "v_mbcnt_hi_u32_b32 %[t], vcc_hi, %[t]\n\t"
+        "v_lshl_add_u32 %[t], %[t], 2, %[q]\n\t"
+        "s_mov_b64 exec, vcc\n\t"
+        "ds_write_b32 %[t], %[d2]\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        "s_bcnt1_i32_b64 %[n], vcc\n\t"
+        "s_lshl2_add_u32 %[q], %[n], %[q]\n"
+        ".Lvmd_p4_2_%=:\n\t"
+        "v_cmp_gt_f32 vcc, %[r2], %[d3]\n\t"
+        "s_cbranch_vccz .Lvmd_p4_3_%=\n\t"
+        "v_mbcnt_lo_u32_b32 %[t], vcc_lo, 0\n\t"
+        "v_mbcnt_hi_u32_b32 %[t], vcc_hi, %[t]\n\t"
+        "v_lshl_add_u32 %[t], %[t], 2, %[q]\n\t"
+        "s_mov_b64 exec, vcc\n\t"
+        "ds_write_b32 %[t], %[d3]\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        "s_bcnt1_i32_b64 %[n], vcc\n\t"
+        "s_lshl2_add_u32 %[q], %[n], %[q]\n"
+        ".Lvmd_p4_3_%=:\n\t"
+        : [q] "+s"(w.qtop), [t] "=&v"(t), [n] "=&s"(n)
+        : [d0] "v"(d0), [d1] "v"(d1), [d2] "v"(d2), [d3] "v"(d3), [r2] "s"(r2)
+        : "vcc", "scc", "memory");
+}
+// own pencil: column k counts only j + k > i.  ik = i - k as signed integers (indices stay far below 2^31), so the four
+// conditions are v_cmp_gt_i32 j, ik with ONE uniform j.
+__device__ __forceinline__ void vmd_push_hot4_masked(vmd_wave_acc_t& w, float d0, float d1, float d2, float d3, float r2,
+                                                     int j, int i0, int i1, int i2, int i3) {
+    unsigned t, n;
+    unsigned long long m;
+    asm volatile(
+        "s_nop 0\n\t"
+        "v_cmp_gt_f32 vcc, %[r2], %[d0]\n\t"
+        "v_cmp_gt_i32 %[m], %[j], %[i0]\n\t"
+        "s_and_b64 vcc, vcc, %[m]\n\t"
+        "s_cbranch_scc0 .Lvmd_p4m_0_%=\n\t"
+        "v_mbcnt_lo_u32_b32 %[t], vcc_lo, 0\n\t"
+        "v_mbcnt_hi_u32_b32 %[t], vcc_hi, %[t]\n\t"
+        "v_lshl_add_u32 %[t], %[t], 2, %[q]\n\t"
+        "s_mov_b64 exec, vcc\n\t"
+        "ds_write_b32 %[t], %[d0]\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        "s_bcnt1_i32_b64 %[n], vcc\n\t"
+        "s_lshl2_add_u32 %[q], %[n], %[q]\n"
+        ".Lvmd_p4m_0_%=:\n\t"
+        "v_cmp_gt_f32 vcc, %[r2], %[d1]\n\t"
+        "v_cmp_gt_i32 %[m], %[j], %[i1]\n\t"
+        "s_and_b64 vcc, vcc, %[m]\n\t"
+        "s_cbranch_scc0 .Lvmd_p4m_1_%=\n\t"
+        "v_mbcnt_lo_u32_b32 %[t], vcc_lo, 0\n\t"
+        "v_mbcnt_hi_u32_b32 %[t], vcc_hi, %[t]\n\t"
+        "v_lshl_add_u32 %[t], %[t], 2, %[q]\n\t"
+        "s_mov_b64 exec, vcc\n\t"
+        "ds_write_b32 %[t], %[d1]\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        "s_bcnt1_i32_b64 %[n], vcc\n\t"
+        "s_lshl2_add_u32 %[q], %[n], %[q]\n"
+        ".Lvmd_p4m_1_%=:\n\t"
+        "v_cmp_gt_f32 vcc, %[r2], %[d2]\n\t"
+        "v_cmp_gt_i32 %[m], %[j], %[i2]\n\t"
+        "s_and_b64 vcc, vcc, %[m]\n\t"
+        "s_cbranch_scc0 .Lvmd_p4m_2_%=\n\t"
+        "v_mbcnt_lo_u32_b32 %[t], vcc_lo, 0\n\t"
+        "v_mbcnt_hi_u32_b32 %[t], vcc_hi, %[t]\n\t"
+        "v_lshl_add_u32 %[t], %[t], 2, %[q]\n\t"
+        "s_mov_b64 exec, vcc\n\t"
+        "ds_write_b32 %[t], %[d2]\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        "s_bcnt1_i32_b64 %[n], vcc\n\t"
+        "s_lshl2_add_u32 %[q], %[n], %[q]\n"
+        ".Lvmd_p4m_2_%=:\n\t"
+        "v_cmp_gt_f32 vcc, %[r2], %[d3]\n\t"
+        "v_cmp_gt_i32 %[m], %[j], %[i3]\n\t"
+        "s_and_b64 vcc, vcc, %[m]\n\t"
+        "s_cbranch_scc0 .Lvmd_p4m_3_%=\n\t"
+        "v_mbcnt_lo_u32_b32 %[t], vcc_lo, 0\n\t"
+        "v_mbcnt_hi_u32_b32 %[t], vcc_hi, %[t]\n\t"
+        "v_lshl_add_u32 %[t], %[t], 2, %[q]\n\t"
+        "s_mov_b64 exec, vcc\n\t"
+        "ds_write_b32 %[t], %[d3]\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        "s_bcnt1_i32_b64 %[n], vcc\n\t"
+        "s_lshl2_add_u32 %[q], %[n], %[q]\n"
+        ".Lvmd_p4m_3_%=:\n\t"
+        : [q] "+s"(w.qtop), [t] "=&v"(t), [n] "=&s"(n), [m] "=&s"(m)
+        : [d0] "v"(d0), [d1] "v"(d1), [d2] "v"(d2), [d3] "v"(d3), [r2] "s"(r2), [j] "s"(j), [i0] "v"(i0), [i1] "v"(i1), [i2] "v"(i2), [i3] "v"(i3)
+        : "vcc", "scc", "memory");
+}
 #else
 #define VMD_LDS_ADDRESS(p) 0u
 #endif
@@ -700,22 +819,28 @@ __device__ __forceinline__ void vmd_segment_loop(const vmd_pair_params_t& p, vmd
     const vmd_f2 sx2 = {sx, sx}, sy2 = {sy, sy}, sz2 = {sz, sz};
     // four columns (two packed pairs) from one s_load_dwordx4 per coordinate
     auto group = [&](const vmd_f4& xj, const vmd_f4& yj, const vmd_f4& zj, unsigned k0) {
+        vmd_f2 d2[2];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const vmd_f2 xj2 = {xj[2 * h], xj[2 * h + 1]}, yj2 = {yj[2 * h], yj[2 * h + 1]}, zj2 = {zj[2 * h], zj[2 * h + 1]};
             vmd_f2 dx = xi2 - xj2, dy = yi2 - yj2, dz = zi2 - zj2;
             if (SHIFT) { dx = dx - sx2; dy = dy - sy2; dz = dz - sz2; }
-            const vmd_f2 d2 = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
+            d2[h] = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+        }
 #ifndef VMD_NO_INLINE_ASM
-                if (VARIANT == 0 && !MASKED) { vmd_push_hot(w, d2[u], r2); continue; }
-                if (VARIANT == 0 && MASKED) { vmd_push_hot_masked(w, d2[u], r2, ja + k0 + 2 * h + u, i); continue; }
+        if (VARIANT == 0) {
+            if (MASKED) vmd_push_hot4_masked(w, d2[0][0], d2[0][1], d2[1][0], d2[1][1], r2, (int)(ja + k0), (int)i, (int)i - 1, (int)i - 2, (int)i - 3);
+            else vmd_push_hot4(w, d2[0][0], d2[0][1], d2[1][0], d2[1][1], r2);
+            vmd_drain_full<VARIANT, INC>(p.bin, w, lane);
+            return;
+        }
 #endif
-                bool hit = d2[u] < r2;
-                if (MASKED) hit = hit && (ja + k0 + 2 * h + u > i);
-                vmd_push<VARIANT, INC>(p.bin, w, hit, d2[u]);
-            }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float v = d2[c >> 1][c & 1];
+            bool hit = v < r2;
+            if (MASKED) hit = hit && (ja + k0 + c > i);
+            vmd_push<VARIANT, INC>(p.bin, w, hit, v);
         }
         vmd_drain_full<VARIANT, INC>(p.bin, w, lane);
     };
