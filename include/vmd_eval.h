@@ -228,6 +228,8 @@ bool vmd_devtraj_upload_atoms(vmd_devtraj_t* t, size_t frame_beg, size_t frame_c
 /* seeded synthetic water box of SURVEY 8d (same integer RNG as oracle S9) for frames [beg,end) */
 bool vmd_devtraj_synth(vmd_devtraj_t* t, uint64_t seed, float L, float sigma, uint32_t n_blob,
                        size_t frame_beg, size_t frame_end);
+/* replace the unit cell of frames [beg,end) (coordinates stay as they are: they are wrapped on use) */
+bool vmd_devtraj_set_cell(vmd_devtraj_t* t, size_t frame_beg, size_t frame_end, const vmd_unitcell_t* cell);
 float* vmd_devtraj_device_ptr(vmd_devtraj_t* t, size_t* frame_stride, size_t* row_stride);
 
 /* host-resident trajectory in pinned memory, float[F][3][npad] (the PCIe-inclusive path: frames cross the bus per batch) */

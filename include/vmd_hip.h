@@ -56,7 +56,9 @@ int vmd_hip_cells_build(void* stream, const float* xyz, size_t frame_stride, siz
 /* K2: RDF pair histogram over a batch from cell-sorted selections (ref may equal tgt -> half shell).
  *   partial   u64[vmd_hip_rdf_partial_words()] scratch (per-wave rows + the work counter)
  *   counts    u64[nbins]  accumulated (+=) with device atomics
- *   variant   0 = wave queue (default), 1 = inline hit path */
+ *   variant   0 = wave queue (default), 1 = inline hit path
+ *   triclinic non-zero: boxes carry tilt factors, the selections were sorted by vmd_hip_cells_build in the unsheared
+ *             coordinates s_k * L_k (SPEC S3t); the grid must satisfy edge >= rmax measured perpendicular to the cell faces */
 int vmd_hip_rdf_num_blocks(void);
 int vmd_hip_set_rdf_nsub(int n);       /* tuning knob: work items per pencil (1..64, 0 = automatic), returns the previous value */
 int vmd_hip_set_rdf_blocks(int n);     /* tuning knob: persistent grid size (8..2048), returns the previous value */
@@ -64,7 +66,7 @@ size_t vmd_hip_rdf_partial_words(void);
 int vmd_hip_rdf_pencil(void* stream, const float* sorted_ref, const uint32_t* cell_start_ref, int nref, int nref_pad,
                        const float* sorted_tgt, const uint32_t* cell_start_tgt, int ntgt, int ntgt_pad,
                        const float* boxes, int B, vmd_grid_t grid, float rmin, float rmax, int nbins,
-                       int same_set, int variant, uint64_t* partial, uint64_t* counts);
+                       int same_set, int variant, int triclinic, uint64_t* partial, uint64_t* counts);
 
 /* general RDF (any periodicity flags, any cutoff, no grid): O(nref*ntgt) per frame, SPEC S3 by comparison */
 int vmd_hip_rdf_brute(void* stream, const float* xyz, size_t frame_stride, size_t row_stride,

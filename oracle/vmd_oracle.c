@@ -81,12 +81,32 @@ static inline void vo_mi_tri_d(const vo_box_t* b, double d[3]) {
     d[1] = s[1] * (double)b->L[1] + (double)b->yz * s[2];
     d[0] = s[0] * (double)b->L[0] + (double)b->xy * s[1] + (double)b->xz * s[2];
 }
-/* pair displacement on fractional coordinates (triclinic S3t): d = cart(ds - rint(ds)) */
-static inline float vo_pair_d2_tri(const vo_box_t* b, const float si[3], const float sj[3]) {
-    float ds[3], d[3];
-    for (int a = 0; a < 3; ++a) { ds[a] = si[a] - sj[a]; ds[a] = ds[a] - rintf(ds[a]); }
-    vo_cart(b, ds, d);
-    return fmaf(d[2], d[2], fmaf(d[1], d[1], d[0] * d[0]));
+/* SPEC S3t wrap: fractional coordinates folded into [0,1), back to Cartesian.  u[3] (optional) receives the unsheared
+ * coordinates s_k * L_k the cell grid bins by. */
+static inline void vo_wrap_tri(const vo_box_t* b, float x, float y, float z, float r[3], float u[3]) {
+    float s[3];
+    vo_frac(b, x, y, z, s);
+    for (int a = 0; a < 3; ++a) {
+        s[a] = s[a] - floorf(s[a]);
+        if (!(s[a] < 1.0f)) s[a] = 0.0f;
+    }
+    r[2] = s[2] * b->L[2];
+    r[1] = fmaf(b->yz, s[2], s[1] * b->L[1]);
+    r[0] = fmaf(b->xz, s[2], fmaf(b->xy, s[1], s[0] * b->L[0]));
+    if (u) { u[0] = s[0] * b->L[0]; u[1] = s[1] * b->L[1]; u[2] = s[2] * b->L[2]; }
+}
+/* SPEC S3t pair: wrapped Cartesian positions; the lattice image n is chosen by rounding the displacement in fractional
+ * space, the displacement itself is the Cartesian difference minus the lattice vector n (same form as S3) */
+static inline float vo_pair_d2_tri(const vo_box_t* b, const float ri[3], const float rj[3]) {
+    const float d0[3] = {ri[0] - rj[0], ri[1] - rj[1], ri[2] - rj[2]};
+    float s[3];
+    vo_frac(b, d0[0], d0[1], d0[2], s);
+    const float nx = rintf(s[0]), ny = rintf(s[1]), nz = rintf(s[2]);
+    const float shx = fmaf(nz, b->xz, fmaf(ny, b->xy, nx * b->L[0]));
+    const float shy = fmaf(nz, b->yz, ny * b->L[1]);
+    const float shz = nz * b->L[2];
+    const float dx = d0[0] - shx, dy = d0[1] - shy, dz = d0[2] - shz;
+    return fmaf(dz, dz, fmaf(dy, dy, dx * dx));
 }
 
 /* S3 on one axis */
@@ -127,10 +147,10 @@ static void vo_gather_wrapped(const float* x, const float* y, const float* z, co
                               const int32_t* idx, size_t n, float* ox, float* oy, float* oz) {
     for (size_t i = 0; i < n; ++i) {
         const int32_t a = idx ? idx[i] : (int32_t)i;
-        if (bx->tri) {          /* S3t works on fractional coordinates */
-            float sfr[3];
-            vo_frac(bx, x[a], y[a], z[a], sfr);
-            ox[i] = sfr[0]; oy[i] = sfr[1]; oz[i] = sfr[2];
+        if (bx->tri) {          /* S3t: wrapped through fractional space */
+            float r[3];
+            vo_wrap_tri(bx, x[a], y[a], z[a], r, NULL);
+            ox[i] = r[0]; oy[i] = r[1]; oz[i] = r[2];
             continue;
         }
         ox[i] = bx->pbc[0] ? vo_wrap(x[a], bx->L[0]) : x[a];
@@ -642,10 +662,10 @@ float vo_distance_com(const float* x, const float* y, const float* z, const vo_c
 
 static float vo_pair_d2(const float* x, const float* y, const float* z, const vo_box_t* bx, int32_t i, int32_t j) {
     if (bx->tri) {
-        float si[3], sj[3];
-        vo_frac(bx, x[i], y[i], z[i], si);
-        vo_frac(bx, x[j], y[j], z[j], sj);
-        return vo_pair_d2_tri(bx, si, sj);
+        float ri[3], rj[3];
+        vo_wrap_tri(bx, x[i], y[i], z[i], ri, NULL);
+        vo_wrap_tri(bx, x[j], y[j], z[j], rj, NULL);
+        return vo_pair_d2_tri(bx, ri, rj);
     }
     const float xi = bx->pbc[0] ? vo_wrap(x[i], bx->L[0]) : x[i];
     const float yi = bx->pbc[1] ? vo_wrap(y[i], bx->L[1]) : y[i];

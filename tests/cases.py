@@ -270,7 +270,32 @@ def triclinic_cases(lib, O, n_water, device=False):
             coords[f][:, idx] = c0 + 0.15 * (coords[f][:, idx] - c0)
     o = np.arange(n_s, N, 3, dtype=np.int32)
     h = np.array([i for i in range(n_s, N) if (i - n_s) % 3], np.int32)
-    check_rdf(lib, O, coords, box, [("goo", o, o, 0.0, 9.0), ("goh", o, h, 0.5, 8.0)], device=device, oracle_method="brute")
+    # pencil grid in the sheared cell (default) and the all-pairs kernel: both must reproduce the oracle's S3t arithmetic
+    import ctypes as C
+    for brute in (0, 1):
+        old = lib.vmd_set_option(b"force_brute", brute)
+        lib.vmd_profile_reset(); lib.vmd_profile_enable(True)
+        try:
+            check_rdf(lib, O, coords, box, [("goo", o, o, 0.0, 9.0), ("goh", o, h, 0.5, 8.0)], device=device, oracle_method="brute")
+        finally:
+            lib.vmd_set_option(b"force_brute", old)
+            lib.vmd_profile_enable(False)
+        n_grid, n_brute = C.c_uint64(0), C.c_uint64(0)
+        lib.vmd_profile_ms(b"rdf_pencil", C.byref(n_grid)); lib.vmd_profile_ms(b"rdf_brute", C.byref(n_brute))
+        assert (n_grid.value, n_brute.value) == ((0, 2) if brute else (2, 0)), "wrong kernel family for the triclinic batch"
+    # strongly sheared cell (tilts at the reduced-cell limit), cell fluctuating from frame to frame, atoms outside the cell
+    rng = np.random.default_rng(77)
+    nO = max(200, n_water // 3)
+    boxes, frames = [], []
+    for f in range(2):
+        Lx, Ly, Lz = 44.0 + f, 40.0 - 0.5 * f, 36.0 + 0.25 * f
+        bx = (Lx, Ly, Lz, 0.5 * Lx, -0.5 * Lx + f, 0.5 * Ly - 0.5 * f)
+        Af = np.array([[bx[0], bx[3], bx[4]], [0, bx[1], bx[5]], [0, 0, bx[2]]])
+        frames.append((Af @ rng.uniform(-0.3, 1.3, (3, nO))).astype(np.float32))
+        boxes.append(bx)
+    c2 = np.stack(frames)
+    a = np.arange(0, nO, 2, dtype=np.int32); b2 = np.arange(1, nO, 2, dtype=np.int32); allo = np.arange(nO, dtype=np.int32)
+    check_rdf(lib, O, c2, boxes, [("gaa", allo, allo, 0.0, 8.0), ("gab", a, b2, 1.0, 7.5)], device=device, oracle_method="brute")
     check_sdf(lib, O, coords, box, structures, mass, o, 6.0, device=device)
     check_distances(lib, O, coords, box, mass, [("d", structures[0], structures[1], L.DIST_COM), ("m", structures[0], structures[2], L.DIST_MIN),
                                                ("x", structures[1], structures[2], L.DIST_MAX), ("p", structures[0][:2], o[:3], L.DIST_PAIR)],

@@ -386,3 +386,32 @@ def test_filtered_evaluation_at_config2_shape(gpu_lib, oracle):
     filt.clear_data()
     assert filt.frame_range(sysm, traj, 7, 50)
     assert filt.frame_stats() == (9 + 2, 32)       # frames 7-15 and 48-49 computed, blocks [16,32) [32,48) reused
+
+
+def test_triclinic_config2_shape_against_oracle(gpu_lib, oracle):
+    """The 100k-atom water box evaluated in a sheared cell of the same volume: the pencil grid in fractional space against
+    the oracle's all-pairs S3t evaluation (1.1e9 pair tests), one frame, plus grid == brute on the device for more frames."""
+    N, box, tilt = 100002, 100.0, (30.0, -20.0, 25.0)
+    ocell = oracle.make_cell(box, 7, tilt)
+    vcell = V.make_unitcell(box, tilt=tilt)
+    traj = V.DeviceTrajectory(3, N)
+    traj.synth(2, box, 0.05)
+    traj.set_cell(vcell)
+    ox = cases.oxygen(N)
+    ir = V.ScriptIR(); ir.add_rdf("g", ox, ox, 12.0)
+    sysm = V.MolSystem(N, unitcell=vcell)
+    ev = V.ScriptEval(3, ir)
+    assert ev.frame_range(sysm, traj, 0, 1)
+    xyz, _ = traj.download_frame(0)
+    counts, hits = oracle.rdf_frame(xyz[0], xyz[1], xyz[2], ocell, ox, ox, 0.0, 12.0, method="brute")
+    assert hits > 7_000_000
+    np.testing.assert_array_equal(ev.property_data("g").counts, counts)
+    assert ev.frame_range(sysm, traj, 1, 3)
+    grid = ev.property_data("g").counts.copy()
+    old = gpu_lib.vmd_set_option(b"force_brute", 1)
+    try:
+        ev2 = V.ScriptEval(3, ir)
+        assert ev2.frame_range(sysm, traj, 0, 3)
+    finally:
+        gpu_lib.vmd_set_option(b"force_brute", old)
+    np.testing.assert_array_equal(ev2.property_data("g").counts, grid)

@@ -121,6 +121,7 @@ SIGNATURES = [
     ("vmd_devtraj_interface", C.POINTER(TrajectoryI), [_vp]),
     ("vmd_devtraj_upload_frame", C.c_bool, [_vp, C.c_size_t, C.POINTER(Unitcell), c_float_p, c_float_p, c_float_p]),
     ("vmd_devtraj_upload_atoms", C.c_bool, [_vp, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, c_float_p]),
+    ("vmd_devtraj_set_cell", C.c_bool, [_vp, C.c_size_t, C.c_size_t, C.POINTER(Unitcell)]),
     ("vmd_devtraj_synth", C.c_bool, [_vp, C.c_uint64, C.c_float, C.c_float, C.c_uint32, C.c_size_t, C.c_size_t]),
     ("vmd_devtraj_device_ptr", _vp, [_vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     ("vmd_hosttraj_create", _vp, [C.c_size_t, C.c_size_t]),
@@ -151,7 +152,7 @@ SIGNATURES = [
     ("vmd_hip_cells_scratch_words", C.c_size_t, [Grid, C.c_int]),
     ("vmd_hip_rdf_partial_words", C.c_size_t, []),
     ("vmd_hip_rdf_pencil", C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, C.c_int, C.c_int, _vp, C.c_int, Grid,
-                                     C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, _vp, _vp]),
+                                     C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     ("vmd_hip_rdf_brute", C.c_int, [_vp, _vp, C.c_size_t, C.c_size_t, _vp, C.c_uint32, C.c_int, _vp, C.c_int, _vp, C.c_int,
                                     C.c_float, C.c_float, C.c_int, _vp]),
     ("vmd_hip_sdf_align", C.c_int, [_vp, _vp, C.c_size_t, C.c_size_t, _vp, C.c_uint32, C.c_int, _vp, _vp, C.c_int, C.c_int, _vp,

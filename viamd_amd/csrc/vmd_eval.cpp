@@ -862,24 +862,34 @@ static uint32_t batch_pbc(const Stage& st) {
 // pencil grid for a batch and cutoff; false when the batch cannot use the grid kernel
 static bool choose_grid(const Stage& st, size_t nb, float rmax, vmd_grid_t* g) {
     if (g_opt.force_brute) return false;
-    if (batch_pbc(st) != VMD_UNITCELL_PBC_ALL) return false;
-    float Lmin[3] = {3.4e38f, 3.4e38f, 3.4e38f};
-    for (size_t b = 0; b < nb; ++b) for (int a = 0; a < 3; ++a) Lmin[a] = std::min(Lmin[a], st.h_boxes[9 * b + a]);
-    // minimum image must be unique for every hit: rmax < L/2 with margin
-    for (int a = 0; a < 3; ++a) if (!(rmax * 2.0f * 1.001f < Lmin[a])) return false;
+    const uint32_t pbc = batch_pbc(st);
+    if ((pbc & VMD_UNITCELL_PBC_ALL) != VMD_UNITCELL_PBC_ALL) return false;
+    // smallest extent per axis over the batch, measured perpendicular to the cell faces (SPEC S3t: a triclinic cell's
+    // pencils are sheared, what has to be >= rmax is their width w_k = 1 / |reciprocal vector k|)
+    float wmin[3] = {3.4e38f, 3.4e38f, 3.4e38f}, Lxmin = 3.4e38f;
+    for (size_t b = 0; b < nb; ++b) {
+        const float* q = &st.h_boxes[9 * b];
+        const double Lx = q[0], Ly = q[1], Lz = q[2], xy = q[6], xz = q[7], yz = q[8];
+        const double wx = Lx / std::sqrt(1.0 + (xy / Ly) * (xy / Ly) + ((xy * yz - Ly * xz) / (Ly * Lz)) * ((xy * yz - Ly * xz) / (Ly * Lz)));
+        const double wy = Ly / std::sqrt(1.0 + (yz / Lz) * (yz / Lz));
+        wmin[0] = std::min(wmin[0], (float)wx); wmin[1] = std::min(wmin[1], (float)wy); wmin[2] = std::min(wmin[2], (float)Lz);
+        Lxmin = std::min(Lxmin, q[0]);
+    }
+    // minimum image must be unique for every hit: rmax < w/2 with margin
+    for (int a = 0; a < 3; ++a) if (!(rmax * 2.0f * 1.001f < wmin[a])) return false;
     int n[3];
     for (int a = 1; a < 3; ++a) {
-        int k = (int)std::floor(Lmin[a] / rmax);
-        while (k > 1 && ((float)k / Lmin[a]) * rmax > 0.9999f) k -= 1;
+        int k = (int)std::floor(wmin[a] / rmax);
+        while (k > 1 && ((float)k / wmin[a]) * rmax > 0.9999f) k -= 1;
         if (k < 2) return false;
         n[a] = std::min(k, 1024);
     }
     const float cx = rmax / (float)std::max(1, g_opt.nxf_divisor.load());
-    int nxf = (int)std::floor(Lmin[0] / cx);
+    int nxf = (int)std::floor(Lxmin / cx);
     nxf = std::max(1, std::min(nxf, 4096));
     // keep the cell table small enough for the LDS-resident build (24576 counters) as long as the fine cells stay <= rmax/3
     const int nxf_lds = 24575 / (n[1] * n[2]);
-    if (nxf > nxf_lds && nxf_lds >= (int)std::ceil(3.0f * Lmin[0] / rmax)) nxf = nxf_lds;
+    if (nxf > nxf_lds && nxf_lds >= (int)std::ceil(3.0f * Lxmin / rmax)) nxf = nxf_lds;
     g->nxf = nxf; g->ny = n[1]; g->nz = n[2];
     const long long ncell = (long long)nxf * n[1] * n[2];
     if (ncell > (1ll << 26)) return false;
@@ -1063,7 +1073,7 @@ static bool process_range(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
                     KRN_OK(vmd_hip_rdf_pencil(e->stream, sa->sorted.p, sa->cell_start.p, (int)sa->idx.size(), sa->nsel_pad,
                                               sb->sorted.p, sb->cell_start.p, (int)sb->idx.size(), sb->nsel_pad,
                                               src.d_boxes.p, (int)nb, g, d.rmin, d.rmax, VMD_RDF_NUM_BINS,
-                                              p->same_set ? 1 : 0, g_opt.rdf_variant, e->d_partial.p, acc));
+                                              p->same_set ? 1 : 0, g_opt.rdf_variant, (pbc & 8u) ? 1 : 0, e->d_partial.p, acc));
                     e->prof.end(e->stream);
                 } else {
                     Selection* sa = e->sels[p->sel_a].get();
@@ -1324,6 +1334,12 @@ extern "C" bool vmd_devtraj_synth(vmd_devtraj_t* t, uint64_t seed, float L, floa
     }
     HIP_OK(hipDeviceSynchronize());
     for (size_t f = frame_beg; f < frame_end; ++f) t->cells[f] = c;
+    return true;
+}
+
+extern "C" bool vmd_devtraj_set_cell(vmd_devtraj_t* t, size_t frame_beg, size_t frame_end, const vmd_unitcell_t* cell) {
+    if (!t || !cell || frame_end > t->num_frames || frame_beg > frame_end) return vmd_fail("vmd_devtraj_set_cell: bad frame range");
+    for (size_t f = frame_beg; f < frame_end; ++f) t->cells[f] = *cell;
     return true;
 }
 

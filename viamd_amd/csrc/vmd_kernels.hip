@@ -123,17 +123,39 @@ __device__ __forceinline__ void vmd_cart(const vmd_box_t& b, float sx, float sy,
     dy = fmaf(b.yz, sz, sy * b.Ly);
     dx = fmaf(b.xz, sz, fmaf(b.xy, sy, sx * b.Lx));
 }
-// squared minimum-image distance of two atoms given by fractional coordinates (triclinic)
-__device__ __forceinline__ float vmd_pair_d2_tri(const vmd_box_t& b, float six, float siy, float siz, float sjx, float sjy, float sjz) {
-    float dsx = six - sjx, dsy = siy - sjy, dsz = siz - sjz;
-    dsx = dsx - rintf(dsx); dsy = dsy - rintf(dsy); dsz = dsz - rintf(dsz);
-    float dx, dy, dz;
-    vmd_cart(b, dsx, dsy, dsz, dx, dy, dz);
-    return vmd_d2(dx, dy, dz);
+// SPEC S3t wrap: fractional coordinates folded into [0,1), back to Cartesian; (ux,uy,uz) = s_k * L_k are the unsheared
+// coordinates the cell grid bins by
+__device__ __forceinline__ void vmd_wrap_tri(const vmd_box_t& b, float x, float y, float z, float& xw, float& yw, float& zw,
+                                             float& ux, float& uy, float& uz) {
+    float sx, sy, sz;
+    vmd_frac(b, x, y, z, sx, sy, sz);
+    sx = sx - floorf(sx); if (!(sx < 1.0f)) sx = 0.0f;
+    sy = sy - floorf(sy); if (!(sy < 1.0f)) sy = 0.0f;
+    sz = sz - floorf(sz); if (!(sz < 1.0f)) sz = 0.0f;
+    ux = sx * b.Lx; uy = sy * b.Ly; uz = sz * b.Lz;
+    zw = uz;
+    yw = fmaf(b.yz, sz, uy);
+    xw = fmaf(b.xz, sz, fmaf(b.xy, sy, ux));
 }
-// the coordinates pair kernels work on: wrapped Cartesian (S2) for orthorhombic / open cells, fractional for triclinic
+// SPEC S3t lattice vector n = (nx, ny, nz) in Cartesian components
+__device__ __forceinline__ void vmd_lattice_shift(float Lx, float Ly, float Lz, float xy, float xz, float yz, float nx, float ny, float nz,
+                                                  float& shx, float& shy, float& shz) {
+    shx = fmaf(nz, xz, fmaf(ny, xy, nx * Lx));
+    shy = fmaf(nz, yz, ny * Ly);
+    shz = nz * Lz;
+}
+// SPEC S3t pair on wrapped Cartesian positions: image by rounding the displacement in fractional space
+__device__ __forceinline__ float vmd_pair_d2_tri(const vmd_box_t& b, float xi, float yi, float zi, float xj, float yj, float zj) {
+    const float d0x = xi - xj, d0y = yi - yj, d0z = zi - zj;
+    float sx, sy, sz;
+    vmd_frac(b, d0x, d0y, d0z, sx, sy, sz);
+    float shx, shy, shz;
+    vmd_lattice_shift(b.Lx, b.Ly, b.Lz, b.xy, b.xz, b.yz, rintf(sx), rintf(sy), rintf(sz), shx, shy, shz);
+    return vmd_d2(d0x - shx, d0y - shy, d0z - shz);
+}
+// the coordinates pair kernels work on: wrapped Cartesian (S2 per axis for orthorhombic / open cells, S3t for triclinic)
 __device__ __forceinline__ void vmd_pair_coords(const vmd_box_t& b, float x, float y, float z, float& ox, float& oy, float& oz) {
-    if (b.tri) { vmd_frac(b, x, y, z, ox, oy, oz); return; }
+    if (b.tri) { float ux, uy, uz; vmd_wrap_tri(b, x, y, z, ox, oy, oz, ux, uy, uz); return; }
     ox = b.px ? vmd_wrap(x, b.Lx, b.iLx) : x;
     oy = b.py ? vmd_wrap(y, b.Ly, b.iLy) : y;
     oz = b.pz ? vmd_wrap(z, b.Lz, b.iLz) : z;
@@ -242,12 +264,20 @@ __device__ __forceinline__ uint32_t vmd_cell_of(const vmd_cells_params_t& p, int
     const float* fx = p.xyz + (size_t)b * p.frame_stride;
     const float* bq = p.boxes + (size_t)VMD_BOX_STRIDE * b;
     const float Lx = bq[0], Ly = bq[1], Lz = bq[2], iLx = bq[3], iLy = bq[4], iLz = bq[5];
-    xw = vmd_wrap(fx[a], Lx, iLx);
-    yw = vmd_wrap(fx[p.row_stride + a], Ly, iLy);
-    zw = vmd_wrap(fx[2 * p.row_stride + a], Lz, iLz);
-    const int cx = vmd_cell_coord(xw, (float)p.grid.nxf * iLx, p.grid.nxf);
-    const int cy = vmd_cell_coord(yw, (float)p.grid.ny * iLy, p.grid.ny);
-    const int cz = vmd_cell_coord(zw, (float)p.grid.nz * iLz, p.grid.nz);
+    float ux, uy, uz;     // what the grid bins by: the wrapped coordinates themselves, or s_k * L_k in a triclinic cell
+    if (bq[6] != 0.0f || bq[7] != 0.0f || bq[8] != 0.0f) {
+        vmd_box_t bx;
+        bx.Lx = Lx; bx.Ly = Ly; bx.Lz = Lz; bx.iLx = iLx; bx.iLy = iLy; bx.iLz = iLz; bx.xy = bq[6]; bx.xz = bq[7]; bx.yz = bq[8];
+        bx.px = bx.py = bx.pz = bx.tri = true;
+        vmd_wrap_tri(bx, fx[a], fx[p.row_stride + a], fx[2 * p.row_stride + a], xw, yw, zw, ux, uy, uz);
+    } else {
+        ux = xw = vmd_wrap(fx[a], Lx, iLx);
+        uy = yw = vmd_wrap(fx[p.row_stride + a], Ly, iLy);
+        uz = zw = vmd_wrap(fx[2 * p.row_stride + a], Lz, iLz);
+    }
+    const int cx = vmd_cell_coord(ux, (float)p.grid.nxf * iLx, p.grid.nxf);
+    const int cy = vmd_cell_coord(uy, (float)p.grid.ny * iLy, p.grid.ny);
+    const int cz = vmd_cell_coord(uz, (float)p.grid.nz * iLz, p.grid.nz);
     return (uint32_t)((cz * p.grid.ny + cy) * p.grid.nxf + cx);
 }
 
@@ -903,7 +933,10 @@ __device__ __forceinline__ int vmd_next_item(unsigned* counters, int& q, int& tr
 
 // SGPR cap: the kernel wants 106 SGPRs (6 waves/SIMD); at 96 a 7th wave fits and the extra spills land in the outer
 // (per work item / per segment) loops.  Measured +1.7 % on c2 (profiles/r01s_ab.txt); a cap of 80 (8 waves) gives it back.
-template <int VARIANT, bool SAME>
+// TRI: triclinic cell (SPEC S3t).  Pencils and fine cells live in the unsheared coordinates s_k * L_k; a neighbour pencil's
+// periodic image is displaced by the lattice vector (kx, nb, nc), and because the Cartesian x of its atoms is
+// s_x*Lx + xy*s_y + xz*s_z, the x window is widened by the range that offset takes over the pencil's cross-section.
+template <int VARIANT, bool SAME, bool TRI>
 __global__ __launch_bounds__(256) VMD_SGPR_CAP(96) void k_rdf_pencil(vmd_pair_params_t p) {
     __shared__ unsigned s_hist[4][VMD_MAX_BINS];
     __shared__ float s_queue[4][VMD_QUEUE_CAP];
@@ -947,6 +980,8 @@ __global__ __launch_bounds__(256) VMD_SGPR_CAP(96) void k_rdf_pencil(vmd_pair_pa
         vmd_cf32* boxes = (vmd_cf32*)p.boxes;
         const float Lx = boxes[VMD_BOX_STRIDE * b + 0], Ly = boxes[VMD_BOX_STRIDE * b + 1], Lz = boxes[VMD_BOX_STRIDE * b + 2];
         const float inv_cx = (float)nxf * boxes[VMD_BOX_STRIDE * b + 3];
+        const float txy = TRI ? boxes[VMD_BOX_STRIDE * b + 6] : 0.0f, txz = TRI ? boxes[VMD_BOX_STRIDE * b + 7] : 0.0f,
+                    tyz = TRI ? boxes[VMD_BOX_STRIDE * b + 8] : 0.0f;
         vmd_cu32* csr = (vmd_cu32*)p.cs_ref + (size_t)b * (p.grid.ncell + 1);
         vmd_cu32* cst = (vmd_cu32*)p.cs_tgt + (size_t)b * (p.grid.ncell + 1);
         const float* __restrict__ sr = p.sref + (size_t)b * 3 * p.nref_pad;
@@ -964,18 +999,27 @@ __global__ __launch_bounds__(256) VMD_SGPR_CAP(96) void k_rdf_pencil(vmd_pair_pa
             const float xhi = vmd_uniform(vmd_wave_max(valid ? xi : -3.0e38f));
 
             for (int dz = SAME ? 0 : -1; dz <= 1; ++dz) {
-                int qz = pz + dz; float sz = 0.0f;
-                if (qz < 0) { qz += nz; sz = -Lz; } else if (qz >= nz) { qz -= nz; sz = Lz; }
+                int qz = pz + dz; float sz = 0.0f, nc = 0.0f;
+                if (qz < 0) { qz += nz; sz = -Lz; nc = -1.0f; } else if (qz >= nz) { qz -= nz; sz = Lz; nc = 1.0f; }
                 for (int dy = -1; dy <= 1; ++dy) {
                     if (SAME && dz == 0 && dy < 0) continue;
-                    int qy = py + dy; float sy = 0.0f;
-                    if (qy < 0) { qy += ny; sy = -Ly; } else if (qy >= ny) { qy -= ny; sy = Ly; }
+                    int qy = py + dy; float sy = 0.0f, nb = 0.0f;
+                    if (qy < 0) { qy += ny; sy = -Ly; nb = -1.0f; } else if (qy >= ny) { qy -= ny; sy = Ly; nb = 1.0f; }
                     const bool own = SAME && dz == 0 && dy == 0;
                     const int q = qz * ny + qy;
+                    float offmin = 0.0f, offmax = 0.0f;
+                    if (TRI) {
+                        // range of xy*s_y + xz*s_z over the cross-section of pencil q (+ head room for the roundings)
+                        const float y0 = txy * ((float)qy / (float)ny), y1 = txy * ((float)(qy + 1) / (float)ny);
+                        const float z0 = txz * ((float)qz / (float)nz), z1 = txz * ((float)(qz + 1) / (float)nz);
+                        offmin = fminf(y0, y1) + fminf(z0, z1) - 1.0e-3f;
+                        offmax = fmaxf(y0, y1) + fmaxf(z0, z1) + 1.0e-3f;
+                    }
                     for (int kx = -1; kx <= 1; ++kx) {
-                        const float sx = (float)kx * Lx;
-                        const float lo = (xlo - p.rpad) - sx;
-                        const float hi = (xhi + p.rpad) - sx;
+                        float sx = (float)kx * Lx;
+                        if (TRI) vmd_lattice_shift(Lx, Ly, Lz, txy, txz, tyz, (float)kx, nb, nc, sx, sy, sz);
+                        const float lo = (xlo - p.rpad) - sx - offmax;
+                        const float hi = (xhi + p.rpad) - sx - offmin;
                         if (hi < 0.0f || lo >= Lx) continue;
                         const int ca = lo <= 0.0f ? 0 : vmd_cell_coord(lo, inv_cx, nxf);
                         const int cb = hi >= Lx ? nxf - 1 : vmd_cell_coord(hi, inv_cx, nxf);
@@ -1609,7 +1653,7 @@ extern "C" size_t vmd_hip_rdf_partial_words(void) {
 extern "C" int vmd_hip_rdf_pencil(void* stream, const float* sorted_ref, const uint32_t* cell_start_ref, int nref, int nref_pad,
                                   const float* sorted_tgt, const uint32_t* cell_start_tgt, int ntgt, int ntgt_pad,
                                   const float* boxes, int B, vmd_grid_t grid, float rmin, float rmax, int nbins,
-                                  int same_set, int variant, uint64_t* partial, uint64_t* counts) {
+                                  int same_set, int variant, int triclinic, uint64_t* partial, uint64_t* counts) {
     hipStream_t s = (hipStream_t)stream;
     if (nbins <= 0 || nbins > VMD_MAX_BINS) return (int)hipErrorInvalidValue;
     if (B <= 0 || nref <= 0 || ntgt <= 0) return 0;
@@ -1643,12 +1687,16 @@ extern "C" int vmd_hip_rdf_pencil(void* stream, const float* sorted_ref, const u
     if (nblocks < 8) nblocks = 8;
     if (nblocks > g_rdf_blocks) nblocks = g_rdf_blocks;
     const dim3 g(nblocks), blk(256);
-    if (same_set) {
-        if (variant == 1) hipLaunchKernelGGL((k_rdf_pencil<1, true>), g, blk, 0, s, p);
-        else hipLaunchKernelGGL((k_rdf_pencil<0, true>), g, blk, 0, s, p);
-    } else {
-        if (variant == 1) hipLaunchKernelGGL((k_rdf_pencil<1, false>), g, blk, 0, s, p);
-        else hipLaunchKernelGGL((k_rdf_pencil<0, false>), g, blk, 0, s, p);
+    const int which = (variant == 1 ? 4 : 0) | (same_set ? 2 : 0) | (triclinic ? 1 : 0);
+    switch (which) {
+    case 0: hipLaunchKernelGGL((k_rdf_pencil<0, false, false>), g, blk, 0, s, p); break;
+    case 1: hipLaunchKernelGGL((k_rdf_pencil<0, false, true>), g, blk, 0, s, p); break;
+    case 2: hipLaunchKernelGGL((k_rdf_pencil<0, true, false>), g, blk, 0, s, p); break;
+    case 3: hipLaunchKernelGGL((k_rdf_pencil<0, true, true>), g, blk, 0, s, p); break;
+    case 4: hipLaunchKernelGGL((k_rdf_pencil<1, false, false>), g, blk, 0, s, p); break;
+    case 5: hipLaunchKernelGGL((k_rdf_pencil<1, false, true>), g, blk, 0, s, p); break;
+    case 6: hipLaunchKernelGGL((k_rdf_pencil<1, true, false>), g, blk, 0, s, p); break;
+    default: hipLaunchKernelGGL((k_rdf_pencil<1, true, true>), g, blk, 0, s, p); break;
     }
     VMD_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_hist_reduce, dim3((nbins + 255) / 256, (nblocks + 31) / 32), dim3(256), 0, s, (const uint64_t*)partial, nblocks, nbins, counts);

@@ -164,6 +164,12 @@ class DeviceTrajectory:
         if not self.lib.vmd_devtraj_synth(self.h, int(seed), float(L_box), float(sigma), int(n_blob), int(frame_beg), int(frame_end)):
             raise VmdError(self.lib.last_error())
 
+    def set_cell(self, cell, frame_beg=0, frame_end=None):
+        """Replace the unit cell of frames [beg, end); coordinates are wrapped on use (e.g. a sheared cell of the same volume)."""
+        frame_end = self._num_frames if frame_end is None else frame_end
+        if not self.lib.vmd_devtraj_set_cell(self.h, int(frame_beg), int(frame_end), C.byref(cell)):
+            raise VmdError(self.lib.last_error())
+
     def download_frame(self, frame):
         out = np.zeros((3, self._num_atoms), np.float32)
         hdr = L.FrameHeader()
