@@ -232,6 +232,14 @@ bool vmd_devtraj_synth(vmd_devtraj_t* t, uint64_t seed, float L, float sigma, ui
 bool vmd_devtraj_set_cell(vmd_devtraj_t* t, size_t frame_beg, size_t frame_end, const vmd_unitcell_t* cell);
 float* vmd_devtraj_device_ptr(vmd_devtraj_t* t, size_t* frame_stride, size_t* row_stride);
 
+/* DCD (CHARMM / NAMD) trajectory file as a vmd_trajectory_i — VIAMD attaches these through md_dcd_attach_from_file
+ * (src/loader.cpp:151-152).  Random access, either byte order, unit-cell block -> {x,y,z,xy,xz,yz}; NULL + vmd_last_error
+ * on failure.  load_frame is thread safe (pread). */
+typedef struct vmd_dcdtraj_t vmd_dcdtraj_t;
+vmd_dcdtraj_t*    vmd_dcdtraj_open(const char* path);
+void              vmd_dcdtraj_close(vmd_dcdtraj_t* t);
+vmd_trajectory_i* vmd_dcdtraj_interface(vmd_dcdtraj_t* t);
+
 /* host-resident trajectory in pinned memory, float[F][3][npad] (the PCIe-inclusive path: frames cross the bus per batch) */
 typedef struct vmd_hosttraj_t vmd_hosttraj_t;
 vmd_hosttraj_t*   vmd_hosttraj_create(size_t num_frames, size_t num_atoms);

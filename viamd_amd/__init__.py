@@ -8,7 +8,9 @@ from ._lib import (DIST_COM, DIST_MAX, DIST_MIN, DIST_PAIR, FLAG_DISTRIBUTION, F
                    RDF_NUM_BINS, VOLUME_DIM, VmdLib, default_lib)
 from .eval import (MolSystem, PropertyDataView, ScriptEval, ScriptIR, VmdError, compute_histogram_masked,
                    downsample_histogram, make_unitcell)
+from .dcd import DcdTrajectory, write_dcd
 from .trajectory import DeviceTrajectory, HostTrajectory, PinnedHostTrajectory
 
-__all__ = ["ScriptIR", "ScriptEval", "MolSystem", "HostTrajectory", "DeviceTrajectory", "PinnedHostTrajectory", "PropertyDataView", "VmdError",
+__all__ = ["ScriptIR", "ScriptEval", "MolSystem", "HostTrajectory", "DeviceTrajectory", "PinnedHostTrajectory", "DcdTrajectory", "write_dcd",
+           "PropertyDataView", "VmdError",
            "make_unitcell", "downsample_histogram", "compute_histogram_masked", "VmdLib", "default_lib"]

@@ -128,6 +128,9 @@ SIGNATURES = [
     ("vmd_hosttraj_free", None, [_vp]),
     ("vmd_hosttraj_interface", C.POINTER(TrajectoryI), [_vp]),
     ("vmd_hosttraj_frame_ptr", c_float_p, [_vp, C.c_size_t, C.POINTER(C.c_size_t)]),
+    ("vmd_dcdtraj_open", _vp, [C.c_char_p]),
+    ("vmd_dcdtraj_close", None, [_vp]),
+    ("vmd_dcdtraj_interface", C.POINTER(TrajectoryI), [_vp]),
     ("vmd_hosttraj_set_cell", C.c_bool, [_vp, C.c_size_t, C.POINTER(Unitcell)]),
     ("vmd_hosttraj_copy_from_device", C.c_bool, [_vp, _vp, C.c_size_t, C.c_size_t]),
     ("vmd_downsample_histogram", None, [c_float_p, C.c_int, c_float_p, c_float_p, C.c_int]),

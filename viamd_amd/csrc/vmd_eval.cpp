@@ -16,6 +16,7 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -52,6 +53,7 @@ struct Options {
     std::atomic<int> rdf_variant{0};     // 0 queue, 1 inline
     std::atomic<int> batch_frames{0};    // 0 = auto
     std::atomic<int> force_brute{0};
+    std::atomic<int> load_threads{8};    // host threads decoding one staged batch through load_frame
     std::atomic<int> nxf_divisor{8};     // fine x cell = rmax / nxf_divisor
     std::atomic<int> cells_aos{1};       // sort through 16-byte records + repack
     std::atomic<int> sdf_dense{0};       // dense-target SDF scatter (stream whole frames, select by tag): measured slower, off
@@ -63,6 +65,7 @@ extern "C" int vmd_set_option(const char* key, int value) {
     if (!strcmp(key, "rdf_variant")) o = &g_opt.rdf_variant;
     else if (!strcmp(key, "batch_frames")) o = &g_opt.batch_frames;
     else if (!strcmp(key, "force_brute")) o = &g_opt.force_brute;
+    else if (!strcmp(key, "load_threads")) o = &g_opt.load_threads;
     else if (!strcmp(key, "nxf_divisor")) o = &g_opt.nxf_divisor;
     else if (!strcmp(key, "cells_aos")) o = &g_opt.cells_aos;
     else if (!strcmp(key, "sdf_dense")) o = &g_opt.sdf_dense;
@@ -75,6 +78,8 @@ extern "C" int vmd_set_option(const char* key, int value) {
 }
 
 extern "C" const char* vmd_last_error(void) { return g_last_error.c_str(); }
+// for the other translation units of the library (not part of the public headers)
+extern "C" void vmd_set_last_error(const char* msg) { g_last_error = msg ? msg : ""; }
 extern "C" const char* vmd_version(void) { return "viamd_amd 0.1 (gfx950)"; }
 
 extern "C" int vmd_device_count(void) {
@@ -808,14 +813,41 @@ static bool fetch_stage(vmd_script_eval_t* e, Stage& st, vmd_trajectory_i* traj,
             st.hcap = need;
         }
         if (!st.d.ensure(need)) return false;
-        for (size_t b = 0; b < nb; ++b) {
-            vmd_frame_header_t hdr;
-            memset(&hdr, 0, sizeof(hdr));
-            float* x = st.h + b * 3 * npad;
-            if (!traj->load_frame(traj->inst, (int64_t)(f0 + b), &hdr, x, x + npad, x + 2 * npad))
-                return vmd_fail("trajectory load_frame(%zu) failed", f0 + b);
-            st.cells[b] = hdr.unitcell;
+        // md_trajectory_load_frame is called from all of VIAMD's pool threads at once (src/main.cpp:995-996 inside the
+        // enkiTS range tasks), so the decoder behind it is re-entrant: decode the batch on a few threads
+        const size_t nthreads = std::max<size_t>(1, std::min<size_t>((size_t)std::max(1, g_opt.load_threads.load()), nb / 4));
+        std::atomic<size_t> next{0};
+        std::atomic<bool> ok{true};
+        std::mutex err_mtx;
+        std::string err;
+        auto work = [&]() {
+            for (;;) {
+                const size_t b = next.fetch_add(1);
+                if (b >= nb || !ok.load()) break;
+                vmd_frame_header_t hdr;
+                memset(&hdr, 0, sizeof(hdr));
+                float* x = st.h + b * 3 * npad;
+                if (!traj->load_frame(traj->inst, (int64_t)(f0 + b), &hdr, x, x + npad, x + 2 * npad)) {
+                    std::lock_guard<std::mutex> l(err_mtx);
+                    if (ok.exchange(false)) {
+                        char buf[96];
+                        snprintf(buf, sizeof(buf), "trajectory load_frame(%zu) failed", f0 + b);
+                        err = buf;
+                        if (!g_last_error.empty()) err += ": " + g_last_error;     // the decoder's own message (this thread's)
+                    }
+                    break;
+                }
+                st.cells[b] = hdr.unitcell;
+            }
+        };
+        if (nthreads == 1) work();
+        else {
+            std::vector<std::thread> pool;
+            for (size_t t = 1; t < nthreads; ++t) pool.emplace_back(work);
+            work();
+            for (auto& t : pool) t.join();
         }
+        if (!ok.load()) return vmd_fail("%s", err.c_str());
         HIP_OK(hipMemcpyAsync(st.d.p, st.h, need * sizeof(float), hipMemcpyHostToDevice, e->copy_stream));
         st.base = st.d.p;
         st.frame_stride = 3 * npad;
