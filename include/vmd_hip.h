@@ -48,8 +48,12 @@ int vmd_hip_cells_split_blocks(vmd_grid_t grid, int nsel);
 int vmd_hip_set_cells_split(int on);   /* A-B switch, returns the previous value */
 /* u32 words per frame the `rank` scratch of vmd_hip_cells_build must hold for this grid and selection */
 size_t vmd_hip_cells_scratch_words(vmd_grid_t grid, int nsel);
+/* bounding box of all atoms of each frame: out f32[B][6] = {min x,y,z, max x,y,z} (open axes: the grid spans this box) */
+int vmd_hip_bbox(void* stream, const float* xyz, size_t frame_stride, size_t row_stride, int B, int natoms, float* out);
+/* pbc_flags: bits 0..2 periodic axes, bit 3 triclinic.  On an open axis boxes[b] holds the extent of the batch's bounding box
+ * in the L slot, its inverse in the 1/L slot and its origin in slot 6 + axis (the tilt slots, unused without bit 3). */
 int vmd_hip_cells_build(void* stream, const float* xyz, size_t frame_stride, size_t row_stride,
-                        const float* boxes, int B, const int32_t* sel, int nsel, int nsel_pad,
+                        const float* boxes, uint32_t pbc_flags, int B, const int32_t* sel, int nsel, int nsel_pad,
                         vmd_grid_t grid, uint32_t* cell_count, uint32_t* rank, uint32_t* cell_start, float* sorted,
                         float* aos);
 
@@ -57,8 +61,9 @@ int vmd_hip_cells_build(void* stream, const float* xyz, size_t frame_stride, siz
  *   partial   u64[vmd_hip_rdf_partial_words()] scratch (per-wave rows + the work counter)
  *   counts    u64[nbins]  accumulated (+=) with device atomics
  *   variant   0 = wave queue (default), 1 = inline hit path
- *   triclinic non-zero: boxes carry tilt factors, the selections were sorted by vmd_hip_cells_build in the unsheared
- *             coordinates s_k * L_k (SPEC S3t); the grid must satisfy edge >= rmax measured perpendicular to the cell faces */
+ *   pbc_flags as for vmd_hip_cells_build (the same boxes and flags the selections were sorted with).  Triclinic: boxes
+ *             carry tilt factors, cells live in the unsheared coordinates s_k * L_k (SPEC S3t) and the grid edge must be
+ *             >= rmax measured perpendicular to the cell faces.  Open axes: no images, neighbours end at the bounding box. */
 int vmd_hip_rdf_num_blocks(void);
 int vmd_hip_set_rdf_nsub(int n);       /* tuning knob: work items per pencil (1..64, 0 = automatic), returns the previous value */
 int vmd_hip_set_rdf_blocks(int n);     /* tuning knob: persistent grid size (8..2048), returns the previous value */
@@ -66,7 +71,7 @@ size_t vmd_hip_rdf_partial_words(void);
 int vmd_hip_rdf_pencil(void* stream, const float* sorted_ref, const uint32_t* cell_start_ref, int nref, int nref_pad,
                        const float* sorted_tgt, const uint32_t* cell_start_tgt, int ntgt, int ntgt_pad,
                        const float* boxes, int B, vmd_grid_t grid, float rmin, float rmax, int nbins,
-                       int same_set, int variant, int triclinic, uint64_t* partial, uint64_t* counts);
+                       int same_set, int variant, uint32_t pbc_flags, uint64_t* partial, uint64_t* counts);
 
 /* general RDF (any periodicity flags, any cutoff, no grid): O(nref*ntgt) per frame, SPEC S3 by comparison */
 int vmd_hip_rdf_brute(void* stream, const float* xyz, size_t frame_stride, size_t row_stride,

@@ -28,7 +28,7 @@ def run(sel, label, fused=0, use_aos=True):
     srt = torch.zeros(B * 3 * nsel_pad + 64, dtype=torch.float32, device=dev)
     seli = sel.to(torch.int32).to(dev)
     aos = torch.zeros(B * 4 * nsel_pad, dtype=torch.float32, device=dev)
-    args = (None, base, fs, rs, boxes.data_ptr(), B, seli.data_ptr(), nsel, nsel_pad, g, cc.data_ptr(), rank.data_ptr(), cs.data_ptr(), srt.data_ptr(), aos.data_ptr() if use_aos else None)
+    args = (None, base, fs, rs, boxes.data_ptr(), 7, B, seli.data_ptr(), nsel, nsel_pad, g, cc.data_ptr(), rank.data_ptr(), cs.data_ptr(), srt.data_ptr(), aos.data_ptr() if use_aos else None)
     for _ in range(2):
         assert lib.vmd_hip_cells_build(*args) == 0
     torch.cuda.synchronize()

@@ -376,3 +376,44 @@ def filtered_cases(lib, O, n_water, device=False):
         V.ScriptEval(F, ir).set_source(V.ScriptEval(F, ir))     # source keeps no blocks
     with pytest.raises(V.VmdError):
         full.set_block_frames(2)                                  # not after frames were evaluated
+
+
+def _kernel_family(lib):
+    import ctypes as C
+    n_grid, n_brute = C.c_uint64(0), C.c_uint64(0)
+    lib.vmd_profile_ms(b"rdf_pencil", C.byref(n_grid)); lib.vmd_profile_ms(b"rdf_brute", C.byref(n_brute))
+    return int(n_grid.value), int(n_brute.value)
+
+
+def open_boundary_cases(lib, O, n, device=False):
+    """Systems without a periodic cell, and slabs (periodic in two directions): the pencil grid over the batch's bounding box
+    must reproduce SPEC S3 with the open axes left alone, exactly like the all-pairs kernel does."""
+    rng = np.random.default_rng(41)
+    F = 3
+    # a drifting, breathing cloud: the bounding box differs from frame to frame; a few far outliers stretch it
+    c = np.stack([rng.normal(0, 14.0 + 2 * f, (3, n)) + np.array([[5.0 * f], [-30.0], [100.0]]) for f in range(F)]).astype(np.float32)
+    c[:, :, :5] += 60.0
+    a, b, allidx = np.arange(0, n, 2), np.arange(1, n, 3), np.arange(n)
+    props = [("gaa", allidx, allidx, 0.0, 9.0), ("gab", a, b, 0.5, 7.0)]
+    for brute in (0, 1):
+        old = lib.vmd_set_option(b"force_brute", brute)
+        lib.vmd_profile_reset(); lib.vmd_profile_enable(True)
+        try:
+            check_rdf(lib, O, c, None, props, device=device, oracle_method="brute")
+        finally:
+            lib.vmd_set_option(b"force_brute", old); lib.vmd_profile_enable(False)
+        assert _kernel_family(lib) == ((0, 2) if brute else (2, 0))
+    # slab: periodic in x and y (box 40 x 36), open along z; and a wire: periodic along z only
+    s = c.copy()
+    lib.vmd_profile_reset(); lib.vmd_profile_enable(True)
+    try:
+        check_rdf(lib, O, s, (40.0, 36.0, 50.0), props, flags=3, device=device, oracle_method="brute")
+        check_rdf(lib, O, s, (40.0, 36.0, 44.0), props, flags=4, device=device, oracle_method="brute")
+    finally:
+        lib.vmd_profile_enable(False)
+    assert _kernel_family(lib) == (4, 0)
+    # flat system (zero extent along z), and a cutoff larger than the whole cloud (one cell per axis)
+    flat = c.copy(); flat[:, 2, :] = 3.25
+    check_rdf(lib, O, flat, None, [("g", allidx, allidx, 0.0, 9.0)], device=device, oracle_method="brute")
+    small = (c[:, :, :200] * 0.1).astype(np.float32)
+    check_rdf(lib, O, small, None, [("g", np.arange(200), np.arange(200), 0.0, 12.0)], device=device, oracle_method="brute")

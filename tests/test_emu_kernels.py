@@ -170,3 +170,7 @@ def test_triclinic_cell_all_property_kinds(emu_lib, oracle):
 
 def test_filtered_evaluation_reuses_block_partials(emu_lib, oracle):
     cases.filtered_cases(emu_lib, oracle, 900)
+
+
+def test_open_boundaries_and_slabs_on_the_grid(emu_lib, oracle):
+    cases.open_boundary_cases(emu_lib, oracle, 700)

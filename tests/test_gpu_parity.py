@@ -415,3 +415,8 @@ def test_triclinic_config2_shape_against_oracle(gpu_lib, oracle):
     finally:
         gpu_lib.vmd_set_option(b"force_brute", old)
     np.testing.assert_array_equal(ev2.property_data("g").counts, grid)
+
+
+def test_open_boundaries_and_slabs_on_the_grid(gpu_lib, oracle):
+    cases.open_boundary_cases(gpu_lib, oracle, 6000, device=True)
+    cases.open_boundary_cases(gpu_lib, oracle, 1500, device=False)

@@ -144,7 +144,8 @@ SIGNATURES = [
     ("vmd_profile_ms", C.c_double, [C.c_char_p, c_uint64_p]),
     ("vmd_profile_enable", None, [C.c_bool]),
     # vmd_hip.h
-    ("vmd_hip_cells_build", C.c_int, [_vp, _vp, C.c_size_t, C.c_size_t, _vp, C.c_int, _vp, C.c_int, C.c_int, Grid, _vp, _vp, _vp, _vp, _vp]),
+    ("vmd_hip_bbox", C.c_int, [_vp, _vp, C.c_size_t, C.c_size_t, C.c_int, C.c_int, _vp]),
+    ("vmd_hip_cells_build", C.c_int, [_vp, _vp, C.c_size_t, C.c_size_t, _vp, C.c_uint32, C.c_int, _vp, C.c_int, C.c_int, Grid, _vp, _vp, _vp, _vp, _vp]),
     ("vmd_hip_cells_fused_ok", C.c_int, [Grid, C.c_int]),
     ("vmd_hip_set_cells_fused", C.c_int, [C.c_int]),
     ("vmd_hip_rdf_num_blocks", C.c_int, []),
@@ -155,7 +156,7 @@ SIGNATURES = [
     ("vmd_hip_cells_scratch_words", C.c_size_t, [Grid, C.c_int]),
     ("vmd_hip_rdf_partial_words", C.c_size_t, []),
     ("vmd_hip_rdf_pencil", C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, C.c_int, C.c_int, _vp, C.c_int, Grid,
-                                     C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]),
+                                     C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, C.c_uint32, _vp, _vp]),
     ("vmd_hip_rdf_brute", C.c_int, [_vp, _vp, C.c_size_t, C.c_size_t, _vp, C.c_uint32, C.c_int, _vp, C.c_int, _vp, C.c_int,
                                     C.c_float, C.c_float, C.c_int, _vp]),
     ("vmd_hip_sdf_align", C.c_int, [_vp, _vp, C.c_size_t, C.c_size_t, _vp, C.c_uint32, C.c_int, _vp, _vp, C.c_int, C.c_int, _vp,

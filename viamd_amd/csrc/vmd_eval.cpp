@@ -380,6 +380,10 @@ struct vmd_script_eval_t {
         DevBuf<float> d_boxes;
         std::vector<float> h_boxes;              // [nb][6]: L, 1/L
         std::vector<vmd_unitcell_t> cells;
+        // batches with open (non-periodic) axes: per-frame bounding box -> the boxes the pencil grid uses (extent, 1/extent, origin)
+        DevBuf<float> d_bbox, d_gboxes;
+        std::vector<float> h_bbox, h_gboxes;
+        bool gboxes_ready = false;
         hipEvent_t ready = nullptr;
         const float* base = nullptr; size_t frame_stride = 0, row_stride = 0;   // where the kernels read the batch
         size_t f0 = 0, nb = 0;
@@ -490,7 +494,7 @@ extern "C" void vmd_eval_free(vmd_script_eval_t* eval) {
         for (auto& st : eval->stages) {
             if (st.h) (void)hipHostFree(st.h);
             st.h = nullptr;
-            st.d.release(); st.d_boxes.release();
+            st.d.release(); st.d_boxes.release(); st.d_bbox.release(); st.d_gboxes.release();
             if (st.ready) (void)hipEventDestroy(st.ready);
             st.ready = nullptr;
         }
@@ -787,6 +791,7 @@ static bool fetch_stage(vmd_script_eval_t* e, Stage& st, vmd_trajectory_i* traj,
     vmd_host_view_t hv;
     const vmd_host_view_t* hview = (!view && traj->host_view && traj->host_view(traj->inst, &hv)) ? &hv : nullptr;
     st.f0 = f0; st.nb = nb;
+    st.gboxes_ready = false;
     st.cells.resize(nb);
     st.h_boxes.resize(nb * 9);
     if (view) {
@@ -891,29 +896,59 @@ static uint32_t batch_pbc(const Stage& st) {
     return f;
 }
 
-// pencil grid for a batch and cutoff; false when the batch cannot use the grid kernel
-static bool choose_grid(const Stage& st, size_t nb, float rmax, vmd_grid_t* g) {
+// Batches with open axes: the grid spans the bounding box of the batch's atoms.  Fills st.h_gboxes / st.d_gboxes with
+// {extent or L, inverse, origin or 0} per frame (one bbox kernel + one small readback per batch).
+static bool prepare_open_boxes(vmd_script_eval_t* e, Stage& st, size_t nb, uint32_t pbc, size_t num_atoms) {
+    if (st.gboxes_ready) return true;
+    if (!st.d_bbox.ensure(nb * 6) || !st.d_gboxes.ensure(nb * 9)) return false;
+    st.h_bbox.resize(nb * 6);
+    KRN_OK(vmd_hip_bbox(e->stream, st.base, st.frame_stride, st.row_stride, (int)nb, (int)num_atoms, st.d_bbox.p));
+    HIP_OK(hipMemcpyAsync(st.h_bbox.data(), st.d_bbox.p, nb * 6 * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    HIP_OK(hipStreamSynchronize(e->stream));
+    st.h_gboxes = st.h_boxes;
+    for (size_t b = 0; b < nb; ++b) {
+        float* g = &st.h_gboxes[9 * b];
+        for (int a = 0; a < 3; ++a) {
+            g[6 + a] = 0.0f;
+            if (pbc & (1u << a)) continue;
+            const float lo = st.h_bbox[6 * b + a], hi = st.h_bbox[6 * b + 3 + a];
+            const float pad = std::max(1.0e-2f, 1.0e-3f * (hi - lo));
+            g[6 + a] = lo - pad;                    // origin
+            g[a] = (hi - lo) + 2.0f * pad;          // extent
+            g[3 + a] = 1.0f / g[a];
+        }
+    }
+    if (!st.d_gboxes.upload(st.h_gboxes.data(), nb * 9, e->stream)) return false;
+    st.gboxes_ready = true;
+    return true;
+}
+
+// pencil grid for a batch and cutoff; false when the batch cannot use the grid kernel.  `boxes` = st.h_boxes, or
+// st.h_gboxes when some axes are open (pbc bits clear): those carry the bounding-box extent instead of a cell edge.
+static bool choose_grid(const std::vector<float>& boxes, uint32_t pbc, size_t nb, float rmax, vmd_grid_t* g) {
     if (g_opt.force_brute) return false;
-    const uint32_t pbc = batch_pbc(st);
-    if ((pbc & VMD_UNITCELL_PBC_ALL) != VMD_UNITCELL_PBC_ALL) return false;
+    const bool tri = (pbc & 8u) != 0;
+    if (tri && (pbc & VMD_UNITCELL_PBC_ALL) != VMD_UNITCELL_PBC_ALL) return false;
     // smallest extent per axis over the batch, measured perpendicular to the cell faces (SPEC S3t: a triclinic cell's
     // pencils are sheared, what has to be >= rmax is their width w_k = 1 / |reciprocal vector k|)
     float wmin[3] = {3.4e38f, 3.4e38f, 3.4e38f}, Lxmin = 3.4e38f;
     for (size_t b = 0; b < nb; ++b) {
-        const float* q = &st.h_boxes[9 * b];
-        const double Lx = q[0], Ly = q[1], Lz = q[2], xy = q[6], xz = q[7], yz = q[8];
+        const float* q = &boxes[9 * b];
+        const double Lx = q[0], Ly = q[1], Lz = q[2];
+        const double xy = tri ? q[6] : 0.0, xz = tri ? q[7] : 0.0, yz = tri ? q[8] : 0.0;
         const double wx = Lx / std::sqrt(1.0 + (xy / Ly) * (xy / Ly) + ((xy * yz - Ly * xz) / (Ly * Lz)) * ((xy * yz - Ly * xz) / (Ly * Lz)));
         const double wy = Ly / std::sqrt(1.0 + (yz / Lz) * (yz / Lz));
         wmin[0] = std::min(wmin[0], (float)wx); wmin[1] = std::min(wmin[1], (float)wy); wmin[2] = std::min(wmin[2], (float)Lz);
         Lxmin = std::min(Lxmin, q[0]);
     }
-    // minimum image must be unique for every hit: rmax < w/2 with margin
-    for (int a = 0; a < 3; ++a) if (!(rmax * 2.0f * 1.001f < wmin[a])) return false;
+    // periodic axes: the minimum image must be unique for every hit (rmax < w/2 with margin); open axes: no restriction
+    for (int a = 0; a < 3; ++a) if ((pbc & (1u << a)) && !(rmax * 2.0f * 1.001f < wmin[a])) return false;
     int n[3];
     for (int a = 1; a < 3; ++a) {
         int k = (int)std::floor(wmin[a] / rmax);
         while (k > 1 && ((float)k / wmin[a]) * rmax > 0.9999f) k -= 1;
-        if (k < 2) return false;
+        if (pbc & (1u << a)) { if (k < 2) return false; }
+        else k = std::max(k, 1);
         n[a] = std::min(k, 1024);
     }
     const float cx = rmax / (float)std::max(1, g_opt.nxf_divisor.load());
@@ -929,7 +964,7 @@ static bool choose_grid(const Stage& st, size_t nb, float rmax, vmd_grid_t* g) {
     return true;
 }
 
-static bool build_selection(vmd_script_eval_t* e, Selection* s, const Stage& src, size_t nb, const vmd_grid_t& g) {
+static bool build_selection(vmd_script_eval_t* e, Selection* s, const Stage& src, const float* d_boxes, uint32_t pbc, size_t nb, const vmd_grid_t& g) {
     if (s->built && s->built_grid.nxf == g.nxf && s->built_grid.ny == g.ny && s->built_grid.nz == g.nz) return true;
     const int nsel = (int)s->idx.size();
     s->nsel_pad = (nsel + 63) & ~63;
@@ -938,7 +973,7 @@ static bool build_selection(vmd_script_eval_t* e, Selection* s, const Stage& src
     const bool use_aos = g_opt.cells_aos != 0;
     if (use_aos && !s->aos.ensure(nb * 4 * (size_t)s->nsel_pad)) return false;
     e->prof.begin("cells_build", e->stream);
-    KRN_OK(vmd_hip_cells_build(e->stream, src.base, src.frame_stride, src.row_stride, src.d_boxes.p, (int)nb, s->d_idx.p, nsel,
+    KRN_OK(vmd_hip_cells_build(e->stream, src.base, src.frame_stride, src.row_stride, d_boxes, pbc, (int)nb, s->d_idx.p, nsel,
                                s->nsel_pad, g, s->cell_count.p, s->rank.p, s->cell_start.p, s->sorted.p, use_aos ? s->aos.p : nullptr));
     e->prof.end(e->stream);
     s->built = true;
@@ -1094,18 +1129,23 @@ static bool process_range(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
             }
             if (d.kind == PROP_RDF) {
                 vmd_grid_t g;
-                if (choose_grid(src, nb, d.rmax, &g)) {
+                // fully periodic cells use the frame boxes; open axes (non-periodic systems, slabs) span the batch's bounding box
+                const bool open_axes = (pbc & 8u) == 0 && (pbc & VMD_UNITCELL_PBC_ALL) != VMD_UNITCELL_PBC_ALL;
+                if (open_axes && !g_opt.force_brute && !prepare_open_boxes(e, src, nb, pbc, num_atoms)) return false;
+                const std::vector<float>& gb = (open_axes && src.gboxes_ready) ? src.h_gboxes : src.h_boxes;
+                const float* d_gb = (open_axes && src.gboxes_ready) ? src.d_gboxes.p : src.d_boxes.p;
+                if (choose_grid(gb, pbc, nb, d.rmax, &g)) {
                     Selection* sa = e->sels[p->sel_a].get();
                     Selection* sb = e->sels[p->sel_b].get();
                     // properties with the same cutoff share the sorted copies; build_selection re-sorts when the grid differs
-                    if (!build_selection(e, sa, src, nb, g)) return false;
-                    if (sb != sa && !build_selection(e, sb, src, nb, g)) return false;
+                    if (!build_selection(e, sa, src, d_gb, pbc, nb, g)) return false;
+                    if (sb != sa && !build_selection(e, sb, src, d_gb, pbc, nb, g)) return false;
                     if (!e->d_partial.ensure(vmd_hip_rdf_partial_words())) return false;
                     e->prof.begin("rdf_pencil", e->stream);
                     KRN_OK(vmd_hip_rdf_pencil(e->stream, sa->sorted.p, sa->cell_start.p, (int)sa->idx.size(), sa->nsel_pad,
                                               sb->sorted.p, sb->cell_start.p, (int)sb->idx.size(), sb->nsel_pad,
-                                              src.d_boxes.p, (int)nb, g, d.rmin, d.rmax, VMD_RDF_NUM_BINS,
-                                              p->same_set ? 1 : 0, g_opt.rdf_variant, (pbc & 8u) ? 1 : 0, e->d_partial.p, acc));
+                                              d_gb, (int)nb, g, d.rmin, d.rmax, VMD_RDF_NUM_BINS,
+                                              p->same_set ? 1 : 0, g_opt.rdf_variant, pbc, e->d_partial.p, acc));
                     e->prof.end(e->stream);
                 } else {
                     Selection* sa = e->sels[p->sel_a].get();

@@ -198,6 +198,7 @@ __device__ __forceinline__ void vmd_mi3_rint(const vmd_box_t& b, double& dx, dou
 
 __device__ __forceinline__ int vmd_cell_coord(float v, float inv, int n) {
     int c = (int)(v * inv);
+    c = c < 0 ? 0 : c;
     return c > n - 1 ? n - 1 : c;
 }
 
@@ -253,7 +254,7 @@ __device__ __forceinline__ int vmd_bin_of(const vmd_binning_t& b, float d2) {
 
 struct vmd_cells_params_t {
     const float* xyz; size_t frame_stride; size_t row_stride;
-    const float* boxes; const int32_t* sel; int nsel; int nsel_pad;
+    const float* boxes; uint32_t pbc; const int32_t* sel; int nsel; int nsel_pad;
     vmd_grid_t grid;
     uint32_t* cell_count; uint32_t* rank; uint32_t* cell_start; float* sorted;
     float* aos;   // optional f32[B][nsel_pad][4] staging: scatter ONE 16-byte record per atom, k_cells_repack makes the SoA rows
@@ -264,16 +265,18 @@ __device__ __forceinline__ uint32_t vmd_cell_of(const vmd_cells_params_t& p, int
     const float* fx = p.xyz + (size_t)b * p.frame_stride;
     const float* bq = p.boxes + (size_t)VMD_BOX_STRIDE * b;
     const float Lx = bq[0], Ly = bq[1], Lz = bq[2], iLx = bq[3], iLy = bq[4], iLz = bq[5];
-    float ux, uy, uz;     // what the grid bins by: the wrapped coordinates themselves, or s_k * L_k in a triclinic cell
-    if (bq[6] != 0.0f || bq[7] != 0.0f || bq[8] != 0.0f) {
+    float ux, uy, uz;     // what the grid bins by: wrapped coordinate (periodic axis), offset from the batch's bounding box
+                          // (open axis; L is then the box extent, slots 6..8 the origin), or s_k * L_k (triclinic cell)
+    if (p.pbc & VMD_PBC_TRICLINIC) {
         vmd_box_t bx;
         bx.Lx = Lx; bx.Ly = Ly; bx.Lz = Lz; bx.iLx = iLx; bx.iLy = iLy; bx.iLz = iLz; bx.xy = bq[6]; bx.xz = bq[7]; bx.yz = bq[8];
         bx.px = bx.py = bx.pz = bx.tri = true;
         vmd_wrap_tri(bx, fx[a], fx[p.row_stride + a], fx[2 * p.row_stride + a], xw, yw, zw, ux, uy, uz);
     } else {
-        ux = xw = vmd_wrap(fx[a], Lx, iLx);
-        uy = yw = vmd_wrap(fx[p.row_stride + a], Ly, iLy);
-        uz = zw = vmd_wrap(fx[2 * p.row_stride + a], Lz, iLz);
+        const float x = fx[a], y = fx[p.row_stride + a], z = fx[2 * p.row_stride + a];
+        if (p.pbc & 1u) { ux = xw = vmd_wrap(x, Lx, iLx); } else { xw = x; ux = x - bq[6]; }
+        if (p.pbc & 2u) { uy = yw = vmd_wrap(y, Ly, iLy); } else { yw = y; uy = y - bq[7]; }
+        if (p.pbc & 4u) { uz = zw = vmd_wrap(z, Lz, iLz); } else { zw = z; uz = z - bq[8]; }
     }
     const int cx = vmd_cell_coord(ux, (float)p.grid.nxf * iLx, p.grid.nxf);
     const int cy = vmd_cell_coord(uy, (float)p.grid.ny * iLy, p.grid.ny);
@@ -489,6 +492,29 @@ __global__ __launch_bounds__(1024) void k_cells_split_scatter(vmd_cells_split_t 
     }
 }
 
+// bounding box of all atoms of every frame (open axes: the pencil grid spans the box of the batch): out[b] = {min xyz, max xyz}
+__global__ __launch_bounds__(1024) void k_bbox(const float* __restrict__ xyz, size_t frame_stride, size_t row_stride, int natoms,
+                                               float* __restrict__ out) {
+    __shared__ float s_lo[3][16], s_hi[3][16];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* fx = xyz + (size_t)b * frame_stride;
+    float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+    for (int a = tid; a < natoms; a += 1024)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { const float v = fx[k * row_stride + a]; lo[k] = fminf(lo[k], v); hi[k] = fmaxf(hi[k], v); }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        lo[k] = vmd_wave_min(lo[k]); hi[k] = vmd_wave_max(hi[k]);
+        if ((tid & 63) == 0) { s_lo[k][tid >> 6] = lo[k]; s_hi[k][tid >> 6] = hi[k]; }
+    }
+    __syncthreads();
+    if (tid < 3) {
+        float l = s_lo[tid][0], h = s_hi[tid][0];
+        for (int w = 1; w < 16; ++w) { l = fminf(l, s_lo[tid][w]); h = fmaxf(h, s_hi[tid][w]); }
+        out[6 * b + tid] = l; out[6 * b + 3 + tid] = h;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ K2: RDF, pencil grid
 
 struct vmd_pair_params_t {
@@ -503,6 +529,7 @@ struct vmd_pair_params_t {
     unsigned long long* counts;  // the accumulators: target of the (rare) overflow flush
     unsigned* work_counter;  // [8 * VMD_COUNTER_STRIDE], zeroed before launch: one dynamic work queue per XCD (frames f = q mod 8)
     int nsub;                // work items per pencil (i-chunks are dealt round-robin to the items)
+    uint32_t pbc;            // bits 0..2: periodic axes (an open axis spans the batch's bounding box: boxes slots 6..8 = origin)
 };
 #define VMD_COUNTER_STRIDE 32    // one 128-byte line per queue counter
 
@@ -982,6 +1009,9 @@ __global__ __launch_bounds__(256) VMD_SGPR_CAP(96) void k_rdf_pencil(vmd_pair_pa
         const float inv_cx = (float)nxf * boxes[VMD_BOX_STRIDE * b + 3];
         const float txy = TRI ? boxes[VMD_BOX_STRIDE * b + 6] : 0.0f, txz = TRI ? boxes[VMD_BOX_STRIDE * b + 7] : 0.0f,
                     tyz = TRI ? boxes[VMD_BOX_STRIDE * b + 8] : 0.0f;
+        // open x axis: fine cells count from the bounding-box origin (0 on a periodic axis)
+        const float orgx = (!TRI && !(p.pbc & 1u)) ? boxes[VMD_BOX_STRIDE * b + 6] : 0.0f;
+        const bool open_x = !TRI && !(p.pbc & 1u), open_y = !TRI && !(p.pbc & 2u), open_z = !TRI && !(p.pbc & 4u);
         vmd_cu32* csr = (vmd_cu32*)p.cs_ref + (size_t)b * (p.grid.ncell + 1);
         vmd_cu32* cst = (vmd_cu32*)p.cs_tgt + (size_t)b * (p.grid.ncell + 1);
         const float* __restrict__ sr = p.sref + (size_t)b * 3 * p.nref_pad;
@@ -1000,10 +1030,12 @@ __global__ __launch_bounds__(256) VMD_SGPR_CAP(96) void k_rdf_pencil(vmd_pair_pa
 
             for (int dz = SAME ? 0 : -1; dz <= 1; ++dz) {
                 int qz = pz + dz; float sz = 0.0f, nc = 0.0f;
+                if (open_z && (qz < 0 || qz >= nz)) continue;       // nothing beyond the bounding box
                 if (qz < 0) { qz += nz; sz = -Lz; nc = -1.0f; } else if (qz >= nz) { qz -= nz; sz = Lz; nc = 1.0f; }
                 for (int dy = -1; dy <= 1; ++dy) {
                     if (SAME && dz == 0 && dy < 0) continue;
                     int qy = py + dy; float sy = 0.0f, nb = 0.0f;
+                    if (open_y && (qy < 0 || qy >= ny)) continue;
                     if (qy < 0) { qy += ny; sy = -Ly; nb = -1.0f; } else if (qy >= ny) { qy -= ny; sy = Ly; nb = 1.0f; }
                     const bool own = SAME && dz == 0 && dy == 0;
                     const int q = qz * ny + qy;
@@ -1016,10 +1048,11 @@ __global__ __launch_bounds__(256) VMD_SGPR_CAP(96) void k_rdf_pencil(vmd_pair_pa
                         offmax = fmaxf(y0, y1) + fmaxf(z0, z1) + 1.0e-3f;
                     }
                     for (int kx = -1; kx <= 1; ++kx) {
+                        if (open_x && kx != 0) continue;
                         float sx = (float)kx * Lx;
                         if (TRI) vmd_lattice_shift(Lx, Ly, Lz, txy, txz, tyz, (float)kx, nb, nc, sx, sy, sz);
-                        const float lo = (xlo - p.rpad) - sx - offmax;
-                        const float hi = (xhi + p.rpad) - sx - offmin;
+                        const float lo = (xlo - p.rpad) - sx - offmax - orgx;
+                        const float hi = (xhi + p.rpad) - sx - offmin - orgx;
                         if (hi < 0.0f || lo >= Lx) continue;
                         const int ca = lo <= 0.0f ? 0 : vmd_cell_coord(lo, inv_cx, nxf);
                         const int cb = hi >= Lx ? nxf - 1 : vmd_cell_coord(hi, inv_cx, nxf);
@@ -1601,13 +1634,13 @@ static int vmd_lds_opt_in(const void* kernel) {
 }
 
 extern "C" int vmd_hip_cells_build(void* stream, const float* xyz, size_t frame_stride, size_t row_stride,
-                                   const float* boxes, int B, const int32_t* sel, int nsel, int nsel_pad,
+                                   const float* boxes, uint32_t pbc_flags, int B, const int32_t* sel, int nsel, int nsel_pad,
                                    vmd_grid_t grid, uint32_t* cell_count, uint32_t* rank, uint32_t* cell_start, float* sorted,
                                    float* aos) {
     hipStream_t s = (hipStream_t)stream;
     if (B <= 0 || nsel <= 0) return 0;
     const dim3 grp((nsel + 255) / 256, B);
-    vmd_cells_params_t p{xyz, frame_stride, row_stride, boxes, sel, nsel, nsel_pad, grid, cell_count, rank, cell_start, sorted, aos};
+    vmd_cells_params_t p{xyz, frame_stride, row_stride, boxes, pbc_flags, sel, nsel, nsel_pad, grid, cell_count, rank, cell_start, sorted, aos};
     if (vmd_hip_cells_fused_ok(grid, nsel)) {
         const size_t shm = sizeof(uint32_t) * ((size_t)grid.ncell + 1 + 1024);
         int ea = vmd_lds_opt_in((const void*)k_cells_fused);
@@ -1653,7 +1686,7 @@ extern "C" size_t vmd_hip_rdf_partial_words(void) {
 extern "C" int vmd_hip_rdf_pencil(void* stream, const float* sorted_ref, const uint32_t* cell_start_ref, int nref, int nref_pad,
                                   const float* sorted_tgt, const uint32_t* cell_start_tgt, int ntgt, int ntgt_pad,
                                   const float* boxes, int B, vmd_grid_t grid, float rmin, float rmax, int nbins,
-                                  int same_set, int variant, int triclinic, uint64_t* partial, uint64_t* counts) {
+                                  int same_set, int variant, uint32_t pbc_flags, uint64_t* partial, uint64_t* counts) {
     hipStream_t s = (hipStream_t)stream;
     if (nbins <= 0 || nbins > VMD_MAX_BINS) return (int)hipErrorInvalidValue;
     if (B <= 0 || nref <= 0 || ntgt <= 0) return 0;
@@ -1687,7 +1720,8 @@ extern "C" int vmd_hip_rdf_pencil(void* stream, const float* sorted_ref, const u
     if (nblocks < 8) nblocks = 8;
     if (nblocks > g_rdf_blocks) nblocks = g_rdf_blocks;
     const dim3 g(nblocks), blk(256);
-    const int which = (variant == 1 ? 4 : 0) | (same_set ? 2 : 0) | (triclinic ? 1 : 0);
+    p.pbc = pbc_flags;
+    const int which = (variant == 1 ? 4 : 0) | (same_set ? 2 : 0) | ((pbc_flags & VMD_PBC_TRICLINIC) ? 1 : 0);
     switch (which) {
     case 0: hipLaunchKernelGGL((k_rdf_pencil<0, false, false>), g, blk, 0, s, p); break;
     case 1: hipLaunchKernelGGL((k_rdf_pencil<0, false, true>), g, blk, 0, s, p); break;
@@ -1776,6 +1810,13 @@ extern "C" int vmd_hip_distance(void* stream, const float* xyz, size_t frame_str
     case 3: hipLaunchKernelGGL(k_distance_pair, dim3((unsigned)((per + 255) / 256), B * P), dim3(256), 0, s, p); break;
     default: return (int)hipErrorInvalidValue;
     }
+    VMD_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int vmd_hip_bbox(void* stream, const float* xyz, size_t frame_stride, size_t row_stride, int B, int natoms, float* out) {
+    if (B <= 0 || natoms <= 0) return 0;
+    hipLaunchKernelGGL(k_bbox, dim3(B), dim3(1024), 0, (hipStream_t)stream, xyz, frame_stride, row_stride, natoms, out);
     VMD_LAUNCH_CHECK();
     return 0;
 }
