@@ -963,8 +963,12 @@ __device__ __forceinline__ int vmd_next_item(unsigned* counters, int& q, int& tr
 // TRI: triclinic cell (SPEC S3t).  Pencils and fine cells live in the unsheared coordinates s_k * L_k; a neighbour pencil's
 // periodic image is displaced by the lattice vector (kx, nb, nc), and because the Cartesian x of its atoms is
 // s_x*Lx + xy*s_y + xz*s_z, the x window is widened by the range that offset takes over the pencil's cross-section.
-template <int VARIANT, bool SAME, bool TRI>
+// CELL = 2: orthorhombic with open axes (non-periodic systems, slabs): an open axis spans the bounding box of the batch (its
+// origin sits in the tilt slot of the box record), has no images, and neighbour pencils end at the box.  CELL = 0 is the fully
+// periodic orthorhombic cell and carries none of this.
+template <int VARIANT, bool SAME, int CELL>
 __global__ __launch_bounds__(256) VMD_SGPR_CAP(96) void k_rdf_pencil(vmd_pair_params_t p) {
+    constexpr bool TRI = CELL == 1, OPEN = CELL == 2;
     __shared__ unsigned s_hist[4][VMD_MAX_BINS];
     __shared__ float s_queue[4][VMD_QUEUE_CAP];
     constexpr unsigned INC = SAME ? 2u : 1u;
@@ -1010,8 +1014,8 @@ __global__ __launch_bounds__(256) VMD_SGPR_CAP(96) void k_rdf_pencil(vmd_pair_pa
         const float txy = TRI ? boxes[VMD_BOX_STRIDE * b + 6] : 0.0f, txz = TRI ? boxes[VMD_BOX_STRIDE * b + 7] : 0.0f,
                     tyz = TRI ? boxes[VMD_BOX_STRIDE * b + 8] : 0.0f;
         // open x axis: fine cells count from the bounding-box origin (0 on a periodic axis)
-        const float orgx = (!TRI && !(p.pbc & 1u)) ? boxes[VMD_BOX_STRIDE * b + 6] : 0.0f;
-        const bool open_x = !TRI && !(p.pbc & 1u), open_y = !TRI && !(p.pbc & 2u), open_z = !TRI && !(p.pbc & 4u);
+        const bool open_x = OPEN && !(p.pbc & 1u), open_y = OPEN && !(p.pbc & 2u), open_z = OPEN && !(p.pbc & 4u);
+        const float orgx = open_x ? boxes[VMD_BOX_STRIDE * b + 6] : 0.0f;
         vmd_cu32* csr = (vmd_cu32*)p.cs_ref + (size_t)b * (p.grid.ncell + 1);
         vmd_cu32* cst = (vmd_cu32*)p.cs_tgt + (size_t)b * (p.grid.ncell + 1);
         const float* __restrict__ sr = p.sref + (size_t)b * 3 * p.nref_pad;
@@ -1721,16 +1725,21 @@ extern "C" int vmd_hip_rdf_pencil(void* stream, const float* sorted_ref, const u
     if (nblocks > g_rdf_blocks) nblocks = g_rdf_blocks;
     const dim3 g(nblocks), blk(256);
     p.pbc = pbc_flags;
-    const int which = (variant == 1 ? 4 : 0) | (same_set ? 2 : 0) | ((pbc_flags & VMD_PBC_TRICLINIC) ? 1 : 0);
+    const int cell = (pbc_flags & VMD_PBC_TRICLINIC) ? 1 : ((pbc_flags & 7u) != 7u ? 2 : 0);
+    const int which = (variant == 1 ? 6 : 0) + (same_set ? 3 : 0) + cell;
     switch (which) {
-    case 0: hipLaunchKernelGGL((k_rdf_pencil<0, false, false>), g, blk, 0, s, p); break;
-    case 1: hipLaunchKernelGGL((k_rdf_pencil<0, false, true>), g, blk, 0, s, p); break;
-    case 2: hipLaunchKernelGGL((k_rdf_pencil<0, true, false>), g, blk, 0, s, p); break;
-    case 3: hipLaunchKernelGGL((k_rdf_pencil<0, true, true>), g, blk, 0, s, p); break;
-    case 4: hipLaunchKernelGGL((k_rdf_pencil<1, false, false>), g, blk, 0, s, p); break;
-    case 5: hipLaunchKernelGGL((k_rdf_pencil<1, false, true>), g, blk, 0, s, p); break;
-    case 6: hipLaunchKernelGGL((k_rdf_pencil<1, true, false>), g, blk, 0, s, p); break;
-    default: hipLaunchKernelGGL((k_rdf_pencil<1, true, true>), g, blk, 0, s, p); break;
+    case 0: hipLaunchKernelGGL((k_rdf_pencil<0, false, 0>), g, blk, 0, s, p); break;
+    case 1: hipLaunchKernelGGL((k_rdf_pencil<0, false, 1>), g, blk, 0, s, p); break;
+    case 2: hipLaunchKernelGGL((k_rdf_pencil<0, false, 2>), g, blk, 0, s, p); break;
+    case 3: hipLaunchKernelGGL((k_rdf_pencil<0, true, 0>), g, blk, 0, s, p); break;
+    case 4: hipLaunchKernelGGL((k_rdf_pencil<0, true, 1>), g, blk, 0, s, p); break;
+    case 5: hipLaunchKernelGGL((k_rdf_pencil<0, true, 2>), g, blk, 0, s, p); break;
+    case 6: hipLaunchKernelGGL((k_rdf_pencil<1, false, 0>), g, blk, 0, s, p); break;
+    case 7: hipLaunchKernelGGL((k_rdf_pencil<1, false, 1>), g, blk, 0, s, p); break;
+    case 8: hipLaunchKernelGGL((k_rdf_pencil<1, false, 2>), g, blk, 0, s, p); break;
+    case 9: hipLaunchKernelGGL((k_rdf_pencil<1, true, 0>), g, blk, 0, s, p); break;
+    case 10: hipLaunchKernelGGL((k_rdf_pencil<1, true, 1>), g, blk, 0, s, p); break;
+    default: hipLaunchKernelGGL((k_rdf_pencil<1, true, 2>), g, blk, 0, s, p); break;
     }
     VMD_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_hist_reduce, dim3((nbins + 255) / 256, (nblocks + 31) / 32), dim3(256), 0, s, (const uint64_t*)partial, nblocks, nbins, counts);
