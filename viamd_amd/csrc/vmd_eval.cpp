@@ -1141,6 +1141,9 @@ static bool process_range(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
                     if (!build_selection(e, sa, src, d_gb, pbc, nb, g)) return false;
                     if (sb != sa && !build_selection(e, sb, src, d_gb, pbc, nb, g)) return false;
                     if (!e->d_partial.ensure(vmd_hip_rdf_partial_words())) return false;
+                    // the pair set is symmetric in (ref, target): put the denser selection in the lanes - 64 of its atoms span a
+                    // shorter stretch of the pencil, so the x window of every segment carries less padding
+                    if (sb->idx.size() > sa->idx.size()) std::swap(sa, sb);
                     e->prof.begin("rdf_pencil", e->stream);
                     KRN_OK(vmd_hip_rdf_pencil(e->stream, sa->sorted.p, sa->cell_start.p, (int)sa->idx.size(), sa->nsel_pad,
                                               sb->sorted.p, sb->cell_start.p, (int)sb->idx.size(), sb->nsel_pad,
