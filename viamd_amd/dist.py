@@ -37,9 +37,8 @@ def _alias_counts(view, on_gpu):
 def reduce_eval(ev, group=None):
     """Merge the accumulators of all ranks into every rank's evaluator, then refresh its host views.
 
-    u64 counts (RDF bins, SDF voxels): SUM as int64 (two's complement sum == unsigned sum);
-    fp64 weights: SUM; temporal rows: SUM (rows of frames a rank did not evaluate are zero);
-    frame mask: MAX."""
+    u64 counts (RDF bins, SDF voxels): SUM as int64 (two's complement sum == unsigned sum), in place on the device;
+    fp64 weights, temporal rows (zero for frames a rank did not evaluate) and the frame mask: one packed fp64 SUM."""
     import torch
     import torch.distributed as dist
 
@@ -47,26 +46,31 @@ def reduce_eval(ev, group=None):
         return          # nothing to merge; frame_range already refreshed the host views
     on_gpu = dist.get_backend(group) == "nccl"
     dev = "cuda" if on_gpu else "cpu"
-    keep = []
+    keep, host_parts = [], []
     for v in ev.accum_views():
         if v.counts_dev and v.num_counts:
             t = _alias_counts(v, on_gpu)
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)      # in place on the evaluator's device accumulators
             keep.append(t)
         for ptr, n, ctype in ((v.weights64, v.num_weights, C.c_double), (v.temporal, v.num_temporal, C.c_float)):
-            if not ptr or not n:
-                continue
-            host = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ctype)), shape=(n,))
-            t = torch.from_numpy(host)
-            if on_gpu:
-                g = t.to(dev)
-                dist.all_reduce(g, op=dist.ReduceOp.SUM, group=group)
-                t.copy_(g.cpu())
-            else:
-                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
-    mask = torch.from_numpy(np.array(ev.frame_mask(), dtype=np.uint8, copy=True)).to(torch.int32).to(dev)
-    dist.all_reduce(mask, op=dist.ReduceOp.MAX, group=group)
+            if ptr and n:
+                host_parts.append(np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ctype)), shape=(n,)))
+    # everything that lives on the host (fp64 weights, temporal rows, the frame mask) travels as ONE fp64 buffer: a frame is
+    # evaluated by one rank, so SUM of the masks is 0/1 (> 0 is taken, which also covers ranks that evaluated the same frames)
+    mask = np.array(ev.frame_mask(), dtype=np.uint8, copy=True)
+    packed = np.concatenate([h.astype(np.float64, copy=False).ravel() for h in host_parts] + [mask.astype(np.float64)])
+    t = torch.from_numpy(packed)
     if on_gpu:
-        torch.cuda.synchronize()
-    ev.set_frame_mask(mask.cpu().to(torch.uint8).numpy())
+        g = t.to(dev)
+        dist.all_reduce(g, op=dist.ReduceOp.SUM, group=group)
+        t = g.cpu()
+        torch.cuda.synchronize()                                      # the in-place counts are final before finalize() reads them
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    merged = t.numpy()
+    off = 0
+    for h in host_parts:
+        h[...] = merged[off:off + h.size].astype(h.dtype)
+        off += h.size
+    ev.set_frame_mask((merged[off:] > 0.5).astype(np.uint8))
     ev.finalize()
