@@ -134,3 +134,41 @@ def test_dcd_trajectory_through_the_evaluator_on_emulator(tmp_path, emu_lib, ora
     np.testing.assert_array_equal(a.property_data("g").counts, b.property_data("g").counts)
     np.testing.assert_array_equal(a.property_data("g").weights64, b.property_data("g").weights64)
     assert a.property_data("g").counts.sum() > 0
+
+
+def test_staged_batches_are_decoded_on_several_threads(tmp_path, emu_lib, oracle):
+    """load_frame is called concurrently for the frames of one staged batch (VIAMD's decoders are re-entrant: its pool threads
+    call md_trajectory_load_frame at once, src/main.cpp:995-996): results must not depend on the thread count, and a failing
+    frame must surface as an error naming it."""
+    import cases
+    import pytest
+    box, F, N = 30.0, 40, 300
+    coords = cases.water_box(oracle, 21, N, box, F)
+    cell = V.make_unitcell(box)
+    p = tmp_path / "t.dcd"
+    V.write_dcd(p, coords, cell)
+    o = cases.oxygen(N)
+    ir = V.ScriptIR(emu_lib); ir.add_rdf("g", o, o, 8.0)
+    sysm = V.MolSystem(N, unitcell=cell)
+    res = []
+    for threads in (1, 8):
+        old = emu_lib.vmd_set_option(b"load_threads", threads)
+        try:
+            for traj in (V.DcdTrajectory(p, lib=emu_lib), V.HostTrajectory(coords, cell)):
+                ev = V.ScriptEval(F, ir)
+                assert ev.frame_range(sysm, traj, 0, F)
+                res.append(ev.property_data("g").counts.copy())
+        finally:
+            emu_lib.vmd_set_option(b"load_threads", old)
+    for r in res[1:]:
+        np.testing.assert_array_equal(r, res[0])
+    assert res[0].sum() > 0
+    # a truncated file: the frame count comes from the file size, so cut inside the last frame and ask for it
+    data = p.read_bytes()
+    q = tmp_path / "cut.dcd"
+    q.write_bytes(data[:len(data) - 100])
+    t = V.DcdTrajectory(q, lib=emu_lib)
+    assert t.num_frames() == F - 1
+    ev = V.ScriptEval(F, ir)
+    with pytest.raises(V.VmdError, match="fewer frames"):
+        ev.frame_range(sysm, t, 0, F)
