@@ -172,3 +172,46 @@ def test_staged_batches_are_decoded_on_several_threads(tmp_path, emu_lib, oracle
     ev = V.ScriptEval(F, ir)
     with pytest.raises(V.VmdError, match="fewer frames"):
         ev.frame_range(sysm, t, 0, F)
+
+
+def test_xyz_and_lammps_dump_readers(tmp_path):
+    from viamd_amd import textio
+    rng = np.random.default_rng(8)
+    F, N = 3, 11
+    coords = rng.normal(0, 9, (F, 3, N)).astype(np.float32)
+    elems = np.array(["O", "H", "H"] * 4)[:N]
+    cells = [V.make_unitcell((20.0 + f, 18.0, 16.0), tilt=(2.0, -1.0, 0.5 * f)) for f in range(F)]
+    p = tmp_path / "t.xyz"
+    textio.write_xyz(p, coords, elems, cells)
+    c2, e2, k2 = textio.read_xyz(p)
+    np.testing.assert_allclose(c2, coords, atol=1e-6)
+    assert list(e2) == list(elems)
+    for a, b in zip(k2, cells):
+        assert (a.x, a.y, a.z, a.xy, a.xz, a.yz, a.flags) == (b.x, b.y, b.z, b.xy, b.xz, b.yz, 7)
+    textio.write_xyz(p, coords, elems)                       # plain XYZ: no cell
+    assert textio.read_xyz(p)[2][0].flags == 0
+    # LAMMPS dump, triclinic, atoms out of order, scaled coordinates in the second frame
+    q = tmp_path / "d.lammpstrj"
+    xy, xz, yz, L = 3.0, -2.0, 1.5, (24.0, 22.0, 20.0)
+    lo = (-1.0, 2.0, 0.5)
+    with open(q, "w") as f:
+        for m in range(2):
+            f.write(f"ITEM: TIMESTEP\n{100 * m}\nITEM: NUMBER OF ATOMS\n{N}\nITEM: BOX BOUNDS xy xz yz pp pp pp\n")
+            f.write(f"{lo[0] + min(0, xy, xz, xy + xz)} {lo[0] + L[0] + max(0, xy, xz, xy + xz)} {xy}\n")
+            f.write(f"{lo[1] + min(0, yz)} {lo[1] + L[1] + max(0, yz)} {xz}\n{lo[2]} {lo[2] + L[2]} {yz}\n")
+            order = rng.permutation(N)
+            if m == 0:
+                f.write("ITEM: ATOMS id type x y z\n")
+                for i in order:
+                    f.write(f"{i + 1} {1 + i % 2} {float(coords[m, 0, i])!r} {float(coords[m, 1, i])!r} {float(coords[m, 2, i])!r}\n")
+            else:
+                f.write("ITEM: ATOMS id type xs ys zs\n")
+                A = np.array([[L[0], xy, xz], [0, L[1], yz], [0, 0, L[2]]])
+                s = np.linalg.solve(A, coords[m].astype(np.float64) - np.array(lo)[:, None])
+                for i in order:
+                    f.write(f"{i + 1} {1 + i % 2} {float(s[0, i])!r} {float(s[1, i])!r} {float(s[2, i])!r}\n")
+    c3, types, k3, steps = textio.read_lammps_dump(q)
+    assert steps == [0, 100] and list(types) == [1 + i % 2 for i in range(N)]
+    np.testing.assert_allclose(c3, coords[:2], atol=2e-5)
+    assert abs(k3[0].x - L[0]) < 1e-5 and abs(k3[0].y - L[1]) < 1e-5 and abs(k3[0].z - L[2]) < 1e-5
+    assert (abs(k3[1].xy - xy), abs(k3[1].xz - xz), abs(k3[1].yz - yz)) < (1e-6, 1e-6, 1e-6) and k3[0].flags == 7

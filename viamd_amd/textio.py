@@ -1,0 +1,119 @@
+"""Text trajectory decoders for the staging step in front of the hot path: multi-frame XYZ / XMOL and LAMMPS
+dump files.  VIAMD reads both through mdlib (`md_xyz_system_init_from_file`, `md_lammps_trajectory_attach_from_file`,
+/root/reference/src/loader.cpp:129-136, 147-148).  They return plain arrays; `viamd_amd.HostTrajectory(coords, cells)` or
+`PinnedHostTrajectory.upload` stages them for the evaluator."""
+import numpy as np
+
+from .eval import make_unitcell
+
+
+def read_xyz(path):
+    """Multi-frame XYZ: [natoms, comment, natoms x (element x y z ...)] repeated.  An extended-XYZ `Lattice="ax ay az bx by bz
+    cx cy cz"` in the comment line becomes the unit cell (lower-triangular form required).
+    Returns (coords float32 [F, 3, N], elements [N], cells list[F])."""
+    frames, cells, elements = [], [], None
+    with open(path) as f:
+        while True:
+            head = f.readline()
+            if not head.strip():
+                if head == "":
+                    break
+                continue
+            n = int(head.split()[0])
+            comment = f.readline()
+            xyz = np.empty((3, n), np.float32)
+            elems = []
+            for i in range(n):
+                t = f.readline().split()
+                if len(t) < 4:
+                    raise ValueError(f"{path}: frame {len(frames)}: atom line {i} is incomplete")
+                elems.append(t[0])
+                xyz[:, i] = (float(t[1]), float(t[2]), float(t[3]))
+            if elements is None:
+                elements = elems
+            elif len(elems) != len(elements):
+                raise ValueError(f"{path}: frame {len(frames)} has {len(elems)} atoms, the first frame {len(elements)}")
+            frames.append(xyz)
+            cells.append(_lattice_cell(comment))
+    if not frames:
+        raise ValueError(f"{path}: no frames")
+    return np.stack(frames), np.array(elements), cells
+
+
+def _lattice_cell(comment):
+    key = 'Lattice="'
+    i = comment.find(key)
+    if i < 0:
+        return make_unitcell(None)
+    v = [float(t) for t in comment[i + len(key):comment.index('"', i + len(key))].split()]
+    if len(v) != 9 or abs(v[1]) > 1e-6 or abs(v[2]) > 1e-6 or abs(v[5]) > 1e-6:
+        raise ValueError("extended XYZ lattice must be lower triangular: a=(x,0,0), b=(xy,y,0), c=(xz,yz,z)")
+    return make_unitcell((v[0], v[4], v[8]), tilt=(v[3], v[6], v[7]))
+
+
+def write_xyz(path, coords, elements, cells=None):
+    coords = np.asarray(coords)
+    with open(path, "w") as f:
+        for m in range(coords.shape[0]):
+            f.write(f"{coords.shape[2]}\n")
+            c = cells[m] if cells is not None else None
+            if c is not None and c.flags:
+                f.write(f'Lattice="{c.x!r} 0.0 0.0 {c.xy!r} {c.y!r} 0.0 {c.xz!r} {c.yz!r} {c.z!r}" frame={m}\n')
+            else:
+                f.write(f"frame {m}\n")
+            for i in range(coords.shape[2]):
+                f.write(f"{elements[i]} {coords[m, 0, i]:.6f} {coords[m, 1, i]:.6f} {coords[m, 2, i]:.6f}\n")
+
+
+def read_lammps_dump(path):
+    """LAMMPS text dump (`dump custom`): per frame ITEM: TIMESTEP / NUMBER OF ATOMS / BOX BOUNDS [xy xz yz] / ATOMS <columns>.
+    Columns: id (frames are sorted by it), type, and one of x y z | xu yu zu | xs ys zs (scaled by the cell).
+    Returns (coords float32 [F, 3, N], types int [N], cells list[F], timesteps list[F])."""
+    frames, cells, steps, types = [], [], [], None
+    with open(path) as f:
+        line = f.readline()
+        while line:
+            if not line.startswith("ITEM: TIMESTEP"):
+                line = f.readline()
+                continue
+            steps.append(int(f.readline()))
+            assert f.readline().startswith("ITEM: NUMBER OF ATOMS")
+            n = int(f.readline())
+            bounds = f.readline()
+            assert bounds.startswith("ITEM: BOX BOUNDS")
+            tri = "xy" in bounds.split()
+            periodic = [t for t in bounds.split() if len(t) == 2 and t[0] in "pfsm" and t[1] in "pfsm"]
+            rows = [[float(v) for v in f.readline().split()] for _ in range(3)]
+            xy, xz, yz = (rows[0][2], rows[1][2], rows[2][2]) if tri else (0.0, 0.0, 0.0)
+            # bounds of a triclinic box are those of its bounding box: undo (LAMMPS manual, "triclinic")
+            xlo = rows[0][0] - min(0.0, xy, xz, xy + xz); xhi = rows[0][1] - max(0.0, xy, xz, xy + xz)
+            ylo = rows[1][0] - min(0.0, yz); yhi = rows[1][1] - max(0.0, yz)
+            zlo, zhi = rows[2][0], rows[2][1]
+            flags = sum((1 << a) for a in range(3) if a < len(periodic) and periodic[a] == "pp") if periodic else 7
+            cell = make_unitcell((xhi - xlo, yhi - ylo, zhi - zlo), flags, (xy, xz, yz))
+            head = f.readline()
+            assert head.startswith("ITEM: ATOMS")
+            cols = head.split()[2:]
+            data = np.array([f.readline().split() for _ in range(n)], dtype=np.float64)
+            if "id" in cols:
+                data = data[np.argsort(data[:, cols.index("id")], kind="stable")]
+            for names, scaled in ((("x", "y", "z"), False), (("xu", "yu", "zu"), False), (("xs", "ys", "zs"), True)):
+                if all(c in cols for c in names):
+                    xyz = np.stack([data[:, cols.index(c)] for c in names])
+                    if scaled:
+                        s = xyz
+                        xyz = np.stack([xlo + s[0] * (xhi - xlo) + s[1] * xy + s[2] * xz, ylo + s[1] * (yhi - ylo) + s[2] * yz,
+                                        zlo + s[2] * (zhi - zlo)])
+                    break
+            else:
+                raise ValueError(f"{path}: no coordinate columns among {cols}")
+            if types is None:
+                types = data[:, cols.index("type")].astype(np.int64) if "type" in cols else np.zeros(n, np.int64)
+            elif xyz.shape[1] != types.size:
+                raise ValueError(f"{path}: the atom count changes between frames")
+            frames.append(xyz.astype(np.float32))
+            cells.append(cell)
+            line = f.readline()
+    if not frames:
+        raise ValueError(f"{path}: no frames")
+    return np.stack(frames), types, cells, steps
