@@ -417,3 +417,13 @@ def open_boundary_cases(lib, O, n, device=False):
     check_rdf(lib, O, flat, None, [("g", allidx, allidx, 0.0, 9.0)], device=device, oracle_method="brute")
     small = (c[:, :, :200] * 0.1).astype(np.float32)
     check_rdf(lib, O, small, None, [("g", np.arange(200), np.arange(200), 0.0, 12.0)], device=device, oracle_method="brute")
+
+
+def sdf_triclinic_spread_structures(lib, O, device=False):
+    """Regression (found by scripts/fuzz_emu_sdf.py): four reference structures spread over a triclinic cell.  The scatter's
+    group pre-filter relies on the triangle inequality of the minimum-image metric, which rounding in fractional space only
+    provides for vectors shorter than half the cell width; the filter must stand down when its reach is longer."""
+    import os
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sdf_triclinic_spread_structures.npz"))
+    box = tuple(float(v) for v in d["box"])
+    check_sdf(lib, O, d["coords"], box, d["structures"], d["mass"], d["tgt"], float(d["cutoff"]), device=device)

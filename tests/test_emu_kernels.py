@@ -174,3 +174,7 @@ def test_filtered_evaluation_reuses_block_partials(emu_lib, oracle):
 
 def test_open_boundaries_and_slabs_on_the_grid(emu_lib, oracle):
     cases.open_boundary_cases(emu_lib, oracle, 700)
+
+
+def test_sdf_triclinic_spread_structures_regression(emu_lib, oracle):
+    cases.sdf_triclinic_spread_structures(emu_lib, oracle)

@@ -420,3 +420,7 @@ def test_triclinic_config2_shape_against_oracle(gpu_lib, oracle):
 def test_open_boundaries_and_slabs_on_the_grid(gpu_lib, oracle):
     cases.open_boundary_cases(gpu_lib, oracle, 6000, device=True)
     cases.open_boundary_cases(gpu_lib, oracle, 1500, device=False)
+
+
+def test_sdf_triclinic_spread_structures_regression(gpu_lib, oracle):
+    cases.sdf_triclinic_spread_structures(gpu_lib, oracle, device=True)

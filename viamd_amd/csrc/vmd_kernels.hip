@@ -1391,12 +1391,21 @@ __device__ __forceinline__ void vmd_sdf_atom_k(const vmd_scatter_params_t& p, co
 
 // group pre-filter (k_sdf_group): can this atom reach ANY structure's cube?  A voxel hit needs |q|_inf < s, hence
 // |d| = |q| < sqrt(3) s; with the group sphere (centre g, radius g[3]) one distance test replaces K.
+// The argument is the triangle inequality of the minimum-image metric.  Per-axis rounding (orthorhombic) IS that metric;
+// rounding in fractional space (triclinic, S5) only agrees with it for vectors shorter than half the smallest cell width, so
+// in a triclinic cell the filter is used only while the whole reach stays below that (else every atom goes to the K tests).
 __device__ __forceinline__ bool vmd_sdf_near(const vmd_scatter_params_t& p, const vmd_box_t& bx, int b, float x, float y, float z) {
     if (!p.group) return true;
     const float* g = p.group + 4 * (size_t)b;
+    const float reach = (1.7320508f * p.extent * 1.0005f + 1.0e-3f) + g[3];
+    if (bx.tri) {
+        const float ty = bx.yz * bx.iLz, tx1 = bx.xy * bx.iLy, tx2 = (bx.xy * bx.yz - bx.Ly * bx.xz) * (bx.iLy * bx.iLz);
+        const float wy = bx.Ly / sqrtf(1.0f + ty * ty), wx = bx.Lx / sqrtf(1.0f + tx1 * tx1 + tx2 * tx2);
+        const float wmin = fminf(bx.Lz, fminf(wx, wy));
+        if (!(reach < 0.499f * wmin)) return true;
+    }
     float dx = x - g[0], dy = y - g[1], dz = z - g[2];
     vmd_mi3_rintf(bx, dx, dy, dz);
-    const float reach = (1.7320508f * p.extent * 1.0005f + 1.0e-3f) + g[3];
     return vmd_d2(dx, dy, dz) <= reach * reach;
 }
 
