@@ -36,6 +36,8 @@ for it in range(ncases):
         coords[:, :, : n // 4] = coords[:, :, : n // 4] * 0.2 + np.array([Lx, Ly, Lz])[None, :, None] * 0.4   # a dense blob
     if rng.random() < 0.2:
         coords[:, int(rng.integers(0, 3)), :] = np.float32(rng.uniform(0, 10))                               # planar
+    if rng.random() < 0.25:                             # an unwrapped / far-away system: whole cells (or kilo-Angstroms) off the origin
+        coords += (A @ rng.integers(-30, 30, (3, 1))).astype(np.float32)[None] if flags == 7 else np.float32(rng.uniform(-3000, 3000))
     same = rng.random() < 0.5
     a = np.sort(rng.choice(n, int(rng.integers(1, n + 1)), replace=False)).astype(np.int32)
     b = a if same else np.sort(rng.choice(n, int(rng.integers(1, n + 1)), replace=False)).astype(np.int32)

@@ -946,7 +946,10 @@ static bool choose_grid(const std::vector<float>& boxes, uint32_t pbc, size_t nb
     int n[3];
     for (int a = 1; a < 3; ++a) {
         int k = (int)std::floor(wmin[a] / rmax);
-        while (k > 1 && ((float)k / wmin[a]) * rmax > 0.9999f) k -= 1;
+        // head room between the pencil edge and rmax: wrapped coordinates are exact to ~1e-6 of the edge; on an open axis
+        // coordinates keep their raw magnitude (possibly far from the origin), so leave ten times more
+        const float edge_margin = (pbc & (1u << a)) ? 0.9999f : 0.999f;
+        while (k > 1 && ((float)k / wmin[a]) * rmax > edge_margin) k -= 1;
         if (pbc & (1u << a)) { if (k < 2) return false; }
         else k = std::max(k, 1);
         n[a] = std::min(k, 1024);

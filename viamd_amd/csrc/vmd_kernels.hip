@@ -1016,6 +1016,9 @@ __global__ __launch_bounds__(256) VMD_SGPR_CAP(96) void k_rdf_pencil(vmd_pair_pa
         // open x axis: fine cells count from the bounding-box origin (0 on a periodic axis)
         const bool open_x = OPEN && !(p.pbc & 1u), open_y = OPEN && !(p.pbc & 2u), open_z = OPEN && !(p.pbc & 4u);
         const float orgx = open_x ? boxes[VMD_BOX_STRIDE * b + 6] : 0.0f;
+        // open x axis: coordinates are not wrapped, so x - origin is rounded at the magnitude of the raw coordinate, in the
+        // build and again here; widen the window by a few such ulps (a system far from the origin must not lose a boundary pair)
+        const float pad_open = open_x ? 8.0e-7f * (fabsf(orgx) + Lx) : 0.0f;
         vmd_cu32* csr = (vmd_cu32*)p.cs_ref + (size_t)b * (p.grid.ncell + 1);
         vmd_cu32* cst = (vmd_cu32*)p.cs_tgt + (size_t)b * (p.grid.ncell + 1);
         const float* __restrict__ sr = p.sref + (size_t)b * 3 * p.nref_pad;
@@ -1055,8 +1058,8 @@ __global__ __launch_bounds__(256) VMD_SGPR_CAP(96) void k_rdf_pencil(vmd_pair_pa
                         if (open_x && kx != 0) continue;
                         float sx = (float)kx * Lx;
                         if (TRI) vmd_lattice_shift(Lx, Ly, Lz, txy, txz, tyz, (float)kx, nb, nc, sx, sy, sz);
-                        const float lo = (xlo - p.rpad) - sx - offmax - orgx;
-                        const float hi = (xhi + p.rpad) - sx - offmin - orgx;
+                        const float lo = (xlo - p.rpad) - sx - offmax - orgx - pad_open;
+                        const float hi = (xhi + p.rpad) - sx - offmin - orgx + pad_open;
                         if (hi < 0.0f || lo >= Lx) continue;
                         const int ca = lo <= 0.0f ? 0 : vmd_cell_coord(lo, inv_cx, nxf);
                         const int cb = hi >= Lx ? nxf - 1 : vmd_cell_coord(hi, inv_cx, nxf);
