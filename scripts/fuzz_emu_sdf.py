@@ -51,7 +51,16 @@ for it in range(ncases):
         cases.check_sdf(lib, O, coords, box, structures, mass, tgt, cutoff, flags=flags)
         specs = [("d", structures[0], structures[-1], L.DIST_COM), ("mn", structures[0], tgt[:40], L.DIST_MIN),
                  ("mx", structures[-1][:2], tgt[5:30], L.DIST_MAX), ("p", structures[0][:2], tgt[:3], L.DIST_PAIR)]
-        cases.check_distances(lib, O, coords, box, mass, specs, flags=flags)
+        if K > 1:       # populations: `distance*(...) in <contexts>`, one context per structure
+            h = max(1, m // 2)
+            specs += [("pc", [s_[:h] for s_ in structures], [s_[h:] for s_ in structures], L.DIST_COM, "pop"),
+                      ("pm", [s_[:1] for s_ in structures], [s_[1:] for s_ in structures], L.DIST_MIN, "pop"),
+                      ("px", [s_[:h] for s_ in structures], [s_[h:] for s_ in structures], L.DIST_MAX, "pop"),
+                      ("pp", [s_[:2] for s_ in structures], [s_[2:] for s_ in structures], L.DIST_PAIR, "pop")]
+        rg = None
+        if F > 1 and rng.random() < 0.5:
+            kk = int(rng.integers(1, F)); rg = [(kk, F), (0, kk)]
+        cases.check_distances(lib, O, coords, box, mass, specs, flags=flags, ranges=rg)
     except AssertionError as e:
         if not str(e):
             continue                      # the harness's own "volume is not empty" check: nothing to compare in this case
