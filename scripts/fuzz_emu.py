@@ -15,7 +15,7 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 bad = 0
 for it in range(ncases):
     kind = rng.choice(["ortho", "tri", "open", "mixed"])
-    n = int(rng.integers(40, 700))
+    n = int(rng.integers(40, int(os.environ.get("FUZZ_NMAX", "700"))))
     F = int(rng.integers(1, 4))
     Lx, Ly, Lz = rng.uniform(18, 60, 3)
     rmax = float(rng.uniform(2.0, 0.49 * min(Lx, Ly, Lz)))
