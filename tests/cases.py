@@ -415,6 +415,9 @@ def open_boundary_cases(lib, O, n, device=False):
     # flat system (zero extent along z), and a cutoff larger than the whole cloud (one cell per axis)
     flat = c.copy(); flat[:, 2, :] = 3.25
     check_rdf(lib, O, flat, None, [("g", allidx, allidx, 0.0, 9.0)], device=device, oracle_method="brute")
+    # the same cloud kilo-Angstroms away from the origin: x - origin is rounded at the magnitude of the raw coordinate
+    far = (c + np.float32(2500.0)).astype(np.float32)
+    check_rdf(lib, O, far, None, [("g", a, b, 0.0, 9.0)], device=device, oracle_method="brute")
     small = (c[:, :, :200] * 0.1).astype(np.float32)
     check_rdf(lib, O, small, None, [("g", np.arange(200), np.arange(200), 0.0, 12.0)], device=device, oracle_method="brute")
 
