@@ -3,9 +3,9 @@
  *
  * Mirrors the part of mdlib's md_script surface that VIAMD calls on its evaluation hot path
  * (SURVEY.md 8b).  Each entry point names the reference call site it replaces (paths relative to
- * /root/reference).  The script *compiler* (md_script_ir_compile_from_source, src/main.cpp:878) is out
- * of scope: the IR here is a list of property descriptors filled by vmd_ir_add_* (a mini front-end that
- * produces them from script text lives in viamd_amd/script.py).
+ * /root/reference).  The full script *compiler* (md_script_ir_compile_from_source, src/main.cpp:878) is out
+ * of scope: the IR here is a list of property descriptors filled by vmd_ir_add_*, or by the mini front-end
+ * vmd_ir_compile_from_source for the script forms VIAMD ships and generates.
  *
  * All compute runs in hand-written HIP kernels (include/vmd_hip.h); there is no CPU fallback: every
  * function that needs the device returns false/NULL and logs when no HIP device is usable.
@@ -122,6 +122,21 @@ bool vmd_ir_add_distance(vmd_script_ir_t* ir, const char* name, vmd_distance_kin
  * back to back; context c owns a[a_offsets[c] .. a_offsets[c+1]) and b[b_offsets[c] .. b_offsets[c+1]). */
 bool vmd_ir_add_distance_population(vmd_script_ir_t* ir, const char* name, vmd_distance_kind_t kind, size_t P,
                                     const int32_t* a, const int32_t* a_offsets, const int32_t* b, const int32_t* b_offsets);
+/* md_script_ir_compile_from_source stand-in (src/main.cpp:878) for the script subset of the hot path: statements
+ * `s = <selection>;`, `r = rdf(sel, sel, rmax | rmin:rmax | {rmin, rmax});`, `v = sdf(structures, sel, cutoff);`,
+ * `d = distance[_min|_max|_pair](sel, sel) [in <structures>];` with selections element('X'), type/name/label('X'),
+ * resname("X"), residue(a:b), resid(a:b), atom(a:b), a[:b] (1-based atom indices, src/main.cpp:2817), all, water, protein,
+ * and / or / not, parentheses, and sel[a:b] slicing an array of structures (viamd_amd/csrc/vmd_script.cpp).  Appends one
+ * descriptor per property to `ir`; false + vmd_last_error() on a syntax or range error (the ir may then hold the properties
+ * of the statements before the error).  The topology is the part of md_system_t selections resolve against. */
+typedef struct vmd_topology_t {
+    size_t num_atoms;
+    const char* const* elements;     /* per atom, e.g. "O" */
+    const char* const* names;        /* per atom (atom type / label); NULL = elements */
+    const char* const* resnames;     /* per atom; NULL = "UNK" */
+    const int32_t* residue_index;    /* per atom, 0-based; NULL = one residue */
+} vmd_topology_t;
+bool     vmd_ir_compile_from_source(vmd_script_ir_t* ir, const char* source, const vmd_topology_t* topology);
 bool     vmd_ir_valid(const vmd_script_ir_t* ir);                       /* md_script_ir_valid, src/main.cpp:936 */
 uint64_t vmd_ir_fingerprint(const vmd_script_ir_t* ir);                 /* md_script_ir_fingerprint, src/main.cpp:937 */
 size_t   vmd_ir_property_count(const vmd_script_ir_t* ir);              /* md_script_ir_property_count, src/main.cpp:992,1277 */

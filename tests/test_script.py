@@ -82,3 +82,47 @@ def test_script_driven_evaluation_matches_oracle(emu_lib, oracle):
     np.testing.assert_array_equal(ev.property_data("d").values.reshape(F, -1), d)
     m = cases.oracle_distance(oracle, coords, ocell, topo.mass, info["m"]["a"], info["m"]["b"], L.DIST_MAX)
     np.testing.assert_array_equal(ev.property_data("m").values.reshape(F, -1), m)
+
+
+GOOD_SCRIPTS = [
+    "g = rdf(element('O') and water, element('O') and water, 12.0);",
+    """# default script shape of src/main.cpp:528
+       s1 = resname("ALA")[2:8];
+       r = rdf(element('C'), element('H'), 10.0);
+       v = sdf(s1, element('H'), 10.0);
+       d1 = distance(10, 30);
+       d2 = distance_min(residue(3), water and element('O'));
+       h = rdf(not element('H'), not element('H'), {2.0, 9.0});""",
+    "s = residue(5:11); v = sdf(s, element('O') and water, 10.0)",
+    "d = distance(1, 5) in residue(3); p = distance_min(1:2, element('O')) in resname(\"ALA\")[2:4];",
+    "q = distance_pair(1:2, 4:6) in residue(10:14); x = distance_max(atom(3), atom(7:9)) in resname('ALA')[1:3];",
+    "a = (element('N', 'C') or name('O')) and protein and not residue(1:5); g = rdf(a, water and element('H'), 1.5:7.25); ;",
+    "w = water[3:40]; v = sdf(w, all, 4.5); m = distance_min(w[1:2], protein);",
+    "t = type('H') and resid(201:300); g = rdf(t, t, 6.0); d = distance(t, label('C'));",
+    "v = sdf(residue(1:2) and element('C', 'N'), all, 3.0) ; w = sdf(residue(1) or residue(201), all, 3.0);",
+    # BASELINE config 5
+    "goo = rdf(element('O') and water, element('O') and water, 12.0);goh = rdf(element('O') and water, element('H') and water, 12.0);"
+    "ghv = rdf(not element('H'), not element('H'), 12.0);s = residue(5:11); v = sdf(s, element('O') and water, 10.0);"
+    "d1 = distance(1, 1990); d2 = distance(residue(1), residue(200));d3 = distance_min(residue(3), residue(150)); d4 = distance_max(residue(10), residue(20));",
+]
+
+BAD_SCRIPTS = ["g = rdf(element('X'), all, 5.0);", "v = sdf(all[1:2], all, 5.0);", "d = distance(1, 999999);", "d = distance(1, 2) in all;",
+               "d = distance(1, 99) in residue(3);", "g = rdf(all, all 5.0);", "x = frobnicate(3);", "g = rdf(residue(0), all, 5.0);",
+               "g = rdf(all, all, 5.0", "v = sdf(resname('ALA')[1:900], all, 3.0);", "s = element('O) ; g = rdf(s, s, 4.0);", "g = rdf(all, @, 4.0);",
+               "w = sdf(resname('ALA', 'HOH')[200:201], all, 3.0);"]
+
+
+def test_native_front_end_matches_the_python_one(emu_lib, topo):
+    """vmd_ir_compile_from_source (C++) against viamd_amd/script.py: identical descriptors, i.e. identical IR fingerprints,
+    names and flags; the same scripts are rejected."""
+    for text in GOOD_SCRIPTS:
+        ir_py, _ = script.compile_script(text, topo, lib=emu_lib)
+        ir_c = script.compile_script_native(text, topo, lib=emu_lib)
+        assert ir_c.property_names() == ir_py.property_names(), text
+        assert [ir_c.property_flags(n) for n in ir_c.property_names()] == [ir_py.property_flags(n) for n in ir_py.property_names()]
+        assert ir_c.fingerprint() == ir_py.fingerprint(), text
+    for text in BAD_SCRIPTS:
+        with pytest.raises((script.ScriptError, V.VmdError)):
+            script.compile_script_native(text, topo, lib=emu_lib)
+        with pytest.raises((script.ScriptError, V.VmdError, ValueError)):
+            script.compile_script(text, topo, lib=emu_lib)

@@ -56,6 +56,11 @@ class HostView(C.Structure):
 HOST_VIEW_FN = C.CFUNCTYPE(C.c_bool, C.c_void_p, C.POINTER(HostView))
 
 
+class TopologyC(C.Structure):
+    _fields_ = [("num_atoms", C.c_size_t), ("elements", C.POINTER(C.c_char_p)), ("names", C.POINTER(C.c_char_p)),
+                ("resnames", C.POINTER(C.c_char_p)), ("residue_index", c_int32_p)]
+
+
 class TrajectoryI(C.Structure):
     _fields_ = [("inst", C.c_void_p), ("num_frames", NUM_FRAMES_FN), ("num_atoms", NUM_ATOMS_FN),
                 ("load_frame", LOAD_FRAME_FN), ("device_view", DEVICE_VIEW_FN), ("host_view", HOST_VIEW_FN)]
@@ -92,6 +97,7 @@ SIGNATURES = [
     ("vmd_ir_add_sdf", C.c_bool, [_vp, C.c_char_p, c_int32_p, C.c_size_t, C.c_size_t, c_int32_p, C.c_size_t, C.c_float]),
     ("vmd_ir_add_distance", C.c_bool, [_vp, C.c_char_p, C.c_int, c_int32_p, C.c_size_t, c_int32_p, C.c_size_t]),
     ("vmd_ir_add_distance_population", C.c_bool, [_vp, C.c_char_p, C.c_int, C.c_size_t, c_int32_p, c_int32_p, c_int32_p, c_int32_p]),
+    ("vmd_ir_compile_from_source", C.c_bool, [_vp, C.c_char_p, C.POINTER(TopologyC)]),
     ("vmd_ir_valid", C.c_bool, [_vp]),
     ("vmd_ir_fingerprint", C.c_uint64, [_vp]),
     ("vmd_ir_property_count", C.c_size_t, [_vp]),

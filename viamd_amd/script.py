@@ -310,3 +310,21 @@ def compile_script(text, topo, lib=None):
         if p.peek()[0] is not None:
             p.take(";")
     return ir, info
+
+
+def compile_script_native(text, topo, lib=None):
+    """The same front-end in C++ (vmd_ir_compile_from_source, viamd_amd/csrc/vmd_script.cpp): what a C / C++ host calls.
+    Returns a ScriptIR; raises ScriptError with the library's message."""
+    import ctypes as C
+    ir = ScriptIR(lib)
+    n = topo.num_atoms
+
+    def strings(arr):
+        return (C.c_char_p * n)(*[str(v).encode() for v in arr])
+
+    el, nm, rn = strings(topo.elements), strings(topo.names), strings(topo.resnames)
+    ri = np.ascontiguousarray(topo.residue_index, np.int32)
+    tc = L.TopologyC(n, el, nm, rn, ri.ctypes.data_as(L.c_int32_p))
+    if not ir.lib.vmd_ir_compile_from_source(ir.h, text.encode(), C.byref(tc)):
+        raise ScriptError(ir.lib.last_error())
+    return ir
