@@ -32,3 +32,45 @@ def test_native_host_runs_like_viamd():
     out = subprocess.run([exe, "96"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     assert out.stdout.startswith("OK frames=96"), out.stdout
+
+
+def test_native_host_from_dcd_and_script_text_on_the_emulator(tmp_path, emu_lib, oracle):
+    """No Python on the hot path: a C++ program links the C ABI (here the SIMT-emulator build of the same sources, so it runs
+    without a GPU), reads a DCD file, compiles the script text with vmd_ir_compile_from_source and evaluates it; its output
+    must equal what the Python host computes for the same file."""
+    import numpy as np
+    import cases
+    import conftest
+    import viamd_amd as V
+    from viamd_amd import script, synth
+    n_blob, n_atoms, box, F = 60, 60 + 600, 28.0, 3
+    topo = synth.water_box_topology(n_atoms, n_blob)
+    coords = cases.host_frames(oracle, 17, n_atoms, box, F, n_blob)
+    cell = V.make_unitcell(box)
+    dcd = tmp_path / "t.dcd"
+    V.write_dcd(dcd, coords, cell)
+    text = ("s = residue(2:4); v = sdf(s, element('O') and water, 7.0); g = rdf(element('O') and water, not element('H'), 8.0);"
+            "d = distance(residue(1), residue(6)); m = distance_min(1:2, element('O')) in residue(2:5);")
+    src = os.path.join(ROOT, "tests", "native", "cabi_script_demo.cpp")
+    exe = str(tmp_path / "cabi_script_demo")
+    emu = conftest.build_emu()
+    subprocess.check_call(["g++", "-std=c++17", "-O1", src, "-I" + os.path.join(ROOT, "include"), emu, "-Wl,-rpath," + os.path.dirname(emu),
+                           "-lpthread", "-o", exe])
+    out = subprocess.run([exe, str(dcd), str(n_blob), text], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = dict(l.split(" ", 1) for l in out.stdout.strip().split("\n"))
+    ir, info = script.compile_script(text, topo, lib=emu_lib)
+    ev = V.ScriptEval(F, ir)
+    assert ev.frame_range(V.MolSystem(n_atoms, mass=topo.mass, unitcell=cell), V.DcdTrajectory(dcd, lib=emu_lib), 0, F)
+    for name in ("v", "g"):
+        want = float(ev.property_data(name).counts.sum())
+        got = float(lines[name].split("sum=")[1].split()[0])
+        assert got == want and want > 0, (name, lines[name])
+    for name in ("d", "m"):
+        want = float(ev.property_data(name).values.astype(np.float64).sum())
+        got = float(lines[name].split("sum=")[1].split()[0])
+        assert abs(got - want) <= 1e-6 * abs(want), (name, lines[name])
+    assert lines["m"].split()[1].startswith("dim=3,4")             # 3 frames x a population of 4 contexts
+    g8 = V.downsample_histogram(ev.property_data("g").values, ev.property_data("g").weights, 8, lib=emu_lib)
+    got8 = [float(t) for t in lines["g"].split("g8=")[1].split(",")]
+    np.testing.assert_allclose(got8, g8[6:8], rtol=1e-5)
