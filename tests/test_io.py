@@ -215,3 +215,19 @@ def test_xyz_and_lammps_dump_readers(tmp_path):
     np.testing.assert_allclose(c3, coords[:2], atol=2e-5)
     assert abs(k3[0].x - L[0]) < 1e-5 and abs(k3[0].y - L[1]) < 1e-5 and abs(k3[0].z - L[2]) < 1e-5
     assert (abs(k3[1].xy - xy), abs(k3[1].xz - xz), abs(k3[1].yz - yz)) < (1e-6, 1e-6, 1e-6) and k3[0].flags == 7
+
+
+def test_gro_reader_multi_frame_and_triclinic_box(tmp_path):
+    from viamd_amd import textio
+    rng = np.random.default_rng(3)
+    F, N = 2, 9
+    coords = rng.uniform(-5, 45, (F, 3, N)).astype(np.float32)
+    resid = np.repeat(np.arange(1, 4), 3); resname = np.array(["SOL"] * N); name = np.array(["OW", "HW1", "HW2"] * 3)
+    cells = [V.make_unitcell((40.0, 38.0, 36.0)), V.make_unitcell((40.0, 38.0, 36.0), tilt=(5.0, -3.0, 4.0))]
+    p = tmp_path / "w.gro"
+    textio.write_gro(p, coords, resid, resname, name, cells)
+    c2, meta, k2 = textio.read_gro(p)
+    np.testing.assert_allclose(c2, coords, atol=6e-3)              # %8.3f in nm = 0.005 A
+    assert list(meta["name"]) == list(name) and list(meta["resid"]) == list(resid) and meta["resname"][0] == "SOL"
+    assert (k2[0].x, k2[0].y, k2[0].z, k2[0].xy, k2[0].flags) == (40.0, 38.0, 36.0, 0.0, 7)
+    np.testing.assert_allclose([k2[1].xy, k2[1].xz, k2[1].yz], [5.0, -3.0, 4.0], atol=1e-4)

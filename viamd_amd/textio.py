@@ -117,3 +117,66 @@ def read_lammps_dump(path):
     if not frames:
         raise ValueError(f"{path}: no frames")
     return np.stack(frames), types, cells, steps
+
+
+def read_gro(path):
+    """GROMACS .gro, one or many frames (VIAMD: md_gro_system_init_from_file, src/loader.cpp:125-126).  Fixed columns
+    `%5d%-5s%5s%5d%8.3f%8.3f%8.3f`, nanometres (converted to Angstrom here); box line `v1x v2y v3z [v1y v1z v2x v2z v3x v3y]`.
+    Returns (coords float32 [F, 3, N] in Angstrom, dict(resid, resname, name) of the first frame, cells list[F])."""
+    frames, cells, meta = [], [], None
+    with open(path) as f:
+        while True:
+            title = f.readline()
+            if title == "":
+                break
+            count = f.readline()
+            if not count.strip():
+                break
+            n = int(count)
+            xyz = np.empty((3, n), np.float32)
+            resid, resname, name = [], [], []
+            for i in range(n):
+                line = f.readline()
+                if len(line) < 44:
+                    raise ValueError(f"{path}: frame {len(frames)}: atom line {i} is too short")
+                if meta is None:
+                    resid.append(int(line[0:5])); resname.append(line[5:10].strip()); name.append(line[10:15].strip())
+                # the coordinate columns may be wider than 8.3 (higher precision files): split the rest evenly in 3 or 6 fields
+                rest = line[20:].rstrip("\n")
+                ncol = 6 if len(rest.split()) >= 6 else 3
+                w = len(rest) // ncol if len(rest) % ncol == 0 else 8
+                xyz[:, i] = [10.0 * float(rest[k * w:(k + 1) * w]) for k in range(3)]
+            box = [10.0 * float(t) for t in f.readline().split()]
+            if len(box) == 3:
+                cell = make_unitcell(box)
+            elif len(box) == 9:
+                if abs(box[3]) > 1e-6 or abs(box[4]) > 1e-6 or abs(box[6]) > 1e-6:
+                    raise ValueError(f"{path}: box vectors must be lower triangular (v1 along x, v2 in the xy plane)")
+                cell = make_unitcell(box[:3], tilt=(box[5], box[7], box[8]))
+            else:
+                raise ValueError(f"{path}: bad box line")
+            if meta is None:
+                meta = dict(resid=np.array(resid), resname=np.array(resname), name=np.array(name))
+            elif xyz.shape[1] != meta["resid"].size:
+                raise ValueError(f"{path}: the atom count changes between frames")
+            frames.append(xyz)
+            cells.append(cell)
+    if not frames:
+        raise ValueError(f"{path}: no frames")
+    return np.stack(frames), meta, cells
+
+
+def write_gro(path, coords, resid, resname, name, cells):
+    """coords in Angstrom [F, 3, N]; one Unitcell per frame."""
+    coords = np.asarray(coords)
+    with open(path, "w") as f:
+        for m in range(coords.shape[0]):
+            f.write(f"frame t= {float(m):.5f}\n{coords.shape[2]:5d}\n")
+            for i in range(coords.shape[2]):
+                f.write("%5d%-5s%5s%5d%8.3f%8.3f%8.3f\n" % (resid[i] % 100000, resname[i][:5], name[i][:5], (i + 1) % 100000,
+                                                            coords[m, 0, i] / 10.0, coords[m, 1, i] / 10.0, coords[m, 2, i] / 10.0))
+            c = cells[m]
+            if c.xy == 0.0 and c.xz == 0.0 and c.yz == 0.0:
+                f.write("%10.5f%10.5f%10.5f\n" % (c.x / 10, c.y / 10, c.z / 10))
+            else:
+                f.write("%10.5f%10.5f%10.5f%10.5f%10.5f%10.5f%10.5f%10.5f%10.5f\n" % (c.x / 10, c.y / 10, c.z / 10, 0, 0, c.xy / 10, 0, c.xz / 10, c.yz / 10))
