@@ -257,6 +257,24 @@ vmd_dcdtraj_t*    vmd_dcdtraj_open(const char* path);
 void              vmd_dcdtraj_close(vmd_dcdtraj_t* t);
 vmd_trajectory_i* vmd_dcdtraj_interface(vmd_dcdtraj_t* t);
 
+/* GROMACS XTC (compressed) / TRR trajectory file as a vmd_trajectory_i - VIAMD attaches these through md_xtc_attach_from_file /
+ * md_trr_attach_from_file (src/loader.cpp:147-150).  The file type is taken from the magic number; a frame-offset index is
+ * built on open; nm -> Angstrom; box rows -> {x,y,z,xy,xz,yz}; TRR frames without positions are skipped.  load_frame is
+ * thread safe (pread + thread-local scratch), so staged batches are decompressed on several host threads. */
+typedef struct vmd_xdrtraj_t vmd_xdrtraj_t;
+vmd_xdrtraj_t*    vmd_xdrtraj_open(const char* path);
+void              vmd_xdrtraj_close(vmd_xdrtraj_t* t);
+vmd_trajectory_i* vmd_xdrtraj_interface(vmd_xdrtraj_t* t);
+int               vmd_xdrtraj_kind(const vmd_xdrtraj_t* t);                 /* 0 = XTC, 1 = TRR */
+int64_t           vmd_xdrtraj_frame_step(const vmd_xdrtraj_t* t, size_t frame);   /* MD step number stored with the frame */
+/* writer for the same two formats (test fixtures, `bench.py --traj xtc`): kind 0 = XTC at `precision` (1000 = 0.001 nm),
+ * 1 = TRR single precision.  Coordinates and cell in Angstrom. */
+typedef struct vmd_xdrwriter_t vmd_xdrwriter_t;
+vmd_xdrwriter_t*  vmd_xdrwriter_open(const char* path, int kind, size_t num_atoms, float precision);
+bool              vmd_xdrwriter_write_frame(vmd_xdrwriter_t* w, int64_t step, float time_ps, const vmd_unitcell_t* cell,
+                                            const float* x, const float* y, const float* z);
+bool              vmd_xdrwriter_close(vmd_xdrwriter_t* w);
+
 /* host-resident trajectory in pinned memory, float[F][3][npad] (the PCIe-inclusive path: frames cross the bus per batch) */
 typedef struct vmd_hosttraj_t vmd_hosttraj_t;
 vmd_hosttraj_t*   vmd_hosttraj_create(size_t num_frames, size_t num_atoms);

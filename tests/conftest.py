@@ -28,6 +28,7 @@ EMU_LIB = os.path.join(EMU_DIR, "libviamd_emu.so")
 EMU_SOURCES = [os.path.join(ROOT, "viamd_amd", "csrc", "vmd_kernels.hip"),
                os.path.join(ROOT, "viamd_amd", "csrc", "vmd_eval.cpp"),
                os.path.join(ROOT, "viamd_amd", "csrc", "vmd_dcd.cpp"),
+               os.path.join(ROOT, "viamd_amd", "csrc", "vmd_xdr.cpp"),
                os.path.join(ROOT, "viamd_amd", "csrc", "vmd_script.cpp"),
                os.path.join(EMU_DIR, "emu.cpp")]
 EMU_DEPS = EMU_SOURCES + [os.path.join(EMU_DIR, "hip", "hip_runtime.h"),

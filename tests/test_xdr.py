@@ -1,0 +1,246 @@
+"""GROMACS XTC / TRR readers (viamd_amd/csrc/vmd_xdr.cpp; VIAMD: md_xtc_attach_from_file / md_trr_attach_from_file,
+/root/reference/src/loader.cpp:147-150).  No GROMACS-written fixture exists in /root/reference, so the format is pinned to
+tests/xtc_ref.py, an independent byte-wise restatement of the published compression: files of the two writers must be
+byte-identical and both decoders must return the same integers."""
+import struct
+
+import numpy as np
+import pytest
+
+import viamd_amd as V
+import xtc_ref
+
+
+def _systems():
+    rng = np.random.default_rng(11)
+    out = {}
+    # water (rigid TIP3P geometry, random orientations) -> runs of 2, the water swap, smallidx adaptation
+    n_w = 7 * 8 * 8                                                          # liquid-like: no two molecules overlap
+    o = np.stack(np.meshgrid(np.arange(7), np.arange(8), np.arange(8), indexing="ij"), -1).reshape(-1, 3) * 3.1
+    o = o + rng.uniform(-0.3, 0.3, o.shape) + 1.0
+    u = rng.normal(0, 1, (n_w, 3)); u /= np.linalg.norm(u, axis=1, keepdims=True)          # bisector
+    v = np.cross(u, rng.normal(0, 1, (n_w, 3))); v /= np.linalg.norm(v, axis=1, keepdims=True)  # in-plane normal to it
+    half = np.radians(104.52 / 2)
+    h = o[:, None, :] + 0.9572 * np.stack([np.cos(half) * u + np.sin(half) * v, np.cos(half) * u - np.sin(half) * v], axis=1)
+    w = np.concatenate([o[:, None, :], h], axis=1).reshape(-1, 3)
+    out["water"] = w.T.astype(np.float32)
+    # ideal gas with negative coordinates: hardly any run
+    out["gas"] = rng.uniform(-40.0, 55.0, (3, 257)).astype(np.float32)
+    # a chain: long runs, smallidx walks down and up
+    steps = rng.normal(0, 0.3, (900, 3))
+    steps[300:600] *= 8.0
+    out["chain"] = np.cumsum(steps, axis=0).T.astype(np.float32)
+    # a range above 2^24 grid steps on x: the three-field branch (bitsize == 0)
+    wide = rng.uniform(0, 50.0, (3, 64)).astype(np.float32)
+    wide[0] *= 5000.0
+    out["wide"] = wide
+    # exactly on a lattice: many identical differences, zero differences
+    g = np.stack(np.meshgrid(np.arange(6), np.arange(5), np.arange(4), indexing="ij"), -1).reshape(-1, 3) * 1.5
+    out["lattice"] = g.T.astype(np.float32)
+    # tight clusters of 2..9 atoms far from each other: every run length 1..8
+    cl = []
+    for g_i in range(64):
+        centre = rng.uniform(0, 60.0, 3)
+        cl.append(centre + rng.normal(0, 0.05, (2 + g_i % 8, 3)))
+    out["clusters"] = np.concatenate(cl).T.astype(np.float32)
+    out["tiny"] = rng.uniform(0, 10.0, (3, 7)).astype(np.float32)          # <= 9 atoms: stored as plain floats
+    out["ten"] = rng.uniform(0, 10.0, (3, 10)).astype(np.float32)          # smallest compressed frame
+    return out
+
+
+def _expected_xtc(coords_A, precision):
+    """What the reader must return: fl(fl(int * fl(1/precision)) * 10) of the integers the format stores."""
+    nm = (np.asarray(coords_A, np.float32) * np.float32(0.1)).T
+    ints = xtc_ref.to_ints(nm, precision)
+    invp = np.float32(1.0) / np.float32(precision)
+    return ((ints.astype(np.float32) * invp) * np.float32(10.0)).T, ints
+
+
+@pytest.mark.parametrize("precision", [1000.0, 100.0, 12345.0])
+def test_xtc_reader_and_writer_against_the_bytewise_restatement(tmp_path, emu_lib, precision):
+    systems = _systems()
+    box = np.array([[31.0, 0, 0], [4.0, 29.5, 0], [-3.0, 5.5, 33.25]], np.float32)
+    cell = V.make_unitcell((31.0, 29.5, 33.25), tilt=(4.0, -3.0, 5.5))
+    for name, xyz in systems.items():
+        if name == "wide" and precision > 1000.0:
+            continue                                                       # beyond the integer range of the format
+        F = 3
+        frames = [xyz + np.float32(0.37 * f) for f in range(F)]
+        blob = b"".join(xtc_ref.frame_bytes(frames[f], box, 10 * f, 0.5 * f, precision) for f in range(F))
+        p_ref = tmp_path / f"{name}_ref.xtc"
+        p_ref.write_bytes(blob)
+        # 1. the native writer produces the same bytes as the byte-wise restatement
+        p_nat = tmp_path / f"{name}_nat.xtc"
+        w = emu_lib.vmd_xdrwriter_open(str(p_nat).encode(), 0, xyz.shape[1], precision)
+        assert w
+        import ctypes as C
+        from viamd_amd import _lib as L
+        for f in range(F):
+            a = np.ascontiguousarray(frames[f], np.float32)
+            assert emu_lib.vmd_xdrwriter_write_frame(w, 10 * f, 0.5 * f, C.byref(cell), a[0].ctypes.data_as(L.c_float_p),
+                                                     a[1].ctypes.data_as(L.c_float_p), a[2].ctypes.data_as(L.c_float_p))
+        assert emu_lib.vmd_xdrwriter_close(w)
+        assert p_nat.read_bytes() == blob, name
+        # 2. the native reader returns the stored integers (through the float formula), the box, step and time
+        t = V.XdrTrajectory(p_ref, lib=emu_lib)
+        assert (t.kind, t.num_frames(), t.num_atoms()) == ("xtc", F, xyz.shape[1])
+        for f in (F - 1, 0, 1):
+            got, c, hdr = t.load_frame(f, with_header=True)
+            if xyz.shape[1] <= 9:
+                want = ((frames[f] * np.float32(0.1)) * np.float32(10.0)).astype(np.float32)
+            else:
+                want, ints = _expected_xtc(frames[f], precision)
+            np.testing.assert_array_equal(got, want, err_msg=name)
+            assert abs(got - frames[f]).max() <= 10.0 * 0.5 / precision * 1.001 + 4e-7 * abs(frames[f]).max()   # half a grid step + float rounding
+            np.testing.assert_allclose([c.x, c.y, c.z, c.xy, c.xz, c.yz], [31.0, 29.5, 33.25, 4.0, -3.0, 5.5], rtol=1e-6)
+            assert c.flags == 7 and hdr.timestamp == 0.5 * f and t.frame_step(f) == 10 * f
+        t.close()
+        # 3. the byte-wise decoder reads the natively written file back to the same integers
+        if xyz.shape[1] > 9:
+            for f, fr in enumerate(xtc_ref.parse_frames(p_nat.read_bytes())):
+                np.testing.assert_array_equal(fr["ints"], _expected_xtc(frames[f], precision)[1])
+
+
+def test_xtc_fixtures_reach_every_branch_of_the_format():
+    """Guards the fixtures: the water swap, runs of every length up to 8, unchanged and changed run flags, smallidx moving
+    in both directions and the three-field branch all occur, and water compresses the way the format is meant to."""
+    s = _systems()
+    tot = {}
+    for name in ("water", "chain", "wide", "gas", "lattice", "clusters"):
+        st = {}
+        ints = xtc_ref.to_ints((s[name] * np.float32(0.1)).T, 1000.0)
+        mi, ma, sidx, payload = xtc_ref.compress(ints, st)
+        if name == "water":
+            size = [ma[k] - mi[k] + 1 for k in range(3)]
+            assert len(payload) * 8 < 0.9 * len(ints) * xtc_ref.sizeofints(size)
+            assert st["swaps"] > 300 and st["runs"].get(2, 0) > 300
+        for k, v in st.items():
+            if k == "runs":
+                for r, c in v.items():
+                    tot.setdefault("runs", {})[r] = tot.get("runs", {}).get(r, 0) + c
+            else:
+                tot[k] = tot.get(k, 0) + v
+    assert all(tot[k] > 0 for k in ("swaps", "up", "down", "flag0", "flag1", "three_field")), tot
+    assert set(tot["runs"]) >= set(range(0, 9)), tot["runs"]
+
+
+def _trr_frame(xyz_A, box_A, step, time, double=False, with_x=True, natoms=None):
+    n = xyz_A.shape[1] if natoms is None else natoms
+    rs = 8 if double else 4
+    e = ">d" if double else ">f"
+    xyz_nm = (xyz_A.astype(np.float64) * 0.1 if double else (xyz_A * np.float32(0.1))).T
+    sizes = [0, 0, 9 * rs, 9 * rs, 0, 0, 0, 3 * n * rs if with_x else 0, 3 * n * rs, 0, n, step, 0]
+    out = struct.pack(">i", 1993) + struct.pack(">ii", 13, 12) + b"GMX_trn_file" + struct.pack(">13i", *sizes)
+    out += struct.pack(e, time) + struct.pack(e, 0.0)
+    box = np.asarray(box_A, np.float64).ravel() * 0.1
+    out += box.astype(e).tobytes()
+    out += np.zeros(9).astype(e).tobytes()                                   # virial block
+    if with_x:
+        out += xyz_nm.astype(e).tobytes()
+    out += np.full(3 * n, 0.25).astype(e).tobytes()                          # velocities
+    return out
+
+
+def test_trr_reader_single_and_double_precision(tmp_path, emu_lib):
+    rng = np.random.default_rng(3)
+    F, N = 4, 53
+    coords = rng.normal(0, 25, (F, 3, N)).astype(np.float32)
+    box = [[40.0, 0, 0], [0, 42.5, 0], [0, 0, 38.0]]
+    for double in (False, True):
+        blob = b""
+        for f in range(F):
+            blob += _trr_frame(coords[f], box, 100 * f, 2.0 * f, double)
+            blob += _trr_frame(coords[f], box, 100 * f + 50, 2.0 * f + 1.0, double, with_x=False)   # velocity-only frame: skipped
+        p = tmp_path / f"d{int(double)}.trr"
+        p.write_bytes(blob + b"\0\0\0")                                     # trailing garbage is ignored
+        t = V.XdrTrajectory(p, lib=emu_lib)
+        assert (t.kind, t.num_frames(), t.num_atoms()) == ("trr", F, N)
+        for f in (2, 0, F - 1):
+            got, c, hdr = t.load_frame(f, with_header=True)
+            if double:
+                want = ((coords[f].astype(np.float64) * 0.1) * 10.0).astype(np.float32)
+            else:
+                want = (coords[f] * np.float32(0.1)) * np.float32(10.0)
+            np.testing.assert_array_equal(got, want)
+            assert (c.x, c.y, c.z, c.xy, c.xz, c.yz, c.flags) == (40.0, 42.5, 38.0, 0.0, 0.0, 0.0, 7)
+            assert hdr.timestamp == 2.0 * f and t.frame_step(f) == 100 * f
+    # the native TRR writer is read back bit for bit (x * 0.1f * 10.0f)
+    q = tmp_path / "w.trr"
+    cell = V.make_unitcell((40.0, 42.5, 38.0), tilt=(3.0, -2.0, 1.5))
+    V.write_trr(q, coords, cell, dt=2.0, lib=emu_lib)
+    t = V.XdrTrajectory(q, lib=emu_lib)
+    assert t.num_frames() == F
+    got, c = t.load_frame(1)
+    np.testing.assert_array_equal(got, (coords[1] * np.float32(0.1)) * np.float32(10.0))
+    np.testing.assert_allclose([c.x, c.y, c.z, c.xy, c.xz, c.yz], [40.0, 42.5, 38.0, 3.0, -2.0, 1.5], rtol=1e-6)
+
+
+def test_xdr_error_paths_and_truncation(tmp_path, emu_lib):
+    xyz = _systems()["water"]
+    p = tmp_path / "w.xtc"
+    V.write_xtc(p, np.stack([xyz, xyz + 1, xyz + 2]), V.make_unitcell(31.0), lib=emu_lib)
+    data = p.read_bytes()
+    bad = tmp_path / "bad.xtc"
+    bad.write_bytes(b"\0\0\0\1 this is not a trajectory ..........................................")
+    with pytest.raises(V.VmdError, match="neither an XTC nor a TRR"):
+        V.XdrTrajectory(bad, lib=emu_lib)
+    with pytest.raises(V.VmdError, match="cannot open"):
+        V.XdrTrajectory(tmp_path / "missing.xtc", lib=emu_lib)
+    cut = tmp_path / "cut.xtc"
+    cut.write_bytes(data[:len(data) - 40])                                  # last frame incomplete -> dropped from the index
+    t = V.XdrTrajectory(cut, lib=emu_lib)
+    assert t.num_frames() == 2
+    with pytest.raises(V.VmdError, match="out of range"):
+        t.load_frame(2)
+    # corrupt payloads must be rejected or decoded to garbage, never crash: flip bytes all over the first frame
+    rng = np.random.default_rng(0)
+    first = len(xtc_ref.frame_bytes(xyz, np.diag([31.0] * 3), 0, 0.0))
+    assert data[:first] == xtc_ref.frame_bytes(xyz, np.diag([31.0] * 3), 0, 0.0)
+    rejected = 0
+    for trial in range(300):
+        b = bytearray(data)
+        for _ in range(rng.integers(1, 6)):
+            b[rng.integers(56, first)] = rng.integers(0, 256)
+        f = tmp_path / "fuzz.xtc"
+        f.write_bytes(bytes(b))
+        try:
+            tt = V.XdrTrajectory(f, lib=emu_lib)
+            if tt.num_frames():
+                tt.load_frame(0)
+            tt.close()
+        except V.VmdError:
+            rejected += 1
+    assert rejected > 0
+
+
+def test_xtc_trajectory_through_the_evaluator_on_emulator(tmp_path, emu_lib, oracle):
+    """An XTC file staged through load_frame (frames decompressed on several host threads) gives the same histogram as the
+    decoded frames handed over from memory, and the oracle agrees on those coordinates."""
+    import cases
+    box, F, N = 36.0, 10, 1200
+    coords = cases.water_box(oracle, 31, N, box, F)
+    cell = V.make_unitcell(box)
+    p = tmp_path / "w.xtc"
+    V.write_xtc(p, coords, cell, lib=emu_lib)
+    t = V.XdrTrajectory(p, lib=emu_lib)
+    decoded = np.stack([t.load_frame(f)[0] for f in range(F)])
+    assert abs(decoded - coords).max() < 0.0051
+    o = cases.oxygen(N)
+    ir = V.ScriptIR(emu_lib); ir.add_rdf("g", o, o, 9.0)
+    sysm = V.MolSystem(N, unitcell=cell)
+    res = []
+    for threads in (1, 8):
+        old_t = emu_lib.vmd_set_option(b"load_threads", threads)
+        old_b = emu_lib.vmd_set_option(b"batch_frames", 4)
+        try:
+            for traj in (V.XdrTrajectory(p, lib=emu_lib), V.HostTrajectory(decoded, cell)):
+                ev = V.ScriptEval(F, ir)
+                assert ev.frame_range(sysm, traj, 0, F)
+                res.append(ev.property_data("g").counts.copy())
+        finally:
+            emu_lib.vmd_set_option(b"load_threads", old_t)
+            emu_lib.vmd_set_option(b"batch_frames", old_b)
+    for r in res[1:]:
+        np.testing.assert_array_equal(r, res[0])
+    cases.check_rdf(emu_lib, oracle, decoded, box, [("g", o, o, 0.0, 9.0)])
+    assert res[0].sum() > 0

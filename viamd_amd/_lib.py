@@ -137,6 +137,14 @@ SIGNATURES = [
     ("vmd_dcdtraj_open", _vp, [C.c_char_p]),
     ("vmd_dcdtraj_close", None, [_vp]),
     ("vmd_dcdtraj_interface", C.POINTER(TrajectoryI), [_vp]),
+    ("vmd_xdrtraj_open", _vp, [C.c_char_p]),
+    ("vmd_xdrtraj_close", None, [_vp]),
+    ("vmd_xdrtraj_interface", C.POINTER(TrajectoryI), [_vp]),
+    ("vmd_xdrtraj_kind", C.c_int, [_vp]),
+    ("vmd_xdrtraj_frame_step", C.c_int64, [_vp, C.c_size_t]),
+    ("vmd_xdrwriter_open", _vp, [C.c_char_p, C.c_int, C.c_size_t, C.c_float]),
+    ("vmd_xdrwriter_write_frame", C.c_bool, [_vp, C.c_int64, C.c_float, C.POINTER(Unitcell), c_float_p, c_float_p, c_float_p]),
+    ("vmd_xdrwriter_close", C.c_bool, [_vp]),
     ("vmd_hosttraj_set_cell", C.c_bool, [_vp, C.c_size_t, C.POINTER(Unitcell)]),
     ("vmd_hosttraj_copy_from_device", C.c_bool, [_vp, _vp, C.c_size_t, C.c_size_t]),
     ("vmd_downsample_histogram", None, [c_float_p, C.c_int, c_float_p, c_float_p, C.c_int]),
