@@ -1,0 +1,17 @@
+#!/bin/bash
+# Host-code hygiene: the emulator build (same .hip/.cpp sources, g++) under AddressSanitizer + UBSan, driven by the CPU test
+# suite.  The fibers of the emulator switch stacks with swapcontext, so stack-use-after-return detection is off.
+# usage: bash scripts/sanitize_emu.sh [address,undefined|thread] [pytest args...]
+set -e
+cd "$(dirname "$0")/.."
+SAN=${1:-address,undefined}; shift || true
+export VIAMD_EMU_SANITIZE=$SAN
+case "$SAN" in
+  thread*) RT=$(g++ -print-file-name=libtsan.so);;
+  *)       RT=$(g++ -print-file-name=libasan.so);;
+esac
+export ASAN_OPTIONS=detect_leaks=0:detect_stack_use_after_return=0:abort_on_error=0:halt_on_error=1
+export UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1
+export TSAN_OPTIONS=halt_on_error=0:report_signal_unsafe=0
+TARGETS=("$@"); [ ${#TARGETS[@]} -eq 0 ] && TARGETS=(tests)
+LD_PRELOAD=$RT python -m pytest "${TARGETS[@]}" -q -m "not gpu" -x

@@ -36,13 +36,19 @@ EMU_DEPS = EMU_SOURCES + [os.path.join(EMU_DIR, "hip", "hip_runtime.h"),
 
 
 def build_emu():
-    """g++ build of the *same* kernel + host sources against the test-only SIMT emulator (tests/emu)."""
-    if os.path.exists(EMU_LIB) and all(os.path.getmtime(EMU_LIB) >= os.path.getmtime(s) for s in EMU_DEPS):
-        return EMU_LIB
+    """g++ build of the *same* kernel + host sources against the test-only SIMT emulator (tests/emu).
+    VIAMD_EMU_SANITIZE=address,undefined (or thread) builds an instrumented copy next to it: run the suite under it with
+    LD_PRELOAD=$(g++ -print-file-name=libasan.so) (scripts/sanitize_emu.sh)."""
+    san = os.environ.get("VIAMD_EMU_SANITIZE", "")
+    out = EMU_LIB if not san else EMU_LIB.replace(".so", "_" + san.replace(",", "_") + ".so")
+    if os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(s) for s in EMU_DEPS):
+        return out
     cmd = ["g++", "-O2", "-g", "-shared", "-fPIC", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-mavx2", "-mfma",
-           "-I" + EMU_DIR, "-I" + os.path.join(ROOT, "include"), "-x", "c++"] + EMU_SOURCES + ["-o", EMU_LIB]
+           "-I" + EMU_DIR, "-I" + os.path.join(ROOT, "include"), "-x", "c++"] + EMU_SOURCES + ["-o", out]
+    if san:
+        cmd[1:1] = ["-fsanitize=" + san, "-fno-omit-frame-pointer", "-fno-sanitize-recover=undefined"]
     subprocess.check_call(cmd)
-    return EMU_LIB
+    return out
 
 
 @pytest.fixture(scope="session")

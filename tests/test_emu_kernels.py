@@ -178,3 +178,25 @@ def test_open_boundaries_and_slabs_on_the_grid(emu_lib, oracle):
 
 def test_sdf_triclinic_spread_structures_regression(emu_lib, oracle):
     cases.sdf_triclinic_spread_structures(emu_lib, oracle)
+
+
+def test_result_views_keep_their_eval_alive(emu_lib, oracle):
+    """VIAMD caches md_script_property_data_t pointers for the eval's lifetime (src/main.cpp:1286,1303); in the Python mirror a
+    view must therefore keep the eval alive: `check(...).property_data(n).counts` on a temporary used to read freed memory."""
+    import gc
+    import viamd_amd as V
+    coords = cases.water_box(oracle, 3, 600, 30.0, 2)
+    o = cases.oxygen(600)
+
+    def views():
+        ir = V.ScriptIR(emu_lib); ir.add_rdf("g", o, o, 8.0)
+        ev = V.ScriptEval(2, ir)
+        assert ev.frame_range(V.MolSystem(600, unitcell=V.make_unitcell(30.0)), V.HostTrajectory(coords, V.make_unitcell(30.0)), 0, 2)
+        pd = ev.property_data("g")
+        return pd.counts, pd.values[:10], ev.frame_mask(), pd.counts.copy()
+
+    c, v, m, ref = views()
+    gc.collect()
+    junk = [np.full(1024, 0xAB, np.uint64) for _ in range(64)]            # recycle freed blocks, if any
+    np.testing.assert_array_equal(c, ref)
+    assert m.all() and ref.sum() > 0 and len(junk) == 64 and v.shape == (10,)

@@ -231,3 +231,126 @@ def test_gro_reader_multi_frame_and_triclinic_box(tmp_path):
     assert list(meta["name"]) == list(name) and list(meta["resid"]) == list(resid) and meta["resname"][0] == "SOL"
     assert (k2[0].x, k2[0].y, k2[0].z, k2[0].xy, k2[0].flags) == (40.0, 38.0, 36.0, 0.0, 7)
     np.testing.assert_allclose([k2[1].xy, k2[1].xz, k2[1].yz], [5.0, -3.0, 4.0], atol=1e-4)
+
+
+def test_mmcif_lammps_data_and_loader_dispatch(tmp_path, emu_lib, oracle):
+    """The loader table of src/loader.cpp:22-77 (type from the extension, System / Trajectory flags) in front of the readers:
+    mmCIF (two models, quoted tokens, missing label_seq_id), LAMMPS data (atom style from the Atoms comment, unsorted ids,
+    tilt), and every trajectory type opening through one call."""
+    import cases
+    import pytest
+    from viamd_amd import loader, textio
+    cif = tmp_path / "m.cif"
+    cif.write_text("""data_TEST
+#
+_cell.length_a 30.000
+_cell.length_b 28.0(1)
+_cell.length_c 26.000
+_cell.angle_alpha 90.00
+_cell.angle_beta 90.00
+_cell.angle_gamma 80.00
+#
+loop_
+_atom_site.group_PDB
+_atom_site.id
+_atom_site.type_symbol
+_atom_site.label_atom_id
+_atom_site.label_comp_id
+_atom_site.label_asym_id
+_atom_site.label_seq_id
+_atom_site.Cartn_x
+_atom_site.Cartn_y
+_atom_site.Cartn_z
+_atom_site.auth_seq_id
+_atom_site.pdbx_PDB_model_num
+ATOM 1 N N ALA A 1 1.000 2.000 3.000 5 1
+ATOM 2 C CA ALA A 1 2.000 2.500 3.500 5 1
+ATOM 3 C "C'" GLY A 2 3.000 3.500 4.500 6 1
+HETATM 4 O O HOH B . 9.000 9.500 9.750 101 1
+HETATM 5 ZN ZN 'ZN' C . 5.000 5.500 5.750 201 1
+ATOM 1 N N ALA A 1 1.100 2.100 3.100 5 2
+ATOM 2 C CA ALA A 1 2.100 2.600 3.600 5 2
+ATOM 3 C "C'" GLY A 2 3.100 3.600 4.600 6 2
+HETATM 4 O O HOH B . 9.100 9.600 9.850 101 2
+HETATM 5 ZN ZN 'ZN' C . 5.100 5.600 5.850 201 2
+#
+loop_
+_other.thing
+x
+""")
+    coords, meta, params = textio.read_mmcif(cif)
+    assert coords.shape == (2, 3, 5) and params == (30.0, 28.0, 26.0, 90.0, 90.0, 80.0)
+    np.testing.assert_allclose(coords[1, :, 3], [9.1, 9.6, 9.85], rtol=1e-6)
+    assert list(meta["name"]) == ["N", "CA", "C'", "O", "ZN"] and list(meta["resid"]) == [1, 1, 2, 101, 201]
+    topo, xyz0, cell = loader.load_system(cif)
+    assert topo.num_residues == 4 and list(topo.elements) == ["N", "C", "C", "O", "Zn"]
+    np.testing.assert_allclose([cell.x, cell.y, cell.xy], [30.0, 28.0 * np.sin(np.radians(80)), 28.0 * np.cos(np.radians(80))], rtol=1e-6)
+    assert abs(float(topo.mass[4]) - 65.38) < 1e-3 and cell.flags == 7
+
+    data = tmp_path / "w.data"
+    data.write_text("""LAMMPS data file via test
+
+6 atoms
+2 atom types
+
+-1.0 19.0 xlo xhi
+0.0 20.0 ylo yhi
+0.0 22.0 zlo zhi
+2.0 -1.0 0.5 xy xz yz
+
+Masses
+
+1 15.9994
+2 1.008
+
+Atoms # full
+
+3 1 2 0.4 1.5 1.0 1.0 0 0 0
+1 1 1 -0.8 1.0 1.0 1.0
+2 1 2 0.4 0.5 1.0 1.0
+6 2 2 0.4 6.5 6.0 6.0
+4 2 1 -0.8 6.0 6.0 6.0
+5 2 2 0.4 5.5 6.0 6.0
+
+Velocities
+
+1 0 0 0
+""")
+    topo, xyz0, cell = loader.load_system(data)
+    assert list(topo.elements) == ["O", "H", "H", "O", "H", "H"] and topo.num_residues == 2
+    np.testing.assert_array_equal(xyz0[0], np.array([1.0, 0.5, 1.5, 6.0, 5.5, 6.5], np.float32))
+    assert (cell.x, cell.y, cell.z, cell.xy, cell.xz, cell.yz) == (20.0, 20.0, 22.0, 2.0, -1.0, 0.5)
+    with pytest.raises(ValueError, match="atom style"):
+        bad = tmp_path / "nostyle.data"
+        bad.write_text(data.read_text().replace("Atoms # full", "Atoms"))
+        loader.load_system(bad)
+    topo2, _, _ = loader.load_system(bad, atom_style="full")
+    assert topo2.num_atoms == 6
+
+    # one call opens every trajectory type; the same frames give the same histogram whatever the container
+    box, F, N = 30.0, 4, 300
+    coords = cases.water_box(oracle, 77, N, box, F)
+    cellb = V.make_unitcell(box)
+    V.write_dcd(tmp_path / "t.dcd", coords, cellb)
+    V.write_trr(tmp_path / "t.trr", coords, cellb, lib=emu_lib)
+    V.write_xtc(tmp_path / "t.xtc", coords, cellb, lib=emu_lib)
+    textio.write_xyz(tmp_path / "t.xyz", coords, ["O", "H", "H"] * (N // 3), [cellb] * F)
+    o = cases.oxygen(N)
+    ir = V.ScriptIR(emu_lib); ir.add_rdf("g", o, o, 8.0)
+    sysm = V.MolSystem(N, unitcell=cellb)
+    counts = {}
+    for ext in ("dcd", "trr", "xtc", "xyz"):
+        traj = loader.open_trajectory(tmp_path / f"t.{ext}", lib=emu_lib)
+        assert (traj.num_frames(), traj.num_atoms()) == (F, N)
+        ev = V.ScriptEval(F, ir)
+        assert ev.frame_range(sysm, traj, 0, F)
+        counts[ext] = ev.property_data("g").counts.copy()
+    np.testing.assert_array_equal(counts["dcd"], cases.check_rdf(emu_lib, oracle, coords, box, [("g", o, o, 0.0, 8.0)]).property_data("g").counts)
+    assert counts["dcd"].sum() > 0 and abs(int(counts["xtc"].sum()) - int(counts["dcd"].sum())) < 0.01 * counts["dcd"].sum()
+    assert loader.loader_type("a/b/c.XTC") == ("xtc", loader.FLAG_TRAJECTORY)
+    with pytest.raises(ValueError, match="no trajectory"):
+        loader.open_trajectory(tmp_path / "x.gro")
+    with pytest.raises(ValueError, match="no system"):
+        loader.load_system(tmp_path / "t.dcd")
+    with pytest.raises(ValueError, match="could not determine loader type"):
+        loader.loader_type("file.unknown")

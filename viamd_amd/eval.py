@@ -119,8 +119,16 @@ class ScriptIR:
         return int(self.lib.vmd_ir_property_flags(self.h, name.encode()))
 
 
+class _EvalArray(np.ndarray):
+    """ndarray view into memory owned by a ScriptEval: keeps the eval alive for as long as the view (or a slice of it) is."""
+
+    def __array_finalize__(self, obj):
+        self._owner = getattr(obj, "_owner", None)
+
+
 class PropertyDataView:
-    """Zero-copy numpy views of one md_script_property_data_t."""
+    """Zero-copy numpy views of one md_script_property_data_t.  The arrays stay valid for the lifetime of the
+    eval (md_script_property_data_t addresses are stable, src/main.cpp:1286,1303) and hold a reference to it."""
 
     def __init__(self, c, ev=None, name=None):
         self.c = c  # ctypes PropertyData (owned by the eval)
@@ -137,7 +145,9 @@ class PropertyDataView:
     def _arr(self, ptr, n, dtype):
         if not ptr or n == 0:
             return None
-        return np.ctypeslib.as_array(ptr, shape=(n,)).view(dtype)
+        a = np.ctypeslib.as_array(ptr, shape=(n,)).view(dtype).view(_EvalArray)
+        a._owner = self._ev
+        return a
 
     @property
     def values(self):
@@ -182,9 +192,13 @@ class PropertyDataView:
             return None
         a = self.c.aggregate.contents
         n = a.num_values
-        return {"mean": np.ctypeslib.as_array(a.population_mean, shape=(n,)),
-                "var": np.ctypeslib.as_array(a.population_var, shape=(n,)),
-                "ext": np.ctypeslib.as_array(a.population_ext, shape=(n * 2,)).reshape(n, 2)}
+        def own(arr):
+            arr = arr.view(_EvalArray)
+            arr._owner = self._ev
+            return arr
+        return {"mean": own(np.ctypeslib.as_array(a.population_mean, shape=(n,))),
+                "var": own(np.ctypeslib.as_array(a.population_var, shape=(n,))),
+                "ext": own(np.ctypeslib.as_array(a.population_ext, shape=(n * 2,))).reshape(n, 2)}
 
 
 class ScriptEval:
@@ -263,7 +277,9 @@ class ScriptEval:
 
     def frame_mask(self):
         n = self.num_frames()
-        return np.ctypeslib.as_array(self.lib.vmd_eval_frame_mask(self.h), shape=(n,))
+        m = np.ctypeslib.as_array(self.lib.vmd_eval_frame_mask(self.h), shape=(n,)).view(_EvalArray)
+        m._owner = self
+        return m
 
     def set_frame_mask(self, mask):
         m = np.ascontiguousarray(mask, dtype=np.uint8)

@@ -6,7 +6,14 @@ import numpy as np
 
 from .script import Topology
 
-MASS = {"C": 12.011, "N": 14.007, "O": 15.999, "H": 1.008}
+# standard atomic weights of the elements that occur in biomolecular / materials trajectories (md_atom_mass analogue:
+# masses weight the centre of mass of the SDF alignment, /root/reference/src/viamd.cpp:2253)
+MASS = {"H": 1.008, "He": 4.0026, "Li": 6.94, "Be": 9.0122, "B": 10.81, "C": 12.011, "N": 14.007, "O": 15.999, "F": 18.998,
+        "Ne": 20.180, "Na": 22.990, "Mg": 24.305, "Al": 26.982, "Si": 28.085, "P": 30.974, "S": 32.06, "Cl": 35.45,
+        "Ar": 39.948, "K": 39.098, "Ca": 40.078, "Ti": 47.867, "Cr": 51.996, "Mn": 54.938, "Fe": 55.845, "Co": 58.933,
+        "Ni": 58.693, "Cu": 63.546, "Zn": 65.38, "Se": 78.971, "Br": 79.904, "Rb": 85.468, "Sr": 87.62, "Mo": 95.95,
+        "Ag": 107.87, "Cd": 112.41, "I": 126.90, "Cs": 132.91, "Ba": 137.33, "Pt": 195.08, "Au": 196.97, "Hg": 200.59,
+        "Pb": 207.2}
 
 
 def water_box_topology(n_atoms, n_blob=0, atoms_per_residue=10):

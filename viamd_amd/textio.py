@@ -180,3 +180,167 @@ def write_gro(path, coords, resid, resname, name, cells):
                 f.write("%10.5f%10.5f%10.5f\n" % (c.x / 10, c.y / 10, c.z / 10))
             else:
                 f.write("%10.5f%10.5f%10.5f%10.5f%10.5f%10.5f%10.5f%10.5f%10.5f\n" % (c.x / 10, c.y / 10, c.z / 10, 0, 0, c.xy / 10, 0, c.xz / 10, c.yz / 10))
+
+
+def _cif_tokens(line):
+    """Whitespace-separated mmCIF tokens with '...' / "..." quoting."""
+    out, i, n = [], 0, len(line)
+    while i < n:
+        c = line[i]
+        if c.isspace():
+            i += 1
+        elif c in "'\"" and (i == 0 or line[i - 1].isspace()):
+            j = i + 1
+            while j < n and not (line[j] == c and (j + 1 == n or line[j + 1].isspace())):
+                j += 1
+            out.append(line[i + 1:j])
+            i = j + 1
+        elif c == "#":
+            break
+        else:
+            j = i
+            while j < n and not line[j].isspace():
+                j += 1
+            out.append(line[i:j])
+            i = j
+    return out
+
+
+def read_mmcif(path):
+    """PDBx/mmCIF (VIAMD: md_mmcif_system_init_from_file, src/loader.cpp:137-138): the `_atom_site` loop (Cartn_x/y/z,
+    type_symbol, label_atom_id, label_comp_id, label_asym_id / auth_asym_id, label_seq_id / auth_seq_id, pdbx_PDB_model_num) and
+    the `_cell.*` items.  Returns (coords float32 [F, 3, N] - one frame per model -, dict(element, name, resname, chain, resid),
+    cell_params (a, b, c, alpha, beta, gamma) or None)."""
+    cell, cols, rows = {}, [], []
+    loop_cols, in_header = None, False          # loop_cols: column names of the loop being read (None outside a loop)
+    with open(path) as f:
+        for raw in f:
+            line = raw.rstrip("\n")
+            s = line.strip()
+            if not s or s.startswith("#"):
+                loop_cols = None                                            # blank line / comment ends a loop
+                continue
+            if s == "loop_":
+                loop_cols, in_header = [], True
+                continue
+            if s.startswith("data_"):
+                loop_cols = None
+                continue
+            if s.startswith("_"):
+                if loop_cols is not None and in_header:
+                    loop_cols.append(s.split()[0])
+                    continue
+                loop_cols = None                                            # a key-value item: any loop before it is over
+                if s.startswith("_cell."):
+                    t = _cif_tokens(s)
+                    if len(t) >= 2:
+                        cell[t[0][6:]] = t[1]
+                continue
+            if loop_cols is not None:                                       # a data row of the current loop
+                in_header = False
+                if loop_cols and loop_cols[0].startswith("_atom_site."):
+                    if not cols:
+                        cols = [c[11:] for c in loop_cols]
+                    t = _cif_tokens(line)
+                    if len(t) == len(cols):
+                        rows.append(t)
+    if not rows:
+        raise ValueError(f"{path}: no _atom_site records")
+    ci = {c: k for k, c in enumerate(cols)}
+    for need in ("Cartn_x", "Cartn_y", "Cartn_z"):
+        if need not in ci:
+            raise ValueError(f"{path}: _atom_site.{need} is missing")
+
+    def col(*names, default="."):
+        for nm in names:
+            if nm in ci:
+                return [r[ci[nm]] for r in rows]
+        return [default] * len(rows)
+
+    model = col("pdbx_PDB_model_num", default="1")
+    models = sorted(set(model), key=lambda m: int(m))
+    xyz = np.array([[float(r[ci["Cartn_x"]]), float(r[ci["Cartn_y"]]), float(r[ci["Cartn_z"]])] for r in rows], np.float32)
+    model = np.array(model)
+    frames = [xyz[model == m].T for m in models]
+    n = frames[0].shape[1]
+    if any(fr.shape[1] != n for fr in frames):
+        raise ValueError(f"{path}: the models have different atom counts")
+    first = model == models[0]
+    pick = lambda v: np.array(v)[first]
+    seq = pick(col("label_seq_id", "auth_seq_id", default="0"))
+    if "auth_seq_id" in ci:
+        auth = pick(col("auth_seq_id"))
+        seq = np.where(np.isin(seq, (".", "?")), auth, seq)           # waters / ligands carry no label_seq_id
+    elem = pick(col("type_symbol", "label_atom_id"))
+    meta = dict(element=np.array([e.capitalize() for e in elem]), name=pick(col("label_atom_id", "auth_atom_id")),
+                resname=pick(col("label_comp_id", "auth_comp_id")), chain=pick(col("label_asym_id", "auth_asym_id")),
+                resid=np.array([int(v) if v.lstrip("-").isdigit() else 0 for v in seq]))
+    params = None
+    if all(k in cell for k in ("length_a", "length_b", "length_c")):
+        g = lambda k, d: float(cell.get(k, d).split("(")[0])
+        params = (g("length_a", "0"), g("length_b", "0"), g("length_c", "0"), g("angle_alpha", "90"), g("angle_beta", "90"), g("angle_gamma", "90"))
+    return np.stack(frames), meta, params
+
+
+def cell_from_parameters(a, b, c, alpha=90.0, beta=90.0, gamma=90.0):
+    """(a, b, c, alpha, beta, gamma) -> Unitcell with a = (x,0,0), b = (xy,y,0), c = (xz,yz,z) (the CRYST1 / _cell convention)."""
+    if not (a > 0 and b > 0 and c > 0):
+        return make_unitcell(None)
+    ca, cb, cg = (0.0 if ang == 90.0 else float(np.cos(np.deg2rad(ang))) for ang in (alpha, beta, gamma))
+    xy, xz = b * cg, c * cb
+    ly = float(np.sqrt(b * b - xy * xy))
+    yz = (b * c * ca - xy * xz) / ly
+    lz = float(np.sqrt(c * c - xz * xz - yz * yz))
+    return make_unitcell((a, ly, lz), tilt=tuple(0.0 if abs(v) < 1e-6 else float(v) for v in (xy, xz, yz)))
+
+
+LAMMPS_ATOM_STYLES = {          # columns after the atom id: where type, (molecule), x are (md_lammps_atom_format_*, loader.cpp:80-88)
+    "atomic": dict(type=1, mol=None, x=2), "charge": dict(type=1, mol=None, x=3), "molecular": dict(type=2, mol=1, x=3),
+    "full": dict(type=2, mol=1, x=4), "bond": dict(type=2, mol=1, x=3), "angle": dict(type=2, mol=1, x=3),
+}
+
+
+def read_lammps_data(path, atom_style=None):
+    """LAMMPS data file (VIAMD: md_lammps_system_init_from_file, src/loader.cpp:139-142): header counts, box bounds (+ tilt),
+    Masses and Atoms sections.  `atom_style` comes from the `Atoms # style` comment when not given (VIAMD asks the user when it
+    cannot tell, src/loader.cpp:80-88).  Returns (coords float32 [1, 3, N] sorted by atom id, dict(type, mol, mass, id), cell)."""
+    with open(path) as f:
+        lines = [ln.rstrip("\n") for ln in f]
+    lo, hi, tilt = [0.0] * 3, [0.0] * 3, (0.0, 0.0, 0.0)
+    natoms, masses, atoms, section = None, {}, [], None
+    for ln in lines[1:]:
+        body = ln.split("#")[0].strip()
+        if not body:
+            continue
+        t = body.split()
+        if body.endswith("atoms") and len(t) == 2:
+            natoms = int(t[0])
+        elif len(t) == 4 and t[2].endswith("lo") and t[3].endswith("hi"):
+            k = "xyz".index(t[2][0])
+            lo[k], hi[k] = float(t[0]), float(t[1])
+        elif len(t) == 6 and t[3:] == ["xy", "xz", "yz"]:
+            tilt = (float(t[0]), float(t[1]), float(t[2]))
+        elif t[0] in ("Masses", "Atoms", "Velocities", "Bonds", "Angles", "Dihedrals", "Impropers", "Pair", "PairIJ", "Bond", "Angle",
+                      "Dihedral", "Improper", "Ellipsoids", "Lines", "Triangles", "Bodies") and not t[0][0].isdigit():
+            section = t[0]
+            if section == "Atoms" and atom_style is None and "#" in ln:
+                atom_style = ln.split("#")[1].split()[0]
+        elif section == "Masses" and len(t) >= 2:
+            masses[int(t[0])] = float(t[1])
+        elif section == "Atoms":
+            atoms.append(t)
+    if atom_style is None:
+        raise ValueError(f"{path}: cannot determine the LAMMPS atom style (no `Atoms # style` comment): pass atom_style")
+    if atom_style not in LAMMPS_ATOM_STYLES:
+        raise ValueError(f"{path}: unsupported atom style '{atom_style}'")
+    st = LAMMPS_ATOM_STYLES[atom_style]
+    if not atoms or (natoms is not None and len(atoms) != natoms):
+        raise ValueError(f"{path}: the Atoms section has {len(atoms)} lines, the header says {natoms}")
+    atoms.sort(key=lambda t: int(t[0]))
+    xyz = np.array([[float(t[st["x"] + k]) for k in range(3)] for t in atoms], np.float32).T
+    types = np.array([int(t[st["type"]]) for t in atoms])
+    meta = dict(id=np.array([int(t[0]) for t in atoms]), type=types,
+                mol=np.array([int(t[st["mol"]]) for t in atoms]) if st["mol"] is not None else np.zeros(len(atoms), np.int64),
+                mass=np.array([masses.get(int(tp), 0.0) for tp in types], np.float32))
+    cell = make_unitcell((hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2]), tilt=tilt)
+    return xyz[None], meta, cell
