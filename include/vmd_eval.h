@@ -74,8 +74,9 @@ typedef struct vmd_host_view_t {
 /* md_trajectory_i stand-in.  load_frame has the signature of md_trajectory_load_frame
  * (src/viamd.cpp:465-467, :1815-1817) and, like it, must be re-entrant: VIAMD's pool threads call it concurrently
  * (src/main.cpp:995-996), and the evaluator decodes the frames of one staged batch on several threads
- * (vmd_set_option("load_threads", n); 1 = strictly serial).  device_view is an extension: when non-NULL and successful
- * the evaluator reads frames in place from HBM instead of staging them through load_frame. */
+ * (vmd_set_option("load_threads", n); 1 = strictly serial, 0 = default: an eighth of the host's hardware threads within
+ * [8, 32]).  device_view is an extension: when non-NULL and successful the evaluator reads frames in place from HBM instead
+ * of staging them through load_frame. */
 typedef struct vmd_trajectory_i {
     void* inst;
     size_t (*num_frames)(void* inst);

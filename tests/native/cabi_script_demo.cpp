@@ -1,11 +1,13 @@
-// A C++ host that goes from files and script text to results through the C ABI alone: DCD trajectory (vmd_dcdtraj_open),
+// A C++ host that goes from files and script text to results through the C ABI alone: DCD / XTC / TRR trajectory chosen by
+// the file extension like VIAMD's loader does (vmd_dcdtraj_open, vmd_xdrtraj_open; src/loader.cpp:40-56, 79-84),
 // script front-end (vmd_ir_compile_from_source), evaluator (vmd_eval_*), consumer post-processing (vmd_downsample_histogram).
-// usage: cabi_script_demo <trajectory.dcd> <n_blob_atoms> "<script>"
+// usage: cabi_script_demo <trajectory.dcd|.xtc|.trr> <n_blob_atoms> "<script>"
 // Topology: the synthetic system of viamd_amd/synth.py ([ALA-like residues of 10 atoms][O,H,H waters]).
 // Prints one line per property: name, flags, dim, sum of the integer accumulators (or of the temporal values).
 // tests/test_native.py links it against the SIMT-emulator build (CPU) and compares with the Python host.
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <string>
 #include <vector>
 
@@ -13,9 +15,14 @@
 
 int main(int argc, char** argv) {
     if (argc < 4) { fprintf(stderr, "usage: %s traj.dcd n_blob script\n", argv[0]); return 2; }
-    vmd_dcdtraj_t* dcd = vmd_dcdtraj_open(argv[1]);
-    if (!dcd) { fprintf(stderr, "open failed: %s\n", vmd_last_error()); return 1; }
-    vmd_trajectory_i* traj = vmd_dcdtraj_interface(dcd);
+    const char* ext = strrchr(argv[1], '.');
+    vmd_dcdtraj_t* dcd = nullptr;
+    vmd_xdrtraj_t* xdr = nullptr;
+    if (ext && !strcmp(ext, ".dcd")) dcd = vmd_dcdtraj_open(argv[1]);
+    else if (ext && (!strcmp(ext, ".xtc") || !strcmp(ext, ".trr"))) xdr = vmd_xdrtraj_open(argv[1]);
+    else { fprintf(stderr, "could not determine loader type from file extension\n"); return 2; }
+    if (!dcd && !xdr) { fprintf(stderr, "open failed: %s\n", vmd_last_error()); return 1; }
+    vmd_trajectory_i* traj = dcd ? vmd_dcdtraj_interface(dcd) : vmd_xdrtraj_interface(xdr);
     const size_t n = traj->num_atoms(traj->inst), frames = traj->num_frames(traj->inst);
     const size_t n_blob = (size_t)atol(argv[2]);
 
@@ -68,5 +75,6 @@ int main(int argc, char** argv) {
     vmd_eval_free(ev);
     vmd_ir_free(ir);
     vmd_dcdtraj_close(dcd);
+    vmd_xdrtraj_close(xdr);
     return 0;
 }

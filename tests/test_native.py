@@ -34,9 +34,10 @@ def test_native_host_runs_like_viamd():
     assert out.stdout.startswith("OK frames=96"), out.stdout
 
 
-def test_native_host_from_dcd_and_script_text_on_the_emulator(tmp_path, emu_lib, oracle):
+@pytest.mark.parametrize("fmt", ["dcd", "xtc"])
+def test_native_host_from_dcd_and_script_text_on_the_emulator(tmp_path, emu_lib, oracle, fmt):
     """No Python on the hot path: a C++ program links the C ABI (here the SIMT-emulator build of the same sources, so it runs
-    without a GPU), reads a DCD file, compiles the script text with vmd_ir_compile_from_source and evaluates it; its output
+    without a GPU), reads a DCD or XTC file (chosen by extension), compiles the script text with vmd_ir_compile_from_source and evaluates it; its output
     must equal what the Python host computes for the same file."""
     import numpy as np
     import cases
@@ -47,8 +48,11 @@ def test_native_host_from_dcd_and_script_text_on_the_emulator(tmp_path, emu_lib,
     topo = synth.water_box_topology(n_atoms, n_blob)
     coords = cases.host_frames(oracle, 17, n_atoms, box, F, n_blob)
     cell = V.make_unitcell(box)
-    dcd = tmp_path / "t.dcd"
-    V.write_dcd(dcd, coords, cell)
+    dcd = tmp_path / f"t.{fmt}"
+    if fmt == "dcd":
+        V.write_dcd(dcd, coords, cell)
+    else:
+        V.write_xtc(dcd, coords, cell, lib=emu_lib)
     text = ("s = residue(2:4); v = sdf(s, element('O') and water, 7.0); g = rdf(element('O') and water, not element('H'), 8.0);"
             "d = distance(residue(1), residue(6)); m = distance_min(1:2, element('O')) in residue(2:5);")
     src = os.path.join(ROOT, "tests", "native", "cabi_script_demo.cpp")
@@ -61,7 +65,7 @@ def test_native_host_from_dcd_and_script_text_on_the_emulator(tmp_path, emu_lib,
     lines = dict(l.split(" ", 1) for l in out.stdout.strip().split("\n"))
     ir, info = script.compile_script(text, topo, lib=emu_lib)
     ev = V.ScriptEval(F, ir)
-    assert ev.frame_range(V.MolSystem(n_atoms, mass=topo.mass, unitcell=cell), V.DcdTrajectory(dcd, lib=emu_lib), 0, F)
+    assert ev.frame_range(V.MolSystem(n_atoms, mass=topo.mass, unitcell=cell), (V.DcdTrajectory if fmt == "dcd" else V.XdrTrajectory)(dcd, lib=emu_lib), 0, F)
     for name in ("v", "g"):
         want = float(ev.property_data(name).counts.sum())
         got = float(lines[name].split("sum=")[1].split()[0])

@@ -53,12 +53,21 @@ struct Options {
     std::atomic<int> rdf_variant{0};     // 0 queue, 1 inline
     std::atomic<int> batch_frames{0};    // 0 = auto
     std::atomic<int> force_brute{0};
-    std::atomic<int> load_threads{8};    // host threads decoding one staged batch through load_frame
+    std::atomic<int> load_threads{0};    // host threads decoding one staged batch through load_frame; 0 = auto (see load_threads())
     std::atomic<int> nxf_divisor{8};     // fine x cell = rmax / nxf_divisor
     std::atomic<int> cells_aos{1};       // sort through 16-byte records + repack
     std::atomic<int> sdf_dense{0};       // dense-target SDF scatter (stream whole frames, select by tag): measured slower, off
 };
 static Options g_opt;
+
+// One process per GPU and 8 GPUs per node share the host: an eighth of the hardware threads, at least 8 (memcpy-bound DCD
+// frames saturate there), at most 32 (compressed XTC frames scale further).
+static size_t load_threads() {
+    const int v = g_opt.load_threads.load();
+    if (v > 0) return (size_t)v;
+    const unsigned hw = std::thread::hardware_concurrency();
+    return std::min<size_t>(32, std::max<size_t>(8, hw / 8));
+}
 
 extern "C" int vmd_set_option(const char* key, int value) {
     std::atomic<int>* o = nullptr;
@@ -820,7 +829,7 @@ static bool fetch_stage(vmd_script_eval_t* e, Stage& st, vmd_trajectory_i* traj,
         if (!st.d.ensure(need)) return false;
         // md_trajectory_load_frame is called from all of VIAMD's pool threads at once (src/main.cpp:995-996 inside the
         // enkiTS range tasks), so the decoder behind it is re-entrant: decode the batch on a few threads
-        const size_t nthreads = std::max<size_t>(1, std::min<size_t>((size_t)std::max(1, g_opt.load_threads.load()), nb / 4));
+        const size_t nthreads = std::max<size_t>(1, std::min<size_t>(load_threads(), nb / 4));
         std::atomic<size_t> next{0};
         std::atomic<bool> ok{true};
         std::mutex err_mtx;
