@@ -23,6 +23,14 @@ for w in c3 c4 c5; do
 done
 echo "== bench c2, trajectory in pinned host memory (PCIe-inclusive)"
 timeout 300 python bench.py --traj pinned --no-cpu-baseline > $OUT/bench_c2_pinned.json 2>> $OUT/bench_c2.err; cat $OUT/bench_c2_pinned.json
+echo "== bench c2 from trajectory files (file -> host decode threads -> pinned staging -> PCIe): dcd, trr, xtc; xtc with 8 / 32 / 64 decode threads"
+for t in dcd trr xtc; do
+  timeout 600 python bench.py --traj $t --no-cpu-baseline --steps 5 > $OUT/bench_c2_$t.json 2>> $OUT/bench_c2.err; cat $OUT/bench_c2_$t.json
+done
+for n in 8 32 64; do
+  timeout 600 python bench.py --traj xtc --no-cpu-baseline --steps 5 --opt load_threads=$n > $OUT/bench_c2_xtc_t$n.json 2>> $OUT/bench_c2.err
+  python -c "import json;d=json.load(open('$OUT/bench_c2_xtc_t$n.json'));print('xtc load_threads=$n', round(d['value']), 'frames/s')"
+done
 echo "== rocprofv3 --kernel-trace --stats of the default bench command"
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_c2 -o c2 -- python $R/bench.py --no-cpu-baseline > $OUT/prof_c2.log 2>&1; echo "rocprof rc=$?"
