@@ -34,6 +34,11 @@ def _systems():
     wide = rng.uniform(0, 50.0, (3, 64)).astype(np.float32)
     wide[0] *= 5000.0
     out["wide"] = wide
+    # every axis just below 2^24 grid steps: one packed number of 68 bits per atom (the 128-bit path of the native reader),
+    # with a few close pairs so that small triples follow
+    huge = rng.uniform(0, 60000.0, (3, 48)).astype(np.float32)
+    huge[:, 1::4] = huge[:, 0::4] + rng.normal(0, 0.5, (3, 12)).astype(np.float32)
+    out["huge"] = huge
     # exactly on a lattice: many identical differences, zero differences
     g = np.stack(np.meshgrid(np.arange(6), np.arange(5), np.arange(4), indexing="ij"), -1).reshape(-1, 3) * 1.5
     out["lattice"] = g.T.astype(np.float32)
@@ -62,7 +67,7 @@ def test_xtc_reader_and_writer_against_the_bytewise_restatement(tmp_path, emu_li
     box = np.array([[31.0, 0, 0], [4.0, 29.5, 0], [-3.0, 5.5, 33.25]], np.float32)
     cell = V.make_unitcell((31.0, 29.5, 33.25), tilt=(4.0, -3.0, 5.5))
     for name, xyz in systems.items():
-        if name == "wide" and precision > 1000.0:
+        if name in ("wide", "huge") and precision > 1000.0:
             continue                                                       # beyond the integer range of the format
         F = 3
         frames = [xyz + np.float32(0.37 * f) for f in range(F)]

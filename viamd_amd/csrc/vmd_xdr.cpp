@@ -156,14 +156,7 @@ inline uint64_t div_recip(uint64_t w, uint64_t d, double inv) {
 }
 
 inline void unpack3(u128 v, const Radix& rx, int out[3]) {
-    if ((v >> 52) == 0) {
-        const uint64_t w = (uint64_t)v;
-        const uint64_t a = div_recip(w, rx.s[2], rx.inv2);       // w / s2
-        const uint64_t b = div_recip(w, rx.s12, rx.inv12);       // w / (s1 s2)
-        out[2] = (int)(w - a * rx.s[2]);
-        out[1] = (int)(a - b * rx.s[1]);
-        out[0] = (int)b;
-    } else if ((v >> 64) == 0) {
+    if ((v >> 64) == 0) {
         const uint64_t w = (uint64_t)v;
         const uint64_t a = w / rx.s[2];
         out[2] = (int)(w - a * rx.s[2]);
@@ -176,6 +169,23 @@ inline void unpack3(u128 v, const Radix& rx, int out[3]) {
         const u128 b = a / rx.s[1];
         out[1] = (int)(uint64_t)(a - b * rx.s[1]);
         out[0] = (int)(uint64_t)b;
+    }
+}
+
+// read one triple of `bits` bits and split it; everything below 53 bits (every realistic frame) stays in 64-bit registers
+inline void get_triple(BitReader& br, int bits, const Radix& rx, int out[3]) {
+    if (bits <= 52 && bits > 0) {
+        const int q = (bits - 1) >> 3, r = bits - 8 * q;
+        const uint64_t raw = br.get(bits);
+        const uint64_t top = raw >> r, low = raw & ((1ull << r) - 1);
+        const uint64_t w = (q ? (__builtin_bswap64(top) >> (64 - 8 * q)) : 0ull) | (low << (8 * q));
+        const uint64_t a = div_recip(w, rx.s[2], rx.inv2);       // w / s2
+        const uint64_t b = div_recip(w, rx.s12, rx.inv12);       // w / (s1 s2)
+        out[2] = (int)(w - a * rx.s[2]);
+        out[1] = (int)(a - b * rx.s[1]);
+        out[0] = (int)b;
+    } else {
+        unpack3(get_packed(br, bits), rx, out);
     }
 }
 
@@ -296,7 +306,7 @@ const char* xtc_decode(const unsigned char* hdr, const unsigned char* data, size
                 cur[k] = (int)(uint32_t)(b > 24 ? ((br.get(b - 24) << 24) | br.get(24)) : br.get(b));
             }
         } else {
-            unpack3(get_packed(br, bitsize), large, cur);
+            get_triple(br, bitsize, large, cur);
         }
         for (int k = 0; k < 3; ++k) { cur[k] += minint[k]; prev[k] = cur[k]; }
         int is_smaller = 0;
@@ -310,7 +320,7 @@ const char* xtc_decode(const unsigned char* hdr, const unsigned char* data, size
             if (i + 1 + (size_t)(run / 3) > natoms) return "XTC '%s': corrupt frame (run past the last atom)";
             for (int k = 0; k < run; k += 3) {
                 int d[3], nxt[3];
-                unpack3(get_packed(br, smallidx), small, d);
+                get_triple(br, smallidx, small, d);
                 for (int c = 0; c < 3; ++c) nxt[c] = d[c] + prev[c] - smallnum;
                 if (k == 0) {
                     // the large triple in front of the run is the SECOND atom of the pair
