@@ -9,7 +9,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libvmd_oracle.so")
+# VMD_ORACLE_LIB: another build of the same source (scripts/sanitize_emu.sh points it at an ASan/UBSan build)
+_LIB_PATH = os.environ.get("VMD_ORACLE_LIB") or os.path.join(_HERE, "libvmd_oracle.so")
 
 PBC_ALL = 7
 

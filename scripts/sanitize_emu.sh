@@ -13,5 +13,12 @@ esac
 export ASAN_OPTIONS=detect_leaks=0:detect_stack_use_after_return=0:abort_on_error=0:halt_on_error=1
 export UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1
 export TSAN_OPTIONS=halt_on_error=0:report_signal_unsafe=0
+if [[ "$SAN" != thread* ]]; then     # the oracle (the checker) gets the same treatment
+  gcc -O1 -g -fPIC -std=c11 -ffp-contract=off -fno-fast-math -mavx2 -mfma -fopenmp -fsanitize=$SAN -fno-sanitize-recover=undefined \
+      -fno-omit-frame-pointer -shared -o /tmp/libvmd_oracle_san.so oracle/vmd_oracle.c -lm
+  export VMD_ORACLE_LIB=/tmp/libvmd_oracle_san.so
+fi
 TARGETS=("$@"); [ ${#TARGETS[@]} -eq 0 ] && TARGETS=(tests)
-LD_PRELOAD=$RT python -m pytest "${TARGETS[@]}" -q -m "not gpu" -x
+# libstdc++ is preloaded next to the runtime: the __cxa_throw interceptor of a preloaded libasan needs it resolvable at start-up
+# (the script front-end throws and catches internally)
+LD_PRELOAD="$RT $(g++ -print-file-name=libstdc++.so)" python -m pytest "${TARGETS[@]}" -q -m "not gpu" -x
