@@ -65,3 +65,11 @@ def gpu_lib():
     lib = default_lib()
     assert lib.vmd_device_count() > 0, "no HIP device visible: -m gpu tests must run on the MI355X box"
     return lib
+
+
+@pytest.fixture(scope="session", params=["emu", "product"])
+def host_lib(request):
+    """For entry points that are pure host code (file readers / writers, script front-end, post-processing): the g++ emulator
+    build and the hipcc-built product library (clang, -O3) - the latter loads without a GPU, only device calls need one."""
+    from viamd_amd import VmdLib, default_lib
+    return VmdLib(build_emu()) if request.param == "emu" else default_lib()

@@ -71,7 +71,8 @@ def test_pdb_triclinic_cell_roundtrip(tmp_path):
     assert cell.flags == 7
 
 
-def test_dcd_reader_roundtrip_both_byte_orders_and_cells(tmp_path, emu_lib):
+def test_dcd_reader_roundtrip_both_byte_orders_and_cells(tmp_path, host_lib):
+    emu_lib = host_lib       # pure host code: the g++ emulator build and the hipcc-built product library
     """The native DCD reader (vmd_dcd.cpp; VIAMD: md_dcd_attach_from_file, src/loader.cpp:151-152): coordinates bit for bit,
     orthorhombic cells exactly, triclinic cells through angles (degrees and cosines), no-cell files, error paths."""
     rng = np.random.default_rng(5)

@@ -112,7 +112,8 @@ BAD_SCRIPTS = ["g = rdf(element('X'), all, 5.0);", "v = sdf(all[1:2], all, 5.0);
                "w = sdf(resname('ALA', 'HOH')[200:201], all, 3.0);"]
 
 
-def test_native_front_end_matches_the_python_one(emu_lib, topo):
+def test_native_front_end_matches_the_python_one(host_lib, topo):
+    emu_lib = host_lib       # pure host code: the g++ emulator build and the hipcc-built product library
     """vmd_ir_compile_from_source (C++) against viamd_amd/script.py: identical descriptors, i.e. identical IR fingerprints,
     names and flags; the same scripts are rejected."""
     for text in GOOD_SCRIPTS:

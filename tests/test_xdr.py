@@ -62,7 +62,8 @@ def _expected_xtc(coords_A, precision):
 
 
 @pytest.mark.parametrize("precision", [1000.0, 100.0, 12345.0])
-def test_xtc_reader_and_writer_against_the_bytewise_restatement(tmp_path, emu_lib, precision):
+def test_xtc_reader_and_writer_against_the_bytewise_restatement(tmp_path, host_lib, precision):
+    emu_lib = host_lib
     systems = _systems()
     box = np.array([[31.0, 0, 0], [4.0, 29.5, 0], [-3.0, 5.5, 33.25]], np.float32)
     cell = V.make_unitcell((31.0, 29.5, 33.25), tilt=(4.0, -3.0, 5.5))
@@ -146,7 +147,8 @@ def _trr_frame(xyz_A, box_A, step, time, double=False, with_x=True, natoms=None)
     return out
 
 
-def test_trr_reader_single_and_double_precision(tmp_path, emu_lib):
+def test_trr_reader_single_and_double_precision(tmp_path, host_lib):
+    emu_lib = host_lib
     rng = np.random.default_rng(3)
     F, N = 4, 53
     coords = rng.normal(0, 25, (F, 3, N)).astype(np.float32)
@@ -180,7 +182,8 @@ def test_trr_reader_single_and_double_precision(tmp_path, emu_lib):
     np.testing.assert_allclose([c.x, c.y, c.z, c.xy, c.xz, c.yz], [40.0, 42.5, 38.0, 3.0, -2.0, 1.5], rtol=1e-6)
 
 
-def test_xdr_error_paths_and_truncation(tmp_path, emu_lib):
+def test_xdr_error_paths_and_truncation(tmp_path, host_lib):
+    emu_lib = host_lib
     xyz = _systems()["water"]
     p = tmp_path / "w.xtc"
     V.write_xtc(p, np.stack([xyz, xyz + 1, xyz + 2]), V.make_unitcell(31.0), lib=emu_lib)
