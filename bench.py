@@ -51,12 +51,48 @@ WORKLOADS = {
 }
 
 
+def host_cpus():
+    """(logical CPUs this process may run on, physical cores among them, cgroup CPU quota in cores or None)."""
+    logical = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    physical, quota = logical, None
+    try:
+        allowed = os.sched_getaffinity(0)
+        cores, cpu, phys = set(), None, "0"
+        for line in open("/proc/cpuinfo"):
+            k, _, v = line.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "processor":
+                cpu = int(v)
+            elif k == "physical id":
+                phys = v
+            elif k == "core id" and cpu in allowed:
+                cores.add((phys, v))
+        if cores:
+            physical = len(cores)
+    except Exception:
+        pass
+    try:
+        if os.path.exists("/sys/fs/cgroup/cpu.max"):                          # cgroup v2: "max 100000" or "<quota> <period>"
+            q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+            quota = None if q == "max" else float(q) / float(per)
+        else:                                                                 # cgroup v1
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            quota = q / per if q > 0 else None
+    except Exception:
+        pass
+    return logical, physical, quota
+
+
 def cpu_baseline(name, w, topo, info):
-    """The oracle (a port — ext/mdlib is empty, so mdlib itself cannot be timed) driven like VIAMD drives mdlib:
-    all host cores, frames handed out dynamically with grain 1, on a bounded sample of the same workload."""
+    """The oracle (a port - ext/mdlib is empty, so mdlib itself cannot be timed) driven like VIAMD drives mdlib: one thread per
+    physical core (src/main.cpp:494-495), frames handed out dynamically with grain 1 (src/task_system.cpp:73-81), on a bounded
+    sample of the same workload.  A single-thread run of the same code is timed first, so the line shows how many cores' worth
+    of CPU the box really delivered (a containerised slice of a node reports all of the node's CPUs)."""
     from oracle import oracle as O
     from viamd_amd import synth
-    cores = os.cpu_count() or 1
+    logical, physical, quota = host_cpus()
+    cores = max(1, min(physical, int(np.ceil(quota))) if quota else physical)
     cell = O.make_cell(w["box"])
     budget = 15.0                       # seconds of wall time aimed at
     mass = topo.mass
@@ -86,6 +122,10 @@ def cpu_baseline(name, w, topo, info):
     cap = max(1, int(6e9 // (12 * w["atoms"])))                    # host copy below ~6 GB
     nfr = min(cores, cap)
     traj = frames_for(nfr)
+    n1 = 1 if w["atoms"] > 500000 else min(2, nfr)                 # the same code on ONE thread
+    t = time.perf_counter()
+    run(traj[:n1], 1)
+    single = n1 / (time.perf_counter() - t)
     t = time.perf_counter()
     hits = run(traj, cores)
     dt = time.perf_counter() - t
@@ -97,10 +137,14 @@ def cpu_baseline(name, w, topo, info):
             t = time.perf_counter()
             hits = run(traj, cores)
             dt = time.perf_counter() - t
-    return {"value": nfr / dt, "unit": "frames/s", "cores": cores, "kind": "port",
+    value = nfr / dt
+    return {"value": value, "unit": "frames/s", "cores": cores, "kind": "port",
             "sample": f"{nfr} frames of {name} ({w['atoms']} atoms), oracle (cell-list RDF / SDF align+scatter), "
-                      f"OpenMP dynamic grain 1 over frames, {dt:.1f} s",
-            "pairs_per_s": hits / dt}
+                      f"{cores} OpenMP threads, dynamic grain 1 over frames, {dt:.1f} s",
+            "pairs_per_s": hits / dt,
+            "single_thread": {"value": single, "unit": "frames/s", "frames": n1},
+            "parallel_speedup": value / single,       # far below `cores` = the box delivers fewer CPUs than it lists
+            "host": {"logical_cpus": logical, "physical_cores": physical, "cgroup_quota_cores": quota}}
 
 
 def main():
