@@ -296,6 +296,12 @@ void vmd_compute_histogram_masked(float* bins, int num_bins, float range_min, fl
 int         vmd_device_count(void);                 /* 0 when no HIP device is usable */
 bool        vmd_set_device(int device);
 const char* vmd_last_error(void);                   /* thread-local message of the last failure */
+/* md_log_register analogue (VIAMD turns mdlib's log messages into toasts, src/main.cpp:384-420): evaluator failures are
+ * delivered to `fn` (from whichever thread hit them) instead of stderr; NULL restores stderr. */
+#define VMD_LOG_INFO  1
+#define VMD_LOG_ERROR 2
+typedef void (*vmd_log_fn)(int level, const char* message, void* user);
+void        vmd_log_register(vmd_log_fn fn, void* user);
 const char* vmd_version(void);
 /* tuning knobs (kernel variant, frames per batch); returns previous value, -1 for unknown key */
 int         vmd_set_option(const char* key, int value);

@@ -73,3 +73,21 @@ def test_ir_validation(product_lib):
     fp = ir.fingerprint()
     ir.add_distance("d2", [0], [2], V.DIST_MIN)
     assert ir.fingerprint() != fp
+
+
+def test_log_hook_receives_failures(emu_lib, capfd):
+    """md_log_register analogue (VIAMD shows mdlib's messages as toasts, src/main.cpp:384-420): a registered callback gets the
+    evaluator's failure messages instead of stderr; NULL restores stderr."""
+    from viamd_amd import _lib as L
+    seen = []
+    cb = L.LOG_FN(lambda level, msg, user: seen.append((level, msg.decode())))
+    emu_lib.vmd_log_register(cb, None)
+    try:
+        assert not emu_lib.vmd_eval_frame_range(None, None, None, None, 0, 1)
+    finally:
+        emu_lib.vmd_log_register(L.LOG_FN(0), None)
+    assert seen and seen[0][0] == 2 and "NULL argument" in seen[0][1]
+    assert "NULL argument" in emu_lib.last_error()
+    assert "NULL argument" not in capfd.readouterr().err
+    assert not emu_lib.vmd_eval_frame_range(None, None, None, None, 0, 1)
+    assert "NULL argument" in capfd.readouterr().err

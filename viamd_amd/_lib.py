@@ -17,6 +17,7 @@ RDF_NUM_BINS = 1024
 VOLUME_DIM = 128
 
 c_float_p = C.POINTER(C.c_float)
+LOG_FN = C.CFUNCTYPE(None, C.c_int, C.c_char_p, C.c_void_p)      # vmd_log_fn
 c_int32_p = C.POINTER(C.c_int32)
 c_uint8_p = C.POINTER(C.c_uint8)
 c_uint64_p = C.POINTER(C.c_uint64)
@@ -152,6 +153,7 @@ SIGNATURES = [
     ("vmd_device_count", C.c_int, []),
     ("vmd_set_device", C.c_bool, [C.c_int]),
     ("vmd_last_error", C.c_char_p, []),
+    ("vmd_log_register", None, [LOG_FN, _vp]),
     ("vmd_version", C.c_char_p, []),
     ("vmd_set_option", C.c_int, [C.c_char_p, C.c_int]),
     ("vmd_profile_reset", None, []),

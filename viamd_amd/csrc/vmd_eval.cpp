@@ -27,6 +27,27 @@
 
 static thread_local std::string g_last_error;
 
+// md_log_register analogue (VIAMD installs a logger that turns messages into toasts, src/main.cpp:384-420): failures go to
+// the registered callback, or to stderr when there is none.  The callback may be invoked from any thread that calls the API.
+static std::mutex g_log_mtx;
+static vmd_log_fn g_log_fn = nullptr;
+static void* g_log_user = nullptr;
+extern "C" void vmd_log_register(vmd_log_fn fn, void* user) {
+    std::lock_guard<std::mutex> l(g_log_mtx);
+    g_log_fn = fn;
+    g_log_user = user;
+}
+static void vmd_log(int level, const char* msg) {
+    vmd_log_fn fn;
+    void* user;
+    {
+        std::lock_guard<std::mutex> l(g_log_mtx);
+        fn = g_log_fn; user = g_log_user;
+    }
+    if (fn) fn(level, msg, user);
+    else fprintf(stderr, "[viamd_amd] %s: %s\n", level >= VMD_LOG_ERROR ? "error" : "info", msg);
+}
+
 static bool vmd_fail(const char* fmt, ...) {
     char buf[512];
     va_list ap;
@@ -34,7 +55,7 @@ static bool vmd_fail(const char* fmt, ...) {
     vsnprintf(buf, sizeof(buf), fmt, ap);
     va_end(ap);
     g_last_error = buf;
-    fprintf(stderr, "[viamd_amd] error: %s\n", buf);
+    vmd_log(VMD_LOG_ERROR, buf);
     return false;
 }
 
