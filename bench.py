@@ -318,6 +318,9 @@ def main():
             "kernel_ms": dict(kernel_ms, timed_region=elapsed * 1e3),
             "synth_s": gen_s,
         }
+        if args.traj == "xtc":
+            # > 0 only with --opt xtc_device_decode=1: the compressed frames crossed PCIe and were decompressed by k_xtc_decode
+            out["config"]["frames_decompressed_on_device_per_step"] = ev.frames_device_decoded()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload, w, topo, info)
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]

@@ -77,6 +77,18 @@ typedef struct vmd_host_view_t {
  * (vmd_set_option("load_threads", n); 1 = strictly serial, 0 = default: an eighth of the host's hardware threads within
  * [8, 32]).  device_view is an extension: when non-NULL and successful the evaluator reads frames in place from HBM instead
  * of staging them through load_frame. */
+/* A frame handed over still compressed, to be decoded on the device (extension; today: the XTC coordinate block).  The
+ * decoder parameters are in host byte order; the `nbytes` bytes of the bit stream are written to the caller's buffer. */
+#define VMD_RAW_CODEC_XTC 1u
+typedef struct vmd_raw_frame_t {
+    uint32_t codec;             /* VMD_RAW_CODEC_* */
+    float    precision;         /* XTC: grid steps per nm */
+    int32_t  minint[3], maxint[3];
+    int32_t  smallidx;
+    uint32_t reserved;
+    uint64_t nbytes;            /* bytes of the bit stream */
+} vmd_raw_frame_t;
+
 typedef struct vmd_trajectory_i {
     void* inst;
     size_t (*num_frames)(void* inst);
@@ -84,6 +96,11 @@ typedef struct vmd_trajectory_i {
     bool (*load_frame)(void* inst, int64_t idx, vmd_frame_header_t* header, float* x, float* y, float* z);
     bool (*device_view)(void* inst, vmd_device_view_t* out);
     bool (*host_view)(void* inst, vmd_host_view_t* out);     /* extension, may be NULL */
+    /* extension, may be NULL: frame `idx` as stored in the file.  dst == NULL: only fill `info` (nbytes = buffer size needed).
+     * Returns false when this frame cannot be handed over raw (the evaluator then takes load_frame); re-entrant like
+     * load_frame.  With vmd_set_option("xtc_device_decode", 1) the evaluator moves the compressed bytes over PCIe and
+     * decompresses a whole batch on the GPU (k_xtc_decode). */
+    bool (*load_raw)(void* inst, int64_t idx, vmd_frame_header_t* header, vmd_raw_frame_t* info, void* dst, size_t cap);
 } vmd_trajectory_i;
 
 /* ---- IR: property descriptors (md_script_ir_t stand-in) ----------------------------------------- */
@@ -231,6 +248,8 @@ bool   vmd_eval_set_block_frames(vmd_script_eval_t* eval, size_t block_frames);
 bool   vmd_eval_set_source(vmd_script_eval_t* eval, vmd_script_eval_t* source);
 /* frames evaluated by kernels / frames served from block partials since the last clear_data */
 void   vmd_eval_frame_stats(const vmd_script_eval_t* eval, size_t* frames_computed, size_t* frames_reused);
+/* frames whose coordinates were decompressed on the device (load_raw + k_xtc_decode) since the last clear_data */
+size_t vmd_eval_frames_device_decoded(const vmd_script_eval_t* eval);
 
 /* ---- device-resident trajectories (pre-staged in HBM) ---------------------------------- */
 typedef struct vmd_devtraj_t vmd_devtraj_t;

@@ -14,6 +14,7 @@
  *   vmd_hip_rdf_*     <- rdf() pair loop + md_spatial_hash query (a4, a5)
  *   vmd_hip_sdf_*     <- sdf() alignment + density-volume accumulation (a6, a7, a9)
  *   vmd_hip_distance  <- distance / distance_min / distance_max / distance_pair (a8)
+ *   vmd_hip_xtc_decode <- md_xtc frame decompression (f1; /root/reference/src/loader.cpp:147-148)
  */
 #ifndef VMD_HIP_H
 #define VMD_HIP_H
@@ -113,6 +114,21 @@ int vmd_hip_distance(void* stream, const float* xyz, size_t frame_stride, size_t
 int vmd_hip_add_u64(void* stream, uint64_t* dst, const uint64_t* src, size_t n);
 /* u64 counters -> f32 values (values[i] = (float)counts[i]) + max reduction into max_out[0] (device f32) */
 int vmd_hip_counts_to_float(void* stream, const uint64_t* counts, size_t n, float* values, float* max_out);
+
+/* XTC coordinate blocks decompressed on the device (the compressed bytes cross PCIe, not the floats): one
+ * thread per frame walks its bit stream (frames are independent, a stream is strictly sequential).
+ *   raw     u8: the bit streams, frame b at raw + info[b].offset (16-byte aligned, >= 16 readable bytes behind each stream)
+ *   info    one record per frame, host byte order
+ *   xyz     out, frame layout as above, Angstrom: fl(fl(int * fl(1/precision)) * 10) like the host reader (vmd_xdr.cpp)
+ *   status  u32[B] out: 0 ok, 1 corrupt stream, 2 not supported on the device (a packed triple wider than 64 bits) */
+typedef struct vmd_xtc_frame_t {
+    float    precision;
+    int32_t  minint[3], maxint[3];
+    int32_t  smallidx;
+    uint64_t offset, nbytes;
+} vmd_xtc_frame_t;
+int vmd_hip_xtc_decode(void* stream, const unsigned char* raw, const vmd_xtc_frame_t* info, int B, int natoms,
+                       float* xyz, size_t frame_stride, size_t row_stride, uint32_t* status);
 
 /* synthetic water box (oracle S9 twin): fills frames [frame0, frame0+B) of a batch laid out as above */
 int vmd_hip_synth_frames(void* stream, float* xyz, size_t frame_stride, size_t row_stride, int B, uint32_t frame0,

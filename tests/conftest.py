@@ -26,6 +26,7 @@ def oracle():
 EMU_DIR = os.path.join(ROOT, "tests", "emu")
 EMU_LIB = os.path.join(EMU_DIR, "libviamd_emu.so")
 EMU_SOURCES = [os.path.join(ROOT, "viamd_amd", "csrc", "vmd_kernels.hip"),
+               os.path.join(ROOT, "viamd_amd", "csrc", "vmd_xtc_device.hip"),
                os.path.join(ROOT, "viamd_amd", "csrc", "vmd_eval.cpp"),
                os.path.join(ROOT, "viamd_amd", "csrc", "vmd_dcd.cpp"),
                os.path.join(ROOT, "viamd_amd", "csrc", "vmd_xdr.cpp"),

@@ -252,3 +252,113 @@ def test_xtc_trajectory_through_the_evaluator_on_emulator(tmp_path, emu_lib, ora
         np.testing.assert_array_equal(r, res[0])
     cases.check_rdf(emu_lib, oracle, decoded, box, [("g", o, o, 0.0, 9.0)])
     assert res[0].sum() > 0
+
+
+def _device_decode(lib, blob, natoms):
+    """Run vmd_hip_xtc_decode (emulator build: "device" memory is host memory) on every frame of an XTC byte string."""
+    import ctypes as C
+    from viamd_amd import _lib as L
+    off, infos, streams = 0, [], []
+    while off < len(blob):
+        n = struct.unpack_from(">i", blob, off + 4)[0]
+        precision, = struct.unpack_from(">f", blob, off + 56)
+        mm = struct.unpack_from(">7i", blob, off + 60)
+        nbytes, = struct.unpack_from(">i", blob, off + 88)
+        streams.append(blob[off + 92: off + 92 + nbytes])
+        infos.append((precision, mm[0:3], mm[3:6], mm[6], nbytes))
+        off += 92 + ((nbytes + 3) & ~3)
+        assert n == natoms
+    B = len(infos)
+    raw = bytearray()
+    arr = (L.XtcFrame * B)()
+    for b, (precision, mi, ma, sidx, nbytes) in enumerate(infos):
+        arr[b].precision = precision
+        arr[b].minint[:] = mi
+        arr[b].maxint[:] = ma
+        arr[b].smallidx = sidx
+        arr[b].offset = len(raw)
+        arr[b].nbytes = nbytes
+        raw += streams[b] + b"\0" * ((-len(streams[b])) % 64 + 64)
+    # 64-byte alignment of the stream starts: copy into an aligned numpy buffer
+    store = np.zeros(len(raw) + 64, np.uint8)
+    base = (-store.ctypes.data) % 64
+    store[base:base + len(raw)] = np.frombuffer(raw, np.uint8)
+    npad = (natoms + 63) & ~63
+    out = np.full((B, 3, npad), np.nan, np.float32)
+    status = np.full(B, 99, np.uint32)
+    rc = lib.vmd_hip_xtc_decode(None, store.ctypes.data + base, C.addressof(arr), B, natoms, out.ctypes.data, 3 * npad, npad,
+                                status.ctypes.data)
+    assert rc == 0
+    return out[:, :, :natoms], status
+
+
+def test_device_xtc_decoder_matches_the_host_reader(tmp_path, emu_lib):
+    """k_xtc_decode (one GPU thread per frame; here on the SIMT emulator) against the host reader on every fixture: the same
+    floats bit for bit; a 68-bit packed triple is reported as unsupported (status 2), a damaged stream as corrupt (status 1) or
+    decoded without leaving the frame's buffers."""
+    systems = _systems()
+    for name, xyz in systems.items():
+        if xyz.shape[1] <= 9:
+            continue
+        F = 3
+        frames = [xyz + np.float32(0.37 * f) for f in range(F)]
+        blob = b"".join(xtc_ref.frame_bytes(frames[f], np.diag([30.0, 30.0, 30.0]), f, 0.0, 1000.0) for f in range(F))
+        got, status = _device_decode(emu_lib, blob, xyz.shape[1])
+        if name == "huge":
+            assert (status == 2).all()
+            continue
+        assert (status == 0).all(), (name, status)
+        p = tmp_path / f"{name}.xtc"
+        p.write_bytes(blob)
+        t = V.XdrTrajectory(p, lib=emu_lib)
+        for f in range(F):
+            np.testing.assert_array_equal(got[f], t.load_frame(f)[0], err_msg=name)
+    # damaged streams: never out of bounds (the emulator build runs under ASan in scripts/sanitize_emu.sh), some are rejected
+    rng = np.random.default_rng(1)
+    xyz = systems["water"]
+    blob = xtc_ref.frame_bytes(xyz, np.diag([30.0, 30.0, 30.0]), 0, 0.0, 1000.0)
+    rejected = 0
+    for trial in range(60):
+        b = bytearray(blob)
+        for _ in range(rng.integers(1, 5)):
+            b[rng.integers(92, len(b))] = rng.integers(0, 256)
+        _, status = _device_decode(emu_lib, bytes(b), xyz.shape[1])
+        rejected += int(status[0] != 0)
+    assert rejected > 0
+
+
+def test_xtc_batches_decoded_on_the_device_through_the_evaluator(tmp_path, emu_lib, oracle):
+    """vmd_set_option("xtc_device_decode", 1): the evaluator pulls the compressed frames (load_raw), moves the bit streams to
+    the device and decompresses the batch there; same histogram as host decoding, every frame counted as device-decoded; a TRR
+    file (nothing to decompress) and a damaged XTC file fall back to load_frame."""
+    import cases
+    box, F, N = 36.0, 10, 1200
+    coords = cases.water_box(oracle, 31, N, box, F)
+    cell = V.make_unitcell(box)
+    p = tmp_path / "w.xtc"
+    V.write_xtc(p, coords, cell, lib=emu_lib)
+    q = tmp_path / "w.trr"
+    V.write_trr(q, coords, cell, lib=emu_lib)
+    o = cases.oxygen(N)
+    ir = V.ScriptIR(emu_lib); ir.add_rdf("g", o, o, 9.0)
+    sysm = V.MolSystem(N, unitcell=cell)
+    old_b = emu_lib.vmd_set_option(b"batch_frames", 4)
+    res = {}
+    try:
+        for mode in (0, 1):
+            old = emu_lib.vmd_set_option(b"xtc_device_decode", mode)
+            try:
+                ev = V.ScriptEval(F, ir)
+                assert ev.frame_range(sysm, V.XdrTrajectory(p, lib=emu_lib), 0, F)
+                res[mode] = ev.property_data("g").counts.copy()
+                assert ev.frames_device_decoded() == (F if mode else 0)
+                if mode:
+                    ev2 = V.ScriptEval(F, ir)
+                    assert ev2.frame_range(sysm, V.XdrTrajectory(q, lib=emu_lib), 0, F)
+                    assert ev2.frames_device_decoded() == 0 and ev2.property_data("g").counts.sum() > 0
+            finally:
+                emu_lib.vmd_set_option(b"xtc_device_decode", old)
+    finally:
+        emu_lib.vmd_set_option(b"batch_frames", old_b)
+    np.testing.assert_array_equal(res[1], res[0])
+    assert res[0].sum() > 0

@@ -31,6 +31,18 @@ def _xdr_through_the_evaluator(lib, oracle, tmp_path, box, F, N, device_check):
         counts, _ = cases.oracle_rdf(oracle, decoded, oracle.make_cell(box), o, o, 0.0, 9.0)
         np.testing.assert_array_equal(got, counts, err_msg=fmt)            # bit-exact on the coordinates the file holds
         res[fmt] = got
+        if fmt == "xtc":
+            # the same file with the batch decompressed on the device (k_xtc_decode): identical integers, every frame counted
+            old_d = lib.vmd_set_option(b"xtc_device_decode", 1)
+            old = lib.vmd_set_option(b"batch_frames", max(4, F // 3))
+            try:
+                ev = V.ScriptEval(F, ir)
+                assert ev.frame_range(sysm, V.XdrTrajectory(p, lib=lib), 0, F)
+            finally:
+                lib.vmd_set_option(b"batch_frames", old)
+                lib.vmd_set_option(b"xtc_device_decode", old_d)
+            assert ev.frames_device_decoded() == F
+            np.testing.assert_array_equal(ev.property_data("g").counts, counts, err_msg="xtc, device decode")
     assert res["xtc"].sum() > 0 and abs(int(res["xtc"].sum()) - int(res["trr"].sum())) < 0.01 * res["trr"].sum()
 
 

@@ -62,9 +62,15 @@ class TopologyC(C.Structure):
                 ("resnames", C.POINTER(C.c_char_p)), ("residue_index", c_int32_p)]
 
 
+class XtcFrame(C.Structure):             # vmd_xtc_frame_t (include/vmd_hip.h)
+    _fields_ = [("precision", C.c_float), ("minint", C.c_int32 * 3), ("maxint", C.c_int32 * 3), ("smallidx", C.c_int32),
+                ("offset", C.c_uint64), ("nbytes", C.c_uint64)]
+
+
 class TrajectoryI(C.Structure):
     _fields_ = [("inst", C.c_void_p), ("num_frames", NUM_FRAMES_FN), ("num_atoms", NUM_ATOMS_FN),
-                ("load_frame", LOAD_FRAME_FN), ("device_view", DEVICE_VIEW_FN), ("host_view", HOST_VIEW_FN)]
+                ("load_frame", LOAD_FRAME_FN), ("device_view", DEVICE_VIEW_FN), ("host_view", HOST_VIEW_FN),
+                ("load_raw", C.c_void_p)]          # native readers only (compressed frames for the device decoder); NULL here
 
 
 class Aggregate(C.Structure):
@@ -123,6 +129,7 @@ SIGNATURES = [
     ("vmd_eval_set_block_frames", C.c_bool, [_vp, C.c_size_t]),
     ("vmd_eval_set_source", C.c_bool, [_vp, _vp]),
     ("vmd_eval_frame_stats", None, [_vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    ("vmd_eval_frames_device_decoded", C.c_size_t, [_vp]),
     ("vmd_devtraj_create", _vp, [C.c_size_t, C.c_size_t]),
     ("vmd_devtraj_free", None, [_vp]),
     ("vmd_devtraj_interface", C.POINTER(TrajectoryI), [_vp]),
@@ -160,6 +167,7 @@ SIGNATURES = [
     ("vmd_profile_ms", C.c_double, [C.c_char_p, c_uint64_p]),
     ("vmd_profile_enable", None, [C.c_bool]),
     # vmd_hip.h
+    ("vmd_hip_xtc_decode", C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _vp, C.c_size_t, C.c_size_t, _vp]),
     ("vmd_hip_bbox", C.c_int, [_vp, _vp, C.c_size_t, C.c_size_t, C.c_int, C.c_int, _vp]),
     ("vmd_hip_cells_build", C.c_int, [_vp, _vp, C.c_size_t, C.c_size_t, _vp, C.c_uint32, C.c_int, _vp, C.c_int, C.c_int, Grid, _vp, _vp, _vp, _vp, _vp]),
     ("vmd_hip_cells_fused_ok", C.c_int, [Grid, C.c_int]),

@@ -5,7 +5,8 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_HERE)
-SOURCES = [os.path.join(_HERE, "csrc", "vmd_kernels.hip"), os.path.join(_HERE, "csrc", "vmd_eval.cpp"),
+SOURCES = [os.path.join(_HERE, "csrc", "vmd_kernels.hip"), os.path.join(_HERE, "csrc", "vmd_xtc_device.hip"),
+           os.path.join(_HERE, "csrc", "vmd_eval.cpp"),
            os.path.join(_HERE, "csrc", "vmd_dcd.cpp"), os.path.join(_HERE, "csrc", "vmd_xdr.cpp"),
            os.path.join(_HERE, "csrc", "vmd_script.cpp")]
 HEADERS = [os.path.join(ROOT, "include", "vmd_eval.h"), os.path.join(ROOT, "include", "vmd_hip.h")]

@@ -198,6 +198,7 @@ extern "C" vmd_dcdtraj_t* vmd_dcdtraj_open(const char* path) {
     d.iface.load_frame = dcd_load_frame;
     d.iface.device_view = nullptr;
     d.iface.host_view = nullptr;
+    d.iface.load_raw = nullptr;
     return t;
 }
 

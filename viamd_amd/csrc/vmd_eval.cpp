@@ -77,6 +77,7 @@ struct Options {
     std::atomic<int> load_threads{0};    // host threads decoding one staged batch through load_frame; 0 = auto (see load_threads())
     std::atomic<int> nxf_divisor{8};     // fine x cell = rmax / nxf_divisor
     std::atomic<int> cells_aos{1};       // sort through 16-byte records + repack
+    std::atomic<int> xtc_device_decode{0};   // 1: frames offered raw (load_raw) are decompressed on the device (k_xtc_decode)
     std::atomic<int> sdf_dense{0};       // dense-target SDF scatter (stream whole frames, select by tag): measured slower, off
 };
 static Options g_opt;
@@ -99,6 +100,7 @@ extern "C" int vmd_set_option(const char* key, int value) {
     else if (!strcmp(key, "nxf_divisor")) o = &g_opt.nxf_divisor;
     else if (!strcmp(key, "cells_aos")) o = &g_opt.cells_aos;
     else if (!strcmp(key, "sdf_dense")) o = &g_opt.sdf_dense;
+    else if (!strcmp(key, "xtc_device_decode")) o = &g_opt.xtc_device_decode;
     else if (!strcmp(key, "cells_fused")) return vmd_hip_set_cells_fused(value);
     else if (!strcmp(key, "cells_split")) return vmd_hip_set_cells_split(value);
     else if (!strcmp(key, "rdf_blocks")) return vmd_hip_set_rdf_blocks(value);
@@ -407,6 +409,13 @@ struct vmd_script_eval_t {
     struct Stage {
         float* h = nullptr; size_t hcap = 0;     // pinned host frames [nb][3][npad]
         DevBuf<float> d;                         // their device copy
+        // compressed frames for the device decoder (load_raw): pinned bit streams + per-frame records, device copies, status
+        unsigned char* hraw = nullptr; size_t hraw_cap = 0;
+        DevBuf<unsigned char> d_raw;
+        std::vector<vmd_xtc_frame_t> raw_info;
+        DevBuf<vmd_xtc_frame_t> d_raw_info;
+        DevBuf<uint32_t> d_raw_status;
+        uint32_t* h_raw_status = nullptr; size_t h_raw_status_cap = 0;
         DevBuf<float> d_boxes;
         std::vector<float> h_boxes;              // [nb][6]: L, 1/L
         std::vector<vmd_unitcell_t> cells;
@@ -427,7 +436,7 @@ struct vmd_script_eval_t {
     std::unique_ptr<std::atomic<uint8_t>[]> block_ready;
     size_t num_blocks = 0;
     vmd_script_eval_t* source = nullptr;
-    std::atomic<size_t> frames_computed{0}, frames_reused{0};
+    std::atomic<size_t> frames_computed{0}, frames_reused{0}, frames_device_decoded{0};
 };
 typedef vmd_script_eval_t::Stage Stage;
 
@@ -524,6 +533,10 @@ extern "C" void vmd_eval_free(vmd_script_eval_t* eval) {
         for (auto& st : eval->stages) {
             if (st.h) (void)hipHostFree(st.h);
             st.h = nullptr;
+            if (st.hraw) (void)hipHostFree(st.hraw);
+            st.hraw = nullptr;
+            if (st.h_raw_status) (void)hipHostFree(st.h_raw_status);
+            st.h_raw_status = nullptr;
             st.d.release(); st.d_boxes.release(); st.d_bbox.release(); st.d_gboxes.release();
             if (st.ready) (void)hipEventDestroy(st.ready);
             st.ready = nullptr;
@@ -544,7 +557,7 @@ extern "C" void vmd_eval_clear_data(vmd_script_eval_t* eval) {
     eval->interrupt = false;
     std::fill(eval->frame_mask.begin(), eval->frame_mask.end(), (uint8_t)0);
     eval->frames_done = 0;
-    eval->frames_computed = 0; eval->frames_reused = 0;
+    eval->frames_computed = 0; eval->frames_reused = 0; eval->frames_device_decoded = 0;
     for (size_t b = 0; b < eval->num_blocks; ++b) eval->block_ready[b] = 0;
     for (auto& p : eval->props) {
         std::fill(p->values.begin(), p->values.end(), 0.0f);
@@ -703,6 +716,8 @@ extern "C" bool vmd_eval_set_source(vmd_script_eval_t* eval, vmd_script_eval_t* 
     return true;
 }
 
+extern "C" size_t vmd_eval_frames_device_decoded(const vmd_script_eval_t* eval) { return eval ? eval->frames_device_decoded.load() : 0; }
+
 extern "C" void vmd_eval_frame_stats(const vmd_script_eval_t* eval, size_t* frames_computed, size_t* frames_reused) {
     if (frames_computed) *frames_computed = eval ? eval->frames_computed.load() : 0;
     if (frames_reused) *frames_reused = eval ? eval->frames_reused.load() : 0;
@@ -814,6 +829,76 @@ struct BatchSrc {
     size_t frame_stride = 0, row_stride = 0;
 };
 
+// Device-side decompression of a staged batch (vmd_trajectory_i::load_raw + k_xtc_decode): the compressed bit streams are read
+// into pinned memory on the decode threads, cross PCIe as they are (0.4x the float bytes for water) and are decompressed by one
+// GPU thread per frame on the copy stream, i.e. under the kernels of the previous batch.  Returns 1 when the batch now sits in
+// st.d, 0 when it has to go through load_frame (a frame is not available raw, or the device reported a stream it does not
+// handle), -1 on error.
+static int fetch_stage_raw(vmd_script_eval_t* e, Stage& st, vmd_trajectory_i* traj, size_t num_atoms, size_t f0, size_t nb, size_t npad) {
+    st.raw_info.resize(nb);
+    std::vector<vmd_raw_frame_t> infos(nb);
+    size_t total = 0;
+    for (size_t b = 0; b < nb; ++b) {                      // sizes first (no payload), then one pinned block for the batch
+        vmd_frame_header_t hdr;
+        if (!traj->load_raw(traj->inst, (int64_t)(f0 + b), &hdr, &infos[b], nullptr, 0) || infos[b].codec != VMD_RAW_CODEC_XTC) return 0;
+        if (hdr.num_atoms != num_atoms) return 0;
+        st.cells[b] = hdr.unitcell;
+        vmd_xtc_frame_t& fi = st.raw_info[b];
+        fi.precision = infos[b].precision;
+        for (int k = 0; k < 3; ++k) { fi.minint[k] = infos[b].minint[k]; fi.maxint[k] = infos[b].maxint[k]; }
+        fi.smallidx = infos[b].smallidx;
+        fi.offset = total;
+        fi.nbytes = infos[b].nbytes;
+        total += ((size_t)infos[b].nbytes + 16 + 63) & ~(size_t)63;     // >= 16 readable bytes behind every stream, 64-byte aligned starts
+    }
+    if (total > st.hraw_cap) {
+        if (st.hraw) (void)hipHostFree(st.hraw);
+        st.hraw = nullptr; st.hraw_cap = 0;
+        if (hipHostMalloc((void**)&st.hraw, total, hipHostMallocDefault) != hipSuccess) { vmd_fail("hipHostMalloc(%zu bytes) failed", total); return -1; }
+        st.hraw_cap = total;
+    }
+    if (nb > st.h_raw_status_cap) {
+        if (st.h_raw_status) (void)hipHostFree(st.h_raw_status);
+        st.h_raw_status = nullptr; st.h_raw_status_cap = 0;
+        if (hipHostMalloc((void**)&st.h_raw_status, nb * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) { vmd_fail("hipHostMalloc failed"); return -1; }
+        st.h_raw_status_cap = nb;
+    }
+    const size_t nthreads = std::max<size_t>(1, std::min<size_t>(load_threads(), nb / 4));
+    std::atomic<size_t> next{0};
+    std::atomic<bool> ok{true};
+    auto work = [&]() {
+        for (;;) {
+            const size_t b = next.fetch_add(1);
+            if (b >= nb || !ok.load()) break;
+            const vmd_xtc_frame_t& fi = st.raw_info[b];
+            vmd_raw_frame_t info;
+            unsigned char* dst = st.hraw + fi.offset;
+            if (!traj->load_raw(traj->inst, (int64_t)(f0 + b), nullptr, &info, dst, (size_t)fi.nbytes) || info.nbytes != fi.nbytes) { ok = false; break; }
+            memset(dst + fi.nbytes, 0, (((size_t)fi.nbytes + 16 + 63) & ~(size_t)63) - (size_t)fi.nbytes);
+        }
+    };
+    if (nthreads == 1) work();
+    else {
+        std::vector<std::thread> pool;
+        for (size_t t = 1; t < nthreads; ++t) pool.emplace_back(work);
+        work();
+        for (auto& t : pool) t.join();
+    }
+    if (!ok.load()) return 0;                              // let load_frame produce the real error message
+    if (!st.d.ensure(nb * 3 * npad) || !st.d_raw.ensure(total) || !st.d_raw_status.ensure(nb)) return -1;
+    if (!st.d_raw_info.upload(st.raw_info.data(), nb, e->copy_stream)) return -1;
+    if (hipMemcpyAsync(st.d_raw.p, st.hraw, total, hipMemcpyHostToDevice, e->copy_stream) != hipSuccess) { vmd_fail("hipMemcpyAsync of the compressed batch failed"); return -1; }
+    if (vmd_hip_xtc_decode(e->copy_stream, st.d_raw.p, st.d_raw_info.p, (int)nb, (int)num_atoms, st.d.p, 3 * npad, npad, st.d_raw_status.p) != 0) {
+        vmd_fail("k_xtc_decode launch failed");
+        return -1;
+    }
+    if (hipMemcpyAsync(st.h_raw_status, st.d_raw_status.p, nb * sizeof(uint32_t), hipMemcpyDeviceToHost, e->copy_stream) != hipSuccess ||
+        hipStreamSynchronize(e->copy_stream) != hipSuccess) { vmd_fail("device XTC decode failed"); return -1; }
+    for (size_t b = 0; b < nb; ++b) if (st.h_raw_status[b] != 0) return 0;     // corrupt or unsupported stream: the host reader decides
+    e->frames_device_decoded += nb;
+    return 1;
+}
+
 // bring frames [f0, f0+nb) to the device (or alias them in place) through stage `st`: fills st.cells / st.h_boxes, queues
 // the copies on copy_stream and records st.ready
 static bool fetch_stage(vmd_script_eval_t* e, Stage& st, vmd_trajectory_i* traj, const vmd_device_view_t* view, size_t num_atoms,
@@ -841,6 +926,16 @@ static bool fetch_stage(vmd_script_eval_t* e, Stage& st, vmd_trajectory_i* traj,
     } else {
         const size_t npad = (num_atoms + 63) & ~(size_t)63;
         const size_t need = nb * 3 * npad;
+        int raw = 0;
+        if (g_opt.xtc_device_decode.load() && traj->load_raw) {
+            raw = fetch_stage_raw(e, st, traj, num_atoms, f0, nb, npad);
+            if (raw < 0) return false;
+        }
+        if (raw == 1) {
+            st.base = st.d.p;
+            st.frame_stride = 3 * npad;
+            st.row_stride = npad;
+        } else {
         if (need > st.hcap) {
             if (st.h) (void)hipHostFree(st.h);
             st.h = nullptr; st.hcap = 0;
@@ -887,6 +982,7 @@ static bool fetch_stage(vmd_script_eval_t* e, Stage& st, vmd_trajectory_i* traj,
         st.base = st.d.p;
         st.frame_stride = 3 * npad;
         st.row_stride = npad;
+        }
     }
     for (size_t b = 0; b < nb; ++b) {
         const vmd_unitcell_t& c = st.cells[b];
@@ -1398,6 +1494,7 @@ extern "C" vmd_devtraj_t* vmd_devtraj_create(size_t num_frames, size_t num_atoms
     t->iface.inst = t.get();
     t->iface.num_frames = dt_num_frames; t->iface.num_atoms = dt_num_atoms;
     t->iface.load_frame = dt_load_frame; t->iface.device_view = dt_device_view; t->iface.host_view = nullptr;
+    t->iface.load_raw = nullptr;
     return t.release();
 }
 extern "C" void vmd_devtraj_free(vmd_devtraj_t* t) {
@@ -1494,6 +1591,7 @@ extern "C" vmd_hosttraj_t* vmd_hosttraj_create(size_t num_frames, size_t num_ato
     t->iface.inst = t.get();
     t->iface.num_frames = ht_num_frames; t->iface.num_atoms = ht_num_atoms; t->iface.load_frame = ht_load_frame;
     t->iface.device_view = nullptr; t->iface.host_view = ht_host_view;
+    t->iface.load_raw = nullptr;
     return t.release();
 }
 extern "C" void vmd_hosttraj_free(vmd_hosttraj_t* t) { if (!t) return; if (t->h) (void)hipHostFree(t->h); delete t; }

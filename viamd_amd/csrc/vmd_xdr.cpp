@@ -517,6 +517,37 @@ bool xdr_load_frame(void* inst, int64_t idx, vmd_frame_header_t* hdr, float* x, 
     return true;
 }
 
+// The frame as stored, for the device decoder (vmd_trajectory_i::load_raw): decoder parameters in host byte order, the bit
+// stream copied verbatim.  false = not available raw (TRR, frames of <= 9 atoms stored as floats): the caller uses load_frame.
+bool xdr_load_raw(void* inst, int64_t idx, vmd_frame_header_t* hdr, vmd_raw_frame_t* info, void* dst, size_t cap) {
+    Xdr* d = (Xdr*)inst;
+    if (d->kind != KIND_XTC || idx < 0 || (size_t)idx >= d->frames.size() || !info) return false;
+    const FrameRec& r = d->frames[(size_t)idx];
+    if (!r.bytes) return false;
+    unsigned char h[100];
+    if (!read_at(d->fd, h, r.head, r.off)) return fail("XTC '%s': truncated frame", d->path);
+    memset(info, 0, sizeof(*info));
+    info->codec = VMD_RAW_CODEC_XTC;
+    info->precision = be_f32(h + 56);
+    for (int k = 0; k < 3; ++k) { info->minint[k] = (int32_t)be32(h + 60 + 4 * k); info->maxint[k] = (int32_t)be32(h + 72 + 4 * k); }
+    info->smallidx = (int32_t)be32(h + 84);
+    info->nbytes = r.bytes;
+    if (hdr) {
+        float box[9];
+        for (int k = 0; k < 9; ++k) box[k] = be_f32(h + 16 + 4 * k);
+        memset(hdr, 0, sizeof(*hdr));
+        hdr->num_atoms = d->num_atoms;
+        hdr->index = idx;
+        hdr->timestamp = r.time;
+        hdr->unitcell = cell_from_box_nm(box);
+    }
+    if (dst) {
+        if (cap < r.bytes) return fail("XTC '%s': raw frame buffer too small", d->path);
+        if (!read_at(d->fd, dst, (size_t)r.bytes, r.off + r.head)) return fail("XTC '%s': truncated frame", d->path);
+    }
+    return true;
+}
+
 // ------------------------------------------------------------------ writer
 struct Writer {
     FILE* fh = nullptr;
@@ -696,6 +727,7 @@ extern "C" vmd_xdrtraj_t* vmd_xdrtraj_open(const char* path) {
     d.iface.load_frame = xdr_load_frame;
     d.iface.device_view = nullptr;
     d.iface.host_view = nullptr;
+    d.iface.load_raw = d.kind == KIND_XTC ? xdr_load_raw : nullptr;
     return t;
 }
 

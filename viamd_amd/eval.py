@@ -269,6 +269,10 @@ class ScriptEval:
         self.lib.vmd_eval_frame_stats(self.h, C.byref(a), C.byref(b))
         return int(a.value), int(b.value)
 
+    def frames_device_decoded(self):
+        """Frames whose coordinates were decompressed on the device (load_raw + k_xtc_decode) since the last clear_data."""
+        return int(self.lib.vmd_eval_frames_device_decoded(self.h))
+
     def num_frames(self):
         return int(self.lib.vmd_eval_num_frames(self.h))
 
