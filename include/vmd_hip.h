@@ -117,10 +117,10 @@ int vmd_hip_counts_to_float(void* stream, const uint64_t* counts, size_t n, floa
 
 /* XTC coordinate blocks decompressed on the device (the compressed bytes cross PCIe, not the floats): one
  * thread per frame walks its bit stream (frames are independent, a stream is strictly sequential).
- *   raw     u8: the bit streams, frame b at raw + info[b].offset (16-byte aligned, >= 16 readable bytes behind each stream)
+ *   raw     u8: the bit streams, frame b at raw + info[b].offset (64-byte aligned, >= 32 readable bytes behind each stream)
  *   info    one record per frame, host byte order
  *   xyz     out, frame layout as above, Angstrom: fl(fl(int * fl(1/precision)) * 10) like the host reader (vmd_xdr.cpp)
- *   status  u32[B] out: 0 ok, 1 corrupt stream, 2 not supported on the device (a packed triple wider than 64 bits) */
+ *   status  u32[B] out: 0 ok, 1 corrupt stream, 2 not supported on the device (a packed triple whose value needs more than 64 bits) */
 typedef struct vmd_xtc_frame_t {
     float    precision;
     int32_t  minint[3], maxint[3];

@@ -849,7 +849,7 @@ static int fetch_stage_raw(vmd_script_eval_t* e, Stage& st, vmd_trajectory_i* tr
         fi.smallidx = infos[b].smallidx;
         fi.offset = total;
         fi.nbytes = infos[b].nbytes;
-        total += ((size_t)infos[b].nbytes + 16 + 63) & ~(size_t)63;     // >= 16 readable bytes behind every stream, 64-byte aligned starts
+        total += ((size_t)infos[b].nbytes + 32 + 63) & ~(size_t)63;     // >= 32 readable bytes behind every stream, 64-byte aligned starts
     }
     if (total > st.hraw_cap) {
         if (st.hraw) (void)hipHostFree(st.hraw);
@@ -874,7 +874,7 @@ static int fetch_stage_raw(vmd_script_eval_t* e, Stage& st, vmd_trajectory_i* tr
             vmd_raw_frame_t info;
             unsigned char* dst = st.hraw + fi.offset;
             if (!traj->load_raw(traj->inst, (int64_t)(f0 + b), nullptr, &info, dst, (size_t)fi.nbytes) || info.nbytes != fi.nbytes) { ok = false; break; }
-            memset(dst + fi.nbytes, 0, (((size_t)fi.nbytes + 16 + 63) & ~(size_t)63) - (size_t)fi.nbytes);
+            memset(dst + fi.nbytes, 0, (((size_t)fi.nbytes + 32 + 63) & ~(size_t)63) - (size_t)fi.nbytes);
         }
     };
     if (nthreads == 1) work();

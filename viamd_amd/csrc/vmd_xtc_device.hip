@@ -13,8 +13,9 @@
 //
 // The arithmetic is the host reader's (vmd_xdr.cpp: xtc_decode), so both produce the same floats: a packed triple is rebuilt as
 // one integer from its little-endian wire bytes and split by two independent reciprocal multiplications in fp64 (exact below
-// 2^52 after a +-1 fix-up; MI355X runs fp64 at full VALU rate), 53..64-bit numbers by integer division, wider ones
-// (three ranges just below 2^24 each: never seen in practice) are reported back (status 2) and the batch falls back to the host.
+// 2^52 after a +-1 fix-up; MI355X runs fp64 at full VALU rate), 53..64-bit numbers by integer division; a number that does not
+// fit 64 bits (three ranges just below 2^24 each: never seen in practice) is reported back (status 2) and the batch falls back
+// to the host reader, which carries 128-bit arithmetic for it.
 #include <hip/hip_runtime.h>
 
 #include <stdint.h>
@@ -35,19 +36,35 @@ __device__ const int kXtcMagic[XTC_LASTIDX] = {
     832255, 1048576, 1321122, 1664510, 2097152, 2642245, 3329021,
     4194304, 5284491, 6658042, 8388607, 10568983, 13316085, 16777216};
 
+// MSB-first bit reader over 8-byte words held in registers: `hi` is the big-endian word that contains the next bit, `lo` the one
+// behind it, `nxt` the one after that - already in flight since the previous word boundary, so the stream's memory latency is
+// hidden behind ~two atoms of arithmetic and a field costs a handful of ALU instructions, not two dependent loads.
 struct Bits {
-    const unsigned char* base;   // 16-byte aligned, >= 16 readable bytes behind the stream
+    const uint64_t* words;       // 64-byte aligned stream start, >= 32 readable bytes behind the stream
     uint64_t pos;                // next bit
+    uint64_t hi, lo, nxt;
+    uint64_t nwords;             // readable words: a damaged stream keeps asking for more, the prefetch index is clamped
 };
-
-// `bits` in [1, 56], MSB first: two aligned 8-byte loads cover any such field
+__device__ __forceinline__ void xtc_open(Bits& b, const unsigned char* base, uint64_t nbytes) {
+    b.words = (const uint64_t*)base;
+    b.nwords = (nbytes + 32ull) >> 3;
+    b.pos = 0;
+    b.hi = __builtin_bswap64(b.words[0]);
+    b.lo = __builtin_bswap64(b.words[1]);
+    b.nxt = __builtin_bswap64(b.words[2]);
+}
+// `bits` in [1, 56]
 __device__ __forceinline__ uint64_t xtc_get(Bits& b, int bits) {
-    const uint64_t byte = b.pos >> 3;
-    const uint64_t* q = (const uint64_t*)(b.base + (byte & ~7ull));
-    const uint64_t w0 = __builtin_bswap64(q[0]), w1 = __builtin_bswap64(q[1]);
-    const unsigned sh = (unsigned)(byte & 7ull) * 8u + (unsigned)(b.pos & 7ull);       // 0 .. 63
-    const uint64_t w = sh ? ((w0 << sh) | (w1 >> (64u - sh))) : w0;
+    const unsigned sh = (unsigned)(b.pos & 63ull);
+    const uint64_t w = sh ? ((b.hi << sh) | (b.lo >> (64u - sh))) : b.hi;
+    const uint64_t word = b.pos >> 6;
     b.pos += (uint64_t)bits;
+    if ((b.pos >> 6) != word) {                      // at most one boundary per field (bits < 64)
+        b.hi = b.lo;
+        b.lo = b.nxt;
+        const uint64_t k = word + 3;
+        b.nxt = __builtin_bswap64(b.words[k < b.nwords ? k : b.nwords - 1]);
+    }
     return w >> (64 - bits);
 }
 
@@ -72,18 +89,22 @@ __device__ __forceinline__ uint64_t xtc_div(uint64_t w, uint64_t d, double inv) 
     return q;
 }
 
-// one packed triple of `bits` <= 64 bits: little-endian bytes on the wire, the partial top byte last
-__device__ __forceinline__ void xtc_triple(Bits& b, int bits, const Radix& rx, int out[3]) {
+// one packed triple of `bits` bits: little-endian bytes on the wire, the partial top byte last.  Numbers up to 64 bits are
+// handled here; false = the number has bits set above 2^64 (possible for bits > 64 only): the caller reports status 2.
+__device__ __forceinline__ bool xtc_triple(Bits& b, int bits, const Radix& rx, int out[3]) {
     const int q = (bits - 1) >> 3, r = bits - 8 * q;            // q full bytes, then r in [1, 8] bits
     uint64_t w;
+    bool ok = true;
     if (bits <= 56) {
         const uint64_t raw = xtc_get(b, bits);
         const uint64_t top = raw >> r, low = raw & ((1ull << r) - 1ull);
         w = (q ? (__builtin_bswap64(top) >> (64 - 8 * q)) : 0ull) | (low << (8 * q));
     } else {
         w = 0;
-        for (int j = 0; j < q; ++j) w |= xtc_get(b, 8) << (8 * j);
-        w |= xtc_get(b, r) << (8 * q);
+        for (int j = 0; j < q && j < 8; ++j) w |= xtc_get(b, 8) << (8 * j);
+        const uint64_t last = xtc_get(b, r);
+        if (q < 8) w |= last << (8 * q);
+        else ok = last == 0;                                     // byte 8 of the number
     }
     uint64_t qa, qb;
     if (bits <= 52) {
@@ -96,6 +117,7 @@ __device__ __forceinline__ void xtc_triple(Bits& b, int bits, const Radix& rx, i
     out[2] = (int)(w - qa * rx.s2);
     out[1] = (int)(qa - qb * rx.s1);
     out[0] = (int)qb;
+    return ok;
 }
 
 __global__ __launch_bounds__(64) void k_xtc_decode(const unsigned char* __restrict__ raw, const vmd_xtc_frame_t* __restrict__ info,
@@ -131,7 +153,6 @@ __global__ __launch_bounds__(64) void k_xtc_decode(const unsigned char* __restri
             const uint64_t lo = (p01 & 0xffffffffull) * sizeint[2], hi = (p01 >> 32) * sizeint[2];
             const uint64_t top = hi + (lo >> 32);                                      // product >> 32
             bitsize = top ? 32 + xtc_bit_length(top) : xtc_bit_length(lo);
-            if (bitsize > 64) { st = 2; break; }
         }
         int smaller = kXtcMagic[smallidx - 1 > XTC_FIRSTIDX ? smallidx - 1 : XTC_FIRSTIDX] / 2;
         int smallnum = kXtcMagic[smallidx] / 2;
@@ -140,8 +161,7 @@ __global__ __launch_bounds__(64) void k_xtc_decode(const unsigned char* __restri
         xtc_radix(small, (uint32_t)kXtcMagic[smallidx], (uint32_t)kXtcMagic[smallidx]);
 
         Bits br;
-        br.base = raw + fi.offset;
-        br.pos = 0;
+        xtc_open(br, raw + fi.offset, fi.nbytes);
         const uint64_t nbits = 8ull * fi.nbytes;
         int i = 0, run = 0;
         while (i < natoms) {
@@ -152,7 +172,7 @@ __global__ __launch_bounds__(64) void k_xtc_decode(const unsigned char* __restri
                     cur[k] = (int)(uint32_t)(nb > 24 ? ((xtc_get(br, nb - 24) << 24) | xtc_get(br, 24)) : xtc_get(br, nb));
                 }
             } else {
-                xtc_triple(br, bitsize, large, cur);
+                if (!xtc_triple(br, bitsize, large, cur)) { st = 2; break; }
             }
             for (int k = 0; k < 3; ++k) { cur[k] += fi.minint[k]; prev[k] = cur[k]; }
             int is_smaller = 0;
@@ -166,7 +186,7 @@ __global__ __launch_bounds__(64) void k_xtc_decode(const unsigned char* __restri
                 if (i + 1 + run / 3 > natoms) { st = 1; break; }
                 for (int k = 0; k < run; k += 3) {
                     int d[3], nxt[3];
-                    xtc_triple(br, smallidx, small, d);
+                    if (!xtc_triple(br, smallidx, small, d)) st = 2;
                     for (int c = 0; c < 3; ++c) nxt[c] = d[c] + prev[c] - smallnum;
                     x[i] = ((float)nxt[0] * invp) * 10.0f;
                     y[i] = ((float)nxt[1] * invp) * 10.0f;
@@ -180,6 +200,7 @@ __global__ __launch_bounds__(64) void k_xtc_decode(const unsigned char* __restri
                     }
                     for (int c = 0; c < 3; ++c) prev[c] = nxt[c];
                 }
+                if (st) break;
             } else {
                 x[i] = ((float)cur[0] * invp) * 10.0f;
                 y[i] = ((float)cur[1] * invp) * 10.0f;
