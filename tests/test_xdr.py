@@ -318,7 +318,7 @@ def test_device_xtc_decoder_matches_the_host_reader(tmp_path, emu_lib):
     xyz = systems["water"]
     blob = xtc_ref.frame_bytes(xyz, np.diag([30.0, 30.0, 30.0]), 0, 0.0, 1000.0)
     rejected = 0
-    for trial in range(60):
+    for trial in range(25):
         b = bytearray(blob)
         for _ in range(rng.integers(1, 5)):
             b[rng.integers(92, len(b))] = rng.integers(0, 256)
