@@ -41,7 +41,7 @@ def build_emu():
     VIAMD_EMU_SANITIZE=address,undefined (or thread) builds an instrumented copy next to it: run the suite under it with
     LD_PRELOAD=$(g++ -print-file-name=libasan.so) (scripts/sanitize_emu.sh)."""
     san = os.environ.get("VIAMD_EMU_SANITIZE", "")
-    out = EMU_LIB if not san else EMU_LIB.replace(".so", "_" + san.replace(",", "_") + ".so")
+    out = EMU_LIB if not san else os.path.join("/tmp", "libviamd_emu_" + san.replace(",", "_") + ".so")   # never into the tree: in-tree .so files travel to the GPU box
     if os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(s) for s in EMU_DEPS):
         return out
     cmd = ["g++", "-O2", "-g", "-shared", "-fPIC", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-mavx2", "-mfma",
