@@ -13,6 +13,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import conftest          # noqa: E402
 import xtc_ref           # noqa: E402
+import test_xdr          # noqa: E402
 import viamd_amd as V    # noqa: E402
 
 
@@ -41,6 +42,7 @@ def main():
     lib = V.VmdLib(conftest.build_emu())
     rng = np.random.default_rng(seed)
     tmp = tempfile.mkdtemp()
+    ndev = 0
     for t in range(trials):
         xyz = random_system(rng)
         precision = float(rng.choice([10.0, 100.0, 1000.0, 1000.0, 5000.0]))
@@ -57,7 +59,13 @@ def main():
         want = ((ints.astype(np.float32) * (np.float32(1) / np.float32(precision))) * np.float32(10)).T
         assert np.array_equal(got, want), f"trial {t}: native decode differs (seed {seed})"
         assert np.array_equal(xtc_ref.parse_frames(nat)[0]["ints"], ints), f"trial {t}: python decode differs"
-    print(f"{trials} random XTC frames: native and byte-wise implementations agree (seed {seed})")
+        dev, status = test_xdr._device_decode(lib, nat, xyz.shape[1])          # k_xtc_decode on the SIMT emulator
+        assert status[0] in (0, 2), f"trial {t}: device decoder rejected a valid stream (seed {seed})"
+        if status[0] == 0:
+            assert np.array_equal(dev[0], want), f"trial {t}: device decode differs (seed {seed})"
+            ndev += 1
+    print(f"{trials} random XTC frames: native and byte-wise implementations agree, device decoder agrees on {ndev} "
+          f"(the others need more than 64 bits per number: status 2) (seed {seed})")
 
 
 if __name__ == "__main__":
