@@ -936,52 +936,52 @@ static bool fetch_stage(vmd_script_eval_t* e, Stage& st, vmd_trajectory_i* traj,
             st.frame_stride = 3 * npad;
             st.row_stride = npad;
         } else {
-        if (need > st.hcap) {
-            if (st.h) (void)hipHostFree(st.h);
-            st.h = nullptr; st.hcap = 0;
-            HIP_OK(hipHostMalloc((void**)&st.h, need * sizeof(float), hipHostMallocDefault));
-            st.hcap = need;
-        }
-        if (!st.d.ensure(need)) return false;
-        // md_trajectory_load_frame is called from all of VIAMD's pool threads at once (src/main.cpp:995-996 inside the
-        // enkiTS range tasks), so the decoder behind it is re-entrant: decode the batch on a few threads
-        const size_t nthreads = std::max<size_t>(1, std::min<size_t>(load_threads(), nb / 4));
-        std::atomic<size_t> next{0};
-        std::atomic<bool> ok{true};
-        std::mutex err_mtx;
-        std::string err;
-        auto work = [&]() {
-            for (;;) {
-                const size_t b = next.fetch_add(1);
-                if (b >= nb || !ok.load()) break;
-                vmd_frame_header_t hdr;
-                memset(&hdr, 0, sizeof(hdr));
-                float* x = st.h + b * 3 * npad;
-                if (!traj->load_frame(traj->inst, (int64_t)(f0 + b), &hdr, x, x + npad, x + 2 * npad)) {
-                    std::lock_guard<std::mutex> l(err_mtx);
-                    if (ok.exchange(false)) {
-                        char buf[96];
-                        snprintf(buf, sizeof(buf), "trajectory load_frame(%zu) failed", f0 + b);
-                        err = buf;
-                        if (!g_last_error.empty()) err += ": " + g_last_error;     // the decoder's own message (this thread's)
-                    }
-                    break;
-                }
-                st.cells[b] = hdr.unitcell;
+            if (need > st.hcap) {
+                if (st.h) (void)hipHostFree(st.h);
+                st.h = nullptr; st.hcap = 0;
+                HIP_OK(hipHostMalloc((void**)&st.h, need * sizeof(float), hipHostMallocDefault));
+                st.hcap = need;
             }
-        };
-        if (nthreads == 1) work();
-        else {
-            std::vector<std::thread> pool;
-            for (size_t t = 1; t < nthreads; ++t) pool.emplace_back(work);
-            work();
-            for (auto& t : pool) t.join();
-        }
-        if (!ok.load()) return vmd_fail("%s", err.c_str());
-        HIP_OK(hipMemcpyAsync(st.d.p, st.h, need * sizeof(float), hipMemcpyHostToDevice, e->copy_stream));
-        st.base = st.d.p;
-        st.frame_stride = 3 * npad;
-        st.row_stride = npad;
+            if (!st.d.ensure(need)) return false;
+            // md_trajectory_load_frame is called from all of VIAMD's pool threads at once (src/main.cpp:995-996 inside the
+            // enkiTS range tasks), so the decoder behind it is re-entrant: decode the batch on a few threads
+            const size_t nthreads = std::max<size_t>(1, std::min<size_t>(load_threads(), nb / 4));
+            std::atomic<size_t> next{0};
+            std::atomic<bool> ok{true};
+            std::mutex err_mtx;
+            std::string err;
+            auto work = [&]() {
+                for (;;) {
+                    const size_t b = next.fetch_add(1);
+                    if (b >= nb || !ok.load()) break;
+                    vmd_frame_header_t hdr;
+                    memset(&hdr, 0, sizeof(hdr));
+                    float* x = st.h + b * 3 * npad;
+                    if (!traj->load_frame(traj->inst, (int64_t)(f0 + b), &hdr, x, x + npad, x + 2 * npad)) {
+                        std::lock_guard<std::mutex> l(err_mtx);
+                        if (ok.exchange(false)) {
+                            char buf[96];
+                            snprintf(buf, sizeof(buf), "trajectory load_frame(%zu) failed", f0 + b);
+                            err = buf;
+                            if (!g_last_error.empty()) err += ": " + g_last_error;     // the decoder's own message (this thread's)
+                        }
+                        break;
+                    }
+                    st.cells[b] = hdr.unitcell;
+                }
+            };
+            if (nthreads == 1) work();
+            else {
+                std::vector<std::thread> pool;
+                for (size_t t = 1; t < nthreads; ++t) pool.emplace_back(work);
+                work();
+                for (auto& t : pool) t.join();
+            }
+            if (!ok.load()) return vmd_fail("%s", err.c_str());
+            HIP_OK(hipMemcpyAsync(st.d.p, st.h, need * sizeof(float), hipMemcpyHostToDevice, e->copy_stream));
+            st.base = st.d.p;
+            st.frame_stride = 3 * npad;
+            st.row_stride = npad;
         }
     }
     for (size_t b = 0; b < nb; ++b) {
