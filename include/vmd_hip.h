@@ -129,6 +129,12 @@ typedef struct vmd_xtc_frame_t {
 } vmd_xtc_frame_t;
 int vmd_hip_xtc_decode(void* stream, const unsigned char* raw, const vmd_xtc_frame_t* info, int B, int natoms,
                        float* xyz, size_t frame_stride, size_t row_stride, uint32_t* status);
+/* the same result in two passes: k_xtc_index (one thread per frame) follows only flags and field widths and drops a checkpoint
+ * at the first atom-group boundary at or after every `chunk` atoms (>= 64), k_xtc_chunks decodes all chunks of all frames in
+ * parallel (one thread per chunk).  scratch: vmd_hip_xtc_scratch_bytes(B, natoms, chunk) device bytes, 8-byte aligned. */
+size_t vmd_hip_xtc_scratch_bytes(int B, int natoms, int chunk);
+int vmd_hip_xtc_decode_chunked(void* stream, const unsigned char* raw, const vmd_xtc_frame_t* info, int B, int natoms,
+                               float* xyz, size_t frame_stride, size_t row_stride, uint32_t* status, int chunk, void* scratch);
 
 /* synthetic water box (oracle S9 twin): fills frames [frame0, frame0+B) of a batch laid out as above */
 int vmd_hip_synth_frames(void* stream, float* xyz, size_t frame_stride, size_t row_stride, int B, uint32_t frame0,

@@ -33,6 +33,10 @@ for n in 8 32 64; do
 done
 echo "== bench c2 from an XTC file, frames decompressed on the device (k_xtc_decode): compressed bytes cross PCIe"
 timeout 600 python bench.py --traj xtc --no-cpu-baseline --steps 5 --opt xtc_device_decode=1 > $OUT/bench_c2_xtc_device.json 2>> $OUT/bench_c2.err; cat $OUT/bench_c2_xtc_device.json
+for ch in 128 256 1024; do
+  timeout 600 python bench.py --traj xtc --no-cpu-baseline --steps 5 --opt xtc_device_decode=2 --opt xtc_chunk=$ch > $OUT/bench_c2_xtc_device2_$ch.json 2>> $OUT/bench_c2.err
+  python -c "import json;d=json.load(open('$OUT/bench_c2_xtc_device2_$ch.json'));print('xtc two-pass device decode, chunk $ch:', round(d['value']), 'frames/s')"
+done
 echo "== rocprofv3 --kernel-trace --stats of the default bench command"
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_c2 -o c2 -- python $R/bench.py --no-cpu-baseline > $OUT/prof_c2.log 2>&1; echo "rocprof rc=$?"

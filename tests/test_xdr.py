@@ -254,7 +254,7 @@ def test_xtc_trajectory_through_the_evaluator_on_emulator(tmp_path, emu_lib, ora
     assert res[0].sum() > 0
 
 
-def _device_decode(lib, blob, natoms):
+def _device_decode(lib, blob, natoms, chunk=0):
     """Run vmd_hip_xtc_decode (emulator build: "device" memory is host memory) on every frame of an XTC byte string."""
     import ctypes as C
     from viamd_amd import _lib as L
@@ -286,14 +286,21 @@ def _device_decode(lib, blob, natoms):
     npad = (natoms + 63) & ~63
     out = np.full((B, 3, npad), np.nan, np.float32)
     status = np.full(B, 99, np.uint32)
-    rc = lib.vmd_hip_xtc_decode(None, store.ctypes.data + base, C.addressof(arr), B, natoms, out.ctypes.data, 3 * npad, npad,
-                                status.ctypes.data)
+    if chunk:                  # two passes: index (one thread per frame) + chunks (one thread per chunk)
+        scratch = np.zeros(lib.vmd_hip_xtc_scratch_bytes(B, natoms, chunk) // 8 + 1, np.uint64)
+        rc = lib.vmd_hip_xtc_decode_chunked(None, store.ctypes.data + base, C.addressof(arr), B, natoms, out.ctypes.data, 3 * npad,
+                                            npad, status.ctypes.data, chunk, scratch.ctypes.data)
+    else:
+        rc = lib.vmd_hip_xtc_decode(None, store.ctypes.data + base, C.addressof(arr), B, natoms, out.ctypes.data, 3 * npad, npad,
+                                    status.ctypes.data)
     assert rc == 0
     return out[:, :, :natoms], status
 
 
-def test_device_xtc_decoder_matches_the_host_reader(tmp_path, emu_lib):
-    """k_xtc_decode (one GPU thread per frame; here on the SIMT emulator) against the host reader on every fixture: the same
+@pytest.mark.parametrize("chunk", [0, 64, 300])
+def test_device_xtc_decoder_matches_the_host_reader(tmp_path, emu_lib, chunk):
+    """k_xtc_decode (one GPU thread per frame) and the two-pass k_xtc_index + k_xtc_chunks (one thread per chunk of `chunk` atoms;
+    both here on the SIMT emulator) against the host reader on every fixture: the same
     floats bit for bit; a 68-bit packed triple is reported as unsupported (status 2), a damaged stream as corrupt (status 1) or
     decoded without leaving the frame's buffers."""
     systems = _systems()
@@ -303,7 +310,7 @@ def test_device_xtc_decoder_matches_the_host_reader(tmp_path, emu_lib):
         F = 3
         frames = [xyz + np.float32(0.37 * f) for f in range(F)]
         blob = b"".join(xtc_ref.frame_bytes(frames[f], np.diag([30.0, 30.0, 30.0]), f, 0.0, 1000.0) for f in range(F))
-        got, status = _device_decode(emu_lib, blob, xyz.shape[1])
+        got, status = _device_decode(emu_lib, blob, xyz.shape[1], chunk)
         if name == "huge":
             assert (status == 2).all()
             continue
@@ -322,7 +329,7 @@ def test_device_xtc_decoder_matches_the_host_reader(tmp_path, emu_lib):
         b = bytearray(blob)
         for _ in range(rng.integers(1, 5)):
             b[rng.integers(92, len(b))] = rng.integers(0, 256)
-        _, status = _device_decode(emu_lib, bytes(b), xyz.shape[1])
+        _, status = _device_decode(emu_lib, bytes(b), xyz.shape[1], chunk)
         rejected += int(status[0] != 0)
     assert rejected > 0
 
@@ -345,8 +352,9 @@ def test_xtc_batches_decoded_on_the_device_through_the_evaluator(tmp_path, emu_l
     old_b = emu_lib.vmd_set_option(b"batch_frames", 4)
     res = {}
     try:
-        for mode in (0, 1):
+        for mode in (0, 1, 2):
             old = emu_lib.vmd_set_option(b"xtc_device_decode", mode)
+            old_c = emu_lib.vmd_set_option(b"xtc_chunk", 64)
             try:
                 ev = V.ScriptEval(F, ir)
                 assert ev.frame_range(sysm, V.XdrTrajectory(p, lib=emu_lib), 0, F)
@@ -358,7 +366,9 @@ def test_xtc_batches_decoded_on_the_device_through_the_evaluator(tmp_path, emu_l
                     assert ev2.frames_device_decoded() == 0 and ev2.property_data("g").counts.sum() > 0
             finally:
                 emu_lib.vmd_set_option(b"xtc_device_decode", old)
+                emu_lib.vmd_set_option(b"xtc_chunk", old_c)
     finally:
         emu_lib.vmd_set_option(b"batch_frames", old_b)
     np.testing.assert_array_equal(res[1], res[0])
+    np.testing.assert_array_equal(res[2], res[0])
     assert res[0].sum() > 0

@@ -32,17 +32,21 @@ def _xdr_through_the_evaluator(lib, oracle, tmp_path, box, F, N, device_check):
         np.testing.assert_array_equal(got, counts, err_msg=fmt)            # bit-exact on the coordinates the file holds
         res[fmt] = got
         if fmt == "xtc":
-            # the same file with the batch decompressed on the device (k_xtc_decode): identical integers, every frame counted
-            old_d = lib.vmd_set_option(b"xtc_device_decode", 1)
-            old = lib.vmd_set_option(b"batch_frames", max(4, F // 3))
-            try:
-                ev = V.ScriptEval(F, ir)
-                assert ev.frame_range(sysm, V.XdrTrajectory(p, lib=lib), 0, F)
-            finally:
-                lib.vmd_set_option(b"batch_frames", old)
-                lib.vmd_set_option(b"xtc_device_decode", old_d)
-            assert ev.frames_device_decoded() == F
-            np.testing.assert_array_equal(ev.property_data("g").counts, counts, err_msg="xtc, device decode")
+            # the same file with the batch decompressed on the device: one thread per frame (1), index pass + one thread per
+            # chunk (2); identical integers, every frame counted as device-decoded
+            for mode in (1, 2):
+                old_d = lib.vmd_set_option(b"xtc_device_decode", mode)
+                old_c = lib.vmd_set_option(b"xtc_chunk", 256)
+                old = lib.vmd_set_option(b"batch_frames", max(4, F // 3))
+                try:
+                    ev = V.ScriptEval(F, ir)
+                    assert ev.frame_range(sysm, V.XdrTrajectory(p, lib=lib), 0, F)
+                finally:
+                    lib.vmd_set_option(b"batch_frames", old)
+                    lib.vmd_set_option(b"xtc_chunk", old_c)
+                    lib.vmd_set_option(b"xtc_device_decode", old_d)
+                assert ev.frames_device_decoded() == F
+                np.testing.assert_array_equal(ev.property_data("g").counts, counts, err_msg=f"xtc, device decode variant {mode}")
     assert res["xtc"].sum() > 0 and abs(int(res["xtc"].sum()) - int(res["trr"].sum())) < 0.01 * res["trr"].sum()
 
 

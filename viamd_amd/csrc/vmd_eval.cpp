@@ -77,7 +77,9 @@ struct Options {
     std::atomic<int> load_threads{0};    // host threads decoding one staged batch through load_frame; 0 = auto (see load_threads())
     std::atomic<int> nxf_divisor{8};     // fine x cell = rmax / nxf_divisor
     std::atomic<int> cells_aos{1};       // sort through 16-byte records + repack
-    std::atomic<int> xtc_device_decode{0};   // 1: frames offered raw (load_raw) are decompressed on the device (k_xtc_decode)
+    std::atomic<int> xtc_device_decode{0};   // frames offered raw (load_raw) are decompressed on the device: 1 = one thread per
+                                             // frame (k_xtc_decode), 2 = index pass + one thread per chunk (k_xtc_index / k_xtc_chunks)
+    std::atomic<int> xtc_chunk{256};         // atoms per chunk of variant 2
     std::atomic<int> sdf_dense{0};       // dense-target SDF scatter (stream whole frames, select by tag): measured slower, off
 };
 static Options g_opt;
@@ -101,6 +103,7 @@ extern "C" int vmd_set_option(const char* key, int value) {
     else if (!strcmp(key, "cells_aos")) o = &g_opt.cells_aos;
     else if (!strcmp(key, "sdf_dense")) o = &g_opt.sdf_dense;
     else if (!strcmp(key, "xtc_device_decode")) o = &g_opt.xtc_device_decode;
+    else if (!strcmp(key, "xtc_chunk")) o = &g_opt.xtc_chunk;
     else if (!strcmp(key, "cells_fused")) return vmd_hip_set_cells_fused(value);
     else if (!strcmp(key, "cells_split")) return vmd_hip_set_cells_split(value);
     else if (!strcmp(key, "rdf_blocks")) return vmd_hip_set_rdf_blocks(value);
@@ -415,6 +418,7 @@ struct vmd_script_eval_t {
         std::vector<vmd_xtc_frame_t> raw_info;
         DevBuf<vmd_xtc_frame_t> d_raw_info;
         DevBuf<uint32_t> d_raw_status;
+        DevBuf<uint64_t> d_raw_scratch;          // checkpoints of the two-pass decoder
         uint32_t* h_raw_status = nullptr; size_t h_raw_status_cap = 0;
         DevBuf<float> d_boxes;
         std::vector<float> h_boxes;              // [nb][6]: L, 1/L
@@ -888,8 +892,17 @@ static int fetch_stage_raw(vmd_script_eval_t* e, Stage& st, vmd_trajectory_i* tr
     if (!st.d.ensure(nb * 3 * npad) || !st.d_raw.ensure(total) || !st.d_raw_status.ensure(nb)) return -1;
     if (!st.d_raw_info.upload(st.raw_info.data(), nb, e->copy_stream)) return -1;
     if (hipMemcpyAsync(st.d_raw.p, st.hraw, total, hipMemcpyHostToDevice, e->copy_stream) != hipSuccess) { vmd_fail("hipMemcpyAsync of the compressed batch failed"); return -1; }
-    if (vmd_hip_xtc_decode(e->copy_stream, st.d_raw.p, st.d_raw_info.p, (int)nb, (int)num_atoms, st.d.p, 3 * npad, npad, st.d_raw_status.p) != 0) {
-        vmd_fail("k_xtc_decode launch failed");
+    int rc;
+    if (g_opt.xtc_device_decode.load() >= 2) {
+        const int chunk = std::max(64, g_opt.xtc_chunk.load());
+        if (!st.d_raw_scratch.ensure((vmd_hip_xtc_scratch_bytes((int)nb, (int)num_atoms, chunk) + 7) / 8)) return -1;
+        rc = vmd_hip_xtc_decode_chunked(e->copy_stream, st.d_raw.p, st.d_raw_info.p, (int)nb, (int)num_atoms, st.d.p, 3 * npad, npad,
+                                        st.d_raw_status.p, chunk, st.d_raw_scratch.p);
+    } else {
+        rc = vmd_hip_xtc_decode(e->copy_stream, st.d_raw.p, st.d_raw_info.p, (int)nb, (int)num_atoms, st.d.p, 3 * npad, npad, st.d_raw_status.p);
+    }
+    if (rc != 0) {
+        vmd_fail("XTC decode kernel launch failed");
         return -1;
     }
     if (hipMemcpyAsync(st.h_raw_status, st.d_raw_status.p, nb * sizeof(uint32_t), hipMemcpyDeviceToHost, e->copy_stream) != hipSuccess ||

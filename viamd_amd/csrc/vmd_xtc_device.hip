@@ -45,13 +45,14 @@ struct Bits {
     uint64_t hi, lo, nxt;
     uint64_t nwords;             // readable words: a damaged stream keeps asking for more, the prefetch index is clamped
 };
-__device__ __forceinline__ void xtc_open(Bits& b, const unsigned char* base, uint64_t nbytes) {
+__device__ __forceinline__ void xtc_open(Bits& b, const unsigned char* base, uint64_t nbytes, uint64_t pos) {
     b.words = (const uint64_t*)base;
     b.nwords = (nbytes + 32ull) >> 3;
-    b.pos = 0;
-    b.hi = __builtin_bswap64(b.words[0]);
-    b.lo = __builtin_bswap64(b.words[1]);
-    b.nxt = __builtin_bswap64(b.words[2]);
+    b.pos = pos;
+    const uint64_t w = pos >> 6;
+    b.hi = __builtin_bswap64(b.words[w < b.nwords ? w : b.nwords - 1]);
+    b.lo = __builtin_bswap64(b.words[w + 1 < b.nwords ? w + 1 : b.nwords - 1]);
+    b.nxt = __builtin_bswap64(b.words[w + 2 < b.nwords ? w + 2 : b.nwords - 1]);
 }
 // `bits` in [1, 56]
 __device__ __forceinline__ uint64_t xtc_get(Bits& b, int bits) {
@@ -120,6 +121,109 @@ __device__ __forceinline__ bool xtc_triple(Bits& b, int bits, const Radix& rx, i
     return ok;
 }
 
+// what is fixed for a whole frame
+struct FrameSetup {
+    float invp;
+    uint32_t sizeint[3];
+    int bitsizeint[3], bitsize;          // bitsize == 0: three separate fields
+    Radix large;
+};
+// 0 ok, 1 corrupt header
+__device__ __forceinline__ uint32_t xtc_setup(const vmd_xtc_frame_t& fi, FrameSetup& fs) {
+    if (!(fi.precision > 0.0f)) return 1;
+    fs.invp = 1.0f / fi.precision;
+    if (fi.smallidx < XTC_FIRSTIDX || fi.smallidx >= XTC_LASTIDX) return 1;
+    bool bad = false;
+    for (int k = 0; k < 3; ++k) {
+        const int64_t s = (int64_t)fi.maxint[k] - (int64_t)fi.minint[k] + 1;
+        if (s <= 0 || s > 0xffffffffll) bad = true;
+        fs.sizeint[k] = (uint32_t)s;
+    }
+    if (bad) return 1;
+    fs.bitsizeint[0] = fs.bitsizeint[1] = fs.bitsizeint[2] = 0;
+    if ((fs.sizeint[0] | fs.sizeint[1] | fs.sizeint[2]) > 0xffffffu) {
+        for (int k = 0; k < 3; ++k) fs.bitsizeint[k] = xtc_bit_length(fs.sizeint[k]);
+        fs.bitsize = 0;
+    } else {
+        // bit length of the product of the three ranges (each < 2^24): 128-bit product through two 64-bit halves
+        const uint64_t p01 = (uint64_t)fs.sizeint[0] * fs.sizeint[1];                  // < 2^48
+        const uint64_t lo = (p01 & 0xffffffffull) * fs.sizeint[2], hi = (p01 >> 32) * fs.sizeint[2];
+        const uint64_t top = hi + (lo >> 32);                                          // product >> 32
+        fs.bitsize = top ? 32 + xtc_bit_length(top) : xtc_bit_length(lo);
+    }
+    xtc_radix(fs.large, fs.sizeint[1], fs.sizeint[2]);
+    return 0;
+}
+
+// Decode the atom groups that start at bit `pos` with atom `i`, state (smallidx, run), up to atom `end_i` (a group boundary or
+// natoms).  The decoder state at a group boundary is exactly (pos, i, smallidx, run): smallnum is magic[smallidx] / 2 and the
+// "smaller" value magic[smallidx - 1] / 2 at all times.  Returns the status.
+__device__ __forceinline__ uint32_t xtc_decode_range(const unsigned char* stream, const vmd_xtc_frame_t& fi, const FrameSetup& fs,
+                                                     int natoms, uint64_t pos, int i, int smallidx, int run, int end_i,
+                                                     float* __restrict__ x, float* __restrict__ y, float* __restrict__ z) {
+    const float invp = fs.invp;
+    int smallnum = kXtcMagic[smallidx] / 2;
+    Radix small;
+    xtc_radix(small, (uint32_t)kXtcMagic[smallidx], (uint32_t)kXtcMagic[smallidx]);
+    Bits br;
+    xtc_open(br, stream, fi.nbytes, pos);
+    const uint64_t nbits = 8ull * fi.nbytes;
+    uint32_t st = 0;
+    while (i < end_i) {
+        int cur[3], prev[3];
+        if (fs.bitsize == 0) {
+            for (int k = 0; k < 3; ++k) {
+                const int nb = fs.bitsizeint[k];
+                cur[k] = (int)(uint32_t)(nb > 24 ? ((xtc_get(br, nb - 24) << 24) | xtc_get(br, 24)) : xtc_get(br, nb));
+            }
+        } else {
+            if (!xtc_triple(br, fs.bitsize, fs.large, cur)) { st = 2; break; }
+        }
+        for (int k = 0; k < 3; ++k) { cur[k] += fi.minint[k]; prev[k] = cur[k]; }
+        int is_smaller = 0;
+        if (xtc_get(br, 1)) {
+            run = (int)xtc_get(br, 5);
+            is_smaller = run % 3;
+            run -= is_smaller;
+            is_smaller--;
+        }
+        if (run > 0) {
+            if (i + 1 + run / 3 > natoms) { st = 1; break; }
+            for (int k = 0; k < run; k += 3) {
+                int d[3], nxt[3];
+                if (!xtc_triple(br, smallidx, small, d)) st = 2;
+                for (int c = 0; c < 3; ++c) nxt[c] = d[c] + prev[c] - smallnum;
+                x[i] = ((float)nxt[0] * invp) * 10.0f;
+                y[i] = ((float)nxt[1] * invp) * 10.0f;
+                z[i] = ((float)nxt[2] * invp) * 10.0f;
+                ++i;
+                if (k == 0) {            // the large triple in front of the run is the SECOND atom of the pair
+                    x[i] = ((float)cur[0] * invp) * 10.0f;
+                    y[i] = ((float)cur[1] * invp) * 10.0f;
+                    z[i] = ((float)cur[2] * invp) * 10.0f;
+                    ++i;
+                }
+                for (int c = 0; c < 3; ++c) prev[c] = nxt[c];
+            }
+            if (st) break;
+        } else {
+            x[i] = ((float)cur[0] * invp) * 10.0f;
+            y[i] = ((float)cur[1] * invp) * 10.0f;
+            z[i] = ((float)cur[2] * invp) * 10.0f;
+            ++i;
+        }
+        if (is_smaller) {
+            smallidx += is_smaller;
+            if (smallidx <= XTC_FIRSTIDX - 1 || smallidx >= XTC_LASTIDX) { st = 1; break; }
+            smallnum = kXtcMagic[smallidx] / 2;
+            xtc_radix(small, (uint32_t)kXtcMagic[smallidx], (uint32_t)kXtcMagic[smallidx]);
+        }
+        if (br.pos > nbits) { st = 1; break; }
+    }
+    return st;
+}
+
+// ---- variant 1: one thread per frame, the whole stream
 __global__ __launch_bounds__(64) void k_xtc_decode(const unsigned char* __restrict__ raw, const vmd_xtc_frame_t* __restrict__ info,
                                                    int B, int natoms, float* __restrict__ xyz, size_t frame_stride,
                                                    size_t row_stride, uint32_t* __restrict__ status) {
@@ -127,105 +231,139 @@ __global__ __launch_bounds__(64) void k_xtc_decode(const unsigned char* __restri
     if (f >= B) return;
     const vmd_xtc_frame_t fi = info[f];
     float* x = xyz + (size_t)f * frame_stride;
-    float* y = x + row_stride;
-    float* z = y + row_stride;
-    uint32_t st = 0;
-    do {
-        if (!(fi.precision > 0.0f)) { st = 1; break; }
-        const float invp = 1.0f / fi.precision;
-        int smallidx = fi.smallidx;
-        if (smallidx < XTC_FIRSTIDX || smallidx >= XTC_LASTIDX) { st = 1; break; }
-        uint32_t sizeint[3];
-        bool bad = false;
-        for (int k = 0; k < 3; ++k) {
-            const int64_t s = (int64_t)fi.maxint[k] - (int64_t)fi.minint[k] + 1;
-            if (s <= 0 || s > 0xffffffffll) bad = true;
-            sizeint[k] = (uint32_t)s;
-        }
-        if (bad) { st = 1; break; }
-        int bitsizeint[3] = {0, 0, 0}, bitsize;
-        if ((sizeint[0] | sizeint[1] | sizeint[2]) > 0xffffffu) {
-            for (int k = 0; k < 3; ++k) bitsizeint[k] = xtc_bit_length(sizeint[k]);
-            bitsize = 0;
-        } else {
-            // bit length of the product of the three ranges (each < 2^24): 128-bit product through two 64-bit halves
-            const uint64_t p01 = (uint64_t)sizeint[0] * sizeint[1];                    // < 2^48
-            const uint64_t lo = (p01 & 0xffffffffull) * sizeint[2], hi = (p01 >> 32) * sizeint[2];
-            const uint64_t top = hi + (lo >> 32);                                      // product >> 32
-            bitsize = top ? 32 + xtc_bit_length(top) : xtc_bit_length(lo);
-        }
-        int smaller = kXtcMagic[smallidx - 1 > XTC_FIRSTIDX ? smallidx - 1 : XTC_FIRSTIDX] / 2;
-        int smallnum = kXtcMagic[smallidx] / 2;
-        Radix large, small;
-        xtc_radix(large, sizeint[1], sizeint[2]);
-        xtc_radix(small, (uint32_t)kXtcMagic[smallidx], (uint32_t)kXtcMagic[smallidx]);
-
-        Bits br;
-        xtc_open(br, raw + fi.offset, fi.nbytes);
-        const uint64_t nbits = 8ull * fi.nbytes;
-        int i = 0, run = 0;
-        while (i < natoms) {
-            int cur[3], prev[3];
-            if (bitsize == 0) {
-                for (int k = 0; k < 3; ++k) {
-                    const int nb = bitsizeint[k];
-                    cur[k] = (int)(uint32_t)(nb > 24 ? ((xtc_get(br, nb - 24) << 24) | xtc_get(br, 24)) : xtc_get(br, nb));
-                }
-            } else {
-                if (!xtc_triple(br, bitsize, large, cur)) { st = 2; break; }
-            }
-            for (int k = 0; k < 3; ++k) { cur[k] += fi.minint[k]; prev[k] = cur[k]; }
-            int is_smaller = 0;
-            if (xtc_get(br, 1)) {
-                run = (int)xtc_get(br, 5);
-                is_smaller = run % 3;
-                run -= is_smaller;
-                is_smaller--;
-            }
-            if (run > 0) {
-                if (i + 1 + run / 3 > natoms) { st = 1; break; }
-                for (int k = 0; k < run; k += 3) {
-                    int d[3], nxt[3];
-                    if (!xtc_triple(br, smallidx, small, d)) st = 2;
-                    for (int c = 0; c < 3; ++c) nxt[c] = d[c] + prev[c] - smallnum;
-                    x[i] = ((float)nxt[0] * invp) * 10.0f;
-                    y[i] = ((float)nxt[1] * invp) * 10.0f;
-                    z[i] = ((float)nxt[2] * invp) * 10.0f;
-                    ++i;
-                    if (k == 0) {            // the large triple in front of the run is the SECOND atom of the pair
-                        x[i] = ((float)cur[0] * invp) * 10.0f;
-                        y[i] = ((float)cur[1] * invp) * 10.0f;
-                        z[i] = ((float)cur[2] * invp) * 10.0f;
-                        ++i;
-                    }
-                    for (int c = 0; c < 3; ++c) prev[c] = nxt[c];
-                }
-                if (st) break;
-            } else {
-                x[i] = ((float)cur[0] * invp) * 10.0f;
-                y[i] = ((float)cur[1] * invp) * 10.0f;
-                z[i] = ((float)cur[2] * invp) * 10.0f;
-                ++i;
-            }
-            if (is_smaller) {
-                smallidx += is_smaller;
-                if (smallidx < XTC_FIRSTIDX || smallidx >= XTC_LASTIDX) { st = 1; break; }
-                if (is_smaller < 0) {
-                    smallnum = smaller;
-                    smaller = smallidx > XTC_FIRSTIDX ? kXtcMagic[smallidx - 1] / 2 : 0;
-                } else {
-                    smaller = smallnum;
-                    smallnum = kXtcMagic[smallidx] / 2;
-                }
-                xtc_radix(small, (uint32_t)kXtcMagic[smallidx], (uint32_t)kXtcMagic[smallidx]);
-            }
-            if (br.pos > nbits) { st = 1; break; }
-        }
-    } while (false);
+    FrameSetup fs;
+    uint32_t st = xtc_setup(fi, fs);
+    if (!st) st = xtc_decode_range(raw + fi.offset, fi, fs, natoms, 0, 0, fi.smallidx, 0, natoms, x, x + row_stride, x + 2 * row_stride);
     status[f] = st;
 }
 
+// ---- variant 2: two passes.  A stream can only be ENTERED at an atom-group boundary whose bit position is known, and positions
+// depend on every flag before them - but finding them needs no arithmetic on the coordinates: k_xtc_index (one thread per
+// frame) follows only the flag bit, the 5-bit run code and the field widths, ~20 ALU instructions per group, and drops a
+// checkpoint (bit position, atom index, smallidx, run length) at the first group boundary at or after every `chunk` atoms.
+// k_xtc_chunks then decodes all chunks of all frames in parallel, one thread per (frame, chunk): thousands of waves instead of
+// sixteen, and the expensive part (mixed-radix splits, float conversion, stores) is the parallel one.
+struct Peek {                       // random-access MSB-first reads of up to 8 bits
+    const uint64_t* words;
+    uint64_t nwords;
+    uint64_t word;                  // index of the cached pair
+    uint64_t hi, lo;
+};
+__device__ __forceinline__ uint64_t xtc_peek(Peek& p, uint64_t pos, int bits) {
+    const uint64_t w = pos >> 6;
+    if (w != p.word) {
+        const uint64_t w1 = w + 1;
+        p.hi = __builtin_bswap64(p.words[w < p.nwords ? w : p.nwords - 1]);
+        p.lo = __builtin_bswap64(p.words[w1 < p.nwords ? w1 : p.nwords - 1]);
+        p.word = w;
+    }
+    const unsigned sh = (unsigned)(pos & 63ull);
+    const uint64_t v = sh ? ((p.hi << sh) | (p.lo >> (64u - sh))) : p.hi;
+    return v >> (64 - bits);
+}
+
+__global__ __launch_bounds__(64) void k_xtc_index(const unsigned char* __restrict__ raw, const vmd_xtc_frame_t* __restrict__ info,
+                                                  int B, int natoms, int chunk, int maxck, uint64_t* __restrict__ ck_pos,
+                                                  uint32_t* __restrict__ ck_atom, uint32_t* __restrict__ ck_state,
+                                                  uint32_t* __restrict__ nck, uint32_t* __restrict__ status) {
+    const int f = blockIdx.x * 64 + threadIdx.x;
+    if (f >= B) return;
+    const vmd_xtc_frame_t fi = info[f];
+    FrameSetup fs;
+    uint32_t st = xtc_setup(fi, fs);
+    uint32_t n = 0;
+    if (!st) {
+        const int large_bits = fs.bitsize ? fs.bitsize : fs.bitsizeint[0] + fs.bitsizeint[1] + fs.bitsizeint[2];
+        Peek pk;
+        pk.words = (const uint64_t*)(raw + fi.offset);
+        pk.nwords = (fi.nbytes + 32ull) >> 3;
+        pk.word = ~0ull;
+        const uint64_t nbits = 8ull * fi.nbytes;
+        uint64_t pos = 0;
+        int i = 0, smallidx = fi.smallidx, run = 0;
+        while (i < natoms) {
+            if (i >= (int)n * chunk && (int)n < maxck) {
+                const size_t o = (size_t)f * maxck + n;
+                ck_pos[o] = pos;
+                ck_atom[o] = (uint32_t)i;
+                ck_state[o] = (uint32_t)smallidx | ((uint32_t)run << 8);
+                ++n;
+            }
+            pos += (uint64_t)large_bits;
+            int is_smaller = 0;
+            const uint64_t code = xtc_peek(pk, pos, 6);          // flag + run code in one read
+            if (code & 32u) {
+                run = (int)(code & 31u);
+                is_smaller = run % 3;
+                run -= is_smaller;
+                is_smaller--;
+                pos += 6;
+            } else {
+                pos += 1;
+            }
+            if (run > 0) {
+                if (i + 1 + run / 3 > natoms) { st = 1; break; }
+                pos += (uint64_t)(run / 3) * (uint64_t)smallidx;
+                i += 1 + run / 3;
+            } else {
+                i += 1;
+            }
+            smallidx += is_smaller;
+            if (smallidx <= XTC_FIRSTIDX - 1 || smallidx >= XTC_LASTIDX) { st = 1; break; }
+            if (pos > nbits) { st = 1; break; }
+        }
+    }
+    nck[f] = n;
+    status[f] = st;
+}
+
+__global__ __launch_bounds__(64) void k_xtc_chunks(const unsigned char* __restrict__ raw, const vmd_xtc_frame_t* __restrict__ info,
+                                                   int B, int natoms, int maxck, const uint64_t* __restrict__ ck_pos,
+                                                   const uint32_t* __restrict__ ck_atom, const uint32_t* __restrict__ ck_state,
+                                                   const uint32_t* __restrict__ nck, float* __restrict__ xyz, size_t frame_stride,
+                                                   size_t row_stride, uint32_t* __restrict__ status) {
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    const int f = blockIdx.y;
+    if (f >= B || status[f] == 1u || c >= (int)nck[f]) return;
+    const vmd_xtc_frame_t fi = info[f];
+    FrameSetup fs;
+    if (xtc_setup(fi, fs)) return;
+    const size_t o = (size_t)f * maxck + c;
+    const int end_i = c + 1 < (int)nck[f] ? (int)ck_atom[o + 1] : natoms;
+    const uint32_t state = ck_state[o];
+    float* x = xyz + (size_t)f * frame_stride;
+    const uint32_t st = xtc_decode_range(raw + fi.offset, fi, fs, natoms, ck_pos[o], (int)ck_atom[o], (int)(state & 255u), (int)(state >> 8),
+                                         end_i, x, x + row_stride, x + 2 * row_stride);
+    if (st) atomicMax(&status[f], st);
+}
+
 }  // namespace
+
+extern "C" size_t vmd_hip_xtc_scratch_bytes(int B, int natoms, int chunk) {
+    if (chunk < 64) chunk = 64;
+    const size_t maxck = (size_t)(natoms + chunk - 1) / (size_t)chunk + 1;
+    return (size_t)B * maxck * 16 + (size_t)B * 4 + 64;
+}
+
+extern "C" int vmd_hip_xtc_decode_chunked(void* stream, const unsigned char* raw, const vmd_xtc_frame_t* info, int B, int natoms,
+                                          float* xyz, size_t frame_stride, size_t row_stride, uint32_t* status, int chunk,
+                                          void* scratch) {
+    if (B <= 0) return 0;
+    if (chunk < 64) chunk = 64;
+    const int maxck = (natoms + chunk - 1) / chunk + 1;
+    uint64_t* ck_pos = (uint64_t*)scratch;
+    uint32_t* ck_atom = (uint32_t*)(ck_pos + (size_t)B * maxck);
+    uint32_t* ck_state = ck_atom + (size_t)B * maxck;
+    uint32_t* nck = ck_state + (size_t)B * maxck;
+    hipLaunchKernelGGL(k_xtc_index, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, (hipStream_t)stream, raw, info, B, natoms, chunk,
+                       maxck, ck_pos, ck_atom, ck_state, nck, status);
+    int rc = (int)hipGetLastError();
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_xtc_chunks, dim3((unsigned)((maxck + 63) / 64), (unsigned)B), dim3(64), 0, (hipStream_t)stream, raw, info, B,
+                       natoms, maxck, (const uint64_t*)ck_pos, (const uint32_t*)ck_atom, (const uint32_t*)ck_state,
+                       (const uint32_t*)nck, xyz, frame_stride, row_stride, status);
+    return (int)hipGetLastError();
+}
 
 extern "C" int vmd_hip_xtc_decode(void* stream, const unsigned char* raw, const vmd_xtc_frame_t* info, int B, int natoms,
                                   float* xyz, size_t frame_stride, size_t row_stride, uint32_t* status) {
