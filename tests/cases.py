@@ -430,3 +430,28 @@ def sdf_triclinic_spread_structures(lib, O, device=False):
     d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sdf_triclinic_spread_structures.npz"))
     box = tuple(float(v) for v in d["box"])
     check_sdf(lib, O, d["coords"], box, d["structures"], d["mass"], d["tgt"], float(d["cutoff"]), device=device)
+
+
+def sheared_sc_lattice(lib, device=False):
+    """Known answer that owes nothing to the oracle (tests/test_oracle.py: test_sc_lattice_in_sheared_cells): the simple cubic
+    lattice Z^3 * a0 described by cells a = (n,0,0), b = (s,n,0), c = (t,u,n) (integer s,t,u: the same crystal) must show the
+    exact shell multiplicities 6, 12, 8, 6, 24, 24, 12, 30, 24 per atom in the evaluator's 1024-bin histogram.  a0 = 1.0024 keeps every
+    shell radius >= 0.23 bins away from a bin edge at r_max = 3.2."""
+    n, a0, rmax = 8, 1.0024, 3.2
+    pts = np.stack(np.meshgrid(*[np.arange(n)] * 3, indexing="ij")).reshape(3, -1).astype(np.float32) * np.float32(a0)
+    N = pts.shape[1]
+    idx = np.arange(N, dtype=np.int32)
+    expect = np.zeros(1024, np.uint64)
+    for d2, mult in ((1, 6), (2, 12), (3, 8), (4, 6), (5, 24), (6, 24), (8, 12), (9, 30), (10, 24)):
+        expect[int(np.sqrt(d2) * a0 / rmax * 1024.0)] += mult * N
+    for s, t, u in ((0, 0, 0), (3, -2, 3), (-3, 3, -2)):
+        moved = pts.copy()
+        moved[:, ::3] += (np.array([s, n, 0], np.float32) * np.float32(a0))[:, None]
+        moved[:, 1::5] -= (np.array([t, u, n], np.float32) * np.float32(a0))[:, None]
+        cell = V.make_unitcell(n * a0, tilt=(s * a0, t * a0, u * a0))
+        ir = V.ScriptIR(lib)
+        ir.add_rdf("g", idx, idx, (0.0, rmax))          # cutoff below half the cell width: the pencil grid (sheared for s,t,u != 0)
+        ev = V.ScriptEval(2, ir)
+        traj = make_traj(lib, np.stack([pts, moved]), cell, device)
+        assert ev.frame_range(V.MolSystem(N, unitcell=cell), traj, 0, 2)
+        np.testing.assert_array_equal(ev.property_data("g").counts, 2 * expect, err_msg=f"tilt {(s, t, u)}")

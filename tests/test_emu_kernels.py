@@ -200,3 +200,7 @@ def test_result_views_keep_their_eval_alive(emu_lib, oracle):
     junk = [np.full(1024, 0xAB, np.uint64) for _ in range(64)]            # recycle freed blocks, if any
     np.testing.assert_array_equal(c, ref)
     assert m.all() and ref.sum() > 0 and len(junk) == 64 and v.shape == (10,)
+
+
+def test_sheared_sc_lattice_known_answer(emu_lib):
+    cases.sheared_sc_lattice(emu_lib)

@@ -206,3 +206,30 @@ def test_triclinic_minimum_image_against_27_image_search(oracle):
     assert abs(dmin - best[3, 77]) < 1e-4
     dcom = oracle.distance_com(pts[0], pts[1], pts[2], cell, a, None, b, None)
     assert abs(dcom - best[3, 77]) < 1e-4
+
+
+def test_sc_lattice_in_sheared_cells(oracle, golden):
+    """The same crystal described by a sheared cell: Z^3 is invariant under a = (n,0,0), b = (s,n,0), c = (t,u,n) with integer
+    s, t, u, and the n^3 points of the cube are one representative per class of Z^3 / <a,b,c>.  The triclinic minimum image
+    (SPEC S3t) must therefore reproduce the exact shell multiplicities 6, 12, 8, 6, 24, 24, 12, 30 - a known answer that owes
+    nothing to the oracle's own 27-image search.  The spacing 1.003 keeps every shell radius >= 0.2 bins away from a bin edge."""
+    g = golden["sc_lattice"]
+    n, a0 = g["n"], 1.003
+    pts = np.stack(np.meshgrid(*[np.arange(n)] * 3, indexing="ij")).reshape(3, -1).astype(np.float32) * np.float32(a0)
+    idx = np.arange(pts.shape[1])
+    rmax, nbins = 3.2, 320
+    expect = np.zeros(nbins, np.uint64)
+    for d2, mult in g["shells"].items():
+        if np.sqrt(int(d2)) * a0 < rmax:
+            expect[int(np.sqrt(int(d2)) * a0 * 100.0)] += mult * pts.shape[1]
+    for s, t, u in ((0, 0, 0), (3, 0, 0), (3, -2, 3), (-3, 3, -2), (1, 3, -3)):
+        cell = oracle.make_cell(n * a0, tilt=(s * a0, t * a0, u * a0))
+        # atoms anywhere in space describe the same crystal: shift some by lattice vectors of the sheared cell
+        moved = pts.copy()
+        moved[:, ::3] += (np.array([s, n, 0], np.float32) * np.float32(a0))[:, None]
+        moved[:, 1::5] -= (np.array([t, u, n], np.float32) * np.float32(a0))[:, None]
+        for xyz in (pts, moved):
+            for method in ("brute", "cells"):
+                counts, hits = oracle.rdf_frame(xyz[0], xyz[1], xyz[2], cell, idx, idx, 0.0, rmax, nbins=nbins, method=method)
+                np.testing.assert_array_equal(counts, expect, err_msg=f"tilt {(s, t, u)}, {method}")
+                assert hits == expect.sum()

@@ -81,3 +81,9 @@ def test_dense_all_atom_rdf(gpu_lib, oracle):
     box = float((N / 0.1) ** (1.0 / 3.0))
     c = _dense_all_atom_rdf(gpu_lib, oracle, 6, N, box, 2, True)
     assert 1.0e8 * 2 < c.sum() < 1.2e8 * 2
+
+
+@pytest.mark.gpu
+def test_sheared_sc_lattice_known_answer(gpu_lib):
+    """Exact shell multiplicities of a simple cubic crystal in cubic and sheared cells (no oracle involved)."""
+    cases.sheared_sc_lattice(gpu_lib, device=True)
