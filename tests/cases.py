@@ -455,3 +455,40 @@ def sheared_sc_lattice(lib, device=False):
         traj = make_traj(lib, np.stack([pts, moved]), cell, device)
         assert ev.frame_range(V.MolSystem(N, unitcell=cell), traj, 0, 2)
         np.testing.assert_array_equal(ev.property_data("g").counts, 2 * expect, err_msg=f"tilt {(s, t, u)}")
+
+
+def open_sc_lattice(lib, O=None, device=False):
+    """Known answer for open and partly periodic systems (no oracle involved unless `O` is given, which is then checked against
+    the same numbers): a finite n^3 block of a simple cubic lattice.  The number of ordered pairs with displacement (dx,dy,dz) is
+    prod_k (n if axis k is periodic else n - |d_k|), exactly."""
+    n, a0, rmax = 8, 1.0024, 3.2
+    pts = np.stack(np.meshgrid(*[np.arange(n)] * 3, indexing="ij")).reshape(3, -1).astype(np.float32) * np.float32(a0)
+    pts = pts + np.float32(37.5)                      # away from the origin: open axes use the raw coordinates
+    N = pts.shape[1]
+    idx = np.arange(N, dtype=np.int32)
+    r = np.arange(-3, 4)
+    for flags in (0, 3, 4, 5):
+        expect = np.zeros(1024, np.uint64)
+        for dx in r:
+            for dy in r:
+                for dz in r:
+                    d2 = int(dx * dx + dy * dy + dz * dz)
+                    if d2 == 0 or np.sqrt(d2) * a0 >= rmax:
+                        continue
+                    pairs = 1
+                    for k, d in enumerate((dx, dy, dz)):
+                        pairs *= n if flags >> k & 1 else n - abs(int(d))
+                    expect[int(np.sqrt(d2) * a0 / rmax * 1024.0)] += pairs
+        cell = V.make_unitcell(n * a0, flags=flags) if flags else V.make_unitcell(None)
+        ir = V.ScriptIR(lib)
+        ir.add_rdf("g", idx, idx, (0.0, rmax))
+        ev = V.ScriptEval(1, ir)
+        assert ev.frame_range(V.MolSystem(N, unitcell=cell), make_traj(lib, pts[None], cell, device), 0, 1)
+        np.testing.assert_array_equal(ev.property_data("g").counts, expect, err_msg=f"pbc flags {flags}")
+        if O is not None:
+            ocell = O.make_cell(n * a0, flags=flags) if flags else O.make_cell(None)
+            for method in ("brute", "cells"):
+                counts, hits = O.rdf_frame(pts[0], pts[1], pts[2], ocell, idx, idx, 0.0, rmax, nbins=1024, method=method)
+                if hits == 2 ** 64 - 1:
+                    continue                           # this oracle method does not cover the cell type
+                np.testing.assert_array_equal(counts, expect, err_msg=f"oracle {method}, pbc flags {flags}")

@@ -204,3 +204,7 @@ def test_result_views_keep_their_eval_alive(emu_lib, oracle):
 
 def test_sheared_sc_lattice_known_answer(emu_lib):
     cases.sheared_sc_lattice(emu_lib)
+
+
+def test_open_sc_lattice_known_answer(emu_lib, oracle):
+    cases.open_sc_lattice(emu_lib, oracle)

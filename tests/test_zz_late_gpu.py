@@ -87,3 +87,9 @@ def test_dense_all_atom_rdf(gpu_lib, oracle):
 def test_sheared_sc_lattice_known_answer(gpu_lib):
     """Exact shell multiplicities of a simple cubic crystal in cubic and sheared cells (no oracle involved)."""
     cases.sheared_sc_lattice(gpu_lib, device=True)
+
+
+@pytest.mark.gpu
+def test_open_sc_lattice_known_answer(gpu_lib):
+    """Exact pair counts of a finite lattice block without a cell, as a slab and as wires (no oracle involved)."""
+    cases.open_sc_lattice(gpu_lib, device=True)
