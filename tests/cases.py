@@ -492,3 +492,54 @@ def open_sc_lattice(lib, O=None, device=False):
                 if hits == 2 ** 64 - 1:
                     continue                           # this oracle method does not cover the cell type
                 np.testing.assert_array_equal(counts, expect, err_msg=f"oracle {method}, pbc flags {flags}")
+
+
+def sdf_rotations_known_answer(lib, device=False):
+    """Known answer for sdf() that owes nothing to the oracle: a rigid, asymmetric 4-atom structure (equal masses, centre of mass
+    exactly representable) carried through the 24 proper rotations of the cube (signed permutation matrices: exact in float) and
+    integer translations, with target atoms sitting on voxel CENTRES of the aligned 128^3 grid.  Whatever the alignment's last
+    bits are, every target must land in its own voxel in every frame: counts == number of frames there, 0 elsewhere, x fastest
+    (`values[z*d*d + y*d + x]`, /root/reference/src/main.cpp:5811-5815), and the world->reference matrices are the inverse
+    rotations."""
+    import itertools
+    s, dim = 8.0, 128
+    body = np.array([[2, 0, 0], [0, 1, 0], [0, 0, 0.5], [-2, -1, -0.5]], np.float64)         # sum = 0: COM at the centre
+    rng = np.random.default_rng(12)
+    vox = rng.integers(0, dim, (300, 3))                                                       # (ix, iy, iz) of every target
+    vox = np.unique(vox, axis=0)
+    q = -s + (2 * s / dim) * (vox + 0.5)                                                       # voxel centres, exact
+    rots = []
+    for perm in itertools.permutations(range(3)):
+        for signs in itertools.product((1, -1), repeat=3):
+            R = np.zeros((3, 3))
+            for r in range(3):
+                R[r, perm[r]] = signs[r]
+            if round(np.linalg.det(R)) == 1:
+                rots.append(R)
+    assert len(rots) == 24
+    rots.sort(key=lambda R: -np.trace(R))                                                      # identity first: frame 0 is the pose
+    F = len(rots)
+    coords = np.zeros((F, 3, 4 + len(q)), np.float32)
+    centres = rng.integers(-20, 21, (F, 3)).astype(np.float64) + 40.0
+    for f, R in enumerate(rots):
+        coords[f, :, :4] = (body @ R.T + centres[f]).T
+        coords[f, :, 4:] = (q @ R.T + centres[f]).T
+    assert np.array_equal(coords.astype(np.float64)[0, :, :4].T, body + centres[0])           # everything is exactly representable
+    N = coords.shape[2]
+    cell = V.make_unitcell(None)
+    ir = V.ScriptIR(lib)
+    ir.add_sdf("v", np.arange(4, dtype=np.int32)[None, :], np.arange(4, N, dtype=np.int32), s)
+    ev = V.ScriptEval(F, ir)
+    sysm = V.MolSystem(N, mass=np.ones(N, np.float32), unitcell=cell)
+    traj = make_traj(lib, coords, cell, device)
+    assert ev.frame_range(sysm, traj, 0, F)
+    vol = ev.property_data("v").counts.reshape(dim, dim, dim)                                  # [z][y][x]
+    expect = np.zeros((dim, dim, dim), np.uint64)
+    expect[vox[:, 2], vox[:, 1], vox[:, 0]] = F
+    np.testing.assert_array_equal(vol, expect)
+    for f in (0, 7, F - 1):
+        M4, ext = ev.sdf_matrices("v", sysm, traj, f)
+        assert ext == np.float32(s)
+        A = np.asarray(M4[0], np.float64)               # rows of the world -> reference matrix: q = R^T (x - centre)
+        np.testing.assert_allclose(A[:3, :3], rots[f].T, atol=1e-6)
+        np.testing.assert_allclose(A[:3, :3] @ centres[f] + A[:3, 3], 0.0, atol=1e-4)

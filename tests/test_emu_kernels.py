@@ -208,3 +208,7 @@ def test_sheared_sc_lattice_known_answer(emu_lib):
 
 def test_open_sc_lattice_known_answer(emu_lib, oracle):
     cases.open_sc_lattice(emu_lib, oracle)
+
+
+def test_sdf_rotations_known_answer(emu_lib):
+    cases.sdf_rotations_known_answer(emu_lib)

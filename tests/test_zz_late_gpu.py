@@ -93,3 +93,9 @@ def test_sheared_sc_lattice_known_answer(gpu_lib):
 def test_open_sc_lattice_known_answer(gpu_lib):
     """Exact pair counts of a finite lattice block without a cell, as a slab and as wires (no oracle involved)."""
     cases.open_sc_lattice(gpu_lib, device=True)
+
+
+@pytest.mark.gpu
+def test_sdf_rotations_known_answer(gpu_lib):
+    """Targets on voxel centres of the aligned grid through the 24 cube rotations: exact volume, inverse rotations (no oracle)."""
+    cases.sdf_rotations_known_answer(gpu_lib, device=True)
