@@ -543,3 +543,26 @@ def sdf_rotations_known_answer(lib, device=False):
         A = np.asarray(M4[0], np.float64)               # rows of the world -> reference matrix: q = R^T (x - centre)
         np.testing.assert_allclose(A[:3, :3], rots[f].T, atol=1e-6)
         np.testing.assert_allclose(A[:3, :3] @ centres[f] + A[:3, 3], 0.0, atol=1e-4)
+
+
+def distance_known_answer(lib, device=False):
+    """Closed-form answers for the distance family (no oracle): integer coordinates across the periodic boundary of a cube of 20.
+    a = {(1,1,1), (1,1,3)} (COM (1,1,2)), b = {(18,5,2), (18,5,6)} (COM (18,5,4)): the minimum image of the COM separation is
+    (3, -4, -2) -> sqrt(29); atom pairs: (3,4,1) sqrt 26, (3,4,5) sqrt 50, (3,4,1) sqrt 26, (3,4,3) sqrt 34."""
+    xyz = np.array([[1, 1, 1], [1, 1, 3], [18, 5, 2], [18, 5, 6]], np.float32)
+    F = 3
+    coords = np.stack([(xyz + np.float32(20.0 * f)).T for f in range(F)])        # whole-box shifts change nothing
+    cell = V.make_unitcell(20.0)
+    ir = V.ScriptIR(lib)
+    ir.add_distance("com", [0, 1], [2, 3], L.DIST_COM)
+    ir.add_distance("min", [0, 1], [2, 3], L.DIST_MIN)
+    ir.add_distance("max", [0, 1], [2, 3], L.DIST_MAX)
+    ir.add_distance("pair", [0, 1], [2, 3], L.DIST_PAIR)
+    ev = V.ScriptEval(F, ir)
+    assert ev.frame_range(V.MolSystem(4, mass=np.ones(4, np.float32), unitcell=cell), make_traj(lib, coords, cell, device), 0, F)
+    f32 = lambda v: np.sqrt(np.float32(v))
+    for f in range(F):
+        assert ev.property_data("com").values.reshape(F, -1)[f, 0] == f32(29)
+        assert ev.property_data("min").values.reshape(F, -1)[f, 0] == f32(26)
+        assert ev.property_data("max").values.reshape(F, -1)[f, 0] == f32(50)
+        np.testing.assert_array_equal(np.sort(ev.property_data("pair").values.reshape(F, -1)[f]), np.sort([f32(26), f32(50), f32(26), f32(34)]))

@@ -212,3 +212,7 @@ def test_open_sc_lattice_known_answer(emu_lib, oracle):
 
 def test_sdf_rotations_known_answer(emu_lib):
     cases.sdf_rotations_known_answer(emu_lib)
+
+
+def test_distance_known_answer(emu_lib):
+    cases.distance_known_answer(emu_lib)

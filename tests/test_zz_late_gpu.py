@@ -99,3 +99,8 @@ def test_open_sc_lattice_known_answer(gpu_lib):
 def test_sdf_rotations_known_answer(gpu_lib):
     """Targets on voxel centres of the aligned grid through the 24 cube rotations: exact volume, inverse rotations (no oracle)."""
     cases.sdf_rotations_known_answer(gpu_lib, device=True)
+
+
+@pytest.mark.gpu
+def test_distance_known_answer(gpu_lib):
+    cases.distance_known_answer(gpu_lib, device=True)
