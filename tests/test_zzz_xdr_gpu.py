@@ -1,0 +1,59 @@
+"""XTC / TRR files staged through the multi-threaded host decode into the kernels, and XTC batches decompressed on the device
+(k_xtc_decode, k_xtc_index + k_xtc_chunks).  Written after the last GPU session of round 1: the file name sorts last so that
+`pytest -x` reaches the never-run-on-hardware device decoder only after everything else has passed."""
+import numpy as np
+import pytest
+
+import cases
+import viamd_amd as V
+
+
+def _xdr_through_the_evaluator(lib, oracle, tmp_path, box, F, N, device_check):
+    coords = cases.water_box(oracle, 31, N, box, F)
+    cell = V.make_unitcell(box)
+    o = cases.oxygen(N)
+    ir = V.ScriptIR(lib); ir.add_rdf("g", o, o, 9.0)
+    sysm = V.MolSystem(N, unitcell=cell)
+    res = {}
+    for fmt, write in (("xtc", V.write_xtc), ("trr", V.write_trr)):
+        p = tmp_path / f"w.{fmt}"
+        write(p, coords, cell, lib=lib)
+        t = V.XdrTrajectory(p, lib=lib)
+        decoded = np.stack([t.load_frame(f)[0] for f in range(F)])
+        assert abs(decoded - coords).max() < (0.0051 if fmt == "xtc" else 1e-4)
+        old = lib.vmd_set_option(b"batch_frames", max(4, F // 3))          # several staged batches, decoded on several threads
+        try:
+            ev = V.ScriptEval(F, ir)
+            assert ev.frame_range(sysm, V.XdrTrajectory(p, lib=lib), 0, F)
+        finally:
+            lib.vmd_set_option(b"batch_frames", old)
+        got = ev.property_data("g").counts.copy()
+        counts, _ = cases.oracle_rdf(oracle, decoded, oracle.make_cell(box), o, o, 0.0, 9.0)
+        np.testing.assert_array_equal(got, counts, err_msg=fmt)            # bit-exact on the coordinates the file holds
+        res[fmt] = got
+        if fmt == "xtc":
+            # the same file with the batch decompressed on the device: one thread per frame (1), index pass + one thread per
+            # chunk (2); identical integers, every frame counted as device-decoded
+            for mode in (1, 2):
+                old_d = lib.vmd_set_option(b"xtc_device_decode", mode)
+                old_c = lib.vmd_set_option(b"xtc_chunk", 256)
+                old = lib.vmd_set_option(b"batch_frames", max(4, F // 3))
+                try:
+                    ev = V.ScriptEval(F, ir)
+                    assert ev.frame_range(sysm, V.XdrTrajectory(p, lib=lib), 0, F)
+                finally:
+                    lib.vmd_set_option(b"batch_frames", old)
+                    lib.vmd_set_option(b"xtc_chunk", old_c)
+                    lib.vmd_set_option(b"xtc_device_decode", old_d)
+                assert ev.frames_device_decoded() == F
+                np.testing.assert_array_equal(ev.property_data("g").counts, counts, err_msg=f"xtc, device decode variant {mode}")
+    assert res["xtc"].sum() > 0 and abs(int(res["xtc"].sum()) - int(res["trr"].sum())) < 0.01 * res["trr"].sum()
+
+
+def test_xdr_files_through_the_evaluator_on_emulator(emu_lib, oracle, tmp_path):
+    _xdr_through_the_evaluator(emu_lib, oracle, tmp_path, 30.0, 6, 600, False)
+
+
+@pytest.mark.gpu
+def test_xdr_files_through_the_evaluator(gpu_lib, oracle, tmp_path):
+    _xdr_through_the_evaluator(gpu_lib, oracle, tmp_path, 70.0, 24, 30000, True)
