@@ -60,6 +60,7 @@ typedef struct vmd_device_view_t {
     size_t row_stride;
     const vmd_unitcell_t* cells;
     int device;
+    size_t resident_beg, resident_end;   /* frames present behind `base` (a rank's shard); 0, 0 = all of them */
 } vmd_device_view_t;
 
 /* host-resident view of a trajectory with the same SoA frame layout (e.g. a frame cache in pinned memory): lets the
@@ -233,6 +234,39 @@ bool   vmd_eval_finalize(vmd_script_eval_t* eval);
 /* mark frames as evaluated elsewhere (after a mask all-reduce) */
 void   vmd_eval_set_frame_mask(vmd_script_eval_t* eval, const uint8_t* mask, size_t n);
 
+/* The merge itself, behind the ABI (viamd_amd/csrc/vmd_reduce.cpp).  VIAMD's evaluation is driven from C++
+ * (src/main.cpp:993-1008: pool threads call md_script_eval_frame_range on disjoint ranges of one eval); across GPUs the same
+ * happens one process per GPU, every rank on its block of frames, followed by ONE vmd_eval_reduce: the u64 accumulators are
+ * summed in place on the device (8 KB per RDF, 16.8 MB per SDF volume), the host-side parts (fp64 weights, temporal rows,
+ * frame mask) in one packed fp64 all-reduce, then the float views are re-derived (vmd_eval_finalize).  Afterwards every rank
+ * holds the result of the whole trajectory, bit-identical in the integer parts for any rank count.
+ * The collective is an interface so that hosts with their own transport can plug it in; vmd_comm_* is the RCCL one. */
+typedef struct vmd_collective_i {
+    void* inst;
+    int  (*rank)(void* inst);
+    int  (*size)(void* inst);
+    /* in-place SUM over all ranks of `n` elements of DEVICE memory, enqueued on `stream` (hipStream_t) */
+    bool (*allreduce_sum_u64)(void* inst, uint64_t* buf, size_t n, void* stream);
+    bool (*allreduce_sum_f64)(void* inst, double* buf, size_t n, void* stream);
+} vmd_collective_i;
+/* call on every rank after its last vmd_eval_frame_range has returned; `stream`: hipStream_t the collectives run on (NULL = the
+ * default stream); synchronous on return */
+bool   vmd_eval_reduce(vmd_script_eval_t* eval, const vmd_collective_i* coll, void* stream);
+
+/* RCCL communicator (one per process = per GPU; xGMI inside a node).  librccl is loaded at run time by soname, so a host that
+ * already carries an RCCL (e.g. PyTorch's) shares that copy.  Either let the library create the communicator - rank 0 makes the
+ * id, the host program distributes its 128 bytes by whatever means it has (MPI, a file, a socket), every rank calls
+ * vmd_comm_create on its own device - or wrap an ncclComm_t the host already owns (not destroyed by vmd_comm_destroy). */
+#define VMD_COMM_ID_BYTES 128
+typedef struct vmd_comm_t vmd_comm_t;
+bool        vmd_comm_unique_id(uint8_t id[VMD_COMM_ID_BYTES]);                        /* ncclGetUniqueId */
+vmd_comm_t* vmd_comm_create(int nranks, int rank, const uint8_t id[VMD_COMM_ID_BYTES]); /* ncclCommInitRank on the current device */
+vmd_comm_t* vmd_comm_from_nccl(void* nccl_comm);                                      /* ncclComm_t owned by the caller */
+void        vmd_comm_destroy(vmd_comm_t* comm);
+const vmd_collective_i* vmd_comm_collective(vmd_comm_t* comm);
+int         vmd_comm_rank(const vmd_comm_t* comm);
+int         vmd_comm_size(const vmd_comm_t* comm);
+
 /* ---- filtered evaluation (VIAMD: the "Eval Filt" task, src/main.cpp:1014-1039) ----------
  * VIAMD answers a timeline sub-range by re-running md_script_eval_frame_range over it on a second eval object
  * every time the range slider moves.  With frame blocks the full evaluation additionally keeps one partial
@@ -254,6 +288,9 @@ size_t vmd_eval_frames_device_decoded(const vmd_script_eval_t* eval);
 /* ---- device-resident trajectories (pre-staged in HBM) ---------------------------------- */
 typedef struct vmd_devtraj_t vmd_devtraj_t;
 vmd_devtraj_t*    vmd_devtraj_create(size_t num_frames, size_t num_atoms);
+/* one rank's shard of a frame-sharded trajectory: reports `num_frames_total` frames, keeps only
+ * [frame_beg, frame_end) resident; every frame index of this API stays global */
+vmd_devtraj_t*    vmd_devtraj_create_shard(size_t num_frames_total, size_t frame_beg, size_t frame_end, size_t num_atoms);
 void              vmd_devtraj_free(vmd_devtraj_t* t);
 vmd_trajectory_i* vmd_devtraj_interface(vmd_devtraj_t* t);
 bool vmd_devtraj_upload_frame(vmd_devtraj_t* t, size_t frame, const vmd_unitcell_t* cell,
@@ -267,6 +304,7 @@ bool vmd_devtraj_synth(vmd_devtraj_t* t, uint64_t seed, float L, float sigma, ui
                        size_t frame_beg, size_t frame_end);
 /* replace the unit cell of frames [beg,end) (coordinates stay as they are: they are wrapped on use) */
 bool vmd_devtraj_set_cell(vmd_devtraj_t* t, size_t frame_beg, size_t frame_end, const vmd_unitcell_t* cell);
+/* device address of the first RESIDENT frame */
 float* vmd_devtraj_device_ptr(vmd_devtraj_t* t, size_t* frame_stride, size_t* row_stride);
 
 /* DCD (CHARMM / NAMD) trajectory file as a vmd_trajectory_i — VIAMD attaches these through md_dcd_attach_from_file

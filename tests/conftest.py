@@ -31,6 +31,7 @@ EMU_SOURCES = [os.path.join(ROOT, "viamd_amd", "csrc", "vmd_kernels.hip"),
                os.path.join(ROOT, "viamd_amd", "csrc", "vmd_dcd.cpp"),
                os.path.join(ROOT, "viamd_amd", "csrc", "vmd_xdr.cpp"),
                os.path.join(ROOT, "viamd_amd", "csrc", "vmd_script.cpp"),
+               os.path.join(ROOT, "viamd_amd", "csrc", "vmd_reduce.cpp"),
                os.path.join(EMU_DIR, "emu.cpp")]
 EMU_DEPS = EMU_SOURCES + [os.path.join(EMU_DIR, "hip", "hip_runtime.h"),
                           os.path.join(ROOT, "include", "vmd_eval.h"), os.path.join(ROOT, "include", "vmd_hip.h")]
@@ -45,7 +46,7 @@ def build_emu():
     if os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(s) for s in EMU_DEPS):
         return out
     cmd = ["g++", "-O2", "-g", "-shared", "-fPIC", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-mavx2", "-mfma",
-           "-I" + EMU_DIR, "-I" + os.path.join(ROOT, "include"), "-x", "c++"] + EMU_SOURCES + ["-o", out]
+           "-I" + EMU_DIR, "-I" + os.path.join(ROOT, "include"), "-x", "c++"] + EMU_SOURCES + ["-ldl", "-o", out]
     if san:
         cmd[1:1] = ["-fsanitize=" + san, "-fno-omit-frame-pointer", "-fno-sanitize-recover=undefined"]
     subprocess.check_call(cmd)

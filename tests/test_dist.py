@@ -9,7 +9,7 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, tmpdir):
+def _worker(rank, world, port, tmpdir, mode="host"):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch.distributed as dist
@@ -36,8 +36,20 @@ def _worker(rank, world, port, tmpdir):
     ir.add_distance("dp", structures[0][:2], structures[2][:3], L.DIST_PAIR)
     ev = V.ScriptEval(F, ir)
     vcell = V.make_unitcell(36.0)
-    traj = V.HostTrajectory(coords, vcell)
     beg, end = shard_frames(F, rank, world)
+    if mode == "host":
+        traj = V.HostTrajectory(coords, vcell)
+    else:
+        # one rank's shard of a device-resident trajectory: global frame indices, only [beg, end) (+ frame 0: SDF reference
+        # pose) resident; frames outside the shard must be refused
+        traj = V.DeviceTrajectory(F, N, lib=lib, shard=(beg, end))
+        for f in sorted(set(range(beg, end)) | {0}):
+            traj.upload_frame(f, vcell, coords[f, 0], coords[f, 1], coords[f, 2])
+        if rank == 1:
+            import pytest
+            with pytest.raises(V.VmdError, match="not resident"):
+                ev.frame_range(V.MolSystem(N, mass=mass, unitcell=vcell), traj, 0, F)
+            ev.clear_data()
     assert ev.frame_range(V.MolSystem(N, mass=mass, unitcell=vcell), traj, beg, end)
     assert ev.frames_done() == end - beg
     reduce_eval(ev)
@@ -59,11 +71,17 @@ def test_shard_frames_covers_everything():
             assert got == list(range(F))
 
 
-def test_two_rank_gloo_merge_matches_oracle(oracle, emu_lib, tmp_path):
+import pytest
+
+
+@pytest.mark.parametrize("mode", ["host", "shard"])
+def test_two_rank_gloo_merge_matches_oracle(oracle, emu_lib, tmp_path, mode):
+    """every rank evaluates its block of frames, ONE vmd_eval_reduce (C++, behind the ABI) merges; `shard`: each rank holds
+    only its block of a device trajectory"""
     import cases
     from viamd_amd import _lib as L
-    port = 29500 + (os.getpid() % 2000)
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    port = 29500 + (os.getpid() % 2000) + (7 if mode == "shard" else 0)
+    mp.spawn(_worker, args=(2, port, str(tmp_path), mode), nprocs=2, join=True)
     F = 5
     coords, structures, mass = cases.sdf_system(oracle, 21, 900, 36.0, F)
     N = coords.shape[2]

@@ -21,9 +21,38 @@ def build_demo():
     return EXE
 
 
+def build_reduce_demo():
+    from viamd_amd import build
+    lib = build.build()
+    src = os.path.join(ROOT, "tests", "native", "cabi_reduce_demo.cpp")
+    exe = os.path.join(ROOT, "tests", "native", "cabi_reduce_demo")
+    if os.path.exists(exe) and os.path.getmtime(exe) >= max(os.path.getmtime(src), os.path.getmtime(lib)):
+        return exe
+    subprocess.check_call(["g++", "-std=c++17", "-O2", src, "-I" + os.path.join(ROOT, "include"), "-L" + os.path.join(ROOT, "viamd_amd"),
+                           "-lviamd_amd", "-L/opt/rocm/lib", "-Wl,-rpath,$ORIGIN/../../viamd_amd", "-Wl,-rpath,/opt/rocm/lib",
+                           "-Wl,-rpath-link,/opt/rocm/lib", "-lpthread", "-o", exe])
+    return exe
+
+
 def test_native_host_builds_against_the_c_abi():
     exe = build_demo()
     assert os.access(exe, os.X_OK)
+    assert os.access(build_reduce_demo(), os.X_OK)
+
+
+@pytest.mark.gpu
+def test_native_rccl_merge_behind_the_abi(tmp_path, gpu_lib):
+    """C++ ranks (one process per GPU; a 1-rank communicator on a 1-GPU box, 2 ranks when the node has more GPUs): sharded
+    frame_range + ONE vmd_eval_reduce over RCCL == the whole trajectory on one GPU, checked inside the program."""
+    exe = build_reduce_demo()
+    nranks = 2 if gpu_lib.vmd_device_count() >= 2 else 1
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([exe, str(nranks), str(r), str(tmp_path / "rccl.id"), "24"], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                              text=True, env=env) for r in range(nranks)]
+    for r, p in enumerate(procs):
+        out, err = p.communicate(timeout=600)
+        assert p.returncode == 0, err[-2000:]
+        assert out.startswith(f"OK ranks={nranks} rank={r}"), out
 
 
 @pytest.mark.gpu

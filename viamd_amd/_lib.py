@@ -41,7 +41,7 @@ class FrameHeader(C.Structure):
 
 class DeviceView(C.Structure):
     _fields_ = [("base", c_float_p), ("frame_stride", C.c_size_t), ("row_stride", C.c_size_t),
-                ("cells", C.POINTER(Unitcell)), ("device", C.c_int)]
+                ("cells", C.POINTER(Unitcell)), ("device", C.c_int), ("resident_beg", C.c_size_t), ("resident_end", C.c_size_t)]
 
 
 NUM_FRAMES_FN = C.CFUNCTYPE(C.c_size_t, C.c_void_p)
@@ -90,6 +90,19 @@ class AccumView(C.Structure):
                 ("weights64", c_double_p), ("num_weights", C.c_size_t), ("temporal", c_float_p), ("num_temporal", C.c_size_t)]
 
 
+ALLREDUCE_U64_FN = C.CFUNCTYPE(C.c_bool, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+ALLREDUCE_F64_FN = C.CFUNCTYPE(C.c_bool, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+COMM_INT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p)
+
+
+class CollectiveI(C.Structure):          # vmd_collective_i
+    _fields_ = [("inst", C.c_void_p), ("rank", COMM_INT_FN), ("size", COMM_INT_FN),
+                ("allreduce_sum_u64", ALLREDUCE_U64_FN), ("allreduce_sum_f64", ALLREDUCE_F64_FN)]
+
+
+COMM_ID_BYTES = 128
+
+
 class Grid(C.Structure):
     _fields_ = [("nxf", C.c_int32), ("ny", C.c_int32), ("nz", C.c_int32), ("ncell", C.c_int32)]
 
@@ -126,11 +139,20 @@ SIGNATURES = [
     ("vmd_eval_refresh_counts", C.c_bool, [_vp, C.c_char_p]),
     ("vmd_eval_finalize", C.c_bool, [_vp]),
     ("vmd_eval_set_frame_mask", None, [_vp, c_uint8_p, C.c_size_t]),
+    ("vmd_eval_reduce", C.c_bool, [_vp, C.POINTER(CollectiveI), _vp]),
+    ("vmd_comm_unique_id", C.c_bool, [c_uint8_p]),
+    ("vmd_comm_create", _vp, [C.c_int, C.c_int, c_uint8_p]),
+    ("vmd_comm_from_nccl", _vp, [_vp]),
+    ("vmd_comm_destroy", None, [_vp]),
+    ("vmd_comm_collective", C.POINTER(CollectiveI), [_vp]),
+    ("vmd_comm_rank", C.c_int, [_vp]),
+    ("vmd_comm_size", C.c_int, [_vp]),
     ("vmd_eval_set_block_frames", C.c_bool, [_vp, C.c_size_t]),
     ("vmd_eval_set_source", C.c_bool, [_vp, _vp]),
     ("vmd_eval_frame_stats", None, [_vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     ("vmd_eval_frames_device_decoded", C.c_size_t, [_vp]),
     ("vmd_devtraj_create", _vp, [C.c_size_t, C.c_size_t]),
+    ("vmd_devtraj_create_shard", _vp, [C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t]),
     ("vmd_devtraj_free", None, [_vp]),
     ("vmd_devtraj_interface", C.POINTER(TrajectoryI), [_vp]),
     ("vmd_devtraj_upload_frame", C.c_bool, [_vp, C.c_size_t, C.POINTER(Unitcell), c_float_p, c_float_p, c_float_p]),

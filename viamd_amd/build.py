@@ -8,7 +8,7 @@ ROOT = os.path.dirname(_HERE)
 SOURCES = [os.path.join(_HERE, "csrc", "vmd_kernels.hip"), os.path.join(_HERE, "csrc", "vmd_xtc_device.hip"),
            os.path.join(_HERE, "csrc", "vmd_eval.cpp"),
            os.path.join(_HERE, "csrc", "vmd_dcd.cpp"), os.path.join(_HERE, "csrc", "vmd_xdr.cpp"),
-           os.path.join(_HERE, "csrc", "vmd_script.cpp")]
+           os.path.join(_HERE, "csrc", "vmd_script.cpp"), os.path.join(_HERE, "csrc", "vmd_reduce.cpp")]
 HEADERS = [os.path.join(ROOT, "include", "vmd_eval.h"), os.path.join(ROOT, "include", "vmd_hip.h")]
 OUT = os.path.join(_HERE, "libviamd_amd.so")
 
@@ -34,7 +34,7 @@ def up_to_date():
 def build(force=False, verbose=False):
     if not force and up_to_date():
         return OUT
-    cmd = [hipcc()] + FLAGS + ["-I", os.path.join(ROOT, "include"), "-x", "hip"] + SOURCES + ["-o", OUT]
+    cmd = [hipcc()] + FLAGS + ["-I", os.path.join(ROOT, "include"), "-x", "hip"] + SOURCES + ["-ldl", "-o", OUT]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -1206,6 +1206,12 @@ static bool reuse_blocks(vmd_script_eval_t* e, size_t beg, size_t end, std::vect
     return true;
 }
 
+// a sharded device trajectory keeps only its block of frames behind the view; other frames (frame 0 for the SDF reference
+// pose) come through load_frame
+static bool view_holds(bool have_view, const vmd_device_view_t& view, size_t frame) {
+    return have_view && (view.resident_end <= view.resident_beg || (frame >= view.resident_beg && frame < view.resident_end));
+}
+
 // evaluates frames [frame_beg, frame_end) in large batches; returns false on interrupt (empty error) or failure
 static bool process_range(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_trajectory_i* traj, uint32_t frame_beg, uint32_t frame_end) {
     g_last_error.clear();
@@ -1219,13 +1225,16 @@ static bool process_range(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
     if (!upload_static(e, sys)) return false;
 
     vmd_device_view_t view;
+    memset(&view, 0, sizeof(view));
     const bool have_view = traj->device_view && traj->device_view(traj->inst, &view) && view.device == e->device;
+    if (have_view && view.resident_end > view.resident_beg && (frame_beg < view.resident_beg || frame_end > view.resident_end))
+        return vmd_fail("frames [%u, %u) are not resident on this rank (its shard holds [%zu, %zu))", frame_beg, frame_end, view.resident_beg, view.resident_end);
 
     // SDF reference pose: structure 0 at trajectory frame 0 (SPEC S5)
     for (auto& p : e->props) {
         if (p->prop.kind != PROP_SDF || p->ref_pose_ready) continue;
         BatchSrc src;
-        if (!fetch_batch(e, traj, have_view ? &view : nullptr, num_atoms, 0, 1, &src)) return false;
+        if (!fetch_batch(e, traj, view_holds(have_view, view, 0) ? &view : nullptr, num_atoms, 0, 1, &src)) return false;
         KRN_OK(vmd_hip_sdf_ref_pose(e->stream, src.base, src.row_stride, e->stages[0].d_boxes.p, batch_pbc(e->stages[0]), p->d_structs.p, p->d_mass.p,
                                     (int)p->prop.m, p->d_ref_pose.p));
         HIP_OK(hipStreamSynchronize(e->stream));
@@ -1434,16 +1443,17 @@ extern "C" bool vmd_eval_sdf_matrices(vmd_script_eval_t* eval, const char* name,
     const size_t num_atoms = traj->num_atoms(traj->inst);
     if (!check_atoms(e, num_atoms) || !upload_static(e, sys)) return false;
     vmd_device_view_t view;
+    memset(&view, 0, sizeof(view));
     const bool have_view = traj->device_view && traj->device_view(traj->inst, &view) && view.device == e->device;
     BatchSrc src;
     if (!p->ref_pose_ready) {
-        if (!fetch_batch(e, traj, have_view ? &view : nullptr, num_atoms, 0, 1, &src)) return false;
+        if (!fetch_batch(e, traj, view_holds(have_view, view, 0) ? &view : nullptr, num_atoms, 0, 1, &src)) return false;
         KRN_OK(vmd_hip_sdf_ref_pose(e->stream, src.base, src.row_stride, e->stages[0].d_boxes.p, batch_pbc(e->stages[0]), p->d_structs.p, p->d_mass.p,
                                     (int)p->prop.m, p->d_ref_pose.p));
         HIP_OK(hipStreamSynchronize(e->stream));
         p->ref_pose_ready = true;
     }
-    if (!fetch_batch(e, traj, have_view ? &view : nullptr, num_atoms, frame, 1, &src)) return false;
+    if (!fetch_batch(e, traj, view_holds(have_view, view, frame) ? &view : nullptr, num_atoms, frame, 1, &src)) return false;
     const size_t K = p->prop.K;
     DevBuf<double> dM;
     if (!dM.ensure(K * 12) || !p->d_R32.ensure(K * 9) || !p->d_c32.ensure(K * 3)) return false;
@@ -1469,7 +1479,11 @@ extern "C" bool vmd_eval_sdf_matrices(vmd_script_eval_t* eval, const char* name,
 
 struct vmd_devtraj_t {
     size_t num_frames = 0, num_atoms = 0, npad = 0;
-    float* d = nullptr;
+    size_t first = 0, resident = 0;     // frames [first, first + resident) are in HBM (a rank's shard; the whole trajectory otherwise)
+    float* d = nullptr;                 // frame `first`
+    float* d0 = nullptr;                // shards that do not start at frame 0 keep a copy of it: the SDF reference pose is taken there (SPEC S5)
+    bool has(size_t beg, size_t end) const { return (beg >= first && end <= first + resident && beg <= end) || (d0 && beg == 0 && end == 1); }
+    float* frame(size_t f) const { return (d0 && f == 0) ? d0 : d + (f - first) * 3 * npad; }
     int device = 0;
     std::vector<vmd_unitcell_t> cells;
     vmd_trajectory_i iface;
@@ -1479,8 +1493,8 @@ static size_t dt_num_frames(void* inst) { return ((vmd_devtraj_t*)inst)->num_fra
 static size_t dt_num_atoms(void* inst) { return ((vmd_devtraj_t*)inst)->num_atoms; }
 static bool dt_load_frame(void* inst, int64_t idx, vmd_frame_header_t* hdr, float* x, float* y, float* z) {
     vmd_devtraj_t* t = (vmd_devtraj_t*)inst;
-    if (idx < 0 || (size_t)idx >= t->num_frames) return vmd_fail("devtraj: frame %lld out of range", (long long)idx);
-    const float* f = t->d + (size_t)idx * 3 * t->npad;
+    if (idx < 0 || !t->has((size_t)idx, (size_t)idx + 1)) return vmd_fail("devtraj: frame %lld is not resident on this rank", (long long)idx);
+    const float* f = t->frame((size_t)idx);
     if (x) HIP_OK(hipMemcpy(x, f, t->num_atoms * sizeof(float), hipMemcpyDeviceToHost));
     if (y) HIP_OK(hipMemcpy(y, f + t->npad, t->num_atoms * sizeof(float), hipMemcpyDeviceToHost));
     if (z) HIP_OK(hipMemcpy(z, f + 2 * t->npad, t->num_atoms * sizeof(float), hipMemcpyDeviceToHost));
@@ -1489,17 +1503,23 @@ static bool dt_load_frame(void* inst, int64_t idx, vmd_frame_header_t* hdr, floa
 }
 static bool dt_device_view(void* inst, vmd_device_view_t* out) {
     vmd_devtraj_t* t = (vmd_devtraj_t*)inst;
-    out->base = t->d; out->frame_stride = 3 * t->npad; out->row_stride = t->npad; out->cells = t->cells.data(); out->device = t->device;
+    // frame f sits at base + f * frame_stride: for a shard the base lies `first` frames before the allocation and is only ever
+    // used with resident frame indices (the evaluator is handed ranges inside the shard)
+    out->base = t->d - t->first * 3 * t->npad; out->frame_stride = 3 * t->npad; out->row_stride = t->npad; out->cells = t->cells.data(); out->device = t->device;
+    out->resident_beg = t->first; out->resident_end = t->first + t->resident;
     return true;
 }
 
-extern "C" vmd_devtraj_t* vmd_devtraj_create(size_t num_frames, size_t num_atoms) {
+extern "C" vmd_devtraj_t* vmd_devtraj_create_shard(size_t num_frames, size_t frame_beg, size_t frame_end, size_t num_atoms) {
     if (vmd_device_count() <= 0) { vmd_fail("vmd_devtraj_create: no usable HIP device"); return nullptr; }
+    if (frame_beg > frame_end || frame_end > num_frames) { vmd_fail("vmd_devtraj_create_shard: bad frame range"); return nullptr; }
     auto t = std::make_unique<vmd_devtraj_t>();
     t->num_frames = num_frames; t->num_atoms = num_atoms; t->npad = (num_atoms + 63) & ~(size_t)63;
+    t->first = frame_beg; t->resident = frame_end - frame_beg;
     if (hipGetDevice(&t->device) != hipSuccess) { vmd_fail("hipGetDevice failed"); return nullptr; }
-    const size_t bytes = std::max<size_t>(num_frames * 3 * t->npad, 1) * sizeof(float);
+    const size_t bytes = std::max<size_t>(t->resident * 3 * t->npad, 1) * sizeof(float);
     hipError_t err = hipMalloc((void**)&t->d, bytes);
+    if (err == hipSuccess && frame_beg > 0) err = hipMalloc((void**)&t->d0, 3 * t->npad * sizeof(float));
     if (err != hipSuccess) { vmd_fail("vmd_devtraj_create: hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(err)); return nullptr; }
     vmd_unitcell_t none;
     memset(&none, 0, sizeof(none));
@@ -1510,17 +1530,19 @@ extern "C" vmd_devtraj_t* vmd_devtraj_create(size_t num_frames, size_t num_atoms
     t->iface.load_raw = nullptr;
     return t.release();
 }
+extern "C" vmd_devtraj_t* vmd_devtraj_create(size_t num_frames, size_t num_atoms) { return vmd_devtraj_create_shard(num_frames, 0, num_frames, num_atoms); }
 extern "C" void vmd_devtraj_free(vmd_devtraj_t* t) {
     if (!t) return;
     if (t->d) (void)hipFree(t->d);
+    if (t->d0) (void)hipFree(t->d0);
     delete t;
 }
 extern "C" vmd_trajectory_i* vmd_devtraj_interface(vmd_devtraj_t* t) { return t ? &t->iface : nullptr; }
 
 extern "C" bool vmd_devtraj_upload_frame(vmd_devtraj_t* t, size_t frame, const vmd_unitcell_t* cell,
                                          const float* x, const float* y, const float* z) {
-    if (!t || frame >= t->num_frames) return vmd_fail("vmd_devtraj_upload_frame: bad frame");
-    float* f = t->d + frame * 3 * t->npad;
+    if (!t || !t->has(frame, frame + 1)) return vmd_fail("vmd_devtraj_upload_frame: bad frame");
+    float* f = t->frame(frame);
     HIP_OK(hipMemcpy(f, x, t->num_atoms * sizeof(float), hipMemcpyHostToDevice));
     HIP_OK(hipMemcpy(f + t->npad, y, t->num_atoms * sizeof(float), hipMemcpyHostToDevice));
     HIP_OK(hipMemcpy(f + 2 * t->npad, z, t->num_atoms * sizeof(float), hipMemcpyHostToDevice));
@@ -1530,10 +1552,10 @@ extern "C" bool vmd_devtraj_upload_frame(vmd_devtraj_t* t, size_t frame, const v
 
 extern "C" bool vmd_devtraj_upload_atoms(vmd_devtraj_t* t, size_t frame_beg, size_t frame_count, size_t first_atom, size_t atom_count,
                                         const float* xyz /* [frame_count][3][atom_count] */) {
-    if (!t || frame_beg + frame_count > t->num_frames || first_atom + atom_count > t->num_atoms) return vmd_fail("vmd_devtraj_upload_atoms: bad range");
+    if (!t || !t->has(frame_beg, frame_beg + frame_count) || first_atom + atom_count > t->num_atoms) return vmd_fail("vmd_devtraj_upload_atoms: bad range");
     for (size_t f = 0; f < frame_count; ++f)
         for (int c = 0; c < 3; ++c)
-            HIP_OK(hipMemcpyAsync(t->d + (frame_beg + f) * 3 * t->npad + (size_t)c * t->npad + first_atom,
+            HIP_OK(hipMemcpyAsync(t->frame(frame_beg + f) + (size_t)c * t->npad + first_atom,
                                   xyz + (f * 3 + c) * atom_count, atom_count * sizeof(float), hipMemcpyHostToDevice, nullptr));
     HIP_OK(hipDeviceSynchronize());
     return true;
@@ -1541,14 +1563,18 @@ extern "C" bool vmd_devtraj_upload_atoms(vmd_devtraj_t* t, size_t frame_beg, siz
 
 extern "C" bool vmd_devtraj_synth(vmd_devtraj_t* t, uint64_t seed, float L, float sigma, uint32_t n_blob,
                                   size_t frame_beg, size_t frame_end) {
-    if (!t || frame_end > t->num_frames || frame_beg > frame_end) return vmd_fail("vmd_devtraj_synth: bad range");
+    if (!t || !t->has(frame_beg, frame_end)) return vmd_fail("vmd_devtraj_synth: bad range");
     vmd_unitcell_t c;
     memset(&c, 0, sizeof(c));
     c.x = c.y = c.z = L; c.flags = VMD_UNITCELL_PBC_ALL;
     for (size_t f0 = frame_beg; f0 < frame_end; f0 += 1024) {
         const size_t nb = std::min<size_t>(1024, frame_end - f0);
-        KRN_OK(vmd_hip_synth_frames(nullptr, t->d + f0 * 3 * t->npad, 3 * t->npad, t->npad, (int)nb, (uint32_t)f0, seed,
+        KRN_OK(vmd_hip_synth_frames(nullptr, t->frame(f0), 3 * t->npad, t->npad, (int)nb, (uint32_t)f0, seed,
                                     (uint32_t)t->num_atoms, n_blob, L, sigma));
+    }
+    if (t->d0) {    // the shard's copy of frame 0
+        KRN_OK(vmd_hip_synth_frames(nullptr, t->d0, 3 * t->npad, t->npad, 1, 0u, seed, (uint32_t)t->num_atoms, n_blob, L, sigma));
+        t->cells[0] = c;
     }
     HIP_OK(hipDeviceSynchronize());
     for (size_t f = frame_beg; f < frame_end; ++f) t->cells[f] = c;
@@ -1622,7 +1648,8 @@ extern "C" bool vmd_hosttraj_set_cell(vmd_hosttraj_t* t, size_t frame, const vmd
 extern "C" bool vmd_hosttraj_copy_from_device(vmd_hosttraj_t* t, vmd_devtraj_t* src, size_t frame_beg, size_t frame_end) {
     if (!t || !src || frame_end > t->num_frames || frame_end > src->num_frames || src->num_atoms != t->num_atoms) return vmd_fail("vmd_hosttraj_copy_from_device: shape mismatch");
     if (frame_beg >= frame_end) return true;
-    HIP_OK(hipMemcpy(t->h + frame_beg * 3 * t->npad, src->d + frame_beg * 3 * src->npad, (frame_end - frame_beg) * 3 * t->npad * sizeof(float), hipMemcpyDeviceToHost));
+    if (!src->has(frame_beg, frame_end)) return vmd_fail("vmd_hosttraj_copy_from_device: frames are not resident on this rank");
+    HIP_OK(hipMemcpy(t->h + frame_beg * 3 * t->npad, src->frame(frame_beg), (frame_end - frame_beg) * 3 * t->npad * sizeof(float), hipMemcpyDeviceToHost));
     for (size_t f = frame_beg; f < frame_end; ++f) t->cells[f] = src->cells[f];
     return true;
 }

@@ -1,0 +1,192 @@
+// viamd_amd/csrc/vmd_reduce.cpp — the multi-GPU merge behind the C ABI (include/vmd_eval.h "multi-GPU merge").
+//
+// VIAMD evaluates a script from C++ (/root/reference/src/main.cpp:993-1008: pool threads call md_script_eval_frame_range
+// on disjoint frame ranges of ONE eval).  Across GPUs the same thing happens one process per GPU: every rank runs
+// vmd_eval_frame_range on its block of frames, then ONE call - vmd_eval_reduce - sums the integer accumulators of all
+// ranks in place on the device (RCCL all-reduce over xGMI), merges what lives on the host (fp64 normalisation weights,
+// temporal rows, the frame mask) in one packed fp64 all-reduce, and re-derives the float views.  Integer sums make the
+// merged result independent of the rank count.
+//
+// The collective is an interface (vmd_collective_i): vmd_comm_* is its RCCL implementation - librccl is loaded at run
+// time (dlopen of the soname, so a host that already carries an RCCL, e.g. through PyTorch, shares that copy; a plain C++
+// host gets /opt/rocm/lib/librccl.so.1) - and tests plug in a gloo-backed one on the CPU emulator build.
+// This file only uses the public C ABI of the evaluator.
+#include <hip/hip_runtime.h>
+
+#include <dlfcn.h>
+
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "vmd_eval.h"
+
+extern "C" void vmd_set_last_error(const char* msg);
+
+static bool red_fail(const std::string& msg) {
+    vmd_set_last_error(msg.c_str());
+    fprintf(stderr, "[viamd_amd] error: %s\n", msg.c_str());
+    return false;
+}
+
+// ------------------------------------------------------------------------------------------------ RCCL, loaded at run time
+// The handful of RCCL entry points and constants the merge needs (rccl.h: ncclDataType_t ncclUint64 = 5, ncclFloat64 = 8;
+// ncclRedOp_t ncclSum = 0; ncclResult_t ncclSuccess = 0; ncclUniqueId = 128 opaque bytes passed by value).
+namespace {
+struct NcclUniqueId { char internal[VMD_COMM_ID_BYTES]; };
+typedef void* NcclComm;
+struct Rccl {
+    void* handle = nullptr;
+    int (*GetUniqueId)(NcclUniqueId*) = nullptr;
+    int (*CommInitRank)(NcclComm*, int, NcclUniqueId, int) = nullptr;
+    int (*CommDestroy)(NcclComm) = nullptr;
+    int (*CommCount)(const NcclComm, int*) = nullptr;
+    int (*CommUserRank)(const NcclComm, int*) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, NcclComm, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    std::string error;
+};
+Rccl* rccl() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char* n : names) {
+            r.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+            if (r.handle) break;
+        }
+        if (!r.handle) { r.error = std::string("cannot load librccl: ") + (dlerror() ? dlerror() : "?"); return; }
+        auto sym = [&](const char* s) { void* p = dlsym(r.handle, s); if (!p && r.error.empty()) r.error = std::string("librccl lacks ") + s; return p; };
+        r.GetUniqueId = (int (*)(NcclUniqueId*))sym("ncclGetUniqueId");
+        r.CommInitRank = (int (*)(NcclComm*, int, NcclUniqueId, int))sym("ncclCommInitRank");
+        r.CommDestroy = (int (*)(NcclComm))sym("ncclCommDestroy");
+        r.CommCount = (int (*)(const NcclComm, int*))sym("ncclCommCount");
+        r.CommUserRank = (int (*)(const NcclComm, int*))sym("ncclCommUserRank");
+        r.AllReduce = (int (*)(const void*, void*, size_t, int, int, NcclComm, hipStream_t))sym("ncclAllReduce");
+        r.GetErrorString = (const char* (*)(int))sym("ncclGetErrorString");
+    });
+    return &r;
+}
+bool rccl_ok(Rccl* r, int rc, const char* what) {
+    if (rc == 0) return true;
+    return red_fail(std::string(what) + " failed: " + (r->GetErrorString ? r->GetErrorString(rc) : "RCCL error"));
+}
+}  // namespace
+
+struct vmd_comm_t {
+    NcclComm comm = nullptr;
+    bool owned = false;
+    int rank = 0, size = 1;
+    vmd_collective_i iface;
+};
+
+static int comm_rank(void* inst) { return ((vmd_comm_t*)inst)->rank; }
+static int comm_size(void* inst) { return ((vmd_comm_t*)inst)->size; }
+static bool comm_allreduce(void* inst, void* buf, size_t n, int dtype, void* stream) {
+    vmd_comm_t* c = (vmd_comm_t*)inst;
+    Rccl* r = rccl();
+    if (n == 0) return true;
+    return rccl_ok(r, r->AllReduce(buf, buf, n, dtype, /*ncclSum*/ 0, c->comm, (hipStream_t)stream), "ncclAllReduce");
+}
+static bool comm_allreduce_u64(void* inst, uint64_t* buf, size_t n, void* stream) { return comm_allreduce(inst, buf, n, /*ncclUint64*/ 5, stream); }
+static bool comm_allreduce_f64(void* inst, double* buf, size_t n, void* stream) { return comm_allreduce(inst, buf, n, /*ncclFloat64*/ 8, stream); }
+
+static vmd_comm_t* comm_wrap(NcclComm comm, bool owned) {
+    Rccl* r = rccl();
+    vmd_comm_t* c = new vmd_comm_t();
+    c->comm = comm; c->owned = owned;
+    if (!rccl_ok(r, r->CommCount(comm, &c->size), "ncclCommCount") || !rccl_ok(r, r->CommUserRank(comm, &c->rank), "ncclCommUserRank")) {
+        delete c;
+        return nullptr;
+    }
+    c->iface.inst = c;
+    c->iface.rank = comm_rank; c->iface.size = comm_size;
+    c->iface.allreduce_sum_u64 = comm_allreduce_u64; c->iface.allreduce_sum_f64 = comm_allreduce_f64;
+    return c;
+}
+
+extern "C" bool vmd_comm_unique_id(uint8_t id[VMD_COMM_ID_BYTES]) {
+    Rccl* r = rccl();
+    if (!r->error.empty()) return red_fail(r->error);
+    NcclUniqueId u;
+    if (!rccl_ok(r, r->GetUniqueId(&u), "ncclGetUniqueId")) return false;
+    memcpy(id, u.internal, VMD_COMM_ID_BYTES);
+    return true;
+}
+
+extern "C" vmd_comm_t* vmd_comm_create(int nranks, int rank, const uint8_t id[VMD_COMM_ID_BYTES]) {
+    Rccl* r = rccl();
+    if (!r->error.empty()) { red_fail(r->error); return nullptr; }
+    if (nranks < 1 || rank < 0 || rank >= nranks || !id) { red_fail("vmd_comm_create: bad rank / size / id"); return nullptr; }
+    NcclUniqueId u;
+    memcpy(u.internal, id, VMD_COMM_ID_BYTES);
+    NcclComm comm = nullptr;
+    if (!rccl_ok(r, r->CommInitRank(&comm, nranks, u, rank), "ncclCommInitRank")) return nullptr;
+    vmd_comm_t* c = comm_wrap(comm, true);
+    if (!c) r->CommDestroy(comm);
+    return c;
+}
+
+extern "C" vmd_comm_t* vmd_comm_from_nccl(void* nccl_comm) {
+    Rccl* r = rccl();
+    if (!r->error.empty()) { red_fail(r->error); return nullptr; }
+    if (!nccl_comm) { red_fail("vmd_comm_from_nccl: NULL communicator"); return nullptr; }
+    return comm_wrap((NcclComm)nccl_comm, false);
+}
+
+extern "C" void vmd_comm_destroy(vmd_comm_t* c) {
+    if (!c) return;
+    if (c->owned && c->comm) rccl()->CommDestroy(c->comm);
+    delete c;
+}
+
+extern "C" const vmd_collective_i* vmd_comm_collective(vmd_comm_t* c) { return c ? &c->iface : nullptr; }
+extern "C" int vmd_comm_rank(const vmd_comm_t* c) { return c ? c->rank : 0; }
+extern "C" int vmd_comm_size(const vmd_comm_t* c) { return c ? c->size : 1; }
+
+// ------------------------------------------------------------------------------------------------ the merge
+
+extern "C" bool vmd_eval_reduce(vmd_script_eval_t* eval, const vmd_collective_i* coll, void* stream) {
+    if (!eval) return red_fail("vmd_eval_reduce: eval is NULL");
+    if (!coll || !coll->allreduce_sum_u64 || !coll->allreduce_sum_f64) return red_fail("vmd_eval_reduce: incomplete collective interface");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t nviews = vmd_eval_accum_views(eval, nullptr, 0);
+    std::vector<vmd_accum_view_t> views(nviews);
+    vmd_eval_accum_views(eval, views.data(), nviews);
+    // (1) integer accumulators: SUM in place on the evaluator's own device buffers (8 KB per RDF, 16.8 MB per SDF volume)
+    for (const vmd_accum_view_t& v : views)
+        if (v.counts_dev && v.num_counts && !coll->allreduce_sum_u64(coll->inst, v.counts_dev, v.num_counts, s)) return false;
+    // (2) everything that lives on the host travels as ONE fp64 buffer: normalisation weights, temporal rows (zero on the ranks
+    // that did not evaluate the frame; a float survives the trip through fp64 unchanged) and the frame mask (a frame is
+    // evaluated by one rank, so the sum is 0/1; > 0 also covers ranks that evaluated the same frame)
+    const size_t F = vmd_eval_num_frames(eval);
+    size_t total = F;
+    for (const vmd_accum_view_t& v : views) total += (v.weights64 ? v.num_weights : 0) + (v.temporal ? v.num_temporal : 0);
+    std::vector<double> packed(total);
+    size_t off = 0;
+    for (const vmd_accum_view_t& v : views) {
+        if (v.weights64) { memcpy(&packed[off], v.weights64, v.num_weights * sizeof(double)); off += v.num_weights; }
+        if (v.temporal) { for (size_t i = 0; i < v.num_temporal; ++i) packed[off + i] = (double)v.temporal[i]; off += v.num_temporal; }
+    }
+    const uint8_t* mask = vmd_eval_frame_mask(eval);
+    for (size_t f = 0; f < F; ++f) packed[off + f] = mask[f] ? 1.0 : 0.0;
+    double* d_packed = nullptr;
+    if (hipMalloc((void**)&d_packed, total * sizeof(double)) != hipSuccess) return red_fail("vmd_eval_reduce: hipMalloc failed");
+    bool ok = hipMemcpyAsync(d_packed, packed.data(), total * sizeof(double), hipMemcpyHostToDevice, s) == hipSuccess;
+    ok = ok && coll->allreduce_sum_f64(coll->inst, d_packed, total, s);
+    ok = ok && hipMemcpyAsync(packed.data(), d_packed, total * sizeof(double), hipMemcpyDeviceToHost, s) == hipSuccess;
+    ok = ok && hipStreamSynchronize(s) == hipSuccess;       // also: the in-place counts are final before finalize reads them
+    (void)hipFree(d_packed);
+    if (!ok) return red_fail("vmd_eval_reduce: the packed host-side all-reduce failed");
+    off = 0;
+    for (const vmd_accum_view_t& v : views) {
+        if (v.weights64) { memcpy(v.weights64, &packed[off], v.num_weights * sizeof(double)); off += v.num_weights; }
+        if (v.temporal) { for (size_t i = 0; i < v.num_temporal; ++i) v.temporal[i] = (float)packed[off + i]; off += v.num_temporal; }
+    }
+    std::vector<uint8_t> merged(F);
+    for (size_t f = 0; f < F; ++f) merged[f] = packed[off + f] > 0.5 ? 1 : 0;
+    vmd_eval_set_frame_mask(eval, merged.data(), F);
+    return vmd_eval_finalize(eval);
+}

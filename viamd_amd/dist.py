@@ -1,13 +1,19 @@
 """Multi-GPU evaluation: frames are block-sharded over ranks, one process per GPU; every rank
-accumulates integer histograms / volumes for its frames and ONE collective at the end merges them.
+accumulates integer histograms / volumes for its frames and ONE merge at the end combines them.
 
-The collective is torch.distributed (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in CPU tests).
-The reduction runs in place on the evaluator's own device accumulators (zero copy through
-__cuda_array_interface__), sums are integers, so the merged result is bit-identical for any rank count.
+The merge is C++ behind the C ABI (vmd_eval_reduce, viamd_amd/csrc/vmd_reduce.cpp): the u64 accumulators are summed in
+place on the device, the host-side parts in one packed fp64 all-reduce.  This module only supplies the collective:
+  * on the GPU box the library's own RCCL communicator (vmd_comm_create; one per process, created once - rank 0 makes the
+    128-byte id, torch.distributed broadcasts it: that is the only thing torch does for the merge);
+  * in the CPU tests (emulator build, "device" memory is host memory) a vmd_collective_i whose callbacks run
+    torch.distributed all-reduces on the gloo backend.
+Sums are integers, so the merged result is bit-identical for any rank count.
 """
 import ctypes as C
 
 import numpy as np
+
+from . import _lib as L
 
 
 def shard_frames(num_frames, rank, world_size):
@@ -17,60 +23,78 @@ def shard_frames(num_frames, rank, world_size):
     return beg, min(num_frames, beg + per)
 
 
-class _DevArray:
-    """Minimal __cuda_array_interface__ carrier so torch can alias a raw device pointer without copying."""
+class RcclComm:
+    """vmd_comm_t: the library's RCCL communicator of this process (rendezvous of the 128-byte id through torch.distributed)."""
 
-    def __init__(self, ptr, n, typestr):
-        self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+    def __init__(self, lib, group=None):
+        import torch
+        import torch.distributed as dist
+        self.lib = lib
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        ident = np.zeros(L.COMM_ID_BYTES, np.uint8)
+        if rank == 0 and not lib.vmd_comm_unique_id(ident.ctypes.data_as(L.c_uint8_p)):
+            raise RuntimeError(lib.last_error())
+        t = torch.from_numpy(ident)
+        on_gpu = dist.get_backend(group) == "nccl"
+        if on_gpu:
+            t = t.cuda()
+        dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        ident = t.cpu().numpy().copy()
+        self.h = lib.vmd_comm_create(world, rank, ident.ctypes.data_as(L.c_uint8_p))
+        if not self.h:
+            raise RuntimeError(lib.last_error())
+
+    def collective(self):
+        return self.lib.vmd_comm_collective(self.h)
+
+    def close(self):
+        if self.h:
+            self.lib.vmd_comm_destroy(self.h)
+            self.h = None
 
 
-def _alias_counts(view, on_gpu):
-    import torch
-    n = view.num_counts
-    if on_gpu:
-        return torch.as_tensor(_DevArray(view.counts_dev, n, "<i8"), device="cuda")
-    # emulator build (tests only): "device" memory is host memory
-    buf = (C.c_int64 * n).from_address(view.counts_dev)
-    return torch.from_numpy(np.ctypeslib.as_array(buf))
+class TorchCollective:
+    """vmd_collective_i over torch.distributed for the CPU tests: buffers the evaluator calls "device" are host memory in the
+    emulator build, so the callbacks alias them as numpy arrays and all-reduce those (gloo)."""
+
+    def __init__(self, group=None):
+        import torch
+        import torch.distributed as dist
+
+        def allreduce(ptr, n, ctype, view):
+            buf = (ctype * n).from_address(ptr)
+            t = torch.from_numpy(np.ctypeslib.as_array(buf).view(view))
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+            return True
+
+        self._cb = (L.COMM_INT_FN(lambda _: dist.get_rank(group)), L.COMM_INT_FN(lambda _: dist.get_world_size(group)),
+                    L.ALLREDUCE_U64_FN(lambda _, p, n, s: allreduce(p, n, C.c_int64, np.int64)),      # two's complement sum == unsigned sum
+                    L.ALLREDUCE_F64_FN(lambda _, p, n, s: allreduce(p, n, C.c_double, np.float64)))
+        self.c = L.CollectiveI(None, *self._cb)
+
+    def collective(self):
+        return C.byref(self.c)
+
+
+_comms = {}
 
 
 def reduce_eval(ev, group=None):
-    """Merge the accumulators of all ranks into every rank's evaluator, then refresh its host views.
-
-    u64 counts (RDF bins, SDF voxels): SUM as int64 (two's complement sum == unsigned sum), in place on the device;
-    fp64 weights, temporal rows (zero for frames a rank did not evaluate) and the frame mask: one packed fp64 SUM."""
-    import torch
+    """Merge the accumulators of all ranks into every rank's evaluator (vmd_eval_reduce), then its host views are current."""
     import torch.distributed as dist
 
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return          # nothing to merge; frame_range already refreshed the host views
-    on_gpu = dist.get_backend(group) == "nccl"
-    dev = "cuda" if on_gpu else "cpu"
-    keep, host_parts = [], []
-    for v in ev.accum_views():
-        if v.counts_dev and v.num_counts:
-            t = _alias_counts(v, on_gpu)
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)      # in place on the evaluator's device accumulators
-            keep.append(t)
-        for ptr, n, ctype in ((v.weights64, v.num_weights, C.c_double), (v.temporal, v.num_temporal, C.c_float)):
-            if ptr and n:
-                host_parts.append(np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ctype)), shape=(n,)))
-    # everything that lives on the host (fp64 weights, temporal rows, the frame mask) travels as ONE fp64 buffer: a frame is
-    # evaluated by one rank, so SUM of the masks is 0/1 (> 0 is taken, which also covers ranks that evaluated the same frames)
-    mask = np.array(ev.frame_mask(), dtype=np.uint8, copy=True)
-    packed = np.concatenate([h.astype(np.float64, copy=False).ravel() for h in host_parts] + [mask.astype(np.float64)])
-    t = torch.from_numpy(packed)
-    if on_gpu:
-        g = t.to(dev)
-        dist.all_reduce(g, op=dist.ReduceOp.SUM, group=group)
-        t = g.cpu()
-        torch.cuda.synchronize()                                      # the in-place counts are final before finalize() reads them
-    else:
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
-    merged = t.numpy()
-    off = 0
-    for h in host_parts:
-        h[...] = merged[off:off + h.size].astype(h.dtype)
-        off += h.size
-    ev.set_frame_mask((merged[off:] > 0.5).astype(np.uint8))
-    ev.finalize()
+    key = (id(ev.lib), group)
+    if key not in _comms:
+        _comms[key] = RcclComm(ev.lib, group) if dist.get_backend(group) == "nccl" else TorchCollective(group)
+    if not ev.lib.vmd_eval_reduce(ev.h, _comms[key].collective(), None):
+        raise RuntimeError(ev.lib.last_error())
+
+
+def close_comms():
+    """Destroy the cached RCCL communicators (before torch.distributed.destroy_process_group)."""
+    for c in _comms.values():
+        if hasattr(c, "close"):
+            c.close()
+    _comms.clear()

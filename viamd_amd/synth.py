@@ -67,11 +67,17 @@ def blob_trajectory(seed, n_blob, box, frames, atoms_per_residue=10, chunk=512):
         yield f0, out
 
 
-def make_device_trajectory(V, seed, n_atoms, box, frames, n_blob=0, sigma=0.05, lib=None):
-    """DeviceTrajectory of the synthetic system, generated in place in HBM."""
-    traj = V.DeviceTrajectory(frames, n_atoms, lib=lib)
+def make_device_trajectory(V, seed, n_atoms, box, frames, n_blob=0, sigma=0.05, lib=None, shard=None):
+    """DeviceTrajectory of the synthetic system, generated in place in HBM.  shard = (beg, end): only that block of frames
+    (and frame 0) is resident - one rank's part of a frame-sharded trajectory, same content as the whole one."""
+    traj = V.DeviceTrajectory(frames, n_atoms, lib=lib, shard=shard)
     traj.synth(seed, box, sigma, n_blob=n_blob)
     if n_blob:
-        for f0, xyz in blob_trajectory(seed, n_blob, box, frames):
-            traj.upload_atoms(f0, 0, xyz)
+        beg, end = (0, frames) if shard is None else shard
+        for f0, xyz in blob_trajectory(seed, n_blob, box, end):          # a sequential random walk: generated from frame 0 on
+            lo, hi = max(f0, beg), min(f0 + xyz.shape[0], end)
+            if lo < hi:
+                traj.upload_atoms(lo, 0, xyz[lo - f0:hi - f0])
+            if f0 == 0 and beg > 0:
+                traj.upload_atoms(0, 0, xyz[:1])
     return traj

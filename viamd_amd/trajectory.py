@@ -110,9 +110,12 @@ class PinnedHostTrajectory:
 class DeviceTrajectory:
     """Trajectory resident in HBM as float[F][3][npad] (SoA per frame, npad multiple of 64) — SURVEY.md 8d."""
 
-    def __init__(self, num_frames, num_atoms, lib=None):
+    def __init__(self, num_frames, num_atoms, lib=None, shard=None):
+        """shard = (frame_beg, frame_end): this rank keeps only that block of the `num_frames` frames resident (plus frame 0,
+        where the SDF reference pose is taken); frame indices stay global."""
         self.lib = lib or L.default_lib()
-        self.h = self.lib.vmd_devtraj_create(int(num_frames), int(num_atoms))
+        self.first, self.last = (0, int(num_frames)) if shard is None else (int(shard[0]), int(shard[1]))
+        self.h = self.lib.vmd_devtraj_create_shard(int(num_frames), self.first, self.last, int(num_atoms))
         if not self.h:
             raise VmdError(self.lib.last_error())
         self._num_frames, self._num_atoms = int(num_frames), int(num_atoms)
@@ -160,7 +163,8 @@ class DeviceTrajectory:
 
     def synth(self, seed, L_box, sigma=0.05, n_blob=0, frame_beg=0, frame_end=None):
         """Fill frames with the seeded synthetic water box of SURVEY.md 8d (generated on the device)."""
-        frame_end = self._num_frames if frame_end is None else frame_end
+        frame_beg = max(int(frame_beg), self.first)
+        frame_end = self.last if frame_end is None else frame_end
         if not self.lib.vmd_devtraj_synth(self.h, int(seed), float(L_box), float(sigma), int(n_blob), int(frame_beg), int(frame_end)):
             raise VmdError(self.lib.last_error())
 
