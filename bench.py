@@ -7,9 +7,14 @@ before the timed region (trajectories are pre-staged).  N > 1: one
 (torch.distributed / RCCL), every rank owns its own block of frames (weak scaling), one all-reduce per step
 merges the integer accumulators.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c3d|c4|c5] [--frames F]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c3d|c4|c5] [--frames F] [--scaling weak|strong]
 
-Default (no flags): N = 1, workload c2 = BASELINE.json configs[1] (100k-atom box, 1k frames, O-O RDF r_cut 12 A).
+Default (no flags): N = 1, workload c3 = BASELINE.json configs[2], the configuration the metric and north_star are quoted on
+(1M-atom box, 1k frames, all-heavy-atom RDF r_cut 12 A; 12 GB resident).  At N = 1 the same JSON line carries a `secondary`
+block with short runs of the other single-GPU configurations (c2 = configs[1], c4 = configs[3], c5 = configs[4]): value,
+ms_per_step, dominant-kernel time, kernel-level and step-level HBM fraction each.
+--scaling strong: the workload's frames are block-sharded over the ranks (configs[3]: 10 000 frames / N) instead of every
+rank owning its own frames; either way ONE vmd_eval_reduce (RCCL, C++ behind the ABI) merges per step.
 """
 import argparse
 import ctypes as C
@@ -24,11 +29,16 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0                    # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-VALU_PEAK_WINST_S = 256 * 4 * 2.4e9 / 4  # 256 CUs x 4 SIMDs, one wave64 VALU instruction per 4 cycles at 2.4 GHz
+# VALU issue peak: measured, not assumed - scripts/valu_calib.hip (profiles/r02_valu_calibration.txt): cycles per wave64
+# instruction per SIMD for plain and packed fp32 ops at 8 waves/SIMD.  VALU_CYCLES_PER_INST is the figure for the pair
+# kernel's own instruction mix (the "filter + push" row of that table), so frac = 1 means "as fast as that stream runs alone".
+VALU_CYCLES_PER_INST = 4.0
+VALU_CLOCK_HZ = 2.4e9
+VALU_PEAK_WINST_S = 256 * 4 * VALU_CLOCK_HZ / VALU_CYCLES_PER_INST
 
 WORKLOADS = {
     # SURVEY.md 8d.  frames = frames resident per GPU and evaluated per step.
-    "c2": dict(atoms=100002, blob=0, box=100.0, frames=1000, seed=2, steps=20, kernel="rdf_pencil",
+    "c2": dict(atoms=100002, blob=0, box=100.0, frames=1000, seed=2, steps=20, sec_steps=10, kernel="rdf_pencil",
                script="g = rdf(element('O'), element('O'), 12.0);",
                desc="BASELINE configs[1]: synthetic 100002-atom periodic water box, 1000 frames, O-O RDF r_cut=12 A, 1024 bins"),
     "c3": dict(atoms=1000002, blob=0, box=215.443, frames=1000, seed=3, steps=3, kernel="rdf_pencil",
@@ -37,10 +47,10 @@ WORKLOADS = {
     "c3d": dict(atoms=1000002, blob=0, box=215.443, frames=200, seed=3, steps=3, kernel="rdf_pencil",
                 script="g = rdf(all, all, 12.0);",
                 desc="SURVEY 8d C3-dense: synthetic 1000002-atom box, every atom counted as heavy (7.24e8 ordered pairs per frame), RDF r_cut=12 A"),
-    "c4": dict(atoms=100001, blob=2000, box=100.0, frames=2000, seed=4, steps=5, kernel="sdf_scatter",
+    "c4": dict(atoms=100001, blob=2000, box=100.0, frames=10000, seed=4, steps=5, sec_steps=3, kernel="sdf_scatter",
                script="s = residue(5:11); v = sdf(s, element('O') and water, 10.0);",
-               desc="BASELINE configs[3]: 100001-atom solvated protein-like blob, SDF 128^3 around 7 residues + reference-frame tracking"),
-    "c5": dict(atoms=1001999, blob=2000, box=215.443, frames=500, seed=5, steps=3, kernel="rdf_pencil",
+               desc="BASELINE configs[3]: 100001-atom solvated protein-like blob, 10000 frames, SDF 128^3 around 7 residues + reference-frame tracking"),
+    "c5": dict(atoms=1001999, blob=2000, box=215.443, frames=500, seed=5, steps=3, sec_steps=2, kernel="rdf_pencil",
                script=("goo = rdf(element('O') and water, element('O') and water, 12.0);"
                        "goh = rdf(element('O') and water, element('H') and water, 12.0);"
                        "ghv = rdf(not element('H'), not element('H'), 12.0);"
@@ -147,79 +157,50 @@ def cpu_baseline(name, w, topo, info):
             "host": {"logical_cpus": logical, "physical_cores": physical, "cgroup_quota_cores": quota}}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=None)
-    ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
-    ap.add_argument("--frames", type=int, default=None, help="frames resident per GPU (default: per workload)")
-    ap.add_argument("--variant", type=int, default=0)
-    ap.add_argument("--batch", type=int, default=0)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--opt", action="append", default=[], help="library tuning knob key=value (vmd_set_option)")
-    ap.add_argument("--tilt", default=None, help="xy,xz,yz in Angstrom: evaluate in a sheared (triclinic) cell of the same volume")
-    ap.add_argument("--traj", default="device", choices=["device", "pinned", "dcd", "xtc", "trr"],
-                    help="device: frames resident in HBM (the metric); pinned: frames in pinned host memory, PCIe-inclusive; "
-                         "dcd / xtc / trr: frames decoded from a trajectory file on disk by the native readers "
-                         "(file -> decode on host threads -> pinned staging -> PCIe); xtc is lossy (0.01 A grid)")
-    args = ap.parse_args()
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N ...")
-        args.gpus = world
-
+def run_workload(name, args, ctx, steps, warmup, frames=None, with_cpu=False, opts=()):
+    """One workload end to end: synthesise the (rank's) trajectory in HBM, compile the script, W untimed + K timed steps
+    bracketed by barrier + device sync, max over ranks.  Returns the result dict (rank 0: complete)."""
     import torch
-    import viamd_amd as V
-    from viamd_amd import script, synth
-    from viamd_amd.dist import reduce_eval
-    lib = V.default_lib()                       # hipcc-built library or ImportError: there is no fallback
-    if lib.vmd_device_count() <= 0:
-        raise SystemExit("bench.py needs a HIP device")
-    torch.cuda.set_device(local_rank)
-    lib.vmd_set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-
-    w = dict(WORKLOADS[args.workload])
-    frames = args.frames or w["frames"]
-    steps = args.steps if args.steps is not None else w["steps"]
-    warmup = args.warmup if args.warmup is not None else 2
+    V, lib, script, synth, reduce_eval, dist = ctx["V"], ctx["lib"], ctx["script"], ctx["synth"], ctx["reduce_eval"], ctx["dist"]
+    world, rank = ctx["world"], ctx["rank"]
+    w = dict(WORKLOADS[name])
+    F = frames or w["frames"]
+    strong = args.scaling == "strong"
     lib.vmd_set_option(b"rdf_variant", args.variant)
-    for kv in args.opt:
+    for kv in opts:
         k, v = kv.split("=")
-        assert lib.vmd_set_option(k.encode(), int(v)) != -1 or True
+        if lib.vmd_set_option(k.encode(), int(v)) == -1:
+            raise SystemExit(f"--opt {k}: unknown option")
     if args.batch:
         lib.vmd_set_option(b"batch_frames", args.batch)
 
-    # synthetic trajectory of this rank, generated in HBM; every rank gets its own seed -> its own block of frames
+    # weak: every rank owns F frames of its own (own seed); strong: the F frames of ONE trajectory are block-sharded
     t0 = time.perf_counter()
-    traj = synth.make_device_trajectory(V, w["seed"] + 1000 * rank, w["atoms"], w["box"], frames, w["blob"])
+    if strong:
+        from viamd_amd.dist import shard_frames
+        beg, end = shard_frames(F, rank, world)
+        traj = synth.make_device_trajectory(V, w["seed"], w["atoms"], w["box"], F, w["blob"], shard=(beg, end))
+    else:
+        beg, end = 0, F
+        traj = synth.make_device_trajectory(V, w["seed"] + 1000 * rank, w["atoms"], w["box"], F, w["blob"])
     topo = synth.water_box_topology(w["atoms"], w["blob"])
     cell = V.make_unitcell(w["box"])
     if args.tilt:
         cell = V.make_unitcell(w["box"], tilt=tuple(float(t) for t in args.tilt.split(",")))
-        traj.set_cell(cell)
+        traj.set_cell(cell, beg, end)
         w["desc"] += f", sheared cell (tilt {args.tilt})"
     if args.traj == "pinned":                   # PCIe-inclusive variant: every batch is DMA'd from host memory
         dev_traj = traj
-        traj = V.PinnedHostTrajectory(frames, w["atoms"])
-        traj.copy_from_device(dev_traj)
+        traj = V.PinnedHostTrajectory(F, w["atoms"])
+        traj.copy_from_device(dev_traj, beg, end)
         dev_traj.close()
     elif args.traj in ("dcd", "xtc", "trr"):    # end to end from a trajectory file (page cache after the first pass)
         import tempfile
         dev_traj = traj
-        host = V.PinnedHostTrajectory(frames, w["atoms"])
+        host = V.PinnedHostTrajectory(F, w["atoms"])
         host.copy_from_device(dev_traj)
         dev_traj.close()
-        path = os.path.join(tempfile.gettempdir(), f"viamd_amd_bench_{args.workload}_{rank}.{args.traj}")
+        path = os.path.join(tempfile.gettempdir(), f"viamd_amd_bench_{name}_{rank}.{args.traj}")
         {"dcd": V.write_dcd, "xtc": V.write_xtc, "trr": V.write_trr}[args.traj](path, host, cell)
         host.close()
         traj = V.DcdTrajectory(path) if args.traj == "dcd" else V.XdrTrajectory(path)
@@ -227,13 +208,13 @@ def main():
     gen_s = time.perf_counter() - t0
 
     ir, info = script.compile_script(w["script"], topo)
-    ev = V.ScriptEval(frames, ir)
+    ev = V.ScriptEval(F, ir)
     sysm = V.MolSystem(w["atoms"], mass=topo.mass, unitcell=cell)
 
     def step():
         ev.clear_data()
-        assert ev.frame_range(sysm, traj, 0, frames)
-        reduce_eval(ev)                          # RCCL all-reduce of the integer accumulators (no-op at N = 1)
+        assert ev.frame_range(sysm, traj, beg, end)
+        reduce_eval(ev)                          # vmd_eval_reduce over RCCL: ONE merge of the accumulators per step (no-op at N = 1)
 
     for _ in range(warmup):
         step()
@@ -255,10 +236,12 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # after the merge every rank holds the counts of all ranks' frames
     hits_per_step = sum(int(ev.property_data(n).counts.sum()) for n, d in info.items() if d["kind"] == "rdf")
     voxel_hits = sum(int(ev.property_data(n).counts.sum()) for n, d in info.items() if d["kind"] == "sdf")
-    total_frames = steps * frames * world
-    value = total_frames / elapsed
+    frames_per_step = F if strong else F * world          # whole job
+    value = steps * frames_per_step / elapsed
+    local_frames = end - beg
 
     kernel_ms, kernel_launches = {}, {}
     for k in ("rdf_pencil", "rdf_brute", "cells_build", "sdf_align", "sdf_scatter", "distance"):
@@ -269,14 +252,16 @@ def main():
     dom = w["kernel"]
     nl = max(kernel_launches.get(dom, 0), 1)
     t_launch = kernel_ms.get(dom, 0.0) / nl * 1e-3
-    n_rdf = max(1, sum(1 for d in info.values() if d["kind"] == "rdf")) if dom == "rdf_pencil" else 1
-    frames_per_launch = steps * frames * n_rdf / nl      # one pencil launch handles one RDF property of one frame batch
+    nbt = C.c_uint64(0)
+    lib.vmd_profile_ms(b"batches", C.byref(nbt))             # frame batches evaluated in the timed region
+    frames_per_launch = steps * local_frames / max(1, nbt.value)      # one launch of the dominant kernel covers one frame batch
     alg_bytes = 12.0 * w["atoms"] * frames_per_launch      # 12*N bytes per frame, x frames in one launch
     achieved = alg_bytes / t_launch / 1e9 if t_launch > 0 else 0.0
+    step_gbs = 12.0 * w["atoms"] * local_frames * steps / elapsed / 1e9       # the same bytes against the whole timed region (this rank)
 
     traffic, traffic_src, valu = None, None, None
     try:
-        pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))[args.workload]
+        pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))[name]
         k = pt["kernels"]["k_" + dom]
         # the guide's gfx950 correction: FETCH_SIZE counts half the bytes of a streaming read; WRITE_SIZE is 1:1.  Both are
         # confirmed on known byte counts in this code base (k_synth writes 12*N*F bytes -> WRITE_SIZE matches; k_sdf_scatter
@@ -284,48 +269,121 @@ def main():
         per_frame = k["hbm_bytes_per_launch_read_x2"] / pt["frames_per_launch"]
         traffic = per_frame * frames_per_launch
         if "valu_insts_per_launch" in k and t_launch > 0:
-            # the roofline that actually binds the pair kernel: wave64 VALU instructions issued per second against
-            # 1024 SIMDs x 2.4 GHz / 4 cycles per instruction; instruction count from the PMC pass
             per_frame_insts = k["valu_insts_per_launch"] / pt["frames_per_launch"]
             rate = per_frame_insts * frames_per_launch / t_launch
             valu = {"insts_per_frame": per_frame_insts, "achieved": rate, "peak": VALU_PEAK_WINST_S, "unit": "wave64 VALU instructions/s",
-                    "frac": rate / VALU_PEAK_WINST_S, "source": f"SQ_INSTS_VALU, profiles/pmc_traffic.json ({pt['source']})"}
+                    "frac": rate / VALU_PEAK_WINST_S, "cycles_per_inst_assumed": VALU_CYCLES_PER_INST,
+                    "source": f"SQ_INSTS_VALU, profiles/pmc_traffic.json ({pt['source']}); peak: profiles/r02_valu_calibration.txt"}
         traffic_src = (f"profiles/pmc_traffic.json ({pt['source']}): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, "
                        f"(2 x FETCH_SIZE + WRITE_SIZE) KiB*1024 per frame x frames_per_launch; uncorrected: "
                        f"{k['hbm_bytes_per_frame_raw'] * frames_per_launch:.4g}")
     except Exception:
         pass
+    out = {
+        "metric": "trajectory frames/s for RDF+SDF eval (BASELINE.json metric; atom-pairs/s in pairs_per_s)",
+        "value": value, "unit": "frames/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": w["desc"], "name": name, "script": w["script"], "atoms": w["atoms"],
+                   "frames_per_step": frames_per_step, "frames_per_step_per_gpu": local_frames,
+                   "parallelism": (f"frames block-sharded x{world} ({args.scaling} scaling), one vmd_eval_reduce (RCCL all-reduce in place on the "
+                                   f"device accumulators) per step"), "rdf_variant": args.variant,
+                   "trajectory": {"device": "resident in HBM", "pinned": "pinned host memory, DMA per batch (PCIe-inclusive)",
+                                  "dcd": "DCD file, native reader -> pinned staging -> DMA (file- and PCIe-inclusive)",
+                                  "xtc": "GROMACS XTC file (compressed, 0.01 A grid), native decoder on host threads -> pinned staging -> DMA",
+                                  "trr": "GROMACS TRR file, native reader -> pinned staging -> DMA"}[args.traj]},
+        "pairs_per_s": hits_per_step * steps / elapsed,
+        "voxel_hits_per_s": voxel_hits * steps / elapsed,
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                     "kernel": "k_" + dom, "avg_launch_ms": t_launch * 1e3, "launches": nl,
+                     "algorithmic_bytes_per_launch": alg_bytes, "frames_per_launch": frames_per_launch, "valu": valu,
+                     "step_level": {"achieved": step_gbs, "frac": step_gbs / HBM_PEAK_GBS,
+                                    "note": "12*N bytes x frames of this rank / wall time of the timed region (all kernels, launches, host work)"},
+                     "note": ("k_rdf_pencil is VALU-issue bound, not HBM bound (DESIGN.md 3.1/5): achieved is the brief's "
+                              "12*N*frames/launch-time figure" if dom == "rdf_pencil" else "HBM stream kernel")},
+        "kernel_ms": dict(kernel_ms, timed_region=elapsed * 1e3),
+        "synth_s": gen_s,
+    }
+    if args.traj == "xtc":
+        # > 0 only with --opt xtc_device_decode=1: the compressed frames crossed PCIe and were decompressed by k_xtc_decode
+        out["config"]["frames_decompressed_on_device_per_step"] = ev.frames_device_decoded()
+    ev.close()
+    traj.close() if hasattr(traj, "close") else None
+    if with_cpu and rank == 0:
+        out["cpu_baseline"] = cpu_baseline(name, w, topo, info)
+        out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--frames", type=int, default=None, help="frames per GPU (weak) / in total (strong); default: per workload")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: every rank owns `frames` frames of its own; strong: the workload's frames are block-sharded over the ranks")
+    ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--batch", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the short c2 / c4 / c5 runs of the default N = 1 line")
+    ap.add_argument("--opt", action="append", default=[], help="library tuning knob key=value (vmd_set_option)")
+    ap.add_argument("--tilt", default=None, help="xy,xz,yz in Angstrom: evaluate in a sheared (triclinic) cell of the same volume")
+    ap.add_argument("--traj", default="device", choices=["device", "pinned", "dcd", "xtc", "trr"],
+                    help="device: frames resident in HBM (the metric); pinned: frames in pinned host memory, PCIe-inclusive; "
+                         "dcd / xtc / trr: frames decoded from a trajectory file on disk by the native readers "
+                         "(file -> decode on host threads -> pinned staging -> PCIe); xtc is lossy (0.01 A grid)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N ...")
+        args.gpus = world
+
+    import torch
+    import viamd_amd as V
+    from viamd_amd import script, synth
+    from viamd_amd.dist import close_comms, reduce_eval
+    lib = V.default_lib()                       # hipcc-built library or ImportError: there is no fallback
+    if lib.vmd_device_count() <= 0:
+        raise SystemExit("bench.py needs a HIP device")
+    torch.cuda.set_device(local_rank)
+    lib.vmd_set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    ctx = dict(V=V, lib=lib, script=script, synth=synth, reduce_eval=reduce_eval, dist=dist, world=world, rank=rank)
+
+    w = WORKLOADS[args.workload]
+    steps = args.steps if args.steps is not None else w["steps"]
+    warmup = args.warmup if args.warmup is not None else 2
+    out = run_workload(args.workload, args, ctx, steps, warmup, frames=args.frames, with_cpu=(world == 1 and not args.no_cpu_baseline),
+                       opts=args.opt)
+    # the other single-GPU configurations of BASELINE.json, short runs in the same line (N = 1, default invocation only)
+    if world == 1 and not args.no_secondary and args.workload == "c3" and args.traj == "device" and not args.frames:
+        sec = {}
+        for nm in ("c2", "c4", "c5"):
+            r = run_workload(nm, args, ctx, WORKLOADS[nm]["sec_steps"], 1, opts=args.opt)
+            rf = r["roofline"]
+            sec[nm] = {"workload": r["config"]["workload"], "value": r["value"], "unit": "frames/s", "steps": r["steps"], "warmup": r["warmup"],
+                       "ms_per_step": r["ms_per_step"], "frames_per_step": r["config"]["frames_per_step"],
+                       "pairs_per_s": r["pairs_per_s"], "voxel_hits_per_s": r["voxel_hits_per_s"], "kernel_ms": r["kernel_ms"],
+                       "roofline": {"bound": "hbm", "kernel": rf["kernel"], "avg_launch_ms": rf["avg_launch_ms"], "launches": rf["launches"],
+                                    "achieved": rf["achieved"], "peak": rf["peak"], "unit": rf["unit"], "frac": rf["frac"],
+                                    "frames_per_launch": rf["frames_per_launch"], "traffic": rf["traffic"],
+                                    "step_level": rf["step_level"], "valu": rf["valu"]}}
+        out["secondary"] = sec
     if rank == 0:
-        out = {
-            "metric": "trajectory frames/s for RDF+SDF eval (BASELINE.json metric; atom-pairs/s in pairs_per_s)",
-            "value": value, "unit": "frames/s", "n_gpus": world, "steps": steps, "warmup": warmup,
-            "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": w["desc"], "script": w["script"], "atoms": w["atoms"], "frames_per_step_per_gpu": frames,
-                       "parallelism": f"frames sharded x{world}, one RCCL all-reduce per step", "rdf_variant": args.variant,
-                       "trajectory": {"device": "resident in HBM", "pinned": "pinned host memory, DMA per batch (PCIe-inclusive)",
-                                      "dcd": "DCD file, native reader -> pinned staging -> DMA (file- and PCIe-inclusive)",
-                                      "xtc": "GROMACS XTC file (compressed, 0.01 A grid), native decoder on host threads -> pinned staging -> DMA",
-                                      "trr": "GROMACS TRR file, native reader -> pinned staging -> DMA"}[args.traj]},
-            "pairs_per_s": hits_per_step * steps / elapsed,
-            "voxel_hits_per_s": voxel_hits * steps / elapsed,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "k_" + dom, "avg_launch_ms": t_launch * 1e3, "launches": nl,
-                         "algorithmic_bytes_per_launch": alg_bytes, "frames_per_launch": frames_per_launch, "valu": valu,
-                         "note": ("k_rdf_pencil is VALU-issue bound, not HBM bound (DESIGN.md 3.1/5): achieved is the brief's "
-                                  "12*N*frames/launch-time figure" if dom == "rdf_pencil" else "HBM stream kernel")},
-            "kernel_ms": dict(kernel_ms, timed_region=elapsed * 1e3),
-            "synth_s": gen_s,
-        }
-        if args.traj == "xtc":
-            # > 0 only with --opt xtc_device_decode=1: the compressed frames crossed PCIe and were decompressed by k_xtc_decode
-            out["config"]["frames_decompressed_on_device_per_step"] = ev.frames_device_decoded()
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.workload, w, topo, info)
-            out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
         print(json.dumps(out))
     if dist:
+        close_comms()
         dist.destroy_process_group()
 
 

@@ -1361,6 +1361,7 @@ static bool process_range(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
         }
         HIP_OK(hipStreamSynchronize(e->stream));
         e->prof.resolve();
+        if (g_prof_on) { std::lock_guard<std::mutex> l(g_prof_mtx); g_prof["batches"].launches += 1; }
         toff = 0;
         for (auto& p : e->props) {
             if (p->prop.kind != PROP_DIST) continue;
