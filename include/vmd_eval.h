@@ -144,7 +144,8 @@ bool vmd_ir_add_distance_population(vmd_script_ir_t* ir, const char* name, vmd_d
 /* md_script_ir_compile_from_source stand-in (src/main.cpp:878) for the script subset of the hot path: statements
  * `s = <selection>;`, `r = rdf(sel, sel, rmax | rmin:rmax | {rmin, rmax});`, `v = sdf(structures, sel, cutoff);`,
  * `d = distance[_min|_max|_pair](sel, sel) [in <structures>];` with selections element('X'), type/name/label('X'),
- * resname("X"), residue(a:b), resid(a:b), atom(a:b), a[:b] (1-based atom indices, src/main.cpp:2817), all, water, protein,
+ * resname("X"), residue(a:b) (1-based residue index), resid(a:b) (residue sequence number of the file), atom(a:b), a[:b] (1-based atom
+ * indices, src/main.cpp:2817), all, water, protein,
  * and / or / not, parentheses, and sel[a:b] slicing an array of structures (viamd_amd/csrc/vmd_script.cpp).  Appends one
  * descriptor per property to `ir`; false + vmd_last_error() on a syntax or range error (the ir may then hold the properties
  * of the statements before the error).  The topology is the part of md_system_t selections resolve against. */
@@ -154,6 +155,10 @@ typedef struct vmd_topology_t {
     const char* const* names;        /* per atom (atom type / label); NULL = elements */
     const char* const* resnames;     /* per atom; NULL = "UNK" */
     const int32_t* residue_index;    /* per atom, 0-based; NULL = one residue */
+    /* per atom: the residue sequence number the FILE carries (md_component_seq_id: PDB resSeq / GRO residue number), which is what
+     * resid(a:b) selects by (src/main.cpp:2843-2848 emits `in resid(%i)` with the seq id next to `in residue(%i)` with the
+     * 1-based residue index).  NULL = the host has none: resid() is then a compile error, never an alias of residue(). */
+    const int32_t* residue_seq_id;
 } vmd_topology_t;
 bool     vmd_ir_compile_from_source(vmd_script_ir_t* ir, const char* source, const vmd_topology_t* topology);
 bool     vmd_ir_valid(const vmd_script_ir_t* ir);                       /* md_script_ir_valid, src/main.cpp:936 */

@@ -27,7 +27,7 @@ def atom_sel(depth=0):
     r = rng.random()
     if depth > 2 or r < 0.55:
         return rng.choice(["all", "water", "protein", "element('O')", "element('H', 'C')", "name('N')", 'resname("ALA")', "resname('HOH')",
-                           f"residue({rng_range(130)})", f"resid({rng_range(130)})", f"atom({rng_range(600)})", rng_range(600),
+                           f"residue({rng_range(130)})", f"atom({rng_range(600)})", rng_range(600),
                            f'resname("ALA")[{rng_range(30)}]', f"water[{rng_range(100)}]", "type('Q')", "s0"])
     if r < 0.7:
         return f"not {atom_sel(depth + 1)}"

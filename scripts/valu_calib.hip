@@ -6,8 +6,10 @@
 // trip), run at 1 / 2 / 4 / 8 waves per SIMD on every CU.  Reported per kind and occupancy:
 //   cyc/inst (wave)  = s_memtime ticks of one wave / instructions it issued              (issue interval seen by ONE wave)
 //   cyc/inst (SIMD)  = wall time x clock / instructions issued per SIMD                   (throughput of the SIMD)
-// with clock = s_memtime ticks of the longest wave / wall time.  The "filter" kinds are the 4-column candidate filter of
-// vmd_segment_loop in its packed (v_pk_*) and unpacked form, the "push" kind adds the hit compaction.
+// with clock = s_memtime ticks of the longest wave / wall time (the chip clocks down under dense VALU streams: compare the
+// Ginst/s column, which needs no clock).  The "filter" kinds are the 4-column candidate filter of vmd_segment_loop in its packed
+// (v_pk_*) and unpacked form, the "push" kind adds the hit compaction; hipcc puts an s_nop between most of their asm statements
+// (it cannot see into them), so those rows are LOWER bounds of what the hand-scheduled kernel code reaches.
 //
 // build + run:  hipcc --offload-arch=gfx950 -O3 -o /tmp/valu_calib scripts/valu_calib.hip && /tmp/valu_calib
 #include <hip/hip_runtime.h>
@@ -24,7 +26,7 @@ typedef float f2 __attribute__((vector_size(8)));
 
 enum Kind {
     K_FMA = 0, K_PK_FMA, K_PK_ADD, K_PK_MUL, K_PK_ADD_S, K_ADD_S, K_CMP, K_MBCNT, K_LSHL_ADD, K_SQRT, K_CVT_FLR, K_FRACT,
-    K_SALU, K_VALU_SALU, K_FILTER_PK, K_FILTER_UNPK, K_FILTER_PK_SHIFT, K_PUSH, K_DS_WRITE, K_DS_ADD, K_COUNT
+    K_SALU, K_VALU_SALU, K_FILTER_PK, K_FILTER_UNPK, K_FILTER_PK_SHIFT, K_PUSH, K_DS_WRITE, K_DS_ADD, K_SUB_VVV, K_MUL_VVV, K_FMA_S, K_COUNT
 };
 static const char* kind_name[K_COUNT] = {
     "v_fma_f32 v,v,v,v", "v_pk_fma_f32", "v_pk_add_f32 v,v,v", "v_pk_mul_f32 v,v,v", "v_pk_add_f32 v,v,s[2]", "v_add_f32 v,s,v",
@@ -32,9 +34,10 @@ static const char* kind_name[K_COUNT] = {
     "s_add_u32 (SALU only)", "v_fma_f32 + s_add_u32 alternating (per pair)",
     "filter 4 col packed (6 pk + 4 cmp = 10 inst)", "filter 4 col unpacked (12 + 4 cmp = 16 inst)",
     "filter 4 col packed + image shift (9 pk + 4 cmp = 13 inst)",
-    "filter 4 col packed + push, ~14 % lanes hit (10 + 4x(3 VALU + ds_write + 4 SALU))", "ds_write_b32 (stride 4)", "ds_add_u32 (random bins)"};
+    "filter 4 col packed + push, ~14 % lanes hit (10 + 4x(3 VALU + ds_write + 4 SALU))", "ds_write_b32 (stride 4)", "ds_add_u32 (random bins)",
+    "v_sub_f32 v,v,v", "v_mul_f32 v,v,v", "v_fma_f32 v,s,v,v"};
 // instructions counted per unrolled unit (for cyc/inst)
-static const int kind_insts[K_COUNT] = {1, 1, 1, 1, 1, 1, 1, 2, 1, 1, 1, 1, 1, 2, 10, 16, 13, 10, 1, 1};
+static const int kind_insts[K_COUNT] = {1, 1, 1, 1, 1, 1, 1, 2, 1, 1, 1, 1, 1, 2, 10, 16, 13, 10, 1, 1, 1, 1, 1};
 
 template <int KIND>
 __global__ __launch_bounds__(256) void k_stream(int iters, uint64_t* ticks, float* sink, float sj0, float sj1, float sj2, float sj3) {
@@ -197,6 +200,18 @@ __global__ __launch_bounds__(256) void k_stream(int iters, uint64_t* ticks, floa
                 for (int k = 0; k < 4; ++k) asm volatile("v_cmp_gt_f32 vcc, %1, %0" : : "v"(q[k]), "s"(r2) : "vcc");
                 acc += q[0] + q[3];
             }
+        } else if (KIND == K_SUB_VVV) {
+#define X(n) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(a##n) : "v"(d));
+            REP64(X)
+#undef X
+        } else if (KIND == K_MUL_VVV) {
+#define X(n) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a##n) : "v"(c));
+            REP64(X)
+#undef X
+        } else if (KIND == K_FMA_S) {
+#define X(n) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a##n) : "s"(sj0), "v"(d));
+            REP64(X)
+#undef X
         } else if (KIND == K_DS_WRITE) {
 #define X(n) asm volatile("ds_write_b32 %0, %1" : : "v"(lane4), "v"(a##n) : "memory");
             REP64(X)
@@ -222,7 +237,7 @@ template <int K> static kern_t get() { return k_stream<K>; }
 static kern_t kern_of(int k) {
     switch (k) {
 #define C(K) case K: return get<K>();
-        C(0) C(1) C(2) C(3) C(4) C(5) C(6) C(7) C(8) C(9) C(10) C(11) C(12) C(13) C(14) C(15) C(16) C(17) C(18) C(19)
+        C(0) C(1) C(2) C(3) C(4) C(5) C(6) C(7) C(8) C(9) C(10) C(11) C(12) C(13) C(14) C(15) C(16) C(17) C(18) C(19) C(20) C(21) C(22)
 #undef C
     }
     return nullptr;

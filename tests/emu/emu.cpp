@@ -156,6 +156,13 @@ static std::vector<uint64_t> g_dynshm;
 void* dyn_shared() { return g_dynshm.data(); }
 
 void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body) {
+    // the hardware's launch limits (a grid.y above 65535 went unnoticed here and would fail on the GPU)
+    if (grid.y > 65535u || grid.z > 65535u || grid.x > 2147483647u || block.x * block.y * block.z > 1024u || shmem > 160u * 1024u ||
+        grid.x == 0 || grid.y == 0 || grid.z == 0) {
+        fprintf(stderr, "emu: launch outside the hardware limits: grid (%u, %u, %u), block (%u, %u, %u), %zu bytes of LDS\n", grid.x, grid.y,
+                grid.z, block.x, block.y, block.z, shmem);
+        abort();
+    }
     g_dynshm.assign(shmem / 8 + 2, 0);
     g_body = &body;
     g_gridDim = grid;

@@ -305,29 +305,27 @@ def test_interrupt_and_errors(gpu_lib, oracle, box30k):
 
 
 def test_nccl_single_rank_reduce_is_identity(gpu_lib, oracle, box30k):
-    """The RCCL merge path on one GPU: world_size 1 process group, reduce in place on the device accumulators."""
-    import os
-    import torch
-    import torch.distributed as dist
-    from viamd_amd.dist import reduce_eval
+    """The RCCL merge path on one GPU through torch's process group: a world_size-1 group makes reduce_eval a no-op, so the
+    collective is exercised explicitly - the library's own communicator (vmd_comm_create, 1 rank) + vmd_eval_reduce: in-place
+    ncclAllReduce on the device accumulators, packed fp64 all-reduce of the host parts, finalize."""
+    import ctypes as C
+    from viamd_amd import _lib as LL
     o = cases.oxygen(30000)
     ev = cases.check_rdf(gpu_lib, oracle, box30k[:2], 80.0, [("goo", o, o, 0.0, 12.0)], device=True)
     ref = ev.property_data("goo").counts.copy()
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29641")
-    torch.cuda.set_device(0)
-    dist.init_process_group("nccl", rank=0, world_size=1)
+    w = ev.property_data("goo").weights64.copy()
+    ident = np.zeros(LL.COMM_ID_BYTES, np.uint8)
+    assert gpu_lib.vmd_comm_unique_id(ident.ctypes.data_as(LL.c_uint8_p)), gpu_lib.last_error()
+    comm = gpu_lib.vmd_comm_create(1, 0, ident.ctypes.data_as(LL.c_uint8_p))
+    assert comm, gpu_lib.last_error()
     try:
-        # exercise the aliasing + collective explicitly even though world_size is 1
-        from viamd_amd.dist import _alias_counts
-        for v in ev.accum_views():
-            t = _alias_counts(v, True)
-            dist.all_reduce(t)
-            torch.cuda.synchronize()
-            np.testing.assert_array_equal(t.cpu().numpy().view(np.uint64), ref)
-        reduce_eval(ev)
+        assert gpu_lib.vmd_comm_size(comm) == 1 and gpu_lib.vmd_comm_rank(comm) == 0
+        assert gpu_lib.vmd_eval_reduce(ev.h, gpu_lib.vmd_comm_collective(comm), None), gpu_lib.last_error()
     finally:
-        dist.destroy_process_group()
+        gpu_lib.vmd_comm_destroy(comm)
     np.testing.assert_array_equal(ev.property_data("goo").counts, ref)
+    np.testing.assert_array_equal(ev.property_data("goo").weights64, w)
+    assert ev.frame_mask().all()
 
 
 def test_synthetic_blob_system_device_equals_host_and_script_eval(gpu_lib, oracle):

@@ -52,7 +52,7 @@ def test_native_rccl_merge_behind_the_abi(tmp_path, gpu_lib):
     for r, p in enumerate(procs):
         out, err = p.communicate(timeout=600)
         assert p.returncode == 0, err[-2000:]
-        assert out.startswith(f"OK ranks={nranks} rank={r}"), out
+        assert f"OK ranks={nranks} rank={r}" in out, out        # RCCL may print its version banner first
 
 
 @pytest.mark.gpu

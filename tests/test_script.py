@@ -98,7 +98,7 @@ GOOD_SCRIPTS = [
     "q = distance_pair(1:2, 4:6) in residue(10:14); x = distance_max(atom(3), atom(7:9)) in resname('ALA')[1:3];",
     "a = (element('N', 'C') or name('O')) and protein and not residue(1:5); g = rdf(a, water and element('H'), 1.5:7.25); ;",
     "w = water[3:40]; v = sdf(w, all, 4.5); m = distance_min(w[1:2], protein);",
-    "t = type('H') and resid(201:300); g = rdf(t, t, 6.0); d = distance(t, label('C'));",
+    "t = type('H') and residue(201:300); g = rdf(t, t, 6.0); d = distance(t, label('C'));",
     "v = sdf(residue(1:2) and element('C', 'N'), all, 3.0) ; w = sdf(residue(1) or residue(201), all, 3.0);",
     # BASELINE config 5
     "goo = rdf(element('O') and water, element('O') and water, 12.0);goh = rdf(element('O') and water, element('H') and water, 12.0);"
@@ -110,6 +110,35 @@ BAD_SCRIPTS = ["g = rdf(element('X'), all, 5.0);", "v = sdf(all[1:2], all, 5.0);
                "d = distance(1, 99) in residue(3);", "g = rdf(all, all 5.0);", "x = frobnicate(3);", "g = rdf(residue(0), all, 5.0);",
                "g = rdf(all, all, 5.0", "v = sdf(resname('ALA')[1:900], all, 3.0);", "s = element('O) ; g = rdf(s, s, 4.0);", "g = rdf(all, @, 4.0);",
                "w = sdf(resname('ALA', 'HOH')[200:201], all, 3.0);"]
+
+
+def test_resid_selects_by_the_sequence_number_of_the_file(host_lib, topo):
+    """VIAMD emits `in resid(%i)` with md_component_seq_id (the PDB resSeq) next to `in residue(%i)` with the
+    residue index + 1 (src/main.cpp:2843-2848).  The two differ whenever resSeq does not start at 1 or restarts per chain;
+    without sequence numbers resid() must be rejected, never aliased to residue()."""
+    for compile_ in (lambda t, tp: script.compile_script(t, tp, lib=host_lib)[0], lambda t, tp: script.compile_script_native(t, tp, lib=host_lib)):
+        with pytest.raises((script.ScriptError, V.VmdError), match="sequence numbers"):
+            compile_("d = distance(1, 2) in resid(3);", topo)
+    # resSeq starts at 17 in chain A (residues 0..99), restarts at 1 in chain B (residues 100..199), waters count on from 500
+    ri = np.asarray(topo.residue_index)
+    seq = np.where(ri < 100, ri + 17, np.where(ri < 200, ri - 100 + 1, ri + 300))
+    tp = script.Topology(topo.elements, topo.resnames, topo.residue_index, topo.names, mass=topo.mass, residue_seq_id=seq)
+    for text, same_as in (("d = distance(1, 2) in resid(20);", "d = distance(1, 2) in residue(4:4) ;"),                  # 20 = 17 + 3 -> residue index 3 (1-based 4) ...
+                          ("d = distance_min(1, 2:3) in resid(17:18);", None),
+                          ("g = rdf(resid(1:2) and element('C'), water and element('O'), 6.0);", "g = rdf(residue(101:102) and element('C'), water and element('O'), 6.0);"),
+                          ("g = rdf(resid(20), all, 5.0);", "g = rdf(residue(4) or residue(120), all, 5.0);")):      # ... and 20 also exists in chain B
+        ir_py, info = script.compile_script(text, tp, lib=host_lib)
+        ir_c = script.compile_script_native(text, tp, lib=host_lib)
+        assert ir_c.fingerprint() == ir_py.fingerprint(), text
+        if same_as:
+            if "in resid(20)" in text:      # a population of two contexts (chain A residue 4, chain B residue 120)
+                assert len(info["d"]["a_sets"]) == 2 and info["d"]["a_sets"][0].tolist() == [30] and info["d"]["a_sets"][1].tolist() == [1190]
+            else:
+                assert script.compile_script(same_as, tp, lib=host_lib)[0].fingerprint() == ir_py.fingerprint(), text
+    with pytest.raises((script.ScriptError, V.VmdError), match="matches no residue"):
+        script.compile_script_native("g = rdf(resid(400), all, 5.0);", tp, lib=host_lib)
+    with pytest.raises((script.ScriptError, V.VmdError), match="matches no residue"):
+        script.compile_script("g = rdf(resid(400), all, 5.0);", tp, lib=host_lib)
 
 
 def test_native_front_end_matches_the_python_one(host_lib, topo):

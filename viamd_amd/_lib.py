@@ -59,7 +59,7 @@ HOST_VIEW_FN = C.CFUNCTYPE(C.c_bool, C.c_void_p, C.POINTER(HostView))
 
 class TopologyC(C.Structure):
     _fields_ = [("num_atoms", C.c_size_t), ("elements", C.POINTER(C.c_char_p)), ("names", C.POINTER(C.c_char_p)),
-                ("resnames", C.POINTER(C.c_char_p)), ("residue_index", c_int32_p)]
+                ("resnames", C.POINTER(C.c_char_p)), ("residue_index", c_int32_p), ("residue_seq_id", c_int32_p)]
 
 
 class XtcFrame(C.Structure):             # vmd_xtc_frame_t (include/vmd_hip.h)

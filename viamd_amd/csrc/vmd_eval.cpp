@@ -759,7 +759,7 @@ extern "C" size_t vmd_eval_accum_views(vmd_script_eval_t* eval, vmd_accum_view_t
 
 // ---- the hot call -----------------------------------------------------------------------------------------------
 
-static bool upload_static(vmd_script_eval_t* e, const vmd_system_t* sys) {
+static bool upload_static(vmd_script_eval_t* e, const vmd_system_t* sys, size_t traj_atoms) {
     for (auto& s : e->sels) {
         if (!s->d_idx.p) { if (!s->d_idx.upload(s->idx.data(), s->idx.size(), e->stream)) return false; }
     }
@@ -794,7 +794,9 @@ static bool upload_static(vmd_script_eval_t* e, const vmd_system_t* sys) {
             p->have_owner = unique;
             if (unique && !p->d_owner.upload(owner.data(), owner.size(), e->stream)) return false;
             // dense targets: stream whole frames and select by a per-atom tag instead of gathering through the index list
-            const size_t natoms = sys ? sys->atom_count : 0;
+            // sized from the TRAJECTORY's atom count (the target indices were validated against it, check_atoms), never from
+            // sys->atom_count, which a host may leave unset or out of step
+            const size_t natoms = traj_atoms;
             p->have_tag = unique && d.K <= 253 && natoms > 0 && d.b.size() * 8 >= natoms && g_opt.sdf_dense != 0;
             if (p->have_tag) {
                 p->tag_len = (natoms + 63) & ~(size_t)63;
@@ -1222,7 +1224,7 @@ static bool process_range(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
     const size_t num_atoms = traj->num_atoms(traj->inst);
     if (traj->num_frames(traj->inst) < frame_end) return vmd_fail("trajectory has fewer frames than the requested range");
     if (!check_atoms(e, num_atoms)) return false;
-    if (!upload_static(e, sys)) return false;
+    if (!upload_static(e, sys, num_atoms)) return false;
 
     vmd_device_view_t view;
     memset(&view, 0, sizeof(view));
@@ -1442,7 +1444,7 @@ extern "C" bool vmd_eval_sdf_matrices(vmd_script_eval_t* eval, const char* name,
     HIP_OK(hipSetDevice(eval->device));
     vmd_script_eval_t* e = eval;
     const size_t num_atoms = traj->num_atoms(traj->inst);
-    if (!check_atoms(e, num_atoms) || !upload_static(e, sys)) return false;
+    if (!check_atoms(e, num_atoms) || !upload_static(e, sys, num_atoms)) return false;
     vmd_device_view_t view;
     memset(&view, 0, sizeof(view));
     const bool have_view = traj->device_view && traj->device_view(traj->inst, &view) && view.device == e->device;

@@ -1560,10 +1560,11 @@ __global__ __launch_bounds__(256) void k_distance_minmax(vmd_dist_params_t p) {
     if (threadIdx.x == 0) p.out[blockIdx.x] = sqrtf(s_red[0]);
 }
 
-// grid (ceil(per/256), B*P): all |a_c| x |b_c| pairs of context c, row-major
+// grid (B*P, ceil(per/256)): all |a_c| x |b_c| pairs of context c, row-major.  The (frame, context) index sits on grid.x: a
+// population of >= 64 contexts over a 1 024-frame batch exceeds the 65 535 limit of grid.y
 __global__ __launch_bounds__(256) void k_distance_pair(vmd_dist_params_t p) {
-    const long long k = (long long)blockIdx.x * 256 + threadIdx.x;
-    const int b = blockIdx.y / p.P, c = blockIdx.y - b * p.P;
+    const long long k = (long long)blockIdx.y * 256 + threadIdx.x;
+    const int b = blockIdx.x / p.P, c = blockIdx.x - b * p.P;
     if (k >= p.per) return;
     const int a0 = p.aoff[c], b0 = p.boff[c], nb = p.boff[c + 1] - b0;
     const int ia = (int)(k / nb), ib = (int)(k - (long long)ia * nb);
@@ -1828,7 +1829,10 @@ extern "C" int vmd_hip_distance(void* stream, const float* xyz, size_t frame_str
     case 0: hipLaunchKernelGGL(k_distance_com, dim3((B * P + 63) / 64), dim3(64), 0, s, p); break;
     case 1: hipLaunchKernelGGL((k_distance_minmax<false>), dim3(B * P), dim3(256), 0, s, p); break;
     case 2: hipLaunchKernelGGL((k_distance_minmax<true>), dim3(B * P), dim3(256), 0, s, p); break;
-    case 3: hipLaunchKernelGGL(k_distance_pair, dim3((unsigned)((per + 255) / 256), B * P), dim3(256), 0, s, p); break;
+    case 3:
+        if ((per + 255) / 256 > 65535) return (int)hipErrorInvalidValue;      // > 16.7M pairs per context: not a distance_pair population
+        hipLaunchKernelGGL(k_distance_pair, dim3((unsigned)(B * P), (unsigned)((per + 255) / 256)), dim3(256), 0, s, p);
+        break;
     default: return (int)hipErrorInvalidValue;
     }
     VMD_LAUNCH_CHECK();

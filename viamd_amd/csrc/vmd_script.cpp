@@ -95,6 +95,7 @@ struct Topo {
     size_t n = 0, nres = 0;
     std::vector<std::string> elements, names, resnames;
     std::vector<std::vector<int32_t>> res_atoms;     // ascending atom indices per residue
+    std::vector<int32_t> res_seq;                    // residue sequence number of the file per residue (resid()); empty = unknown
 
     explicit Topo(const vmd_topology_t* t) {
         n = t->num_atoms;
@@ -111,6 +112,10 @@ struct Topo {
         if (n == 0) nres = 0;
         res_atoms.resize(nres);
         for (size_t i = 0; i < n; ++i) res_atoms[ri[i]].push_back((int32_t)i);
+        if (t->residue_seq_id) {
+            res_seq.assign(nres, 0);
+            for (size_t r = 0; r < nres; ++r) if (!res_atoms[r].empty()) res_seq[r] = t->residue_seq_id[res_atoms[r][0]];
+        }
     }
     const std::string& residue_name(size_t r) const { static const std::string unk = "UNK"; return res_atoms[r].empty() ? unk : resnames[res_atoms[r][0]]; }
 };
@@ -275,7 +280,21 @@ struct Parser {
             for (size_t a = 0; a < topo.n; ++a) s.mask[a] = in_names(arr[a]);
             return s;
         }
-        if (v == "residue" || v == "resid" || v == "atom") {
+        if (v == "resid") {
+            // the residue sequence number of the file (PDB resSeq: may start anywhere and restart per chain), NOT the residue index:
+            // VIAMD emits both forms side by side (src/main.cpp:2843-2848)
+            take("(");
+            const long a = integer();
+            long b = a;
+            if (accept(":")) b = integer();
+            take(")");
+            if (b < a) fail("bad range %ld:%ld", a, b);
+            if (topo.res_seq.empty()) fail("resid(): the topology carries no residue sequence numbers (vmd_topology_t.residue_seq_id); use residue() for the 1-based residue index");
+            Sel s = residues([&](size_t r) { return (long)topo.res_seq[r] >= a && (long)topo.res_seq[r] <= b; });
+            if (s.structs.empty()) fail("resid(%ld:%ld) matches no residue", a, b);
+            return s;
+        }
+        if (v == "residue" || v == "atom") {
             take("(");
             long a, b;
             range(a, b);

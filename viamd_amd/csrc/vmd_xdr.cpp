@@ -217,7 +217,8 @@ enum Kind { KIND_XTC = 0, KIND_TRR = 1 };
 
 struct FrameRec {
     uint64_t off;        // first byte of the frame
-    uint64_t bytes;      // XTC: compressed payload bytes (0 = raw floats); TRR: unused
+    uint64_t bytes;      // XTC: payload bytes (compressed stream, or 12 * natoms raw floats when `raw`); TRR: unused
+    bool raw;            // XTC: <= 9 atoms are stored as plain floats
     uint32_t head;       // bytes from `off` to the payload (XTC) / to the box block (TRR)
     // TRR block sizes
     uint32_t box_size, skip_size, x_size, real_size;
@@ -303,7 +304,13 @@ const char* xtc_decode(const unsigned char* hdr, const unsigned char* data, size
             for (int k = 0; k < 3; ++k) {
                 // a range above 24 bits: three plain MSB-first fields of up to 32 bits
                 const int b = bitsizeint[k];
-                cur[k] = (int)(uint32_t)(b > 24 ? ((br.get(b - 24) << 24) | br.get(24)) : br.get(b));
+                if (b > 24) {       // two reads from the stream: sequenced explicitly (operands of | have no evaluation order)
+                    const uint64_t hi = br.get(b - 24);
+                    const uint64_t lo = br.get(24);
+                    cur[k] = (int)(uint32_t)((hi << 24) | lo);
+                } else {
+                    cur[k] = (int)(uint32_t)br.get(b);
+                }
             }
         } else {
             get_triple(br, bitsize, large, cur);
@@ -378,16 +385,25 @@ bool xtc_index(Xdr* d, uint64_t file_bytes) {
         r.time = be_f32(h + 12);
         uint64_t total;
         if (natoms <= 9) {
-            r.head = 56; r.bytes = 0;
+            r.head = 56; r.bytes = 12ull * natoms; r.raw = true;
             total = 56 + 12ull * natoms;
         } else {
             const bool big = magic == kXtcMagicBig;
             if (want < (size_t)(big ? 100 : 96)) break;
             r.bytes = big ? be64(h + 88) : be32(h + 88);
             r.head = big ? 96 : 92;
+            // the byte count comes from the file (64 bits for magic 2023): bound it by what the file can hold BEFORE any
+            // arithmetic on it, so that neither the 4-byte padding nor off + total can wrap; an empty compressed stream is corrupt
+            if (r.bytes == 0 || r.bytes > file_bytes - off - r.head) {
+                if (off == 0) return fail("XTC '%s': corrupt first frame (payload size)", d->path);
+                break;
+            }
             total = r.head + ((r.bytes + 3) & ~3ull);
         }
-        if (off + total > file_bytes) break;                     // truncated last frame
+        if (total > file_bytes - off) {                          // truncated last frame (only the padding can be missing here)
+            if (!(natoms > 9 && r.head + r.bytes <= file_bytes - off)) break;
+            total = file_bytes - off;
+        }
         d->frames.push_back(r);
         off += total;
     }
@@ -397,14 +413,14 @@ bool xtc_index(Xdr* d, uint64_t file_bytes) {
 
 bool xtc_load(Xdr* d, const FrameRec& r, vmd_unitcell_t* cell, float* x, float* y, float* z) {
     static thread_local std::vector<unsigned char> buf;
-    const size_t payload = r.bytes ? (size_t)r.bytes : 12 * d->num_atoms;
+    const size_t payload = (size_t)r.bytes;
     buf.resize(r.head + payload + kStreamPad);
     if (!read_at(d->fd, buf.data(), r.head + payload, r.off)) return fail("XTC '%s': truncated frame", d->path);
     memset(buf.data() + r.head + payload, 0, kStreamPad);
     float box[9];
     for (int k = 0; k < 9; ++k) box[k] = be_f32(buf.data() + 16 + 4 * k);
     *cell = cell_from_box_nm(box);
-    if (!r.bytes) {
+    if (r.raw) {
         const unsigned char* p = buf.data() + r.head;
         for (size_t i = 0; i < d->num_atoms; ++i, p += 12) {
             if (x) x[i] = be_f32(p) * 10.0f;
@@ -523,7 +539,7 @@ bool xdr_load_raw(void* inst, int64_t idx, vmd_frame_header_t* hdr, vmd_raw_fram
     Xdr* d = (Xdr*)inst;
     if (d->kind != KIND_XTC || idx < 0 || (size_t)idx >= d->frames.size() || !info) return false;
     const FrameRec& r = d->frames[(size_t)idx];
-    if (!r.bytes) return false;
+    if (r.raw) return false;
     unsigned char h[100];
     if (!read_at(d->fd, h, r.head, r.off)) return fail("XTC '%s': truncated frame", d->path);
     memset(info, 0, sizeof(*info));

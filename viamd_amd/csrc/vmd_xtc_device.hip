@@ -174,7 +174,13 @@ __device__ __forceinline__ uint32_t xtc_decode_range(const unsigned char* stream
         if (fs.bitsize == 0) {
             for (int k = 0; k < 3; ++k) {
                 const int nb = fs.bitsizeint[k];
-                cur[k] = (int)(uint32_t)(nb > 24 ? ((xtc_get(br, nb - 24) << 24) | xtc_get(br, 24)) : xtc_get(br, nb));
+                if (nb > 24) {      // two reads from the stream: sequenced explicitly (operands of | have no evaluation order)
+                    const uint64_t hi = xtc_get(br, nb - 24);
+                    const uint64_t lo = xtc_get(br, 24);
+                    cur[k] = (int)(uint32_t)((hi << 24) | lo);
+                } else {
+                    cur[k] = (int)(uint32_t)xtc_get(br, nb);
+                }
             }
         } else {
             if (!xtc_triple(br, fs.bitsize, fs.large, cur)) { st = 2; break; }

@@ -80,7 +80,7 @@ def load_system(path, atom_style=None):
         coords, meta, cells = textio.read_gro(path)
         elems = [_guess_element(n) for n in meta["name"]]
         topo = Topology(elems, meta["resname"], _residue_index(zip(meta["resid"], meta["resname"])), meta["name"],
-                        mass=np.array([MASS.get(e, 12.0) for e in elems], np.float32))
+                        mass=np.array([MASS.get(e, 12.0) for e in elems], np.float32), residue_seq_id=meta["resid"])
         return topo, coords[0], cells[0]
     if kind == "xyz":
         coords, elements, cells = textio.read_xyz(path)
@@ -90,7 +90,8 @@ def load_system(path, atom_style=None):
     if kind == "cif":
         coords, meta, params = textio.read_mmcif(path)
         topo = Topology(meta["element"], meta["resname"], _residue_index(zip(meta["chain"], meta["resid"], meta["resname"])),
-                        meta["name"], mass=np.array([MASS.get(e, 12.0) for e in meta["element"]], np.float32))
+                        meta["name"], mass=np.array([MASS.get(e, 12.0) for e in meta["element"]], np.float32),
+                        residue_seq_id=meta["resid"])
         cell = textio.cell_from_parameters(*params) if params else textio.make_unitcell(None)
         return topo, coords[0], cell
     coords, meta, cell = textio.read_lammps_data(path, atom_style)

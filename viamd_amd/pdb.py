@@ -68,6 +68,6 @@ def read_pdb(path):
             last = r
         ridx.append(k)
     mass = np.array([MASS.get(e, 12.0) for e in elems], np.float32)
-    topo = Topology(elems, resn, ridx, names, mass=mass)
+    topo = Topology(elems, resn, ridx, names, mass=mass, residue_seq_id=[r[1] for r in resi])
     cell = make_unitcell(box, tilt=tilt) if box is not None else make_unitcell(None)
     return coords, topo, cell

@@ -32,9 +32,12 @@ class ScriptError(ValueError):
 class Topology:
     """What selections are resolved against: per-atom element / name / residue name / residue index (0-based, contiguous)."""
 
-    def __init__(self, elements, resnames=None, residue_index=None, names=None, mass=None):
+    def __init__(self, elements, resnames=None, residue_index=None, names=None, mass=None, residue_seq_id=None):
         self.elements = np.asarray(elements)
         n = self.elements.size
+        # per atom: the residue sequence number the file carries (PDB resSeq, GRO residue number) - what resid() selects by;
+        # None = unknown (resid() is then an error, never an alias of residue(); src/main.cpp:2843-2848 emits both forms)
+        self.residue_seq_id = None if residue_seq_id is None else np.asarray(residue_seq_id, dtype=np.int64)
         self.resnames = np.asarray(resnames) if resnames is not None else np.array(["UNK"] * n)
         self.residue_index = np.asarray(residue_index, dtype=np.int64) if residue_index is not None else np.zeros(n, np.int64)
         self.names = np.asarray(names) if names is not None else self.elements
@@ -214,7 +217,24 @@ class _Parser:
                 return self._residues(lambda r: topo.residue_name(r) in names)
             arr = topo.elements if v == "element" else topo.names
             return Sel(np.isin(arr, names))
-        if v in ("residue", "resid", "atom"):
+        if v == "resid":
+            self.take("(")
+            a = int(self.take(kind="num"))
+            b = a
+            if self.accept(":"):
+                b = int(self.take(kind="num"))
+            self.take(")")
+            if b < a:
+                raise ScriptError(f"bad range {a}:{b}")
+            if topo.residue_seq_id is None:
+                raise ScriptError("resid(): the topology carries no residue sequence numbers (vmd_topology_t.residue_seq_id); "
+                                  "use residue() for the 1-based residue index")
+            seq = [int(topo.residue_seq_id[topo._res_atoms[r][0]]) for r in range(topo.num_residues)]
+            s = self._residues(lambda r: a <= seq[r] <= b)
+            if not s.structures:
+                raise ScriptError(f"resid({a}:{b}) matches no residue")
+            return s
+        if v in ("residue", "atom"):
             self.take("(")
             a, b = self.range_()
             self.take(")")
@@ -324,7 +344,8 @@ def compile_script_native(text, topo, lib=None):
 
     el, nm, rn = strings(topo.elements), strings(topo.names), strings(topo.resnames)
     ri = np.ascontiguousarray(topo.residue_index, np.int32)
-    tc = L.TopologyC(n, el, nm, rn, ri.ctypes.data_as(L.c_int32_p))
+    sq = None if topo.residue_seq_id is None else np.ascontiguousarray(topo.residue_seq_id, np.int32)
+    tc = L.TopologyC(n, el, nm, rn, ri.ctypes.data_as(L.c_int32_p), sq.ctypes.data_as(L.c_int32_p) if sq is not None else None)
     if not ir.lib.vmd_ir_compile_from_source(ir.h, text.encode(), C.byref(tc)):
         raise ScriptError(ir.lib.last_error())
     return ir
