@@ -58,6 +58,26 @@ int vmd_hip_cells_build(void* stream, const float* xyz, size_t frame_stride, siz
                         vmd_grid_t grid, uint32_t* cell_count, uint32_t* rank, uint32_t* cell_start, float* sorted,
                         float* aos);
 
+/* K1, two-level build (the default whenever the grid has <= 4096 pencils): the frame is read once, every atom travels as one
+ * 16-byte record {x, y, z, fine cell} through a per-pencil bucket, and one block per (frame, pencil) sorts its bucket in LDS and
+ * writes its stretch of `sorted` / `cell_start` coalesced (k_cells_bin, k_cells_pen_scan, k_cells_pen_sort).
+ *   pen_off    u32[npen + 1]: exclusive prefix of the bucket capacities in records (npen = ny*nz), chosen by the host from
+ *              vmd_hip_cells_pencil_count of a few frames plus head room; every capacity <= vmd_hip_cells_pencil_cap_max()
+ *   total_cap  pen_off[npen]; cap_max: the largest capacity
+ *   pen_count  u32[B][npen] scratch (zeroed by the call), pen_start u32[B][npen + 1] scratch, bucket f32[B][total_cap][4] scratch
+ *   overflow   u32[1]: set to 1 when an atom found its bucket full (never cleared here).  The sorted copy is then incomplete;
+ *              vmd_hip_rdf_pencil / vmd_hip_axpy_u64 given the same flag do nothing, the caller enlarges the buckets and repeats */
+int vmd_hip_cells_pencil_ok(vmd_grid_t grid);
+int vmd_hip_set_cells_pencil(int on);  /* A-B switch (0 = the single-level builds below), returns the previous value */
+int vmd_hip_cells_pencil_cap_max(void);
+/* atoms per pencil of S frames: counts u32[S][npen], zeroed by the call */
+int vmd_hip_cells_pencil_count(void* stream, const float* xyz, size_t frame_stride, size_t row_stride, const float* boxes,
+                               uint32_t pbc_flags, int S, const int32_t* sel, int nsel, vmd_grid_t grid, uint32_t* counts);
+int vmd_hip_cells_build_pencil(void* stream, const float* xyz, size_t frame_stride, size_t row_stride, const float* boxes,
+                               uint32_t pbc_flags, int B, const int32_t* sel, int nsel, int nsel_pad, vmd_grid_t grid,
+                               const uint32_t* pen_off, int total_cap, int cap_max, uint32_t* pen_count, uint32_t* pen_start,
+                               float* bucket, uint32_t* overflow, uint32_t* cell_start, float* sorted);
+
 /* K2: RDF pair histogram over a batch from cell-sorted selections (ref may equal tgt -> half shell).
  *   partial   u64[vmd_hip_rdf_partial_words()] scratch (per-wave rows + the work counter)
  *   counts    u64[nbins]  accumulated (+=) with device atomics
@@ -72,7 +92,8 @@ size_t vmd_hip_rdf_partial_words(void);
 int vmd_hip_rdf_pencil(void* stream, const float* sorted_ref, const uint32_t* cell_start_ref, int nref, int nref_pad,
                        const float* sorted_tgt, const uint32_t* cell_start_tgt, int ntgt, int ntgt_pad,
                        const float* boxes, int B, vmd_grid_t grid, float rmin, float rmax, int nbins,
-                       int same_set, int variant, uint32_t pbc_flags, uint64_t* partial, uint64_t* counts);
+                       int same_set, int variant, uint32_t pbc_flags, uint64_t* partial, uint64_t* counts,
+                       const uint32_t* skip_flag /* device u32 or NULL: non-zero = do nothing (see vmd_hip_cells_build_pencil) */);
 
 /* general RDF (any periodicity flags, any cutoff, no grid): O(nref*ntgt) per frame, SPEC S3 by comparison */
 int vmd_hip_rdf_brute(void* stream, const float* xyz, size_t frame_stride, size_t row_stride,
@@ -110,6 +131,8 @@ int vmd_hip_distance(void* stream, const float* xyz, size_t frame_stride, size_t
                      const int32_t* a, const float* mass_a, const int32_t* aoff,
                      const int32_t* b, const float* mass_b, const int32_t* boff, float* out);
 
+/* dst[i] += mult * src[i] (u64): one pair pass feeding several histograms; does nothing when *skip_flag != 0 */
+int vmd_hip_axpy_u64(void* stream, uint64_t* dst, const uint64_t* src, size_t n, uint64_t mult, const uint32_t* skip_flag);
 /* dst[i] += src[i] (u64): merges a frame block's partial accumulator into the totals */
 int vmd_hip_add_u64(void* stream, uint64_t* dst, const uint64_t* src, size_t n);
 /* u64 counters -> f32 values (values[i] = (float)counts[i]) + max reduction into max_out[0] (device f32) */

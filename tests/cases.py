@@ -123,6 +123,70 @@ def rdf_edge_cases(lib, O, device=False):
               device=device)
 
 
+def cell_build_cases(lib, O, coords, box, device=False):
+    """every build of the cell-sorted copies: two-level (pencil buckets, the default), atomic 3-kernel build, LDS-fused
+    single-block build, split build (G blocks per frame, forced with 2048-atom slices)"""
+    n = coords.shape[2]
+    o, h = oxygen(n), hydrogen(n)
+    for pencil, fused, split in ((1, 1, 1), (0, 0, 1), (0, 1, 1), (0, 1, 2)):
+        old = lib.vmd_set_option(b"cells_pencil", pencil), lib.vmd_set_option(b"cells_fused", fused), lib.vmd_set_option(b"cells_split", split)
+        try:
+            check_rdf(lib, O, coords[:2], box, [("goo", o, o, 0.0, 12.0), ("goh", o, h, 0.0, 9.0)], device=device)
+        finally:
+            lib.vmd_set_option(b"cells_pencil", old[0]); lib.vmd_set_option(b"cells_fused", old[1]); lib.vmd_set_option(b"cells_split", old[2])
+
+
+def cell_build_overflow_case(lib, O, device=False, n=3000, box=60.0):
+    """The two-level build sizes its pencil buckets from the first and last frames of a batch.  Here the middle frames pile
+    every oxygen into one corner of the cell: their buckets overflow, nothing may reach the histograms (device flag), and the
+    evaluator has to re-measure and repeat the batch - the result still equals the oracle bit for bit."""
+    F = 12
+    coords = water_box(O, 5, n, box, F)
+    o = oxygen(n)
+    rng = np.random.default_rng(3)
+    for f in (5, 6, 7):
+        coords[f][:, o] = rng.uniform(1.0, 11.0, (3, o.size)).astype(np.float32)      # all inside one 12 A pencil
+    import ctypes as C
+    lib.vmd_profile_reset(); lib.vmd_profile_enable(True)
+    try:
+        check_rdf(lib, O, coords, box, [("goo", o, o, 0.0, 12.0)], device=device)
+    finally:
+        lib.vmd_profile_enable(False)
+    nb = C.c_uint64(0)
+    lib.vmd_profile_ms(b"cells_build", C.byref(nb))
+    assert nb.value >= 2, "the overflowing batch was not rebuilt"
+
+
+def class_decomposition_cases(lib, O, device=False, n_water=3000, box=40.0):
+    """Co-evaluated RDFs of one range share pair passes through disjoint atom classes (BASELINE config 5: goo is a subset of
+    ghv).  With and without the decomposition every property equals its own oracle histogram; sets that overlap partially,
+    nested sets, a set that lists an atom twice (-> no decomposition) and a second range in the same script."""
+    import ctypes as C
+    coords, structures, mass = sdf_system(O, 12, n_water, box, 2, K=3, m=8)
+    n_s, N = structures.size, coords.shape[2]
+    o = np.arange(n_s, N, 3, dtype=np.int32)
+    h = np.array([i for i in range(n_s, N) if (i - n_s) % 3], np.int32)
+    heavy = np.concatenate([np.arange(0, n_s, 2, dtype=np.int32), o])          # water oxygens + every other blob atom
+    a = np.concatenate([o[: o.size // 2], h[: h.size // 3]])                      # overlaps with b in a quarter of the oxygens
+    b = np.concatenate([o[o.size // 4:], np.arange(1, n_s, 2, dtype=np.int32)])
+    base = [("goo", o, o, 0.0, 9.0), ("goh", o, h, 0.0, 9.0), ("ghv", heavy, heavy, 0.0, 9.0), ("gab", a, b, 0.0, 9.0),
+            ("gba", b, a, 0.0, 9.0), ("short", o, heavy, 0.5, 6.0)]
+    launches = {}
+    for classes in (1, 0):
+        old = lib.vmd_set_option(b"rdf_classes", classes)
+        lib.vmd_profile_reset(); lib.vmd_profile_enable(True)
+        try:
+            check_rdf(lib, O, coords, box, base, device=device)
+        finally:
+            lib.vmd_set_option(b"rdf_classes", old); lib.vmd_profile_enable(False)
+        nl = C.c_uint64(0)
+        lib.vmd_profile_ms(b"rdf_pencil", C.byref(nl))
+        launches[classes] = nl.value
+    assert launches[0] == len(base) and launches[1] != launches[0], launches       # one pass per property vs one per class pair
+    dup = np.concatenate([o[:50], o[:5]])                                         # an atom listed twice counts twice: direct passes only
+    check_rdf(lib, O, coords, box, [("gdup", dup, o, 0.0, 9.0), ("goo", o, o, 0.0, 9.0)], device=device)
+
+
 # ---- SDF scenario: K rigid-ish structures of m atoms tumbling in a water box -------------------------------------------
 
 def sdf_system(O, seed, n_water_atoms, box, frames, K=4, m=6):

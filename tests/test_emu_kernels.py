@@ -25,14 +25,15 @@ def test_rdf_two_sets_full_shell_and_range(emu_lib, oracle, box3k):
 
 
 def test_all_cell_build_paths(emu_lib, oracle, box3k):
-    """atomic 3-kernel build, LDS-fused single-block build, split build (G blocks per frame, forced with 2048-atom slices)"""
-    o, h = cases.oxygen(3000), cases.hydrogen(3000)
-    for fused, split in ((0, 1), (1, 1), (1, 2)):
-        old = emu_lib.vmd_set_option(b"cells_fused", fused), emu_lib.vmd_set_option(b"cells_split", split)
-        try:
-            cases.check_rdf(emu_lib, oracle, box3k[:2], 60.0, [("goo", o, o, 0.0, 12.0), ("goh", o, h, 0.0, 9.0)])
-        finally:
-            emu_lib.vmd_set_option(b"cells_fused", old[0]); emu_lib.vmd_set_option(b"cells_split", old[1])
+    cases.cell_build_cases(emu_lib, oracle, box3k, 60.0)
+
+
+def test_cell_build_bucket_overflow_is_caught_and_repeated(emu_lib, oracle):
+    cases.cell_build_overflow_case(emu_lib, oracle)
+
+
+def test_coevaluated_rdfs_share_pair_passes(emu_lib, oracle):
+    cases.class_decomposition_cases(emu_lib, oracle, n_water=1800, box=38.0)
 
 
 def test_rdf_inline_variant_matches(emu_lib, oracle, box3k):

@@ -37,14 +37,15 @@ def test_rdf_two_sets_ranges_shared_grid(gpu_lib, oracle, box30k):
 
 
 def test_all_cell_build_paths(gpu_lib, oracle, box30k):
-    """atomic 3-kernel build, LDS-fused single-block build, split build (G blocks per frame, forced with 2048-atom slices)"""
-    o, h = cases.oxygen(30000), cases.hydrogen(30000)
-    for fused, split in ((0, 1), (1, 1), (1, 2)):
-        old = gpu_lib.vmd_set_option(b"cells_fused", fused), gpu_lib.vmd_set_option(b"cells_split", split)
-        try:
-            cases.check_rdf(gpu_lib, oracle, box30k[:2], 80.0, [("goo", o, o, 0.0, 12.0), ("goh", o, h, 0.0, 9.0)], device=True)
-        finally:
-            gpu_lib.vmd_set_option(b"cells_fused", old[0]); gpu_lib.vmd_set_option(b"cells_split", old[1])
+    cases.cell_build_cases(gpu_lib, oracle, box30k, 80.0, device=True)
+
+
+def test_cell_build_bucket_overflow_is_caught_and_repeated(gpu_lib, oracle):
+    cases.cell_build_overflow_case(gpu_lib, oracle, device=True, n=30000, box=80.0)
+
+
+def test_coevaluated_rdfs_share_pair_passes(gpu_lib, oracle):
+    cases.class_decomposition_cases(gpu_lib, oracle, device=True, n_water=30000, box=70.0)
 
 
 def test_rdf_inline_variant_and_host_staging(gpu_lib, oracle, box30k):

@@ -204,7 +204,14 @@ SIGNATURES = [
     ("vmd_hip_cells_scratch_words", C.c_size_t, [Grid, C.c_int]),
     ("vmd_hip_rdf_partial_words", C.c_size_t, []),
     ("vmd_hip_rdf_pencil", C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, C.c_int, C.c_int, _vp, C.c_int, Grid,
-                                     C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, C.c_uint32, _vp, _vp]),
+                                     C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, C.c_uint32, _vp, _vp, _vp]),
+    ("vmd_hip_cells_pencil_ok", C.c_int, [Grid]),
+    ("vmd_hip_set_cells_pencil", C.c_int, [C.c_int]),
+    ("vmd_hip_cells_pencil_cap_max", C.c_int, []),
+    ("vmd_hip_cells_pencil_count", C.c_int, [_vp, _vp, C.c_size_t, C.c_size_t, _vp, C.c_uint32, C.c_int, _vp, C.c_int, Grid, _vp]),
+    ("vmd_hip_cells_build_pencil", C.c_int, [_vp, _vp, C.c_size_t, C.c_size_t, _vp, C.c_uint32, C.c_int, _vp, C.c_int, C.c_int, Grid,
+                                             _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp]),
+    ("vmd_hip_axpy_u64", C.c_int, [_vp, _vp, _vp, C.c_size_t, C.c_uint64, _vp]),
     ("vmd_hip_rdf_brute", C.c_int, [_vp, _vp, C.c_size_t, C.c_size_t, _vp, C.c_uint32, C.c_int, _vp, C.c_int, _vp, C.c_int,
                                     C.c_float, C.c_float, C.c_int, _vp]),
     ("vmd_hip_sdf_align", C.c_int, [_vp, _vp, C.c_size_t, C.c_size_t, _vp, C.c_uint32, C.c_int, _vp, _vp, C.c_int, C.c_int, _vp,

@@ -81,6 +81,7 @@ struct Options {
                                              // frame (k_xtc_decode), 2 = index pass + one thread per chunk (k_xtc_index / k_xtc_chunks)
     std::atomic<int> xtc_chunk{256};         // atoms per chunk of variant 2
     std::atomic<int> sdf_dense{0};       // dense-target SDF scatter (stream whole frames, select by tag): measured slower, off
+    std::atomic<int> rdf_classes{1};     // co-evaluated RDFs of one range share pair passes through disjoint atom classes (0 = one pass per property)
 };
 static Options g_opt;
 
@@ -104,6 +105,8 @@ extern "C" int vmd_set_option(const char* key, int value) {
     else if (!strcmp(key, "sdf_dense")) o = &g_opt.sdf_dense;
     else if (!strcmp(key, "xtc_device_decode")) o = &g_opt.xtc_device_decode;
     else if (!strcmp(key, "xtc_chunk")) o = &g_opt.xtc_chunk;
+    else if (!strcmp(key, "rdf_classes")) o = &g_opt.rdf_classes;
+    else if (!strcmp(key, "cells_pencil")) return vmd_hip_set_cells_pencil(value);
     else if (!strcmp(key, "cells_fused")) return vmd_hip_set_cells_fused(value);
     else if (!strcmp(key, "cells_split")) return vmd_hip_set_cells_split(value);
     else if (!strcmp(key, "rdf_blocks")) return vmd_hip_set_rdf_blocks(value);
@@ -342,6 +345,32 @@ struct Selection {
     int nsel_pad = 0;
     bool built = false;     // for the current batch ...
     vmd_grid_t built_grid;  // ... on this grid
+    // two-level build: bucket capacity per pencil (records), measured on a few frames and kept for the eval's lifetime
+    std::vector<uint32_t> pen_off;      // [npen + 1] exclusive prefix; empty = not measured
+    int pen_ny = 0, pen_nz = 0;         // the pencil layout the capacities belong to
+    int cap_max = 0, total_cap = 0;
+    float cap_margin = 1.25f;
+    int overflows = 0;                  // times a bucket overflowed; after 3 the selection stays on the single-level builds
+    bool used_pencil = false;           // the current batch was built through the buckets
+    DevBuf<uint32_t> d_pen_off, pen_count, pen_start;
+    DevBuf<float> bucket;
+};
+
+// One launch of the pair kernel and the histograms it feeds.  Co-evaluated RDF properties of the same range are decomposed
+// into disjoint atom classes (by which reference / target sets an atom belongs to): every class pair is evaluated once and added
+// to each property that contains it - `goo = rdf(O, O)` and `ghv = rdf(heavy, heavy)` share the O-O pass, which is nearly all
+// of ghv (BASELINE config 5).  mult: ordered-pair multiplicity of the pass in the property (same-class pass: the kernel already
+// counts both orders; cross pass (c, d): 1 for (c in ref, d in target), +1 for (d in ref, c in target)).
+struct PairPass {
+    int sel_a = -1, sel_b = -1;
+    bool same = false;
+    std::vector<std::pair<int, uint64_t>> targets;      // (index into eval->props, mult)
+};
+struct RdfGroup {
+    float rmin = 0.0f, rmax = 0.0f;
+    std::vector<int> props;                             // indices into eval->props
+    std::vector<PairPass> passes;
+    bool classes = false;                               // passes come from the class decomposition
 };
 
 struct PropState {
@@ -434,6 +463,11 @@ struct vmd_script_eval_t {
     Stage stages[2];
     hipStream_t copy_stream = nullptr;
     DevBuf<uint64_t> d_partial;
+    std::vector<RdfGroup> rdf_groups;
+    DevBuf<uint64_t> d_pass;                 // [passes with several targets][bins]: scratch histogram of one pair pass
+    DevBuf<uint32_t> d_overflow;             // device flag raised by the two-level cell build when a pencil bucket is full
+    uint32_t* h_overflow = nullptr;          // pinned host copy, read at every batch's synchronisation point
+    DevBuf<uint32_t> d_pen_sample;
     std::vector<float> h_temporal;
     // filtered evaluation: per-block partial accumulators and the eval whose blocks this one may reuse
     size_t block_frames = 0;
@@ -456,6 +490,95 @@ static int intern_selection(vmd_script_eval_t* e, const std::vector<int32_t>& id
     s->idx = idx;
     e->sels.push_back(std::move(s));
     return (int)e->sels.size() - 1;
+}
+
+// Groups the RDF properties by range and decides, per group, between one pair pass per property and the class decomposition
+// (see PairPass).  Classes are used when every set is duplicate-free, there are at most 8 of them, and the pair work
+// (sum over passes of n_a * n_b, halved for same-set passes) drops by at least 10 %.
+static void build_rdf_plan(vmd_script_eval_t* e) {
+    e->rdf_groups.clear();
+    for (size_t i = 0; i < e->props.size(); ++i) {
+        const Property& d = e->props[i]->prop;
+        if (d.kind != PROP_RDF) continue;
+        RdfGroup* g = nullptr;
+        for (auto& q : e->rdf_groups) if (memcmp(&q.rmin, &d.rmin, sizeof(float)) == 0 && memcmp(&q.rmax, &d.rmax, sizeof(float)) == 0) g = &q;
+        if (!g) { e->rdf_groups.emplace_back(); g = &e->rdf_groups.back(); g->rmin = d.rmin; g->rmax = d.rmax; }
+        g->props.push_back((int)i);
+    }
+    // every property keeps its own sets as selections (index lists only; sorted copies exist for the selections passes use):
+    // the all-pairs kernel, which takes over when a batch cannot use the grid, works per property
+    for (auto& p : e->props) {
+        if (p->prop.kind != PROP_RDF) continue;
+        p->sel_a = intern_selection(e, p->prop.a);
+        p->sel_b = p->same_set ? p->sel_a : intern_selection(e, p->prop.b);
+    }
+    for (auto& g : e->rdf_groups) {
+        auto direct = [&]() {
+            g.passes.clear(); g.classes = false;
+            for (int pi : g.props) {
+                PropState* p = e->props[pi].get();
+                PairPass ps;
+                ps.sel_a = p->sel_a; ps.sel_b = p->sel_b;
+                ps.same = p->same_set;
+                ps.targets.push_back({pi, 1});
+                g.passes.push_back(std::move(ps));
+            }
+        };
+        const size_t np = g.props.size();
+        if (np < 2 || np > 30 || !g_opt.rdf_classes) { direct(); continue; }
+        // signature of every atom: bit 2k = in the reference set of the group's k-th property, bit 2k + 1 = in its target set
+        int32_t amax = 0;
+        for (int pi : g.props) { for (int32_t a : e->props[pi]->prop.a) amax = std::max(amax, a); for (int32_t b : e->props[pi]->prop.b) amax = std::max(amax, b); }
+        std::vector<uint64_t> sig((size_t)amax + 1, 0);
+        bool dup = false;
+        for (size_t k = 0; k < np && !dup; ++k) {
+            const Property& d = e->props[g.props[k]]->prop;
+            for (int side = 0; side < 2 && !dup; ++side) {
+                const uint64_t bit = 1ull << (2 * k + side);
+                for (int32_t a : (side ? d.b : d.a)) { if (sig[a] & bit) { dup = true; break; } sig[a] |= bit; }
+            }
+        }
+        if (dup) { direct(); continue; }      // a set that lists an atom twice counts it twice: only the direct passes reproduce that
+        std::vector<uint64_t> csig;
+        std::vector<std::vector<int32_t>> cidx;
+        bool too_many = false;
+        for (int32_t a = 0; a <= amax && !too_many; ++a) {
+            if (!sig[a]) continue;
+            size_t c = 0;
+            while (c < csig.size() && csig[c] != sig[a]) ++c;
+            if (c == csig.size()) { if (csig.size() == 8) { too_many = true; break; } csig.push_back(sig[a]); cidx.emplace_back(); }
+            cidx[c].push_back(a);
+        }
+        if (too_many) { direct(); continue; }
+        std::vector<PairPass> passes;
+        double cost_classes = 0.0, cost_direct = 0.0;
+        for (size_t c = 0; c < csig.size(); ++c)
+            for (size_t d = c; d < csig.size(); ++d) {
+                PairPass ps;
+                for (size_t k = 0; k < np; ++k) {
+                    const uint64_t X = 1ull << (2 * k), Y = 1ull << (2 * k + 1);
+                    uint64_t mult;
+                    if (c == d) mult = ((csig[c] & X) && (csig[c] & Y)) ? 1 : 0;
+                    else mult = (((csig[c] & X) && (csig[d] & Y)) ? 1 : 0) + (((csig[d] & X) && (csig[c] & Y)) ? 1 : 0);
+                    if (mult) ps.targets.push_back({g.props[k], mult});
+                }
+                if (ps.targets.empty()) continue;
+                ps.same = c == d;
+                ps.sel_a = (int)c; ps.sel_b = (int)d;          // class indices for now
+                cost_classes += (double)cidx[c].size() * (double)cidx[d].size() * (c == d ? 0.5 : 1.0);
+                passes.push_back(std::move(ps));
+            }
+        for (int pi : g.props) {
+            const PropState* p = e->props[pi].get();
+            cost_direct += (double)p->prop.a.size() * (double)p->prop.b.size() * (p->same_set ? 0.5 : 1.0);
+        }
+        if (!(cost_classes < 0.9 * cost_direct)) { direct(); continue; }
+        std::vector<int> csel(csig.size());
+        for (size_t c = 0; c < csig.size(); ++c) csel[c] = intern_selection(e, cidx[c]);
+        for (auto& ps : passes) { ps.sel_a = csel[ps.sel_a]; ps.sel_b = csel[ps.sel_b]; }
+        g.passes = std::move(passes);
+        g.classes = true;
+    }
 }
 
 extern "C" vmd_script_eval_t* vmd_eval_create(size_t num_frames, const vmd_script_ir_t* ir) {
@@ -483,9 +606,7 @@ extern "C" vmd_script_eval_t* vmd_eval_create(size_t num_frames, const vmd_scrip
             st->data.weights = st->weights.data();
             st->data.weights64 = st->weights64.data();
             st->data.min_range[0] = p.rmin; st->data.max_range[0] = p.rmax;
-            st->same_set = (p.a == p.b);
-            st->sel_a = intern_selection(e.get(), p.a);
-            st->sel_b = st->same_set ? st->sel_a : intern_selection(e.get(), p.b);
+            st->same_set = (p.a == p.b);         // selections are interned by build_rdf_plan (own sets, or the classes they split into)
             break;
         case PROP_SDF:
             st->ncounts = (size_t)VMD_VOLUME_DIM * VMD_VOLUME_DIM * VMD_VOLUME_DIM;
@@ -524,6 +645,10 @@ extern "C" vmd_script_eval_t* vmd_eval_create(size_t num_frames, const vmd_scrip
         }
         e->props.push_back(std::move(st));
     }
+    build_rdf_plan(e.get());
+    if (!e->d_overflow.ensure(1) || hipMemsetAsync(e->d_overflow.p, 0, sizeof(uint32_t), e->stream) != hipSuccess ||
+        hipHostMalloc((void**)&e->h_overflow, sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) { vmd_fail("allocating the overflow flag failed"); return nullptr; }
+    *e->h_overflow = 0;
     if (hipStreamSynchronize(e->stream) != hipSuccess) { vmd_fail("hipStreamSynchronize failed"); return nullptr; }
     return e.release();
 }
@@ -549,6 +674,8 @@ extern "C" void vmd_eval_free(vmd_script_eval_t* eval) {
         eval->copy_stream = nullptr;
         eval->props.clear();
         eval->sels.clear();
+        if (eval->h_overflow) (void)hipHostFree(eval->h_overflow);
+        eval->h_overflow = nullptr;
         if (eval->stream) (void)hipStreamDestroy(eval->stream);
         eval->stream = nullptr;
     }
@@ -1099,8 +1226,10 @@ static bool choose_grid(const std::vector<float>& boxes, uint32_t pbc, size_t nb
     int nxf = (int)std::floor(Lxmin / cx);
     nxf = std::max(1, std::min(nxf, 4096));
     // keep the cell table small enough for the LDS-resident build (24576 counters) as long as the fine cells stay <= rmax/3
+    // (the single-level builds only: the two-level build keeps a table of pencils, not of cells)
     const int nxf_lds = 24575 / (n[1] * n[2]);
-    if (nxf > nxf_lds && nxf_lds >= (int)std::ceil(3.0f * Lxmin / rmax)) nxf = nxf_lds;
+    vmd_grid_t probe{nxf, n[1], n[2], 0};
+    if (!vmd_hip_cells_pencil_ok(probe) && nxf > nxf_lds && nxf_lds >= (int)std::ceil(3.0f * Lxmin / rmax)) nxf = nxf_lds;
     g->nxf = nxf; g->ny = n[1]; g->nz = n[2];
     const long long ncell = (long long)nxf * n[1] * n[2];
     if (ncell > (1ll << 26)) return false;
@@ -1108,12 +1237,66 @@ static bool choose_grid(const std::vector<float>& boxes, uint32_t pbc, size_t nb
     return true;
 }
 
+// Bucket capacities of the two-level build for selection `s` on the pencils of grid `g`: per-pencil maximum over the first and
+// last (up to) 4 frames of the batch x margin + a few standard deviations.  One small readback, then kept for the eval's
+// lifetime (frames of one trajectory look alike; a bucket that overflows later is caught by the device flag and re-measured).
+static bool ensure_pencil_caps(vmd_script_eval_t* e, Selection* s, const Stage& src, const float* d_boxes, uint32_t pbc, size_t nb, const vmd_grid_t& g) {
+    if (!s->pen_off.empty() && s->pen_ny == g.ny && s->pen_nz == g.nz) return true;
+    const int npen = g.ny * g.nz, nsel = (int)s->idx.size();
+    // after an overflow: every frame of the batch (exact populations), otherwise the first and last 4
+    const bool exhaustive = s->overflows > 0 || nb <= 8;
+    const size_t S = exhaustive ? nb : 4, rows = exhaustive ? nb : 8;
+    if (!e->d_pen_sample.ensure(rows * (size_t)npen)) return false;
+    std::vector<uint32_t> h(rows * (size_t)npen);
+    KRN_OK(vmd_hip_cells_pencil_count(e->stream, src.base, src.frame_stride, src.row_stride, d_boxes, pbc, (int)S, s->d_idx.p, nsel, g, e->d_pen_sample.p));
+    if (!exhaustive) {
+        const size_t tail = nb - S;
+        KRN_OK(vmd_hip_cells_pencil_count(e->stream, src.base + tail * src.frame_stride, src.frame_stride, src.row_stride, d_boxes + 9 * tail, pbc, (int)S,
+                                          s->d_idx.p, nsel, g, e->d_pen_sample.p + S * (size_t)npen));
+    }
+    HIP_OK(hipMemcpyAsync(h.data(), e->d_pen_sample.p, h.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
+    HIP_OK(hipStreamSynchronize(e->stream));
+    s->pen_off.assign((size_t)npen + 1, 0);
+    s->cap_max = 0;
+    uint64_t total = 0;
+    for (int p = 0; p < npen; ++p) {
+        uint32_t m = 0;
+        for (size_t k = 0; k < rows; ++k) m = std::max(m, h[k * npen + p]);
+        uint32_t cap = (uint32_t)std::ceil((double)m * s->cap_margin + 6.0 * std::sqrt((double)m)) + 16;
+        cap = (cap + 3u) & ~3u;
+        s->pen_off[p] = (uint32_t)total;
+        total += cap;
+        s->cap_max = std::max<int>(s->cap_max, (int)cap);
+    }
+    if (total > 0x7fffffffull) { s->pen_off.clear(); s->overflows = 99; return true; }     // not a job for the buckets
+    s->pen_off[npen] = (uint32_t)total;
+    s->total_cap = (int)total;
+    s->pen_ny = g.ny; s->pen_nz = g.nz;
+    return s->d_pen_off.upload(s->pen_off.data(), s->pen_off.size(), e->stream);
+}
+
 static bool build_selection(vmd_script_eval_t* e, Selection* s, const Stage& src, const float* d_boxes, uint32_t pbc, size_t nb, const vmd_grid_t& g) {
     if (s->built && s->built_grid.nxf == g.nxf && s->built_grid.ny == g.ny && s->built_grid.nz == g.nz) return true;
     const int nsel = (int)s->idx.size();
     s->nsel_pad = (nsel + 63) & ~63;
-    if (!s->cell_count.ensure(nb * (size_t)(g.ncell + 1)) || !s->cell_start.ensure(nb * (size_t)(g.ncell + 1)) ||
-        !s->rank.ensure(nb * vmd_hip_cells_scratch_words(g, nsel)) || !s->sorted.ensure(nb * 3 * (size_t)s->nsel_pad + 64)) return false;   // +64: the pair kernel prefetches past a segment
+    if (!s->cell_start.ensure(nb * (size_t)(g.ncell + 1)) || !s->sorted.ensure(nb * 3 * (size_t)s->nsel_pad + 64)) return false;   // +64: the pair kernel prefetches past a segment
+    s->used_pencil = false;
+    // two-level build through per-pencil buckets (one read of the frame, coalesced sorted rows); single-level builds otherwise
+    if (vmd_hip_cells_pencil_ok(g) && s->overflows < 3) {
+        if (!ensure_pencil_caps(e, s, src, d_boxes, pbc, nb, g)) return false;
+        if (!s->pen_off.empty() && s->cap_max <= vmd_hip_cells_pencil_cap_max()) {
+            const size_t npen = (size_t)g.ny * g.nz;
+            if (!s->pen_count.ensure(nb * npen) || !s->pen_start.ensure(nb * (npen + 1)) || !s->bucket.ensure(nb * (size_t)s->total_cap * 4)) return false;
+            e->prof.begin("cells_build", e->stream);
+            KRN_OK(vmd_hip_cells_build_pencil(e->stream, src.base, src.frame_stride, src.row_stride, d_boxes, pbc, (int)nb, s->d_idx.p, nsel, s->nsel_pad, g,
+                                              s->d_pen_off.p, s->total_cap, s->cap_max, s->pen_count.p, s->pen_start.p, s->bucket.p, e->d_overflow.p,
+                                              s->cell_start.p, s->sorted.p));
+            e->prof.end(e->stream);
+            s->built = true; s->built_grid = g; s->used_pencil = true;
+            return true;
+        }
+    }
+    if (!s->cell_count.ensure(nb * (size_t)(g.ncell + 1)) || !s->rank.ensure(nb * vmd_hip_cells_scratch_words(g, nsel))) return false;
     const bool use_aos = g_opt.cells_aos != 0;
     if (use_aos && !s->aos.ensure(nb * 4 * (size_t)s->nsel_pad)) return false;
     e->prof.begin("cells_build", e->stream);
@@ -1272,46 +1455,78 @@ static bool process_range(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
         e->h_temporal.resize(temporal_floats);
         size_t toff = 0;
 
-        for (auto& p : e->props) {
-            const Property& d = p->prop;
-            // a whole frame block accumulates into its own partial first and is merged into the totals afterwards
-            uint64_t* acc = p->d_counts.p;
-            if (bt.blk >= 0 && p->ncounts) {
-                acc = p->d_blocks.p + (size_t)bt.blk * p->ncounts;
-                HIP_OK(hipMemsetAsync(acc, 0, p->ncounts * sizeof(uint64_t), e->stream));
+        // a whole frame block accumulates into its own partial first and is merged into the totals afterwards
+        auto acc_of = [&](PropState* p) -> uint64_t* {
+            return (bt.blk >= 0 && p->ncounts) ? p->d_blocks.p + (size_t)bt.blk * p->ncounts : p->d_counts.p;
+        };
+        if (bt.blk >= 0)
+            for (auto& p : e->props) if (p->ncounts) HIP_OK(hipMemsetAsync(acc_of(p.get()), 0, p->ncounts * sizeof(uint64_t), e->stream));
+
+        // ---- RDF: one pair pass per (group, pass); launch_rdf may run again for this batch when a cell-build bucket overflowed
+        auto launch_rdf = [&]() -> bool {
+            size_t scratch_rows = 0;
+            for (auto& g : e->rdf_groups) for (auto& ps : g.passes) if (!(ps.targets.size() == 1 && ps.targets[0].second == 1)) scratch_rows += 1;
+            if (scratch_rows) {
+                if (!e->d_pass.ensure(scratch_rows * VMD_RDF_NUM_BINS)) return false;
+                HIP_OK(hipMemsetAsync(e->d_pass.p, 0, scratch_rows * VMD_RDF_NUM_BINS * sizeof(uint64_t), e->stream));
             }
-            if (d.kind == PROP_RDF) {
-                vmd_grid_t g;
+            size_t row = 0;
+            for (auto& g : e->rdf_groups) {
+                vmd_grid_t grid;
                 // fully periodic cells use the frame boxes; open axes (non-periodic systems, slabs) span the batch's bounding box
                 const bool open_axes = (pbc & 8u) == 0 && (pbc & VMD_UNITCELL_PBC_ALL) != VMD_UNITCELL_PBC_ALL;
                 if (open_axes && !g_opt.force_brute && !prepare_open_boxes(e, src, nb, pbc, num_atoms)) return false;
                 const std::vector<float>& gb = (open_axes && src.gboxes_ready) ? src.h_gboxes : src.h_boxes;
                 const float* d_gb = (open_axes && src.gboxes_ready) ? src.d_gboxes.p : src.d_boxes.p;
-                if (choose_grid(gb, pbc, nb, d.rmax, &g)) {
-                    Selection* sa = e->sels[p->sel_a].get();
-                    Selection* sb = e->sels[p->sel_b].get();
-                    // properties with the same cutoff share the sorted copies; build_selection re-sorts when the grid differs
-                    if (!build_selection(e, sa, src, d_gb, pbc, nb, g)) return false;
-                    if (sb != sa && !build_selection(e, sb, src, d_gb, pbc, nb, g)) return false;
-                    if (!e->d_partial.ensure(vmd_hip_rdf_partial_words())) return false;
+                if (!choose_grid(gb, pbc, nb, g.rmax, &grid)) {
+                    // no grid for this batch (cutoff >= half the cell width, ...): all pairs, per property
+                    for (int pi : g.props) {
+                        PropState* p = e->props[pi].get();
+                        Selection* sa = e->sels[p->sel_a].get();
+                        Selection* sb = e->sels[p->sel_b].get();
+                        e->prof.begin("rdf_brute", e->stream);
+                        KRN_OK(vmd_hip_rdf_brute(e->stream, src.base, src.frame_stride, src.row_stride, src.d_boxes.p, pbc, (int)nb,
+                                                 sa->d_idx.p, (int)sa->idx.size(), sb->d_idx.p, (int)sb->idx.size(),
+                                                 g.rmin, g.rmax, VMD_RDF_NUM_BINS, acc_of(p)));
+                        e->prof.end(e->stream);
+                    }
+                    for (auto& ps : g.passes) if (!(ps.targets.size() == 1 && ps.targets[0].second == 1)) row += 1;
+                    continue;
+                }
+                if (!e->d_partial.ensure(vmd_hip_rdf_partial_words())) return false;
+                for (auto& ps : g.passes) {
+                    Selection* sa = e->sels[ps.sel_a].get();
+                    Selection* sb = e->sels[ps.sel_b].get();
+                    // passes with the same cutoff share the sorted copies; build_selection re-sorts when the grid differs
+                    if (!build_selection(e, sa, src, d_gb, pbc, nb, grid)) return false;
+                    if (sb != sa && !build_selection(e, sb, src, d_gb, pbc, nb, grid)) return false;
                     // the pair set is symmetric in (ref, target): put the denser selection in the lanes - 64 of its atoms span a
                     // shorter stretch of the pencil, so the x window of every segment carries less padding
                     if (sb->idx.size() > sa->idx.size()) std::swap(sa, sb);
+                    const bool direct = ps.targets.size() == 1 && ps.targets[0].second == 1;
+                    uint64_t* dst = direct ? acc_of(e->props[ps.targets[0].first].get()) : e->d_pass.p + row * VMD_RDF_NUM_BINS;
                     e->prof.begin("rdf_pencil", e->stream);
                     KRN_OK(vmd_hip_rdf_pencil(e->stream, sa->sorted.p, sa->cell_start.p, (int)sa->idx.size(), sa->nsel_pad,
                                               sb->sorted.p, sb->cell_start.p, (int)sb->idx.size(), sb->nsel_pad,
-                                              d_gb, (int)nb, g, d.rmin, d.rmax, VMD_RDF_NUM_BINS,
-                                              p->same_set ? 1 : 0, g_opt.rdf_variant, pbc, e->d_partial.p, acc));
+                                              d_gb, (int)nb, grid, g.rmin, g.rmax, VMD_RDF_NUM_BINS,
+                                              ps.same ? 1 : 0, g_opt.rdf_variant, pbc, e->d_partial.p, dst, e->d_overflow.p));
                     e->prof.end(e->stream);
-                } else {
-                    Selection* sa = e->sels[p->sel_a].get();
-                    Selection* sb = e->sels[p->sel_b].get();
-                    e->prof.begin("rdf_brute", e->stream);
-                    KRN_OK(vmd_hip_rdf_brute(e->stream, src.base, src.frame_stride, src.row_stride, src.d_boxes.p, pbc, (int)nb,
-                                             sa->d_idx.p, (int)sa->idx.size(), sb->d_idx.p, (int)sb->idx.size(),
-                                             d.rmin, d.rmax, VMD_RDF_NUM_BINS, acc));
-                    e->prof.end(e->stream);
+                    if (!direct) {
+                        for (auto& tg : ps.targets)
+                            KRN_OK(vmd_hip_axpy_u64(e->stream, acc_of(e->props[tg.first].get()), dst, VMD_RDF_NUM_BINS, tg.second, e->d_overflow.p));
+                        row += 1;
+                    }
                 }
+            }
+            HIP_OK(hipMemcpyAsync(e->h_overflow, e->d_overflow.p, sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
+            return true;
+        };
+        if (!e->rdf_groups.empty() && !launch_rdf()) return false;
+
+        for (auto& p : e->props) {
+            const Property& d = p->prop;
+            uint64_t* acc = acc_of(p.get());
+            if (d.kind == PROP_RDF) {
                 // SPEC S4 normalisation, fp64 on the host (needs only the box)
                 double* bw = bt.blk >= 0 ? &p->block_weights64[(size_t)bt.blk * p->ncounts] : nullptr;
                 if (bw) std::fill(bw, bw + p->ncounts, 0.0);
@@ -1355,13 +1570,30 @@ static bool process_range(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
                 toff += nb * p->dim1;
                 p->dirty = true;
             }
-            if (acc != p->d_counts.p) KRN_OK(vmd_hip_add_u64(e->stream, p->d_counts.p, acc, p->ncounts));
         }
         // the kernels of this batch are queued: load the next batch on the host while they run
         if (bi + 1 < batches.size() && !e->interrupt) {
             if (!fetch_stage(e, e->stages[cur ^ 1], traj, vw, num_atoms, batches[bi + 1].f0, batches[bi + 1].nb)) return false;
         }
         HIP_OK(hipStreamSynchronize(e->stream));
+        // a bucket of the two-level cell build was too small: nothing reached the histograms (every consumer saw the flag).
+        // Re-measure the selections that used buckets with more head room and evaluate the RDF part of this batch again.
+        for (int attempt = 0; *e->h_overflow != 0; ++attempt) {
+            if (attempt >= 4) return vmd_fail("cell build: pencil buckets keep overflowing");
+            for (auto& sl : e->sels) {
+                sl->built = false;
+                if (!sl->used_pencil) continue;
+                sl->pen_off.clear();
+                sl->cap_margin *= 1.6f;
+                sl->overflows += 1;
+            }
+            *e->h_overflow = 0;
+            HIP_OK(hipMemsetAsync(e->d_overflow.p, 0, sizeof(uint32_t), e->stream));
+            if (!launch_rdf()) return false;
+            HIP_OK(hipStreamSynchronize(e->stream));
+        }
+        if (bt.blk >= 0)
+            for (auto& p : e->props) if (p->ncounts) KRN_OK(vmd_hip_add_u64(e->stream, p->d_counts.p, acc_of(p.get()), p->ncounts));
         e->prof.resolve();
         if (g_prof_on) { std::lock_guard<std::mutex> l(g_prof_mtx); g_prof["batches"].launches += 1; }
         toff = 0;

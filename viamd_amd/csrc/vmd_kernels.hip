@@ -492,6 +492,149 @@ __global__ __launch_bounds__(1024) void k_cells_split_scatter(vmd_cells_split_t 
     }
 }
 
+// Two-level build (the default): the frame is read ONCE and the sorted SoA rows are written once, with one 16-byte record per
+// atom in between - against two reads of the frame, a scattered AoS write and a repack pass in the builds above.
+//   level 1, k_cells_bin: a block takes a slice of the selection, wraps the atoms, counts them per PENCIL in LDS (a pencil =
+//     one row of nxf fine cells; there are only ny*nz of them, so the table is tiny whatever nxf is), reserves room in every
+//     pencil's bucket with one global atomic per (block, pencil) and writes the records {x, y, z, fine cell} there: a block's
+//     atoms of one pencil land next to each other, so the scattered writes are short runs, not single records.
+//   level 2, k_cells_pen_sort: one block per (frame, pencil) pulls the pencil's bucket through LDS (counting sort by fine cell)
+//     and writes its stretch of the sorted rows and of cell_start fully coalesced.
+// Buckets have a fixed capacity per pencil (pen_off, measured on a few frames by the host with k_cells_bin in counting mode, plus
+// head room); an atom that finds its bucket full raises *overflow, every consumer of the sorted copy (k_rdf_pencil,
+// k_hist_reduce) then does nothing, and the host re-measures and repeats the batch.  The order of atoms inside a cell depends on
+// the order of the atomics (it is arbitrary in every build; the histograms do not depend on it).
+struct vmd_bin_params_t {
+    vmd_cells_params_t c;            // frame, boxes, selection, grid (cell_count / rank / aos unused)
+    const uint32_t* pen_off;         // [npen + 1] exclusive prefix of the bucket capacities (records), NULL in counting mode
+    uint32_t* pen_count;             // [B][npen], zeroed before the launch: atoms per pencil
+    float* bucket;                   // [B][pen_off[npen]][4], NULL in counting mode
+    uint32_t* overflow;              // [1]
+    int npen; int total_cap;
+};
+#define VMD_BIN_ILP 4
+__global__ __launch_bounds__(1024) void k_cells_bin(vmd_bin_params_t q) {
+    HIP_DYNAMIC_SHARED(uint32_t, s_dyn)
+    uint32_t* s_cnt = s_dyn;                 // [npen] atoms of this block per pencil, then the block's first slot in the bucket
+    const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int npen = q.npen, nxf = q.c.grid.nxf;
+    for (int c = tid; c < npen; c += 1024) s_cnt[c] = 0u;
+    __syncthreads();
+    float xw[VMD_BIN_ILP], yw[VMD_BIN_ILP], zw[VMD_BIN_ILP];
+    uint32_t pen[VMD_BIN_ILP], cx[VMD_BIN_ILP], rank[VMD_BIN_ILP];
+#pragma unroll
+    for (int u = 0; u < VMD_BIN_ILP; ++u) {
+        const int t = (g * VMD_BIN_ILP + u) * 1024 + tid;
+        pen[u] = 0xffffffffu;
+        if (t < q.c.nsel) {
+            const uint32_t cell = vmd_cell_of(q.c, b, t, xw[u], yw[u], zw[u]);
+            pen[u] = cell / (uint32_t)nxf;
+            cx[u] = cell - pen[u] * (uint32_t)nxf;
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < VMD_BIN_ILP; ++u) if (pen[u] != 0xffffffffu) rank[u] = atomicAdd(&s_cnt[pen[u]], 1u);
+    __syncthreads();
+    uint32_t* gcount = q.pen_count + (size_t)b * npen;
+    for (int c = tid; c < npen; c += 1024) {
+        const uint32_t n = s_cnt[c];
+        if (n) s_cnt[c] = atomicAdd(&gcount[c], n);
+    }
+    if (!q.bucket) return;                   // counting mode: the host only wants the populations
+    __syncthreads();
+    float* bk = q.bucket + (size_t)b * q.total_cap * 4;
+#pragma unroll
+    for (int u = 0; u < VMD_BIN_ILP; ++u) {
+        if (pen[u] == 0xffffffffu) continue;
+        const uint32_t off = q.pen_off[pen[u]], cap = q.pen_off[pen[u] + 1] - off;
+        const uint32_t slot = s_cnt[pen[u]] + rank[u];
+        if (slot < cap) {
+            const vmd_f4a v = {xw[u], yw[u], zw[u], __int_as_float((int)cx[u])};
+            *(vmd_f4a*)(bk + 4 * (size_t)(off + slot)) = v;
+        } else {
+            *q.overflow = 1u;
+        }
+    }
+}
+
+// per frame: exclusive prefix of the (capacity-clamped) pencil populations = first sorted slot of every pencil
+__global__ __launch_bounds__(256) void k_cells_pen_scan(const uint32_t* __restrict__ pen_count, const uint32_t* __restrict__ pen_off,
+                                                        uint32_t* __restrict__ pen_start, int npen) {
+    __shared__ uint32_t part[256];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const uint32_t* cnt = pen_count + (size_t)b * npen;
+    uint32_t* out = pen_start + (size_t)b * (npen + 1);
+    const int per = (npen + 255) / 256;
+    const int beg = tid * per, end = beg + per < npen ? beg + per : npen;
+    uint32_t s = 0;
+    for (int c = beg; c < end; ++c) { const uint32_t cap = pen_off[c + 1] - pen_off[c]; s += cnt[c] < cap ? cnt[c] : cap; }
+    part[tid] = s;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+        const uint32_t v = tid >= o ? part[tid - o] : 0u;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[tid] - s;
+    for (int c = beg; c < end; ++c) { const uint32_t cap = pen_off[c + 1] - pen_off[c]; out[c] = run; run += cnt[c] < cap ? cnt[c] : cap; }
+    if (tid == 255) out[npen] = part[255];
+}
+
+struct vmd_pensort_params_t {
+    const float* bucket; const uint32_t* pen_off; const uint32_t* pen_count; const uint32_t* pen_start;
+    uint32_t* cell_start; float* sorted;
+    int npen, nxf, ncell, nsel_pad, total_cap, cap_max;
+};
+__global__ __launch_bounds__(256) void k_cells_pen_sort(vmd_pensort_params_t q) {
+    HIP_DYNAMIC_SHARED(uint32_t, s_dyn)
+    __shared__ uint32_t s_part[256];
+    uint32_t* s_cnt = s_dyn;                                  // [nxf]
+    float* s_xyz = (float*)(s_dyn + q.nxf);                   // [3][cap_max]
+    const int pen = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int nxf = q.nxf;
+    const uint32_t off = q.pen_off[pen], cap = q.pen_off[pen + 1] - off;
+    uint32_t n = q.pen_count[(size_t)b * q.npen + pen];
+    n = n < cap ? n : cap;
+    const uint32_t start = q.pen_start[(size_t)b * (q.npen + 1) + pen];
+    const float* bk = q.bucket + 4 * ((size_t)b * q.total_cap + off);
+    for (int c = tid; c < nxf; c += 256) s_cnt[c] = 0u;
+    __syncthreads();
+    for (uint32_t k = tid; k < n; k += 256) atomicAdd(&s_cnt[(uint32_t)__float_as_int(bk[4 * (size_t)k + 3])], 1u);
+    __syncthreads();
+    // exclusive scan over the fine cells of the pencil
+    const int per = (nxf + 255) / 256;
+    const int beg = tid * per, end = beg + per < nxf ? beg + per : nxf;
+    uint32_t sum = 0;
+    for (int c = beg; c < end; ++c) sum += s_cnt[c];
+    s_part[tid] = sum;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+        const uint32_t v = tid >= o ? s_part[tid - o] : 0u;
+        __syncthreads();
+        s_part[tid] += v;
+        __syncthreads();
+    }
+    uint32_t run = s_part[tid] - sum;
+    uint32_t* cs = q.cell_start + (size_t)b * (q.ncell + 1) + (size_t)pen * nxf;
+    for (int c = beg; c < end; ++c) { const uint32_t m = s_cnt[c]; s_cnt[c] = run; cs[c] = start + run; run += m; }
+    if (pen == q.npen - 1 && tid == 255) q.cell_start[(size_t)b * (q.ncell + 1) + q.ncell] = start + n;
+    __syncthreads();
+    float* sx = s_xyz; float* sy = s_xyz + q.cap_max; float* sz = s_xyz + 2 * (size_t)q.cap_max;
+    for (uint32_t k = tid; k < n; k += 256) {
+        const vmd_f4a v = *(const vmd_f4a*)(bk + 4 * (size_t)k);
+        const uint32_t pos = atomicAdd(&s_cnt[(uint32_t)__float_as_int(v[3])], 1u);
+        sx[pos] = v[0]; sy[pos] = v[1]; sz[pos] = v[2];
+    }
+    __syncthreads();
+    float* srt = q.sorted + (size_t)b * 3 * q.nsel_pad + start;
+    for (uint32_t k = tid; k < n; k += 256) {
+        srt[k] = sx[k];
+        srt[q.nsel_pad + k] = sy[k];
+        srt[2 * (size_t)q.nsel_pad + k] = sz[k];
+    }
+}
+
 // bounding box of all atoms of every frame (open axes: the pencil grid spans the box of the batch): out[b] = {min xyz, max xyz}
 __global__ __launch_bounds__(1024) void k_bbox(const float* __restrict__ xyz, size_t frame_stride, size_t row_stride, int natoms,
                                                float* __restrict__ out) {
@@ -530,6 +673,7 @@ struct vmd_pair_params_t {
     unsigned* work_counter;  // [8 * VMD_COUNTER_STRIDE], zeroed before launch: one dynamic work queue per XCD (frames f = q mod 8)
     int nsub;                // work items per pencil (i-chunks are dealt round-robin to the items)
     uint32_t pbc;            // bits 0..2: periodic axes (an open axis spans the batch's bounding box: boxes slots 6..8 = origin)
+    const uint32_t* skip;    // device flag or NULL: non-zero = the sorted copies are incomplete (a bucket of the cell build overflowed), do nothing
 };
 #define VMD_COUNTER_STRIDE 32    // one 128-byte line per queue counter
 
@@ -972,6 +1116,7 @@ __global__ __launch_bounds__(256) VMD_SGPR_CAP(96) void k_rdf_pencil(vmd_pair_pa
     __shared__ unsigned s_hist[4][VMD_MAX_BINS];
     __shared__ float s_queue[4][VMD_QUEUE_CAP];
     constexpr unsigned INC = SAME ? 2u : 1u;
+    if (p.skip && *p.skip) return;       // set before this launch by the cell build; the host repeats the batch with larger buckets
 
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
@@ -1110,7 +1255,8 @@ __global__ __launch_bounds__(256) VMD_SGPR_CAP(96) void k_rdf_pencil(vmd_pair_pa
 // sum the per-block partial rows into the u64 accumulators: block (x = 256 bins, y = slice of 32 rows), coalesced
 // row reads, one atomicAdd(u64) per bin and slice
 __global__ __launch_bounds__(256) void k_hist_reduce(const uint64_t* __restrict__ partial, int nrows, int nbins,
-                                                     uint64_t* __restrict__ counts) {
+                                                     uint64_t* __restrict__ counts, const uint32_t* __restrict__ skip) {
+    if (skip && *skip) return;
     const int b = blockIdx.x * 256 + threadIdx.x;
     if (b >= nbins) return;
     const int r0 = blockIdx.y * 32;
@@ -1703,7 +1849,8 @@ extern "C" size_t vmd_hip_rdf_partial_words(void) {
 extern "C" int vmd_hip_rdf_pencil(void* stream, const float* sorted_ref, const uint32_t* cell_start_ref, int nref, int nref_pad,
                                   const float* sorted_tgt, const uint32_t* cell_start_tgt, int ntgt, int ntgt_pad,
                                   const float* boxes, int B, vmd_grid_t grid, float rmin, float rmax, int nbins,
-                                  int same_set, int variant, uint32_t pbc_flags, uint64_t* partial, uint64_t* counts) {
+                                  int same_set, int variant, uint32_t pbc_flags, uint64_t* partial, uint64_t* counts,
+                                  const uint32_t* skip_flag) {
     hipStream_t s = (hipStream_t)stream;
     if (nbins <= 0 || nbins > VMD_MAX_BINS) return (int)hipErrorInvalidValue;
     if (B <= 0 || nref <= 0 || ntgt <= 0) return 0;
@@ -1738,6 +1885,7 @@ extern "C" int vmd_hip_rdf_pencil(void* stream, const float* sorted_ref, const u
     if (nblocks > g_rdf_blocks) nblocks = g_rdf_blocks;
     const dim3 g(nblocks), blk(256);
     p.pbc = pbc_flags;
+    p.skip = skip_flag;
     const int cell = (pbc_flags & VMD_PBC_TRICLINIC) ? 1 : ((pbc_flags & 7u) != 7u ? 2 : 0);
     const int which = (variant == 1 ? 6 : 0) + (same_set ? 3 : 0) + cell;
     switch (which) {
@@ -1755,7 +1903,7 @@ extern "C" int vmd_hip_rdf_pencil(void* stream, const float* sorted_ref, const u
     default: hipLaunchKernelGGL((k_rdf_pencil<1, true, 2>), g, blk, 0, s, p); break;
     }
     VMD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_hist_reduce, dim3((nbins + 255) / 256, (nblocks + 31) / 32), dim3(256), 0, s, (const uint64_t*)partial, nblocks, nbins, counts);
+    hipLaunchKernelGGL(k_hist_reduce, dim3((nbins + 255) / 256, (nblocks + 31) / 32), dim3(256), 0, s, (const uint64_t*)partial, nblocks, nbins, counts, skip_flag);
     VMD_LAUNCH_CHECK();
     return 0;
 }
@@ -1842,6 +1990,70 @@ extern "C" int vmd_hip_distance(void* stream, const float* xyz, size_t frame_str
 extern "C" int vmd_hip_bbox(void* stream, const float* xyz, size_t frame_stride, size_t row_stride, int B, int natoms, float* out) {
     if (B <= 0 || natoms <= 0) return 0;
     hipLaunchKernelGGL(k_bbox, dim3(B), dim3(1024), 0, (hipStream_t)stream, xyz, frame_stride, row_stride, natoms, out);
+    VMD_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- two-level cell build (k_cells_bin / k_cells_pen_scan / k_cells_pen_sort) --------------------------------------------------
+#define VMD_PEN_MAX 4096            // pencils per frame the LDS table of k_cells_bin holds
+#define VMD_PEN_CAP_MAX 8192        // atoms of one pencil k_cells_pen_sort stages through LDS (96 KB)
+static int g_cells_pencil = 1;
+extern "C" int vmd_hip_set_cells_pencil(int on) { const int old = g_cells_pencil; g_cells_pencil = on; return old; }
+extern "C" int vmd_hip_cells_pencil_ok(vmd_grid_t grid) {
+    return g_cells_pencil && (long long)grid.ny * grid.nz <= VMD_PEN_MAX && grid.nxf <= 8192;
+}
+extern "C" int vmd_hip_cells_pencil_cap_max(void) { return VMD_PEN_CAP_MAX; }
+
+extern "C" int vmd_hip_cells_pencil_count(void* stream, const float* xyz, size_t frame_stride, size_t row_stride, const float* boxes,
+                                          uint32_t pbc_flags, int S, const int32_t* sel, int nsel, vmd_grid_t grid, uint32_t* counts) {
+    hipStream_t s = (hipStream_t)stream;
+    if (S <= 0 || nsel <= 0) return 0;
+    const int npen = grid.ny * grid.nz;
+    hipError_t e = hipMemsetAsync(counts, 0, sizeof(uint32_t) * (size_t)S * npen, s);
+    if (e != hipSuccess) return (int)e;
+    vmd_bin_params_t q{{xyz, frame_stride, row_stride, boxes, pbc_flags, sel, nsel, 0, grid, nullptr, nullptr, nullptr, nullptr, nullptr},
+                       nullptr, counts, nullptr, nullptr, npen, 0};
+    hipLaunchKernelGGL(k_cells_bin, dim3((nsel + 1024 * VMD_BIN_ILP - 1) / (1024 * VMD_BIN_ILP), S), dim3(1024), sizeof(uint32_t) * npen, s, q);
+    VMD_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int vmd_hip_cells_build_pencil(void* stream, const float* xyz, size_t frame_stride, size_t row_stride, const float* boxes,
+                                          uint32_t pbc_flags, int B, const int32_t* sel, int nsel, int nsel_pad, vmd_grid_t grid,
+                                          const uint32_t* pen_off, int total_cap, int cap_max, uint32_t* pen_count, uint32_t* pen_start,
+                                          float* bucket, uint32_t* overflow, uint32_t* cell_start, float* sorted) {
+    hipStream_t s = (hipStream_t)stream;
+    if (B <= 0 || nsel <= 0) return 0;
+    const int npen = grid.ny * grid.nz;
+    if (!vmd_hip_cells_pencil_ok(grid) || cap_max > VMD_PEN_CAP_MAX) return (int)hipErrorInvalidValue;
+    hipError_t e = hipMemsetAsync(pen_count, 0, sizeof(uint32_t) * (size_t)B * npen, s);
+    if (e != hipSuccess) return (int)e;
+    vmd_bin_params_t q{{xyz, frame_stride, row_stride, boxes, pbc_flags, sel, nsel, nsel_pad, grid, nullptr, nullptr, nullptr, nullptr, nullptr},
+                       pen_off, pen_count, bucket, overflow, npen, total_cap};
+    hipLaunchKernelGGL(k_cells_bin, dim3((nsel + 1024 * VMD_BIN_ILP - 1) / (1024 * VMD_BIN_ILP), B), dim3(1024), sizeof(uint32_t) * npen, s, q);
+    VMD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_cells_pen_scan, dim3(B), dim3(256), 0, s, (const uint32_t*)pen_count, pen_off, pen_start, npen);
+    VMD_LAUNCH_CHECK();
+    vmd_pensort_params_t ps{bucket, pen_off, pen_count, pen_start, cell_start, sorted, npen, grid.nxf, grid.ncell, nsel_pad, total_cap, cap_max};
+    const size_t shm = sizeof(uint32_t) * ((size_t)grid.nxf + 3 * (size_t)cap_max);
+    int ea = vmd_lds_opt_in((const void*)k_cells_pen_sort);
+    if (ea) return ea;
+    // grid.y = B <= 65535 (frame batches are far smaller); pencils on grid.x
+    hipLaunchKernelGGL(k_cells_pen_sort, dim3(npen, B), dim3(256), shm, s, ps);
+    VMD_LAUNCH_CHECK();
+    return 0;
+}
+
+// dst[i] += mult * src[i] (u64): one pair pass feeding several histograms (class decomposition of co-evaluated RDFs)
+__global__ __launch_bounds__(256) void k_axpy_u64(uint64_t* __restrict__ dst, const uint64_t* __restrict__ src, size_t n, uint64_t mult,
+                                                  const uint32_t* __restrict__ skip) {
+    if (skip && *skip) return;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) { const uint64_t v = src[i]; if (v) dst[i] += mult * v; }
+}
+extern "C" int vmd_hip_axpy_u64(void* stream, uint64_t* dst, const uint64_t* src, size_t n, uint64_t mult, const uint32_t* skip_flag) {
+    if (n == 0 || mult == 0) return 0;
+    hipLaunchKernelGGL(k_axpy_u64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dst, src, n, mult, skip_flag);
     VMD_LAUNCH_CHECK();
     return 0;
 }
