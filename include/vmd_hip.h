@@ -121,7 +121,11 @@ int vmd_hip_sdf_scatter(void* stream, const float* xyz, size_t frame_stride, siz
                         const int32_t* tgt, const int8_t* owner, int ntgt, float extent, int dim, uint64_t* volume,
                         const float* group /* from vmd_hip_sdf_align, or NULL */,
                         const uint8_t* atom_tag /* u8[row_stride] or NULL: dense-target path, one tag per ATOM: 255 = not a
-                                                   target, 254 = target, k <= 253 = target that belongs to structure k */);
+                                                   target, 254 = target, k <= 253 = target that belongs to structure k */,
+                        int tgt_first, int tgt_stride /* tgt_stride > 0: target t is atom tgt_first + t*tgt_stride (the index list
+                                                         is an arithmetic progression: no index load in front of the gathers) */,
+                        int unowned /* 1: no target is a member of any structure (owner all -1): skip the owner loads */);
+int vmd_hip_set_sdf_ilp(int n);        /* tuning knob: target atoms per thread of the scatter (4 or 8), returns the previous value */
 
 /* K5: distance family, one row per frame: out f32[B][P*per].  kind as vmd_distance_kind_t; P contexts (population);
  * context c uses a[aoff[c]..aoff[c+1]) and b[boff[c]..boff[c+1]); per = 1 (COM/MIN/MAX) or |a_c|*|b_c| (PAIR, equal

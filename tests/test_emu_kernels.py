@@ -118,6 +118,16 @@ def test_sdf_sparse_and_dense_target_paths(emu_lib, oracle):
             cases.check_sdf(emu_lib, oracle, coords, 36.0, structures, mass, sparse, 9.0)
         finally:
             emu_lib.vmd_set_option(b"sdf_dense", old)
+    # the scatter's target addressing: index list / arithmetic progression generated on the device, 4 / 8 atoms per thread,
+    # targets with and without owners, an irregular list (no progression)
+    irregular = np.sort(np.random.default_rng(5).choice(np.arange(0, N, dtype=np.int32), N // 4, replace=False)).astype(np.int32)
+    for arith, ilp in ((0, 4), (1, 8), (0, 8)):
+        old = emu_lib.vmd_set_option(b"sdf_arith", arith), emu_lib.vmd_set_option(b"sdf_ilp", ilp)
+        try:
+            cases.check_sdf(emu_lib, oracle, coords, 36.0, structures, mass, dense, 8.0)
+            cases.check_sdf(emu_lib, oracle, coords, 36.0, structures, mass, irregular, 8.0)
+        finally:
+            emu_lib.vmd_set_option(b"sdf_arith", old[0]); emu_lib.vmd_set_option(b"sdf_ilp", old[1])
 
 
 def test_distance_family(emu_lib, oracle):

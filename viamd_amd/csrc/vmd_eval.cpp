@@ -81,6 +81,7 @@ struct Options {
                                              // frame (k_xtc_decode), 2 = index pass + one thread per chunk (k_xtc_index / k_xtc_chunks)
     std::atomic<int> xtc_chunk{256};         // atoms per chunk of variant 2
     std::atomic<int> sdf_dense{0};       // dense-target SDF scatter (stream whole frames, select by tag): measured slower, off
+    std::atomic<int> sdf_arith{1};       // SDF target lists that are arithmetic progressions are generated on the device (0 = always load the index list)
     std::atomic<int> rdf_classes{1};     // co-evaluated RDFs of one range share pair passes through disjoint atom classes (0 = one pass per property)
 };
 static Options g_opt;
@@ -106,6 +107,8 @@ extern "C" int vmd_set_option(const char* key, int value) {
     else if (!strcmp(key, "xtc_device_decode")) o = &g_opt.xtc_device_decode;
     else if (!strcmp(key, "xtc_chunk")) o = &g_opt.xtc_chunk;
     else if (!strcmp(key, "rdf_classes")) o = &g_opt.rdf_classes;
+    else if (!strcmp(key, "sdf_arith")) o = &g_opt.sdf_arith;
+    else if (!strcmp(key, "sdf_ilp")) return vmd_hip_set_sdf_ilp(value);
     else if (!strcmp(key, "cells_pencil")) return vmd_hip_set_cells_pencil(value);
     else if (!strcmp(key, "cells_fused")) return vmd_hip_set_cells_fused(value);
     else if (!strcmp(key, "cells_split")) return vmd_hip_set_cells_split(value);
@@ -394,6 +397,8 @@ struct PropState {
     DevBuf<int32_t> d_structs, d_tgt;
     DevBuf<int8_t> d_owner;
     bool have_owner = false;
+    bool unowned = false;               // no target atom belongs to any structure
+    int tgt_first = 0, tgt_stride = 0;  // > 0: the target list is the arithmetic progression first + t * stride
     DevBuf<uint8_t> d_tag;              // dense-target path: one tag per atom
     bool have_tag = false;
     size_t tag_len = 0;
@@ -691,7 +696,14 @@ extern "C" void vmd_eval_clear_data(vmd_script_eval_t* eval) {
     eval->frames_computed = 0; eval->frames_reused = 0; eval->frames_device_decoded = 0;
     for (size_t b = 0; b < eval->num_blocks; ++b) eval->block_ready[b] = 0;
     for (auto& p : eval->props) {
-        std::fill(p->values.begin(), p->values.end(), 0.0f);
+        // the 8.4 MB float view of a volume is pinned: the copy engine zeroes it (from the cleared device view) while this
+        // thread clears the rest, instead of a host memset in the middle of every re-evaluation
+        if (p->prop.kind == PROP_SDF && p->pinned && p->d_values.ensure(p->ncounts) &&
+            hipMemsetAsync(p->d_values.p, 0, p->ncounts * sizeof(float), eval->stream) == hipSuccess &&
+            hipMemcpyAsync(p->values.data(), p->d_values.p, p->ncounts * sizeof(float), hipMemcpyDeviceToHost, eval->stream) == hipSuccess) {
+        } else {
+            std::fill(p->values.begin(), p->values.end(), 0.0f);
+        }
         std::fill(p->weights.begin(), p->weights.end(), 0.0f);
         // the 17 MB u64 mirror of a volume is only ever read after vmd_eval_refresh_counts: mark it stale instead of zeroing it
         if (p->prop.kind == PROP_SDF) p->counts_stale = true;
@@ -920,6 +932,15 @@ static bool upload_static(vmd_script_eval_t* e, const vmd_system_t* sys, size_t 
             }
             p->have_owner = unique;
             if (unique && !p->d_owner.upload(owner.data(), owner.size(), e->stream)) return false;
+            p->unowned = unique && std::all_of(owner.begin(), owner.end(), [](int8_t o) { return o < 0; });
+            // an arithmetic progression (every water oxygen of a regular solvent box: first + 3 t) needs no index list on the device
+            p->tgt_first = d.b[0]; p->tgt_stride = 0;
+            if (d.b.size() >= 2 && d.b[1] > d.b[0] && g_opt.sdf_arith != 0) {
+                const int64_t st = (int64_t)d.b[1] - d.b[0];
+                bool ok = true;
+                for (size_t t = 2; t < d.b.size() && ok; ++t) ok = (int64_t)d.b[t] - d.b[t - 1] == st;
+                if (ok && st < (1 << 20)) p->tgt_stride = (int)st;
+            }
             // dense targets: stream whole frames and select by a per-atom tag instead of gathering through the index list
             // sized from the TRAJECTORY's atom count (the target indices were validated against it, check_atoms), never from
             // sys->atom_count, which a host may leave unset or out of step
@@ -1308,15 +1329,23 @@ static bool build_selection(vmd_script_eval_t* e, Selection* s, const Stage& src
     return true;
 }
 
-static size_t auto_batch(const vmd_script_eval_t* e, size_t num_atoms) {
+static size_t auto_batch(const vmd_script_eval_t* e, size_t num_atoms, bool staged) {
     const int forced = g_opt.batch_frames;
     if (forced > 0) return (size_t)forced;
-    // scratch per frame: every selection holds ~20 B per selected atom + the staged frame itself (host trajectories)
-    size_t per_frame = 12 * num_atoms;
-    for (auto& s : e->sels) per_frame += 40 * s->idx.size();
+    // scratch per frame: a selection that takes part in a pair pass holds ~40 B per atom (sorted rows, bucket records, tables);
+    // host trajectories add the staged frame itself; SDF / distance properties need a few hundred bytes
+    size_t per_frame = staged ? 12 * num_atoms : 0;
+    std::vector<char> used(e->sels.size(), 0);
+    for (auto& g : e->rdf_groups) for (auto& ps : g.passes) { used[ps.sel_a] = 1; used[ps.sel_b] = 1; }
+    for (size_t i = 0; i < e->sels.size(); ++i) if (used[i]) per_frame += 40 * e->sels[i]->idx.size();
+    for (auto& p : e->props) per_frame += p->prop.kind == PROP_SDF ? 64 * p->prop.K : (p->prop.kind == PROP_DIST ? 4 * p->dim1 : 0);
     // 288 GB of HBM: a 12 GB scratch budget keeps whole 1k-frame trajectories of the 1M-atom configs in one or two launches
     size_t B = (size_t)(12ull << 30) / std::max<size_t>(per_frame, 1);
-    B = std::max<size_t>(1, std::min<size_t>(B, 1024));
+    // pair passes are long (a 1 024-frame batch of the 1M-atom RDF runs ~90 ms: interrupts are polled between batches); scripts
+    // without them stream whole frames at HBM speed and take much larger batches, so that launches, the alignment kernel's
+    // latency and the per-batch synchronisation stay small against the stream (grid.y = frames of the batch <= 65535)
+    const size_t cap = e->rdf_groups.empty() ? 16384 : 1024;
+    B = std::max<size_t>(1, std::min<size_t>(B, cap));
     return B;
 }
 
@@ -1431,7 +1460,7 @@ static bool process_range(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
     if (!reuse_blocks(e, frame_beg, frame_end, &segments)) return false;
 
     // frames per launch: as many as the scratch budget allows, split evenly so that no small tail batch is left
-    size_t Bmax = auto_batch(e, num_atoms);
+    size_t Bmax = auto_batch(e, num_atoms, !have_view);
     const vmd_device_view_t* vw = have_view ? &view : nullptr;
     // host trajectories are staged in smaller batches so that load_frame of batch k+1 overlaps the kernels of batch k
     if (!have_view && g_opt.batch_frames <= 0) Bmax = std::min<size_t>(Bmax, 128);
@@ -1556,7 +1585,8 @@ static bool process_range(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
                 KRN_OK(vmd_hip_sdf_scatter(e->stream, src.base, src.frame_stride, src.row_stride, src.d_boxes.p, pbc, (int)nb,
                                            p->d_structs.p, (int)d.K, (int)d.m, p->d_R32.p, p->d_c32.p, p->d_tgt.p, p->have_owner ? p->d_owner.p : nullptr, (int)d.b.size(),
                                            d.rmax, VMD_VOLUME_DIM, acc, p->d_group.p,
-                                           (p->have_tag && p->tag_len == src.row_stride) ? p->d_tag.p : nullptr));
+                                           (p->have_tag && p->tag_len == src.row_stride) ? p->d_tag.p : nullptr,
+                                           p->tgt_first, p->tgt_stride, p->unowned ? 1 : 0));
                 e->prof.end(e->stream);
                 p->dirty = true;
             } else {

@@ -1505,6 +1505,8 @@ struct vmd_scatter_params_t {
     const int32_t* __restrict__ tgt; const int8_t* __restrict__ owner; int ntgt; float extent; int dim;
     unsigned long long* volume;
     const float* __restrict__ group;   // f32[B][4] from k_sdf_group, or NULL
+    int tgt_first, tgt_stride;         // tgt_stride > 0: target t is atom tgt_first + t * tgt_stride (no index list to chase)
+    int unowned;                       // 1: no target belongs to any structure (the exclusion rule never applies)
 };
 
 // one target atom against structure k of frame b (SPEC S5 scatter).  own_k: structure the atom belongs to (-1 none,
@@ -1562,32 +1564,39 @@ __device__ __forceinline__ bool vmd_sdf_near(const vmd_scatter_params_t& p, cons
 // running the K transforms under the divergent mask would cost every wave the full loop at ~5 % lane use.  Instead a block
 // first compacts the atoms that pass the group test into LDS (1024 candidates per block, all gathers in flight at once),
 // then spreads the (atom, structure) pairs evenly over its threads.
-#define VMD_SDF_ILP 4
+// ARITH: the target list is an arithmetic progression (every water oxygen of a regular solvent box: first + 3 t), so the atom index
+// is computed instead of loaded and the coordinate gathers do not wait for an index load - one memory round trip per block
+// instead of two (the kernel is bound by the latency of its loads under load: a wave used to live ~12 us).
+// ILP atoms per thread: all their gathers are in flight at once.
+template <int ILP, bool ARITH>
 __global__ __launch_bounds__(256) void k_sdf_scatter(vmd_scatter_params_t p) {
-    __shared__ float s_x[256 * VMD_SDF_ILP], s_y[256 * VMD_SDF_ILP], s_z[256 * VMD_SDF_ILP];
-    __shared__ int s_own[256 * VMD_SDF_ILP], s_idx[256 * VMD_SDF_ILP];
+    __shared__ float s_x[256 * ILP], s_y[256 * ILP], s_z[256 * ILP];
+    __shared__ int s_own[256 * ILP], s_idx[256 * ILP];
     __shared__ unsigned s_n;
-    const int t0 = blockIdx.x * (256 * VMD_SDF_ILP) + threadIdx.x;
+    const int t0 = blockIdx.x * (256 * ILP) + threadIdx.x;
     const int b = blockIdx.y;
     const vmd_box_t bx = vmd_load_box(p.boxes, b, p.pbc);
     const float* fx = p.xyz + (size_t)b * p.frame_stride;
     if (threadIdx.x == 0) s_n = 0u;
-    int idx[VMD_SDF_ILP], own[VMD_SDF_ILP];
-    float x[VMD_SDF_ILP], y[VMD_SDF_ILP], z[VMD_SDF_ILP];
+    int idx[ILP], own[ILP];
+    float x[ILP], y[ILP], z[ILP];
 #pragma unroll
-    for (int u = 0; u < VMD_SDF_ILP; ++u) {
+    for (int u = 0; u < ILP; ++u) {
         const int t = t0 + 256 * u;
-        idx[u] = -1; own[u] = -2;
-        if (t < p.ntgt) { idx[u] = p.tgt ? p.tgt[t] : t; own[u] = p.owner ? (int)p.owner[t] : -2; }
+        idx[u] = -1; own[u] = p.unowned ? -1 : -2;
+        if (t < p.ntgt) {
+            idx[u] = ARITH ? p.tgt_first + t * p.tgt_stride : (p.tgt ? p.tgt[t] : t);
+            if (!p.unowned && p.owner) own[u] = (int)p.owner[t];
+        }
     }
 #pragma unroll
-    for (int u = 0; u < VMD_SDF_ILP; ++u) {
+    for (int u = 0; u < ILP; ++u) {
         x[u] = y[u] = z[u] = 0.0f;
         if (idx[u] >= 0) { x[u] = fx[idx[u]]; y[u] = fx[p.row_stride + idx[u]]; z[u] = fx[2 * p.row_stride + idx[u]]; }
     }
     __syncthreads();
 #pragma unroll
-    for (int u = 0; u < VMD_SDF_ILP; ++u) {
+    for (int u = 0; u < ILP; ++u) {
         if (idx[u] >= 0 && vmd_sdf_near(p, bx, b, x[u], y[u], z[u])) {
             const unsigned slot = atomicAdd(&s_n, 1u);
             s_x[slot] = x[u]; s_y[slot] = y[u]; s_z[slot] = z[u]; s_own[slot] = own[u]; s_idx[slot] = idx[u];
@@ -1946,22 +1955,33 @@ extern "C" int vmd_hip_sdf_ref_pose(void* stream, const float* xyz, size_t row_s
     return 0;
 }
 
+static int g_sdf_ilp = 4;
+extern "C" int vmd_hip_set_sdf_ilp(int n) { const int old = g_sdf_ilp; if (n == 4 || n == 8) g_sdf_ilp = n; return old; }
 extern "C" int vmd_hip_sdf_scatter(void* stream, const float* xyz, size_t frame_stride, size_t row_stride,
                                    const float* boxes, uint32_t pbc_flags, int B,
                                    const int32_t* structs, int K, int m, const float* R32, const float* c32,
                                    const int32_t* tgt, const int8_t* owner, int ntgt, float extent, int dim, uint64_t* volume,
-                                   const float* group, const uint8_t* atom_tag) {
+                                   const float* group, const uint8_t* atom_tag, int tgt_first, int tgt_stride, int unowned) {
     hipStream_t s = (hipStream_t)stream;
     if (B <= 0 || K <= 0 || ntgt <= 0) return 0;
     vmd_scatter_params_t p{xyz, frame_stride, row_stride, boxes, pbc_flags, B, structs, K, m, R32, c32, tgt, owner, ntgt, extent, dim,
-                           (unsigned long long*)volume, group};
+                           (unsigned long long*)volume, group, tgt_first, tgt_stride, unowned};
     if (atom_tag) {
         const int natoms4 = (int)(row_stride / 4);       // rows are padded to a multiple of 64 floats; the tag array covers the padding
         hipLaunchKernelGGL(k_sdf_scatter_dense, dim3((natoms4 + 255) / 256, B), dim3(256), 0, s, p, atom_tag, natoms4);
         VMD_LAUNCH_CHECK();
         return 0;
     }
-    hipLaunchKernelGGL(k_sdf_scatter, dim3((ntgt + 256 * VMD_SDF_ILP - 1) / (256 * VMD_SDF_ILP), B), dim3(256), 0, s, p);
+    const bool arith = tgt_stride > 0;
+    if (g_sdf_ilp == 8) {
+        const dim3 g((ntgt + 256 * 8 - 1) / (256 * 8), B);
+        if (arith) hipLaunchKernelGGL((k_sdf_scatter<8, true>), g, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((k_sdf_scatter<8, false>), g, dim3(256), 0, s, p);
+    } else {
+        const dim3 g((ntgt + 256 * 4 - 1) / (256 * 4), B);
+        if (arith) hipLaunchKernelGGL((k_sdf_scatter<4, true>), g, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((k_sdf_scatter<4, false>), g, dim3(256), 0, s, p);
+    }
     VMD_LAUNCH_CHECK();
     return 0;
 }
