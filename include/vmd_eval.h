@@ -219,6 +219,35 @@ size_t   vmd_eval_frames_done(const vmd_script_eval_t* eval);
 bool vmd_eval_sdf_matrices(vmd_script_eval_t* eval, const char* name, const vmd_system_t* sys,
                            vmd_trajectory_i* traj, uint32_t frame, float* matrices, size_t* K_out, float* extent_out);
 
+/* the rest of the vis payload VIAMD consumes next to the matrices (md_script_vis_eval_payload with MD_SCRIPT_VISUALIZE_ATOMS |
+ * MD_SCRIPT_VISUALIZE_SDF: vis.sdf.structures, density_volume.cpp:263-269; export_cube writes the atoms of structure 0,
+ * src/main.cpp:5793-5803): the K x m atom indices of the reference structures (eval-owned, valid for its lifetime) */
+const int32_t* vmd_eval_sdf_structures(const vmd_script_eval_t* eval, const char* name, size_t* num_structures, size_t* atoms_per_structure);
+typedef struct vmd_sdf_payload_t {
+    size_t num_structures, atoms_per_structure;
+    const int32_t* structures;      /* [num_structures][atoms_per_structure], eval-owned */
+    const float*   matrices;        /* [num_structures][16] column-major world->reference of the requested frame; valid until the
+                                       calling thread's next vmd_eval_sdf_payload */
+    float extent;                   /* half edge of the volume in Angstrom (vis.sdf.extent) */
+} vmd_sdf_payload_t;
+bool vmd_eval_sdf_payload(vmd_script_eval_t* eval, const char* name, const vmd_system_t* sys, vmd_trajectory_i* traj, uint32_t frame,
+                          vmd_sdf_payload_t* out);
+
+/* ---- export, viamd_amd/csrc/vmd_export.cpp: the files VIAMD writes from evaluated properties ---------------------
+ * export_xvg / export_csv (src/main.cpp:5640-5716): columns[j][i], one label per column */
+bool vmd_export_xvg(const char* path, const float* const* columns, const char* const* labels, size_t num_columns, size_t num_rows);
+bool vmd_export_csv(const char* path, const float* const* columns, const char* const* labels, size_t num_columns, size_t num_rows);
+/* the table the property-export window assembles for one property (src/main.cpp:5953-6040): temporal -> time (frame_times, or the
+ * frame index when NULL) + one column per population member; distribution -> num_bins (0 = 128) display bins over
+ * [min_range[0], max_range[0]].  format: "xvg" or "csv" */
+bool vmd_export_property_table(const char* path, vmd_script_eval_t* eval, const char* name, const char* format,
+                               const double* frame_times, int num_bins);
+/* export_cube (src/main.cpp:5718-5830): Gaussian cube file of volume property `name` in Bohr, x outermost / z innermost over the
+ * x-fastest array, preceded by the atoms of reference structure 0 (coordinates of trajectory frame 0 through the
+ * world->reference matrix of `frame` - VIAMD passes the displayed frame).  atomic_numbers: per atom, or NULL (written as 0) */
+bool vmd_export_cube(const char* path, vmd_script_eval_t* eval, const char* name, const vmd_system_t* sys, vmd_trajectory_i* traj,
+                     uint32_t frame, const uint8_t* atomic_numbers);
+
 /* ---- multi-GPU merge: integer accumulators are exported / imported as plain device or host
  * buffers so the host runtime (torch.distributed = RCCL) can all-reduce them ------------------------- */
 typedef struct vmd_accum_view_t {

@@ -26,7 +26,7 @@ typedef float f2 __attribute__((vector_size(8)));
 
 enum Kind {
     K_FMA = 0, K_PK_FMA, K_PK_ADD, K_PK_MUL, K_PK_ADD_S, K_ADD_S, K_CMP, K_MBCNT, K_LSHL_ADD, K_SQRT, K_CVT_FLR, K_FRACT,
-    K_SALU, K_VALU_SALU, K_FILTER_PK, K_FILTER_UNPK, K_FILTER_PK_SHIFT, K_PUSH, K_DS_WRITE, K_DS_ADD, K_SUB_VVV, K_MUL_VVV, K_FMA_S, K_COUNT
+    K_SALU, K_VALU_SALU, K_FILTER_PK, K_FILTER_UNPK, K_FILTER_PK_SHIFT, K_PUSH, K_DS_WRITE, K_DS_ADD, K_SUB_VVV, K_MUL_VVV, K_FMA_S, K_CMP_VV, K_CMP_VV_SDST, K_LSHLREV_VV, K_LSHL_ADD_VV, K_MBCNT_V, K_COUNT
 };
 static const char* kind_name[K_COUNT] = {
     "v_fma_f32 v,v,v,v", "v_pk_fma_f32", "v_pk_add_f32 v,v,v", "v_pk_mul_f32 v,v,v", "v_pk_add_f32 v,v,s[2]", "v_add_f32 v,s,v",
@@ -35,9 +35,10 @@ static const char* kind_name[K_COUNT] = {
     "filter 4 col packed (6 pk + 4 cmp = 10 inst)", "filter 4 col unpacked (12 + 4 cmp = 16 inst)",
     "filter 4 col packed + image shift (9 pk + 4 cmp = 13 inst)",
     "filter 4 col packed + push, ~14 % lanes hit (10 + 4x(3 VALU + ds_write + 4 SALU))", "ds_write_b32 (stride 4)", "ds_add_u32 (random bins)",
-    "v_sub_f32 v,v,v", "v_mul_f32 v,v,v", "v_fma_f32 v,s,v,v"};
+    "v_sub_f32 v,v,v", "v_mul_f32 v,v,v", "v_fma_f32 v,s,v,v",
+    "v_cmp_gt_f32 vcc,v,v", "v_cmp_gt_f32 s[2],v,v", "v_lshlrev_b32 v,2,v", "v_lshl_add_u32 v,v,2,v", "v_mbcnt_lo+hi with VGPR masks (2 inst)"};
 // instructions counted per unrolled unit (for cyc/inst)
-static const int kind_insts[K_COUNT] = {1, 1, 1, 1, 1, 1, 1, 2, 1, 1, 1, 1, 1, 2, 10, 16, 13, 10, 1, 1, 1, 1, 1};
+static const int kind_insts[K_COUNT] = {1, 1, 1, 1, 1, 1, 1, 2, 1, 1, 1, 1, 1, 2, 10, 16, 13, 10, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2};
 
 template <int KIND>
 __global__ __launch_bounds__(256) void k_stream(int iters, uint64_t* ticks, float* sink, float sj0, float sj1, float sj2, float sj3) {
@@ -212,6 +213,28 @@ __global__ __launch_bounds__(256) void k_stream(int iters, uint64_t* ticks, floa
 #define X(n) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a##n) : "s"(sj0), "v"(d));
             REP64(X)
 #undef X
+        } else if (KIND == K_CMP_VV) {
+#define X(n) asm volatile("v_cmp_gt_f32 vcc, %1, %0" : : "v"(a##n), "v"(c) : "vcc");
+            REP64(X)
+#undef X
+        } else if (KIND == K_CMP_VV_SDST) {
+            unsigned long long m;
+#define X(n) asm volatile("v_cmp_gt_f32 %0, %2, %1" : "=s"(m) : "v"(a##n), "v"(c));
+            REP64(X)
+#undef X
+            s0 += (unsigned)m;
+        } else if (KIND == K_LSHLREV_VV) {
+#define X(n) asm volatile("v_lshlrev_b32 %0, 2, %0" : "+v"(i##n));
+            REP64(X)
+#undef X
+        } else if (KIND == K_LSHL_ADD_VV) {
+#define X(n) asm volatile("v_lshl_add_u32 %0, %0, 2, %1" : "+v"(i##n) : "v"(i0));
+            REP64(X)
+#undef X
+        } else if (KIND == K_MBCNT_V) {
+#define X(n) asm volatile("v_mbcnt_lo_u32_b32 %0, %1, 0\n\tv_mbcnt_hi_u32_b32 %0, %2, %0" : "=&v"(i##n) : "v"(i0), "v"(i1));
+            REP64(X)
+#undef X
         } else if (KIND == K_DS_WRITE) {
 #define X(n) asm volatile("ds_write_b32 %0, %1" : : "v"(lane4), "v"(a##n) : "memory");
             REP64(X)
@@ -237,7 +260,7 @@ template <int K> static kern_t get() { return k_stream<K>; }
 static kern_t kern_of(int k) {
     switch (k) {
 #define C(K) case K: return get<K>();
-        C(0) C(1) C(2) C(3) C(4) C(5) C(6) C(7) C(8) C(9) C(10) C(11) C(12) C(13) C(14) C(15) C(16) C(17) C(18) C(19) C(20) C(21) C(22)
+        C(0) C(1) C(2) C(3) C(4) C(5) C(6) C(7) C(8) C(9) C(10) C(11) C(12) C(13) C(14) C(15) C(16) C(17) C(18) C(19) C(20) C(21) C(22) C(23) C(24) C(25) C(26) C(27)
 #undef C
     }
     return nullptr;

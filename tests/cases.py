@@ -630,3 +630,73 @@ def distance_known_answer(lib, device=False):
         assert ev.property_data("min").values.reshape(F, -1)[f, 0] == f32(26)
         assert ev.property_data("max").values.reshape(F, -1)[f, 0] == f32(50)
         np.testing.assert_array_equal(np.sort(ev.property_data("pair").values.reshape(F, -1)[f]), np.sort([f32(26), f32(50), f32(26), f32(34)]))
+
+
+def export_cases(lib, O, tmp_path, device=False, n_water=1500, box=34.0):
+    """SURVEY 8f-2 behind the C ABI: an evaluated script -> Gaussian cube (volume + atoms of reference structure 0, export_cube,
+    src/main.cpp:5718-5830) and XVG / CSV tables (src/main.cpp:5640-5716, 5953-6040); everything read back and compared with
+    the evaluator's own arrays and the vis payload (matrices, structures, extent)."""
+    from viamd_amd import export
+    F = 3
+    coords, structures, mass = sdf_system(O, 8, n_water, box, F, K=3, m=7)
+    n_s, N = structures.size, coords.shape[2]
+    ox = np.arange(n_s, N, 3, dtype=np.int32)
+    ocell, vcell = cell_pair(O, box)
+    ir = V.ScriptIR(lib)
+    ir.add_sdf("v", structures, ox, 7.0)
+    ir.add_rdf("g", ox, ox, (0.0, 9.0))
+    ir.add_distance("d", structures[0], structures[1], L.DIST_COM)
+    ir.add_distance_population("p", [s[:2] for s in structures], [s[3:5] for s in structures], L.DIST_MIN)
+    ev = V.ScriptEval(F, ir)
+    traj = make_traj(lib, coords, vcell, device)
+    sysm = V.MolSystem(N, mass=mass, unitcell=vcell)
+    assert ev.frame_range(sysm, traj, 0, F)
+    # vis payload: matrices of a frame + the structures' atoms + the half extent
+    mats, st, ext = ev.sdf_payload("v", sysm, traj, 1)
+    np.testing.assert_array_equal(st, structures)
+    M4, ext2 = ev.sdf_matrices("v", sysm, traj, 1)
+    np.testing.assert_array_equal(mats, M4)
+    assert ext == ext2 == np.float32(7.0)
+    # cube: structure 0's atoms at frame-0 coordinates through the matrix of the requested frame, then the volume
+    anum = np.where(mass > 15.0, 8, np.where(mass > 13.0, 7, np.where(mass > 11.0, 6, 1))).astype(np.uint8)
+    path = tmp_path / "v.cube"
+    ev.export_cube(path, "v", sysm, traj, frame=1, atomic_numbers=anum)
+    back = export.read_cube(path)
+    vol = ev.property_data("v").counts
+    assert vol.sum() > 0
+    np.testing.assert_array_equal(back["volume"], vol.astype(np.float64))        # counts stay far below 1e6: %12.6E is exact
+    b = export.ANGSTROM_TO_BOHR
+    assert back["dim"] == [128] * 3 and abs(back["origin"][0] + 7.0 * b) < 1e-5 and abs(back["voxel"][1] - 14.0 * b / 128) < 1e-6
+    assert len(back["atoms"]) == structures.shape[1]
+    want = (mats[0] @ np.concatenate([coords[0][:, np.sort(structures[0])], np.ones((1, structures.shape[1]))]))[:3].T * b
+    got = np.array([a[2:] for a in back["atoms"]])
+    np.testing.assert_allclose(got, want, atol=2e-5)
+    assert [int(a[0]) for a in back["atoms"]] == [int(anum[i]) for i in np.sort(structures[0])]
+    lines = path.read_text().split("\n")
+    assert lines[0] == "EXPORTED DENSITY VOLUME FROM VIAMD, UNITS IN BOHR" and lines[1] == "OUTER LOOP: X, MIDDLE LOOP: Y, INNER LOOP: Z"
+    # tables
+    for fmt in ("xvg", "csv"):
+        for name in ("g", "d", "p"):
+            ev.export_table(tmp_path / f"{name}.{fmt}", name, fmt)
+    rows = [l for l in (tmp_path / "d.xvg").read_text().split("\n") if l and l[0] not in "#@"]
+    d = ev.property_data("d").values
+    assert len(rows) == F and [float(r.split()[0]) for r in rows] == [0.0, 1.0, 2.0]
+    np.testing.assert_allclose([float(r.split()[1]) for r in rows], d, atol=6e-7)
+    assert '@ s1 legend "d"' in (tmp_path / "d.xvg").read_text()
+    csv = (tmp_path / "p.csv").read_text().split("\n")
+    assert csv[0] == "Frame,p[1],p[2],p[3],"                                      # trailing comma as export_csv writes it
+    p = ev.property_data("p").values.reshape(F, 3)
+    np.testing.assert_allclose([[float(t) for t in r.split(",")[1:4]] for r in csv[1:1 + F]], p, rtol=1e-5)      # %.6g
+    g = [l for l in (tmp_path / "g.csv").read_text().split("\n")[1:] if l]
+    assert len(g) == 128
+    gd = V.downsample_histogram(ev.property_data("g").values, ev.property_data("g").weights, 128, lib=lib)
+    np.testing.assert_allclose([float(r.split(",")[1]) for r in g], gd, rtol=1e-5, atol=1e-12)
+    x = [float(r.split(",")[0]) for r in g]
+    assert x[0] == 0.0 and abs(x[-1] - 9.0) < 1e-6 and abs(x[1] - 9.0 / 127) < 1e-6     # sample_range: both ends included
+    with pytest_raises(V.VmdError):
+        ev.export_table(tmp_path / "v.csv", "v", "csv")
+
+
+def pytest_raises(exc):
+    import pytest
+    return pytest.raises(exc)

@@ -433,3 +433,8 @@ def test_open_boundaries_and_slabs_on_the_grid(gpu_lib, oracle):
 
 def test_sdf_triclinic_spread_structures_regression(gpu_lib, oracle):
     cases.sdf_triclinic_spread_structures(gpu_lib, oracle, device=True)
+
+
+def test_cube_and_table_export_from_a_gpu_evaluation(tmp_path, gpu_lib, oracle):
+    """VERDICT r01 #9: GPU-evaluated SDF -> vmd_export_cube (C++) -> read back == counts; vis payload with the structures."""
+    cases.export_cases(gpu_lib, oracle, tmp_path, device=True, n_water=30000, box=70.0)

@@ -355,3 +355,8 @@ Velocities
         loader.load_system(tmp_path / "t.dcd")
     with pytest.raises(ValueError, match="could not determine loader type"):
         loader.loader_type("file.unknown")
+
+
+def test_export_in_the_product_library_on_the_emulator(tmp_path, emu_lib, oracle):
+    import cases
+    cases.export_cases(emu_lib, oracle, tmp_path)

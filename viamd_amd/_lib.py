@@ -103,6 +103,11 @@ class CollectiveI(C.Structure):          # vmd_collective_i
 COMM_ID_BYTES = 128
 
 
+class SdfPayload(C.Structure):          # vmd_sdf_payload_t
+    _fields_ = [("num_structures", C.c_size_t), ("atoms_per_structure", C.c_size_t), ("structures", c_int32_p),
+                ("matrices", c_float_p), ("extent", C.c_float)]
+
+
 class Grid(C.Structure):
     _fields_ = [("nxf", C.c_int32), ("ny", C.c_int32), ("nz", C.c_int32), ("ncell", C.c_int32)]
 
@@ -139,6 +144,12 @@ SIGNATURES = [
     ("vmd_eval_refresh_counts", C.c_bool, [_vp, C.c_char_p]),
     ("vmd_eval_finalize", C.c_bool, [_vp]),
     ("vmd_eval_set_frame_mask", None, [_vp, c_uint8_p, C.c_size_t]),
+    ("vmd_eval_sdf_structures", c_int32_p, [_vp, C.c_char_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    ("vmd_eval_sdf_payload", C.c_bool, [_vp, C.c_char_p, C.POINTER(System), C.POINTER(TrajectoryI), C.c_uint32, C.POINTER(SdfPayload)]),
+    ("vmd_export_xvg", C.c_bool, [C.c_char_p, C.POINTER(c_float_p), C.POINTER(C.c_char_p), C.c_size_t, C.c_size_t]),
+    ("vmd_export_csv", C.c_bool, [C.c_char_p, C.POINTER(c_float_p), C.POINTER(C.c_char_p), C.c_size_t, C.c_size_t]),
+    ("vmd_export_property_table", C.c_bool, [C.c_char_p, _vp, C.c_char_p, C.c_char_p, c_double_p, C.c_int]),
+    ("vmd_export_cube", C.c_bool, [C.c_char_p, _vp, C.c_char_p, C.POINTER(System), C.POINTER(TrajectoryI), C.c_uint32, c_uint8_p]),
     ("vmd_eval_reduce", C.c_bool, [_vp, C.POINTER(CollectiveI), _vp]),
     ("vmd_comm_unique_id", C.c_bool, [c_uint8_p]),
     ("vmd_comm_create", _vp, [C.c_int, C.c_int, c_uint8_p]),

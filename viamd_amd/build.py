@@ -8,7 +8,8 @@ ROOT = os.path.dirname(_HERE)
 SOURCES = [os.path.join(_HERE, "csrc", "vmd_kernels.hip"), os.path.join(_HERE, "csrc", "vmd_xtc_device.hip"),
            os.path.join(_HERE, "csrc", "vmd_eval.cpp"),
            os.path.join(_HERE, "csrc", "vmd_dcd.cpp"), os.path.join(_HERE, "csrc", "vmd_xdr.cpp"),
-           os.path.join(_HERE, "csrc", "vmd_script.cpp"), os.path.join(_HERE, "csrc", "vmd_reduce.cpp")]
+           os.path.join(_HERE, "csrc", "vmd_script.cpp"), os.path.join(_HERE, "csrc", "vmd_reduce.cpp"),
+           os.path.join(_HERE, "csrc", "vmd_export.cpp")]
 HEADERS = [os.path.join(ROOT, "include", "vmd_eval.h"), os.path.join(ROOT, "include", "vmd_hip.h")]
 OUT = os.path.join(_HERE, "libviamd_amd.so")
 

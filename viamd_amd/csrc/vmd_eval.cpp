@@ -1697,6 +1697,14 @@ extern "C" bool vmd_eval_frame_range(vmd_script_eval_t* eval, const vmd_script_i
     return me.ok;
 }
 
+extern "C" const int32_t* vmd_eval_sdf_structures(const vmd_script_eval_t* eval, const char* name, size_t* num_structures, size_t* atoms_per_structure) {
+    PropState* p = find_prop(eval, name);
+    if (!p || p->prop.kind != PROP_SDF) { vmd_fail("'%s' is not an sdf property", name ? name : "(null)"); return nullptr; }
+    if (num_structures) *num_structures = p->prop.K;
+    if (atoms_per_structure) *atoms_per_structure = p->prop.m;
+    return p->prop.a.data();
+}
+
 extern "C" bool vmd_eval_sdf_matrices(vmd_script_eval_t* eval, const char* name, const vmd_system_t* sys,
                                       vmd_trajectory_i* traj, uint32_t frame, float* matrices, size_t* K_out, float* extent_out) {
     if (!eval || !traj) return vmd_fail("vmd_eval_sdf_matrices: NULL argument");

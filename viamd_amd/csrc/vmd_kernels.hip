@@ -588,9 +588,9 @@ struct vmd_pensort_params_t {
 };
 __global__ __launch_bounds__(256) void k_cells_pen_sort(vmd_pensort_params_t q) {
     HIP_DYNAMIC_SHARED(uint32_t, s_dyn)
-    __shared__ uint32_t s_part[256];
     uint32_t* s_cnt = s_dyn;                                  // [nxf]
-    float* s_xyz = (float*)(s_dyn + q.nxf);                   // [3][cap_max]
+    uint32_t* s_part = s_dyn + q.nxf;                         // [256] scan partials (no static LDS: the dynamic part may take it all)
+    float* s_xyz = (float*)(s_dyn + q.nxf + 256);             // [3][cap_max]
     const int pen = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
     const int nxf = q.nxf;
     const uint32_t off = q.pen_off[pen], cap = q.pen_off[pen + 1] - off;
@@ -1730,11 +1730,19 @@ __global__ __launch_bounds__(256) void k_distance_pair(vmd_dist_params_t p) {
 
 __global__ __launch_bounds__(256) void k_counts_to_float(const uint64_t* __restrict__ counts, size_t n, float* __restrict__ values,
                                                          unsigned* __restrict__ max_bits) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const float v = (float)counts[i];
-    values[i] = v;
-    if (max_bits && v > 0.0f) atomicMax(max_bits, (unsigned)__float_as_int(v));
+    // 8 voxels per thread, one atomicMax per WAVE: a filled 128^3 volume used to issue ~10^6 same-address atomics (0.38 ms per call,
+    // more than the conversion's 25 MB of traffic costs)
+    const size_t i0 = (size_t)blockIdx.x * 2048 + threadIdx.x;
+    float vmax = 0.0f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const size_t i = i0 + 256 * (size_t)u;
+        if (i < n) { const float v = (float)counts[i]; values[i] = v; vmax = fmaxf(vmax, v); }
+    }
+    if (max_bits) {
+        vmax = vmd_wave_max(vmax);
+        if ((threadIdx.x & 63) == 0 && vmax > 0.0f) atomicMax(max_bits, (unsigned)__float_as_int(vmax));
+    }
 }
 
 __device__ __forceinline__ uint64_t vmd_mix64(uint64_t z) {
@@ -2055,7 +2063,8 @@ extern "C" int vmd_hip_cells_build_pencil(void* stream, const float* xyz, size_t
     hipLaunchKernelGGL(k_cells_pen_scan, dim3(B), dim3(256), 0, s, (const uint32_t*)pen_count, pen_off, pen_start, npen);
     VMD_LAUNCH_CHECK();
     vmd_pensort_params_t ps{bucket, pen_off, pen_count, pen_start, cell_start, sorted, npen, grid.nxf, grid.ncell, nsel_pad, total_cap, cap_max};
-    const size_t shm = sizeof(uint32_t) * ((size_t)grid.nxf + 3 * (size_t)cap_max);
+    const size_t shm = sizeof(uint32_t) * ((size_t)grid.nxf + 256 + 3 * (size_t)cap_max);
+    if (shm > 160 * 1024 - 64) return (int)hipErrorInvalidValue;
     int ea = vmd_lds_opt_in((const void*)k_cells_pen_sort);
     if (ea) return ea;
     // grid.y = B <= 65535 (frame batches are far smaller); pencils on grid.x
@@ -2097,7 +2106,7 @@ extern "C" int vmd_hip_counts_to_float(void* stream, const uint64_t* counts, siz
         hipError_t e = hipMemsetAsync(max_out, 0, sizeof(float), s);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL(k_counts_to_float, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, counts, n, values, (unsigned*)max_out);
+    hipLaunchKernelGGL(k_counts_to_float, dim3((unsigned)((n + 2047) / 2048)), dim3(256), 0, s, counts, n, values, (unsigned*)max_out);
     VMD_LAUNCH_CHECK();
     return 0;
 }

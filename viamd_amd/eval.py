@@ -314,6 +314,41 @@ class ScriptEval:
         return mats.reshape(-1, 4, 4).transpose(0, 2, 1).copy(), float(ext.value)
 
 
+def _sdf_payload(self, name, sys, traj, frame):
+    """md_script_vis_eval_payload(ATOMS | SDF) as VIAMD consumes it: (matrices [K,4,4] with M[k] @ [x,y,z,1], structures [K,m]
+    atom indices, extent) - density_volume.cpp:183-204, 263-269."""
+    pl = L.SdfPayload()
+    sysp = C.byref(sys.c) if sys is not None else None
+    if not self.lib.vmd_eval_sdf_payload(self.h, name.encode(), sysp, traj.interface(), int(frame), C.byref(pl)):
+        raise VmdError(self.lib.last_error())
+    K, m = pl.num_structures, pl.atoms_per_structure
+    mats = np.ctypeslib.as_array(pl.matrices, shape=(K, 16)).copy().reshape(K, 4, 4).transpose(0, 2, 1).copy()
+    structures = np.ctypeslib.as_array(pl.structures, shape=(K, m)).copy()
+    return mats, structures, float(pl.extent)
+
+
+def _export_cube(self, path, name, sys, traj, frame=0, atomic_numbers=None):
+    """export_cube (src/main.cpp:5718-5830) in C++ behind the ABI: the volume + the atoms of reference structure 0."""
+    an = None if atomic_numbers is None else np.ascontiguousarray(atomic_numbers, np.uint8)
+    sysp = C.byref(sys.c) if sys is not None else None
+    if not self.lib.vmd_export_cube(str(path).encode(), self.h, name.encode(), sysp, traj.interface(), int(frame),
+                                    an.ctypes.data_as(L.c_uint8_p) if an is not None else None):
+        raise VmdError(self.lib.last_error())
+
+
+def _export_table(self, path, name, fmt="xvg", frame_times=None, num_bins=0):
+    """the XVG / CSV table VIAMD's export window writes for a temporal or distribution property (src/main.cpp:5953-6040)"""
+    ft = None if frame_times is None else np.ascontiguousarray(frame_times, np.float64)
+    if not self.lib.vmd_export_property_table(str(path).encode(), self.h, name.encode(), fmt.encode(),
+                                              ft.ctypes.data_as(L.c_double_p) if ft is not None else None, int(num_bins)):
+        raise VmdError(self.lib.last_error())
+
+
+ScriptEval.sdf_payload = _sdf_payload
+ScriptEval.export_cube = _export_cube
+ScriptEval.export_table = _export_table
+
+
 def downsample_histogram(values, weights, num_bins, lib=None):
     """What VIAMD plots for a distribution property: g = sum(values)/sum(weights) per display bin (src/main.cpp:232-250)."""
     lib = lib or L.default_lib()
