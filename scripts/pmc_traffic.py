@@ -25,7 +25,12 @@ for f in sorted(glob.glob(os.path.join(src, "p*", "**", "*counter_collection.csv
 res = json.load(open(out)) if os.path.exists(out) else {}
 res[workload] = {"frames_per_launch": frames_per_launch, "source": os.path.basename(src.rstrip("/")), "kernels": {}}
 for k in sorted(acc):
-    f = acc[k].get("FETCH_SIZE", [0]); w = acc[k].get("WRITE_SIZE", [0])
+    def full(vals):
+        # a kernel may also be launched on a few frames only (k_cells_bin in counting mode): keep the full-batch dispatches
+        m = max(vals)
+        big = [v for v in vals if v >= 0.5 * m] or vals
+        return big
+    f = full(acc[k].get("FETCH_SIZE", [0])); w = full(acc[k].get("WRITE_SIZE", [0]))
     fetch, write = sum(f) / len(f) * 1024, sum(w) / len(w) * 1024
     res[workload]["kernels"][k] = {"fetch_bytes_per_launch_raw": fetch, "write_bytes_per_launch": write,
                                    "hbm_bytes_per_launch_raw": fetch + write,
@@ -34,6 +39,7 @@ for k in sorted(acc):
     for cname, key in (("SQ_INSTS_VALU", "valu_insts_per_launch"), ("SQ_INSTS_SALU", "salu_insts_per_launch")):
         v = acc[k].get(cname)
         if v:
+            v = full(v)
             res[workload]["kernels"][k][key] = sum(v) / len(v)     # wave-level instructions
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps(res[workload]["kernels"].get("k_rdf_pencil", {}), indent=1))

@@ -230,7 +230,7 @@ def test_sdf_sparse_and_dense_target_paths(gpu_lib, oracle):
     # the scatter's target addressing: index list / arithmetic progression generated on the device, 4 / 8 atoms per thread,
     # targets with and without owners, an irregular list (no progression)
     irregular = np.sort(np.random.default_rng(5).choice(np.arange(0, N, dtype=np.int32), N // 4, replace=False)).astype(np.int32)
-    for arith, ilp in ((0, 4), (1, 8), (0, 8)):
+    for arith, ilp in ((0, 4), (1, 8), (0, 16)):
         old = gpu_lib.vmd_set_option(b"sdf_arith", arith), gpu_lib.vmd_set_option(b"sdf_ilp", ilp)
         try:
             cases.check_sdf(gpu_lib, oracle, coords, 70.0, structures, mass, dense, 10.0, device=True)

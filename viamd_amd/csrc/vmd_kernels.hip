@@ -512,7 +512,7 @@ struct vmd_bin_params_t {
     uint32_t* overflow;              // [1]
     int npen; int total_cap;
 };
-#define VMD_BIN_ILP 4
+#define VMD_BIN_ILP 8          // atoms per thread: 8192-atom slices, i.e. runs of ~30 records per pencil for the 1M-atom configs
 __global__ __launch_bounds__(1024) void k_cells_bin(vmd_bin_params_t q) {
     HIP_DYNAMIC_SHARED(uint32_t, s_dyn)
     uint32_t* s_cnt = s_dyn;                 // [npen] atoms of this block per pencil, then the block's first slot in the bucket
@@ -600,7 +600,16 @@ __global__ __launch_bounds__(256) void k_cells_pen_sort(vmd_pensort_params_t q) 
     const float* bk = q.bucket + 4 * ((size_t)b * q.total_cap + off);
     for (int c = tid; c < nxf; c += 256) s_cnt[c] = 0u;
     __syncthreads();
-    for (uint32_t k = tid; k < n; k += 256) atomicAdd(&s_cnt[(uint32_t)__float_as_int(bk[4 * (size_t)k + 3])], 1u);
+    // the bucket is read ONCE: up to 8 records per thread stay in registers between the counting and the placing pass (pencils
+    // above 2 048 atoms re-read the rest)
+    constexpr int R = 8;
+    vmd_f4a rec[R];
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+        const uint32_t k = tid + 256u * u;
+        if (k < n) { rec[u] = *(const vmd_f4a*)(bk + 4 * (size_t)k); atomicAdd(&s_cnt[(uint32_t)__float_as_int(rec[u][3])], 1u); }
+    }
+    for (uint32_t k = tid + 256u * R; k < n; k += 256) atomicAdd(&s_cnt[(uint32_t)__float_as_int(bk[4 * (size_t)k + 3])], 1u);
     __syncthreads();
     // exclusive scan over the fine cells of the pencil
     const int per = (nxf + 255) / 256;
@@ -621,7 +630,15 @@ __global__ __launch_bounds__(256) void k_cells_pen_sort(vmd_pensort_params_t q) 
     if (pen == q.npen - 1 && tid == 255) q.cell_start[(size_t)b * (q.ncell + 1) + q.ncell] = start + n;
     __syncthreads();
     float* sx = s_xyz; float* sy = s_xyz + q.cap_max; float* sz = s_xyz + 2 * (size_t)q.cap_max;
-    for (uint32_t k = tid; k < n; k += 256) {
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+        const uint32_t k = tid + 256u * u;
+        if (k < n) {
+            const uint32_t pos = atomicAdd(&s_cnt[(uint32_t)__float_as_int(rec[u][3])], 1u);
+            sx[pos] = rec[u][0]; sy[pos] = rec[u][1]; sz[pos] = rec[u][2];
+        }
+    }
+    for (uint32_t k = tid + 256u * R; k < n; k += 256) {
         const vmd_f4a v = *(const vmd_f4a*)(bk + 4 * (size_t)k);
         const uint32_t pos = atomicAdd(&s_cnt[(uint32_t)__float_as_int(v[3])], 1u);
         sx[pos] = v[0]; sy[pos] = v[1]; sz[pos] = v[2];
@@ -1568,16 +1585,16 @@ __device__ __forceinline__ bool vmd_sdf_near(const vmd_scatter_params_t& p, cons
 // is computed instead of loaded and the coordinate gathers do not wait for an index load - one memory round trip per block
 // instead of two (the kernel is bound by the latency of its loads under load: a wave used to live ~12 us).
 // ILP atoms per thread: all their gathers are in flight at once.
+#define VMD_SDF_CAP 512      // survivors of the group test a block holds in LDS at a time (~1 % of its atoms pass; more take another round)
 template <int ILP, bool ARITH>
 __global__ __launch_bounds__(256) void k_sdf_scatter(vmd_scatter_params_t p) {
-    __shared__ float s_x[256 * ILP], s_y[256 * ILP], s_z[256 * ILP];
-    __shared__ int s_own[256 * ILP], s_idx[256 * ILP];
+    __shared__ float s_x[VMD_SDF_CAP], s_y[VMD_SDF_CAP], s_z[VMD_SDF_CAP];
+    __shared__ int s_own[VMD_SDF_CAP], s_idx[VMD_SDF_CAP];
     __shared__ unsigned s_n;
     const int t0 = blockIdx.x * (256 * ILP) + threadIdx.x;
     const int b = blockIdx.y;
     const vmd_box_t bx = vmd_load_box(p.boxes, b, p.pbc);
     const float* fx = p.xyz + (size_t)b * p.frame_stride;
-    if (threadIdx.x == 0) s_n = 0u;
     int idx[ILP], own[ILP];
     float x[ILP], y[ILP], z[ILP];
 #pragma unroll
@@ -1594,19 +1611,31 @@ __global__ __launch_bounds__(256) void k_sdf_scatter(vmd_scatter_params_t p) {
         x[u] = y[u] = z[u] = 0.0f;
         if (idx[u] >= 0) { x[u] = fx[idx[u]]; y[u] = fx[p.row_stride + idx[u]]; z[u] = fx[2 * p.row_stride + idx[u]]; }
     }
-    __syncthreads();
+    unsigned pending = 0u;
 #pragma unroll
-    for (int u = 0; u < ILP; ++u) {
-        if (idx[u] >= 0 && vmd_sdf_near(p, bx, b, x[u], y[u], z[u])) {
-            const unsigned slot = atomicAdd(&s_n, 1u);
-            s_x[slot] = x[u]; s_y[slot] = y[u]; s_z[slot] = z[u]; s_own[slot] = own[u]; s_idx[slot] = idx[u];
+    for (int u = 0; u < ILP; ++u) if (idx[u] >= 0 && vmd_sdf_near(p, bx, b, x[u], y[u], z[u])) pending |= 1u << u;
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) s_n = 0u;
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < ILP; ++u) {
+            if (pending & (1u << u)) {
+                const unsigned slot = atomicAdd(&s_n, 1u);
+                if (slot < VMD_SDF_CAP) {
+                    s_x[slot] = x[u]; s_y[slot] = y[u]; s_z[slot] = z[u]; s_own[slot] = own[u]; s_idx[slot] = idx[u];
+                    pending &= ~(1u << u);
+                }
+            }
         }
-    }
-    __syncthreads();
-    const int nwork = (int)s_n * p.K;
-    for (int w = threadIdx.x; w < nwork; w += 256) {
-        const int a = w / p.K, k = w - a * p.K;
-        vmd_sdf_atom_k(p, bx, b, k, s_x[a], s_y[a], s_z[a], s_own[a], s_idx[a]);
+        __syncthreads();
+        const unsigned total = s_n;
+        const int nwork = (int)(total < VMD_SDF_CAP ? total : VMD_SDF_CAP) * p.K;
+        for (int w = threadIdx.x; w < nwork; w += 256) {
+            const int a = w / p.K, k = w - a * p.K;
+            vmd_sdf_atom_k(p, bx, b, k, s_x[a], s_y[a], s_z[a], s_own[a], s_idx[a]);
+        }
+        if (total <= VMD_SDF_CAP) break;      // block-uniform: everybody read the same s_n
     }
 }
 
@@ -1964,7 +1993,7 @@ extern "C" int vmd_hip_sdf_ref_pose(void* stream, const float* xyz, size_t row_s
 }
 
 static int g_sdf_ilp = 4;
-extern "C" int vmd_hip_set_sdf_ilp(int n) { const int old = g_sdf_ilp; if (n == 4 || n == 8) g_sdf_ilp = n; return old; }
+extern "C" int vmd_hip_set_sdf_ilp(int n) { const int old = g_sdf_ilp; if (n == 4 || n == 8 || n == 16) g_sdf_ilp = n; return old; }
 extern "C" int vmd_hip_sdf_scatter(void* stream, const float* xyz, size_t frame_stride, size_t row_stride,
                                    const float* boxes, uint32_t pbc_flags, int B,
                                    const int32_t* structs, int K, int m, const float* R32, const float* c32,
@@ -1981,7 +2010,11 @@ extern "C" int vmd_hip_sdf_scatter(void* stream, const float* xyz, size_t frame_
         return 0;
     }
     const bool arith = tgt_stride > 0;
-    if (g_sdf_ilp == 8) {
+    if (g_sdf_ilp == 16) {
+        const dim3 g((ntgt + 256 * 16 - 1) / (256 * 16), B);
+        if (arith) hipLaunchKernelGGL((k_sdf_scatter<16, true>), g, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((k_sdf_scatter<16, false>), g, dim3(256), 0, s, p);
+    } else if (g_sdf_ilp == 8) {
         const dim3 g((ntgt + 256 * 8 - 1) / (256 * 8), B);
         if (arith) hipLaunchKernelGGL((k_sdf_scatter<8, true>), g, dim3(256), 0, s, p);
         else hipLaunchKernelGGL((k_sdf_scatter<8, false>), g, dim3(256), 0, s, p);
