@@ -60,7 +60,7 @@ def make_traj(lib, coords, vcell, device):
     return V.HostTrajectory(coords, vcell)
 
 
-def check_rdf(lib, O, coords, box, props, flags=L.PBC_ALL, device=False, ranges=None, variant=0, oracle_method="cells"):
+def check_rdf(lib, O, coords, box, props, flags=L.PBC_ALL, device=False, ranges=None, variant=None, oracle_method="cells"):
     """props: list of (name, ref, tgt, rmin, rmax).  Bit-exact counts, 1e-12 weights, 1e-5 normalised g(r).
     box may be a list with one box per frame (NPT trajectories)."""
     F, _, N = coords.shape
@@ -75,12 +75,13 @@ def check_rdf(lib, O, coords, box, props, flags=L.PBC_ALL, device=False, ranges=
     ev = V.ScriptEval(F, ir)
     traj = make_traj(lib, coords, vcell, device)
     sysm = V.MolSystem(N, unitcell=vcell[0] if isinstance(vcell, list) else vcell)
-    old = lib.vmd_set_option(b"rdf_variant", variant)
+    old = lib.vmd_set_option(b"rdf_variant", variant) if variant is not None else None      # None: whatever the library is set to
     try:
         for beg, end in (ranges or [(0, F)]):
             assert ev.frame_range(sysm, traj, beg, end)
     finally:
-        lib.vmd_set_option(b"rdf_variant", old)
+        if variant is not None:
+            lib.vmd_set_option(b"rdf_variant", old)
     assert ev.frame_mask().all() and ev.frames_done() == F
     for name, ref, tgt, rmin, rmax in props:
         pd = ev.property_data(name)

@@ -41,6 +41,21 @@ def test_rdf_inline_variant_matches(emu_lib, oracle, box3k):
     cases.check_rdf(emu_lib, oracle, box3k[:1], 60.0, [("goo", o, o, 0.0, 12.0)], variant=1)
 
 
+@pytest.mark.parametrize("variant", [0, 2])
+def test_rdf_hit_compaction_variants(emu_lib, oracle, box3k, variant):
+    """variant 0: one compaction per candidate column; variant 2: pair entries (two columns share one compaction, the partner that
+    is no hit is dropped by the binning) - same sets, ranges with r_min > 0, own-pencil half shell, edge cases, triclinic and open cells"""
+    o, h = cases.oxygen(3000), cases.hydrogen(3000)
+    old = emu_lib.vmd_set_option(b"rdf_variant", variant)
+    try:
+        cases.check_rdf(emu_lib, oracle, box3k[:2], 60.0, [("goo", o, o, 0.0, 12.0), ("goh", o, h, 0.0, 10.0), ("ring", h, o, 2.5, 9.0),
+                                                          ("shell", o, o, 11.5, 12.0)], variant=variant)
+        cases.rdf_edge_cases(emu_lib, oracle)
+        cases.triclinic_cases(emu_lib, oracle, 600)
+    finally:
+        emu_lib.vmd_set_option(b"rdf_variant", old)
+
+
 def test_rdf_two_pencils_per_axis(emu_lib, oracle):
     # L = 26, rc = 12 -> ny = nz = 2: both neighbour offsets map to the same pencil with different images
     c = cases.water_box(oracle, 11, 1500, 26.0, 2)

@@ -48,6 +48,33 @@ def test_coevaluated_rdfs_share_pair_passes(gpu_lib, oracle):
     cases.class_decomposition_cases(gpu_lib, oracle, device=True, n_water=30000, box=70.0)
 
 
+@pytest.mark.parametrize("variant", [0, 2])
+def test_rdf_hit_compaction_variants(gpu_lib, oracle, box30k, variant):
+    """variant 0: one compaction per candidate column; variant 2: pair entries (two columns share one compaction; hand-scheduled
+    push / pop of their own) - same / different sets, r_min > 0, a thin shell at the cutoff, edge cases, triclinic and open cells,
+    and the BASELINE config 2 shape"""
+    o, h = cases.oxygen(30000), cases.hydrogen(30000)
+    old = gpu_lib.vmd_set_option(b"rdf_variant", variant)
+    try:
+        cases.check_rdf(gpu_lib, oracle, box30k[:3], 80.0, [("goo", o, o, 0.0, 12.0), ("goh", o, h, 0.0, 10.0), ("ring", h, o, 2.5, 9.0),
+                                                          ("shell", o, o, 11.5, 12.0)], device=True)
+        cases.rdf_edge_cases(gpu_lib, oracle, device=True)
+        cases.triclinic_cases(gpu_lib, oracle, 3000, device=True)
+        cases.open_boundary_cases(gpu_lib, oracle, 6000, device=True)
+        N, F = 100002, 2
+        t = V.DeviceTrajectory(F, N)
+        t.synth(2, 100.0, 0.05)
+        oo = cases.oxygen(N)
+        ir = V.ScriptIR(); ir.add_rdf("g", oo, oo, 12.0)
+        ev = V.ScriptEval(F, ir)
+        assert ev.frame_range(V.MolSystem(N), t, 0, F)
+        coords = np.stack([oracle.synth_frame(2, N, 100.0, 0.05, f) for f in range(F)])
+        counts, _ = cases.oracle_rdf(oracle, coords, oracle.make_cell(100.0), oo, oo, 0.0, 12.0)
+        np.testing.assert_array_equal(ev.property_data("g").counts, counts)
+    finally:
+        gpu_lib.vmd_set_option(b"rdf_variant", old)
+
+
 def test_rdf_inline_variant_and_host_staging(gpu_lib, oracle, box30k):
     o = cases.oxygen(30000)
     cases.check_rdf(gpu_lib, oracle, box30k[:2], 80.0, [("goo", o, o, 0.0, 12.0)], variant=1, device=False)

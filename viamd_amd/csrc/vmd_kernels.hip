@@ -25,7 +25,9 @@
 
 #define VMD_WAVE 64
 #define VMD_MAX_BINS 1024
-#define VMD_QUEUE_CAP 384          // < 64 pending + 4 undrained candidate columns of 64, + the 64-entry slow stack
+#define VMD_QUEUE_CAP 384          // floats: < 64 pending + 4 undrained candidate columns of 64 (variant 2: < 64 + 64 pair entries of 8 bytes,
+                                   // drained after every pair-column), + the 64-entry slow stack
+#define VMD_JUNK 3.0e38f           // partner value of a pair entry that must never be counted: far beyond any r_max
 #define VMD_FAR 1.0e18f            // coordinate of a padding lane: never within any cutoff, squares stay finite
 
 // Wave-uniform read-only data (j coordinates, cell offsets, boxes) is read through the constant address space so
@@ -227,6 +229,7 @@ struct vmd_binning_t {
     // fast_delta/4; it is trusted when it lies at least fast_delta away from every integer (bin edge, and through bins 0 and
     // nbins-1 also from r_min / r_max); everything else takes the exact path
     float fast_k, fast_c, fast_half;   // fast_half = 0.5 - fast_delta
+    float fast_far;                    // t' >= fast_far: beyond r_max by a whole bin, i.e. certainly not a hit (pair entries carry such partners)
 };
 __host__ __device__ inline vmd_binning_t vmd_make_binning(float rmin, float rmax, int nbins) {
     vmd_binning_t b;
@@ -239,7 +242,8 @@ __host__ __device__ inline vmd_binning_t vmd_make_binning(float rmin, float rmax
     b.fast_k = b.inv_range * b.fnbins;
     b.fast_c = -rmin * b.fast_k;
     b.fast_half = 0.5f - delta;
-    if (!(delta < 0.25f)) b.fast_half = -1.0f;      // degenerate range: nothing is ever "sure", exact path only
+    b.fast_far = b.fnbins + 1.0f;                   // |t' - t| <= delta / 4 << 1: t' >= nbins + 1 implies d > r_max
+    if (!(delta < 0.25f)) { b.fast_half = -1.0f; b.fast_far = 3.0e38f; }      // degenerate range: nothing is ever "sure", exact path only
     return b;
 }
 __device__ __forceinline__ int vmd_bin_of(const vmd_binning_t& b, float d2) {
@@ -702,6 +706,7 @@ struct vmd_wave_acc_t {
     unsigned hbase;       // LDS byte address of hist[0] (product build only)
     unsigned qtop;        // wave-uniform: LDS byte address of the top of the stack
     float fast_c;         // bn.fast_c held in a VGPR
+    float fast_k, fast_far;   // variant 2: bn.fast_k / bn.fast_far in VGPRs (an SGPR operand halves the issue rate of v_fma_f32)
     float* slow;          // LDS, 64 floats behind the stack: hits whose fast binning was not provably exact, waiting for
     unsigned nslow;       // (wave-uniform count) a full wave of them to go through the exact path together
     unsigned ncols;       // wave-uniform: candidate columns (<= 64 hits each) since the last flush
@@ -798,6 +803,84 @@ __device__ __forceinline__ unsigned long long vmd_pop_hot(const vmd_binning_t& b
 }
 #endif
 
+// variant 2: the same with the "certainly outside" test in front of the parking (a pair entry's partner is usually no hit)
+template <unsigned INC>
+__device__ __forceinline__ void vmd_bin_add_deferred_far(const vmd_binning_t& bn, vmd_wave_acc_t& w, float d2, bool active, int lane) {
+    const float t = fmaf(__builtin_amdgcn_sqrtf(d2), bn.fast_k, w.fast_c);
+    const int bin = vmd_floor_to_int(t);
+    const float fr = vmd_fract(t);
+    const bool sure = fabsf(fr - 0.5f) < bn.fast_half && (unsigned)bin < (unsigned)bn.nbins;
+    if (active && sure) atomicAdd(&w.hist[bin], INC);
+    const bool unsure = active && !sure && t < bn.fast_far;
+    const unsigned long long m = VMD_BALLOT(unsure);
+    if (m) vmd_slow_park<INC>(bn, w, d2, m, unsure, lane);
+}
+#ifndef VMD_NO_INLINE_ASM
+// variant 2 pop: 64 pair entries = 128 values, two interleaved binning chains; returns the two park masks.  19 VALU.
+template <unsigned INC>
+__device__ __forceinline__ void vmd_pop_hot2(const vmd_binning_t& bn, vmd_wave_acc_t& w, unsigned lane8, unsigned inc, float& a, float& b,
+                                             unsigned long long& ma, unsigned long long& mb) {
+    unsigned long long sa;
+    float ta, tb;
+    int ba, bb;
+    asm volatile(
+        "v_add_u32 %[ba], %[q], %[l8]\n\t"
+        "ds_read_b32 %[a], %[ba]\n\t"
+        "ds_read_b32 %[b], %[ba] offset:4\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_sqrt_f32 %[ta], %[a]\n\t"
+        "v_sqrt_f32 %[tb], %[b]\n\t"
+        "s_nop 0\n\t"
+        "v_fma_f32 %[ta], %[k], %[ta], %[c]\n\t"
+        "v_fma_f32 %[tb], %[k], %[tb], %[c]\n\t"
+        "v_cvt_flr_i32_f32 %[ba], %[ta]\n\t"
+        "v_cvt_flr_i32_f32 %[bb], %[tb]\n\t"
+        "v_cmp_gt_f32 %[ma], %[far], %[ta]\n\t"
+        "v_cmp_gt_f32 %[mb], %[far], %[tb]\n\t"
+        "v_fract_f32 %[ta], %[ta]\n\t"
+        "v_fract_f32 %[tb], %[tb]\n\t"
+        "v_add_f32 %[ta], -0.5, %[ta]\n\t"
+        "v_add_f32 %[tb], -0.5, %[tb]\n\t"
+        "v_cmp_lt_f32 %[sa], |%[ta]|, %[half]\n\t"
+        "v_cmp_gt_u32 vcc, %[nb], %[ba]\n\t"
+        "s_and_b64 vcc, vcc, %[sa]\n\t"
+        "s_andn2_b64 %[ma], %[ma], vcc\n\t"
+        "v_lshl_add_u32 %[ba], %[ba], 2, %[hb]\n\t"
+        "s_mov_b64 exec, vcc\n\t"
+        "ds_add_u32 %[ba], %[inc]\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        "v_cmp_lt_f32 %[sa], |%[tb]|, %[half]\n\t"
+        "v_cmp_gt_u32 vcc, %[nb], %[bb]\n\t"
+        "s_and_b64 vcc, vcc, %[sa]\n\t"
+        "s_andn2_b64 %[mb], %[mb], vcc\n\t"
+        "v_lshl_add_u32 %[bb], %[bb], 2, %[hb]\n\t"
+        "s_mov_b64 exec, vcc\n\t"
+        "ds_add_u32 %[bb], %[inc]\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        : [ma] "=&s"(ma), [mb] "=&s"(mb), [sa] "=&s"(sa), [ta] "=&v"(ta), [tb] "=&v"(tb), [ba] "=&v"(ba), [bb] "=&v"(bb), [a] "=&v"(a), [b] "=&v"(b)
+        : [q] "s"(w.qtop), [l8] "v"(lane8), [k] "v"(w.fast_k), [c] "v"(w.fast_c), [far] "v"(w.fast_far), [half] "s"(bn.fast_half),
+          [nb] "s"(bn.nbins), [hb] "s"(w.hbase), [inc] "v"(inc)
+        : "vcc", "scc", "memory");
+}
+#endif
+
+// variant 2: TWO candidate columns share one compaction.  A lane whose smaller d2 of the pair is a candidate pushes both
+// values as one 8-byte entry (they sit in one packed register pair already); the pop bins both and drops the partner that is
+// no hit with one compare.  Per pair of columns: v_min + v_cmp + 2 v_mbcnt + v_lshl_add + one ds_write_b64 instead of
+// 2 x (v_cmp + 2 v_mbcnt + v_lshl_add + ds_write_b32): the integer ops of the prefix issue at 4 cycles per wave whatever their
+// operands are (profiles/r02_valu_calibration.txt), so halving them is what counts; the pop handles ~1.85 values per hit.
+__device__ __forceinline__ void vmd_push2(vmd_wave_acc_t& w, bool hit, float a, float b) {
+    const unsigned long long mask = VMD_BALLOT(hit);
+    if (mask) {
+        const unsigned pre = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+        if (hit) {
+            float* e = (float*)((char*)w.queue + ((w.qtop - w.qbase) + 8u * pre));
+            e[0] = a; e[1] = b;
+        }
+        w.qtop += 8u * (unsigned)__popcll(mask);
+    }
+}
+
 // VARIANT 0: compact the hits of one candidate column onto the wave's LDS stack (order is irrelevant for a
 // histogram, so LIFO: no head pointer, no wrap-around); vmd_drain_full pops full waves of 64 so that
 // sqrt + binning + ds_add always run with every lane busy.
@@ -808,6 +891,7 @@ __device__ __forceinline__ void vmd_push(const vmd_binning_t& bn, vmd_wave_acc_t
         vmd_bin_add<INC>(bn, w.hist, d2, hit);
         return;
     }
+    if (VARIANT == 2) { vmd_push2(w, hit, d2, VMD_JUNK); return; }
     const unsigned long long mask = VMD_BALLOT(hit);
     if (mask) {
         const unsigned pre = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
@@ -819,6 +903,26 @@ __device__ __forceinline__ void vmd_push(const vmd_binning_t& bn, vmd_wave_acc_t
 template <int VARIANT, unsigned INC>
 __device__ __forceinline__ void vmd_drain_full(const vmd_binning_t& bn, vmd_wave_acc_t& w, int lane) {
     if (VARIANT == 1) return;
+    if (VARIANT == 2) {
+        while (w.qtop - w.qbase >= 8u * VMD_WAVE) {
+            w.qtop -= 8u * VMD_WAVE;
+            float a, b;
+#ifndef VMD_NO_INLINE_ASM
+            unsigned long long ma, mb;
+            vmd_pop_hot2<INC>(bn, w, 8u * (unsigned)lane, INC, a, b, ma, mb);
+            if (ma) vmd_slow_park<INC>(bn, w, a, ma, (ma >> lane) & 1ull, lane);
+            if (mb) vmd_slow_park<INC>(bn, w, b, mb, (mb >> lane) & 1ull, lane);
+#else
+            __builtin_amdgcn_wave_barrier();
+            const float* e = (const float*)((const char*)w.queue + ((w.qtop - w.qbase) + 8u * (unsigned)lane));
+            a = e[0]; b = e[1];
+            __builtin_amdgcn_wave_barrier();
+            vmd_bin_add_deferred_far<INC>(bn, w, a, true, lane);
+            vmd_bin_add_deferred_far<INC>(bn, w, b, true, lane);
+#endif
+        }
+        return;
+    }
     while (w.qtop - w.qbase >= 4u * VMD_WAVE) {
         w.qtop -= 4u * VMD_WAVE;
 #ifndef VMD_NO_INLINE_ASM
@@ -838,6 +942,17 @@ template <int VARIANT, unsigned INC>
 __device__ __forceinline__ void vmd_drain(const vmd_binning_t& bn, vmd_wave_acc_t& w, int lane) {
     if (VARIANT == 1) return;
     vmd_drain_full<VARIANT, INC>(bn, w, lane);
+    if (VARIANT == 2) {
+        const unsigned rem = (w.qtop - w.qbase) / 8u;
+        __builtin_amdgcn_wave_barrier();
+        const float a = w.queue[2 * lane], b = w.queue[2 * lane + 1];
+        __builtin_amdgcn_wave_barrier();
+        w.qtop = w.qbase;
+        vmd_bin_add_deferred_far<INC>(bn, w, a, (unsigned)lane < rem, lane);
+        vmd_bin_add_deferred_far<INC>(bn, w, b, (unsigned)lane < rem, lane);
+        vmd_slow_flush<INC>(bn, w, lane);
+        return;
+    }
     const unsigned rem = (w.qtop - w.qbase) / 4u;
     __builtin_amdgcn_wave_barrier();
     const float v = w.queue[lane];
@@ -1016,6 +1131,54 @@ __device__ __forceinline__ void vmd_push_hot4_masked(vmd_wave_acc_t& w, float d0
         : [d0] "v"(d0), [d1] "v"(d1), [d2] "v"(d2), [d3] "v"(d3), [r2] "s"(r2), [j] "s"(j), [i0] "v"(i0), [i1] "v"(i1), [i2] "v"(i2), [i3] "v"(i3)
         : "vcc", "scc", "memory");
 }
+// variant 2: one pair-column (two candidate columns).  a, b = the two d2 values, dd = the packed register pair that holds them.
+// The stack is drained after every pair-column, so it never holds more than 64 + 64 entries (LDS: 7 blocks per CU still fit).
+__device__ __forceinline__ void vmd_push_hot2p(vmd_wave_acc_t& w, float a, float b, vmd_f2 dd, float r2) {
+    unsigned t, n;
+    float m;
+    asm volatile(
+        "s_nop 0\n\t"
+        "v_min_f32 %[m], %[a], %[b]\n\t"
+        "v_cmp_gt_f32 vcc, %[r2], %[m]\n\t"
+        "s_cbranch_vccz .Lvmd_pp_%=\n\t"
+        "v_mbcnt_lo_u32_b32 %[t], vcc_lo, 0\n\t"
+        "v_mbcnt_hi_u32_b32 %[t], vcc_hi, %[t]\n\t"
+        "v_lshl_add_u32 %[t], %[t], 3, %[q]\n\t"
+        "s_mov_b64 exec, vcc\n\t"
+        "ds_write_b64 %[t], %[dd]\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        "s_bcnt1_i32_b64 %[n], vcc\n\t"
+        "s_lshl3_add_u32 %[q], %[n], %[q]\n"
+        ".Lvmd_pp_%=:\n\t"
+        : [q] "+s"(w.qtop), [t] "=&v"(t), [n] "=&s"(n), [m] "=&v"(m)
+        : [a] "v"(a), [b] "v"(b), [dd] "v"(dd), [r2] "s"(r2)
+        : "vcc", "scc", "memory");
+}
+// own pencil: the chunk against itself.  Lane L holds atom cbeg + L; the pair-column (j, j + 1) counts for the lanes L <= j - cbeg
+// only (unordered pairs once).  On lane L == j - cbeg the first value is the atom's distance to itself, 0: it is pushed
+// and the binning rejects it like any d <= r_min (SPEC S4: open interval).  lm: that lane mask, wave-uniform.
+__device__ __forceinline__ void vmd_push_hot2p_masked(vmd_wave_acc_t& w, float a, float b, vmd_f2 dd, float r2, unsigned long long lm) {
+    unsigned t, n;
+    float m;
+    asm volatile(
+        "s_nop 0\n\t"
+        "v_min_f32 %[m], %[a], %[b]\n\t"
+        "v_cmp_gt_f32 vcc, %[r2], %[m]\n\t"
+        "s_and_b64 vcc, vcc, %[lm]\n\t"
+        "s_cbranch_scc0 .Lvmd_ppm_%=\n\t"
+        "v_mbcnt_lo_u32_b32 %[t], vcc_lo, 0\n\t"
+        "v_mbcnt_hi_u32_b32 %[t], vcc_hi, %[t]\n\t"
+        "v_lshl_add_u32 %[t], %[t], 3, %[q]\n\t"
+        "s_mov_b64 exec, vcc\n\t"
+        "ds_write_b64 %[t], %[dd]\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        "s_bcnt1_i32_b64 %[n], vcc\n\t"
+        "s_lshl3_add_u32 %[q], %[n], %[q]\n"
+        ".Lvmd_ppm_%=:\n\t"
+        : [q] "+s"(w.qtop), [t] "=&v"(t), [n] "=&s"(n), [m] "=&v"(m)
+        : [a] "v"(a), [b] "v"(b), [dd] "v"(dd), [r2] "s"(r2), [lm] "s"(lm)
+        : "vcc", "scc", "memory");
+}
 #else
 #define VMD_LDS_ADDRESS(p) 0u
 #endif
@@ -1052,7 +1215,34 @@ __device__ __forceinline__ void vmd_segment_loop(const vmd_pair_params_t& p, vmd
             vmd_drain_full<VARIANT, INC>(p.bin, w, lane);
             return;
         }
+        if (VARIANT == 2) {
+            if (MASKED) {
+                // lanes 0 .. (j - cbeg) of the pair-column starting at j; the chunk starts at the atom of lane 0
+                const int a = (int)(ja + k0) - __builtin_amdgcn_readfirstlane((int)i);
+                const unsigned long long lm0 = a >= 63 ? ~0ull : ((2ull << a) - 1ull);
+                const unsigned long long lm1 = a + 2 >= 63 ? ~0ull : ((2ull << (a + 2)) - 1ull);
+                vmd_push_hot2p_masked(w, d2[0][0], d2[0][1], d2[0], r2, lm0);
+                vmd_drain_full<VARIANT, INC>(p.bin, w, lane);
+                vmd_push_hot2p_masked(w, d2[1][0], d2[1][1], d2[1], r2, lm1);
+            } else {
+                vmd_push_hot2p(w, d2[0][0], d2[0][1], d2[0], r2);
+                vmd_drain_full<VARIANT, INC>(p.bin, w, lane);
+                vmd_push_hot2p(w, d2[1][0], d2[1][1], d2[1], r2);
+            }
+            vmd_drain_full<VARIANT, INC>(p.bin, w, lane);
+            return;
+        }
 #endif
+        if (VARIANT == 2) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                float a = d2[h][0], b = d2[h][1];
+                if (MASKED) { if (!(ja + k0 + 2 * h > i)) a = VMD_JUNK; if (!(ja + k0 + 2 * h + 1 > i)) b = VMD_JUNK; }
+                vmd_push2(w, fminf(a, b) < r2, a, b);
+                vmd_drain_full<VARIANT, INC>(p.bin, w, lane);
+            }
+            return;
+        }
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const float v = d2[c >> 1][c & 1];
@@ -1082,6 +1272,7 @@ __device__ __forceinline__ void vmd_segment_loop(const vmd_pair_params_t& p, vmd
         bool hit = d2 < r2;
         if (MASKED) hit = hit && (ja + k > i);
         vmd_push<VARIANT, INC>(p.bin, w, hit, d2);
+        if (VARIANT == 2) vmd_drain_full<VARIANT, INC>(p.bin, w, lane);      // 8-byte entries: room for one column beyond the 64 pending
     }
     vmd_drain_full<VARIANT, INC>(p.bin, w, lane);
 }
@@ -1148,6 +1339,8 @@ __global__ __launch_bounds__(256) VMD_SGPR_CAP(96) void k_rdf_pencil(vmd_pair_pa
     w.slow = &s_queue[wave][VMD_QUEUE_CAP - VMD_WAVE];
     w.nslow = 0;
     w.fast_c = vmd_in_vgpr(p.bin.fast_c);
+    w.fast_k = vmd_in_vgpr(p.bin.fast_k);
+    w.fast_far = vmd_in_vgpr(p.bin.fast_far);
     w.ncols = 0;
     for (int b = lane; b < nbins; b += VMD_WAVE) w.hist[b] = 0u;
     __builtin_amdgcn_wave_barrier();
@@ -1933,21 +2126,18 @@ extern "C" int vmd_hip_rdf_pencil(void* stream, const float* sorted_ref, const u
     p.pbc = pbc_flags;
     p.skip = skip_flag;
     const int cell = (pbc_flags & VMD_PBC_TRICLINIC) ? 1 : ((pbc_flags & 7u) != 7u ? 2 : 0);
-    const int which = (variant == 1 ? 6 : 0) + (same_set ? 3 : 0) + cell;
+    const int which = (variant == 1 ? 6 : variant == 2 ? 12 : 0) + (same_set ? 3 : 0) + cell;
+#define VMD_PENCIL_CASE(n, V, S, C) case n: hipLaunchKernelGGL((k_rdf_pencil<V, S, C>), g, blk, 0, s, p); break;
     switch (which) {
-    case 0: hipLaunchKernelGGL((k_rdf_pencil<0, false, 0>), g, blk, 0, s, p); break;
-    case 1: hipLaunchKernelGGL((k_rdf_pencil<0, false, 1>), g, blk, 0, s, p); break;
-    case 2: hipLaunchKernelGGL((k_rdf_pencil<0, false, 2>), g, blk, 0, s, p); break;
-    case 3: hipLaunchKernelGGL((k_rdf_pencil<0, true, 0>), g, blk, 0, s, p); break;
-    case 4: hipLaunchKernelGGL((k_rdf_pencil<0, true, 1>), g, blk, 0, s, p); break;
-    case 5: hipLaunchKernelGGL((k_rdf_pencil<0, true, 2>), g, blk, 0, s, p); break;
-    case 6: hipLaunchKernelGGL((k_rdf_pencil<1, false, 0>), g, blk, 0, s, p); break;
-    case 7: hipLaunchKernelGGL((k_rdf_pencil<1, false, 1>), g, blk, 0, s, p); break;
-    case 8: hipLaunchKernelGGL((k_rdf_pencil<1, false, 2>), g, blk, 0, s, p); break;
-    case 9: hipLaunchKernelGGL((k_rdf_pencil<1, true, 0>), g, blk, 0, s, p); break;
-    case 10: hipLaunchKernelGGL((k_rdf_pencil<1, true, 1>), g, blk, 0, s, p); break;
-    default: hipLaunchKernelGGL((k_rdf_pencil<1, true, 2>), g, blk, 0, s, p); break;
+    VMD_PENCIL_CASE(0, 0, false, 0) VMD_PENCIL_CASE(1, 0, false, 1) VMD_PENCIL_CASE(2, 0, false, 2)
+    VMD_PENCIL_CASE(3, 0, true, 0) VMD_PENCIL_CASE(4, 0, true, 1) VMD_PENCIL_CASE(5, 0, true, 2)
+    VMD_PENCIL_CASE(6, 1, false, 0) VMD_PENCIL_CASE(7, 1, false, 1) VMD_PENCIL_CASE(8, 1, false, 2)
+    VMD_PENCIL_CASE(9, 1, true, 0) VMD_PENCIL_CASE(10, 1, true, 1) VMD_PENCIL_CASE(11, 1, true, 2)
+    VMD_PENCIL_CASE(12, 2, false, 0) VMD_PENCIL_CASE(13, 2, false, 1) VMD_PENCIL_CASE(14, 2, false, 2)
+    VMD_PENCIL_CASE(15, 2, true, 0) VMD_PENCIL_CASE(16, 2, true, 1)
+    default: hipLaunchKernelGGL((k_rdf_pencil<2, true, 2>), g, blk, 0, s, p); break;
     }
+#undef VMD_PENCIL_CASE
     VMD_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_hist_reduce, dim3((nbins + 255) / 256, (nblocks + 31) / 32), dim3(256), 0, s, (const uint64_t*)partial, nblocks, nbins, counts, skip_flag);
     VMD_LAUNCH_CHECK();
