@@ -25,8 +25,9 @@
 
 #define VMD_WAVE 64
 #define VMD_MAX_BINS 1024
-#define VMD_QUEUE_CAP 384          // floats: < 64 pending + 4 undrained candidate columns of 64 (variant 2: < 64 + 64 pair entries of 8 bytes,
-                                   // drained after every pair-column), + the 64-entry slow stack
+#define VMD_QUEUE_CAP 384          // floats: < 64 pending + 4 undrained candidate columns of 64 (variant 2: < 64 + 64 pair entries in two
+                                   // planes of 128 floats, drained after every pair-column), + the 64-entry slow stack
+#define VMD_PAIR_B 128             // variant 2: float offset of the second value of a pair entry (at most 64 + 64 entries are ever pending)
 #define VMD_JUNK 3.0e38f           // partner value of a pair entry that must never be counted: far beyond any r_max
 #define VMD_FAR 1.0e18f            // coordinate of a padding lane: never within any cutoff, squares stay finite
 
@@ -516,7 +517,7 @@ struct vmd_bin_params_t {
     uint32_t* overflow;              // [1]
     int npen; int total_cap;
 };
-#define VMD_BIN_ILP 8          // atoms per thread: 8192-atom slices, i.e. runs of ~30 records per pencil for the 1M-atom configs
+#define VMD_BIN_ILP 4          // atoms per thread: 4096-atom slices (8 per thread: measured slower, profiles/r02d_ab.txt)
 __global__ __launch_bounds__(1024) void k_cells_bin(vmd_bin_params_t q) {
     HIP_DYNAMIC_SHARED(uint32_t, s_dyn)
     uint32_t* s_cnt = s_dyn;                 // [npen] atoms of this block per pencil, then the block's first slot in the bucket
@@ -604,16 +605,7 @@ __global__ __launch_bounds__(256) void k_cells_pen_sort(vmd_pensort_params_t q) 
     const float* bk = q.bucket + 4 * ((size_t)b * q.total_cap + off);
     for (int c = tid; c < nxf; c += 256) s_cnt[c] = 0u;
     __syncthreads();
-    // the bucket is read ONCE: up to 8 records per thread stay in registers between the counting and the placing pass (pencils
-    // above 2 048 atoms re-read the rest)
-    constexpr int R = 8;
-    vmd_f4a rec[R];
-#pragma unroll
-    for (int u = 0; u < R; ++u) {
-        const uint32_t k = tid + 256u * u;
-        if (k < n) { rec[u] = *(const vmd_f4a*)(bk + 4 * (size_t)k); atomicAdd(&s_cnt[(uint32_t)__float_as_int(rec[u][3])], 1u); }
-    }
-    for (uint32_t k = tid + 256u * R; k < n; k += 256) atomicAdd(&s_cnt[(uint32_t)__float_as_int(bk[4 * (size_t)k + 3])], 1u);
+    for (uint32_t k = tid; k < n; k += 256) atomicAdd(&s_cnt[(uint32_t)__float_as_int(bk[4 * (size_t)k + 3])], 1u);
     __syncthreads();
     // exclusive scan over the fine cells of the pencil
     const int per = (nxf + 255) / 256;
@@ -634,15 +626,7 @@ __global__ __launch_bounds__(256) void k_cells_pen_sort(vmd_pensort_params_t q) 
     if (pen == q.npen - 1 && tid == 255) q.cell_start[(size_t)b * (q.ncell + 1) + q.ncell] = start + n;
     __syncthreads();
     float* sx = s_xyz; float* sy = s_xyz + q.cap_max; float* sz = s_xyz + 2 * (size_t)q.cap_max;
-#pragma unroll
-    for (int u = 0; u < R; ++u) {
-        const uint32_t k = tid + 256u * u;
-        if (k < n) {
-            const uint32_t pos = atomicAdd(&s_cnt[(uint32_t)__float_as_int(rec[u][3])], 1u);
-            sx[pos] = rec[u][0]; sy[pos] = rec[u][1]; sz[pos] = rec[u][2];
-        }
-    }
-    for (uint32_t k = tid + 256u * R; k < n; k += 256) {
+    for (uint32_t k = tid; k < n; k += 256) {
         const vmd_f4a v = *(const vmd_f4a*)(bk + 4 * (size_t)k);
         const uint32_t pos = atomicAdd(&s_cnt[(uint32_t)__float_as_int(v[3])], 1u);
         sx[pos] = v[0]; sy[pos] = v[1]; sz[pos] = v[2];
@@ -818,7 +802,7 @@ __device__ __forceinline__ void vmd_bin_add_deferred_far(const vmd_binning_t& bn
 #ifndef VMD_NO_INLINE_ASM
 // variant 2 pop: 64 pair entries = 128 values, two interleaved binning chains; returns the two park masks.  19 VALU.
 template <unsigned INC>
-__device__ __forceinline__ void vmd_pop_hot2(const vmd_binning_t& bn, vmd_wave_acc_t& w, unsigned lane8, unsigned inc, float& a, float& b,
+__device__ __forceinline__ void vmd_pop_hot2(const vmd_binning_t& bn, vmd_wave_acc_t& w, unsigned lane8 /* 4 * lane: entries are slots of 4 bytes */, unsigned inc, float& a, float& b,
                                              unsigned long long& ma, unsigned long long& mb) {
     unsigned long long sa;
     float ta, tb;
@@ -826,7 +810,7 @@ __device__ __forceinline__ void vmd_pop_hot2(const vmd_binning_t& bn, vmd_wave_a
     asm volatile(
         "v_add_u32 %[ba], %[q], %[l8]\n\t"
         "ds_read_b32 %[a], %[ba]\n\t"
-        "ds_read_b32 %[b], %[ba] offset:4\n\t"
+        "ds_read_b32 %[b], %[ba] offset:512\n\t"
         "s_waitcnt lgkmcnt(0)\n\t"
         "v_sqrt_f32 %[ta], %[a]\n\t"
         "v_sqrt_f32 %[tb], %[b]\n\t"
@@ -865,8 +849,9 @@ __device__ __forceinline__ void vmd_pop_hot2(const vmd_binning_t& bn, vmd_wave_a
 #endif
 
 // variant 2: TWO candidate columns share one compaction.  A lane whose smaller d2 of the pair is a candidate pushes both
-// values as one 8-byte entry (they sit in one packed register pair already); the pop bins both and drops the partner that is
-// no hit with one compare.  Per pair of columns: v_min + v_cmp + 2 v_mbcnt + v_lshl_add + one ds_write_b64 instead of
+// values as one entry: slot s of the stack holds the first value at queue[s] and the second at queue[VMD_PAIR_B + s] (two
+// conflict-free 4-byte accesses per lane instead of one 8-byte access with a 2-way bank conflict); the pop bins both and drops the
+// partner that is no hit with one compare.  Per pair of columns: v_min + v_cmp + 2 v_mbcnt + v_lshl_add + one ds_write_b64 instead of
 // 2 x (v_cmp + 2 v_mbcnt + v_lshl_add + ds_write_b32): the integer ops of the prefix issue at 4 cycles per wave whatever their
 // operands are (profiles/r02_valu_calibration.txt), so halving them is what counts; the pop handles ~1.85 values per hit.
 __device__ __forceinline__ void vmd_push2(vmd_wave_acc_t& w, bool hit, float a, float b) {
@@ -874,10 +859,10 @@ __device__ __forceinline__ void vmd_push2(vmd_wave_acc_t& w, bool hit, float a, 
     if (mask) {
         const unsigned pre = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
         if (hit) {
-            float* e = (float*)((char*)w.queue + ((w.qtop - w.qbase) + 8u * pre));
-            e[0] = a; e[1] = b;
+            float* e = (float*)((char*)w.queue + ((w.qtop - w.qbase) + 4u * pre));
+            e[0] = a; e[VMD_PAIR_B] = b;
         }
-        w.qtop += 8u * (unsigned)__popcll(mask);
+        w.qtop += 4u * (unsigned)__popcll(mask);
     }
 }
 
@@ -904,18 +889,18 @@ template <int VARIANT, unsigned INC>
 __device__ __forceinline__ void vmd_drain_full(const vmd_binning_t& bn, vmd_wave_acc_t& w, int lane) {
     if (VARIANT == 1) return;
     if (VARIANT == 2) {
-        while (w.qtop - w.qbase >= 8u * VMD_WAVE) {
-            w.qtop -= 8u * VMD_WAVE;
+        while (w.qtop - w.qbase >= 4u * VMD_WAVE) {
+            w.qtop -= 4u * VMD_WAVE;
             float a, b;
 #ifndef VMD_NO_INLINE_ASM
             unsigned long long ma, mb;
-            vmd_pop_hot2<INC>(bn, w, 8u * (unsigned)lane, INC, a, b, ma, mb);
+            vmd_pop_hot2<INC>(bn, w, 4u * (unsigned)lane, INC, a, b, ma, mb);
             if (ma) vmd_slow_park<INC>(bn, w, a, ma, (ma >> lane) & 1ull, lane);
             if (mb) vmd_slow_park<INC>(bn, w, b, mb, (mb >> lane) & 1ull, lane);
 #else
             __builtin_amdgcn_wave_barrier();
-            const float* e = (const float*)((const char*)w.queue + ((w.qtop - w.qbase) + 8u * (unsigned)lane));
-            a = e[0]; b = e[1];
+            const float* e = (const float*)((const char*)w.queue + ((w.qtop - w.qbase) + 4u * (unsigned)lane));
+            a = e[0]; b = e[VMD_PAIR_B];
             __builtin_amdgcn_wave_barrier();
             vmd_bin_add_deferred_far<INC>(bn, w, a, true, lane);
             vmd_bin_add_deferred_far<INC>(bn, w, b, true, lane);
@@ -943,9 +928,9 @@ __device__ __forceinline__ void vmd_drain(const vmd_binning_t& bn, vmd_wave_acc_
     if (VARIANT == 1) return;
     vmd_drain_full<VARIANT, INC>(bn, w, lane);
     if (VARIANT == 2) {
-        const unsigned rem = (w.qtop - w.qbase) / 8u;
+        const unsigned rem = (w.qtop - w.qbase) / 4u;
         __builtin_amdgcn_wave_barrier();
-        const float a = w.queue[2 * lane], b = w.queue[2 * lane + 1];
+        const float a = w.queue[lane], b = w.queue[VMD_PAIR_B + lane];
         __builtin_amdgcn_wave_barrier();
         w.qtop = w.qbase;
         vmd_bin_add_deferred_far<INC>(bn, w, a, (unsigned)lane < rem, lane);
@@ -1131,9 +1116,9 @@ __device__ __forceinline__ void vmd_push_hot4_masked(vmd_wave_acc_t& w, float d0
         : [d0] "v"(d0), [d1] "v"(d1), [d2] "v"(d2), [d3] "v"(d3), [r2] "s"(r2), [j] "s"(j), [i0] "v"(i0), [i1] "v"(i1), [i2] "v"(i2), [i3] "v"(i3)
         : "vcc", "scc", "memory");
 }
-// variant 2: one pair-column (two candidate columns).  a, b = the two d2 values, dd = the packed register pair that holds them.
-// The stack is drained after every pair-column, so it never holds more than 64 + 64 entries (LDS: 7 blocks per CU still fit).
-__device__ __forceinline__ void vmd_push_hot2p(vmd_wave_acc_t& w, float a, float b, vmd_f2 dd, float r2) {
+// variant 2: one pair-column (two candidate columns), a / b = its two d2 values.  The stack is drained after every pair-column, so it
+// never holds more than 64 + 64 entries.
+__device__ __forceinline__ void vmd_push_hot2p(vmd_wave_acc_t& w, float a, float b, float r2) {
     unsigned t, n;
     float m;
     asm volatile(
@@ -1143,21 +1128,22 @@ __device__ __forceinline__ void vmd_push_hot2p(vmd_wave_acc_t& w, float a, float
         "s_cbranch_vccz .Lvmd_pp_%=\n\t"
         "v_mbcnt_lo_u32_b32 %[t], vcc_lo, 0\n\t"
         "v_mbcnt_hi_u32_b32 %[t], vcc_hi, %[t]\n\t"
-        "v_lshl_add_u32 %[t], %[t], 3, %[q]\n\t"
+        "v_lshl_add_u32 %[t], %[t], 2, %[q]\n\t"
         "s_mov_b64 exec, vcc\n\t"
-        "ds_write_b64 %[t], %[dd]\n\t"
+        "ds_write_b32 %[t], %[a]\n\t"
+        "ds_write_b32 %[t], %[b] offset:512\n\t"
         "s_mov_b64 exec, -1\n\t"
         "s_bcnt1_i32_b64 %[n], vcc\n\t"
-        "s_lshl3_add_u32 %[q], %[n], %[q]\n"
+        "s_lshl2_add_u32 %[q], %[n], %[q]\n"
         ".Lvmd_pp_%=:\n\t"
         : [q] "+s"(w.qtop), [t] "=&v"(t), [n] "=&s"(n), [m] "=&v"(m)
-        : [a] "v"(a), [b] "v"(b), [dd] "v"(dd), [r2] "s"(r2)
+        : [a] "v"(a), [b] "v"(b), [r2] "s"(r2)
         : "vcc", "scc", "memory");
 }
 // own pencil: the chunk against itself.  Lane L holds atom cbeg + L; the pair-column (j, j + 1) counts for the lanes L <= j - cbeg
-// only (unordered pairs once).  On lane L == j - cbeg the first value is the atom's distance to itself, 0: it is pushed
-// and the binning rejects it like any d <= r_min (SPEC S4: open interval).  lm: that lane mask, wave-uniform.
-__device__ __forceinline__ void vmd_push_hot2p_masked(vmd_wave_acc_t& w, float a, float b, vmd_f2 dd, float r2, unsigned long long lm) {
+// only (unordered pairs once; on lane L == j - cbeg the first value is the atom's distance to itself: the caller replaces it by
+// VMD_JUNK).  lm: that lane mask, wave-uniform.
+__device__ __forceinline__ void vmd_push_hot2p_masked(vmd_wave_acc_t& w, float a, float b, float r2, unsigned long long lm) {
     unsigned t, n;
     float m;
     asm volatile(
@@ -1168,15 +1154,16 @@ __device__ __forceinline__ void vmd_push_hot2p_masked(vmd_wave_acc_t& w, float a
         "s_cbranch_scc0 .Lvmd_ppm_%=\n\t"
         "v_mbcnt_lo_u32_b32 %[t], vcc_lo, 0\n\t"
         "v_mbcnt_hi_u32_b32 %[t], vcc_hi, %[t]\n\t"
-        "v_lshl_add_u32 %[t], %[t], 3, %[q]\n\t"
+        "v_lshl_add_u32 %[t], %[t], 2, %[q]\n\t"
         "s_mov_b64 exec, vcc\n\t"
-        "ds_write_b64 %[t], %[dd]\n\t"
+        "ds_write_b32 %[t], %[a]\n\t"
+        "ds_write_b32 %[t], %[b] offset:512\n\t"
         "s_mov_b64 exec, -1\n\t"
         "s_bcnt1_i32_b64 %[n], vcc\n\t"
-        "s_lshl3_add_u32 %[q], %[n], %[q]\n"
+        "s_lshl2_add_u32 %[q], %[n], %[q]\n"
         ".Lvmd_ppm_%=:\n\t"
         : [q] "+s"(w.qtop), [t] "=&v"(t), [n] "=&s"(n), [m] "=&v"(m)
-        : [a] "v"(a), [b] "v"(b), [dd] "v"(dd), [r2] "s"(r2), [lm] "s"(lm)
+        : [a] "v"(a), [b] "v"(b), [r2] "s"(r2), [lm] "s"(lm)
         : "vcc", "scc", "memory");
 }
 #else
@@ -1221,13 +1208,16 @@ __device__ __forceinline__ void vmd_segment_loop(const vmd_pair_params_t& p, vmd
                 const int a = (int)(ja + k0) - __builtin_amdgcn_readfirstlane((int)i);
                 const unsigned long long lm0 = a >= 63 ? ~0ull : ((2ull << a) - 1ull);
                 const unsigned long long lm1 = a + 2 >= 63 ? ~0ull : ((2ull << (a + 2)) - 1ull);
-                vmd_push_hot2p_masked(w, d2[0][0], d2[0][1], d2[0], r2, lm0);
+                // the self pair (lane a of the first column, lane a + 2 of the third) never enters the stack
+                const float s0 = lane == a ? VMD_JUNK : d2[0][0];
+                const float s1 = lane == a + 2 ? VMD_JUNK : d2[1][0];
+                vmd_push_hot2p_masked(w, s0, d2[0][1], r2, lm0);
                 vmd_drain_full<VARIANT, INC>(p.bin, w, lane);
-                vmd_push_hot2p_masked(w, d2[1][0], d2[1][1], d2[1], r2, lm1);
+                vmd_push_hot2p_masked(w, s1, d2[1][1], r2, lm1);
             } else {
-                vmd_push_hot2p(w, d2[0][0], d2[0][1], d2[0], r2);
+                vmd_push_hot2p(w, d2[0][0], d2[0][1], r2);
                 vmd_drain_full<VARIANT, INC>(p.bin, w, lane);
-                vmd_push_hot2p(w, d2[1][0], d2[1][1], d2[1], r2);
+                vmd_push_hot2p(w, d2[1][0], d2[1][1], r2);
             }
             vmd_drain_full<VARIANT, INC>(p.bin, w, lane);
             return;
@@ -1272,7 +1262,7 @@ __device__ __forceinline__ void vmd_segment_loop(const vmd_pair_params_t& p, vmd
         bool hit = d2 < r2;
         if (MASKED) hit = hit && (ja + k > i);
         vmd_push<VARIANT, INC>(p.bin, w, hit, d2);
-        if (VARIANT == 2) vmd_drain_full<VARIANT, INC>(p.bin, w, lane);      // 8-byte entries: room for one column beyond the 64 pending
+        if (VARIANT == 2) vmd_drain_full<VARIANT, INC>(p.bin, w, lane);      // pair entries: room for one column beyond the 64 pending
     }
     vmd_drain_full<VARIANT, INC>(p.bin, w, lane);
 }
