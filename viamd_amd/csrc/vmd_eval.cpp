@@ -390,6 +390,9 @@ struct PropState {
     DevBuf<uint64_t> d_blocks;          // [nblocks][ncounts]: per-frame-block partial accumulators (filtered evaluation)
     std::vector<double> block_weights64; // [nblocks][ncounts], distributions only
     DevBuf<float> d_values;             // volume float view (device)
+    DevBuf<float> d_zero;               // volume: zeros, the source of the host view's clearing DMA
+    hipEvent_t zero_done = nullptr;     // volume: that DMA has landed (awaited before the view is written again)
+    bool zero_pending = false;
     DevBuf<float> d_max;
     int sel_a = -1, sel_b = -1;         // RDF: indices into eval->sels
     bool same_set = false;
@@ -411,7 +414,10 @@ struct PropState {
     DevBuf<float> d_ma, d_mb, d_out;
     bool uploaded = false;
     bool pinned = false;
-    ~PropState() { if (pinned) { (void)hipHostUnregister(values.data()); (void)hipHostUnregister(counts.data()); } }
+    ~PropState() {
+        if (zero_done) { (void)hipEventSynchronize(zero_done); (void)hipEventDestroy(zero_done); }
+        if (pinned) { (void)hipHostUnregister(values.data()); (void)hipHostUnregister(counts.data()); }
+    }
     bool dirty = false;                 // device accumulators changed since the last host refresh
     bool counts_stale = false;          // volume: host u64 mirror older than the device accumulators
 };
@@ -696,14 +702,20 @@ extern "C" void vmd_eval_clear_data(vmd_script_eval_t* eval) {
     eval->frames_computed = 0; eval->frames_reused = 0; eval->frames_device_decoded = 0;
     for (size_t b = 0; b < eval->num_blocks; ++b) eval->block_ready[b] = 0;
     for (auto& p : eval->props) {
-        // the 8.4 MB float view of a volume is pinned: the copy engine zeroes it (from the cleared device view) while this
-        // thread clears the rest, instead of a host memset in the middle of every re-evaluation
-        if (p->prop.kind == PROP_SDF && p->pinned && p->d_values.ensure(p->ncounts) &&
-            hipMemsetAsync(p->d_values.p, 0, p->ncounts * sizeof(float), eval->stream) == hipSuccess &&
-            hipMemcpyAsync(p->values.data(), p->d_values.p, p->ncounts * sizeof(float), hipMemcpyDeviceToHost, eval->stream) == hipSuccess) {
-        } else {
-            std::fill(p->values.begin(), p->values.end(), 0.0f);
+        // the 8.4 MB float view of a volume is pinned: the copy engine zeroes it from a zero buffer in HBM, in the background -
+        // the DMA overlaps the kernels of the evaluation that follows (VIAMD clears and immediately re-evaluates,
+        // src/main.cpp:990-996) and is awaited before the view is written again; a host memset here cost 10 % of a
+        // 10 000-frame SDF evaluation.  Until it lands (~0.2 ms) a reader may still see the previous volume.
+        bool dma = false;
+        if (p->prop.kind == PROP_SDF && p->pinned) {
+            if (!p->d_zero.p && p->d_zero.ensure(p->ncounts)) (void)hipMemsetAsync(p->d_zero.p, 0, p->ncounts * sizeof(float), eval->copy_stream);
+            if (!p->zero_done) (void)hipEventCreateWithFlags(&p->zero_done, hipEventDisableTiming);
+            dma = p->d_zero.p && p->zero_done &&
+                  hipMemcpyAsync(p->values.data(), p->d_zero.p, p->ncounts * sizeof(float), hipMemcpyDeviceToHost, eval->copy_stream) == hipSuccess &&
+                  hipEventRecord(p->zero_done, eval->copy_stream) == hipSuccess;
+            p->zero_pending = dma;
         }
+        if (!dma) std::fill(p->values.begin(), p->values.end(), 0.0f);
         std::fill(p->weights.begin(), p->weights.end(), 0.0f);
         // the 17 MB u64 mirror of a volume is only ever read after vmd_eval_refresh_counts: mark it stale instead of zeroing it
         if (p->prop.kind == PROP_SDF) p->counts_stale = true;
@@ -756,6 +768,7 @@ static bool refresh_volume(vmd_script_eval_t* e, PropState* p) {
     if (!p->d_values.ensure(p->ncounts) || !p->d_max.ensure(1)) return false;
     KRN_OK(vmd_hip_counts_to_float(e->stream, p->d_counts.p, p->ncounts, p->d_values.p, p->d_max.p));
     float vmax = 0.0f;
+    if (p->zero_pending) { HIP_OK(hipStreamWaitEvent(e->stream, p->zero_done, 0)); p->zero_pending = false; }
     HIP_OK(hipMemcpyAsync(p->values.data(), p->d_values.p, p->ncounts * sizeof(float), hipMemcpyDeviceToHost, e->stream));
     // the 17 MB u64 mirror behind `counts` is an extension VIAMD never reads: it is synchronised on demand
     // (vmd_eval_refresh_counts), only the float view travels after every range
