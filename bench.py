@@ -29,10 +29,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0                    # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-# VALU issue peak: measured, not assumed - scripts/valu_calib.hip (profiles/r02_valu_calibration.txt): cycles per wave64
-# instruction per SIMD for plain and packed fp32 ops at 8 waves/SIMD.  VALU_CYCLES_PER_INST is the figure for the pair
-# kernel's own instruction mix (the "filter + push" row of that table), so frac = 1 means "as fast as that stream runs alone".
-VALU_CYCLES_PER_INST = 4.0
+# VALU issue peak: measured, not assumed - scripts/valu_calib.hip (profiles/r02_valu_calibration.txt), all CUs, 8 waves/SIMD:
+# v_cmp / v_mbcnt / v_lshl_add / v_cvt and every fp32 op with an SGPR operand issue one wave64 instruction per 4.1-4.2 cycles
+# per SIMD (570-600 G/s chip-wide; the packed v_pk_* ops 2.6-4.2); only v_fma/v_add/v_mul_f32 on VGPR operands reach 2 cycles.
+# The pair kernel is made of the 4-cycle class, so that is the peak its instruction rate is priced against.
+VALU_CYCLES_PER_INST = 4.15
 VALU_CLOCK_HZ = 2.4e9
 VALU_PEAK_WINST_S = 256 * 4 * VALU_CLOCK_HZ / VALU_CYCLES_PER_INST
 

@@ -209,6 +209,38 @@ struct DevBuf {
     DevBuf& operator=(const DevBuf&) = delete;
 };
 
+// Host array behind a md_script_property_data_t view.  The views of a volume (8 + 17 MB) are read and written by the copy engine
+// after every range: those live in their own pinned allocation (hipHostMalloc) - registering the pages of a heap block
+// (hipHostRegister) shares pages with neighbouring blocks, fails when two evals sit next to each other, and leaks the
+// registration when only one of two succeeds.
+template <typename T>
+struct HostBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    bool pinned = false;
+    HostBuf() = default;
+    HostBuf(const HostBuf&) = delete;
+    HostBuf& operator=(const HostBuf&) = delete;
+    ~HostBuf() { release(); }
+    void release() { if (p) { if (pinned) (void)hipHostFree(p); else delete[] p; } p = nullptr; n = 0; pinned = false; }
+    void assign(size_t count, T v, bool want_pinned = false) {
+        release();
+        if (count == 0) return;
+        if (want_pinned && hipHostMalloc((void**)&p, count * sizeof(T), hipHostMallocDefault) == hipSuccess) pinned = true;
+        else { (void)hipGetLastError(); p = new T[count]; }
+        n = count;
+        std::fill(p, p + n, v);
+    }
+    T* data() { return p; }
+    const T* data() const { return p; }
+    size_t size() const { return n; }
+    bool empty() const { return n == 0; }
+    T* begin() { return p; }
+    T* end() { return p + n; }
+    T& operator[](size_t i) { return p[i]; }
+    const T& operator[](size_t i) const { return p[i]; }
+};
+
 // ------------------------------------------------------------------------------------------------ IR
 
 enum PropKind { PROP_RDF = 0, PROP_SDF = 1, PROP_DIST = 2 };
@@ -380,8 +412,9 @@ struct PropState {
     Property prop;                      // private copy of the descriptor
     vmd_script_property_data_t data;
     vmd_script_aggregate_t aggregate;
-    std::vector<float> values, weights, agg_mean, agg_var, agg_ext;
-    std::vector<uint64_t> counts;       // host mirror of d_counts
+    HostBuf<float> values;              // what data.values points at
+    std::vector<float> weights, agg_mean, agg_var, agg_ext;
+    HostBuf<uint64_t> counts;           // host mirror of d_counts
     std::vector<double> weights64;
     size_t ncounts = 0;                 // bins or voxels
     size_t dim1 = 0;                    // temporal population
@@ -416,7 +449,6 @@ struct PropState {
     bool pinned = false;
     ~PropState() {
         if (zero_done) { (void)hipEventSynchronize(zero_done); (void)hipEventDestroy(zero_done); }
-        if (pinned) { (void)hipHostUnregister(values.data()); (void)hipHostUnregister(counts.data()); }
     }
     bool dirty = false;                 // device accumulators changed since the last host refresh
     bool counts_stale = false;          // volume: host u64 mirror older than the device accumulators
@@ -621,12 +653,10 @@ extern "C" vmd_script_eval_t* vmd_eval_create(size_t num_frames, const vmd_scrip
             break;
         case PROP_SDF:
             st->ncounts = (size_t)VMD_VOLUME_DIM * VMD_VOLUME_DIM * VMD_VOLUME_DIM;
-            st->values.assign(st->ncounts, 0.0f);
-            st->counts.assign(st->ncounts, 0);
             // the 8 + 17 MB host views of a volume are pinned: their D2H refresh runs at PCIe speed
-            st->pinned = hipHostRegister(st->values.data(), st->ncounts * sizeof(float), hipHostRegisterDefault) == hipSuccess &&
-                         hipHostRegister(st->counts.data(), st->ncounts * sizeof(uint64_t), hipHostRegisterDefault) == hipSuccess;
-            if (!st->pinned) (void)hipGetLastError();
+            st->values.assign(st->ncounts, 0.0f, true);
+            st->counts.assign(st->ncounts, 0, true);
+            st->pinned = st->values.pinned && st->counts.pinned;
             st->data.dim[0] = 1; st->data.dim[1] = st->data.dim[2] = st->data.dim[3] = VMD_VOLUME_DIM;
             st->data.min_range[0] = -p.rmax; st->data.max_range[0] = p.rmax;
             break;
