@@ -94,6 +94,8 @@ static inline emu_f2 emu_fma2(emu_f2 a, emu_f2 b, emu_f2 c) { emu_f2 r = {fmaf(a
 
 template <typename T>
 static inline T atomicAdd(T* p, T v) { T old = *p; *p = old + v; return old; }
+template <typename T>
+static inline T atomicExch(T* p, T v) { T old = *p; *p = v; return old; }
 static inline unsigned atomicMax(unsigned* p, unsigned v) { unsigned old = *p; if (v > old) *p = v; return old; }
 
 // ---- host runtime -------------------------------------------------------------------------------------------------

@@ -48,13 +48,14 @@ def test_coevaluated_rdfs_share_pair_passes(gpu_lib, oracle):
     cases.class_decomposition_cases(gpu_lib, oracle, device=True, n_water=30000, box=70.0)
 
 
-@pytest.mark.parametrize("variant", [0, 2])
-def test_rdf_hit_compaction_variants(gpu_lib, oracle, box30k, variant):
+@pytest.mark.parametrize("variant,shist", [(0, 0), (2, 0), (0, 1)])
+def test_rdf_hit_compaction_variants(gpu_lib, oracle, box30k, variant, shist):
     """variant 0: one compaction per candidate column; variant 2: pair entries (two columns share one compaction; hand-scheduled
     push / pop of their own) - same / different sets, r_min > 0, a thin shell at the cutoff, edge cases, triclinic and open cells,
     and the BASELINE config 2 shape"""
     o, h = cases.oxygen(30000), cases.hydrogen(30000)
     old = gpu_lib.vmd_set_option(b"rdf_variant", variant)
+    old_sh = gpu_lib.vmd_set_option(b"rdf_shared_hist", shist)      # one LDS histogram per block instead of one per wave
     try:
         cases.check_rdf(gpu_lib, oracle, box30k[:3], 80.0, [("goo", o, o, 0.0, 12.0), ("goh", o, h, 0.0, 10.0), ("ring", h, o, 2.5, 9.0),
                                                           ("shell", o, o, 11.5, 12.0)], device=True)
@@ -73,6 +74,7 @@ def test_rdf_hit_compaction_variants(gpu_lib, oracle, box30k, variant):
         np.testing.assert_array_equal(ev.property_data("g").counts, counts)
     finally:
         gpu_lib.vmd_set_option(b"rdf_variant", old)
+        gpu_lib.vmd_set_option(b"rdf_shared_hist", old_sh)
 
 
 def test_rdf_inline_variant_and_host_staging(gpu_lib, oracle, box30k):

@@ -113,6 +113,7 @@ extern "C" int vmd_set_option(const char* key, int value) {
     else if (!strcmp(key, "cells_fused")) return vmd_hip_set_cells_fused(value);
     else if (!strcmp(key, "cells_split")) return vmd_hip_set_cells_split(value);
     else if (!strcmp(key, "rdf_blocks")) return vmd_hip_set_rdf_blocks(value);
+    else if (!strcmp(key, "rdf_shared_hist")) return vmd_hip_set_rdf_shared_hist(value);
     else if (!strcmp(key, "rdf_nsub")) return vmd_hip_set_rdf_nsub(value);
     if (!o) return -1;
     return o->exchange(value);
@@ -505,6 +506,7 @@ struct vmd_script_eval_t {
     };
     Stage stages[2];
     hipStream_t copy_stream = nullptr;
+    hipStream_t aux_stream = nullptr;        // background work nothing else queues behind (the clearing DMA of a volume's host view)
     DevBuf<uint64_t> d_partial;
     std::vector<RdfGroup> rdf_groups;
     DevBuf<uint64_t> d_pass;                 // [passes with several targets][bins]: scratch histogram of one pair pass
@@ -631,6 +633,7 @@ extern "C" vmd_script_eval_t* vmd_eval_create(size_t num_frames, const vmd_scrip
     if (hipGetDevice(&e->device) != hipSuccess) { vmd_fail("hipGetDevice failed"); return nullptr; }
     if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) { vmd_fail("hipStreamCreate failed"); return nullptr; }
     if (hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking) != hipSuccess) { vmd_fail("hipStreamCreate failed"); return nullptr; }
+    if (hipStreamCreateWithFlags(&e->aux_stream, hipStreamNonBlocking) != hipSuccess) { vmd_fail("hipStreamCreate failed"); return nullptr; }
     for (auto& st : e->stages) if (hipEventCreate(&st.ready) != hipSuccess) { vmd_fail("hipEventCreate failed"); return nullptr; }
     e->ir_fingerprint = vmd_ir_fingerprint(ir);
     e->num_frames = num_frames;
@@ -700,6 +703,7 @@ extern "C" void vmd_eval_free(vmd_script_eval_t* eval) {
         std::lock_guard<std::mutex> l(eval->mtx);
         if (eval->stream) { (void)hipStreamSynchronize(eval->stream); }
         if (eval->copy_stream) { (void)hipStreamSynchronize(eval->copy_stream); }
+        if (eval->aux_stream) { (void)hipStreamSynchronize(eval->aux_stream); }
         for (auto& st : eval->stages) {
             if (st.h) (void)hipHostFree(st.h);
             st.h = nullptr;
@@ -713,6 +717,8 @@ extern "C" void vmd_eval_free(vmd_script_eval_t* eval) {
         }
         if (eval->copy_stream) (void)hipStreamDestroy(eval->copy_stream);
         eval->copy_stream = nullptr;
+        if (eval->aux_stream) (void)hipStreamDestroy(eval->aux_stream);
+        eval->aux_stream = nullptr;
         eval->props.clear();
         eval->sels.clear();
         if (eval->h_overflow) (void)hipHostFree(eval->h_overflow);
@@ -738,11 +744,12 @@ extern "C" void vmd_eval_clear_data(vmd_script_eval_t* eval) {
         // 10 000-frame SDF evaluation.  Until it lands (~0.2 ms) a reader may still see the previous volume.
         bool dma = false;
         if (p->prop.kind == PROP_SDF && p->pinned) {
-            if (!p->d_zero.p && p->d_zero.ensure(p->ncounts)) (void)hipMemsetAsync(p->d_zero.p, 0, p->ncounts * sizeof(float), eval->copy_stream);
+            // on its own stream: the staging copies of the next frame_range must not queue behind 8 MB of PCIe traffic
+            if (!p->d_zero.p && p->d_zero.ensure(p->ncounts)) (void)hipMemsetAsync(p->d_zero.p, 0, p->ncounts * sizeof(float), eval->aux_stream);
             if (!p->zero_done) (void)hipEventCreateWithFlags(&p->zero_done, hipEventDisableTiming);
             dma = p->d_zero.p && p->zero_done &&
-                  hipMemcpyAsync(p->values.data(), p->d_zero.p, p->ncounts * sizeof(float), hipMemcpyDeviceToHost, eval->copy_stream) == hipSuccess &&
-                  hipEventRecord(p->zero_done, eval->copy_stream) == hipSuccess;
+                  hipMemcpyAsync(p->values.data(), p->d_zero.p, p->ncounts * sizeof(float), hipMemcpyDeviceToHost, eval->aux_stream) == hipSuccess &&
+                  hipEventRecord(p->zero_done, eval->aux_stream) == hipSuccess;
             p->zero_pending = dma;
         }
         if (!dma) std::fill(p->values.begin(), p->values.end(), 0.0f);

@@ -1308,10 +1308,12 @@ __device__ __forceinline__ int vmd_next_item(unsigned* counters, int& q, int& tr
 // CELL = 2: orthorhombic with open axes (non-periodic systems, slabs): an open axis spans the bounding box of the batch (its
 // origin sits in the tilt slot of the box record), has no images, and neighbour pencils end at the box.  CELL = 0 is the fully
 // periodic orthorhombic cell and carries none of this.
-template <int VARIANT, bool SAME, int CELL>
+// SHIST: ONE LDS histogram per block (ds_add is atomic across its four waves) instead of one per wave: 10 KB of LDS per block
+// instead of 22.5, so 8 blocks = 8 waves per SIMD fit a CU instead of 7.
+template <int VARIANT, bool SAME, int CELL, bool SHIST>
 __global__ __launch_bounds__(256) VMD_SGPR_CAP(96) void k_rdf_pencil(vmd_pair_params_t p) {
     constexpr bool TRI = CELL == 1, OPEN = CELL == 2;
-    __shared__ unsigned s_hist[4][VMD_MAX_BINS];
+    __shared__ unsigned s_hist[SHIST ? 1 : 4][VMD_MAX_BINS];
     __shared__ float s_queue[4][VMD_QUEUE_CAP];
     constexpr unsigned INC = SAME ? 2u : 1u;
     if (p.skip && *p.skip) return;       // set before this launch by the cell build; the host repeats the batch with larger buckets
@@ -1321,10 +1323,10 @@ __global__ __launch_bounds__(256) VMD_SGPR_CAP(96) void k_rdf_pencil(vmd_pair_pa
     const int nbins = p.bin.nbins;
 
     vmd_wave_acc_t w;
-    w.hist = s_hist[wave];
+    w.hist = s_hist[SHIST ? 0 : wave];
     w.queue = s_queue[wave];
     w.qbase = VMD_LDS_ADDRESS(s_queue[wave]);
-    w.hbase = VMD_LDS_ADDRESS(s_hist[wave]);
+    w.hbase = VMD_LDS_ADDRESS(s_hist[SHIST ? 0 : wave]);
     w.qtop = w.qbase;
     w.slow = &s_queue[wave][VMD_QUEUE_CAP - VMD_WAVE];
     w.nslow = 0;
@@ -1332,8 +1334,13 @@ __global__ __launch_bounds__(256) VMD_SGPR_CAP(96) void k_rdf_pencil(vmd_pair_pa
     w.fast_k = vmd_in_vgpr(p.bin.fast_k);
     w.fast_far = vmd_in_vgpr(p.bin.fast_far);
     w.ncols = 0;
-    for (int b = lane; b < nbins; b += VMD_WAVE) w.hist[b] = 0u;
-    __builtin_amdgcn_wave_barrier();
+    if (SHIST) {
+        for (int b = threadIdx.x; b < nbins; b += 256) s_hist[0][b] = 0u;
+        __syncthreads();
+    } else {
+        for (int b = lane; b < nbins; b += VMD_WAVE) w.hist[b] = 0u;
+        __builtin_amdgcn_wave_barrier();
+    }
 
     const int nxf = p.grid.nxf, ny = p.grid.ny, nz = p.grid.nz;
     const int npen = ny * nz;
@@ -1430,13 +1437,15 @@ __global__ __launch_bounds__(256) VMD_SGPR_CAP(96) void k_rdf_pencil(vmd_pair_pa
             }
             // u32 LDS counters: every candidate column adds at most 64*INC; flush long before 2^32 (rare: straight to the
             // device accumulators with atomics)
-            if (w.ncols >= (1u << 23)) {
+            // (a shared histogram receives the columns of four waves: a quarter of the budget each, and the flush takes the bins
+            // with an atomic exchange - an increment of another wave lands either before it, and travels now, or after it, and stays)
+            if (w.ncols >= (SHIST ? (1u << 21) : (1u << 23))) {
                 vmd_drain<VARIANT, INC>(p.bin, w, lane);
                 __builtin_amdgcn_wave_barrier();
                 for (int bb = lane; bb < nbins; bb += VMD_WAVE) {
-                    const unsigned v = w.hist[bb];
+                    const unsigned v = SHIST ? atomicExch(&w.hist[bb], 0u) : w.hist[bb];
                     if (v) atomicAdd(&p.counts[bb], (unsigned long long)v);
-                    w.hist[bb] = 0u;
+                    if (!SHIST) w.hist[bb] = 0u;
                 }
                 __builtin_amdgcn_wave_barrier();
                 w.ncols = 0;
@@ -1448,8 +1457,11 @@ __global__ __launch_bounds__(256) VMD_SGPR_CAP(96) void k_rdf_pencil(vmd_pair_pa
     // one row per block: the four wave histograms are summed through LDS and stored with plain, coalesced writes
     __syncthreads();
     uint64_t* __restrict__ prow = p.partial + (size_t)blockIdx.x * nbins;
-    for (int bb = threadIdx.x; bb < nbins; bb += 256)
-        prow[bb] = (uint64_t)s_hist[0][bb] + s_hist[1][bb] + s_hist[2][bb] + s_hist[3][bb];
+    for (int bb = threadIdx.x; bb < nbins; bb += 256) {
+        uint64_t v = s_hist[0][bb];
+        if (!SHIST) v = v + s_hist[1][bb] + s_hist[2][bb] + s_hist[3][bb];
+        prow[bb] = v;
+    }
 }
 
 // sum the per-block partial rows into the u64 accumulators: block (x = 256 bins, y = slice of 32 rows), coalesced
@@ -2068,6 +2080,8 @@ extern "C" int vmd_hip_cells_build(void* stream, const float* xyz, size_t frame_
 
 static int g_rdf_nsub = 0;   // 0 = automatic: about one i-chunk per item
 extern "C" int vmd_hip_set_rdf_nsub(int n) { const int old = g_rdf_nsub; if (n >= 0 && n <= 64) g_rdf_nsub = n; return old; }
+static int g_rdf_shist = 0;       // one LDS histogram per block instead of one per wave (8 instead of 7 waves per SIMD)
+extern "C" int vmd_hip_set_rdf_shared_hist(int on) { const int old = g_rdf_shist; g_rdf_shist = on ? 1 : 0; return old; }
 static int g_rdf_blocks = 2048;   // 8 blocks x 4 waves per CU requested; 6 fit (SGPR budget)
 extern "C" int vmd_hip_rdf_num_blocks(void) { return 2048; }   // capacity of the partial-row scratch
 extern "C" int vmd_hip_set_rdf_blocks(int n) { const int old = g_rdf_blocks; if (n >= 8 && n <= 2048) g_rdf_blocks = n; return old; }
@@ -2117,15 +2131,16 @@ extern "C" int vmd_hip_rdf_pencil(void* stream, const float* sorted_ref, const u
     p.skip = skip_flag;
     const int cell = (pbc_flags & VMD_PBC_TRICLINIC) ? 1 : ((pbc_flags & 7u) != 7u ? 2 : 0);
     const int which = (variant == 1 ? 6 : variant == 2 ? 12 : 0) + (same_set ? 3 : 0) + cell;
-#define VMD_PENCIL_CASE(n, V, S, C) case n: hipLaunchKernelGGL((k_rdf_pencil<V, S, C>), g, blk, 0, s, p); break;
+#define VMD_PENCIL_CASE(n, V, S, C) case n: if (g_rdf_shist) hipLaunchKernelGGL((k_rdf_pencil<V, S, C, true>), g, blk, 0, s, p); \
+                                            else hipLaunchKernelGGL((k_rdf_pencil<V, S, C, false>), g, blk, 0, s, p); break;
     switch (which) {
     VMD_PENCIL_CASE(0, 0, false, 0) VMD_PENCIL_CASE(1, 0, false, 1) VMD_PENCIL_CASE(2, 0, false, 2)
     VMD_PENCIL_CASE(3, 0, true, 0) VMD_PENCIL_CASE(4, 0, true, 1) VMD_PENCIL_CASE(5, 0, true, 2)
     VMD_PENCIL_CASE(6, 1, false, 0) VMD_PENCIL_CASE(7, 1, false, 1) VMD_PENCIL_CASE(8, 1, false, 2)
     VMD_PENCIL_CASE(9, 1, true, 0) VMD_PENCIL_CASE(10, 1, true, 1) VMD_PENCIL_CASE(11, 1, true, 2)
     VMD_PENCIL_CASE(12, 2, false, 0) VMD_PENCIL_CASE(13, 2, false, 1) VMD_PENCIL_CASE(14, 2, false, 2)
-    VMD_PENCIL_CASE(15, 2, true, 0) VMD_PENCIL_CASE(16, 2, true, 1)
-    default: hipLaunchKernelGGL((k_rdf_pencil<2, true, 2>), g, blk, 0, s, p); break;
+    VMD_PENCIL_CASE(15, 2, true, 0) VMD_PENCIL_CASE(16, 2, true, 1) VMD_PENCIL_CASE(17, 2, true, 2)
+    default: return (int)hipErrorInvalidValue;
     }
 #undef VMD_PENCIL_CASE
     VMD_LAUNCH_CHECK();

@@ -172,13 +172,22 @@ extern "C" bool vmd_eval_reduce(vmd_script_eval_t* eval, const vmd_collective_i*
     }
     const uint8_t* mask = vmd_eval_frame_mask(eval);
     for (size_t f = 0; f < F; ++f) packed[off + f] = mask[f] ? 1.0 : 0.0;
-    double* d_packed = nullptr;
-    if (hipMalloc((void**)&d_packed, total * sizeof(double)) != hipSuccess) return red_fail("vmd_eval_reduce: hipMalloc failed");
+    // device staging of the packed buffer, kept per calling thread (one merge per evaluation: no allocation in the steady state)
+    struct Scratch { double* p = nullptr; size_t cap = 0; int device = -1; };
+    static thread_local Scratch sc;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (sc.cap < total || sc.device != dev) {
+        if (sc.p && sc.device == dev) (void)hipFree(sc.p);
+        sc.p = nullptr; sc.cap = 0; sc.device = dev;
+        if (hipMalloc((void**)&sc.p, total * sizeof(double)) != hipSuccess) return red_fail("vmd_eval_reduce: hipMalloc failed");
+        sc.cap = total;
+    }
+    double* d_packed = sc.p;
     bool ok = hipMemcpyAsync(d_packed, packed.data(), total * sizeof(double), hipMemcpyHostToDevice, s) == hipSuccess;
     ok = ok && coll->allreduce_sum_f64(coll->inst, d_packed, total, s);
     ok = ok && hipMemcpyAsync(packed.data(), d_packed, total * sizeof(double), hipMemcpyDeviceToHost, s) == hipSuccess;
     ok = ok && hipStreamSynchronize(s) == hipSuccess;       // also: the in-place counts are final before finalize reads them
-    (void)hipFree(d_packed);
     if (!ok) return red_fail("vmd_eval_reduce: the packed host-side all-reduce failed");
     off = 0;
     for (const vmd_accum_view_t& v : views) {
