@@ -156,6 +156,17 @@ def cell_build_overflow_case(lib, O, device=False, n=3000, box=60.0):
     nb = C.c_uint64(0)
     lib.vmd_profile_ms(b"cells_build", C.byref(nb))
     assert nb.value >= 2, "the overflowing batch was not rebuilt"
+    # the overflow happens in the build of a LATER pass (the hydrogens of the second property, the third range): the passes that
+    # ran before it must not survive into the repeated batch (all-or-nothing commit at the end of the batch)
+    coords = water_box(O, 6, n, box, F)
+    h = hydrogen(n)[: o.size]
+    for f in (4, 5, 6):
+        coords[f][:, h] = rng.uniform(30.0, 41.0, (3, h.size)).astype(np.float32)
+    old = lib.vmd_set_option(b"rdf_classes", 0)
+    try:
+        check_rdf(lib, O, coords, box, [("goo", o, o, 0.0, 12.0), ("ghh", h, h, 0.0, 12.0), ("short", o, o, 0.0, 7.0)], device=device)
+    finally:
+        lib.vmd_set_option(b"rdf_classes", old)
 
 
 def class_decomposition_cases(lib, O, device=False, n_water=3000, box=40.0):
@@ -701,3 +712,49 @@ def export_cases(lib, O, tmp_path, device=False, n_water=1500, box=34.0):
 def pytest_raises(exc):
     import pytest
     return pytest.raises(exc)
+
+
+def filtered_contention_case(lib, O, device=False, n=3000, box=60.0, F=12, S=2, rounds=10):
+    """"Eval Filt" attached to a source that is still RUNNING.  One thread drives the full evaluation in
+    small ranges (it keeps one partial accumulator per block of S frames), another keeps clearing the filtered eval and asking
+    for random sub-ranges: whatever blocks happen to be finished are served from the partials, the rest is computed - every
+    answer must equal the oracle's histogram of that range, bit for bit."""
+    import threading
+    coords = water_box(O, 9, n, box, F)
+    o = oxygen(n)
+    ocell, vcell = cell_pair(O, box)
+    per_frame = [oracle_rdf(O, coords, ocell, o, o, 0.0, 10.0, frames=(f,))[0] for f in range(F)]
+    ir = V.ScriptIR(lib)
+    ir.add_rdf("g", o, o, 10.0)
+    traj = make_traj(lib, coords, vcell, device)
+    sysm = V.MolSystem(n, unitcell=vcell)
+    rng = np.random.default_rng(4)
+    for rnd in range(2):
+        full, filt = V.ScriptEval(F, ir), V.ScriptEval(F, ir)
+        full.set_block_frames(S)
+        filt.set_source(full)
+        errors = []
+
+        def run_full():
+            try:
+                for beg in range(0, F, S):                       # whole blocks, one call each (like enkiTS ranges)
+                    assert full.frame_range(sysm, traj, beg, min(F, beg + S))
+            except Exception as ex:                              # noqa: BLE001
+                errors.append(ex)
+
+        th = threading.Thread(target=run_full)
+        th.start()
+        reused = 0
+        for k in range(rounds):
+            a = int(rng.integers(0, F - 1)); b = int(rng.integers(a + 1, F + 1))
+            filt.clear_data()
+            assert filt.frame_range(sysm, traj, a, b)
+            want = np.sum([per_frame[f] for f in range(a, b)], axis=0).astype(np.uint64)
+            np.testing.assert_array_equal(filt.property_data("g").counts, want, err_msg=f"filtered range [{a}, {b}) while the source runs")
+            reused += filt.frame_stats()[1]
+        th.join()
+        assert not errors, errors
+        np.testing.assert_array_equal(full.property_data("g").counts, np.sum(per_frame, axis=0).astype(np.uint64))
+        filt.clear_data()
+        assert filt.frame_range(sysm, traj, 0, F) and filt.frame_stats() == (0, F)      # afterwards everything comes from the partials
+        filt.set_source(None)

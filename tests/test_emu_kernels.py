@@ -244,3 +244,7 @@ def test_sdf_rotations_known_answer(emu_lib):
 
 def test_distance_known_answer(emu_lib):
     cases.distance_known_answer(emu_lib)
+
+
+def test_filtered_eval_against_a_running_source(emu_lib, oracle):
+    cases.filtered_contention_case(emu_lib, oracle, n=1500, box=40.0, F=8, S=2, rounds=6)

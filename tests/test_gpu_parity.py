@@ -467,3 +467,7 @@ def test_sdf_triclinic_spread_structures_regression(gpu_lib, oracle):
 def test_cube_and_table_export_from_a_gpu_evaluation(tmp_path, gpu_lib, oracle):
     """VERDICT r01 #9: GPU-evaluated SDF -> vmd_export_cube (C++) -> read back == counts; vis payload with the structures."""
     cases.export_cases(gpu_lib, oracle, tmp_path, device=True, n_water=30000, box=70.0)
+
+
+def test_filtered_eval_against_a_running_source(gpu_lib, oracle):
+    cases.filtered_contention_case(gpu_lib, oracle, device=True, n=30000, box=80.0, F=24, S=4, rounds=25)

@@ -509,7 +509,7 @@ struct vmd_script_eval_t {
     hipStream_t aux_stream = nullptr;        // background work nothing else queues behind (the clearing DMA of a volume's host view)
     DevBuf<uint64_t> d_partial;
     std::vector<RdfGroup> rdf_groups;
-    DevBuf<uint64_t> d_pass;                 // [passes with several targets][bins]: scratch histogram of one pair pass
+    DevBuf<uint64_t> d_pass;                 // [passes of the batch][bins]: scratch histogram of every pair pass, committed at the batch's end
     DevBuf<uint32_t> d_overflow;             // device flag raised by the two-level cell build when a pencil bucket is full
     uint32_t* h_overflow = nullptr;          // pinned host copy, read at every batch's synchronisation point
     DevBuf<uint32_t> d_pen_sample;
@@ -1389,8 +1389,9 @@ static size_t auto_batch(const vmd_script_eval_t* e, size_t num_atoms, bool stag
     for (auto& g : e->rdf_groups) for (auto& ps : g.passes) { used[ps.sel_a] = 1; used[ps.sel_b] = 1; }
     for (size_t i = 0; i < e->sels.size(); ++i) if (used[i]) per_frame += 40 * e->sels[i]->idx.size();
     for (auto& p : e->props) per_frame += p->prop.kind == PROP_SDF ? 64 * p->prop.K : (p->prop.kind == PROP_DIST ? 4 * p->dim1 : 0);
-    // 288 GB of HBM: a 12 GB scratch budget keeps whole 1k-frame trajectories of the 1M-atom configs in one or two launches
-    size_t B = (size_t)(12ull << 30) / std::max<size_t>(per_frame, 1);
+    // 288 GB of HBM: a 16 GB scratch budget holds the 1 000 frames of the 1M-atom RDF (333k selected atoms) in ONE batch
+    // (every batch boundary costs ~1 ms of host round trips against ~37 ms of kernels per 500 frames)
+    size_t B = (size_t)(16ull << 30) / std::max<size_t>(per_frame, 1);
     // pair passes are long (a 1 024-frame batch of the 1M-atom RDF runs ~90 ms: interrupts are polled between batches); scripts
     // without them stream whole frames at HBM speed and take much larger batches, so that launches, the alignment kernel's
     // latency and the per-batch synchronisation stay small against the stream (grid.y = frames of the batch <= 65535)
@@ -1542,13 +1543,17 @@ static bool process_range(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
             for (auto& p : e->props) if (p->ncounts) HIP_OK(hipMemsetAsync(acc_of(p.get()), 0, p->ncounts * sizeof(uint64_t), e->stream));
 
         // ---- RDF: one pair pass per (group, pass); launch_rdf may run again for this batch when a cell-build bucket overflowed
+        // Every pass accumulates into its own scratch row and the rows are committed to the properties' accumulators by ONE
+        // group of k_axpy_u64 launches at the very end, behind the overflow flag: by then every cell build of the batch has run,
+        // so the flag is final and the batch's RDF part is all-or-nothing (a bucket of a LATER build may overflow after earlier
+        // passes have long finished; nothing of them may stay behind when the batch is repeated).
         auto launch_rdf = [&]() -> bool {
             size_t scratch_rows = 0;
-            for (auto& g : e->rdf_groups) for (auto& ps : g.passes) if (!(ps.targets.size() == 1 && ps.targets[0].second == 1)) scratch_rows += 1;
-            if (scratch_rows) {
-                if (!e->d_pass.ensure(scratch_rows * VMD_RDF_NUM_BINS)) return false;
-                HIP_OK(hipMemsetAsync(e->d_pass.p, 0, scratch_rows * VMD_RDF_NUM_BINS * sizeof(uint64_t), e->stream));
-            }
+            for (auto& g : e->rdf_groups) scratch_rows += std::max(g.passes.size(), g.props.size());
+            if (!e->d_pass.ensure(std::max<size_t>(scratch_rows, 1) * VMD_RDF_NUM_BINS)) return false;
+            HIP_OK(hipMemsetAsync(e->d_pass.p, 0, scratch_rows * VMD_RDF_NUM_BINS * sizeof(uint64_t), e->stream));
+            struct Commit { uint64_t* dst; const uint64_t* src; uint64_t mult; };
+            std::vector<Commit> commits;
             size_t row = 0;
             for (auto& g : e->rdf_groups) {
                 vmd_grid_t grid;
@@ -1563,13 +1568,14 @@ static bool process_range(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
                         PropState* p = e->props[pi].get();
                         Selection* sa = e->sels[p->sel_a].get();
                         Selection* sb = e->sels[p->sel_b].get();
+                        uint64_t* dst = e->d_pass.p + (row++) * VMD_RDF_NUM_BINS;
                         e->prof.begin("rdf_brute", e->stream);
                         KRN_OK(vmd_hip_rdf_brute(e->stream, src.base, src.frame_stride, src.row_stride, src.d_boxes.p, pbc, (int)nb,
                                                  sa->d_idx.p, (int)sa->idx.size(), sb->d_idx.p, (int)sb->idx.size(),
-                                                 g.rmin, g.rmax, VMD_RDF_NUM_BINS, acc_of(p)));
+                                                 g.rmin, g.rmax, VMD_RDF_NUM_BINS, dst));
                         e->prof.end(e->stream);
+                        commits.push_back({acc_of(p), dst, 1});
                     }
-                    for (auto& ps : g.passes) if (!(ps.targets.size() == 1 && ps.targets[0].second == 1)) row += 1;
                     continue;
                 }
                 if (!e->d_partial.ensure(vmd_hip_rdf_partial_words())) return false;
@@ -1582,21 +1588,17 @@ static bool process_range(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
                     // the pair set is symmetric in (ref, target): put the denser selection in the lanes - 64 of its atoms span a
                     // shorter stretch of the pencil, so the x window of every segment carries less padding
                     if (sb->idx.size() > sa->idx.size()) std::swap(sa, sb);
-                    const bool direct = ps.targets.size() == 1 && ps.targets[0].second == 1;
-                    uint64_t* dst = direct ? acc_of(e->props[ps.targets[0].first].get()) : e->d_pass.p + row * VMD_RDF_NUM_BINS;
+                    uint64_t* dst = e->d_pass.p + (row++) * VMD_RDF_NUM_BINS;
                     e->prof.begin("rdf_pencil", e->stream);
                     KRN_OK(vmd_hip_rdf_pencil(e->stream, sa->sorted.p, sa->cell_start.p, (int)sa->idx.size(), sa->nsel_pad,
                                               sb->sorted.p, sb->cell_start.p, (int)sb->idx.size(), sb->nsel_pad,
                                               d_gb, (int)nb, grid, g.rmin, g.rmax, VMD_RDF_NUM_BINS,
                                               ps.same ? 1 : 0, g_opt.rdf_variant, pbc, e->d_partial.p, dst, e->d_overflow.p));
                     e->prof.end(e->stream);
-                    if (!direct) {
-                        for (auto& tg : ps.targets)
-                            KRN_OK(vmd_hip_axpy_u64(e->stream, acc_of(e->props[tg.first].get()), dst, VMD_RDF_NUM_BINS, tg.second, e->d_overflow.p));
-                        row += 1;
-                    }
+                    for (auto& tg : ps.targets) commits.push_back({acc_of(e->props[tg.first].get()), dst, tg.second});
                 }
             }
+            for (auto& c : commits) KRN_OK(vmd_hip_axpy_u64(e->stream, c.dst, c.src, VMD_RDF_NUM_BINS, c.mult, e->d_overflow.p));
             HIP_OK(hipMemcpyAsync(e->h_overflow, e->d_overflow.p, sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
             return true;
         };

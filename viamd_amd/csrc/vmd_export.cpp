@@ -28,7 +28,10 @@ extern "C" bool vmd_export_xvg(const char* path, const float* const* columns, co
     if (!f) return exp_fail(std::string("Failed to open file '") + path + "' to write data.");
     time_t t;
     time(&t);
-    fprintf(f, "# This file was created %s", asctime(localtime(&t)));
+    struct tm tmv;
+    char tbuf[64];
+    localtime_r(&t, &tmv);
+    fprintf(f, "# This file was created %s", asctime_r(&tmv, tbuf));
     fprintf(f, "# Created by:\n");
     fprintf(f, "# VIAMD \n");
     fprintf(f, "@    title \"VIAMD Properties\"\n");

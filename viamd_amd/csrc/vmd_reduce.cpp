@@ -178,7 +178,7 @@ extern "C" bool vmd_eval_reduce(vmd_script_eval_t* eval, const vmd_collective_i*
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (sc.cap < total || sc.device != dev) {
-        if (sc.p && sc.device == dev) (void)hipFree(sc.p);
+        if (sc.p) (void)hipFree(sc.p);
         sc.p = nullptr; sc.cap = 0; sc.device = dev;
         if (hipMalloc((void**)&sc.p, total * sizeof(double)) != hipSuccess) return red_fail("vmd_eval_reduce: hipMalloc failed");
         sc.cap = total;
