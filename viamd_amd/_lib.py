@@ -232,6 +232,7 @@ SIGNATURES = [
     ("vmd_hip_sdf_scatter", C.c_int, [_vp, _vp, C.c_size_t, C.c_size_t, _vp, C.c_uint32, C.c_int, _vp, C.c_int, C.c_int, _vp, _vp,
                                       _vp, _vp, C.c_int, C.c_float, C.c_int, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int]),
     ("vmd_hip_set_sdf_ilp", C.c_int, [C.c_int]),
+    ("vmd_hip_set_sdf_rows", C.c_int, [C.c_int]),
     ("vmd_hip_distance", C.c_int, [_vp, _vp, C.c_size_t, C.c_size_t, _vp, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int,
                                    _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     ("vmd_hip_add_u64", C.c_int, [_vp, _vp, _vp, C.c_size_t]),

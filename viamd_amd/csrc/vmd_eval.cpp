@@ -109,6 +109,7 @@ extern "C" int vmd_set_option(const char* key, int value) {
     else if (!strcmp(key, "rdf_classes")) o = &g_opt.rdf_classes;
     else if (!strcmp(key, "sdf_arith")) o = &g_opt.sdf_arith;
     else if (!strcmp(key, "sdf_ilp")) return vmd_hip_set_sdf_ilp(value);
+    else if (!strcmp(key, "sdf_rows")) return vmd_hip_set_sdf_rows(value);
     else if (!strcmp(key, "cells_pencil")) return vmd_hip_set_cells_pencil(value);
     else if (!strcmp(key, "cells_fused")) return vmd_hip_set_cells_fused(value);
     else if (!strcmp(key, "cells_split")) return vmd_hip_set_cells_split(value);

@@ -1834,6 +1834,78 @@ __global__ __launch_bounds__(256) void k_sdf_scatter(vmd_scatter_params_t p) {
     }
 }
 
+// Row-streaming variant for arithmetic-progression targets (first + t * stride, e.g. every water oxygen: stride 3): the lines of
+// the x / y / z rows are needed in full anyway (a stride-3 selection touches every 32-byte sector), so a thread takes GPT groups of
+// 4 consecutive ATOMS with 16-byte loads - three perfectly coalesced dwordx4 loads per group instead of twelve strided dword
+// gathers - and tests only the atoms of its groups that are targets (one or two of four for stride 3).  Survivors of the group
+// test go through the same bounded LDS compaction and K-structure loop as in k_sdf_scatter; same arithmetic, same result.
+template <int GPT>
+__global__ __launch_bounds__(256) void k_sdf_scatter_rows(vmd_scatter_params_t p, int g_first, int ngroups) {
+    __shared__ float s_x[VMD_SDF_CAP], s_y[VMD_SDF_CAP], s_z[VMD_SDF_CAP];
+    __shared__ int s_own[VMD_SDF_CAP], s_idx[VMD_SDF_CAP];
+    __shared__ unsigned s_n;
+    const int b = blockIdx.y;
+    const vmd_box_t bx = vmd_load_box(p.boxes, b, p.pbc);
+    const float* fx = p.xyz + (size_t)b * p.frame_stride;
+    const int s = p.tgt_stride, first = p.tgt_first;
+    vmd_f4a x4[GPT], y4[GPT], z4[GPT];
+    int a0[GPT];
+#pragma unroll
+    for (int u = 0; u < GPT; ++u) {
+        const int gl = (blockIdx.x * GPT + u) * 256 + threadIdx.x;
+        a0[u] = -1;
+        if (gl < ngroups) {
+            a0[u] = 4 * (g_first + gl);
+            x4[u] = *(const vmd_f4a*)(fx + a0[u]);
+            y4[u] = *(const vmd_f4a*)(fx + p.row_stride + a0[u]);
+            z4[u] = *(const vmd_f4a*)(fx + 2 * p.row_stride + a0[u]);
+        }
+    }
+    unsigned pending = 0u;          // bit 4u + k: atom k of group u is a target that passed the group test
+#pragma unroll
+    for (int u = 0; u < GPT; ++u) {
+        if (a0[u] < 0) continue;
+        // first target at or after atom a0: offset k0 in [0, s)
+        const int d = a0[u] - first;
+        int k0 = d >= 0 ? (s - d % s) % s : -d;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (k != k0) continue;
+            const int t = (a0[u] + k - first) / s;
+            if (t < p.ntgt && vmd_sdf_near(p, bx, b, x4[u][k], y4[u][k], z4[u][k])) pending |= 1u << (4 * u + k);
+            k0 += s;
+        }
+    }
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) s_n = 0u;
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < GPT; ++u) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (pending & (1u << (4 * u + k))) {
+                    const unsigned slot = atomicAdd(&s_n, 1u);
+                    if (slot < VMD_SDF_CAP) {
+                        const int idx = a0[u] + k;
+                        s_x[slot] = x4[u][k]; s_y[slot] = y4[u][k]; s_z[slot] = z4[u][k]; s_idx[slot] = idx;
+                        s_own[slot] = p.unowned ? -1 : (p.owner ? (int)p.owner[(idx - first) / s] : -2);
+                        pending &= ~(1u << (4 * u + k));
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        const unsigned total = s_n;
+        const int nwork = (int)(total < VMD_SDF_CAP ? total : VMD_SDF_CAP) * p.K;
+        for (int w = threadIdx.x; w < nwork; w += 256) {
+            const int a = w / p.K, k = w - a * p.K;
+            vmd_sdf_atom_k(p, bx, b, k, s_x[a], s_y[a], s_z[a], s_own[a], s_idx[a]);
+        }
+        if (total <= VMD_SDF_CAP) break;
+    }
+}
+
 // dense targets (a sizeable fraction of all atoms, e.g. every water oxygen): stream the WHOLE frame with 16-byte loads per
 // lane and pick the targets by a per-atom tag byte (255 = not a target, 254 = target, k <= 253 = target owned by structure k)
 // instead of gathering 4 bytes per lane through an index list.  Same arithmetic, same result.
@@ -2187,6 +2259,8 @@ extern "C" int vmd_hip_sdf_ref_pose(void* stream, const float* xyz, size_t row_s
     return 0;
 }
 
+static int g_sdf_rows = 0;      // row-streaming scatter for arithmetic-progression targets: groups of 4 atoms per thread (0 = off, 1 / 2 / 4)
+extern "C" int vmd_hip_set_sdf_rows(int n) { const int old = g_sdf_rows; if (n == 0 || n == 1 || n == 2 || n == 4) g_sdf_rows = n; return old; }
 static int g_sdf_ilp = 4;
 extern "C" int vmd_hip_set_sdf_ilp(int n) { const int old = g_sdf_ilp; if (n == 4 || n == 8 || n == 16) g_sdf_ilp = n; return old; }
 extern "C" int vmd_hip_sdf_scatter(void* stream, const float* xyz, size_t frame_stride, size_t row_stride,
@@ -2205,6 +2279,17 @@ extern "C" int vmd_hip_sdf_scatter(void* stream, const float* xyz, size_t frame_
         return 0;
     }
     const bool arith = tgt_stride > 0;
+    if (arith && g_sdf_rows && tgt_stride <= 4 && ((uintptr_t)xyz & 15u) == 0 && row_stride % 4 == 0 && frame_stride % 4 == 0) {
+        // the rows are read in full anyway: stream them with 16-byte loads (stride <= 4: every group of 4 atoms holds a target)
+        const int g_first = tgt_first / 4;
+        const int g_last = (int)(((long long)tgt_first + (long long)(ntgt - 1) * tgt_stride) / 4);
+        const int ngroups = g_last - g_first + 1;
+        if (g_sdf_rows == 2) hipLaunchKernelGGL((k_sdf_scatter_rows<2>), dim3((ngroups + 511) / 512, B), dim3(256), 0, s, p, g_first, ngroups);
+        else if (g_sdf_rows == 4) hipLaunchKernelGGL((k_sdf_scatter_rows<4>), dim3((ngroups + 1023) / 1024, B), dim3(256), 0, s, p, g_first, ngroups);
+        else hipLaunchKernelGGL((k_sdf_scatter_rows<1>), dim3((ngroups + 255) / 256, B), dim3(256), 0, s, p, g_first, ngroups);
+        VMD_LAUNCH_CHECK();
+        return 0;
+    }
     if (g_sdf_ilp == 16) {
         const dim3 g((ntgt + 256 * 16 - 1) / (256 * 16), B);
         if (arith) hipLaunchKernelGGL((k_sdf_scatter<16, true>), g, dim3(256), 0, s, p);
