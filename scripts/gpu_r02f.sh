@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 2, final evidence call: all GPU tests, smoke, the default bench line as the driver runs it, rocprofv3 kernel stats of the
 # same command, PMC traffic of c3 / c2 / c4, strong-scaling code path at N = 1.
-TAG=${1:-r02f}
+TAG=${1:-r02j}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT

@@ -261,7 +261,9 @@ struct Property {
 struct vmd_script_ir_t {
     std::vector<Property> props;
     std::vector<const char*> names;
-    void rebuild_names() { names.clear(); for (auto& p : props) names.push_back(p.name.c_str()); }
+    mutable std::atomic<uint64_t> fingerprint{0};     // 0 = not computed: hashing a 1M-atom script's index lists takes ~1 ms, and
+                                                      // vmd_eval_frame_range compares fingerprints on every call
+    void rebuild_names() { names.clear(); for (auto& p : props) names.push_back(p.name.c_str()); fingerprint = 0; }
 };
 
 static uint64_t fnv1a(uint64_t h, const void* data, size_t n) {
@@ -351,6 +353,8 @@ extern "C" bool vmd_ir_valid(const vmd_script_ir_t* ir) { return ir != nullptr; 
 
 extern "C" uint64_t vmd_ir_fingerprint(const vmd_script_ir_t* ir) {
     if (!ir) return 0;
+    const uint64_t cached = ir->fingerprint.load();
+    if (cached) return cached;
     uint64_t h = 0xCBF29CE484222325ull;
     for (auto& p : ir->props) {
         h = fnv1a(h, p.name.data(), p.name.size());
@@ -361,7 +365,9 @@ extern "C" uint64_t vmd_ir_fingerprint(const vmd_script_ir_t* ir) {
         h = fnv1a(h, &p.K, sizeof(p.K)); h = fnv1a(h, &p.m, sizeof(p.m)); h = fnv1a(h, &p.dist_kind, sizeof(int));
         h = fnv1a(h, p.aoff.data(), p.aoff.size() * sizeof(int32_t)); h = fnv1a(h, p.boff.data(), p.boff.size() * sizeof(int32_t));
     }
-    return h ? h : 1;
+    h = h ? h : 1;
+    ir->fingerprint = h;
+    return h;
 }
 extern "C" size_t vmd_ir_property_count(const vmd_script_ir_t* ir) { return ir ? ir->props.size() : 0; }
 extern "C" const char* const* vmd_ir_property_names(const vmd_script_ir_t* ir) { return ir ? ir->names.data() : nullptr; }
@@ -521,6 +527,7 @@ struct vmd_script_eval_t {
     size_t num_blocks = 0;
     vmd_script_eval_t* source = nullptr;
     std::atomic<size_t> frames_computed{0}, frames_reused{0}, frames_device_decoded{0};
+    size_t atoms_checked = (size_t)-1;       // trajectory atom count the properties' indices were validated against (under mtx)
 };
 typedef vmd_script_eval_t::Stage Stage;
 
@@ -1021,11 +1028,13 @@ static bool upload_static(vmd_script_eval_t* e, const vmd_system_t* sys, size_t 
     return true;
 }
 
-static bool check_atoms(const vmd_script_eval_t* e, size_t num_atoms) {
+static bool check_atoms(vmd_script_eval_t* e, size_t num_atoms) {
+    if (e->atoms_checked == num_atoms) return true;          // the index lists never change: one pass per trajectory size
     for (auto& p : e->props) {
         for (int32_t i : p->prop.a) if ((size_t)i >= num_atoms) return vmd_fail("property '%s' references atom %d but the trajectory has %zu atoms", p->prop.name.c_str(), i, num_atoms);
         for (int32_t i : p->prop.b) if ((size_t)i >= num_atoms) return vmd_fail("property '%s' references atom %d but the trajectory has %zu atoms", p->prop.name.c_str(), i, num_atoms);
     }
+    e->atoms_checked = num_atoms;
     return true;
 }
 
