@@ -61,6 +61,9 @@ typedef struct vmd_device_view_t {
     const vmd_unitcell_t* cells;
     int device;
     size_t resident_beg, resident_end;   /* frames present behind `base` (a rank's shard); 0, 0 = all of them */
+    uint64_t cells_version;              /* changes whenever the cells OR the coordinates behind the view are modified; 0 = unknown
+                                            (the evaluator then re-reads the cells of every batch instead of keeping the boxes - and,
+                                            for open axes, the bounding boxes - of an unchanged range on the device) */
 } vmd_device_view_t;
 
 /* host-resident view of a trajectory with the same SoA frame layout (e.g. a frame cache in pinned memory): lets the

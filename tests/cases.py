@@ -758,3 +758,43 @@ def filtered_contention_case(lib, O, device=False, n=3000, box=60.0, F=12, S=2, 
         filt.clear_data()
         assert filt.frame_range(sysm, traj, 0, F) and filt.frame_stats() == (0, F)      # afterwards everything comes from the partials
         filt.set_source(None)
+
+
+def device_view_cache_case(lib, O, n=1500, box=40.0):
+    """A resident trajectory whose cells or coordinates change between evaluations: the evaluator keeps the boxes (and, for open
+    axes, the bounding boxes) of an unchanged frame range on the device, keyed by vmd_device_view_t::cells_version - every
+    modification must invalidate them."""
+    F = 3
+    coords = water_box(O, 13, n, box, F)
+    o = oxygen(n)
+    ir = V.ScriptIR(lib)
+    ir.add_rdf("g", o, o, 9.0)
+    ev = V.ScriptEval(F, ir)
+
+    def run_and_check(traj, vcell, ocell, frames_coords):
+        ev.clear_data()
+        assert ev.frame_range(V.MolSystem(n, unitcell=vcell), traj, 0, F)
+        want, _ = oracle_rdf(O, frames_coords, ocell, o, o, 0.0, 9.0)
+        np.testing.assert_array_equal(ev.property_data("g").counts, want)
+
+    ocell, vcell = cell_pair(O, box)
+    traj = V.DeviceTrajectory(F, n, lib=lib)
+    traj.upload(coords, vcell)
+    run_and_check(traj, vcell, ocell, coords)
+    run_and_check(traj, vcell, ocell, coords)                        # second run: served from the cached boxes
+    ocell2, vcell2 = cell_pair(O, box + 3.0)                         # same coordinates in a larger cell
+    traj.set_cell(vcell2)
+    run_and_check(traj, vcell2, ocell2, coords)
+    c2 = coords.copy()
+    c2[1] = water_box(O, 14, n, box, 1)[0]                            # new coordinates in frame 1
+    traj.upload_frame(1, vcell2, c2[1, 0], c2[1, 1], c2[1, 2])
+    run_and_check(traj, vcell2, ocell2, c2)
+    # no cell at all: the grid spans the bounding box of the batch, which moves with the coordinates
+    ocell0, vcell0 = cell_pair(O, None, 0)
+    t0 = V.DeviceTrajectory(F, n, lib=lib)
+    t0.upload(coords, vcell0)
+    run_and_check(t0, vcell0, ocell0, coords)
+    c3 = coords * np.float32(1.5) + np.float32(7.0)                   # the system grows and moves: a stale bounding box would clip it
+    for f in range(F):
+        t0.upload_frame(f, vcell0, c3[f, 0], c3[f, 1], c3[f, 2])
+    run_and_check(t0, vcell0, ocell0, c3)

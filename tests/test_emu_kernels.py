@@ -249,3 +249,7 @@ def test_distance_known_answer(emu_lib):
 
 def test_filtered_eval_against_a_running_source(emu_lib, oracle):
     cases.filtered_contention_case(emu_lib, oracle, n=1500, box=40.0, F=8, S=2, rounds=6)
+
+
+def test_resident_trajectory_changes_invalidate_cached_boxes(emu_lib, oracle):
+    cases.device_view_cache_case(emu_lib, oracle)

@@ -472,3 +472,7 @@ def test_cube_and_table_export_from_a_gpu_evaluation(tmp_path, gpu_lib, oracle):
 
 def test_filtered_eval_against_a_running_source(gpu_lib, oracle):
     cases.filtered_contention_case(gpu_lib, oracle, device=True, n=30000, box=80.0, F=24, S=4, rounds=25)
+
+
+def test_resident_trajectory_changes_invalidate_cached_boxes(gpu_lib, oracle):
+    cases.device_view_cache_case(gpu_lib, oracle, n=30000, box=80.0)

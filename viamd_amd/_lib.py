@@ -41,7 +41,7 @@ class FrameHeader(C.Structure):
 
 class DeviceView(C.Structure):
     _fields_ = [("base", c_float_p), ("frame_stride", C.c_size_t), ("row_stride", C.c_size_t),
-                ("cells", C.POINTER(Unitcell)), ("device", C.c_int), ("resident_beg", C.c_size_t), ("resident_end", C.c_size_t)]
+                ("cells", C.POINTER(Unitcell)), ("device", C.c_int), ("resident_beg", C.c_size_t), ("resident_end", C.c_size_t), ("cells_version", C.c_uint64)]
 
 
 NUM_FRAMES_FN = C.CFUNCTYPE(C.c_size_t, C.c_void_p)

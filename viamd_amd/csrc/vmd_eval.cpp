@@ -510,6 +510,8 @@ struct vmd_script_eval_t {
         hipEvent_t ready = nullptr;
         const float* base = nullptr; size_t frame_stride = 0, row_stride = 0;   // where the kernels read the batch
         size_t f0 = 0, nb = 0;
+        // device views: the range whose cells / boxes this stage holds (host vectors and d_boxes), 0 = none
+        const vmd_unitcell_t* boxes_cells = nullptr; size_t boxes_f0 = 0, boxes_nb = 0; uint64_t boxes_version = 0;
     };
     Stage stages[2];
     hipStream_t copy_stream = nullptr;
@@ -1129,6 +1131,17 @@ static bool fetch_stage(vmd_script_eval_t* e, Stage& st, vmd_trajectory_i* traj,
     vmd_host_view_t hv;
     const vmd_host_view_t* hview = (!view && traj->host_view && traj->host_view(traj->inst, &hv)) ? &hv : nullptr;
     st.f0 = f0; st.nb = nb;
+    if (view && view->cells_version != 0 && st.boxes_version == view->cells_version && st.boxes_cells == view->cells && st.boxes_f0 == f0 &&
+        st.boxes_nb == nb) {
+        // the same frames of an unchanged resident trajectory as last time (VIAMD re-evaluates after every script edit; a 10 000-frame
+        // SDF step spent 0.1 ms here): cells, boxes (also the bounding-box ones of open axes) and their device copy are still valid
+        st.base = view->base + f0 * view->frame_stride;
+        st.frame_stride = view->frame_stride;
+        st.row_stride = view->row_stride;
+        HIP_OK(hipEventRecord(st.ready, e->copy_stream));
+        return true;
+    }
+    st.boxes_version = 0;
     st.gboxes_ready = false;
     st.cells.resize(nb);
     st.h_boxes.resize(nb * 9);
@@ -1222,6 +1235,7 @@ static bool fetch_stage(vmd_script_eval_t* e, Stage& st, vmd_trajectory_i* traj,
     }
     if (!st.d_boxes.upload(st.h_boxes.data(), nb * 9, e->copy_stream)) return false;
     HIP_OK(hipEventRecord(st.ready, e->copy_stream));
+    if (view && view->cells_version != 0) { st.boxes_cells = view->cells; st.boxes_f0 = f0; st.boxes_nb = nb; st.boxes_version = view->cells_version; }
     return true;
 }
 
@@ -1821,6 +1835,7 @@ struct vmd_devtraj_t {
     float* frame(size_t f) const { return (d0 && f == 0) ? d0 : d + (f - first) * 3 * npad; }
     int device = 0;
     std::vector<vmd_unitcell_t> cells;
+    uint64_t cells_version = 1;         // bumped by every change of `cells` (vmd_device_view_t::cells_version)
     vmd_trajectory_i iface;
 };
 
@@ -1842,6 +1857,7 @@ static bool dt_device_view(void* inst, vmd_device_view_t* out) {
     // used with resident frame indices (the evaluator is handed ranges inside the shard)
     out->base = t->d - t->first * 3 * t->npad; out->frame_stride = 3 * t->npad; out->row_stride = t->npad; out->cells = t->cells.data(); out->device = t->device;
     out->resident_beg = t->first; out->resident_end = t->first + t->resident;
+    out->cells_version = t->cells_version;
     return true;
 }
 
@@ -1882,6 +1898,7 @@ extern "C" bool vmd_devtraj_upload_frame(vmd_devtraj_t* t, size_t frame, const v
     HIP_OK(hipMemcpy(f + t->npad, y, t->num_atoms * sizeof(float), hipMemcpyHostToDevice));
     HIP_OK(hipMemcpy(f + 2 * t->npad, z, t->num_atoms * sizeof(float), hipMemcpyHostToDevice));
     if (cell) t->cells[frame] = *cell;
+    t->cells_version += 1;
     return true;
 }
 
@@ -1893,6 +1910,7 @@ extern "C" bool vmd_devtraj_upload_atoms(vmd_devtraj_t* t, size_t frame_beg, siz
             HIP_OK(hipMemcpyAsync(t->frame(frame_beg + f) + (size_t)c * t->npad + first_atom,
                                   xyz + (f * 3 + c) * atom_count, atom_count * sizeof(float), hipMemcpyHostToDevice, nullptr));
     HIP_OK(hipDeviceSynchronize());
+    t->cells_version += 1;       // coordinates changed: bounding boxes cached per range (open axes) are stale too
     return true;
 }
 
@@ -1913,12 +1931,14 @@ extern "C" bool vmd_devtraj_synth(vmd_devtraj_t* t, uint64_t seed, float L, floa
     }
     HIP_OK(hipDeviceSynchronize());
     for (size_t f = frame_beg; f < frame_end; ++f) t->cells[f] = c;
+    t->cells_version += 1;
     return true;
 }
 
 extern "C" bool vmd_devtraj_set_cell(vmd_devtraj_t* t, size_t frame_beg, size_t frame_end, const vmd_unitcell_t* cell) {
     if (!t || !cell || frame_end > t->num_frames || frame_beg > frame_end) return vmd_fail("vmd_devtraj_set_cell: bad frame range");
     for (size_t f = frame_beg; f < frame_end; ++f) t->cells[f] = *cell;
+    t->cells_version += 1;
     return true;
 }
 
