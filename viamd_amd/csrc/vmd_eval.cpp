@@ -75,7 +75,7 @@ struct Options {
     std::atomic<int> batch_frames{0};    // 0 = auto
     std::atomic<int> force_brute{0};
     std::atomic<int> load_threads{0};    // host threads decoding one staged batch through load_frame; 0 = auto (see load_threads())
-    std::atomic<int> nxf_divisor{8};     // fine x cell = rmax / nxf_divisor
+    std::atomic<int> nxf_divisor{16};    // fine x cell = rmax / nxf_divisor (8 / 12 / 16 / 24 / 32 measured: 16 is +0.8 % on c3, profiles/r02l_ab_fine_cells.txt)
     std::atomic<int> cells_aos{1};       // sort through 16-byte records + repack
     std::atomic<int> xtc_device_decode{0};   // frames offered raw (load_raw) are decompressed on the device: 1 = one thread per
                                              // frame (k_xtc_decode), 2 = index pass + one thread per chunk (k_xtc_index / k_xtc_chunks)
