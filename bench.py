@@ -233,7 +233,7 @@ def run_workload(name, args, ctx, steps, warmup, frames=None, with_cpu=False, op
     elapsed = time.perf_counter() - t0
     lib.vmd_profile_enable(False)
     if dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -359,7 +359,12 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        # VIAMD_BENCH_BACKEND=gloo: the CPU dry run of this file's N > 1 logic on the emulator build (tests/test_bench_dryrun.py)
+        backend = os.environ.get("VIAMD_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     ctx = dict(V=V, lib=lib, script=script, synth=synth, reduce_eval=reduce_eval, dist=dist, world=world, rank=rank)
 
     w = WORKLOADS[args.workload]
