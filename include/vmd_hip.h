@@ -89,6 +89,9 @@ int vmd_hip_cells_build_pencil(void* stream, const float* xyz, size_t frame_stri
 int vmd_hip_rdf_num_blocks(void);
 int vmd_hip_set_rdf_nsub(int n);       /* tuning knob: work items per pencil (1..64, 0 = automatic), returns the previous value */
 int vmd_hip_set_rdf_shared_hist(int on); /* A-B switch: one LDS histogram per block instead of one per wave, returns the previous value */
+void vmd_hip_set_pencil_reach(int ry, int rz); /* A-B switch: neighbour reach of the pencil walk in y / z (1 = pencils of cross-section >= rmax,
+                                                 * 2 = split pencils >= rmax/2: 5 instead of 3 neighbours on that axis, x windows shrunk for the
+                                                 * outer ones); process-wide, the grid passed to the cell build and to the walk must be cut to match */
 int vmd_hip_set_rdf_blocks(int n);     /* tuning knob: persistent grid size (8..2048), returns the previous value */
 size_t vmd_hip_rdf_partial_words(void);
 int vmd_hip_rdf_pencil(void* stream, const float* sorted_ref, const uint32_t* cell_start_ref, int nref, int nref_pad,

@@ -75,6 +75,7 @@ struct Options {
     std::atomic<int> batch_frames{0};    // 0 = auto
     std::atomic<int> force_brute{0};
     std::atomic<int> load_threads{0};    // host threads decoding one staged batch through load_frame; 0 = auto (see load_threads())
+    std::atomic<int> pencil_split_y{1}, pencil_split_z{1};   // A/B: pencils of cross-section rmax/split (walk reach = split); 1 x 1 measured best (profiles/r02m_ab_tile_shape.txt)
     std::atomic<int> nxf_divisor{16};    // fine x cell = rmax / nxf_divisor (8 / 12 / 16 / 24 / 32 measured: 16 is +0.8 % on c3, profiles/r02l_ab_fine_cells.txt)
     std::atomic<int> cells_aos{1};       // sort through 16-byte records + repack
     std::atomic<int> xtc_device_decode{0};   // frames offered raw (load_raw) are decompressed on the device: 1 = one thread per
@@ -102,6 +103,8 @@ extern "C" int vmd_set_option(const char* key, int value) {
     else if (!strcmp(key, "force_brute")) o = &g_opt.force_brute;
     else if (!strcmp(key, "load_threads")) o = &g_opt.load_threads;
     else if (!strcmp(key, "nxf_divisor")) o = &g_opt.nxf_divisor;
+    else if (!strcmp(key, "pencil_split_y")) o = &g_opt.pencil_split_y;
+    else if (!strcmp(key, "pencil_split_z")) o = &g_opt.pencil_split_z;
     else if (!strcmp(key, "cells_aos")) o = &g_opt.cells_aos;
     else if (!strcmp(key, "sdf_dense")) o = &g_opt.sdf_dense;
     else if (!strcmp(key, "xtc_device_decode")) o = &g_opt.xtc_device_decode;
@@ -1307,12 +1310,15 @@ static bool choose_grid(const std::vector<float>& boxes, uint32_t pbc, size_t nb
     // periodic axes: the minimum image must be unique for every hit (rmax < w/2 with margin); open axes: no restriction
     for (int a = 0; a < 3; ++a) if ((pbc & (1u << a)) && !(rmax * 2.0f * 1.001f < wmin[a])) return false;
     int n[3];
+    const int split[3] = {1, std::max(1, std::min(4, g_opt.pencil_split_y.load())), std::max(1, std::min(4, g_opt.pencil_split_z.load()))};
+    vmd_hip_set_pencil_reach(split[1], split[2]);
     for (int a = 1; a < 3; ++a) {
-        int k = (int)std::floor(wmin[a] / rmax);
+        const float redge = rmax / (float)split[a];
+        int k = (int)std::floor(wmin[a] / redge);
         // head room between the pencil edge and rmax: wrapped coordinates are exact to ~1e-6 of the edge; on an open axis
         // coordinates keep their raw magnitude (possibly far from the origin), so leave ten times more
         const float edge_margin = (pbc & (1u << a)) ? 0.9999f : 0.999f;
-        while (k > 1 && ((float)k / wmin[a]) * rmax > edge_margin) k -= 1;
+        while (k > 1 && ((float)k / wmin[a]) * redge > edge_margin) k -= 1;
         if (pbc & (1u << a)) { if (k < 2) return false; }
         else k = std::max(k, 1);
         n[a] = std::min(k, 1024);

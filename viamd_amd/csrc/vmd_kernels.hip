@@ -679,6 +679,7 @@ struct vmd_pair_params_t {
     int nsub;                // work items per pencil (i-chunks are dealt round-robin to the items)
     uint32_t pbc;            // bits 0..2: periodic axes (an open axis spans the batch's bounding box: boxes slots 6..8 = origin)
     const uint32_t* skip;    // device flag or NULL: non-zero = the sorted copies are incomplete (a bucket of the cell build overflowed), do nothing
+    int ry, rz;              // neighbour reach in pencils per axis: 1 (cross-section >= rmax), 2 = split pencils (cross-section >= rmax/2)
 };
 #define VMD_COUNTER_STRIDE 32    // one 128-byte line per queue counter
 
@@ -1387,11 +1388,11 @@ __global__ __launch_bounds__(256) VMD_SGPR_CAP(96) void k_rdf_pencil(vmd_pair_pa
             const float xlo = vmd_uniform(vmd_wave_min(valid ? xi : 3.0e38f));
             const float xhi = vmd_uniform(vmd_wave_max(valid ? xi : -3.0e38f));
 
-            for (int dz = SAME ? 0 : -1; dz <= 1; ++dz) {
+            for (int dz = SAME ? 0 : -p.rz; dz <= p.rz; ++dz) {
                 int qz = pz + dz; float sz = 0.0f, nc = 0.0f;
                 if (open_z && (qz < 0 || qz >= nz)) continue;       // nothing beyond the bounding box
                 if (qz < 0) { qz += nz; sz = -Lz; nc = -1.0f; } else if (qz >= nz) { qz -= nz; sz = Lz; nc = 1.0f; }
-                for (int dy = -1; dy <= 1; ++dy) {
+                for (int dy = -p.ry; dy <= p.ry; ++dy) {
                     if (SAME && dz == 0 && dy < 0) continue;
                     int qy = py + dy; float sy = 0.0f, nb = 0.0f;
                     if (open_y && (qy < 0 || qy >= ny)) continue;
@@ -1399,6 +1400,16 @@ __global__ __launch_bounds__(256) VMD_SGPR_CAP(96) void k_rdf_pencil(vmd_pair_pa
                     const bool own = SAME && dz == 0 && dy == 0;
                     const int q = qz * ny + qy;
                     float offmin = 0.0f, offmax = 0.0f;
+                    // split pencils: a neighbour two pencils away is at least one pencil width off in that axis, so its x window shrinks
+                    // (orthorhombic periodic cells only; the widths of the other cell kinds are not the box edge over the count)
+                    float rpad = p.rpad;
+                    if (CELL == 0 && (dy > 1 || dy < -1 || dz > 1 || dz < -1)) {
+                        const float gy = (float)((dy < 0 ? -dy : dy) - 1) * (Ly / (float)ny), gz = (float)((dz < 0 ? -dz : dz) - 1) * (Lz / (float)nz);
+                        const float gyy = gy > 0.0f ? gy : 0.0f, gzz = gz > 0.0f ? gz : 0.0f;
+                        const float rr = p.rpad * p.rpad - 0.998f * (gyy * gyy + gzz * gzz);
+                        if (rr <= 0.0f) continue;
+                        rpad = sqrtf(rr) * 1.0001f;
+                    }
                     if (TRI) {
                         // range of xy*s_y + xz*s_z over the cross-section of pencil q (+ head room for the roundings)
                         const float y0 = txy * ((float)qy / (float)ny), y1 = txy * ((float)(qy + 1) / (float)ny);
@@ -1410,8 +1421,8 @@ __global__ __launch_bounds__(256) VMD_SGPR_CAP(96) void k_rdf_pencil(vmd_pair_pa
                         if (open_x && kx != 0) continue;
                         float sx = (float)kx * Lx;
                         if (TRI) vmd_lattice_shift(Lx, Ly, Lz, txy, txz, tyz, (float)kx, nb, nc, sx, sy, sz);
-                        const float lo = (xlo - p.rpad) - sx - offmax - orgx - pad_open;
-                        const float hi = (xhi + p.rpad) - sx - offmin - orgx + pad_open;
+                        const float lo = (xlo - rpad) - sx - offmax - orgx - pad_open;
+                        const float hi = (xhi + rpad) - sx - offmin - orgx + pad_open;
                         if (hi < 0.0f || lo >= Lx) continue;
                         const int ca = lo <= 0.0f ? 0 : vmd_cell_coord(lo, inv_cx, nxf);
                         const int cb = hi >= Lx ? nxf - 1 : vmd_cell_coord(hi, inv_cx, nxf);
@@ -2154,6 +2165,8 @@ static int g_rdf_nsub = 0;   // 0 = automatic: about one i-chunk per item
 extern "C" int vmd_hip_set_rdf_nsub(int n) { const int old = g_rdf_nsub; if (n >= 0 && n <= 64) g_rdf_nsub = n; return old; }
 static int g_rdf_shist = 0;       // one LDS histogram per block instead of one per wave (8 instead of 7 waves per SIMD)
 extern "C" int vmd_hip_set_rdf_shared_hist(int on) { const int old = g_rdf_shist; g_rdf_shist = on ? 1 : 0; return old; }
+static int g_pen_ry = 1, g_pen_rz = 1;   // neighbour reach of the pencil walk; the grid handed to the build and to the walk must be cut to match
+extern "C" void vmd_hip_set_pencil_reach(int ry, int rz) { g_pen_ry = ry < 1 ? 1 : (ry > 4 ? 4 : ry); g_pen_rz = rz < 1 ? 1 : (rz > 4 ? 4 : rz); }
 static int g_rdf_blocks = 2048;   // 8 blocks x 4 waves per CU requested; 6 fit (SGPR budget)
 extern "C" int vmd_hip_rdf_num_blocks(void) { return 2048; }   // capacity of the partial-row scratch
 extern "C" int vmd_hip_set_rdf_blocks(int n) { const int old = g_rdf_blocks; if (n >= 8 && n <= 2048) g_rdf_blocks = n; return old; }
@@ -2201,6 +2214,7 @@ extern "C" int vmd_hip_rdf_pencil(void* stream, const float* sorted_ref, const u
     const dim3 g(nblocks), blk(256);
     p.pbc = pbc_flags;
     p.skip = skip_flag;
+    p.ry = g_pen_ry; p.rz = g_pen_rz;
     const int cell = (pbc_flags & VMD_PBC_TRICLINIC) ? 1 : ((pbc_flags & 7u) != 7u ? 2 : 0);
     const int which = (variant == 1 ? 6 : variant == 2 ? 12 : 0) + (same_set ? 3 : 0) + cell;
 #define VMD_PENCIL_CASE(n, V, S, C) case n: if (g_rdf_shist) hipLaunchKernelGGL((k_rdf_pencil<V, S, C, true>), g, blk, 0, s, p); \
