@@ -197,6 +197,10 @@ typedef struct vmd_script_property_data_t {
      * Distributions keep it current; for volumes (17 MB) call vmd_eval_refresh_counts before reading it. */
     const uint64_t* counts;
     const double*   weights64;
+    /* md_script_property_data_t::unit[2] (x, y; src/main.cpp:1300-1301) as the strings VIAMD prints them into with md_unit_print
+     * (src/main.cpp:1314-1315): "Å" (UTF-8) for a length, "" for none.  rdf: {"Å", ""}, sdf: {"", ""}, distance*: {"", "Å"}
+     * (x of a temporal property is the frame axis; VIAMD labels it with the trajectory's time unit itself).  Static strings. */
+    const char* unit_str[2];
 } vmd_script_property_data_t;
 
 /* md_script_eval_create(num_frames, ir, alloc), src/main.cpp:971 */

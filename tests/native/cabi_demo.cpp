@@ -5,6 +5,7 @@
 //
 // Prints one line "OK frames=<F> hits=<sum of counts> polls=<n> fingerprint_changes=<n>" and exits 0 on success.
 #include <atomic>
+#include <cstring>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -41,6 +42,8 @@ int main(int argc, char** argv) {
     const vmd_script_property_data_t* pd = vmd_eval_property_data(eval, "r");      // fetched once, like init_display_properties
     const vmd_script_property_data_t* pdd = vmd_eval_property_data(eval, "d");
     if (!pd || !pdd || pd->dim[2] != VMD_RDF_NUM_BINS || pdd->dim[0] != (int)F) fail("property_data");
+    // unit[0] / unit[1] as printed by VIAMD (src/main.cpp:1300-1315): a distribution over a length, a length over frames
+    if (strcmp(pd->unit_str[0], "\xC3\x85") || strcmp(pd->unit_str[1], "") || strcmp(pdd->unit_str[0], "") || strcmp(pdd->unit_str[1], "\xC3\x85")) fail("unit strings");
 
     vmd_system_t sys = {};
     sys.atom_count = N;

@@ -241,6 +241,7 @@ def test_result_views_keep_their_eval_alive(emu_lib, oracle):
         ev = V.ScriptEval(2, ir)
         assert ev.frame_range(V.MolSystem(600, unitcell=V.make_unitcell(30.0)), V.HostTrajectory(coords, V.make_unitcell(30.0)), 0, 2)
         pd = ev.property_data("g")
+        assert pd.unit_str == ("\u00c5", "")                              # md_script_property_data_t::unit as VIAMD prints it
         return pd.counts, pd.values[:10], ev.frame_mask(), pd.counts.copy()
 
     c, v, m, ref = views()

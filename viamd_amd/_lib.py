@@ -82,7 +82,7 @@ class PropertyData(C.Structure):
     _fields_ = [("dim", C.c_int32 * 4), ("values", c_float_p), ("weights", c_float_p), ("num_values", C.c_size_t),
                 ("aggregate", C.POINTER(Aggregate)), ("min_value", C.c_float), ("max_value", C.c_float),
                 ("min_range", C.c_float * 2), ("max_range", C.c_float * 2), ("fingerprint", C.c_uint64),
-                ("counts", c_uint64_p), ("weights64", c_double_p)]
+                ("counts", c_uint64_p), ("weights64", c_double_p), ("unit_str", C.c_char_p * 2)]
 
 
 class AccumView(C.Structure):
@@ -210,6 +210,7 @@ SIGNATURES = [
     ("vmd_hip_rdf_num_blocks", C.c_int, []),
     ("vmd_hip_set_rdf_blocks", C.c_int, [C.c_int]),
     ("vmd_hip_set_rdf_shared_hist", C.c_int, [C.c_int]),
+    ("vmd_hip_set_pencil_reach", None, [C.c_int, C.c_int]),
     ("vmd_hip_set_rdf_nsub", C.c_int, [C.c_int]),
     ("vmd_hip_cells_split_blocks", C.c_int, [Grid, C.c_int]),
     ("vmd_hip_set_cells_split", C.c_int, [C.c_int]),

@@ -665,6 +665,7 @@ extern "C" vmd_script_eval_t* vmd_eval_create(size_t num_frames, const vmd_scrip
             st->data.weights = st->weights.data();
             st->data.weights64 = st->weights64.data();
             st->data.min_range[0] = p.rmin; st->data.max_range[0] = p.rmax;
+            st->data.unit_str[0] = "\xC3\x85"; st->data.unit_str[1] = "";
             st->same_set = (p.a == p.b);         // selections are interned by build_rdf_plan (own sets, or the classes they split into)
             break;
         case PROP_SDF:
@@ -675,6 +676,7 @@ extern "C" vmd_script_eval_t* vmd_eval_create(size_t num_frames, const vmd_scrip
             st->pinned = st->values.pinned && st->counts.pinned;
             st->data.dim[0] = 1; st->data.dim[1] = st->data.dim[2] = st->data.dim[3] = VMD_VOLUME_DIM;
             st->data.min_range[0] = -p.rmax; st->data.max_range[0] = p.rmax;
+            st->data.unit_str[0] = ""; st->data.unit_str[1] = "";
             break;
         case PROP_DIST:
             st->dist_P = p.aoff.size() - 1;
@@ -682,6 +684,7 @@ extern "C" vmd_script_eval_t* vmd_eval_create(size_t num_frames, const vmd_scrip
             st->dim1 = st->dist_P * st->dist_per;
             st->values.assign(num_frames * st->dim1, 0.0f);
             st->data.dim[0] = (int32_t)num_frames; st->data.dim[1] = (int32_t)st->dim1;
+            st->data.unit_str[0] = ""; st->data.unit_str[1] = "\xC3\x85";
             if (st->dim1 > 1) {
                 st->agg_mean.assign(num_frames, 0.0f); st->agg_var.assign(num_frames, 0.0f); st->agg_ext.assign(num_frames * 2, 0.0f);
                 st->aggregate.num_values = num_frames;

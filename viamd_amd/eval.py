@@ -171,6 +171,11 @@ class PropertyDataView:
         return self._arr(self.c.weights64, self.c.dim[2], np.float64) if self.c.weights64 else None
 
     @property
+    def unit_str(self):
+        """(x unit, y unit) as VIAMD prints md_script_property_data_t::unit (src/main.cpp:1314-1315)"""
+        return tuple((u or b"").decode("utf-8") for u in self.c.unit_str)
+
+    @property
     def min_range(self):
         return tuple(self.c.min_range)
 
