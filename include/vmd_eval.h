@@ -217,6 +217,10 @@ bool vmd_eval_frame_range(vmd_script_eval_t* eval, const vmd_script_ir_t* ir, co
 const vmd_script_property_data_t* vmd_eval_property_data(const vmd_script_eval_t* eval, const char* name);
 /* md_script_eval_frame_mask (src/main.cpp:1513): one byte per frame here, non-zero = evaluated */
 const uint8_t* vmd_eval_frame_mask(const vmd_script_eval_t* eval);
+/* the same mask in the shape of an md_bitfield_t's storage (VIAMD tests it bit by bit, src/main.cpp:194-210): bit (f & 63) of word
+ * f / 64 is set when frame f is evaluated.  Writes min(cap, words) words and returns words = ceil(num_frames / 64); a shim fills its
+ * md_bitfield_t {bits, beg_bit = 0, end_bit = num_frames} from it. */
+size_t   vmd_eval_frame_mask_bits(const vmd_script_eval_t* eval, uint64_t* words, size_t cap);
 size_t   vmd_eval_num_frames(const vmd_script_eval_t* eval);
 size_t   vmd_eval_frames_done(const vmd_script_eval_t* eval);
 

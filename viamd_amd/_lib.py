@@ -136,6 +136,7 @@ SIGNATURES = [
     ("vmd_eval_frame_range", C.c_bool, [_vp, _vp, C.POINTER(System), C.POINTER(TrajectoryI), C.c_uint32, C.c_uint32]),
     ("vmd_eval_property_data", C.POINTER(PropertyData), [_vp, C.c_char_p]),
     ("vmd_eval_frame_mask", c_uint8_p, [_vp]),
+    ("vmd_eval_frame_mask_bits", C.c_size_t, [_vp, c_uint64_p, C.c_size_t]),
     ("vmd_eval_num_frames", C.c_size_t, [_vp]),
     ("vmd_eval_frames_done", C.c_size_t, [_vp]),
     ("vmd_eval_sdf_matrices", C.c_bool, [_vp, C.c_char_p, C.POINTER(System), C.POINTER(TrajectoryI), C.c_uint32, c_float_p,

@@ -794,6 +794,17 @@ extern "C" const vmd_script_property_data_t* vmd_eval_property_data(const vmd_sc
     return p ? &p->data : nullptr;
 }
 extern "C" const uint8_t* vmd_eval_frame_mask(const vmd_script_eval_t* eval) { return eval ? eval->frame_mask.data() : nullptr; }
+extern "C" size_t vmd_eval_frame_mask_bits(const vmd_script_eval_t* eval, uint64_t* words, size_t cap) {
+    if (!eval) return 0;
+    const size_t nw = (eval->num_frames + 63) / 64;
+    for (size_t w = 0; w < nw && w < cap && words; ++w) {
+        uint64_t v = 0;
+        const size_t f1 = std::min(eval->num_frames, (w + 1) * 64);
+        for (size_t f = w * 64; f < f1; ++f) if (eval->frame_mask[f]) v |= 1ull << (f & 63);
+        words[w] = v;
+    }
+    return nw;
+}
 extern "C" size_t vmd_eval_num_frames(const vmd_script_eval_t* eval) { return eval ? eval->num_frames : 0; }
 extern "C" size_t vmd_eval_frames_done(const vmd_script_eval_t* eval) { return eval ? eval->frames_done.load() : 0; }
 

@@ -290,6 +290,13 @@ class ScriptEval:
         m._owner = self
         return m
 
+    def frame_mask_bits(self):
+        """the mask as md_bitfield_t storage: uint64 words, bit f & 63 of word f // 64"""
+        nw = int(self.lib.vmd_eval_frame_mask_bits(self.h, None, 0))
+        w = np.zeros(nw, np.uint64)
+        self.lib.vmd_eval_frame_mask_bits(self.h, w.ctypes.data_as(L.c_uint64_p), nw)
+        return w
+
     def set_frame_mask(self, mask):
         m = np.ascontiguousarray(mask, dtype=np.uint8)
         self.lib.vmd_eval_set_frame_mask(self.h, m.ctypes.data_as(L.c_uint8_p), m.size)
