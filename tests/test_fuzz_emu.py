@@ -9,12 +9,13 @@ import cases
 from viamd_amd import _lib as L
 
 
-def scenario(seed):
+def scenario(seed, scale=1):
+    """scale > 1 (the GPU twin, tests/test_fuzz_gpu.py): scale x the atoms in a cell scale^(1/3) x as wide (the same density)"""
     rng = np.random.default_rng(1000 + seed)
-    n = int(rng.integers(40, 700))
+    n = int(rng.integers(40, 700)) * scale
     F = int(rng.integers(1, 4))
     kind = rng.choice(["ortho", "tri", "partial", "open"], p=[0.4, 0.25, 0.2, 0.15])
-    Ls = rng.uniform(16.0, 60.0, 3)
+    Ls = rng.uniform(16.0, 60.0, 3) * float(scale) ** (1.0 / 3.0)
     flags = L.PBC_ALL
     if kind == "partial":
         flags = int(rng.choice([1, 2, 3, 4, 5, 6]))
@@ -47,12 +48,15 @@ def scenario(seed):
     base = [b for b in base if b.size >= 1]
     wmin = float(min(Ls) * 0.97)
     props = []
-    shared_rmax = float(rng.uniform(3.0, 0.48 * wmin))
+    wmin_cut = wmin / float(scale) ** (1.0 / 3.0) if scale > 1 else wmin      # cutoffs stay at molecular scale when the cell grows
+    shared_rmax = float(rng.uniform(3.0, 0.48 * wmin_cut))
     for i in range(int(rng.integers(1, 4))):
         a = base[int(rng.integers(len(base)))]
         b = a if rng.random() < 0.45 else base[int(rng.integers(len(base)))]
         u = rng.random()
-        rmax = shared_rmax if u < 0.6 else float(rng.uniform(2.0, 0.48 * wmin)) if u < 0.9 else float(rng.uniform(0.5 * wmin, 0.8 * wmin))
+        rmax = shared_rmax if u < 0.6 else float(rng.uniform(2.0, 0.48 * wmin_cut)) if u < 0.9 else float(rng.uniform(0.5 * wmin, 0.8 * wmin))
+        if scale > 1 and u >= 0.9 and n > 6000:
+            rmax = shared_rmax                      # the all-pairs kernel is meant for small systems
         if kind == "tri":
             rmax = min(rmax, 0.3 * wmin)            # the perpendicular widths of a sheared cell are smaller than its edges
         rmin = 0.0 if rng.random() < 0.6 else float(rng.uniform(0.1, 0.6) * rmax)

@@ -57,7 +57,11 @@ Rccl* rccl() {
             r.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
             if (r.handle) break;
         }
-        if (!r.handle) { r.error = std::string("cannot load librccl: ") + (dlerror() ? dlerror() : "?"); return; }
+        if (!r.handle) {
+            const char* why = dlerror();            // one call: dlerror() clears the message it returns
+            r.error = std::string("cannot load librccl: ") + (why ? why : "?");
+            return;
+        }
         auto sym = [&](const char* s) { void* p = dlsym(r.handle, s); if (!p && r.error.empty()) r.error = std::string("librccl lacks ") + s; return p; };
         r.GetUniqueId = (int (*)(NcclUniqueId*))sym("ncclGetUniqueId");
         r.CommInitRank = (int (*)(NcclComm*, int, NcclUniqueId, int))sym("ncclCommInitRank");
