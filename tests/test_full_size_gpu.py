@@ -124,3 +124,81 @@ def test_config5_all_eight_properties_in_one_eval(gpu_lib, oracle):
         dd = info[name]
         ref = cases.oracle_distance(oracle, coords, ocell, topo.mass, np.asarray(dd["a"], np.int32), np.asarray(dd["b"], np.int32), kinds[dd["kind"]])
         np.testing.assert_array_equal(ev.property_data(name).values.reshape(F, -1), ref, err_msg=name)
+
+
+# ---- size-independent properties at the sizes the bench launches (no oracle involved: the GPU path against itself through
+# ---- identities of the domain; the oracle comparisons above cover a few frames of each configuration)
+
+def _rdf_counts(w, traj, topo, ref, tgt, frames, ranges=None, opts=()):
+    lib = V.default_lib()
+    old = [(k, lib.vmd_set_option(k, v)) for k, v in opts]
+    try:
+        ir = V.ScriptIR(lib)
+        ir.add_rdf("g", ref, tgt, (0.0, 12.0))
+        ev = V.ScriptEval(frames, ir)
+        sysm = V.MolSystem(w["atoms"], mass=topo.mass, unitcell=V.make_unitcell(w["box"]))
+        for beg, end in (ranges or [(0, frames)]):
+            assert ev.frame_range(sysm, traj, beg, end)
+        return ev.property_data("g").counts.copy()
+    finally:
+        for k, v in old:
+            lib.vmd_set_option(k, v)
+
+
+def test_config3_linearity_and_symmetry_of_the_pair_histogram(gpu_lib):
+    """1 000 002 atoms: with the heavy atoms H split into disjoint A and B, rdf(H, H) = rdf(A, A) + rdf(B, B) + 2 rdf(A, B) and
+    rdf(A, B) = rdf(B, A) - the same-set half-shell walk, the two-set full-shell walk and both lane assignments against each other."""
+    w = bench.WORKLOADS["c3"]
+    F = 2
+    traj = synth.make_device_trajectory(V, w["seed"], w["atoms"], w["box"], F, w["blob"])
+    topo = synth.water_box_topology(w["atoms"], w["blob"])
+    heavy = np.arange(0, w["atoms"], 3, dtype=np.int32)
+    rng = np.random.default_rng(11)
+    pick = rng.random(heavy.size) < 0.37                     # uneven split: A is the sparser set
+    A, B = heavy[pick], heavy[~pick]
+    hh = _rdf_counts(w, traj, topo, heavy, heavy, F)
+    aa = _rdf_counts(w, traj, topo, A, A, F)
+    bb = _rdf_counts(w, traj, topo, B, B, F)
+    ab = _rdf_counts(w, traj, topo, A, B, F)
+    ba = _rdf_counts(w, traj, topo, B, A, F)
+    np.testing.assert_array_equal(ab, ba)
+    np.testing.assert_array_equal(hh, aa + bb + ab + ba)
+    assert (hh % 2 == 0).all() and 7.9e7 * F < hh.sum() < 8.2e7 * F
+    # the brute-force kernel family on a subset small enough for it: the same identity across kernel families
+    a_small, b_small = A[:20000], B[:30000]
+    grid = _rdf_counts(w, traj, topo, a_small, b_small, F)
+    brute = _rdf_counts(w, traj, topo, a_small, b_small, F, opts=[(b"force_brute", 1)])
+    np.testing.assert_array_equal(grid, brute)
+
+
+def test_config3_and_config4_any_frame_partition_gives_the_same_accumulators(gpu_lib):
+    """any sharding of the frames -> identical u64 counts.  c3 at 200 frames in one batch / in ragged ranges with
+    37-frame batches / in reverse block order; c4 at 4 000 frames likewise (volumes)."""
+    lib = V.default_lib()
+    w = bench.WORKLOADS["c3"]
+    F = 200
+    ev1, info, topo, traj = _evaluate(w, F)
+    ref = ev1.property_data("g").counts.copy()
+    old = lib.vmd_set_option(b"batch_frames", 37)
+    try:
+        ev2, _, _, _ = _evaluate(w, F, ranges=[(150, 200), (0, 1), (1, 64), (64, 150)])
+    finally:
+        lib.vmd_set_option(b"batch_frames", old)
+    np.testing.assert_array_equal(ev2.property_data("g").counts, ref)
+    np.testing.assert_allclose(ev2.property_data("g").weights64, ev1.property_data("g").weights64, rtol=1e-12)
+    del ev1, ev2, traj
+    w = bench.WORKLOADS["c4"]
+    F = 4000
+    ev1, info, topo, traj = _evaluate(w, F)
+    name = [n for n, d in info.items() if d["kind"] == "sdf"][0]
+    ref = ev1.property_data(name).counts.copy()
+    assert ref.sum() > 0
+    old = lib.vmd_set_option(b"batch_frames", 333)
+    try:
+        ev2, _, _, _ = _evaluate(w, F, ranges=[(3000, 4000), (0, 7), (7, 3000)])
+    finally:
+        lib.vmd_set_option(b"batch_frames", old)
+    np.testing.assert_array_equal(ev2.property_data(name).counts, ref)
+    for n, d in info.items():
+        if d["kind"].startswith("distance"):
+            np.testing.assert_array_equal(ev2.property_data(n).values, ev1.property_data(n).values)
