@@ -326,7 +326,7 @@ def main():
     ap.add_argument("--frames", type=int, default=None, help="frames per GPU (weak) / in total (strong); default: per workload")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: every rank owns `frames` frames of its own; strong: the workload's frames are block-sharded over the ranks")
-    ap.add_argument("--variant", type=int, default=0, help="pair-kernel hit compaction: 0 = per column (default), 1 = bin in place, 2 = pair entries (A/B)")
+    ap.add_argument("--variant", type=int, default=0, help="pair-kernel hit compaction: 0 = per column (default), 1 = bin in place, 2 = pair entries, 3 = 0 behind a bounding-box test of the j windows (A/B)")
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short c2 / c4 / c5 runs of the default N = 1 line")

@@ -81,8 +81,9 @@ int vmd_hip_cells_build_pencil(void* stream, const float* xyz, size_t frame_stri
 /* K2: RDF pair histogram over a batch from cell-sorted selections (ref may equal tgt -> half shell).
  *   partial   u64[vmd_hip_rdf_partial_words()] scratch (per-wave rows + the work counter)
  *   counts    u64[nbins]  accumulated (+=) with device atomics
- *   variant   0 = wave queue (one compaction per candidate column), 1 = inline hit path, 2 = wave queue with pair entries (two
- *             columns share one compaction; the default of the evaluator)
+ *   variant   0 = wave queue (one compaction per candidate column; the default of the evaluator), 1 = inline hit path,
+ *             2 = wave queue with pair entries (two columns share one compaction), 3 = 0 behind a bounding-box test of the j
+ *             windows; 2 and 3 are measured A/B options (slower), all four give identical counts
  *   pbc_flags as for vmd_hip_cells_build (the same boxes and flags the selections were sorted with).  Triclinic: boxes
  *             carry tilt factors, cells live in the unsheared coordinates s_k * L_k (SPEC S3t) and the grid edge must be
  *             >= rmax measured perpendicular to the cell faces.  Open axes: no images, neighbours end at the bounding box. */

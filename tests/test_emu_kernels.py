@@ -41,10 +41,11 @@ def test_rdf_inline_variant_matches(emu_lib, oracle, box3k):
     cases.check_rdf(emu_lib, oracle, box3k[:1], 60.0, [("goo", o, o, 0.0, 12.0)], variant=1)
 
 
-@pytest.mark.parametrize("variant,shist", [(0, 0), (2, 0), (0, 1)])
+@pytest.mark.parametrize("variant,shist", [(0, 0), (2, 0), (0, 1), (3, 0)])
 def test_rdf_hit_compaction_variants(emu_lib, oracle, box3k, variant, shist):
     """variant 0: one compaction per candidate column; variant 2: pair entries (two columns share one compaction, the partner that
-    is no hit is dropped by the binning) - same sets, ranges with r_min > 0, own-pencil half shell, edge cases, triclinic and open cells"""
+    is no hit is dropped by the binning); variant 3: variant 0 behind a bounding-box test of the j windows - same sets, ranges with
+    r_min > 0, own-pencil half shell, edge cases, triclinic and open cells"""
     o, h = cases.oxygen(3000), cases.hydrogen(3000)
     old = emu_lib.vmd_set_option(b"rdf_variant", variant)
     old_sh = emu_lib.vmd_set_option(b"rdf_shared_hist", shist)      # one LDS histogram per block instead of one per wave
@@ -53,6 +54,8 @@ def test_rdf_hit_compaction_variants(emu_lib, oracle, box3k, variant, shist):
                                                           ("shell", o, o, 11.5, 12.0)], variant=variant)
         cases.rdf_edge_cases(emu_lib, oracle)
         cases.triclinic_cases(emu_lib, oracle, 600)
+        if variant == 3:
+            cases.open_boundary_cases(emu_lib, oracle, 600)       # incl. a system kilo-Angstroms from the origin (reach of the box test)
     finally:
         emu_lib.vmd_set_option(b"rdf_variant", old)
         emu_lib.vmd_set_option(b"rdf_shared_hist", old_sh)

@@ -67,7 +67,7 @@ def scenario(seed, scale=1):
     if rng.random() < 0.2:
         opts["rdf_classes"] = 0
     if rng.random() < 0.2:
-        opts["rdf_variant"] = int(rng.choice([1, 2]))
+        opts["rdf_variant"] = int(rng.choice([1, 2, 3]))
     if rng.random() < 0.15:
         opts["pencil_split_y"] = 2
     if rng.random() < 0.2:

@@ -48,7 +48,7 @@ def test_coevaluated_rdfs_share_pair_passes(gpu_lib, oracle):
     cases.class_decomposition_cases(gpu_lib, oracle, device=True, n_water=30000, box=70.0)
 
 
-@pytest.mark.parametrize("variant,shist", [(0, 0), (2, 0), (0, 1)])
+@pytest.mark.parametrize("variant,shist", [(0, 0), (2, 0), (0, 1), (3, 0)])
 def test_rdf_hit_compaction_variants(gpu_lib, oracle, box30k, variant, shist):
     """variant 0: one compaction per candidate column; variant 2: pair entries (two columns share one compaction; hand-scheduled
     push / pop of their own) - same / different sets, r_min > 0, a thin shell at the cutoff, edge cases, triclinic and open cells,

@@ -1268,6 +1268,114 @@ __device__ __forceinline__ void vmd_segment_loop(const vmd_pair_params_t& p, vmd
     vmd_drain_full<VARIANT, INC>(p.bin, w, lane);
 }
 
+// VARIANT 3 (A/B): the j atoms of a segment are first tested, 64 at a time (one per lane), against the bounding box of the wave's
+// i atoms; only those within reach of the box become candidate columns.  The segment's window is the box-shaped dilation of the
+// chunk (whole neighbour pencils x an x range); ~30 % of its atoms are farther than r from every point of the chunk's box (the corners
+// of the diagonal pencils, the ends of the x range) and would be columns without a single hit.  Survivors are taken off the ballot
+// mask four at a time (s_ff1 / s_bitset0), their coordinates come through scalar loads as before, and the same packed filter and
+// push run on them; a short last group is padded with far-away columns.  Conservative by construction: the box distance is a lower
+// bound of every lane's distance, compared against the padded cutoff - results are bit-identical.
+// Measured (profiles/r02r_ab_variant3.txt): 31 % fewer columns, but c3 runs at 8.1k instead of 12.5k frames/s: the bit scan and the
+// per-survivor addressing cost ~9 SALU instructions per column on top of the push's 5, and an SALU instruction takes the same
+// 4.2-cycle issue slot of the SIMD as the slow VALU classes (profiles/r02_valu_calibration.txt) - the loop turns SALU-issue bound;
+// twelve one-dword scalar requests per group instead of three 16-byte ones do the rest.  Kept as a checked option, off.
+struct vmd_bbox_t { float lox, hix, loy, hiy, loz, hiz, rp2; };
+
+// lowest set bit of a wave-uniform mask (-1 when empty) / clear bit k (k & 63) - one SALU instruction each
+#ifndef VMD_NO_INLINE_ASM
+__device__ __forceinline__ int vmd_sff1(unsigned long long m) { int k; asm("s_ff1_i32_b64 %0, %1" : "=s"(k) : "s"(m)); return k; }
+__device__ __forceinline__ unsigned long long vmd_sbitclr(unsigned long long m, int k) { asm("s_bitset0_b64 %0, %1" : "+s"(m) : "s"(k)); return m; }
+#else
+__device__ __forceinline__ int vmd_sff1(unsigned long long m) { return m ? __builtin_ctzll(m) : -1; }
+__device__ __forceinline__ unsigned long long vmd_sbitclr(unsigned long long m, int k) { return m & ~(1ull << (k & 63)); }
+#endif
+// one wave-uniform float at byte offset `off` (s_load_dword sdst, sbase, soffset)
+__device__ __forceinline__ float vmd_uniform_load1(vmd_cf32* base, unsigned off) {
+    return *(VMD_UNIFORM_AS const float*)((VMD_UNIFORM_AS const char*)base + off);
+}
+
+template <int VARIANT, unsigned INC, bool SHIFT>
+__device__ __forceinline__ void vmd_segment_pruned(const vmd_pair_params_t& p, vmd_wave_acc_t& w, vmd_cf32* tx, vmd_cf32* ty, vmd_cf32* tz,
+                                                   unsigned ja, unsigned jb, float sx, float sy, float sz,
+                                                   float xi, float yi, float zi, const vmd_bbox_t& bb, int lane) {
+    const float r2 = p.r2_up;
+    const vmd_f2 xi2 = {xi, xi}, yi2 = {yi, yi}, zi2 = {zi, zi};
+    const vmd_f2 sx2 = {sx, sx}, sy2 = {sy, sy}, sz2 = {sz, sz};
+    // four survivor columns; have < 4: the group is short, the missing columns (which repeat a valid address) are moved out of reach
+    auto group = [&](vmd_f4 xj, const vmd_f4& yj, const vmd_f4& zj, int have) {
+        if (have < 4) {
+            if (have < 2) xj[1] = VMD_FAR;
+            if (have < 3) xj[2] = VMD_FAR;
+            xj[3] = VMD_FAR;
+        }
+        vmd_f2 d2[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const vmd_f2 xj2 = {xj[2 * h], xj[2 * h + 1]}, yj2 = {yj[2 * h], yj[2 * h + 1]}, zj2 = {zj[2 * h], zj[2 * h + 1]};
+            vmd_f2 dx = xi2 - xj2, dy = yi2 - yj2, dz = zi2 - zj2;
+            if (SHIFT) { dx = dx - sx2; dy = dy - sy2; dz = dz - sz2; }
+            d2[h] = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+        }
+#ifndef VMD_NO_INLINE_ASM
+        vmd_push_hot4(w, d2[0][0], d2[0][1], d2[1][0], d2[1][1], r2);
+#else
+#pragma unroll
+        for (int c = 0; c < 4; ++c) vmd_push<VARIANT, INC>(p.bin, w, d2[c >> 1][c & 1] < r2, d2[c >> 1][c & 1]);
+#endif
+        vmd_drain_full<VARIANT, INC>(p.bin, w, lane);
+    };
+    // takes up to four survivors off the mask and issues their scalar loads; returns how many were real
+    auto fetch = [&](unsigned long long& m, vmd_cf32* px, vmd_cf32* py, vmd_cf32* pz, vmd_f4& xj, vmd_f4& yj, vmd_f4& zj) -> int {
+        const int a0 = vmd_sff1(m); m = vmd_sbitclr(m, a0);
+        int a1 = vmd_sff1(m); m = vmd_sbitclr(m, a1);
+        int a2 = vmd_sff1(m); m = vmd_sbitclr(m, a2);
+        int a3 = vmd_sff1(m); m = vmd_sbitclr(m, a3);
+        const int have = 1 + (a1 >= 0) + (a2 >= 0) + (a3 >= 0);
+        a1 = a1 < 0 ? a0 : a1; a2 = a2 < 0 ? a0 : a2; a3 = a3 < 0 ? a0 : a3;
+        const unsigned o0 = 4u * (unsigned)a0, o1 = 4u * (unsigned)a1, o2 = 4u * (unsigned)a2, o3 = 4u * (unsigned)a3;
+        xj = vmd_f4{vmd_uniform_load1(px, o0), vmd_uniform_load1(px, o1), vmd_uniform_load1(px, o2), vmd_uniform_load1(px, o3)};
+        yj = vmd_f4{vmd_uniform_load1(py, o0), vmd_uniform_load1(py, o1), vmd_uniform_load1(py, o2), vmd_uniform_load1(py, o3)};
+        zj = vmd_f4{vmd_uniform_load1(pz, o0), vmd_uniform_load1(pz, o1), vmd_uniform_load1(pz, o2), vmd_uniform_load1(pz, o3)};
+        return have;
+    };
+    // the window after the current one is loaded while the current one is consumed
+    auto load = [&](unsigned w0, float& qx, float& qy, float& qz) {
+        const unsigned j = w0 + (unsigned)lane;
+        const bool valid = j < jb;
+        qx = valid ? tx[j] : VMD_FAR; qy = valid ? ty[j] : VMD_FAR; qz = valid ? tz[j] : VMD_FAR;
+    };
+    float cx, cy, cz;
+    load(ja, cx, cy, cz);
+    for (unsigned w0 = ja; w0 < jb; w0 += VMD_WAVE) {
+        float nx = VMD_FAR, ny = VMD_FAR, nz = VMD_FAR;
+        if (w0 + VMD_WAVE < jb) load(w0 + VMD_WAVE, nx, ny, nz);
+        float qx = cx, qy = cy, qz = cz;
+        if (SHIFT) { qx = qx + sx; qy = qy + sy; qz = qz + sz; }
+        const float ex = fmaxf(fmaxf(bb.lox - qx, qx - bb.hix), 0.0f);
+        const float ey = fmaxf(fmaxf(bb.loy - qy, qy - bb.hiy), 0.0f);
+        const float ez = fmaxf(fmaxf(bb.loz - qz, qz - bb.hiz), 0.0f);
+        unsigned long long m = VMD_BALLOT(vmd_d2(ex, ey, ez) <= bb.rp2);      // padding lanes sit at VMD_FAR: never within reach
+        vmd_cf32* px = tx + w0;
+        vmd_cf32* py = ty + w0;
+        vmd_cf32* pz = tz + w0;
+        if (m) {
+            vmd_f4 xa, ya, za, xb, yb, zb;
+            int ha = fetch(m, px, py, pz, xa, ya, za), hb = 0;
+            for (;;) {
+                const bool more_b = m != 0ull;
+                if (more_b) hb = fetch(m, px, py, pz, xb, yb, zb);
+                group(xa, ya, za, ha);
+                if (!more_b) break;
+                const bool more_a = m != 0ull;
+                if (more_a) ha = fetch(m, px, py, pz, xa, ya, za);
+                group(xb, yb, zb, hb);
+                if (!more_a) break;
+            }
+        }
+        cx = nx; cy = ny; cz = nz;
+    }
+}
+
 template <int VARIANT, unsigned INC, bool MASKED>
 __device__ __forceinline__ void vmd_segment(const vmd_pair_params_t& p, vmd_wave_acc_t& w, vmd_cf32* st,
                                             unsigned ja, unsigned jb, float sx, float sy, float sz,
@@ -1311,9 +1419,11 @@ __device__ __forceinline__ int vmd_next_item(unsigned* counters, int& q, int& tr
 // periodic orthorhombic cell and carries none of this.
 // SHIST: ONE LDS histogram per block (ds_add is atomic across its four waves) instead of one per wave: 10 KB of LDS per block
 // instead of 22.5, so 8 blocks = 8 waves per SIMD fit a CU instead of 7.
-template <int VARIANT, bool SAME, int CELL, bool SHIST>
+template <int VARIANT_, bool SAME, int CELL, bool SHIST>
 __global__ __launch_bounds__(256) VMD_SGPR_CAP(96) void k_rdf_pencil(vmd_pair_params_t p) {
     constexpr bool TRI = CELL == 1, OPEN = CELL == 2;
+    constexpr bool PRUNE = VARIANT_ == 3;            // variant 3 = variant 0 + bounding-box pruning of the j windows
+    constexpr int VARIANT = PRUNE ? 0 : VARIANT_;
     __shared__ unsigned s_hist[SHIST ? 1 : 4][VMD_MAX_BINS];
     __shared__ float s_queue[4][VMD_QUEUE_CAP];
     constexpr unsigned INC = SAME ? 2u : 1u;
@@ -1387,6 +1497,17 @@ __global__ __launch_bounds__(256) VMD_SGPR_CAP(96) void k_rdf_pencil(vmd_pair_pa
             const float zi = valid ? sr[2 * (size_t)p.nref_pad + i] : VMD_FAR;
             const float xlo = vmd_uniform(vmd_wave_min(valid ? xi : 3.0e38f));
             const float xhi = vmd_uniform(vmd_wave_max(valid ? xi : -3.0e38f));
+            vmd_bbox_t bb = {};
+            if (PRUNE) {
+                bb.lox = xlo; bb.hix = xhi;
+                bb.loy = vmd_uniform(vmd_wave_min(valid ? yi : 3.0e38f)); bb.hiy = vmd_uniform(vmd_wave_max(valid ? yi : -3.0e38f));
+                bb.loz = vmd_uniform(vmd_wave_min(valid ? zi : 3.0e38f)); bb.hiz = vmd_uniform(vmd_wave_max(valid ? zi : -3.0e38f));
+                // reach of the box test: the padded cutoff + the rounding of coordinates of this magnitude (images included)
+                const float mag = fmaxf(fmaxf(fmaxf(fabsf(bb.lox), fabsf(bb.hix)), fmaxf(fabsf(bb.loy), fabsf(bb.hiy))), fmaxf(fabsf(bb.loz), fabsf(bb.hiz)))
+                                  + Lx + Ly + Lz + fabsf(txy) + fabsf(txz) + fabsf(tyz);
+                const float rp = p.rpad + 4.0e-6f * mag;
+                bb.rp2 = rp * rp;
+            }
 
             for (int dz = SAME ? 0 : -p.rz; dz <= p.rz; ++dz) {
                 int qz = pz + dz; float sz = 0.0f, nc = 0.0f;
@@ -1441,7 +1562,13 @@ __global__ __launch_bounds__(256) VMD_SGPR_CAP(96) void k_rdf_pencil(vmd_pair_pa
                         }
                         if (ja < jb) {
                             w.ncols += jb - ja;
-                            vmd_segment<VARIANT, INC, false>(p, w, st, ja, jb, sx, sy, sz, xi, yi, zi, i, lane);
+                            if (PRUNE) {
+                                vmd_cf32* tx = st; vmd_cf32* ty = st + p.ntgt_pad; vmd_cf32* tz = st + 2 * (size_t)p.ntgt_pad;
+                                if (sx == 0.0f && sy == 0.0f && sz == 0.0f) vmd_segment_pruned<VARIANT, INC, false>(p, w, tx, ty, tz, ja, jb, sx, sy, sz, xi, yi, zi, bb, lane);
+                                else vmd_segment_pruned<VARIANT, INC, true>(p, w, tx, ty, tz, ja, jb, sx, sy, sz, xi, yi, zi, bb, lane);
+                            } else {
+                                vmd_segment<VARIANT, INC, false>(p, w, st, ja, jb, sx, sy, sz, xi, yi, zi, i, lane);
+                            }
                         }
                     }
                 }
@@ -2216,7 +2343,7 @@ extern "C" int vmd_hip_rdf_pencil(void* stream, const float* sorted_ref, const u
     p.skip = skip_flag;
     p.ry = g_pen_ry; p.rz = g_pen_rz;
     const int cell = (pbc_flags & VMD_PBC_TRICLINIC) ? 1 : ((pbc_flags & 7u) != 7u ? 2 : 0);
-    const int which = (variant == 1 ? 6 : variant == 2 ? 12 : 0) + (same_set ? 3 : 0) + cell;
+    const int which = (variant == 1 ? 6 : variant == 2 ? 12 : variant == 3 ? 18 : 0) + (same_set ? 3 : 0) + cell;
 #define VMD_PENCIL_CASE(n, V, S, C) case n: if (g_rdf_shist) hipLaunchKernelGGL((k_rdf_pencil<V, S, C, true>), g, blk, 0, s, p); \
                                             else hipLaunchKernelGGL((k_rdf_pencil<V, S, C, false>), g, blk, 0, s, p); break;
     switch (which) {
@@ -2226,6 +2353,12 @@ extern "C" int vmd_hip_rdf_pencil(void* stream, const float* sorted_ref, const u
     VMD_PENCIL_CASE(9, 1, true, 0) VMD_PENCIL_CASE(10, 1, true, 1) VMD_PENCIL_CASE(11, 1, true, 2)
     VMD_PENCIL_CASE(12, 2, false, 0) VMD_PENCIL_CASE(13, 2, false, 1) VMD_PENCIL_CASE(14, 2, false, 2)
     VMD_PENCIL_CASE(15, 2, true, 0) VMD_PENCIL_CASE(16, 2, true, 1) VMD_PENCIL_CASE(17, 2, true, 2)
+    case 18: hipLaunchKernelGGL((k_rdf_pencil<3, false, 0, false>), g, blk, 0, s, p); break;
+    case 19: hipLaunchKernelGGL((k_rdf_pencil<3, false, 1, false>), g, blk, 0, s, p); break;
+    case 20: hipLaunchKernelGGL((k_rdf_pencil<3, false, 2, false>), g, blk, 0, s, p); break;
+    case 21: hipLaunchKernelGGL((k_rdf_pencil<3, true, 0, false>), g, blk, 0, s, p); break;
+    case 22: hipLaunchKernelGGL((k_rdf_pencil<3, true, 1, false>), g, blk, 0, s, p); break;
+    case 23: hipLaunchKernelGGL((k_rdf_pencil<3, true, 2, false>), g, blk, 0, s, p); break;
     default: return (int)hipErrorInvalidValue;
     }
 #undef VMD_PENCIL_CASE
