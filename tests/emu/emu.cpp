@@ -6,6 +6,7 @@
 #include <sys/mman.h>
 #include <ucontext.h>
 
+#include <mutex>
 #include <vector>
 
 namespace emu {
@@ -155,7 +156,12 @@ static void run_block(int nthreads) {
 static std::vector<uint64_t> g_dynshm;
 void* dyn_shared() { return g_dynshm.data(); }
 
+// One kernel at a time, process-wide: the fibers, the exchange buffers and the kernels' static __shared__ arrays are globals.  Host
+// threads that drive different evals concurrently (full + filtered evaluation) therefore take turns launch by launch.
+static std::mutex g_launch_mtx;
+
 void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body) {
+    std::lock_guard<std::mutex> launch_lock(g_launch_mtx);
     // the hardware's launch limits (a grid.y above 65535 went unnoticed here and would fail on the GPU)
     if (grid.y > 65535u || grid.z > 65535u || grid.x > 2147483647u || block.x * block.y * block.z > 1024u || shmem > 160u * 1024u ||
         grid.x == 0 || grid.y == 0 || grid.z == 0) {
