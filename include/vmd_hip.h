@@ -90,6 +90,8 @@ int vmd_hip_cells_build_pencil(void* stream, const float* xyz, size_t frame_stri
 int vmd_hip_rdf_num_blocks(void);
 int vmd_hip_set_rdf_nsub(int n);       /* tuning knob: work items per pencil (1..64, 0 = automatic), returns the previous value */
 int vmd_hip_set_rdf_shared_hist(int on); /* A-B switch: one LDS histogram per block instead of one per wave, returns the previous value */
+int vmd_hip_set_cells_rec3(int on);   /* A-B switch: 12-byte bucket records {x, y, z} in the two-level cell build where the fine cell follows
+                                        * from the wrapped x alone (x-periodic, non-triclinic cells); default on; returns the previous value */
 void vmd_hip_set_pencil_reach(int ry, int rz); /* A-B switch: neighbour reach of the pencil walk in y / z (1 = pencils of cross-section >= rmax,
                                                  * 2 = split pencils >= rmax/2: 5 instead of 3 neighbours on that axis, x windows shrunk for the
                                                  * outer ones); process-wide, the grid passed to the cell build and to the walk must be cut to match */

@@ -72,6 +72,8 @@ def scenario(seed, scale=1):
         opts["pencil_split_y"] = 2
     if rng.random() < 0.2:
         opts["batch_frames"] = 1
+    if seed % 5 == 0:
+        opts["cells_rec3"] = 0                      # 16-byte bucket records (no draw from rng: the scenarios stay what they were)
     return coords, box, flags, props, opts, kind
 
 

@@ -516,6 +516,7 @@ struct vmd_bin_params_t {
     float* bucket;                   // [B][pen_off[npen]][4], NULL in counting mode
     uint32_t* overflow;              // [1]
     int npen; int total_cap;
+    int rec3;                        // 1: 12-byte records {x, y, z} (the fine cell follows from x alone: x-periodic, non-triclinic cells)
 };
 #define VMD_BIN_ILP 4          // atoms per thread: 4096-atom slices (8 per thread: measured slower, profiles/r02d_ab.txt)
 __global__ __launch_bounds__(1024) void k_cells_bin(vmd_bin_params_t q) {
@@ -554,8 +555,13 @@ __global__ __launch_bounds__(1024) void k_cells_bin(vmd_bin_params_t q) {
         const uint32_t off = q.pen_off[pen[u]], cap = q.pen_off[pen[u] + 1] - off;
         const uint32_t slot = s_cnt[pen[u]] + rank[u];
         if (slot < cap) {
-            const vmd_f4a v = {xw[u], yw[u], zw[u], __int_as_float((int)cx[u])};
-            *(vmd_f4a*)(bk + 4 * (size_t)(off + slot)) = v;
+            if (q.rec3) {
+                float* r = bk + 3 * (size_t)(off + slot);
+                r[0] = xw[u]; r[1] = yw[u]; r[2] = zw[u];
+            } else {
+                const vmd_f4a v = {xw[u], yw[u], zw[u], __int_as_float((int)cx[u])};
+                *(vmd_f4a*)(bk + 4 * (size_t)(off + slot)) = v;
+            }
         } else {
             *q.overflow = 1u;
         }
@@ -590,6 +596,7 @@ struct vmd_pensort_params_t {
     const float* bucket; const uint32_t* pen_off; const uint32_t* pen_count; const uint32_t* pen_start;
     uint32_t* cell_start; float* sorted;
     int npen, nxf, ncell, nsel_pad, total_cap, cap_max;
+    const float* boxes; int rec3;      // rec3: 12-byte records, the fine cell is recomputed from x exactly as vmd_cell_of computed it
 };
 __global__ __launch_bounds__(256) void k_cells_pen_sort(vmd_pensort_params_t q) {
     HIP_DYNAMIC_SHARED(uint32_t, s_dyn)
@@ -602,10 +609,15 @@ __global__ __launch_bounds__(256) void k_cells_pen_sort(vmd_pensort_params_t q) 
     uint32_t n = q.pen_count[(size_t)b * q.npen + pen];
     n = n < cap ? n : cap;
     const uint32_t start = q.pen_start[(size_t)b * (q.npen + 1) + pen];
-    const float* bk = q.bucket + 4 * ((size_t)b * q.total_cap + off);
+    const int rs = q.rec3 ? 3 : 4;                           // floats per record; a frame's buckets start at the same place either way
+    const float* bk = q.bucket + 4 * (size_t)b * q.total_cap + (size_t)rs * off;
+    const float inv_cx = (float)nxf * q.boxes[(size_t)VMD_BOX_STRIDE * b + 3];
     for (int c = tid; c < nxf; c += 256) s_cnt[c] = 0u;
     __syncthreads();
-    for (uint32_t k = tid; k < n; k += 256) atomicAdd(&s_cnt[(uint32_t)__float_as_int(bk[4 * (size_t)k + 3])], 1u);
+    for (uint32_t k = tid; k < n; k += 256) {
+        const uint32_t c = q.rec3 ? (uint32_t)vmd_cell_coord(bk[3 * (size_t)k], inv_cx, nxf) : (uint32_t)__float_as_int(bk[4 * (size_t)k + 3]);
+        atomicAdd(&s_cnt[c], 1u);
+    }
     __syncthreads();
     // exclusive scan over the fine cells of the pencil
     const int per = (nxf + 255) / 256;
@@ -627,9 +639,17 @@ __global__ __launch_bounds__(256) void k_cells_pen_sort(vmd_pensort_params_t q) 
     __syncthreads();
     float* sx = s_xyz; float* sy = s_xyz + q.cap_max; float* sz = s_xyz + 2 * (size_t)q.cap_max;
     for (uint32_t k = tid; k < n; k += 256) {
-        const vmd_f4a v = *(const vmd_f4a*)(bk + 4 * (size_t)k);
-        const uint32_t pos = atomicAdd(&s_cnt[(uint32_t)__float_as_int(v[3])], 1u);
-        sx[pos] = v[0]; sy[pos] = v[1]; sz[pos] = v[2];
+        float x, y, z; uint32_t c;
+        if (q.rec3) {
+            const float* r = bk + 3 * (size_t)k;
+            x = r[0]; y = r[1]; z = r[2];
+            c = (uint32_t)vmd_cell_coord(x, inv_cx, nxf);
+        } else {
+            const vmd_f4a v = *(const vmd_f4a*)(bk + 4 * (size_t)k);
+            x = v[0]; y = v[1]; z = v[2]; c = (uint32_t)__float_as_int(v[3]);
+        }
+        const uint32_t pos = atomicAdd(&s_cnt[c], 1u);
+        sx[pos] = x; sy[pos] = y; sz[pos] = z;
     }
     __syncthreads();
     float* srt = q.sorted + (size_t)b * 3 * q.nsel_pad + start;
@@ -2506,6 +2526,8 @@ extern "C" int vmd_hip_cells_pencil_count(void* stream, const float* xyz, size_t
     return 0;
 }
 
+static int g_cells_rec3 = 1;      // 12-byte bucket records where the cell kind allows it (A/B switch)
+extern "C" int vmd_hip_set_cells_rec3(int on) { const int old = g_cells_rec3; g_cells_rec3 = on ? 1 : 0; return old; }
 extern "C" int vmd_hip_cells_build_pencil(void* stream, const float* xyz, size_t frame_stride, size_t row_stride, const float* boxes,
                                           uint32_t pbc_flags, int B, const int32_t* sel, int nsel, int nsel_pad, vmd_grid_t grid,
                                           const uint32_t* pen_off, int total_cap, int cap_max, uint32_t* pen_count, uint32_t* pen_start,
@@ -2516,13 +2538,15 @@ extern "C" int vmd_hip_cells_build_pencil(void* stream, const float* xyz, size_t
     if (!vmd_hip_cells_pencil_ok(grid) || cap_max > VMD_PEN_CAP_MAX) return (int)hipErrorInvalidValue;
     hipError_t e = hipMemsetAsync(pen_count, 0, sizeof(uint32_t) * (size_t)B * npen, s);
     if (e != hipSuccess) return (int)e;
+    // x-periodic, non-triclinic cells: the grid bins the wrapped x itself, so the record need not carry the fine cell
+    const int rec3 = (g_cells_rec3 && (pbc_flags & 1u) && !(pbc_flags & VMD_PBC_TRICLINIC)) ? 1 : 0;
     vmd_bin_params_t q{{xyz, frame_stride, row_stride, boxes, pbc_flags, sel, nsel, nsel_pad, grid, nullptr, nullptr, nullptr, nullptr, nullptr},
-                       pen_off, pen_count, bucket, overflow, npen, total_cap};
+                       pen_off, pen_count, bucket, overflow, npen, total_cap, rec3};
     hipLaunchKernelGGL(k_cells_bin, dim3((nsel + 1024 * VMD_BIN_ILP - 1) / (1024 * VMD_BIN_ILP), B), dim3(1024), sizeof(uint32_t) * npen, s, q);
     VMD_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_cells_pen_scan, dim3(B), dim3(256), 0, s, (const uint32_t*)pen_count, pen_off, pen_start, npen);
     VMD_LAUNCH_CHECK();
-    vmd_pensort_params_t ps{bucket, pen_off, pen_count, pen_start, cell_start, sorted, npen, grid.nxf, grid.ncell, nsel_pad, total_cap, cap_max};
+    vmd_pensort_params_t ps{bucket, pen_off, pen_count, pen_start, cell_start, sorted, npen, grid.nxf, grid.ncell, nsel_pad, total_cap, cap_max, boxes, rec3};
     const size_t shm = sizeof(uint32_t) * ((size_t)grid.nxf + 256 + 3 * (size_t)cap_max);
     if (shm > 160 * 1024 - 64) return (int)hipErrorInvalidValue;
     int ea = vmd_lds_opt_in((const void*)k_cells_pen_sort);
