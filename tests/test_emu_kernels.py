@@ -159,14 +159,16 @@ def test_sdf_sparse_and_dense_target_paths(emu_lib, oracle):
     # the scatter's target addressing: index list / arithmetic progression generated on the device, 4 / 8 atoms per thread,
     # targets with and without owners, an irregular list (no progression)
     irregular = np.sort(np.random.default_rng(5).choice(np.arange(0, N, dtype=np.int32), N // 4, replace=False)).astype(np.int32)
-    for arith, ilp, rows in ((0, 4, 0), (1, 8, 0), (0, 16, 0), (1, 4, 1), (1, 4, 4)):      # rows: 16-byte row streaming for progressions
+    for arith, ilp, rows, wv in ((0, 4, 0, 0), (1, 8, 0, 0), (0, 16, 0, 0), (1, 4, 1, 0), (1, 4, 4, 0), (1, 4, 0, 1), (0, 8, 0, 1)):      # rows: 16-byte row streaming; wv: per-wave compaction
         old = emu_lib.vmd_set_option(b"sdf_arith", arith), emu_lib.vmd_set_option(b"sdf_ilp", ilp), emu_lib.vmd_set_option(b"sdf_rows", rows)
+        old_wv = emu_lib.vmd_set_option(b"sdf_wave", wv)
         try:
             cases.check_sdf(emu_lib, oracle, coords, 36.0, structures, mass, dense, 8.0)
             cases.check_sdf(emu_lib, oracle, coords, 36.0, structures, mass, irregular, 8.0)
             cases.check_sdf(emu_lib, oracle, coords, 36.0, structures, mass, np.arange(N, dtype=np.int32), 5.0)   # stride 1, owners among the targets
         finally:
             emu_lib.vmd_set_option(b"sdf_arith", old[0]); emu_lib.vmd_set_option(b"sdf_ilp", old[1]); emu_lib.vmd_set_option(b"sdf_rows", old[2])
+            emu_lib.vmd_set_option(b"sdf_wave", old_wv)
 
 
 def test_distance_family(emu_lib, oracle):

@@ -156,6 +156,8 @@ def sdf_scenario(seed):
         opts["sdf_ilp"] = int(rng.choice([1, 2, 8]))
     if rng.random() < 0.2:
         opts["batch_frames"] = 1
+    if seed % 3 == 0:
+        opts["sdf_wave"] = 1                        # per-wave compaction (no draw from rng: the scenarios stay what they were)
     dist = []
     for i, kd in enumerate((L.DIST_COM, L.DIST_MIN, L.DIST_MAX, L.DIST_PAIR)):
         a = rng.choice(n, int(rng.integers(1, 9)), replace=False).astype(np.int32)

@@ -113,6 +113,7 @@ extern "C" int vmd_set_option(const char* key, int value) {
     else if (!strcmp(key, "sdf_arith")) o = &g_opt.sdf_arith;
     else if (!strcmp(key, "sdf_ilp")) return vmd_hip_set_sdf_ilp(value);
     else if (!strcmp(key, "sdf_rows")) return vmd_hip_set_sdf_rows(value);
+    else if (!strcmp(key, "sdf_wave")) return vmd_hip_set_sdf_wave(value);
     else if (!strcmp(key, "cells_pencil")) return vmd_hip_set_cells_pencil(value);
     else if (!strcmp(key, "cells_rec3")) return vmd_hip_set_cells_rec3(value);
     else if (!strcmp(key, "cells_fused")) return vmd_hip_set_cells_fused(value);

@@ -1992,6 +1992,66 @@ __global__ __launch_bounds__(256) void k_sdf_scatter(vmd_scatter_params_t p) {
     }
 }
 
+// Wave-level variant (A/B, `sdf_wave`): the survivors of the group test are compacted per WAVE (ballot + prefix, 64 slots of LDS per
+// wave and round) instead of per block, so the kernel has no block barrier at all - a wave that found nothing near the structures
+// (most of them: ~1 % of the atoms pass) retires as soon as its loads are tested.
+template <int ILP, bool ARITH>
+__global__ __launch_bounds__(256) void k_sdf_scatter_wave(vmd_scatter_params_t p) {
+    __shared__ float s_x[4][VMD_WAVE], s_y[4][VMD_WAVE], s_z[4][VMD_WAVE];
+    __shared__ int s_own[4][VMD_WAVE], s_idx[4][VMD_WAVE];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int t0 = blockIdx.x * (256 * ILP) + wave * (VMD_WAVE * ILP) + lane;      // a wave owns 64 * ILP consecutive targets
+    const int b = blockIdx.y;
+    const vmd_box_t bx = vmd_load_box(p.boxes, b, p.pbc);
+    const float* fx = p.xyz + (size_t)b * p.frame_stride;
+    int idx[ILP], own[ILP];
+    float x[ILP], y[ILP], z[ILP];
+#pragma unroll
+    for (int u = 0; u < ILP; ++u) {
+        const int t = t0 + VMD_WAVE * u;
+        idx[u] = -1; own[u] = p.unowned ? -1 : -2;
+        if (t < p.ntgt) {
+            idx[u] = ARITH ? p.tgt_first + t * p.tgt_stride : (p.tgt ? p.tgt[t] : t);
+            if (!p.unowned && p.owner) own[u] = (int)p.owner[t];
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < ILP; ++u) {
+        x[u] = y[u] = z[u] = 0.0f;
+        if (idx[u] >= 0) { x[u] = fx[idx[u]]; y[u] = fx[p.row_stride + idx[u]]; z[u] = fx[2 * p.row_stride + idx[u]]; }
+    }
+    unsigned pending = 0u;
+#pragma unroll
+    for (int u = 0; u < ILP; ++u) if (idx[u] >= 0 && vmd_sdf_near(p, bx, b, x[u], y[u], z[u])) pending |= 1u << u;
+    for (;;) {
+        unsigned base = 0u;                                   // wave-uniform: survivors placed in this round
+        bool left = false;
+#pragma unroll
+        for (int u = 0; u < ILP; ++u) {
+            const bool hit = (pending >> u) & 1u;
+            const unsigned long long m = VMD_BALLOT(hit);
+            if (m == 0ull) continue;
+            const unsigned pre = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+            const unsigned slot = base + pre;
+            if (hit && slot < (unsigned)VMD_WAVE) {
+                s_x[wave][slot] = x[u]; s_y[wave][slot] = y[u]; s_z[wave][slot] = z[u]; s_own[wave][slot] = own[u]; s_idx[wave][slot] = idx[u];
+                pending &= ~(1u << u);
+            }
+            base += (unsigned)__popcll(m);
+            if (base > (unsigned)VMD_WAVE) left = true;
+        }
+        if (base == 0u) break;
+        __builtin_amdgcn_wave_barrier();
+        const int nwork = (int)(base < (unsigned)VMD_WAVE ? base : (unsigned)VMD_WAVE) * p.K;
+        for (int w = lane; w < nwork; w += VMD_WAVE) {
+            const int a = w / p.K, k = w - a * p.K;
+            vmd_sdf_atom_k(p, bx, b, k, s_x[wave][a], s_y[wave][a], s_z[wave][a], s_own[wave][a], s_idx[wave][a]);
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (!left) break;                                     // wave-uniform
+    }
+}
+
 // Row-streaming variant for arithmetic-progression targets (first + t * stride, e.g. every water oxygen: stride 3): the lines of
 // the x / y / z rows are needed in full anyway (a stride-3 selection touches every 32-byte sector), so a thread takes GPT groups of
 // 4 consecutive ATOMS with 16-byte loads - three perfectly coalesced dwordx4 loads per group instead of twelve strided dword
@@ -2428,6 +2488,8 @@ extern "C" int vmd_hip_sdf_ref_pose(void* stream, const float* xyz, size_t row_s
 
 static int g_sdf_rows = 0;      // row-streaming scatter for arithmetic-progression targets: groups of 4 atoms per thread (0 = off, 1 / 2 / 4)
 extern "C" int vmd_hip_set_sdf_rows(int n) { const int old = g_sdf_rows; if (n == 0 || n == 1 || n == 2 || n == 4) g_sdf_rows = n; return old; }
+static int g_sdf_wave = 0;      // per-wave instead of per-block compaction of the group test's survivors (no block barrier)
+extern "C" int vmd_hip_set_sdf_wave(int on) { const int old = g_sdf_wave; g_sdf_wave = on ? 1 : 0; return old; }
 static int g_sdf_ilp = 4;
 extern "C" int vmd_hip_set_sdf_ilp(int n) { const int old = g_sdf_ilp; if (n == 4 || n == 8 || n == 16) g_sdf_ilp = n; return old; }
 extern "C" int vmd_hip_sdf_scatter(void* stream, const float* xyz, size_t frame_stride, size_t row_stride,
@@ -2454,6 +2516,19 @@ extern "C" int vmd_hip_sdf_scatter(void* stream, const float* xyz, size_t frame_
         if (g_sdf_rows == 2) hipLaunchKernelGGL((k_sdf_scatter_rows<2>), dim3((ngroups + 511) / 512, B), dim3(256), 0, s, p, g_first, ngroups);
         else if (g_sdf_rows == 4) hipLaunchKernelGGL((k_sdf_scatter_rows<4>), dim3((ngroups + 1023) / 1024, B), dim3(256), 0, s, p, g_first, ngroups);
         else hipLaunchKernelGGL((k_sdf_scatter_rows<1>), dim3((ngroups + 255) / 256, B), dim3(256), 0, s, p, g_first, ngroups);
+        VMD_LAUNCH_CHECK();
+        return 0;
+    }
+    if (g_sdf_wave) {
+        if (g_sdf_ilp == 8) {
+            const dim3 g((ntgt + 256 * 8 - 1) / (256 * 8), B);
+            if (arith) hipLaunchKernelGGL((k_sdf_scatter_wave<8, true>), g, dim3(256), 0, s, p);
+            else hipLaunchKernelGGL((k_sdf_scatter_wave<8, false>), g, dim3(256), 0, s, p);
+        } else {
+            const dim3 g((ntgt + 256 * 4 - 1) / (256 * 4), B);
+            if (arith) hipLaunchKernelGGL((k_sdf_scatter_wave<4, true>), g, dim3(256), 0, s, p);
+            else hipLaunchKernelGGL((k_sdf_scatter_wave<4, false>), g, dim3(256), 0, s, p);
+        }
         VMD_LAUNCH_CHECK();
         return 0;
     }
