@@ -90,6 +90,8 @@ int vmd_hip_cells_build_pencil(void* stream, const float* xyz, size_t frame_stri
 int vmd_hip_rdf_num_blocks(void);
 int vmd_hip_set_rdf_nsub(int n);       /* tuning knob: work items per pencil (1..64, 0 = automatic), returns the previous value */
 int vmd_hip_set_rdf_shared_hist(int on); /* A-B switch: one LDS histogram per block instead of one per wave, returns the previous value */
+int vmd_hip_set_cells_bin_lds(int on); /* A-B switch: level 1 of the two-level cell build orders a block's records by pencil in LDS and writes
+                                        * them as coalesced runs (default on) instead of one scattered record per lane; returns the previous value */
 int vmd_hip_set_cells_rec3(int on);   /* A-B switch: 12-byte bucket records {x, y, z} in the two-level cell build where the fine cell follows
                                         * from the wrapped x alone (x-periodic, non-triclinic cells); default on; returns the previous value */
 void vmd_hip_set_pencil_reach(int ry, int rz); /* A-B switch: neighbour reach of the pencil walk in y / z (1 = pencils of cross-section >= rmax,

@@ -1,6 +1,6 @@
 #!/bin/bash
-# Round 2: 12-byte bucket records in the two-level cell build, A/B
-TAG=${1:-r02u}
+# Round 2: cell build A/B (12-byte records: r02u; block-local sort in level 1: r02x)
+TAG=${1:-r02x}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
@@ -19,8 +19,8 @@ except Exception as ex:
 PY
 }
 timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_fuzz_gpu.py -x -q -k "cell_build or random_rdf or overflow" 2>&1 | tail -2
-for v in 0 1 0 1; do ab c3_rec3_$v --workload c3 --steps 6 --opt cells_rec3=$v; done
-for v in 0 1; do ab c2_rec3_$v --workload c2 --steps 20 --opt cells_rec3=$v; done
-for v in 0 1; do ab c5_rec3_$v --workload c5 --steps 3 --opt cells_rec3=$v; done
+for v in 0 1 0 1; do ab c3_binlds_$v --workload c3 --steps 6 --opt cells_bin_lds=$v; done
+for v in 0 1; do ab c2_binlds_$v --workload c2 --steps 20 --opt cells_bin_lds=$v; done
+for v in 0 1; do ab c5_binlds_$v --workload c5 --steps 3 --opt cells_bin_lds=$v; done
 tail -3 $OUT/ab.err
 echo done

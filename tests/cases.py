@@ -129,14 +129,16 @@ def cell_build_cases(lib, O, coords, box, device=False):
     single-block build, split build (G blocks per frame, forced with 2048-atom slices)"""
     n = coords.shape[2]
     o, h = oxygen(n), hydrogen(n)
-    for pencil, fused, split, rec3 in ((1, 1, 1, 1), (1, 1, 1, 0), (0, 0, 1, 1), (0, 1, 1, 1), (0, 1, 2, 1)):      # rec3: 12- / 16-byte bucket records
+    # rec3: 12- / 16-byte bucket records; rec3 = 2, 3: the same with level 1 writing one scattered record per lane (no block-local sort)
+    for pencil, fused, split, rec3 in ((1, 1, 1, 1), (1, 1, 1, 0), (1, 1, 1, 2), (1, 1, 1, 3), (0, 0, 1, 1), (0, 1, 1, 1), (0, 1, 2, 1)):
         old = (lib.vmd_set_option(b"cells_pencil", pencil), lib.vmd_set_option(b"cells_fused", fused), lib.vmd_set_option(b"cells_split", split),
-               lib.vmd_set_option(b"cells_rec3", rec3))
+               lib.vmd_set_option(b"cells_rec3", rec3 & 1))
+        old_lds = lib.vmd_set_option(b"cells_bin_lds", 0 if rec3 >= 2 else 1)
         try:
             check_rdf(lib, O, coords[:2], box, [("goo", o, o, 0.0, 12.0), ("goh", o, h, 0.0, 9.0)], device=device)
         finally:
             lib.vmd_set_option(b"cells_pencil", old[0]); lib.vmd_set_option(b"cells_fused", old[1]); lib.vmd_set_option(b"cells_split", old[2])
-            lib.vmd_set_option(b"cells_rec3", old[3])
+            lib.vmd_set_option(b"cells_rec3", old[3]); lib.vmd_set_option(b"cells_bin_lds", old_lds)
 
 
 def cell_build_overflow_case(lib, O, device=False, n=3000, box=60.0):

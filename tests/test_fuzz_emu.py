@@ -74,6 +74,8 @@ def scenario(seed, scale=1):
         opts["batch_frames"] = 1
     if seed % 5 == 0:
         opts["cells_rec3"] = 0                      # 16-byte bucket records (no draw from rng: the scenarios stay what they were)
+    if seed % 7 == 0:
+        opts["cells_bin_lds"] = 0                   # level 1 of the cell build without the block-local sort
     return coords, box, flags, props, opts, kind
 
 

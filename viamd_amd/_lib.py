@@ -213,6 +213,7 @@ SIGNATURES = [
     ("vmd_hip_set_rdf_shared_hist", C.c_int, [C.c_int]),
     ("vmd_hip_set_pencil_reach", None, [C.c_int, C.c_int]),
     ("vmd_hip_set_cells_rec3", C.c_int, [C.c_int]),
+    ("vmd_hip_set_cells_bin_lds", C.c_int, [C.c_int]),
     ("vmd_hip_set_sdf_wave", C.c_int, [C.c_int]),
     ("vmd_hip_set_rdf_nsub", C.c_int, [C.c_int]),
     ("vmd_hip_cells_split_blocks", C.c_int, [Grid, C.c_int]),

@@ -116,6 +116,7 @@ extern "C" int vmd_set_option(const char* key, int value) {
     else if (!strcmp(key, "sdf_wave")) return vmd_hip_set_sdf_wave(value);
     else if (!strcmp(key, "cells_pencil")) return vmd_hip_set_cells_pencil(value);
     else if (!strcmp(key, "cells_rec3")) return vmd_hip_set_cells_rec3(value);
+    else if (!strcmp(key, "cells_bin_lds")) return vmd_hip_set_cells_bin_lds(value);
     else if (!strcmp(key, "cells_fused")) return vmd_hip_set_cells_fused(value);
     else if (!strcmp(key, "cells_split")) return vmd_hip_set_cells_split(value);
     else if (!strcmp(key, "rdf_blocks")) return vmd_hip_set_rdf_blocks(value);

@@ -568,6 +568,103 @@ __global__ __launch_bounds__(1024) void k_cells_bin(vmd_bin_params_t q) {
     }
 }
 
+// Level 1 with a block-local sort (the default): k_cells_bin stores every record from the lane that wrapped the atom, i.e. a wave's 64
+// records go to ~64 different buckets - one partial-line write transaction each.  Here the block first orders its 4 096 records by
+// pencil in LDS (rank inside the pencil from the LDS counter, the pencil's first slot from a block scan of the counters), then
+// consecutive lanes write consecutive records: a (block, pencil) run of ~14 records leaves as one or two coalesced stores.
+// LDS: 3 tables of npen words + 1 040 scan words + 4 096 records of 4 (12-byte output) or 5 (16-byte output) words.
+__global__ __launch_bounds__(1024) void k_cells_bin_sorted(vmd_bin_params_t q) {
+    HIP_DYNAMIC_SHARED(uint32_t, s_dyn)
+    const int npen = q.npen, nxf = q.c.grid.nxf;
+    const int rw = q.rec3 ? 4 : 5;             // words per LDS record: x, y, z, pencil (, fine cell)
+    uint32_t* s_cnt = s_dyn;                   // [npen] atoms of this block per pencil
+    uint32_t* s_off = s_dyn + npen;            // [npen] first LDS slot of the pencil's run
+    uint32_t* s_gbase = s_dyn + 2 * npen;      // [npen] first slot of the run in the pencil's bucket
+    uint32_t* s_p = s_dyn + 3 * npen;          // [1024 + 16] scan partials
+    uint32_t* s_rec = s_p + 1040;              // [4096][rw]
+    const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int c = tid; c < npen; c += 1024) s_cnt[c] = 0u;
+    __syncthreads();
+    float xw[VMD_BIN_ILP], yw[VMD_BIN_ILP], zw[VMD_BIN_ILP];
+    uint32_t pen[VMD_BIN_ILP], cx[VMD_BIN_ILP], rank[VMD_BIN_ILP];
+#pragma unroll
+    for (int u = 0; u < VMD_BIN_ILP; ++u) {
+        const int t = (g * VMD_BIN_ILP + u) * 1024 + tid;
+        pen[u] = 0xffffffffu;
+        if (t < q.c.nsel) {
+            const uint32_t cell = vmd_cell_of(q.c, b, t, xw[u], yw[u], zw[u]);
+            pen[u] = cell / (uint32_t)nxf;
+            cx[u] = cell - pen[u] * (uint32_t)nxf;
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < VMD_BIN_ILP; ++u) if (pen[u] != 0xffffffffu) rank[u] = atomicAdd(&s_cnt[pen[u]], 1u);
+    __syncthreads();
+    // reserve the runs in the buckets, and scan the counters: thread t owns the counters [t * per, t * per + per)
+    uint32_t* gcount = q.pen_count + (size_t)b * npen;
+    const int per = (npen + 1023) / 1024;
+    const int cb = tid * per, ce = cb + per < npen ? cb + per : npen;
+    uint32_t sum = 0;
+    for (int c = cb; c < ce; ++c) {
+        const uint32_t n = s_cnt[c];
+        s_gbase[c] = n ? atomicAdd(&gcount[c], n) : 0u;
+        sum += n;
+    }
+    volatile uint32_t* vp = s_p;                             // lanes exchange through LDS between wave barriers: no caching in registers
+    vp[tid] = sum;
+    __builtin_amdgcn_wave_barrier();
+    for (int o = 1; o < VMD_WAVE; o <<= 1) {                 // inclusive scan of the wave's 64 partials, through LDS
+        const uint32_t v = lane >= o ? vp[tid - o] : 0u;
+        __builtin_amdgcn_wave_barrier();
+        vp[tid] = vp[tid] + v;
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (lane == VMD_WAVE - 1) vp[1024 + wave] = vp[tid];
+    __syncthreads();
+    if (wave == 0) {                                         // the 16 wave totals (every lane of the wave walks the barriers)
+        for (int o = 1; o < 16; o <<= 1) {
+            const uint32_t v = (lane < 16 && lane >= o) ? vp[1024 + lane - o] : 0u;
+            __builtin_amdgcn_wave_barrier();
+            if (lane < 16) vp[1024 + lane] = vp[1024 + lane] + v;
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    __syncthreads();
+    const uint32_t ntot = s_p[1024 + 15];
+    uint32_t run = (s_p[tid] - sum) + (wave ? s_p[1024 + wave - 1] : 0u);
+    for (int c = cb; c < ce; ++c) { s_off[c] = run; run += s_cnt[c]; }
+    if (!q.bucket) return;                   // counting mode: the host only wants the populations
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < VMD_BIN_ILP; ++u) {
+        if (pen[u] == 0xffffffffu) continue;
+        uint32_t* r = s_rec + (size_t)rw * (s_off[pen[u]] + rank[u]);
+        r[0] = (uint32_t)__float_as_int(xw[u]); r[1] = (uint32_t)__float_as_int(yw[u]); r[2] = (uint32_t)__float_as_int(zw[u]); r[3] = pen[u];
+        if (!q.rec3) r[4] = cx[u];
+    }
+    __syncthreads();
+    float* bk = q.bucket + (size_t)b * q.total_cap * 4;
+    bool over = false;
+    for (uint32_t t = tid; t < ntot; t += 1024) {
+        const uint32_t* r = s_rec + (size_t)rw * t;
+        const uint32_t pn = r[3];
+        const uint32_t off = q.pen_off[pn], cap = q.pen_off[pn + 1] - off;
+        const uint32_t slot = s_gbase[pn] + (t - s_off[pn]);
+        if (slot < cap) {
+            if (q.rec3) {
+                float* d = bk + 3 * (size_t)(off + slot);
+                d[0] = __int_as_float((int)r[0]); d[1] = __int_as_float((int)r[1]); d[2] = __int_as_float((int)r[2]);
+            } else {
+                const vmd_f4a v = {__int_as_float((int)r[0]), __int_as_float((int)r[1]), __int_as_float((int)r[2]), __int_as_float((int)r[4])};
+                *(vmd_f4a*)(bk + 4 * (size_t)(off + slot)) = v;
+            }
+        } else {
+            over = true;
+        }
+    }
+    if (over) *q.overflow = 1u;
+}
+
 // per frame: exclusive prefix of the (capacity-clamped) pencil populations = first sorted slot of every pencil
 __global__ __launch_bounds__(256) void k_cells_pen_scan(const uint32_t* __restrict__ pen_count, const uint32_t* __restrict__ pen_off,
                                                         uint32_t* __restrict__ pen_start, int npen) {
@@ -624,15 +721,20 @@ __global__ __launch_bounds__(256) void k_cells_pen_sort(vmd_pensort_params_t q) 
     const int beg = tid * per, end = beg + per < nxf ? beg + per : nxf;
     uint32_t sum = 0;
     for (int c = beg; c < end; ++c) sum += s_cnt[c];
-    s_part[tid] = sum;
-    __syncthreads();
-    for (int o = 1; o < 256; o <<= 1) {
-        const uint32_t v = tid >= o ? s_part[tid - o] : 0u;
-        __syncthreads();
-        s_part[tid] += v;
-        __syncthreads();
+    // inclusive scan of the 256 partials: per wave through LDS (no block barrier), then the four wave totals
+    const int lane = tid & 63, wave = tid >> 6;
+    volatile uint32_t* vpart = s_part;             // lanes exchange through LDS between wave barriers: no caching in registers
+    vpart[tid] = sum;
+    __builtin_amdgcn_wave_barrier();
+    for (int o = 1; o < VMD_WAVE; o <<= 1) {
+        const uint32_t v = lane >= o ? vpart[tid - o] : 0u;
+        __builtin_amdgcn_wave_barrier();
+        vpart[tid] = vpart[tid] + v;
+        __builtin_amdgcn_wave_barrier();
     }
+    __syncthreads();
     uint32_t run = s_part[tid] - sum;
+    for (int w = 0; w < wave; ++w) run += s_part[w * VMD_WAVE + VMD_WAVE - 1];
     uint32_t* cs = q.cell_start + (size_t)b * (q.ncell + 1) + (size_t)pen * nxf;
     for (int c = beg; c < end; ++c) { const uint32_t m = s_cnt[c]; s_cnt[c] = run; cs[c] = start + run; run += m; }
     if (pen == q.npen - 1 && tid == 255) q.cell_start[(size_t)b * (q.ncell + 1) + q.ncell] = start + n;
@@ -2601,6 +2703,8 @@ extern "C" int vmd_hip_cells_pencil_count(void* stream, const float* xyz, size_t
     return 0;
 }
 
+static int g_cells_bin_lds = 1;   // level 1 orders a block's records by pencil in LDS before writing them (A/B switch)
+extern "C" int vmd_hip_set_cells_bin_lds(int on) { const int old = g_cells_bin_lds; g_cells_bin_lds = on ? 1 : 0; return old; }
 static int g_cells_rec3 = 1;      // 12-byte bucket records where the cell kind allows it (A/B switch)
 extern "C" int vmd_hip_set_cells_rec3(int on) { const int old = g_cells_rec3; g_cells_rec3 = on ? 1 : 0; return old; }
 extern "C" int vmd_hip_cells_build_pencil(void* stream, const float* xyz, size_t frame_stride, size_t row_stride, const float* boxes,
@@ -2617,7 +2721,14 @@ extern "C" int vmd_hip_cells_build_pencil(void* stream, const float* xyz, size_t
     const int rec3 = (g_cells_rec3 && (pbc_flags & 1u) && !(pbc_flags & VMD_PBC_TRICLINIC)) ? 1 : 0;
     vmd_bin_params_t q{{xyz, frame_stride, row_stride, boxes, pbc_flags, sel, nsel, nsel_pad, grid, nullptr, nullptr, nullptr, nullptr, nullptr},
                        pen_off, pen_count, bucket, overflow, npen, total_cap, rec3};
-    hipLaunchKernelGGL(k_cells_bin, dim3((nsel + 1024 * VMD_BIN_ILP - 1) / (1024 * VMD_BIN_ILP), B), dim3(1024), sizeof(uint32_t) * npen, s, q);
+    const size_t shm_sorted = sizeof(uint32_t) * (3 * (size_t)npen + 1040 + (size_t)1024 * VMD_BIN_ILP * (rec3 ? 4 : 5));
+    if (g_cells_bin_lds && shm_sorted <= 160 * 1024 - 64) {
+        int eb = vmd_lds_opt_in((const void*)k_cells_bin_sorted);
+        if (eb) return eb;
+        hipLaunchKernelGGL(k_cells_bin_sorted, dim3((nsel + 1024 * VMD_BIN_ILP - 1) / (1024 * VMD_BIN_ILP), B), dim3(1024), shm_sorted, s, q);
+    } else {
+        hipLaunchKernelGGL(k_cells_bin, dim3((nsel + 1024 * VMD_BIN_ILP - 1) / (1024 * VMD_BIN_ILP), B), dim3(1024), sizeof(uint32_t) * npen, s, q);
+    }
     VMD_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_cells_pen_scan, dim3(B), dim3(256), 0, s, (const uint32_t*)pen_count, pen_off, pen_start, npen);
     VMD_LAUNCH_CHECK();
