@@ -6,7 +6,9 @@
 // fmaf() calls the spec names, so integer results are bit-identical to the CPU restatement.
 //
 // Reference functions replaced (sources live in the empty submodule ext/mdlib):
-//   md_spatial_hash build/query  -> k_cells_count / k_cells_scan / k_cells_scatter + the segment walk of k_rdf_pencil
+//   md_spatial_hash build/query  -> k_cells_bin_sorted / k_cells_pen_scan / k_cells_pen_sort (two-level build; single-level builds
+//                                   k_cells_fused, k_cells_split_*, k_cells_count / _scan / _scatter for what it does not take) + the
+//                                   segment walk of k_rdf_pencil
 //   rdf()                        -> k_rdf_pencil (periodic, grid) / k_rdf_brute (general)
 //   sdf() + density volume       -> k_sdf_align (fp64 Horn/Jacobi) + k_sdf_scatter
 //   distance*()                  -> k_distance_com / k_distance_minmax / k_distance_pair
