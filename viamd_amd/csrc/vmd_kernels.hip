@@ -723,20 +723,16 @@ __global__ __launch_bounds__(256) void k_cells_pen_sort(vmd_pensort_params_t q) 
     const int beg = tid * per, end = beg + per < nxf ? beg + per : nxf;
     uint32_t sum = 0;
     for (int c = beg; c < end; ++c) sum += s_cnt[c];
-    // inclusive scan of the 256 partials: per wave through LDS (no block barrier), then the four wave totals
-    const int lane = tid & 63, wave = tid >> 6;
-    volatile uint32_t* vpart = s_part;             // lanes exchange through LDS between wave barriers: no caching in registers
-    vpart[tid] = sum;
-    __builtin_amdgcn_wave_barrier();
-    for (int o = 1; o < VMD_WAVE; o <<= 1) {
-        const uint32_t v = lane >= o ? vpart[tid - o] : 0u;
-        __builtin_amdgcn_wave_barrier();
-        vpart[tid] = vpart[tid] + v;
-        __builtin_amdgcn_wave_barrier();
-    }
+    // (a per-wave scan through LDS with one block barrier measured 7 % slower for this kernel than the plain block scan: profiles/r02y)
+    s_part[tid] = sum;
     __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+        const uint32_t v = tid >= o ? s_part[tid - o] : 0u;
+        __syncthreads();
+        s_part[tid] += v;
+        __syncthreads();
+    }
     uint32_t run = s_part[tid] - sum;
-    for (int w = 0; w < wave; ++w) run += s_part[w * VMD_WAVE + VMD_WAVE - 1];
     uint32_t* cs = q.cell_start + (size_t)b * (q.ncell + 1) + (size_t)pen * nxf;
     for (int c = beg; c < end; ++c) { const uint32_t m = s_cnt[c]; s_cnt[c] = run; cs[c] = start + run; run += m; }
     if (pen == q.npen - 1 && tid == 255) q.cell_start[(size_t)b * (q.ncell + 1) + q.ncell] = start + n;
