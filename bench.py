@@ -306,6 +306,24 @@ def run_workload(name, args, ctx, steps, warmup, frames=None, with_cpu=False, op
         "kernel_ms": dict(kernel_ms, timed_region=elapsed * 1e3),
         "synth_s": gen_s,
     }
+    if "cells_build" in kernel_ms:
+        # the sorted copies behind the pair kernel: share of the step and (where a PMC pass exists) HBM-side traffic against
+        # 12*N (the frame, read once) + 12*N_sel (the sorted rows, written once) per frame
+        cb = {"ms_per_step": kernel_ms["cells_build"] / steps, "frac_of_step": kernel_ms["cells_build"] / (elapsed * 1e3)}
+        try:
+            pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))[name]
+            per_frame = sum(k["hbm_bytes_per_launch_read_x2"] for kn, k in pt["kernels"].items() if kn.startswith("k_cells")) / pt["frames_per_launch"]
+            sel = {}
+            for d in info.values():
+                if d["kind"] == "rdf":
+                    for arr in (d["ref"], d["target"]):
+                        sel[(len(arr), int(arr[0]), int(arr[-1]))] = len(arr)
+            alg = 12.0 * w["atoms"] + 12.0 * sum(sel.values())
+            cb.update({"traffic_bytes_per_frame": per_frame, "algorithmic_bytes_per_frame": alg, "traffic_ratio": per_frame / alg,
+                       "traffic_source": f"profiles/pmc_traffic.json ({pt['source']}), kernels k_cells_*"})
+        except Exception:
+            pass
+        out["cell_build"] = cb
     if args.traj == "xtc":
         # > 0 only with --opt xtc_device_decode=1: the compressed frames crossed PCIe and were decompressed by k_xtc_decode
         out["config"]["frames_decompressed_on_device_per_step"] = ev.frames_device_decoded()
