@@ -55,7 +55,7 @@ def test_default_line_has_the_contract_fields(tmp_path, emu_lib):
         assert k in d["roofline"], k
     assert set(d["secondary"]) == {"c2", "c4", "c5"} and d["secondary"]["c4"]["roofline"]["kernel"] == "k_sdf_scatter"
     assert d["secondary"]["c4"]["voxel_hits_per_s"] > 0 and d["pairs_per_s"] > 0
-    assert 0.0 < d["cell_build"]["frac_of_step"] < 1.0              # the sorted copies behind the pair kernel: share of the step
+    assert 0.0 <= d["cell_build"]["frac_of_step"] < 1.0             # the sorted copies behind the pair kernel: share of the step (event times are 0 on the emulator)
 
 
 @pytest.mark.parametrize("scaling", ["weak", "strong"])
