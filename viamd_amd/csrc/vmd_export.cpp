@@ -82,7 +82,7 @@ extern "C" bool vmd_export_property_table(const char* path, vmd_script_eval_t* e
         rows = (size_t)nb;
         std::vector<float> x(nb), g(nb);
         const double beg = pd->min_range[0], end = pd->max_range[0];
-        const double step = (end - beg) / (double)(nb - 1);       // sample_range, src/main.cpp:5832-5840
+        const double step = nb > 1 ? (end - beg) / (double)(nb - 1) : 0.0;       // sample_range, src/main.cpp:5832-5840
         for (int i = 0; i < nb; ++i) x[i] = (float)(beg + step * (double)i);
         vmd_downsample_histogram(g.data(), nb, pd->values, pd->weights, pd->dim[2]);
         cols.push_back(std::move(x)); labels.push_back("");
@@ -152,6 +152,10 @@ extern "C" bool vmd_export_cube(const char* path, vmd_script_eval_t* eval, const
         std::vector<int32_t> atoms(vis.structures, vis.structures + vis.atoms_per_structure);
         std::sort(atoms.begin(), atoms.end());
         atoms.erase(std::unique(atoms.begin(), atoms.end()), atoms.end());
+        if (!atoms.empty() && (atoms.front() < 0 || (size_t)atoms.back() >= N)) {
+            fclose(f);
+            return exp_fail("Export Cube: a reference structure refers to atoms the trajectory does not have");
+        }
         const int num_atoms = (int)atoms.size();
         const int vol_dim[3] = {pd->dim[1], pd->dim[2], pd->dim[3]};
         const double extent = vis.extent * 2.0 * angstrom_to_bohr;
