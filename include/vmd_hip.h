@@ -89,6 +89,7 @@ int vmd_hip_cells_build_pencil(void* stream, const float* xyz, size_t frame_stri
  *             >= rmax measured perpendicular to the cell faces.  Open axes: no images, neighbours end at the bounding box. */
 int vmd_hip_rdf_num_blocks(void);
 int vmd_hip_set_rdf_nsub(int n);       /* tuning knob: work items per pencil (1..64, 0 = automatic), returns the previous value */
+int vmd_hip_set_rdf_nsub_pct(int pct);  /* tuning knob: the automatic number of work items per pencil as a percentage of the mean number of i-chunks per pencil */
 int vmd_hip_set_rdf_shared_hist(int on); /* A-B switch: one LDS histogram per block instead of one per wave, returns the previous value */
 int vmd_hip_set_cells_bin_lds(int on); /* A-B switch: level 1 of the two-level cell build orders a block's records by pencil in LDS and writes
                                         * them as coalesced runs (default on) instead of one scattered record per lane; returns the previous value */

@@ -211,6 +211,7 @@ SIGNATURES = [
     ("vmd_hip_rdf_num_blocks", C.c_int, []),
     ("vmd_hip_set_rdf_blocks", C.c_int, [C.c_int]),
     ("vmd_hip_set_rdf_shared_hist", C.c_int, [C.c_int]),
+    ("vmd_hip_set_rdf_nsub_pct", C.c_int, [C.c_int]),
     ("vmd_hip_set_pencil_reach", None, [C.c_int, C.c_int]),
     ("vmd_hip_set_cells_rec3", C.c_int, [C.c_int]),
     ("vmd_hip_set_cells_bin_lds", C.c_int, [C.c_int]),

@@ -122,6 +122,7 @@ extern "C" int vmd_set_option(const char* key, int value) {
     else if (!strcmp(key, "rdf_blocks")) return vmd_hip_set_rdf_blocks(value);
     else if (!strcmp(key, "rdf_shared_hist")) return vmd_hip_set_rdf_shared_hist(value);
     else if (!strcmp(key, "rdf_nsub")) return vmd_hip_set_rdf_nsub(value);
+    else if (!strcmp(key, "rdf_nsub_pct")) return vmd_hip_set_rdf_nsub_pct(value);
     if (!o) return -1;
     return o->exchange(value);
 }

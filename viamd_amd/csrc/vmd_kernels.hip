@@ -2470,6 +2470,8 @@ extern "C" int vmd_hip_cells_build(void* stream, const float* xyz, size_t frame_
 
 static int g_rdf_nsub = 0;   // 0 = automatic: about one i-chunk per item
 extern "C" int vmd_hip_set_rdf_nsub(int n) { const int old = g_rdf_nsub; if (n >= 0 && n <= 64) g_rdf_nsub = n; return old; }
+static int g_rdf_nsub_pct = 100;   // automatic nsub = mean chunks per pencil x this / 100
+extern "C" int vmd_hip_set_rdf_nsub_pct(int n) { const int old = g_rdf_nsub_pct; if (n >= 25 && n <= 800) g_rdf_nsub_pct = n; return old; }
 static int g_rdf_shist = 0;       // one LDS histogram per block instead of one per wave (8 instead of 7 waves per SIMD)
 extern "C" int vmd_hip_set_rdf_shared_hist(int on) { const int old = g_rdf_shist; g_rdf_shist = on ? 1 : 0; return old; }
 static int g_pen_ry = 1, g_pen_rz = 1;   // neighbour reach of the pencil walk; the grid handed to the build and to the walk must be cut to match
@@ -2510,7 +2512,7 @@ extern "C" int vmd_hip_rdf_pencil(void* stream, const float* sorted_ref, const u
     p.nsub = g_rdf_nsub;
     if (p.nsub == 0) {
         const long long per_chunk = (long long)grid.ny * grid.nz * VMD_WAVE;
-        p.nsub = (int)((nref + per_chunk - 1) / per_chunk);
+        p.nsub = (int)(((nref + per_chunk - 1) / per_chunk) * g_rdf_nsub_pct / 100);
         if (p.nsub < 1) p.nsub = 1;
         if (p.nsub > 64) p.nsub = 64;
     }
