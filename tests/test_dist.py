@@ -74,14 +74,15 @@ def test_shard_frames_covers_everything():
 import pytest
 
 
-@pytest.mark.parametrize("mode", ["host", "shard"])
-def test_two_rank_gloo_merge_matches_oracle(oracle, emu_lib, tmp_path, mode):
+@pytest.mark.parametrize("mode,world", [("host", 2), ("shard", 2), ("host", 4)])
+def test_two_rank_gloo_merge_matches_oracle(oracle, emu_lib, tmp_path, mode, world):
     """every rank evaluates its block of frames, ONE vmd_eval_reduce (C++, behind the ABI) merges; `shard`: each rank holds
-    only its block of a device trajectory"""
+    only its block of a device trajectory; 4 ranks on 5 frames: blocks of 2, 2, 1 and an EMPTY block (a rank without frames still
+    takes part in the merge)"""
     import cases
     from viamd_amd import _lib as L
-    port = 29500 + (os.getpid() % 2000) + (7 if mode == "shard" else 0)
-    mp.spawn(_worker, args=(2, port, str(tmp_path), mode), nprocs=2, join=True)
+    port = 29500 + (os.getpid() % 2000) + (7 if mode == "shard" else 0) + 13 * (world - 2)
+    mp.spawn(_worker, args=(world, port, str(tmp_path), mode), nprocs=world, join=True)
     F = 5
     coords, structures, mass = cases.sdf_system(oracle, 21, 900, 36.0, F)
     N = coords.shape[2]
@@ -91,7 +92,7 @@ def test_two_rank_gloo_merge_matches_oracle(oracle, emu_lib, tmp_path, mode):
     vol, _ = cases.oracle_sdf(oracle, coords, ocell, structures, mass, o, 8.0)
     d = cases.oracle_distance(oracle, coords, ocell, mass, structures[0], structures[1], L.DIST_COM)
     dp = cases.oracle_distance(oracle, coords, ocell, mass, structures[0][:2], structures[2][:3], L.DIST_PAIR)
-    for r in range(2):
+    for r in range(world):
         z = np.load(tmp_path / f"rank{r}.npz")
         np.testing.assert_array_equal(z["goo"], counts)           # bit-identical on every rank
         np.testing.assert_array_equal(z["gv"], counts.astype(np.float32))
