@@ -175,6 +175,11 @@ int vmd_hip_xtc_decode(void* stream, const unsigned char* raw, const vmd_xtc_fra
 size_t vmd_hip_xtc_scratch_bytes(int B, int natoms, int chunk);
 int vmd_hip_xtc_decode_chunked(void* stream, const unsigned char* raw, const vmd_xtc_frame_t* info, int B, int natoms,
                                float* xyz, size_t frame_stride, size_t row_stride, uint32_t* status, int chunk, void* scratch);
+/* the same result with one WAVE per frame (k_xtc_wave): the wave walks the group boundaries of its stream speculatively (lane k
+ * tests the flag bit of the k-th next group; the stream window lives in VGPRs, no LDS allocation) and decodes 64 groups at a time,
+ * one per lane.  Streams of 2^27 bytes and more are reported as status 2. */
+int vmd_hip_xtc_decode_wave(void* stream, const unsigned char* raw, const vmd_xtc_frame_t* info, int B, int natoms,
+                            float* xyz, size_t frame_stride, size_t row_stride, uint32_t* status);
 
 /* synthetic water box (oracle S9 twin): fills frames [frame0, frame0+B) of a batch laid out as above */
 int vmd_hip_synth_frames(void* stream, float* xyz, size_t frame_stride, size_t row_stride, int B, uint32_t frame0,

@@ -77,6 +77,15 @@ uint32_t shfl_xor_bits(uint32_t v, int mask) {
     return (uint32_t)s[(f->linear & 63) ^ (mask & 63)];
 }
 
+uint32_t shfl_idx_bits(uint32_t v, int src) {
+    Fiber* f = g_cur;
+    const unsigned gen = f->gen++;
+    uint64_t* s = xslot(f, gen);
+    s[f->linear & 63] = v;
+    yield(WAIT_WAVE);
+    return (uint32_t)s[src & 63];
+}
+
 uint32_t readfirstlane_bits(uint32_t v) {
     Fiber* f = g_cur;
     const unsigned gen = f->gen++;

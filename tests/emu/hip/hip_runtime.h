@@ -46,6 +46,7 @@ void sync_wave();
 unsigned long long ballot(int pred);
 uint32_t shfl_xor_bits(uint32_t v, int mask);
 uint32_t readfirstlane_bits(uint32_t v);
+uint32_t shfl_idx_bits(uint32_t v, int src);
 }  // namespace emu
 
 #define threadIdx (emu::cur_tid())
@@ -78,6 +79,10 @@ static inline unsigned emu_mbcnt_hi(unsigned mask, unsigned add) {
 #define __builtin_amdgcn_mbcnt_hi(m, v) emu_mbcnt_hi((m), (v))
 #define __builtin_amdgcn_readfirstlane(v) ((int)emu::readfirstlane_bits((uint32_t)(v)))
 #define __builtin_amdgcn_wave_barrier() emu::sync_wave()
+// ds_bpermute / v_readlane stand-ins (vmd_xtc_device.hip): every live lane of the wave takes part
+#define VMD_SHFL_U32(v, src) emu::shfl_idx_bits((uint32_t)(v), (int)(src))
+#define VMD_READLANE_U32(v, lane) emu::shfl_idx_bits((uint32_t)(v), (int)(lane))
+#define VMD_XTC_BALLOT(pred) __ballot(pred)
 
 // v_sqrt_f32 stand-in with a deliberate +-1 ulp error on half of the inputs: exercises the exactness fix-up of vmd_bin_add
 static inline float emu_approx_sqrtf(float x) {

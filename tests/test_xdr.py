@@ -254,7 +254,7 @@ def test_xtc_trajectory_through_the_evaluator_on_emulator(tmp_path, emu_lib, ora
     assert res[0].sum() > 0
 
 
-def _device_decode(lib, blob, natoms, chunk=0):
+def _device_decode(lib, blob, natoms, chunk=0, gpu=False):
     """Run vmd_hip_xtc_decode (emulator build: "device" memory is host memory) on every frame of an XTC byte string."""
     import ctypes as C
     from viamd_amd import _lib as L
@@ -279,30 +279,43 @@ def _device_decode(lib, blob, natoms, chunk=0):
         arr[b].offset = len(raw)
         arr[b].nbytes = nbytes
         raw += streams[b] + b"\0" * ((-len(streams[b])) % 64 + 64)
-    # 64-byte alignment of the stream starts: copy into an aligned numpy buffer
-    store = np.zeros(len(raw) + 64, np.uint8)
-    base = (-store.ctypes.data) % 64
-    store[base:base + len(raw)] = np.frombuffer(raw, np.uint8)
     npad = (natoms + 63) & ~63
-    out = np.full((B, 3, npad), np.nan, np.float32)
-    status = np.full(B, 99, np.uint32)
-    if chunk:                  # two passes: index (one thread per frame) + chunks (one thread per chunk)
-        scratch = np.zeros(lib.vmd_hip_xtc_scratch_bytes(B, natoms, chunk) // 8 + 1, np.uint64)
-        rc = lib.vmd_hip_xtc_decode_chunked(None, store.ctypes.data + base, C.addressof(arr), B, natoms, out.ctypes.data, 3 * npad,
-                                            npad, status.ctypes.data, chunk, scratch.ctypes.data)
+    if gpu:                    # the product library on a real GPU: torch owns the device memory (hipMalloc: 256-byte aligned)
+        import torch
+        d_raw = torch.frombuffer(bytearray(raw), dtype=torch.uint8).cuda()
+        d_info = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).cuda()
+        d_out = torch.full((B, 3, npad), float("nan"), dtype=torch.float32, device="cuda")
+        d_status = torch.full((B,), 99, dtype=torch.int32, device="cuda")
+        raw_p, info_p, out_p, status_p = d_raw.data_ptr(), d_info.data_ptr(), d_out.data_ptr(), d_status.data_ptr()
+        if chunk > 0:
+            d_scratch = torch.zeros(lib.vmd_hip_xtc_scratch_bytes(B, natoms, chunk) // 8 + 1, dtype=torch.int64, device="cuda")
+            scratch_p = d_scratch.data_ptr()
+        torch.cuda.synchronize()
     else:
-        rc = lib.vmd_hip_xtc_decode(None, store.ctypes.data + base, C.addressof(arr), B, natoms, out.ctypes.data, 3 * npad, npad,
-                                    status.ctypes.data)
+        # 64-byte alignment of the stream starts: copy into an aligned numpy buffer
+        store = np.zeros(len(raw) + 64, np.uint8)
+        base = (-store.ctypes.data) % 64
+        store[base:base + len(raw)] = np.frombuffer(raw, np.uint8)
+        out = np.full((B, 3, npad), np.nan, np.float32)
+        status = np.full(B, 99, np.uint32)
+        raw_p, info_p, out_p, status_p = store.ctypes.data + base, C.addressof(arr), out.ctypes.data, status.ctypes.data
+        if chunk > 0:
+            scratch = np.zeros(lib.vmd_hip_xtc_scratch_bytes(B, natoms, chunk) // 8 + 1, np.uint64)
+            scratch_p = scratch.ctypes.data
+    if chunk == -1:            # one wave per frame (k_xtc_wave)
+        rc = lib.vmd_hip_xtc_decode_wave(None, raw_p, info_p, B, natoms, out_p, 3 * npad, npad, status_p)
+    elif chunk:                # two passes: index (one thread per frame) + chunks (one thread per chunk)
+        rc = lib.vmd_hip_xtc_decode_chunked(None, raw_p, info_p, B, natoms, out_p, 3 * npad, npad, status_p, chunk, scratch_p)
+    else:
+        rc = lib.vmd_hip_xtc_decode(None, raw_p, info_p, B, natoms, out_p, 3 * npad, npad, status_p)
+    if gpu:
+        torch.cuda.synchronize()
+        out, status = d_out.cpu().numpy(), d_status.cpu().numpy().astype(np.uint32)
     assert rc == 0
     return out[:, :, :natoms], status
 
 
-@pytest.mark.parametrize("chunk", [0, 64, 300])
-def test_device_xtc_decoder_matches_the_host_reader(tmp_path, emu_lib, chunk):
-    """k_xtc_decode (one GPU thread per frame) and the two-pass k_xtc_index + k_xtc_chunks (one thread per chunk of `chunk` atoms;
-    both here on the SIMT emulator) against the host reader on every fixture: the same
-    floats bit for bit; a 68-bit packed triple is reported as unsupported (status 2), a damaged stream as corrupt (status 1) or
-    decoded without leaving the frame's buffers."""
+def _device_decoder_against_host_reader(tmp_path, lib, chunk, gpu, trials=25):
     systems = _systems()
     for name, xyz in systems.items():
         if xyz.shape[1] <= 9:
@@ -310,14 +323,14 @@ def test_device_xtc_decoder_matches_the_host_reader(tmp_path, emu_lib, chunk):
         F = 3
         frames = [xyz + np.float32(0.37 * f) for f in range(F)]
         blob = b"".join(xtc_ref.frame_bytes(frames[f], np.diag([30.0, 30.0, 30.0]), f, 0.0, 1000.0) for f in range(F))
-        got, status = _device_decode(emu_lib, blob, xyz.shape[1], chunk)
+        got, status = _device_decode(lib, blob, xyz.shape[1], chunk, gpu)
         if name == "huge":
             assert (status == 2).all()
             continue
         assert (status == 0).all(), (name, status)
         p = tmp_path / f"{name}.xtc"
         p.write_bytes(blob)
-        t = V.XdrTrajectory(p, lib=emu_lib)
+        t = V.XdrTrajectory(p, lib=lib)
         for f in range(F):
             np.testing.assert_array_equal(got[f], t.load_frame(f)[0], err_msg=name)
     # damaged streams: never out of bounds (the emulator build runs under ASan in scripts/sanitize_emu.sh), some are rejected
@@ -325,13 +338,29 @@ def test_device_xtc_decoder_matches_the_host_reader(tmp_path, emu_lib, chunk):
     xyz = systems["water"]
     blob = xtc_ref.frame_bytes(xyz, np.diag([30.0, 30.0, 30.0]), 0, 0.0, 1000.0)
     rejected = 0
-    for trial in range(25):
+    for trial in range(trials):
         b = bytearray(blob)
         for _ in range(rng.integers(1, 5)):
             b[rng.integers(92, len(b))] = rng.integers(0, 256)
-        _, status = _device_decode(emu_lib, bytes(b), xyz.shape[1], chunk)
+        _, status = _device_decode(lib, bytes(b), xyz.shape[1], chunk, gpu)
         rejected += int(status[0] != 0)
     assert rejected > 0
+
+
+@pytest.mark.parametrize("chunk", [0, 64, 300, -1])
+def test_device_xtc_decoder_matches_the_host_reader(tmp_path, emu_lib, chunk):
+    """k_xtc_decode (one GPU thread per frame), the two-pass k_xtc_index + k_xtc_chunks (one thread per chunk of `chunk` atoms) and
+    k_xtc_wave (chunk -1: one wave per frame, speculative group walk; all here on the SIMT emulator) against the host reader on
+    every fixture: the same floats bit for bit; a 68-bit packed triple is reported as unsupported (status 2), a damaged stream as
+    corrupt (status 1) or decoded without leaving the frame's buffers."""
+    _device_decoder_against_host_reader(tmp_path, emu_lib, chunk, False)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("chunk", [-1, 0, 128])
+def test_device_xtc_decoder_matches_the_host_reader_on_the_gpu(tmp_path, gpu_lib, chunk):
+    """The same fixtures through the hipcc-built kernels on the MI355X (device memory from torch)."""
+    _device_decoder_against_host_reader(tmp_path, gpu_lib, chunk, True, trials=10)
 
 
 def test_xtc_batches_decoded_on_the_device_through_the_evaluator(tmp_path, emu_lib, oracle):
@@ -352,7 +381,7 @@ def test_xtc_batches_decoded_on_the_device_through_the_evaluator(tmp_path, emu_l
     old_b = emu_lib.vmd_set_option(b"batch_frames", 4)
     res = {}
     try:
-        for mode in (0, 1, 2):
+        for mode in (0, 1, 2, 3):
             old = emu_lib.vmd_set_option(b"xtc_device_decode", mode)
             old_c = emu_lib.vmd_set_option(b"xtc_chunk", 64)
             try:
@@ -371,4 +400,5 @@ def test_xtc_batches_decoded_on_the_device_through_the_evaluator(tmp_path, emu_l
         emu_lib.vmd_set_option(b"batch_frames", old_b)
     np.testing.assert_array_equal(res[1], res[0])
     np.testing.assert_array_equal(res[2], res[0])
+    np.testing.assert_array_equal(res[3], res[0])
     assert res[0].sum() > 0

@@ -33,8 +33,8 @@ def _xdr_through_the_evaluator(lib, oracle, tmp_path, box, F, N, device_check):
         res[fmt] = got
         if fmt == "xtc":
             # the same file with the batch decompressed on the device: one thread per frame (1), index pass + one thread per
-            # chunk (2); identical integers, every frame counted as device-decoded
-            for mode in (1, 2):
+            # chunk (2), one wave per frame (3); identical integers, every frame counted as device-decoded
+            for mode in (1, 2, 3):
                 old_d = lib.vmd_set_option(b"xtc_device_decode", mode)
                 old_c = lib.vmd_set_option(b"xtc_chunk", 256)
                 old = lib.vmd_set_option(b"batch_frames", max(4, F // 3))

@@ -79,7 +79,8 @@ struct Options {
     std::atomic<int> nxf_divisor{16};    // fine x cell = rmax / nxf_divisor (8 / 12 / 16 / 24 / 32 measured: 16 is +0.8 % on c3, profiles/r02l_ab_fine_cells.txt)
     std::atomic<int> cells_aos{1};       // sort through 16-byte records + repack
     std::atomic<int> xtc_device_decode{0};   // frames offered raw (load_raw) are decompressed on the device: 1 = one thread per
-                                             // frame (k_xtc_decode), 2 = index pass + one thread per chunk (k_xtc_index / k_xtc_chunks)
+                                             // frame (k_xtc_decode), 2 = index pass + one thread per chunk (k_xtc_index / k_xtc_chunks),
+                                             // 3 = one wave per frame (k_xtc_wave)
     std::atomic<int> xtc_chunk{256};         // atoms per chunk of variant 2
     std::atomic<int> sdf_dense{0};       // dense-target SDF scatter (stream whole frames, select by tag): measured slower, off
     std::atomic<int> sdf_arith{1};       // SDF target lists that are arithmetic progressions are generated on the device (0 = always load the index list)
@@ -1126,7 +1127,9 @@ static int fetch_stage_raw(vmd_script_eval_t* e, Stage& st, vmd_trajectory_i* tr
     if (!st.d_raw_info.upload(st.raw_info.data(), nb, e->copy_stream)) return -1;
     if (hipMemcpyAsync(st.d_raw.p, st.hraw, total, hipMemcpyHostToDevice, e->copy_stream) != hipSuccess) { vmd_fail("hipMemcpyAsync of the compressed batch failed"); return -1; }
     int rc;
-    if (g_opt.xtc_device_decode.load() >= 2) {
+    if (g_opt.xtc_device_decode.load() >= 3) {
+        rc = vmd_hip_xtc_decode_wave(e->copy_stream, st.d_raw.p, st.d_raw_info.p, (int)nb, (int)num_atoms, st.d.p, 3 * npad, npad, st.d_raw_status.p);
+    } else if (g_opt.xtc_device_decode.load() == 2) {
         const int chunk = std::max(64, g_opt.xtc_chunk.load());
         if (!st.d_raw_scratch.ensure((vmd_hip_xtc_scratch_bytes((int)nb, (int)num_atoms, chunk) + 7) / 8)) return -1;
         rc = vmd_hip_xtc_decode_chunked(e->copy_stream, st.d_raw.p, st.d_raw_info.p, (int)nb, (int)num_atoms, st.d.p, 3 * npad, npad,

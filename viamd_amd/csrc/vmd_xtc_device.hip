@@ -69,6 +69,43 @@ __device__ __forceinline__ uint64_t xtc_get(Bits& b, int bits) {
     return w >> (64 - bits);
 }
 
+// The reader of variant 3: a lane decodes ONE group, so its first four words (>= 193 bits behind the group's first bit: every
+// group of up to 128 bits, i.e. a large triple and two or three small ones) are requested together up front and a field is picked
+// out of registers; longer groups (runs of 4+ atoms) fetch the words they need.  No load sits between two fields of a normal group.
+struct BitsG {
+    const uint64_t* words;
+    uint64_t nwords;
+    uint64_t first;              // index of w[0]
+    uint64_t pos;
+    uint64_t w[4];
+};
+__device__ __forceinline__ void xtc_open(BitsG& b, const unsigned char* base, uint64_t nbytes, uint64_t pos) {
+    b.words = (const uint64_t*)base;
+    b.nwords = (nbytes + 32ull) >> 3;
+    b.pos = pos;
+    b.first = pos >> 6;
+    for (int k = 0; k < 4; ++k) {
+        const uint64_t i = b.first + (uint64_t)k;
+        b.w[k] = __builtin_bswap64(b.words[i < b.nwords ? i : b.nwords - 1]);
+    }
+}
+__device__ __forceinline__ uint64_t xtc_get(BitsG& b, int bits) {
+    const unsigned sh = (unsigned)(b.pos & 63ull);
+    const uint64_t k = (b.pos >> 6) - b.first;
+    uint64_t hi, lo;
+    if (k <= 2) {
+        hi = k == 0 ? b.w[0] : (k == 1 ? b.w[1] : b.w[2]);
+        lo = k == 0 ? b.w[1] : (k == 1 ? b.w[2] : b.w[3]);
+    } else {
+        const uint64_t i = b.first + k;
+        hi = __builtin_bswap64(b.words[i < b.nwords ? i : b.nwords - 1]);
+        lo = __builtin_bswap64(b.words[i + 1 < b.nwords ? i + 1 : b.nwords - 1]);
+    }
+    const uint64_t w = sh ? ((hi << sh) | (lo >> (64u - sh))) : hi;
+    b.pos += (uint64_t)bits;
+    return w >> (64 - bits);
+}
+
 __device__ __forceinline__ int xtc_bit_length(uint64_t v) { return v ? 64 - __builtin_clzll(v) : 0; }
 
 struct Radix {
@@ -92,7 +129,8 @@ __device__ __forceinline__ uint64_t xtc_div(uint64_t w, uint64_t d, double inv) 
 
 // one packed triple of `bits` bits: little-endian bytes on the wire, the partial top byte last.  Numbers up to 64 bits are
 // handled here; false = the number has bits set above 2^64 (possible for bits > 64 only): the caller reports status 2.
-__device__ __forceinline__ bool xtc_triple(Bits& b, int bits, const Radix& rx, int out[3]) {
+template <class BR>
+__device__ __forceinline__ bool xtc_triple(BR& b, int bits, const Radix& rx, int out[3]) {
     const int q = (bits - 1) >> 3, r = bits - 8 * q;            // q full bytes, then r in [1, 8] bits
     uint64_t w;
     bool ok = true;
@@ -155,78 +193,89 @@ __device__ __forceinline__ uint32_t xtc_setup(const vmd_xtc_frame_t& fi, FrameSe
     return 0;
 }
 
+// One atom group at the reader's position: the large triple, the run flag, the run's small triples.  The decoder state at a group
+// boundary is exactly (pos, i, smallidx, run); `small` is the radix record of `smallidx` on entry.  Advances i / smallidx / run
+// (the caller refreshes `small` when smallidx moved).  Returns the status: 0 ok, 1 corrupt, 2 a number above 2^64.
+template <class BR>
+__device__ __forceinline__ uint32_t xtc_group(BR& br, const vmd_xtc_frame_t& fi, const FrameSetup& fs, int natoms, int& i, int& smallidx,
+                                              int& run, const Radix& small, float* __restrict__ x, float* __restrict__ y,
+                                              float* __restrict__ z) {
+    const float invp = fs.invp;
+    const int smallnum = kXtcMagic[smallidx] / 2;
+    uint32_t st = 0;
+    int cur[3], prev[3];
+    if (fs.bitsize == 0) {
+        for (int k = 0; k < 3; ++k) {
+            const int nb = fs.bitsizeint[k];
+            if (nb > 24) {      // two reads from the stream: sequenced explicitly (operands of | have no evaluation order)
+                const uint64_t hi = xtc_get(br, nb - 24);
+                const uint64_t lo = xtc_get(br, 24);
+                cur[k] = (int)(uint32_t)((hi << 24) | lo);
+            } else {
+                cur[k] = (int)(uint32_t)xtc_get(br, nb);
+            }
+        }
+    } else {
+        if (!xtc_triple(br, fs.bitsize, fs.large, cur)) return 2;
+    }
+    for (int k = 0; k < 3; ++k) { cur[k] += fi.minint[k]; prev[k] = cur[k]; }
+    int is_smaller = 0;
+    if (xtc_get(br, 1)) {
+        run = (int)xtc_get(br, 5);
+        is_smaller = run % 3;
+        run -= is_smaller;
+        is_smaller--;
+    }
+    if (run > 0) {
+        if (i + 1 + run / 3 > natoms) return 1;
+        for (int k = 0; k < run; k += 3) {
+            int d[3], nxt[3];
+            if (!xtc_triple(br, smallidx, small, d)) st = 2;
+            for (int c = 0; c < 3; ++c) nxt[c] = d[c] + prev[c] - smallnum;
+            x[i] = ((float)nxt[0] * invp) * 10.0f;
+            y[i] = ((float)nxt[1] * invp) * 10.0f;
+            z[i] = ((float)nxt[2] * invp) * 10.0f;
+            ++i;
+            if (k == 0) {            // the large triple in front of the run is the SECOND atom of the pair
+                x[i] = ((float)cur[0] * invp) * 10.0f;
+                y[i] = ((float)cur[1] * invp) * 10.0f;
+                z[i] = ((float)cur[2] * invp) * 10.0f;
+                ++i;
+            }
+            for (int c = 0; c < 3; ++c) prev[c] = nxt[c];
+        }
+        if (st) return st;
+    } else {
+        x[i] = ((float)cur[0] * invp) * 10.0f;
+        y[i] = ((float)cur[1] * invp) * 10.0f;
+        z[i] = ((float)cur[2] * invp) * 10.0f;
+        ++i;
+    }
+    if (is_smaller) {
+        smallidx += is_smaller;
+        if (smallidx <= XTC_FIRSTIDX - 1 || smallidx >= XTC_LASTIDX) return 1;
+    }
+    return 0;
+}
+
 // Decode the atom groups that start at bit `pos` with atom `i`, state (smallidx, run), up to atom `end_i` (a group boundary or
-// natoms).  The decoder state at a group boundary is exactly (pos, i, smallidx, run): smallnum is magic[smallidx] / 2 and the
-// "smaller" value magic[smallidx - 1] / 2 at all times.  Returns the status.
+// natoms).  Returns the status.
 __device__ __forceinline__ uint32_t xtc_decode_range(const unsigned char* stream, const vmd_xtc_frame_t& fi, const FrameSetup& fs,
                                                      int natoms, uint64_t pos, int i, int smallidx, int run, int end_i,
                                                      float* __restrict__ x, float* __restrict__ y, float* __restrict__ z) {
-    const float invp = fs.invp;
-    int smallnum = kXtcMagic[smallidx] / 2;
     Radix small;
     xtc_radix(small, (uint32_t)kXtcMagic[smallidx], (uint32_t)kXtcMagic[smallidx]);
     Bits br;
     xtc_open(br, stream, fi.nbytes, pos);
     const uint64_t nbits = 8ull * fi.nbytes;
-    uint32_t st = 0;
     while (i < end_i) {
-        int cur[3], prev[3];
-        if (fs.bitsize == 0) {
-            for (int k = 0; k < 3; ++k) {
-                const int nb = fs.bitsizeint[k];
-                if (nb > 24) {      // two reads from the stream: sequenced explicitly (operands of | have no evaluation order)
-                    const uint64_t hi = xtc_get(br, nb - 24);
-                    const uint64_t lo = xtc_get(br, 24);
-                    cur[k] = (int)(uint32_t)((hi << 24) | lo);
-                } else {
-                    cur[k] = (int)(uint32_t)xtc_get(br, nb);
-                }
-            }
-        } else {
-            if (!xtc_triple(br, fs.bitsize, fs.large, cur)) { st = 2; break; }
-        }
-        for (int k = 0; k < 3; ++k) { cur[k] += fi.minint[k]; prev[k] = cur[k]; }
-        int is_smaller = 0;
-        if (xtc_get(br, 1)) {
-            run = (int)xtc_get(br, 5);
-            is_smaller = run % 3;
-            run -= is_smaller;
-            is_smaller--;
-        }
-        if (run > 0) {
-            if (i + 1 + run / 3 > natoms) { st = 1; break; }
-            for (int k = 0; k < run; k += 3) {
-                int d[3], nxt[3];
-                if (!xtc_triple(br, smallidx, small, d)) st = 2;
-                for (int c = 0; c < 3; ++c) nxt[c] = d[c] + prev[c] - smallnum;
-                x[i] = ((float)nxt[0] * invp) * 10.0f;
-                y[i] = ((float)nxt[1] * invp) * 10.0f;
-                z[i] = ((float)nxt[2] * invp) * 10.0f;
-                ++i;
-                if (k == 0) {            // the large triple in front of the run is the SECOND atom of the pair
-                    x[i] = ((float)cur[0] * invp) * 10.0f;
-                    y[i] = ((float)cur[1] * invp) * 10.0f;
-                    z[i] = ((float)cur[2] * invp) * 10.0f;
-                    ++i;
-                }
-                for (int c = 0; c < 3; ++c) prev[c] = nxt[c];
-            }
-            if (st) break;
-        } else {
-            x[i] = ((float)cur[0] * invp) * 10.0f;
-            y[i] = ((float)cur[1] * invp) * 10.0f;
-            z[i] = ((float)cur[2] * invp) * 10.0f;
-            ++i;
-        }
-        if (is_smaller) {
-            smallidx += is_smaller;
-            if (smallidx <= XTC_FIRSTIDX - 1 || smallidx >= XTC_LASTIDX) { st = 1; break; }
-            smallnum = kXtcMagic[smallidx] / 2;
-            xtc_radix(small, (uint32_t)kXtcMagic[smallidx], (uint32_t)kXtcMagic[smallidx]);
-        }
-        if (br.pos > nbits) { st = 1; break; }
+        const int before = smallidx;
+        const uint32_t st = xtc_group(br, fi, fs, natoms, i, smallidx, run, small, x, y, z);
+        if (st) return st;
+        if (smallidx != before) xtc_radix(small, (uint32_t)kXtcMagic[smallidx], (uint32_t)kXtcMagic[smallidx]);
+        if (br.pos > nbits) return 1;
     }
-    return st;
+    return 0;
 }
 
 // ---- variant 1: one thread per frame, the whole stream
@@ -343,6 +392,152 @@ __global__ __launch_bounds__(64) void k_xtc_chunks(const unsigned char* __restri
     if (st) atomicMax(&status[f], st);
 }
 
+// ---- variant 3: one WAVE per frame.  The serial part of a stream is only the walk from group to group (flag bit, 5-bit run code,
+// field widths); everything else - mixed-radix splits, conversions, stores - is independent per group.  So a wave walks its frame
+// and decodes it 64 groups at a time:
+//   * window: the next 192 big-endian dwords of the stream sit in three VGPRs (one dword per lane, coalesced 256-byte loads issued
+//     a block ahead), so the walk never waits for memory and needs no LDS allocation (the pair kernel next door owns the CU's LDS);
+//   * speculative walk: a group whose flag bit is 0 inherits (run, smallidx) and has the same length L as the one before it, so
+//     lane k looks at the flag bit of "group k from here, if every flag before it is 0" (two ds_bpermute per dword out of the
+//     window); a ballot finds the first flag that is set (or leaves the window / the frame), every group before it is confirmed at
+//     once, the flagged group is stepped over with scalar arithmetic on its 6-bit code, and the walk speculates again from there.
+//     ~60 instructions confirm 1 + (zero-flag run) groups: 12 on average for the synthetic water box, 1-3 for a real liquid;
+//   * every confirmed group gets a lane: (bit position, atom index, smallidx, run) - the complete decoder state at a group boundary.
+//     When 64 are known (or the frame ends) all lanes decode their group with the code of variant 1 (xtc_group), reading the
+//     stream through L1 (the window loads touched those lines a moment ago).  The reciprocals of the 64 possible small radices are
+//     computed once per wave, one per lane, and fetched with ds_bpermute instead of two fp64 divisions per group.
+// A batch of 1 000 frames is 1 000 waves: one per SIMD of the chip.
+#ifndef VMD_SHFL_U32
+#define VMD_SHFL_U32(v, src) ((uint32_t)__shfl((int)(v), (int)(src)))
+#define VMD_READLANE_U32(v, lane) ((uint32_t)__builtin_amdgcn_readlane((int)(v), (int)(lane)))
+#define VMD_XTC_BALLOT(pred) __builtin_amdgcn_ballot_w64(pred)
+#endif
+
+__device__ __forceinline__ double xtc_shfl_f64(double v, int src) {
+    uint64_t b;
+    memcpy(&b, &v, 8);
+    const uint32_t lo = VMD_SHFL_U32((uint32_t)b, src), hi = VMD_SHFL_U32((uint32_t)(b >> 32), src);
+    b = ((uint64_t)hi << 32) | lo;
+    double r;
+    memcpy(&r, &b, 8);
+    return r;
+}
+
+__global__ __launch_bounds__(64) void k_xtc_wave(const unsigned char* __restrict__ raw, const vmd_xtc_frame_t* __restrict__ info,
+                                                 int B, int natoms, float* __restrict__ xyz, size_t frame_stride, size_t row_stride,
+                                                 uint32_t* __restrict__ status) {
+    const int f = blockIdx.x;
+    const int lane = (int)threadIdx.x;
+    if (f >= B) return;
+    const vmd_xtc_frame_t fi = info[f];
+    FrameSetup fs;
+    uint32_t st = xtc_setup(fi, fs);
+    if (!st && fi.nbytes >= (1ull << 27)) st = 2;                 // bit positions are kept in 32 bits here
+    if (st) {
+        if (lane == 0) status[f] = st;
+        return;
+    }
+    const unsigned char* stream = raw + fi.offset;
+    const uint32_t* dw = (const uint32_t*)stream;
+    const uint32_t ndw = (uint32_t)((fi.nbytes + 32ull) >> 2);   // readable dwords (the pad behind the stream included)
+    const uint32_t nbits = (uint32_t)(8ull * fi.nbytes);
+    const uint32_t large_bits = (uint32_t)(fs.bitsize ? fs.bitsize : fs.bitsizeint[0] + fs.bitsizeint[1] + fs.bitsizeint[2]);
+    float* x = xyz + (size_t)f * frame_stride;
+    float* y = x + row_stride;
+    float* z = y + row_stride;
+    // lane l keeps the reciprocals of small radix XTC_FIRSTIDX + l (64 lanes = the 64 legal values of smallidx)
+    const uint32_t my_magic = (uint32_t)kXtcMagic[XTC_FIRSTIDX + lane];
+    const double t_inv2 = 1.0 / (double)my_magic, t_inv12 = 1.0 / (double)((uint64_t)my_magic * my_magic);
+
+    uint32_t base = 0;                                            // first dword of the window
+    auto load_block = [&](uint32_t first) {
+        uint32_t k = first + (uint32_t)lane;
+        k = k < ndw ? k : ndw - 1;
+        return __builtin_bswap32(dw[k]);
+    };
+    uint32_t w0 = load_block(0), w1 = load_block(64), w2 = load_block(128);
+    auto window = [&](uint32_t q) {                               // dword q of the window, q < 128 (anything for q >= 128)
+        const uint32_t a = VMD_SHFL_U32(w0, q & 63u), b = VMD_SHFL_U32(w1, q & 63u);
+        return (q & 64u) ? b : a;
+    };
+
+    uint32_t pos = 0;                                             // uniform walk state: next group's first bit, its first atom, ...
+    int i = 0, smallidx = fi.smallidx, run = 0;
+    int g = 0;                                                    // groups waiting in the lanes
+    uint32_t vpos = 0, vstate = (uint32_t)XTC_FIRSTIDX;           // per lane: the group this lane will decode
+    int vatom = 0;
+    for (;;) {
+        const bool finished = i >= natoms || st != 0;
+        if (g == 64 || (finished && g > 0)) {
+            const int sidx = (int)(vstate & 255u);
+            Radix small;
+            const uint32_t m = (uint32_t)kXtcMagic[sidx];
+            small.s1 = small.s2 = m;
+            small.s12 = (uint64_t)m * m;
+            small.inv2 = xtc_shfl_f64(t_inv2, (sidx - XTC_FIRSTIDX) & 63);
+            small.inv12 = xtc_shfl_f64(t_inv12, (sidx - XTC_FIRSTIDX) & 63);
+            uint32_t lst = 0;
+            if (lane < g) {
+                BitsG br;
+                xtc_open(br, stream, fi.nbytes, (uint64_t)vpos);
+                int gi = vatom, gs = sidx, gr = (int)(vstate >> 8);
+                lst = xtc_group(br, fi, fs, natoms, gi, gs, gr, small, x, y, z);
+                if (!lst && br.pos > (uint64_t)nbits) lst = 1;
+            }
+            if (VMD_XTC_BALLOT(lst == 1u)) st = 1;
+            else if (VMD_XTC_BALLOT(lst == 2u) && !st) st = 2;
+            g = 0;
+        }
+        if (i >= natoms || st != 0) break;
+        while ((pos >> 5) - base >= 64u) {                        // slide by whole blocks; the new block was requested a block ago
+            w0 = w1; w1 = w2;
+            base += 64u;
+            w2 = load_block(base + 128u);
+        }
+        const int per = 1 + run / 3;                              // atoms and bits of a group that inherits (run, smallidx)
+        const uint32_t L = large_bits + 1u + (uint32_t)(run / 3) * (uint32_t)smallidx;
+        const uint32_t P = pos + large_bits + (uint32_t)lane * L; // this lane's flag bit
+        const uint32_t q = (P >> 5) - base;
+        const uint32_t d0 = window(q), d1 = window(q + 1u);
+        const uint32_t sh = P & 31u;
+        const uint32_t code = (uint32_t)(((((uint64_t)d0 << 32) | (uint64_t)d1) << sh) >> 58);   // flag + run code
+        // why the speculation ends at this lane: 3 = past the last atom, 2 = outside the window, 1 = flag set
+        const uint32_t reason = (i + lane * per >= natoms) ? 3u : (q + 1u >= 128u) ? 2u : (code >> 5);
+        const unsigned long long stop = VMD_XTC_BALLOT(reason != 0u);
+        const int n0 = stop ? __builtin_ctzll(stop) : 64;         // groups with flag 0 in front of it
+        const int room = 64 - g;
+        const int take0 = n0 < room ? n0 : room;
+        uint32_t why = 0, code_n0 = 0;
+        if (n0 < 64) {
+            why = VMD_READLANE_U32(reason, n0);
+            code_n0 = VMD_READLANE_U32(code, n0);
+        }
+        const bool flagged = n0 < room && why == 1u;              // the group with the set flag goes along
+        const int ntake = take0 + (flagged ? 1 : 0);
+        const int rel = lane - g;
+        if (rel >= 0 && rel < ntake) {
+            vpos = pos + (uint32_t)rel * L;
+            vatom = i + rel * per;
+            vstate = (uint32_t)smallidx | ((uint32_t)run << 8);
+        }
+        g += ntake;
+        pos += (uint32_t)take0 * L;
+        i += take0 * per;
+        if (flagged) {
+            int nrun = (int)(code_n0 & 31u);
+            const int is_smaller = nrun % 3;
+            nrun -= is_smaller;
+            pos += large_bits + 6u + (uint32_t)(nrun / 3) * (uint32_t)smallidx;
+            i += 1 + nrun / 3;
+            run = nrun;
+            smallidx += is_smaller - 1;
+            if (smallidx <= XTC_FIRSTIDX - 1 || smallidx >= XTC_LASTIDX) st = 1;
+        }
+        if (i > natoms || pos > nbits || ntake == 0) st = 1;      // a group past the last atom / the last bit (ntake == 0: cannot happen)
+    }
+    if (lane == 0) status[f] = st;
+}
+
 }  // namespace
 
 extern "C" size_t vmd_hip_xtc_scratch_bytes(int B, int natoms, int chunk) {
@@ -376,5 +571,13 @@ extern "C" int vmd_hip_xtc_decode(void* stream, const unsigned char* raw, const 
     if (B <= 0) return 0;
     hipLaunchKernelGGL(k_xtc_decode, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, (hipStream_t)stream, raw, info, B, natoms, xyz,
                        frame_stride, row_stride, status);
+    return (int)hipGetLastError();
+}
+
+extern "C" int vmd_hip_xtc_decode_wave(void* stream, const unsigned char* raw, const vmd_xtc_frame_t* info, int B, int natoms,
+                                       float* xyz, size_t frame_stride, size_t row_stride, uint32_t* status) {
+    if (B <= 0) return 0;
+    hipLaunchKernelGGL(k_xtc_wave, dim3((unsigned)B), dim3(64), 0, (hipStream_t)stream, raw, info, B, natoms, xyz, frame_stride,
+                       row_stride, status);
     return (int)hipGetLastError();
 }
