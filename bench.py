@@ -195,16 +195,22 @@ def run_workload(name, args, ctx, steps, warmup, frames=None, with_cpu=False, op
         traj = V.PinnedHostTrajectory(F, w["atoms"])
         traj.copy_from_device(dev_traj, beg, end)
         dev_traj.close()
-    elif args.traj in ("dcd", "xtc", "trr"):    # end to end from a trajectory file (page cache after the first pass)
+    elif args.traj in ("dcd", "xtc", "trr", "xtc-resident"):    # end to end from a trajectory file (page cache after the first pass)
         import tempfile
         dev_traj = traj
         host = V.PinnedHostTrajectory(F, w["atoms"])
         host.copy_from_device(dev_traj)
         dev_traj.close()
-        path = os.path.join(tempfile.gettempdir(), f"viamd_amd_bench_{name}_{rank}.{args.traj}")
-        {"dcd": V.write_dcd, "xtc": V.write_xtc, "trr": V.write_trr}[args.traj](path, host, cell)
+        ext = "xtc" if args.traj == "xtc-resident" else args.traj
+        path = os.path.join(tempfile.gettempdir(), f"viamd_amd_bench_{name}_{rank}.{ext}")
+        {"dcd": V.write_dcd, "xtc": V.write_xtc, "trr": V.write_trr}[ext](path, host, cell)
         host.close()
         traj = V.DcdTrajectory(path) if args.traj == "dcd" else V.XdrTrajectory(path)
+        if args.traj == "xtc-resident":          # the file is read and uploaded ONCE, still compressed; every step decodes from HBM
+            t1 = time.perf_counter()
+            traj = V.CompressedDeviceTrajectory(traj)
+            resident_info = {"upload_s": time.perf_counter() - t1, "hbm_bytes": traj.device_bytes(),
+                             "file_bytes_per_frame": os.path.getsize(path) / F}
     torch.cuda.synchronize()
     gen_s = time.perf_counter() - t0
 
@@ -245,7 +251,7 @@ def run_workload(name, args, ctx, steps, warmup, frames=None, with_cpu=False, op
     local_frames = end - beg
 
     kernel_ms, kernel_launches = {}, {}
-    for k in ("rdf_pencil", "rdf_brute", "cells_build", "sdf_align", "sdf_scatter", "distance"):
+    for k in ("rdf_pencil", "rdf_brute", "cells_build", "sdf_align", "sdf_scatter", "distance", "xtc_decode"):
         n = C.c_uint64(0)
         ms = lib.vmd_profile_ms(k.encode(), C.byref(n))
         if n.value:
@@ -291,7 +297,10 @@ def run_workload(name, args, ctx, steps, warmup, frames=None, with_cpu=False, op
                                    f"device accumulators) per step"), "rdf_variant": args.variant,
                    "trajectory": {"device": "resident in HBM", "pinned": "pinned host memory, DMA per batch (PCIe-inclusive)",
                                   "dcd": "DCD file, native reader -> pinned staging -> DMA (file- and PCIe-inclusive)",
-                                  "xtc": "GROMACS XTC file (compressed, 0.01 A grid), native decoder on host threads -> pinned staging -> DMA",
+                                  "xtc": "GROMACS XTC file (compressed, 0.01 A grid): native decoder on host threads -> pinned staging -> DMA, or "
+                                         "(xtc_device_decode) compressed bytes -> pinned staging -> DMA -> k_xtc_wave; file- and PCIe-inclusive",
+                                  "xtc-resident": "GROMACS XTC file uploaded once, kept COMPRESSED in HBM (vmd_rawtraj); every step decompresses its "
+                                                  "batches on the device (k_xtc_wave) - no host work, no PCIe per step",
                                   "trr": "GROMACS TRR file, native reader -> pinned staging -> DMA"}[args.traj]},
         "pairs_per_s": hits_per_step * steps / elapsed,
         "voxel_hits_per_s": voxel_hits * steps / elapsed,
@@ -324,9 +333,11 @@ def run_workload(name, args, ctx, steps, warmup, frames=None, with_cpu=False, op
         except Exception:
             pass
         out["cell_build"] = cb
-    if args.traj == "xtc":
-        # > 0 only with --opt xtc_device_decode=1: the compressed frames crossed PCIe and were decompressed by k_xtc_decode
+    if args.traj in ("xtc", "xtc-resident"):
+        # > 0 only with --opt xtc_device_decode=N or a compressed-resident trajectory: decompressed by the k_xtc_* kernels
         out["config"]["frames_decompressed_on_device_per_step"] = ev.frames_device_decoded()
+        if args.traj == "xtc-resident":
+            out["config"]["compressed_resident"] = resident_info
     ev.close()
     traj.close() if hasattr(traj, "close") else None
     if with_cpu and rank == 0:
@@ -350,7 +361,7 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the short c2 / c4 / c5 runs of the default N = 1 line")
     ap.add_argument("--opt", action="append", default=[], help="library tuning knob key=value (vmd_set_option)")
     ap.add_argument("--tilt", default=None, help="xy,xz,yz in Angstrom: evaluate in a sheared (triclinic) cell of the same volume")
-    ap.add_argument("--traj", default="device", choices=["device", "pinned", "dcd", "xtc", "trr"],
+    ap.add_argument("--traj", default="device", choices=["device", "pinned", "dcd", "xtc", "trr", "xtc-resident"],
                     help="device: frames resident in HBM (the metric); pinned: frames in pinned host memory, PCIe-inclusive; "
                          "dcd / xtc / trr: frames decoded from a trajectory file on disk by the native readers "
                          "(file -> decode on host threads -> pinned staging -> PCIe); xtc is lossy (0.01 A grid)")

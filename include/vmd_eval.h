@@ -93,6 +93,18 @@ typedef struct vmd_raw_frame_t {
     uint64_t nbytes;            /* bytes of the bit stream */
 } vmd_raw_frame_t;
 
+/* Compressed frames resident in HBM (extension): the bit streams of EVERY frame of the trajectory and their decoder records on
+ * the device - 0.3 .. 0.5 of the float bytes for liquids, so 288 GB hold trajectories 2 - 3 times larger than as floats.  The
+ * evaluator decompresses a batch straight from there (k_xtc_wave on the copy stream, under the pair kernel of the previous batch):
+ * no host work and no PCIe traffic per evaluation.  vmd_rawtraj_* builds one from any trajectory that offers load_raw. */
+typedef struct vmd_raw_device_view_t {
+    const unsigned char* base;      /* device: bit streams */
+    const void* info;               /* device: vmd_xtc_frame_t[num_frames] (include/vmd_hip.h), offsets relative to base */
+    const vmd_unitcell_t* cells;    /* host, one per frame */
+    uint32_t codec;                 /* VMD_RAW_CODEC_* */
+    int device;
+} vmd_raw_device_view_t;
+
 typedef struct vmd_trajectory_i {
     void* inst;
     size_t (*num_frames)(void* inst);
@@ -105,6 +117,8 @@ typedef struct vmd_trajectory_i {
      * load_frame.  With vmd_set_option("xtc_device_decode", 1) the evaluator moves the compressed bytes over PCIe and
      * decompresses a whole batch on the GPU (k_xtc_decode). */
     bool (*load_raw)(void* inst, int64_t idx, vmd_frame_header_t* header, vmd_raw_frame_t* info, void* dst, size_t cap);
+    /* extension, may be NULL: the whole trajectory compressed in HBM (see vmd_raw_device_view_t) */
+    bool (*raw_device_view)(void* inst, vmd_raw_device_view_t* out);
 } vmd_trajectory_i;
 
 /* ---- IR: property descriptors (md_script_ir_t stand-in) ----------------------------------------- */
@@ -377,6 +391,17 @@ vmd_xdrwriter_t*  vmd_xdrwriter_open(const char* path, int kind, size_t num_atom
 bool              vmd_xdrwriter_write_frame(vmd_xdrwriter_t* w, int64_t step, float time_ps, const vmd_unitcell_t* cell,
                                             const float* x, const float* y, const float* z);
 bool              vmd_xdrwriter_close(vmd_xdrwriter_t* w);
+
+/* A trajectory kept COMPRESSED in HBM: every frame of `src` (which must offer load_raw, i.e. an XTC file) is read once and uploaded
+ * as stored; evaluations decompress their batches on the device straight from that copy (raw_device_view) - no host work, no PCIe
+ * traffic per evaluation, 0.3 - 0.5 of the float footprint.  VIAMD's counterpart is the host-side frame cache of the loader
+ * (src/loader.cpp:111-159).  `src` is borrowed and must outlive the object (single frames for vis payloads and streams the device
+ * rejects are read through it). */
+typedef struct vmd_rawtraj_t vmd_rawtraj_t;
+vmd_rawtraj_t*    vmd_rawtraj_create(vmd_trajectory_i* src);
+void              vmd_rawtraj_free(vmd_rawtraj_t* t);
+vmd_trajectory_i* vmd_rawtraj_interface(vmd_rawtraj_t* t);
+size_t            vmd_rawtraj_device_bytes(const vmd_rawtraj_t* t);         /* bytes of HBM the compressed frames occupy */
 
 /* host-resident trajectory in pinned memory, float[F][3][npad] (the PCIe-inclusive path: frames cross the bus per batch) */
 typedef struct vmd_hosttraj_t vmd_hosttraj_t;

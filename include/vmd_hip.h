@@ -180,6 +180,9 @@ int vmd_hip_xtc_decode_chunked(void* stream, const unsigned char* raw, const vmd
  * one per lane.  Streams of 2^27 bytes and more are reported as status 2. */
 int vmd_hip_xtc_decode_wave(void* stream, const unsigned char* raw, const vmd_xtc_frame_t* info, int B, int natoms,
                             float* xyz, size_t frame_stride, size_t row_stride, uint32_t* status);
+/* waves that share one frame in k_xtc_wave (each walks the whole stream and decodes every n-th tile of 64 groups); 0 = automatic
+ * (enough to put ~4 waves on every SIMD of the chip); returns the previous value */
+int vmd_hip_set_xtc_waves(int n);
 
 /* synthetic water box (oracle S9 twin): fills frames [frame0, frame0+B) of a batch laid out as above */
 int vmd_hip_synth_frames(void* stream, float* xyz, size_t frame_stride, size_t row_stride, int B, uint32_t frame0,

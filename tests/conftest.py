@@ -64,6 +64,12 @@ def emu_lib():
 @pytest.fixture(scope="session")
 def gpu_lib():
     """The product: hipcc-built libviamd_amd.so on a real GPU.  Fails (not skips) when the library or GPU is missing."""
+    # torch first, as in bench.py: a few GPU tests take device memory from torch, and its bundled HIP runtime only finds the GPU
+    # when it is loaded before the library pulls in the system one (the other order: "No HIP GPUs are available", r03a)
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
     from viamd_amd import default_lib
     lib = default_lib()
     assert lib.vmd_device_count() > 0, "no HIP device visible: -m gpu tests must run on the MI355X box"

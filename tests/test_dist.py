@@ -45,7 +45,7 @@ def _worker(rank, world, port, tmpdir, mode="host"):
         traj = V.DeviceTrajectory(F, N, lib=lib, shard=(beg, end))
         for f in sorted(set(range(beg, end)) | {0}):
             traj.upload_frame(f, vcell, coords[f, 0], coords[f, 1], coords[f, 2])
-        if rank == 1:
+        if rank == world - 1:       # world 4: the EMPTY shard [5, 5) - nothing is resident there, it is not "the whole trajectory"
             import pytest
             with pytest.raises(V.VmdError, match="not resident"):
                 ev.frame_range(V.MolSystem(N, mass=mass, unitcell=vcell), traj, 0, F)
@@ -74,7 +74,7 @@ def test_shard_frames_covers_everything():
 import pytest
 
 
-@pytest.mark.parametrize("mode,world", [("host", 2), ("shard", 2), ("host", 4)])
+@pytest.mark.parametrize("mode,world", [("host", 2), ("shard", 2), ("host", 4), ("shard", 4)])
 def test_two_rank_gloo_merge_matches_oracle(oracle, emu_lib, tmp_path, mode, world):
     """every rank evaluates its block of frames, ONE vmd_eval_reduce (C++, behind the ABI) merges; `shard`: each rank holds
     only its block of a device trajectory; 4 ranks on 5 frames: blocks of 2, 2, 1 and an EMPTY block (a rank without frames still
@@ -82,6 +82,7 @@ def test_two_rank_gloo_merge_matches_oracle(oracle, emu_lib, tmp_path, mode, wor
     import cases
     from viamd_amd import _lib as L
     port = 29500 + (os.getpid() % 2000) + (7 if mode == "shard" else 0) + 13 * (world - 2)
+    # ("shard", 4): rank 3 owns no frame; its device view must refuse every range (it used to read as "unsharded")
     mp.spawn(_worker, args=(world, port, str(tmp_path), mode), nprocs=world, join=True)
     F = 5
     coords, structures, mass = cases.sdf_system(oracle, 21, 900, 36.0, F)

@@ -402,3 +402,18 @@ def test_xtc_batches_decoded_on_the_device_through_the_evaluator(tmp_path, emu_l
     np.testing.assert_array_equal(res[2], res[0])
     np.testing.assert_array_equal(res[3], res[0])
     assert res[0].sum() > 0
+    # the same file kept compressed in device memory (vmd_rawtraj_*): batches are decoded from the resident copy whatever the option
+    # says, two evaluations in a row, several frame ranges; a TRR file has no compressed form
+    old_b = emu_lib.vmd_set_option(b"batch_frames", 3)
+    try:
+        ct = V.CompressedDeviceTrajectory(V.XdrTrajectory(p, lib=emu_lib))
+        assert 0 < ct.device_bytes() < coords.nbytes
+        for rep in range(2):
+            ev = V.ScriptEval(F, ir)
+            assert ev.frame_range(sysm, ct, 0, 4) and ev.frame_range(sysm, ct, 4, F)
+            np.testing.assert_array_equal(ev.property_data("g").counts, res[0])
+            assert ev.frames_device_decoded() == F
+        with pytest.raises(V.VmdError, match="compressed"):
+            V.CompressedDeviceTrajectory(V.XdrTrajectory(q, lib=emu_lib))
+    finally:
+        emu_lib.vmd_set_option(b"batch_frames", old_b)

@@ -70,7 +70,8 @@ class XtcFrame(C.Structure):             # vmd_xtc_frame_t (include/vmd_hip.h)
 class TrajectoryI(C.Structure):
     _fields_ = [("inst", C.c_void_p), ("num_frames", NUM_FRAMES_FN), ("num_atoms", NUM_ATOMS_FN),
                 ("load_frame", LOAD_FRAME_FN), ("device_view", DEVICE_VIEW_FN), ("host_view", HOST_VIEW_FN),
-                ("load_raw", C.c_void_p)]          # native readers only (compressed frames for the device decoder); NULL here
+                ("load_raw", C.c_void_p),          # native readers only (compressed frames for the device decoder); NULL here
+                ("raw_device_view", C.c_void_p)]   # vmd_rawtraj_* only (compressed frames resident in HBM); NULL here
 
 
 class Aggregate(C.Structure):
@@ -172,6 +173,10 @@ SIGNATURES = [
     ("vmd_devtraj_set_cell", C.c_bool, [_vp, C.c_size_t, C.c_size_t, C.POINTER(Unitcell)]),
     ("vmd_devtraj_synth", C.c_bool, [_vp, C.c_uint64, C.c_float, C.c_float, C.c_uint32, C.c_size_t, C.c_size_t]),
     ("vmd_devtraj_device_ptr", _vp, [_vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    ("vmd_rawtraj_create", _vp, [_vp]),
+    ("vmd_rawtraj_free", None, [_vp]),
+    ("vmd_rawtraj_interface", C.POINTER(TrajectoryI), [_vp]),
+    ("vmd_rawtraj_device_bytes", C.c_size_t, [_vp]),
     ("vmd_hosttraj_create", _vp, [C.c_size_t, C.c_size_t]),
     ("vmd_hosttraj_free", None, [_vp]),
     ("vmd_hosttraj_interface", C.POINTER(TrajectoryI), [_vp]),
@@ -203,6 +208,7 @@ SIGNATURES = [
     # vmd_hip.h
     ("vmd_hip_xtc_decode", C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _vp, C.c_size_t, C.c_size_t, _vp]),
     ("vmd_hip_xtc_decode_wave", C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _vp, C.c_size_t, C.c_size_t, _vp]),
+    ("vmd_hip_set_xtc_waves", C.c_int, [C.c_int]),
     ("vmd_hip_xtc_scratch_bytes", C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     ("vmd_hip_xtc_decode_chunked", C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _vp, C.c_size_t, C.c_size_t, _vp, C.c_int, _vp]),
     ("vmd_hip_bbox", C.c_int, [_vp, _vp, C.c_size_t, C.c_size_t, C.c_int, C.c_int, _vp]),

@@ -82,6 +82,7 @@ struct Options {
                                              // frame (k_xtc_decode), 2 = index pass + one thread per chunk (k_xtc_index / k_xtc_chunks),
                                              // 3 = one wave per frame (k_xtc_wave)
     std::atomic<int> xtc_chunk{256};         // atoms per chunk of variant 2
+    std::atomic<int> stage_frames{128};      // frames per staged batch of a host / file trajectory (batch_frames <= 0)
     std::atomic<int> sdf_dense{0};       // dense-target SDF scatter (stream whole frames, select by tag): measured slower, off
     std::atomic<int> sdf_arith{1};       // SDF target lists that are arithmetic progressions are generated on the device (0 = always load the index list)
     std::atomic<int> rdf_classes{1};     // co-evaluated RDFs of one range share pair passes through disjoint atom classes (0 = one pass per property)
@@ -110,6 +111,8 @@ extern "C" int vmd_set_option(const char* key, int value) {
     else if (!strcmp(key, "sdf_dense")) o = &g_opt.sdf_dense;
     else if (!strcmp(key, "xtc_device_decode")) o = &g_opt.xtc_device_decode;
     else if (!strcmp(key, "xtc_chunk")) o = &g_opt.xtc_chunk;
+    else if (!strcmp(key, "xtc_waves")) return vmd_hip_set_xtc_waves(value);
+    else if (!strcmp(key, "stage_frames")) o = &g_opt.stage_frames;
     else if (!strcmp(key, "rdf_classes")) o = &g_opt.rdf_classes;
     else if (!strcmp(key, "sdf_arith")) o = &g_opt.sdf_arith;
     else if (!strcmp(key, "sdf_ilp")) return vmd_hip_set_sdf_ilp(value);
@@ -495,6 +498,7 @@ struct vmd_script_eval_t {
     hipStream_t stream = nullptr;
     int device = 0;
     Profiler prof;
+    Profiler prof_copy;                               // events on copy_stream (device decode of staged batches): resolved by settle_stage
     // batch scratch.  Two stages: while the kernels of batch k run, the host loads batch k+1 through load_frame into
     // the other pinned buffer and its H2D copy runs on copy_stream (trajectory staging).
     struct Stage {
@@ -508,6 +512,7 @@ struct vmd_script_eval_t {
         DevBuf<uint32_t> d_raw_status;
         DevBuf<uint64_t> d_raw_scratch;          // checkpoints of the two-pass decoder
         uint32_t* h_raw_status = nullptr; size_t h_raw_status_cap = 0;
+        bool raw_pending = false;                // a device decode is queued behind `ready`: its status words are checked before use
         DevBuf<float> d_boxes;
         std::vector<float> h_boxes;              // [nb][6]: L, 1/L
         std::vector<vmd_unitcell_t> cells;
@@ -1067,11 +1072,41 @@ struct BatchSrc {
     size_t frame_stride = 0, row_stride = 0;
 };
 
-// Device-side decompression of a staged batch (vmd_trajectory_i::load_raw + k_xtc_decode): the compressed bit streams are read
-// into pinned memory on the decode threads, cross PCIe as they are (0.4x the float bytes for water) and are decompressed by one
-// GPU thread per frame on the copy stream, i.e. under the kernels of the previous batch.  Returns 1 when the batch now sits in
-// st.d, 0 when it has to go through load_frame (a frame is not available raw, or the device reported a stream it does not
-// handle), -1 on error.
+// Device-side decompression of a staged batch (vmd_trajectory_i::load_raw + k_xtc_wave): the compressed bit streams are read
+// into pinned memory on the decode threads, cross PCIe as they are (0.4x the float bytes for water) and are decompressed on the
+// copy stream, i.e. under the kernels of the previous batch.  Nothing here waits for the device: the status words come back
+// with the batch's `ready` event and are looked at when the batch is about to be used (settle_stage).  Returns 1 when the decode
+// is queued into st.d, 0 when the batch has to go through load_frame (a frame is not available raw), -1 on error.
+static int launch_raw_decode(vmd_script_eval_t* e, Stage& st, const unsigned char* d_raw, const vmd_xtc_frame_t* d_info, size_t num_atoms,
+                             size_t nb, size_t npad) {
+    if (nb > st.h_raw_status_cap) {
+        if (st.h_raw_status) (void)hipHostFree(st.h_raw_status);
+        st.h_raw_status = nullptr; st.h_raw_status_cap = 0;
+        if (hipHostMalloc((void**)&st.h_raw_status, nb * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) { vmd_fail("hipHostMalloc failed"); return -1; }
+        st.h_raw_status_cap = nb;
+    }
+    if (!st.d.ensure(nb * 3 * npad) || !st.d_raw_status.ensure(nb)) return -1;
+    int rc;
+    const int mode = g_opt.xtc_device_decode.load();
+    e->prof_copy.begin("xtc_decode", e->copy_stream);
+    if (mode == 2) {
+        const int chunk = std::max(64, g_opt.xtc_chunk.load());
+        if (!st.d_raw_scratch.ensure((vmd_hip_xtc_scratch_bytes((int)nb, (int)num_atoms, chunk) + 7) / 8)) return -1;
+        rc = vmd_hip_xtc_decode_chunked(e->copy_stream, d_raw, d_info, (int)nb, (int)num_atoms, st.d.p, 3 * npad, npad,
+                                        st.d_raw_status.p, chunk, st.d_raw_scratch.p);
+    } else if (mode == 1) {
+        rc = vmd_hip_xtc_decode(e->copy_stream, d_raw, d_info, (int)nb, (int)num_atoms, st.d.p, 3 * npad, npad, st.d_raw_status.p);
+    } else {
+        rc = vmd_hip_xtc_decode_wave(e->copy_stream, d_raw, d_info, (int)nb, (int)num_atoms, st.d.p, 3 * npad, npad, st.d_raw_status.p);
+    }
+    e->prof_copy.end(e->copy_stream);
+    if (rc != 0) { vmd_fail("XTC decode kernel launch failed"); return -1; }
+    for (size_t b = 0; b < nb; ++b) st.h_raw_status[b] = 99u;
+    if (hipMemcpyAsync(st.h_raw_status, st.d_raw_status.p, nb * sizeof(uint32_t), hipMemcpyDeviceToHost, e->copy_stream) != hipSuccess) { vmd_fail("device XTC decode failed"); return -1; }
+    st.raw_pending = true;
+    return 1;
+}
+
 static int fetch_stage_raw(vmd_script_eval_t* e, Stage& st, vmd_trajectory_i* traj, size_t num_atoms, size_t f0, size_t nb, size_t npad) {
     st.raw_info.resize(nb);
     std::vector<vmd_raw_frame_t> infos(nb);
@@ -1092,14 +1127,9 @@ static int fetch_stage_raw(vmd_script_eval_t* e, Stage& st, vmd_trajectory_i* tr
     if (total > st.hraw_cap) {
         if (st.hraw) (void)hipHostFree(st.hraw);
         st.hraw = nullptr; st.hraw_cap = 0;
-        if (hipHostMalloc((void**)&st.hraw, total, hipHostMallocDefault) != hipSuccess) { vmd_fail("hipHostMalloc(%zu bytes) failed", total); return -1; }
-        st.hraw_cap = total;
-    }
-    if (nb > st.h_raw_status_cap) {
-        if (st.h_raw_status) (void)hipHostFree(st.h_raw_status);
-        st.h_raw_status = nullptr; st.h_raw_status_cap = 0;
-        if (hipHostMalloc((void**)&st.h_raw_status, nb * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) { vmd_fail("hipHostMalloc failed"); return -1; }
-        st.h_raw_status_cap = nb;
+        const size_t cap = total + total / 8;                            // frames of one trajectory differ by a few per cent
+        if (hipHostMalloc((void**)&st.hraw, cap, hipHostMallocDefault) != hipSuccess) { vmd_fail("hipHostMalloc(%zu bytes) failed", cap); return -1; }
+        st.hraw_cap = cap;
     }
     const size_t nthreads = std::max<size_t>(1, std::min<size_t>(load_threads(), nb / 4));
     std::atomic<size_t> next{0};
@@ -1123,35 +1153,17 @@ static int fetch_stage_raw(vmd_script_eval_t* e, Stage& st, vmd_trajectory_i* tr
         for (auto& t : pool) t.join();
     }
     if (!ok.load()) return 0;                              // let load_frame produce the real error message
-    if (!st.d.ensure(nb * 3 * npad) || !st.d_raw.ensure(total) || !st.d_raw_status.ensure(nb)) return -1;
+    if (!st.d_raw.ensure(total + total / 8)) return -1;
     if (!st.d_raw_info.upload(st.raw_info.data(), nb, e->copy_stream)) return -1;
     if (hipMemcpyAsync(st.d_raw.p, st.hraw, total, hipMemcpyHostToDevice, e->copy_stream) != hipSuccess) { vmd_fail("hipMemcpyAsync of the compressed batch failed"); return -1; }
-    int rc;
-    if (g_opt.xtc_device_decode.load() >= 3) {
-        rc = vmd_hip_xtc_decode_wave(e->copy_stream, st.d_raw.p, st.d_raw_info.p, (int)nb, (int)num_atoms, st.d.p, 3 * npad, npad, st.d_raw_status.p);
-    } else if (g_opt.xtc_device_decode.load() == 2) {
-        const int chunk = std::max(64, g_opt.xtc_chunk.load());
-        if (!st.d_raw_scratch.ensure((vmd_hip_xtc_scratch_bytes((int)nb, (int)num_atoms, chunk) + 7) / 8)) return -1;
-        rc = vmd_hip_xtc_decode_chunked(e->copy_stream, st.d_raw.p, st.d_raw_info.p, (int)nb, (int)num_atoms, st.d.p, 3 * npad, npad,
-                                        st.d_raw_status.p, chunk, st.d_raw_scratch.p);
-    } else {
-        rc = vmd_hip_xtc_decode(e->copy_stream, st.d_raw.p, st.d_raw_info.p, (int)nb, (int)num_atoms, st.d.p, 3 * npad, npad, st.d_raw_status.p);
-    }
-    if (rc != 0) {
-        vmd_fail("XTC decode kernel launch failed");
-        return -1;
-    }
-    if (hipMemcpyAsync(st.h_raw_status, st.d_raw_status.p, nb * sizeof(uint32_t), hipMemcpyDeviceToHost, e->copy_stream) != hipSuccess ||
-        hipStreamSynchronize(e->copy_stream) != hipSuccess) { vmd_fail("device XTC decode failed"); return -1; }
-    for (size_t b = 0; b < nb; ++b) if (st.h_raw_status[b] != 0) return 0;     // corrupt or unsupported stream: the host reader decides
-    e->frames_device_decoded += nb;
-    return 1;
+    return launch_raw_decode(e, st, st.d_raw.p, st.d_raw_info.p, num_atoms, nb, npad);
 }
 
 // bring frames [f0, f0+nb) to the device (or alias them in place) through stage `st`: fills st.cells / st.h_boxes, queues
 // the copies on copy_stream and records st.ready
 static bool fetch_stage(vmd_script_eval_t* e, Stage& st, vmd_trajectory_i* traj, const vmd_device_view_t* view, size_t num_atoms,
-                        size_t f0, size_t nb) {
+                        size_t f0, size_t nb, bool force_host = false) {
+    st.raw_pending = false;
     vmd_host_view_t hv;
     const vmd_host_view_t* hview = (!view && traj->host_view && traj->host_view(traj->inst, &hv)) ? &hv : nullptr;
     st.f0 = f0; st.nb = nb;
@@ -1187,7 +1199,14 @@ static bool fetch_stage(vmd_script_eval_t* e, Stage& st, vmd_trajectory_i* traj,
         const size_t npad = (num_atoms + 63) & ~(size_t)63;
         const size_t need = nb * 3 * npad;
         int raw = 0;
-        if (g_opt.xtc_device_decode.load() && traj->load_raw) {
+        vmd_raw_device_view_t rv;
+        memset(&rv, 0, sizeof(rv));
+        if (!force_host && traj->raw_device_view && traj->raw_device_view(traj->inst, &rv) && rv.codec == VMD_RAW_CODEC_XTC && rv.device == e->device) {
+            // the compressed trajectory is resident in HBM: no host work, no PCIe - decode the batch where it lies
+            for (size_t b = 0; b < nb; ++b) st.cells[b] = rv.cells[f0 + b];
+            raw = launch_raw_decode(e, st, rv.base, (const vmd_xtc_frame_t*)rv.info + f0, num_atoms, nb, npad);
+            if (raw < 0) return false;
+        } else if (!force_host && g_opt.xtc_device_decode.load() && traj->load_raw) {
             raw = fetch_stage_raw(e, st, traj, num_atoms, f0, nb, npad);
             if (raw < 0) return false;
         }
@@ -1263,11 +1282,26 @@ static bool fetch_stage(vmd_script_eval_t* e, Stage& st, vmd_trajectory_i* traj,
     return true;
 }
 
+// A stage whose frames were decompressed on the device: wait for its `ready` event (the decode ran under the previous batch's
+// kernels, so this rarely waits) and look at the status words.  A stream the device rejects - damaged, or a packed number above
+// 2^64 - sends the whole batch through the host reader, which decides and reports.
+static bool settle_stage(vmd_script_eval_t* e, Stage& st, vmd_trajectory_i* traj, size_t num_atoms) {
+    if (!st.raw_pending) return true;
+    HIP_OK(hipEventSynchronize(st.ready));
+    e->prof_copy.resolve();
+    st.raw_pending = false;
+    bool good = true;
+    for (size_t b = 0; b < st.nb; ++b) if (st.h_raw_status[b] != 0) good = false;
+    if (good) { e->frames_device_decoded += st.nb; return true; }
+    return fetch_stage(e, st, traj, nullptr, num_atoms, st.f0, st.nb, true);
+}
+
 // synchronous variant used for single frames (reference pose, vis payload)
 static bool fetch_batch(vmd_script_eval_t* e, vmd_trajectory_i* traj, const vmd_device_view_t* view, size_t num_atoms,
                         size_t f0, size_t nb, BatchSrc* src) {
     Stage& st = e->stages[0];
     if (!fetch_stage(e, st, traj, view, num_atoms, f0, nb)) return false;
+    if (!settle_stage(e, st, traj, num_atoms)) return false;
     HIP_OK(hipStreamSynchronize(e->copy_stream));
     src->base = st.base; src->frame_stride = st.frame_stride; src->row_stride = st.row_stride;
     return true;
@@ -1524,8 +1558,11 @@ static bool reuse_blocks(vmd_script_eval_t* e, size_t beg, size_t end, std::vect
 
 // a sharded device trajectory keeps only its block of frames behind the view; other frames (frame 0 for the SDF reference
 // pose) come through load_frame
+// (resident_beg, resident_end) = (0, 0) means "every frame"; any other pair is a shard, and beg == end != 0 is an EMPTY shard (a rank
+// that owns no frame: 4 ranks on 5 frames) - nothing is resident then, not everything
+static bool view_sharded(const vmd_device_view_t& view) { return view.resident_beg != 0 || view.resident_end != 0; }
 static bool view_holds(bool have_view, const vmd_device_view_t& view, size_t frame) {
-    return have_view && (view.resident_end <= view.resident_beg || (frame >= view.resident_beg && frame < view.resident_end));
+    return have_view && (!view_sharded(view) || (frame >= view.resident_beg && frame < view.resident_end));
 }
 
 // evaluates frames [frame_beg, frame_end) in large batches; returns false on interrupt (empty error) or failure
@@ -1543,7 +1580,7 @@ static bool process_range(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
     vmd_device_view_t view;
     memset(&view, 0, sizeof(view));
     const bool have_view = traj->device_view && traj->device_view(traj->inst, &view) && view.device == e->device;
-    if (have_view && view.resident_end > view.resident_beg && (frame_beg < view.resident_beg || frame_end > view.resident_end))
+    if (have_view && view_sharded(view) && frame_beg < frame_end && (frame_beg < view.resident_beg || frame_end > view.resident_end))
         return vmd_fail("frames [%u, %u) are not resident on this rank (its shard holds [%zu, %zu))", frame_beg, frame_end, view.resident_beg, view.resident_end);
 
     // SDF reference pose: structure 0 at trajectory frame 0 (SPEC S5)
@@ -1565,7 +1602,7 @@ static bool process_range(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
     size_t Bmax = auto_batch(e, num_atoms, !have_view);
     const vmd_device_view_t* vw = have_view ? &view : nullptr;
     // host trajectories are staged in smaller batches so that load_frame of batch k+1 overlaps the kernels of batch k
-    if (!have_view && g_opt.batch_frames <= 0) Bmax = std::min<size_t>(Bmax, 128);
+    if (!have_view && g_opt.batch_frames <= 0) Bmax = std::min<size_t>(Bmax, (size_t)std::max(1, g_opt.stage_frames.load()));
     std::vector<Batch> batches;
     for (auto& sg : segments) plan_batches(e, sg.first, sg.second, Bmax, &batches);
 
@@ -1577,6 +1614,7 @@ static bool process_range(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
         const Batch& bt = batches[bi];
         const size_t f0 = bt.f0, nb = bt.nb;
         Stage& src = e->stages[cur];
+        if (!settle_stage(e, src, traj, num_atoms)) return false;
         HIP_OK(hipStreamWaitEvent(e->stream, src.ready, 0));
         const uint32_t pbc = batch_pbc(src);
         for (auto& s : e->sels) s->built = false;
@@ -1906,6 +1944,7 @@ extern "C" vmd_devtraj_t* vmd_devtraj_create_shard(size_t num_frames, size_t fra
     t->iface.num_frames = dt_num_frames; t->iface.num_atoms = dt_num_atoms;
     t->iface.load_frame = dt_load_frame; t->iface.device_view = dt_device_view; t->iface.host_view = nullptr;
     t->iface.load_raw = nullptr;
+    t->iface.raw_device_view = nullptr;
     return t.release();
 }
 extern "C" vmd_devtraj_t* vmd_devtraj_create(size_t num_frames, size_t num_atoms) { return vmd_devtraj_create_shard(num_frames, 0, num_frames, num_atoms); }
@@ -1976,6 +2015,132 @@ extern "C" float* vmd_devtraj_device_ptr(vmd_devtraj_t* t, size_t* frame_stride,
     return t->d;
 }
 
+// ------------------------------------------------------------------------------------------------ compressed trajectory in HBM
+
+// Every frame of a trajectory that offers load_raw (today: XTC), still compressed, in ONE device allocation + the decoder records
+// as a device array.  Evaluations decode batches straight from it (fetch_stage: raw_device_view), so a file-backed trajectory is
+// read and crosses PCIe once, not once per evaluation - VIAMD keeps a host-side cache of decoded frames for the same reason
+// (/root/reference/src/loader.cpp:111-159); here the cache is the compressed stream and it lives next to the kernels.
+struct vmd_rawtraj_t {
+    vmd_trajectory_i* src = nullptr;     // borrowed: must outlive this object (load_frame of single frames, fallbacks)
+    size_t num_frames = 0, num_atoms = 0, bytes = 0;
+    int device = 0;
+    unsigned char* d_raw = nullptr;
+    vmd_xtc_frame_t* d_info = nullptr;
+    std::vector<vmd_unitcell_t> cells;
+    vmd_trajectory_i iface;
+};
+static size_t rt_num_frames(void* inst) { return ((vmd_rawtraj_t*)inst)->num_frames; }
+static size_t rt_num_atoms(void* inst) { return ((vmd_rawtraj_t*)inst)->num_atoms; }
+static bool rt_load_frame(void* inst, int64_t idx, vmd_frame_header_t* hdr, float* x, float* y, float* z) {
+    vmd_rawtraj_t* t = (vmd_rawtraj_t*)inst;
+    return t->src->load_frame(t->src->inst, idx, hdr, x, y, z);
+}
+static bool rt_load_raw(void* inst, int64_t idx, vmd_frame_header_t* hdr, vmd_raw_frame_t* info, void* dst, size_t cap) {
+    vmd_rawtraj_t* t = (vmd_rawtraj_t*)inst;
+    return t->src->load_raw(t->src->inst, idx, hdr, info, dst, cap);
+}
+static bool rt_raw_device_view(void* inst, vmd_raw_device_view_t* out) {
+    vmd_rawtraj_t* t = (vmd_rawtraj_t*)inst;
+    out->base = t->d_raw; out->info = t->d_info; out->cells = t->cells.data(); out->codec = VMD_RAW_CODEC_XTC; out->device = t->device;
+    return true;
+}
+
+extern "C" void vmd_rawtraj_free(vmd_rawtraj_t* t) {
+    if (!t) return;
+    if (t->d_raw) (void)hipFree(t->d_raw);
+    if (t->d_info) (void)hipFree(t->d_info);
+    delete t;
+}
+
+extern "C" vmd_rawtraj_t* vmd_rawtraj_create(vmd_trajectory_i* src) {
+    if (!src || !src->load_raw) { vmd_fail("vmd_rawtraj_create: the trajectory does not offer its frames compressed (load_raw)"); return nullptr; }
+    if (vmd_device_count() <= 0) { vmd_fail("vmd_rawtraj_create: no usable HIP device"); return nullptr; }
+    std::unique_ptr<vmd_rawtraj_t, void (*)(vmd_rawtraj_t*)> t(new vmd_rawtraj_t(), vmd_rawtraj_free);
+    t->src = src;
+    t->num_frames = src->num_frames(src->inst);
+    t->num_atoms = src->num_atoms(src->inst);
+    if (hipGetDevice(&t->device) != hipSuccess) { vmd_fail("hipGetDevice failed"); return nullptr; }
+    const size_t F = t->num_frames;
+    std::vector<vmd_xtc_frame_t> info(F);
+    t->cells.resize(F);
+    size_t total = 0;
+    for (size_t f = 0; f < F; ++f) {
+        vmd_frame_header_t hdr;
+        vmd_raw_frame_t ri;
+        if (!src->load_raw(src->inst, (int64_t)f, &hdr, &ri, nullptr, 0) || ri.codec != VMD_RAW_CODEC_XTC || hdr.num_atoms != t->num_atoms) {
+            vmd_fail("vmd_rawtraj_create: frame %zu is not available compressed", f);
+            return nullptr;
+        }
+        t->cells[f] = hdr.unitcell;
+        info[f].precision = ri.precision;
+        for (int k = 0; k < 3; ++k) { info[f].minint[k] = ri.minint[k]; info[f].maxint[k] = ri.maxint[k]; }
+        info[f].smallidx = ri.smallidx;
+        info[f].offset = total;
+        info[f].nbytes = ri.nbytes;
+        total += ((size_t)ri.nbytes + 32 + 63) & ~(size_t)63;            // the layout the decode kernels expect (vmd_hip.h)
+    }
+    t->bytes = total;
+    hipError_t err = hipMalloc((void**)&t->d_raw, std::max<size_t>(total, 64));
+    if (err == hipSuccess) err = hipMalloc((void**)&t->d_info, std::max<size_t>(F, 1) * sizeof(vmd_xtc_frame_t));
+    if (err != hipSuccess) { vmd_fail("vmd_rawtraj_create: hipMalloc(%zu) failed: %s", total, hipGetErrorString(err)); return nullptr; }
+    if (F && hipMemcpy(t->d_info, info.data(), F * sizeof(vmd_xtc_frame_t), hipMemcpyHostToDevice) != hipSuccess) { vmd_fail("vmd_rawtraj_create: upload failed"); return nullptr; }
+    // upload in pinned pieces of <= 256 MB, each filled by the load threads
+    const size_t piece_cap = std::min<size_t>(std::max<size_t>(total, 64), (size_t)256 << 20);
+    unsigned char* pin = nullptr;
+    size_t pin_cap = 0;
+    auto grow = [&](size_t need) {
+        if (need <= pin_cap) return true;
+        if (pin) (void)hipHostFree(pin);
+        pin = nullptr; pin_cap = 0;
+        if (hipHostMalloc((void**)&pin, need, hipHostMallocDefault) != hipSuccess) return false;
+        pin_cap = need;
+        return true;
+    };
+    bool good = true;
+    for (size_t f0 = 0; f0 < F && good;) {
+        size_t f1 = f0, piece = 0;
+        while (f1 < F && (f1 == f0 || piece + (info[f1].offset + (((size_t)info[f1].nbytes + 32 + 63) & ~(size_t)63) - info[f1].offset) <= piece_cap)) {
+            piece = info[f1].offset + (((size_t)info[f1].nbytes + 32 + 63) & ~(size_t)63) - info[f0].offset;
+            ++f1;
+        }
+        if (!grow(piece)) { vmd_fail("hipHostMalloc(%zu bytes) failed", piece); good = false; break; }
+        const size_t nthreads = std::max<size_t>(1, std::min<size_t>(load_threads(), (f1 - f0) / 4));
+        std::atomic<size_t> next{f0};
+        std::atomic<bool> ok{true};
+        auto work = [&]() {
+            for (;;) {
+                const size_t f = next.fetch_add(1);
+                if (f >= f1 || !ok.load()) break;
+                unsigned char* dst = pin + (info[f].offset - info[f0].offset);
+                vmd_raw_frame_t ri;
+                if (!src->load_raw(src->inst, (int64_t)f, nullptr, &ri, dst, (size_t)info[f].nbytes) || ri.nbytes != info[f].nbytes) { ok = false; break; }
+                memset(dst + info[f].nbytes, 0, (((size_t)info[f].nbytes + 32 + 63) & ~(size_t)63) - (size_t)info[f].nbytes);
+            }
+        };
+        if (nthreads == 1) work();
+        else {
+            std::vector<std::thread> pool;
+            for (size_t k = 1; k < nthreads; ++k) pool.emplace_back(work);
+            work();
+            for (auto& th : pool) th.join();
+        }
+        if (!ok.load()) { if (g_last_error.empty()) vmd_fail("vmd_rawtraj_create: reading the compressed frames failed"); good = false; break; }
+        if (hipMemcpy(t->d_raw + info[f0].offset, pin, piece, hipMemcpyHostToDevice) != hipSuccess) { vmd_fail("vmd_rawtraj_create: upload failed"); good = false; break; }
+        f0 = f1;
+    }
+    if (pin) (void)hipHostFree(pin);
+    if (!good) return nullptr;
+    t->iface.inst = t.get();
+    t->iface.num_frames = rt_num_frames; t->iface.num_atoms = rt_num_atoms;
+    t->iface.load_frame = rt_load_frame; t->iface.device_view = nullptr; t->iface.host_view = nullptr;
+    t->iface.load_raw = rt_load_raw;
+    t->iface.raw_device_view = rt_raw_device_view;
+    return t.release();
+}
+extern "C" vmd_trajectory_i* vmd_rawtraj_interface(vmd_rawtraj_t* t) { return t ? &t->iface : nullptr; }
+extern "C" size_t vmd_rawtraj_device_bytes(const vmd_rawtraj_t* t) { return t ? t->bytes : 0; }
+
 // ------------------------------------------------------------------------------------------------ host trajectory (pinned)
 
 struct vmd_hosttraj_t {
@@ -2013,6 +2178,7 @@ extern "C" vmd_hosttraj_t* vmd_hosttraj_create(size_t num_frames, size_t num_ato
     t->iface.num_frames = ht_num_frames; t->iface.num_atoms = ht_num_atoms; t->iface.load_frame = ht_load_frame;
     t->iface.device_view = nullptr; t->iface.host_view = ht_host_view;
     t->iface.load_raw = nullptr;
+    t->iface.raw_device_view = nullptr;
     return t.release();
 }
 extern "C" void vmd_hosttraj_free(vmd_hosttraj_t* t) { if (!t) return; if (t->h) (void)hipHostFree(t->h); delete t; }

@@ -231,6 +231,10 @@ struct Xdr {
     Kind kind = KIND_XTC;
     size_t num_atoms = 0;
     std::vector<FrameRec> frames;
+    // XTC: decoder parameters and cell of every compressed frame, parsed once while indexing (load_raw's info-only pass - one call
+    // per frame of every staged batch - then needs no system call)
+    std::vector<vmd_raw_frame_t> raw_info;
+    std::vector<vmd_unitcell_t> raw_cell;
     vmd_trajectory_i iface;
     std::string path;
 };
@@ -405,6 +409,22 @@ bool xtc_index(Xdr* d, uint64_t file_bytes) {
             total = file_bytes - off;
         }
         d->frames.push_back(r);
+        vmd_raw_frame_t info;
+        memset(&info, 0, sizeof(info));
+        vmd_unitcell_t cell;
+        memset(&cell, 0, sizeof(cell));
+        if (!r.raw) {
+            info.codec = VMD_RAW_CODEC_XTC;
+            info.precision = be_f32(h + 56);
+            for (int k = 0; k < 3; ++k) { info.minint[k] = (int32_t)be32(h + 60 + 4 * k); info.maxint[k] = (int32_t)be32(h + 72 + 4 * k); }
+            info.smallidx = (int32_t)be32(h + 84);
+            info.nbytes = r.bytes;
+            float box[9];
+            for (int k = 0; k < 9; ++k) box[k] = be_f32(h + 16 + 4 * k);
+            cell = cell_from_box_nm(box);
+        }
+        d->raw_info.push_back(info);
+        d->raw_cell.push_back(cell);
         off += total;
     }
     if (d->frames.empty()) return fail("XTC '%s': no complete frame", d->path);
@@ -540,22 +560,13 @@ bool xdr_load_raw(void* inst, int64_t idx, vmd_frame_header_t* hdr, vmd_raw_fram
     if (d->kind != KIND_XTC || idx < 0 || (size_t)idx >= d->frames.size() || !info) return false;
     const FrameRec& r = d->frames[(size_t)idx];
     if (r.raw) return false;
-    unsigned char h[100];
-    if (!read_at(d->fd, h, r.head, r.off)) return fail("XTC '%s': truncated frame", d->path);
-    memset(info, 0, sizeof(*info));
-    info->codec = VMD_RAW_CODEC_XTC;
-    info->precision = be_f32(h + 56);
-    for (int k = 0; k < 3; ++k) { info->minint[k] = (int32_t)be32(h + 60 + 4 * k); info->maxint[k] = (int32_t)be32(h + 72 + 4 * k); }
-    info->smallidx = (int32_t)be32(h + 84);
-    info->nbytes = r.bytes;
+    *info = d->raw_info[(size_t)idx];
     if (hdr) {
-        float box[9];
-        for (int k = 0; k < 9; ++k) box[k] = be_f32(h + 16 + 4 * k);
         memset(hdr, 0, sizeof(*hdr));
         hdr->num_atoms = d->num_atoms;
         hdr->index = idx;
         hdr->timestamp = r.time;
-        hdr->unitcell = cell_from_box_nm(box);
+        hdr->unitcell = d->raw_cell[(size_t)idx];
     }
     if (dst) {
         if (cap < r.bytes) return fail("XTC '%s': raw frame buffer too small", d->path);
@@ -744,6 +755,7 @@ extern "C" vmd_xdrtraj_t* vmd_xdrtraj_open(const char* path) {
     d.iface.device_view = nullptr;
     d.iface.host_view = nullptr;
     d.iface.load_raw = d.kind == KIND_XTC ? xdr_load_raw : nullptr;
+    d.iface.raw_device_view = nullptr;
     return t;
 }
 

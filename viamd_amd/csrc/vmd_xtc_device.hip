@@ -201,7 +201,7 @@ __device__ __forceinline__ uint32_t xtc_group(BR& br, const vmd_xtc_frame_t& fi,
                                               int& run, const Radix& small, float* __restrict__ x, float* __restrict__ y,
                                               float* __restrict__ z) {
     const float invp = fs.invp;
-    const int smallnum = kXtcMagic[smallidx] / 2;
+    const int smallnum = (int)(small.s1 / 2u);             // small.s1 == kXtcMagic[smallidx]
     uint32_t st = 0;
     int cur[3], prev[3];
     if (fs.bitsize == 0) {
@@ -427,6 +427,10 @@ __global__ __launch_bounds__(64) void k_xtc_wave(const unsigned char* __restrict
                                                  int B, int natoms, float* __restrict__ xyz, size_t frame_stride, size_t row_stride,
                                                  uint32_t* __restrict__ status) {
     const int f = blockIdx.x;
+    // gridDim.y waves share a frame: every one of them walks the whole stream (the walk is cheap and needs no communication) and
+    // decodes every gridDim.y-th tile of 64 groups - the part that costs - so a small batch still fills the chip
+    const int nshare = (int)gridDim.y;
+    int turn = (int)blockIdx.y;                                   // tiles until this wave's next one
     const int lane = (int)threadIdx.x;
     if (f >= B) return;
     const vmd_xtc_frame_t fi = info[f];
@@ -434,7 +438,7 @@ __global__ __launch_bounds__(64) void k_xtc_wave(const unsigned char* __restrict
     uint32_t st = xtc_setup(fi, fs);
     if (!st && fi.nbytes >= (1ull << 27)) st = 2;                 // bit positions are kept in 32 bits here
     if (st) {
-        if (lane == 0) status[f] = st;
+        if (lane == 0) atomicMax(&status[f], st);
         return;
     }
     const unsigned char* stream = raw + fi.offset;
@@ -445,7 +449,7 @@ __global__ __launch_bounds__(64) void k_xtc_wave(const unsigned char* __restrict
     float* x = xyz + (size_t)f * frame_stride;
     float* y = x + row_stride;
     float* z = y + row_stride;
-    // lane l keeps the reciprocals of small radix XTC_FIRSTIDX + l (64 lanes = the 64 legal values of smallidx)
+    // lane l keeps small radix XTC_FIRSTIDX + l and its reciprocals (64 lanes = the 64 legal values of smallidx)
     const uint32_t my_magic = (uint32_t)kXtcMagic[XTC_FIRSTIDX + lane];
     const double t_inv2 = 1.0 / (double)my_magic, t_inv12 = 1.0 / (double)((uint64_t)my_magic * my_magic);
 
@@ -469,23 +473,28 @@ __global__ __launch_bounds__(64) void k_xtc_wave(const unsigned char* __restrict
     for (;;) {
         const bool finished = i >= natoms || st != 0;
         if (g == 64 || (finished && g > 0)) {
-            const int sidx = (int)(vstate & 255u);
-            Radix small;
-            const uint32_t m = (uint32_t)kXtcMagic[sidx];
-            small.s1 = small.s2 = m;
-            small.s12 = (uint64_t)m * m;
-            small.inv2 = xtc_shfl_f64(t_inv2, (sidx - XTC_FIRSTIDX) & 63);
-            small.inv12 = xtc_shfl_f64(t_inv12, (sidx - XTC_FIRSTIDX) & 63);
-            uint32_t lst = 0;
-            if (lane < g) {
-                BitsG br;
-                xtc_open(br, stream, fi.nbytes, (uint64_t)vpos);
-                int gi = vatom, gs = sidx, gr = (int)(vstate >> 8);
-                lst = xtc_group(br, fi, fs, natoms, gi, gs, gr, small, x, y, z);
-                if (!lst && br.pos > (uint64_t)nbits) lst = 1;
+            const bool mine = turn == 0;
+            turn = mine ? nshare - 1 : turn - 1;
+            if (mine) {
+                const int sidx = (int)(vstate & 255u);
+                const int tl = (sidx - XTC_FIRSTIDX) & 63;
+                Radix small;
+                const uint32_t m = VMD_SHFL_U32(my_magic, tl);
+                small.s1 = small.s2 = m;
+                small.s12 = (uint64_t)m * m;
+                small.inv2 = xtc_shfl_f64(t_inv2, tl);
+                small.inv12 = xtc_shfl_f64(t_inv12, tl);
+                uint32_t lst = 0;
+                if (lane < g) {
+                    BitsG br;
+                    xtc_open(br, stream, fi.nbytes, (uint64_t)vpos);
+                    int gi = vatom, gs = sidx, gr = (int)(vstate >> 8);
+                    lst = xtc_group(br, fi, fs, natoms, gi, gs, gr, small, x, y, z);
+                    if (!lst && br.pos > (uint64_t)nbits) lst = 1;
+                }
+                if (VMD_XTC_BALLOT(lst == 1u)) st = 1;
+                else if (VMD_XTC_BALLOT(lst == 2u) && !st) st = 2;
             }
-            if (VMD_XTC_BALLOT(lst == 1u)) st = 1;
-            else if (VMD_XTC_BALLOT(lst == 2u) && !st) st = 2;
             g = 0;
         }
         if (i >= natoms || st != 0) break;
@@ -535,7 +544,7 @@ __global__ __launch_bounds__(64) void k_xtc_wave(const unsigned char* __restrict
         }
         if (i > natoms || pos > nbits || ntake == 0) st = 1;      // a group past the last atom / the last bit (ntake == 0: cannot happen)
     }
-    if (lane == 0) status[f] = st;
+    if (st && lane == 0) atomicMax(&status[f], st);
 }
 
 }  // namespace
@@ -574,10 +583,22 @@ extern "C" int vmd_hip_xtc_decode(void* stream, const unsigned char* raw, const 
     return (int)hipGetLastError();
 }
 
+static int g_xtc_waves = 0;     // waves per frame of k_xtc_wave; 0 = enough to put ~4 waves on every SIMD
+extern "C" int vmd_hip_set_xtc_waves(int n) { const int old = g_xtc_waves; g_xtc_waves = n < 0 ? 0 : (n > 64 ? 64 : n); return old; }
+
 extern "C" int vmd_hip_xtc_decode_wave(void* stream, const unsigned char* raw, const vmd_xtc_frame_t* info, int B, int natoms,
                                        float* xyz, size_t frame_stride, size_t row_stride, uint32_t* status) {
     if (B <= 0) return 0;
-    hipLaunchKernelGGL(k_xtc_wave, dim3((unsigned)B), dim3(64), 0, (hipStream_t)stream, raw, info, B, natoms, xyz, frame_stride,
-                       row_stride, status);
+    int share = g_xtc_waves;
+    if (share <= 0) {
+        share = (4096 + B - 1) / B;                                 // 1024 SIMDs x 4
+        const int tiles = natoms / 128 + 1;                        // a frame has at most natoms groups; a wave should own a few tiles
+        if (share > tiles) share = tiles;
+        if (share > 16) share = 16;
+        if (share < 1) share = 1;
+    }
+    if (hipMemsetAsync(status, 0, (size_t)B * sizeof(uint32_t), (hipStream_t)stream) != hipSuccess) return 1;
+    hipLaunchKernelGGL(k_xtc_wave, dim3((unsigned)B, (unsigned)share), dim3(64), 0, (hipStream_t)stream, raw, info, B, natoms, xyz,
+                       frame_stride, row_stride, status);
     return (int)hipGetLastError();
 }

@@ -63,6 +63,43 @@ class XdrTrajectory:
             pass
 
 
+class CompressedDeviceTrajectory:
+    """Every frame of an XTC trajectory, still compressed, resident in HBM (vmd_rawtraj_*): evaluations decompress their batches
+    on the device straight from that copy - the file is read and crosses PCIe once, not once per evaluation."""
+
+    def __init__(self, src):
+        self.src = src                                   # kept alive: the native object borrows its interface
+        self.lib = src.lib
+        self.h = self.lib.vmd_rawtraj_create(src.interface())
+        if not self.h:
+            raise VmdError(self.lib.last_error())
+        self._iface = self.lib.vmd_rawtraj_interface(self.h)
+
+    def interface(self):
+        return self._iface
+
+    def num_frames(self):
+        return self.src.num_frames()
+
+    def num_atoms(self):
+        return self.src.num_atoms()
+
+    def device_bytes(self):
+        return int(self.lib.vmd_rawtraj_device_bytes(self.h))
+
+    def close(self):
+        if self.h:
+            self.lib.vmd_rawtraj_free(self.h)
+            self.h = None
+        self.src.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def _write(path, kind, coords, cells, precision, dt, lib):
     lib = lib or L.default_lib()
     if hasattr(coords, "frame"):
