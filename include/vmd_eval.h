@@ -418,6 +418,13 @@ void vmd_downsample_histogram(float* dst_bins, int num_dst_bins, const float* sr
                               int num_src_bins);
 void vmd_compute_histogram_masked(float* bins, int num_bins, float range_min, float range_max, const float* values,
                                   int dim, const uint8_t* frame_mask, int num_frames, bool aggregate);
+/* the same + y_range[2] = {y_min, y_max} of the histogram as VIAMD stores them (src/main.cpp:212-229); NULL = not wanted */
+void vmd_compute_histogram_masked_y(float* bins, int num_bins, float range_min, float range_max, const float* values,
+                                    int dim, const uint8_t* frame_mask, int num_frames, bool aggregate, float* y_range);
+/* compute_histogram (src/main.cpp:139-170) and scale_histogram (:252-261) */
+void vmd_compute_histogram(float* bins, int num_bins, float range_min, float range_max, const float* values, int num_values,
+                           float* bin_val_min, float* bin_val_max);
+void vmd_scale_histogram(float* bins, const float* weights, int num_bins);
 
 /* ---- runtime ---------------------------------------------------------------------------------------- */
 int         vmd_device_count(void);                 /* 0 when no HIP device is usable */

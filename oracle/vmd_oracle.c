@@ -751,8 +751,10 @@ void vo_compute_histogram(float* bins, int num_bins, float range_min, float rang
     const float scl = 1.0f / (width * count);
     for (int i = 0; i < num_bins; ++i) {
         bins[i] *= scl;
-        if (bins[i] < min_val) min_val = bins[i];
-        if (bins[i] > max_val) max_val = bins[i];
+        /* the reference's MIN(min_val, x) / MAX(max_val, x) macros = (min_val < x ? min_val : x): a NaN bin REPLACES the running
+         * value (found by tests/test_ref_pin.py against the compiled reference: an empty range gives NaN, NaN there) */
+        min_val = min_val < bins[i] ? min_val : bins[i];
+        max_val = max_val > bins[i] ? max_val : bins[i];
     }
     if (bin_val_min) *bin_val_min = min_val;
     if (bin_val_max) *bin_val_max = max_val;

@@ -196,6 +196,9 @@ SIGNATURES = [
     ("vmd_hosttraj_copy_from_device", C.c_bool, [_vp, _vp, C.c_size_t, C.c_size_t]),
     ("vmd_downsample_histogram", None, [c_float_p, C.c_int, c_float_p, c_float_p, C.c_int]),
     ("vmd_compute_histogram_masked", None, [c_float_p, C.c_int, C.c_float, C.c_float, c_float_p, C.c_int, c_uint8_p, C.c_int, C.c_bool]),
+    ("vmd_compute_histogram_masked_y", None, [c_float_p, C.c_int, C.c_float, C.c_float, c_float_p, C.c_int, c_uint8_p, C.c_int, C.c_bool, c_float_p]),
+    ("vmd_compute_histogram", None, [c_float_p, C.c_int, C.c_float, C.c_float, c_float_p, C.c_int, c_float_p, c_float_p]),
+    ("vmd_scale_histogram", None, [c_float_p, c_float_p, C.c_int]),
     ("vmd_device_count", C.c_int, []),
     ("vmd_set_device", C.c_bool, [C.c_int]),
     ("vmd_last_error", C.c_char_p, []),

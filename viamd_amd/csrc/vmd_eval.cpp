@@ -6,6 +6,8 @@
 // device buffers and keeps the md_script_property_data_t views up to date.  There is no CPU compute path.
 #include <hip/hip_runtime.h>
 
+#include <float.h>
+
 #include <algorithm>
 #include <atomic>
 #include <cmath>
@@ -2220,9 +2222,10 @@ extern "C" void vmd_downsample_histogram(float* dst_bins, int num_dst_bins, cons
     }
 }
 
-// temporal -> distribution as VIAMD builds it from the frame mask (/root/reference/src/main.cpp:172-230)
-extern "C" void vmd_compute_histogram_masked(float* bins, int num_bins, float range_min, float range_max, const float* values,
-                                             int dim, const uint8_t* frame_mask, int num_frames, bool aggregate) {
+// temporal -> distribution as VIAMD builds it from the frame mask (/root/reference/src/main.cpp:172-230); y_range = the
+// Histogram's y_min / y_max (:212-229; untouched when no frame is set, as there)
+extern "C" void vmd_compute_histogram_masked_y(float* bins, int num_bins, float range_min, float range_max, const float* values,
+                                               int dim, const uint8_t* frame_mask, int num_frames, bool aggregate, float* y_range) {
     const int hdim = aggregate ? 1 : dim;
     std::fill(bins, bins + (size_t)hdim * num_bins, 0.0f);
     const float ext = range_max - range_min;
@@ -2241,10 +2244,56 @@ extern "C" void vmd_compute_histogram_masked(float* bins, int num_bins, float ra
             count[row] += 1;
         }
     }
-    if (!any) return;
+    if (!any || dim <= 0) return;
+    float lo = FLT_MAX, hi = -FLT_MAX;
     const float width = ext / num_bins;
     for (int r = 0; r < hdim; ++r) {
         const float scl = 1.0f / (width * count[r]);
-        for (int j = 0; j < num_bins; ++j) bins[(size_t)r * num_bins + j] *= scl;
+        for (int j = 0; j < num_bins; ++j) {
+            float& v = bins[(size_t)r * num_bins + j];
+            v *= scl;
+            lo = lo < v ? lo : v;          // MIN(min_bin, val) / MAX(max_bin, val) as the reference's macros order them: a NaN bin
+            hi = hi > v ? hi : v;          // (a row without samples: 0 * inf) REPLACES the running value
+        }
     }
+    if (y_range) { y_range[0] = lo; y_range[1] = hi; }
+}
+extern "C" void vmd_compute_histogram_masked(float* bins, int num_bins, float range_min, float range_max, const float* values,
+                                             int dim, const uint8_t* frame_mask, int num_frames, bool aggregate) {
+    vmd_compute_histogram_masked_y(bins, num_bins, range_min, range_max, values, dim, frame_mask, num_frames, aggregate, nullptr);
+}
+
+// the unmasked form (/root/reference/src/main.cpp:139-170): normalised by 1 / (bin width x samples inside the range)
+extern "C" void vmd_compute_histogram(float* bins, int num_bins, float range_min, float range_max, const float* values, int num_values,
+                                      float* bin_val_min, float* bin_val_max) {
+    std::fill(bins, bins + num_bins, 0.0f);
+    const float ext = range_max - range_min;
+    const float inv = 1.0f / ext;
+    int count = 0;
+    for (int i = 0; i < num_values; ++i) {
+        if (values[i] < range_min || range_max < values[i]) continue;
+        const int b = std::min(std::max((int)(((values[i] - range_min) * inv) * num_bins), 0), num_bins - 1);
+        bins[b] += 1.0f;
+        count += 1;
+    }
+    if (count == 0) {
+        if (bin_val_min) *bin_val_min = 0;
+        if (bin_val_max) *bin_val_max = 0;
+        return;
+    }
+    float lo = FLT_MAX, hi = -FLT_MAX;
+    const float width = ext / num_bins;
+    const float scl = 1.0f / (width * count);
+    for (int i = 0; i < num_bins; ++i) {
+        bins[i] *= scl;
+        lo = lo < bins[i] ? lo : bins[i];
+        hi = hi > bins[i] ? hi : bins[i];
+    }
+    if (bin_val_min) *bin_val_min = lo;
+    if (bin_val_max) *bin_val_max = hi;
+}
+
+// bins[i] /= weights[i] where the weight is not zero (/root/reference/src/main.cpp:252-261)
+extern "C" void vmd_scale_histogram(float* bins, const float* weights, int num_bins) {
+    for (int i = 0; i < num_bins; ++i) if (weights[i]) bins[i] /= weights[i];
 }

@@ -75,31 +75,34 @@ __device__ __forceinline__ uint64_t xtc_get(Bits& b, int bits) {
 struct BitsG {
     const uint64_t* words;
     uint64_t nwords;
-    uint64_t first;              // index of w[0]
+    uint64_t first;              // index of w0
     uint64_t pos;
-    uint64_t w[4];
+    uint64_t w0, w1, w2, w3;     // four named registers, not an array: an array indexed by the word number ends up in scratch memory
 };
+__device__ __forceinline__ uint64_t xtc_word(const BitsG& b, uint64_t i) { return __builtin_bswap64(b.words[i < b.nwords ? i : b.nwords - 1]); }
 __device__ __forceinline__ void xtc_open(BitsG& b, const unsigned char* base, uint64_t nbytes, uint64_t pos) {
     b.words = (const uint64_t*)base;
     b.nwords = (nbytes + 32ull) >> 3;
     b.pos = pos;
     b.first = pos >> 6;
-    for (int k = 0; k < 4; ++k) {
-        const uint64_t i = b.first + (uint64_t)k;
-        b.w[k] = __builtin_bswap64(b.words[i < b.nwords ? i : b.nwords - 1]);
-    }
+    b.w0 = xtc_word(b, b.first);
+    b.w1 = xtc_word(b, b.first + 1);
+    b.w2 = xtc_word(b, b.first + 2);
+    b.w3 = xtc_word(b, b.first + 3);
 }
 __device__ __forceinline__ uint64_t xtc_get(BitsG& b, int bits) {
     const unsigned sh = (unsigned)(b.pos & 63ull);
     const uint64_t k = (b.pos >> 6) - b.first;
     uint64_t hi, lo;
     if (k <= 2) {
-        hi = k == 0 ? b.w[0] : (k == 1 ? b.w[1] : b.w[2]);
-        lo = k == 0 ? b.w[1] : (k == 1 ? b.w[2] : b.w[3]);
+        // masks, not a chain of selects between the fields: the compiler folds "select of two loaded fields" into a load through a
+        // selected ADDRESS, which pins the whole reader in scratch memory
+        const uint64_t m0 = k == 0 ? ~0ull : 0ull, m1 = k == 1 ? ~0ull : 0ull, m2 = k == 2 ? ~0ull : 0ull;
+        hi = (b.w0 & m0) | (b.w1 & m1) | (b.w2 & m2);
+        lo = (b.w1 & m0) | (b.w2 & m1) | (b.w3 & m2);
     } else {
-        const uint64_t i = b.first + k;
-        hi = __builtin_bswap64(b.words[i < b.nwords ? i : b.nwords - 1]);
-        lo = __builtin_bswap64(b.words[i + 1 < b.nwords ? i + 1 : b.nwords - 1]);
+        hi = xtc_word(b, b.first + k);
+        lo = xtc_word(b, b.first + k + 1);
     }
     const uint64_t w = sh ? ((hi << sh) | (lo >> (64u - sh))) : hi;
     b.pos += (uint64_t)bits;
@@ -395,18 +398,24 @@ __global__ __launch_bounds__(64) void k_xtc_chunks(const unsigned char* __restri
 // ---- variant 3: one WAVE per frame.  The serial part of a stream is only the walk from group to group (flag bit, 5-bit run code,
 // field widths); everything else - mixed-radix splits, conversions, stores - is independent per group.  So a wave walks its frame
 // and decodes it 64 groups at a time:
-//   * window: the next 192 big-endian dwords of the stream sit in three VGPRs (one dword per lane, coalesced 256-byte loads issued
-//     a block ahead), so the walk never waits for memory and needs no LDS allocation (the pair kernel next door owns the CU's LDS);
+//   * the stream lives in VGPRs, never in LDS (the pair kernel next door owns the CU's LDS): two banks of eight registers, one
+//     64-dword block per register.  While the walk is inside one bank (an "epoch" of 512 dwords) the other bank is in flight:
+//     its eight coalesced 256-byte loads are issued at the start of the epoch and nobody touches those registers until the walk
+//     gets there, 2 KB later.  The loop body exists twice, once per bank role, so that no register is ever moved - a move of a
+//     loaded value is a use, and a use waits (the first version rotated three registers and stalled a full memory latency per
+//     block: 3.9 of 6.1 ms per 100k-atom frame);
 //   * speculative walk: a group whose flag bit is 0 inherits (run, smallidx) and has the same length L as the one before it, so
-//     lane k looks at the flag bit of "group k from here, if every flag before it is 0" (two ds_bpermute per dword out of the
-//     window); a ballot finds the first flag that is set (or leaves the window / the frame), every group before it is confirmed at
-//     once, the flagged group is stepped over with scalar arithmetic on its 6-bit code, and the walk speculates again from there.
-//     ~60 instructions confirm 1 + (zero-flag run) groups: 12 on average for the synthetic water box, 1-3 for a real liquid;
+//     lane k looks at the flag bit of "group k from here, if every flag before it is 0" (ds_bpermute out of the two blocks of the
+//     window, picked by a uniform switch); a ballot finds the first flag that is set (or leaves the window / the frame), every
+//     group before it is confirmed at once, the flagged group is stepped over with scalar arithmetic on its 6-bit code, and the
+//     walk speculates again from there.  ~60 instructions confirm 1 + (zero-flag run) groups: 12 on average for the synthetic
+//     water box, 40 - 64 for rigid water;
 //   * every confirmed group gets a lane: (bit position, atom index, smallidx, run) - the complete decoder state at a group boundary.
 //     When 64 are known (or the frame ends) all lanes decode their group with the code of variant 1 (xtc_group), reading the
-//     stream through L1 (the window loads touched those lines a moment ago).  The reciprocals of the 64 possible small radices are
-//     computed once per wave, one per lane, and fetched with ds_bpermute instead of two fp64 divisions per group.
-// A batch of 1 000 frames is 1 000 waves: one per SIMD of the chip.
+//     stream through L1 (the bank loads touched those lines a moment ago).  The reciprocals of the 64 possible small radices are
+//     computed once per wave, one per lane, and fetched with ds_bpermute instead of two fp64 divisions per group;
+//   * gridDim.y waves share a frame: every one of them walks the whole stream (the walk needs no communication) and decodes every
+//     gridDim.y-th tile, so a small batch still fills the chip.
 #ifndef VMD_SHFL_U32
 #define VMD_SHFL_U32(v, src) ((uint32_t)__shfl((int)(v), (int)(src)))
 #define VMD_READLANE_U32(v, lane) ((uint32_t)__builtin_amdgcn_readlane((int)(v), (int)(lane)))
@@ -423,12 +432,12 @@ __device__ __forceinline__ double xtc_shfl_f64(double v, int src) {
     return r;
 }
 
+struct XtcBank { uint32_t r[8]; };          // eight 64-dword blocks of the stream, one dword per lane, as loaded (little-endian)
+
 __global__ __launch_bounds__(64) void k_xtc_wave(const unsigned char* __restrict__ raw, const vmd_xtc_frame_t* __restrict__ info,
                                                  int B, int natoms, float* __restrict__ xyz, size_t frame_stride, size_t row_stride,
                                                  uint32_t* __restrict__ status) {
     const int f = blockIdx.x;
-    // gridDim.y waves share a frame: every one of them walks the whole stream (the walk is cheap and needs no communication) and
-    // decodes every gridDim.y-th tile of 64 groups - the part that costs - so a small batch still fills the chip
     const int nshare = (int)gridDim.y;
     int turn = (int)blockIdx.y;                                   // tiles until this wave's next one
     const int lane = (int)threadIdx.x;
@@ -453,96 +462,120 @@ __global__ __launch_bounds__(64) void k_xtc_wave(const unsigned char* __restrict
     const uint32_t my_magic = (uint32_t)kXtcMagic[XTC_FIRSTIDX + lane];
     const double t_inv2 = 1.0 / (double)my_magic, t_inv12 = 1.0 / (double)((uint64_t)my_magic * my_magic);
 
-    uint32_t base = 0;                                            // first dword of the window
     auto load_block = [&](uint32_t first) {
         uint32_t k = first + (uint32_t)lane;
         k = k < ndw ? k : ndw - 1;
-        return __builtin_bswap32(dw[k]);
+        return dw[k];
     };
-    uint32_t w0 = load_block(0), w1 = load_block(64), w2 = load_block(128);
-    auto window = [&](uint32_t q) {                               // dword q of the window, q < 128 (anything for q >= 128)
-        const uint32_t a = VMD_SHFL_U32(w0, q & 63u), b = VMD_SHFL_U32(w1, q & 63u);
-        return (q & 64u) ? b : a;
-    };
-
+    uint32_t epoch = 0;                                           // first dword of the bank the walk is in
     uint32_t pos = 0;                                             // uniform walk state: next group's first bit, its first atom, ...
     int i = 0, smallidx = fi.smallidx, run = 0;
     int g = 0;                                                    // groups waiting in the lanes
     uint32_t vpos = 0, vstate = (uint32_t)XTC_FIRSTIDX;           // per lane: the group this lane will decode
     int vatom = 0;
-    for (;;) {
-        const bool finished = i >= natoms || st != 0;
-        if (g == 64 || (finished && g > 0)) {
-            const bool mine = turn == 0;
-            turn = mine ? nshare - 1 : turn - 1;
-            if (mine) {
-                const int sidx = (int)(vstate & 255u);
-                const int tl = (sidx - XTC_FIRSTIDX) & 63;
-                Radix small;
-                const uint32_t m = VMD_SHFL_U32(my_magic, tl);
-                small.s1 = small.s2 = m;
-                small.s12 = (uint64_t)m * m;
-                small.inv2 = xtc_shfl_f64(t_inv2, tl);
-                small.inv12 = xtc_shfl_f64(t_inv12, tl);
-                uint32_t lst = 0;
-                if (lane < g) {
-                    BitsG br;
-                    xtc_open(br, stream, fi.nbytes, (uint64_t)vpos);
-                    int gi = vatom, gs = sidx, gr = (int)(vstate >> 8);
-                    lst = xtc_group(br, fi, fs, natoms, gi, gs, gr, small, x, y, z);
-                    if (!lst && br.pos > (uint64_t)nbits) lst = 1;
+    bool done = false;
+
+    // walks while the window stays inside `cur` (dwords [epoch, epoch + 512)); `nxt` receives the 512 dwords behind it
+    auto run_epoch = [&](const XtcBank& cur, XtcBank& nxt) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) nxt.r[k] = load_block(epoch + 512u + 64u * (uint32_t)k);
+        for (;;) {
+            const bool finished = i >= natoms || st != 0;
+            if (g == 64 || (finished && g > 0)) {
+                const bool mine = turn == 0;
+                turn = mine ? nshare - 1 : turn - 1;
+                if (mine) {
+                    const int sidx = (int)(vstate & 255u);
+                    const int tl = (sidx - XTC_FIRSTIDX) & 63;
+                    Radix small;
+                    const uint32_t m = VMD_SHFL_U32(my_magic, tl);
+                    small.s1 = small.s2 = m;
+                    small.s12 = (uint64_t)m * m;
+                    small.inv2 = xtc_shfl_f64(t_inv2, tl);
+                    small.inv12 = xtc_shfl_f64(t_inv12, tl);
+                    uint32_t lst = 0;
+                    if (lane < g) {
+                        BitsG br;
+                        xtc_open(br, stream, fi.nbytes, (uint64_t)vpos);
+                        int gi = vatom, gs = sidx, gr = (int)(vstate >> 8);
+                        lst = xtc_group(br, fi, fs, natoms, gi, gs, gr, small, x, y, z);
+                        if (!lst && br.pos > (uint64_t)nbits) lst = 1;
+                    }
+                    if (VMD_XTC_BALLOT(lst == 1u)) st = 1;
+                    else if (VMD_XTC_BALLOT(lst == 2u) && !st) st = 2;
                 }
-                if (VMD_XTC_BALLOT(lst == 1u)) st = 1;
-                else if (VMD_XTC_BALLOT(lst == 2u) && !st) st = 2;
+                g = 0;
             }
-            g = 0;
+            if (i >= natoms || st != 0) { done = true; return; }
+            const uint32_t blk = ((pos >> 5) - epoch) >> 6;       // the window is blocks blk, blk + 1 of this epoch
+            if (blk >= 8u) return;                                // the walk has left the bank
+            const uint32_t base = epoch + 64u * blk;
+            const int per = 1 + run / 3;                          // atoms and bits of a group that inherits (run, smallidx)
+            const uint32_t L = large_bits + 1u + (uint32_t)(run / 3) * (uint32_t)smallidx;
+            const uint32_t P = pos + large_bits + (uint32_t)lane * L;    // this lane's flag bit
+            const uint32_t q = (P >> 5) - base, q1 = q + 1u;      // dwords q, q + 1 of the window hold it and the run code
+            uint32_t a0, b0, a1, b1;
+#define XTC_WIN(A, Bk) a0 = VMD_SHFL_U32(A, q & 63u); b0 = VMD_SHFL_U32(Bk, q & 63u); a1 = VMD_SHFL_U32(A, q1 & 63u); b1 = VMD_SHFL_U32(Bk, q1 & 63u)
+            switch (blk) {
+                case 0: XTC_WIN(cur.r[0], cur.r[1]); break;
+                case 1: XTC_WIN(cur.r[1], cur.r[2]); break;
+                case 2: XTC_WIN(cur.r[2], cur.r[3]); break;
+                case 3: XTC_WIN(cur.r[3], cur.r[4]); break;
+                case 4: XTC_WIN(cur.r[4], cur.r[5]); break;
+                case 5: XTC_WIN(cur.r[5], cur.r[6]); break;
+                case 6: XTC_WIN(cur.r[6], cur.r[7]); break;
+                default: XTC_WIN(cur.r[7], nxt.r[0]); break;
+            }
+#undef XTC_WIN
+            const uint32_t d0 = __builtin_bswap32((q & 64u) ? b0 : a0), d1 = __builtin_bswap32((q1 & 64u) ? b1 : a1);
+            const uint32_t sh = P & 31u;
+            const uint32_t code = (uint32_t)(((((uint64_t)d0 << 32) | (uint64_t)d1) << sh) >> 58);   // flag + run code
+            // why the speculation ends at this lane: 3 = past the last atom, 2 = outside the window, 1 = flag set
+            const uint32_t reason = (i + lane * per >= natoms) ? 3u : (q1 >= 128u) ? 2u : (code >> 5);
+            const unsigned long long stop = VMD_XTC_BALLOT(reason != 0u);
+            const int n0 = stop ? __builtin_ctzll(stop) : 64;     // groups with flag 0 in front of it
+            const int room = 64 - g;
+            const int take0 = n0 < room ? n0 : room;
+            uint32_t why = 0, code_n0 = 0;
+            if (n0 < 64) {
+                why = VMD_READLANE_U32(reason, n0);
+                code_n0 = VMD_READLANE_U32(code, n0);
+            }
+            const bool flagged = n0 < room && why == 1u;          // the group with the set flag goes along
+            const int ntake = take0 + (flagged ? 1 : 0);
+            const int rel = lane - g;
+            if (rel >= 0 && rel < ntake) {
+                vpos = pos + (uint32_t)rel * L;
+                vatom = i + rel * per;
+                vstate = (uint32_t)smallidx | ((uint32_t)run << 8);
+            }
+            g += ntake;
+            pos += (uint32_t)take0 * L;
+            i += take0 * per;
+            if (flagged) {
+                int nrun = (int)(code_n0 & 31u);
+                const int is_smaller = nrun % 3;
+                nrun -= is_smaller;
+                pos += large_bits + 6u + (uint32_t)(nrun / 3) * (uint32_t)smallidx;
+                i += 1 + nrun / 3;
+                run = nrun;
+                smallidx += is_smaller - 1;
+                if (smallidx <= XTC_FIRSTIDX - 1 || smallidx >= XTC_LASTIDX) st = 1;
+            }
+            if (i > natoms || pos > nbits || ntake == 0) st = 1;  // a group past the last atom / the last bit (ntake == 0: cannot happen)
         }
-        if (i >= natoms || st != 0) break;
-        while ((pos >> 5) - base >= 64u) {                        // slide by whole blocks; the new block was requested a block ago
-            w0 = w1; w1 = w2;
-            base += 64u;
-            w2 = load_block(base + 128u);
-        }
-        const int per = 1 + run / 3;                              // atoms and bits of a group that inherits (run, smallidx)
-        const uint32_t L = large_bits + 1u + (uint32_t)(run / 3) * (uint32_t)smallidx;
-        const uint32_t P = pos + large_bits + (uint32_t)lane * L; // this lane's flag bit
-        const uint32_t q = (P >> 5) - base;
-        const uint32_t d0 = window(q), d1 = window(q + 1u);
-        const uint32_t sh = P & 31u;
-        const uint32_t code = (uint32_t)(((((uint64_t)d0 << 32) | (uint64_t)d1) << sh) >> 58);   // flag + run code
-        // why the speculation ends at this lane: 3 = past the last atom, 2 = outside the window, 1 = flag set
-        const uint32_t reason = (i + lane * per >= natoms) ? 3u : (q + 1u >= 128u) ? 2u : (code >> 5);
-        const unsigned long long stop = VMD_XTC_BALLOT(reason != 0u);
-        const int n0 = stop ? __builtin_ctzll(stop) : 64;         // groups with flag 0 in front of it
-        const int room = 64 - g;
-        const int take0 = n0 < room ? n0 : room;
-        uint32_t why = 0, code_n0 = 0;
-        if (n0 < 64) {
-            why = VMD_READLANE_U32(reason, n0);
-            code_n0 = VMD_READLANE_U32(code, n0);
-        }
-        const bool flagged = n0 < room && why == 1u;              // the group with the set flag goes along
-        const int ntake = take0 + (flagged ? 1 : 0);
-        const int rel = lane - g;
-        if (rel >= 0 && rel < ntake) {
-            vpos = pos + (uint32_t)rel * L;
-            vatom = i + rel * per;
-            vstate = (uint32_t)smallidx | ((uint32_t)run << 8);
-        }
-        g += ntake;
-        pos += (uint32_t)take0 * L;
-        i += take0 * per;
-        if (flagged) {
-            int nrun = (int)(code_n0 & 31u);
-            const int is_smaller = nrun % 3;
-            nrun -= is_smaller;
-            pos += large_bits + 6u + (uint32_t)(nrun / 3) * (uint32_t)smallidx;
-            i += 1 + nrun / 3;
-            run = nrun;
-            smallidx += is_smaller - 1;
-            if (smallidx <= XTC_FIRSTIDX - 1 || smallidx >= XTC_LASTIDX) st = 1;
-        }
-        if (i > natoms || pos > nbits || ntake == 0) st = 1;      // a group past the last atom / the last bit (ntake == 0: cannot happen)
+    };
+
+    XtcBank bank_a, bank_b;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { bank_a.r[k] = load_block(64u * (uint32_t)k); bank_b.r[k] = 0; }
+    for (;;) {
+        run_epoch(bank_a, bank_b);
+        if (done) break;
+        epoch += 512u;
+        run_epoch(bank_b, bank_a);
+        if (done) break;
+        epoch += 512u;
     }
     if (st && lane == 0) atomicMax(&status[f], st);
 }

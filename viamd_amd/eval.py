@@ -380,3 +380,35 @@ def compute_histogram_masked(values, dim, mask, num_bins, rmin, rmax, aggregate=
     lib.vmd_compute_histogram_masked(out.ctypes.data_as(L.c_float_p), num_bins, float(rmin), float(rmax),
                                      v.ctypes.data_as(L.c_float_p), dim, m.ctypes.data_as(L.c_uint8_p), m.size, bool(aggregate))
     return out
+
+
+def compute_histogram_masked_y(values, dim, mask, num_bins, rmin, rmax, aggregate=False, lib=None):
+    """-> (bins, (y_min, y_max)): compute_histogram_masked plus the value range VIAMD stores with the histogram (src/main.cpp:212-229)."""
+    lib = lib or L.default_lib()
+    v = np.ascontiguousarray(values, np.float32)
+    m = np.ascontiguousarray(mask, np.uint8)
+    out = np.zeros((1 if aggregate else dim) * num_bins, np.float32)
+    yr = np.zeros(2, np.float32)
+    lib.vmd_compute_histogram_masked_y(out.ctypes.data_as(L.c_float_p), num_bins, float(rmin), float(rmax), v.ctypes.data_as(L.c_float_p),
+                                       dim, m.ctypes.data_as(L.c_uint8_p), m.size, bool(aggregate), yr.ctypes.data_as(L.c_float_p))
+    return out, (float(yr[0]), float(yr[1]))
+
+
+def compute_histogram(values, num_bins, rmin, rmax, lib=None):
+    """-> (bins, min, max): VIAMD's unmasked compute_histogram (src/main.cpp:139-170)."""
+    lib = lib or L.default_lib()
+    v = np.ascontiguousarray(values, np.float32)
+    out = np.zeros(num_bins, np.float32)
+    lo, hi = C.c_float(0), C.c_float(0)
+    lib.vmd_compute_histogram(out.ctypes.data_as(L.c_float_p), num_bins, float(rmin), float(rmax), v.ctypes.data_as(L.c_float_p), v.size,
+                              C.cast(C.byref(lo), L.c_float_p), C.cast(C.byref(hi), L.c_float_p))
+    return out, lo.value, hi.value
+
+
+def scale_histogram(bins, weights, lib=None):
+    """bins / weights where the weight is not zero (src/main.cpp:252-261); returns a new array."""
+    lib = lib or L.default_lib()
+    b = np.array(bins, np.float32)
+    w = np.ascontiguousarray(weights, np.float32)
+    lib.vmd_scale_histogram(b.ctypes.data_as(L.c_float_p), w.ctypes.data_as(L.c_float_p), b.size)
+    return b
