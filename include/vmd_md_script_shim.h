@@ -1,0 +1,207 @@
+/* vmd_md_script_shim.h - mdlib's evaluator entry points (md_script_eval_*, as VIAMD calls them) implemented on libviamd_amd.so.
+ *
+ * C++ header, header-only.  Include it AFTER mdlib's own headers (md_script.h, md_molecule.h, md_trajectory.h, core/md_str.h,
+ * core/md_bitfield.h, core/md_unit.h): it uses their types by name and defines the functions VIAMD calls on the evaluation path
+ * with the signatures inferred from the call sites:
+ *
+ *     md_script_eval_create / _free / _clear_data / _interrupt / _ir_fingerprint      /root/reference/src/main.cpp:971,960,990,829,987
+ *     md_script_eval_frame_range                                                      /root/reference/src/main.cpp:996,1032
+ *     md_script_eval_property_data / md_script_eval_frame_mask                        /root/reference/src/main.cpp:1286,1513
+ *
+ * With VMD_SHIM_PREFIX undefined the functions are emitted under those very names (a VIAMD build that drops mdlib's
+ * md_script_eval.c from the link); define VMD_SHIM_PREFIX(name) to put them elsewhere (the compile test uses vmdshim_##name
+ * next to a mock of mdlib's declarations).
+ *
+ * What the shim needs from the host besides the types: the property DESCRIPTORS.  mdlib's IR is opaque, so the host registers,
+ * once per compiled script, the vmd_script_ir_t that carries its rdf / sdf / distance properties (INTEGRATION.md section 3 shows how
+ * VIAMD derives them from the evaluated argument bitfields):      vmd_shim_bind_ir(md_ir, vmd_ir);
+ *
+ * tests/native/shim_callsites.cpp re-types VIAMD's call sequence against tests/native/md_mock.h and runs it. */
+#ifndef VMD_MD_SCRIPT_SHIM_H
+#define VMD_MD_SCRIPT_SHIM_H
+
+#include <string.h>
+
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "vmd_eval.h"
+
+#ifndef VMD_SHIM_PREFIX
+#define VMD_SHIM_PREFIX(name) name
+#endif
+
+/* ---- IR registry: md_script_ir_t* -> the descriptors of its properties ------------------------------------------------------ */
+namespace vmd_shim {
+struct Registry {
+    std::mutex mtx;
+    std::map<const void*, const vmd_script_ir_t*> ir;
+};
+inline Registry& registry() { static Registry r; return r; }
+inline const vmd_script_ir_t* find_ir(const void* md_ir) {
+    Registry& r = registry();
+    std::lock_guard<std::mutex> l(r.mtx);
+    auto it = r.ir.find(md_ir);
+    return it == r.ir.end() ? nullptr : it->second;
+}
+
+/* md_unitcell_t -> vmd_unitcell_t: the six basis parameters VIAMD itself reads (src/viamd.cpp:1837-1842) + the periodicity bits */
+template <class Cell>
+inline vmd_unitcell_t unitcell(const Cell& c) {
+    vmd_unitcell_t u;
+    u.x = (float)c.x; u.y = (float)c.y; u.z = (float)c.z; u.xy = (float)c.xy; u.xz = (float)c.xz; u.yz = (float)c.yz;
+    u.flags = (uint32_t)c.flags & VMD_UNITCELL_PBC_ALL;
+    return u;
+}
+
+/* md_trajectory_i behind vmd_trajectory_i: VIAMD only ever calls md_trajectory_load_frame on it (src/viamd.cpp:465-467) */
+inline bool load_frame_adapter(void* inst, int64_t idx, vmd_frame_header_t* h, float* x, float* y, float* z) {
+    md_trajectory_i* traj = (md_trajectory_i*)inst;
+    md_trajectory_frame_header_t hdr = {};
+    if (!md_trajectory_load_frame(traj, idx, &hdr, x, y, z)) return false;
+    if (h) {
+        h->num_atoms = (size_t)hdr.num_atoms; h->index = (int64_t)hdr.index; h->timestamp = (double)hdr.timestamp;
+        h->unitcell = unitcell(hdr.unitcell);
+    }
+    return true;
+}
+inline size_t num_frames_adapter(void* inst) { return (size_t)md_trajectory_num_frames((md_trajectory_i*)inst); }
+inline size_t num_atoms_adapter(void* inst) { return (size_t)md_trajectory_num_atoms((md_trajectory_i*)inst); }
+inline vmd_trajectory_i wrap_trajectory(md_trajectory_i* traj) {
+    vmd_trajectory_i t;
+    memset(&t, 0, sizeof(t));
+    t.inst = traj; t.num_frames = num_frames_adapter; t.num_atoms = num_atoms_adapter; t.load_frame = load_frame_adapter;
+    return t;
+}
+inline vmd_system_t wrap_system(const md_system_t* sys) {
+    vmd_system_t s;
+    memset(&s, 0, sizeof(s));
+    s.atom_count = (size_t)sys->atom.count;
+    s.x = sys->atom.x; s.y = sys->atom.y; s.z = sys->atom.z; s.mass = sys->atom.mass;
+    s.unitcell = unitcell(sys->unitcell);
+    return s;
+}
+}  // namespace vmd_shim
+
+/* the host's one extra call: which descriptors belong to this compiled script (NULL unbinds; call before md_script_eval_create) */
+inline void vmd_shim_bind_ir(const md_script_ir_t* md_ir, const vmd_script_ir_t* vmd_ir) {
+    vmd_shim::Registry& r = vmd_shim::registry();
+    std::lock_guard<std::mutex> l(r.mtx);
+    if (vmd_ir) r.ir[md_ir] = vmd_ir; else r.ir.erase(md_ir);
+}
+
+/* ---- md_script_eval_t ------------------------------------------------------------------------------------------------------ */
+struct md_script_eval_t {
+    vmd_script_eval_t* eval = nullptr;
+    const vmd_script_ir_t* vir = nullptr;
+    /* md_script_property_data_t records handed to VIAMD: fetched once and cached by the GUI (src/main.cpp:1286,1303), so their
+     * addresses are stable for the eval's lifetime; the arrays they point at are the backend's own (equally stable), the scalar
+     * fields (fingerprint, ranges, max_value) are refreshed from the backend whenever data may have changed */
+    struct Prop { std::string name; const vmd_script_property_data_t* src; md_script_property_data_t dst; md_script_aggregate_t agg; };
+    std::vector<std::unique_ptr<Prop>> props;
+    std::vector<uint64_t> mask_words;
+    md_bitfield_t mask;
+    std::mutex mtx;
+
+    void refresh() {
+        for (auto& p : props) {
+            const vmd_script_property_data_t* s = p->src;
+            md_script_property_data_t& d = p->dst;
+            for (int k = 0; k < 4; ++k) d.dim[k] = s->dim[k];
+            d.values = s->values; d.weights = s->weights; d.num_values = s->num_values;
+            d.min_value = s->min_value; d.max_value = s->max_value;
+            for (int k = 0; k < 2; ++k) { d.min_range[k] = s->min_range[k]; d.max_range[k] = s->max_range[k]; }
+            if (s->aggregate) {
+                p->agg.num_values = s->aggregate->num_values;
+                p->agg.population_mean = s->aggregate->population_mean;
+                p->agg.population_var = s->aggregate->population_var;
+                p->agg.population_ext = (decltype(p->agg.population_ext))s->aggregate->population_ext;
+                d.aggregate = &p->agg;
+            } else {
+                d.aggregate = nullptr;
+            }
+            d.fingerprint = s->fingerprint;      /* last: the GUI compares it to decide whether to re-read (src/main.cpp:1508-1509) */
+        }
+    }
+};
+
+inline md_script_eval_t* VMD_SHIM_PREFIX(md_script_eval_create)(size_t num_frames, const md_script_ir_t* ir, md_allocator_i* alloc) {
+    (void)alloc;                                 /* host allocations are the library's own */
+    const vmd_script_ir_t* vir = vmd_shim::find_ir(ir);
+    if (!vir) return nullptr;
+    std::unique_ptr<md_script_eval_t> e(new md_script_eval_t());
+    e->vir = vir;
+    e->eval = vmd_eval_create(num_frames, vir);
+    if (!e->eval) return nullptr;
+    const size_t n = vmd_ir_property_count(vir);
+    for (size_t i = 0; i < n; ++i) {
+        std::unique_ptr<md_script_eval_t::Prop> p(new md_script_eval_t::Prop());
+        p->name = vmd_ir_property_name(vir, i);
+        p->src = vmd_eval_property_data(e->eval, p->name.c_str());
+        memset(&p->dst, 0, sizeof(p->dst));
+        memset(&p->agg, 0, sizeof(p->agg));
+        /* unit[2]: mdlib's md_unit_t is not visible here; the backend carries the printed form (unit_str), which is what VIAMD
+         * shows (src/main.cpp:1314-1315) - a host with the real md_unit.h maps "\xC3\x85" to md_unit_angstrom() */
+        e->props.push_back(std::move(p));
+    }
+    e->mask_words.assign((num_frames + 63) / 64 + 1, 0);
+    memset(&e->mask, 0, sizeof(e->mask));
+    e->mask.bits = e->mask_words.data();
+    e->mask.beg_bit = 0;
+    e->mask.end_bit = (uint32_t)num_frames;
+    e->refresh();
+    return e.release();
+}
+inline void VMD_SHIM_PREFIX(md_script_eval_free)(md_script_eval_t* e) {
+    if (!e) return;
+    vmd_eval_free(e->eval);
+    delete e;
+}
+inline void VMD_SHIM_PREFIX(md_script_eval_clear_data)(md_script_eval_t* e) {
+    if (!e) return;
+    vmd_eval_clear_data(e->eval);
+    std::lock_guard<std::mutex> l(e->mtx);
+    e->refresh();
+}
+inline void VMD_SHIM_PREFIX(md_script_eval_interrupt)(md_script_eval_t* e) { if (e) vmd_eval_interrupt(e->eval); }
+inline uint64_t VMD_SHIM_PREFIX(md_script_eval_ir_fingerprint)(const md_script_eval_t* e) { return e ? vmd_eval_ir_fingerprint(e->eval) : 0; }
+/* md_script_ir_fingerprint of the bound IR: what src/main.cpp:987 compares the eval's fingerprint with */
+inline uint64_t vmd_shim_ir_fingerprint(const md_script_ir_t* ir) {
+    const vmd_script_ir_t* vir = vmd_shim::find_ir(ir);
+    return vir ? vmd_ir_fingerprint(vir) : 0;
+}
+
+/* the hot call: pool threads, disjoint ranges, one eval (src/main.cpp:993-997) */
+inline bool VMD_SHIM_PREFIX(md_script_eval_frame_range)(md_script_eval_t* e, const md_script_ir_t* ir, const md_system_t* sys,
+                                                        md_trajectory_i* traj, uint32_t frame_beg, uint32_t frame_end) {
+    if (!e || !sys || !traj) return false;
+    const vmd_script_ir_t* vir = vmd_shim::find_ir(ir);
+    if (vir != e->vir) return false;             /* mdlib compares fingerprints the same way */
+    const vmd_system_t vsys = vmd_shim::wrap_system(sys);
+    vmd_trajectory_i vtraj = vmd_shim::wrap_trajectory(traj);
+    const bool ok = vmd_eval_frame_range(e->eval, vir, &vsys, &vtraj, frame_beg, frame_end);
+    std::lock_guard<std::mutex> l(e->mtx);
+    e->refresh();
+    return ok;
+}
+
+inline const md_script_property_data_t* VMD_SHIM_PREFIX(md_script_eval_property_data)(const md_script_eval_t* e, str_t name) {
+    if (!e) return nullptr;
+    for (auto& p : e->props)
+        if (p->name.size() == (size_t)name.len && memcmp(p->name.data(), name.ptr, (size_t)name.len) == 0) return &p->dst;
+    return nullptr;
+}
+
+/* frames evaluated so far as the bitfield VIAMD iterates (src/main.cpp:194-210, 1513); refreshed by every call */
+inline const md_bitfield_t* VMD_SHIM_PREFIX(md_script_eval_frame_mask)(const md_script_eval_t* ce) {
+    md_script_eval_t* e = const_cast<md_script_eval_t*>(ce);
+    if (!e) return nullptr;
+    std::lock_guard<std::mutex> l(e->mtx);
+    vmd_eval_frame_mask_bits(e->eval, e->mask_words.data(), e->mask_words.size());
+    return &e->mask;
+}
+
+#endif /* VMD_MD_SCRIPT_SHIM_H */

@@ -529,6 +529,20 @@ struct vmd_script_eval_t {
         const vmd_unitcell_t* boxes_cells = nullptr; size_t boxes_f0 = 0, boxes_nb = 0; uint64_t boxes_version = 0;
     };
     Stage stages[2];
+    // compressed batches on their way to the device decoder, a ring of three: while the pair kernels of batch k run, batch k + 1 is
+    // being decompressed (decode_stream) and the bit streams of batch k + 2 cross PCIe (copy_stream) - three engines, three batches
+    struct RawSlot {
+        unsigned char* h = nullptr; size_t hcap = 0;     // pinned bit streams
+        DevBuf<unsigned char> d;
+        std::vector<vmd_xtc_frame_t> info;
+        DevBuf<vmd_xtc_frame_t> d_info;
+        std::vector<vmd_unitcell_t> cells;
+        hipEvent_t uploaded = nullptr;
+        size_t f0 = 0, nb = 0;
+        int state = 0;                                   // 1 = [f0, f0 + nb) uploaded (event recorded), 0 = nothing, -1 = not available raw
+    };
+    RawSlot raw_slots[3];
+    hipStream_t decode_stream = nullptr;
     hipStream_t copy_stream = nullptr;
     hipStream_t aux_stream = nullptr;        // background work nothing else queues behind (the clearing DMA of a volume's host view)
     DevBuf<uint64_t> d_partial;
@@ -547,6 +561,7 @@ struct vmd_script_eval_t {
     size_t atoms_checked = (size_t)-1;       // trajectory atom count the properties' indices were validated against (under mtx)
 };
 typedef vmd_script_eval_t::Stage Stage;
+typedef vmd_script_eval_t::RawSlot RawSlot;
 
 static PropState* find_prop(const vmd_script_eval_t* e, const char* name) {
     if (!e || !name) return nullptr;
@@ -659,6 +674,8 @@ extern "C" vmd_script_eval_t* vmd_eval_create(size_t num_frames, const vmd_scrip
     if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) { vmd_fail("hipStreamCreate failed"); return nullptr; }
     if (hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking) != hipSuccess) { vmd_fail("hipStreamCreate failed"); return nullptr; }
     if (hipStreamCreateWithFlags(&e->aux_stream, hipStreamNonBlocking) != hipSuccess) { vmd_fail("hipStreamCreate failed"); return nullptr; }
+    if (hipStreamCreateWithFlags(&e->decode_stream, hipStreamNonBlocking) != hipSuccess) { vmd_fail("hipStreamCreate failed"); return nullptr; }
+    for (auto& rs : e->raw_slots) if (hipEventCreateWithFlags(&rs.uploaded, hipEventDisableTiming) != hipSuccess) { vmd_fail("hipEventCreate failed"); return nullptr; }
     for (auto& st : e->stages) if (hipEventCreate(&st.ready) != hipSuccess) { vmd_fail("hipEventCreate failed"); return nullptr; }
     e->ir_fingerprint = vmd_ir_fingerprint(ir);
     e->num_frames = num_frames;
@@ -732,6 +749,15 @@ extern "C" void vmd_eval_free(vmd_script_eval_t* eval) {
         if (eval->stream) { (void)hipStreamSynchronize(eval->stream); }
         if (eval->copy_stream) { (void)hipStreamSynchronize(eval->copy_stream); }
         if (eval->aux_stream) { (void)hipStreamSynchronize(eval->aux_stream); }
+        if (eval->decode_stream) { (void)hipStreamSynchronize(eval->decode_stream); (void)hipStreamDestroy(eval->decode_stream); }
+        eval->decode_stream = nullptr;
+        for (auto& rs : eval->raw_slots) {
+            if (rs.h) (void)hipHostFree(rs.h);
+            rs.h = nullptr;
+            rs.d.release(); rs.d_info.release();
+            if (rs.uploaded) (void)hipEventDestroy(rs.uploaded);
+            rs.uploaded = nullptr;
+        }
         for (auto& st : eval->stages) {
             if (st.h) (void)hipHostFree(st.h);
             st.h = nullptr;
@@ -1080,7 +1106,7 @@ struct BatchSrc {
 // with the batch's `ready` event and are looked at when the batch is about to be used (settle_stage).  Returns 1 when the decode
 // is queued into st.d, 0 when the batch has to go through load_frame (a frame is not available raw), -1 on error.
 static int launch_raw_decode(vmd_script_eval_t* e, Stage& st, const unsigned char* d_raw, const vmd_xtc_frame_t* d_info, size_t num_atoms,
-                             size_t nb, size_t npad) {
+                             size_t nb, size_t npad, hipStream_t stream) {
     if (nb > st.h_raw_status_cap) {
         if (st.h_raw_status) (void)hipHostFree(st.h_raw_status);
         st.h_raw_status = nullptr; st.h_raw_status_cap = 0;
@@ -1090,35 +1116,38 @@ static int launch_raw_decode(vmd_script_eval_t* e, Stage& st, const unsigned cha
     if (!st.d.ensure(nb * 3 * npad) || !st.d_raw_status.ensure(nb)) return -1;
     int rc;
     const int mode = g_opt.xtc_device_decode.load();
-    e->prof_copy.begin("xtc_decode", e->copy_stream);
+    e->prof_copy.begin("xtc_decode", stream);
     if (mode == 2) {
         const int chunk = std::max(64, g_opt.xtc_chunk.load());
         if (!st.d_raw_scratch.ensure((vmd_hip_xtc_scratch_bytes((int)nb, (int)num_atoms, chunk) + 7) / 8)) return -1;
-        rc = vmd_hip_xtc_decode_chunked(e->copy_stream, d_raw, d_info, (int)nb, (int)num_atoms, st.d.p, 3 * npad, npad,
+        rc = vmd_hip_xtc_decode_chunked(stream, d_raw, d_info, (int)nb, (int)num_atoms, st.d.p, 3 * npad, npad,
                                         st.d_raw_status.p, chunk, st.d_raw_scratch.p);
     } else if (mode == 1) {
-        rc = vmd_hip_xtc_decode(e->copy_stream, d_raw, d_info, (int)nb, (int)num_atoms, st.d.p, 3 * npad, npad, st.d_raw_status.p);
+        rc = vmd_hip_xtc_decode(stream, d_raw, d_info, (int)nb, (int)num_atoms, st.d.p, 3 * npad, npad, st.d_raw_status.p);
     } else {
-        rc = vmd_hip_xtc_decode_wave(e->copy_stream, d_raw, d_info, (int)nb, (int)num_atoms, st.d.p, 3 * npad, npad, st.d_raw_status.p);
+        rc = vmd_hip_xtc_decode_wave(stream, d_raw, d_info, (int)nb, (int)num_atoms, st.d.p, 3 * npad, npad, st.d_raw_status.p);
     }
-    e->prof_copy.end(e->copy_stream);
+    e->prof_copy.end(stream);
     if (rc != 0) { vmd_fail("XTC decode kernel launch failed"); return -1; }
     for (size_t b = 0; b < nb; ++b) st.h_raw_status[b] = 99u;
-    if (hipMemcpyAsync(st.h_raw_status, st.d_raw_status.p, nb * sizeof(uint32_t), hipMemcpyDeviceToHost, e->copy_stream) != hipSuccess) { vmd_fail("device XTC decode failed"); return -1; }
+    if (hipMemcpyAsync(st.h_raw_status, st.d_raw_status.p, nb * sizeof(uint32_t), hipMemcpyDeviceToHost, stream) != hipSuccess) { vmd_fail("device XTC decode failed"); return -1; }
     st.raw_pending = true;
     return 1;
 }
 
-static int fetch_stage_raw(vmd_script_eval_t* e, Stage& st, vmd_trajectory_i* traj, size_t num_atoms, size_t f0, size_t nb, size_t npad) {
-    st.raw_info.resize(nb);
+// First half of the compressed path: read the bit streams of frames [f0, f0 + nb) into the slot's pinned block (load threads) and queue
+// their DMA on copy_stream.  1 = queued (slot.uploaded recorded), 0 = a frame is not available raw, -1 error.
+static int raw_upload(vmd_script_eval_t* e, RawSlot& rs, vmd_trajectory_i* traj, size_t num_atoms, size_t f0, size_t nb) {
+    rs.state = 0; rs.f0 = f0; rs.nb = nb;
+    rs.info.resize(nb);
+    rs.cells.resize(nb);
     std::vector<vmd_raw_frame_t> infos(nb);
     size_t total = 0;
     for (size_t b = 0; b < nb; ++b) {                      // sizes first (no payload), then one pinned block for the batch
         vmd_frame_header_t hdr;
-        if (!traj->load_raw(traj->inst, (int64_t)(f0 + b), &hdr, &infos[b], nullptr, 0) || infos[b].codec != VMD_RAW_CODEC_XTC) return 0;
-        if (hdr.num_atoms != num_atoms) return 0;
-        st.cells[b] = hdr.unitcell;
-        vmd_xtc_frame_t& fi = st.raw_info[b];
+        if (!traj->load_raw(traj->inst, (int64_t)(f0 + b), &hdr, &infos[b], nullptr, 0) || infos[b].codec != VMD_RAW_CODEC_XTC || hdr.num_atoms != num_atoms) { rs.state = -1; return 0; }
+        rs.cells[b] = hdr.unitcell;
+        vmd_xtc_frame_t& fi = rs.info[b];
         fi.precision = infos[b].precision;
         for (int k = 0; k < 3; ++k) { fi.minint[k] = infos[b].minint[k]; fi.maxint[k] = infos[b].maxint[k]; }
         fi.smallidx = infos[b].smallidx;
@@ -1126,12 +1155,12 @@ static int fetch_stage_raw(vmd_script_eval_t* e, Stage& st, vmd_trajectory_i* tr
         fi.nbytes = infos[b].nbytes;
         total += ((size_t)infos[b].nbytes + 32 + 63) & ~(size_t)63;     // >= 32 readable bytes behind every stream, 64-byte aligned starts
     }
-    if (total > st.hraw_cap) {
-        if (st.hraw) (void)hipHostFree(st.hraw);
-        st.hraw = nullptr; st.hraw_cap = 0;
+    if (total > rs.hcap) {
+        if (rs.h) (void)hipHostFree(rs.h);
+        rs.h = nullptr; rs.hcap = 0;
         const size_t cap = total + total / 8;                            // frames of one trajectory differ by a few per cent
-        if (hipHostMalloc((void**)&st.hraw, cap, hipHostMallocDefault) != hipSuccess) { vmd_fail("hipHostMalloc(%zu bytes) failed", cap); return -1; }
-        st.hraw_cap = cap;
+        if (hipHostMalloc((void**)&rs.h, cap, hipHostMallocDefault) != hipSuccess) { vmd_fail("hipHostMalloc(%zu bytes) failed", cap); return -1; }
+        rs.hcap = cap;
     }
     const size_t nthreads = std::max<size_t>(1, std::min<size_t>(load_threads(), nb / 4));
     std::atomic<size_t> next{0};
@@ -1140,9 +1169,9 @@ static int fetch_stage_raw(vmd_script_eval_t* e, Stage& st, vmd_trajectory_i* tr
         for (;;) {
             const size_t b = next.fetch_add(1);
             if (b >= nb || !ok.load()) break;
-            const vmd_xtc_frame_t& fi = st.raw_info[b];
+            const vmd_xtc_frame_t& fi = rs.info[b];
             vmd_raw_frame_t info;
-            unsigned char* dst = st.hraw + fi.offset;
+            unsigned char* dst = rs.h + fi.offset;
             if (!traj->load_raw(traj->inst, (int64_t)(f0 + b), nullptr, &info, dst, (size_t)fi.nbytes) || info.nbytes != fi.nbytes) { ok = false; break; }
             memset(dst + fi.nbytes, 0, (((size_t)fi.nbytes + 32 + 63) & ~(size_t)63) - (size_t)fi.nbytes);
         }
@@ -1154,18 +1183,21 @@ static int fetch_stage_raw(vmd_script_eval_t* e, Stage& st, vmd_trajectory_i* tr
         work();
         for (auto& t : pool) t.join();
     }
-    if (!ok.load()) return 0;                              // let load_frame produce the real error message
-    if (!st.d_raw.ensure(total + total / 8)) return -1;
-    if (!st.d_raw_info.upload(st.raw_info.data(), nb, e->copy_stream)) return -1;
-    if (hipMemcpyAsync(st.d_raw.p, st.hraw, total, hipMemcpyHostToDevice, e->copy_stream) != hipSuccess) { vmd_fail("hipMemcpyAsync of the compressed batch failed"); return -1; }
-    return launch_raw_decode(e, st, st.d_raw.p, st.d_raw_info.p, num_atoms, nb, npad);
+    if (!ok.load()) { rs.state = -1; return 0; }           // let load_frame produce the real error message
+    if (!rs.d.ensure(total + total / 8)) return -1;
+    if (!rs.d_info.upload(rs.info.data(), nb, e->copy_stream)) return -1;
+    if (hipMemcpyAsync(rs.d.p, rs.h, total, hipMemcpyHostToDevice, e->copy_stream) != hipSuccess) { vmd_fail("hipMemcpyAsync of the compressed batch failed"); return -1; }
+    if (hipEventRecord(rs.uploaded, e->copy_stream) != hipSuccess) { vmd_fail("hipEventRecord failed"); return -1; }
+    rs.state = 1;
+    return 1;
 }
 
 // bring frames [f0, f0+nb) to the device (or alias them in place) through stage `st`: fills st.cells / st.h_boxes, queues
 // the copies on copy_stream and records st.ready
 static bool fetch_stage(vmd_script_eval_t* e, Stage& st, vmd_trajectory_i* traj, const vmd_device_view_t* view, size_t num_atoms,
-                        size_t f0, size_t nb, bool force_host = false) {
+                        size_t f0, size_t nb, bool force_host = false, RawSlot* pre = nullptr) {
     st.raw_pending = false;
+    hipStream_t ss = e->copy_stream;         // the stream this stage's `ready` is recorded on
     vmd_host_view_t hv;
     const vmd_host_view_t* hview = (!view && traj->host_view && traj->host_view(traj->inst, &hv)) ? &hv : nullptr;
     st.f0 = f0; st.nb = nb;
@@ -1206,11 +1238,21 @@ static bool fetch_stage(vmd_script_eval_t* e, Stage& st, vmd_trajectory_i* traj,
         if (!force_host && traj->raw_device_view && traj->raw_device_view(traj->inst, &rv) && rv.codec == VMD_RAW_CODEC_XTC && rv.device == e->device) {
             // the compressed trajectory is resident in HBM: no host work, no PCIe - decode the batch where it lies
             for (size_t b = 0; b < nb; ++b) st.cells[b] = rv.cells[f0 + b];
-            raw = launch_raw_decode(e, st, rv.base, (const vmd_xtc_frame_t*)rv.info + f0, num_atoms, nb, npad);
+            raw = launch_raw_decode(e, st, rv.base, (const vmd_xtc_frame_t*)rv.info + f0, num_atoms, nb, npad, ss);
             if (raw < 0) return false;
         } else if (!force_host && g_opt.xtc_device_decode.load() && traj->load_raw) {
-            raw = fetch_stage_raw(e, st, traj, num_atoms, f0, nb, npad);
-            if (raw < 0) return false;
+            // the bit streams were (or are now) sent ahead through a slot of the ring; decompression runs on its own stream
+            RawSlot* rs = (pre && pre->f0 == f0 && pre->nb == nb && pre->state != 0) ? pre : &e->raw_slots[0];
+            if (rs != pre && (raw = raw_upload(e, *rs, traj, num_atoms, f0, nb)) < 0) return false;
+            if (rs->state == 1) {
+                ss = e->decode_stream;
+                st.cells = rs->cells;
+                HIP_OK(hipStreamWaitEvent(ss, rs->uploaded, 0));
+                raw = launch_raw_decode(e, st, rs->d.p, rs->d_info.p, num_atoms, nb, npad, ss);
+                if (raw < 0) return false;
+            } else {
+                raw = 0;
+            }
         }
         if (raw == 1) {
             st.base = st.d.p;
@@ -1278,8 +1320,8 @@ static bool fetch_stage(vmd_script_eval_t* e, Stage& st, vmd_trajectory_i* traj,
         hb[3] = 1.0f / c.x; hb[4] = 1.0f / c.y; hb[5] = 1.0f / c.z;      // SPEC S2: invL = fl(1.0f / L)
         hb[6] = c.xy; hb[7] = c.xz; hb[8] = c.yz;
     }
-    if (!st.d_boxes.upload(st.h_boxes.data(), nb * 9, e->copy_stream)) return false;
-    HIP_OK(hipEventRecord(st.ready, e->copy_stream));
+    if (!st.d_boxes.upload(st.h_boxes.data(), nb * 9, ss)) return false;
+    HIP_OK(hipEventRecord(st.ready, ss));
     if (view && view->cells_version != 0) { st.boxes_cells = view->cells; st.boxes_f0 = f0; st.boxes_nb = nb; st.boxes_version = view->cells_version; }
     return true;
 }
@@ -1304,7 +1346,7 @@ static bool fetch_batch(vmd_script_eval_t* e, vmd_trajectory_i* traj, const vmd_
     Stage& st = e->stages[0];
     if (!fetch_stage(e, st, traj, view, num_atoms, f0, nb)) return false;
     if (!settle_stage(e, st, traj, num_atoms)) return false;
-    HIP_OK(hipStreamSynchronize(e->copy_stream));
+    HIP_OK(hipEventSynchronize(st.ready));
     src->base = st.base; src->frame_stride = st.frame_stride; src->row_stride = st.row_stride;
     return true;
 }
@@ -1610,7 +1652,19 @@ static bool process_range(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
 
     bool completed = true;
     int cur = 0;
-    if (!batches.empty() && !fetch_stage(e, e->stages[cur], traj, vw, num_atoms, batches[0].f0, batches[0].nb)) return false;
+    // compressed frames for the device decoder travel two batches ahead through a ring of three slots (RawSlot)
+    vmd_host_view_t hv_probe;
+    vmd_raw_device_view_t rv_probe;
+    const bool raw_ring = !have_view && traj->load_raw && g_opt.xtc_device_decode.load() != 0 &&
+                          !(traj->host_view && traj->host_view(traj->inst, &hv_probe)) &&
+                          !(traj->raw_device_view && traj->raw_device_view(traj->inst, &rv_probe));
+    auto slot_of = [&](size_t bi) -> RawSlot* { return raw_ring ? &e->raw_slots[bi % 3] : nullptr; };
+    if (raw_ring) {
+        for (auto& rs : e->raw_slots) rs.state = 0;
+        for (size_t bi = 0; bi < std::min<size_t>(2, batches.size()); ++bi)
+            if (raw_upload(e, *slot_of(bi), traj, num_atoms, batches[bi].f0, batches[bi].nb) < 0) return false;
+    }
+    if (!batches.empty() && !fetch_stage(e, e->stages[cur], traj, vw, num_atoms, batches[0].f0, batches[0].nb, false, slot_of(0))) return false;
     for (size_t bi = 0; bi < batches.size(); ++bi, cur ^= 1) {
         if (e->interrupt) { completed = false; break; }
         const Batch& bt = batches[bi];
@@ -1746,7 +1800,10 @@ static bool process_range(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
         }
         // the kernels of this batch are queued: load the next batch on the host while they run
         if (bi + 1 < batches.size() && !e->interrupt) {
-            if (!fetch_stage(e, e->stages[cur ^ 1], traj, vw, num_atoms, batches[bi + 1].f0, batches[bi + 1].nb)) return false;
+            if (!fetch_stage(e, e->stages[cur ^ 1], traj, vw, num_atoms, batches[bi + 1].f0, batches[bi + 1].nb, false, slot_of(bi + 1))) return false;
+            // ... and send the bit streams of the batch after that on their way (its slot held batch bi - 1: decoded long ago)
+            if (raw_ring && bi + 2 < batches.size() &&
+                raw_upload(e, *slot_of(bi + 2), traj, num_atoms, batches[bi + 2].f0, batches[bi + 2].nb) < 0) return false;
         }
         HIP_OK(hipStreamSynchronize(e->stream));
         // a bucket of the two-level cell build was too small: nothing reached the histograms (every consumer saw the flag).
