@@ -139,7 +139,7 @@ inline md_script_eval_t* VMD_SHIM_PREFIX(md_script_eval_create)(size_t num_frame
     const size_t n = vmd_ir_property_count(vir);
     for (size_t i = 0; i < n; ++i) {
         std::unique_ptr<md_script_eval_t::Prop> p(new md_script_eval_t::Prop());
-        p->name = vmd_ir_property_name(vir, i);
+        p->name = vmd_ir_property_names(vir)[i];
         p->src = vmd_eval_property_data(e->eval, p->name.c_str());
         memset(&p->dst, 0, sizeof(p->dst));
         memset(&p->agg, 0, sizeof(p->agg));

@@ -107,3 +107,43 @@ def test_native_host_from_dcd_and_script_text_on_the_emulator(tmp_path, emu_lib,
     g8 = V.downsample_histogram(ev.property_data("g").values, ev.property_data("g").weights, 8, lib=emu_lib)
     got8 = [float(t) for t in lines["g"].split("g8=")[1].split(",")]
     np.testing.assert_allclose(got8, g8[6:8], rtol=1e-5)
+
+
+SHIM_SRC = os.path.join(ROOT, "tests", "native", "shim_callsites.cpp")
+SHIM_EXE = os.path.join(ROOT, "tests", "native", "shim_callsites")
+
+
+def build_shim_callsites():
+    """VIAMD's call sequence re-typed against a mock of mdlib's declarations, bound to libviamd_amd.so through
+    include/vmd_md_script_shim.h (compiled by __graft_entry__.build() too: a boundary that stops compiling is caught without a GPU)."""
+    from viamd_amd import build
+    lib = build.build()
+    deps = [SHIM_SRC, lib, os.path.join(ROOT, "include", "vmd_md_script_shim.h"), os.path.join(ROOT, "tests", "native", "md_mock.h")]
+    if os.path.exists(SHIM_EXE) and os.path.getmtime(SHIM_EXE) >= max(os.path.getmtime(d) for d in deps):
+        return SHIM_EXE
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", SHIM_SRC, "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "tests", "native"),
+                           "-L" + os.path.join(ROOT, "viamd_amd"), "-lviamd_amd", "-L/opt/rocm/lib", "-Wl,-rpath,$ORIGIN/../../viamd_amd",
+                           "-Wl,-rpath,/opt/rocm/lib", "-Wl,-rpath-link,/opt/rocm/lib", "-lpthread", "-o", SHIM_EXE])
+    return SHIM_EXE
+
+
+def test_md_script_shim_call_sites_on_the_emulator(tmp_path, emu_lib):
+    """include/vmd_md_script_shim.h: md_script_eval_create / _clear_data / _frame_range (pool threads) / _property_data / _frame_mask /
+    _interrupt / _free with mdlib's signatures, driven by a re-typed copy of /root/reference/src/main.cpp:951-1039, 1275-1316, 1508-1524
+    (here against the SIMT-emulator build of the library, so it runs without a GPU): same bits as direct vmd_* calls."""
+    import conftest
+    assert os.access(build_shim_callsites(), os.X_OK)                  # links against the product library
+    emu = conftest.build_emu()
+    exe = str(tmp_path / "shim_callsites_emu")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", SHIM_SRC, "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "tests", "native"), emu,
+                           "-Wl,-rpath," + os.path.dirname(emu), "-lpthread", "-o", exe])
+    out = subprocess.run([exe, "12"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.startswith("OK frames=12"), out.stdout
+
+
+@pytest.mark.gpu
+def test_md_script_shim_call_sites(gpu_lib):
+    out = subprocess.run([build_shim_callsites(), "48"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.startswith("OK frames=48"), out.stdout

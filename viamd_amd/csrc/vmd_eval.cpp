@@ -85,6 +85,8 @@ struct Options {
                                              // 3 = one wave per frame (k_xtc_wave)
     std::atomic<int> xtc_chunk{256};         // atoms per chunk of variant 2
     std::atomic<int> stage_frames{128};      // frames per staged batch of a host / file trajectory (batch_frames <= 0)
+    std::atomic<int> rdf_blocks_decode{1536};   // pair-kernel grid while batches are decompressed on the device: 6 blocks per CU leave every
+                                                // SIMD one wave slot and 80 VGPRs, so k_xtc_wave of batch k + 1 runs under the pair kernel of batch k
     std::atomic<int> sdf_dense{0};       // dense-target SDF scatter (stream whole frames, select by tag): measured slower, off
     std::atomic<int> sdf_arith{1};       // SDF target lists that are arithmetic progressions are generated on the device (0 = always load the index list)
     std::atomic<int> rdf_classes{1};     // co-evaluated RDFs of one range share pair passes through disjoint atom classes (0 = one pass per property)
@@ -115,6 +117,7 @@ extern "C" int vmd_set_option(const char* key, int value) {
     else if (!strcmp(key, "xtc_chunk")) o = &g_opt.xtc_chunk;
     else if (!strcmp(key, "xtc_waves")) return vmd_hip_set_xtc_waves(value);
     else if (!strcmp(key, "stage_frames")) o = &g_opt.stage_frames;
+    else if (!strcmp(key, "rdf_blocks_decode")) o = &g_opt.rdf_blocks_decode;
     else if (!strcmp(key, "rdf_classes")) o = &g_opt.rdf_classes;
     else if (!strcmp(key, "sdf_arith")) o = &g_opt.sdf_arith;
     else if (!strcmp(key, "sdf_ilp")) return vmd_hip_set_sdf_ilp(value);
@@ -674,7 +677,11 @@ extern "C" vmd_script_eval_t* vmd_eval_create(size_t num_frames, const vmd_scrip
     if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) { vmd_fail("hipStreamCreate failed"); return nullptr; }
     if (hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking) != hipSuccess) { vmd_fail("hipStreamCreate failed"); return nullptr; }
     if (hipStreamCreateWithFlags(&e->aux_stream, hipStreamNonBlocking) != hipSuccess) { vmd_fail("hipStreamCreate failed"); return nullptr; }
-    if (hipStreamCreateWithFlags(&e->decode_stream, hipStreamNonBlocking) != hipSuccess) { vmd_fail("hipStreamCreate failed"); return nullptr; }
+    {   // the decoder's waves should get the wave slots the pair kernel leaves free as soon as a batch has arrived: highest priority
+        int lo = 0, hi = 0;
+        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { lo = hi = 0; }
+        if (hipStreamCreateWithPriority(&e->decode_stream, hipStreamNonBlocking, hi) != hipSuccess) { vmd_fail("hipStreamCreate failed"); return nullptr; }
+    }
     for (auto& rs : e->raw_slots) if (hipEventCreateWithFlags(&rs.uploaded, hipEventDisableTiming) != hipSuccess) { vmd_fail("hipEventCreate failed"); return nullptr; }
     for (auto& st : e->stages) if (hipEventCreate(&st.ready) != hipSuccess) { vmd_fail("hipEventCreate failed"); return nullptr; }
     e->ir_fingerprint = vmd_ir_fingerprint(ir);
@@ -1642,16 +1649,6 @@ static bool process_range(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
     std::vector<std::pair<size_t, size_t>> segments;
     if (!reuse_blocks(e, frame_beg, frame_end, &segments)) return false;
 
-    // frames per launch: as many as the scratch budget allows, split evenly so that no small tail batch is left
-    size_t Bmax = auto_batch(e, num_atoms, !have_view);
-    const vmd_device_view_t* vw = have_view ? &view : nullptr;
-    // host trajectories are staged in smaller batches so that load_frame of batch k+1 overlaps the kernels of batch k
-    if (!have_view && g_opt.batch_frames <= 0) Bmax = std::min<size_t>(Bmax, (size_t)std::max(1, g_opt.stage_frames.load()));
-    std::vector<Batch> batches;
-    for (auto& sg : segments) plan_batches(e, sg.first, sg.second, Bmax, &batches);
-
-    bool completed = true;
-    int cur = 0;
     // compressed frames for the device decoder travel two batches ahead through a ring of three slots (RawSlot)
     vmd_host_view_t hv_probe;
     vmd_raw_device_view_t rv_probe;
@@ -1659,6 +1656,42 @@ static bool process_range(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
                           !(traj->host_view && traj->host_view(traj->inst, &hv_probe)) &&
                           !(traj->raw_device_view && traj->raw_device_view(traj->inst, &rv_probe));
     auto slot_of = [&](size_t bi) -> RawSlot* { return raw_ring ? &e->raw_slots[bi % 3] : nullptr; };
+    // batches decompressed on the device while the previous batch is in the pair kernel: the persistent pair grid leaves room for them
+    const bool device_decode = raw_ring || (!have_view && traj->raw_device_view && traj->raw_device_view(traj->inst, &rv_probe));
+
+    // frames per launch: as many as the scratch budget allows, split evenly so that no small tail batch is left
+    size_t Bmax = auto_batch(e, num_atoms, !have_view);
+    const vmd_device_view_t* vw = have_view ? &view : nullptr;
+    // host trajectories are staged in smaller batches so that load_frame of batch k+1 overlaps the kernels of batch k
+    if (!have_view && g_opt.batch_frames <= 0) Bmax = std::min<size_t>(Bmax, (size_t)std::max(1, g_opt.stage_frames.load()) * (device_decode ? 4 : 1));
+    std::vector<Batch> batches;
+    if (device_decode && g_opt.batch_frames <= 0 && e->block_frames == 0) {
+        // the decoder is latency bound - a batch of 512 frames takes little longer than one of 64 - so batches should be large, but
+        // nothing overlaps the FIRST batch's trip (PCIe, decode): ramp up from a small one (64, 128, 256, ... frames)
+        for (auto& sg : segments) {
+            size_t size = std::min<size_t>(64, Bmax);
+            for (size_t f = sg.first; f < sg.second;) {
+                size_t nbf = std::min(size, sg.second - f);
+                if (sg.second - f - nbf < size / 2) nbf = sg.second - f;       // no crumb at the end
+                batches.push_back({f, nbf, -1});
+                f += nbf;
+                size = std::min(size * 2, Bmax);
+            }
+        }
+    } else {
+        for (auto& sg : segments) plan_batches(e, sg.first, sg.second, Bmax, &batches);
+    }
+
+    bool completed = true;
+    int cur = 0;
+    struct BlocksGuard {
+        int old = -1;
+        ~BlocksGuard() { if (old > 0) vmd_hip_set_rdf_blocks(old); }
+    } blocks_guard;
+    if (device_decode && batches.size() > 1 && g_opt.rdf_blocks_decode.load() >= 8) {
+        blocks_guard.old = vmd_hip_set_rdf_blocks(g_opt.rdf_blocks_decode.load());
+        if (blocks_guard.old < g_opt.rdf_blocks_decode.load()) vmd_hip_set_rdf_blocks(blocks_guard.old);      // never raise a smaller setting
+    }
     if (raw_ring) {
         for (auto& rs : e->raw_slots) rs.state = 0;
         for (size_t bi = 0; bi < std::min<size_t>(2, batches.size()); ++bi)

@@ -398,10 +398,9 @@ __global__ __launch_bounds__(64) void k_xtc_chunks(const unsigned char* __restri
 // ---- variant 3: one WAVE per frame.  The serial part of a stream is only the walk from group to group (flag bit, 5-bit run code,
 // field widths); everything else - mixed-radix splits, conversions, stores - is independent per group.  So a wave walks its frame
 // and decodes it 64 groups at a time:
-//   * the stream lives in VGPRs, never in LDS (the pair kernel next door owns the CU's LDS): two banks of eight registers, one
-//     64-dword block per register.  While the walk is inside one bank (an "epoch" of 512 dwords) the other bank is in flight:
-//     its eight coalesced 256-byte loads are issued at the start of the epoch and nobody touches those registers until the walk
-//     gets there, 2 KB later.  The loop body exists twice, once per bank role, so that no register is ever moved - a move of a
+//   * the stream lives in VGPRs, never in LDS (the pair kernel next door owns the CU's LDS): two banks of XTC_BANK registers, one
+//     64-dword block per register.  While the walk is inside one bank (an "epoch") the other bank is in flight: its coalesced
+//     256-byte loads are issued at the start of the epoch and nobody touches those registers until the walk gets there.  The loop body exists twice, once per bank role, so that no register is ever moved - a move of a
 //     loaded value is a use, and a use waits (the first version rotated three registers and stalled a full memory latency per
 //     block: 3.9 of 6.1 ms per 100k-atom frame);
 //   * speculative walk: a group whose flag bit is 0 inherits (run, smallidx) and has the same length L as the one before it, so
@@ -432,9 +431,12 @@ __device__ __forceinline__ double xtc_shfl_f64(double v, int src) {
     return r;
 }
 
-struct XtcBank { uint32_t r[8]; };          // eight 64-dword blocks of the stream, one dword per lane, as loaded (little-endian)
+#define XTC_BANK 4                          // blocks per bank: 4 x 256 bytes in flight behind the walk (8 cost 8 more VGPRs for nothing measurable)
+struct XtcBank { uint32_t r[XTC_BANK]; };   // 64-dword blocks of the stream, one dword per lane, as loaded (little-endian)
 
-__global__ __launch_bounds__(64) void k_xtc_wave(const unsigned char* __restrict__ raw, const vmd_xtc_frame_t* __restrict__ info,
+// at most 80 VGPRs: one of these waves then fits on a SIMD next to six waves of the pair kernel (72 VGPRs each) - the decode of batch
+// k + 1 is meant to run UNDER the pair kernel of batch k, not after it
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_xtc_wave(const unsigned char* __restrict__ raw, const vmd_xtc_frame_t* __restrict__ info,
                                                  int B, int natoms, float* __restrict__ xyz, size_t frame_stride, size_t row_stride,
                                                  uint32_t* __restrict__ status) {
     const int f = blockIdx.x;
@@ -475,10 +477,10 @@ __global__ __launch_bounds__(64) void k_xtc_wave(const unsigned char* __restrict
     int vatom = 0;
     bool done = false;
 
-    // walks while the window stays inside `cur` (dwords [epoch, epoch + 512)); `nxt` receives the 512 dwords behind it
+    // walks while the window stays inside `cur` (dwords [epoch, epoch + 64 * XTC_BANK)); `nxt` receives the blocks behind it
     auto run_epoch = [&](const XtcBank& cur, XtcBank& nxt) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) nxt.r[k] = load_block(epoch + 512u + 64u * (uint32_t)k);
+        for (int k = 0; k < XTC_BANK; ++k) nxt.r[k] = load_block(epoch + 64u * (uint32_t)XTC_BANK + 64u * (uint32_t)k);
         for (;;) {
             const bool finished = i >= natoms || st != 0;
             if (g == 64 || (finished && g > 0)) {
@@ -508,7 +510,7 @@ __global__ __launch_bounds__(64) void k_xtc_wave(const unsigned char* __restrict
             }
             if (i >= natoms || st != 0) { done = true; return; }
             const uint32_t blk = ((pos >> 5) - epoch) >> 6;       // the window is blocks blk, blk + 1 of this epoch
-            if (blk >= 8u) return;                                // the walk has left the bank
+            if (blk >= (uint32_t)XTC_BANK) return;                // the walk has left the bank
             const uint32_t base = epoch + 64u * blk;
             const int per = 1 + run / 3;                          // atoms and bits of a group that inherits (run, smallidx)
             const uint32_t L = large_bits + 1u + (uint32_t)(run / 3) * (uint32_t)smallidx;
@@ -520,11 +522,13 @@ __global__ __launch_bounds__(64) void k_xtc_wave(const unsigned char* __restrict
                 case 0: XTC_WIN(cur.r[0], cur.r[1]); break;
                 case 1: XTC_WIN(cur.r[1], cur.r[2]); break;
                 case 2: XTC_WIN(cur.r[2], cur.r[3]); break;
+#if XTC_BANK == 8
                 case 3: XTC_WIN(cur.r[3], cur.r[4]); break;
                 case 4: XTC_WIN(cur.r[4], cur.r[5]); break;
                 case 5: XTC_WIN(cur.r[5], cur.r[6]); break;
                 case 6: XTC_WIN(cur.r[6], cur.r[7]); break;
-                default: XTC_WIN(cur.r[7], nxt.r[0]); break;
+#endif
+                default: XTC_WIN(cur.r[XTC_BANK - 1], nxt.r[0]); break;
             }
 #undef XTC_WIN
             const uint32_t d0 = __builtin_bswap32((q & 64u) ? b0 : a0), d1 = __builtin_bswap32((q1 & 64u) ? b1 : a1);
@@ -568,14 +572,14 @@ __global__ __launch_bounds__(64) void k_xtc_wave(const unsigned char* __restrict
 
     XtcBank bank_a, bank_b;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { bank_a.r[k] = load_block(64u * (uint32_t)k); bank_b.r[k] = 0; }
+    for (int k = 0; k < XTC_BANK; ++k) { bank_a.r[k] = load_block(64u * (uint32_t)k); bank_b.r[k] = 0; }
     for (;;) {
         run_epoch(bank_a, bank_b);
         if (done) break;
-        epoch += 512u;
+        epoch += 64u * (uint32_t)XTC_BANK;
         run_epoch(bank_b, bank_a);
         if (done) break;
-        epoch += 512u;
+        epoch += 64u * (uint32_t)XTC_BANK;
     }
     if (st && lane == 0) atomicMax(&status[f], st);
 }
