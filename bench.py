@@ -235,15 +235,20 @@ def run_workload(name, args, ctx, steps, warmup, frames=None, with_cpu=False, op
     ev = V.ScriptEval(F, ir)
     sysm = V.MolSystem(w["atoms"], mass=topo.mass, unitcell=cell)
 
+    merge_s = [0.0]
+
     def step():
         ev.clear_data()
         assert ev.frame_range(sysm, traj, beg, end)
+        t_m = time.perf_counter()
         reduce_eval(ev)                          # vmd_eval_reduce over RCCL: ONE merge of the accumulators per step (no-op at N = 1)
+        merge_s[0] += time.perf_counter() - t_m
 
     for _ in range(warmup):
         step()
     lib.vmd_profile_reset()
     lib.vmd_profile_enable(True)
+    merge_s[0] = 0.0
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
@@ -350,6 +355,15 @@ def run_workload(name, args, ctx, steps, warmup, frames=None, with_cpu=False, op
         except Exception:
             pass
         out["cell_build"] = cb
+    if dist:
+        # what carried the merge, how many ranks IT saw (not WORLD_SIZE: the driver can check rccl_ranks == n_gpus), what it moved
+        from viamd_amd.dist import collective_info, reduce_stats
+        ci = collective_info(lib) or {}
+        out["merge"] = dict(reduce_stats(ev), collective=ci.get("kind"), rccl_ranks=ci.get("ranks"), fallback_reason=ci.get("fallback_reason"),
+                            host_ms_per_step=merge_s[0] / steps * 1e3,
+                            note="one vmd_eval_reduce per step: all all-reduces of a merge inside one ncclGroupStart / End; device_ms = hipEvents "
+                                 "around the staged collectives of the LAST step, host_ms_per_step = wall time of the call (pack, merge, "
+                                 "unpack, finalize) averaged over the timed steps, this rank")
     if args.traj in ("xtc", "xtc-resident"):
         # > 0 only with --opt xtc_device_decode=N or a compressed-resident trajectory: decompressed by the k_xtc_* kernels
         out["config"]["frames_decompressed_on_device_per_step"] = ev.frames_device_decoded()

@@ -284,6 +284,8 @@ typedef struct vmd_accum_view_t {
     size_t    num_weights;
     float*    temporal;        /* host, temporal rows */
     size_t    num_temporal;
+    uint64_t  count_bound;     /* no element of counts_dev can exceed this after the merge of ALL frames (0 = unknown): a volume whose
+                                  bound fits 32 bits is merged as u32, half the bytes on the links */
 } vmd_accum_view_t;
 size_t vmd_eval_accum_views(vmd_script_eval_t* eval, vmd_accum_view_t* out, size_t cap);
 /* bring the host u64 mirror (`counts`) of a property up to date with the device accumulators */
@@ -307,10 +309,25 @@ typedef struct vmd_collective_i {
     /* in-place SUM over all ranks of `n` elements of DEVICE memory, enqueued on `stream` (hipStream_t) */
     bool (*allreduce_sum_u64)(void* inst, uint64_t* buf, size_t n, void* stream);
     bool (*allreduce_sum_f64)(void* inst, double* buf, size_t n, void* stream);
+    /* optional, may be NULL.  group_begin / group_end bracket all all-reduces of one merge so that they leave as ONE collective
+     * launch (ncclGroupStart / ncclGroupEnd); allreduce_sum_u32: in-place SUM of 32-bit device memory */
+    bool (*group_begin)(void* inst);
+    bool (*group_end)(void* inst);
+    bool (*allreduce_sum_u32)(void* inst, uint32_t* buf, size_t n, void* stream);
 } vmd_collective_i;
 /* call on every rank after its last vmd_eval_frame_range has returned; `stream`: hipStream_t the collectives run on (NULL = the
  * default stream); synchronous on return */
 bool   vmd_eval_reduce(vmd_script_eval_t* eval, const vmd_collective_i* coll, void* stream);
+/* what the last vmd_eval_reduce of this eval did: bytes handed to the collective (per rank), all-reduce calls issued, whether they
+ * were grouped into one launch, and the wall time of the call in milliseconds */
+typedef struct vmd_reduce_stats_t {
+    uint64_t bytes;
+    uint32_t calls;
+    uint32_t grouped;
+    uint32_t volumes_as_u32;
+    double   ms;
+} vmd_reduce_stats_t;
+void   vmd_eval_reduce_stats(const vmd_script_eval_t* eval, vmd_reduce_stats_t* out);
 
 /* RCCL communicator (one per process = per GPU; xGMI inside a node).  librccl is loaded at run time by soname, so a host that
  * already carries an RCCL (e.g. PyTorch's) shares that copy.  Either let the library create the communicator - rank 0 makes the

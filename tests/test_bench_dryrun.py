@@ -63,6 +63,12 @@ def test_two_ranks(tmp_path, emu_lib, scaling):
     one = _run(tmp_path, emu_lib.path, 1, ["--steps", "1", "--warmup", "0", "--workload", "c4", "--scaling", scaling, "--no-cpu-baseline"])
     two = _run(tmp_path, emu_lib.path, 2, ["--steps", "1", "--warmup", "0", "--workload", "c4", "--scaling", scaling, "--no-cpu-baseline"])
     assert two["n_gpus"] == 2 and two["scaling"] == scaling
+    # the line says what carried the merge and how many ranks THAT saw (the driver checks rccl_ranks == n_gpus on the GPU node)
+    m = two["merge"]
+    assert m["rccl_ranks"] == 2 and m["collective"].startswith("torch.distributed") and m["allreduce_calls"] >= 2 and m["bytes"] > 0
+    assert m["host_ms_per_step"] >= 0.0 and "merge" not in one
+    if scaling == "strong":
+        assert m["volumes_as_u32"] == 1           # 6 frames x 4 structures x 467 targets fits 32 bits: the volume travelled as u32
     if scaling == "strong":       # the same 6 frames, block-sharded: the merged volume holds exactly the hits of the 1-rank run
         assert two["config"]["frames_per_step"] == 6 and two["config"]["frames_per_step_per_gpu"] == 3
         assert round(two["voxel_hits_per_s"] * two["ms_per_step"]) == round(one["voxel_hits_per_s"] * one["ms_per_step"])

@@ -88,7 +88,8 @@ class PropertyData(C.Structure):
 
 class AccumView(C.Structure):
     _fields_ = [("name", C.c_char_p), ("flags", C.c_uint32), ("counts_dev", C.c_void_p), ("num_counts", C.c_size_t),
-                ("weights64", c_double_p), ("num_weights", C.c_size_t), ("temporal", c_float_p), ("num_temporal", C.c_size_t)]
+                ("weights64", c_double_p), ("num_weights", C.c_size_t), ("temporal", c_float_p), ("num_temporal", C.c_size_t),
+                ("count_bound", C.c_uint64)]
 
 
 ALLREDUCE_U64_FN = C.CFUNCTYPE(C.c_bool, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
@@ -96,9 +97,18 @@ ALLREDUCE_F64_FN = C.CFUNCTYPE(C.c_bool, C.c_void_p, C.c_void_p, C.c_size_t, C.c
 COMM_INT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p)
 
 
+GROUP_FN = C.CFUNCTYPE(C.c_bool, C.c_void_p)
+ALLREDUCE_U32_FN = C.CFUNCTYPE(C.c_bool, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+
+
 class CollectiveI(C.Structure):          # vmd_collective_i
     _fields_ = [("inst", C.c_void_p), ("rank", COMM_INT_FN), ("size", COMM_INT_FN),
-                ("allreduce_sum_u64", ALLREDUCE_U64_FN), ("allreduce_sum_f64", ALLREDUCE_F64_FN)]
+                ("allreduce_sum_u64", ALLREDUCE_U64_FN), ("allreduce_sum_f64", ALLREDUCE_F64_FN),
+                ("group_begin", GROUP_FN), ("group_end", GROUP_FN), ("allreduce_sum_u32", ALLREDUCE_U32_FN)]   # optional: may stay NULL
+
+
+class ReduceStats(C.Structure):          # vmd_reduce_stats_t
+    _fields_ = [("bytes", C.c_uint64), ("calls", C.c_uint32), ("grouped", C.c_uint32), ("volumes_as_u32", C.c_uint32), ("ms", C.c_double)]
 
 
 COMM_ID_BYTES = 128
@@ -153,6 +163,7 @@ SIGNATURES = [
     ("vmd_export_property_table", C.c_bool, [C.c_char_p, _vp, C.c_char_p, C.c_char_p, c_double_p, C.c_int]),
     ("vmd_export_cube", C.c_bool, [C.c_char_p, _vp, C.c_char_p, C.POINTER(System), C.POINTER(TrajectoryI), C.c_uint32, c_uint8_p]),
     ("vmd_eval_reduce", C.c_bool, [_vp, C.POINTER(CollectiveI), _vp]),
+    ("vmd_eval_reduce_stats", None, [_vp, C.POINTER(ReduceStats)]),
     ("vmd_comm_unique_id", C.c_bool, [c_uint8_p]),
     ("vmd_comm_create", _vp, [C.c_int, C.c_int, c_uint8_p]),
     ("vmd_comm_from_nccl", _vp, [_vp]),

@@ -561,6 +561,7 @@ struct vmd_script_eval_t {
     size_t num_blocks = 0;
     vmd_script_eval_t* source = nullptr;
     std::atomic<size_t> frames_computed{0}, frames_reused{0}, frames_device_decoded{0};
+    vmd_reduce_stats_t reduce_stats = {};
     size_t atoms_checked = (size_t)-1;       // trajectory atom count the properties' indices were validated against (under mtx)
 };
 typedef vmd_script_eval_t::Stage Stage;
@@ -1009,6 +1010,11 @@ extern "C" size_t vmd_eval_accum_views(vmd_script_eval_t* eval, vmd_accum_view_t
             v.name = p->prop.name.c_str();
             v.flags = p->prop.flags;
             if (p->ncounts) { v.counts_dev = p->d_counts.p; v.num_counts = p->ncounts; }
+            // a voxel receives at most one count per (frame, structure, target atom)
+            if (p->prop.kind == PROP_SDF) {
+                const long double b = (long double)eval->num_frames * (long double)p->prop.K * (long double)p->prop.b.size();
+                v.count_bound = b < 1.8e19L ? (uint64_t)b : 0;
+            }
             if (!p->weights64.empty()) { v.weights64 = p->weights64.data(); v.num_weights = p->weights64.size(); }
             if (p->prop.kind == PROP_DIST) { v.temporal = p->values.data(); v.num_temporal = p->values.size(); }
             out[n] = v;
@@ -1016,6 +1022,15 @@ extern "C" size_t vmd_eval_accum_views(vmd_script_eval_t* eval, vmd_accum_view_t
         n += 1;
     }
     return n;
+}
+
+// hooks for vmd_reduce.cpp (same library, not part of the public headers)
+extern "C" int vmd_eval_internal_device(const vmd_script_eval_t* eval) { return eval ? eval->device : 0; }
+extern "C" void vmd_eval_internal_lock(vmd_script_eval_t* eval, int lock) { if (eval) { if (lock) eval->mtx.lock(); else eval->mtx.unlock(); } }
+extern "C" vmd_reduce_stats_t* vmd_eval_internal_reduce_stats(vmd_script_eval_t* eval) { return eval ? &eval->reduce_stats : nullptr; }
+extern "C" void vmd_eval_reduce_stats(const vmd_script_eval_t* eval, vmd_reduce_stats_t* out) {
+    if (!out) return;
+    if (eval) *out = eval->reduce_stats; else memset(out, 0, sizeof(*out));
 }
 
 // ---- the hot call -----------------------------------------------------------------------------------------------
@@ -1663,24 +1678,16 @@ static bool process_range(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
     size_t Bmax = auto_batch(e, num_atoms, !have_view);
     const vmd_device_view_t* vw = have_view ? &view : nullptr;
     // host trajectories are staged in smaller batches so that load_frame of batch k+1 overlaps the kernels of batch k
-    if (!have_view && g_opt.batch_frames <= 0) Bmax = std::min<size_t>(Bmax, (size_t)std::max(1, g_opt.stage_frames.load()) * (device_decode ? 4 : 1));
-    std::vector<Batch> batches;
-    if (device_decode && g_opt.batch_frames <= 0 && e->block_frames == 0) {
-        // the decoder is latency bound - a batch of 512 frames takes little longer than one of 64 - so batches should be large, but
-        // nothing overlaps the FIRST batch's trip (PCIe, decode): ramp up from a small one (64, 128, 256, ... frames)
-        for (auto& sg : segments) {
-            size_t size = std::min<size_t>(64, Bmax);
-            for (size_t f = sg.first; f < sg.second;) {
-                size_t nbf = std::min(size, sg.second - f);
-                if (sg.second - f - nbf < size / 2) nbf = sg.second - f;       // no crumb at the end
-                batches.push_back({f, nbf, -1});
-                f += nbf;
-                size = std::min(size * 2, Bmax);
-            }
-        }
-    } else {
-        for (auto& sg : segments) plan_batches(e, sg.first, sg.second, Bmax, &batches);
+    // ... except when the batches are decompressed on the device: k_xtc_wave is latency bound - a batch of 512 frames takes little
+    // longer than one of 64 (measured: profiles/r03e_xtc_pipeline.txt) - so its batches are as large as the pipeline allows: two per
+    // evaluation when the bit streams still have to cross PCIe (the second upload and decode run under the first batch's kernels),
+    // one when they are already resident in HBM
+    if (!have_view && g_opt.batch_frames <= 0) {
+        const size_t S = (size_t)std::max(1, g_opt.stage_frames.load());
+        Bmax = std::min<size_t>(Bmax, device_decode ? (raw_ring ? 4 * S : 8 * S) : S);
     }
+    std::vector<Batch> batches;
+    for (auto& sg : segments) plan_batches(e, sg.first, sg.second, Bmax, &batches);
 
     bool completed = true;
     int cur = 0;

@@ -45,6 +45,8 @@ struct Rccl {
     int (*CommCount)(const NcclComm, int*) = nullptr;
     int (*CommUserRank)(const NcclComm, int*) = nullptr;
     int (*AllReduce)(const void*, void*, size_t, int, int, NcclComm, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
     std::string error;
 };
@@ -69,6 +71,8 @@ Rccl* rccl() {
         r.CommCount = (int (*)(const NcclComm, int*))sym("ncclCommCount");
         r.CommUserRank = (int (*)(const NcclComm, int*))sym("ncclCommUserRank");
         r.AllReduce = (int (*)(const void*, void*, size_t, int, int, NcclComm, hipStream_t))sym("ncclAllReduce");
+        r.GroupStart = (int (*)())sym("ncclGroupStart");
+        r.GroupEnd = (int (*)())sym("ncclGroupEnd");
         r.GetErrorString = (const char* (*)(int))sym("ncclGetErrorString");
     });
     return &r;
@@ -96,6 +100,9 @@ static bool comm_allreduce(void* inst, void* buf, size_t n, int dtype, void* str
 }
 static bool comm_allreduce_u64(void* inst, uint64_t* buf, size_t n, void* stream) { return comm_allreduce(inst, buf, n, /*ncclUint64*/ 5, stream); }
 static bool comm_allreduce_f64(void* inst, double* buf, size_t n, void* stream) { return comm_allreduce(inst, buf, n, /*ncclFloat64*/ 8, stream); }
+static bool comm_allreduce_u32(void* inst, uint32_t* buf, size_t n, void* stream) { return comm_allreduce(inst, buf, n, /*ncclUint32*/ 3, stream); }
+static bool comm_group_begin(void*) { Rccl* r = rccl(); return rccl_ok(r, r->GroupStart(), "ncclGroupStart"); }
+static bool comm_group_end(void*) { Rccl* r = rccl(); return rccl_ok(r, r->GroupEnd(), "ncclGroupEnd"); }
 
 static vmd_comm_t* comm_wrap(NcclComm comm, bool owned) {
     Rccl* r = rccl();
@@ -108,6 +115,8 @@ static vmd_comm_t* comm_wrap(NcclComm comm, bool owned) {
     c->iface.inst = c;
     c->iface.rank = comm_rank; c->iface.size = comm_size;
     c->iface.allreduce_sum_u64 = comm_allreduce_u64; c->iface.allreduce_sum_f64 = comm_allreduce_f64;
+    c->iface.group_begin = comm_group_begin; c->iface.group_end = comm_group_end;
+    c->iface.allreduce_sum_u32 = comm_allreduce_u32;
     return c;
 }
 
@@ -152,54 +161,151 @@ extern "C" int vmd_comm_size(const vmd_comm_t* c) { return c ? c->size : 1; }
 
 // ------------------------------------------------------------------------------------------------ the merge
 
+extern "C" int vmd_eval_internal_device(const vmd_script_eval_t* eval);
+extern "C" void vmd_eval_internal_lock(vmd_script_eval_t* eval, int lock);
+extern "C" vmd_reduce_stats_t* vmd_eval_internal_reduce_stats(vmd_script_eval_t* eval);
+
+namespace {
+// u64 voxels <-> u32 for the trip over the links (only when the merged counts provably fit: vmd_accum_view_t::count_bound)
+__global__ void k_narrow_u64(const uint64_t* __restrict__ src, uint32_t* __restrict__ dst, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = (uint32_t)src[i];
+}
+__global__ void k_widen_u32(const uint32_t* __restrict__ src, uint64_t* __restrict__ dst, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = (uint64_t)src[i];
+}
+// staging of what travels: one buffer per device for the whole process (a merge per evaluation: no allocation in the steady state);
+// merges on one device take turns (the buffer used to be thread_local - leaked per thread - and lived on whatever
+// device the caller had current)
+struct Scratch { void* p = nullptr; size_t cap = 0; };
+std::mutex g_scratch_mtx;
+Scratch g_scratch[64];
+struct EvalLock {
+    vmd_script_eval_t* e;
+    explicit EvalLock(vmd_script_eval_t* ev) : e(ev) { vmd_eval_internal_lock(e, 1); }
+    ~EvalLock() { vmd_eval_internal_lock(e, 0); }
+};
+}  // namespace
+
 extern "C" bool vmd_eval_reduce(vmd_script_eval_t* eval, const vmd_collective_i* coll, void* stream) {
     if (!eval) return red_fail("vmd_eval_reduce: eval is NULL");
     if (!coll || !coll->allreduce_sum_u64 || !coll->allreduce_sum_f64) return red_fail("vmd_eval_reduce: incomplete collective interface");
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    const int dev = vmd_eval_internal_device(eval);
+    if (dev < 0 || dev >= 64 || hipSetDevice(dev) != hipSuccess) return red_fail("vmd_eval_reduce: cannot select the evaluator's device");
     hipStream_t s = (hipStream_t)stream;
+    (void)hipEventCreate(&t0); (void)hipEventCreate(&t1);
+    if (t0) (void)hipEventRecord(t0, s);
     const size_t nviews = vmd_eval_accum_views(eval, nullptr, 0);
     std::vector<vmd_accum_view_t> views(nviews);
     vmd_eval_accum_views(eval, views.data(), nviews);
-    // (1) integer accumulators: SUM in place on the evaluator's own device buffers (8 KB per RDF, 16.8 MB per SDF volume)
-    for (const vmd_accum_view_t& v : views)
-        if (v.counts_dev && v.num_counts && !coll->allreduce_sum_u64(coll->inst, v.counts_dev, v.num_counts, s)) return false;
-    // (2) everything that lives on the host travels as ONE fp64 buffer: normalisation weights, temporal rows (zero on the ranks
-    // that did not evaluate the frame; a float survives the trip through fp64 unchanged) and the frame mask (a frame is
-    // evaluated by one rank, so the sum is 0/1; > 0 also covers ranks that evaluated the same frame)
     const size_t F = vmd_eval_num_frames(eval);
-    size_t total = F;
-    for (const vmd_accum_view_t& v : views) total += (v.weights64 ? v.num_weights : 0) + (v.temporal ? v.num_temporal : 0);
-    std::vector<double> packed(total);
-    size_t off = 0;
-    for (const vmd_accum_view_t& v : views) {
-        if (v.weights64) { memcpy(&packed[off], v.weights64, v.num_weights * sizeof(double)); off += v.num_weights; }
-        if (v.temporal) { for (size_t i = 0; i < v.num_temporal; ++i) packed[off + i] = (double)v.temporal[i]; off += v.num_temporal; }
+    // what travels besides the u64 accumulators:
+    //  * u32 copies of the volumes whose merged counts fit 32 bits (half the bytes of the one payload that has a size: 8.4 instead of
+    //    16.8 MB per 128^3 volume);
+    //  * everything that lives on the host as ONE fp64 buffer: normalisation weights, temporal rows (zero on the ranks that did not
+    //    evaluate the frame; a float survives the trip through fp64 unchanged) and the frame mask (a frame is evaluated by one rank,
+    //    so the sum is 0/1; > 0 also covers ranks that evaluated the same frame)
+    size_t n_f64 = F, n_u32 = 0;
+    std::vector<char> narrow(nviews, 0);
+    for (size_t i = 0; i < nviews; ++i) {
+        const vmd_accum_view_t& v = views[i];
+        n_f64 += (v.weights64 ? v.num_weights : 0) + (v.temporal ? v.num_temporal : 0);
+        if (coll->allreduce_sum_u32 && v.counts_dev && v.num_counts >= 65536 && v.count_bound != 0 && v.count_bound <= 0xffffffffull) {
+            narrow[i] = 1;
+            n_u32 += (v.num_counts + 1) & ~(size_t)1;               // keep the fp64 part behind it 8-byte aligned
+        }
     }
-    const uint8_t* mask = vmd_eval_frame_mask(eval);
-    for (size_t f = 0; f < F; ++f) packed[off + f] = mask[f] ? 1.0 : 0.0;
-    // device staging of the packed buffer, kept per calling thread (one merge per evaluation: no allocation in the steady state)
-    struct Scratch { double* p = nullptr; size_t cap = 0; int device = -1; };
-    static thread_local Scratch sc;
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (sc.cap < total || sc.device != dev) {
+    std::vector<double> packed(n_f64);
+    {
+        EvalLock lock(eval);                                         // the host-side arrays belong to the evaluator
+        size_t off = 0;
+        for (const vmd_accum_view_t& v : views) {
+            if (v.weights64) { memcpy(&packed[off], v.weights64, v.num_weights * sizeof(double)); off += v.num_weights; }
+            if (v.temporal) { for (size_t i = 0; i < v.num_temporal; ++i) packed[off + i] = (double)v.temporal[i]; off += v.num_temporal; }
+        }
+        const uint8_t* mask = vmd_eval_frame_mask(eval);
+        for (size_t f = 0; f < F; ++f) packed[off + f] = mask[f] ? 1.0 : 0.0;
+    }
+    std::lock_guard<std::mutex> scratch_lock(g_scratch_mtx);
+    Scratch& sc = g_scratch[dev];
+    const size_t need = n_u32 * sizeof(uint32_t) + n_f64 * sizeof(double);
+    if (sc.cap < need) {
         if (sc.p) (void)hipFree(sc.p);
-        sc.p = nullptr; sc.cap = 0; sc.device = dev;
-        if (hipMalloc((void**)&sc.p, total * sizeof(double)) != hipSuccess) return red_fail("vmd_eval_reduce: hipMalloc failed");
-        sc.cap = total;
+        sc.p = nullptr; sc.cap = 0;
+        if (hipMalloc(&sc.p, need) != hipSuccess) return red_fail("vmd_eval_reduce: hipMalloc failed");
+        sc.cap = need;
     }
-    double* d_packed = sc.p;
-    bool ok = hipMemcpyAsync(d_packed, packed.data(), total * sizeof(double), hipMemcpyHostToDevice, s) == hipSuccess;
-    ok = ok && coll->allreduce_sum_f64(coll->inst, d_packed, total, s);
-    ok = ok && hipMemcpyAsync(packed.data(), d_packed, total * sizeof(double), hipMemcpyDeviceToHost, s) == hipSuccess;
+    uint32_t* d_u32 = (uint32_t*)sc.p;
+    double* d_packed = (double*)((char*)sc.p + n_u32 * sizeof(uint32_t));
+    bool ok = hipMemcpyAsync(d_packed, packed.data(), n_f64 * sizeof(double), hipMemcpyHostToDevice, s) == hipSuccess;
+    {
+        size_t o = 0;
+        for (size_t i = 0; i < nviews && ok; ++i) {
+            if (!narrow[i]) continue;
+            const size_t n = views[i].num_counts;
+            hipLaunchKernelGGL(k_narrow_u64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const uint64_t*)views[i].counts_dev, d_u32 + o, n);
+            ok = hipGetLastError() == hipSuccess;
+            o += (n + 1) & ~(size_t)1;
+        }
+    }
+    if (!ok) return red_fail("vmd_eval_reduce: staging the merge failed");
+    // ---- ONE collective launch: every all-reduce of this merge inside one group (north_star: "a single RCCL reduce")
+    vmd_reduce_stats_t st;
+    memset(&st, 0, sizeof(st));
+    const bool grouped = coll->group_begin && coll->group_end;
+    if (grouped && !coll->group_begin(coll->inst)) return false;
+    {
+        size_t o = 0;
+        for (size_t i = 0; i < nviews && ok; ++i) {
+            const vmd_accum_view_t& v = views[i];
+            if (!v.counts_dev || !v.num_counts) continue;
+            if (narrow[i]) {
+                ok = coll->allreduce_sum_u32(coll->inst, d_u32 + o, v.num_counts, s);
+                o += (v.num_counts + 1) & ~(size_t)1;
+                st.bytes += v.num_counts * sizeof(uint32_t); st.volumes_as_u32 += 1;
+            } else {
+                ok = coll->allreduce_sum_u64(coll->inst, v.counts_dev, v.num_counts, s);      // in place on the evaluator's accumulators
+                st.bytes += v.num_counts * sizeof(uint64_t);
+            }
+            st.calls += 1;
+        }
+        ok = ok && coll->allreduce_sum_f64(coll->inst, d_packed, n_f64, s);
+        st.bytes += n_f64 * sizeof(double); st.calls += 1;
+    }
+    if (grouped && !coll->group_end(coll->inst)) return false;
+    st.grouped = grouped ? 1 : 0;
+    if (!ok) return red_fail("vmd_eval_reduce: an all-reduce failed");
+    {
+        size_t o = 0;
+        for (size_t i = 0; i < nviews && ok; ++i) {
+            if (!narrow[i]) continue;
+            const size_t n = views[i].num_counts;
+            hipLaunchKernelGGL(k_widen_u32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const uint32_t*)(d_u32 + o), views[i].counts_dev, n);
+            ok = hipGetLastError() == hipSuccess;
+            o += (n + 1) & ~(size_t)1;
+        }
+    }
+    ok = ok && hipMemcpyAsync(packed.data(), d_packed, n_f64 * sizeof(double), hipMemcpyDeviceToHost, s) == hipSuccess;
+    if (t1) (void)hipEventRecord(t1, s);
     ok = ok && hipStreamSynchronize(s) == hipSuccess;       // also: the in-place counts are final before finalize reads them
-    if (!ok) return red_fail("vmd_eval_reduce: the packed host-side all-reduce failed");
-    off = 0;
-    for (const vmd_accum_view_t& v : views) {
-        if (v.weights64) { memcpy(v.weights64, &packed[off], v.num_weights * sizeof(double)); off += v.num_weights; }
-        if (v.temporal) { for (size_t i = 0; i < v.num_temporal; ++i) v.temporal[i] = (float)packed[off + i]; off += v.num_temporal; }
-    }
+    if (!ok) return red_fail("vmd_eval_reduce: the merge failed on the device");
     std::vector<uint8_t> merged(F);
-    for (size_t f = 0; f < F; ++f) merged[f] = packed[off + f] > 0.5 ? 1 : 0;
+    {
+        EvalLock lock(eval);
+        size_t off = 0;
+        for (const vmd_accum_view_t& v : views) {
+            if (v.weights64) { memcpy(v.weights64, &packed[off], v.num_weights * sizeof(double)); off += v.num_weights; }
+            if (v.temporal) { for (size_t i = 0; i < v.num_temporal; ++i) v.temporal[i] = (float)packed[off + i]; off += v.num_temporal; }
+        }
+        for (size_t f = 0; f < F; ++f) merged[f] = packed[off + f] > 0.5 ? 1 : 0;
+    }
     vmd_eval_set_frame_mask(eval, merged.data(), F);
+    float ms = 0.0f;
+    if (t0 && t1 && hipEventElapsedTime(&ms, t0, t1) == hipSuccess) st.ms = ms;
+    if (t0) (void)hipEventDestroy(t0);
+    if (t1) (void)hipEventDestroy(t1);
+    if (vmd_reduce_stats_t* dst = vmd_eval_internal_reduce_stats(eval)) *dst = st;
     return vmd_eval_finalize(eval);
 }

@@ -54,29 +54,93 @@ class RcclComm:
 
 
 class TorchCollective:
-    """vmd_collective_i over torch.distributed for the CPU tests: buffers the evaluator calls "device" are host memory in the
-    emulator build, so the callbacks alias them as numpy arrays and all-reduce those (gloo)."""
+    """vmd_collective_i over torch.distributed.  CPU tests (gloo): buffers the evaluator calls "device" are host memory in the
+    emulator build, so the callbacks alias them as numpy arrays and all-reduce those.  GPU (nccl backend): the FALLBACK when the
+    library's own communicator cannot be created (bench.py, N > 1: the first contact of that path with real hardware is the
+    driver's run) - the callbacks alias the evaluator's device memory as torch tensors (__cuda_array_interface__, zero copy) and
+    torch's RCCL communicator carries the same SUMs; torch runs them on its own stream, so every call is bracketed by device
+    synchronisation (a merge per step: microseconds against a step)."""
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, device=False):
         import torch
         import torch.distributed as dist
+        self.kind = "torch.distributed (" + dist.get_backend(group) + ")"
 
-        def allreduce(ptr, n, ctype, view):
-            buf = (ctype * n).from_address(ptr)
-            t = torch.from_numpy(np.ctypeslib.as_array(buf).view(view))
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        class _Dev:
+            def __init__(self, ptr, n, typestr):
+                self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr, False), "version": 2}
+
+        def allreduce(ptr, n, ctype, view, typestr):
+            if n == 0:
+                return True
+            if device:
+                torch.cuda.synchronize()
+                t = torch.as_tensor(_Dev(ptr, n, typestr), device="cuda")
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+                torch.cuda.synchronize()
+            else:
+                buf = (ctype * n).from_address(ptr)
+                t = torch.from_numpy(np.ctypeslib.as_array(buf).view(view))
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
             return True
 
+        # two's complement sums == unsigned sums
         self._cb = (L.COMM_INT_FN(lambda _: dist.get_rank(group)), L.COMM_INT_FN(lambda _: dist.get_world_size(group)),
-                    L.ALLREDUCE_U64_FN(lambda _, p, n, s: allreduce(p, n, C.c_int64, np.int64)),      # two's complement sum == unsigned sum
-                    L.ALLREDUCE_F64_FN(lambda _, p, n, s: allreduce(p, n, C.c_double, np.float64)))
+                    L.ALLREDUCE_U64_FN(lambda _, p, n, s: allreduce(p, n, C.c_int64, np.int64, "<i8")),
+                    L.ALLREDUCE_F64_FN(lambda _, p, n, s: allreduce(p, n, C.c_double, np.float64, "<f8")),
+                    L.GROUP_FN(), L.GROUP_FN(),
+                    L.ALLREDUCE_U32_FN(lambda _, p, n, s: allreduce(p, n, C.c_int32, np.int32, "<i4")))
         self.c = L.CollectiveI(None, *self._cb)
+        self.ranks = dist.get_world_size(group)
 
     def collective(self):
         return C.byref(self.c)
 
 
 _comms = {}
+
+
+def _make_comm(lib, group):
+    """The library's own RCCL communicator where it can be made on EVERY rank, torch.distributed's otherwise (all ranks decide alike:
+    a mixed job would dead-lock).  VIAMD_AMD_COLLECTIVE=torch|rccl forces one of them; VIAMD_AMD_COMM_TIMEOUT (seconds, default 120)
+    bounds ncclCommInitRank, which blocks until every rank has arrived."""
+    import os
+    import threading
+
+    import torch
+    import torch.distributed as dist
+    on_gpu = dist.get_backend(group) == "nccl"
+    if not on_gpu:
+        return TorchCollective(group)
+    want = os.environ.get("VIAMD_AMD_COLLECTIVE", "").lower()
+    comm, why = None, ""
+    if want != "torch":
+        box = {}
+
+        def make():
+            try:
+                box["comm"] = RcclComm(lib, group)
+            except Exception as e:                     # noqa: BLE001 - whatever went wrong, the job falls back as one
+                box["err"] = repr(e)
+
+        t = threading.Thread(target=make, daemon=True)
+        t.start()
+        t.join(float(os.environ.get("VIAMD_AMD_COMM_TIMEOUT", "120")))
+        comm = box.get("comm")
+        why = box.get("err", "ncclCommInitRank did not return in time" if t.is_alive() else "")
+    ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device="cuda")
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+    if int(ok.item()) == 1:
+        comm.kind = "rccl (vmd_comm_create)"
+        comm.ranks = int(lib.vmd_comm_size(comm.h))
+        return comm
+    if want == "rccl":
+        raise RuntimeError("VIAMD_AMD_COLLECTIVE=rccl but the communicator could not be created on every rank: " + why)
+    if comm is not None:
+        comm.close()
+    fb = TorchCollective(group, device=True)
+    fb.fallback_reason = why or "another rank could not create its communicator"
+    return fb
 
 
 def reduce_eval(ev, group=None):
@@ -87,9 +151,24 @@ def reduce_eval(ev, group=None):
         return          # nothing to merge; frame_range already refreshed the host views
     key = (id(ev.lib), group)
     if key not in _comms:
-        _comms[key] = RcclComm(ev.lib, group) if dist.get_backend(group) == "nccl" else TorchCollective(group)
+        _comms[key] = _make_comm(ev.lib, group)
     if not ev.lib.vmd_eval_reduce(ev.h, _comms[key].collective(), None):
         raise RuntimeError(ev.lib.last_error())
+
+
+def collective_info(lib, group=None):
+    """What carried the merges of this process so far: {"kind", "ranks", "fallback_reason"} or None before the first merge."""
+    c = _comms.get((id(lib), group))
+    if c is None:
+        return None
+    return {"kind": getattr(c, "kind", type(c).__name__), "ranks": getattr(c, "ranks", None), "fallback_reason": getattr(c, "fallback_reason", None)}
+
+
+def reduce_stats(ev):
+    st = L.ReduceStats()
+    ev.lib.vmd_eval_reduce_stats(ev.h, C.byref(st))
+    return {"bytes": int(st.bytes), "allreduce_calls": int(st.calls), "grouped_into_one_launch": bool(st.grouped),
+            "volumes_as_u32": int(st.volumes_as_u32), "device_ms": float(st.ms)}
 
 
 def close_comms():
