@@ -152,8 +152,13 @@ int vmd_hip_distance(void* stream, const float* xyz, size_t frame_stride, size_t
 int vmd_hip_axpy_u64(void* stream, uint64_t* dst, const uint64_t* src, size_t n, uint64_t mult, const uint32_t* skip_flag);
 /* dst[i] += src[i] (u64): merges a frame block's partial accumulator into the totals */
 int vmd_hip_add_u64(void* stream, uint64_t* dst, const uint64_t* src, size_t n);
-/* u64 counters -> f32 values (values[i] = (float)counts[i]) + max reduction into max_out[0] (device f32) */
-int vmd_hip_counts_to_float(void* stream, const uint64_t* counts, size_t n, float* values, float* max_out);
+/* u64 counters -> f32 values (values[i] = fl((float)counts[i] * scale); scale = 1: the raw counts of SPEC S5) + max reduction into
+ * max_out[0] (device f32) */
+int vmd_hip_counts_to_float(void* stream, const uint64_t* counts, size_t n, float* values, float* max_out, float scale);
+/* counts[0] += value on the device (closed-interval RDF: the self pairs a half-shell pass never visits) */
+int vmd_hip_bump_u64(void* stream, uint64_t* p, uint64_t value);
+/* DECISION(D-RDF-OPEN) as a switch: 1 = hit iff r_min <= d <= r_max in the pair kernels launched from now on; returns the old value */
+int vmd_hip_set_rdf_closed(int on);
 
 /* XTC coordinate blocks decompressed on the device (the compressed bytes cross PCIe, not the floats): one
  * thread per frame walks its bit stream (frames are independent, a stream is strictly sequential).

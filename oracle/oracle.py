@@ -252,6 +252,17 @@ def distance_pair(x, y, z, cell, a, b):
     return out
 
 
+def set_spec(key, value):
+    """DECISION switch of SPEC.md ("rdf_closed", "sdf_include_self"); returns the previous value."""
+    L = lib()
+    L.vo_set_spec.restype = C.c_int
+    L.vo_set_spec.argtypes = [C.c_char_p, C.c_int]
+    old = L.vo_set_spec(key.encode(), int(value))
+    if old < 0:
+        raise KeyError(key)
+    return old
+
+
 def downsample_histogram(values, weights, num_dst_bins):
     values = np.ascontiguousarray(values, np.float32)
     weights = None if weights is None else np.ascontiguousarray(weights, np.float32)

@@ -134,9 +134,23 @@ static vo_bin_t vo_bin_setup(float rmin, float rmax, int nbins) {
     return b;
 }
 
+/* The DECISION: tags of SPEC.md as run-time switches (vo_set_spec; the product mirrors every one of them as
+ * vmd_set_option("spec_...")): 0 = the default written in SPEC.md, 1 = the alternative mdlib may turn out to use. */
+static int g_spec_rdf_closed = 0;        /* D-RDF-OPEN: 1 = closed interval r_min <= d <= r_max (self pairs at d = 0 count when r_min = 0) */
+static int g_spec_sdf_include_self = 0;  /* D-SDF-EXCL: 1 = target atoms that belong to structure k are NOT skipped */
+int vo_set_spec(const char* key, int value) {
+    int* o = NULL;
+    if (!strcmp(key, "rdf_closed")) o = &g_spec_rdf_closed;
+    else if (!strcmp(key, "sdf_include_self")) o = &g_spec_sdf_include_self;
+    if (!o) return -1;
+    const int old = *o;
+    *o = value ? 1 : 0;
+    return old;
+}
+
 static inline int vo_bin_of(const vo_bin_t* b, float d2) {
     const float d = sqrtf(d2);
-    if (!(b->rmin < d && d < b->rmax)) return -1;
+    if (g_spec_rdf_closed ? !(b->rmin <= d && d <= b->rmax) : !(b->rmin < d && d < b->rmax)) return -1;
     int bin = (int)(((d - b->rmin) * b->inv_range) * b->fnbins);
     if (bin < 0) bin = 0;
     if (bin > b->nbins - 1) bin = b->nbins - 1;
@@ -538,7 +552,8 @@ uint64_t vo_sdf_frame_scatter(const float* x, const float* y, const float* z, co
         for (size_t t = 0; t < ntgt; ++t) {
             const int32_t i = tgt_idx ? tgt_idx[t] : (int32_t)t;
             int own = 0;
-            for (size_t a = 0; a < m; ++a) if (sidx[a] == i) { own = 1; break; }
+            if (!g_spec_sdf_include_self)
+                for (size_t a = 0; a < m; ++a) if (sidx[a] == i) { own = 1; break; }
             if (own) continue;
             float dv[3] = {x[i] - c[0], y[i] - c[1], z[i] - c[2]};
             vo_mi3_rintf(&bx, dv);

@@ -91,6 +91,11 @@ float vo_distance_max(const float* x, const float* y, const float* z, const vo_c
 void  vo_distance_pair(const float* x, const float* y, const float* z, const vo_cell_t* cell,
                        const int32_t* a, size_t na, const int32_t* b, size_t nb, float* out);
 
+/* DECISION switches of SPEC.md ("rdf_closed", "sdf_include_self"): returns the previous value, -1 for an unknown key.  The other
+ * two switches need no oracle code: "dist_geometric_com" = call with unit masses, "sdf_density" = the documented scaling of the
+ * float view (SPEC S5). */
+int vo_set_spec(const char* key, int value);
+
 /* S8: restated from /root/reference/src/main.cpp:232-250, :139-170, :172-230 */
 void vo_downsample_histogram(float* dst_bins, int num_dst_bins, const float* src_bins, const float* src_weights,
                              int num_src_bins);

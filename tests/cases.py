@@ -802,3 +802,74 @@ def device_view_cache_case(lib, O, n=1500, box=40.0):
     for f in range(F):
         t0.upload_frame(f, vcell0, c3[f, 0], c3[f, 1], c3[f, 2])
     run_and_check(t0, vcell0, ocell0, c3)
+
+
+def spec_switch_check(lib, oracle):
+    """oracle/SPEC.md's DECISION: tags as configuration (VERDICT r02 next #3b): vmd_set_option("spec_*", 1) flips the product, the
+    oracle flips with vo_set_spec / its inputs, and the two still agree bit for bit - so matching a real mdlib later is a
+    setting, not a kernel edit.  Every switch is also shown to CHANGE the result on this system (the test would pass vacuously
+    otherwise)."""
+    coords, structures, mass = sdf_system(oracle, 5, 1500, 30.0, 3)
+    N = coords.shape[2]
+    # two atoms on top of each other and a pair at exactly r_max along x: the cases the open / closed interval disagree on
+    coords[:, :, 700] = coords[:, :, 703]
+    coords[:, :, 706] = coords[:, :, 709]
+    coords[:, 0, 706] = np.mod(coords[:, 0, 709] + np.float32(6.0), np.float32(30.0))
+    n_s = structures.size
+    o = np.arange(n_s + (-n_s) % 3 + 1, N, 3, dtype=np.int32)          # 700, 703, 706, 709 are among them
+    assert {700, 703, 706, 709} <= set(o.tolist())
+    cell, ocell = V.make_unitcell(30.0), oracle.make_cell(30.0)
+    members = structures.reshape(-1)
+    tgt = np.unique(np.concatenate([o, members[::2]])).astype(np.int32)        # targets that ARE structure atoms: the exclusion rule matters
+    F = coords.shape[0]
+
+    def product(**opts):
+        old = {k: lib.vmd_set_option(("spec_" + k).encode(), v) for k, v in opts.items()}
+        try:
+            ir = V.ScriptIR(lib)
+            ir.add_rdf("g", o, o, 6.0)                                   # same set: half-shell pass
+            ir.add_rdf("h", o[: o.size // 2], o, 6.0)                    # overlapping sets: full-shell pass
+            ir.add_sdf("v", structures, tgt, 8.0)
+            ir.add_distance("d", structures[0], structures[1], L.DIST_COM)
+            ev = V.ScriptEval(F, ir)
+            assert ev.frame_range(V.MolSystem(N, mass=mass, unitcell=cell), V.HostTrajectory(coords, cell), 0, F)
+            return {k: (ev.property_data(k).counts.copy() if k != "d" else None, np.array(ev.property_data(k).values)) for k in "ghvd"}
+        finally:
+            for k, v in old.items():
+                lib.vmd_set_option(("spec_" + k).encode(), v)
+
+    base = product()
+    # --- D-RDF-OPEN
+    got = product(rdf_closed=1)
+    old = oracle.set_spec("rdf_closed", 1)
+    try:
+        want_g, _ = oracle_rdf(oracle, coords, ocell, o, o, 0.0, 6.0)
+        want_h, _ = oracle_rdf(oracle, coords, ocell, o[: o.size // 2], o, 0.0, 6.0)
+    finally:
+        oracle.set_spec("rdf_closed", old)
+    np.testing.assert_array_equal(got["g"][0], want_g)
+    np.testing.assert_array_equal(got["h"][0], want_h)
+    assert got["g"][0][0] == base["g"][0][0] + F * (o.size + 2)          # self pairs + the coincident pair (700, 703), both orders
+    assert got["g"][0].sum() > base["g"][0].sum() and got["h"][0].sum() > base["h"][0].sum()
+    np.testing.assert_array_equal(base["g"][0], oracle_rdf(oracle, coords, ocell, o, o, 0.0, 6.0)[0])
+    # --- D-SDF-EXCL
+    got = product(sdf_include_self=1)
+    old = oracle.set_spec("sdf_include_self", 1)
+    try:
+        want_v, _ = oracle_sdf(oracle, coords, ocell, structures, mass, tgt, 8.0)
+    finally:
+        oracle.set_spec("sdf_include_self", old)
+    np.testing.assert_array_equal(got["v"][0], want_v.reshape(-1))
+    assert got["v"][0].sum() > base["v"][0].sum()
+    # --- D-SDF-NORM: the float view becomes a number density, the integer accumulators stay what they are
+    got = product(sdf_density=1)
+    np.testing.assert_array_equal(got["v"][0], base["v"][0])
+    edge = 2.0 * 8.0 / 128
+    scale = np.float32(1.0 / (F * edge ** 3))
+    np.testing.assert_array_equal(got["v"][1], base["v"][0].astype(np.float32) * scale)
+    assert got["v"][1].max() > 0 and not np.array_equal(got["v"][1], base["v"][1])
+    # --- D-DIST-COM: geometric centres = the oracle's centre of mass with unit masses
+    got = product(dist_geometric_com=1)
+    want_d = oracle_distance(oracle, coords, ocell, np.ones_like(mass), structures[0], structures[1], L.DIST_COM)
+    np.testing.assert_array_equal(got["d"][1].reshape(F, -1), want_d)
+    assert not np.array_equal(got["d"][1], base["d"][1])

@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 
 import cases
+import viamd_amd as V
 from viamd_amd import _lib as L
 
 
@@ -296,3 +297,7 @@ def test_filtered_eval_against_a_running_source(emu_lib, oracle):
 
 def test_resident_trajectory_changes_invalidate_cached_boxes(emu_lib, oracle):
     cases.device_view_cache_case(emu_lib, oracle)
+
+
+def test_spec_decisions_are_switches(emu_lib, oracle):
+    cases.spec_switch_check(emu_lib, oracle)

@@ -54,3 +54,10 @@ def test_dense_all_atom_rdf(gpu_lib, oracle):
     box = float((N / 0.1) ** (1.0 / 3.0))
     c = _dense_all_atom_rdf(gpu_lib, oracle, 6, N, box, 2, True)
     assert 1.0e8 * 2 < c.sum() < 1.2e8 * 2
+
+
+@pytest.mark.gpu
+def test_spec_decisions_are_switches_on_the_gpu(gpu_lib, oracle):
+    """the DECISION switches through the hipcc-built kernels: closed RDF interval (a pair at exactly r_max, coincident atoms, the self
+    pairs of the half-shell pass), SDF without the exclusion rule, density-scaled float view, geometric-centre distance"""
+    cases.spec_switch_check(gpu_lib, oracle)

@@ -80,13 +80,20 @@ struct Options {
     std::atomic<int> pencil_split_y{1}, pencil_split_z{1};   // A/B: pencils of cross-section rmax/split (walk reach = split); 1 x 1 measured best (profiles/r02m_ab_tile_shape.txt)
     std::atomic<int> nxf_divisor{16};    // fine x cell = rmax / nxf_divisor (8 / 12 / 16 / 24 / 32 measured: 16 is +0.8 % on c3, profiles/r02l_ab_fine_cells.txt)
     std::atomic<int> cells_aos{1};       // sort through 16-byte records + repack
-    std::atomic<int> xtc_device_decode{0};   // frames offered raw (load_raw) are decompressed on the device: 1 = one thread per
+    std::atomic<int> xtc_device_decode{3};   // frames offered raw (load_raw) are decompressed on the device (0 = on the host threads): 1 = one thread per
                                              // frame (k_xtc_decode), 2 = index pass + one thread per chunk (k_xtc_index / k_xtc_chunks),
                                              // 3 = one wave per frame (k_xtc_wave)
     std::atomic<int> xtc_chunk{256};         // atoms per chunk of variant 2
+    // oracle/SPEC.md's DECISION: tags as switches - 0 = the documented default, 1 = the alternative; read when an eval is created
+    std::atomic<int> spec_rdf_closed{0};          // D-RDF-OPEN: r_min <= d <= r_max instead of the open interval
+    std::atomic<int> spec_sdf_include_self{0};    // D-SDF-EXCL: targets that are atoms of structure k are scattered like any other
+    std::atomic<int> spec_sdf_density{0};         // D-SDF-NORM: values = counts / (frames evaluated x voxel volume) instead of raw counts
+    std::atomic<int> spec_dist_geometric_com{0};  // D-DIST-COM: distance(a, b) between geometric centres, not centres of mass
     std::atomic<int> stage_frames{128};      // frames per staged batch of a host / file trajectory (batch_frames <= 0)
-    std::atomic<int> rdf_blocks_decode{1536};   // pair-kernel grid while batches are decompressed on the device: 6 blocks per CU leave every
-                                                // SIMD one wave slot and 80 VGPRs, so k_xtc_wave of batch k + 1 runs under the pair kernel of batch k
+    std::atomic<int> rdf_blocks_decode{0};   // > 0: pair-kernel grid while batches are decompressed on the device (1536 = 6 blocks per CU leave
+                                             // every SIMD a wave slot and 80 VGPRs for k_xtc_wave).  Measured and left OFF: a decode wave that shares
+                                             // its SIMD with six VALU-bound pair waves gets a seventh of the issue slots, and a latency-bound serial
+                                             // walk slows down by about what the overlap would save (profiles/r03_xtc_device_decode.txt)
     std::atomic<int> sdf_dense{0};       // dense-target SDF scatter (stream whole frames, select by tag): measured slower, off
     std::atomic<int> sdf_arith{1};       // SDF target lists that are arithmetic progressions are generated on the device (0 = always load the index list)
     std::atomic<int> rdf_classes{1};     // co-evaluated RDFs of one range share pair passes through disjoint atom classes (0 = one pass per property)
@@ -117,6 +124,10 @@ extern "C" int vmd_set_option(const char* key, int value) {
     else if (!strcmp(key, "xtc_chunk")) o = &g_opt.xtc_chunk;
     else if (!strcmp(key, "xtc_waves")) return vmd_hip_set_xtc_waves(value);
     else if (!strcmp(key, "stage_frames")) o = &g_opt.stage_frames;
+    else if (!strcmp(key, "spec_rdf_closed")) o = &g_opt.spec_rdf_closed;
+    else if (!strcmp(key, "spec_sdf_include_self")) o = &g_opt.spec_sdf_include_self;
+    else if (!strcmp(key, "spec_sdf_density")) o = &g_opt.spec_sdf_density;
+    else if (!strcmp(key, "spec_dist_geometric_com")) o = &g_opt.spec_dist_geometric_com;
     else if (!strcmp(key, "rdf_blocks_decode")) o = &g_opt.rdf_blocks_decode;
     else if (!strcmp(key, "rdf_classes")) o = &g_opt.rdf_classes;
     else if (!strcmp(key, "sdf_arith")) o = &g_opt.sdf_arith;
@@ -562,6 +573,7 @@ struct vmd_script_eval_t {
     vmd_script_eval_t* source = nullptr;
     std::atomic<size_t> frames_computed{0}, frames_reused{0}, frames_device_decoded{0};
     vmd_reduce_stats_t reduce_stats = {};
+    struct Spec { bool rdf_closed = false, sdf_include_self = false, sdf_density = false, dist_geometric_com = false; } spec;   // fixed at creation
     size_t atoms_checked = (size_t)-1;       // trajectory atom count the properties' indices were validated against (under mtx)
 };
 typedef vmd_script_eval_t::Stage Stage;
@@ -687,6 +699,10 @@ extern "C" vmd_script_eval_t* vmd_eval_create(size_t num_frames, const vmd_scrip
     for (auto& st : e->stages) if (hipEventCreate(&st.ready) != hipSuccess) { vmd_fail("hipEventCreate failed"); return nullptr; }
     e->ir_fingerprint = vmd_ir_fingerprint(ir);
     e->num_frames = num_frames;
+    e->spec.rdf_closed = g_opt.spec_rdf_closed.load() != 0;
+    e->spec.sdf_include_self = g_opt.spec_sdf_include_self.load() != 0;
+    e->spec.sdf_density = g_opt.spec_sdf_density.load() != 0;
+    e->spec.dist_geometric_com = g_opt.spec_dist_geometric_com.load() != 0;
     e->frame_mask.assign(num_frames, 0);
     for (auto& p : ir->props) {
         auto st = std::make_unique<PropState>();
@@ -876,7 +892,14 @@ static bool refresh_distribution(vmd_script_eval_t* e, PropState* p) {
 
 static bool refresh_volume(vmd_script_eval_t* e, PropState* p) {
     if (!p->d_values.ensure(p->ncounts) || !p->d_max.ensure(1)) return false;
-    KRN_OK(vmd_hip_counts_to_float(e->stream, p->d_counts.p, p->ncounts, p->d_values.p, p->d_max.p));
+    float scale = 1.0f;
+    if (e->spec.sdf_density) {
+        // DECISION(D-SDF-NORM) flipped: number density per cubic Angstrom, averaged over the frames evaluated so far
+        const double edge = 2.0 * (double)p->prop.rmax / (double)VMD_VOLUME_DIM;
+        const size_t nf = e->frames_done.load();
+        scale = nf ? (float)(1.0 / ((double)nf * edge * edge * edge)) : 0.0f;
+    }
+    KRN_OK(vmd_hip_counts_to_float(e->stream, p->d_counts.p, p->ncounts, p->d_values.p, p->d_max.p, scale));
     float vmax = 0.0f;
     if (p->zero_pending) { HIP_OK(hipStreamWaitEvent(e->stream, p->zero_done, 0)); p->zero_pending = false; }
     HIP_OK(hipMemcpyAsync(p->values.data(), p->d_values.p, p->ncounts * sizeof(float), hipMemcpyDeviceToHost, e->stream));
@@ -1046,6 +1069,7 @@ static bool upload_static(vmd_script_eval_t* e, const vmd_system_t* sys, size_t 
             out.resize(idx.size());
             for (size_t i = 0; i < idx.size(); ++i)
                 out[i] = (sys && sys->mass && (size_t)idx[i] < sys->atom_count) ? sys->mass[idx[i]] : 1.0f;
+            if (d.kind == PROP_DIST && e->spec.dist_geometric_com) std::fill(out.begin(), out.end(), 1.0f);   // D-DIST-COM flipped
         };
         std::vector<float> tmp;
         if (d.kind == PROP_SDF) {
@@ -1678,13 +1702,13 @@ static bool process_range(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
     size_t Bmax = auto_batch(e, num_atoms, !have_view);
     const vmd_device_view_t* vw = have_view ? &view : nullptr;
     // host trajectories are staged in smaller batches so that load_frame of batch k+1 overlaps the kernels of batch k
-    // ... except when the batches are decompressed on the device: k_xtc_wave is latency bound - a batch of 512 frames takes little
-    // longer than one of 64 (measured: profiles/r03e_xtc_pipeline.txt) - so its batches are as large as the pipeline allows: two per
-    // evaluation when the bit streams still have to cross PCIe (the second upload and decode run under the first batch's kernels),
-    // one when they are already resident in HBM
+    // ... except when the batches are decompressed on the device: k_xtc_wave is latency bound - a batch of 1 000 frames takes little
+    // longer than one of 64 (profiles/r03_xtc_device_decode.txt: c2 6.7 ms per 500 frames, 5.9 ms per 1 000) - and it does not hide
+    // under the pair kernel, so its batches are large: 8 x stage_frames.  A long file still overlaps the PCIe trip of batch k + 1
+    // with decode + pair kernel of batch k (ring of three slots)
     if (!have_view && g_opt.batch_frames <= 0) {
         const size_t S = (size_t)std::max(1, g_opt.stage_frames.load());
-        Bmax = std::min<size_t>(Bmax, device_decode ? (raw_ring ? 4 * S : 8 * S) : S);
+        Bmax = std::min<size_t>(Bmax, device_decode ? 8 * S : S);
     }
     std::vector<Batch> batches;
     for (auto& sg : segments) plan_batches(e, sg.first, sg.second, Bmax, &batches);
@@ -1733,6 +1757,7 @@ static bool process_range(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
         // so the flag is final and the batch's RDF part is all-or-nothing (a bucket of a LATER build may overflow after earlier
         // passes have long finished; nothing of them may stay behind when the batch is repeated).
         auto launch_rdf = [&]() -> bool {
+            vmd_hip_set_rdf_closed(e->spec.rdf_closed ? 1 : 0);
             size_t scratch_rows = 0;
             for (auto& g : e->rdf_groups) scratch_rows += std::max(g.passes.size(), g.props.size());
             if (!e->d_pass.ensure(std::max<size_t>(scratch_rows, 1) * VMD_RDF_NUM_BINS)) return false;
@@ -1780,6 +1805,13 @@ static bool process_range(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
                                               d_gb, (int)nb, grid, g.rmin, g.rmax, VMD_RDF_NUM_BINS,
                                               ps.same ? 1 : 0, g_opt.rdf_variant, pbc, e->d_partial.p, dst, e->d_overflow.p));
                     e->prof.end(e->stream);
+                    if (e->spec.rdf_closed && ps.same && g.rmin <= 0.0f && 0.0f <= g.rmax) {
+                        // closed interval: d = 0 is a hit, but a same-set pass walks the half shell (j > i, every hit twice) and never
+                        // meets the pairs (i, i) - one per list entry and frame, all in the bin of d = 0 (SPEC S4 binning of 0)
+                        int bin0 = (int)(((0.0f - g.rmin) * (1.0f / (g.rmax - g.rmin))) * (float)VMD_RDF_NUM_BINS);
+                        bin0 = std::min(std::max(bin0, 0), VMD_RDF_NUM_BINS - 1);
+                        KRN_OK(vmd_hip_bump_u64(e->stream, dst + bin0, (uint64_t)nb * (uint64_t)sa->idx.size()));
+                    }
                     for (auto& tg : ps.targets) commits.push_back({acc_of(e->props[tg.first].get()), dst, tg.second});
                 }
             }
@@ -1820,10 +1852,10 @@ static bool process_range(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
                 e->prof.end(e->stream);
                 e->prof.begin("sdf_scatter", e->stream);
                 KRN_OK(vmd_hip_sdf_scatter(e->stream, src.base, src.frame_stride, src.row_stride, src.d_boxes.p, pbc, (int)nb,
-                                           p->d_structs.p, (int)d.K, (int)d.m, p->d_R32.p, p->d_c32.p, p->d_tgt.p, p->have_owner ? p->d_owner.p : nullptr, (int)d.b.size(),
+                                           p->d_structs.p, (int)d.K, (int)d.m, p->d_R32.p, p->d_c32.p, p->d_tgt.p, (p->have_owner && !e->spec.sdf_include_self) ? p->d_owner.p : nullptr, (int)d.b.size(),
                                            d.rmax, VMD_VOLUME_DIM, acc, p->d_group.p,
-                                           (p->have_tag && p->tag_len == src.row_stride) ? p->d_tag.p : nullptr,
-                                           p->tgt_first, p->tgt_stride, p->unowned ? 1 : 0));
+                                           (p->have_tag && p->tag_len == src.row_stride && !e->spec.sdf_include_self) ? p->d_tag.p : nullptr,
+                                           p->tgt_first, p->tgt_stride, (p->unowned || e->spec.sdf_include_self) ? 1 : 0));
                 e->prof.end(e->stream);
                 p->dirty = true;
             } else {

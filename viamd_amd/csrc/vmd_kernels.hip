@@ -233,9 +233,14 @@ struct vmd_binning_t {
     // nbins-1 also from r_min / r_max); everything else takes the exact path
     float fast_k, fast_c, fast_half;   // fast_half = 0.5 - fast_delta
     float fast_far;                    // t' >= fast_far: beyond r_max by a whole bin, i.e. certainly not a hit (pair entries carry such partners)
+    int closed;                        // DECISION(D-RDF-OPEN) flipped: hit iff r_min <= d <= r_max.  Only vmd_bin_of looks at it: the fast path is
+                                       // never trusted within delta of a bin edge, and d = r_min / r_max sit exactly on one
 };
-__host__ __device__ inline vmd_binning_t vmd_make_binning(float rmin, float rmax, int nbins) {
+static int g_rdf_closed = 0;
+extern "C" int vmd_hip_set_rdf_closed(int on) { const int old = g_rdf_closed; g_rdf_closed = on ? 1 : 0; return old; }
+__host__ __device__ inline vmd_binning_t vmd_make_binning(float rmin, float rmax, int nbins, int closed = 0) {
     vmd_binning_t b;
+    b.closed = closed;
     b.rmin = rmin; b.rmax = rmax; b.inv_range = 1.0f / (rmax - rmin); b.fnbins = (float)nbins; b.nbins = nbins;
     // error budget of t' = fma(v_sqrt(d2), k, c) against the spec value ((d - rmin) * inv_range) * nbins, in ulps of
     // T = rmax * inv_range * nbins (the largest intermediate): v_sqrt_f32 1 + fma 0.5 on our side, sqrtf 0.5 + subtraction
@@ -251,7 +256,7 @@ __host__ __device__ inline vmd_binning_t vmd_make_binning(float rmin, float rmax
 }
 __device__ __forceinline__ int vmd_bin_of(const vmd_binning_t& b, float d2) {
     const float d = sqrtf(d2);
-    if (!(b.rmin < d && d < b.rmax)) return -1;
+    if (b.closed ? !(b.rmin <= d && d <= b.rmax) : !(b.rmin < d && d < b.rmax)) return -1;
     int bin = (int)(((d - b.rmin) * b.inv_range) * b.fnbins);
     bin = bin < 0 ? 0 : bin;
     return bin > b.nbins - 1 ? b.nbins - 1 : bin;
@@ -2343,7 +2348,7 @@ __global__ __launch_bounds__(256) void k_distance_pair(vmd_dist_params_t p) {
 // ------------------------------------------------------------------------------------------------ misc
 
 __global__ __launch_bounds__(256) void k_counts_to_float(const uint64_t* __restrict__ counts, size_t n, float* __restrict__ values,
-                                                         unsigned* __restrict__ max_bits) {
+                                                         unsigned* __restrict__ max_bits, float scale) {
     // 8 voxels per thread, one atomicMax per WAVE: a filled 128^3 volume used to issue ~10^6 same-address atomics (0.38 ms per call,
     // more than the conversion's 25 MB of traffic costs)
     const size_t i0 = (size_t)blockIdx.x * 2048 + threadIdx.x;
@@ -2351,7 +2356,7 @@ __global__ __launch_bounds__(256) void k_counts_to_float(const uint64_t* __restr
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
         const size_t i = i0 + 256 * (size_t)u;
-        if (i < n) { const float v = (float)counts[i]; values[i] = v; vmax = fmaxf(vmax, v); }
+        if (i < n) { const float v = (float)counts[i] * scale; values[i] = v; vmax = fmaxf(vmax, v); }   // scale = 1: raw counts (SPEC S5)
     }
     if (max_bits) {
         vmax = vmd_wave_max(vmax);
@@ -2502,7 +2507,7 @@ extern "C" int vmd_hip_rdf_pencil(void* stream, const float* sorted_ref, const u
     p.sref = sorted_ref; p.cs_ref = cell_start_ref; p.nref_pad = nref_pad;
     p.stgt = sorted_tgt; p.cs_tgt = cell_start_tgt; p.ntgt_pad = ntgt_pad;
     p.boxes = boxes; p.B = B; p.grid = grid;
-    p.bin = vmd_make_binning(rmin, rmax, nbins);
+    p.bin = vmd_make_binning(rmin, rmax, nbins, g_rdf_closed);
     p.r2_up = nextafterf(rmax * rmax, 3.0e38f) * 1.0001f;
     p.rpad = rmax * 1.0001f + 1.0e-4f;
     p.partial = partial;
@@ -2558,7 +2563,7 @@ extern "C" int vmd_hip_rdf_brute(void* stream, const float* xyz, size_t frame_st
     if (nbins <= 0 || nbins > VMD_MAX_BINS) return (int)hipErrorInvalidValue;
     if (B <= 0 || nref <= 0 || ntgt <= 0) return 0;
     vmd_brute_params_t p{xyz, frame_stride, row_stride, boxes, pbc_flags, B, ref, nref, tgt, ntgt, {}, counts};
-    p.bin = vmd_make_binning(rmin, rmax, nbins);
+    p.bin = vmd_make_binning(rmin, rmax, nbins, g_rdf_closed);
     hipLaunchKernelGGL(k_rdf_brute, dim3((nref + 255) / 256, B), dim3(256), 0, s, p);
     VMD_LAUNCH_CHECK();
     return 0;
@@ -2769,14 +2774,22 @@ extern "C" int vmd_hip_add_u64(void* stream, uint64_t* dst, const uint64_t* src,
     return 0;
 }
 
-extern "C" int vmd_hip_counts_to_float(void* stream, const uint64_t* counts, size_t n, float* values, float* max_out) {
+// counts[index] += value: the self pairs (d = 0) a half-shell pass never visits, when the closed interval counts them
+__global__ void k_bump_u64(uint64_t* p, uint64_t v) { if (threadIdx.x == 0 && blockIdx.x == 0) *p += v; }
+extern "C" int vmd_hip_bump_u64(void* stream, uint64_t* p, uint64_t v) {
+    hipLaunchKernelGGL(k_bump_u64, dim3(1), dim3(64), 0, (hipStream_t)stream, p, v);
+    VMD_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int vmd_hip_counts_to_float(void* stream, const uint64_t* counts, size_t n, float* values, float* max_out, float scale) {
     hipStream_t s = (hipStream_t)stream;
     if (n == 0) return 0;
     if (max_out) {
         hipError_t e = hipMemsetAsync(max_out, 0, sizeof(float), s);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL(k_counts_to_float, dim3((unsigned)((n + 2047) / 2048)), dim3(256), 0, s, counts, n, values, (unsigned*)max_out);
+    hipLaunchKernelGGL(k_counts_to_float, dim3((unsigned)((n + 2047) / 2048)), dim3(256), 0, s, counts, n, values, (unsigned*)max_out, scale);
     VMD_LAUNCH_CHECK();
     return 0;
 }

@@ -620,7 +620,7 @@ extern "C" int vmd_hip_xtc_decode(void* stream, const unsigned char* raw, const 
     return (int)hipGetLastError();
 }
 
-static int g_xtc_waves = 0;     // waves per frame of k_xtc_wave; 0 = enough to put ~4 waves on every SIMD
+static int g_xtc_waves = 0;     // waves per frame of k_xtc_wave; 0 = automatic (see vmd_hip_xtc_decode_wave)
 extern "C" int vmd_hip_set_xtc_waves(int n) { const int old = g_xtc_waves; g_xtc_waves = n < 0 ? 0 : (n > 64 ? 64 : n); return old; }
 
 extern "C" int vmd_hip_xtc_decode_wave(void* stream, const unsigned char* raw, const vmd_xtc_frame_t* info, int B, int natoms,
@@ -628,10 +628,12 @@ extern "C" int vmd_hip_xtc_decode_wave(void* stream, const unsigned char* raw, c
     if (B <= 0) return 0;
     int share = g_xtc_waves;
     if (share <= 0) {
-        share = (4096 + B - 1) / B;                                 // 1024 SIMDs x 4
+        // measured (profiles/r03_xtc_device_decode.txt): every sharing wave repeats the walk, so sharing pays only while SIMDs would
+        // otherwise idle - 8 waves per frame for a batch of 128, 2 for 1 024, 1 from 2 048 frames on (2 waves per SIMD of the chip)
+        share = (2048 + B / 2) / B;
         const int tiles = natoms / 128 + 1;                        // a frame has at most natoms groups; a wave should own a few tiles
         if (share > tiles) share = tiles;
-        if (share > 16) share = 16;
+        if (share > 8) share = 8;
         if (share < 1) share = 1;
     }
     if (hipMemsetAsync(status, 0, (size_t)B * sizeof(uint32_t), (hipStream_t)stream) != hipSuccess) return 1;
