@@ -95,26 +95,48 @@ def host_cpus():
     return logical, physical, quota
 
 
+def node_physical_cores():
+    """physical cores of the whole node (/proc/cpuinfo), whatever slice of it this process may use"""
+    try:
+        cores, phys = set(), "0"
+        for line in open("/proc/cpuinfo"):
+            k, _, v = line.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "physical id":
+                phys = v
+            elif k == "core id":
+                cores.add((phys, v))
+        return len(cores) or None
+    except Exception:
+        return None
+
+
 def cpu_baseline(name, w, topo, info):
-    """The oracle (a port - ext/mdlib is empty, so mdlib itself cannot be timed) driven like VIAMD drives mdlib: one thread per
-    physical core (src/main.cpp:494-495), frames handed out dynamically with grain 1 (src/task_system.cpp:73-81), on a bounded
-    sample of the same workload.  A single-thread run of the same code is timed first, so the line shows how many cores' worth
-    of CPU the box really delivered (a containerised slice of a node reports all of the node's CPUs)."""
+    """The CPU column, driven like VIAMD drives mdlib: one thread per physical core this process is granted (src/main.cpp:494-495),
+    frames handed out dynamically with grain 1 (src/task_system.cpp:73-81), on a bounded sample of the same workload.  ext/mdlib is
+    empty, so mdlib itself cannot be timed; two stand-ins are:
+      scalar - the oracle (oracle/vmd_oracle.c): r_c cells, full 27-cell shell, scalar binning - the checker, not a tuned code;
+      simd   - oracle/vmd_cpu_fast.c: half shell, AVX-512 filter + hit compaction, the same integers (tests/test_oracle.py) - what a
+               careful CPU implementation reaches; RDF only, the SDF / distance part of a script stays with the oracle.
+    `value` is the FASTER of the two.  A single-thread run is timed as well, so the line shows how many cores' worth of CPU the box
+    really delivered, and `extrapolated_to_node` scales the value to every physical core of the node (frames are independent)."""
     from oracle import oracle as O
     from viamd_amd import synth
     logical, physical, quota = host_cpus()
     cores = max(1, min(physical, int(np.ceil(quota))) if quota else physical)
     cell = O.make_cell(w["box"])
-    budget = 15.0                       # seconds of wall time aimed at
+    budget = 9.0                        # seconds of wall time aimed at, per leg
     mass = topo.mass
 
-    def run(traj, nthreads):
+    def run(traj, nthreads, fast):
         hits = 0
+        cells = [cell] * len(traj)
         for nm, d in info.items():
             if d["kind"] == "rdf":
-                hits += O.rdf_run(traj, [cell] * len(traj), d["ref"], d["target"], d["rmin"], d["rmax"], nthreads=nthreads)[2]
+                r = O.rdf_run_fast(traj, cells, d["ref"], d["target"], d["rmin"], d["rmax"], nthreads=nthreads) if fast else None
+                hits += r[1] if r is not None else O.rdf_run(traj, cells, d["ref"], d["target"], d["rmin"], d["rmax"], nthreads=nthreads)[2]
             elif d["kind"] == "sdf":
-                O.sdf_run(traj, [cell] * len(traj), d["structures"], mass[d["structures"]], d["target"], d["cutoff"], nthreads=nthreads)
+                O.sdf_run(traj, cells, d["structures"], mass[d["structures"]], d["target"], d["cutoff"], nthreads=nthreads)
             # the distance family is O(|a||b|) on a handful of atoms: below timer resolution next to rdf/sdf
         return hits
 
@@ -129,32 +151,48 @@ def cpu_baseline(name, w, topo, info):
                 out[b0:b0 + xyz.shape[0], :, :w["blob"]] = xyz
         return out
 
-    # calibrate on one frame per core (all cores busy), then spend the rest of the budget on a larger sample
     cap = max(1, int(6e9 // (12 * w["atoms"])))                    # host copy below ~6 GB
-    nfr = min(cores, cap)
-    traj = frames_for(nfr)
-    n1 = 1 if w["atoms"] > 500000 else min(2, nfr)                 # the same code on ONE thread
-    t = time.perf_counter()
-    run(traj[:n1], 1)
-    single = n1 / (time.perf_counter() - t)
-    t = time.perf_counter()
-    hits = run(traj, cores)
-    dt = time.perf_counter() - t
-    if dt < 0.4 * budget:
-        n2 = int(min(cap, 1000, nfr * 0.8 * budget / max(dt, 1e-3)))
-        if n2 > 2 * nfr:
-            nfr = n2
-            traj = frames_for(nfr)
-            t = time.perf_counter()
-            hits = run(traj, cores)
-            dt = time.perf_counter() - t
-    value = nfr / dt
-    return {"value": value, "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"{nfr} frames of {name} ({w['atoms']} atoms), oracle (cell-list RDF / SDF align+scatter), "
-                      f"{cores} OpenMP threads, dynamic grain 1 over frames, {dt:.1f} s",
-            "pairs_per_s": hits / dt,
-            "single_thread": {"value": single, "unit": "frames/s", "frames": n1},
-            "parallel_speedup": value / single,       # far below `cores` = the box delivers fewer CPUs than it lists
+
+    def leg(fast):
+        # calibrate on one frame per core (all cores busy), then spend the rest of the budget on a larger sample
+        nfr = min(cores, cap)
+        traj = frames_for(nfr)
+        n1 = 1 if w["atoms"] > 500000 else min(2, nfr)             # the same code on ONE thread
+        t = time.perf_counter()
+        run(traj[:n1], 1, fast)
+        single = n1 / (time.perf_counter() - t)
+        t = time.perf_counter()
+        hits = run(traj, cores, fast)
+        dt = time.perf_counter() - t
+        if dt < 0.4 * budget:
+            n2 = int(min(cap, 1000, nfr * 0.8 * budget / max(dt, 1e-3)))
+            if n2 > 2 * nfr:
+                nfr = n2
+                traj = frames_for(nfr)
+                t = time.perf_counter()
+                hits = run(traj, cores, fast)
+                dt = time.perf_counter() - t
+        v = nfr / dt
+        return {"value": v, "unit": "frames/s", "frames": nfr, "seconds": dt, "pairs_per_s": hits / dt,
+                "single_thread": {"value": single, "unit": "frames/s", "frames": n1}, "parallel_speedup": v / single}
+
+    scalar = leg(False)
+    has_rdf = any(d["kind"] == "rdf" for d in info.values())
+    simd = leg(True) if has_rdf else None
+    if simd is not None:
+        simd["avx512"] = bool(O.have_avx512())
+    best = simd if (simd is not None and simd["value"] > scalar["value"]) else scalar
+    node = node_physical_cores()
+    return {"value": best["value"], "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"{best['frames']} frames of {name} ({w['atoms']} atoms), {'tuned CPU code (half shell, AVX-512; oracle for SDF)' if best is simd else 'oracle (cell-list RDF / SDF align+scatter)'}, "
+                      f"{cores} OpenMP threads, dynamic grain 1 over frames, {best['seconds']:.1f} s",
+            "pairs_per_s": best["pairs_per_s"],
+            "scalar": scalar, "simd": simd,
+            "single_thread": best["single_thread"],
+            "parallel_speedup": best["parallel_speedup"],       # far below `cores` = the box delivers fewer CPUs than it lists
+            # frames are independent: a node-wide run of the same code scales with the cores (memory bandwidth permitting)
+            "extrapolated_to_node": {"physical_cores": node, "value": best["value"] * node / cores if node else None, "unit": "frames/s",
+                                     "note": "value x node cores / cores used: the lease grants a slice of the node's CPUs"},
             "host": {"logical_cpus": logical, "physical_cores": physical, "cgroup_quota_cores": quota}}
 
 
@@ -248,6 +286,7 @@ def run_workload(name, args, ctx, steps, warmup, frames=None, with_cpu=False, op
         step()
     lib.vmd_profile_reset()
     lib.vmd_profile_enable(True)
+    lib.vmd_hip_rdf_columns(1)
     merge_s[0] = 0.0
     if dist:
         dist.barrier()
@@ -265,6 +304,7 @@ def run_workload(name, args, ctx, steps, warmup, frames=None, with_cpu=False, op
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    rdf_columns = int(lib.vmd_hip_rdf_columns(1))          # candidate columns this rank's pair kernel walked in the timed region
     # after the merge every rank holds the counts of all ranks' frames
     hits_per_step = sum(int(ev.property_data(n).counts.sum()) for n, d in info.items() if d["kind"] == "rdf")
     voxel_hits = sum(int(ev.property_data(n).counts.sum()) for n, d in info.items() if d["kind"] == "sdf")
@@ -325,6 +365,10 @@ def run_workload(name, args, ctx, steps, warmup, frames=None, with_cpu=False, op
                                                   "batches on the device (k_xtc_wave) - no host work, no PCIe per step",
                                   "trr": "GROMACS TRR file, native reader -> pinned staging -> DMA"}[args.traj]},
         "pairs_per_s": hits_per_step * steps / elapsed,
+        # measured, not modelled: one column = one target atom against the 64 reference atoms of a chunk.  Per ORDERED
+        # pair of the histograms (a same-set pass counts an unordered pair once and adds 2: halve the hits for lanes per unordered hit)
+        "pair_kernel_columns": {"columns_per_step": rdf_columns / steps if steps else 0,
+                                "candidate_lanes_per_ordered_pair": (64.0 * rdf_columns / steps) / (hits_per_step * local_frames / frames_per_step) if hits_per_step else None},
         "voxel_hits_per_s": voxel_hits * steps / elapsed,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
@@ -374,6 +418,8 @@ def run_workload(name, args, ctx, steps, warmup, frames=None, with_cpu=False, op
     if with_cpu and rank == 0:
         out["cpu_baseline"] = cpu_baseline(name, w, topo, info)
         out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+        en = out["cpu_baseline"]["extrapolated_to_node"]["value"]
+        out["gpu_over_cpu_node"] = value / en if en else None        # against every physical core of the node (extrapolated)
     return out
 
 

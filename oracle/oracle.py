@@ -12,6 +12,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # VMD_ORACLE_LIB: another build of the same source (scripts/sanitize_emu.sh points it at an ASan/UBSan build)
 _LIB_PATH = os.environ.get("VMD_ORACLE_LIB") or os.path.join(_HERE, "libvmd_oracle.so")
 
+_FAST_PATH = os.path.join(_HERE, "libvmd_cpu_fast.so")
+
 PBC_ALL = 7
 
 
@@ -27,9 +29,9 @@ class Synth(C.Structure):
 
 
 def build(force=False):
-    src = [os.path.join(_HERE, f) for f in ("vmd_oracle.c", "vmd_oracle.h", "Makefile")]
-    if (not force and os.path.exists(_LIB_PATH)
-            and all(os.path.getmtime(_LIB_PATH) >= os.path.getmtime(s) for s in src)):
+    src = [os.path.join(_HERE, f) for f in ("vmd_oracle.c", "vmd_oracle.h", "Makefile", "vmd_cpu_fast.c")]
+    if (not force and os.path.exists(_LIB_PATH) and os.path.exists(_FAST_PATH)
+            and all(min(os.path.getmtime(_LIB_PATH), os.path.getmtime(_FAST_PATH)) >= os.path.getmtime(s) for s in src)):
         return _LIB_PATH
     subprocess.check_call(["make", "-C", _HERE, "-B"], stdout=subprocess.DEVNULL)
     return _LIB_PATH
@@ -250,6 +252,41 @@ def distance_pair(x, y, z, cell, a, b):
     out = np.zeros(a.size * b.size, np.float32)
     lib().vo_distance_pair(_f(x), _f(y), _f(z), C.byref(cell), _i(a), a.size, _i(b), b.size, _f(out))
     return out
+
+
+_fast = None
+
+
+def rdf_run_fast(traj, cells, ref_idx, tgt_idx, rmin, rmax, nbins=1024, nthreads=1, simd=True):
+    """bench.py's tuned CPU baseline (oracle/vmd_cpu_fast.c: half shell, AVX-512 where the CPU has it): -> (counts u64, hits) with
+    the integers of rdf_run, or None when the cell kind is not supported (orthorhombic + fully periodic only).  NOT the checker."""
+    global _fast
+    if _fast is None:
+        build()
+        _fast = C.CDLL(_FAST_PATH)
+        _fast.vf_rdf_run.restype = C.c_uint64
+        _fast.vf_rdf_run.argtypes = [C.POINTER(C.c_float), C.POINTER(Cell), C.c_size_t, C.c_size_t, C.POINTER(C.c_int32), C.c_size_t,
+                                     C.POINTER(C.c_int32), C.c_size_t, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint64)]
+        _fast.vf_have_avx512.restype = C.c_int
+    traj = np.ascontiguousarray(traj, np.float32)
+    F, _, npad = traj.shape
+    ref_idx = np.ascontiguousarray(ref_idx, np.int32)
+    tgt_idx = np.ascontiguousarray(tgt_idx, np.int32)
+    same = ref_idx.shape == tgt_idx.shape and np.array_equal(ref_idx, tgt_idx)
+    carr = (Cell * F)(*cells)
+    counts = np.zeros(nbins, np.uint64)
+    ip = C.POINTER(C.c_int32)
+    h = _fast.vf_rdf_run(traj.ctypes.data_as(C.POINTER(C.c_float)), carr, F, npad, ref_idx.ctypes.data_as(ip), ref_idx.size,
+                         tgt_idx.ctypes.data_as(ip), tgt_idx.size, 1 if same else 0, rmin, rmax, nbins, nthreads, 1 if simd else 0,
+                         counts.ctypes.data_as(C.POINTER(C.c_uint64)))
+    if h == 2 ** 64 - 1:
+        return None
+    return counts, int(h)
+
+
+def have_avx512():
+    rdf_run_fast(np.zeros((0, 3, 1), np.float32), [], np.zeros(1, np.int32), np.zeros(1, np.int32), 0.0, 1.0)
+    return bool(_fast.vf_have_avx512())
 
 
 def set_spec(key, value):

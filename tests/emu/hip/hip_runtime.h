@@ -133,6 +133,7 @@ static inline hipError_t hipHostUnregister(void*) { return hipSuccess; }
 static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
+static inline hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); return hipSuccess; }
 static inline hipError_t hipFuncSetAttribute(const void*, int, int) { return hipSuccess; }
 static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = (hipEvent_t)0x1; return hipSuccess; }
 #define hipEventDisableTiming 2

@@ -233,3 +233,23 @@ def test_sc_lattice_in_sheared_cells(oracle, golden):
                 counts, hits = oracle.rdf_frame(xyz[0], xyz[1], xyz[2], cell, idx, idx, 0.0, rmax, nbins=nbins, method=method)
                 np.testing.assert_array_equal(counts, expect, err_msg=f"tilt {(s, t, u)}, {method}")
                 assert hits == expect.sum()
+
+
+@pytest.mark.parametrize("simd", [True, False])
+def test_tuned_cpu_baseline_counts_what_the_oracle_counts(oracle, simd):
+    """oracle/vmd_cpu_fast.c (bench.py's cpu_baseline "simd" leg: half shell, AVX-512 hit compaction) is NOT the checker - it is
+    checked: the same integers as vo_rdf_run, same-set and cross passes, on a box with atoms on cell faces and coincident atoms."""
+    import cases
+    coords = cases.water_box(oracle, 3, 3000, 41.0, 2)
+    coords[:, :, 10] = coords[:, :, 13]                      # coincident atoms (d = 0: outside the open interval)
+    coords[0, 0, 16] = 0.0; coords[0, 1, 19] = 41.0 - 1e-5     # on / next to a cell face
+    cell = oracle.make_cell(41.0)
+    o, h = cases.oxygen(3000), cases.hydrogen(3000)
+    for ref, tgt, rmin, rmax in ((o, o, 0.0, 12.0), (o, h, 0.0, 12.0), (h[:700], o, 1.5, 9.0)):
+        want, _, hits = oracle.rdf_run(coords, [cell] * 2, ref, tgt, rmin, rmax, nthreads=2)
+        got = oracle.rdf_run_fast(coords, [cell] * 2, ref, tgt, rmin, rmax, nthreads=2, simd=simd)
+        assert got is not None
+        np.testing.assert_array_equal(got[0], want)
+        assert got[1] == hits and hits > 0
+    tri = oracle.make_cell(41.0, tilt=(5.0, 0.0, 0.0))
+    assert oracle.rdf_run_fast(coords, [tri] * 2, o, o, 0.0, 12.0) is None          # triclinic: not its business

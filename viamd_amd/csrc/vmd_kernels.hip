@@ -805,6 +805,8 @@ struct vmd_pair_params_t {
     uint32_t pbc;            // bits 0..2: periodic axes (an open axis spans the batch's bounding box: boxes slots 6..8 = origin)
     const uint32_t* skip;    // device flag or NULL: non-zero = the sorted copies are incomplete (a bucket of the cell build overflowed), do nothing
     int ry, rz;              // neighbour reach in pencils per axis: 1 (cross-section >= rmax), 2 = split pencils (cross-section >= rmax/2)
+    unsigned long long* cols_total;   // device counter or NULL: candidate columns of every launch since the host last reset it (one atomic per
+                                      // wave at kernel end): bench.py's "candidate lanes per counted hit" is measured, not modelled
 };
 #define VMD_COUNTER_STRIDE 32    // one 128-byte line per queue counter
 
@@ -1581,6 +1583,7 @@ __global__ __launch_bounds__(256) VMD_SGPR_CAP(96) void k_rdf_pencil(vmd_pair_pa
     const int nxf = p.grid.nxf, ny = p.grid.ny, nz = p.grid.nz;
     const int npen = ny * nz;
 
+    unsigned long long cols_before_flush = 0ull;
     // work items are handed out dynamically (one returning atomic per item, fetched one item ahead)
     int q = blockIdx.x & 7, tries = 0;
     int item = -1, next_item = -1;
@@ -1703,6 +1706,7 @@ __global__ __launch_bounds__(256) VMD_SGPR_CAP(96) void k_rdf_pencil(vmd_pair_pa
             // (a shared histogram receives the columns of four waves: a quarter of the budget each, and the flush takes the bins
             // with an atomic exchange - an increment of another wave lands either before it, and travels now, or after it, and stays)
             if (w.ncols >= (SHIST ? (1u << 21) : (1u << 23))) {
+                cols_before_flush += w.ncols;
                 vmd_drain<VARIANT, INC>(p.bin, w, lane);
                 __builtin_amdgcn_wave_barrier();
                 for (int bb = lane; bb < nbins; bb += VMD_WAVE) {
@@ -1717,6 +1721,7 @@ __global__ __launch_bounds__(256) VMD_SGPR_CAP(96) void k_rdf_pencil(vmd_pair_pa
         next_item = __builtin_amdgcn_readfirstlane(next_item);
     }
     vmd_drain<VARIANT, INC>(p.bin, w, lane);
+    if (p.cols_total && lane == 0) atomicAdd(p.cols_total, cols_before_flush + (unsigned long long)w.ncols);
     // one row per block: the four wave histograms are summed through LDS and stored with plain, coalesced writes
     __syncthreads();
     uint64_t* __restrict__ prow = p.partial + (size_t)blockIdx.x * nbins;
@@ -2481,6 +2486,24 @@ static int g_rdf_shist = 0;       // one LDS histogram per block instead of one 
 extern "C" int vmd_hip_set_rdf_shared_hist(int on) { const int old = g_rdf_shist; g_rdf_shist = on ? 1 : 0; return old; }
 static int g_pen_ry = 1, g_pen_rz = 1;   // neighbour reach of the pencil walk; the grid handed to the build and to the walk must be cut to match
 extern "C" void vmd_hip_set_pencil_reach(int ry, int rz) { g_pen_ry = ry < 1 ? 1 : (ry > 4 ? 4 : ry); g_pen_rz = rz < 1 ? 1 : (rz > 4 ? 4 : rz); }
+// candidate columns walked by k_rdf_pencil (all launches of this process on the current device) since the last reset
+static unsigned long long* g_cols_dev[64] = {};
+static unsigned long long* vmd_cols_counter() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    if (!g_cols_dev[dev]) {
+        if (hipMalloc((void**)&g_cols_dev[dev], sizeof(unsigned long long)) != hipSuccess) { g_cols_dev[dev] = nullptr; return nullptr; }
+        (void)hipMemset(g_cols_dev[dev], 0, sizeof(unsigned long long));
+    }
+    return g_cols_dev[dev];
+}
+extern "C" uint64_t vmd_hip_rdf_columns(int reset) {
+    unsigned long long* c = vmd_cols_counter();
+    unsigned long long v = 0;
+    if (!c || hipDeviceSynchronize() != hipSuccess || hipMemcpy(&v, c, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    if (reset) (void)hipMemset(c, 0, sizeof(v));
+    return (uint64_t)v;
+}
 static int g_rdf_blocks = 2048;   // 8 blocks x 4 waves per CU requested; 6 fit (SGPR budget)
 extern "C" int vmd_hip_rdf_num_blocks(void) { return 2048; }   // capacity of the partial-row scratch
 extern "C" int vmd_hip_set_rdf_blocks(int n) { const int old = g_rdf_blocks; if (n >= 8 && n <= 2048) g_rdf_blocks = n; return old; }
@@ -2529,6 +2552,7 @@ extern "C" int vmd_hip_rdf_pencil(void* stream, const float* sorted_ref, const u
     p.pbc = pbc_flags;
     p.skip = skip_flag;
     p.ry = g_pen_ry; p.rz = g_pen_rz;
+    p.cols_total = vmd_cols_counter();
     const int cell = (pbc_flags & VMD_PBC_TRICLINIC) ? 1 : ((pbc_flags & 7u) != 7u ? 2 : 0);
     const int which = (variant == 1 ? 6 : variant == 2 ? 12 : variant == 3 ? 18 : 0) + (same_set ? 3 : 0) + cell;
 #define VMD_PENCIL_CASE(n, V, S, C) case n: if (g_rdf_shist) hipLaunchKernelGGL((k_rdf_pencil<V, S, C, true>), g, blk, 0, s, p); \
