@@ -418,7 +418,7 @@ def run_workload(name, args, ctx, steps, warmup, frames=None, with_cpu=False, op
     if with_cpu and rank == 0:
         out["cpu_baseline"] = cpu_baseline(name, w, topo, info)
         out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
-        en = out["cpu_baseline"]["extrapolated_to_node"]["value"]
+        en = (out["cpu_baseline"].get("extrapolated_to_node") or {}).get("value")
         out["gpu_over_cpu_node"] = value / en if en else None        # against every physical core of the node (extrapolated)
     return out
 
