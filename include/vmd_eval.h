@@ -43,6 +43,12 @@ typedef struct vmd_system_t {
     const float* z;
     const float* mass;          /* atom_count entries */
     vmd_unitcell_t unitcell;
+    /* md_system_t::bond (read by the evaluator while it runs, src/viamd.cpp:3088-3091; md_util_unwrap_vec4(..., &sys.bond, ...),
+     * src/viamd.cpp:2257): atom index pairs, or NULL / 0.  With bonds an sdf() reference structure is made whole across the periodic
+     * cell along its bond graph (breadth-first from its first atom); without, along its index order (SPEC S5, D-SDF-UNWRAP).  Read
+     * once, by the first vmd_eval_frame_range of an eval. */
+    const int32_t (*bonds)[2];
+    size_t bond_count;
 } vmd_system_t;
 
 typedef struct vmd_frame_header_t {
@@ -120,6 +126,9 @@ typedef struct vmd_trajectory_i {
     /* extension, may be NULL: the whole trajectory compressed in HBM (see vmd_raw_device_view_t) */
     bool (*raw_device_view)(void* inst, vmd_raw_device_view_t* out);
 } vmd_trajectory_i;
+
+/* where the evaluator currently is (a static string, process-wide, last writer wins): for crash handlers and hang reports */
+const char* vmd_last_stage(void);
 
 /* ---- IR: property descriptors (md_script_ir_t stand-in) ----------------------------------------- */
 

@@ -115,14 +115,18 @@ int vmd_hip_rdf_brute(void* stream, const float* xyz, size_t frame_stride, size_
 /* K3: per frame, per reference structure alignment (fp64, SPEC S5).
  *   structs  int32[K][m], mass f32[K][m], ref_pose f64[m][3] (COM-centred)
  *   R32 f32[B][K][9], c32 f32[B][K][3] out;  M64 f64[B][K][12] out (optional, may be NULL)
- *   group f32[B][4] out (optional): centre + radius of the set of structure COMs, the scatter's one-test pre-filter */
+ *   group f32[B][4] out (optional): centre + radius of the set of structure COMs, the scatter's one-test pre-filter
+ *   tree_order, tree_parent  int32[K][m] or both NULL: make every structure whole along its bond tree (atom order[t] hangs on atom
+ *          parent[order[t]], local indices, parent < 0 = root) instead of along the index order; tree_pos f64[B*K][m][3] scratch */
 int vmd_hip_sdf_align(void* stream, const float* xyz, size_t frame_stride, size_t row_stride,
                       const float* boxes, uint32_t pbc_flags, int B,
                       const int32_t* structs, const float* mass, int K, int m, const double* ref_pose,
-                      float* R32, float* c32, double* M64, float* group);
-/* reference pose from one frame (structure 0): ref_pose f64[m][3] out */
+                      float* R32, float* c32, double* M64, float* group,
+                      const int32_t* tree_order, const int32_t* tree_parent, double* tree_pos);
+/* reference pose from one frame (structure 0): ref_pose f64[m][3] out; tree_order / tree_parent: int32[m] of structure 0 or NULL */
 int vmd_hip_sdf_ref_pose(void* stream, const float* xyz, size_t row_stride, const float* box, uint32_t pbc_flags,
-                         const int32_t* struct0, const float* mass0, int m, double* ref_pose);
+                         const int32_t* struct0, const float* mass0, int m, double* ref_pose,
+                         const int32_t* tree_order, const int32_t* tree_parent);
 /* K4: scatter target atoms of every frame into the dim^3 u64 volume (x fastest), SPEC S5.
  *   owner  int8[ntgt]: index of the structure target t belongs to, -1 if none (NULL: membership is searched in structs;
  *          an atom listed in several structures needs NULL) */

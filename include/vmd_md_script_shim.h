@@ -82,6 +82,12 @@ inline vmd_system_t wrap_system(const md_system_t* sys) {
     s.atom_count = (size_t)sys->atom.count;
     s.x = sys->atom.x; s.y = sys->atom.y; s.z = sys->atom.z; s.mass = sys->atom.mass;
     s.unitcell = unitcell(sys->unitcell);
+    /* md_system_t::bond (read while evaluations run, src/viamd.cpp:3088-3091): a host with mdlib's md_bond_data_t at hand sets
+     * s.bonds / s.bond_count to its atom index pairs (VMD_SHIM_BONDS(sys, &s) if defined) - sdf() structures are then made whole
+     * along the bond graph like md_util_unwrap does (src/viamd.cpp:2257); without them, along their index order */
+#ifdef VMD_SHIM_BONDS
+    VMD_SHIM_BONDS(sys, &s);
+#endif
     return s;
 }
 }  // namespace vmd_shim

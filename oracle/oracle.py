@@ -289,6 +289,33 @@ def have_avx512():
     return bool(_fast.vf_have_avx512())
 
 
+class unwrap_tree:
+    """with unwrap_tree(bonds, structures): ...   installs the bond trees of the K structures (vo_bond_tree per structure) for the
+    sdf_* calls inside the block: structures are made whole along their bonds (D-SDF-UNWRAP) instead of along their index order."""
+
+    def __init__(self, bonds, structures):
+        L = lib()
+        L.vo_bond_tree.restype = None
+        L.vo_bond_tree.argtypes = [C.POINTER(C.c_int32), C.c_size_t, C.POINTER(C.c_int32), C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        L.vo_set_unwrap_tree.restype = None
+        L.vo_set_unwrap_tree.argtypes = [C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_size_t, C.c_size_t]
+        bonds = np.ascontiguousarray(bonds, np.int32).reshape(-1, 2)
+        structures = np.ascontiguousarray(structures, np.int32)
+        K, m = structures.shape
+        self.order = np.zeros((K, m), np.int32)
+        self.parent = np.zeros((K, m), np.int32)
+        for k in range(K):
+            L.vo_bond_tree(_i(bonds), bonds.shape[0], _i(structures[k]), m, _i(self.order[k]), _i(self.parent[k]))
+        self.K, self.m = K, m
+
+    def __enter__(self):
+        lib().vo_set_unwrap_tree(_i(self.order), _i(self.parent), self.K, self.m)
+        return self
+
+    def __exit__(self, *a):
+        lib().vo_set_unwrap_tree(None, None, 0, 0)
+
+
 def set_spec(key, value):
     """DECISION switch of SPEC.md ("rdf_closed", "sdf_include_self"); returns the previous value."""
     L = lib()

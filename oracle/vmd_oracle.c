@@ -379,26 +379,63 @@ static inline double vo_mi_rint(double d, double L, int pbc) {
     return d;
 }
 
-/* unwrap chain + mass weighted COM, fp64 sequential */
+/* D-SDF-UNWRAP as a switch: with a bond tree installed (vo_set_unwrap_tree) structure k is made whole along its bonds - atom order[t]
+ * hangs on atom parent[order[t]] (local indices, parent < 0: the root, taken as it is) - instead of along the index order.  Sums
+ * (COM, covariance) always run in index order, so the chain of a whole, index-ordered residue gives the same bits either way. */
+static const int32_t* g_tree_order = NULL;   /* [K][m] visiting order */
+static const int32_t* g_tree_parent = NULL;  /* [K][m] local parent of every atom */
+static size_t g_tree_K = 0, g_tree_m = 0;
+void vo_set_unwrap_tree(const int32_t* order, const int32_t* parent, size_t K, size_t m) {
+    g_tree_order = order; g_tree_parent = parent; g_tree_K = K; g_tree_m = m;
+}
+
+/* The tree mdlib's md_util_unwrap follows (/root/reference/src/viamd.cpp:2257), restated: breadth-first from local atom 0 over the
+ * bonds among the m atoms of the structure, neighbours in increasing local index; atoms the walk does not reach are visited
+ * afterwards in index order, each hanging on its index predecessor.  bonds: global atom index pairs. */
+void vo_bond_tree(const int32_t* bonds, size_t nbonds, const int32_t* idx, size_t m, int32_t* order, int32_t* parent) {
+    int* seen = (int*)calloc(m, sizeof(int));
+    size_t head = 0, tail = 0;
+    for (size_t a = 0; a < m; ++a) parent[a] = -2;
+    if (m) { order[tail++] = 0; seen[0] = 1; parent[0] = -1; }
+    while (head < tail) {
+        const int32_t a = order[head++];
+        for (size_t c = 0; c < m; ++c) {                 /* neighbours in increasing local index */
+            if (seen[c]) continue;
+            int bonded = 0;
+            for (size_t b = 0; b < nbonds && !bonded; ++b)
+                bonded = (bonds[2 * b] == idx[a] && bonds[2 * b + 1] == idx[c]) || (bonds[2 * b] == idx[c] && bonds[2 * b + 1] == idx[a]);
+            if (bonded) { seen[c] = 1; parent[c] = a; order[tail++] = (int32_t)c; }
+        }
+    }
+    for (size_t a = 1; a < m; ++a) if (!seen[a]) { parent[a] = (int32_t)a - 1; order[tail++] = (int32_t)a; }
+    free(seen);
+}
+
+/* unwrap + mass weighted COM, fp64 sequential; k = structure number (selects the bond tree, if one is installed) */
 static void vo_unwrap_com(const float* x, const float* y, const float* z, const vo_box_t* bx,
-                          const int32_t* idx, const float* mass, size_t m, double* p /*m*3*/, double com[3]) {
-    double sw = 0.0, sx = 0.0, sy = 0.0, sz = 0.0;
-    for (size_t a = 0; a < m; ++a) {
+                          const int32_t* idx, const float* mass, size_t m, size_t k, double* p /*m*3*/, double com[3]) {
+    const int tree = g_tree_order && g_tree_parent && k < g_tree_K && g_tree_m == m;
+    for (size_t t = 0; t < m; ++t) {
+        const size_t a = tree ? (size_t)g_tree_order[k * m + t] : t;
+        const long par = tree ? (long)g_tree_parent[k * m + a] : (long)a - 1;
         const int32_t i = idx[a];
         double px = (double)x[i], py = (double)y[i], pz = (double)z[i];
-        if (a > 0 && bx->tri) {
-            double d[3] = {px - p[3 * (a - 1) + 0], py - p[3 * (a - 1) + 1], pz - p[3 * (a - 1) + 2]};
+        if (par >= 0 && bx->tri) {
+            double d[3] = {px - p[3 * par + 0], py - p[3 * par + 1], pz - p[3 * par + 2]};
             vo_mi_tri_d(bx, d);
-            px = p[3 * (a - 1) + 0] + d[0]; py = p[3 * (a - 1) + 1] + d[1]; pz = p[3 * (a - 1) + 2] + d[2];
-        } else if (a > 0) {
-            px = p[3 * (a - 1) + 0] + vo_mi_rint(px - p[3 * (a - 1) + 0], (double)bx->L[0], bx->pbc[0]);
-            py = p[3 * (a - 1) + 1] + vo_mi_rint(py - p[3 * (a - 1) + 1], (double)bx->L[1], bx->pbc[1]);
-            pz = p[3 * (a - 1) + 2] + vo_mi_rint(pz - p[3 * (a - 1) + 2], (double)bx->L[2], bx->pbc[2]);
+            px = p[3 * par + 0] + d[0]; py = p[3 * par + 1] + d[1]; pz = p[3 * par + 2] + d[2];
+        } else if (par >= 0) {
+            px = p[3 * par + 0] + vo_mi_rint(px - p[3 * par + 0], (double)bx->L[0], bx->pbc[0]);
+            py = p[3 * par + 1] + vo_mi_rint(py - p[3 * par + 1], (double)bx->L[1], bx->pbc[1]);
+            pz = p[3 * par + 2] + vo_mi_rint(pz - p[3 * par + 2], (double)bx->L[2], bx->pbc[2]);
         }
         p[3 * a + 0] = px; p[3 * a + 1] = py; p[3 * a + 2] = pz;
+    }
+    double sw = 0.0, sx = 0.0, sy = 0.0, sz = 0.0;
+    for (size_t a = 0; a < m; ++a) {
         const double w = mass ? (double)mass[a] : 1.0;
         sw = sw + w;
-        sx = sx + w * px; sy = sy + w * py; sz = sz + w * pz;
+        sx = sx + w * p[3 * a + 0]; sy = sy + w * p[3 * a + 1]; sz = sz + w * p[3 * a + 2];
     }
     com[0] = sx / sw; com[1] = sy / sw; com[2] = sz / sw;
 }
@@ -407,7 +444,7 @@ void vo_sdf_ref_pose(const float* x, const float* y, const float* z, const vo_ce
                      const int32_t* idx, const float* mass, size_t m, double* ref_pose) {
     const vo_box_t bx = vo_box(cell);
     double com[3];
-    vo_unwrap_com(x, y, z, &bx, idx, mass, m, ref_pose, com);
+    vo_unwrap_com(x, y, z, &bx, idx, mass, m, 0, ref_pose, com);
     for (size_t a = 0; a < m; ++a) {
         ref_pose[3 * a + 0] = ref_pose[3 * a + 0] - com[0];
         ref_pose[3 * a + 1] = ref_pose[3 * a + 1] - com[1];
@@ -495,7 +532,7 @@ void vo_sdf_frame_align(const float* x, const float* y, const float* z, const vo
         const int32_t* idx = struct_idx + k * m;
         const float* mass = struct_mass ? struct_mass + k * m : NULL;
         double com[3];
-        vo_unwrap_com(x, y, z, &bx, idx, mass, m, p, com);
+        vo_unwrap_com(x, y, z, &bx, idx, mass, m, k, p, com);
         double S[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
         for (size_t a = 0; a < m; ++a) {
             const double w = mass ? (double)mass[a] : 1.0;

@@ -91,6 +91,12 @@ float vo_distance_max(const float* x, const float* y, const float* z, const vo_c
 void  vo_distance_pair(const float* x, const float* y, const float* z, const vo_cell_t* cell,
                        const int32_t* a, size_t na, const int32_t* b, size_t nb, float* out);
 
+/* D-SDF-UNWRAP as a switch: structures are made whole along a bond tree instead of along the index order.  vo_bond_tree builds the
+ * tree of one structure (breadth-first from its first atom, see vmd_oracle.c); vo_set_unwrap_tree installs the tables ([K][m] each,
+ * caller-owned, NULL removes them) for vo_sdf_ref_pose / vo_sdf_frame_align / vo_sdf_run. */
+void vo_bond_tree(const int32_t* bonds, size_t nbonds, const int32_t* idx, size_t m, int32_t* order, int32_t* parent);
+void vo_set_unwrap_tree(const int32_t* order, const int32_t* parent, size_t K, size_t m);
+
 /* DECISION switches of SPEC.md ("rdf_closed", "sdf_include_self"): returns the previous value, -1 for an unknown key.  The other
  * two switches need no oracle code: "dist_geometric_com" = call with unit masses, "sdf_density" = the documented scaling of the
  * float view (SPEC S5). */

@@ -873,3 +873,84 @@ def spec_switch_check(lib, oracle):
     want_d = oracle_distance(oracle, coords, ocell, np.ones_like(mass), structures[0], structures[1], L.DIST_COM)
     np.testing.assert_array_equal(got["d"][1].reshape(F, -1), want_d)
     assert not np.array_equal(got["d"][1], base["d"][1])
+
+
+def bonded_ring_case(O, frames=4, box=24.0, seed=3):
+    """D-SDF-UNWRAP with bonds (VERDICT r02 missing #3): K ring-shaped ligands of m = 8 atoms whose INDEX order jumps across the ring
+    (0, 4, 1, 5, 2, 6, 3, 7 around the circle: index neighbours sit on opposite sides), each ring straddling a face of the cell.
+    Chained along the index order a hop of more than half the cell would be folded the wrong way; along the bonds every hop is one
+    bond length.  -> (coords [F,3,N], structures [K,m], mass, bonds [nb,2], targets, whole [F,K,m,3] = the rings before wrapping)"""
+    rng = np.random.default_rng(seed)
+    K, m, radius = 3, 8, 7.5                      # ring diameter 15 A > box / 2 = 12 A: opposite atoms are more than half a cell apart
+    perm = np.array([0, 4, 1, 5, 2, 6, 3, 7])     # ring position of local atom a
+    nwater = 600
+    N = K * m + nwater
+    coords = np.zeros((frames, 3, N), np.float32)
+    whole = np.zeros((frames, K, m, 3))
+    structures = np.arange(K * m, dtype=np.int32).reshape(K, m)
+    bonds = []
+    for k in range(K):
+        pos_of = {int(perm[a]): a for a in range(m)}                  # ring position -> local atom
+        for r in range(m):
+            bonds.append((k * m + pos_of[r], k * m + pos_of[(r + 1) % m]))
+    bonds = np.array(bonds, np.int32)
+    rng.shuffle(bonds)
+    ang = 2 * np.pi * perm / m
+    base = np.stack([radius * np.cos(ang), radius * np.sin(ang), 0.6 * np.sin(3 * ang)], 1)      # a puckered, asymmetric ring
+    base[:, 0] *= 1.15
+    for f in range(frames):
+        for k in range(K):
+            a, b = rng.normal(size=3), rng.normal(size=3)
+            a /= np.linalg.norm(a); b -= a * (a @ b); b /= np.linalg.norm(b)
+            Rm = np.stack([a, b, np.cross(a, b)], 1)
+            centre = np.array([0.3, box / 2, box / 2]) if k == 0 else rng.uniform(0, box, 3)     # ring 0 always straddles the x = 0 face
+            pts = base @ Rm.T + centre + rng.normal(0, 0.05, (m, 3))
+            coords[f, :, k * m:(k + 1) * m] = np.mod(pts, box).T
+            whole[f, k] = pts
+        coords[f, :, K * m:] = rng.uniform(0, box, (3, nwater))
+    mass = np.ones(N, np.float32)
+    mass[:K * m] = np.tile(rng.uniform(1.0, 16.0, m).astype(np.float32), K)      # the same weights in every ring: rigid copies align exactly
+    return coords, structures, mass, bonds, np.arange(K * m, N, dtype=np.int32), whole
+
+
+def check_bonded_unwrap(lib, O):
+    coords, structures, mass, bonds, tgt, whole = bonded_ring_case(O)
+    F, _, N = coords.shape
+    ocell, vcell = cell_pair(O, 24.0, L.PBC_ALL)
+
+    def product(with_bonds):
+        ir = V.ScriptIR(lib)
+        ir.add_sdf("v", structures, tgt, 9.0)
+        ev = V.ScriptEval(F, ir)
+        sysm = V.MolSystem(N, mass=mass, unitcell=vcell, bonds=bonds if with_bonds else None)
+        assert ev.frame_range(sysm, V.HostTrajectory(coords, vcell), 0, F)
+        mats = np.stack([ev.sdf_matrices("v", sysm, V.HostTrajectory(coords, vcell), f)[0] for f in range(F)])
+        return ev.property_data("v").counts.copy(), mats
+
+    with O.unwrap_tree(bonds, structures) as tree:
+        assert (tree.parent[:, 0] == -1).all() and (tree.parent[:, 1:] >= 0).all()
+        want_vol, want_M = oracle_sdf(O, coords, ocell, structures, mass, tgt, 9.0)
+    plain_vol, plain_M = oracle_sdf(O, coords, ocell, structures, mass, tgt, 9.0)
+    got_vol, got_M = product(True)
+    np.testing.assert_array_equal(got_vol, want_vol)                       # bonds handed over: the bond-tree unwrap, bit for bit
+    got_plain, _ = product(False)
+    np.testing.assert_array_equal(got_plain, plain_vol)                    # without bonds: the index chain, as before
+    assert not np.array_equal(want_vol, plain_vol)                         # and the two really differ on this system
+    np.testing.assert_allclose(got_M[:, :, :3, :], want_M, atol=2e-4)
+    # known answer, no oracle: every ring is a rigid copy of one template (+ 0.05 A of jitter), so with the rings made whole correctly
+    # the world->reference matrices carry every (frame, ring) onto the pose of ring 0 at frame 0; a ring folded the wrong way is off
+    # by Angstroms.  The whole ring is placed on the periodic image whose root atom is the wrapped one (where the unwrap starts).
+    def aligned(M):
+        out = np.zeros(whole.shape)
+        for f in range(F):
+            for k in range(structures.shape[0]):
+                root = coords[f, :, structures[k, 0]].astype(np.float64)
+                pts = whole[f, k] + (root - whole[f, k, 0])
+                out[f, k] = pts @ M[f, k][:3, :3].T + M[f, k][:3, 3]
+        return out
+    q = aligned(got_M)
+    assert np.sqrt(((q - q[0, 0]) ** 2).sum(-1)).max() < 0.5
+    _, chain_M = product(False)
+    qc = aligned(chain_M)
+    assert np.sqrt(((qc - qc[0, 0]) ** 2).sum(-1)).max() > 3.0              # the index chain tears at least one of these rings apart
+    return want_vol.sum()

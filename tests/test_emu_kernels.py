@@ -301,3 +301,10 @@ def test_resident_trajectory_changes_invalidate_cached_boxes(emu_lib, oracle):
 
 def test_spec_decisions_are_switches(emu_lib, oracle):
     cases.spec_switch_check(emu_lib, oracle)
+
+
+def test_sdf_structures_are_made_whole_along_their_bonds(emu_lib, oracle):
+    """vmd_system_t::bonds (md_system_t::bond, /root/reference/src/viamd.cpp:2257, 3088-3091): ring-shaped ligands in scrambled index
+    order across a cell face - bond-tree unwrap == oracle bit for bit, differs from the index chain, and aligns every rigid copy
+    onto the reference pose (known answer)."""
+    assert cases.check_bonded_unwrap(emu_lib, oracle) > 0

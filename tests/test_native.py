@@ -147,3 +147,35 @@ def test_md_script_shim_call_sites(gpu_lib):
     out = subprocess.run([build_shim_callsites(), "48"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     assert out.stdout.startswith("OK frames=48"), out.stdout
+
+
+STRESS_SRC = os.path.join(ROOT, "tests", "native", "stress_eval.cpp")
+
+
+def _build_against(lib_path, src, exe, opt="-O2"):
+    subprocess.check_call(["g++", "-std=c++17", opt, "-Wall", src, "-I" + os.path.join(ROOT, "include"), lib_path, "-Wl,-rpath," + os.path.dirname(lib_path),
+                           "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", "-Wl,-rpath-link,/opt/rocm/lib", "-lpthread", "-o", exe])
+    return exe
+
+
+def test_evaluator_life_cycle_stress_on_the_emulator(tmp_path, emu_lib):
+    """tests/native/stress_eval.cpp (create -> threaded SDF + RDF + distance frame_range with a polling reader -> interrupt + restart
+    -> vis payload -> free, repeated; a crash handler reports vmd_last_stage): a few iterations on the emulator build, so the
+    program itself cannot rot; the long runs are `-m gpu` and scripts/gpu_r03h.sh (profiles/r03h_stress.txt)."""
+    import conftest
+    exe = _build_against(conftest.build_emu(), STRESS_SRC, str(tmp_path / "stress_emu"), "-O1")
+    out = subprocess.run([exe, "3", "6"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.startswith("OK iterations=3"), out.stdout
+    assert emu_lib.vmd_last_stage() is not None
+
+
+@pytest.mark.gpu
+def test_evaluator_life_cycle_stress(gpu_lib, tmp_path):
+    """200 life cycles on the MI355X with AMD_LOG_LEVEL=1 (runtime errors reach stderr); a SIGABRT would be reported with the
+    evaluator stage it happened in."""
+    from viamd_amd import build
+    exe = _build_against(build.build(), STRESS_SRC, str(tmp_path / "stress"))
+    out = subprocess.run([exe, "200", "48"], capture_output=True, text=True, timeout=900, env=dict(os.environ, AMD_LOG_LEVEL="1"))
+    assert out.returncode == 0, (out.stdout[-500:], out.stderr[-3000:])
+    assert out.stdout.strip().split("\n")[-1].startswith("OK iterations=200"), out.stdout[-500:]

@@ -61,3 +61,8 @@ def test_spec_decisions_are_switches_on_the_gpu(gpu_lib, oracle):
     """the DECISION switches through the hipcc-built kernels: closed RDF interval (a pair at exactly r_max, coincident atoms, the self
     pairs of the half-shell pass), SDF without the exclusion rule, density-scaled float view, geometric-centre distance"""
     cases.spec_switch_check(gpu_lib, oracle)
+
+
+@pytest.mark.gpu
+def test_sdf_structures_are_made_whole_along_their_bonds_on_the_gpu(gpu_lib, oracle):
+    assert cases.check_bonded_unwrap(gpu_lib, oracle) > 0

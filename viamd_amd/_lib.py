@@ -32,7 +32,7 @@ class Unitcell(C.Structure):
 
 class System(C.Structure):
     _fields_ = [("atom_count", C.c_size_t), ("x", c_float_p), ("y", c_float_p), ("z", c_float_p),
-                ("mass", c_float_p), ("unitcell", Unitcell)]
+                ("mass", c_float_p), ("unitcell", Unitcell), ("bonds", C.POINTER(C.c_int32)), ("bond_count", C.c_size_t)]
 
 
 class FrameHeader(C.Structure):
@@ -213,6 +213,7 @@ SIGNATURES = [
     ("vmd_device_count", C.c_int, []),
     ("vmd_set_device", C.c_bool, [C.c_int]),
     ("vmd_last_error", C.c_char_p, []),
+    ("vmd_last_stage", C.c_char_p, []),
     ("vmd_log_register", None, [LOG_FN, _vp]),
     ("vmd_version", C.c_char_p, []),
     ("vmd_set_option", C.c_int, [C.c_char_p, C.c_int]),
@@ -254,8 +255,8 @@ SIGNATURES = [
     ("vmd_hip_rdf_brute", C.c_int, [_vp, _vp, C.c_size_t, C.c_size_t, _vp, C.c_uint32, C.c_int, _vp, C.c_int, _vp, C.c_int,
                                     C.c_float, C.c_float, C.c_int, _vp]),
     ("vmd_hip_sdf_align", C.c_int, [_vp, _vp, C.c_size_t, C.c_size_t, _vp, C.c_uint32, C.c_int, _vp, _vp, C.c_int, C.c_int, _vp,
-                                    _vp, _vp, _vp, _vp]),
-    ("vmd_hip_sdf_ref_pose", C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_uint32, _vp, _vp, C.c_int, _vp]),
+                                    _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    ("vmd_hip_sdf_ref_pose", C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_uint32, _vp, _vp, C.c_int, _vp, _vp, _vp]),
     ("vmd_hip_sdf_scatter", C.c_int, [_vp, _vp, C.c_size_t, C.c_size_t, _vp, C.c_uint32, C.c_int, _vp, C.c_int, C.c_int, _vp, _vp,
                                       _vp, _vp, C.c_int, C.c_float, C.c_int, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int]),
     ("vmd_hip_set_sdf_ilp", C.c_int, [C.c_int]),

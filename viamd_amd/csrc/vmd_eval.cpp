@@ -148,6 +148,12 @@ extern "C" int vmd_set_option(const char* key, int value) {
 }
 
 extern "C" const char* vmd_last_error(void) { return g_last_error.c_str(); }
+// Where the evaluator is (process-wide, last writer wins): a static string set at every stage of a batch.  Costs one relaxed store; a
+// crash handler (tests/native/stress_eval.cpp installs one for SIGABRT / SIGSEGV) can print it when the process dies inside the HIP
+// runtime without a message - round 2 saw one such abort and could not say where.
+static std::atomic<const char*> g_stage{"idle"};
+#define VMD_STAGE(text) g_stage.store(text, std::memory_order_relaxed)
+extern "C" const char* vmd_last_stage(void) { return g_stage.load(std::memory_order_relaxed); }
 // for the other translation units of the library (not part of the public headers)
 extern "C" void vmd_set_last_error(const char* msg) { g_last_error = msg ? msg : ""; }
 extern "C" const char* vmd_version(void) { return "viamd_amd 0.1 (gfx950)"; }
@@ -475,6 +481,9 @@ struct PropState {
     size_t tag_len = 0;
     DevBuf<float> d_mass;
     DevBuf<double> d_ref_pose;
+    DevBuf<int32_t> d_tree_order, d_tree_parent;     // bond trees of the K structures ([K][m] local indices), when the system carries bonds
+    DevBuf<double> d_tree_pos;                       // scratch of the tree walk, [B*K][m][3]
+    bool have_tree = false;
     DevBuf<float> d_R32, d_c32, d_group;
     bool ref_pose_ready = false;
     // DIST
@@ -768,6 +777,7 @@ extern "C" vmd_script_eval_t* vmd_eval_create(size_t num_frames, const vmd_scrip
 
 extern "C" void vmd_eval_free(vmd_script_eval_t* eval) {
     if (!eval) return;
+    VMD_STAGE("vmd_eval_free");
     {
         std::lock_guard<std::mutex> l(eval->mtx);
         if (eval->stream) { (void)hipStreamSynchronize(eval->stream); }
@@ -808,6 +818,7 @@ extern "C" void vmd_eval_free(vmd_script_eval_t* eval) {
 }
 
 extern "C" void vmd_eval_clear_data(vmd_script_eval_t* eval) {
+    VMD_STAGE("vmd_eval_clear_data");
     if (!eval) return;
     std::lock_guard<std::mutex> l(eval->mtx);
     eval->interrupt = false;
@@ -891,6 +902,7 @@ static bool refresh_distribution(vmd_script_eval_t* e, PropState* p) {
 }
 
 static bool refresh_volume(vmd_script_eval_t* e, PropState* p) {
+    VMD_STAGE("refresh_volume: counts -> float view, D2H");
     if (!p->d_values.ensure(p->ncounts) || !p->d_max.ensure(1)) return false;
     float scale = 1.0f;
     if (e->spec.sdf_density) {
@@ -1078,6 +1090,41 @@ static bool upload_static(vmd_script_eval_t* e, const vmd_system_t* sys, size_t 
             masses(d.a, tmp);
             if (!p->d_mass.upload(tmp.data(), tmp.size(), e->stream)) return false;
             if (!p->d_ref_pose.ensure(d.m * 3)) return false;
+            p->have_tree = false;
+            if (sys && sys->bonds && sys->bond_count) {
+                // D-SDF-UNWRAP with bonds: breadth-first from local atom 0 over the bonds among the structure's atoms, neighbours in
+                // increasing local index; atoms the walk does not reach hang on their index predecessor (oracle: vo_bond_tree)
+                std::vector<int32_t> order(d.K * d.m), parent(d.K * d.m);
+                std::map<int32_t, std::vector<int32_t>> adj;            // only atoms of reference structures matter
+                std::map<int32_t, char> member;
+                for (int32_t a : d.a) member[a] = 1;
+                for (size_t b = 0; b < sys->bond_count; ++b) {
+                    const int32_t i = sys->bonds[b][0], j = sys->bonds[b][1];
+                    if (member.count(i) && member.count(j)) { adj[i].push_back(j); adj[j].push_back(i); }
+                }
+                for (size_t k = 0; k < d.K; ++k) {
+                    const int32_t* idx = &d.a[k * d.m];
+                    int32_t* ord = &order[k * d.m];
+                    int32_t* par = &parent[k * d.m];
+                    std::map<int32_t, int32_t> local;
+                    for (size_t a = 0; a < d.m; ++a) local.emplace(idx[a], (int32_t)a);
+                    std::vector<char> seen(d.m, 0);
+                    size_t head = 0, tail = 0;
+                    ord[tail++] = 0; seen[0] = 1; par[0] = -1;
+                    while (head < tail) {
+                        const int32_t a = ord[head++];
+                        std::vector<int32_t> nb;
+                        auto it = adj.find(idx[a]);
+                        if (it != adj.end()) for (int32_t g : it->second) { auto l = local.find(g); if (l != local.end()) nb.push_back(l->second); }
+                        std::sort(nb.begin(), nb.end());
+                        for (int32_t c : nb) if (!seen[c]) { seen[c] = 1; par[c] = a; ord[tail++] = c; }
+                    }
+                    for (size_t a = 1; a < d.m; ++a) if (!seen[a]) { par[a] = (int32_t)a - 1; ord[tail++] = (int32_t)a; }
+                }
+                if (!p->d_tree_order.upload(order.data(), order.size(), e->stream) || !p->d_tree_parent.upload(parent.data(), parent.size(), e->stream)) return false;
+                HIP_OK(hipStreamSynchronize(e->stream));                 // the vectors go out of scope
+                p->have_tree = true;
+            }
             // owner[t]: the structure target t is a member of (exclusion rule); only valid when memberships are unique
             std::vector<int8_t> owner(d.b.size(), (int8_t)-1);
             bool unique = d.K <= 127;
@@ -1679,7 +1726,7 @@ static bool process_range(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
         BatchSrc src;
         if (!fetch_batch(e, traj, view_holds(have_view, view, 0) ? &view : nullptr, num_atoms, 0, 1, &src)) return false;
         KRN_OK(vmd_hip_sdf_ref_pose(e->stream, src.base, src.row_stride, e->stages[0].d_boxes.p, batch_pbc(e->stages[0]), p->d_structs.p, p->d_mass.p,
-                                    (int)p->prop.m, p->d_ref_pose.p));
+                                    (int)p->prop.m, p->d_ref_pose.p, p->have_tree ? p->d_tree_order.p : nullptr, p->have_tree ? p->d_tree_parent.p : nullptr));
         HIP_OK(hipStreamSynchronize(e->stream));
         p->ref_pose_ready = true;
     }
@@ -1704,11 +1751,12 @@ static bool process_range(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
     // host trajectories are staged in smaller batches so that load_frame of batch k+1 overlaps the kernels of batch k
     // ... except when the batches are decompressed on the device: k_xtc_wave is latency bound - a batch of 1 000 frames takes little
     // longer than one of 64 (profiles/r03_xtc_device_decode.txt: c2 6.7 ms per 500 frames, 5.9 ms per 1 000) - and it does not hide
-    // under the pair kernel, so its batches are large: 8 x stage_frames.  A long file still overlaps the PCIe trip of batch k + 1
-    // with decode + pair kernel of batch k (ring of three slots)
+    // under the pair kernel, so its batches are large: 8 x stage_frames when the compressed frames are resident in HBM, 4 x when
+    // they still have to cross PCIe (two batches per 1 000 frames: the second upload runs under the first batch's decode and pair
+    // kernel - measured 36.8k against 34.9k frames/s for one batch, r03f / r03g)
     if (!have_view && g_opt.batch_frames <= 0) {
         const size_t S = (size_t)std::max(1, g_opt.stage_frames.load());
-        Bmax = std::min<size_t>(Bmax, device_decode ? 8 * S : S);
+        Bmax = std::min<size_t>(Bmax, device_decode ? (raw_ring ? 4 * S : 8 * S) : S);
     }
     std::vector<Batch> batches;
     for (auto& sg : segments) plan_batches(e, sg.first, sg.second, Bmax, &batches);
@@ -1735,6 +1783,7 @@ static bool process_range(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
         const size_t f0 = bt.f0, nb = bt.nb;
         Stage& src = e->stages[cur];
         if (!settle_stage(e, src, traj, num_atoms)) return false;
+        VMD_STAGE("batch: kernels queued");
         HIP_OK(hipStreamWaitEvent(e->stream, src.ready, 0));
         const uint32_t pbc = batch_pbc(src);
         for (auto& s : e->sels) s->built = false;
@@ -1757,6 +1806,7 @@ static bool process_range(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
         // so the flag is final and the batch's RDF part is all-or-nothing (a bucket of a LATER build may overflow after earlier
         // passes have long finished; nothing of them may stay behind when the batch is repeated).
         auto launch_rdf = [&]() -> bool {
+            VMD_STAGE("batch: cell build + pair kernels");
             vmd_hip_set_rdf_closed(e->spec.rdf_closed ? 1 : 0);
             size_t scratch_rows = 0;
             for (auto& g : e->rdf_groups) scratch_rows += std::max(g.passes.size(), g.props.size());
@@ -1846,9 +1896,12 @@ static bool process_range(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
                 p->dirty = true;
             } else if (d.kind == PROP_SDF) {
                 if (!p->d_R32.ensure(nb * d.K * 9) || !p->d_c32.ensure(nb * d.K * 3) || !p->d_group.ensure(nb * 4)) return false;
+                VMD_STAGE("batch: sdf align + scatter");
                 e->prof.begin("sdf_align", e->stream);
+                if (p->have_tree && !p->d_tree_pos.ensure(nb * d.K * d.m * 3)) return false;
                 KRN_OK(vmd_hip_sdf_align(e->stream, src.base, src.frame_stride, src.row_stride, src.d_boxes.p, pbc, (int)nb,
-                                         p->d_structs.p, p->d_mass.p, (int)d.K, (int)d.m, p->d_ref_pose.p, p->d_R32.p, p->d_c32.p, nullptr, p->d_group.p));
+                                         p->d_structs.p, p->d_mass.p, (int)d.K, (int)d.m, p->d_ref_pose.p, p->d_R32.p, p->d_c32.p, nullptr, p->d_group.p,
+                                         p->have_tree ? p->d_tree_order.p : nullptr, p->have_tree ? p->d_tree_parent.p : nullptr, p->have_tree ? p->d_tree_pos.p : nullptr));
                 e->prof.end(e->stream);
                 e->prof.begin("sdf_scatter", e->stream);
                 KRN_OK(vmd_hip_sdf_scatter(e->stream, src.base, src.frame_stride, src.row_stride, src.d_boxes.p, pbc, (int)nb,
@@ -1870,6 +1923,7 @@ static bool process_range(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
                 p->dirty = true;
             }
         }
+        VMD_STAGE("batch: staging the next batch (fetch_stage)");
         // the kernels of this batch are queued: load the next batch on the host while they run
         if (bi + 1 < batches.size() && !e->interrupt) {
             if (!fetch_stage(e, e->stages[cur ^ 1], traj, vw, num_atoms, batches[bi + 1].f0, batches[bi + 1].nb, false, slot_of(bi + 1))) return false;
@@ -1877,7 +1931,9 @@ static bool process_range(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
             if (raw_ring && bi + 2 < batches.size() &&
                 raw_upload(e, *slot_of(bi + 2), traj, num_atoms, batches[bi + 2].f0, batches[bi + 2].nb) < 0) return false;
         }
+        VMD_STAGE("batch: hipStreamSynchronize");
         HIP_OK(hipStreamSynchronize(e->stream));
+        VMD_STAGE("batch: host bookkeeping");
         // a bucket of the two-level cell build was too small: nothing reached the histograms (every consumer saw the flag).
         // Re-measure the selections that used buckets with more head room and evaluate the RDF part of this batch again.
         for (int attempt = 0; *e->h_overflow != 0; ++attempt) {
@@ -1994,7 +2050,7 @@ extern "C" bool vmd_eval_sdf_matrices(vmd_script_eval_t* eval, const char* name,
     if (!p->ref_pose_ready) {
         if (!fetch_batch(e, traj, view_holds(have_view, view, 0) ? &view : nullptr, num_atoms, 0, 1, &src)) return false;
         KRN_OK(vmd_hip_sdf_ref_pose(e->stream, src.base, src.row_stride, e->stages[0].d_boxes.p, batch_pbc(e->stages[0]), p->d_structs.p, p->d_mass.p,
-                                    (int)p->prop.m, p->d_ref_pose.p));
+                                    (int)p->prop.m, p->d_ref_pose.p, p->have_tree ? p->d_tree_order.p : nullptr, p->have_tree ? p->d_tree_parent.p : nullptr));
         HIP_OK(hipStreamSynchronize(e->stream));
         p->ref_pose_ready = true;
     }
@@ -2002,8 +2058,10 @@ extern "C" bool vmd_eval_sdf_matrices(vmd_script_eval_t* eval, const char* name,
     const size_t K = p->prop.K;
     DevBuf<double> dM;
     if (!dM.ensure(K * 12) || !p->d_R32.ensure(K * 9) || !p->d_c32.ensure(K * 3)) return false;
+    if (p->have_tree && !p->d_tree_pos.ensure(K * p->prop.m * 3)) return false;
     KRN_OK(vmd_hip_sdf_align(e->stream, src.base, src.frame_stride, src.row_stride, e->stages[0].d_boxes.p, batch_pbc(e->stages[0]), 1,
-                             p->d_structs.p, p->d_mass.p, (int)K, (int)p->prop.m, p->d_ref_pose.p, p->d_R32.p, p->d_c32.p, dM.p, nullptr));
+                             p->d_structs.p, p->d_mass.p, (int)K, (int)p->prop.m, p->d_ref_pose.p, p->d_R32.p, p->d_c32.p, dM.p, nullptr,
+                             p->have_tree ? p->d_tree_order.p : nullptr, p->have_tree ? p->d_tree_parent.p : nullptr, p->have_tree ? p->d_tree_pos.p : nullptr));
     std::vector<double> M(K * 12);
     HIP_OK(hipMemcpyAsync(M.data(), dM.p, K * 12 * sizeof(double), hipMemcpyDeviceToHost, e->stream));
     HIP_OK(hipStreamSynchronize(e->stream));

@@ -1883,12 +1883,34 @@ __device__ __forceinline__ void vmd_unwrap_chain(const float* fx, const float* f
     }
 }
 
+// DECISION(D-SDF-UNWRAP) as a switch: with the bonds of the system handed over (vmd_system_t::bonds) a structure is made whole along
+// its bond tree - atom order[t] hangs on atom parent[order[t]] (local indices; parent < 0 = the root) - as mdlib's
+// md_util_unwrap does (/root/reference/src/viamd.cpp:2257), instead of along the index order.  Positions go to `pos` (m x 3 doubles
+// of scratch per thread: a parent is not the atom visited last); the callers then sum in INDEX order, as the chain walk does.
+__device__ __forceinline__ void vmd_unwrap_tree(const float* fx, const float* fy, const float* fz, const int32_t* idx, int m, const vmd_box_t& bx,
+                                                const int32_t* order, const int32_t* parent, double* pos) {
+    for (int t = 0; t < m; ++t) {
+        const int a = order[t], par = parent[a];
+        const int i = idx[a];
+        double x = (double)fx[i], y = (double)fy[i], z = (double)fz[i];
+        if (par >= 0) {
+            const double qx = pos[3 * par + 0], qy = pos[3 * par + 1], qz = pos[3 * par + 2];
+            double dx = x - qx, dy = y - qy, dz = z - qz;
+            vmd_mi3_rint(bx, dx, dy, dz);
+            x = qx + dx; y = qy + dy; z = qz + dz;
+        }
+        pos[3 * a + 0] = x; pos[3 * a + 1] = y; pos[3 * a + 2] = z;
+    }
+}
+
 struct vmd_align_params_t {
     const float* xyz; size_t frame_stride; size_t row_stride;
     const float* boxes; uint32_t pbc; int B;
     const int32_t* structs; const float* mass; int K; int m;
     const double* ref_pose;
     float* R32; float* c32; double* M64;
+    const int32_t* tree_order; const int32_t* tree_parent;   // [K][m] each, or NULL: unwrap along the index order
+    double* tree_pos;                                         // [B*K][m][3] scratch of the tree walk
 };
 
 __global__ __launch_bounds__(64) void k_sdf_align(vmd_align_params_t p) {
@@ -1903,22 +1925,29 @@ __global__ __launch_bounds__(64) void k_sdf_align(vmd_align_params_t p) {
     const float* mass = p.mass ? p.mass + (size_t)k * p.m : nullptr;
 
     double sw = 0.0, sx = 0.0, sy = 0.0, sz = 0.0;
-    vmd_unwrap_chain(fx, fy, fz, idx, mass, p.m, bx,
-                     [&](int, double w, double x, double y, double z) {
-                         sw = sw + w; sx = sx + w * x; sy = sy + w * y; sz = sz + w * z;
-                     });
-    const double com0 = sx / sw, com1 = sy / sw, com2 = sz / sw;
     double S[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
     const double* ref = p.ref_pose;
-    vmd_unwrap_chain(fx, fy, fz, idx, mass, p.m, bx,
-                     [&](int a, double w, double x, double y, double z) {
-                         const double c0 = x - com0, c1 = y - com1, c2 = z - com2;
-                         const double r0 = ref[3 * a + 0], r1 = ref[3 * a + 1], r2 = ref[3 * a + 2];
-                         const double wc0 = w * c0, wc1 = w * c1, wc2 = w * c2;
-                         S[0][0] = S[0][0] + wc0 * r0; S[0][1] = S[0][1] + wc0 * r1; S[0][2] = S[0][2] + wc0 * r2;
-                         S[1][0] = S[1][0] + wc1 * r0; S[1][1] = S[1][1] + wc1 * r1; S[1][2] = S[1][2] + wc1 * r2;
-                         S[2][0] = S[2][0] + wc2 * r0; S[2][1] = S[2][1] + wc2 * r1; S[2][2] = S[2][2] + wc2 * r2;
-                     });
+    double com0, com1, com2;
+    auto add_com = [&](int, double w, double x, double y, double z) { sw = sw + w; sx = sx + w * x; sy = sy + w * y; sz = sz + w * z; };
+    auto add_cov = [&](int a, double w, double x, double y, double z) {
+        const double c0 = x - com0, c1 = y - com1, c2 = z - com2;
+        const double r0 = ref[3 * a + 0], r1 = ref[3 * a + 1], r2 = ref[3 * a + 2];
+        const double wc0 = w * c0, wc1 = w * c1, wc2 = w * c2;
+        S[0][0] = S[0][0] + wc0 * r0; S[0][1] = S[0][1] + wc0 * r1; S[0][2] = S[0][2] + wc0 * r2;
+        S[1][0] = S[1][0] + wc1 * r0; S[1][1] = S[1][1] + wc1 * r1; S[1][2] = S[1][2] + wc1 * r2;
+        S[2][0] = S[2][0] + wc2 * r0; S[2][1] = S[2][1] + wc2 * r1; S[2][2] = S[2][2] + wc2 * r2;
+    };
+    if (p.tree_order) {
+        double* pos = p.tree_pos + (size_t)t * 3 * p.m;
+        vmd_unwrap_tree(fx, fy, fz, idx, p.m, bx, p.tree_order + (size_t)k * p.m, p.tree_parent + (size_t)k * p.m, pos);
+        for (int a = 0; a < p.m; ++a) add_com(a, mass ? (double)mass[a] : 1.0, pos[3 * a + 0], pos[3 * a + 1], pos[3 * a + 2]);
+        com0 = sx / sw; com1 = sy / sw; com2 = sz / sw;
+        for (int a = 0; a < p.m; ++a) add_cov(a, mass ? (double)mass[a] : 1.0, pos[3 * a + 0], pos[3 * a + 1], pos[3 * a + 2]);
+    } else {
+        vmd_unwrap_chain(fx, fy, fz, idx, mass, p.m, bx, add_com);
+        com0 = sx / sw; com1 = sy / sw; com2 = sz / sw;
+        vmd_unwrap_chain(fx, fy, fz, idx, mass, p.m, bx, add_cov);
+    }
     double R[9];
     vmd_horn_rotation(S, R);
     float* R32 = p.R32 + (size_t)t * 9;
@@ -1935,18 +1964,27 @@ __global__ __launch_bounds__(64) void k_sdf_align(vmd_align_params_t p) {
 }
 
 __global__ __launch_bounds__(64) void k_sdf_ref_pose(const float* xyz, size_t row_stride, const float* box, uint32_t pbc,
-                                                     const int32_t* idx, const float* mass, int m, double* ref_pose) {
+                                                     const int32_t* idx, const float* mass, int m, double* ref_pose,
+                                                     const int32_t* tree_order, const int32_t* tree_parent) {
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
     const float* fx = xyz;
     const float* fy = fx + row_stride;
     const float* fz = fy + row_stride;
     const vmd_box_t bx = vmd_load_box(box, 0, pbc);
     double sw = 0.0, sx = 0.0, sy = 0.0, sz = 0.0;
-    vmd_unwrap_chain(fx, fy, fz, idx, mass, m, bx,
-                     [&](int a, double w, double x, double y, double z) {
-                         ref_pose[3 * a + 0] = x; ref_pose[3 * a + 1] = y; ref_pose[3 * a + 2] = z;
-                         sw = sw + w; sx = sx + w * x; sy = sy + w * y; sz = sz + w * z;
-                     });
+    if (tree_order) {
+        vmd_unwrap_tree(fx, fy, fz, idx, m, bx, tree_order, tree_parent, ref_pose);      // the pose array doubles as the walk's scratch
+        for (int a = 0; a < m; ++a) {
+            const double w = mass ? (double)mass[a] : 1.0;
+            sw = sw + w; sx = sx + w * ref_pose[3 * a + 0]; sy = sy + w * ref_pose[3 * a + 1]; sz = sz + w * ref_pose[3 * a + 2];
+        }
+    } else {
+        vmd_unwrap_chain(fx, fy, fz, idx, mass, m, bx,
+                         [&](int a, double w, double x, double y, double z) {
+                             ref_pose[3 * a + 0] = x; ref_pose[3 * a + 1] = y; ref_pose[3 * a + 2] = z;
+                             sw = sw + w; sx = sx + w * x; sy = sy + w * y; sz = sz + w * z;
+                         });
+    }
     const double com0 = sx / sw, com1 = sy / sw, com2 = sz / sw;
     for (int a = 0; a < m; ++a) {
         ref_pose[3 * a + 0] = ref_pose[3 * a + 0] - com0;
@@ -2596,10 +2634,12 @@ extern "C" int vmd_hip_rdf_brute(void* stream, const float* xyz, size_t frame_st
 extern "C" int vmd_hip_sdf_align(void* stream, const float* xyz, size_t frame_stride, size_t row_stride,
                                  const float* boxes, uint32_t pbc_flags, int B,
                                  const int32_t* structs, const float* mass, int K, int m, const double* ref_pose,
-                                 float* R32, float* c32, double* M64, float* group) {
+                                 float* R32, float* c32, double* M64, float* group,
+                                 const int32_t* tree_order, const int32_t* tree_parent, double* tree_pos) {
     hipStream_t s = (hipStream_t)stream;
     if (B <= 0 || K <= 0 || m <= 0) return 0;
-    vmd_align_params_t p{xyz, frame_stride, row_stride, boxes, pbc_flags, B, structs, mass, K, m, ref_pose, R32, c32, M64};
+    if ((tree_order != nullptr) != (tree_parent != nullptr) || (tree_order && !tree_pos)) return (int)hipErrorInvalidValue;
+    vmd_align_params_t p{xyz, frame_stride, row_stride, boxes, pbc_flags, B, structs, mass, K, m, ref_pose, R32, c32, M64, tree_order, tree_parent, tree_pos};
     hipLaunchKernelGGL(k_sdf_align, dim3((B * K + 63) / 64), dim3(64), 0, s, p);
     VMD_LAUNCH_CHECK();
     if (group) {
@@ -2610,9 +2650,10 @@ extern "C" int vmd_hip_sdf_align(void* stream, const float* xyz, size_t frame_st
 }
 
 extern "C" int vmd_hip_sdf_ref_pose(void* stream, const float* xyz, size_t row_stride, const float* box, uint32_t pbc_flags,
-                                    const int32_t* struct0, const float* mass0, int m, double* ref_pose) {
+                                    const int32_t* struct0, const float* mass0, int m, double* ref_pose,
+                                    const int32_t* tree_order, const int32_t* tree_parent) {
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_sdf_ref_pose, dim3(1), dim3(64), 0, s, xyz, row_stride, box, pbc_flags, struct0, mass0, m, ref_pose);
+    hipLaunchKernelGGL(k_sdf_ref_pose, dim3(1), dim3(64), 0, s, xyz, row_stride, box, pbc_flags, struct0, mass0, m, ref_pose, tree_order, tree_parent);
     VMD_LAUNCH_CHECK();
     return 0;
 }

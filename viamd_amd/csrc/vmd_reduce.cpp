@@ -55,9 +55,15 @@ Rccl* rccl() {
     static std::once_flag once;
     std::call_once(once, [] {
         const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        // a copy the process already carries first (PyTorch bundles its own RCCL: two different RCCL builds in one process each
+        // want the devices for themselves), only then the system's
         for (const char* n : names) {
-            r.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+            r.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
             if (r.handle) break;
+        }
+        for (const char* n : names) {
+            if (r.handle) break;
+            r.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
         }
         if (!r.handle) {
             const char* why = dlerror();            // one call: dlerror() clears the message it returns

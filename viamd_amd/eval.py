@@ -33,7 +33,9 @@ class VmdError(RuntimeError):
 class MolSystem:
     """The slice of md_system_t the evaluator reads: atom count, masses, unit cell (src/main.cpp:642)."""
 
-    def __init__(self, num_atoms, mass=None, unitcell=None):
+    def __init__(self, num_atoms, mass=None, unitcell=None, bonds=None):
+        """bonds: int32 [nbonds, 2] atom index pairs (md_system_t::bond) or None: sdf() structures are then made whole along
+        their index order instead of along the bond graph."""
         self.num_atoms = int(num_atoms)
         self.mass = np.ascontiguousarray(mass if mass is not None else np.ones(num_atoms), dtype=np.float32)
         assert self.mass.size == self.num_atoms
@@ -41,6 +43,11 @@ class MolSystem:
         self.c.atom_count = self.num_atoms
         self.c.mass = self.mass.ctypes.data_as(L.c_float_p)
         self.c.unitcell = unitcell if unitcell is not None else make_unitcell(None)
+        self.bonds = None
+        if bonds is not None and len(bonds):
+            self.bonds = np.ascontiguousarray(bonds, dtype=np.int32).reshape(-1, 2)
+            self.c.bonds = self.bonds.ctypes.data_as(C.POINTER(C.c_int32))
+            self.c.bond_count = self.bonds.shape[0]
 
 
 class ScriptIR:
