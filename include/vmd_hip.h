@@ -159,6 +159,8 @@ int vmd_hip_add_u64(void* stream, uint64_t* dst, const uint64_t* src, size_t n);
 /* u64 counters -> f32 values (values[i] = fl((float)counts[i] * scale); scale = 1: the raw counts of SPEC S5) + max reduction into
  * max_out[0] (device f32) */
 int vmd_hip_counts_to_float(void* stream, const uint64_t* counts, size_t n, float* values, float* max_out, float scale);
+/* 1: k_sdf_scatter reads the frame with non-temporal loads; returns the previous value */
+int vmd_hip_set_sdf_nt(int on);
 /* candidate columns (one target atom against the 64 reference atoms of a chunk: 64 candidate lanes) k_rdf_pencil has walked on the
  * current device since the counter was last reset; synchronises the device */
 uint64_t vmd_hip_rdf_columns(int reset);

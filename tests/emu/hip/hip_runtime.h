@@ -25,6 +25,7 @@
 #define VMD_SGPR_CAP(n)
 #define VMD_BALLOT(pred) __ballot(pred)
 #define VMD_NO_INLINE_ASM
+#define VMD_LOAD_NT(ptr) (*(ptr))
 
 struct dim3 {
     unsigned x, y, z;
@@ -128,6 +129,7 @@ static inline hipError_t hipMalloc(void** p, size_t n) { *p = calloc(n ? n : 1, 
 static inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
 static inline hipError_t hipHostMalloc(void** p, size_t n, unsigned) { return hipMalloc(p, n); }
 static inline hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
+static inline hipError_t hipHostGetDevicePointer(void** d, void* h, unsigned) { *d = h; return hipSuccess; }
 static inline hipError_t hipHostRegister(void*, size_t, unsigned) { return hipSuccess; }
 static inline hipError_t hipHostUnregister(void*) { return hipSuccess; }
 static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }

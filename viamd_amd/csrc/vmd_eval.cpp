@@ -89,6 +89,7 @@ struct Options {
     std::atomic<int> spec_sdf_include_self{0};    // D-SDF-EXCL: targets that are atoms of structure k are scattered like any other
     std::atomic<int> spec_sdf_density{0};         // D-SDF-NORM: values = counts / (frames evaluated x voxel volume) instead of raw counts
     std::atomic<int> spec_dist_geometric_com{0};  // D-DIST-COM: distance(a, b) between geometric centres, not centres of mass
+    std::atomic<int> sdf_direct_view{1};          // k_counts_to_float writes the volume's float view into its pinned host pages itself
     std::atomic<int> stage_frames{128};      // frames per staged batch of a host / file trajectory (batch_frames <= 0)
     std::atomic<int> rdf_blocks_decode{0};   // > 0: pair-kernel grid while batches are decompressed on the device (1536 = 6 blocks per CU leave
                                              // every SIMD a wave slot and 80 VGPRs for k_xtc_wave).  Measured and left OFF: a decode wave that shares
@@ -124,6 +125,8 @@ extern "C" int vmd_set_option(const char* key, int value) {
     else if (!strcmp(key, "xtc_chunk")) o = &g_opt.xtc_chunk;
     else if (!strcmp(key, "xtc_waves")) return vmd_hip_set_xtc_waves(value);
     else if (!strcmp(key, "stage_frames")) o = &g_opt.stage_frames;
+    else if (!strcmp(key, "sdf_direct_view")) o = &g_opt.sdf_direct_view;
+    else if (!strcmp(key, "sdf_nt")) return vmd_hip_set_sdf_nt(value);
     else if (!strcmp(key, "spec_rdf_closed")) o = &g_opt.spec_rdf_closed;
     else if (!strcmp(key, "spec_sdf_include_self")) o = &g_opt.spec_sdf_include_self;
     else if (!strcmp(key, "spec_sdf_density")) o = &g_opt.spec_sdf_density;
@@ -903,7 +906,7 @@ static bool refresh_distribution(vmd_script_eval_t* e, PropState* p) {
 
 static bool refresh_volume(vmd_script_eval_t* e, PropState* p) {
     VMD_STAGE("refresh_volume: counts -> float view, D2H");
-    if (!p->d_values.ensure(p->ncounts) || !p->d_max.ensure(1)) return false;
+    if (!p->d_max.ensure(1)) return false;
     float scale = 1.0f;
     if (e->spec.sdf_density) {
         // DECISION(D-SDF-NORM) flipped: number density per cubic Angstrom, averaged over the frames evaluated so far
@@ -911,10 +914,22 @@ static bool refresh_volume(vmd_script_eval_t* e, PropState* p) {
         const size_t nf = e->frames_done.load();
         scale = nf ? (float)(1.0 / ((double)nf * edge * edge * edge)) : 0.0f;
     }
-    KRN_OK(vmd_hip_counts_to_float(e->stream, p->d_counts.p, p->ncounts, p->d_values.p, p->d_max.p, scale));
     float vmax = 0.0f;
     if (p->zero_pending) { HIP_OK(hipStreamWaitEvent(e->stream, p->zero_done, 0)); p->zero_pending = false; }
-    HIP_OK(hipMemcpyAsync(p->values.data(), p->d_values.p, p->ncounts * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    float* host_view_dev = nullptr;
+    if (g_opt.sdf_direct_view.load() && p->values.pinned && hipHostGetDevicePointer((void**)&host_view_dev, p->values.data(), 0) != hipSuccess) {
+        (void)hipGetLastError();
+        host_view_dev = nullptr;
+    }
+    if (host_view_dev) {
+        // the conversion kernel writes the float view VIAMD reads straight into its pinned host pages (8.4 MB over PCIe at the
+        // DMA's rate): no device-side copy of the view, no separate DMA behind the kernel
+        KRN_OK(vmd_hip_counts_to_float(e->stream, p->d_counts.p, p->ncounts, host_view_dev, p->d_max.p, scale));
+    } else {
+        if (!p->d_values.ensure(p->ncounts)) return false;
+        KRN_OK(vmd_hip_counts_to_float(e->stream, p->d_counts.p, p->ncounts, p->d_values.p, p->d_max.p, scale));
+        HIP_OK(hipMemcpyAsync(p->values.data(), p->d_values.p, p->ncounts * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    }
     // the 17 MB u64 mirror behind `counts` is an extension VIAMD never reads: it is synchronised on demand
     // (vmd_eval_refresh_counts), only the float view travels after every range
     p->counts_stale = true;

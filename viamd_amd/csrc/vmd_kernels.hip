@@ -2015,6 +2015,9 @@ __global__ __launch_bounds__(64) void k_sdf_group(const float* __restrict__ c32,
 
 // ------------------------------------------------------------------------------------------------ K4: SDF scatter
 
+#ifndef VMD_LOAD_NT
+#define VMD_LOAD_NT(ptr) __builtin_nontemporal_load(ptr)
+#endif
 struct vmd_scatter_params_t {
     const float* __restrict__ xyz; size_t frame_stride; size_t row_stride;
     const float* __restrict__ boxes; uint32_t pbc; int B;
@@ -2025,6 +2028,7 @@ struct vmd_scatter_params_t {
     const float* __restrict__ group;   // f32[B][4] from k_sdf_group, or NULL
     int tgt_first, tgt_stride;         // tgt_stride > 0: target t is atom tgt_first + t * tgt_stride (no index list to chase)
     int unowned;                       // 1: no target belongs to any structure (the exclusion rule never applies)
+    int nt;                            // 1: the frame is read with non-temporal loads (a pure stream: nothing of it is read twice)
 };
 
 // one target atom against structure k of frame b (SPEC S5 scatter).  own_k: structure the atom belongs to (-1 none,
@@ -2110,7 +2114,13 @@ __global__ __launch_bounds__(256) void k_sdf_scatter(vmd_scatter_params_t p) {
 #pragma unroll
     for (int u = 0; u < ILP; ++u) {
         x[u] = y[u] = z[u] = 0.0f;
-        if (idx[u] >= 0) { x[u] = fx[idx[u]]; y[u] = fx[p.row_stride + idx[u]]; z[u] = fx[2 * p.row_stride + idx[u]]; }
+        if (idx[u] >= 0) {
+            if (p.nt) {
+                x[u] = VMD_LOAD_NT(fx + idx[u]); y[u] = VMD_LOAD_NT(fx + p.row_stride + idx[u]); z[u] = VMD_LOAD_NT(fx + 2 * p.row_stride + idx[u]);
+            } else {
+                x[u] = fx[idx[u]]; y[u] = fx[p.row_stride + idx[u]]; z[u] = fx[2 * p.row_stride + idx[u]];
+            }
+        }
     }
     unsigned pending = 0u;
 #pragma unroll
@@ -2658,6 +2668,8 @@ extern "C" int vmd_hip_sdf_ref_pose(void* stream, const float* xyz, size_t row_s
     return 0;
 }
 
+static int g_sdf_nt = 0;        // the scatter's gathers as non-temporal loads (A/B: profiles/r03i_ab_c4.txt)
+extern "C" int vmd_hip_set_sdf_nt(int on) { const int old = g_sdf_nt; g_sdf_nt = on ? 1 : 0; return old; }
 static int g_sdf_rows = 0;      // row-streaming scatter for arithmetic-progression targets: groups of 4 atoms per thread (0 = off, 1 / 2 / 4)
 extern "C" int vmd_hip_set_sdf_rows(int n) { const int old = g_sdf_rows; if (n == 0 || n == 1 || n == 2 || n == 4) g_sdf_rows = n; return old; }
 static int g_sdf_wave = 0;      // per-wave instead of per-block compaction of the group test's survivors (no block barrier)
@@ -2672,7 +2684,7 @@ extern "C" int vmd_hip_sdf_scatter(void* stream, const float* xyz, size_t frame_
     hipStream_t s = (hipStream_t)stream;
     if (B <= 0 || K <= 0 || ntgt <= 0) return 0;
     vmd_scatter_params_t p{xyz, frame_stride, row_stride, boxes, pbc_flags, B, structs, K, m, R32, c32, tgt, owner, ntgt, extent, dim,
-                           (unsigned long long*)volume, group, tgt_first, tgt_stride, unowned};
+                           (unsigned long long*)volume, group, tgt_first, tgt_stride, unowned, g_sdf_nt};
     if (atom_tag) {
         const int natoms4 = (int)(row_stride / 4);       // rows are padded to a multiple of 64 floats; the tag array covers the padding
         hipLaunchKernelGGL(k_sdf_scatter_dense, dim3((natoms4 + 255) / 256, B), dim3(256), 0, s, p, atom_tag, natoms4);
