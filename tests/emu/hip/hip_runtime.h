@@ -84,6 +84,7 @@ static inline unsigned emu_mbcnt_hi(unsigned mask, unsigned add) {
 #define VMD_SHFL_U32(v, src) emu::shfl_idx_bits((uint32_t)(v), (int)(src))
 #define VMD_READLANE_U32(v, lane) emu::shfl_idx_bits((uint32_t)(v), (int)(lane))
 #define VMD_XTC_BALLOT(pred) __ballot(pred)
+#define VMD_XTC_SETPRIO() ((void)0)
 
 // v_sqrt_f32 stand-in with a deliberate +-1 ulp error on half of the inputs: exercises the exactness fix-up of vmd_bin_add
 static inline float emu_approx_sqrtf(float x) {

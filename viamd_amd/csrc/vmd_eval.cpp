@@ -91,6 +91,16 @@ struct Options {
     std::atomic<int> spec_dist_geometric_com{0};  // D-DIST-COM: distance(a, b) between geometric centres, not centres of mass
     std::atomic<int> sdf_direct_view{1};          // k_counts_to_float writes the volume's float view into its pinned host pages itself
     std::atomic<int> stage_frames{128};      // frames per staged batch of a host / file trajectory (batch_frames <= 0)
+    std::atomic<int> rdf_blocks_decode{1536};   // pair-kernel grid while batches are decompressed on the device: 6 blocks per CU leave every
+                                                // SIMD a wave slot and 80 VGPRs, so k_xtc_wave of batch k + 1 (wave priority 3) runs under the pair
+                                                // kernel of batch k; costs the pair kernel ~4 % (0 = leave the grid alone)
+    // oracle/SPEC.md's DECISION: tags as switches - 0 = the documented default, 1 = the alternative; read when an eval is created
+    std::atomic<int> spec_rdf_closed{0};          // D-RDF-OPEN: r_min <= d <= r_max instead of the open interval
+    std::atomic<int> spec_sdf_include_self{0};    // D-SDF-EXCL: targets that are atoms of structure k are scattered like any other
+    std::atomic<int> spec_sdf_density{0};         // D-SDF-NORM: values = counts / (frames evaluated x voxel volume) instead of raw counts
+    std::atomic<int> spec_dist_geometric_com{0};  // D-DIST-COM: distance(a, b) between geometric centres, not centres of mass
+    std::atomic<int> sdf_direct_view{1};          // k_counts_to_float writes the volume's float view into its pinned host pages itself
+    std::atomic<int> stage_frames{128};      // frames per staged batch of a host / file trajectory (batch_frames <= 0)
     std::atomic<int> rdf_blocks_decode{0};   // > 0: pair-kernel grid while batches are decompressed on the device (1536 = 6 blocks per CU leave
                                              // every SIMD a wave slot and 80 VGPRs for k_xtc_wave).  Measured and left OFF: a decode wave that shares
                                              // its SIMD with six VALU-bound pair waves gets a seventh of the issue slots, and a latency-bound serial
@@ -1764,14 +1774,15 @@ static bool process_range(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
     size_t Bmax = auto_batch(e, num_atoms, !have_view);
     const vmd_device_view_t* vw = have_view ? &view : nullptr;
     // host trajectories are staged in smaller batches so that load_frame of batch k+1 overlaps the kernels of batch k
-    // ... except when the batches are decompressed on the device: k_xtc_wave is latency bound - a batch of 1 000 frames takes little
-    // longer than one of 64 (profiles/r03_xtc_device_decode.txt: c2 6.7 ms per 500 frames, 5.9 ms per 1 000) - and it does not hide
-    // under the pair kernel, so its batches are large: 8 x stage_frames when the compressed frames are resident in HBM, 4 x when
-    // they still have to cross PCIe (two batches per 1 000 frames: the second upload runs under the first batch's decode and pair
-    // kernel - measured 36.8k against 34.9k frames/s for one batch, r03f / r03g)
+    // ... except when the batches are decompressed on the device.  k_xtc_wave is a latency-bound chain per frame (a batch of 500
+    // frames takes little longer than one of 64), but at wave priority 3 it runs UNDER the pair kernel of the previous batch once
+    // that kernel's grid leaves it a wave slot per SIMD (rdf_blocks_decode): measured on c2 with rigid water (profiles/
+    // r03_xtc_device_decode.txt) 96.6k frames/s with batches of 512 against 86.3k for one batch of 1 000 (compressed frames resident
+    // in HBM), and 62.7k / 55.5k from the file with batches of 128 / 500; the loosely packed synthetic box, whose walk is five
+    // times longer, is indifferent (66.9k / 69.6k; 38.4k / 42.1k).  So: 4 x stage_frames resident, 2 x from a file.
     if (!have_view && g_opt.batch_frames <= 0) {
         const size_t S = (size_t)std::max(1, g_opt.stage_frames.load());
-        Bmax = std::min<size_t>(Bmax, device_decode ? (raw_ring ? 4 * S : 8 * S) : S);
+        Bmax = std::min<size_t>(Bmax, device_decode ? (raw_ring ? 2 * S : 4 * S) : S);
     }
     std::vector<Batch> batches;
     for (auto& sg : segments) plan_batches(e, sg.first, sg.second, Bmax, &batches);

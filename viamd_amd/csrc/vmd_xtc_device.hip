@@ -416,6 +416,7 @@ __global__ __launch_bounds__(64) void k_xtc_chunks(const unsigned char* __restri
 //   * gridDim.y waves share a frame: every one of them walks the whole stream (the walk needs no communication) and decodes every
 //     gridDim.y-th tile, so a small batch still fills the chip.
 #ifndef VMD_SHFL_U32
+#define VMD_XTC_SETPRIO() __builtin_amdgcn_s_setprio(3)
 #define VMD_SHFL_U32(v, src) ((uint32_t)__shfl((int)(v), (int)(src)))
 #define VMD_READLANE_U32(v, lane) ((uint32_t)__builtin_amdgcn_readlane((int)(v), (int)(lane)))
 #define VMD_XTC_BALLOT(pred) __builtin_amdgcn_ballot_w64(pred)
@@ -439,6 +440,9 @@ struct XtcBank { uint32_t r[XTC_BANK]; };   // 64-dword blocks of the stream, on
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_xtc_wave(const unsigned char* __restrict__ raw, const vmd_xtc_frame_t* __restrict__ info,
                                                  int B, int natoms, float* __restrict__ xyz, size_t frame_stride, size_t row_stride,
                                                  uint32_t* __restrict__ status) {
+    // a serial walk issues one dependent instruction every few cycles: next to the VALU-bound waves of the pair kernel it would get a
+    // seventh of the SIMD's issue slots and crawl.  At the highest wave priority it takes the slots it can use (a fifth of them) first.
+    VMD_XTC_SETPRIO();
     const int f = blockIdx.x;
     const int nshare = (int)gridDim.y;
     int turn = (int)blockIdx.y;                                   // tiles until this wave's next one
