@@ -94,17 +94,6 @@ struct Options {
     std::atomic<int> rdf_blocks_decode{1536};   // pair-kernel grid while batches are decompressed on the device: 6 blocks per CU leave every
                                                 // SIMD a wave slot and 80 VGPRs, so k_xtc_wave of batch k + 1 (wave priority 3) runs under the pair
                                                 // kernel of batch k; costs the pair kernel ~4 % (0 = leave the grid alone)
-    // oracle/SPEC.md's DECISION: tags as switches - 0 = the documented default, 1 = the alternative; read when an eval is created
-    std::atomic<int> spec_rdf_closed{0};          // D-RDF-OPEN: r_min <= d <= r_max instead of the open interval
-    std::atomic<int> spec_sdf_include_self{0};    // D-SDF-EXCL: targets that are atoms of structure k are scattered like any other
-    std::atomic<int> spec_sdf_density{0};         // D-SDF-NORM: values = counts / (frames evaluated x voxel volume) instead of raw counts
-    std::atomic<int> spec_dist_geometric_com{0};  // D-DIST-COM: distance(a, b) between geometric centres, not centres of mass
-    std::atomic<int> sdf_direct_view{1};          // k_counts_to_float writes the volume's float view into its pinned host pages itself
-    std::atomic<int> stage_frames{128};      // frames per staged batch of a host / file trajectory (batch_frames <= 0)
-    std::atomic<int> rdf_blocks_decode{0};   // > 0: pair-kernel grid while batches are decompressed on the device (1536 = 6 blocks per CU leave
-                                             // every SIMD a wave slot and 80 VGPRs for k_xtc_wave).  Measured and left OFF: a decode wave that shares
-                                             // its SIMD with six VALU-bound pair waves gets a seventh of the issue slots, and a latency-bound serial
-                                             // walk slows down by about what the overlap would save (profiles/r03_xtc_device_decode.txt)
     std::atomic<int> sdf_dense{0};       // dense-target SDF scatter (stream whole frames, select by tag): measured slower, off
     std::atomic<int> sdf_arith{1};       // SDF target lists that are arithmetic progressions are generated on the device (0 = always load the index list)
     std::atomic<int> rdf_classes{1};     // co-evaluated RDFs of one range share pair passes through disjoint atom classes (0 = one pass per property)
