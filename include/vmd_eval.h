@@ -109,6 +109,12 @@ typedef struct vmd_raw_device_view_t {
     const vmd_unitcell_t* cells;    /* host, one per frame */
     uint32_t codec;                 /* VMD_RAW_CODEC_* */
     int device;
+    /* optional (NULL = none): room for the decoder's checkpoints, so that only the FIRST decode of a frame has to walk its bit stream
+     * from the start (vmd_hip.h: vmd_xtc_ck_t).  ck: device, num_frames x VMD_XTC_CK_MAX records; nck: device, one counter per frame;
+     * ck_have: host, one byte per frame, set by the evaluator once the frame's checkpoints are valid */
+    void*     ck;
+    uint32_t* nck;
+    uint8_t*  ck_have;
 } vmd_raw_device_view_t;
 
 typedef struct vmd_trajectory_i {

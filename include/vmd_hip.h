@@ -194,6 +194,17 @@ int vmd_hip_xtc_decode_chunked(void* stream, const unsigned char* raw, const vmd
  * one per lane.  Streams of 2^27 bytes and more are reported as status 2. */
 int vmd_hip_xtc_decode_wave(void* stream, const unsigned char* raw, const vmd_xtc_frame_t* info, int B, int natoms,
                             float* xyz, size_t frame_stride, size_t row_stride, uint32_t* status);
+/* Checkpoints: the decoder state at a tile boundary of a frame's stream (bit position, atom index, smallidx | run << 8).  A first
+ * pass (use = 0) decodes as vmd_hip_xtc_decode_wave does and writes up to VMD_XTC_CK_MAX of them per frame (ck[b][.], nck[b]); a
+ * later pass over the SAME frames (use = 1) splits every frame into that many independent sections - no walk is repeated, a frame
+ * occupies as many SIMDs as it has sections.  ck: device, B x VMD_XTC_CK_MAX records; nck: device, B counters. */
+#define VMD_XTC_CK_MAX 16
+typedef struct vmd_xtc_ck_t {
+    uint32_t pos, atom, state, reserved;
+} vmd_xtc_ck_t;
+int vmd_hip_xtc_decode_wave_ck(void* stream, const unsigned char* raw, const vmd_xtc_frame_t* info, int B, int natoms,
+                               float* xyz, size_t frame_stride, size_t row_stride, uint32_t* status, int use,
+                               vmd_xtc_ck_t* ck, uint32_t* nck);
 /* waves that share one frame in k_xtc_wave (each walks the whole stream and decodes every n-th tile of 64 groups); 0 = automatic
  * (enough to put ~4 waves on every SIMD of the chip); returns the previous value */
 int vmd_hip_set_xtc_waves(int n);

@@ -19,7 +19,7 @@ import viamd_amd as V
 from viamd_amd import _lib as L
 from viamd_amd import synth
 
-SHARES = (1, 2, 4, 8, 16, 32, 0)
+SHARES = (1, 4, 0)
 QUICK = "--quick" in sys.argv
 lib = V.default_lib()
 lib.vmd_set_device(0)
@@ -104,6 +104,24 @@ def run(name, path, natoms, B):
         same = all(np.array_equal(got[f], ref[f]) for f in range(len(ref)))
         best = min(ms[1:])
         say(f"  variant 3, {share:2d} waves per frame (0 = auto) {best:9.3f} ms per batch = {B / best * 1e3:10.0f} frames/s   status ok: {bool((d_status.cpu().numpy() == 0).all())}  floats == host reader: {same}")
+    # checkpoints: first pass (walk + emit), then sectioned passes
+    d_ck = torch.zeros(B * 16 * 4, dtype=torch.int32, device="cuda")
+    d_nck = torch.zeros(B, dtype=torch.int32, device="cuda")
+    ms = []
+    for r in range(4):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        d_xyz.zero_()
+        torch.cuda.synchronize()
+        e0.record()
+        assert lib.vmd_hip_xtc_decode_wave_ck(None, d_raw.data_ptr(), d_info.data_ptr(), B, natoms, d_xyz.data_ptr(), 3 * npad, npad, d_status.data_ptr(),
+                                              0 if r == 0 else 1, d_ck.data_ptr(), d_nck.data_ptr()) == 0
+        e1.record()
+        torch.cuda.synchronize()
+        ms.append(e0.elapsed_time(e1))
+    got = d_xyz[:len(ref), :, :natoms].cpu().numpy()
+    same = all(np.array_equal(got[f], ref[f]) for f in range(len(ref)))
+    say(f"  variant 3 with checkpoints: first pass (emits) {ms[0]:8.3f} ms, sectioned passes {min(ms[1:]):8.3f} ms per batch = {B / min(ms[1:]) * 1e3:10.0f} frames/s"
+        f"   sections per frame {d_nck.float().mean().item():.1f}  status ok: {bool((d_status.cpu().numpy() == 0).all())}  floats == host reader: {same}")
     for vname, fn in variants.items():
         reps = 3 if vname.startswith("3") else 1
         if not vname.startswith("3") and (B > 1024 or QUICK):
@@ -142,6 +160,6 @@ p2 = os.path.join(tmp, "exp_water.xtc")
 frames = np.stack([real_water(N // 3, 100.0, 100 + f) for f in range(16)])
 V.write_xtc(p2, frames, cell)
 say(f"wrote {p2}: {os.path.getsize(p2) / 16 / 1e6:.3f} MB/frame")
-for B in (128, 1024, 4096):
+for B in (128, 512, 1024, 4096):
     run("synthetic c2", p1, N, B)
     run("real water geometry", p2, N, B)

@@ -302,7 +302,37 @@ def _device_decode(lib, blob, natoms, chunk=0, gpu=False):
         if chunk > 0:
             scratch = np.zeros(lib.vmd_hip_xtc_scratch_bytes(B, natoms, chunk) // 8 + 1, np.uint64)
             scratch_p = scratch.ctypes.data
-    if chunk == -1:            # one wave per frame (k_xtc_wave)
+    if chunk == -2:            # k_xtc_wave twice: the first pass leaves checkpoints, the second decodes the frames in sections from them
+        CK = 16
+        if gpu:
+            d_ck = torch.zeros(B * CK * 4, dtype=torch.int32, device="cuda")
+            d_nck = torch.zeros(B, dtype=torch.int32, device="cuda")
+            ck_p, nck_p = d_ck.data_ptr(), d_nck.data_ptr()
+        else:
+            ck = np.zeros(B * CK * 4, np.uint32)
+            nck = np.zeros(B, np.uint32)
+            ck_p, nck_p = ck.ctypes.data, nck.ctypes.data
+        rc = lib.vmd_hip_xtc_decode_wave_ck(None, raw_p, info_p, B, natoms, out_p, 3 * npad, npad, status_p, 0, ck_p, nck_p)
+        assert rc == 0
+        if gpu:
+            torch.cuda.synchronize()
+            first, st1 = d_out.cpu().numpy().copy(), d_status.cpu().numpy().copy()
+            d_out.fill_(float("nan"))
+            counts = d_nck.cpu().numpy()
+        else:
+            first, st1 = out.copy(), status.copy()
+            out[:] = np.nan
+            counts = nck
+        if (st1 == 0).all():
+            assert (counts >= 1).all() and (counts <= CK).all(), counts
+            rc = lib.vmd_hip_xtc_decode_wave_ck(None, raw_p, info_p, B, natoms, out_p, 3 * npad, npad, status_p, 1, ck_p, nck_p)
+            if gpu:
+                torch.cuda.synchronize()
+                second = d_out.cpu().numpy()
+            else:
+                second = out
+            np.testing.assert_array_equal(second[:, :, :natoms], first[:, :, :natoms])      # sections == one walk, bit for bit
+    elif chunk == -1:          # one wave per frame (k_xtc_wave)
         rc = lib.vmd_hip_xtc_decode_wave(None, raw_p, info_p, B, natoms, out_p, 3 * npad, npad, status_p)
     elif chunk:                # two passes: index (one thread per frame) + chunks (one thread per chunk)
         rc = lib.vmd_hip_xtc_decode_chunked(None, raw_p, info_p, B, natoms, out_p, 3 * npad, npad, status_p, chunk, scratch_p)
@@ -347,7 +377,7 @@ def _device_decoder_against_host_reader(tmp_path, lib, chunk, gpu, trials=25):
     assert rejected > 0
 
 
-@pytest.mark.parametrize("chunk", [0, 64, 300, -1])
+@pytest.mark.parametrize("chunk", [0, 64, 300, -1, -2])
 def test_device_xtc_decoder_matches_the_host_reader(tmp_path, emu_lib, chunk):
     """k_xtc_decode (one GPU thread per frame), the two-pass k_xtc_index + k_xtc_chunks (one thread per chunk of `chunk` atoms) and
     k_xtc_wave (chunk -1: one wave per frame, speculative group walk; all here on the SIMT emulator) against the host reader on
@@ -357,7 +387,7 @@ def test_device_xtc_decoder_matches_the_host_reader(tmp_path, emu_lib, chunk):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("chunk", [-1, 0, 128])
+@pytest.mark.parametrize("chunk", [-1, -2, 0, 128])
 def test_device_xtc_decoder_matches_the_host_reader_on_the_gpu(tmp_path, gpu_lib, chunk):
     """The same fixtures through the hipcc-built kernels on the MI355X (device memory from torch)."""
     _device_decoder_against_host_reader(tmp_path, gpu_lib, chunk, True, trials=10)
@@ -386,9 +416,17 @@ def test_xtc_batches_decoded_on_the_device_through_the_evaluator(tmp_path, emu_l
             old_c = emu_lib.vmd_set_option(b"xtc_chunk", 64)
             try:
                 ev = V.ScriptEval(F, ir)
-                assert ev.frame_range(sysm, V.XdrTrajectory(p, lib=emu_lib), 0, F)
+                xt = V.XdrTrajectory(p, lib=emu_lib)
+                assert ev.frame_range(sysm, xt, 0, F)
                 res[mode] = ev.property_data("g").counts.copy()
                 assert ev.frames_device_decoded() == (F if mode else 0)
+                if mode == 3:
+                    # the same eval, the same file again (VIAMD re-evaluates after every script edit): the first pass left decoder
+                    # checkpoints, this one decodes every frame in sections from them - and must count the same pairs
+                    ev.clear_data()
+                    assert ev.frame_range(sysm, xt, 0, 5) and ev.frame_range(sysm, xt, 5, F)
+                    np.testing.assert_array_equal(ev.property_data("g").counts, res[mode])
+                    assert ev.frames_device_decoded() == F
                 if mode:
                     ev2 = V.ScriptEval(F, ir)
                     assert ev2.frame_range(sysm, V.XdrTrajectory(q, lib=emu_lib), 0, F)

@@ -84,6 +84,7 @@ struct Options {
                                              // frame (k_xtc_decode), 2 = index pass + one thread per chunk (k_xtc_index / k_xtc_chunks),
                                              // 3 = one wave per frame (k_xtc_wave)
     std::atomic<int> xtc_chunk{256};         // atoms per chunk of variant 2
+    std::atomic<int> xtc_checkpoints{1};     // variant 3: the first decode of a frame leaves checkpoints, later ones decode it in sections
     // oracle/SPEC.md's DECISION: tags as switches - 0 = the documented default, 1 = the alternative; read when an eval is created
     std::atomic<int> spec_rdf_closed{0};          // D-RDF-OPEN: r_min <= d <= r_max instead of the open interval
     std::atomic<int> spec_sdf_include_self{0};    // D-SDF-EXCL: targets that are atoms of structure k are scattered like any other
@@ -122,6 +123,7 @@ extern "C" int vmd_set_option(const char* key, int value) {
     else if (!strcmp(key, "sdf_dense")) o = &g_opt.sdf_dense;
     else if (!strcmp(key, "xtc_device_decode")) o = &g_opt.xtc_device_decode;
     else if (!strcmp(key, "xtc_chunk")) o = &g_opt.xtc_chunk;
+    else if (!strcmp(key, "xtc_checkpoints")) o = &g_opt.xtc_checkpoints;
     else if (!strcmp(key, "xtc_waves")) return vmd_hip_set_xtc_waves(value);
     else if (!strcmp(key, "stage_frames")) o = &g_opt.stage_frames;
     else if (!strcmp(key, "sdf_direct_view")) o = &g_opt.sdf_direct_view;
@@ -540,6 +542,7 @@ struct vmd_script_eval_t {
         DevBuf<uint64_t> d_raw_scratch;          // checkpoints of the two-pass decoder
         uint32_t* h_raw_status = nullptr; size_t h_raw_status_cap = 0;
         bool raw_pending = false;                // a device decode is queued behind `ready`: its status words are checked before use
+        uint8_t* ck_mark = nullptr;              // that decode also writes the frames' checkpoints: mark them valid (ck_mark[0 .. nb)) when it succeeded
         DevBuf<float> d_boxes;
         std::vector<float> h_boxes;              // [nb][6]: L, 1/L
         std::vector<vmd_unitcell_t> cells;
@@ -567,6 +570,14 @@ struct vmd_script_eval_t {
         int state = 0;                                   // 1 = [f0, f0 + nb) uploaded (event recorded), 0 = nothing, -1 = not available raw
     };
     RawSlot raw_slots[3];
+    // decoder checkpoints of a file-backed trajectory (raw ring): written by the first evaluation of its frames, used by every later
+    // one - the frames still cross PCIe each time, but no bit stream is walked from its start twice
+    struct CkCache {
+        void* traj_inst = nullptr; size_t frames = 0, atoms = 0;
+        DevBuf<vmd_xtc_ck_t> ck;
+        DevBuf<uint32_t> nck;
+        std::vector<uint8_t> have;
+    } ck_cache;
     hipStream_t decode_stream = nullptr;
     hipStream_t copy_stream = nullptr;
     hipStream_t aux_stream = nullptr;        // background work nothing else queues behind (the clearing DMA of a volume's host view)
@@ -1213,7 +1224,9 @@ struct BatchSrc {
 // with the batch's `ready` event and are looked at when the batch is about to be used (settle_stage).  Returns 1 when the decode
 // is queued into st.d, 0 when the batch has to go through load_frame (a frame is not available raw), -1 on error.
 static int launch_raw_decode(vmd_script_eval_t* e, Stage& st, const unsigned char* d_raw, const vmd_xtc_frame_t* d_info, size_t num_atoms,
-                             size_t nb, size_t npad, hipStream_t stream) {
+                             size_t nb, size_t npad, hipStream_t stream, vmd_xtc_ck_t* ck = nullptr, uint32_t* nck = nullptr,
+                             uint8_t* ck_have = nullptr) {
+    st.ck_mark = nullptr;
     if (nb > st.h_raw_status_cap) {
         if (st.h_raw_status) (void)hipHostFree(st.h_raw_status);
         st.h_raw_status = nullptr; st.h_raw_status_cap = 0;
@@ -1231,6 +1244,12 @@ static int launch_raw_decode(vmd_script_eval_t* e, Stage& st, const unsigned cha
                                         st.d_raw_status.p, chunk, st.d_raw_scratch.p);
     } else if (mode == 1) {
         rc = vmd_hip_xtc_decode(stream, d_raw, d_info, (int)nb, (int)num_atoms, st.d.p, 3 * npad, npad, st.d_raw_status.p);
+    } else if (ck && nck && ck_have && g_opt.xtc_checkpoints.load()) {
+        bool all = true;
+        for (size_t b = 0; b < nb; ++b) all = all && ck_have[b] != 0;
+        // every frame of the batch has been decoded before: sections from its checkpoints; otherwise decode and leave checkpoints
+        rc = vmd_hip_xtc_decode_wave_ck(stream, d_raw, d_info, (int)nb, (int)num_atoms, st.d.p, 3 * npad, npad, st.d_raw_status.p, all ? 1 : 0, ck, nck);
+        if (!all) st.ck_mark = ck_have;
     } else {
         rc = vmd_hip_xtc_decode_wave(stream, d_raw, d_info, (int)nb, (int)num_atoms, st.d.p, 3 * npad, npad, st.d_raw_status.p);
     }
@@ -1345,7 +1364,8 @@ static bool fetch_stage(vmd_script_eval_t* e, Stage& st, vmd_trajectory_i* traj,
         if (!force_host && traj->raw_device_view && traj->raw_device_view(traj->inst, &rv) && rv.codec == VMD_RAW_CODEC_XTC && rv.device == e->device) {
             // the compressed trajectory is resident in HBM: no host work, no PCIe - decode the batch where it lies
             for (size_t b = 0; b < nb; ++b) st.cells[b] = rv.cells[f0 + b];
-            raw = launch_raw_decode(e, st, rv.base, (const vmd_xtc_frame_t*)rv.info + f0, num_atoms, nb, npad, ss);
+            raw = launch_raw_decode(e, st, rv.base, (const vmd_xtc_frame_t*)rv.info + f0, num_atoms, nb, npad, ss,
+                                    rv.ck ? (vmd_xtc_ck_t*)rv.ck + f0 * VMD_XTC_CK_MAX : nullptr, rv.nck ? rv.nck + f0 : nullptr, rv.ck_have ? rv.ck_have + f0 : nullptr);
             if (raw < 0) return false;
         } else if (!force_host && g_opt.xtc_device_decode.load() && traj->load_raw) {
             // the bit streams were (or are now) sent ahead through a slot of the ring; decompression runs on its own stream
@@ -1355,7 +1375,14 @@ static bool fetch_stage(vmd_script_eval_t* e, Stage& st, vmd_trajectory_i* traj,
                 ss = e->decode_stream;
                 st.cells = rs->cells;
                 HIP_OK(hipStreamWaitEvent(ss, rs->uploaded, 0));
-                raw = launch_raw_decode(e, st, rs->d.p, rs->d_info.p, num_atoms, nb, npad, ss);
+                vmd_script_eval_t::CkCache& cc = e->ck_cache;
+                const size_t F = traj->num_frames(traj->inst);
+                if (cc.traj_inst != traj->inst || cc.frames != F || cc.atoms != num_atoms) {         // another trajectory: start over
+                    cc.traj_inst = traj->inst; cc.frames = F; cc.atoms = num_atoms;
+                    cc.have.assign(F, 0);
+                    if (!cc.ck.ensure(std::max<size_t>(F, 1) * VMD_XTC_CK_MAX) || !cc.nck.ensure(std::max<size_t>(F, 1))) return false;
+                }
+                raw = launch_raw_decode(e, st, rs->d.p, rs->d_info.p, num_atoms, nb, npad, ss, cc.ck.p + f0 * VMD_XTC_CK_MAX, cc.nck.p + f0, cc.have.data() + f0);
                 if (raw < 0) return false;
             } else {
                 raw = 0;
@@ -1443,7 +1470,13 @@ static bool settle_stage(vmd_script_eval_t* e, Stage& st, vmd_trajectory_i* traj
     st.raw_pending = false;
     bool good = true;
     for (size_t b = 0; b < st.nb; ++b) if (st.h_raw_status[b] != 0) good = false;
-    if (good) { e->frames_device_decoded += st.nb; return true; }
+    if (good) {
+        if (st.ck_mark) for (size_t b = 0; b < st.nb; ++b) st.ck_mark[b] = 1;
+        st.ck_mark = nullptr;
+        e->frames_device_decoded += st.nb;
+        return true;
+    }
+    st.ck_mark = nullptr;
     return fetch_stage(e, st, traj, nullptr, num_atoms, st.f0, st.nb, true);
 }
 
@@ -2231,6 +2264,9 @@ struct vmd_rawtraj_t {
     int device = 0;
     unsigned char* d_raw = nullptr;
     vmd_xtc_frame_t* d_info = nullptr;
+    vmd_xtc_ck_t* d_ck = nullptr;        // decoder checkpoints, filled by the first evaluation of each frame
+    uint32_t* d_nck = nullptr;
+    std::vector<uint8_t> ck_have;
     std::vector<vmd_unitcell_t> cells;
     vmd_trajectory_i iface;
 };
@@ -2247,6 +2283,7 @@ static bool rt_load_raw(void* inst, int64_t idx, vmd_frame_header_t* hdr, vmd_ra
 static bool rt_raw_device_view(void* inst, vmd_raw_device_view_t* out) {
     vmd_rawtraj_t* t = (vmd_rawtraj_t*)inst;
     out->base = t->d_raw; out->info = t->d_info; out->cells = t->cells.data(); out->codec = VMD_RAW_CODEC_XTC; out->device = t->device;
+    out->ck = t->d_ck; out->nck = t->d_nck; out->ck_have = t->d_ck ? t->ck_have.data() : nullptr;
     return true;
 }
 
@@ -2254,6 +2291,8 @@ extern "C" void vmd_rawtraj_free(vmd_rawtraj_t* t) {
     if (!t) return;
     if (t->d_raw) (void)hipFree(t->d_raw);
     if (t->d_info) (void)hipFree(t->d_info);
+    if (t->d_ck) (void)hipFree(t->d_ck);
+    if (t->d_nck) (void)hipFree(t->d_nck);
     delete t;
 }
 
@@ -2287,6 +2326,9 @@ extern "C" vmd_rawtraj_t* vmd_rawtraj_create(vmd_trajectory_i* src) {
     t->bytes = total;
     hipError_t err = hipMalloc((void**)&t->d_raw, std::max<size_t>(total, 64));
     if (err == hipSuccess) err = hipMalloc((void**)&t->d_info, std::max<size_t>(F, 1) * sizeof(vmd_xtc_frame_t));
+    if (err == hipSuccess) err = hipMalloc((void**)&t->d_ck, std::max<size_t>(F, 1) * VMD_XTC_CK_MAX * sizeof(vmd_xtc_ck_t));
+    if (err == hipSuccess) err = hipMalloc((void**)&t->d_nck, std::max<size_t>(F, 1) * sizeof(uint32_t));
+    t->ck_have.assign(F, 0);
     if (err != hipSuccess) { vmd_fail("vmd_rawtraj_create: hipMalloc(%zu) failed: %s", total, hipGetErrorString(err)); return nullptr; }
     if (F && hipMemcpy(t->d_info, info.data(), F * sizeof(vmd_xtc_frame_t), hipMemcpyHostToDevice) != hipSuccess) { vmd_fail("vmd_rawtraj_create: upload failed"); return nullptr; }
     // upload in pinned pieces of <= 256 MB, each filled by the load threads

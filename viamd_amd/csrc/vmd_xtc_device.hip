@@ -437,17 +437,32 @@ struct XtcBank { uint32_t r[XTC_BANK]; };   // 64-dword blocks of the stream, on
 
 // at most 80 VGPRs: one of these waves then fits on a SIMD next to six waves of the pair kernel (72 VGPRs each) - the decode of batch
 // k + 1 is meant to run UNDER the pair kernel of batch k, not after it
+// Checkpoints (vmd_xtc_ck_t: the decoder state at a tile boundary).  A stream can only be entered where that state is known, and
+// the first pass over a frame has to walk it from bit 0 - but it can leave breadcrumbs: with `ck_out` the wave that walks the frame
+// drops the state at every ck_tiles-th tile boundary.  A later pass over the same frame (VIAMD re-evaluates a loaded trajectory
+// after every script edit; mdlib keeps a frame-offset cache per file for the same reason) is given them as `ck_in` and splits the
+// frame into SECTIONS: wave y walks and decodes sections y, y + gridDim.y, ... - no walk is repeated, and a frame occupies as many
+// SIMDs as it has sections instead of one.
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_xtc_wave(const unsigned char* __restrict__ raw, const vmd_xtc_frame_t* __restrict__ info,
                                                  int B, int natoms, float* __restrict__ xyz, size_t frame_stride, size_t row_stride,
-                                                 uint32_t* __restrict__ status) {
+                                                 uint32_t* __restrict__ status, const vmd_xtc_ck_t* __restrict__ ck_in,
+                                                 vmd_xtc_ck_t* __restrict__ ck_out, uint32_t* __restrict__ nck, int ck_max, int ck_tiles) {
     // a serial walk issues one dependent instruction every few cycles: next to the VALU-bound waves of the pair kernel it would get a
     // seventh of the SIMD's issue slots and crawl.  At the highest wave priority it takes the slots it can use (a fifth of them) first.
     VMD_XTC_SETPRIO();
     const int f = blockIdx.x;
-    const int nshare = (int)gridDim.y;
-    int turn = (int)blockIdx.y;                                   // tiles until this wave's next one
+    const bool sectioned = ck_in != nullptr;
+    const int nshare = sectioned ? 1 : (int)gridDim.y;
+    int turn = sectioned ? 0 : (int)blockIdx.y;                   // tiles until this wave's next one
     const int lane = (int)threadIdx.x;
     if (f >= B) return;
+    const int nsec = sectioned ? (int)nck[f] : 1;
+    if (sectioned && ((int)blockIdx.y >= nsec || nsec > ck_max)) {
+        if (nsec < 1 || nsec > ck_max) { if (lane == 0) atomicMax(&status[f], 1u); }      // a frame without checkpoints: the caller's bug
+        return;
+    }
+    const bool emit = ck_out != nullptr && !sectioned && blockIdx.y == 0;
+    uint32_t tile_no = 0, emitted = 0;
     const vmd_xtc_frame_t fi = info[f];
     FrameSetup fs;
     uint32_t st = xtc_setup(fi, fs);
@@ -476,6 +491,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
     uint32_t epoch = 0;                                           // first dword of the bank the walk is in
     uint32_t pos = 0;                                             // uniform walk state: next group's first bit, its first atom, ...
     int i = 0, smallidx = fi.smallidx, run = 0;
+    int end_i = natoms;                                           // where this wave's walk ends (the next section's first atom)
     int g = 0;                                                    // groups waiting in the lanes
     uint32_t vpos = 0, vstate = (uint32_t)XTC_FIRSTIDX;           // per lane: the group this lane will decode
     int vatom = 0;
@@ -486,8 +502,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
 #pragma unroll
         for (int k = 0; k < XTC_BANK; ++k) nxt.r[k] = load_block(epoch + 64u * (uint32_t)XTC_BANK + 64u * (uint32_t)k);
         for (;;) {
-            const bool finished = i >= natoms || st != 0;
+            const bool finished = i >= end_i || st != 0;
+            if (g == 0 && emit && !finished && tile_no % (uint32_t)ck_tiles == 0u && emitted < (uint32_t)ck_max) {
+                // a tile starts here: (pos, i, smallidx, run) is everything a decoder needs to enter the stream at this bit
+                if (lane == 0) {
+                    vmd_xtc_ck_t c;
+                    c.pos = pos; c.atom = (uint32_t)i; c.state = (uint32_t)smallidx | ((uint32_t)run << 8); c.reserved = 0;
+                    ck_out[(size_t)f * ck_max + emitted] = c;
+                }
+                emitted += 1;
+            }
             if (g == 64 || (finished && g > 0)) {
+                tile_no += 1;
                 const bool mine = turn == 0;
                 turn = mine ? nshare - 1 : turn - 1;
                 if (mine) {
@@ -512,7 +538,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
                 }
                 g = 0;
             }
-            if (i >= natoms || st != 0) { done = true; return; }
+            if (i >= end_i || st != 0) { done = true; return; }
             const uint32_t blk = ((pos >> 5) - epoch) >> 6;       // the window is blocks blk, blk + 1 of this epoch
             if (blk >= (uint32_t)XTC_BANK) return;                // the walk has left the bank
             const uint32_t base = epoch + 64u * blk;
@@ -539,7 +565,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
             const uint32_t sh = P & 31u;
             const uint32_t code = (uint32_t)(((((uint64_t)d0 << 32) | (uint64_t)d1) << sh) >> 58);   // flag + run code
             // why the speculation ends at this lane: 3 = past the last atom, 2 = outside the window, 1 = flag set
-            const uint32_t reason = (i + lane * per >= natoms) ? 3u : (q1 >= 128u) ? 2u : (code >> 5);
+            const uint32_t reason = (i + lane * per >= end_i) ? 3u : (q1 >= 128u) ? 2u : (code >> 5);
             const unsigned long long stop = VMD_XTC_BALLOT(reason != 0u);
             const int n0 = stop ? __builtin_ctzll(stop) : 64;     // groups with flag 0 in front of it
             const int room = 64 - g;
@@ -570,21 +596,34 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
                 smallidx += is_smaller - 1;
                 if (smallidx <= XTC_FIRSTIDX - 1 || smallidx >= XTC_LASTIDX) st = 1;
             }
-            if (i > natoms || pos > nbits || ntake == 0) st = 1;  // a group past the last atom / the last bit (ntake == 0: cannot happen)
+            if (i > end_i || pos > nbits || ntake == 0) st = 1;   // a group past the last atom (or into the next section) / the last bit
         }
     };
 
     XtcBank bank_a, bank_b;
+    for (int sec = sectioned ? (int)blockIdx.y : 0; sec < nsec; sec += sectioned ? (int)gridDim.y : 1) {
+        if (sectioned) {
+            const vmd_xtc_ck_t c = ck_in[(size_t)f * ck_max + sec];
+            pos = c.pos; i = (int)c.atom; smallidx = (int)(c.state & 255u); run = (int)(c.state >> 8);
+            end_i = sec + 1 < nsec ? (int)ck_in[(size_t)f * ck_max + sec + 1].atom : natoms;
+            // a checkpoint table that does not belong to this frame must not take the walk anywhere it cannot go
+            if (pos > nbits || i < 0 || i >= natoms || end_i <= i || end_i > natoms || smallidx < XTC_FIRSTIDX || smallidx >= XTC_LASTIDX || run > 30 || run % 3) { st = 1; break; }
+            g = 0; done = false;
+        }
+        epoch = ((pos >> 5) / (64u * (uint32_t)XTC_BANK)) * (64u * (uint32_t)XTC_BANK);
 #pragma unroll
-    for (int k = 0; k < XTC_BANK; ++k) { bank_a.r[k] = load_block(64u * (uint32_t)k); bank_b.r[k] = 0; }
-    for (;;) {
-        run_epoch(bank_a, bank_b);
-        if (done) break;
-        epoch += 64u * (uint32_t)XTC_BANK;
-        run_epoch(bank_b, bank_a);
-        if (done) break;
-        epoch += 64u * (uint32_t)XTC_BANK;
+        for (int k = 0; k < XTC_BANK; ++k) { bank_a.r[k] = load_block(epoch + 64u * (uint32_t)k); bank_b.r[k] = 0; }
+        for (;;) {
+            run_epoch(bank_a, bank_b);
+            if (done) break;
+            epoch += 64u * (uint32_t)XTC_BANK;
+            run_epoch(bank_b, bank_a);
+            if (done) break;
+            epoch += 64u * (uint32_t)XTC_BANK;
+        }
+        if (st) break;
     }
+    if (emit && lane == 0) nck[f] = st ? 0u : emitted;
     if (st && lane == 0) atomicMax(&status[f], st);
 }
 
@@ -627,11 +666,18 @@ extern "C" int vmd_hip_xtc_decode(void* stream, const unsigned char* raw, const 
 static int g_xtc_waves = 0;     // waves per frame of k_xtc_wave; 0 = automatic (see vmd_hip_xtc_decode_wave)
 extern "C" int vmd_hip_set_xtc_waves(int n) { const int old = g_xtc_waves; g_xtc_waves = n < 0 ? 0 : (n > 64 ? 64 : n); return old; }
 
-extern "C" int vmd_hip_xtc_decode_wave(void* stream, const unsigned char* raw, const vmd_xtc_frame_t* info, int B, int natoms,
-                                       float* xyz, size_t frame_stride, size_t row_stride, uint32_t* status) {
+// mode 0: plain; 1: emit checkpoints while decoding (ck, nck: out); 2: decode in sections from checkpoints (ck, nck: in);
+// 3: walk only and emit checkpoints (xyz may be NULL)
+static int xtc_launch_wave(void* stream, const unsigned char* raw, const vmd_xtc_frame_t* info, int B, int natoms, float* xyz,
+                           size_t frame_stride, size_t row_stride, uint32_t* status, int mode, vmd_xtc_ck_t* ck, uint32_t* nck) {
     if (B <= 0) return 0;
     int share = g_xtc_waves;
-    if (share <= 0) {
+    if (mode == 2) {
+        // sections are independent: up to VMD_XTC_CK_MAX waves per frame, as many as fill the chip a few times over
+        share = (8192 + B - 1) / B;
+        if (share > VMD_XTC_CK_MAX) share = VMD_XTC_CK_MAX;
+        if (share < 1) share = 1;
+    } else if (share <= 0) {
         // measured (profiles/r03_xtc_device_decode.txt): every sharing wave repeats the walk, so sharing pays only while SIMDs would
         // otherwise idle - 8 waves per frame for a batch of 128, 2 for 1 024, 1 from 2 048 frames on (2 waves per SIMD of the chip)
         share = (2048 + B / 2) / B;
@@ -641,7 +687,22 @@ extern "C" int vmd_hip_xtc_decode_wave(void* stream, const unsigned char* raw, c
         if (share < 1) share = 1;
     }
     if (hipMemsetAsync(status, 0, (size_t)B * sizeof(uint32_t), (hipStream_t)stream) != hipSuccess) return 1;
-    hipLaunchKernelGGL(k_xtc_wave, dim3((unsigned)B, (unsigned)share), dim3(64), 0, (hipStream_t)stream, raw, info, B, natoms, xyz,
-                       frame_stride, row_stride, status);
+    // a frame has at most natoms / 64 + 1 tiles of 64 groups: a checkpoint every ck_tiles-th of them gives <= VMD_XTC_CK_MAX sections
+    const int ck_tiles = (natoms / 64 + 1 + VMD_XTC_CK_MAX - 1) / VMD_XTC_CK_MAX;
+    hipLaunchKernelGGL(k_xtc_wave, dim3((unsigned)B, (unsigned)share), dim3(64), 0, (hipStream_t)stream, raw, info, B, natoms, xyz, frame_stride,
+                       row_stride, status, mode == 2 ? (const vmd_xtc_ck_t*)ck : (const vmd_xtc_ck_t*)nullptr,
+                       (mode == 1 || mode == 3) ? ck : (vmd_xtc_ck_t*)nullptr, nck, VMD_XTC_CK_MAX, ck_tiles < 1 ? 1 : ck_tiles);
     return (int)hipGetLastError();
+}
+
+extern "C" int vmd_hip_xtc_decode_wave(void* stream, const unsigned char* raw, const vmd_xtc_frame_t* info, int B, int natoms,
+                                       float* xyz, size_t frame_stride, size_t row_stride, uint32_t* status) {
+    return xtc_launch_wave(stream, raw, info, B, natoms, xyz, frame_stride, row_stride, status, 0, nullptr, nullptr);
+}
+
+extern "C" int vmd_hip_xtc_decode_wave_ck(void* stream, const unsigned char* raw, const vmd_xtc_frame_t* info, int B, int natoms,
+                                          float* xyz, size_t frame_stride, size_t row_stride, uint32_t* status, int use,
+                                          vmd_xtc_ck_t* ck, uint32_t* nck) {
+    if (!ck || !nck) return (int)hipErrorInvalidValue;
+    return xtc_launch_wave(stream, raw, info, B, natoms, xyz, frame_stride, row_stride, status, use ? 2 : 1, ck, nck);
 }
