@@ -462,7 +462,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
         return;
     }
     const bool emit = ck_out != nullptr && !sectioned && blockIdx.y == 0;
-    uint32_t tile_no = 0, emitted = 0;
+    uint32_t tile_no = 0, emitted = 0, next_ck_tile = 0;
     const vmd_xtc_frame_t fi = info[f];
     FrameSetup fs;
     uint32_t st = xtc_setup(fi, fs);
@@ -503,15 +503,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
         for (int k = 0; k < XTC_BANK; ++k) nxt.r[k] = load_block(epoch + 64u * (uint32_t)XTC_BANK + 64u * (uint32_t)k);
         for (;;) {
             const bool finished = i >= end_i || st != 0;
-            if (g == 0 && emit && !finished && tile_no % (uint32_t)ck_tiles == 0u && emitted < (uint32_t)ck_max) {
-                // a tile starts here: (pos, i, smallidx, run) is everything a decoder needs to enter the stream at this bit
-                if (lane == 0) {
-                    vmd_xtc_ck_t c;
-                    c.pos = pos; c.atom = (uint32_t)i; c.state = (uint32_t)smallidx | ((uint32_t)run << 8); c.reserved = 0;
-                    ck_out[(size_t)f * ck_max + emitted] = c;
-                }
-                emitted += 1;
-            }
             if (g == 64 || (finished && g > 0)) {
                 tile_no += 1;
                 const bool mine = turn == 0;
@@ -539,6 +530,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
                 g = 0;
             }
             if (i >= end_i || st != 0) { done = true; return; }
+            if (emit && g == 0 && tile_no == next_ck_tile && emitted < (uint32_t)ck_max) {
+                // a tile starts here: (pos, i, smallidx, run) is everything a decoder needs to enter the stream at this bit
+                if (lane == 0) {
+                    vmd_xtc_ck_t c;
+                    c.pos = pos; c.atom = (uint32_t)i; c.state = (uint32_t)smallidx | ((uint32_t)run << 8); c.reserved = 0;
+                    ck_out[(size_t)f * ck_max + emitted] = c;
+                }
+                emitted += 1;
+                next_ck_tile += (uint32_t)ck_tiles;
+            }
             const uint32_t blk = ((pos >> 5) - epoch) >> 6;       // the window is blocks blk, blk + 1 of this epoch
             if (blk >= (uint32_t)XTC_BANK) return;                // the walk has left the bank
             const uint32_t base = epoch + 64u * blk;
