@@ -1796,15 +1796,19 @@ static bool process_range(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
     size_t Bmax = auto_batch(e, num_atoms, !have_view);
     const vmd_device_view_t* vw = have_view ? &view : nullptr;
     // host trajectories are staged in smaller batches so that load_frame of batch k+1 overlaps the kernels of batch k
-    // ... except when the batches are decompressed on the device.  k_xtc_wave is a latency-bound chain per frame (a batch of 500
-    // frames takes little longer than one of 64), but at wave priority 3 it runs UNDER the pair kernel of the previous batch once
-    // that kernel's grid leaves it a wave slot per SIMD (rdf_blocks_decode): measured on c2 with rigid water (profiles/
-    // r03_xtc_device_decode.txt) 96.6k frames/s with batches of 512 against 86.3k for one batch of 1 000 (compressed frames resident
-    // in HBM), and 62.7k / 55.5k from the file with batches of 128 / 500; the loosely packed synthetic box, whose walk is five
-    // times longer, is indifferent (66.9k / 69.6k; 38.4k / 42.1k).  So: 4 x stage_frames resident, 2 x from a file.
+    // ... except when the batches are decompressed on the device (profiles/r03_xtc_device_decode.txt).  The FIRST decode of a frame
+    // walks its whole bit stream - a latency-bound chain, 7 ms per batch whether it holds 64 or 1 000 synthetic frames - so first passes
+    // use large batches (4 x stage_frames).  It leaves checkpoints; every later pass decodes in sections at 2 - 3 us per frame, and
+    // then small batches win from a file (the PCIe trip of batch k + 1 hides under decode + pair kernel of batch k: 64.6k frames/s
+    // with batches of 128 against 51.3k with 512) and one large batch from HBM (103.8k against 98.8k).
     if (!have_view && g_opt.batch_frames <= 0) {
         const size_t S = (size_t)std::max(1, g_opt.stage_frames.load());
-        Bmax = std::min<size_t>(Bmax, device_decode ? (raw_ring ? 2 * S : 4 * S) : S);
+        bool warm = false;                                  // does the first frame of the range have checkpoints already?
+        if (device_decode && g_opt.xtc_checkpoints.load() && frame_beg < frame_end) {
+            if (raw_ring) warm = e->ck_cache.traj_inst == traj->inst && e->ck_cache.have.size() > frame_beg && e->ck_cache.have[frame_beg];
+            else warm = rv_probe.ck_have && rv_probe.ck_have[frame_beg];
+        }
+        Bmax = std::min<size_t>(Bmax, !device_decode ? S : (raw_ring ? (warm ? S : 4 * S) : (warm ? 8 * S : 4 * S)));
     }
     std::vector<Batch> batches;
     for (auto& sg : segments) plan_batches(e, sg.first, sg.second, Bmax, &batches);
