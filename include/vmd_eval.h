@@ -373,8 +373,10 @@ bool   vmd_eval_set_block_frames(vmd_script_eval_t* eval, size_t block_frames);
 bool   vmd_eval_set_source(vmd_script_eval_t* eval, vmd_script_eval_t* source);
 /* frames evaluated by kernels / frames served from block partials since the last clear_data */
 void   vmd_eval_frame_stats(const vmd_script_eval_t* eval, size_t* frames_computed, size_t* frames_reused);
-/* frames whose coordinates were decompressed on the device (load_raw + k_xtc_decode) since the last clear_data */
+/* frames whose coordinates were decompressed on the device (load_raw + k_xtc_wave) since the last clear_data, and how many of them
+ * from decoder checkpoints (in sections, no walk from bit 0: the trajectory's frames had been decoded before - by any eval) */
 size_t vmd_eval_frames_device_decoded(const vmd_script_eval_t* eval);
+size_t vmd_eval_frames_section_decoded(const vmd_script_eval_t* eval);
 
 /* ---- device-resident trajectories (pre-staged in HBM) ---------------------------------- */
 typedef struct vmd_devtraj_t vmd_devtraj_t;

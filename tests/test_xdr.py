@@ -426,7 +426,15 @@ def test_xtc_batches_decoded_on_the_device_through_the_evaluator(tmp_path, emu_l
                     ev.clear_data()
                     assert ev.frame_range(sysm, xt, 0, 5) and ev.frame_range(sysm, xt, 5, F)
                     np.testing.assert_array_equal(ev.property_data("g").counts, res[mode])
-                    assert ev.frames_device_decoded() == F
+                    assert ev.frames_device_decoded() == F and ev.frames_section_decoded() == F
+                    # VIAMD creates a NEW eval for every script edit (src/main.cpp:966-972): the checkpoints belong to the trajectory,
+                    # not to the eval, so a fresh eval decodes in sections right away; a different file (another trajectory object,
+                    # whatever its address) starts from bit 0 again
+                    ev3 = V.ScriptEval(F, ir)
+                    assert ev3.frame_range(sysm, xt, 0, F) and ev3.frames_section_decoded() == F
+                    np.testing.assert_array_equal(ev3.property_data("g").counts, res[mode])
+                    ev4 = V.ScriptEval(F, ir)
+                    assert ev4.frame_range(sysm, V.XdrTrajectory(p, lib=emu_lib), 0, F) and ev4.frames_section_decoded() == 0
                 if mode:
                     ev2 = V.ScriptEval(F, ir)
                     assert ev2.frame_range(sysm, V.XdrTrajectory(q, lib=emu_lib), 0, F)

@@ -175,6 +175,7 @@ SIGNATURES = [
     ("vmd_eval_set_source", C.c_bool, [_vp, _vp]),
     ("vmd_eval_frame_stats", None, [_vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     ("vmd_eval_frames_device_decoded", C.c_size_t, [_vp]),
+    ("vmd_eval_frames_section_decoded", C.c_size_t, [_vp]),
     ("vmd_devtraj_create", _vp, [C.c_size_t, C.c_size_t]),
     ("vmd_devtraj_create_shard", _vp, [C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t]),
     ("vmd_devtraj_free", None, [_vp]),

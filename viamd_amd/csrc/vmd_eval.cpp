@@ -502,6 +502,53 @@ struct PropState {
     bool counts_stale = false;          // volume: host u64 mirror older than the device accumulators
 };
 
+// Decoder checkpoints of file-backed trajectories (k_xtc_wave), kept per TRAJECTORY for the whole process: VIAMD creates
+// a fresh md_script_eval_t for every script edit (src/main.cpp:966-972), so a cache inside the eval would never be hit by the
+// re-evaluations it exists for.  Keyed by the trajectory's instance pointer; a frame's checkpoints are only used while the frame's
+// signature (stream length, decoder parameters, its first bytes) is the one they were written for - a different file behind a
+// recycled pointer can therefore not be entered at a stale bit position.  vmd_ckcache_drop(inst) forgets a trajectory (the native
+// readers call it when they close).
+struct CkCache {
+    size_t frames = 0, atoms = 0;
+    int device = -1;
+    DevBuf<vmd_xtc_ck_t> ck;
+    DevBuf<uint32_t> nck;
+    std::vector<uint8_t> have;
+    std::vector<uint64_t> sig;
+};
+static std::mutex g_ck_mtx;
+static std::map<const void*, std::shared_ptr<CkCache>> g_ck_store;
+static std::shared_ptr<CkCache> ckcache_for(const void* inst, size_t frames, size_t atoms, int device) {
+    std::lock_guard<std::mutex> l(g_ck_mtx);
+    std::shared_ptr<CkCache>& c = g_ck_store[inst];
+    if (!c || c->frames != frames || c->atoms != atoms || c->device != device) {
+        c = std::make_shared<CkCache>();
+        c->frames = frames; c->atoms = atoms; c->device = device;
+        c->have.assign(frames, 0);
+        c->sig.assign(frames, 0);
+        if (!c->ck.ensure(std::max<size_t>(frames, 1) * VMD_XTC_CK_MAX) || !c->nck.ensure(std::max<size_t>(frames, 1))) { g_ck_store.erase(inst); return nullptr; }
+        if (g_ck_store.size() > 16) {                       // a handful of open trajectories at most: forget the others
+            for (auto it = g_ck_store.begin(); it != g_ck_store.end();) it = it->first == inst ? std::next(it) : g_ck_store.erase(it);
+        }
+    }
+    return c;
+}
+extern "C" void vmd_ckcache_drop(const void* inst) {
+    std::lock_guard<std::mutex> l(g_ck_mtx);
+    g_ck_store.erase(inst);
+}
+static uint64_t frame_signature(const vmd_xtc_frame_t& fi, const unsigned char* bytes) {
+    uint64_t h = 0x9E3779B97F4A7C15ull ^ fi.nbytes;
+    auto mix = [&](uint64_t v) { h ^= v + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2); };
+    uint32_t p; memcpy(&p, &fi.precision, 4);
+    mix(p); mix((uint32_t)fi.smallidx);
+    for (int k = 0; k < 3; ++k) { mix((uint32_t)fi.minint[k]); mix((uint32_t)fi.maxint[k]); }
+    const size_t n = fi.nbytes < 64 ? (size_t)fi.nbytes : 64;
+    for (size_t i = 0; i + 8 <= n; i += 8) { uint64_t w; memcpy(&w, bytes + i, 8); mix(w); }
+    if (fi.nbytes >= 72) { uint64_t w; memcpy(&w, bytes + fi.nbytes - 8, 8); mix(w); }
+    return h | 1ull;
+}
+
 // one pending vmd_eval_frame_range call (lives on the caller's stack)
 struct RangeRequest {
     uint32_t beg = 0, end = 0;
@@ -542,6 +589,7 @@ struct vmd_script_eval_t {
         DevBuf<uint64_t> d_raw_scratch;          // checkpoints of the two-pass decoder
         uint32_t* h_raw_status = nullptr; size_t h_raw_status_cap = 0;
         bool raw_pending = false;                // a device decode is queued behind `ready`: its status words are checked before use
+        bool sectioned = false;                  // that decode ran from checkpoints (sections), not from bit 0
         uint8_t* ck_mark = nullptr;              // that decode also writes the frames' checkpoints: mark them valid (ck_mark[0 .. nb)) when it succeeded
         DevBuf<float> d_boxes;
         std::vector<float> h_boxes;              // [nb][6]: L, 1/L
@@ -570,14 +618,8 @@ struct vmd_script_eval_t {
         int state = 0;                                   // 1 = [f0, f0 + nb) uploaded (event recorded), 0 = nothing, -1 = not available raw
     };
     RawSlot raw_slots[3];
-    // decoder checkpoints of a file-backed trajectory (raw ring): written by the first evaluation of its frames, used by every later
-    // one - the frames still cross PCIe each time, but no bit stream is walked from its start twice
-    struct CkCache {
-        void* traj_inst = nullptr; size_t frames = 0, atoms = 0;
-        DevBuf<vmd_xtc_ck_t> ck;
-        DevBuf<uint32_t> nck;
-        std::vector<uint8_t> have;
-    } ck_cache;
+    std::shared_ptr<CkCache> ck_cache;       // the decoder checkpoints of the trajectory being evaluated (process-wide store)
+    std::atomic<size_t> frames_section_decoded{0};
     hipStream_t decode_stream = nullptr;
     hipStream_t copy_stream = nullptr;
     hipStream_t aux_stream = nullptr;        // background work nothing else queues behind (the clearing DMA of a volume's host view)
@@ -837,7 +879,7 @@ extern "C" void vmd_eval_clear_data(vmd_script_eval_t* eval) {
     eval->interrupt = false;
     std::fill(eval->frame_mask.begin(), eval->frame_mask.end(), (uint8_t)0);
     eval->frames_done = 0;
-    eval->frames_computed = 0; eval->frames_reused = 0; eval->frames_device_decoded = 0;
+    eval->frames_computed = 0; eval->frames_reused = 0; eval->frames_device_decoded = 0; eval->frames_section_decoded = 0;
     for (size_t b = 0; b < eval->num_blocks; ++b) eval->block_ready[b] = 0;
     for (auto& p : eval->props) {
         // the 8.4 MB float view of a volume is pinned: the copy engine zeroes it from a zero buffer in HBM, in the background -
@@ -1043,6 +1085,7 @@ extern "C" bool vmd_eval_set_source(vmd_script_eval_t* eval, vmd_script_eval_t* 
 }
 
 extern "C" size_t vmd_eval_frames_device_decoded(const vmd_script_eval_t* eval) { return eval ? eval->frames_device_decoded.load() : 0; }
+extern "C" size_t vmd_eval_frames_section_decoded(const vmd_script_eval_t* eval) { return eval ? eval->frames_section_decoded.load() : 0; }
 
 extern "C" void vmd_eval_frame_stats(const vmd_script_eval_t* eval, size_t* frames_computed, size_t* frames_reused) {
     if (frames_computed) *frames_computed = eval ? eval->frames_computed.load() : 0;
@@ -1227,6 +1270,7 @@ static int launch_raw_decode(vmd_script_eval_t* e, Stage& st, const unsigned cha
                              size_t nb, size_t npad, hipStream_t stream, vmd_xtc_ck_t* ck = nullptr, uint32_t* nck = nullptr,
                              uint8_t* ck_have = nullptr) {
     st.ck_mark = nullptr;
+    st.sectioned = false;
     if (nb > st.h_raw_status_cap) {
         if (st.h_raw_status) (void)hipHostFree(st.h_raw_status);
         st.h_raw_status = nullptr; st.h_raw_status_cap = 0;
@@ -1250,6 +1294,7 @@ static int launch_raw_decode(vmd_script_eval_t* e, Stage& st, const unsigned cha
         // every frame of the batch has been decoded before: sections from its checkpoints; otherwise decode and leave checkpoints
         rc = vmd_hip_xtc_decode_wave_ck(stream, d_raw, d_info, (int)nb, (int)num_atoms, st.d.p, 3 * npad, npad, st.d_raw_status.p, all ? 1 : 0, ck, nck);
         if (!all) st.ck_mark = ck_have;
+        st.sectioned = all;
     } else {
         rc = vmd_hip_xtc_decode_wave(stream, d_raw, d_info, (int)nb, (int)num_atoms, st.d.p, 3 * npad, npad, st.d_raw_status.p);
     }
@@ -1375,14 +1420,18 @@ static bool fetch_stage(vmd_script_eval_t* e, Stage& st, vmd_trajectory_i* traj,
                 ss = e->decode_stream;
                 st.cells = rs->cells;
                 HIP_OK(hipStreamWaitEvent(ss, rs->uploaded, 0));
-                vmd_script_eval_t::CkCache& cc = e->ck_cache;
-                const size_t F = traj->num_frames(traj->inst);
-                if (cc.traj_inst != traj->inst || cc.frames != F || cc.atoms != num_atoms) {         // another trajectory: start over
-                    cc.traj_inst = traj->inst; cc.frames = F; cc.atoms = num_atoms;
-                    cc.have.assign(F, 0);
-                    if (!cc.ck.ensure(std::max<size_t>(F, 1) * VMD_XTC_CK_MAX) || !cc.nck.ensure(std::max<size_t>(F, 1))) return false;
+                std::shared_ptr<CkCache> cc = ckcache_for(traj->inst, traj->num_frames(traj->inst), num_atoms, e->device);
+                e->ck_cache = cc;
+                if (cc) {
+                    // a frame's checkpoints count only for the very bytes they were written for
+                    for (size_t b = 0; b < nb; ++b) {
+                        const uint64_t sg = frame_signature(rs->info[b], rs->h + rs->info[b].offset);
+                        if (cc->sig[f0 + b] != sg) { cc->sig[f0 + b] = sg; cc->have[f0 + b] = 0; }
+                    }
+                    raw = launch_raw_decode(e, st, rs->d.p, rs->d_info.p, num_atoms, nb, npad, ss, cc->ck.p + f0 * VMD_XTC_CK_MAX, cc->nck.p + f0, cc->have.data() + f0);
+                } else {
+                    raw = launch_raw_decode(e, st, rs->d.p, rs->d_info.p, num_atoms, nb, npad, ss);
                 }
-                raw = launch_raw_decode(e, st, rs->d.p, rs->d_info.p, num_atoms, nb, npad, ss, cc.ck.p + f0 * VMD_XTC_CK_MAX, cc.nck.p + f0, cc.have.data() + f0);
                 if (raw < 0) return false;
             } else {
                 raw = 0;
@@ -1474,6 +1523,7 @@ static bool settle_stage(vmd_script_eval_t* e, Stage& st, vmd_trajectory_i* traj
         if (st.ck_mark) for (size_t b = 0; b < st.nb; ++b) st.ck_mark[b] = 1;
         st.ck_mark = nullptr;
         e->frames_device_decoded += st.nb;
+        if (st.sectioned) e->frames_section_decoded += st.nb;
         return true;
     }
     st.ck_mark = nullptr;
@@ -1805,7 +1855,12 @@ static bool process_range(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
         const size_t S = (size_t)std::max(1, g_opt.stage_frames.load());
         bool warm = false;                                  // does the first frame of the range have checkpoints already?
         if (device_decode && g_opt.xtc_checkpoints.load() && frame_beg < frame_end) {
-            if (raw_ring) warm = e->ck_cache.traj_inst == traj->inst && e->ck_cache.have.size() > frame_beg && e->ck_cache.have[frame_beg];
+            if (raw_ring) {
+                std::lock_guard<std::mutex> l(g_ck_mtx);
+                auto it = g_ck_store.find(traj->inst);
+                warm = it != g_ck_store.end() && it->second && it->second->frames == traj->num_frames(traj->inst) && it->second->atoms == num_atoms &&
+                       it->second->device == e->device && it->second->have.size() > frame_beg && it->second->have[frame_beg];
+            }
             else warm = rv_probe.ck_have && rv_probe.ck_have[frame_beg];
         }
         Bmax = std::min<size_t>(Bmax, !device_decode ? S : (raw_ring ? (warm ? S : 4 * S) : (warm ? 8 * S : 4 * S)));

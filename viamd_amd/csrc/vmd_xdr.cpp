@@ -759,8 +759,10 @@ extern "C" vmd_xdrtraj_t* vmd_xdrtraj_open(const char* path) {
     return t;
 }
 
+extern "C" void vmd_ckcache_drop(const void* inst);      // vmd_eval.cpp: the decoder checkpoints kept for this trajectory
 extern "C" void vmd_xdrtraj_close(vmd_xdrtraj_t* t) {
     if (!t) return;
+    vmd_ckcache_drop(&t->d);
     if (t->d.fd >= 0) close(t->d.fd);
     delete t;
 }

@@ -285,6 +285,10 @@ class ScriptEval:
         """Frames whose coordinates were decompressed on the device (load_raw + k_xtc_decode) since the last clear_data."""
         return int(self.lib.vmd_eval_frames_device_decoded(self.h))
 
+    def frames_section_decoded(self):
+        """... and how many of those were decoded in sections from the trajectory's decoder checkpoints (a re-evaluation)."""
+        return int(self.lib.vmd_eval_frames_section_decoded(self.h))
+
     def num_frames(self):
         return int(self.lib.vmd_eval_num_frames(self.h))
 
