@@ -31,15 +31,24 @@ class RcclComm:
         import torch.distributed as dist
         self.lib = lib
         rank, world = dist.get_rank(group), dist.get_world_size(group)
-        ident = np.zeros(L.COMM_ID_BYTES, np.uint8)
-        if rank == 0 and not lib.vmd_comm_unique_id(ident.ctypes.data_as(L.c_uint8_p)):
-            raise RuntimeError(lib.last_error())
-        t = torch.from_numpy(ident)
+        # 1 flag byte + the 128-byte id.  Rank 0 ALWAYS takes part in the broadcast, also when it could not make an id: a rank that
+        # skipped it would leave the others stuck in a collective of torch's process group, and everything queued behind it with them
+        msg = np.zeros(1 + L.COMM_ID_BYTES, np.uint8)
+        err0 = ""
+        if rank == 0:
+            if lib.vmd_comm_unique_id(msg[1:].ctypes.data_as(L.c_uint8_p)):
+                msg[0] = 1
+            else:
+                err0 = lib.last_error()
+        t = torch.from_numpy(msg)
         on_gpu = dist.get_backend(group) == "nccl"
         if on_gpu:
             t = t.cuda()
         dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-        ident = t.cpu().numpy().copy()
+        msg = t.cpu().numpy().copy()
+        if msg[0] != 1:
+            raise RuntimeError("rank 0 could not create an RCCL id" + (": " + err0 if err0 else ""))
+        ident = np.ascontiguousarray(msg[1:])
         self.h = lib.vmd_comm_create(world, rank, ident.ctypes.data_as(L.c_uint8_p))
         if not self.h:
             raise RuntimeError(lib.last_error())
@@ -116,9 +125,14 @@ def _make_comm(lib, group):
     comm, why = None, ""
     if want != "torch":
         box = {}
+        dev = torch.cuda.current_device()
 
         def make():
             try:
+                # the current device is a property of the host THREAD: without this every rank's helper thread would sit on device 0
+                # and ncclCommInitRank would see eight ranks on one GPU
+                torch.cuda.set_device(dev)
+                lib.vmd_set_device(dev)
                 box["comm"] = RcclComm(lib, group)
             except Exception as e:                     # noqa: BLE001 - whatever went wrong, the job falls back as one
                 box["err"] = repr(e)
