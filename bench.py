@@ -227,7 +227,12 @@ def run_workload(name, args, ctx, steps, warmup, frames=None, with_cpu=False, op
     if args.tilt:
         cell = V.make_unitcell(w["box"], tilt=tuple(float(t) for t in args.tilt.split(",")))
         traj.set_cell(cell, beg, end)
+        if beg > 0:
+            traj.set_cell(cell, 0, 1)           # a shard keeps frame 0 for the SDF reference pose: it lives in the same sheared cell
         w["desc"] += f", sheared cell (tilt {args.tilt})"
+    if strong and world > 1 and args.traj not in ("device", "pinned"):
+        # a file holds the WHOLE trajectory, a strong-scaling shard only this rank's block of it
+        raise SystemExit("--scaling strong with N > 1 needs --traj device or pinned (a trajectory file is written from the whole device trajectory)")
     if args.traj == "pinned":                   # PCIe-inclusive variant: every batch is DMA'd from host memory
         dev_traj = traj
         traj = V.PinnedHostTrajectory(F, w["atoms"])

@@ -54,6 +54,23 @@ def build_emu():
     return out
 
 
+TWIN_LIB = os.path.join(ROOT, "tests", "native", "libviamd_amd_twin.so")
+
+
+def build_twin():
+    """hipcc build of the product sources with -DVMD_NO_INLINE_ASM: the C++ twins the emulator runs, compiled for gfx950.
+    The GPU suite evaluates the same inputs through this library and through the product and compares the accumulators bit for
+    bit (tests/test_zz_late_gpu.py) - that ties the inline-asm blocks to the code the CPU suite covers.  Test-only: it lives
+    under tests/native, never next to the package, and nothing in viamd_amd/ loads it."""
+    from viamd_amd import build as vb
+    deps = vb.SOURCES + vb.HEADERS
+    if os.path.exists(TWIN_LIB) and all(os.path.getmtime(TWIN_LIB) >= os.path.getmtime(s) for s in deps):
+        return TWIN_LIB
+    cmd = [vb.hipcc()] + vb.FLAGS + ["-DVMD_NO_INLINE_ASM", "-I", os.path.join(ROOT, "include"), "-x", "hip"] + vb.SOURCES + ["-ldl", "-o", TWIN_LIB]
+    subprocess.check_call(cmd)
+    return TWIN_LIB
+
+
 @pytest.fixture(scope="session")
 def emu_lib():
     """Kernels + host code compiled for the CPU SIMT emulator: logic checks only, never the product path."""

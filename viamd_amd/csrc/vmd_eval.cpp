@@ -434,6 +434,10 @@ struct Selection {
     bool used_pencil = false;           // the current batch was built through the buckets
     DevBuf<uint32_t> d_pen_off, pen_count, pen_start;
     DevBuf<float> bucket;
+    // capacities measured for other pencil layouts: two RDF groups with different cutoffs on one selection alternate between two
+    // grids in every batch, and re-measuring costs two launches, a readback and a synchronisation each time
+    struct Caps { int ny, nz, cap_max, total_cap; std::vector<uint32_t> pen_off; };
+    std::vector<Caps> caps_cache;
 };
 
 // One launch of the pair kernel and the histograms it feeds.  Co-evaluated RDF properties of the same range are decomposed
@@ -1632,6 +1636,19 @@ static bool choose_grid(const std::vector<float>& boxes, uint32_t pbc, size_t nb
 // lifetime (frames of one trajectory look alike; a bucket that overflows later is caught by the device flag and re-measured).
 static bool ensure_pencil_caps(vmd_script_eval_t* e, Selection* s, const Stage& src, const float* d_boxes, uint32_t pbc, size_t nb, const vmd_grid_t& g) {
     if (!s->pen_off.empty() && s->pen_ny == g.ny && s->pen_nz == g.nz) return true;
+    if (!s->pen_off.empty()) {                 // keep what was measured for the layout we are leaving
+        bool known = false;
+        for (auto& c : s->caps_cache) known = known || (c.ny == s->pen_ny && c.nz == s->pen_nz);
+        if (!known) {
+            if (s->caps_cache.size() >= 4) s->caps_cache.erase(s->caps_cache.begin());
+            s->caps_cache.push_back({s->pen_ny, s->pen_nz, s->cap_max, s->total_cap, s->pen_off});
+        }
+    }
+    for (auto& c : s->caps_cache) {
+        if (c.ny != g.ny || c.nz != g.nz) continue;
+        s->pen_off = c.pen_off; s->cap_max = c.cap_max; s->total_cap = c.total_cap; s->pen_ny = c.ny; s->pen_nz = c.nz;
+        return s->d_pen_off.upload(s->pen_off.data(), s->pen_off.size(), e->stream);      // pageable source: the copy is staged before the call returns
+    }
     const int npen = g.ny * g.nz, nsel = (int)s->idx.size();
     // after an overflow: every frame of the batch (exact populations), otherwise the first and last 4
     const bool exhaustive = s->overflows > 0 || nb <= 8;
@@ -2049,6 +2066,7 @@ static bool process_range(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
                 sl->built = false;
                 if (!sl->used_pencil) continue;
                 sl->pen_off.clear();
+                sl->caps_cache.clear();
                 sl->cap_margin *= 1.6f;
                 sl->overflows += 1;
             }
@@ -2187,6 +2205,10 @@ extern "C" bool vmd_eval_sdf_matrices(vmd_script_eval_t* eval, const char* name,
 
 // ------------------------------------------------------------------------------------------------ device trajectory
 
+static uint64_t next_cells_version() {
+    static std::atomic<uint64_t> counter{1};
+    return counter.fetch_add(1) + 1;
+}
 struct vmd_devtraj_t {
     size_t num_frames = 0, num_atoms = 0, npad = 0;
     size_t first = 0, resident = 0;     // frames [first, first + resident) are in HBM (a rank's shard; the whole trajectory otherwise)
@@ -2196,7 +2218,8 @@ struct vmd_devtraj_t {
     float* frame(size_t f) const { return (d0 && f == 0) ? d0 : d + (f - first) * 3 * npad; }
     int device = 0;
     std::vector<vmd_unitcell_t> cells;
-    uint64_t cells_version = 1;         // bumped by every change of `cells` (vmd_device_view_t::cells_version)
+    uint64_t cells_version = next_cells_version();   // a new process-wide number for every change of `cells` or of the coordinates: two
+                                                     // trajectories (one freed, one created at the same address) never share one
     vmd_trajectory_i iface;
 };
 
@@ -2260,7 +2283,7 @@ extern "C" bool vmd_devtraj_upload_frame(vmd_devtraj_t* t, size_t frame, const v
     HIP_OK(hipMemcpy(f + t->npad, y, t->num_atoms * sizeof(float), hipMemcpyHostToDevice));
     HIP_OK(hipMemcpy(f + 2 * t->npad, z, t->num_atoms * sizeof(float), hipMemcpyHostToDevice));
     if (cell) t->cells[frame] = *cell;
-    t->cells_version += 1;
+    t->cells_version = next_cells_version();
     return true;
 }
 
@@ -2272,7 +2295,7 @@ extern "C" bool vmd_devtraj_upload_atoms(vmd_devtraj_t* t, size_t frame_beg, siz
             HIP_OK(hipMemcpyAsync(t->frame(frame_beg + f) + (size_t)c * t->npad + first_atom,
                                   xyz + (f * 3 + c) * atom_count, atom_count * sizeof(float), hipMemcpyHostToDevice, nullptr));
     HIP_OK(hipDeviceSynchronize());
-    t->cells_version += 1;       // coordinates changed: bounding boxes cached per range (open axes) are stale too
+    t->cells_version = next_cells_version();       // coordinates changed: bounding boxes cached per range (open axes) are stale too
     return true;
 }
 
@@ -2293,14 +2316,14 @@ extern "C" bool vmd_devtraj_synth(vmd_devtraj_t* t, uint64_t seed, float L, floa
     }
     HIP_OK(hipDeviceSynchronize());
     for (size_t f = frame_beg; f < frame_end; ++f) t->cells[f] = c;
-    t->cells_version += 1;
+    t->cells_version = next_cells_version();
     return true;
 }
 
 extern "C" bool vmd_devtraj_set_cell(vmd_devtraj_t* t, size_t frame_beg, size_t frame_end, const vmd_unitcell_t* cell) {
     if (!t || !cell || frame_end > t->num_frames || frame_beg > frame_end) return vmd_fail("vmd_devtraj_set_cell: bad frame range");
     for (size_t f = frame_beg; f < frame_end; ++f) t->cells[f] = *cell;
-    t->cells_version += 1;
+    t->cells_version = next_cells_version();
     return true;
 }
 
