@@ -323,7 +323,8 @@ def run_workload(name, args, ctx, steps, warmup, frames=None, with_cpu=False, op
     local_frames = end - beg
 
     kernel_ms, kernel_launches = {}, {}
-    for k in ("rdf_pencil", "rdf_brute", "cells_build", "sdf_align", "sdf_scatter", "distance", "xtc_decode"):
+    for k in ("rdf_pencil", "rdf_brute", "cells_build", "sdf_align", "sdf_scatter", "distance", "xtc_decode",
+              "host_raw_upload", "host_raw_read", "host_raw_map", "host_refresh", "host_queue_to_sync", "host_settle", "host_fetch_stage", "host_sync_wait"):
         n = C.c_uint64(0)
         ms = lib.vmd_profile_ms(k.encode(), C.byref(n))
         if n.value:

@@ -117,6 +117,17 @@ typedef struct vmd_raw_device_view_t {
     uint8_t*  ck_have;
 } vmd_raw_device_view_t;
 
+/* A trajectory FILE mapped into the address space (read-only).  The evaluator pins the mapping (hipHostRegister, in windows) and the
+ * copy engine reads the compressed frames of a batch straight out of the page cache: no host thread touches the bytes.  Streams sit
+ * where the file has them (XDR: 4-byte aligned). */
+typedef struct vmd_raw_mapped_view_t {
+    const unsigned char* base;      /* host: the mapping, page aligned */
+    size_t bytes;                   /* its length (the file size when it was mapped) */
+    const uint64_t* stream_offset;  /* host, one per frame: where frame i's compressed bytes start, relative to base
+                                     * (their length and decoder parameters: load_raw's info) */
+    uint32_t codec;                 /* VMD_RAW_CODEC_* */
+} vmd_raw_mapped_view_t;
+
 typedef struct vmd_trajectory_i {
     void* inst;
     size_t (*num_frames)(void* inst);
@@ -131,6 +142,8 @@ typedef struct vmd_trajectory_i {
     bool (*load_raw)(void* inst, int64_t idx, vmd_frame_header_t* header, vmd_raw_frame_t* info, void* dst, size_t cap);
     /* extension, may be NULL: the whole trajectory compressed in HBM (see vmd_raw_device_view_t) */
     bool (*raw_device_view)(void* inst, vmd_raw_device_view_t* out);
+    /* extension, may be NULL: the file behind load_raw, mapped (see vmd_raw_mapped_view_t); false = not mappable, use load_raw */
+    bool (*raw_mapped_view)(void* inst, vmd_raw_mapped_view_t* out);
 } vmd_trajectory_i;
 
 /* where the evaluator currently is (a static string, process-wide, last writer wins): for crash handlers and hang reports */
@@ -377,6 +390,8 @@ void   vmd_eval_frame_stats(const vmd_script_eval_t* eval, size_t* frames_comput
  * from decoder checkpoints (in sections, no walk from bit 0: the trajectory's frames had been decoded before - by any eval) */
 size_t vmd_eval_frames_device_decoded(const vmd_script_eval_t* eval);
 size_t vmd_eval_frames_section_decoded(const vmd_script_eval_t* eval);
+/* ... and how many of them reached the device by DMA straight from the mapped file (raw_mapped_view), no host copy */
+size_t vmd_eval_frames_mapped(const vmd_script_eval_t* eval);
 
 /* ---- device-resident trajectories (pre-staged in HBM) ---------------------------------- */
 typedef struct vmd_devtraj_t vmd_devtraj_t;

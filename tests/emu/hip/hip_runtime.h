@@ -131,7 +131,8 @@ static inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
 static inline hipError_t hipHostMalloc(void** p, size_t n, unsigned) { return hipMalloc(p, n); }
 static inline hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
 static inline hipError_t hipHostGetDevicePointer(void** d, void* h, unsigned) { *d = h; return hipSuccess; }
-static inline hipError_t hipHostRegister(void*, size_t, unsigned) { return hipSuccess; }
+// VIAMD_EMU_NO_HOST_REGISTER=1: the driver refuses to pin a file mapping (the evaluator must fall back to the load_raw copy)
+static inline hipError_t hipHostRegister(void*, size_t, unsigned) { return getenv("VIAMD_EMU_NO_HOST_REGISTER") ? hipErrorInvalidValue : hipSuccess; }
 static inline hipError_t hipHostUnregister(void*) { return hipSuccess; }
 static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return hipSuccess; }

@@ -463,3 +463,55 @@ def test_xtc_batches_decoded_on_the_device_through_the_evaluator(tmp_path, emu_l
             V.CompressedDeviceTrajectory(V.XdrTrajectory(q, lib=emu_lib))
     finally:
         emu_lib.vmd_set_option(b"batch_frames", old_b)
+
+
+def test_xtc_batches_leave_the_mapped_file_by_dma(tmp_path, emu_lib, oracle):
+    """The native XTC reader maps its file (raw_mapped_view); the evaluator pins the mapping and the copy engine takes every batch's
+    span of it as it lies in the file - streams on 4-byte boundaries, frame headers in between.  Same histogram as the load_raw copy
+    into a pinned block and as host decoding; the copy stays the fallback when the mapping cannot be pinned or the option is off."""
+    import os
+    import cases
+    box, F, N = 33.0, 11, 1101            # frame sizes of every residue modulo 8: both phases of the 8-byte reader
+    coords = cases.water_box(oracle, 17, N, box, F)
+    cell = V.make_unitcell(box)
+    p = tmp_path / "m.xtc"
+    V.write_xtc(p, coords, cell, lib=emu_lib)
+    o = cases.oxygen(N)
+    ir = V.ScriptIR(emu_lib); ir.add_rdf("g", o, o, 8.0)
+    sysm = V.MolSystem(N, unitcell=cell)
+    old_b = emu_lib.vmd_set_option(b"batch_frames", 4)
+    old_d = emu_lib.vmd_set_option(b"xtc_device_decode", 0)
+    try:
+        ev = V.ScriptEval(F, ir)
+        assert ev.frame_range(sysm, V.XdrTrajectory(p, lib=emu_lib), 0, F)
+        want = ev.property_data("g").counts.copy()
+        assert want.sum() > 0 and ev.frames_mapped() == 0
+        emu_lib.vmd_set_option(b"xtc_device_decode", 3)
+        xt = V.XdrTrajectory(p, lib=emu_lib)
+        for rep in range(2):               # the second evaluation enters every frame at its checkpoints, through the mapping again
+            ev = V.ScriptEval(F, ir)
+            assert ev.frame_range(sysm, xt, 0, 3) and ev.frame_range(sysm, xt, 3, F)
+            np.testing.assert_array_equal(ev.property_data("g").counts, want)
+            assert ev.frames_device_decoded() == F and ev.frames_mapped() == F
+            assert ev.frames_section_decoded() == (F if rep else 0)
+        old_m = emu_lib.vmd_set_option(b"xtc_mapped", 0)
+        try:
+            ev = V.ScriptEval(F, ir)
+            assert ev.frame_range(sysm, xt, 0, F)
+            np.testing.assert_array_equal(ev.property_data("g").counts, want)
+            assert ev.frames_device_decoded() == F and ev.frames_mapped() == 0
+        finally:
+            emu_lib.vmd_set_option(b"xtc_mapped", old_m)
+        # the driver refuses to pin the mapping (emulator switch): the window is marked refused, batches take the copy
+        os.environ["VIAMD_EMU_NO_HOST_REGISTER"] = "1"
+        try:
+            xt2 = V.XdrTrajectory(p, lib=emu_lib)
+            ev = V.ScriptEval(F, ir)
+            assert ev.frame_range(sysm, xt2, 0, F)
+            np.testing.assert_array_equal(ev.property_data("g").counts, want)
+            assert ev.frames_device_decoded() == F and ev.frames_mapped() == 0
+        finally:
+            del os.environ["VIAMD_EMU_NO_HOST_REGISTER"]
+    finally:
+        emu_lib.vmd_set_option(b"xtc_device_decode", old_d)
+        emu_lib.vmd_set_option(b"batch_frames", old_b)

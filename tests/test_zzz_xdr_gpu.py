@@ -57,3 +57,41 @@ def test_xdr_files_through_the_evaluator_on_emulator(emu_lib, oracle, tmp_path):
 @pytest.mark.gpu
 def test_xdr_files_through_the_evaluator(gpu_lib, oracle, tmp_path):
     _xdr_through_the_evaluator(gpu_lib, oracle, tmp_path, 70.0, 24, 30000, True)
+
+
+@pytest.mark.gpu
+def test_xtc_batches_leave_the_mapped_file_by_dma_on_the_gpu(gpu_lib, oracle, tmp_path):
+    """hipHostRegister on the reader's file mapping, hipMemcpyAsync straight out of it, k_xtc_wave on streams that start on 4-byte
+    boundaries: identical histogram to the pinned-block copy and to host decoding, first pass and re-evaluation from checkpoints."""
+    box, F, N = 60.0, 40, 21003
+    coords = cases.water_box(oracle, 23, N, box, F)
+    cell = V.make_unitcell(box)
+    p = tmp_path / "m.xtc"
+    V.write_xtc(p, coords, cell, lib=gpu_lib)
+    o = cases.oxygen(N)
+    ir = V.ScriptIR(gpu_lib); ir.add_rdf("g", o, o, 9.0)
+    sysm = V.MolSystem(N, unitcell=cell)
+    res = {}
+    old_b = gpu_lib.vmd_set_option(b"batch_frames", 16)
+    try:
+        for name, decode, mapped in (("host", 0, 0), ("copy", 3, 0), ("mapped", 3, 1)):
+            old_d = gpu_lib.vmd_set_option(b"xtc_device_decode", decode)
+            old_m = gpu_lib.vmd_set_option(b"xtc_mapped", mapped)
+            try:
+                xt = V.XdrTrajectory(p, lib=gpu_lib)
+                for rep in range(2):
+                    ev = V.ScriptEval(F, ir)
+                    assert ev.frame_range(sysm, xt, 0, 7) and ev.frame_range(sysm, xt, 7, F)
+                    got = ev.property_data("g").counts.copy()
+                    assert ev.frames_device_decoded() == (F if decode else 0) and ev.frames_mapped() == (F if mapped else 0)
+                    if decode:
+                        assert ev.frames_section_decoded() == (F if rep else 0)
+                    np.testing.assert_array_equal(got, res.setdefault(name, got))
+            finally:
+                gpu_lib.vmd_set_option(b"xtc_mapped", old_m)
+                gpu_lib.vmd_set_option(b"xtc_device_decode", old_d)
+    finally:
+        gpu_lib.vmd_set_option(b"batch_frames", old_b)
+    np.testing.assert_array_equal(res["copy"], res["host"])
+    np.testing.assert_array_equal(res["mapped"], res["host"])
+    assert res["host"].sum() > 0

@@ -71,7 +71,8 @@ class TrajectoryI(C.Structure):
     _fields_ = [("inst", C.c_void_p), ("num_frames", NUM_FRAMES_FN), ("num_atoms", NUM_ATOMS_FN),
                 ("load_frame", LOAD_FRAME_FN), ("device_view", DEVICE_VIEW_FN), ("host_view", HOST_VIEW_FN),
                 ("load_raw", C.c_void_p),          # native readers only (compressed frames for the device decoder); NULL here
-                ("raw_device_view", C.c_void_p)]   # vmd_rawtraj_* only (compressed frames resident in HBM); NULL here
+                ("raw_device_view", C.c_void_p),   # vmd_rawtraj_* only (compressed frames resident in HBM); NULL here
+                ("raw_mapped_view", C.c_void_p)]   # native XTC reader only (the file mapped for the copy engine); NULL here
 
 
 class Aggregate(C.Structure):
@@ -176,6 +177,7 @@ SIGNATURES = [
     ("vmd_eval_frame_stats", None, [_vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     ("vmd_eval_frames_device_decoded", C.c_size_t, [_vp]),
     ("vmd_eval_frames_section_decoded", C.c_size_t, [_vp]),
+    ("vmd_eval_frames_mapped", C.c_size_t, [_vp]),
     ("vmd_devtraj_create", _vp, [C.c_size_t, C.c_size_t]),
     ("vmd_devtraj_create_shard", _vp, [C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t]),
     ("vmd_devtraj_free", None, [_vp]),

@@ -200,6 +200,7 @@ extern "C" vmd_dcdtraj_t* vmd_dcdtraj_open(const char* path) {
     d.iface.host_view = nullptr;
     d.iface.load_raw = nullptr;
     d.iface.raw_device_view = nullptr;
+    d.iface.raw_mapped_view = nullptr;
     return t;
 }
 

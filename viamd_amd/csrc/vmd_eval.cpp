@@ -10,6 +10,8 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <unistd.h>
 #include <cmath>
 #include <condition_variable>
 #include <cstdarg>
@@ -84,6 +86,10 @@ struct Options {
                                              // frame (k_xtc_decode), 2 = index pass + one thread per chunk (k_xtc_index / k_xtc_chunks),
                                              // 3 = one wave per frame (k_xtc_wave)
     std::atomic<int> xtc_chunk{256};         // atoms per chunk of variant 2
+    std::atomic<int> xtc_ramp{0};            // file-backed device decode: small first and last batches (pipeline fill / drain); r03o: no gain, off
+    std::atomic<int> xtc_decode_ahead{1};    // batches the device decoder runs ahead of the kernels (1 or 2); r03n: 2 changes nothing
+    std::atomic<int> xtc_mapped{1};          // variant 3: DMA the compressed frames straight out of the mapped file (raw_mapped_view), no host copy
+    std::atomic<int> xtc_map_limit_mb{0};    // pinned bytes of mapped files, all trajectories together (0 = half of the physical memory)
     std::atomic<int> xtc_checkpoints{1};     // variant 3: the first decode of a frame leaves checkpoints, later ones decode it in sections
     // oracle/SPEC.md's DECISION: tags as switches - 0 = the documented default, 1 = the alternative; read when an eval is created
     std::atomic<int> spec_rdf_closed{0};          // D-RDF-OPEN: r_min <= d <= r_max instead of the open interval
@@ -124,6 +130,10 @@ extern "C" int vmd_set_option(const char* key, int value) {
     else if (!strcmp(key, "xtc_device_decode")) o = &g_opt.xtc_device_decode;
     else if (!strcmp(key, "xtc_chunk")) o = &g_opt.xtc_chunk;
     else if (!strcmp(key, "xtc_checkpoints")) o = &g_opt.xtc_checkpoints;
+    else if (!strcmp(key, "xtc_mapped")) o = &g_opt.xtc_mapped;
+    else if (!strcmp(key, "xtc_ramp")) o = &g_opt.xtc_ramp;
+    else if (!strcmp(key, "xtc_decode_ahead")) o = &g_opt.xtc_decode_ahead;
+    else if (!strcmp(key, "xtc_map_limit_mb")) o = &g_opt.xtc_map_limit_mb;
     else if (!strcmp(key, "xtc_waves")) return vmd_hip_set_xtc_waves(value);
     else if (!strcmp(key, "stage_frames")) o = &g_opt.stage_frames;
     else if (!strcmp(key, "sdf_direct_view")) o = &g_opt.sdf_direct_view;
@@ -188,6 +198,18 @@ extern "C" double vmd_profile_ms(const char* which, uint64_t* launches) {
     if (launches) *launches = it->second.launches;
     return it->second.ms;
 }
+
+// host wall time of a scope, booked under `name` next to the device event times (profiling only: where the eval thread waits)
+struct HostTimer {
+    const char* name; std::chrono::steady_clock::time_point t0; bool on;
+    explicit HostTimer(const char* n) : name(n), on(g_prof_on.load()) { if (on) t0 = std::chrono::steady_clock::now(); }
+    ~HostTimer() {
+        if (!on) return;
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        std::lock_guard<std::mutex> l(g_prof_mtx);
+        g_prof[name].ms += ms; g_prof[name].launches += 1;
+    }
+};
 
 struct ProfPending { const char* name; hipEvent_t a, b; };
 struct Profiler {
@@ -541,6 +563,61 @@ extern "C" void vmd_ckcache_drop(const void* inst) {
     std::lock_guard<std::mutex> l(g_ck_mtx);
     g_ck_store.erase(inst);
 }
+// Mapped trajectory files (vmd_trajectory_i::raw_mapped_view), pinned for the copy engine in windows of 1 GiB on first use
+// (hipHostRegister on the mapping: 5 ms per 512 MB once, then DMA at the rate of hipHostMalloc memory - profiles/r03c_hostio.txt).
+// Process-wide, keyed by the mapping's base; the reader that owns the mapping calls vmd_mapreg_drop before it unmaps.  A window
+// that cannot be pinned (limit reached, the driver refuses) stays unpinned: its batches take the load_raw copy instead.
+struct MapReg {
+    size_t bytes = 0;
+    std::vector<uint8_t> state;              // per window: 0 = not tried, 1 = pinned, 2 = refused
+};
+static std::mutex g_map_mtx;
+static std::map<const unsigned char*, MapReg> g_map_store;
+static size_t g_map_pinned = 0;
+static const size_t kMapWindow = (size_t)1 << 30;
+static void mapreg_release(const unsigned char* base, MapReg& m) {
+    for (size_t w = 0; w < m.state.size(); ++w) {
+        if (m.state[w] != 1) continue;
+        (void)hipHostUnregister((void*)(base + w * kMapWindow));
+        g_map_pinned -= std::min(kMapWindow, m.bytes - w * kMapWindow);
+    }
+    m.state.clear();
+}
+static bool mapreg_pin(const unsigned char* base, size_t bytes, size_t lo, size_t hi) {
+    std::lock_guard<std::mutex> l(g_map_mtx);
+    MapReg& m = g_map_store[base];
+    if (m.bytes != bytes) {                  // a new mapping at a recycled address whose owner never dropped the old one
+        mapreg_release(base, m);
+        m.bytes = bytes;
+        m.state.assign((bytes + kMapWindow - 1) / kMapWindow, 0);
+    }
+    size_t limit = (size_t)std::max(0, g_opt.xtc_map_limit_mb.load()) << 20;
+    if (!limit) {
+        const long pages = sysconf(_SC_PHYS_PAGES), psz = sysconf(_SC_PAGESIZE);
+        limit = (pages > 0 && psz > 0) ? (size_t)pages * (size_t)psz / 2 : ((size_t)8 << 30);
+    }
+    for (size_t w = lo / kMapWindow; w <= (hi - 1) / kMapWindow; ++w) {
+        if (m.state[w] == 1) continue;
+        if (m.state[w] == 2) return false;
+        const size_t len = std::min(kMapWindow, bytes - w * kMapWindow);
+        if (g_map_pinned + len > limit || hipHostRegister((void*)(base + w * kMapWindow), len, hipHostRegisterDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            m.state[w] = 2;
+            return false;
+        }
+        m.state[w] = 1;
+        g_map_pinned += len;
+    }
+    return true;
+}
+extern "C" void vmd_mapreg_drop(const void* base) {
+    std::lock_guard<std::mutex> l(g_map_mtx);
+    auto it = g_map_store.find((const unsigned char*)base);
+    if (it == g_map_store.end()) return;
+    mapreg_release(it->first, it->second);
+    g_map_store.erase(it);
+}
+
 static uint64_t frame_signature(const vmd_xtc_frame_t& fi, const unsigned char* bytes) {
     uint64_t h = 0x9E3779B97F4A7C15ull ^ fi.nbytes;
     auto mix = [&](uint64_t v) { h ^= v + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2); };
@@ -608,22 +685,27 @@ struct vmd_script_eval_t {
         // device views: the range whose cells / boxes this stage holds (host vectors and d_boxes), 0 = none
         const vmd_unitcell_t* boxes_cells = nullptr; size_t boxes_f0 = 0, boxes_nb = 0; uint64_t boxes_version = 0;
     };
-    Stage stages[2];
+    Stage stages[3];                         // batch k evaluated, k + 1 (device decode: and k + 2) being staged
     // compressed batches on their way to the device decoder, a ring of three: while the pair kernels of batch k run, batch k + 1 is
     // being decompressed (decode_stream) and the bit streams of batch k + 2 cross PCIe (copy_stream) - three engines, three batches
     struct RawSlot {
         unsigned char* h = nullptr; size_t hcap = 0;     // pinned bit streams
-        DevBuf<unsigned char> d;
+        DevBuf<unsigned char> d;                         // [frame table, info_bytes][bit streams]: one DMA per batch
         std::vector<vmd_xtc_frame_t> info;
-        DevBuf<vmd_xtc_frame_t> d_info;
+        size_t info_bytes = 0;
+        const vmd_xtc_frame_t* d_info() const { return (const vmd_xtc_frame_t*)d.p; }
+        const unsigned char* d_streams() const { return d.p + info_bytes; }
+        const unsigned char* h_streams = nullptr;        // host: where info[b].offset counts from (the pinned block, or the mapped file)
         std::vector<vmd_unitcell_t> cells;
         hipEvent_t uploaded = nullptr;
         size_t f0 = 0, nb = 0;
         int state = 0;                                   // 1 = [f0, f0 + nb) uploaded (event recorded), 0 = nothing, -1 = not available raw
     };
-    RawSlot raw_slots[3];
+    static constexpr size_t kRawSlots = 6;
+    RawSlot raw_slots[kRawSlots];
     std::shared_ptr<CkCache> ck_cache;       // the decoder checkpoints of the trajectory being evaluated (process-wide store)
     std::atomic<size_t> frames_section_decoded{0};
+    std::atomic<size_t> frames_mapped{0};
     hipStream_t decode_stream = nullptr;
     hipStream_t copy_stream = nullptr;
     hipStream_t aux_stream = nullptr;        // background work nothing else queues behind (the clearing DMA of a volume's host view)
@@ -847,7 +929,7 @@ extern "C" void vmd_eval_free(vmd_script_eval_t* eval) {
         for (auto& rs : eval->raw_slots) {
             if (rs.h) (void)hipHostFree(rs.h);
             rs.h = nullptr;
-            rs.d.release(); rs.d_info.release();
+            rs.d.release();
             if (rs.uploaded) (void)hipEventDestroy(rs.uploaded);
             rs.uploaded = nullptr;
         }
@@ -883,7 +965,7 @@ extern "C" void vmd_eval_clear_data(vmd_script_eval_t* eval) {
     eval->interrupt = false;
     std::fill(eval->frame_mask.begin(), eval->frame_mask.end(), (uint8_t)0);
     eval->frames_done = 0;
-    eval->frames_computed = 0; eval->frames_reused = 0; eval->frames_device_decoded = 0; eval->frames_section_decoded = 0;
+    eval->frames_computed = 0; eval->frames_reused = 0; eval->frames_device_decoded = 0; eval->frames_section_decoded = 0; eval->frames_mapped = 0;
     for (size_t b = 0; b < eval->num_blocks; ++b) eval->block_ready[b] = 0;
     for (auto& p : eval->props) {
         // the 8.4 MB float view of a volume is pinned: the copy engine zeroes it from a zero buffer in HBM, in the background -
@@ -1090,6 +1172,7 @@ extern "C" bool vmd_eval_set_source(vmd_script_eval_t* eval, vmd_script_eval_t* 
 
 extern "C" size_t vmd_eval_frames_device_decoded(const vmd_script_eval_t* eval) { return eval ? eval->frames_device_decoded.load() : 0; }
 extern "C" size_t vmd_eval_frames_section_decoded(const vmd_script_eval_t* eval) { return eval ? eval->frames_section_decoded.load() : 0; }
+extern "C" size_t vmd_eval_frames_mapped(const vmd_script_eval_t* eval) { return eval ? eval->frames_mapped.load() : 0; }
 
 extern "C" void vmd_eval_frame_stats(const vmd_script_eval_t* eval, size_t* frames_computed, size_t* frames_reused) {
     if (frames_computed) *frames_computed = eval ? eval->frames_computed.load() : 0;
@@ -1313,6 +1396,7 @@ static int launch_raw_decode(vmd_script_eval_t* e, Stage& st, const unsigned cha
 // First half of the compressed path: read the bit streams of frames [f0, f0 + nb) into the slot's pinned block (load threads) and queue
 // their DMA on copy_stream.  1 = queued (slot.uploaded recorded), 0 = a frame is not available raw, -1 error.
 static int raw_upload(vmd_script_eval_t* e, RawSlot& rs, vmd_trajectory_i* traj, size_t num_atoms, size_t f0, size_t nb) {
+    HostTimer host_timer("host_raw_upload");
     rs.state = 0; rs.f0 = f0; rs.nb = nb;
     rs.info.resize(nb);
     rs.cells.resize(nb);
@@ -1330,6 +1414,50 @@ static int raw_upload(vmd_script_eval_t* e, RawSlot& rs, vmd_trajectory_i* traj,
         fi.nbytes = infos[b].nbytes;
         total += ((size_t)infos[b].nbytes + 32 + 63) & ~(size_t)63;     // >= 32 readable bytes behind every stream, 64-byte aligned starts
     }
+    rs.info_bytes = (nb * sizeof(vmd_xtc_frame_t) + 255) & ~(size_t)255;
+    // The file is mapped: the copy engine takes the batch's span of it as it lies there (frame headers in between and all), this
+    // thread only writes the frame table.  r03m: reading the streams into the pinned block took 9.7 ms of a 15.8 ms c2 step (1 000
+    // frames, 0.51 GB, ~53 GB/s whatever the thread count) and sat on the eval thread's critical path.
+    vmd_raw_mapped_view_t mv;
+    if (g_opt.xtc_mapped.load() && g_opt.xtc_device_decode.load() == 3 && traj->raw_mapped_view && traj->raw_mapped_view(traj->inst, &mv) &&
+        mv.codec == VMD_RAW_CODEC_XTC && mv.base && mv.stream_offset) {
+        bool usable = true;
+        uint64_t prev_end = 0;
+        for (size_t b = 0; b < nb && usable; ++b) {
+            const uint64_t so = mv.stream_offset[f0 + b];
+            usable = (so & 3u) == 0 && so >= prev_end && so + infos[b].nbytes <= mv.bytes;
+            prev_end = so + infos[b].nbytes;
+        }
+        const size_t lo = usable ? (size_t)(mv.stream_offset[f0] & ~(uint64_t)7) : 0;
+        const size_t hi = usable ? std::min<size_t>(mv.bytes, (size_t)prev_end + 40) : 0;
+        if (usable && hi > lo && mapreg_pin(mv.base, mv.bytes, lo, hi)) {
+            HostTimer map_timer("host_raw_map");
+            for (size_t b = 0; b < nb; ++b) rs.info[b].offset = mv.stream_offset[f0 + b] - lo;
+            if (rs.info_bytes > rs.hcap) {
+                if (rs.h) (void)hipHostFree(rs.h);
+                rs.h = nullptr; rs.hcap = 0;
+                if (hipHostMalloc((void**)&rs.h, 2 * rs.info_bytes, hipHostMallocDefault) != hipSuccess) { vmd_fail("hipHostMalloc(%zu bytes) failed", 2 * rs.info_bytes); return -1; }
+                rs.hcap = 2 * rs.info_bytes;
+            }
+            memcpy(rs.h, rs.info.data(), nb * sizeof(vmd_xtc_frame_t));
+            rs.h_streams = mv.base + lo;
+            const size_t span = hi - lo;
+            if (!rs.d.ensure(rs.info_bytes + span + span / 8 + 64)) return -1;        // >= 32 readable bytes behind the last stream even at the file's end
+            if (hipMemcpyAsync(rs.d.p, rs.h, nb * sizeof(vmd_xtc_frame_t), hipMemcpyHostToDevice, e->copy_stream) != hipSuccess) { vmd_fail("hipMemcpyAsync of the frame table failed"); return -1; }
+            for (size_t a = lo; a < hi;) {                  // one copy per pinned window the span touches
+                const size_t stop = std::min(hi, (a / kMapWindow + 1) * kMapWindow);
+                if (hipMemcpyAsync(rs.d.p + rs.info_bytes + (a - lo), mv.base + a, stop - a, hipMemcpyHostToDevice, e->copy_stream) != hipSuccess) { vmd_fail("hipMemcpyAsync from the mapped trajectory file failed"); return -1; }
+                a = stop;
+            }
+            if (hipEventRecord(rs.uploaded, e->copy_stream) != hipSuccess) { vmd_fail("hipEventRecord failed"); return -1; }
+            e->frames_mapped += nb;
+            rs.state = 1;
+            return 1;
+        }
+    }
+    // the frame table travels at the head of the same pinned block: a second copy from pageable memory would stall this thread
+    // behind the DMA already queued on copy_stream (r03m: 11.5 ms of a 17.4 ms c2 step were spent in this function)
+    total += rs.info_bytes;
     if (total > rs.hcap) {
         if (rs.h) (void)hipHostFree(rs.h);
         rs.h = nullptr; rs.hcap = 0;
@@ -1346,21 +1474,25 @@ static int raw_upload(vmd_script_eval_t* e, RawSlot& rs, vmd_trajectory_i* traj,
             if (b >= nb || !ok.load()) break;
             const vmd_xtc_frame_t& fi = rs.info[b];
             vmd_raw_frame_t info;
-            unsigned char* dst = rs.h + fi.offset;
+            unsigned char* dst = rs.h + rs.info_bytes + fi.offset;
             if (!traj->load_raw(traj->inst, (int64_t)(f0 + b), nullptr, &info, dst, (size_t)fi.nbytes) || info.nbytes != fi.nbytes) { ok = false; break; }
             memset(dst + fi.nbytes, 0, (((size_t)fi.nbytes + 32 + 63) & ~(size_t)63) - (size_t)fi.nbytes);
         }
     };
-    if (nthreads == 1) work();
-    else {
-        std::vector<std::thread> pool;
-        for (size_t t = 1; t < nthreads; ++t) pool.emplace_back(work);
-        work();
-        for (auto& t : pool) t.join();
+    {
+        HostTimer read_timer("host_raw_read");
+        memcpy(rs.h, rs.info.data(), nb * sizeof(vmd_xtc_frame_t));
+        if (nthreads == 1) work();
+        else {
+            std::vector<std::thread> pool;
+            for (size_t t = 1; t < nthreads; ++t) pool.emplace_back(work);
+            work();
+            for (auto& t : pool) t.join();
+        }
     }
     if (!ok.load()) { rs.state = -1; return 0; }           // let load_frame produce the real error message
+    rs.h_streams = rs.h + rs.info_bytes;
     if (!rs.d.ensure(total + total / 8)) return -1;
-    if (!rs.d_info.upload(rs.info.data(), nb, e->copy_stream)) return -1;
     if (hipMemcpyAsync(rs.d.p, rs.h, total, hipMemcpyHostToDevice, e->copy_stream) != hipSuccess) { vmd_fail("hipMemcpyAsync of the compressed batch failed"); return -1; }
     if (hipEventRecord(rs.uploaded, e->copy_stream) != hipSuccess) { vmd_fail("hipEventRecord failed"); return -1; }
     rs.state = 1;
@@ -1429,12 +1561,12 @@ static bool fetch_stage(vmd_script_eval_t* e, Stage& st, vmd_trajectory_i* traj,
                 if (cc) {
                     // a frame's checkpoints count only for the very bytes they were written for
                     for (size_t b = 0; b < nb; ++b) {
-                        const uint64_t sg = frame_signature(rs->info[b], rs->h + rs->info[b].offset);
+                        const uint64_t sg = frame_signature(rs->info[b], rs->h_streams + rs->info[b].offset);
                         if (cc->sig[f0 + b] != sg) { cc->sig[f0 + b] = sg; cc->have[f0 + b] = 0; }
                     }
-                    raw = launch_raw_decode(e, st, rs->d.p, rs->d_info.p, num_atoms, nb, npad, ss, cc->ck.p + f0 * VMD_XTC_CK_MAX, cc->nck.p + f0, cc->have.data() + f0);
+                    raw = launch_raw_decode(e, st, rs->d_streams(), rs->d_info(), num_atoms, nb, npad, ss, cc->ck.p + f0 * VMD_XTC_CK_MAX, cc->nck.p + f0, cc->have.data() + f0);
                 } else {
-                    raw = launch_raw_decode(e, st, rs->d.p, rs->d_info.p, num_atoms, nb, npad, ss);
+                    raw = launch_raw_decode(e, st, rs->d_streams(), rs->d_info(), num_atoms, nb, npad, ss);
                 }
                 if (raw < 0) return false;
             } else {
@@ -1802,7 +1934,8 @@ static bool reuse_blocks(vmd_script_eval_t* e, size_t beg, size_t end, std::vect
         HIP_OK(hipStreamSynchronize(e->stream));   // the source's partials are read before its mutex is released
         e->frames_done += reused;
         e->frames_reused += reused;
-        for (auto& p : e->props) if (p->prop.kind == PROP_RDF) { if (!refresh_distribution(e, p.get())) return false; }
+        { HostTimer host_timer("host_refresh");
+          for (auto& p : e->props) if (p->prop.kind == PROP_RDF) { if (!refresh_distribution(e, p.get())) return false; } }
     }
     return true;
 }
@@ -1855,7 +1988,13 @@ static bool process_range(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
     const bool raw_ring = !have_view && traj->load_raw && g_opt.xtc_device_decode.load() != 0 &&
                           !(traj->host_view && traj->host_view(traj->inst, &hv_probe)) &&
                           !(traj->raw_device_view && traj->raw_device_view(traj->inst, &rv_probe));
-    auto slot_of = [&](size_t bi) -> RawSlot* { return raw_ring ? &e->raw_slots[bi % 3] : nullptr; };
+    // how many batches the bit streams run ahead of the kernels (one more than the decoder, which runs two ahead).  Copied through
+    // pinned blocks (host threads read them, this thread waits): 3.  Taken out of the mapped file by the copy engine alone: as many as the ring holds minus the one being decoded - the
+    // DMAs then queue back to back and PCIe never waits for this thread (r03n: 12.4 ms per c2 step against 9.4 ms of transfers).
+    vmd_raw_mapped_view_t mv_probe;
+    const size_t raw_ahead = (raw_ring && g_opt.xtc_mapped.load() && g_opt.xtc_device_decode.load() == 3 && traj->raw_mapped_view &&
+                              traj->raw_mapped_view(traj->inst, &mv_probe)) ? vmd_script_eval_t::kRawSlots - 1 : 3;      // always > stage_ahead
+    auto slot_of = [&](size_t bi) -> RawSlot* { return raw_ring ? &e->raw_slots[bi % vmd_script_eval_t::kRawSlots] : nullptr; };
     // batches decompressed on the device while the previous batch is in the pair kernel: the persistent pair grid leaves room for them
     const bool device_decode = raw_ring || (!have_view && traj->raw_device_view && traj->raw_device_view(traj->inst, &rv_probe));
 
@@ -1884,9 +2023,28 @@ static bool process_range(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
     }
     std::vector<Batch> batches;
     for (auto& sg : segments) plan_batches(e, sg.first, sg.second, Bmax, &batches);
+    // From a file the first batch has to cross PCIe and be decompressed before any kernel can start, and nothing overlaps the last
+    // batch's kernels (r03p timeline: 1.7 ms of a 12.3 ms c2 step before the first pair kernel, one DMA = 1.13 ms per 128 frames).
+    // Option xtc_ramp: the run starts with an eighth and a quarter of a batch and ends with a quarter.  Measured (r03o): the shorter
+    // fill is paid back by the pair kernel's lower efficiency on small launches - 81.5k frames/s either way, so it is off.
+    if (raw_ring && g_opt.xtc_ramp.load() && batches.size() >= 3) {
+        std::vector<Batch> ramped;
+        auto carve_front = [&](Batch& b, size_t n) { ramped.push_back({b.f0, n, -1}); b.f0 += n; b.nb -= n; };
+        Batch first = batches.front(), last = batches.back();
+        if (first.blk < 0 && first.nb >= 64) { carve_front(first, first.nb / 8); carve_front(first, first.nb / 3); }
+        ramped.push_back(first);
+        for (size_t i = 1; i + 1 < batches.size(); ++i) ramped.push_back(batches[i]);
+        if (last.blk < 0 && last.nb >= 64) { const size_t tail = last.nb / 4; ramped.push_back({last.f0, last.nb - tail, -1}); ramped.push_back({last.f0 + last.nb - tail, tail, -1}); }
+        else ramped.push_back(last);
+        batches.swap(ramped);
+    }
 
     bool completed = true;
-    int cur = 0;
+    // Batches staged ahead of the one being evaluated: one; optionally two when they are decompressed on the device (the decoder runs
+    // UNDER the pair kernel, in the wave slots that kernel leaves).  r03n/r03p: the wait in settle_stage is the pipeline filling at the
+    // start of a range, not a late decoder - two ahead measures the same, so one is the default.
+    const size_t stage_ahead = (raw_ring && g_opt.xtc_device_decode.load() == 3 && g_opt.xtc_decode_ahead.load() >= 2) ? 2 : 1;
+    auto stage_of = [&](size_t bi) -> Stage& { return e->stages[bi % (stage_ahead + 1)]; };
     struct BlocksGuard {
         int old = -1;
         ~BlocksGuard() { if (old > 0) vmd_hip_set_rdf_blocks(old); }
@@ -1897,17 +2055,19 @@ static bool process_range(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
     }
     if (raw_ring) {
         for (auto& rs : e->raw_slots) rs.state = 0;
-        for (size_t bi = 0; bi < std::min<size_t>(2, batches.size()); ++bi)
+        for (size_t bi = 0; bi < std::min<size_t>(raw_ahead, batches.size()); ++bi)
             if (raw_upload(e, *slot_of(bi), traj, num_atoms, batches[bi].f0, batches[bi].nb) < 0) return false;
     }
-    if (!batches.empty() && !fetch_stage(e, e->stages[cur], traj, vw, num_atoms, batches[0].f0, batches[0].nb, false, slot_of(0))) return false;
-    for (size_t bi = 0; bi < batches.size(); ++bi, cur ^= 1) {
+    for (size_t bi = 0; bi < std::min(stage_ahead, batches.size()); ++bi)
+        if (!fetch_stage(e, stage_of(bi), traj, vw, num_atoms, batches[bi].f0, batches[bi].nb, false, slot_of(bi))) return false;
+    for (size_t bi = 0; bi < batches.size(); ++bi) {
         if (e->interrupt) { completed = false; break; }
         const Batch& bt = batches[bi];
         const size_t f0 = bt.f0, nb = bt.nb;
-        Stage& src = e->stages[cur];
-        if (!settle_stage(e, src, traj, num_atoms)) return false;
+        Stage& src = stage_of(bi);
+        { HostTimer host_timer("host_settle"); if (!settle_stage(e, src, traj, num_atoms)) return false; }
         VMD_STAGE("batch: kernels queued");
+        HostTimer queue_timer("host_queue_to_sync");
         HIP_OK(hipStreamWaitEvent(e->stream, src.ready, 0));
         const uint32_t pbc = batch_pbc(src);
         for (auto& s : e->sels) s->built = false;
@@ -2050,13 +2210,17 @@ static bool process_range(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
         VMD_STAGE("batch: staging the next batch (fetch_stage)");
         // the kernels of this batch are queued: load the next batch on the host while they run
         if (bi + 1 < batches.size() && !e->interrupt) {
-            if (!fetch_stage(e, e->stages[cur ^ 1], traj, vw, num_atoms, batches[bi + 1].f0, batches[bi + 1].nb, false, slot_of(bi + 1))) return false;
+            if (bi + stage_ahead < batches.size()) {
+                HostTimer host_timer("host_fetch_stage");
+                const size_t nx = bi + stage_ahead;
+                if (!fetch_stage(e, stage_of(nx), traj, vw, num_atoms, batches[nx].f0, batches[nx].nb, false, slot_of(nx))) return false;
+            }
             // ... and send the bit streams of the batch after that on their way (its slot held batch bi - 1: decoded long ago)
-            if (raw_ring && bi + 2 < batches.size() &&
-                raw_upload(e, *slot_of(bi + 2), traj, num_atoms, batches[bi + 2].f0, batches[bi + 2].nb) < 0) return false;
+            if (raw_ring && bi + raw_ahead < batches.size() &&
+                raw_upload(e, *slot_of(bi + raw_ahead), traj, num_atoms, batches[bi + raw_ahead].f0, batches[bi + raw_ahead].nb) < 0) return false;
         }
         VMD_STAGE("batch: hipStreamSynchronize");
-        HIP_OK(hipStreamSynchronize(e->stream));
+        { HostTimer host_timer("host_sync_wait"); HIP_OK(hipStreamSynchronize(e->stream)); }
         VMD_STAGE("batch: host bookkeeping");
         // a bucket of the two-level cell build was too small: nothing reached the histograms (every consumer saw the flag).
         // Re-measure the selections that used buckets with more head room and evaluate the RDF part of this batch again.
@@ -2264,6 +2428,7 @@ extern "C" vmd_devtraj_t* vmd_devtraj_create_shard(size_t num_frames, size_t fra
     t->iface.load_frame = dt_load_frame; t->iface.device_view = dt_device_view; t->iface.host_view = nullptr;
     t->iface.load_raw = nullptr;
     t->iface.raw_device_view = nullptr;
+    t->iface.raw_mapped_view = nullptr;
     return t.release();
 }
 extern "C" vmd_devtraj_t* vmd_devtraj_create(size_t num_frames, size_t num_atoms) { return vmd_devtraj_create_shard(num_frames, 0, num_frames, num_atoms); }
@@ -2464,6 +2629,7 @@ extern "C" vmd_rawtraj_t* vmd_rawtraj_create(vmd_trajectory_i* src) {
     t->iface.load_frame = rt_load_frame; t->iface.device_view = nullptr; t->iface.host_view = nullptr;
     t->iface.load_raw = rt_load_raw;
     t->iface.raw_device_view = rt_raw_device_view;
+    t->iface.raw_mapped_view = nullptr;
     return t.release();
 }
 extern "C" vmd_trajectory_i* vmd_rawtraj_interface(vmd_rawtraj_t* t) { return t ? &t->iface : nullptr; }
@@ -2507,6 +2673,7 @@ extern "C" vmd_hosttraj_t* vmd_hosttraj_create(size_t num_frames, size_t num_ato
     t->iface.device_view = nullptr; t->iface.host_view = ht_host_view;
     t->iface.load_raw = nullptr;
     t->iface.raw_device_view = nullptr;
+    t->iface.raw_mapped_view = nullptr;
     return t.release();
 }
 extern "C" void vmd_hosttraj_free(vmd_hosttraj_t* t) { if (!t) return; if (t->h) (void)hipHostFree(t->h); delete t; }

@@ -30,10 +30,12 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
 #include <fcntl.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -237,6 +239,12 @@ struct Xdr {
     std::vector<vmd_unitcell_t> raw_cell;
     vmd_trajectory_i iface;
     std::string path;
+    // the file mapped read-only on first request (raw_mapped_view): the evaluator DMAs compressed frames straight out of it
+    std::mutex map_mtx;
+    const unsigned char* map = nullptr;
+    size_t map_bytes = 0;
+    bool map_failed = false;
+    std::vector<uint64_t> stream_off;
 };
 
 bool read_at(int fd, void* dst, size_t n, uint64_t off) {
@@ -575,6 +583,36 @@ bool xdr_load_raw(void* inst, int64_t idx, vmd_frame_header_t* hdr, vmd_raw_fram
     return true;
 }
 
+// The file mapped for the evaluator's DMA (vmd_trajectory_i::raw_mapped_view).  Mapped once, on first request; frames this reader
+// cannot hand over raw make the whole file unmappable (load_raw refuses them one by one, the evaluator then decodes on the host).
+bool xdr_raw_mapped_view(void* inst, vmd_raw_mapped_view_t* out) {
+    Xdr* d = (Xdr*)inst;
+    if (d->kind != KIND_XTC || !out || d->frames.empty()) return false;
+    std::lock_guard<std::mutex> lk(d->map_mtx);
+    if (d->map_failed) return false;
+    if (!d->map) {
+        struct stat sb;
+        if (fstat(d->fd, &sb) != 0 || sb.st_size <= 0) { d->map_failed = true; return false; }
+        const FrameRec& last = d->frames.back();
+        if (last.off + last.head + last.bytes > (uint64_t)sb.st_size) { d->map_failed = true; return false; }   // truncated since it was indexed
+        void* m = mmap(nullptr, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE, d->fd, 0);
+        if (m == MAP_FAILED) { d->map_failed = true; return false; }
+        (void)madvise(m, (size_t)sb.st_size, MADV_SEQUENTIAL);
+        d->stream_off.resize(d->frames.size());
+        for (size_t i = 0; i < d->frames.size(); ++i) {
+            if (d->frames[i].raw) { munmap(m, (size_t)sb.st_size); d->map_failed = true; return false; }
+            d->stream_off[i] = d->frames[i].off + d->frames[i].head;
+        }
+        d->map = (const unsigned char*)m;
+        d->map_bytes = (size_t)sb.st_size;
+    }
+    out->base = d->map;
+    out->bytes = d->map_bytes;
+    out->stream_offset = d->stream_off.data();
+    out->codec = VMD_RAW_CODEC_XTC;
+    return true;
+}
+
 // ------------------------------------------------------------------ writer
 struct Writer {
     FILE* fh = nullptr;
@@ -756,13 +794,19 @@ extern "C" vmd_xdrtraj_t* vmd_xdrtraj_open(const char* path) {
     d.iface.host_view = nullptr;
     d.iface.load_raw = d.kind == KIND_XTC ? xdr_load_raw : nullptr;
     d.iface.raw_device_view = nullptr;
+    d.iface.raw_mapped_view = d.kind == KIND_XTC ? xdr_raw_mapped_view : nullptr;
     return t;
 }
 
 extern "C" void vmd_ckcache_drop(const void* inst);      // vmd_eval.cpp: the decoder checkpoints kept for this trajectory
+extern "C" void vmd_mapreg_drop(const void* base);       // vmd_eval.cpp: the pinned windows of this mapping
 extern "C" void vmd_xdrtraj_close(vmd_xdrtraj_t* t) {
     if (!t) return;
     vmd_ckcache_drop(&t->d);
+    if (t->d.map) {
+        vmd_mapreg_drop(t->d.map);
+        munmap((void*)t->d.map, t->d.map_bytes);
+    }
     if (t->d.fd >= 0) close(t->d.fd);
     delete t;
 }

@@ -473,6 +473,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
     }
     const unsigned char* stream = raw + fi.offset;
     const uint32_t* dw = (const uint32_t*)stream;
+    // a stream DMA'd straight out of the mapped file starts where the file has it: on a 4-byte boundary (XDR).  The walk reads
+    // dwords; the per-lane reader works on 8-byte words and enters 4 bytes early, all its bit positions shifted by 32.
+    const uint64_t phase = (uint64_t)((uintptr_t)stream & 4u);
     const uint32_t ndw = (uint32_t)((fi.nbytes + 32ull) >> 2);   // readable dwords (the pad behind the stream included)
     const uint32_t nbits = (uint32_t)(8ull * fi.nbytes);
     const uint32_t large_bits = (uint32_t)(fs.bitsize ? fs.bitsize : fs.bitsizeint[0] + fs.bitsizeint[1] + fs.bitsizeint[2]);
@@ -519,10 +522,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
                     uint32_t lst = 0;
                     if (lane < g) {
                         BitsG br;
-                        xtc_open(br, stream, fi.nbytes, (uint64_t)vpos);
+                        xtc_open(br, stream - phase, fi.nbytes + phase, (uint64_t)vpos + 8ull * phase);
                         int gi = vatom, gs = sidx, gr = (int)(vstate >> 8);
                         lst = xtc_group(br, fi, fs, natoms, gi, gs, gr, small, x, y, z);
-                        if (!lst && br.pos > (uint64_t)nbits) lst = 1;
+                        if (!lst && br.pos > (uint64_t)nbits + 8ull * phase) lst = 1;
                     }
                     if (VMD_XTC_BALLOT(lst == 1u)) st = 1;
                     else if (VMD_XTC_BALLOT(lst == 2u) && !st) st = 2;

@@ -289,6 +289,10 @@ class ScriptEval:
         """... and how many of those were decoded in sections from the trajectory's decoder checkpoints (a re-evaluation)."""
         return int(self.lib.vmd_eval_frames_section_decoded(self.h))
 
+    def frames_mapped(self):
+        """... and how many reached the device by DMA straight out of the mapped file (no host copy of the compressed bytes)."""
+        return int(self.lib.vmd_eval_frames_mapped(self.h))
+
     def num_frames(self):
         return int(self.lib.vmd_eval_num_frames(self.h))
 
