@@ -90,13 +90,24 @@ typedef struct vmd_host_view_t {
 /* A frame handed over still compressed, to be decoded on the device (extension; today: the XTC coordinate block).  The
  * decoder parameters are in host byte order; the `nbytes` bytes of the bit stream are written to the caller's buffer. */
 #define VMD_RAW_CODEC_XTC 1u
+/* plain 32-bit floats as the file stores them (TRR: big-endian nm, xyz interleaved; DCD: one block per component, either byte
+ * order).  Only handed over through raw_mapped_view - load_raw fills `info` and refuses a payload copy: the copy engine takes the
+ * frames out of the mapped file and a kernel swaps / scales / transposes them into the evaluator's layout (k_raw_f32). */
+#define VMD_RAW_CODEC_F32 2u
+#define VMD_RAW_F32_BIG_ENDIAN 1u
 typedef struct vmd_raw_frame_t {
     uint32_t codec;             /* VMD_RAW_CODEC_* */
     float    precision;         /* XTC: grid steps per nm */
     int32_t  minint[3], maxint[3];
     int32_t  smallidx;
     uint32_t reserved;
-    uint64_t nbytes;            /* bytes of the bit stream */
+    uint64_t nbytes;            /* XTC: bytes of the bit stream; F32: bytes from the frame's stream_offset to the end of its last float */
+    /* VMD_RAW_CODEC_F32: component c of atom i is the float at stream_offset + f32_offset[c] + 4 * f32_stride * i */
+    uint64_t f32_offset[3];
+    uint32_t f32_stride;        /* floats from one atom to the next: 1 = a block per component, 3 = xyz interleaved */
+    uint32_t f32_flags;         /* VMD_RAW_F32_* */
+    float    f32_scale;         /* file unit -> Angstrom, applied as one fp32 multiply (1 = none) */
+    uint32_t reserved2;
 } vmd_raw_frame_t;
 
 /* Compressed frames resident in HBM (extension): the bit streams of EVERY frame of the trajectory and their decoder records on

@@ -181,6 +181,18 @@ typedef struct vmd_xtc_frame_t {
     int32_t  smallidx;
     uint64_t offset, nbytes;
 } vmd_xtc_frame_t;
+/* Frames stored as plain floats (TRR, DCD), DMA'd as they lie in the file: swap / scale / transpose into the frame layout above.
+ * raw + info[b].offset[c] + 4 * stride * i = component c of atom i of frame b (4-byte aligned); scale is one fp32 multiply, skipped
+ * when it is 1 (the host readers do the same: vmd_xdr.cpp trr_load, vmd_dcd.cpp dcd_load_frame). */
+typedef struct vmd_f32_frame_t {
+    uint64_t offset[3];
+    uint32_t stride, flags;     /* flags: bit 0 = big-endian */
+    float    scale;
+    uint32_t reserved;
+} vmd_f32_frame_t;
+int vmd_hip_raw_f32_decode(void* stream, const unsigned char* raw, const vmd_f32_frame_t* info, int B, int natoms,
+                           float* xyz, size_t frame_stride, size_t row_stride);
+
 int vmd_hip_xtc_decode(void* stream, const unsigned char* raw, const vmd_xtc_frame_t* info, int B, int natoms,
                        float* xyz, size_t frame_stride, size_t row_stride, uint32_t* status);
 /* the same result in two passes: k_xtc_index (one thread per frame) follows only flags and field widths and drops a checkpoint

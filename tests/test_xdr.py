@@ -438,7 +438,8 @@ def test_xtc_batches_decoded_on_the_device_through_the_evaluator(tmp_path, emu_l
                 if mode:
                     ev2 = V.ScriptEval(F, ir)
                     assert ev2.frame_range(sysm, V.XdrTrajectory(q, lib=emu_lib), 0, F)
-                    assert ev2.frames_device_decoded() == 0 and ev2.property_data("g").counts.sum() > 0
+                    # nothing to decompress in a TRR file: its floats leave the mapped file by DMA and k_raw_f32 lays them out
+                    assert ev2.frames_device_decoded() == F and ev2.frames_section_decoded() == 0 and ev2.property_data("g").counts.sum() > 0
             finally:
                 emu_lib.vmd_set_option(b"xtc_device_decode", old)
                 emu_lib.vmd_set_option(b"xtc_chunk", old_c)
@@ -514,4 +515,64 @@ def test_xtc_batches_leave_the_mapped_file_by_dma(tmp_path, emu_lib, oracle):
             del os.environ["VIAMD_EMU_NO_HOST_REGISTER"]
     finally:
         emu_lib.vmd_set_option(b"xtc_device_decode", old_d)
+        emu_lib.vmd_set_option(b"batch_frames", old_b)
+
+
+def test_plain_float_files_leave_the_mapped_file_by_dma(tmp_path, emu_lib, oracle):
+    """TRR (big-endian nm, xyz interleaved) and DCD (a block per component, either byte order, with or without a cell record): the
+    copy engine takes every batch's span of the mapped file, k_raw_f32 swaps / scales / transposes it into the frame layout.  Same
+    integers as load_frame on host threads (raw_f32_device = 0), which stays the path when the mapping cannot be pinned."""
+    import os
+    import cases
+    box, F, N = 31.0, 9, 1001
+    coords = cases.water_box(oracle, 41, N, box, F)
+    cell = V.make_unitcell(box)
+    o = cases.oxygen(N)
+    ir = V.ScriptIR(emu_lib); ir.add_rdf("g", o, o, 8.0)
+    sysm = V.MolSystem(N, unitcell=cell)
+    files = {}
+    q = tmp_path / "f.trr"; V.write_trr(q, coords, cell, lib=emu_lib); files["trr"] = lambda: V.XdrTrajectory(q, lib=emu_lib)
+    for tag, kw in (("dcd", {}), ("dcd_be", {"big_endian": True})):
+        d = tmp_path / (tag + ".dcd"); V.write_dcd(d, coords, cell, **kw)
+        files[tag] = (lambda d=d: V.DcdTrajectory(d, lib=emu_lib))
+    dn = tmp_path / "nocell.dcd"; V.write_dcd(dn, coords, None)
+    old_b = emu_lib.vmd_set_option(b"batch_frames", 4)
+    try:
+        for tag, opener in files.items():
+            old = emu_lib.vmd_set_option(b"raw_f32_device", 0)
+            try:
+                ev = V.ScriptEval(F, ir)
+                assert ev.frame_range(sysm, opener(), 0, F)
+                want = ev.property_data("g").counts.copy()
+                assert want.sum() > 0 and ev.frames_mapped() == 0 and ev.frames_device_decoded() == 0
+            finally:
+                emu_lib.vmd_set_option(b"raw_f32_device", old)
+            t = opener()
+            ev = V.ScriptEval(F, ir)
+            assert ev.frame_range(sysm, t, 0, 2) and ev.frame_range(sysm, t, 2, F)
+            np.testing.assert_array_equal(ev.property_data("g").counts, want, err_msg=tag)
+            assert ev.frames_mapped() == F and ev.frames_device_decoded() == F, tag
+            os.environ["VIAMD_EMU_NO_HOST_REGISTER"] = "1"        # the mapping cannot be pinned: load_frame on host threads
+            try:
+                ev = V.ScriptEval(F, ir)
+                assert ev.frame_range(sysm, opener(), 0, F)
+                np.testing.assert_array_equal(ev.property_data("g").counts, want, err_msg=tag)
+                assert ev.frames_mapped() == 0 and ev.frames_device_decoded() == 0
+            finally:
+                del os.environ["VIAMD_EMU_NO_HOST_REGISTER"]
+        # a DCD file without cell records: open boundaries from the system, same floats either way
+        sys_open = V.MolSystem(N)
+        got = []
+        for dev in (0, 1):
+            old = emu_lib.vmd_set_option(b"raw_f32_device", dev)
+            try:
+                ev = V.ScriptEval(F, ir)
+                assert ev.frame_range(sys_open, V.DcdTrajectory(dn, lib=emu_lib), 0, F)
+                got.append(ev.property_data("g").counts.copy())
+                assert ev.frames_mapped() == (F if dev else 0)
+            finally:
+                emu_lib.vmd_set_option(b"raw_f32_device", old)
+        np.testing.assert_array_equal(got[0], got[1])
+        assert got[0].sum() > 0
+    finally:
         emu_lib.vmd_set_option(b"batch_frames", old_b)

@@ -95,3 +95,37 @@ def test_xtc_batches_leave_the_mapped_file_by_dma_on_the_gpu(gpu_lib, oracle, tm
     np.testing.assert_array_equal(res["copy"], res["host"])
     np.testing.assert_array_equal(res["mapped"], res["host"])
     assert res["host"].sum() > 0
+
+
+@pytest.mark.gpu
+def test_plain_float_files_leave_the_mapped_file_by_dma_on_the_gpu(gpu_lib, oracle, tmp_path):
+    """TRR and DCD frames: DMA out of the pinned file mapping + k_raw_f32 against load_frame on host threads - the same floats, so the
+    same integers; every frame counted as mapped and device-decoded."""
+    box, F, N = 60.0, 36, 21003
+    coords = cases.water_box(oracle, 29, N, box, F)
+    cell = V.make_unitcell(box)
+    o = cases.oxygen(N)
+    ir = V.ScriptIR(gpu_lib); ir.add_rdf("g", o, o, 9.0)
+    sysm = V.MolSystem(N, unitcell=cell)
+    q = tmp_path / "f.trr"; V.write_trr(q, coords, cell, lib=gpu_lib)
+    d1 = tmp_path / "le.dcd"; V.write_dcd(d1, coords, cell)
+    d2 = tmp_path / "be.dcd"; V.write_dcd(d2, coords, cell, big_endian=True)
+    openers = {"trr": lambda: V.XdrTrajectory(q, lib=gpu_lib), "dcd": lambda: V.DcdTrajectory(d1, lib=gpu_lib), "dcd_be": lambda: V.DcdTrajectory(d2, lib=gpu_lib)}
+    old_b = gpu_lib.vmd_set_option(b"batch_frames", 8)
+    try:
+        for tag, opener in openers.items():
+            res = []
+            for dev in (0, 1):
+                old = gpu_lib.vmd_set_option(b"raw_f32_device", dev)
+                try:
+                    t = opener()
+                    ev = V.ScriptEval(F, ir)
+                    assert ev.frame_range(sysm, t, 0, 5) and ev.frame_range(sysm, t, 5, F)
+                    res.append(ev.property_data("g").counts.copy())
+                    assert ev.frames_mapped() == (F if dev else 0) and ev.frames_device_decoded() == (F if dev else 0), tag
+                finally:
+                    gpu_lib.vmd_set_option(b"raw_f32_device", old)
+            np.testing.assert_array_equal(res[0], res[1], err_msg=tag)
+            assert res[0].sum() > 0
+    finally:
+        gpu_lib.vmd_set_option(b"batch_frames", old_b)

@@ -11,14 +11,17 @@
 //   per frame: [6 x float64 unit cell: A, gamma, B, beta, alpha, C (angles in degrees, or their cosines)] X Y Z [W]
 // Either byte order is accepted.  Files with fixed atoms (frames after the first hold only the free atoms) are rejected.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
 #include <fcntl.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -38,6 +41,12 @@ struct Dcd {
     size_t header_bytes = 0, frame_bytes = 0;
     vmd_trajectory_i iface;
     std::string path;
+    // the file mapped read-only on first request (raw_mapped_view): the evaluator DMAs the coordinate records straight out of it
+    std::mutex map_mtx;
+    std::atomic<const unsigned char*> map{nullptr};
+    size_t map_bytes = 0;
+    bool map_failed = false;
+    std::vector<uint64_t> stream_off;
 };
 
 bool fail(const char* fmt, const std::string& path) {
@@ -139,6 +148,73 @@ bool dcd_load_frame(void* inst, int64_t idx, vmd_frame_header_t* hdr, float* x, 
     return true;
 }
 
+// The frame as the file stores it, for the device path (vmd_trajectory_i::load_raw + raw_mapped_view): three blocks of floats
+// behind their record markers.  Only `info` (and the header) - the payload is never copied, the copy engine reads the mapping.
+bool dcd_load_raw(void* inst, int64_t idx, vmd_frame_header_t* hdr, vmd_raw_frame_t* info, void* dst, size_t) {
+    Dcd* d = (Dcd*)inst;
+    if (idx < 0 || (size_t)idx >= d->num_frames || !info || dst) return false;
+    const size_t off = d->header_bytes + (size_t)idx * d->frame_bytes;
+    const size_t lead = d->has_cell ? 56 : 0;
+    const size_t nbytes = 4 * d->num_atoms;
+    unsigned char rec[56];
+    vmd_unitcell_t cell;
+    memset(&cell, 0, sizeof(cell));
+    const unsigned char* mb = d->map.load(std::memory_order_acquire);
+    const unsigned char* m = mb ? mb + off : nullptr;             // headers come from the mapping once there is one: no system call
+    if (d->has_cell) {
+        if (m) memcpy(rec, m, sizeof(rec));
+        else if (!read_at(d, rec, sizeof(rec), off)) return false;
+        if (u32(d, rec) != 48 || u32(d, rec + 52) != 48) return false;
+        cell = decode_cell(d, rec + 4);
+    }
+    for (int a = 0; a < 3; ++a) {                                   // the three record markers: a frame that fails here goes through load_frame
+        unsigned char mark[4];
+        const size_t at = lead + (size_t)a * (nbytes + 8);
+        if (m) memcpy(mark, m + at, 4);
+        else if (!read_at(d, mark, 4, off + at)) return false;
+        if (u32(d, mark) != nbytes) return false;
+    }
+    memset(info, 0, sizeof(*info));
+    info->codec = VMD_RAW_CODEC_F32;
+    for (int a = 0; a < 3; ++a) info->f32_offset[a] = lead + (uint64_t)a * (nbytes + 8) + 4;
+    info->f32_stride = 1;
+    info->f32_flags = d->swap ? VMD_RAW_F32_BIG_ENDIAN : 0u;      // "the other byte order": the kernel swaps, whatever the host's is called
+    info->f32_scale = 1.0f;
+    info->nbytes = lead + 3 * (nbytes + 8) - 4;
+    if (hdr) {
+        memset(hdr, 0, sizeof(*hdr));
+        hdr->num_atoms = d->num_atoms;
+        hdr->index = idx;
+        hdr->timestamp = (double)idx;
+        hdr->unitcell = cell;
+    }
+    return true;
+}
+
+bool dcd_raw_mapped_view(void* inst, vmd_raw_mapped_view_t* out) {
+    Dcd* d = (Dcd*)inst;
+    if (!out || d->num_frames == 0) return false;
+    std::lock_guard<std::mutex> lk(d->map_mtx);
+    if (d->map_failed) return false;
+    if (!d->map.load()) {
+        struct stat sb;
+        const size_t need = d->header_bytes + d->num_frames * d->frame_bytes;
+        if (fstat(d->fd, &sb) != 0 || (size_t)sb.st_size < need) { d->map_failed = true; return false; }
+        void* m = mmap(nullptr, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE, d->fd, 0);
+        if (m == MAP_FAILED) { d->map_failed = true; return false; }
+        (void)madvise(m, (size_t)sb.st_size, MADV_SEQUENTIAL);
+        d->stream_off.resize(d->num_frames);
+        for (size_t i = 0; i < d->num_frames; ++i) d->stream_off[i] = d->header_bytes + i * d->frame_bytes;
+        d->map_bytes = (size_t)sb.st_size;
+        d->map.store((const unsigned char*)m, std::memory_order_release);
+    }
+    out->base = d->map.load();
+    out->bytes = d->map_bytes;
+    out->stream_offset = d->stream_off.data();
+    out->codec = VMD_RAW_CODEC_F32;
+    return true;
+}
+
 }  // namespace
 
 struct vmd_dcdtraj_t { Dcd d; };
@@ -198,14 +274,19 @@ extern "C" vmd_dcdtraj_t* vmd_dcdtraj_open(const char* path) {
     d.iface.load_frame = dcd_load_frame;
     d.iface.device_view = nullptr;
     d.iface.host_view = nullptr;
-    d.iface.load_raw = nullptr;
+    d.iface.load_raw = dcd_load_raw;
     d.iface.raw_device_view = nullptr;
-    d.iface.raw_mapped_view = nullptr;
+    d.iface.raw_mapped_view = dcd_raw_mapped_view;
     return t;
 }
 
+extern "C" void vmd_mapreg_drop(const void* base);       // vmd_eval.cpp: the pinned windows of this mapping
 extern "C" void vmd_dcdtraj_close(vmd_dcdtraj_t* t) {
     if (!t) return;
+    if (const unsigned char* m = t->d.map.load()) {
+        vmd_mapreg_drop(m);
+        munmap((void*)m, t->d.map_bytes);
+    }
     if (t->d.fd >= 0) close(t->d.fd);
     delete t;
 }

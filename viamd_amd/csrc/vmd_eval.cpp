@@ -88,6 +88,7 @@ struct Options {
     std::atomic<int> xtc_chunk{256};         // atoms per chunk of variant 2
     std::atomic<int> xtc_ramp{0};            // file-backed device decode: small first and last batches (pipeline fill / drain); r03o: no gain, off
     std::atomic<int> xtc_decode_ahead{1};    // batches the device decoder runs ahead of the kernels (1 or 2); r03n: 2 changes nothing
+    std::atomic<int> raw_f32_device{1};      // TRR / DCD: frames DMA'd out of the mapped file, swapped / scaled / transposed by k_raw_f32 (0: host threads)
     std::atomic<int> xtc_mapped{1};          // variant 3: DMA the compressed frames straight out of the mapped file (raw_mapped_view), no host copy
     std::atomic<int> xtc_map_limit_mb{0};    // pinned bytes of mapped files, all trajectories together (0 = half of the physical memory)
     std::atomic<int> xtc_checkpoints{1};     // variant 3: the first decode of a frame leaves checkpoints, later ones decode it in sections
@@ -131,6 +132,7 @@ extern "C" int vmd_set_option(const char* key, int value) {
     else if (!strcmp(key, "xtc_chunk")) o = &g_opt.xtc_chunk;
     else if (!strcmp(key, "xtc_checkpoints")) o = &g_opt.xtc_checkpoints;
     else if (!strcmp(key, "xtc_mapped")) o = &g_opt.xtc_mapped;
+    else if (!strcmp(key, "raw_f32_device")) o = &g_opt.raw_f32_device;
     else if (!strcmp(key, "xtc_ramp")) o = &g_opt.xtc_ramp;
     else if (!strcmp(key, "xtc_decode_ahead")) o = &g_opt.xtc_decode_ahead;
     else if (!strcmp(key, "xtc_map_limit_mb")) o = &g_opt.xtc_map_limit_mb;
@@ -692,6 +694,8 @@ struct vmd_script_eval_t {
         unsigned char* h = nullptr; size_t hcap = 0;     // pinned bit streams
         DevBuf<unsigned char> d;                         // [frame table, info_bytes][bit streams]: one DMA per batch
         std::vector<vmd_xtc_frame_t> info;
+        uint32_t codec = VMD_RAW_CODEC_XTC;              // what the slot holds: XTC bit streams (info) or plain floats (f32)
+        std::vector<vmd_f32_frame_t> f32;
         size_t info_bytes = 0;
         const vmd_xtc_frame_t* d_info() const { return (const vmd_xtc_frame_t*)d.p; }
         const unsigned char* d_streams() const { return d.p + info_bytes; }
@@ -706,6 +710,7 @@ struct vmd_script_eval_t {
     std::shared_ptr<CkCache> ck_cache;       // the decoder checkpoints of the trajectory being evaluated (process-wide store)
     std::atomic<size_t> frames_section_decoded{0};
     std::atomic<size_t> frames_mapped{0};
+    bool raw_skip = false;                   // the range being evaluated does not use the raw ring (set by the leader in evaluate_range)
     hipStream_t decode_stream = nullptr;
     hipStream_t copy_stream = nullptr;
     hipStream_t aux_stream = nullptr;        // background work nothing else queues behind (the clearing DMA of a volume's host view)
@@ -1393,6 +1398,56 @@ static int launch_raw_decode(vmd_script_eval_t* e, Stage& st, const unsigned cha
     return 1;
 }
 
+// Frames stored as plain floats: the copy engine takes the batch's span of the mapped file, k_raw_f32 turns it into the frame layout.
+// 1 = queued, 0 = not this way (no mapping, not pinnable, option off), -1 error.
+static int raw_upload_f32(vmd_script_eval_t* e, vmd_script_eval_t::RawSlot& rs, vmd_trajectory_i* traj, const std::vector<vmd_raw_frame_t>& infos,
+                          size_t num_atoms, size_t f0, size_t nb) {
+    vmd_raw_mapped_view_t mv;
+    if (!g_opt.raw_f32_device.load() || !g_opt.xtc_mapped.load() || !traj->raw_mapped_view || !traj->raw_mapped_view(traj->inst, &mv) ||
+        mv.codec != VMD_RAW_CODEC_F32 || !mv.base || !mv.stream_offset) return 0;
+    uint64_t lo64 = ~(uint64_t)0, hi64 = 0;
+    for (size_t b = 0; b < nb; ++b) {
+        const uint64_t so = mv.stream_offset[f0 + b];
+        const vmd_raw_frame_t& fi = infos[b];
+        if (fi.f32_stride == 0 || so + fi.nbytes > mv.bytes) return 0;
+        for (int c = 0; c < 3; ++c)
+            if (((so + fi.f32_offset[c]) & 3u) != 0 || fi.f32_offset[c] + 4ull * fi.f32_stride * (num_atoms - 1) + 4 > fi.nbytes) return 0;
+        lo64 = std::min(lo64, so);
+        hi64 = std::max(hi64, so + fi.nbytes);
+    }
+    const size_t lo = (size_t)(lo64 & ~(uint64_t)7), hi = (size_t)hi64;
+    if (hi <= lo || !mapreg_pin(mv.base, mv.bytes, lo, hi)) return 0;
+    HostTimer map_timer("host_raw_map");
+    rs.f32.resize(nb);
+    for (size_t b = 0; b < nb; ++b) {
+        vmd_f32_frame_t& o = rs.f32[b];
+        memset(&o, 0, sizeof(o));
+        for (int c = 0; c < 3; ++c) o.offset[c] = mv.stream_offset[f0 + b] - lo + infos[b].f32_offset[c];
+        o.stride = infos[b].f32_stride; o.flags = infos[b].f32_flags; o.scale = infos[b].f32_scale;
+    }
+    rs.info_bytes = (nb * sizeof(vmd_f32_frame_t) + 255) & ~(size_t)255;
+    if (rs.info_bytes > rs.hcap) {
+        if (rs.h) (void)hipHostFree(rs.h);
+        rs.h = nullptr; rs.hcap = 0;
+        if (hipHostMalloc((void**)&rs.h, 2 * rs.info_bytes, hipHostMallocDefault) != hipSuccess) { vmd_fail("hipHostMalloc(%zu bytes) failed", 2 * rs.info_bytes); return -1; }
+        rs.hcap = 2 * rs.info_bytes;
+    }
+    memcpy(rs.h, rs.f32.data(), nb * sizeof(vmd_f32_frame_t));
+    rs.h_streams = mv.base + lo;
+    const size_t span = hi - lo;
+    if (!rs.d.ensure(rs.info_bytes + span + span / 8 + 64)) return -1;
+    if (hipMemcpyAsync(rs.d.p, rs.h, nb * sizeof(vmd_f32_frame_t), hipMemcpyHostToDevice, e->copy_stream) != hipSuccess) { vmd_fail("hipMemcpyAsync of the frame table failed"); return -1; }
+    for (size_t a = lo; a < hi;) {                          // one copy per pinned window the span touches
+        const size_t stop = std::min(hi, (a / kMapWindow + 1) * kMapWindow);
+        if (hipMemcpyAsync(rs.d.p + rs.info_bytes + (a - lo), mv.base + a, stop - a, hipMemcpyHostToDevice, e->copy_stream) != hipSuccess) { vmd_fail("hipMemcpyAsync from the mapped trajectory file failed"); return -1; }
+        a = stop;
+    }
+    if (hipEventRecord(rs.uploaded, e->copy_stream) != hipSuccess) { vmd_fail("hipEventRecord failed"); return -1; }
+    e->frames_mapped += nb;
+    rs.state = 1;
+    return 1;
+}
+
 // First half of the compressed path: read the bit streams of frames [f0, f0 + nb) into the slot's pinned block (load threads) and queue
 // their DMA on copy_stream.  1 = queued (slot.uploaded recorded), 0 = a frame is not available raw, -1 error.
 static int raw_upload(vmd_script_eval_t* e, RawSlot& rs, vmd_trajectory_i* traj, size_t num_atoms, size_t f0, size_t nb) {
@@ -1404,7 +1459,8 @@ static int raw_upload(vmd_script_eval_t* e, RawSlot& rs, vmd_trajectory_i* traj,
     size_t total = 0;
     for (size_t b = 0; b < nb; ++b) {                      // sizes first (no payload), then one pinned block for the batch
         vmd_frame_header_t hdr;
-        if (!traj->load_raw(traj->inst, (int64_t)(f0 + b), &hdr, &infos[b], nullptr, 0) || infos[b].codec != VMD_RAW_CODEC_XTC || hdr.num_atoms != num_atoms) { rs.state = -1; return 0; }
+        if (!traj->load_raw(traj->inst, (int64_t)(f0 + b), &hdr, &infos[b], nullptr, 0) || hdr.num_atoms != num_atoms || infos[b].codec != infos[0].codec ||
+            (infos[b].codec != VMD_RAW_CODEC_XTC && infos[b].codec != VMD_RAW_CODEC_F32)) { rs.state = -1; return 0; }
         rs.cells[b] = hdr.unitcell;
         vmd_xtc_frame_t& fi = rs.info[b];
         fi.precision = infos[b].precision;
@@ -1413,6 +1469,13 @@ static int raw_upload(vmd_script_eval_t* e, RawSlot& rs, vmd_trajectory_i* traj,
         fi.offset = total;
         fi.nbytes = infos[b].nbytes;
         total += ((size_t)infos[b].nbytes + 32 + 63) & ~(size_t)63;     // >= 32 readable bytes behind every stream, 64-byte aligned starts
+    }
+    rs.codec = infos[0].codec;
+    if (rs.codec == VMD_RAW_CODEC_F32) {
+        // plain floats (TRR, DCD): only out of the mapped file - copying them through a pinned block first is what load_frame does
+        const int up = raw_upload_f32(e, rs, traj, infos, num_atoms, f0, nb);
+        if (up <= 0) rs.state = -1;
+        return up;
     }
     rs.info_bytes = (nb * sizeof(vmd_xtc_frame_t) + 255) & ~(size_t)255;
     // The file is mapped: the copy engine takes the batch's span of it as it lies there (frame headers in between and all), this
@@ -1548,7 +1611,7 @@ static bool fetch_stage(vmd_script_eval_t* e, Stage& st, vmd_trajectory_i* traj,
             raw = launch_raw_decode(e, st, rv.base, (const vmd_xtc_frame_t*)rv.info + f0, num_atoms, nb, npad, ss,
                                     rv.ck ? (vmd_xtc_ck_t*)rv.ck + f0 * VMD_XTC_CK_MAX : nullptr, rv.nck ? rv.nck + f0 : nullptr, rv.ck_have ? rv.ck_have + f0 : nullptr);
             if (raw < 0) return false;
-        } else if (!force_host && g_opt.xtc_device_decode.load() && traj->load_raw) {
+        } else if (!force_host && g_opt.xtc_device_decode.load() && traj->load_raw && !(e->raw_skip && !pre)) {
             // the bit streams were (or are now) sent ahead through a slot of the ring; decompression runs on its own stream
             RawSlot* rs = (pre && pre->f0 == f0 && pre->nb == nb && pre->state != 0) ? pre : &e->raw_slots[0];
             if (rs != pre && (raw = raw_upload(e, *rs, traj, num_atoms, f0, nb)) < 0) return false;
@@ -1556,6 +1619,14 @@ static bool fetch_stage(vmd_script_eval_t* e, Stage& st, vmd_trajectory_i* traj,
                 ss = e->decode_stream;
                 st.cells = rs->cells;
                 HIP_OK(hipStreamWaitEvent(ss, rs->uploaded, 0));
+                if (rs->codec == VMD_RAW_CODEC_F32) {
+                    if (!st.d.ensure(nb * 3 * npad)) return false;
+                    e->prof_copy.begin("raw_f32", ss);
+                    KRN_OK(vmd_hip_raw_f32_decode(ss, rs->d_streams(), (const vmd_f32_frame_t*)rs->d.p, (int)nb, (int)num_atoms, st.d.p, 3 * npad, npad));
+                    e->prof_copy.end(ss);
+                    e->frames_device_decoded += nb;
+                    raw = 1;
+                } else {
                 std::shared_ptr<CkCache> cc = ckcache_for(traj->inst, traj->num_frames(traj->inst), num_atoms, e->device);
                 e->ck_cache = cc;
                 if (cc) {
@@ -1569,6 +1640,7 @@ static bool fetch_stage(vmd_script_eval_t* e, Stage& st, vmd_trajectory_i* traj,
                     raw = launch_raw_decode(e, st, rs->d_streams(), rs->d_info(), num_atoms, nb, npad, ss);
                 }
                 if (raw < 0) return false;
+                }
             } else {
                 raw = 0;
             }
@@ -1985,15 +2057,25 @@ static bool process_range(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
     // compressed frames for the device decoder travel two batches ahead through a ring of three slots (RawSlot)
     vmd_host_view_t hv_probe;
     vmd_raw_device_view_t rv_probe;
-    const bool raw_ring = !have_view && traj->load_raw && g_opt.xtc_device_decode.load() != 0 &&
-                          !(traj->host_view && traj->host_view(traj->inst, &hv_probe)) &&
-                          !(traj->raw_device_view && traj->raw_device_view(traj->inst, &rv_probe));
+    bool raw_ring = !have_view && traj->load_raw && g_opt.xtc_device_decode.load() != 0 &&
+                    !(traj->host_view && traj->host_view(traj->inst, &hv_probe)) &&
+                    !(traj->raw_device_view && traj->raw_device_view(traj->inst, &rv_probe));
+    vmd_raw_mapped_view_t mv_probe;
+    memset(&mv_probe, 0, sizeof(mv_probe));
+    const bool have_map = raw_ring && g_opt.xtc_mapped.load() && traj->raw_mapped_view && traj->raw_mapped_view(traj->inst, &mv_probe);
+    // plain-float files (TRR, DCD) take the ring only out of a mapping: without one their frames go through load_frame as before
+    bool f32_ring = false;
+    if (raw_ring && frame_beg < frame_end) {
+        vmd_raw_frame_t probe;
+        memset(&probe, 0, sizeof(probe));
+        if (!traj->load_raw(traj->inst, (int64_t)frame_beg, nullptr, &probe, nullptr, 0)) raw_ring = false;
+        else if (probe.codec == VMD_RAW_CODEC_F32) { f32_ring = have_map && mv_probe.codec == VMD_RAW_CODEC_F32 && g_opt.raw_f32_device.load(); raw_ring = f32_ring; }
+    }
+    e->raw_skip = traj->load_raw && !raw_ring;              // fetch_stage: do not ask this trajectory for raw frames batch by batch
     // how many batches the bit streams run ahead of the kernels (one more than the decoder, which runs two ahead).  Copied through
     // pinned blocks (host threads read them, this thread waits): 3.  Taken out of the mapped file by the copy engine alone: as many as the ring holds minus the one being decoded - the
     // DMAs then queue back to back and PCIe never waits for this thread (r03n: 12.4 ms per c2 step against 9.4 ms of transfers).
-    vmd_raw_mapped_view_t mv_probe;
-    const size_t raw_ahead = (raw_ring && g_opt.xtc_mapped.load() && g_opt.xtc_device_decode.load() == 3 && traj->raw_mapped_view &&
-                              traj->raw_mapped_view(traj->inst, &mv_probe)) ? vmd_script_eval_t::kRawSlots - 1 : 3;      // always > stage_ahead
+    const size_t raw_ahead = (raw_ring && have_map && (f32_ring || g_opt.xtc_device_decode.load() == 3)) ? vmd_script_eval_t::kRawSlots - 1 : 3;      // always > stage_ahead
     auto slot_of = [&](size_t bi) -> RawSlot* { return raw_ring ? &e->raw_slots[bi % vmd_script_eval_t::kRawSlots] : nullptr; };
     // batches decompressed on the device while the previous batch is in the pair kernel: the persistent pair grid leaves room for them
     const bool device_decode = raw_ring || (!have_view && traj->raw_device_view && traj->raw_device_view(traj->inst, &rv_probe));
@@ -2009,8 +2091,8 @@ static bool process_range(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
     // with batches of 128 against 51.3k with 512) and one large batch from HBM (103.8k against 98.8k).
     if (!have_view && g_opt.batch_frames <= 0) {
         const size_t S = (size_t)std::max(1, g_opt.stage_frames.load());
-        bool warm = false;                                  // does the first frame of the range have checkpoints already?
-        if (device_decode && g_opt.xtc_checkpoints.load() && frame_beg < frame_end) {
+        bool warm = f32_ring;                               // does the first frame of the range have checkpoints already?  (plain floats need none)
+        if (!f32_ring && device_decode && g_opt.xtc_checkpoints.load() && frame_beg < frame_end) {
             if (raw_ring) {
                 std::lock_guard<std::mutex> l(g_ck_mtx);
                 auto it = g_ck_store.find(traj->inst);

@@ -25,6 +25,7 @@
 //   (XTC: fl(fl(int * fl(1/precision)) * 10), the xdrfile float followed by the unit conversion).
 //   Box rows are the lattice vectors a = (x,0,0), b = (xy,y,0), c = (xz,yz,z) of md_unitcell_t.
 #include <algorithm>
+#include <atomic>
 #include <climits>
 #include <cmath>
 #include <cstdint>
@@ -241,7 +242,7 @@ struct Xdr {
     std::string path;
     // the file mapped read-only on first request (raw_mapped_view): the evaluator DMAs compressed frames straight out of it
     std::mutex map_mtx;
-    const unsigned char* map = nullptr;
+    std::atomic<const unsigned char*> map{nullptr};
     size_t map_bytes = 0;
     bool map_failed = false;
     std::vector<uint64_t> stream_off;
@@ -563,8 +564,40 @@ bool xdr_load_frame(void* inst, int64_t idx, vmd_frame_header_t* hdr, float* x, 
 
 // The frame as stored, for the device decoder (vmd_trajectory_i::load_raw): decoder parameters in host byte order, the bit
 // stream copied verbatim.  false = not available raw (TRR, frames of <= 9 atoms stored as floats): the caller uses load_frame.
+// TRR: the position block as it lies in the file (big-endian nm, xyz interleaved), for the evaluator's mapped-file path; `info` only
+bool trr_load_raw(Xdr* d, int64_t idx, vmd_frame_header_t* hdr, vmd_raw_frame_t* info, void* dst) {
+    if (idx < 0 || (size_t)idx >= d->frames.size() || !info || dst) return false;
+    const FrameRec& r = d->frames[(size_t)idx];
+    if (r.real_size != 4) return false;                       // double precision files go through load_frame
+    memset(info, 0, sizeof(*info));
+    info->codec = VMD_RAW_CODEC_F32;
+    const uint64_t x0 = (uint64_t)r.box_size + r.skip_size;
+    for (int a = 0; a < 3; ++a) info->f32_offset[a] = x0 + 4u * (unsigned)a;
+    info->f32_stride = 3;
+    info->f32_flags = VMD_RAW_F32_BIG_ENDIAN;
+    info->f32_scale = 10.0f;
+    info->nbytes = x0 + r.x_size;
+    if (hdr) {
+        memset(hdr, 0, sizeof(*hdr));
+        hdr->num_atoms = d->num_atoms;
+        hdr->index = idx;
+        hdr->timestamp = r.time;
+        if (r.box_size) {
+            unsigned char b[36];
+            const unsigned char* mb = d->map.load(std::memory_order_acquire);
+            if (mb) memcpy(b, mb + r.off + r.head, sizeof(b));
+            else if (!read_at(d->fd, b, sizeof(b), r.off + r.head)) return false;
+            float box[9];
+            for (int k = 0; k < 9; ++k) box[k] = be_f32(b + 4 * k);
+            hdr->unitcell = cell_from_box_nm(box);
+        }
+    }
+    return true;
+}
+
 bool xdr_load_raw(void* inst, int64_t idx, vmd_frame_header_t* hdr, vmd_raw_frame_t* info, void* dst, size_t cap) {
     Xdr* d = (Xdr*)inst;
+    if (d->kind == KIND_TRR) return trr_load_raw(d, idx, hdr, info, dst);
     if (d->kind != KIND_XTC || idx < 0 || (size_t)idx >= d->frames.size() || !info) return false;
     const FrameRec& r = d->frames[(size_t)idx];
     if (r.raw) return false;
@@ -587,29 +620,30 @@ bool xdr_load_raw(void* inst, int64_t idx, vmd_frame_header_t* hdr, vmd_raw_fram
 // cannot hand over raw make the whole file unmappable (load_raw refuses them one by one, the evaluator then decodes on the host).
 bool xdr_raw_mapped_view(void* inst, vmd_raw_mapped_view_t* out) {
     Xdr* d = (Xdr*)inst;
-    if (d->kind != KIND_XTC || !out || d->frames.empty()) return false;
+    if (!out || d->frames.empty()) return false;
     std::lock_guard<std::mutex> lk(d->map_mtx);
     if (d->map_failed) return false;
-    if (!d->map) {
+    if (!d->map.load()) {
         struct stat sb;
         if (fstat(d->fd, &sb) != 0 || sb.st_size <= 0) { d->map_failed = true; return false; }
         const FrameRec& last = d->frames.back();
-        if (last.off + last.head + last.bytes > (uint64_t)sb.st_size) { d->map_failed = true; return false; }   // truncated since it was indexed
+        const uint64_t last_end = last.off + last.head + (d->kind == KIND_XTC ? last.bytes : (uint64_t)last.box_size + last.skip_size + last.x_size);
+        if (last_end > (uint64_t)sb.st_size) { d->map_failed = true; return false; }   // truncated since it was indexed
         void* m = mmap(nullptr, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE, d->fd, 0);
         if (m == MAP_FAILED) { d->map_failed = true; return false; }
         (void)madvise(m, (size_t)sb.st_size, MADV_SEQUENTIAL);
         d->stream_off.resize(d->frames.size());
         for (size_t i = 0; i < d->frames.size(); ++i) {
-            if (d->frames[i].raw) { munmap(m, (size_t)sb.st_size); d->map_failed = true; return false; }
+            if (d->kind == KIND_XTC ? d->frames[i].raw : d->frames[i].real_size != 4) { munmap(m, (size_t)sb.st_size); d->map_failed = true; return false; }
             d->stream_off[i] = d->frames[i].off + d->frames[i].head;
         }
-        d->map = (const unsigned char*)m;
         d->map_bytes = (size_t)sb.st_size;
+        d->map.store((const unsigned char*)m, std::memory_order_release);
     }
-    out->base = d->map;
+    out->base = d->map.load();
     out->bytes = d->map_bytes;
     out->stream_offset = d->stream_off.data();
-    out->codec = VMD_RAW_CODEC_XTC;
+    out->codec = d->kind == KIND_XTC ? VMD_RAW_CODEC_XTC : VMD_RAW_CODEC_F32;
     return true;
 }
 
@@ -792,9 +826,9 @@ extern "C" vmd_xdrtraj_t* vmd_xdrtraj_open(const char* path) {
     d.iface.load_frame = xdr_load_frame;
     d.iface.device_view = nullptr;
     d.iface.host_view = nullptr;
-    d.iface.load_raw = d.kind == KIND_XTC ? xdr_load_raw : nullptr;
+    d.iface.load_raw = xdr_load_raw;
     d.iface.raw_device_view = nullptr;
-    d.iface.raw_mapped_view = d.kind == KIND_XTC ? xdr_raw_mapped_view : nullptr;
+    d.iface.raw_mapped_view = xdr_raw_mapped_view;
     return t;
 }
 
@@ -803,9 +837,9 @@ extern "C" void vmd_mapreg_drop(const void* base);       // vmd_eval.cpp: the pi
 extern "C" void vmd_xdrtraj_close(vmd_xdrtraj_t* t) {
     if (!t) return;
     vmd_ckcache_drop(&t->d);
-    if (t->d.map) {
-        vmd_mapreg_drop(t->d.map);
-        munmap((void*)t->d.map, t->d.map_bytes);
+    if (const unsigned char* m = t->d.map.load()) {
+        vmd_mapreg_drop(m);
+        munmap((void*)m, t->d.map_bytes);
     }
     if (t->d.fd >= 0) close(t->d.fd);
     delete t;

@@ -639,6 +639,33 @@ extern "C" size_t vmd_hip_xtc_scratch_bytes(int B, int natoms, int chunk) {
     return (size_t)B * maxck * 16 + (size_t)B * 4 + 64;
 }
 
+// ---- plain floats (TRR / DCD frames DMA'd out of the mapped file): one thread per atom, one block row per frame
+__global__ __launch_bounds__(256) void k_raw_f32(const unsigned char* __restrict__ raw, const vmd_f32_frame_t* __restrict__ info, int natoms,
+                                                 float* __restrict__ xyz, size_t frame_stride, size_t row_stride) {
+    const int f = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= natoms) return;
+    const vmd_f32_frame_t fi = info[f];
+    float* out = xyz + (size_t)f * frame_stride + (size_t)i;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        uint32_t w = *(const uint32_t*)(raw + fi.offset[c] + 4ull * fi.stride * (uint64_t)i);
+        if (fi.flags & 1u) w = __builtin_bswap32(w);
+        float v;
+        __builtin_memcpy(&v, &w, 4);
+        if (fi.scale != 1.0f) v = v * fi.scale;
+        out[(size_t)c * row_stride] = v;
+    }
+}
+
+extern "C" int vmd_hip_raw_f32_decode(void* stream, const unsigned char* raw, const vmd_f32_frame_t* info, int B, int natoms,
+                                      float* xyz, size_t frame_stride, size_t row_stride) {
+    if (B <= 0 || natoms <= 0) return 0;
+    hipLaunchKernelGGL(k_raw_f32, dim3((unsigned)((natoms + 255) / 256), (unsigned)B), dim3(256), 0, (hipStream_t)stream, raw, info, natoms, xyz,
+                       frame_stride, row_stride);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 extern "C" int vmd_hip_xtc_decode_chunked(void* stream, const unsigned char* raw, const vmd_xtc_frame_t* info, int B, int natoms,
                                           float* xyz, size_t frame_stride, size_t row_stride, uint32_t* status, int chunk,
                                           void* scratch) {
