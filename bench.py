@@ -339,7 +339,7 @@ def run_workload(name, args, ctx, steps, warmup, frames=None, with_cpu=False, op
     achieved = alg_bytes / t_launch / 1e9 if t_launch > 0 else 0.0
     step_gbs = 12.0 * w["atoms"] * local_frames * steps / elapsed / 1e9       # the same bytes against the whole timed region (this rank)
 
-    traffic, traffic_src, valu = None, None, None
+    traffic, traffic_src, valu, counters_current = None, None, None, None
     try:
         pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))[name]
         k = pt["kernels"]["k_" + dom]
@@ -354,6 +354,10 @@ def run_workload(name, args, ctx, steps, warmup, frames=None, with_cpu=False, op
             valu = {"insts_per_frame": per_frame_insts, "achieved": rate, "peak": VALU_PEAK_WINST_S, "unit": "wave64 VALU instructions/s",
                     "frac": rate / VALU_PEAK_WINST_S, "cycles_per_inst_assumed": VALU_CYCLES_PER_INST,
                     "source": f"SQ_INSTS_VALU, profiles/pmc_traffic.json ({pt['source']}); peak: profiles/r02_valu_calibration.txt"}
+        # the counters are read from a committed collection, not measured by this run: say whether the kernels have changed since
+        import hashlib
+        ksha = hashlib.sha256(open(os.path.join(ROOT, "viamd_amd", "csrc", "vmd_kernels.hip"), "rb").read()).hexdigest()[:16]
+        counters_current = (pt.get("kernels_sha256_16") == ksha) if pt.get("kernels_sha256_16") else None
         traffic_src = (f"profiles/pmc_traffic.json ({pt['source']}): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, "
                        f"(2 x FETCH_SIZE + WRITE_SIZE) KiB*1024 per frame x frames_per_launch; uncorrected: "
                        f"{k['hbm_bytes_per_frame_raw'] * frames_per_launch:.4g}")
@@ -383,6 +387,7 @@ def run_workload(name, args, ctx, steps, warmup, frames=None, with_cpu=False, op
         "voxel_hits_per_s": voxel_hits * steps / elapsed,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                     "traffic_counters_match_kernel_source": counters_current,     # None: the collection predates the marker
                      "kernel": "k_" + dom, "avg_launch_ms": t_launch * 1e3, "launches": nl,
                      "algorithmic_bytes_per_launch": alg_bytes, "frames_per_launch": frames_per_launch, "valu": valu,
                      "step_level": {"achieved": step_gbs, "frac": step_gbs / HBM_PEAK_GBS,

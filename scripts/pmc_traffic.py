@@ -23,7 +23,11 @@ for f in sorted(glob.glob(os.path.join(src, "p*", "**", "*counter_collection.csv
     for (k, d, c), v in per.items():
         acc[k][c].append(v)
 res = json.load(open(out)) if os.path.exists(out) else {}
-res[workload] = {"frames_per_launch": frames_per_launch, "source": os.path.basename(src.rstrip("/")), "kernels": {}}
+# the kernels these counters were collected on: bench.py compares this with the source it runs and says so when they differ
+import hashlib
+_ksrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "viamd_amd", "csrc", "vmd_kernels.hip")
+_ksha = hashlib.sha256(open(_ksrc, "rb").read()).hexdigest()[:16] if os.path.exists(_ksrc) else None
+res[workload] = {"frames_per_launch": frames_per_launch, "source": os.path.basename(src.rstrip("/")), "kernels_sha256_16": _ksha, "kernels": {}}
 for k in sorted(acc):
     def full(vals):
         # a kernel may also be launched on a few frames only (k_cells_bin in counting mode): keep the full-batch dispatches
