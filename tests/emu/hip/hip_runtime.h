@@ -107,7 +107,7 @@ static inline unsigned atomicMax(unsigned* p, unsigned v) { unsigned old = *p; i
 
 // ---- host runtime -------------------------------------------------------------------------------------------------
 typedef int hipError_t;
-enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2 };
+enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorNotReady = 600 };
 typedef struct emu_stream_t* hipStream_t;
 typedef struct emu_event_t* hipEvent_t;
 enum hipMemcpyKind { hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3 };

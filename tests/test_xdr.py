@@ -503,6 +503,20 @@ def test_xtc_batches_leave_the_mapped_file_by_dma(tmp_path, emu_lib, oracle):
             assert ev.frames_device_decoded() == F and ev.frames_mapped() == 0
         finally:
             emu_lib.vmd_set_option(b"xtc_mapped", old_m)
+        # the evaluator's own batch plan (no batch_frames): a first pass keeps several walks in flight on their own streams (batches of
+        # 2 x stage_frames, four staged ahead), the re-evaluation runs batches of stage_frames one ahead
+        emu_lib.vmd_set_option(b"batch_frames", 0)
+        old_s = emu_lib.vmd_set_option(b"stage_frames", 1)
+        try:
+            xt3 = V.XdrTrajectory(p, lib=emu_lib)
+            for rep in range(2):
+                ev = V.ScriptEval(F, ir)
+                assert ev.frame_range(sysm, xt3, 0, F)
+                np.testing.assert_array_equal(ev.property_data("g").counts, want)
+                assert ev.frames_mapped() == F and ev.frames_section_decoded() == (F if rep else 0)
+        finally:
+            emu_lib.vmd_set_option(b"stage_frames", old_s)
+            emu_lib.vmd_set_option(b"batch_frames", 4)
         # the driver refuses to pin the mapping (emulator switch): the window is marked refused, batches take the copy
         os.environ["VIAMD_EMU_NO_HOST_REGISTER"] = "1"
         try:

@@ -89,6 +89,7 @@ struct Options {
     std::atomic<int> xtc_ramp{0};            // file-backed device decode: small first and last batches (pipeline fill / drain); r03o: no gain, off
     std::atomic<int> xtc_decode_ahead{1};    // batches the device decoder runs ahead of the kernels (1 or 2); r03n: 2 changes nothing
     std::atomic<int> raw_f32_device{1};      // TRR / DCD: frames DMA'd out of the mapped file, swapped / scaled / transposed by k_raw_f32 (0: host threads)
+    std::atomic<int> xtc_cold_streams{1};    // first pass out of a mapped file: up to four batches walked side by side on their own streams
     std::atomic<int> xtc_mapped{1};          // variant 3: DMA the compressed frames straight out of the mapped file (raw_mapped_view), no host copy
     std::atomic<int> xtc_map_limit_mb{0};    // pinned bytes of mapped files, all trajectories together (0 = half of the physical memory)
     std::atomic<int> xtc_checkpoints{1};     // variant 3: the first decode of a frame leaves checkpoints, later ones decode it in sections
@@ -132,6 +133,7 @@ extern "C" int vmd_set_option(const char* key, int value) {
     else if (!strcmp(key, "xtc_chunk")) o = &g_opt.xtc_chunk;
     else if (!strcmp(key, "xtc_checkpoints")) o = &g_opt.xtc_checkpoints;
     else if (!strcmp(key, "xtc_mapped")) o = &g_opt.xtc_mapped;
+    else if (!strcmp(key, "xtc_cold_streams")) o = &g_opt.xtc_cold_streams;
     else if (!strcmp(key, "raw_f32_device")) o = &g_opt.raw_f32_device;
     else if (!strcmp(key, "xtc_ramp")) o = &g_opt.xtc_ramp;
     else if (!strcmp(key, "xtc_decode_ahead")) o = &g_opt.xtc_decode_ahead;
@@ -235,12 +237,15 @@ struct Profiler {
     void resolve() {   // call after the stream is synchronised
         if (pending.empty()) return;
         std::lock_guard<std::mutex> l(g_prof_mtx);
+        std::vector<ProfPending> later;
         for (auto& p : pending) {
             float ms = 0.0f;
-            if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) { g_prof[p.name].ms += ms; g_prof[p.name].launches += 1; }
+            const hipError_t rc = hipEventElapsedTime(&ms, p.a, p.b);
+            if (rc == hipErrorNotReady) { (void)hipGetLastError(); later.push_back(p); continue; }     // queued on another stream, still running
+            if (rc == hipSuccess) { g_prof[p.name].ms += ms; g_prof[p.name].launches += 1; }
             pool.push_back(p.a); pool.push_back(p.b);
         }
-        pending.clear();
+        pending.swap(later);
     }
     ~Profiler() { for (auto e : pool) hipEventDestroy(e); for (auto& p : pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); } }
 };
@@ -687,7 +692,8 @@ struct vmd_script_eval_t {
         // device views: the range whose cells / boxes this stage holds (host vectors and d_boxes), 0 = none
         const vmd_unitcell_t* boxes_cells = nullptr; size_t boxes_f0 = 0, boxes_nb = 0; uint64_t boxes_version = 0;
     };
-    Stage stages[3];                         // batch k evaluated, k + 1 (device decode: and k + 2) being staged
+    static constexpr size_t kDecodeStreams = 4;
+    Stage stages[kDecodeStreams + 1];        // batch k evaluated, k + 1 (first pass of a compressed file: up to k + 4) being staged
     // compressed batches on their way to the device decoder, a ring of three: while the pair kernels of batch k run, batch k + 1 is
     // being decompressed (decode_stream) and the bit streams of batch k + 2 cross PCIe (copy_stream) - three engines, three batches
     struct RawSlot {
@@ -711,7 +717,10 @@ struct vmd_script_eval_t {
     std::atomic<size_t> frames_section_decoded{0};
     std::atomic<size_t> frames_mapped{0};
     bool raw_skip = false;                   // the range being evaluated does not use the raw ring (set by the leader in evaluate_range)
-    hipStream_t decode_stream = nullptr;
+    hipStream_t decode_stream = nullptr;     // = decode_streams[0]
+    // A first pass over compressed frames walks every bit stream from its start: one dependent chain per frame, ~7 ms for a c2 frame
+    // however many frames the launch holds.  Several batches walk side by side on their own streams while their successors cross PCIe.
+    hipStream_t decode_streams[kDecodeStreams] = {nullptr, nullptr, nullptr, nullptr};
     hipStream_t copy_stream = nullptr;
     hipStream_t aux_stream = nullptr;        // background work nothing else queues behind (the clearing DMA of a volume's host view)
     DevBuf<uint64_t> d_partial;
@@ -848,7 +857,9 @@ extern "C" vmd_script_eval_t* vmd_eval_create(size_t num_frames, const vmd_scrip
     {   // the decoder's waves should get the wave slots the pair kernel leaves free as soon as a batch has arrived: highest priority
         int lo = 0, hi = 0;
         if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { lo = hi = 0; }
-        if (hipStreamCreateWithPriority(&e->decode_stream, hipStreamNonBlocking, hi) != hipSuccess) { vmd_fail("hipStreamCreate failed"); return nullptr; }
+        for (auto& ds : e->decode_streams)
+            if (hipStreamCreateWithPriority(&ds, hipStreamNonBlocking, hi) != hipSuccess) { vmd_fail("hipStreamCreate failed"); return nullptr; }
+        e->decode_stream = e->decode_streams[0];
     }
     for (auto& rs : e->raw_slots) if (hipEventCreateWithFlags(&rs.uploaded, hipEventDisableTiming) != hipSuccess) { vmd_fail("hipEventCreate failed"); return nullptr; }
     for (auto& st : e->stages) if (hipEventCreate(&st.ready) != hipSuccess) { vmd_fail("hipEventCreate failed"); return nullptr; }
@@ -929,7 +940,7 @@ extern "C" void vmd_eval_free(vmd_script_eval_t* eval) {
         if (eval->stream) { (void)hipStreamSynchronize(eval->stream); }
         if (eval->copy_stream) { (void)hipStreamSynchronize(eval->copy_stream); }
         if (eval->aux_stream) { (void)hipStreamSynchronize(eval->aux_stream); }
-        if (eval->decode_stream) { (void)hipStreamSynchronize(eval->decode_stream); (void)hipStreamDestroy(eval->decode_stream); }
+        for (auto& ds : eval->decode_streams) { if (ds) { (void)hipStreamSynchronize(ds); (void)hipStreamDestroy(ds); } ds = nullptr; }
         eval->decode_stream = nullptr;
         for (auto& rs : eval->raw_slots) {
             if (rs.h) (void)hipHostFree(rs.h);
@@ -1616,7 +1627,7 @@ static bool fetch_stage(vmd_script_eval_t* e, Stage& st, vmd_trajectory_i* traj,
             RawSlot* rs = (pre && pre->f0 == f0 && pre->nb == nb && pre->state != 0) ? pre : &e->raw_slots[0];
             if (rs != pre && (raw = raw_upload(e, *rs, traj, num_atoms, f0, nb)) < 0) return false;
             if (rs->state == 1) {
-                ss = e->decode_stream;
+                ss = e->decode_streams[pre ? (size_t)(pre - e->raw_slots) % vmd_script_eval_t::kDecodeStreams : 0];
                 st.cells = rs->cells;
                 HIP_OK(hipStreamWaitEvent(ss, rs->uploaded, 0));
                 if (rs->codec == VMD_RAW_CODEC_F32) {
@@ -2080,6 +2091,7 @@ static bool process_range(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
     // batches decompressed on the device while the previous batch is in the pair kernel: the persistent pair grid leaves room for them
     const bool device_decode = raw_ring || (!have_view && traj->raw_device_view && traj->raw_device_view(traj->inst, &rv_probe));
 
+    bool cold_walk = false;
     // frames per launch: as many as the scratch budget allows, split evenly so that no small tail batch is left
     size_t Bmax = auto_batch(e, num_atoms, !have_view);
     const vmd_device_view_t* vw = have_view ? &view : nullptr;
@@ -2101,7 +2113,9 @@ static bool process_range(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
             }
             else warm = rv_probe.ck_have && rv_probe.ck_have[frame_beg];
         }
-        Bmax = std::min<size_t>(Bmax, !device_decode ? S : (raw_ring ? (warm ? S : 4 * S) : (warm ? 8 * S : 4 * S)));
+        // a first pass out of a mapped file keeps four walks in flight (stage_ahead below): half-size batches, twice as many
+        cold_walk = raw_ring && !f32_ring && !warm && have_map && g_opt.xtc_device_decode.load() == 3 && g_opt.xtc_cold_streams.load() != 0;
+        Bmax = std::min<size_t>(Bmax, !device_decode ? S : (raw_ring ? (warm ? S : (cold_walk ? 2 * S : 4 * S)) : (warm ? 8 * S : 4 * S)));
     }
     std::vector<Batch> batches;
     for (auto& sg : segments) plan_batches(e, sg.first, sg.second, Bmax, &batches);
@@ -2125,7 +2139,9 @@ static bool process_range(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
     // Batches staged ahead of the one being evaluated: one; optionally two when they are decompressed on the device (the decoder runs
     // UNDER the pair kernel, in the wave slots that kernel leaves).  r03n/r03p: the wait in settle_stage is the pipeline filling at the
     // start of a range, not a late decoder - two ahead measures the same, so one is the default.
-    const size_t stage_ahead = (raw_ring && g_opt.xtc_device_decode.load() == 3 && g_opt.xtc_decode_ahead.load() >= 2) ? 2 : 1;
+    // A FIRST pass (no checkpoints yet) out of a mapped file: the walks of up to four batches run side by side (decode_streams).
+    size_t stage_ahead = (raw_ring && g_opt.xtc_device_decode.load() == 3 && g_opt.xtc_decode_ahead.load() >= 2) ? 2 : 1;
+    if (cold_walk) stage_ahead = std::min<size_t>(vmd_script_eval_t::kDecodeStreams, raw_ahead - 1);
     auto stage_of = [&](size_t bi) -> Stage& { return e->stages[bi % (stage_ahead + 1)]; };
     struct BlocksGuard {
         int old = -1;
