@@ -258,13 +258,19 @@ def _device_decode(lib, blob, natoms, chunk=0, gpu=False):
     """Run vmd_hip_xtc_decode (emulator build: "device" memory is host memory) on every frame of an XTC byte string."""
     import ctypes as C
     from viamd_amd import _lib as L
-    off, infos, streams = 0, [], []
+    # chunk -3 / -4: k_xtc_wave (-1) / with checkpoints (-2) on the streams WHERE THE FILE HAS THEM (what the evaluator DMAs out of the
+    # mapped file): 4-byte aligned starts of both phases modulo 8, the next frame's header as the readable bytes behind a stream
+    file_layout = chunk in (-3, -4)
+    if file_layout:
+        chunk += 2
+    off, infos, streams, starts = 0, [], [], []
     while off < len(blob):
         n = struct.unpack_from(">i", blob, off + 4)[0]
         precision, = struct.unpack_from(">f", blob, off + 56)
         mm = struct.unpack_from(">7i", blob, off + 60)
         nbytes, = struct.unpack_from(">i", blob, off + 88)
         streams.append(blob[off + 92: off + 92 + nbytes])
+        starts.append(off + 92)
         infos.append((precision, mm[0:3], mm[3:6], mm[6], nbytes))
         off += 92 + ((nbytes + 3) & ~3)
         assert n == natoms
@@ -276,9 +282,13 @@ def _device_decode(lib, blob, natoms, chunk=0, gpu=False):
         arr[b].minint[:] = mi
         arr[b].maxint[:] = ma
         arr[b].smallidx = sidx
-        arr[b].offset = len(raw)
+        arr[b].offset = 8 + starts[b] if file_layout else len(raw)
         arr[b].nbytes = nbytes
-        raw += streams[b] + b"\0" * ((-len(streams[b])) % 64 + 64)
+        if not file_layout:
+            raw += streams[b] + b"\0" * ((-len(streams[b])) % 64 + 64)
+    if file_layout:
+        raw = bytearray(b"\xa5" * 8 + blob + b"\xa5" * 64)
+        assert len({int(a.offset) % 8 for a in arr}) == 2 or B < 4, "fixture without both phases"
     npad = (natoms + 63) & ~63
     if gpu:                    # the product library on a real GPU: torch owns the device memory (hipMalloc: 256-byte aligned)
         import torch
@@ -377,7 +387,7 @@ def _device_decoder_against_host_reader(tmp_path, lib, chunk, gpu, trials=25):
     assert rejected > 0
 
 
-@pytest.mark.parametrize("chunk", [0, 64, 300, -1, -2])
+@pytest.mark.parametrize("chunk", [0, 64, 300, -1, -2, -3, -4])
 def test_device_xtc_decoder_matches_the_host_reader(tmp_path, emu_lib, chunk):
     """k_xtc_decode (one GPU thread per frame), the two-pass k_xtc_index + k_xtc_chunks (one thread per chunk of `chunk` atoms) and
     k_xtc_wave (chunk -1: one wave per frame, speculative group walk; all here on the SIMT emulator) against the host reader on
@@ -387,7 +397,7 @@ def test_device_xtc_decoder_matches_the_host_reader(tmp_path, emu_lib, chunk):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("chunk", [-1, -2, 0, 128])
+@pytest.mark.parametrize("chunk", [-1, -2, -3, -4, 0, 128])
 def test_device_xtc_decoder_matches_the_host_reader_on_the_gpu(tmp_path, gpu_lib, chunk):
     """The same fixtures through the hipcc-built kernels on the MI355X (device memory from torch)."""
     _device_decoder_against_host_reader(tmp_path, gpu_lib, chunk, True, trials=10)
