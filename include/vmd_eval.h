@@ -126,6 +126,13 @@ typedef struct vmd_raw_device_view_t {
     void*     ck;
     uint32_t* nck;
     uint8_t*  ck_have;
+    /* optional (NULL / 0 = none): room for the decoder's group records (vmd_hip.h: vmd_hip_xtc_decode_wave_rec) - rec: device,
+     * num_frames x rec_stride 16-bit entries (rec_stride >= num_atoms); nrec: device, one counter per frame; rec_failed: host, set
+     * by the evaluator when a decode from records was rejected (it then walks the sections from their checkpoints again) */
+    uint16_t* rec;
+    uint32_t* nrec;
+    size_t    rec_stride;
+    bool*     rec_failed;
 } vmd_raw_device_view_t;
 
 /* A trajectory FILE mapped into the address space (read-only).  The evaluator pins the mapping (hipHostRegister, in windows) and the

@@ -217,6 +217,13 @@ typedef struct vmd_xtc_ck_t {
 int vmd_hip_xtc_decode_wave_ck(void* stream, const unsigned char* raw, const vmd_xtc_frame_t* info, int B, int natoms,
                                float* xyz, size_t frame_stride, size_t row_stride, uint32_t* status, int use,
                                vmd_xtc_ck_t* ck, uint32_t* nck);
+/* ... and with GROUP RECORDS next to the checkpoints: use = 0 also leaves one 16-bit record per decoded group (rec: B x rec_stride,
+ * rec_stride >= natoms; nrec: B counters, 0 = no records for the frame): the bits the group spans (10), its smallidx step + 1 (2), the
+ * atoms of its run (4).  use = 1 decodes from them (k_xtc_records): no walk, every tile of 64 groups is placed by three wave-wide
+ * prefix sums and decoded independently; a record that does not describe the group found at its place fails the frame (status 1). */
+int vmd_hip_xtc_decode_wave_rec(void* stream, const unsigned char* raw, const vmd_xtc_frame_t* info, int B, int natoms,
+                                float* xyz, size_t frame_stride, size_t row_stride, uint32_t* status, int use,
+                                vmd_xtc_ck_t* ck, uint32_t* nck, uint16_t* rec, uint32_t* nrec, size_t rec_stride);
 /* waves that share one frame in k_xtc_wave (each walks the whole stream and decodes every n-th tile of 64 groups); 0 = automatic
  * (enough to put ~4 waves on every SIMD of the chip); returns the previous value */
 int vmd_hip_set_xtc_waves(int n);

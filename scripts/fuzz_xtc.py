@@ -59,7 +59,7 @@ def main():
         want = ((ints.astype(np.float32) * (np.float32(1) / np.float32(precision))) * np.float32(10)).T
         assert np.array_equal(got, want), f"trial {t}: native decode differs (seed {seed})"
         assert np.array_equal(xtc_ref.parse_frames(nat)[0]["ints"], ints), f"trial {t}: python decode differs"
-        dev, status = test_xdr._device_decode(lib, nat, xyz.shape[1], chunk=(0, 64, 97, -1, -2, -3, -4)[t % 7])    # every device variant (-1: wave per frame, -2: + checkpointed second pass, -3 / -4: the same on streams laid out as in the file), on the SIMT emulator
+        dev, status = test_xdr._device_decode(lib, nat, xyz.shape[1], chunk=(0, 64, 97, -1, -2, -3, -4, -5, -6)[t % 9])    # every device variant (-1: wave per frame, -2: + checkpointed second pass, -3 / -4: the same on streams laid out as in the file), on the SIMT emulator
         assert status[0] in (0, 2), f"trial {t}: device decoder rejected a valid stream (seed {seed})"
         if status[0] == 0:
             assert np.array_equal(dev[0], want), f"trial {t}: device decode differs (seed {seed})"

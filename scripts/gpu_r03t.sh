@@ -1,0 +1,25 @@
+#!/bin/bash
+# r03t: group records - re-evaluation places every group from a 16-bit record, no walk (k_xtc_records) - against walking the sections
+T=${1:-r03t}; O=gpurun_out/$T; mkdir -p $O
+export HSA_ENABLE_IPC_MODE_LEGACY=0
+timeout 900 python -m pytest tests/test_zzz_xdr_gpu.py tests/test_xdr.py -m gpu -x -q > $O/pytest_xdr.log 2>&1; echo "pytest rc=$?"; tail -3 $O/pytest_xdr.log
+run() {  tag=$1; shift
+  timeout 600 python bench.py --workload c2 --no-cpu-baseline --steps 5 --warmup 2 "$@" > $O/bench_$tag.json 2>> $O/err.log
+  python - <<PY
+import json
+d=json.loads([l for l in open('$O/bench_$tag.json') if l.startswith('{')][-1])
+k=d['kernel_ms']; s=d['steps']; fp=d['config'].get('first_pass')
+print('$tag', round(d['value']), 'frames/s; first step', round(fp['frames_per_s']) if fp else None, {a: round(b/s,2) for a,b in k.items() if not a.startswith('host_q')})
+PY
+}
+run file_rec1 --traj xtc
+run file_rec0 --traj xtc --opt xtc_records=0
+run resident_rec1 --traj xtc-resident
+run resident_rec0 --traj xtc-resident --opt xtc_records=0
+run rw_file_rec1 --traj xtc --rigid-water
+run rw_file_rec0 --traj xtc --rigid-water --opt xtc_records=0
+run rw_resident_rec1 --traj xtc-resident --rigid-water
+run rw_resident_rec0 --traj xtc-resident --rigid-water --opt xtc_records=0
+run file_rec1_nodecblocks --traj xtc --opt rdf_blocks_decode=0
+run file_rec1_s256 --traj xtc --opt stage_frames=256
+tail -3 $O/err.log

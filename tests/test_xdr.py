@@ -260,6 +260,10 @@ def _device_decode(lib, blob, natoms, chunk=0, gpu=False):
     from viamd_amd import _lib as L
     # chunk -3 / -4: k_xtc_wave (-1) / with checkpoints (-2) on the streams WHERE THE FILE HAS THEM (what the evaluator DMAs out of the
     # mapped file): 4-byte aligned starts of both phases modulo 8, the next frame's header as the readable bytes behind a stream
+    # chunk -5 / -6: like -2 / -4 with GROUP RECORDS next to the checkpoints - the second pass places every group from them (k_xtc_records)
+    with_rec = chunk in (-5, -6)
+    if with_rec:
+        chunk += 3
     file_layout = chunk in (-3, -4)
     if file_layout:
         chunk += 2
@@ -322,7 +326,20 @@ def _device_decode(lib, blob, natoms, chunk=0, gpu=False):
             ck = np.zeros(B * CK * 4, np.uint32)
             nck = np.zeros(B, np.uint32)
             ck_p, nck_p = ck.ctypes.data, nck.ctypes.data
-        rc = lib.vmd_hip_xtc_decode_wave_ck(None, raw_p, info_p, B, natoms, out_p, 3 * npad, npad, status_p, 0, ck_p, nck_p)
+        stride = npad
+        if with_rec:
+            if gpu:
+                d_rec = torch.zeros(B * stride, dtype=torch.int16, device="cuda")
+                d_nrec = torch.zeros(B, dtype=torch.int32, device="cuda")
+                rec_p, nrec_p = d_rec.data_ptr(), d_nrec.data_ptr()
+            else:
+                rec = np.zeros(B * stride, np.uint16)
+                nrec = np.zeros(B, np.uint32)
+                rec_p, nrec_p = rec.ctypes.data, nrec.ctypes.data
+            two_pass = lambda use: lib.vmd_hip_xtc_decode_wave_rec(None, raw_p, info_p, B, natoms, out_p, 3 * npad, npad, status_p, use, ck_p, nck_p, rec_p, nrec_p, stride)
+        else:
+            two_pass = lambda use: lib.vmd_hip_xtc_decode_wave_ck(None, raw_p, info_p, B, natoms, out_p, 3 * npad, npad, status_p, use, ck_p, nck_p)
+        rc = two_pass(0)
         assert rc == 0
         if gpu:
             torch.cuda.synchronize()
@@ -335,7 +352,10 @@ def _device_decode(lib, blob, natoms, chunk=0, gpu=False):
             counts = nck
         if (st1 == 0).all():
             assert (counts >= 1).all() and (counts <= CK).all(), counts
-            rc = lib.vmd_hip_xtc_decode_wave_ck(None, raw_p, info_p, B, natoms, out_p, 3 * npad, npad, status_p, 1, ck_p, nck_p)
+            if with_rec:
+                ng = d_nrec.cpu().numpy() if gpu else nrec
+                assert (ng >= 1).all() and (ng <= natoms).all(), ng                  # every frame got its records: one per group
+            rc = two_pass(1)
             if gpu:
                 torch.cuda.synchronize()
                 second = d_out.cpu().numpy()
@@ -387,7 +407,7 @@ def _device_decoder_against_host_reader(tmp_path, lib, chunk, gpu, trials=25):
     assert rejected > 0
 
 
-@pytest.mark.parametrize("chunk", [0, 64, 300, -1, -2, -3, -4])
+@pytest.mark.parametrize("chunk", [0, 64, 300, -1, -2, -3, -4, -5, -6])
 def test_device_xtc_decoder_matches_the_host_reader(tmp_path, emu_lib, chunk):
     """k_xtc_decode (one GPU thread per frame), the two-pass k_xtc_index + k_xtc_chunks (one thread per chunk of `chunk` atoms) and
     k_xtc_wave (chunk -1: one wave per frame, speculative group walk; all here on the SIMT emulator) against the host reader on
@@ -397,7 +417,7 @@ def test_device_xtc_decoder_matches_the_host_reader(tmp_path, emu_lib, chunk):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("chunk", [-1, -2, -3, -4, 0, 128])
+@pytest.mark.parametrize("chunk", [-1, -2, -3, -4, -5, -6, 0, 128])
 def test_device_xtc_decoder_matches_the_host_reader_on_the_gpu(tmp_path, gpu_lib, chunk):
     """The same fixtures through the hipcc-built kernels on the MI355X (device memory from torch)."""
     _device_decoder_against_host_reader(tmp_path, gpu_lib, chunk, True, trials=10)
@@ -463,13 +483,18 @@ def test_xtc_batches_decoded_on_the_device_through_the_evaluator(tmp_path, emu_l
     # says, two evaluations in a row, several frame ranges; a TRR file has no compressed form
     old_b = emu_lib.vmd_set_option(b"batch_frames", 3)
     try:
-        ct = V.CompressedDeviceTrajectory(V.XdrTrajectory(p, lib=emu_lib))
-        assert 0 < ct.device_bytes() < coords.nbytes
-        for rep in range(2):
-            ev = V.ScriptEval(F, ir)
-            assert ev.frame_range(sysm, ct, 0, 4) and ev.frame_range(sysm, ct, 4, F)
-            np.testing.assert_array_equal(ev.property_data("g").counts, res[0])
-            assert ev.frames_device_decoded() == F
+        for records in (1, 2):              # 2: the resident object also keeps group records (a later pass walks nothing)
+            old_r = emu_lib.vmd_set_option(b"xtc_records", records)
+            try:
+                ct = V.CompressedDeviceTrajectory(V.XdrTrajectory(p, lib=emu_lib))
+            finally:
+                emu_lib.vmd_set_option(b"xtc_records", old_r)
+            assert 0 < ct.device_bytes() < coords.nbytes
+            for rep in range(2):
+                ev = V.ScriptEval(F, ir)
+                assert ev.frame_range(sysm, ct, 0, 4) and ev.frame_range(sysm, ct, 4, F)
+                np.testing.assert_array_equal(ev.property_data("g").counts, res[0])
+                assert ev.frames_device_decoded() == F and ev.frames_section_decoded() == (F if rep else 0)
         with pytest.raises(V.VmdError, match="compressed"):
             V.CompressedDeviceTrajectory(V.XdrTrajectory(q, lib=emu_lib))
     finally:

@@ -228,6 +228,8 @@ SIGNATURES = [
     ("vmd_hip_xtc_decode_wave", C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _vp, C.c_size_t, C.c_size_t, _vp]),
     ("vmd_hip_set_xtc_waves", C.c_int, [C.c_int]),
     ("vmd_hip_xtc_decode_wave_ck", C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _vp, C.c_size_t, C.c_size_t, _vp, C.c_int, _vp, _vp]),
+    ("vmd_hip_xtc_decode_wave_rec", C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _vp, C.c_size_t, C.c_size_t, _vp, C.c_int, _vp, _vp, _vp, _vp, C.c_size_t]),
+    ("vmd_hip_raw_f32_decode", C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _vp, C.c_size_t, C.c_size_t]),
     ("vmd_hip_xtc_scratch_bytes", C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     ("vmd_hip_xtc_decode_chunked", C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _vp, C.c_size_t, C.c_size_t, _vp, C.c_int, _vp]),
     ("vmd_hip_bbox", C.c_int, [_vp, _vp, C.c_size_t, C.c_size_t, C.c_int, C.c_int, _vp]),

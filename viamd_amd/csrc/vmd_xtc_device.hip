@@ -446,7 +446,8 @@ struct XtcBank { uint32_t r[XTC_BANK]; };   // 64-dword blocks of the stream, on
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_xtc_wave(const unsigned char* __restrict__ raw, const vmd_xtc_frame_t* __restrict__ info,
                                                  int B, int natoms, float* __restrict__ xyz, size_t frame_stride, size_t row_stride,
                                                  uint32_t* __restrict__ status, const vmd_xtc_ck_t* __restrict__ ck_in,
-                                                 vmd_xtc_ck_t* __restrict__ ck_out, uint32_t* __restrict__ nck, int ck_max, int ck_tiles) {
+                                                 vmd_xtc_ck_t* __restrict__ ck_out, uint32_t* __restrict__ nck, int ck_max, int ck_tiles,
+                                                 uint16_t* __restrict__ rec_out, uint32_t* __restrict__ nrec_out, uint32_t rec_stride) {
     // a serial walk issues one dependent instruction every few cycles: next to the VALU-bound waves of the pair kernel it would get a
     // seventh of the SIMD's issue slots and crawl.  At the highest wave priority it takes the slots it can use (a fifth of them) first.
     VMD_XTC_SETPRIO();
@@ -463,6 +464,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
     }
     const bool emit = ck_out != nullptr && !sectioned && blockIdx.y == 0;
     uint32_t tile_no = 0, emitted = 0, next_ck_tile = 0;
+    uint32_t ngroups = 0;                                         // groups decoded so far (rec_out: the record count of the frame)
+    bool rec_ok = true;
     const vmd_xtc_frame_t fi = info[f];
     FrameSetup fs;
     uint32_t st = xtc_setup(fi, fs);
@@ -482,9 +485,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
     float* x = xyz + (size_t)f * frame_stride;
     float* y = x + row_stride;
     float* z = y + row_stride;
-    // lane l keeps small radix XTC_FIRSTIDX + l and its reciprocals (64 lanes = the 64 legal values of smallidx)
-    const uint32_t my_magic = (uint32_t)kXtcMagic[XTC_FIRSTIDX + lane];
-    const double t_inv2 = 1.0 / (double)my_magic, t_inv12 = 1.0 / (double)((uint64_t)my_magic * my_magic);
 
     auto load_block = [&](uint32_t first) {
         uint32_t k = first + (uint32_t)lane;
@@ -510,7 +510,27 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
                 tile_no += 1;
                 const bool mine = turn == 0;
                 turn = mine ? nshare - 1 : turn - 1;
+                if (rec_out) {
+                    // group records (vmd_hip.h): what the NEXT decode of this frame needs to place a group without walking to it - the
+                    // bits it spans, how it moves smallidx, the run it leaves behind.  A lane's successor holds its after-state; the
+                    // last group's is the walk's own.  Every sharing wave sees the same lanes; the tile's owner writes.
+                    const int nl = lane + 1 < g ? lane + 1 : lane;
+                    uint32_t npos = VMD_SHFL_U32(vpos, nl), nstate = VMD_SHFL_U32(vstate, nl);
+                    if (lane == g - 1) { npos = pos; nstate = (uint32_t)smallidx | ((uint32_t)run << 8); }
+                    const uint32_t len = npos - vpos;
+                    const int dsm = (int)(nstate & 255u) - (int)(vstate & 255u) + 1;
+                    const uint32_t rq = (nstate >> 8) / 3u;
+                    const uint32_t slot = (tile_no - 1u) * 64u + (uint32_t)lane;
+                    const bool bad = lane < g && (len > 1023u || dsm < 0 || dsm > 2 || rq > 15u || slot >= rec_stride);
+                    if (VMD_XTC_BALLOT(bad)) rec_ok = false;
+                    else if (mine && lane < g) rec_out[(size_t)f * rec_stride + slot] = (uint16_t)(len | ((uint32_t)dsm << 10) | (rq << 12));
+                    ngroups += (uint32_t)g;
+                }
                 if (mine) {
+                    // lane l computes small radix XTC_FIRSTIDX + l and its reciprocals (64 lanes = the 64 legal values of smallidx) - here,
+                    // once per tile, not up front: five registers less across the walk, where the kernel sits at its 80-VGPR limit
+                    const uint32_t my_magic = (uint32_t)kXtcMagic[XTC_FIRSTIDX + lane];
+                    const double t_inv2 = 1.0 / (double)my_magic, t_inv12 = 1.0 / (double)((uint64_t)my_magic * my_magic);
                     const int sidx = (int)(vstate & 255u);
                     const int tl = (sidx - XTC_FIRSTIDX) & 63;
                     Radix small;
@@ -628,6 +648,107 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
         if (st) break;
     }
     if (emit && lane == 0) nck[f] = st ? 0u : emitted;
+    if (emit && rec_out && nrec_out && lane == 0) nrec_out[f] = (st || !rec_ok) ? 0u : ngroups;
+    if (st && lane == 0) atomicMax(&status[f], st);
+}
+
+// ---- decode from group records: no walk at all.  A first pass (k_xtc_wave with rec_out) left one 16-bit record per group - bits
+// it spans (10), smallidx step + 1 (2), atoms of its run (4) - and the decoder state at every ck_tiles-th tile boundary.  A section
+// (the groups between two checkpoints) is decoded tile by tile: 64 records, three wave-wide prefix sums (bit position, smallidx,
+// first atom), one group per lane with the arithmetic of the host reader.  What was a dependent chain of ~10k rounds per c2 frame is
+// 520 independent tiles; the kernel is bound by the frame's bytes (0.5 MB in, 1.2 MB out).
+__device__ __forceinline__ uint32_t xtc_scan_incl(uint32_t v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = VMD_SHFL_U32(v, (lane - d) & 63);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_xtc_records(const unsigned char* __restrict__ raw, const vmd_xtc_frame_t* __restrict__ info, int B, int natoms,
+                                                    float* __restrict__ xyz, size_t frame_stride, size_t row_stride, uint32_t* __restrict__ status,
+                                                    const vmd_xtc_ck_t* __restrict__ ck, const uint32_t* __restrict__ nck, int ck_max, int ck_tiles,
+                                                    const uint16_t* __restrict__ rec, const uint32_t* __restrict__ nrec, uint32_t rec_stride) {
+    VMD_XTC_SETPRIO();                                            // like k_xtc_wave: it runs in the wave slots the pair kernel leaves (80 VGPRs)
+    const int f = blockIdx.x;
+    const int lane = (int)threadIdx.x;
+    if (f >= B) return;
+    const int nsec = (int)nck[f];
+    const uint32_t ng = nrec[f];
+    if (nsec < 1 || nsec > ck_max || ng == 0u || ng > rec_stride) {            // no (valid) records for this frame: the caller's bug
+        if (lane == 0 && blockIdx.y == 0) atomicMax(&status[f], 1u);
+        return;
+    }
+    const vmd_xtc_frame_t fi = info[f];
+    FrameSetup fs;
+    uint32_t st = xtc_setup(fi, fs);
+    if (!st && fi.nbytes >= (1ull << 27)) st = 2;
+    if (st) {
+        if (lane == 0) atomicMax(&status[f], st);
+        return;
+    }
+    const unsigned char* stream = raw + fi.offset;
+    const uint64_t phase = (uint64_t)((uintptr_t)stream & 4u);
+    const uint32_t nbits = (uint32_t)(8ull * fi.nbytes);
+    float* x = xyz + (size_t)f * frame_stride;
+    float* y = x + row_stride;
+    float* z = y + row_stride;
+    const uint32_t my_magic = (uint32_t)kXtcMagic[XTC_FIRSTIDX + lane];
+    const double t_inv2 = 1.0 / (double)my_magic, t_inv12 = 1.0 / (double)((uint64_t)my_magic * my_magic);
+    const uint16_t* frec = rec + (size_t)f * rec_stride;
+    for (int sec = (int)blockIdx.y; sec < nsec; sec += (int)gridDim.y) {
+        const vmd_xtc_ck_t c = ck[(size_t)f * ck_max + sec];
+        uint32_t pos = c.pos;
+        int atom = (int)c.atom, sidx = (int)(c.state & 255u), run = (int)(c.state >> 8);
+        const uint32_t q0 = (uint32_t)sec * (uint32_t)ck_tiles * 64u;
+        const uint32_t q1 = sec + 1 < nsec ? (uint32_t)(sec + 1) * (uint32_t)ck_tiles * 64u : ng;
+        if (q0 >= q1 || q1 > ng || pos > nbits || atom < 0 || atom >= natoms || sidx < XTC_FIRSTIDX || sidx >= XTC_LASTIDX || run > 30 || run % 3) { st = 1; break; }
+        for (uint32_t q = q0; q < q1 && !st; q += 64u) {
+            const int n = (int)(q1 - q < 64u ? q1 - q : 64u);
+            const uint32_t r = lane < n ? (uint32_t)frec[q + (uint32_t)lane] : 0u;
+            const uint32_t len = r & 1023u, rq = r >> 12;
+            const uint32_t dsm1 = lane < n ? ((r >> 10) & 3u) : 1u;               // smallidx step + 1
+            const uint32_t nat = lane < n ? 1u + rq : 0u;
+            const uint32_t s_len = xtc_scan_incl(len, lane), s_d = xtc_scan_incl(dsm1, lane), s_at = xtc_scan_incl(nat, lane);
+            const uint32_t vpos = pos + s_len - len;
+            const int vsidx = sidx + (int)(s_d - dsm1) - lane;                      // sum of (step + 1) over the lanes before, minus their count
+            const int vatom = atom + (int)(s_at - nat);
+            const uint32_t prq = VMD_SHFL_U32(rq, (lane - 1) & 63);
+            const int vrun = lane == 0 ? run : 3 * (int)prq;
+            const int tl = (vsidx - XTC_FIRSTIDX) & 63;
+            Radix small;
+            const uint32_t m = VMD_SHFL_U32(my_magic, tl);
+            small.s1 = small.s2 = m;
+            small.s12 = (uint64_t)m * m;
+            small.inv2 = xtc_shfl_f64(t_inv2, tl);
+            small.inv12 = xtc_shfl_f64(t_inv12, tl);
+            uint32_t lst = 0;
+            if (lane < n) {
+                if (vsidx < XTC_FIRSTIDX || vsidx >= XTC_LASTIDX || vpos > nbits || vatom + (int)nat > natoms || dsm1 > 2u || rq > 10u) lst = 1;
+                else {
+                    BitsG br;
+                    xtc_open(br, stream - phase, fi.nbytes + phase, (uint64_t)vpos + 8ull * phase);
+                    int gi = vatom, gs = vsidx, gr = vrun;
+                    lst = xtc_group(br, fi, fs, natoms, gi, gs, gr, small, x, y, z);
+                    // the group must be the one the record describes: it ends where the next begins and leaves the recorded state
+                    if (!lst && (br.pos != (uint64_t)vpos + len + 8ull * phase || gi != vatom + (int)nat || gs != vsidx + (int)dsm1 - 1 || gr != 3 * (int)rq)) lst = 1;
+                }
+            }
+            if (VMD_XTC_BALLOT(lst == 1u)) st = 1;
+            else if (VMD_XTC_BALLOT(lst == 2u)) st = 2;
+            pos += VMD_READLANE_U32(s_len, 63);
+            sidx += (int)VMD_READLANE_U32(s_d, 63) - n;
+            atom += (int)VMD_READLANE_U32(s_at, 63);
+            run = 3 * (int)VMD_READLANE_U32(rq, n - 1);
+        }
+        if (st) break;
+        // a section ends where the next checkpoint begins (the last one: behind the last atom)
+        if (sec + 1 < nsec) {
+            const vmd_xtc_ck_t e = ck[(size_t)f * ck_max + sec + 1];
+            if (e.pos != pos || (int)e.atom != atom || e.state != ((uint32_t)sidx | ((uint32_t)run << 8))) st = 1;
+        } else if (atom != natoms || pos > nbits) st = 1;
+    }
     if (st && lane == 0) atomicMax(&status[f], st);
 }
 
@@ -700,8 +821,21 @@ extern "C" int vmd_hip_set_xtc_waves(int n) { const int old = g_xtc_waves; g_xtc
 // mode 0: plain; 1: emit checkpoints while decoding (ck, nck: out); 2: decode in sections from checkpoints (ck, nck: in);
 // 3: walk only and emit checkpoints (xyz may be NULL)
 static int xtc_launch_wave(void* stream, const unsigned char* raw, const vmd_xtc_frame_t* info, int B, int natoms, float* xyz,
-                           size_t frame_stride, size_t row_stride, uint32_t* status, int mode, vmd_xtc_ck_t* ck, uint32_t* nck) {
+                           size_t frame_stride, size_t row_stride, uint32_t* status, int mode, vmd_xtc_ck_t* ck, uint32_t* nck,
+                           uint16_t* rec = nullptr, uint32_t* nrec = nullptr, size_t rec_stride = 0) {
     if (B <= 0) return 0;
+    if (mode == 2 && rec && nrec) {
+        // group records exist: nothing is walked, a section is a run of independent tiles
+        int share = (8192 + B - 1) / B;
+        if (share > VMD_XTC_CK_MAX) share = VMD_XTC_CK_MAX;
+        if (share < 1) share = 1;
+        if (hipMemsetAsync(status, 0, (size_t)B * sizeof(uint32_t), (hipStream_t)stream) != hipSuccess) return 1;
+        const int ck_tiles_r = (natoms / 64 + 1 + VMD_XTC_CK_MAX - 1) / VMD_XTC_CK_MAX;
+        hipLaunchKernelGGL(k_xtc_records, dim3((unsigned)B, (unsigned)share), dim3(64), 0, (hipStream_t)stream, raw, info, B, natoms, xyz, frame_stride,
+                           row_stride, status, (const vmd_xtc_ck_t*)ck, (const uint32_t*)nck, VMD_XTC_CK_MAX, ck_tiles_r < 1 ? 1 : ck_tiles_r,
+                           (const uint16_t*)rec, (const uint32_t*)nrec, (uint32_t)rec_stride);
+        return (int)hipGetLastError();
+    }
     int share = g_xtc_waves;
     if (mode == 2) {
         // sections are independent: up to VMD_XTC_CK_MAX waves per frame, as many as fill the chip a few times over
@@ -722,8 +856,16 @@ static int xtc_launch_wave(void* stream, const unsigned char* raw, const vmd_xtc
     const int ck_tiles = (natoms / 64 + 1 + VMD_XTC_CK_MAX - 1) / VMD_XTC_CK_MAX;
     hipLaunchKernelGGL(k_xtc_wave, dim3((unsigned)B, (unsigned)share), dim3(64), 0, (hipStream_t)stream, raw, info, B, natoms, xyz, frame_stride,
                        row_stride, status, mode == 2 ? (const vmd_xtc_ck_t*)ck : (const vmd_xtc_ck_t*)nullptr,
-                       (mode == 1 || mode == 3) ? ck : (vmd_xtc_ck_t*)nullptr, nck, VMD_XTC_CK_MAX, ck_tiles < 1 ? 1 : ck_tiles);
+                       (mode == 1 || mode == 3) ? ck : (vmd_xtc_ck_t*)nullptr, nck, VMD_XTC_CK_MAX, ck_tiles < 1 ? 1 : ck_tiles,
+                       (mode == 1 || mode == 3) ? rec : (uint16_t*)nullptr, nrec, (uint32_t)rec_stride);
     return (int)hipGetLastError();
+}
+
+extern "C" int vmd_hip_xtc_decode_wave_rec(void* stream, const unsigned char* raw, const vmd_xtc_frame_t* info, int B, int natoms,
+                                           float* xyz, size_t frame_stride, size_t row_stride, uint32_t* status, int use,
+                                           vmd_xtc_ck_t* ck, uint32_t* nck, uint16_t* rec, uint32_t* nrec, size_t rec_stride) {
+    if (!ck || !nck || !rec || !nrec || rec_stride < (size_t)natoms) return (int)hipErrorInvalidValue;
+    return xtc_launch_wave(stream, raw, info, B, natoms, xyz, frame_stride, row_stride, status, use ? 2 : 1, ck, nck, rec, nrec, rec_stride);
 }
 
 extern "C" int vmd_hip_xtc_decode_wave(void* stream, const unsigned char* raw, const vmd_xtc_frame_t* info, int B, int natoms,
