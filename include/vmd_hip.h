@@ -210,7 +210,7 @@ int vmd_hip_xtc_decode_wave(void* stream, const unsigned char* raw, const vmd_xt
  * pass (use = 0) decodes as vmd_hip_xtc_decode_wave does and writes up to VMD_XTC_CK_MAX of them per frame (ck[b][.], nck[b]); a
  * later pass over the SAME frames (use = 1) splits every frame into that many independent sections - no walk is repeated, a frame
  * occupies as many SIMDs as it has sections.  ck: device, B x VMD_XTC_CK_MAX records; nck: device, B counters. */
-#define VMD_XTC_CK_MAX 16
+#define VMD_XTC_CK_MAX 64
 typedef struct vmd_xtc_ck_t {
     uint32_t pos, atom, state, reserved;
 } vmd_xtc_ck_t;

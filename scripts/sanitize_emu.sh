@@ -10,8 +10,8 @@ case "$SAN" in
   thread*) RT=$(g++ -print-file-name=libtsan.so);;
   *)       RT=$(g++ -print-file-name=libasan.so);;
 esac
-export ASAN_OPTIONS=detect_leaks=0:detect_stack_use_after_return=0:abort_on_error=0:halt_on_error=1
-export UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1
+export ASAN_OPTIONS=detect_leaks=0:detect_stack_use_after_return=0:abort_on_error=0:halt_on_error=1:log_path=${SAN_LOG:-/tmp/viamd_asan}
+export UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1:log_path=${SAN_LOG:-/tmp/viamd_asan}
 export TSAN_OPTIONS=halt_on_error=0:report_signal_unsafe=0
 if [[ "$SAN" != thread* ]]; then     # the oracle (the checker) gets the same treatment
   gcc -O1 -g -fPIC -std=c11 -ffp-contract=off -fno-fast-math -mavx2 -mfma -fopenmp -fsanitize=$SAN -fno-sanitize-recover=undefined \

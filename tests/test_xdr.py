@@ -317,7 +317,7 @@ def _device_decode(lib, blob, natoms, chunk=0, gpu=False):
             scratch = np.zeros(lib.vmd_hip_xtc_scratch_bytes(B, natoms, chunk) // 8 + 1, np.uint64)
             scratch_p = scratch.ctypes.data
     if chunk == -2:            # k_xtc_wave twice: the first pass leaves checkpoints, the second decodes the frames in sections from them
-        CK = 16
+        CK = 64                # VMD_XTC_CK_MAX (include/vmd_hip.h)
         if gpu:
             d_ck = torch.zeros(B * CK * 4, dtype=torch.int32, device="cuda")
             d_nck = torch.zeros(B, dtype=torch.int32, device="cuda")

@@ -93,7 +93,7 @@ struct Options {
     std::atomic<int> xtc_mapped{1};          // variant 3: DMA the compressed frames straight out of the mapped file (raw_mapped_view), no host copy
     std::atomic<int> xtc_map_limit_mb{0};    // pinned bytes of mapped files, all trajectories together (0 = half of the physical memory)
     // variant 3: the first decode also leaves a 16-bit record per group; later decodes place every group from them, no walk.  Measured
-    // (r03t2, c2): +2 % from a file, +3 % compressed-resident - the walk was a third of a re-decode, the per-group arithmetic is the rest.
+    // (r03t2, c2): +2 % from a file, +3 % compressed-resident - the walk was a fifth of a re-decode, the per-group arithmetic is the rest.
     // 1 = for file-backed trajectories (records in the process-wide store), 2 = also for vmd_rawtraj_* objects, whose point is a small
     // footprint (atoms x 2 bytes per frame on top of ~5 bytes per atom of bit stream)
     std::atomic<int> xtc_records{1};
@@ -2137,7 +2137,11 @@ static bool process_range(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
     // then small batches win from a file (the PCIe trip of batch k + 1 hides under decode + pair kernel of batch k: 64.6k frames/s
     // with batches of 128 against 51.3k with 512) and one large batch from HBM (103.8k against 98.8k).
     if (!have_view && g_opt.batch_frames <= 0) {
-        const size_t S = (size_t)std::max(1, g_opt.stage_frames.load());
+        // stage_frames is quoted for a 100 000-atom system (a 154 MB float stage); larger systems get proportionally fewer frames per
+        // batch - r03u: 1M atoms in batches of 128 frames (0.64 GB of bit streams each) spent 15 of 34 ms waiting for the first batch
+        const size_t npad_s = (num_atoms + 63) & ~(size_t)63;
+        const size_t S0 = (size_t)std::max(1, g_opt.stage_frames.load());
+        const size_t S = std::max<size_t>(1, std::min<size_t>(S0, S0 * 100032 / std::max<size_t>(npad_s, 1)));
         bool warm = f32_ring;                               // does the first frame of the range have checkpoints already?  (plain floats need none)
         if (!f32_ring && device_decode && g_opt.xtc_checkpoints.load() && frame_beg < frame_end) {
             if (raw_ring) {
@@ -2150,7 +2154,10 @@ static bool process_range(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
         }
         // a first pass out of a mapped file keeps four walks in flight (stage_ahead below): half-size batches, twice as many
         cold_walk = raw_ring && !f32_ring && !warm && have_map && g_opt.xtc_device_decode.load() == 3 && g_opt.xtc_cold_streams.load() != 0;
-        Bmax = std::min<size_t>(Bmax, !device_decode ? S : (raw_ring ? (warm ? S : (cold_walk ? 2 * S : 4 * S)) : (warm ? 8 * S : 4 * S)));
+        // (a walk takes as long for one frame as for a thousand - 7 ms for a c2 frame, 70 ms for 1M atoms -: never more launches than
+        // decode streams for a short range)
+        const size_t cold_b = std::max<size_t>(2 * S, (frame_end - frame_beg + vmd_script_eval_t::kDecodeStreams - 1) / vmd_script_eval_t::kDecodeStreams);
+        Bmax = std::min<size_t>(Bmax, !device_decode ? S : (raw_ring ? (warm ? S : (cold_walk ? cold_b : 4 * S)) : (warm ? 8 * S : 4 * S)));
     }
     std::vector<Batch> batches;
     for (auto& sg : segments) plan_batches(e, sg.first, sg.second, Bmax, &batches);
