@@ -625,11 +625,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
     };
 
     XtcBank bank_a, bank_b;
-    for (int sec = sectioned ? (int)blockIdx.y : 0; sec < nsec; sec += sectioned ? (int)gridDim.y : 1) {
+    // sectioned: wave y owns the consecutive sections [y * per_wave, (y + 1) * per_wave) and walks them as ONE stretch - entering the
+    // stream costs a bank of loads, and a frame has up to 64 checkpoints however few waves the batch leaves it
+    const int per_wave = sectioned ? (nsec + (int)gridDim.y - 1) / (int)gridDim.y : 1;
+    for (int sec = sectioned ? (int)blockIdx.y * per_wave : 0; sec < nsec; sec = nsec) {
         if (sectioned) {
+            const int sec_end = sec + per_wave < nsec ? sec + per_wave : nsec;
             const vmd_xtc_ck_t c = ck_in[(size_t)f * ck_max + sec];
             pos = c.pos; i = (int)c.atom; smallidx = (int)(c.state & 255u); run = (int)(c.state >> 8);
-            end_i = sec + 1 < nsec ? (int)ck_in[(size_t)f * ck_max + sec + 1].atom : natoms;
+            end_i = sec_end < nsec ? (int)ck_in[(size_t)f * ck_max + sec_end].atom : natoms;
             // a checkpoint table that does not belong to this frame must not take the walk anywhere it cannot go
             if (pos > nbits || i < 0 || i >= natoms || end_i <= i || end_i > natoms || smallidx < XTC_FIRSTIDX || smallidx >= XTC_LASTIDX || run > 30 || run % 3) { st = 1; break; }
             g = 0; done = false;
@@ -697,12 +701,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
     const uint32_t my_magic = (uint32_t)kXtcMagic[XTC_FIRSTIDX + lane];
     const double t_inv2 = 1.0 / (double)my_magic, t_inv12 = 1.0 / (double)((uint64_t)my_magic * my_magic);
     const uint16_t* frec = rec + (size_t)f * rec_stride;
-    for (int sec = (int)blockIdx.y; sec < nsec; sec += (int)gridDim.y) {
+    const int per_wave = (nsec + (int)gridDim.y - 1) / (int)gridDim.y;           // consecutive sections of one wave: one running state
+    for (int sec = (int)blockIdx.y * per_wave; sec < nsec; sec = nsec) {
+        const int sec_end = sec + per_wave < nsec ? sec + per_wave : nsec;
         const vmd_xtc_ck_t c = ck[(size_t)f * ck_max + sec];
         uint32_t pos = c.pos;
         int atom = (int)c.atom, sidx = (int)(c.state & 255u), run = (int)(c.state >> 8);
         const uint32_t q0 = (uint32_t)sec * (uint32_t)ck_tiles * 64u;
-        const uint32_t q1 = sec + 1 < nsec ? (uint32_t)(sec + 1) * (uint32_t)ck_tiles * 64u : ng;
+        const uint32_t q1 = sec_end < nsec ? (uint32_t)sec_end * (uint32_t)ck_tiles * 64u : ng;
         if (q0 >= q1 || q1 > ng || pos > nbits || atom < 0 || atom >= natoms || sidx < XTC_FIRSTIDX || sidx >= XTC_LASTIDX || run > 30 || run % 3) { st = 1; break; }
         for (uint32_t q = q0; q < q1 && !st; q += 64u) {
             const int n = (int)(q1 - q < 64u ? q1 - q : 64u);
@@ -744,8 +750,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
         }
         if (st) break;
         // a section ends where the next checkpoint begins (the last one: behind the last atom)
-        if (sec + 1 < nsec) {
-            const vmd_xtc_ck_t e = ck[(size_t)f * ck_max + sec + 1];
+        if (sec_end < nsec) {
+            const vmd_xtc_ck_t e = ck[(size_t)f * ck_max + sec_end];
             if (e.pos != pos || (int)e.atom != atom || e.state != ((uint32_t)sidx | ((uint32_t)run << 8))) st = 1;
         } else if (atom != natoms || pos > nbits) st = 1;
     }
