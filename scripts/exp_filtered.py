@@ -9,6 +9,10 @@ import bench
 
 name = sys.argv[1] if len(sys.argv) > 1 else "c2"
 S = int(sys.argv[2]) if len(sys.argv) > 2 else 50
+opts = {}
+for kv in sys.argv[3:]:            # library options, key=value (e.g. block_superbatch=0)
+    k, v = kv.split("=")
+    V.default_lib().vmd_set_option(k.encode(), int(v)); opts[k] = int(v)
 w = bench.WORKLOADS[name]
 frames = w["frames"]
 traj = synth.make_device_trajectory(V, w["seed"], w["atoms"], w["box"], frames, w["blob"])
@@ -28,7 +32,7 @@ def timed(ev, beg, end, reps=3):
 plain = V.ScriptEval(frames, ir)
 full = V.ScriptEval(frames, ir); full.set_block_frames(S)
 timed(plain, 0, frames, 1)
-out = {"workload": name, "frames": frames, "block_frames": S}
+out = {"workload": name, "frames": frames, "block_frames": S, "options": opts}
 out["full_plain_ms"] = 1e3 * timed(plain, 0, frames)
 out["full_with_blocks_ms"] = 1e3 * timed(full, 0, frames)
 filt = V.ScriptEval(frames, ir); filt.set_source(full)

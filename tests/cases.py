@@ -173,6 +173,45 @@ def cell_build_overflow_case(lib, O, device=False, n=3000, box=60.0):
         lib.vmd_set_option(b"rdf_classes", old)
 
 
+def blocks_overflow_case(lib, O, device=False, n=3000, box=60.0):
+    """A full evaluation that keeps block partials evaluates consecutive frame blocks as ONE batch (one cell build, a pair launch per
+    block, every other one on a second stream).  Here a bucket overflows in the middle blocks: nothing of the batch may reach any
+    partial, the batch is repeated, and afterwards the totals, every block (through filtered sub-ranges that reuse them) and both
+    ways of planning the batches give the oracle's integers."""
+    F, S = 12, 3
+    coords = water_box(O, 5, n, box, F)
+    o = oxygen(n)
+    rng = np.random.default_rng(3)
+    for f in (5, 6, 7):
+        coords[f][:, o] = rng.uniform(1.0, 11.0, (3, o.size)).astype(np.float32)      # all inside one 12 A pencil
+    ocell, vcell = cell_pair(O, box)
+    ir = V.ScriptIR(lib); ir.add_rdf("goo", o, o, (0.0, 12.0))
+    traj = make_traj(lib, coords, vcell, device)
+    sysm = V.MolSystem(coords.shape[2], unitcell=vcell)
+    per_frame = [oracle_rdf(O, coords, ocell, o, o, 0.0, 12.0, frames=[f])[0] for f in range(F)]
+    import ctypes as C
+    for super_, two in ((1, 1), (1, 0), (0, 0)):
+        old = (lib.vmd_set_option(b"block_superbatch", super_), lib.vmd_set_option(b"block_two_streams", two))
+        lib.vmd_profile_reset(); lib.vmd_profile_enable(True)
+        try:
+            full = V.ScriptEval(F, ir); full.set_block_frames(S)
+            assert full.frame_range(sysm, traj, 0, F)
+            nb = C.c_uint64(0)
+            lib.vmd_profile_ms(b"cells_build", C.byref(nb))
+            assert nb.value >= 2, "the overflowing batch was not rebuilt"
+            np.testing.assert_array_equal(full.property_data("goo").counts, sum(per_frame))
+            filt = V.ScriptEval(F, ir); filt.set_source(full)
+            for beg, end in ((3, 9), (0, 6), (6, 12), (4, 11)):
+                filt.clear_data()
+                assert filt.frame_range(sysm, traj, beg, end)
+                np.testing.assert_array_equal(filt.property_data("goo").counts, sum(per_frame[beg:end]), err_msg=f"[{beg},{end}) super={super_} two={two}")
+            filt.clear_data()
+            assert filt.frame_range(sysm, traj, 3, 9) and filt.frame_stats() == (0, 6)
+        finally:
+            lib.vmd_profile_enable(False)
+            lib.vmd_set_option(b"block_superbatch", old[0]); lib.vmd_set_option(b"block_two_streams", old[1])
+
+
 def class_decomposition_cases(lib, O, device=False, n_water=3000, box=40.0):
     """Co-evaluated RDFs of one range share pair passes through disjoint atom classes (BASELINE config 5: goo is a subset of
     ghv).  With and without the decomposition every property equals its own oracle histogram; sets that overlap partially,

@@ -33,6 +33,10 @@ def test_cell_build_bucket_overflow_is_caught_and_repeated(emu_lib, oracle):
     cases.cell_build_overflow_case(emu_lib, oracle)
 
 
+def test_batch_of_frame_blocks_overflow_is_all_or_nothing(emu_lib, oracle):
+    cases.blocks_overflow_case(emu_lib, oracle)
+
+
 def test_coevaluated_rdfs_share_pair_passes(emu_lib, oracle):
     cases.class_decomposition_cases(emu_lib, oracle, n_water=1800, box=38.0)
 

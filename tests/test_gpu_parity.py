@@ -44,6 +44,10 @@ def test_cell_build_bucket_overflow_is_caught_and_repeated(gpu_lib, oracle):
     cases.cell_build_overflow_case(gpu_lib, oracle, device=True, n=30000, box=80.0)
 
 
+def test_batch_of_frame_blocks_overflow_is_all_or_nothing(gpu_lib, oracle):
+    cases.blocks_overflow_case(gpu_lib, oracle, device=True, n=30000, box=80.0)
+
+
 def test_coevaluated_rdfs_share_pair_passes(gpu_lib, oracle):
     cases.class_decomposition_cases(gpu_lib, oracle, device=True, n_water=30000, box=70.0)
 

@@ -86,6 +86,8 @@ struct Options {
                                              // frame (k_xtc_decode), 2 = index pass + one thread per chunk (k_xtc_index / k_xtc_chunks),
                                              // 3 = one wave per frame (k_xtc_wave)
     std::atomic<int> xtc_chunk{256};         // atoms per chunk of variant 2
+    std::atomic<int> block_superbatch{1};    // filtered evaluation: consecutive frame blocks share ONE batch (one cell build, one synchronisation; a pair launch per block)
+    std::atomic<int> block_two_streams{1};   // ... and the blocks' pair launches alternate between two streams, so that the tail of one runs under the head of the next
     std::atomic<int> xtc_ramp{0};            // file-backed device decode: small first and last batches (pipeline fill / drain); r03o: no gain, off
     std::atomic<int> xtc_decode_ahead{1};    // batches the device decoder runs ahead of the kernels (1 or 2); r03n: 2 changes nothing
     std::atomic<int> raw_f32_device{1};      // TRR / DCD: frames DMA'd out of the mapped file, swapped / scaled / transposed by k_raw_f32 (0: host threads)
@@ -144,6 +146,8 @@ extern "C" int vmd_set_option(const char* key, int value) {
     else if (!strcmp(key, "xtc_cold_streams")) o = &g_opt.xtc_cold_streams;
     else if (!strcmp(key, "raw_f32_device")) o = &g_opt.raw_f32_device;
     else if (!strcmp(key, "xtc_ramp")) o = &g_opt.xtc_ramp;
+    else if (!strcmp(key, "block_superbatch")) o = &g_opt.block_superbatch;
+    else if (!strcmp(key, "block_two_streams")) o = &g_opt.block_two_streams;
     else if (!strcmp(key, "xtc_decode_ahead")) o = &g_opt.xtc_decode_ahead;
     else if (!strcmp(key, "xtc_map_limit_mb")) o = &g_opt.xtc_map_limit_mb;
     else if (!strcmp(key, "xtc_waves")) return vmd_hip_set_xtc_waves(value);
@@ -746,6 +750,9 @@ struct vmd_script_eval_t {
     hipStream_t copy_stream = nullptr;
     hipStream_t aux_stream = nullptr;        // background work nothing else queues behind (the clearing DMA of a volume's host view)
     DevBuf<uint64_t> d_partial;
+    DevBuf<uint64_t> d_partial2;             // partial rows of the pair launches on pair_stream (batches of frame blocks)
+    hipStream_t pair_stream = nullptr;       // every other block of a batch of frame blocks runs its pair kernel here
+    hipEvent_t pair_fork = nullptr, pair_join = nullptr;
     std::vector<RdfGroup> rdf_groups;
     DevBuf<uint64_t> d_pass;                 // [passes of the batch][bins]: scratch histogram of every pair pass, committed at the batch's end
     DevBuf<uint32_t> d_overflow;             // device flag raised by the two-level cell build when a pencil bucket is full
@@ -876,6 +883,8 @@ extern "C" vmd_script_eval_t* vmd_eval_create(size_t num_frames, const vmd_scrip
     if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) { vmd_fail("hipStreamCreate failed"); return nullptr; }
     if (hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking) != hipSuccess) { vmd_fail("hipStreamCreate failed"); return nullptr; }
     if (hipStreamCreateWithFlags(&e->aux_stream, hipStreamNonBlocking) != hipSuccess) { vmd_fail("hipStreamCreate failed"); return nullptr; }
+    if (hipStreamCreateWithFlags(&e->pair_stream, hipStreamNonBlocking) != hipSuccess) { vmd_fail("hipStreamCreate failed"); return nullptr; }
+    if (hipEventCreateWithFlags(&e->pair_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&e->pair_join, hipEventDisableTiming) != hipSuccess) { vmd_fail("hipEventCreate failed"); return nullptr; }
     {   // the decoder's waves should get the wave slots the pair kernel leaves free as soon as a batch has arrived: highest priority
         int lo = 0, hi = 0;
         if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { lo = hi = 0; }
@@ -986,6 +995,11 @@ extern "C" void vmd_eval_free(vmd_script_eval_t* eval) {
         eval->copy_stream = nullptr;
         if (eval->aux_stream) (void)hipStreamDestroy(eval->aux_stream);
         eval->aux_stream = nullptr;
+        if (eval->pair_stream) { (void)hipStreamSynchronize(eval->pair_stream); (void)hipStreamDestroy(eval->pair_stream); }
+        eval->pair_stream = nullptr;
+        if (eval->pair_fork) (void)hipEventDestroy(eval->pair_fork);
+        if (eval->pair_join) (void)hipEventDestroy(eval->pair_join);
+        eval->pair_fork = eval->pair_join = nullptr;
         eval->props.clear();
         eval->sels.clear();
         if (eval->h_overflow) (void)hipHostFree(eval->h_overflow);
@@ -1986,8 +2000,9 @@ static size_t auto_batch(const vmd_script_eval_t* e, size_t num_atoms, bool stag
     return B;
 }
 
-// one kernel batch: frames [f0, f0 + nb); blk >= 0 when the batch is exactly frame block `blk` of this eval
-struct Batch { size_t f0, nb; long blk; };
+// one kernel batch: frames [f0, f0 + nb); blk >= 0 when the batch is made of the whole frame blocks blk .. blk + nblk - 1 of this eval
+// (filtered evaluation: each block accumulates into its own partial; they share the batch's cell build and synchronisation)
+struct Batch { size_t f0, nb; long blk; size_t nblk; };
 
 static void plan_batches(const vmd_script_eval_t* e, size_t beg, size_t end, size_t Bmax, std::vector<Batch>* out) {
     auto even = [&](size_t a, size_t b) {
@@ -1995,18 +2010,21 @@ static void plan_batches(const vmd_script_eval_t* e, size_t beg, size_t end, siz
         if (!total) return;
         const size_t nbatch = (total + Bmax - 1) / Bmax;
         const size_t B = (total + nbatch - 1) / nbatch;
-        for (size_t f = a; f < b; f += B) out->push_back({f, std::min(B, b - f), -1});
+        for (size_t f = a; f < b; f += B) out->push_back({f, std::min(B, b - f), -1, 0});
     };
     const size_t S = e->block_frames;
     if (S == 0) { even(beg, end); return; }
-    // whole blocks that fit one batch become their own batch (their partial is kept), everything else is a plain piece
+    const bool super = g_opt.block_superbatch.load() != 0;
+    // whole blocks that fit one batch become a batch of blocks (their partials are kept), everything else is a plain piece
     size_t run = beg;                          // start of the pending plain piece
     for (size_t f = beg; f < end;) {
         const size_t blk = f / S;
         const size_t bend = std::min((blk + 1) * S, e->num_frames);
         if (f == blk * S && bend <= end && bend - f <= Bmax) {
             even(run, f);
-            out->push_back({f, bend - f, (long)blk});
+            Batch* last = out->empty() ? nullptr : &out->back();
+            if (super && last && last->blk >= 0 && last->f0 + last->nb == f && last->nb + (bend - f) <= Bmax) { last->nb += bend - f; last->nblk += 1; }
+            else out->push_back({f, bend - f, (long)blk, 1});
             f = bend; run = f;
         } else {
             f = std::min(bend, end);
@@ -2167,12 +2185,12 @@ static bool process_range(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
     // fill is paid back by the pair kernel's lower efficiency on small launches - 81.5k frames/s either way, so it is off.
     if (raw_ring && g_opt.xtc_ramp.load() && batches.size() >= 3) {
         std::vector<Batch> ramped;
-        auto carve_front = [&](Batch& b, size_t n) { ramped.push_back({b.f0, n, -1}); b.f0 += n; b.nb -= n; };
+        auto carve_front = [&](Batch& b, size_t n) { ramped.push_back({b.f0, n, -1, 0}); b.f0 += n; b.nb -= n; };
         Batch first = batches.front(), last = batches.back();
         if (first.blk < 0 && first.nb >= 64) { carve_front(first, first.nb / 8); carve_front(first, first.nb / 3); }
         ramped.push_back(first);
         for (size_t i = 1; i + 1 < batches.size(); ++i) ramped.push_back(batches[i]);
-        if (last.blk < 0 && last.nb >= 64) { const size_t tail = last.nb / 4; ramped.push_back({last.f0, last.nb - tail, -1}); ramped.push_back({last.f0 + last.nb - tail, tail, -1}); }
+        if (last.blk < 0 && last.nb >= 64) { const size_t tail = last.nb / 4; ramped.push_back({last.f0, last.nb - tail, -1, 0}); ramped.push_back({last.f0 + last.nb - tail, tail, -1, 0}); }
         else ramped.push_back(last);
         batches.swap(ramped);
     }
@@ -2217,12 +2235,23 @@ static bool process_range(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
         e->h_temporal.resize(temporal_floats);
         size_t toff = 0;
 
-        // a whole frame block accumulates into its own partial first and is merged into the totals afterwards
-        auto acc_of = [&](PropState* p) -> uint64_t* {
-            return (bt.blk >= 0 && p->ncounts) ? p->d_blocks.p + (size_t)bt.blk * p->ncounts : p->d_counts.p;
+        // a whole frame block accumulates into its own partial first and is merged into the totals afterwards.  A batch of blocks
+        // (filtered evaluation) is evaluated block by block - `subs` - behind one cell build and in front of one synchronisation.
+        struct Sub { size_t off, nb; long blk; };
+        std::vector<Sub> subs;
+        if (bt.blk >= 0 && bt.nblk > 1) {
+            const size_t S = e->block_frames;
+            for (size_t j = 0; j < bt.nblk; ++j) subs.push_back({j * S, std::min(S, nb - j * S), bt.blk + (long)j});
+        } else subs.push_back({0, nb, bt.blk});
+        auto acc_of = [&](PropState* p, const Sub& sb) -> uint64_t* {
+            return (sb.blk >= 0 && p->ncounts) ? p->d_blocks.p + (size_t)sb.blk * p->ncounts : p->d_counts.p;
         };
         if (bt.blk >= 0)
-            for (auto& p : e->props) if (p->ncounts) HIP_OK(hipMemsetAsync(acc_of(p.get()), 0, p->ncounts * sizeof(uint64_t), e->stream));
+            for (auto& sb : subs)
+                for (auto& p : e->props) if (p->ncounts) HIP_OK(hipMemsetAsync(acc_of(p.get(), sb), 0, p->ncounts * sizeof(uint64_t), e->stream));
+        // the blocks' pair launches alternate between the eval's stream and a second one (own partial rows): a 50-frame launch of a
+        // 100k-atom system is ~3 work items per resident wave, and the tail of one launch then runs under the head of the next
+        const bool two_streams = subs.size() > 1 && g_opt.block_two_streams.load() != 0;
 
         // ---- RDF: one pair pass per (group, pass); launch_rdf may run again for this batch when a cell-build bucket overflowed
         // Every pass accumulates into its own scratch row and the rows are committed to the properties' accumulators by ONE
@@ -2234,11 +2263,13 @@ static bool process_range(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
             vmd_hip_set_rdf_closed(e->spec.rdf_closed ? 1 : 0);
             size_t scratch_rows = 0;
             for (auto& g : e->rdf_groups) scratch_rows += std::max(g.passes.size(), g.props.size());
+            scratch_rows *= subs.size();
             if (!e->d_pass.ensure(std::max<size_t>(scratch_rows, 1) * VMD_RDF_NUM_BINS)) return false;
             HIP_OK(hipMemsetAsync(e->d_pass.p, 0, scratch_rows * VMD_RDF_NUM_BINS * sizeof(uint64_t), e->stream));
             struct Commit { uint64_t* dst; const uint64_t* src; uint64_t mult; };
             std::vector<Commit> commits;
             size_t row = 0;
+            bool forked = false;
             for (auto& g : e->rdf_groups) {
                 vmd_grid_t grid;
                 // fully periodic cells use the frame boxes; open axes (non-periodic systems, slabs) span the batch's bounding box
@@ -2252,42 +2283,64 @@ static bool process_range(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
                         PropState* p = e->props[pi].get();
                         Selection* sa = e->sels[p->sel_a].get();
                         Selection* sb = e->sels[p->sel_b].get();
-                        uint64_t* dst = e->d_pass.p + (row++) * VMD_RDF_NUM_BINS;
-                        e->prof.begin("rdf_brute", e->stream);
-                        KRN_OK(vmd_hip_rdf_brute(e->stream, src.base, src.frame_stride, src.row_stride, src.d_boxes.p, pbc, (int)nb,
-                                                 sa->d_idx.p, (int)sa->idx.size(), sb->d_idx.p, (int)sb->idx.size(),
-                                                 g.rmin, g.rmax, VMD_RDF_NUM_BINS, dst));
-                        e->prof.end(e->stream);
-                        commits.push_back({acc_of(p), dst, 1});
+                        for (auto& su : subs) {
+                            uint64_t* dst = e->d_pass.p + (row++) * VMD_RDF_NUM_BINS;
+                            e->prof.begin("rdf_brute", e->stream);
+                            KRN_OK(vmd_hip_rdf_brute(e->stream, src.base + su.off * src.frame_stride, src.frame_stride, src.row_stride, src.d_boxes.p + 9 * su.off, pbc, (int)su.nb,
+                                                     sa->d_idx.p, (int)sa->idx.size(), sb->d_idx.p, (int)sb->idx.size(),
+                                                     g.rmin, g.rmax, VMD_RDF_NUM_BINS, dst));
+                            e->prof.end(e->stream);
+                            commits.push_back({acc_of(p, su), dst, 1});
+                        }
                     }
                     continue;
                 }
                 if (!e->d_partial.ensure(vmd_hip_rdf_partial_words())) return false;
+                if (two_streams && !e->d_partial2.ensure(vmd_hip_rdf_partial_words())) return false;
                 for (auto& ps : g.passes) {
                     Selection* sa = e->sels[ps.sel_a].get();
                     Selection* sb = e->sels[ps.sel_b].get();
                     // passes with the same cutoff share the sorted copies; build_selection re-sorts when the grid differs
+                    if (forked) {     // the second stream still reads the sorted copies of the previous pass
+                        HIP_OK(hipEventRecord(e->pair_join, e->pair_stream));
+                        HIP_OK(hipStreamWaitEvent(e->stream, e->pair_join, 0));
+                        forked = false;
+                    }
                     if (!build_selection(e, sa, src, d_gb, pbc, nb, grid)) return false;
                     if (sb != sa && !build_selection(e, sb, src, d_gb, pbc, nb, grid)) return false;
                     // the pair set is symmetric in (ref, target): put the denser selection in the lanes - 64 of its atoms span a
                     // shorter stretch of the pencil, so the x window of every segment carries less padding
                     if (sb->idx.size() > sa->idx.size()) std::swap(sa, sb);
-                    uint64_t* dst = e->d_pass.p + (row++) * VMD_RDF_NUM_BINS;
-                    e->prof.begin("rdf_pencil", e->stream);
-                    KRN_OK(vmd_hip_rdf_pencil(e->stream, sa->sorted.p, sa->cell_start.p, (int)sa->idx.size(), sa->nsel_pad,
-                                              sb->sorted.p, sb->cell_start.p, (int)sb->idx.size(), sb->nsel_pad,
-                                              d_gb, (int)nb, grid, g.rmin, g.rmax, VMD_RDF_NUM_BINS,
-                                              ps.same ? 1 : 0, g_opt.rdf_variant, pbc, e->d_partial.p, dst, e->d_overflow.p));
-                    e->prof.end(e->stream);
-                    if (e->spec.rdf_closed && ps.same && g.rmin <= 0.0f && 0.0f <= g.rmax) {
-                        // closed interval: d = 0 is a hit, but a same-set pass walks the half shell (j > i, every hit twice) and never
-                        // meets the pairs (i, i) - one per list entry and frame, all in the bin of d = 0 (SPEC S4 binning of 0)
-                        int bin0 = (int)(((0.0f - g.rmin) * (1.0f / (g.rmax - g.rmin))) * (float)VMD_RDF_NUM_BINS);
-                        bin0 = std::min(std::max(bin0, 0), VMD_RDF_NUM_BINS - 1);
-                        KRN_OK(vmd_hip_bump_u64(e->stream, dst + bin0, (uint64_t)nb * (uint64_t)sa->idx.size()));
+                    if (two_streams) {
+                        HIP_OK(hipEventRecord(e->pair_fork, e->stream));
+                        HIP_OK(hipStreamWaitEvent(e->pair_stream, e->pair_fork, 0));
+                        forked = true;
                     }
-                    for (auto& tg : ps.targets) commits.push_back({acc_of(e->props[tg.first].get()), dst, tg.second});
+                    size_t si = 0;
+                    for (auto& su : subs) {
+                        uint64_t* dst = e->d_pass.p + (row++) * VMD_RDF_NUM_BINS;
+                        const bool second = two_streams && (si++ & 1);
+                        hipStream_t ks = second ? e->pair_stream : e->stream;
+                        if (!second) e->prof.begin("rdf_pencil", ks);
+                        KRN_OK(vmd_hip_rdf_pencil(ks, sa->sorted.p + su.off * 3 * (size_t)sa->nsel_pad, sa->cell_start.p + su.off * (size_t)(grid.ncell + 1), (int)sa->idx.size(), sa->nsel_pad,
+                                                  sb->sorted.p + su.off * 3 * (size_t)sb->nsel_pad, sb->cell_start.p + su.off * (size_t)(grid.ncell + 1), (int)sb->idx.size(), sb->nsel_pad,
+                                                  d_gb + 9 * su.off, (int)su.nb, grid, g.rmin, g.rmax, VMD_RDF_NUM_BINS,
+                                                  ps.same ? 1 : 0, g_opt.rdf_variant, pbc, second ? e->d_partial2.p : e->d_partial.p, dst, e->d_overflow.p));
+                        if (!second) e->prof.end(ks);
+                        if (e->spec.rdf_closed && ps.same && g.rmin <= 0.0f && 0.0f <= g.rmax) {
+                            // closed interval: d = 0 is a hit, but a same-set pass walks the half shell (j > i, every hit twice) and never
+                            // meets the pairs (i, i) - one per list entry and frame, all in the bin of d = 0 (SPEC S4 binning of 0)
+                            int bin0 = (int)(((0.0f - g.rmin) * (1.0f / (g.rmax - g.rmin))) * (float)VMD_RDF_NUM_BINS);
+                            bin0 = std::min(std::max(bin0, 0), VMD_RDF_NUM_BINS - 1);
+                            KRN_OK(vmd_hip_bump_u64(ks, dst + bin0, (uint64_t)su.nb * (uint64_t)sa->idx.size()));
+                        }
+                        for (auto& tg : ps.targets) commits.push_back({acc_of(e->props[tg.first].get(), su), dst, tg.second});
+                    }
                 }
+            }
+            if (forked) {
+                HIP_OK(hipEventRecord(e->pair_join, e->pair_stream));
+                HIP_OK(hipStreamWaitEvent(e->stream, e->pair_join, 0));
             }
             for (auto& c : commits) KRN_OK(vmd_hip_axpy_u64(e->stream, c.dst, c.src, VMD_RDF_NUM_BINS, c.mult, e->d_overflow.p));
             HIP_OK(hipMemcpyAsync(e->h_overflow, e->d_overflow.p, sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
@@ -2297,24 +2350,25 @@ static bool process_range(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
 
         for (auto& p : e->props) {
             const Property& d = p->prop;
-            uint64_t* acc = acc_of(p.get());
             if (d.kind == PROP_RDF) {
                 // SPEC S4 normalisation, fp64 on the host (needs only the box)
-                double* bw = bt.blk >= 0 ? &p->block_weights64[(size_t)bt.blk * p->ncounts] : nullptr;
-                if (bw) std::fill(bw, bw + p->ncounts, 0.0);
-                for (size_t b = 0; b < nb; ++b) {
-                    const float* L = &src.h_boxes[9 * b];
-                    double V;
-                    if ((pbc & VMD_UNITCELL_PBC_ALL) == VMD_UNITCELL_PBC_ALL) V = (double)L[0] * (double)L[1] * (double)L[2];   // also the triclinic volume
-                    else V = (4.0 / 3.0) * M_PI * (double)d.rmax * (double)d.rmax * (double)d.rmax;
-                    const double rho = (double)d.a.size() * (double)d.b.size() / V;
-                    const double w = ((double)d.rmax - (double)d.rmin) / (double)p->ncounts;
-                    for (size_t k = 0; k < p->ncounts; ++k) {
-                        const double r0 = (double)d.rmin + w * (double)k;
-                        const double r1 = (double)d.rmin + w * (double)(k + 1);
-                        const double wk = rho * (4.0 / 3.0) * M_PI * (r1 * r1 * r1 - r0 * r0 * r0);
-                        p->weights64[k] += wk;
-                        if (bw) bw[k] += wk;
+                for (auto& su : subs) {
+                    double* bw = su.blk >= 0 ? &p->block_weights64[(size_t)su.blk * p->ncounts] : nullptr;
+                    if (bw) std::fill(bw, bw + p->ncounts, 0.0);
+                    for (size_t b = su.off; b < su.off + su.nb; ++b) {
+                        const float* L = &src.h_boxes[9 * b];
+                        double V;
+                        if ((pbc & VMD_UNITCELL_PBC_ALL) == VMD_UNITCELL_PBC_ALL) V = (double)L[0] * (double)L[1] * (double)L[2];   // also the triclinic volume
+                        else V = (4.0 / 3.0) * M_PI * (double)d.rmax * (double)d.rmax * (double)d.rmax;
+                        const double rho = (double)d.a.size() * (double)d.b.size() / V;
+                        const double w = ((double)d.rmax - (double)d.rmin) / (double)p->ncounts;
+                        for (size_t k = 0; k < p->ncounts; ++k) {
+                            const double r0 = (double)d.rmin + w * (double)k;
+                            const double r1 = (double)d.rmin + w * (double)(k + 1);
+                            const double wk = rho * (4.0 / 3.0) * M_PI * (r1 * r1 * r1 - r0 * r0 * r0);
+                            p->weights64[k] += wk;
+                            if (bw) bw[k] += wk;
+                        }
                     }
                 }
                 p->dirty = true;
@@ -2328,11 +2382,13 @@ static bool process_range(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
                                          p->have_tree ? p->d_tree_order.p : nullptr, p->have_tree ? p->d_tree_parent.p : nullptr, p->have_tree ? p->d_tree_pos.p : nullptr));
                 e->prof.end(e->stream);
                 e->prof.begin("sdf_scatter", e->stream);
-                KRN_OK(vmd_hip_sdf_scatter(e->stream, src.base, src.frame_stride, src.row_stride, src.d_boxes.p, pbc, (int)nb,
-                                           p->d_structs.p, (int)d.K, (int)d.m, p->d_R32.p, p->d_c32.p, p->d_tgt.p, (p->have_owner && !e->spec.sdf_include_self) ? p->d_owner.p : nullptr, (int)d.b.size(),
-                                           d.rmax, VMD_VOLUME_DIM, acc, p->d_group.p,
-                                           (p->have_tag && p->tag_len == src.row_stride && !e->spec.sdf_include_self) ? p->d_tag.p : nullptr,
-                                           p->tgt_first, p->tgt_stride, (p->unowned || e->spec.sdf_include_self) ? 1 : 0));
+                for (auto& su : subs)
+                    KRN_OK(vmd_hip_sdf_scatter(e->stream, src.base + su.off * src.frame_stride, src.frame_stride, src.row_stride, src.d_boxes.p + 9 * su.off, pbc, (int)su.nb,
+                                               p->d_structs.p, (int)d.K, (int)d.m, p->d_R32.p + su.off * d.K * 9, p->d_c32.p + su.off * d.K * 3, p->d_tgt.p,
+                                               (p->have_owner && !e->spec.sdf_include_self) ? p->d_owner.p : nullptr, (int)d.b.size(),
+                                               d.rmax, VMD_VOLUME_DIM, acc_of(p.get(), su), p->d_group.p + 4 * su.off,
+                                               (p->have_tag && p->tag_len == src.row_stride && !e->spec.sdf_include_self) ? p->d_tag.p : nullptr,
+                                               p->tgt_first, p->tgt_stride, (p->unowned || e->spec.sdf_include_self) ? 1 : 0));
                 e->prof.end(e->stream);
                 p->dirty = true;
             } else {
@@ -2380,7 +2436,8 @@ static bool process_range(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
             HIP_OK(hipStreamSynchronize(e->stream));
         }
         if (bt.blk >= 0)
-            for (auto& p : e->props) if (p->ncounts) KRN_OK(vmd_hip_add_u64(e->stream, p->d_counts.p, acc_of(p.get()), p->ncounts));
+            for (auto& su : subs)
+                for (auto& p : e->props) if (p->ncounts) KRN_OK(vmd_hip_add_u64(e->stream, p->d_counts.p, acc_of(p.get(), su), p->ncounts));
         e->prof.resolve();
         if (g_prof_on) { std::lock_guard<std::mutex> l(g_prof_mtx); g_prof["batches"].launches += 1; }
         toff = 0;
@@ -2392,7 +2449,7 @@ static bool process_range(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
         for (size_t b = 0; b < nb; ++b) e->frame_mask[f0 + b] = 1;
         e->frames_done += nb;
         e->frames_computed += nb;
-        if (bt.blk >= 0) e->block_ready[bt.blk] = 1;
+        if (bt.blk >= 0) for (auto& su : subs) e->block_ready[su.blk] = 1;
         // cheap views are refreshed every batch so a polling GUI sees progress (src/main.cpp:1508-1524)
         for (auto& p : e->props) if (p->prop.kind == PROP_RDF) { if (!refresh_distribution(e, p.get())) return false; }
     }
