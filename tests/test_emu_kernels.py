@@ -164,7 +164,7 @@ def test_sdf_sparse_and_dense_target_paths(emu_lib, oracle):
     # the scatter's target addressing: index list / arithmetic progression generated on the device, 4 / 8 atoms per thread,
     # targets with and without owners, an irregular list (no progression)
     irregular = np.sort(np.random.default_rng(5).choice(np.arange(0, N, dtype=np.int32), N // 4, replace=False)).astype(np.int32)
-    for arith, ilp, rows, wv in ((0, 4, 0, 0), (1, 8, 0, 0), (0, 16, 0, 0), (1, 4, 1, 0), (1, 4, 4, 0), (1, 4, 0, 1), (0, 8, 0, 1)):      # rows: 16-byte row streaming; wv: per-wave compaction
+    for arith, ilp, rows, wv in ((0, 4, 0, 0), (1, 8, 0, 0), (0, 16, 0, 0), (1, 4, 1, 0), (1, 4, 4, 0), (1, 4, 0, 1), (0, 8, 0, 1), (1, 4, 0, 2), (0, 8, 0, 16)):      # rows: 16-byte row streaming; wv: 1 per-wave compaction, 2 / >= 16 persistent streaming kernel
         old = emu_lib.vmd_set_option(b"sdf_arith", arith), emu_lib.vmd_set_option(b"sdf_ilp", ilp), emu_lib.vmd_set_option(b"sdf_rows", rows)
         old_wv = emu_lib.vmd_set_option(b"sdf_wave", wv)
         try:

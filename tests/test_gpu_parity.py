@@ -263,14 +263,17 @@ def test_sdf_sparse_and_dense_target_paths(gpu_lib, oracle):
     # the scatter's target addressing: index list / arithmetic progression generated on the device, 4 / 8 atoms per thread,
     # targets with and without owners, an irregular list (no progression)
     irregular = np.sort(np.random.default_rng(5).choice(np.arange(0, N, dtype=np.int32), N // 4, replace=False)).astype(np.int32)
-    for arith, ilp, rows in ((0, 4, 0), (1, 8, 0), (0, 16, 0), (1, 4, 1), (1, 4, 4)):      # rows: 16-byte row streaming for progressions
+    # rows: 16-byte row streaming for progressions; wv: 1 per-wave compaction, 2 / >= 16 the persistent streaming kernel (on that many blocks)
+    for arith, ilp, rows, wv in ((0, 4, 0, 0), (1, 8, 0, 0), (0, 16, 0, 0), (1, 4, 1, 0), (1, 4, 4, 0), (1, 4, 0, 1), (1, 4, 0, 2), (0, 8, 0, 2), (1, 4, 0, 16), (0, 4, 0, 512)):
         old = gpu_lib.vmd_set_option(b"sdf_arith", arith), gpu_lib.vmd_set_option(b"sdf_ilp", ilp), gpu_lib.vmd_set_option(b"sdf_rows", rows)
+        old_wv = gpu_lib.vmd_set_option(b"sdf_wave", wv)
         try:
             cases.check_sdf(gpu_lib, oracle, coords, 70.0, structures, mass, dense, 10.0, device=True)
             cases.check_sdf(gpu_lib, oracle, coords, 70.0, structures, mass, irregular, 10.0, device=True)
             cases.check_sdf(gpu_lib, oracle, coords, 70.0, structures, mass, np.arange(N, dtype=np.int32), 6.0, device=True)   # stride 1, owners among the targets
         finally:
             gpu_lib.vmd_set_option(b"sdf_arith", old[0]); gpu_lib.vmd_set_option(b"sdf_ilp", old[1]); gpu_lib.vmd_set_option(b"sdf_rows", old[2])
+            gpu_lib.vmd_set_option(b"sdf_wave", old_wv)
 
 
 def test_sdf_rigid_motion_invariance(gpu_lib, oracle):

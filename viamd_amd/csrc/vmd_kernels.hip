@@ -2210,6 +2210,101 @@ __global__ __launch_bounds__(256) void k_sdf_scatter_wave(vmd_scatter_params_t p
     }
 }
 
+// Streaming variant (`sdf_wave` = 2): the one-shot kernels above retire a block after ~12 KB of gathers and pay the launch of its
+// successor (kernel arguments, box and group record, index arithmetic - about a microsecond in which the wave slot has nothing in
+// flight) once per 1 024 atoms.  Here the grid is persistent: a wave walks the (frame, 64 * ILP targets) tiles w, w + W, w + 2 W, ...
+// (consecutive waves on consecutive tiles, so the grid reads one moving window of the trajectory) and issues the gathers of its NEXT
+// tile before it tests the current one - two register sets, the wave always has a tile in flight.  Survivors of the group test
+// are compacted per wave as in k_sdf_scatter_wave (no block barrier).  Same arithmetic, same result.
+template <int ILP>
+struct vmd_sdf_tile_t { int b; int idx[ILP], own[ILP]; float x[ILP], y[ILP], z[ILP]; };
+
+template <int ILP, bool ARITH>
+__device__ __forceinline__ void vmd_sdf_tile_load(const vmd_scatter_params_t& p, long long tile, int tiles_per_frame, int lane, vmd_sdf_tile_t<ILP>& T) {
+    T.b = (int)(tile / tiles_per_frame);
+    const int c = (int)(tile - (long long)T.b * tiles_per_frame);
+    const float* fx = p.xyz + (size_t)T.b * p.frame_stride;
+    const int t0 = c * (VMD_WAVE * ILP) + lane;
+#pragma unroll
+    for (int u = 0; u < ILP; ++u) {
+        const int t = t0 + VMD_WAVE * u;
+        T.idx[u] = -1; T.own[u] = p.unowned ? -1 : -2;
+        if (t < p.ntgt) {
+            T.idx[u] = ARITH ? p.tgt_first + t * p.tgt_stride : (p.tgt ? p.tgt[t] : t);
+            if (!p.unowned && p.owner) T.own[u] = (int)p.owner[t];
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < ILP; ++u) {
+        T.x[u] = T.y[u] = T.z[u] = 0.0f;
+        if (T.idx[u] >= 0) { T.x[u] = fx[T.idx[u]]; T.y[u] = fx[p.row_stride + T.idx[u]]; T.z[u] = fx[2 * p.row_stride + T.idx[u]]; }
+    }
+}
+
+template <int ILP>
+__device__ __forceinline__ void vmd_sdf_tile_scatter(const vmd_scatter_params_t& p, const vmd_sdf_tile_t<ILP>& T, int lane,
+                                                     float* s_x, float* s_y, float* s_z, int* s_own, int* s_idx) {
+    const int b = T.b;
+    const vmd_box_t bx = vmd_load_box(p.boxes, b, p.pbc);
+    unsigned pending = 0u;
+#pragma unroll
+    for (int u = 0; u < ILP; ++u) if (T.idx[u] >= 0 && vmd_sdf_near(p, bx, b, T.x[u], T.y[u], T.z[u])) pending |= 1u << u;
+    if (VMD_BALLOT(pending != 0u) == 0ull) return;          // ~99 % of the atoms fail the group test: most tiles end here
+    for (;;) {
+        unsigned base = 0u;                                   // wave-uniform: survivors placed in this round
+        bool left = false;
+#pragma unroll
+        for (int u = 0; u < ILP; ++u) {
+            const bool hit = (pending >> u) & 1u;
+            const unsigned long long m = VMD_BALLOT(hit);
+            if (m == 0ull) continue;
+            const unsigned pre = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+            const unsigned slot = base + pre;
+            if (hit && slot < (unsigned)VMD_WAVE) {
+                s_x[slot] = T.x[u]; s_y[slot] = T.y[u]; s_z[slot] = T.z[u]; s_own[slot] = T.own[u]; s_idx[slot] = T.idx[u];
+                pending &= ~(1u << u);
+            }
+            base += (unsigned)__popcll(m);
+            if (base > (unsigned)VMD_WAVE) left = true;
+        }
+        if (base == 0u) break;
+        __builtin_amdgcn_wave_barrier();
+        const int nwork = (int)(base < (unsigned)VMD_WAVE ? base : (unsigned)VMD_WAVE) * p.K;
+        for (int w = lane; w < nwork; w += VMD_WAVE) {
+            const int a = w / p.K, k = w - a * p.K;
+            vmd_sdf_atom_k(p, bx, b, k, s_x[a], s_y[a], s_z[a], s_own[a], s_idx[a]);
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (!left) break;                                     // wave-uniform
+    }
+}
+
+template <int ILP, bool ARITH>
+__global__ __launch_bounds__(256) void k_sdf_scatter_stream(vmd_scatter_params_t p, int tiles_per_frame) {
+    __shared__ float s_x[4][VMD_WAVE], s_y[4][VMD_WAVE], s_z[4][VMD_WAVE];
+    __shared__ int s_own[4][VMD_WAVE], s_idx[4][VMD_WAVE];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    const long long W = (long long)gridDim.x * 4;
+    const long long ntiles = (long long)tiles_per_frame * p.B;
+    long long tile = (long long)blockIdx.x * 4 + wave;
+    if (tile >= ntiles) return;
+    vmd_sdf_tile_t<ILP> A, B2;
+    vmd_sdf_tile_load<ILP, ARITH>(p, tile, tiles_per_frame, lane, A);
+    for (;;) {
+        const bool more1 = tile + W < ntiles;                 // wave-uniform
+        if (more1) vmd_sdf_tile_load<ILP, ARITH>(p, tile + W, tiles_per_frame, lane, B2);
+        vmd_sdf_tile_scatter<ILP>(p, A, lane, s_x[wave], s_y[wave], s_z[wave], s_own[wave], s_idx[wave]);
+        if (!more1) break;
+        tile += W;
+        const bool more2 = tile + W < ntiles;
+        if (more2) vmd_sdf_tile_load<ILP, ARITH>(p, tile + W, tiles_per_frame, lane, A);
+        vmd_sdf_tile_scatter<ILP>(p, B2, lane, s_x[wave], s_y[wave], s_z[wave], s_own[wave], s_idx[wave]);
+        if (!more2) break;
+        tile += W;
+    }
+}
+
 // Row-streaming variant for arithmetic-progression targets (first + t * stride, e.g. every water oxygen: stride 3): the lines of
 // the x / y / z rows are needed in full anyway (a stride-3 selection touches every 32-byte sector), so a thread takes GPT groups of
 // 4 consecutive ATOMS with 16-byte loads - three perfectly coalesced dwordx4 loads per group instead of twelve strided dword
@@ -2672,8 +2767,9 @@ static int g_sdf_nt = 0;        // the scatter's gathers as non-temporal loads (
 extern "C" int vmd_hip_set_sdf_nt(int on) { const int old = g_sdf_nt; g_sdf_nt = on ? 1 : 0; return old; }
 static int g_sdf_rows = 0;      // row-streaming scatter for arithmetic-progression targets: groups of 4 atoms per thread (0 = off, 1 / 2 / 4)
 extern "C" int vmd_hip_set_sdf_rows(int n) { const int old = g_sdf_rows; if (n == 0 || n == 1 || n == 2 || n == 4) g_sdf_rows = n; return old; }
-static int g_sdf_wave = 0;      // per-wave instead of per-block compaction of the group test's survivors (no block barrier)
-extern "C" int vmd_hip_set_sdf_wave(int on) { const int old = g_sdf_wave; g_sdf_wave = on ? 1 : 0; return old; }
+static int g_sdf_wave = 0;      // 1: per-wave instead of per-block compaction of the group test's survivors (no block barrier);
+                                // 2: the persistent streaming kernel (k_sdf_scatter_stream) on 2 048 blocks, n >= 16: on n blocks
+extern "C" int vmd_hip_set_sdf_wave(int on) { const int old = g_sdf_wave; g_sdf_wave = on < 0 ? 0 : (on > 65535 ? 65535 : on); return old; }
 static int g_sdf_ilp = 4;
 extern "C" int vmd_hip_set_sdf_ilp(int n) { const int old = g_sdf_ilp; if (n == 4 || n == 8 || n == 16) g_sdf_ilp = n; return old; }
 extern "C" int vmd_hip_sdf_scatter(void* stream, const float* xyz, size_t frame_stride, size_t row_stride,
@@ -2700,6 +2796,23 @@ extern "C" int vmd_hip_sdf_scatter(void* stream, const float* xyz, size_t frame_
         if (g_sdf_rows == 2) hipLaunchKernelGGL((k_sdf_scatter_rows<2>), dim3((ngroups + 511) / 512, B), dim3(256), 0, s, p, g_first, ngroups);
         else if (g_sdf_rows == 4) hipLaunchKernelGGL((k_sdf_scatter_rows<4>), dim3((ngroups + 1023) / 1024, B), dim3(256), 0, s, p, g_first, ngroups);
         else hipLaunchKernelGGL((k_sdf_scatter_rows<1>), dim3((ngroups + 255) / 256, B), dim3(256), 0, s, p, g_first, ngroups);
+        VMD_LAUNCH_CHECK();
+        return 0;
+    }
+    if (g_sdf_wave >= 2) {
+        const int ilp = g_sdf_ilp == 8 ? 8 : 4;
+        const int tiles_per_frame = (ntgt + VMD_WAVE * ilp - 1) / (VMD_WAVE * ilp);
+        const long long ntiles = (long long)tiles_per_frame * B;
+        long long nblocks = g_sdf_wave >= 16 ? g_sdf_wave : 2048;
+        if (nblocks > (ntiles + 3) / 4) nblocks = (ntiles + 3) / 4;
+        const dim3 g((unsigned)nblocks);
+        if (ilp == 8) {
+            if (arith) hipLaunchKernelGGL((k_sdf_scatter_stream<8, true>), g, dim3(256), 0, s, p, tiles_per_frame);
+            else hipLaunchKernelGGL((k_sdf_scatter_stream<8, false>), g, dim3(256), 0, s, p, tiles_per_frame);
+        } else {
+            if (arith) hipLaunchKernelGGL((k_sdf_scatter_stream<4, true>), g, dim3(256), 0, s, p, tiles_per_frame);
+            else hipLaunchKernelGGL((k_sdf_scatter_stream<4, false>), g, dim3(256), 0, s, p, tiles_per_frame);
+        }
         VMD_LAUNCH_CHECK();
         return 0;
     }
