@@ -39,10 +39,11 @@ int cur_lane() { return g_cur->linear & 63; }
 static void fiber_entry() {
     (*g_body)();
     Fiber* f = g_cur;
+    // A lane that leaves the kernel must read as "not there" in every later collective of its wave - but NOT yet in the one its
+    // siblings are still reading: a lane that returns right after a readlane used to zero its exchange entry before the lanes
+    // scheduled behind it had fetched it (k_xtc_wave: the walk of a wave that does not own the last tile ends on a readlane; found
+    // by scripts/fuzz_xtc.py seed 11).  The entries of finished lanes are cleared where a rendezvous is released (run_block).
     f->state = DONE;
-    const int wave = f->linear >> 6, lane = f->linear & 63;
-    g_xbuf[(size_t)(wave * 2 + 0) * 64 + lane] = 0;
-    g_xbuf[(size_t)(wave * 2 + 1) * 64 + lane] = 0;
     swapcontext(&f->ctx, &g_sched);
 }
 
@@ -152,6 +153,9 @@ static void run_block(int nthreads) {
                 else if (s != DONE) ready = false;
             }
             if (ready && any) {
+                // every live lane has written its entry of this collective and read the previous one: finished lanes drop out of both
+                for (int t = w * 64; t < end; ++t)
+                    if (g_fibers[t].state == DONE) { g_xbuf[(size_t)(w * 2 + 0) * 64 + (t & 63)] = 0; g_xbuf[(size_t)(w * 2 + 1) * 64 + (t & 63)] = 0; }
                 for (int t = w * 64; t < end; ++t) if (g_fibers[t].state == WAIT_WAVE) { g_fibers[t].state = RUNNABLE; released = true; }
             }
         }

@@ -39,6 +39,11 @@ def _systems():
     huge = rng.uniform(0, 60000.0, (3, 48)).astype(np.float32)
     huge[:, 1::4] = huge[:, 0::4] + rng.normal(0, 0.5, (3, 12)).astype(np.float32)
     out["huge"] = huge
+    # 2 500 A along every axis: 250 000 grid steps each, one packed number of 54 bits per atom - wider than the 52 bits fp64 holds
+    # exactly, divided through the reciprocal all the same because the divisors (18 and 36 bits) keep the quotients below 2^50
+    vast = rng.uniform(0, 2500.0, (3, 96)).astype(np.float32)
+    vast[:, 1::3] = vast[:, 0::3] + rng.normal(0, 0.4, (3, 32)).astype(np.float32)
+    out["vast"] = vast
     # exactly on a lattice: many identical differences, zero differences
     g = np.stack(np.meshgrid(np.arange(6), np.arange(5), np.arange(4), indexing="ij"), -1).reshape(-1, 3) * 1.5
     out["lattice"] = g.T.astype(np.float32)

@@ -135,6 +135,30 @@ __device__ __forceinline__ uint64_t xtc_div(uint64_t w, uint64_t d, double inv) 
 template <class BR>
 __device__ __forceinline__ bool xtc_triple(BR& b, int bits, const Radix& rx, int out[3]) {
     const int q = (bits - 1) >> 3, r = bits - 8 * q;            // q full bytes, then r in [1, 8] bits
+    if (bits <= 32) {
+        // the small triples of a run (and the large one of a small system): the number fits 32 bits, so the byte order, both
+        // quotients (u32 -> fp64 is exact, one v_cvt each way) and the remainders are 32-bit work - a third of the instructions
+        // of the 64-bit path below, for two of the three triples of a water molecule
+        const uint32_t raw = (uint32_t)xtc_get(b, bits);
+        const uint32_t top = raw >> r, low = raw & ((1u << r) - 1u);
+        const uint32_t w32 = (q ? (__builtin_bswap32(top) >> (32 - 8 * q)) : 0u) | (low << (8 * q));
+        uint32_t qa = (uint32_t)((double)w32 * rx.inv2);
+        const int32_t ra = (int32_t)(w32 - qa * rx.s2);          // true remainder in (-s2, 2 s2), s2 < 2^31: exact modulo 2^32
+        if (ra < 0) --qa;
+        else if ((uint32_t)ra >= rx.s2) ++qa;
+        uint32_t qb = 0u;
+        if (rx.s12 <= (uint64_t)w32) {                           // otherwise the quotient is 0 (s12 may not even fit 32 bits)
+            const uint32_t d12 = (uint32_t)rx.s12;
+            qb = (uint32_t)((double)w32 * rx.inv12);
+            const int64_t rb = (int64_t)w32 - (int64_t)((uint64_t)qb * d12);
+            if (rb < 0) --qb;
+            else if (rb >= (int64_t)d12) ++qb;
+        }
+        out[2] = (int)(w32 - qa * rx.s2);
+        out[1] = (int)(qa - qb * rx.s1);
+        out[0] = (int)qb;
+        return true;
+    }
     uint64_t w;
     bool ok = true;
     if (bits <= 56) {
@@ -149,7 +173,12 @@ __device__ __forceinline__ bool xtc_triple(BR& b, int bits, const Radix& rx, int
         else ok = last == 0;                                     // byte 8 of the number
     }
     uint64_t qa, qb;
-    if (bits <= 52) {
+    // quotient through the reciprocal in fp64: w and 1/d carry a relative error of 2^-53 each, the product one more, so the estimate
+    // is within 1 of floor(w / d) - which xtc_div repairs - as long as the quotient itself stays below 2^50: always for numbers of up
+    // to 52 bits, and for wider ones when the divisor has the bits to spare (bits - 50 <= floor(log2 d): the large triple of a
+    // 216 A box at precision 1000 is a 54-bit number over divisors of 18 and 36 bits; the integer division it used to take is two
+    // ~150-instruction sequences per atom)
+    if (bits <= 52 || (bits <= 64 && (rx.s2 >> (bits - 50)) != 0u)) {
         qa = xtc_div(w, rx.s2, rx.inv2);
         qb = xtc_div(w, rx.s12, rx.inv12);
     } else {
