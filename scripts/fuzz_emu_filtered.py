@@ -9,16 +9,18 @@ import viamd_amd as V
 from viamd_amd import _lib as L
 from oracle import oracle as O
 
-lib = V.VmdLib(conftest.build_emu())
+on_gpu = len(sys.argv) > 3 and sys.argv[3] == "gpu"          # the product library on a real GPU instead of the emulator build
+lib = V.default_lib() if on_gpu else V.VmdLib(conftest.build_emu())
+scale = 25 if on_gpu else 1
 ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 box = 30.0
 bad = 0
 for it in range(ncases):
     F = int(rng.integers(3, 24))
-    coords, structures, mass = cases.sdf_system(O, int(rng.integers(0, 9999)), 240, box, F, K=2, m=4)
+    coords, structures, mass = cases.sdf_system(O, int(rng.integers(0, 9999)), 240 * scale, box * (scale ** (1.0 / 3.0)), F, K=2, m=4)
     N = coords.shape[2]
-    ocell, vcell = cases.cell_pair(O, box)
+    ocell, vcell = cases.cell_pair(O, box * (scale ** (1.0 / 3.0)))
     ox = np.arange(structures.size, N, 3, dtype=np.int32)
     ir = V.ScriptIR(lib)
     ir.add_rdf("g", ox, ox, (0.0, 8.0)); ir.add_sdf("v", structures, ox, 6.0); ir.add_distance("d", structures[0], structures[1], L.DIST_COM)
@@ -27,6 +29,7 @@ for it in range(ncases):
     S = int(rng.integers(1, F + 3))
     full = V.ScriptEval(F, ir); full.set_block_frames(S)
     old = lib.vmd_set_option(b"batch_frames", int(rng.choice([0, 1, 2, 5])))
+    old_sb = (lib.vmd_set_option(b"block_superbatch", int(rng.integers(0, 2))), lib.vmd_set_option(b"block_two_streams", int(rng.integers(0, 2))))
     try:
         # feed the full evaluation in random contiguous pieces, in random order
         cuts = sorted(set([0, F] + [int(c) for c in rng.integers(1, F, int(rng.integers(0, 4)))]))
@@ -51,4 +54,5 @@ for it in range(ncases):
         print("MISMATCH case", it, F, S, str(e)[:300])
     finally:
         lib.vmd_set_option(b"batch_frames", old)
+        lib.vmd_set_option(b"block_superbatch", old_sb[0]); lib.vmd_set_option(b"block_two_streams", old_sb[1])
 print(f"{ncases} cases, {bad} failures")

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Randomised cross-check of the native XTC writer / reader (viamd_amd/csrc/vmd_xdr.cpp, emulator build: the file code is plain
 host C++) against the byte-wise Python restatement tests/xtc_ref.py: byte-identical files, identical decoded integers.
-usage: python scripts/fuzz_xtc.py [trials] [seed]"""
+usage: python scripts/fuzz_xtc.py [trials] [seed] [gpu]"""
 import os
 import sys
 import tempfile
@@ -39,7 +39,11 @@ def random_system(rng):
 def main():
     trials = int(sys.argv[1]) if len(sys.argv) > 1 else 300
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-    lib = V.VmdLib(conftest.build_emu())
+    on_gpu = len(sys.argv) > 3 and sys.argv[3] == "gpu"      # the device decoders of the product library on a real GPU
+    if on_gpu:
+        import torch  # noqa: F401      torch first, as in bench.py and tests/conftest.py: its bundled HIP runtime must be the one that finds the GPU
+    lib = V.default_lib() if on_gpu else V.VmdLib(conftest.build_emu())      # one library per process: both export the same symbols
+    dev_lib = lib
     rng = np.random.default_rng(seed)
     tmp = tempfile.mkdtemp()
     ndev = 0
@@ -59,7 +63,10 @@ def main():
         want = ((ints.astype(np.float32) * (np.float32(1) / np.float32(precision))) * np.float32(10)).T
         assert np.array_equal(got, want), f"trial {t}: native decode differs (seed {seed})"
         assert np.array_equal(xtc_ref.parse_frames(nat)[0]["ints"], ints), f"trial {t}: python decode differs"
-        dev, status = test_xdr._device_decode(lib, nat, xyz.shape[1], chunk=(0, 64, 97, -1, -2, -3, -4, -5, -6)[t % 9])    # every device variant (-1: wave per frame, -2: + checkpointed second pass, -3 / -4: the same on streams laid out as in the file), on the SIMT emulator
+        try:
+            dev, status = test_xdr._device_decode(dev_lib, nat, xyz.shape[1], chunk=(0, 64, 97, -1, -2, -3, -4, -5, -6)[t % 9], gpu=on_gpu)
+        except AssertionError as e:
+            raise AssertionError(f"trial {t} (seed {seed}, {xyz.shape[1]} atoms, precision {precision}, variant {(0, 64, 97, -1, -2, -3, -4, -5, -6)[t % 9]}): {str(e)[:300]}")    # every device variant (-1: wave per frame, -2: + checkpointed second pass, -3 / -4: the same on streams laid out as in the file), on the SIMT emulator
         assert status[0] in (0, 2), f"trial {t}: device decoder rejected a valid stream (seed {seed})"
         if status[0] == 0:
             assert np.array_equal(dev[0], want), f"trial {t}: device decode differs (seed {seed})"

@@ -376,7 +376,7 @@ def _device_decode(lib, blob, natoms, chunk=0, gpu=False):
     if gpu:
         torch.cuda.synchronize()
         out, status = d_out.cpu().numpy(), d_status.cpu().numpy().astype(np.uint32)
-    assert rc == 0
+    assert rc == 0, f"launch of the device decoder (chunk {chunk}) returned {rc}"
     return out[:, :, :natoms], status
 
 
