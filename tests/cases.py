@@ -160,6 +160,20 @@ def cell_build_overflow_case(lib, O, device=False, n=3000, box=60.0):
     nb = C.c_uint64(0)
     lib.vmd_profile_ms(b"cells_build", C.byref(nb))
     assert nb.value >= 2, "the overflowing batch was not rebuilt"
+    # several batches: the next batch is queued before the host looks at the overflowing one (deferred completion) - it saw the flag
+    # as well and has to repeat its RDF part when its turn comes; with and without the deferral, with the overflow in the middle
+    # batch and in the last one
+    for bf, defer in ((4, 1), (3, 1), (5, 1), (4, 0)):
+        old = (lib.vmd_set_option(b"batch_frames", bf), lib.vmd_set_option(b"defer_sync", defer))
+        lib.vmd_profile_reset(); lib.vmd_profile_enable(True)
+        try:
+            check_rdf(lib, O, coords, box, [("goo", o, o, 0.0, 12.0)], device=device)
+            check_rdf(lib, O, coords[::-1].copy(), box, [("goo", o, o, 0.0, 12.0)], device=device)
+        finally:
+            lib.vmd_profile_enable(False)
+            lib.vmd_set_option(b"batch_frames", old[0]); lib.vmd_set_option(b"defer_sync", old[1])
+        lib.vmd_profile_ms(b"cells_build", C.byref(nb))
+        assert nb.value > 2 * ((F + bf - 1) // bf), "no batch was rebuilt"
     # the overflow happens in the build of a LATER pass (the hydrogens of the second property, the third range): the passes that
     # ran before it must not survive into the repeated batch (all-or-nothing commit at the end of the batch)
     coords = water_box(O, 6, n, box, F)

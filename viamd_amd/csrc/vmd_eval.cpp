@@ -86,6 +86,7 @@ struct Options {
                                              // frame (k_xtc_decode), 2 = index pass + one thread per chunk (k_xtc_index / k_xtc_chunks),
                                              // 3 = one wave per frame (k_xtc_wave)
     std::atomic<int> xtc_chunk{256};         // atoms per chunk of variant 2
+    std::atomic<int> defer_sync{0};          // the next batch is queued before the host waits for the current one (evals without block partials); measured r03ad: no gain (the per-batch host gap is ~0.06 ms; the next decode then lands on the cell build), off
     std::atomic<int> block_superbatch{1};    // filtered evaluation: consecutive frame blocks share ONE batch (one cell build, one synchronisation; a pair launch per block)
     std::atomic<int> block_two_streams{1};   // ... and the blocks' pair launches alternate between two streams, so that the tail of one runs under the head of the next
     std::atomic<int> xtc_ramp{0};            // file-backed device decode: small first and last batches (pipeline fill / drain); r03o: no gain, off
@@ -147,6 +148,7 @@ extern "C" int vmd_set_option(const char* key, int value) {
     else if (!strcmp(key, "raw_f32_device")) o = &g_opt.raw_f32_device;
     else if (!strcmp(key, "xtc_ramp")) o = &g_opt.xtc_ramp;
     else if (!strcmp(key, "block_superbatch")) o = &g_opt.block_superbatch;
+    else if (!strcmp(key, "defer_sync")) o = &g_opt.defer_sync;
     else if (!strcmp(key, "block_two_streams")) o = &g_opt.block_two_streams;
     else if (!strcmp(key, "xtc_decode_ahead")) o = &g_opt.xtc_decode_ahead;
     else if (!strcmp(key, "xtc_map_limit_mb")) o = &g_opt.xtc_map_limit_mb;
@@ -756,9 +758,12 @@ struct vmd_script_eval_t {
     std::vector<RdfGroup> rdf_groups;
     DevBuf<uint64_t> d_pass;                 // [passes of the batch][bins]: scratch histogram of every pair pass, committed at the batch's end
     DevBuf<uint32_t> d_overflow;             // device flag raised by the two-level cell build when a pencil bucket is full
-    uint32_t* h_overflow = nullptr;          // pinned host copy, read at every batch's synchronisation point
+    uint32_t* h_overflow = nullptr;          // pinned host copies (one per batch in flight), read where a batch is completed
+    hipEvent_t batch_done[2] = {nullptr, nullptr};   // end of a queued batch (deferred completion: process_range)
+    uint64_t* h_snap = nullptr; size_t h_snap_cap = 0;   // pinned: the RDF counts behind the commits of the two batches in flight
+    std::vector<double> w_snap;              // ... and the weights that go with them
+    std::vector<float> h_temporal_slot[2];
     DevBuf<uint32_t> d_pen_sample;
-    std::vector<float> h_temporal;
     // filtered evaluation: per-block partial accumulators and the eval whose blocks this one may reuse
     size_t block_frames = 0;
     std::unique_ptr<std::atomic<uint8_t>[]> block_ready;
@@ -957,8 +962,9 @@ extern "C" vmd_script_eval_t* vmd_eval_create(size_t num_frames, const vmd_scrip
     }
     build_rdf_plan(e.get());
     if (!e->d_overflow.ensure(1) || hipMemsetAsync(e->d_overflow.p, 0, sizeof(uint32_t), e->stream) != hipSuccess ||
-        hipHostMalloc((void**)&e->h_overflow, sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) { vmd_fail("allocating the overflow flag failed"); return nullptr; }
-    *e->h_overflow = 0;
+        hipHostMalloc((void**)&e->h_overflow, 2 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) { vmd_fail("allocating the overflow flag failed"); return nullptr; }
+    e->h_overflow[0] = e->h_overflow[1] = 0;
+    for (auto& ev : e->batch_done) if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { vmd_fail("hipEventCreate failed"); return nullptr; }
     if (hipStreamSynchronize(e->stream) != hipSuccess) { vmd_fail("hipStreamSynchronize failed"); return nullptr; }
     return e.release();
 }
@@ -1004,6 +1010,9 @@ extern "C" void vmd_eval_free(vmd_script_eval_t* eval) {
         eval->sels.clear();
         if (eval->h_overflow) (void)hipHostFree(eval->h_overflow);
         eval->h_overflow = nullptr;
+        if (eval->h_snap) (void)hipHostFree(eval->h_snap);
+        eval->h_snap = nullptr;
+        for (auto& ev : eval->batch_done) { if (ev) (void)hipEventDestroy(ev); ev = nullptr; }
         if (eval->stream) (void)hipStreamDestroy(eval->stream);
         eval->stream = nullptr;
     }
@@ -1075,6 +1084,22 @@ extern "C" size_t vmd_eval_num_frames(const vmd_script_eval_t* eval) { return ev
 extern "C" size_t vmd_eval_frames_done(const vmd_script_eval_t* eval) { return eval ? eval->frames_done.load() : 0; }
 
 // ---- host views -------------------------------------------------------------------------------------------------
+
+// the float views of a distribution from integer counts and fp64 weights (the device accumulators, or a snapshot of them)
+static void refresh_distribution_from(PropState* p, const uint64_t* counts, const double* weights64) {
+    float ymax = 0.0f, vmax = 0.0f;
+    for (size_t b = 0; b < p->ncounts; ++b) {
+        p->counts[b] = counts[b];
+        const float v = (float)counts[b];
+        const float w = (float)weights64[b];
+        p->values[b] = v; p->weights[b] = w;
+        vmax = std::max(vmax, v);
+        if (w > 0.0f) ymax = std::max(ymax, v / w);
+    }
+    p->data.min_value = 0.0f; p->data.max_value = vmax;
+    p->data.min_range[1] = 0.0f; p->data.max_range[1] = ymax;
+    p->data.fingerprint += 1;
+}
 
 static bool refresh_distribution(vmd_script_eval_t* e, PropState* p) {
     HIP_OK(hipMemcpyAsync(p->counts.data(), p->d_counts.p, p->ncounts * sizeof(uint64_t), hipMemcpyDeviceToHost, e->stream));
@@ -2218,147 +2243,242 @@ static bool process_range(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
     }
     for (size_t bi = 0; bi < std::min(stage_ahead, batches.size()); ++bi)
         if (!fetch_stage(e, stage_of(bi), traj, vw, num_atoms, batches[bi].f0, batches[bi].nb, false, slot_of(bi))) return false;
+    // ---- one batch in flight, one being queued.  The kernels of batch k + 1 are queued BEFORE the host waits for batch k (on an event,
+    // not on the stream): the device never idles across the host's per-batch work - the wait itself, the bookkeeping, the ~15 launches
+    // of the next batch (~0.15 ms per boundary, a tenth of a step when batches are the 128 frames a file-backed pass stages).  Everything
+    // a batch hands to the host has two slots (overflow flag, temporal rows, a snapshot of the RDF counts behind its commits); a batch
+    // whose cell build overflowed still voids itself AND whatever was queued behind it (the flag is sticky): the later batch is marked
+    // and repeats its RDF part when its turn comes.  Evals that keep block partials complete every batch before the next is queued.
+    struct Sub { size_t off, nb; long blk; };
+    struct BatchCtx {
+        Batch bt{0, 0, -1, 0};
+        Stage* src = nullptr;
+        size_t f0 = 0, nb = 0;
+        uint32_t pbc = 0;
+        std::vector<Sub> subs;
+        bool two_streams = false;
+        int slot = 0;
+        bool active = false;        // queued, not completed
+        bool poisoned = false;      // queued behind a batch that overflowed: its RDF part saw the flag and did nothing
+        bool snapshot = false;      // h_snap[slot] holds the RDF counts behind this batch's commits (+ w_snap: the weights)
+    };
+    BatchCtx ctx[2];
+    const bool defer = g_opt.defer_sync.load() != 0 && e->block_frames == 0 && batches.size() > 1;
+    size_t rdf_counts = 0;
+    for (auto& p : e->props) if (p->prop.kind == PROP_RDF) rdf_counts += p->ncounts;
+    if (defer && rdf_counts) {
+        if (e->h_snap_cap < 2 * rdf_counts) {
+            if (e->h_snap) (void)hipHostFree(e->h_snap);
+            e->h_snap = nullptr; e->h_snap_cap = 0;
+            HIP_OK(hipHostMalloc((void**)&e->h_snap, 2 * rdf_counts * sizeof(uint64_t), hipHostMallocDefault));
+            e->h_snap_cap = 2 * rdf_counts;
+        }
+        e->w_snap.resize(2 * rdf_counts);
+    }
+    auto acc_of = [&](PropState* p, const Sub& sb) -> uint64_t* {
+        return (sb.blk >= 0 && p->ncounts) ? p->d_blocks.p + (size_t)sb.blk * p->ncounts : p->d_counts.p;
+    };
+    // ---- RDF: one pair pass per (group, pass); launch_rdf may run again for this batch when a cell-build bucket overflowed
+    // Every pass accumulates into its own scratch row and the rows are committed to the properties' accumulators by ONE
+    // group of k_axpy_u64 launches at the very end, behind the overflow flag: by then every cell build of the batch has run,
+    // so the flag is final and the batch's RDF part is all-or-nothing (a bucket of a LATER build may overflow after earlier
+    // passes have long finished; nothing of them may stay behind when the batch is repeated).
+    auto launch_rdf = [&](BatchCtx& c) -> bool {
+        VMD_STAGE("batch: cell build + pair kernels");
+        vmd_hip_set_rdf_closed(e->spec.rdf_closed ? 1 : 0);
+        size_t scratch_rows = 0;
+        for (auto& g : e->rdf_groups) scratch_rows += std::max(g.passes.size(), g.props.size());
+        scratch_rows *= c.subs.size();
+        if (!e->d_pass.ensure(std::max<size_t>(scratch_rows, 1) * VMD_RDF_NUM_BINS)) return false;
+        HIP_OK(hipMemsetAsync(e->d_pass.p, 0, scratch_rows * VMD_RDF_NUM_BINS * sizeof(uint64_t), e->stream));
+        struct Commit { uint64_t* dst; const uint64_t* src; uint64_t mult; };
+        std::vector<Commit> commits;
+        size_t row = 0;
+        bool forked = false;
+        for (auto& g : e->rdf_groups) {
+            vmd_grid_t grid;
+            // fully periodic cells use the frame boxes; open axes (non-periodic systems, slabs) span the batch's bounding box
+            const bool open_axes = (c.pbc & 8u) == 0 && (c.pbc & VMD_UNITCELL_PBC_ALL) != VMD_UNITCELL_PBC_ALL;
+            if (open_axes && !g_opt.force_brute && !prepare_open_boxes(e, *c.src, c.nb, c.pbc, num_atoms)) return false;
+            const std::vector<float>& gb = (open_axes && c.src->gboxes_ready) ? c.src->h_gboxes : c.src->h_boxes;
+            const float* d_gb = (open_axes && c.src->gboxes_ready) ? c.src->d_gboxes.p : c.src->d_boxes.p;
+            if (!choose_grid(gb, c.pbc, c.nb, g.rmax, &grid)) {
+                // no grid for this batch (cutoff >= half the cell width, ...): all pairs, per property
+                for (int pi : g.props) {
+                    PropState* p = e->props[pi].get();
+                    Selection* sa = e->sels[p->sel_a].get();
+                    Selection* sb = e->sels[p->sel_b].get();
+                    for (auto& su : c.subs) {
+                        uint64_t* dst = e->d_pass.p + (row++) * VMD_RDF_NUM_BINS;
+                        e->prof.begin("rdf_brute", e->stream);
+                        KRN_OK(vmd_hip_rdf_brute(e->stream, c.src->base + su.off * c.src->frame_stride, c.src->frame_stride, c.src->row_stride, c.src->d_boxes.p + 9 * su.off, c.pbc, (int)su.nb,
+                                                 sa->d_idx.p, (int)sa->idx.size(), sb->d_idx.p, (int)sb->idx.size(),
+                                                 g.rmin, g.rmax, VMD_RDF_NUM_BINS, dst));
+                        e->prof.end(e->stream);
+                        commits.push_back({acc_of(p, su), dst, 1});
+                    }
+                }
+                continue;
+            }
+            if (!e->d_partial.ensure(vmd_hip_rdf_partial_words())) return false;
+            if (c.two_streams && !e->d_partial2.ensure(vmd_hip_rdf_partial_words())) return false;
+            for (auto& ps : g.passes) {
+                Selection* sa = e->sels[ps.sel_a].get();
+                Selection* sb = e->sels[ps.sel_b].get();
+                // passes with the same cutoff share the sorted copies; build_selection re-sorts when the grid differs
+                if (forked) {     // the second stream still reads the sorted copies of the previous pass
+                    HIP_OK(hipEventRecord(e->pair_join, e->pair_stream));
+                    HIP_OK(hipStreamWaitEvent(e->stream, e->pair_join, 0));
+                    forked = false;
+                }
+                if (!build_selection(e, sa, *c.src, d_gb, c.pbc, c.nb, grid)) return false;
+                if (sb != sa && !build_selection(e, sb, *c.src, d_gb, c.pbc, c.nb, grid)) return false;
+                // the pair set is symmetric in (ref, target): put the denser selection in the lanes - 64 of its atoms span a
+                // shorter stretch of the pencil, so the x window of every segment carries less padding
+                if (sb->idx.size() > sa->idx.size()) std::swap(sa, sb);
+                if (c.two_streams) {
+                    HIP_OK(hipEventRecord(e->pair_fork, e->stream));
+                    HIP_OK(hipStreamWaitEvent(e->pair_stream, e->pair_fork, 0));
+                    forked = true;
+                }
+                size_t si = 0;
+                for (auto& su : c.subs) {
+                    uint64_t* dst = e->d_pass.p + (row++) * VMD_RDF_NUM_BINS;
+                    const bool second = c.two_streams && (si++ & 1);
+                    hipStream_t ks = second ? e->pair_stream : e->stream;
+                    if (!second) e->prof.begin("rdf_pencil", ks);
+                    KRN_OK(vmd_hip_rdf_pencil(ks, sa->sorted.p + su.off * 3 * (size_t)sa->nsel_pad, sa->cell_start.p + su.off * (size_t)(grid.ncell + 1), (int)sa->idx.size(), sa->nsel_pad,
+                                              sb->sorted.p + su.off * 3 * (size_t)sb->nsel_pad, sb->cell_start.p + su.off * (size_t)(grid.ncell + 1), (int)sb->idx.size(), sb->nsel_pad,
+                                              d_gb + 9 * su.off, (int)su.nb, grid, g.rmin, g.rmax, VMD_RDF_NUM_BINS,
+                                              ps.same ? 1 : 0, g_opt.rdf_variant, c.pbc, second ? e->d_partial2.p : e->d_partial.p, dst, e->d_overflow.p));
+                    if (!second) e->prof.end(ks);
+                    if (e->spec.rdf_closed && ps.same && g.rmin <= 0.0f && 0.0f <= g.rmax) {
+                        // closed interval: d = 0 is a hit, but a same-set pass walks the half shell (j > i, every hit twice) and never
+                        // meets the pairs (i, i) - one per list entry and frame, all in the bin of d = 0 (SPEC S4 binning of 0)
+                        int bin0 = (int)(((0.0f - g.rmin) * (1.0f / (g.rmax - g.rmin))) * (float)VMD_RDF_NUM_BINS);
+                        bin0 = std::min(std::max(bin0, 0), VMD_RDF_NUM_BINS - 1);
+                        KRN_OK(vmd_hip_bump_u64(ks, dst + bin0, (uint64_t)su.nb * (uint64_t)sa->idx.size()));
+                    }
+                    for (auto& tg : ps.targets) commits.push_back({acc_of(e->props[tg.first].get(), su), dst, tg.second});
+                }
+            }
+        }
+        if (forked) {
+            HIP_OK(hipEventRecord(e->pair_join, e->pair_stream));
+            HIP_OK(hipStreamWaitEvent(e->stream, e->pair_join, 0));
+        }
+        for (auto& cm : commits) KRN_OK(vmd_hip_axpy_u64(e->stream, cm.dst, cm.src, VMD_RDF_NUM_BINS, cm.mult, e->d_overflow.p));
+        HIP_OK(hipMemcpyAsync(&e->h_overflow[c.slot], e->d_overflow.p, sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
+        return true;
+    };
+
+    // waits for a queued batch (`later`: the batch already queued behind it, if any), repeats its RDF part when a bucket overflowed, books its frames
+    auto complete_batch = [&](BatchCtx& c, BatchCtx* later) -> bool {
+        if (!c.active) return true;
+        c.active = false;
+        const bool behind = later && later->active;
+        VMD_STAGE("batch: waiting for its kernels");
+        { HostTimer host_timer("host_sync_wait");
+          if (behind) HIP_OK(hipEventSynchronize(e->batch_done[c.slot]));
+          else HIP_OK(hipStreamSynchronize(e->stream)); }
+        VMD_STAGE("batch: host bookkeeping");
+        // a bucket of the two-level cell build was too small: nothing reached the histograms (every consumer saw the flag).
+        // Re-measure the selections that used buckets with more head room and evaluate the RDF part of this batch again.
+        bool repeated = false;
+        for (int attempt = 0; e->h_overflow[c.slot] != 0; ++attempt) {
+            if (attempt >= 4) return vmd_fail("cell build: pencil buckets keep overflowing");
+            if (behind) {          // the batch behind this one saw the flag too: let it drain, it repeats its RDF part at its own completion
+                HIP_OK(hipStreamSynchronize(e->stream));
+                later->poisoned = true;
+            }
+            const bool own = !(c.poisoned && attempt == 0);      // a poisoned batch did not overflow itself (as far as anyone knows)
+            for (auto& sl : e->sels) {
+                sl->built = false;
+                if (!own || !sl->used_pencil) continue;
+                sl->pen_off.clear();
+                sl->caps_cache.clear();
+                sl->cap_margin *= 1.6f;
+                sl->overflows += 1;
+            }
+            e->h_overflow[c.slot] = 0;
+            HIP_OK(hipMemsetAsync(e->d_overflow.p, 0, sizeof(uint32_t), e->stream));
+            if (!launch_rdf(c)) return false;
+            HIP_OK(hipStreamSynchronize(e->stream));
+            repeated = true;
+        }
+        if (c.bt.blk >= 0)
+            for (auto& su : c.subs)
+                for (auto& p : e->props) if (p->ncounts) KRN_OK(vmd_hip_add_u64(e->stream, p->d_counts.p, acc_of(p.get(), su), p->ncounts));
+        e->prof.resolve();
+        if (g_prof_on) { std::lock_guard<std::mutex> l(g_prof_mtx); g_prof["batches"].launches += 1; }
+        size_t toff = 0;
+        for (auto& p : e->props) {
+            if (p->prop.kind != PROP_DIST) continue;
+            memcpy(&p->values[c.f0 * p->dim1], e->h_temporal_slot[c.slot].data() + toff, c.nb * p->dim1 * sizeof(float));
+            toff += c.nb * p->dim1;
+        }
+        for (size_t b = 0; b < c.nb; ++b) e->frame_mask[c.f0 + b] = 1;
+        e->frames_done += c.nb;
+        e->frames_computed += c.nb;
+        if (c.bt.blk >= 0) for (auto& su : c.subs) e->block_ready[su.blk] = 1;
+        // cheap views are refreshed every batch so a polling GUI sees progress (src/main.cpp:1508-1524): from the device when nothing
+        // is queued behind this batch, from the snapshot taken behind its commits otherwise
+        size_t soff = (size_t)c.slot * rdf_counts;
+        for (auto& p : e->props) {
+            if (p->prop.kind != PROP_RDF) continue;
+            if (behind && c.snapshot && !repeated && !(later && later->poisoned)) refresh_distribution_from(p.get(), e->h_snap + soff, e->w_snap.data() + soff);
+            else if (!behind) { if (!refresh_distribution(e, p.get())) return false; }
+            soff += p->ncounts;
+        }
+        return true;
+    };
+
     for (size_t bi = 0; bi < batches.size(); ++bi) {
         if (e->interrupt) { completed = false; break; }
-        const Batch& bt = batches[bi];
-        const size_t f0 = bt.f0, nb = bt.nb;
-        Stage& src = stage_of(bi);
-        { HostTimer host_timer("host_settle"); if (!settle_stage(e, src, traj, num_atoms)) return false; }
+        BatchCtx& c = ctx[bi & 1];
+        BatchCtx& prev = ctx[(bi & 1) ^ 1];
+        c = BatchCtx{};
+        c.bt = batches[bi]; c.f0 = c.bt.f0; c.nb = c.bt.nb; c.slot = (int)(bi & 1);
+        c.src = &stage_of(bi);
+        { HostTimer host_timer("host_settle"); if (!settle_stage(e, *c.src, traj, num_atoms)) return false; }
         VMD_STAGE("batch: kernels queued");
         HostTimer queue_timer("host_queue_to_sync");
-        HIP_OK(hipStreamWaitEvent(e->stream, src.ready, 0));
-        const uint32_t pbc = batch_pbc(src);
+        HIP_OK(hipStreamWaitEvent(e->stream, c.src->ready, 0));
+        c.pbc = batch_pbc(*c.src);
         for (auto& s : e->sels) s->built = false;
 
         size_t temporal_floats = 0;
-        for (auto& p : e->props) if (p->prop.kind == PROP_DIST) temporal_floats += nb * p->dim1;
-        e->h_temporal.resize(temporal_floats);
+        for (auto& p : e->props) if (p->prop.kind == PROP_DIST) temporal_floats += c.nb * p->dim1;
+        e->h_temporal_slot[c.slot].resize(temporal_floats);
         size_t toff = 0;
 
         // a whole frame block accumulates into its own partial first and is merged into the totals afterwards.  A batch of blocks
         // (filtered evaluation) is evaluated block by block - `subs` - behind one cell build and in front of one synchronisation.
-        struct Sub { size_t off, nb; long blk; };
-        std::vector<Sub> subs;
-        if (bt.blk >= 0 && bt.nblk > 1) {
+        if (c.bt.blk >= 0 && c.bt.nblk > 1) {
             const size_t S = e->block_frames;
-            for (size_t j = 0; j < bt.nblk; ++j) subs.push_back({j * S, std::min(S, nb - j * S), bt.blk + (long)j});
-        } else subs.push_back({0, nb, bt.blk});
-        auto acc_of = [&](PropState* p, const Sub& sb) -> uint64_t* {
-            return (sb.blk >= 0 && p->ncounts) ? p->d_blocks.p + (size_t)sb.blk * p->ncounts : p->d_counts.p;
-        };
-        if (bt.blk >= 0)
-            for (auto& sb : subs)
+            for (size_t j = 0; j < c.bt.nblk; ++j) c.subs.push_back({j * S, std::min(S, c.nb - j * S), c.bt.blk + (long)j});
+        } else c.subs.push_back({0, c.nb, c.bt.blk});
+        if (c.bt.blk >= 0)
+            for (auto& sb : c.subs)
                 for (auto& p : e->props) if (p->ncounts) HIP_OK(hipMemsetAsync(acc_of(p.get(), sb), 0, p->ncounts * sizeof(uint64_t), e->stream));
         // the blocks' pair launches alternate between the eval's stream and a second one (own partial rows): a 50-frame launch of a
         // 100k-atom system is ~3 work items per resident wave, and the tail of one launch then runs under the head of the next
-        const bool two_streams = subs.size() > 1 && g_opt.block_two_streams.load() != 0;
+        c.two_streams = c.subs.size() > 1 && g_opt.block_two_streams.load() != 0;
 
-        // ---- RDF: one pair pass per (group, pass); launch_rdf may run again for this batch when a cell-build bucket overflowed
-        // Every pass accumulates into its own scratch row and the rows are committed to the properties' accumulators by ONE
-        // group of k_axpy_u64 launches at the very end, behind the overflow flag: by then every cell build of the batch has run,
-        // so the flag is final and the batch's RDF part is all-or-nothing (a bucket of a LATER build may overflow after earlier
-        // passes have long finished; nothing of them may stay behind when the batch is repeated).
-        auto launch_rdf = [&]() -> bool {
-            VMD_STAGE("batch: cell build + pair kernels");
-            vmd_hip_set_rdf_closed(e->spec.rdf_closed ? 1 : 0);
-            size_t scratch_rows = 0;
-            for (auto& g : e->rdf_groups) scratch_rows += std::max(g.passes.size(), g.props.size());
-            scratch_rows *= subs.size();
-            if (!e->d_pass.ensure(std::max<size_t>(scratch_rows, 1) * VMD_RDF_NUM_BINS)) return false;
-            HIP_OK(hipMemsetAsync(e->d_pass.p, 0, scratch_rows * VMD_RDF_NUM_BINS * sizeof(uint64_t), e->stream));
-            struct Commit { uint64_t* dst; const uint64_t* src; uint64_t mult; };
-            std::vector<Commit> commits;
-            size_t row = 0;
-            bool forked = false;
-            for (auto& g : e->rdf_groups) {
-                vmd_grid_t grid;
-                // fully periodic cells use the frame boxes; open axes (non-periodic systems, slabs) span the batch's bounding box
-                const bool open_axes = (pbc & 8u) == 0 && (pbc & VMD_UNITCELL_PBC_ALL) != VMD_UNITCELL_PBC_ALL;
-                if (open_axes && !g_opt.force_brute && !prepare_open_boxes(e, src, nb, pbc, num_atoms)) return false;
-                const std::vector<float>& gb = (open_axes && src.gboxes_ready) ? src.h_gboxes : src.h_boxes;
-                const float* d_gb = (open_axes && src.gboxes_ready) ? src.d_gboxes.p : src.d_boxes.p;
-                if (!choose_grid(gb, pbc, nb, g.rmax, &grid)) {
-                    // no grid for this batch (cutoff >= half the cell width, ...): all pairs, per property
-                    for (int pi : g.props) {
-                        PropState* p = e->props[pi].get();
-                        Selection* sa = e->sels[p->sel_a].get();
-                        Selection* sb = e->sels[p->sel_b].get();
-                        for (auto& su : subs) {
-                            uint64_t* dst = e->d_pass.p + (row++) * VMD_RDF_NUM_BINS;
-                            e->prof.begin("rdf_brute", e->stream);
-                            KRN_OK(vmd_hip_rdf_brute(e->stream, src.base + su.off * src.frame_stride, src.frame_stride, src.row_stride, src.d_boxes.p + 9 * su.off, pbc, (int)su.nb,
-                                                     sa->d_idx.p, (int)sa->idx.size(), sb->d_idx.p, (int)sb->idx.size(),
-                                                     g.rmin, g.rmax, VMD_RDF_NUM_BINS, dst));
-                            e->prof.end(e->stream);
-                            commits.push_back({acc_of(p, su), dst, 1});
-                        }
-                    }
-                    continue;
-                }
-                if (!e->d_partial.ensure(vmd_hip_rdf_partial_words())) return false;
-                if (two_streams && !e->d_partial2.ensure(vmd_hip_rdf_partial_words())) return false;
-                for (auto& ps : g.passes) {
-                    Selection* sa = e->sels[ps.sel_a].get();
-                    Selection* sb = e->sels[ps.sel_b].get();
-                    // passes with the same cutoff share the sorted copies; build_selection re-sorts when the grid differs
-                    if (forked) {     // the second stream still reads the sorted copies of the previous pass
-                        HIP_OK(hipEventRecord(e->pair_join, e->pair_stream));
-                        HIP_OK(hipStreamWaitEvent(e->stream, e->pair_join, 0));
-                        forked = false;
-                    }
-                    if (!build_selection(e, sa, src, d_gb, pbc, nb, grid)) return false;
-                    if (sb != sa && !build_selection(e, sb, src, d_gb, pbc, nb, grid)) return false;
-                    // the pair set is symmetric in (ref, target): put the denser selection in the lanes - 64 of its atoms span a
-                    // shorter stretch of the pencil, so the x window of every segment carries less padding
-                    if (sb->idx.size() > sa->idx.size()) std::swap(sa, sb);
-                    if (two_streams) {
-                        HIP_OK(hipEventRecord(e->pair_fork, e->stream));
-                        HIP_OK(hipStreamWaitEvent(e->pair_stream, e->pair_fork, 0));
-                        forked = true;
-                    }
-                    size_t si = 0;
-                    for (auto& su : subs) {
-                        uint64_t* dst = e->d_pass.p + (row++) * VMD_RDF_NUM_BINS;
-                        const bool second = two_streams && (si++ & 1);
-                        hipStream_t ks = second ? e->pair_stream : e->stream;
-                        if (!second) e->prof.begin("rdf_pencil", ks);
-                        KRN_OK(vmd_hip_rdf_pencil(ks, sa->sorted.p + su.off * 3 * (size_t)sa->nsel_pad, sa->cell_start.p + su.off * (size_t)(grid.ncell + 1), (int)sa->idx.size(), sa->nsel_pad,
-                                                  sb->sorted.p + su.off * 3 * (size_t)sb->nsel_pad, sb->cell_start.p + su.off * (size_t)(grid.ncell + 1), (int)sb->idx.size(), sb->nsel_pad,
-                                                  d_gb + 9 * su.off, (int)su.nb, grid, g.rmin, g.rmax, VMD_RDF_NUM_BINS,
-                                                  ps.same ? 1 : 0, g_opt.rdf_variant, pbc, second ? e->d_partial2.p : e->d_partial.p, dst, e->d_overflow.p));
-                        if (!second) e->prof.end(ks);
-                        if (e->spec.rdf_closed && ps.same && g.rmin <= 0.0f && 0.0f <= g.rmax) {
-                            // closed interval: d = 0 is a hit, but a same-set pass walks the half shell (j > i, every hit twice) and never
-                            // meets the pairs (i, i) - one per list entry and frame, all in the bin of d = 0 (SPEC S4 binning of 0)
-                            int bin0 = (int)(((0.0f - g.rmin) * (1.0f / (g.rmax - g.rmin))) * (float)VMD_RDF_NUM_BINS);
-                            bin0 = std::min(std::max(bin0, 0), VMD_RDF_NUM_BINS - 1);
-                            KRN_OK(vmd_hip_bump_u64(ks, dst + bin0, (uint64_t)su.nb * (uint64_t)sa->idx.size()));
-                        }
-                        for (auto& tg : ps.targets) commits.push_back({acc_of(e->props[tg.first].get(), su), dst, tg.second});
-                    }
-                }
-            }
-            if (forked) {
-                HIP_OK(hipEventRecord(e->pair_join, e->pair_stream));
-                HIP_OK(hipStreamWaitEvent(e->stream, e->pair_join, 0));
-            }
-            for (auto& c : commits) KRN_OK(vmd_hip_axpy_u64(e->stream, c.dst, c.src, VMD_RDF_NUM_BINS, c.mult, e->d_overflow.p));
-            HIP_OK(hipMemcpyAsync(e->h_overflow, e->d_overflow.p, sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
-            return true;
-        };
-        if (!e->rdf_groups.empty() && !launch_rdf()) return false;
+        e->h_overflow[c.slot] = 0;
+        if (!e->rdf_groups.empty() && !launch_rdf(c)) return false;
 
         for (auto& p : e->props) {
             const Property& d = p->prop;
             if (d.kind == PROP_RDF) {
                 // SPEC S4 normalisation, fp64 on the host (needs only the box)
-                for (auto& su : subs) {
+                for (auto& su : c.subs) {
                     double* bw = su.blk >= 0 ? &p->block_weights64[(size_t)su.blk * p->ncounts] : nullptr;
                     if (bw) std::fill(bw, bw + p->ncounts, 0.0);
                     for (size_t b = su.off; b < su.off + su.nb; ++b) {
-                        const float* L = &src.h_boxes[9 * b];
+                        const float* L = &c.src->h_boxes[9 * b];
                         double V;
-                        if ((pbc & VMD_UNITCELL_PBC_ALL) == VMD_UNITCELL_PBC_ALL) V = (double)L[0] * (double)L[1] * (double)L[2];   // also the triclinic volume
+                        if ((c.pbc & VMD_UNITCELL_PBC_ALL) == VMD_UNITCELL_PBC_ALL) V = (double)L[0] * (double)L[1] * (double)L[2];   // also the triclinic volume
                         else V = (4.0 / 3.0) * M_PI * (double)d.rmax * (double)d.rmax * (double)d.rmax;
                         const double rho = (double)d.a.size() * (double)d.b.size() / V;
                         const double w = ((double)d.rmax - (double)d.rmin) / (double)p->ncounts;
@@ -2373,36 +2493,53 @@ static bool process_range(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
                 }
                 p->dirty = true;
             } else if (d.kind == PROP_SDF) {
-                if (!p->d_R32.ensure(nb * d.K * 9) || !p->d_c32.ensure(nb * d.K * 3) || !p->d_group.ensure(nb * 4)) return false;
+                if (!p->d_R32.ensure(c.nb * d.K * 9) || !p->d_c32.ensure(c.nb * d.K * 3) || !p->d_group.ensure(c.nb * 4)) return false;
                 VMD_STAGE("batch: sdf align + scatter");
                 e->prof.begin("sdf_align", e->stream);
-                if (p->have_tree && !p->d_tree_pos.ensure(nb * d.K * d.m * 3)) return false;
-                KRN_OK(vmd_hip_sdf_align(e->stream, src.base, src.frame_stride, src.row_stride, src.d_boxes.p, pbc, (int)nb,
+                if (p->have_tree && !p->d_tree_pos.ensure(c.nb * d.K * d.m * 3)) return false;
+                KRN_OK(vmd_hip_sdf_align(e->stream, c.src->base, c.src->frame_stride, c.src->row_stride, c.src->d_boxes.p, c.pbc, (int)c.nb,
                                          p->d_structs.p, p->d_mass.p, (int)d.K, (int)d.m, p->d_ref_pose.p, p->d_R32.p, p->d_c32.p, nullptr, p->d_group.p,
                                          p->have_tree ? p->d_tree_order.p : nullptr, p->have_tree ? p->d_tree_parent.p : nullptr, p->have_tree ? p->d_tree_pos.p : nullptr));
                 e->prof.end(e->stream);
                 e->prof.begin("sdf_scatter", e->stream);
-                for (auto& su : subs)
-                    KRN_OK(vmd_hip_sdf_scatter(e->stream, src.base + su.off * src.frame_stride, src.frame_stride, src.row_stride, src.d_boxes.p + 9 * su.off, pbc, (int)su.nb,
+                for (auto& su : c.subs)
+                    KRN_OK(vmd_hip_sdf_scatter(e->stream, c.src->base + su.off * c.src->frame_stride, c.src->frame_stride, c.src->row_stride, c.src->d_boxes.p + 9 * su.off, c.pbc, (int)su.nb,
                                                p->d_structs.p, (int)d.K, (int)d.m, p->d_R32.p + su.off * d.K * 9, p->d_c32.p + su.off * d.K * 3, p->d_tgt.p,
                                                (p->have_owner && !e->spec.sdf_include_self) ? p->d_owner.p : nullptr, (int)d.b.size(),
                                                d.rmax, VMD_VOLUME_DIM, acc_of(p.get(), su), p->d_group.p + 4 * su.off,
-                                               (p->have_tag && p->tag_len == src.row_stride && !e->spec.sdf_include_self) ? p->d_tag.p : nullptr,
+                                               (p->have_tag && p->tag_len == c.src->row_stride && !e->spec.sdf_include_self) ? p->d_tag.p : nullptr,
                                                p->tgt_first, p->tgt_stride, (p->unowned || e->spec.sdf_include_self) ? 1 : 0));
                 e->prof.end(e->stream);
                 p->dirty = true;
             } else {
-                if (!p->d_out.ensure(nb * p->dim1)) return false;
+                if (!p->d_out.ensure(c.nb * p->dim1)) return false;
                 e->prof.begin("distance", e->stream);
-                KRN_OK(vmd_hip_distance(e->stream, src.base, src.frame_stride, src.row_stride, src.d_boxes.p, pbc, (int)nb, d.dist_kind,
+                KRN_OK(vmd_hip_distance(e->stream, c.src->base, c.src->frame_stride, c.src->row_stride, c.src->d_boxes.p, c.pbc, (int)c.nb, d.dist_kind,
                                         (int)p->dist_P, (int)p->dist_per, p->d_a.p, p->d_ma.p, p->d_aoff.p, p->d_b.p, p->d_mb.p, p->d_boff.p,
                                         p->d_out.p));
                 e->prof.end(e->stream);
-                HIP_OK(hipMemcpyAsync(e->h_temporal.data() + toff, p->d_out.p, nb * p->dim1 * sizeof(float), hipMemcpyDeviceToHost, e->stream));
-                toff += nb * p->dim1;
+                HIP_OK(hipMemcpyAsync(e->h_temporal_slot[c.slot].data() + toff, p->d_out.p, c.nb * p->dim1 * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+                toff += c.nb * p->dim1;
                 p->dirty = true;
             }
         }
+        if (defer) {
+            // what the host will want from this batch once a later one is queued behind it: the RDF counts as they stand behind its
+            // commits (the weights as they stand now), and an event to wait on
+            size_t soff = (size_t)c.slot * rdf_counts;
+            for (auto& p : e->props) {
+                if (p->prop.kind != PROP_RDF) continue;
+                HIP_OK(hipMemcpyAsync(e->h_snap + soff, p->d_counts.p, p->ncounts * sizeof(uint64_t), hipMemcpyDeviceToHost, e->stream));
+                memcpy(e->w_snap.data() + soff, p->weights64.data(), p->ncounts * sizeof(double));
+                soff += p->ncounts;
+            }
+            c.snapshot = true;
+            HIP_OK(hipEventRecord(e->batch_done[c.slot], e->stream));
+        }
+        c.active = true;
+        // deferred: the batch in front of this one is completed now that the device has this one to go on with (its stage is free
+        // for the staging below only then)
+        if (defer && !complete_batch(prev, &c)) return false;
         VMD_STAGE("batch: staging the next batch (fetch_stage)");
         // the kernels of this batch are queued: load the next batch on the host while they run
         if (bi + 1 < batches.size() && !e->interrupt) {
@@ -2415,44 +2552,13 @@ static bool process_range(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
             if (raw_ring && bi + raw_ahead < batches.size() &&
                 raw_upload(e, *slot_of(bi + raw_ahead), traj, num_atoms, batches[bi + raw_ahead].f0, batches[bi + raw_ahead].nb) < 0) return false;
         }
-        VMD_STAGE("batch: hipStreamSynchronize");
-        { HostTimer host_timer("host_sync_wait"); HIP_OK(hipStreamSynchronize(e->stream)); }
-        VMD_STAGE("batch: host bookkeeping");
-        // a bucket of the two-level cell build was too small: nothing reached the histograms (every consumer saw the flag).
-        // Re-measure the selections that used buckets with more head room and evaluate the RDF part of this batch again.
-        for (int attempt = 0; *e->h_overflow != 0; ++attempt) {
-            if (attempt >= 4) return vmd_fail("cell build: pencil buckets keep overflowing");
-            for (auto& sl : e->sels) {
-                sl->built = false;
-                if (!sl->used_pencil) continue;
-                sl->pen_off.clear();
-                sl->caps_cache.clear();
-                sl->cap_margin *= 1.6f;
-                sl->overflows += 1;
-            }
-            *e->h_overflow = 0;
-            HIP_OK(hipMemsetAsync(e->d_overflow.p, 0, sizeof(uint32_t), e->stream));
-            if (!launch_rdf()) return false;
-            HIP_OK(hipStreamSynchronize(e->stream));
-        }
-        if (bt.blk >= 0)
-            for (auto& su : subs)
-                for (auto& p : e->props) if (p->ncounts) KRN_OK(vmd_hip_add_u64(e->stream, p->d_counts.p, acc_of(p.get(), su), p->ncounts));
-        e->prof.resolve();
-        if (g_prof_on) { std::lock_guard<std::mutex> l(g_prof_mtx); g_prof["batches"].launches += 1; }
-        toff = 0;
-        for (auto& p : e->props) {
-            if (p->prop.kind != PROP_DIST) continue;
-            memcpy(&p->values[f0 * p->dim1], e->h_temporal.data() + toff, nb * p->dim1 * sizeof(float));
-            toff += nb * p->dim1;
-        }
-        for (size_t b = 0; b < nb; ++b) e->frame_mask[f0 + b] = 1;
-        e->frames_done += nb;
-        e->frames_computed += nb;
-        if (bt.blk >= 0) for (auto& su : subs) e->block_ready[su.blk] = 1;
-        // cheap views are refreshed every batch so a polling GUI sees progress (src/main.cpp:1508-1524)
-        for (auto& p : e->props) if (p->prop.kind == PROP_RDF) { if (!refresh_distribution(e, p.get())) return false; }
+        if (!defer && !complete_batch(c, nullptr)) return false;
     }
+    // whatever is still in flight (deferred: the last batch queued; after an interrupt: the one before the break)
+    { BatchCtx& a = ctx[0].active && ctx[1].active ? (ctx[0].f0 < ctx[1].f0 ? ctx[0] : ctx[1]) : ctx[0];
+      BatchCtx& b = &a == &ctx[0] ? ctx[1] : ctx[0];
+      if (!complete_batch(a, b.active ? &b : nullptr)) return false;
+      if (!complete_batch(b, nullptr)) return false; }
     for (auto& p : e->props) {
         if (!p->dirty) continue;
         if (p->prop.kind == PROP_SDF) { if (!refresh_volume(e, p.get())) return false; }
