@@ -76,6 +76,9 @@ def scenario(seed, scale=1):
         opts["cells_rec3"] = 0                      # 16-byte bucket records (no draw from rng: the scenarios stay what they were)
     if seed % 7 == 0:
         opts["cells_bin_lds"] = 0                   # level 1 of the cell build without the block-local sort
+    if seed % 4 == 1:
+        opts["defer_sync"] = 1                      # the next batch queued before the host waits for the current one (several batches
+        opts.setdefault("batch_frames", 2)          # needed; no draw from rng)
     return coords, box, flags, props, opts, kind
 
 
@@ -160,6 +163,11 @@ def sdf_scenario(seed):
         opts["batch_frames"] = 1
     if seed % 3 == 0:
         opts["sdf_wave"] = 1                        # per-wave compaction (no draw from rng: the scenarios stay what they were)
+    if seed % 5 == 2:
+        opts["sdf_wave"] = 2                        # the persistent streaming scatter kernel
+    if seed % 4 == 3:
+        opts["defer_sync"] = 1
+        opts.setdefault("batch_frames", 2)
     dist = []
     for i, kd in enumerate((L.DIST_COM, L.DIST_MIN, L.DIST_MAX, L.DIST_PAIR)):
         a = rng.choice(n, int(rng.integers(1, 9)), replace=False).astype(np.int32)
