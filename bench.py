@@ -266,6 +266,17 @@ def run_workload(name, args, ctx, steps, warmup, frames=None, with_cpu=False, op
         {"dcd": V.write_dcd, "xtc": V.write_xtc, "trr": V.write_trr}[ext](path, host, cell)
         host.close()
         traj = V.DcdTrajectory(path) if args.traj == "dcd" else V.XdrTrajectory(path)
+        if args.traj == "xtc" and args.ck_sidecar:
+            # decoder checkpoints of an earlier process (vmd_ckcache_load): the first pass of THIS one decodes in sections.  The
+            # bench writes the sidecar once (a throw-away pass over the file), drops the trajectory object and opens the file again.
+            ckp = path + ".vmdck"
+            ev0 = V.ScriptEval(F, script.compile_script(w["script"], topo)[0])
+            assert ev0.frame_range(V.MolSystem(w["atoms"], mass=topo.mass, unitcell=cell), traj, beg, end)
+            traj.save_checkpoints(ckp)
+            ev0.close(); traj.close()
+            traj = V.XdrTrajectory(path)
+            sidecar_frames = traj.load_checkpoints(ckp, torch.cuda.current_device())
+            w["desc"] += f", decoder checkpoints of {sidecar_frames} frames loaded from a sidecar file ({os.path.getsize(ckp) / F:.0f} bytes per frame)"
         if args.traj == "xtc-resident":          # the file is read and uploaded ONCE, still compressed; every step decodes from HBM
             t1 = time.perf_counter()
             traj = V.CompressedDeviceTrajectory(traj)
@@ -458,6 +469,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short c2 / c4 / c5 runs of the default N = 1 line")
     ap.add_argument("--opt", action="append", default=[], help="library tuning knob key=value (vmd_set_option)")
+    ap.add_argument("--ck-sidecar", action="store_true", help="--traj xtc: the decoder checkpoints come from a sidecar file written by an earlier pass (vmd_ckcache_save / _load); 'first_pass' is then a first pass WITH checkpoints")
     ap.add_argument("--rigid-water", action="store_true", help="file trajectories: give the waters their real geometry before writing the file")
     ap.add_argument("--tilt", default=None, help="xy,xz,yz in Angstrom: evaluate in a sheared (triclinic) cell of the same volume")
     ap.add_argument("--traj", default="device", choices=["device", "pinned", "dcd", "xtc", "trr", "xtc-resident"],

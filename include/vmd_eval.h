@@ -410,6 +410,17 @@ size_t vmd_eval_frames_device_decoded(const vmd_script_eval_t* eval);
 size_t vmd_eval_frames_section_decoded(const vmd_script_eval_t* eval);
 /* ... and how many of them reached the device by DMA straight from the mapped file (raw_mapped_view), no host copy */
 size_t vmd_eval_frames_mapped(const vmd_script_eval_t* eval);
+/* Decoder checkpoints across processes.  The first device decode of a compressed (XTC) frame has to walk its bit stream from the
+ * first bit and leaves the decoder state at up to 64 places of the frame; every later decode enters there (sections, no walk).  The
+ * table lives with the trajectory for the process's lifetime; these two calls carry it over to the next one, the way mdlib keeps a
+ * frame-offset cache file next to a trajectory (ref: ext/mdlib's xtc / trr loaders behind src/loader.cpp:147-150 write `.cache` files).
+ * save: writes the table of `traj` (1 KB per frame) to `path` - false when nothing of the trajectory has been device-decoded yet.
+ * load: installs a table for `traj` on `device`; returns the number of frames it covers, 0 when the file describes another
+ * trajectory (frame or atom count), -1 on error.  A loaded table is a hint, never trusted: a frame uses its checkpoints only while
+ * the signature of its bytes matches the stored one, and a section whose end state disagrees with the next checkpoint is rejected:
+ * that batch is decoded by the host reader and its frames walk from bit 0 again the next time. */
+bool   vmd_ckcache_save(const vmd_trajectory_i* traj, const char* path);
+long   vmd_ckcache_load(const vmd_trajectory_i* traj, const char* path, int device);
 
 /* ---- device-resident trajectories (pre-staged in HBM) ---------------------------------- */
 typedef struct vmd_devtraj_t vmd_devtraj_t;

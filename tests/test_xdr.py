@@ -259,6 +259,96 @@ def test_xtc_trajectory_through_the_evaluator_on_emulator(tmp_path, emu_lib, ora
     assert res[0].sum() > 0
 
 
+def _checkpoint_sidecar_case(tmp_path, lib, oracle, n_water=1200, box=36.0, F=10):
+    """vmd_ckcache_save / vmd_ckcache_load: the decoder checkpoints a first pass leaves survive the process (here: the trajectory
+    object) in a sidecar file.  A trajectory opened later decodes in sections right away; a table that belongs to other bytes
+    (signature) costs a first pass and nothing else; a table that lies about the streams it claims (signatures intact,
+    checkpoints damaged) is rejected by the sectioned decode, the batch falls back to the host reader, the frames walk again."""
+    import cases
+    coords = cases.water_box(oracle, 37, n_water, box, F)
+    cell = V.make_unitcell(box)
+    p, p2 = tmp_path / "a.xtc", tmp_path / "b.xtc"
+    V.write_xtc(p, coords, cell, lib=lib)
+    V.write_xtc(p2, coords + np.float32(0.5), cell, lib=lib)                  # same frame and atom count, other bytes
+    o = cases.oxygen(n_water)
+    ir = V.ScriptIR(lib); ir.add_rdf("g", o, o, 9.0)
+    sysm = V.MolSystem(n_water, unitcell=cell)
+    old = (lib.vmd_set_option(b"xtc_device_decode", 3), lib.vmd_set_option(b"batch_frames", 4))
+    try:
+        a = V.XdrTrajectory(p, lib=lib)
+        with pytest.raises(V.VmdError):
+            a.save_checkpoints(tmp_path / "none.ck")                            # nothing decoded yet
+        ev = V.ScriptEval(F, ir)
+        assert ev.frame_range(sysm, a, 0, F) and ev.frames_device_decoded() == F and ev.frames_section_decoded() == 0
+        want = ev.property_data("g").counts.copy()
+        assert want.sum() > 0
+        ck = tmp_path / "a.xtc.vmdck"
+        a.save_checkpoints(ck)
+        assert 0 < ck.stat().st_size < 2 * (F * 64 * 16 + F * 13 + 64)
+        a.close()
+        # a later "session": a new trajectory object of the same file
+        b = V.XdrTrajectory(p, lib=lib)
+        assert b.load_checkpoints(ck) == F
+        ev = V.ScriptEval(F, ir)
+        assert ev.frame_range(sysm, b, 0, F) and ev.frames_device_decoded() == F and ev.frames_section_decoded() == F
+        np.testing.assert_array_equal(ev.property_data("g").counts, want)
+        # the table of another file: every signature differs -> an ordinary first pass, then sections from ITS OWN checkpoints
+        c = V.XdrTrajectory(p2, lib=lib)
+        assert c.load_checkpoints(ck) == F
+        ev = V.ScriptEval(F, ir)
+        assert ev.frame_range(sysm, c, 0, F) and ev.frames_device_decoded() == F and ev.frames_section_decoded() == 0
+        want2 = ev.property_data("g").counts.copy()
+        ev = V.ScriptEval(F, ir)
+        assert ev.frame_range(sysm, c, 0, F) and ev.frames_section_decoded() == F
+        np.testing.assert_array_equal(ev.property_data("g").counts, want2)
+        # a damaged table behind intact signatures: rejected, host fallback for those batches, right answer; the next pass walks again
+        blob = bytearray(ck.read_bytes())
+        hdr = 8 + 4 + 4 + 8 + 8
+        ck_off = hdr + F + 8 * F + 4 * F
+        for f in range(F):
+            for k in range(1, 3):                                             # checkpoints 1 and 2 of every frame: bit position + 1000
+                off = ck_off + (f * 64 + k) * 16
+                pos = int.from_bytes(blob[off:off + 4], "little")
+                blob[off:off + 4] = ((pos + 1000) & 0xffffffff).to_bytes(4, "little")
+        bad = tmp_path / "bad.vmdck"
+        bad.write_bytes(bytes(blob))
+        d = V.XdrTrajectory(p, lib=lib)
+        assert d.load_checkpoints(bad) == F
+        ev = V.ScriptEval(F, ir)
+        assert ev.frame_range(sysm, d, 0, F)
+        np.testing.assert_array_equal(ev.property_data("g").counts, want)
+        assert ev.frames_section_decoded() < F                                 # frames with a single section have no second checkpoint to trip over
+        ev = V.ScriptEval(F, ir)
+        assert ev.frame_range(sysm, d, 0, F)
+        np.testing.assert_array_equal(ev.property_data("g").counts, want)
+        ev = V.ScriptEval(F, ir)
+        assert ev.frame_range(sysm, d, 0, F) and ev.frames_section_decoded() == F   # ... and by now every frame has good ones again
+        np.testing.assert_array_equal(ev.property_data("g").counts, want)
+        # not this trajectory / not a checkpoint file
+        small = tmp_path / "s.xtc"
+        V.write_xtc(small, coords[:, :, :300], cell, lib=lib)
+        assert V.XdrTrajectory(small, lib=lib).load_checkpoints(ck) == 0
+        with pytest.raises(V.VmdError):
+            d.load_checkpoints(p)
+        with pytest.raises(V.VmdError):
+            d.load_checkpoints(tmp_path / "missing.vmdck")
+        trunc = tmp_path / "t.vmdck"
+        trunc.write_bytes(ck.read_bytes()[:200])
+        with pytest.raises(V.VmdError):
+            d.load_checkpoints(trunc)
+    finally:
+        lib.vmd_set_option(b"xtc_device_decode", old[0]); lib.vmd_set_option(b"batch_frames", old[1])
+
+
+def test_decoder_checkpoints_survive_in_a_sidecar_file(tmp_path, emu_lib, oracle):
+    _checkpoint_sidecar_case(tmp_path, emu_lib, oracle)
+
+
+@pytest.mark.gpu
+def test_decoder_checkpoints_survive_in_a_sidecar_file_on_the_gpu(tmp_path, gpu_lib, oracle):
+    _checkpoint_sidecar_case(tmp_path, gpu_lib, oracle, n_water=9000, box=66.0, F=12)
+
+
 def _device_decode(lib, blob, natoms, chunk=0, gpu=False):
     """Run vmd_hip_xtc_decode (emulator build: "device" memory is host memory) on every frame of an XTC byte string."""
     import ctypes as C

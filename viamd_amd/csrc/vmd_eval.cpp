@@ -597,6 +597,90 @@ extern "C" void vmd_ckcache_drop(const void* inst) {
     std::lock_guard<std::mutex> l(g_ck_mtx);
     g_ck_store.erase(inst);
 }
+
+// ---- checkpoint sidecar.  A first pass over an XTC file walks every bit stream from its first bit (29k c2 frames/s against 84k once
+// the decoder checkpoints exist) - and the checkpoints die with the process.  mdlib keeps a frame-offset cache file next to a
+// trajectory for the same reason; this is the same idea for the decoder state: 1 KB per frame (64 checkpoints of 16 bytes).  A loaded
+// table is only ever a hint: a frame's checkpoints are used while the frame's signature (stream length, decoder parameters, first
+// and last bytes) is the one stored with them, and the sectioned decode verifies every section's end state against the next
+// checkpoint - a sidecar of another file, or a damaged one, costs a first pass, never a wrong coordinate.
+// Group records are not stored (2 bytes per group: 13 - 40 % of the XTC file itself); a trajectory whose checkpoints came from a
+// sidecar decodes in sections from them (r03t2: 80.7k against 82.3k frames/s with records).
+struct CkFileHeader { char magic[8]; uint32_t version, ck_max; uint64_t frames, atoms; };
+static const char kCkMagic[8] = {'V', 'M', 'D', 'X', 'T', 'C', 'C', 'K'};
+
+extern "C" bool vmd_ckcache_save(const vmd_trajectory_i* traj, const char* path) {
+    g_last_error.clear();
+    if (!traj || !path) return vmd_fail("vmd_ckcache_save: NULL argument");
+    std::shared_ptr<CkCache> c;
+    { std::lock_guard<std::mutex> l(g_ck_mtx);
+      auto it = g_ck_store.find(traj->inst);
+      if (it != g_ck_store.end()) c = it->second; }
+    if (!c || c->frames == 0) return vmd_fail("vmd_ckcache_save: no decoder checkpoints exist for this trajectory (nothing of it was decoded on the device yet)");
+    int prev = 0;
+    HIP_OK(hipGetDevice(&prev));
+    HIP_OK(hipSetDevice(c->device));
+    HIP_OK(hipDeviceSynchronize());                       // the tables are written by decode kernels on the evals' streams
+    std::vector<uint32_t> nck(c->frames);
+    std::vector<vmd_xtc_ck_t> ck(c->frames * VMD_XTC_CK_MAX);
+    const bool copied = hipMemcpy(nck.data(), c->nck.p, nck.size() * sizeof(uint32_t), hipMemcpyDeviceToHost) == hipSuccess &&
+                        hipMemcpy(ck.data(), c->ck.p, ck.size() * sizeof(vmd_xtc_ck_t), hipMemcpyDeviceToHost) == hipSuccess;
+    (void)hipSetDevice(prev);
+    if (!copied) return vmd_fail("vmd_ckcache_save: reading the checkpoint tables back failed");
+    CkFileHeader h;
+    memcpy(h.magic, kCkMagic, 8);
+    h.version = 1; h.ck_max = VMD_XTC_CK_MAX; h.frames = c->frames; h.atoms = c->atoms;
+    const std::string tmp = std::string(path) + ".tmp";
+    FILE* f = fopen(tmp.c_str(), "wb");
+    if (!f) return vmd_fail("vmd_ckcache_save: cannot create %s", tmp.c_str());
+    bool ok = fwrite(&h, sizeof(h), 1, f) == 1 && fwrite(c->have.data(), 1, c->frames, f) == c->frames &&
+              fwrite(c->sig.data(), sizeof(uint64_t), c->frames, f) == c->frames && fwrite(nck.data(), sizeof(uint32_t), nck.size(), f) == nck.size() &&
+              fwrite(ck.data(), sizeof(vmd_xtc_ck_t), ck.size(), f) == ck.size();
+    ok = (fclose(f) == 0) && ok;
+    if (!ok || rename(tmp.c_str(), path) != 0) { remove(tmp.c_str()); return vmd_fail("vmd_ckcache_save: writing %s failed", path); }
+    return true;
+}
+
+// -> number of frames whose checkpoints were installed (0: the file does not describe this trajectory), -1 on error
+extern "C" long vmd_ckcache_load(const vmd_trajectory_i* traj, const char* path, int device) {
+    g_last_error.clear();
+    if (!traj || !path) { vmd_fail("vmd_ckcache_load: NULL argument"); return -1; }
+    FILE* f = fopen(path, "rb");
+    if (!f) { vmd_fail("vmd_ckcache_load: cannot open %s", path); return -1; }
+    CkFileHeader h;
+    const size_t frames = traj->num_frames(traj->inst), atoms = traj->num_atoms(traj->inst);
+    if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, kCkMagic, 8) != 0 || h.version != 1) { fclose(f); vmd_fail("vmd_ckcache_load: %s is not a checkpoint file", path); return -1; }
+    if (h.ck_max != VMD_XTC_CK_MAX || h.frames != frames || h.atoms != atoms || frames == 0) { fclose(f); return 0; }
+    std::vector<uint8_t> have(frames);
+    std::vector<uint64_t> sig(frames);
+    std::vector<uint32_t> nck(frames);
+    std::vector<vmd_xtc_ck_t> ck(frames * VMD_XTC_CK_MAX);
+    const bool ok = fread(have.data(), 1, frames, f) == frames && fread(sig.data(), sizeof(uint64_t), frames, f) == frames &&
+                    fread(nck.data(), sizeof(uint32_t), frames, f) == frames && fread(ck.data(), sizeof(vmd_xtc_ck_t), ck.size(), f) == ck.size();
+    fclose(f);
+    if (!ok) { vmd_fail("vmd_ckcache_load: %s is truncated", path); return -1; }
+    long n = 0;
+    for (size_t i = 0; i < frames; ++i) {
+        if (have[i] && (nck[i] < 1 || nck[i] > VMD_XTC_CK_MAX)) have[i] = 0;       // nothing the kernels would accept anyway
+        n += have[i] ? 1 : 0;
+    }
+    int prev = 0;
+    if (hipGetDevice(&prev) != hipSuccess || hipSetDevice(device) != hipSuccess) { vmd_fail("vmd_ckcache_load: no such device"); return -1; }
+    std::shared_ptr<CkCache> c = ckcache_for(traj->inst, frames, atoms, device);
+    bool up = c != nullptr;
+    if (up) {
+        (void)hipDeviceSynchronize();                     // an eval may be decoding this trajectory from the tables being replaced
+        up = hipMemcpy(c->nck.p, nck.data(), nck.size() * sizeof(uint32_t), hipMemcpyHostToDevice) == hipSuccess &&
+             hipMemcpy(c->ck.p, ck.data(), ck.size() * sizeof(vmd_xtc_ck_t), hipMemcpyHostToDevice) == hipSuccess;
+    }
+    (void)hipSetDevice(prev);
+    if (!up) { vmd_fail("vmd_ckcache_load: uploading the checkpoint tables failed"); return -1; }
+    std::lock_guard<std::mutex> l(g_ck_mtx);
+    std::copy(have.begin(), have.end(), c->have.begin());        // in place: stages of a running eval point into these vectors
+    std::copy(sig.begin(), sig.end(), c->sig.begin());
+    c->rec_failed = true;                                  // no records came with them: sections from the checkpoints
+    return n;
+}
 // Mapped trajectory files (vmd_trajectory_i::raw_mapped_view), pinned for the copy engine in windows of 1 GiB on first use
 // (hipHostRegister on the mapping: 5 ms per 512 MB once, then DMA at the rate of hipHostMalloc memory - profiles/r03c_hostio.txt).
 // Process-wide, keyed by the mapping's base; the reader that owns the mapping calls vmd_mapreg_drop before it unmaps.  A window
@@ -707,6 +791,7 @@ struct vmd_script_eval_t {
         bool sectioned = false;                  // that decode ran from checkpoints (sections), not from bit 0
         bool* rec_failed = nullptr;              // that decode placed its groups from records: where to note that they were rejected
         uint8_t* ck_mark = nullptr;              // that decode also writes the frames' checkpoints: mark them valid (ck_mark[0 .. nb)) when it succeeded
+        uint8_t* ck_clear = nullptr;             // that decode entered the frames at their checkpoints: forget them (ck_clear[0 .. nb)) when it was rejected
         DevBuf<float> d_boxes;
         std::vector<float> h_boxes;              // [nb][6]: L, 1/L
         std::vector<vmd_unitcell_t> cells;
@@ -1435,6 +1520,7 @@ static int launch_raw_decode(vmd_script_eval_t* e, Stage& st, const unsigned cha
                              uint8_t* ck_have = nullptr, uint16_t* rec = nullptr, uint32_t* nrec = nullptr, size_t rec_stride = 0,
                              bool* rec_failed = nullptr) {
     st.ck_mark = nullptr;
+    st.ck_clear = nullptr;
     st.rec_failed = nullptr;
     st.sectioned = false;
     if (nb > st.h_raw_status_cap) {
@@ -1466,6 +1552,7 @@ static int launch_raw_decode(vmd_script_eval_t* e, Stage& st, const unsigned cha
         } else
         rc = vmd_hip_xtc_decode_wave_ck(stream, d_raw, d_info, (int)nb, (int)num_atoms, st.d.p, 3 * npad, npad, st.d_raw_status.p, all ? 1 : 0, ck, nck);
         if (!all) st.ck_mark = ck_have;
+        else st.ck_clear = ck_have;
         st.sectioned = all;
     } else {
         rc = vmd_hip_xtc_decode_wave(stream, d_raw, d_info, (int)nb, (int)num_atoms, st.d.p, 3 * npad, npad, st.d_raw_status.p);
@@ -1812,12 +1899,17 @@ static bool settle_stage(vmd_script_eval_t* e, Stage& st, vmd_trajectory_i* traj
     if (good) {
         if (st.ck_mark) for (size_t b = 0; b < st.nb; ++b) st.ck_mark[b] = 1;
         st.ck_mark = nullptr;
+        st.ck_clear = nullptr;
         st.rec_failed = nullptr;
         e->frames_device_decoded += st.nb;
         if (st.sectioned) e->frames_section_decoded += st.nb;
         return true;
     }
     st.ck_mark = nullptr;
+    // checkpoints that did not describe these streams (a sidecar table that passed the signature test and still lies): the frames
+    // walk from bit 0 again next time
+    if (st.ck_clear) for (size_t b = 0; b < st.nb; ++b) st.ck_clear[b] = 0;
+    st.ck_clear = nullptr;
     if (st.rec_failed) *st.rec_failed = true;          // the records did not describe these streams: never again for this trajectory
     st.rec_failed = nullptr;
     return fetch_stage(e, st, traj, nullptr, num_atoms, st.f0, st.nb, true);

@@ -51,6 +51,18 @@ class XdrTrajectory:
             raise VmdError(self.lib.last_error())
         return (out, hdr.unitcell, hdr) if with_header else (out, hdr.unitcell)
 
+    def save_checkpoints(self, path):
+        """Write the decoder checkpoints the device decodes of this trajectory have left so far (vmd_ckcache_save)."""
+        if not self.lib.vmd_ckcache_save(self._iface, str(path).encode()):
+            raise VmdError(self.lib.last_error())
+
+    def load_checkpoints(self, path, device=0):
+        """Install decoder checkpoints written by an earlier process (vmd_ckcache_load) -> frames covered (0: not this trajectory)."""
+        n = int(self.lib.vmd_ckcache_load(self._iface, str(path).encode(), int(device)))
+        if n < 0:
+            raise VmdError(self.lib.last_error())
+        return n
+
     def close(self):
         if self.h:
             self.lib.vmd_xdrtraj_close(self.h)
