@@ -517,6 +517,10 @@ void        vmd_log_register(vmd_log_fn fn, void* user);
 const char* vmd_version(void);
 /* tuning knobs (kernel variant, frames per batch); returns previous value, -1 for unknown key */
 int         vmd_set_option(const char* key, int value);
+/* Evals are created and freed per script edit (src/main.cpp:960-972): the device blocks, pinned blocks, streams and events one gives up
+ * are kept in a process-wide cache for the next (vmd_set_option("pool_mb", MB): bound on the cached device bytes, 0 = no cache).
+ * vmd_pool_trim returns everything cached to the runtime (before another library needs the device memory, before exit). */
+void        vmd_pool_trim(void);
 /* wall-clock ms of kernel `which` accumulated by hipEvents since the last reset (bench instrumentation) */
 void        vmd_profile_reset(void);
 double      vmd_profile_ms(const char* which, uint64_t* launches);

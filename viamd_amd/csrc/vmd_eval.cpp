@@ -21,6 +21,7 @@
 #include <memory>
 #include <mutex>
 #include <thread>
+#include <unordered_map>
 #include <string>
 #include <vector>
 
@@ -86,6 +87,7 @@ struct Options {
                                              // frame (k_xtc_decode), 2 = index pass + one thread per chunk (k_xtc_index / k_xtc_chunks),
                                              // 3 = one wave per frame (k_xtc_wave)
     std::atomic<int> xtc_chunk{256};         // atoms per chunk of variant 2
+    std::atomic<int> pool_mb{16384};         // process-wide cache of device blocks freed by evals (MB; pinned host blocks: a quarter of it); 0 = off
     std::atomic<int> defer_sync{0};          // the next batch is queued before the host waits for the current one (evals without block partials); measured r03ad: no gain (the per-batch host gap is ~0.06 ms; the next decode then lands on the cell build), off
     std::atomic<int> block_superbatch{1};    // filtered evaluation: consecutive frame blocks share ONE batch (one cell build, one synchronisation; a pair launch per block)
     std::atomic<int> block_two_streams{1};   // ... and the blocks' pair launches alternate between two streams, so that the tail of one runs under the head of the next
@@ -149,6 +151,7 @@ extern "C" int vmd_set_option(const char* key, int value) {
     else if (!strcmp(key, "xtc_ramp")) o = &g_opt.xtc_ramp;
     else if (!strcmp(key, "block_superbatch")) o = &g_opt.block_superbatch;
     else if (!strcmp(key, "defer_sync")) o = &g_opt.defer_sync;
+    else if (!strcmp(key, "pool_mb")) { const int old = g_opt.pool_mb.exchange(value < 0 ? 0 : value); vmd_pool_trim(); return old; }
     else if (!strcmp(key, "block_two_streams")) o = &g_opt.block_two_streams;
     else if (!strcmp(key, "xtc_decode_ahead")) o = &g_opt.xtc_decode_ahead;
     else if (!strcmp(key, "xtc_map_limit_mb")) o = &g_opt.xtc_map_limit_mb;
@@ -229,13 +232,137 @@ struct HostTimer {
     }
 };
 
+// ------------------------------------------------------------------------------------------------ resource cache
+// VIAMD creates a fresh md_script_eval_t for every script edit and frees the old one (src/main.cpp:966-972, 960).  An eval owns ~60
+// device buffers, a dozen pinned blocks, nine streams and twenty events; created and destroyed through the runtime that is
+// 1.5 - 3 ms + 3.5 - 6 ms per life cycle (+ 0.7 ms of first-touch allocations inside the first frame_range) against 2.6 ms for
+// the whole 10 000-frame SDF evaluation and 8.2 ms for the 100k-atom RDF (profiles/r03ai).  Blocks, streams and events an eval
+// gives up are therefore kept, process-wide and per device, and handed to the next eval.
+//   * a block is only reused for a request of (nearly) its size: at most 25 % + 1 MB of slack;
+//   * a device block that may still be in use by queued work is given back behind a device synchronisation - what hipFree did
+//     implicitly; vmd_eval_free synchronises the eval's streams once and releases everything inside a PoolIdle scope instead;
+//   * option pool_mb bounds the cached device bytes (pinned: a quarter of it); beyond it, and with pool_mb = 0, blocks go back to
+//     the runtime.  An allocation the runtime refuses is retried once after the cache has been emptied.
+struct ResourcePool {
+    std::mutex mtx;
+    std::multimap<size_t, void*> blocks[65];                       // [device 0..63, 64 = pinned host]: bytes -> free block
+    std::unordered_map<void*, std::pair<size_t, int>> owner;      // every block that came through the pool: bytes, kind
+    size_t pooled[2] = {0, 0};                                     // cached bytes: device, pinned
+    std::vector<hipStream_t> streams[64][2];                       // [device][0 = default priority, 1 = highest]
+    std::vector<hipEvent_t> events[64][2];                         // [device][0 = with timing, 1 = hipEventDisableTiming]
+};
+static ResourcePool& pool() { static ResourcePool* p = new ResourcePool(); return *p; }      // never destroyed: the HIP runtime may be gone first
+static thread_local int t_pool_idle = 0;
+struct PoolIdle { PoolIdle() { ++t_pool_idle; } ~PoolIdle() { --t_pool_idle; } };
+static const int kPinned = 64;
+static int pool_device() { int d = 0; if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) { (void)hipGetLastError(); d = 0; } return d; }
+static hipError_t pool_raw_alloc(int kind, void** p, size_t bytes) {
+    return kind == kPinned ? hipHostMalloc(p, bytes, hipHostMallocDefault) : hipMalloc(p, bytes);
+}
+static void pool_raw_free(int kind, void* p) { if (kind == kPinned) (void)hipHostFree(p); else (void)hipFree(p); }
+extern "C" void vmd_pool_trim(void) {
+    ResourcePool& P = pool();
+    std::vector<std::pair<int, void*>> victims;
+    { std::lock_guard<std::mutex> l(P.mtx);
+      for (int k = 0; k <= kPinned; ++k) { for (auto& b : P.blocks[k]) { victims.push_back({k, b.second}); P.owner.erase(b.second); } P.blocks[k].clear(); }
+      P.pooled[0] = P.pooled[1] = 0; }
+    if (victims.empty()) return;
+    int prev = pool_device();
+    for (auto& v : victims) { if (v.first != kPinned) (void)hipSetDevice(v.first); pool_raw_free(v.first, v.second); }
+    (void)hipSetDevice(prev);
+}
+// kind: kPinned, or -1 = the current device
+static hipError_t pool_take(int kind, void** out, size_t bytes) {
+    if (kind < 0) kind = pool_device();
+    bytes = std::max<size_t>((bytes + 255) & ~(size_t)255, 256);
+    ResourcePool& P = pool();
+    if (g_opt.pool_mb.load() > 0) {
+        std::lock_guard<std::mutex> l(P.mtx);
+        auto it = P.blocks[kind].lower_bound(bytes);
+        if (it != P.blocks[kind].end() && it->first <= bytes + bytes / 4 + ((size_t)1 << 20)) {
+            *out = it->second;
+            P.pooled[kind == kPinned] -= it->first;
+            P.blocks[kind].erase(it);
+            return hipSuccess;
+        }
+    }
+    hipError_t e = pool_raw_alloc(kind, out, bytes);
+    if (e != hipSuccess) { (void)hipGetLastError(); vmd_pool_trim(); e = pool_raw_alloc(kind, out, bytes); }
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> l(P.mtx);
+    P.owner[*out] = {bytes, kind};
+    return hipSuccess;
+}
+static void pool_give(void* p) {
+    if (!p) return;
+    ResourcePool& P = pool();
+    size_t bytes = 0; int kind = -2;
+    { std::lock_guard<std::mutex> l(P.mtx);
+      auto it = P.owner.find(p);
+      if (it != P.owner.end()) { bytes = it->second.first; kind = it->second.second; } }
+    if (kind == -2) { (void)hipFree(p); return; }                  // not ours (never happens: every block comes through pool_take)
+    if (kind != kPinned && !t_pool_idle) (void)hipDeviceSynchronize();     // queued work may still touch it (hipFree's implicit guarantee)
+    const size_t limit = ((size_t)std::max(0, g_opt.pool_mb.load()) << 20) / (kind == kPinned ? 4 : 1);
+    { std::lock_guard<std::mutex> l(P.mtx);
+      if (P.pooled[kind == kPinned] + bytes <= limit) {
+          P.blocks[kind].insert({bytes, p});
+          P.pooled[kind == kPinned] += bytes;
+          return;
+      }
+      P.owner.erase(p); }
+    pool_raw_free(kind, p);
+}
+static hipStream_t pool_stream(bool high_priority) {
+    ResourcePool& P = pool();
+    const int d = pool_device();
+    { std::lock_guard<std::mutex> l(P.mtx);
+      auto& v = P.streams[d][high_priority ? 1 : 0];
+      if (!v.empty() && g_opt.pool_mb.load() > 0) { hipStream_t s = v.back(); v.pop_back(); return s; } }
+    hipStream_t s = nullptr;
+    if (high_priority) {
+        int lo = 0, hi = 0;
+        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { (void)hipGetLastError(); lo = hi = 0; }
+        if (hipStreamCreateWithPriority(&s, hipStreamNonBlocking, hi) != hipSuccess) return nullptr;
+    } else if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    return s;
+}
+// the stream must be idle (synchronised by its owner)
+static void pool_stream_give(hipStream_t s, bool high_priority) {
+    if (!s) return;
+    ResourcePool& P = pool();
+    const int d = pool_device();
+    { std::lock_guard<std::mutex> l(P.mtx);
+      auto& v = P.streams[d][high_priority ? 1 : 0];
+      if (g_opt.pool_mb.load() > 0 && v.size() < 64) { v.push_back(s); return; } }
+    (void)hipStreamDestroy(s);
+}
+static hipEvent_t pool_event(bool timing) {
+    ResourcePool& P = pool();
+    const int d = pool_device();
+    { std::lock_guard<std::mutex> l(P.mtx);
+      auto& v = P.events[d][timing ? 0 : 1];
+      if (!v.empty() && g_opt.pool_mb.load() > 0) { hipEvent_t e = v.back(); v.pop_back(); return e; } }
+    hipEvent_t e = nullptr;
+    if ((timing ? hipEventCreate(&e) : hipEventCreateWithFlags(&e, hipEventDisableTiming)) != hipSuccess) return nullptr;
+    return e;
+}
+static void pool_event_give(hipEvent_t e, bool timing) {
+    if (!e) return;
+    ResourcePool& P = pool();
+    const int d = pool_device();
+    { std::lock_guard<std::mutex> l(P.mtx);
+      auto& v = P.events[d][timing ? 0 : 1];
+      if (g_opt.pool_mb.load() > 0 && v.size() < 512) { v.push_back(e); return; } }
+    (void)hipEventDestroy(e);
+}
+
 struct ProfPending { const char* name; hipEvent_t a, b; };
 struct Profiler {
     std::vector<ProfPending> pending;
     std::vector<hipEvent_t> pool;
     hipEvent_t get() {
         if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
-        hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return nullptr; return e;
+        return pool_event(true);
     }
     void begin(const char* name, hipStream_t s) {
         if (!g_prof_on) return;
@@ -261,7 +388,7 @@ struct Profiler {
         }
         pending.swap(later);
     }
-    ~Profiler() { for (auto e : pool) hipEventDestroy(e); for (auto& p : pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); } }
+    ~Profiler() { for (auto e : pool) pool_event_give(e, true); for (auto& p : pending) { (void)hipEventSynchronize(p.b); pool_event_give(p.a, true); pool_event_give(p.b, true); } }
 };
 
 // ------------------------------------------------------------------------------------------------ device buffer helper
@@ -272,9 +399,9 @@ struct DevBuf {
     size_t cap = 0;
     bool ensure(size_t n) {
         if (n <= cap) return true;
-        if (p) (void)hipFree(p);
+        if (p) pool_give(p);
         p = nullptr; cap = 0;
-        hipError_t e = hipMalloc((void**)&p, std::max<size_t>(n, 1) * sizeof(T));
+        hipError_t e = pool_take(-1, (void**)&p, std::max<size_t>(n, 1) * sizeof(T));
         if (e != hipSuccess) return vmd_fail("hipMalloc(%zu bytes) failed: %s", n * sizeof(T), hipGetErrorString(e));
         cap = n;
         return true;
@@ -284,7 +411,7 @@ struct DevBuf {
         if (n) HIP_OK(hipMemcpyAsync(p, src, n * sizeof(T), hipMemcpyHostToDevice, s));
         return true;
     }
-    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    void release() { if (p) pool_give(p); p = nullptr; cap = 0; }
     ~DevBuf() { release(); }
     DevBuf() = default;
     DevBuf(const DevBuf&) = delete;
@@ -304,11 +431,11 @@ struct HostBuf {
     HostBuf(const HostBuf&) = delete;
     HostBuf& operator=(const HostBuf&) = delete;
     ~HostBuf() { release(); }
-    void release() { if (p) { if (pinned) (void)hipHostFree(p); else delete[] p; } p = nullptr; n = 0; pinned = false; }
+    void release() { if (p) { if (pinned) pool_give(p); else delete[] p; } p = nullptr; n = 0; pinned = false; }
     void assign(size_t count, T v, bool want_pinned = false) {
         release();
         if (count == 0) return;
-        if (want_pinned && hipHostMalloc((void**)&p, count * sizeof(T), hipHostMallocDefault) == hipSuccess) pinned = true;
+        if (want_pinned && pool_take(kPinned, (void**)&p, count * sizeof(T)) == hipSuccess) pinned = true;
         else { (void)hipGetLastError(); p = new T[count]; }
         n = count;
         std::fill(p, p + n, v);
@@ -543,7 +670,7 @@ struct PropState {
     bool uploaded = false;
     bool pinned = false;
     ~PropState() {
-        if (zero_done) { (void)hipEventSynchronize(zero_done); (void)hipEventDestroy(zero_done); }
+        if (zero_done) { (void)hipEventSynchronize(zero_done); pool_event_give(zero_done, false); }
     }
     bool dirty = false;                 // device accumulators changed since the last host refresh
     bool counts_stale = false;          // volume: host u64 mirror older than the device accumulators
@@ -970,20 +1097,15 @@ extern "C" vmd_script_eval_t* vmd_eval_create(size_t num_frames, const vmd_scrip
     if (vmd_device_count() <= 0) { vmd_fail("vmd_eval_create: no usable HIP device (the evaluator has no CPU path)"); return nullptr; }
     auto e = std::make_unique<vmd_script_eval_t>();
     if (hipGetDevice(&e->device) != hipSuccess) { vmd_fail("hipGetDevice failed"); return nullptr; }
-    if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) { vmd_fail("hipStreamCreate failed"); return nullptr; }
-    if (hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking) != hipSuccess) { vmd_fail("hipStreamCreate failed"); return nullptr; }
-    if (hipStreamCreateWithFlags(&e->aux_stream, hipStreamNonBlocking) != hipSuccess) { vmd_fail("hipStreamCreate failed"); return nullptr; }
-    if (hipStreamCreateWithFlags(&e->pair_stream, hipStreamNonBlocking) != hipSuccess) { vmd_fail("hipStreamCreate failed"); return nullptr; }
-    if (hipEventCreateWithFlags(&e->pair_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&e->pair_join, hipEventDisableTiming) != hipSuccess) { vmd_fail("hipEventCreate failed"); return nullptr; }
-    {   // the decoder's waves should get the wave slots the pair kernel leaves free as soon as a batch has arrived: highest priority
-        int lo = 0, hi = 0;
-        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { lo = hi = 0; }
-        for (auto& ds : e->decode_streams)
-            if (hipStreamCreateWithPriority(&ds, hipStreamNonBlocking, hi) != hipSuccess) { vmd_fail("hipStreamCreate failed"); return nullptr; }
-        e->decode_stream = e->decode_streams[0];
-    }
-    for (auto& rs : e->raw_slots) if (hipEventCreateWithFlags(&rs.uploaded, hipEventDisableTiming) != hipSuccess) { vmd_fail("hipEventCreate failed"); return nullptr; }
-    for (auto& st : e->stages) if (hipEventCreate(&st.ready) != hipSuccess) { vmd_fail("hipEventCreate failed"); return nullptr; }
+    // streams and events come out of the process-wide cache (an eval has nine streams and ~20 events; VIAMD makes one per script edit)
+    if (!(e->stream = pool_stream(false)) || !(e->copy_stream = pool_stream(false)) || !(e->aux_stream = pool_stream(false)) ||
+        !(e->pair_stream = pool_stream(false))) { vmd_fail("hipStreamCreate failed"); return nullptr; }
+    if (!(e->pair_fork = pool_event(false)) || !(e->pair_join = pool_event(false))) { vmd_fail("hipEventCreate failed"); return nullptr; }
+    // the decoder's waves should get the wave slots the pair kernel leaves free as soon as a batch has arrived: highest priority
+    for (auto& ds : e->decode_streams) if (!(ds = pool_stream(true))) { vmd_fail("hipStreamCreate failed"); return nullptr; }
+    e->decode_stream = e->decode_streams[0];
+    for (auto& rs : e->raw_slots) if (!(rs.uploaded = pool_event(false))) { vmd_fail("hipEventCreate failed"); return nullptr; }
+    for (auto& st : e->stages) if (!(st.ready = pool_event(true))) { vmd_fail("hipEventCreate failed"); return nullptr; }
     e->ir_fingerprint = vmd_ir_fingerprint(ir);
     e->num_frames = num_frames;
     e->spec.rdf_closed = g_opt.spec_rdf_closed.load() != 0;
@@ -1047,9 +1169,9 @@ extern "C" vmd_script_eval_t* vmd_eval_create(size_t num_frames, const vmd_scrip
     }
     build_rdf_plan(e.get());
     if (!e->d_overflow.ensure(1) || hipMemsetAsync(e->d_overflow.p, 0, sizeof(uint32_t), e->stream) != hipSuccess ||
-        hipHostMalloc((void**)&e->h_overflow, 2 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) { vmd_fail("allocating the overflow flag failed"); return nullptr; }
+        pool_take(kPinned, (void**)&e->h_overflow, 2 * sizeof(uint32_t)) != hipSuccess) { vmd_fail("allocating the overflow flag failed"); return nullptr; }
     e->h_overflow[0] = e->h_overflow[1] = 0;
-    for (auto& ev : e->batch_done) if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { vmd_fail("hipEventCreate failed"); return nullptr; }
+    for (auto& ev : e->batch_done) if (!(ev = pool_event(false))) { vmd_fail("hipEventCreate failed"); return nullptr; }
     if (hipStreamSynchronize(e->stream) != hipSuccess) { vmd_fail("hipStreamSynchronize failed"); return nullptr; }
     return e.release();
 }
@@ -1057,51 +1179,60 @@ extern "C" vmd_script_eval_t* vmd_eval_create(size_t num_frames, const vmd_scrip
 extern "C" void vmd_eval_free(vmd_script_eval_t* eval) {
     if (!eval) return;
     VMD_STAGE("vmd_eval_free");
+    int prev_dev = 0;
+    (void)hipGetDevice(&prev_dev);
+    (void)hipSetDevice(eval->device);
     {
         std::lock_guard<std::mutex> l(eval->mtx);
+        // everything this eval ever queued ran on its own streams: once they are idle its blocks, streams and events can go back to
+        // the process-wide cache without another synchronisation (PoolIdle)
         if (eval->stream) { (void)hipStreamSynchronize(eval->stream); }
         if (eval->copy_stream) { (void)hipStreamSynchronize(eval->copy_stream); }
         if (eval->aux_stream) { (void)hipStreamSynchronize(eval->aux_stream); }
-        for (auto& ds : eval->decode_streams) { if (ds) { (void)hipStreamSynchronize(ds); (void)hipStreamDestroy(ds); } ds = nullptr; }
+        if (eval->pair_stream) { (void)hipStreamSynchronize(eval->pair_stream); }
+        for (auto& ds : eval->decode_streams) { if (ds) { (void)hipStreamSynchronize(ds); pool_stream_give(ds, true); } ds = nullptr; }
         eval->decode_stream = nullptr;
+        PoolIdle idle;
         for (auto& rs : eval->raw_slots) {
-            if (rs.h) (void)hipHostFree(rs.h);
+            if (rs.h) pool_give(rs.h);
             rs.h = nullptr;
             rs.d.release();
-            if (rs.uploaded) (void)hipEventDestroy(rs.uploaded);
+            pool_event_give(rs.uploaded, false);
             rs.uploaded = nullptr;
         }
         for (auto& st : eval->stages) {
-            if (st.h) (void)hipHostFree(st.h);
+            if (st.h) pool_give(st.h);
             st.h = nullptr;
-            if (st.hraw) (void)hipHostFree(st.hraw);
+            if (st.hraw) pool_give(st.hraw);
             st.hraw = nullptr;
-            if (st.h_raw_status) (void)hipHostFree(st.h_raw_status);
+            if (st.h_raw_status) pool_give(st.h_raw_status);
             st.h_raw_status = nullptr;
             st.d.release(); st.d_boxes.release(); st.d_bbox.release(); st.d_gboxes.release();
-            if (st.ready) (void)hipEventDestroy(st.ready);
+            st.d_raw.release(); st.d_raw_info.release(); st.d_raw_status.release(); st.d_raw_scratch.release();
+            pool_event_give(st.ready, true);
             st.ready = nullptr;
         }
-        if (eval->copy_stream) (void)hipStreamDestroy(eval->copy_stream);
-        eval->copy_stream = nullptr;
-        if (eval->aux_stream) (void)hipStreamDestroy(eval->aux_stream);
-        eval->aux_stream = nullptr;
-        if (eval->pair_stream) { (void)hipStreamSynchronize(eval->pair_stream); (void)hipStreamDestroy(eval->pair_stream); }
-        eval->pair_stream = nullptr;
-        if (eval->pair_fork) (void)hipEventDestroy(eval->pair_fork);
-        if (eval->pair_join) (void)hipEventDestroy(eval->pair_join);
+        pool_stream_give(eval->copy_stream, false); eval->copy_stream = nullptr;
+        pool_stream_give(eval->aux_stream, false); eval->aux_stream = nullptr;
+        pool_stream_give(eval->pair_stream, false); eval->pair_stream = nullptr;
+        pool_event_give(eval->pair_fork, false); pool_event_give(eval->pair_join, false);
         eval->pair_fork = eval->pair_join = nullptr;
         eval->props.clear();
         eval->sels.clear();
-        if (eval->h_overflow) (void)hipHostFree(eval->h_overflow);
+        if (eval->h_overflow) pool_give(eval->h_overflow);
         eval->h_overflow = nullptr;
-        if (eval->h_snap) (void)hipHostFree(eval->h_snap);
+        if (eval->h_snap) pool_give(eval->h_snap);
         eval->h_snap = nullptr;
-        for (auto& ev : eval->batch_done) { if (ev) (void)hipEventDestroy(ev); ev = nullptr; }
-        if (eval->stream) (void)hipStreamDestroy(eval->stream);
+        for (auto& ev : eval->batch_done) { pool_event_give(ev, false); ev = nullptr; }
+        eval->d_partial.release(); eval->d_partial2.release(); eval->d_pass.release(); eval->d_overflow.release(); eval->d_pen_sample.release();
+        pool_stream_give(eval->stream, false);
         eval->stream = nullptr;
     }
-    delete eval;
+    {
+        PoolIdle idle;              // whatever the destructors still hold (the profilers' events, the remaining buffers)
+        delete eval;
+    }
+    (void)hipSetDevice(prev_dev);
 }
 
 extern "C" void vmd_eval_clear_data(vmd_script_eval_t* eval) {
@@ -1122,7 +1253,7 @@ extern "C" void vmd_eval_clear_data(vmd_script_eval_t* eval) {
         if (p->prop.kind == PROP_SDF && p->pinned) {
             // on its own stream: the staging copies of the next frame_range must not queue behind 8 MB of PCIe traffic
             if (!p->d_zero.p && p->d_zero.ensure(p->ncounts)) (void)hipMemsetAsync(p->d_zero.p, 0, p->ncounts * sizeof(float), eval->aux_stream);
-            if (!p->zero_done) (void)hipEventCreateWithFlags(&p->zero_done, hipEventDisableTiming);
+            if (!p->zero_done) p->zero_done = pool_event(false);
             dma = p->d_zero.p && p->zero_done &&
                   hipMemcpyAsync(p->values.data(), p->d_zero.p, p->ncounts * sizeof(float), hipMemcpyDeviceToHost, eval->aux_stream) == hipSuccess &&
                   hipEventRecord(p->zero_done, eval->aux_stream) == hipSuccess;
@@ -1524,9 +1655,9 @@ static int launch_raw_decode(vmd_script_eval_t* e, Stage& st, const unsigned cha
     st.rec_failed = nullptr;
     st.sectioned = false;
     if (nb > st.h_raw_status_cap) {
-        if (st.h_raw_status) (void)hipHostFree(st.h_raw_status);
+        if (st.h_raw_status) pool_give(st.h_raw_status);
         st.h_raw_status = nullptr; st.h_raw_status_cap = 0;
-        if (hipHostMalloc((void**)&st.h_raw_status, nb * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) { vmd_fail("hipHostMalloc failed"); return -1; }
+        if (pool_take(kPinned, (void**)&st.h_raw_status, nb * sizeof(uint32_t)) != hipSuccess) { vmd_fail("hipHostMalloc failed"); return -1; }
         st.h_raw_status_cap = nb;
     }
     if (!st.d.ensure(nb * 3 * npad) || !st.d_raw_status.ensure(nb)) return -1;
@@ -1594,9 +1725,9 @@ static int raw_upload_f32(vmd_script_eval_t* e, vmd_script_eval_t::RawSlot& rs, 
     }
     rs.info_bytes = (nb * sizeof(vmd_f32_frame_t) + 255) & ~(size_t)255;
     if (rs.info_bytes > rs.hcap) {
-        if (rs.h) (void)hipHostFree(rs.h);
+        if (rs.h) pool_give(rs.h);
         rs.h = nullptr; rs.hcap = 0;
-        if (hipHostMalloc((void**)&rs.h, 2 * rs.info_bytes, hipHostMallocDefault) != hipSuccess) { vmd_fail("hipHostMalloc(%zu bytes) failed", 2 * rs.info_bytes); return -1; }
+        if (pool_take(kPinned, (void**)&rs.h, 2 * rs.info_bytes) != hipSuccess) { vmd_fail("hipHostMalloc(%zu bytes) failed", 2 * rs.info_bytes); return -1; }
         rs.hcap = 2 * rs.info_bytes;
     }
     memcpy(rs.h, rs.f32.data(), nb * sizeof(vmd_f32_frame_t));
@@ -1664,9 +1795,9 @@ static int raw_upload(vmd_script_eval_t* e, RawSlot& rs, vmd_trajectory_i* traj,
             HostTimer map_timer("host_raw_map");
             for (size_t b = 0; b < nb; ++b) rs.info[b].offset = mv.stream_offset[f0 + b] - lo;
             if (rs.info_bytes > rs.hcap) {
-                if (rs.h) (void)hipHostFree(rs.h);
+                if (rs.h) pool_give(rs.h);
                 rs.h = nullptr; rs.hcap = 0;
-                if (hipHostMalloc((void**)&rs.h, 2 * rs.info_bytes, hipHostMallocDefault) != hipSuccess) { vmd_fail("hipHostMalloc(%zu bytes) failed", 2 * rs.info_bytes); return -1; }
+                if (pool_take(kPinned, (void**)&rs.h, 2 * rs.info_bytes) != hipSuccess) { vmd_fail("hipHostMalloc(%zu bytes) failed", 2 * rs.info_bytes); return -1; }
                 rs.hcap = 2 * rs.info_bytes;
             }
             memcpy(rs.h, rs.info.data(), nb * sizeof(vmd_xtc_frame_t));
@@ -1689,10 +1820,10 @@ static int raw_upload(vmd_script_eval_t* e, RawSlot& rs, vmd_trajectory_i* traj,
     // behind the DMA already queued on copy_stream (r03m: 11.5 ms of a 17.4 ms c2 step were spent in this function)
     total += rs.info_bytes;
     if (total > rs.hcap) {
-        if (rs.h) (void)hipHostFree(rs.h);
+        if (rs.h) pool_give(rs.h);
         rs.h = nullptr; rs.hcap = 0;
         const size_t cap = total + total / 8;                            // frames of one trajectory differ by a few per cent
-        if (hipHostMalloc((void**)&rs.h, cap, hipHostMallocDefault) != hipSuccess) { vmd_fail("hipHostMalloc(%zu bytes) failed", cap); return -1; }
+        if (pool_take(kPinned, (void**)&rs.h, cap) != hipSuccess) { vmd_fail("hipHostMalloc(%zu bytes) failed", cap); return -1; }
         rs.hcap = cap;
     }
     const size_t nthreads = std::max<size_t>(1, std::min<size_t>(load_threads(), nb / 4));
@@ -1820,9 +1951,9 @@ static bool fetch_stage(vmd_script_eval_t* e, Stage& st, vmd_trajectory_i* traj,
             st.row_stride = npad;
         } else {
             if (need > st.hcap) {
-                if (st.h) (void)hipHostFree(st.h);
+                if (st.h) pool_give(st.h);
                 st.h = nullptr; st.hcap = 0;
-                HIP_OK(hipHostMalloc((void**)&st.h, need * sizeof(float), hipHostMallocDefault));
+                HIP_OK(pool_take(kPinned, (void**)&st.h, need * sizeof(float)));
                 st.hcap = need;
             }
             if (!st.d.ensure(need)) return false;
@@ -2360,9 +2491,9 @@ static bool process_range(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
     for (auto& p : e->props) if (p->prop.kind == PROP_RDF) rdf_counts += p->ncounts;
     if (defer && rdf_counts) {
         if (e->h_snap_cap < 2 * rdf_counts) {
-            if (e->h_snap) (void)hipHostFree(e->h_snap);
+            if (e->h_snap) pool_give(e->h_snap);
             e->h_snap = nullptr; e->h_snap_cap = 0;
-            HIP_OK(hipHostMalloc((void**)&e->h_snap, 2 * rdf_counts * sizeof(uint64_t), hipHostMallocDefault));
+            HIP_OK(pool_take(kPinned, (void**)&e->h_snap, 2 * rdf_counts * sizeof(uint64_t)));
             e->h_snap_cap = 2 * rdf_counts;
         }
         e->w_snap.resize(2 * rdf_counts);
