@@ -521,6 +521,7 @@ int         vmd_set_option(const char* key, int value);
  * are kept in a process-wide cache for the next (vmd_set_option("pool_mb", MB): bound on the cached device bytes, 0 = no cache).
  * vmd_pool_trim returns everything cached to the runtime (before another library needs the device memory, before exit). */
 void        vmd_pool_trim(void);
+void        vmd_pool_stats(size_t* cached_device_bytes, size_t* cached_pinned_bytes, size_t* cached_blocks);   /* any pointer may be NULL */
 /* wall-clock ms of kernel `which` accumulated by hipEvents since the last reset (bench instrumentation) */
 void        vmd_profile_reset(void);
 double      vmd_profile_ms(const char* which, uint64_t* launches);

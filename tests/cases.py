@@ -226,6 +226,62 @@ def blocks_overflow_case(lib, O, device=False, n=3000, box=60.0):
             lib.vmd_set_option(b"block_superbatch", old[0]); lib.vmd_set_option(b"block_two_streams", old[1])
 
 
+def resource_cache_case(lib, O, device=False, n_water=1500, box=38.0):
+    """VIAMD creates an eval per script edit and frees the old one: the blocks, streams and events an eval gives up are cached
+    process-wide and reused by the next.  Many life cycles give the oracle's integers every time, the cache stops growing after the
+    first cycle, honours its bound, can be emptied, and can be switched off."""
+    import ctypes as C
+    coords, structures, mass = sdf_system(O, 5, n_water, box, 4)
+    n_s, N = structures.size, coords.shape[2]
+    ocell, vcell = cell_pair(O, box)
+    ox = np.arange(n_s, N, 3, dtype=np.int32)
+    ir = V.ScriptIR(lib)
+    ir.add_rdf("g", ox, ox, (0.0, 9.0)); ir.add_sdf("v", structures, ox, 7.0); ir.add_distance("d", structures[0], structures[1], L.DIST_MIN)
+    traj = make_traj(lib, coords, vcell, device)
+    sysm = V.MolSystem(N, mass=mass, unitcell=vcell)
+    counts, _ = oracle_rdf(O, coords, ocell, ox, ox, 0.0, 9.0)
+    vol, _ = oracle_sdf(O, coords, ocell, structures, mass, ox, 7.0)
+
+    def stats():
+        a, b, c = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
+        lib.vmd_pool_stats(C.byref(a), C.byref(b), C.byref(c))
+        return a.value, b.value, c.value
+
+    def cycle():
+        ev = V.ScriptEval(coords.shape[0], ir)
+        assert ev.frame_range(sysm, traj, 0, coords.shape[0])
+        np.testing.assert_array_equal(ev.property_data("g").counts, counts)
+        np.testing.assert_array_equal(ev.property_data("v").counts, vol)
+        ev.close()
+
+    lib.vmd_pool_trim()
+    assert stats() == (0, 0, 0)
+    cycle()
+    first = stats()
+    assert first[0] > 0 and first[2] > 10, first                     # device blocks came back
+    for _ in range(5):
+        cycle()
+    assert stats() == first, (stats(), first)                        # ... and every later eval lived on them: nothing new was cached
+    # two evals alive at once need a second set; afterwards both sets are cached
+    a = V.ScriptEval(coords.shape[0], ir); b = V.ScriptEval(coords.shape[0], ir)
+    assert a.frame_range(sysm, traj, 0, 2) and b.frame_range(sysm, traj, 2, 4)
+    a.close(); b.close()
+    assert stats()[0] > first[0]
+    lib.vmd_pool_trim()
+    assert stats() == (0, 0, 0)
+    old = lib.vmd_set_option(b"pool_mb", 1)                          # a bound below one volume accumulator (16.8 MB): that block is not kept
+    try:
+        cycle()
+        assert 0 < stats()[0] <= (1 << 20)
+        lib.vmd_set_option(b"pool_mb", 0)                            # off: every block goes back to the runtime
+        cycle()
+        assert stats() == (0, 0, 0)
+    finally:
+        lib.vmd_set_option(b"pool_mb", old)
+    cycle()
+    assert stats()[0] > 0
+
+
 def class_decomposition_cases(lib, O, device=False, n_water=3000, box=40.0):
     """Co-evaluated RDFs of one range share pair passes through disjoint atom classes (BASELINE config 5: goo is a subset of
     ghv).  With and without the decomposition every property equals its own oracle histogram; sets that overlap partially,

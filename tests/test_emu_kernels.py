@@ -37,6 +37,10 @@ def test_batch_of_frame_blocks_overflow_is_all_or_nothing(emu_lib, oracle):
     cases.blocks_overflow_case(emu_lib, oracle)
 
 
+def test_eval_life_cycles_reuse_cached_blocks_streams_and_events(emu_lib, oracle):
+    cases.resource_cache_case(emu_lib, oracle)
+
+
 def test_coevaluated_rdfs_share_pair_passes(emu_lib, oracle):
     cases.class_decomposition_cases(emu_lib, oracle, n_water=1800, box=38.0)
 

@@ -179,6 +179,7 @@ SIGNATURES = [
     ("vmd_eval_frames_section_decoded", C.c_size_t, [_vp]),
     ("vmd_eval_frames_mapped", C.c_size_t, [_vp]),
     ("vmd_pool_trim", None, []),
+    ("vmd_pool_stats", None, [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     ("vmd_ckcache_save", C.c_bool, [C.POINTER(TrajectoryI), C.c_char_p]),
     ("vmd_ckcache_load", C.c_long, [C.POINTER(TrajectoryI), C.c_char_p, C.c_int]),
     ("vmd_devtraj_create", _vp, [C.c_size_t, C.c_size_t]),

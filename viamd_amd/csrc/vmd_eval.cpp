@@ -271,6 +271,15 @@ extern "C" void vmd_pool_trim(void) {
     for (auto& v : victims) { if (v.first != kPinned) (void)hipSetDevice(v.first); pool_raw_free(v.first, v.second); }
     (void)hipSetDevice(prev);
 }
+extern "C" void vmd_pool_stats(size_t* device_bytes, size_t* pinned_bytes, size_t* blocks) {
+    ResourcePool& P = pool();
+    std::lock_guard<std::mutex> l(P.mtx);
+    if (device_bytes) *device_bytes = P.pooled[0];
+    if (pinned_bytes) *pinned_bytes = P.pooled[1];
+    size_t n = 0;
+    for (int k = 0; k <= kPinned; ++k) n += P.blocks[k].size();
+    if (blocks) *blocks = n;
+}
 // kind: kPinned, or -1 = the current device
 static hipError_t pool_take(int kind, void** out, size_t bytes) {
     if (kind < 0) kind = pool_device();
