@@ -88,6 +88,9 @@ struct Options {
                                              // 3 = one wave per frame (k_xtc_wave)
     std::atomic<int> xtc_chunk{256};         // atoms per chunk of variant 2
     std::atomic<int> pool_mb{16384};         // process-wide cache of device blocks freed by evals (MB; pinned host blocks: a quarter of it); 0 = off
+    std::atomic<int> gather_us{150};         // combining queue: how long the leader waits for the other pool threads of the previous round to come back with their next ranges (0 = take what is there)
+    std::atomic<int> lazy_views{1};          // combining queue: the host views are refreshed when no call is waiting (and every lazy_views_ms at the latest), not after every batch
+    std::atomic<int> lazy_views_ms{20};
     std::atomic<int> defer_sync{0};          // the next batch is queued before the host waits for the current one (evals without block partials); measured r03ad: no gain (the per-batch host gap is ~0.06 ms; the next decode then lands on the cell build), off
     std::atomic<int> block_superbatch{1};    // filtered evaluation: consecutive frame blocks share ONE batch (one cell build, one synchronisation; a pair launch per block)
     std::atomic<int> block_two_streams{1};   // ... and the blocks' pair launches alternate between two streams, so that the tail of one runs under the head of the next
@@ -151,6 +154,9 @@ extern "C" int vmd_set_option(const char* key, int value) {
     else if (!strcmp(key, "xtc_ramp")) o = &g_opt.xtc_ramp;
     else if (!strcmp(key, "block_superbatch")) o = &g_opt.block_superbatch;
     else if (!strcmp(key, "defer_sync")) o = &g_opt.defer_sync;
+    else if (!strcmp(key, "gather_us")) o = &g_opt.gather_us;
+    else if (!strcmp(key, "lazy_views")) o = &g_opt.lazy_views;
+    else if (!strcmp(key, "lazy_views_ms")) o = &g_opt.lazy_views_ms;
     else if (!strcmp(key, "pool_mb")) { const int old = g_opt.pool_mb.exchange(value < 0 ? 0 : value); vmd_pool_trim(); return old; }
     else if (!strcmp(key, "block_two_streams")) o = &g_opt.block_two_streams;
     else if (!strcmp(key, "xtc_decode_ahead")) o = &g_opt.xtc_decode_ahead;
@@ -904,6 +910,9 @@ struct vmd_script_eval_t {
     std::condition_variable queue_cv;
     std::vector<RangeRequest*> queue;
     bool leader_active = false;
+    size_t last_round = 0;                            // requests the leader served in its previous round: how many callers to expect back
+    long last_round_us = 0;                           // ... and how long that round took to evaluate
+    std::chrono::steady_clock::time_point views_at{}; // when the host views were last brought up to date (lazy_views)
     std::vector<std::unique_ptr<PropState>> props;
     std::vector<std::unique_ptr<Selection>> sels;
     hipStream_t stream = nullptr;
@@ -2343,7 +2352,9 @@ static bool view_holds(bool have_view, const vmd_device_view_t& view, size_t fra
 }
 
 // evaluates frames [frame_beg, frame_end) in large batches; returns false on interrupt (empty error) or failure
-static bool process_range(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_trajectory_i* traj, uint32_t frame_beg, uint32_t frame_end) {
+// views: bring the host views (values / weights / volume / aggregates) up to date before returning; false = the caller does it later
+// (refresh_views), the device accumulators and the frame mask are complete either way
+static bool process_range(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_trajectory_i* traj, uint32_t frame_beg, uint32_t frame_end, bool views = true) {
     g_last_error.clear();
     if (eval->interrupt) return false;
     std::lock_guard<std::mutex> lock(eval->mtx);
@@ -2659,7 +2670,7 @@ static bool process_range(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
         for (auto& p : e->props) {
             if (p->prop.kind != PROP_RDF) continue;
             if (behind && c.snapshot && !repeated && !(later && later->poisoned)) refresh_distribution_from(p.get(), e->h_snap + soff, e->w_snap.data() + soff);
-            else if (!behind) { if (!refresh_distribution(e, p.get())) return false; }
+            else if (!behind && views) { if (!refresh_distribution(e, p.get())) return false; }
             soff += p->ncounts;
         }
         return true;
@@ -2791,12 +2802,30 @@ static bool process_range(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
       BatchCtx& b = &a == &ctx[0] ? ctx[1] : ctx[0];
       if (!complete_batch(a, b.active ? &b : nullptr)) return false;
       if (!complete_batch(b, nullptr)) return false; }
-    for (auto& p : e->props) {
-        if (!p->dirty) continue;
-        if (p->prop.kind == PROP_SDF) { if (!refresh_volume(e, p.get())) return false; }
-        else if (p->prop.kind == PROP_DIST) refresh_temporal_stats(e, p.get());
+    if (views) {
+        for (auto& p : e->props) {
+            if (!p->dirty) continue;
+            if (p->prop.kind == PROP_SDF) { if (!refresh_volume(e, p.get())) return false; }
+            else if (p->prop.kind == PROP_DIST) refresh_temporal_stats(e, p.get());
+        }
+        e->views_at = std::chrono::steady_clock::now();
     }
     return completed;
+}
+
+// the host views of every property whose accumulators changed since its last refresh (the combining queue calls this when no call
+// is waiting, process_range(views = true) does the same at its end)
+static bool refresh_views(vmd_script_eval_t* e) {
+    std::lock_guard<std::mutex> lock(e->mtx);
+    HIP_OK(hipSetDevice(e->device));
+    for (auto& p : e->props) {
+        if (!p->dirty) continue;
+        if (p->prop.kind == PROP_RDF) { if (!refresh_distribution(e, p.get())) return false; }
+        else if (p->prop.kind == PROP_SDF) { if (!refresh_volume(e, p.get())) return false; }
+        else refresh_temporal_stats(e, p.get());
+    }
+    e->views_at = std::chrono::steady_clock::now();
+    return true;
 }
 
 // The hot call.  VIAMD invokes it from N pool threads with small disjoint ranges (grain 1, src/main.cpp:993-997,
@@ -2823,9 +2852,43 @@ extern "C" bool vmd_eval_frame_range(vmd_script_eval_t* eval, const vmd_script_i
     }
     eval->leader_active = true;
     while (!eval->queue.empty()) {
+        // VIAMD's pool threads pull ranges of a few frames each (enkiTS: num_frames / (threads x (threads - 1)), at least 1) and every
+        // one of them blocks in here, so a round can never hold more than threads x grain frames - and far fewer if the leader runs
+        // off with whatever is queued the instant it looks: the threads it has just released are back with their next ranges within
+        // microseconds.  It waits for them (gather_us at most, only while requests keep arriving) - a batch of 16 x 4 frames costs the
+        // same ~0.15 ms of launches and round trips as a batch of 4.
+        // Waiting is only worth a fraction of what a round costs: the slowest of the released threads needs 50 - 100 us to come back,
+        // which a round of the 10 000-frame SDF (0.08 ms for 16 frames) cannot afford and a round of the 100k-atom RDF (0.3 ms) can:
+        // at most half the previous round's time.  A large pool brings enough frames per round by itself, and on an oversubscribed
+        // host waiting for 128 threads costs more than it gathers: pools of up to 32 callers only.
+        const int gather = (int)std::min<long>(g_opt.gather_us.load(), eval->last_round_us / 2);
+        // Scripts without pair passes (SDF / distance only: 0.7 us of kernels per frame) never gain from it - measured r03an: 129 ms
+        // without, 195 ms with, for the 10 000 frames of config 4 from 16 threads - so only evals with RDF groups wait.
+        if (gather >= 20 && !eval->rdf_groups.empty() && eval->queue.size() < eval->last_round && eval->last_round <= 32) {
+            const auto t0 = std::chrono::steady_clock::now();
+            const auto deadline = t0 + std::chrono::microseconds(gather);
+            auto last_arrival = t0;
+            size_t seen = eval->queue.size();
+            while (eval->queue.size() < eval->last_round && !eval->interrupt) {
+                ql.unlock();
+                std::this_thread::yield();
+                ql.lock();
+                const auto now = std::chrono::steady_clock::now();
+                if (eval->queue.size() != seen) { seen = eval->queue.size(); last_arrival = now; }
+                // nobody new for a third of the window: the task is running out of ranges (its tail), or the pool is busy elsewhere
+                if (now >= deadline || now - last_arrival > std::chrono::microseconds(gather / 3 + 1)) break;
+            }
+        }
         std::vector<RangeRequest*> taken;
         taken.swap(eval->queue);
+        eval->last_round = taken.size();
         ql.unlock();
+        // the views are for readers, and a reader only needs them final when the LAST call returns: while other calls are waiting they
+        // are brought up to date at most every lazy_views_ms (a polling GUI still sees progress), and always before a round whose end
+        // finds the queue empty hands its callers back
+        const bool lazy = g_opt.lazy_views.load() != 0;
+        bool all_ok = true;
+        const auto round_t0 = std::chrono::steady_clock::now();
         // requests for the same trajectory, sorted by first frame; touching ranges fuse into one run
         std::sort(taken.begin(), taken.end(), [](const RangeRequest* a, const RangeRequest* b) {
             return a->traj != b->traj ? a->traj < b->traj : a->beg < b->beg; });
@@ -2834,12 +2897,24 @@ extern "C" bool vmd_eval_frame_range(vmd_script_eval_t* eval, const vmd_script_i
             size_t j = i + 1;
             uint32_t run_end = taken[i]->end;
             while (j < taken.size() && taken[j]->traj == taken[i]->traj && taken[j]->beg == run_end) { run_end = taken[j]->end; ++j; }
-            const bool ok = process_range(eval, taken[i]->sys, taken[i]->traj, taken[i]->beg, run_end);
+            const bool ok = process_range(eval, taken[i]->sys, taken[i]->traj, taken[i]->beg, run_end, !lazy);
             const std::string err = ok ? std::string() : g_last_error;
             for (size_t k = i; k < j; ++k) { taken[k]->ok = ok; taken[k]->error = err; }
+            all_ok = all_ok && ok;
             i = j;
         }
+        const long round_us = (long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - round_t0).count();
         ql.lock();
+        eval->last_round_us = round_us;
+        if (lazy) {
+            const bool overdue = std::chrono::steady_clock::now() - eval->views_at > std::chrono::milliseconds(std::max(1, g_opt.lazy_views_ms.load()));
+            if (eval->queue.empty() || overdue) {
+                ql.unlock();
+                const bool vok = refresh_views(eval);
+                if (!vok && all_ok) { const std::string err = g_last_error; for (RangeRequest* r : taken) { r->ok = false; r->error = err; } }
+                ql.lock();
+            }
+        }
         for (RangeRequest* r : taken) r->done = true;
         eval->queue_cv.notify_all();
     }
