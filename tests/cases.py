@@ -226,6 +226,66 @@ def blocks_overflow_case(lib, O, device=False, n=3000, box=60.0):
             lib.vmd_set_option(b"block_superbatch", old[0]); lib.vmd_set_option(b"block_two_streams", old[1])
 
 
+def pool_threads_case(lib, O, device=False, n_water=1500, box=38.0, F=24, nthreads=6):
+    """frame_range the way VIAMD calls it (src/main.cpp:993-997): pool threads pull ranges of 1 - 3 frames and all call on ONE eval.
+    The combining queue gathers them into rounds and refreshes the host views only when no call is waiting - when the last call
+    has returned every view (values, weights, the float volume and its maximum, temporal rows and their ranges) must be what one
+    call over the whole range leaves, with the waiting and the lazy refresh on and off, and after an interrupt + restart."""
+    import threading
+    coords, structures, mass = sdf_system(O, 11, n_water, box, F)
+    n_s, N = structures.size, coords.shape[2]
+    ocell, vcell = cell_pair(O, box)
+    ox = np.arange(n_s, N, 3, dtype=np.int32)
+    ir = V.ScriptIR(lib)
+    ir.add_rdf("g", ox, ox, (0.0, 9.0)); ir.add_sdf("v", structures, ox, 7.0); ir.add_distance("d", structures[0], structures[1], L.DIST_MIN)
+    traj = make_traj(lib, coords, vcell, device)
+    sysm = V.MolSystem(N, mass=mass, unitcell=vcell)
+    one = V.ScriptEval(F, ir)
+    assert one.frame_range(sysm, traj, 0, F)
+    want = {n: one.property_data(n) for n in ("g", "v", "d")}
+    counts, _ = oracle_rdf(O, coords, ocell, ox, ox, 0.0, 9.0)
+    np.testing.assert_array_equal(want["g"].counts, counts)
+
+    def pooled(ev, grain, stop_at=None):
+        nxt = [0]; lock = threading.Lock(); res = []
+        def work():
+            while True:
+                with lock:
+                    b = nxt[0]; nxt[0] += grain
+                if b >= F:
+                    return
+                if stop_at is not None and b >= stop_at:
+                    ev.interrupt()
+                res.append(ev.frame_range(sysm, traj, b, min(F, b + grain)))
+        ths = [threading.Thread(target=work) for _ in range(nthreads)]
+        [t.start() for t in ths]; [t.join() for t in ths]
+        return res
+
+    for gather, lazy, grain in ((150, 1, 1), (150, 1, 3), (0, 1, 1), (0, 0, 2), (150, 0, 1)):
+        old = (lib.vmd_set_option(b"gather_us", gather), lib.vmd_set_option(b"lazy_views", lazy))
+        try:
+            ev = V.ScriptEval(F, ir)
+            assert all(pooled(ev, grain)) and ev.frames_done() == F and ev.frame_mask().all()
+            for n in ("g", "v", "d"):
+                got = ev.property_data(n)
+                np.testing.assert_array_equal(got.values, want[n].values, err_msg=f"{n} values (gather {gather}, lazy {lazy}, grain {grain})")
+                assert got.max_value == want[n].max_value and got.min_value == want[n].min_value, n
+                assert tuple(got.min_range) == tuple(want[n].min_range) and tuple(got.max_range) == tuple(want[n].max_range), n
+            np.testing.assert_array_equal(ev.property_data("g").weights, want["g"].weights)
+            np.testing.assert_array_equal(ev.property_data("g").counts, want["g"].counts)
+            # interrupted half way, then restarted from scratch (src/main.cpp:984-990): the same views again
+            ev.clear_data()
+            pooled(ev, grain, stop_at=F // 2)
+            assert ev.frames_done() <= F
+            ev.clear_data()
+            assert all(pooled(ev, grain)) and ev.frames_done() == F
+            for n in ("g", "v", "d"):
+                np.testing.assert_array_equal(ev.property_data(n).values, want[n].values, err_msg=f"{n} after interrupt + restart")
+            ev.close()
+        finally:
+            lib.vmd_set_option(b"gather_us", old[0]); lib.vmd_set_option(b"lazy_views", old[1])
+
+
 def resource_cache_case(lib, O, device=False, n_water=1500, box=38.0):
     """VIAMD creates an eval per script edit and frees the old one: the blocks, streams and events an eval gives up are cached
     process-wide and reused by the next.  Many life cycles give the oracle's integers every time, the cache stops growing after the

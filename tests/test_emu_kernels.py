@@ -37,6 +37,10 @@ def test_batch_of_frame_blocks_overflow_is_all_or_nothing(emu_lib, oracle):
     cases.blocks_overflow_case(emu_lib, oracle)
 
 
+def test_pool_threads_with_small_ranges_leave_the_views_of_one_call(emu_lib, oracle):
+    cases.pool_threads_case(emu_lib, oracle)
+
+
 def test_eval_life_cycles_reuse_cached_blocks_streams_and_events(emu_lib, oracle):
     cases.resource_cache_case(emu_lib, oracle)
 
