@@ -46,11 +46,18 @@ def build_emu():
     out = EMU_LIB if not san else os.path.join("/tmp", "libviamd_emu_" + san.replace(",", "_") + ".so")   # never into the tree: in-tree .so files travel to the GPU box
     if os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(s) for s in EMU_DEPS):
         return out
+    # several pytest-xdist workers may find the library missing at once: each builds into its own file and renames it into place
+    tmp = f"{out}.{os.getpid()}.tmp"
     cmd = ["g++", "-O2", "-g", "-shared", "-fPIC", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-mavx2", "-mfma",
-           "-I" + EMU_DIR, "-I" + os.path.join(ROOT, "include"), "-x", "c++"] + EMU_SOURCES + ["-ldl", "-o", out]
+           "-I" + EMU_DIR, "-I" + os.path.join(ROOT, "include"), "-x", "c++"] + EMU_SOURCES + ["-ldl", "-o", tmp]
     if san:
         cmd[1:1] = ["-fsanitize=" + san, "-fno-omit-frame-pointer", "-fno-sanitize-recover=undefined"]
-    subprocess.check_call(cmd)
+    try:
+        subprocess.check_call(cmd)
+        os.replace(tmp, out)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
     return out
 
 
