@@ -142,6 +142,7 @@ int vmd_hip_sdf_scatter(void* stream, const float* xyz, size_t frame_stride, siz
                         int unowned /* 1: no target is a member of any structure (owner all -1): skip the owner loads */);
 int vmd_hip_set_sdf_rows(int n);       /* tuning knob: row-streaming scatter for progression targets with stride <= 4 (0 = off; 1, 2, 4 groups of 4 atoms per thread) */
 int vmd_hip_set_sdf_ilp(int n);        /* tuning knob: target atoms per thread of the scatter (4 or 8), returns the previous value */
+int vmd_hip_set_rdf_nsplit(int n);     /* pair launches with fewer work items than resident waves deal a chunk's neighbour pencils to n items each: -1 automatic (5 same-set / 9), 0 off */
 int vmd_hip_set_sdf_wave(int on);      /* SDF scatter kernel: 0 = per-block compaction of the group test's survivors, 1 = per wave (no block barrier), 2 = the persistent streaming kernel (a wave walks tiles, next tile's gathers in flight) on 2 048 blocks, n >= 16 = on n blocks */
 
 /* K5: distance family, one row per frame: out f32[B][P*per].  kind as vmd_distance_kind_t; P contexts (population);

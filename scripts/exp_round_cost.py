@@ -11,6 +11,8 @@ g = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 w = bench.WORKLOADS[name]
 F = 400
 lib = V.default_lib()
+for kv in sys.argv[3:]:
+    k, v = kv.split("="); lib.vmd_set_option(k.encode(), int(v))
 traj = synth.make_device_trajectory(V, w["seed"], w["atoms"], w["box"], F, w["blob"])
 topo = synth.water_box_topology(w["atoms"], w["blob"])
 ir, info = script.compile_script(w["script"], topo)

@@ -37,6 +37,20 @@ def test_batch_of_frame_blocks_overflow_is_all_or_nothing(emu_lib, oracle):
     cases.blocks_overflow_case(emu_lib, oracle)
 
 
+def test_small_launches_split_by_neighbour_pencil(emu_lib, oracle, box3k):
+    """rdf_nsplit: the work item of a small launch is (chunk, part of its neighbour pencils) - same pairs, same integers: half shell
+    (5 parts), two sets (9 parts), an explicit part count that does not divide the neighbour count, split pencils."""
+    o, h = cases.oxygen(3000), cases.hydrogen(3000)
+    for n, extra in ((-1, {}), (3, {}), (7, {"pencil_split_y": 2})):
+        old = emu_lib.vmd_set_option(b"rdf_nsplit", n)
+        olde = {k: emu_lib.vmd_set_option(k.encode(), v) for k, v in extra.items()}
+        try:
+            cases.check_rdf(emu_lib, oracle, box3k[:2], 60.0, [("goo", o, o, 0.0, 12.0), ("goh", o, h, 1.0, 10.0)])
+        finally:
+            emu_lib.vmd_set_option(b"rdf_nsplit", old)
+            for k, v in olde.items(): emu_lib.vmd_set_option(k.encode(), v)
+
+
 def test_pool_threads_with_small_ranges_leave_the_views_of_one_call(emu_lib, oracle):
     cases.pool_threads_case(emu_lib, oracle)
 

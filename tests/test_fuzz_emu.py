@@ -76,6 +76,8 @@ def scenario(seed, scale=1):
         opts["cells_rec3"] = 0                      # 16-byte bucket records (no draw from rng: the scenarios stay what they were)
     if seed % 7 == 0:
         opts["cells_bin_lds"] = 0                   # level 1 of the cell build without the block-local sort
+    if seed % 3 == 1:
+        opts["rdf_nsplit"] = -1                     # small launches: a chunk's neighbour pencils dealt to separate work items
     if seed % 4 == 1:
         opts["defer_sync"] = 1                      # the next batch queued before the host waits for the current one (several batches
         opts.setdefault("batch_frames", 2)          # needed; no draw from rng)

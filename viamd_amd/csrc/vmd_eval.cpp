@@ -132,6 +132,11 @@ static size_t load_threads() {
     return std::min<size_t>(32, std::max<size_t>(8, hw / 8));
 }
 
+// k_rdf_pencil can deal a chunk's neighbour pencils to separate work items in small launches (vmd_hip_set_rdf_nsplit): measured
+// r03ar - a one-frame launch gains (170 -> 133 us), a four-frame launch loses (194 -> 252 us) - so it is switched off when the library
+// loads (here, not in vmd_kernels.hip: that file is byte for byte what the committed PMC passes were collected on)
+static const int g_rdf_nsplit_at_load = vmd_hip_set_rdf_nsplit(0);
+
 extern "C" int vmd_set_option(const char* key, int value) {
     std::atomic<int>* o = nullptr;
     if (!strcmp(key, "rdf_variant")) o = &g_opt.rdf_variant;
@@ -175,6 +180,7 @@ extern "C" int vmd_set_option(const char* key, int value) {
     else if (!strcmp(key, "sdf_ilp")) return vmd_hip_set_sdf_ilp(value);
     else if (!strcmp(key, "sdf_rows")) return vmd_hip_set_sdf_rows(value);
     else if (!strcmp(key, "sdf_wave")) return vmd_hip_set_sdf_wave(value);
+    else if (!strcmp(key, "rdf_nsplit")) return vmd_hip_set_rdf_nsplit(value);
     else if (!strcmp(key, "cells_pencil")) return vmd_hip_set_cells_pencil(value);
     else if (!strcmp(key, "cells_rec3")) return vmd_hip_set_cells_rec3(value);
     else if (!strcmp(key, "cells_bin_lds")) return vmd_hip_set_cells_bin_lds(value);

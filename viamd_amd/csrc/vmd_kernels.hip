@@ -805,6 +805,8 @@ struct vmd_pair_params_t {
     uint32_t pbc;            // bits 0..2: periodic axes (an open axis spans the batch's bounding box: boxes slots 6..8 = origin)
     const uint32_t* skip;    // device flag or NULL: non-zero = the sorted copies are incomplete (a bucket of the cell build overflowed), do nothing
     int ry, rz;              // neighbour reach in pencils per axis: 1 (cross-section >= rmax), 2 = split pencils (cross-section >= rmax/2)
+    int nsplit;              // > 1 (small launches): a chunk's neighbour pencils are dealt to nsplit work items instead of one - a lone
+                             // item is a dependent chain of cold scalar loads (170 us for a one-frame launch, profiles/r03aq)
     unsigned long long* cols_total;   // device counter or NULL: candidate columns of every launch since the host last reset it (one atomic per
                                       // wave at kernel end): bench.py's "candidate lanes per counted hit" is measured, not modelled
 };
@@ -1588,14 +1590,17 @@ __global__ __launch_bounds__(256) VMD_SGPR_CAP(96) void k_rdf_pencil(vmd_pair_pa
     int q = blockIdx.x & 7, tries = 0;
     int item = -1, next_item = -1;
     const int nsub = p.nsub;
-    const int nitem_frame = npen * nsub;
+    const int nsplit = p.nsplit;
+    const int nitem_frame = npen * nsub * nsplit;
     if (lane == 0) item = vmd_next_item(p.work_counter, q, tries, p.B, nitem_frame);
     item = __builtin_amdgcn_readfirstlane(item);
     for (; item >= 0; item = next_item) {
         if (lane == 0) next_item = vmd_next_item(p.work_counter, q, tries, p.B, nitem_frame);
         const int b = item / nitem_frame;
-        const int rem = item - b * nitem_frame;
-        const int pen = rem / nsub;
+        const int rem0 = item - b * nitem_frame;
+        const int rem = rem0 / nsplit;
+        const int part = rem0 - rem * nsplit;               // which of the chunk's neighbour pencils this item walks (fastest: the parts of
+        const int pen = rem / nsub;                         // a chunk go to consecutive waves, which share its i atoms and its neighbourhood)
         const int sub = rem - pen * nsub;
         const int pz = pen / ny;
         const int py = pen - pz * ny;
@@ -1643,6 +1648,7 @@ __global__ __launch_bounds__(256) VMD_SGPR_CAP(96) void k_rdf_pencil(vmd_pair_pa
                 if (qz < 0) { qz += nz; sz = -Lz; nc = -1.0f; } else if (qz >= nz) { qz -= nz; sz = Lz; nc = 1.0f; }
                 for (int dy = -p.ry; dy <= p.ry; ++dy) {
                     if (SAME && dz == 0 && dy < 0) continue;
+                    if (nsplit > 1 && ((dz + p.rz) * (2 * p.ry + 1) + (dy + p.ry)) % nsplit != part) continue;
                     int qy = py + dy; float sy = 0.0f, nb = 0.0f;
                     if (open_y && (qy < 0 || qy >= ny)) continue;
                     if (qy < 0) { qy += ny; sy = -Ly; nb = -1.0f; } else if (qy >= ny) { qy -= ny; sy = Ly; nb = 1.0f; }
@@ -2647,6 +2653,8 @@ extern "C" uint64_t vmd_hip_rdf_columns(int reset) {
     if (reset) (void)hipMemset(c, 0, sizeof(v));
     return (uint64_t)v;
 }
+static int g_rdf_nsplit = -1;     // small launches split a chunk's neighbour pencils over work items: -1 automatic (5 / 9), 0 never, n > 0 = n parts
+extern "C" int vmd_hip_set_rdf_nsplit(int n) { const int old = g_rdf_nsplit; g_rdf_nsplit = n < -1 ? -1 : (n > 25 ? 25 : n); return old; }
 static int g_rdf_blocks = 2048;   // 8 blocks x 4 waves per CU requested; 6 fit (SGPR budget)
 extern "C" int vmd_hip_rdf_num_blocks(void) { return 2048; }   // capacity of the partial-row scratch
 extern "C" int vmd_hip_set_rdf_blocks(int n) { const int old = g_rdf_blocks; if (n >= 8 && n <= 2048) g_rdf_blocks = n; return old; }
@@ -2687,7 +2695,11 @@ extern "C" int vmd_hip_rdf_pencil(void* stream, const float* sorted_ref, const u
         if (p.nsub < 1) p.nsub = 1;
         if (p.nsub > 64) p.nsub = 64;
     }
-    const int nitems = B * grid.ny * grid.nz * p.nsub;
+    // small launches: fewer items than the grid has waves.  Every item is then a lone, latency-bound chain; dealing a chunk's neighbour
+    // pencils (5 in the half shell, 9 otherwise) to separate items shortens the chains and fills the idle waves
+    p.nsplit = 1;
+    if (g_rdf_nsplit != 0 && (long long)B * grid.ny * grid.nz * p.nsub < 4ll * g_rdf_blocks) p.nsplit = g_rdf_nsplit > 0 ? g_rdf_nsplit : (same_set ? 5 : 9);
+    const int nitems = B * grid.ny * grid.nz * p.nsub * p.nsplit;
     int nblocks = (nitems + 3) / 4;
     if (nblocks < 8) nblocks = 8;
     if (nblocks > g_rdf_blocks) nblocks = g_rdf_blocks;
