@@ -322,16 +322,20 @@ static void pool_give(void* p) {
       auto it = P.owner.find(p);
       if (it != P.owner.end()) { bytes = it->second.first; kind = it->second.second; } }
     if (kind == -2) { (void)hipFree(p); return; }                  // not ours (never happens: every block comes through pool_take)
+    // a device block belongs to ITS device, whatever the calling thread's current one is (a reader closing on another thread)
+    const int prev = kind != kPinned ? pool_device() : 0;
+    if (kind != kPinned && prev != kind) (void)hipSetDevice(kind);
     if (kind != kPinned && !t_pool_idle) (void)hipDeviceSynchronize();     // queued work may still touch it (hipFree's implicit guarantee)
     const size_t limit = ((size_t)std::max(0, g_opt.pool_mb.load()) << 20) / (kind == kPinned ? 4 : 1);
+    bool kept = false;
     { std::lock_guard<std::mutex> l(P.mtx);
       if (P.pooled[kind == kPinned] + bytes <= limit) {
           P.blocks[kind].insert({bytes, p});
           P.pooled[kind == kPinned] += bytes;
-          return;
-      }
-      P.owner.erase(p); }
-    pool_raw_free(kind, p);
+          kept = true;
+      } else P.owner.erase(p); }
+    if (!kept) pool_raw_free(kind, p);
+    if (kind != kPinned && prev != kind) (void)hipSetDevice(prev);
 }
 static hipStream_t pool_stream(bool high_priority) {
     ResourcePool& P = pool();
