@@ -291,9 +291,26 @@ def run_workload(name, args, ctx, steps, warmup, frames=None, with_cpu=False, op
 
     merge_s = [0.0]
 
+    def ranged():
+        # --pool-threads N --grain G: the way VIAMD drives the boundary (src/main.cpp:993-997): N pool threads pull ranges of G frames
+        # and all call frame_range on the SAME eval; every thread blocks until its frames are evaluated
+        import threading
+        nxt = [beg]; lock = threading.Lock(); ok = [True]
+        def work():
+            while ok[0]:
+                with lock:
+                    b = nxt[0]; nxt[0] += args.grain
+                if b >= end:
+                    return
+                if not ev.frame_range(sysm, traj, b, min(end, b + args.grain)):
+                    ok[0] = False
+        ths = [threading.Thread(target=work) for _ in range(args.pool_threads)]
+        [t.start() for t in ths]; [t.join() for t in ths]
+        return ok[0]
+
     def step():
         ev.clear_data()
-        assert ev.frame_range(sysm, traj, beg, end)
+        assert ranged() if args.pool_threads > 0 else ev.frame_range(sysm, traj, beg, end)
         t_m = time.perf_counter()
         reduce_eval(ev)                          # vmd_eval_reduce over RCCL: ONE merge of the accumulators per step (no-op at N = 1)
         merge_s[0] += time.perf_counter() - t_m
@@ -435,6 +452,10 @@ def run_workload(name, args, ctx, steps, warmup, frames=None, with_cpu=False, op
                             note="one vmd_eval_reduce per step: all all-reduces of a merge inside one ncclGroupStart / End; device_ms = hipEvents "
                                  "around the staged collectives of the LAST step, host_ms_per_step = wall time of the call (pack, merge, "
                                  "unpack, finalize) averaged over the timed steps, this rank")
+    if args.pool_threads > 0:
+        out["config"]["call_pattern"] = {"pool_threads": args.pool_threads, "grain": args.grain,
+                                         "note": "frame_range called from pool threads with ranges of `grain` frames on one eval (VIAMD: src/main.cpp:993-997); "
+                                                 "the metric's configuration is one call per step"}
     if args.traj in ("xtc", "xtc-resident"):
         # > 0 only with --opt xtc_device_decode=N or a compressed-resident trajectory: decompressed by the k_xtc_* kernels
         out["config"]["frames_decompressed_on_device_per_step"] = ev.frames_device_decoded()
@@ -469,6 +490,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short c2 / c4 / c5 runs of the default N = 1 line")
     ap.add_argument("--opt", action="append", default=[], help="library tuning knob key=value (vmd_set_option)")
+    ap.add_argument("--pool-threads", type=int, default=0, help="evaluate a step the way VIAMD calls the boundary: this many threads pull ranges of --grain frames and call frame_range on ONE eval (0 = one call per step, the metric's configuration)")
+    ap.add_argument("--grain", type=int, default=1, help="frames per frame_range call with --pool-threads (VIAMD's create_pool_task default: 1)")
     ap.add_argument("--ck-sidecar", action="store_true", help="--traj xtc: the decoder checkpoints come from a sidecar file written by an earlier pass (vmd_ckcache_save / _load); 'first_pass' is then a first pass WITH checkpoints")
     ap.add_argument("--rigid-water", action="store_true", help="file trajectories: give the waters their real geometry before writing the file")
     ap.add_argument("--tilt", default=None, help="xy,xz,yz in Angstrom: evaluate in a sheared (triclinic) cell of the same volume")

@@ -74,3 +74,10 @@ def test_two_ranks(tmp_path, emu_lib, scaling):
         assert round(two["voxel_hits_per_s"] * two["ms_per_step"]) == round(one["voxel_hits_per_s"] * one["ms_per_step"])
     else:                          # every rank its own 6 frames
         assert two["config"]["frames_per_step"] == 12
+
+
+def test_pool_threads_call_pattern(tmp_path, emu_lib):
+    """--pool-threads / --grain: a step evaluated the way VIAMD calls the boundary gives the same line (plus `call_pattern`)."""
+    d = _run(tmp_path, emu_lib.path, 1, ["--steps", "1", "--warmup", "1", "--no-secondary", "--no-cpu-baseline", "--pool-threads", "3", "--grain", "2"])
+    assert d["config"]["call_pattern"] == {"pool_threads": 3, "grain": 2, "note": d["config"]["call_pattern"]["note"]}
+    assert d["value"] > 0 and d["pairs_per_s"] > 0
