@@ -49,7 +49,8 @@ def test_batch_of_frame_blocks_overflow_is_all_or_nothing(gpu_lib, oracle):
 
 
 def test_pool_threads_with_small_ranges_leave_the_views_of_one_call(gpu_lib, oracle):
-    cases.pool_threads_case(gpu_lib, oracle, device=True, n_water=9000, box=66.0, F=96, nthreads=12)
+    cases.pool_threads_case(gpu_lib, oracle, device=True, n_water=9000, box=66.0, F=96, nthreads=12,
+                            combos=((150, 1, 1), (150, 1, 3), (0, 1, 1), (0, 0, 2), (150, 0, 1)))
 
 
 def test_eval_life_cycles_reuse_cached_blocks_streams_and_events(gpu_lib, oracle):
