@@ -508,7 +508,7 @@ def test_device_xtc_decoder_matches_the_host_reader(tmp_path, emu_lib, chunk):
     k_xtc_wave (chunk -1: one wave per frame, speculative group walk; all here on the SIMT emulator) against the host reader on
     every fixture: the same floats bit for bit; a 68-bit packed triple is reported as unsupported (status 2), a damaged stream as
     corrupt (status 1) or decoded without leaving the frame's buffers."""
-    _device_decoder_against_host_reader(tmp_path, emu_lib, chunk, False)
+    _device_decoder_against_host_reader(tmp_path, emu_lib, chunk, False, trials=15)     # damaged streams: 15 here, 10 on the GPU, hundreds in scripts/fuzz_xtc.py
 
 
 @pytest.mark.gpu
