@@ -337,10 +337,14 @@ def run_workload(name, args, ctx, steps, warmup, frames=None, with_cpu=False, op
         dist.barrier()
     elapsed = time.perf_counter() - t0
     lib.vmd_profile_enable(False)
+    per_rank_ms = [elapsed / steps * 1e3]
     if dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        # every rank's own time travels in one SUM (its slot, zeros elsewhere); the step time of the job is the MAX over ranks
+        t = torch.zeros(world, dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        t[rank] = elapsed
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        per_rank_ms = [float(x) / steps * 1e3 for x in t.tolist()]
+        elapsed = float(t.max().item())
 
     rdf_columns = int(lib.vmd_hip_rdf_columns(1))          # candidate columns this rank's pair kernel walked in the timed region
     # after the merge every rank holds the counts of all ranks' frames
@@ -395,7 +399,8 @@ def run_workload(name, args, ctx, steps, warmup, frames=None, with_cpu=False, op
         "metric": "trajectory frames/s for RDF+SDF eval (BASELINE.json metric; atom-pairs/s in pairs_per_s)",
         "value": value, "unit": "frames/s", "n_gpus": world, "steps": steps, "warmup": warmup,
         "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": "f32", "data": "synthetic" if os.environ.get("VIAMD_BENCH_DRYRUN") != "1" else "synthetic - DRY RUN on the CPU emulator build with tiny workloads: no timing claim",
+        "per_rank_ms_per_step": per_rank_ms,
         "config": {"workload": w["desc"], "name": name, "script": w["script"], "atoms": w["atoms"],
                    "frames_per_step": frames_per_step, "frames_per_step_per_gpu": local_frames,
                    "parallelism": (f"frames block-sharded x{world} ({args.scaling} scaling), one vmd_eval_reduce (RCCL all-reduce in place on the "
@@ -476,6 +481,40 @@ def run_workload(name, args, ctx, steps, warmup, frames=None, with_cpu=False, op
     return out
 
 
+def self_launch(n):
+    """`python bench.py --gpus N ...` without a launcher around it: spawn the N ranks through torch.distributed.run on a free local
+    port (rendezvous on 127.0.0.1), same arguments, and return its exit code.  Rank 0 of the children prints the JSON line."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")              # dmabuf IPC: what RCCL needs on this driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def dryrun_setup():
+    """VIAMD_BENCH_DRYRUN=1 (tests/test_bench_dryrun.py): the same file, the same command line, on a machine without a GPU - the
+    SIMT-emulator build of the library (VIAMD_AMD_LIB), gloo instead of RCCL, and workloads of a few frames so that the emulator
+    finishes in seconds.  The line it prints says so in `data`; it carries no timing claim."""
+    import torch
+    torch.cuda.set_device = lambda *a, **k: None
+    torch.cuda.synchronize = lambda *a, **k: None
+    tiny = dict(atoms=1500, blob=0, box=40.0, frames=6, seed=2, steps=1, sec_steps=1, kernel="rdf_pencil",
+                script="g = rdf(element('O'), element('O'), 12.0);", desc="DRY RUN: tiny rdf")
+    tiny4 = dict(atoms=1501, blob=100, box=40.0, frames=6, seed=4, steps=1, sec_steps=1, kernel="sdf_scatter",
+                 script="s = residue(5:8); v = sdf(s, element('O') and water, 10.0); d = distance(residue(1), residue(3));",
+                 desc="DRY RUN: tiny sdf")
+    tiny5 = dict(tiny4, kernel="rdf_pencil", script=tiny["script"] + tiny4["script"], desc="DRY RUN: tiny rdf + sdf + distance")
+    WORKLOADS.update(c3=dict(tiny), c2=dict(tiny), c3d=dict(tiny), c4=tiny4, c5=tiny5)
+    os.environ.setdefault("VIAMD_BENCH_BACKEND", "gloo")
+    globals()["cpu_baseline"] = lambda *a, **k: {"value": 1.0, "unit": "frames/s", "cores": 1, "kind": "port", "sample": "stub (dry run)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -501,13 +540,23 @@ def main():
                          "(file -> decode on host threads -> pinned staging -> PCIe); xtc is lossy (0.01 A grid)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # the bare command `python bench.py --gpus N ...`: this process becomes the launcher of N ranks (one per GPU) and relays
+        # their single JSON line - the way VIAMD's one call fans out over all workers and completes once (src/main.cpp:993-1008)
+        raise SystemExit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N ...")
         args.gpus = world
+    dry = os.environ.get("VIAMD_BENCH_DRYRUN") == "1"
+    if dry:
+        dryrun_setup()
+    share = os.environ.get("VIAMD_BENCH_SHARE_GPU") == "1"        # all ranks on device 0, merge staged through the host (gloo): the
+    if share:                                                      # multi-process path on a 1-GPU box (RCCL refuses two ranks per GPU)
+        local_rank = 0
+        os.environ["VIAMD_BENCH_BACKEND"] = "gloo"
+        os.environ["VIAMD_AMD_STAGED_COLLECTIVE"] = "1"
 
     import torch
     import viamd_amd as V
@@ -548,6 +597,25 @@ def main():
                                     "achieved": rf["achieved"], "peak": rf["peak"], "unit": rf["unit"], "frac": rf["frac"],
                                     "frames_per_launch": rf["frames_per_launch"], "traffic": rf["traffic"],
                                     "step_level": rf["step_level"], "valu": rf["valu"]}}
+        out["secondary"] = sec
+    if world > 1 and not args.no_secondary and args.workload == "c3" and args.traj == "device" and not args.frames and args.scaling == "weak":
+        # the two configurations BASELINE.json quotes on 8 GPUs, STRONG scaling (the named trajectory block-sharded over the ranks,
+        # one merge per step), short runs next to the weak-scaling c3 curve.  Every rank takes the same decisions here (a failure is
+        # caught on all ranks alike or the job dies as one), so the primary line is printed in any case.
+        import copy
+        sec = {}
+        for nm in ("c4", "c5"):
+            a2 = copy.copy(args)
+            a2.scaling = "strong"
+            try:
+                r = run_workload(nm, a2, ctx, WORKLOADS[nm]["sec_steps"], 1, opts=args.opt)
+                sec[nm + "_strong"] = {"workload": r["config"]["workload"], "scaling": "strong", "value": r["value"], "unit": "frames/s",
+                                       "n_gpus": world, "steps": r["steps"], "warmup": r["warmup"], "ms_per_step": r["ms_per_step"],
+                                       "per_rank_ms_per_step": r["per_rank_ms_per_step"], "frames_per_step": r["config"]["frames_per_step"],
+                                       "frames_per_step_per_gpu": r["config"]["frames_per_step_per_gpu"], "pairs_per_s": r["pairs_per_s"],
+                                       "voxel_hits_per_s": r["voxel_hits_per_s"], "merge": r.get("merge")}
+            except Exception as e:          # noqa: BLE001
+                sec[nm + "_strong"] = {"error": repr(e)}
         out["secondary"] = sec
     if rank == 0:
         print(json.dumps(out))

@@ -10,39 +10,45 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-DRIVER = r'''
-import os, sys, json
-sys.path.insert(0, {root!r})
-import torch
-torch.cuda.set_device = lambda *a, **k: None
-torch.cuda.synchronize = lambda *a, **k: None
-import bench
-tiny = dict(atoms=1500, blob=0, box=40.0, frames=6, seed=2, steps=1, sec_steps=1, kernel="rdf_pencil",
-            script="g = rdf(element('O'), element('O'), 12.0);", desc="tiny rdf")
-tiny4 = dict(atoms=1501, blob=100, box=40.0, frames=6, seed=4, steps=1, sec_steps=1, kernel="sdf_scatter",
-             script="s = residue(5:8); v = sdf(s, element('O') and water, 10.0); d = distance(residue(1), residue(3));", desc="tiny sdf")
-bench.WORKLOADS.update(c3=dict(tiny), c2=dict(tiny), c4=tiny4, c5=dict(tiny))
-bench.cpu_baseline = lambda *a, **k: {{"value": 1.0, "unit": "frames/s", "cores": 1, "kind": "port", "sample": "stub"}}
-sys.argv = ["bench.py"] + sys.argv[1:]
-bench.main()
-'''
+BENCH = os.path.join(ROOT, "bench.py")
 
 
-def _run(tmp_path, emu, nproc, extra):
-    drv = tmp_path / "drv.py"
-    drv.write_text(DRIVER.format(root=ROOT))
-    env = dict(os.environ, VIAMD_AMD_LIB=emu, VIAMD_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
-    if nproc == 1:
-        cmd = [sys.executable, str(drv)] + extra
-    else:
+def _run(tmp_path, emu, nproc, extra, launcher=False):
+    """Runs LITERALLY `python3 bench.py --gpus N ...` (the driver's command; bench.py spawns its own ranks when N > 1) with
+    VIAMD_BENCH_DRYRUN=1: emulator library, gloo, workloads of six frames.  launcher=True wraps it in torch.distributed.run instead,
+    the other way the brief says the driver may start it."""
+    env = dict(os.environ, VIAMD_AMD_LIB=emu, VIAMD_BENCH_DRYRUN="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    if launcher:
         port = 29700 + (os.getpid() % 200)
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
-               "--master-port", str(port), str(drv), "--gpus", str(nproc)] + extra
+               "--master-port", str(port), BENCH, "--gpus", str(nproc)] + extra
+    else:
+        cmd = ["python3", BENCH] + (["--gpus", str(nproc)] if nproc > 1 else []) + extra
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=str(tmp_path))
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.split("\n") if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]           # rank 0 prints ONE JSON line
     return json.loads(lines[0])
+
+
+def test_bare_command_launches_its_own_ranks(tmp_path, emu_lib):
+    """VERDICT r03 #1: `python3 bench.py --gpus 2 --steps 2 --warmup 1` with WORLD_SIZE unset must produce the N = 2 line."""
+    d = _run(tmp_path, emu_lib.path, 2, ["--steps", "2", "--warmup", "1"])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak" and d["config"]["name"] == "c3"
+    assert d["merge"]["rccl_ranks"] == 2 and d["merge"]["collective"] and len(d["per_rank_ms_per_step"]) == 2
+    assert abs(max(d["per_rank_ms_per_step"]) - d["ms_per_step"]) < 1e-6 * max(1.0, d["ms_per_step"])
+    assert d["config"]["frames_per_step"] == 12 and "DRY RUN" in d["data"]
+    # the 8-GPU configurations of BASELINE.json ride along as strong-scaling lines
+    s4, s5 = d["secondary"]["c4_strong"], d["secondary"]["c5_strong"]
+    assert s4["scaling"] == "strong" and s4["frames_per_step"] == 6 and s4["frames_per_step_per_gpu"] == 3 and s4["voxel_hits_per_s"] > 0
+    assert s5["pairs_per_s"] > 0 and s5["voxel_hits_per_s"] > 0 and s5["merge"]["rccl_ranks"] == 2
+
+
+def test_under_the_launcher(tmp_path, emu_lib):
+    d = _run(tmp_path, emu_lib.path, 2, ["--steps", "1", "--warmup", "0", "--no-secondary"], launcher=True)
+    assert d["n_gpus"] == 2 and d["merge"]["rccl_ranks"] == 2 and "secondary" not in d
 
 
 def test_default_line_has_the_contract_fields(tmp_path, emu_lib):

@@ -73,7 +73,8 @@ class TorchCollective:
     def __init__(self, group=None, device=False):
         import torch
         import torch.distributed as dist
-        self.kind = "torch.distributed (" + dist.get_backend(group) + ")"
+        staged = device and dist.get_backend(group) != "nccl"
+        self.kind = "torch.distributed (" + dist.get_backend(group) + (", device buffers staged through host memory)" if staged else ")")
 
         class _Dev:
             def __init__(self, ptr, n, typestr):
@@ -82,7 +83,15 @@ class TorchCollective:
         def allreduce(ptr, n, ctype, view, typestr):
             if n == 0:
                 return True
-            if device:
+            if device and staged:
+                # device memory, host collective (gloo): D2H, all-reduce, H2D - several processes on ONE GPU, where RCCL refuses
+                torch.cuda.synchronize()
+                t = torch.as_tensor(_Dev(ptr, n, typestr), device="cuda")
+                h = t.cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+                t.copy_(h)
+                torch.cuda.synchronize()
+            elif device:
                 torch.cuda.synchronize()
                 t = torch.as_tensor(_Dev(ptr, n, typestr), device="cuda")
                 dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
@@ -120,7 +129,9 @@ def _make_comm(lib, group):
     import torch.distributed as dist
     on_gpu = dist.get_backend(group) == "nccl"
     if not on_gpu:
-        return TorchCollective(group)
+        # gloo: the emulator build (its "device" memory is host memory) - or, VIAMD_AMD_STAGED_COLLECTIVE=1, real device memory
+        # staged through the host (several ranks sharing one GPU: tests/test_zz_late_gpu.py, bench.py VIAMD_BENCH_SHARE_GPU=1)
+        return TorchCollective(group, device=os.environ.get("VIAMD_AMD_STAGED_COLLECTIVE") == "1")
     want = os.environ.get("VIAMD_AMD_COLLECTIVE", "").lower()
     comm, why = None, ""
     if want != "torch":
