@@ -9,7 +9,7 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, tmpdir, mode="host"):
+def _worker(rank, world, port, tmpdir, mode="host", on_gpu=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch.distributed as dist
@@ -23,7 +23,17 @@ def _worker(rank, world, port, tmpdir, mode="host"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    lib = V.VmdLib(conftest.EMU_LIB)
+    if on_gpu:
+        # real device memory, real kernels, every process on GPU 0; the merge's all-reduces are staged through host memory (gloo)
+        # because RCCL refuses two ranks on one device.  torch first: its HIP runtime must be the one that finds the GPU (conftest.gpu_lib)
+        import torch
+        torch.cuda.set_device(0)
+        os.environ["VIAMD_AMD_STAGED_COLLECTIVE"] = "1"
+        lib = V.default_lib()
+        assert lib.vmd_device_count() > 0
+        lib.vmd_set_device(0)
+    else:
+        lib = V.VmdLib(conftest.EMU_LIB)
     F = 5
     coords, structures, mass = cases.sdf_system(O, 21, 900, 36.0, F)
     N = coords.shape[2]
@@ -43,6 +53,7 @@ def _worker(rank, world, port, tmpdir, mode="host"):
         # one rank's shard of a device-resident trajectory: global frame indices, only [beg, end) (+ frame 0: SDF reference
         # pose) resident; frames outside the shard must be refused
         traj = V.DeviceTrajectory(F, N, lib=lib, shard=(beg, end))
+        assert not on_gpu or bool(traj.device_ptr()[0])
         for f in sorted(set(range(beg, end)) | {0}):
             traj.upload_frame(f, vcell, coords[f, 0], coords[f, 1], coords[f, 2])
         if rank == world - 1:       # world 4: the EMPTY shard [5, 5) - nothing is resident there, it is not "the whole trajectory"
@@ -101,3 +112,30 @@ def test_two_rank_gloo_merge_matches_oracle(oracle, emu_lib, tmp_path, mode, wor
         np.testing.assert_array_equal(z["v"], vol)
         np.testing.assert_array_equal(z["d"].reshape(F, -1), d)
         np.testing.assert_array_equal(z["dp"].reshape(F, -1), dp)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+def test_processes_sharing_one_gpu_merge_matches_oracle(oracle, gpu_lib, tmp_path, world):
+    """VERDICT r03 #5 / SURVEY 8e on the hardware there is: `world` PROCESSES on GPU 0, each holding only its shard of a device
+    trajectory (vmd_devtraj_create_shard) and running the real kernels on it, ONE vmd_eval_reduce per rank whose collective is a
+    host-staged vmd_collective_i (D2H, gloo all-reduce, H2D).  Covers shard residency, per-process device state and the merge's
+    pack / narrow / unpack on real device memory; the RCCL transport itself needs one GPU per rank (driver's SCALE run)."""
+    import cases
+    from viamd_amd import _lib as L
+    port = 31500 + (os.getpid() % 2000) + world
+    mp.spawn(_worker, args=(world, port, str(tmp_path), "shard", True), nprocs=world, join=True)
+    F = 5
+    coords, structures, mass = cases.sdf_system(oracle, 21, 900, 36.0, F)
+    N = coords.shape[2]
+    o = np.arange(structures.size, N, 3, dtype=np.int32)
+    ocell = oracle.make_cell(36.0)
+    counts, weights = cases.oracle_rdf(oracle, coords, ocell, o, o, 0.0, 12.0)
+    vol, _ = cases.oracle_sdf(oracle, coords, ocell, structures, mass, o, 8.0)
+    d = cases.oracle_distance(oracle, coords, ocell, mass, structures[0], structures[1], L.DIST_COM)
+    for r in range(world):
+        z = np.load(tmp_path / f"rank{r}.npz")
+        np.testing.assert_array_equal(z["goo"], counts)
+        np.testing.assert_allclose(z["w"], weights, rtol=1e-12)
+        np.testing.assert_array_equal(z["v"], vol)
+        np.testing.assert_array_equal(z["d"].reshape(F, -1), d)

@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <climits>
 #include <chrono>
 #include <unistd.h>
 #include <cmath>
@@ -727,9 +728,13 @@ static size_t record_stride_for(size_t frames, size_t atoms, int level = 1) {
     return (frames && stride * 2 <= budget / frames) ? stride : 0;
 }
 static std::mutex g_ck_mtx;
-static std::map<const void*, std::shared_ptr<CkCache>> g_ck_store;
-static std::shared_ptr<CkCache> ckcache_for(const void* inst, size_t frames, size_t atoms, int device) {
+// keyed by (trajectory instance, device): two devices decoding the same file keep a table each instead of replacing each other's on
+// every batch; stages with a decode in flight hold their own reference (Stage::ck_hold), so an eviction never frees what they point into
+typedef std::pair<const void*, int> CkKey;
+static std::map<CkKey, std::shared_ptr<CkCache>> g_ck_store;
+static std::shared_ptr<CkCache> ckcache_for(const void* inst_, size_t frames, size_t atoms, int device) {
     std::lock_guard<std::mutex> l(g_ck_mtx);
+    const CkKey inst(inst_, device);
     std::shared_ptr<CkCache>& c = g_ck_store[inst];
     if (!c || c->frames != frames || c->atoms != atoms || c->device != device) {
         c = std::make_shared<CkCache>();
@@ -747,7 +752,7 @@ static std::shared_ptr<CkCache> ckcache_for(const void* inst, size_t frames, siz
 }
 extern "C" void vmd_ckcache_drop(const void* inst) {
     std::lock_guard<std::mutex> l(g_ck_mtx);
-    g_ck_store.erase(inst);
+    for (auto it = g_ck_store.lower_bound(CkKey(inst, INT_MIN)); it != g_ck_store.end() && it->first.first == inst;) it = g_ck_store.erase(it);
 }
 
 // ---- checkpoint sidecar.  A first pass over an XTC file walks every bit stream from its first bit (29k c2 frames/s against 84k once
@@ -766,8 +771,8 @@ extern "C" bool vmd_ckcache_save(const vmd_trajectory_i* traj, const char* path)
     if (!traj || !path) return vmd_fail("vmd_ckcache_save: NULL argument");
     std::shared_ptr<CkCache> c;
     { std::lock_guard<std::mutex> l(g_ck_mtx);
-      auto it = g_ck_store.find(traj->inst);
-      if (it != g_ck_store.end()) c = it->second; }
+      auto it = g_ck_store.lower_bound(CkKey(traj->inst, INT_MIN));       // whichever device decoded it: the table describes the file
+      if (it != g_ck_store.end() && it->first.first == traj->inst) c = it->second; }
     if (!c || c->frames == 0) return vmd_fail("vmd_ckcache_save: no decoder checkpoints exist for this trajectory (nothing of it was decoded on the device yet)");
     int prev = 0;
     HIP_OK(hipGetDevice(&prev));
@@ -947,6 +952,7 @@ struct vmd_script_eval_t {
         bool* rec_failed = nullptr;              // that decode placed its groups from records: where to note that they were rejected
         uint8_t* ck_mark = nullptr;              // that decode also writes the frames' checkpoints: mark them valid (ck_mark[0 .. nb)) when it succeeded
         uint8_t* ck_clear = nullptr;             // that decode entered the frames at their checkpoints: forget them (ck_clear[0 .. nb)) when it was rejected
+        std::shared_ptr<CkCache> ck_hold;        // the table those three point into, for as long as the decode is pending
         DevBuf<float> d_boxes;
         std::vector<float> h_boxes;              // [nb][6]: L, 1/L
         std::vector<vmd_unitcell_t> cells;
@@ -1956,6 +1962,7 @@ static bool fetch_stage(vmd_script_eval_t* e, Stage& st, vmd_trajectory_i* traj,
                 } else {
                 std::shared_ptr<CkCache> cc = ckcache_for(traj->inst, traj->num_frames(traj->inst), num_atoms, e->device);
                 e->ck_cache = cc;
+                st.ck_hold = cc;
                 if (cc) {
                     // a frame's checkpoints count only for the very bytes they were written for
                     for (size_t b = 0; b < nb; ++b) {
@@ -2053,6 +2060,7 @@ static bool settle_stage(vmd_script_eval_t* e, Stage& st, vmd_trajectory_i* traj
     HIP_OK(hipEventSynchronize(st.ready));
     e->prof_copy.resolve();
     st.raw_pending = false;
+    std::shared_ptr<CkCache> hold = std::move(st.ck_hold);      // released when this function is done with ck_mark / ck_clear / rec_failed
     bool good = true;
     for (size_t b = 0; b < st.nb; ++b) if (st.h_raw_status[b] != 0) good = false;
     if (good) {
@@ -2442,7 +2450,7 @@ static bool process_range(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
         if (!f32_ring && device_decode && g_opt.xtc_checkpoints.load() && frame_beg < frame_end) {
             if (raw_ring) {
                 std::lock_guard<std::mutex> l(g_ck_mtx);
-                auto it = g_ck_store.find(traj->inst);
+                auto it = g_ck_store.find(CkKey(traj->inst, e->device));
                 warm = it != g_ck_store.end() && it->second && it->second->frames == traj->num_frames(traj->inst) && it->second->atoms == num_atoms &&
                        it->second->device == e->device && it->second->have.size() > frame_beg && it->second->have[frame_beg];
             }
@@ -2900,13 +2908,19 @@ extern "C" bool vmd_eval_frame_range(vmd_script_eval_t* eval, const vmd_script_i
         bool all_ok = true;
         const auto round_t0 = std::chrono::steady_clock::now();
         // requests for the same trajectory, sorted by first frame; touching ranges fuse into one run
+        // "the same trajectory" = the same instance behind the same callbacks, not the same interface STRUCT: a host that wraps its own
+        // trajectory type per call (include/vmd_md_script_shim.h did, from every pool thread) presents a different address each time
+        // (such ranges never fused)
+        auto same_traj = [](const vmd_trajectory_i* a, const vmd_trajectory_i* b) {
+            return a == b || (a->inst == b->inst && a->load_frame == b->load_frame && a->device_view == b->device_view && a->load_raw == b->load_raw);
+        };
         std::sort(taken.begin(), taken.end(), [](const RangeRequest* a, const RangeRequest* b) {
-            return a->traj != b->traj ? a->traj < b->traj : a->beg < b->beg; });
+            return a->traj->inst != b->traj->inst ? a->traj->inst < b->traj->inst : a->beg < b->beg; });
         size_t i = 0;
         while (i < taken.size()) {
             size_t j = i + 1;
             uint32_t run_end = taken[i]->end;
-            while (j < taken.size() && taken[j]->traj == taken[i]->traj && taken[j]->beg == run_end) { run_end = taken[j]->end; ++j; }
+            while (j < taken.size() && same_traj(taken[j]->traj, taken[i]->traj) && taken[j]->beg == run_end) { run_end = taken[j]->end; ++j; }
             const bool ok = process_range(eval, taken[i]->sys, taken[i]->traj, taken[i]->beg, run_end, !lazy);
             const std::string err = ok ? std::string() : g_last_error;
             for (size_t k = i; k < j; ++k) { taken[k]->ok = ok; taken[k]->error = err; }

@@ -236,7 +236,7 @@ struct vmd_binning_t {
     int closed;                        // DECISION(D-RDF-OPEN) flipped: hit iff r_min <= d <= r_max.  Only vmd_bin_of looks at it: the fast path is
                                        // never trusted within delta of a bin edge, and d = r_min / r_max sit exactly on one
 };
-static int g_rdf_closed = 0;
+static thread_local int g_rdf_closed = 0;       // per host thread: set from the eval's spec right before that thread's launches (two evals with different specs on two threads must not race)
 extern "C" int vmd_hip_set_rdf_closed(int on) { const int old = g_rdf_closed; g_rdf_closed = on ? 1 : 0; return old; }
 __host__ __device__ inline vmd_binning_t vmd_make_binning(float rmin, float rmax, int nbins, int closed = 0) {
     vmd_binning_t b;

@@ -185,8 +185,19 @@ __global__ void k_widen_u32(const uint32_t* __restrict__ src, uint64_t* __restri
 // merges on one device take turns (the buffer used to be thread_local - leaked per thread - and lived on whatever
 // device the caller had current)
 struct Scratch { void* p = nullptr; size_t cap = 0; };
-std::mutex g_scratch_mtx;
-Scratch g_scratch[64];
+std::mutex g_scratch_mtx[64];                   // per DEVICE: a host that drives several ranks from threads of one process (one GPU each)
+Scratch g_scratch[64];                          // must not serialise them - rank A would wait in the collective for a rank B that waits for A's lock
+// the caller's current device comes back on every exit path; the timing events are destroyed on every exit path
+struct DeviceScope {
+    int prev = -1;
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    DeviceScope() { if (hipGetDevice(&prev) != hipSuccess) { (void)hipGetLastError(); prev = -1; } }
+    ~DeviceScope() {
+        if (t0) (void)hipEventDestroy(t0);
+        if (t1) (void)hipEventDestroy(t1);
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
 struct EvalLock {
     vmd_script_eval_t* e;
     explicit EvalLock(vmd_script_eval_t* ev) : e(ev) { vmd_eval_internal_lock(e, 1); }
@@ -197,11 +208,14 @@ struct EvalLock {
 extern "C" bool vmd_eval_reduce(vmd_script_eval_t* eval, const vmd_collective_i* coll, void* stream) {
     if (!eval) return red_fail("vmd_eval_reduce: eval is NULL");
     if (!coll || !coll->allreduce_sum_u64 || !coll->allreduce_sum_f64) return red_fail("vmd_eval_reduce: incomplete collective interface");
-    hipEvent_t t0 = nullptr, t1 = nullptr;
+    DeviceScope scope;
+    hipEvent_t& t0 = scope.t0;
+    hipEvent_t& t1 = scope.t1;
     const int dev = vmd_eval_internal_device(eval);
     if (dev < 0 || dev >= 64 || hipSetDevice(dev) != hipSuccess) return red_fail("vmd_eval_reduce: cannot select the evaluator's device");
     hipStream_t s = (hipStream_t)stream;
     (void)hipEventCreate(&t0); (void)hipEventCreate(&t1);
+    const int world = coll->size ? coll->size(coll->inst) : 1;
     if (t0) (void)hipEventRecord(t0, s);
     const size_t nviews = vmd_eval_accum_views(eval, nullptr, 0);
     std::vector<vmd_accum_view_t> views(nviews);
@@ -218,7 +232,11 @@ extern "C" bool vmd_eval_reduce(vmd_script_eval_t* eval, const vmd_collective_i*
     for (size_t i = 0; i < nviews; ++i) {
         const vmd_accum_view_t& v = views[i];
         n_f64 += (v.weights64 ? v.num_weights : 0) + (v.temporal ? v.num_temporal : 0);
-        if (coll->allreduce_sum_u32 && v.counts_dev && v.num_counts >= 65536 && v.count_bound != 0 && v.count_bound <= 0xffffffffull) {
+        // count_bound assumes every frame is merged once; the frame mask also tolerates ranks that evaluated the same frames, which can
+        // multiply a voxel by up to the rank count: the narrowed path must hold that too.  Every rank computes the same bound from the
+        // same script and frame count, so all ranks decide alike.
+        if (coll->allreduce_sum_u32 && v.counts_dev && v.num_counts >= 65536 && v.count_bound != 0 && world > 0 &&
+            v.count_bound <= 0xffffffffull / (uint64_t)world) {
             narrow[i] = 1;
             n_u32 += (v.num_counts + 1) & ~(size_t)1;               // keep the fp64 part behind it 8-byte aligned
         }
@@ -234,7 +252,7 @@ extern "C" bool vmd_eval_reduce(vmd_script_eval_t* eval, const vmd_collective_i*
         const uint8_t* mask = vmd_eval_frame_mask(eval);
         for (size_t f = 0; f < F; ++f) packed[off + f] = mask[f] ? 1.0 : 0.0;
     }
-    std::lock_guard<std::mutex> scratch_lock(g_scratch_mtx);
+    std::lock_guard<std::mutex> scratch_lock(g_scratch_mtx[dev]);
     Scratch& sc = g_scratch[dev];
     const size_t need = n_u32 * sizeof(uint32_t) + n_f64 * sizeof(double);
     if (sc.cap < need) {
@@ -310,8 +328,6 @@ extern "C" bool vmd_eval_reduce(vmd_script_eval_t* eval, const vmd_collective_i*
     vmd_eval_set_frame_mask(eval, merged.data(), F);
     float ms = 0.0f;
     if (t0 && t1 && hipEventElapsedTime(&ms, t0, t1) == hipSuccess) st.ms = ms;
-    if (t0) (void)hipEventDestroy(t0);
-    if (t1) (void)hipEventDestroy(t1);
     if (vmd_reduce_stats_t* dst = vmd_eval_internal_reduce_stats(eval)) *dst = st;
     return vmd_eval_finalize(eval);
 }
