@@ -287,6 +287,140 @@ def pool_threads_case(lib, O, device=False, n_water=900, box=32.0, F=12, nthread
             lib.vmd_set_option(b"gather_us", old[0]); lib.vmd_set_option(b"lazy_views", old[1])
 
 
+def readahead_case(lib, O, device=False, n_water=600, box=28.0, F=40, nthreads=6):
+    """VIAMD's call pattern served by read-ahead: pool threads call frame_range with one frame or a few
+    on ONE eval; the first of them evaluates a whole region of frame blocks ahead, the others only mark their frames requested, a block
+    joins the totals when all of it has been asked for, and whoever returns last settles the eval.  Whatever the threads, grains and
+    ranges: when the last call has returned, every view is bit for bit what ONE call over the same range leaves - a filtered range that
+    ends inside a block counts nothing beyond its end, an interrupted evaluation restarts clean, a lone caller and a large range are
+    served directly, blocks set by the caller (filtered evaluation) are the blocks read-ahead uses."""
+    import threading
+    coords, structures, mass = sdf_system(O, 13, n_water, box, F)
+    n_s, N = structures.size, coords.shape[2]
+    ocell, vcell = cell_pair(O, box)
+    ox = np.arange(n_s, N, 3, dtype=np.int32)
+    ir = V.ScriptIR(lib)
+    ir.add_rdf("g", ox, ox, (0.0, 9.0)); ir.add_sdf("v", structures, ox, 7.0); ir.add_distance("d", structures[0], structures[1], L.DIST_MIN)
+    traj = make_traj(lib, coords, vcell, device)
+    sysm = V.MolSystem(N, mass=mass, unitcell=vcell)
+    names = ("g", "v", "d")
+
+    def reference(beg, end):
+        one = V.ScriptEval(F, ir)
+        old = lib.vmd_set_option(b"readahead", 0)
+        try:
+            assert one.frame_range(sysm, traj, beg, end)
+        finally:
+            lib.vmd_set_option(b"readahead", old)
+        out = {n: one.property_data(n) for n in names}
+        out["mask"] = one.frame_mask().copy()
+        out["_keep"] = one
+        return out
+
+    def same(ev, want, what):
+        assert ev.frames_done() == int(want["mask"].sum()), what
+        np.testing.assert_array_equal(ev.frame_mask(), want["mask"], err_msg=what)
+        for n in names:
+            got = ev.property_data(n)
+            np.testing.assert_array_equal(got.values, want[n].values, err_msg=f"{n} values: {what}")
+            assert got.max_value == want[n].max_value and got.min_value == want[n].min_value, (n, what)
+            assert tuple(got.min_range) == tuple(want[n].min_range) and tuple(got.max_range) == tuple(want[n].max_range), (n, what)
+        np.testing.assert_array_equal(ev.property_data("g").weights, want["g"].weights, err_msg=what)
+        np.testing.assert_array_equal(ev.property_data("g").counts, want["g"].counts, err_msg=what)
+        np.testing.assert_array_equal(ev.property_data("v").counts, want["v"].counts, err_msg=what)
+
+    def pooled(ev, beg, end, grain, nth=nthreads, stop_at=None, order=None):
+        starts = list(range(beg, end, grain)) if order is None else order
+        nxt = [0]; lock = threading.Lock(); res = []
+        gate = threading.Barrier(nth)
+        def work():
+            gate.wait()
+            while True:
+                with lock:
+                    k = nxt[0]; nxt[0] += 1
+                if k >= len(starts):
+                    return
+                b = starts[k]
+                if stop_at is not None and b >= stop_at:
+                    ev.interrupt()
+                res.append(ev.frame_range(sysm, traj, b, min(end, b + grain)))
+        ths = [threading.Thread(target=work) for _ in range(nth)]
+        [t.start() for t in ths]; [t.join() for t in ths]
+        return res
+
+    full = reference(0, F)
+    counts, _ = oracle_rdf(O, coords, ocell, ox, ox, 0.0, 9.0)
+    np.testing.assert_array_equal(full["g"].counts, counts)
+    part = reference(7, 29)
+    old = [(k, lib.vmd_set_option(k, v)) for k, v in ((b"readahead_block", 4), (b"readahead_frames", 8), (b"readahead_growth", 2),
+                                                      (b"readahead_company_us", 200000), (b"readahead", 1))]
+    try:
+        # ---- the whole range, grain 1 and a grain that straddles blocks
+        for grain in (1, 3):
+            ev = V.ScriptEval(F, ir)
+            assert all(pooled(ev, 0, F, grain))
+            same(ev, full, f"pool of {nthreads}, grain {grain}")
+            st = ev.readahead_stats()
+            assert st["engaged"] == 1 and st["block_frames"] == 4 and st["regions"] >= 2 and st["committed_blocks"] + st["direct_frames"] // 4 >= 1, st
+            assert st["committed_blocks"] * 4 + st["direct_frames"] == F, st            # every frame counted exactly once, one way or the other
+            assert st["fast_calls"] + st["slow_calls"] > 0 and st["settles"] >= 1, st
+            # again on the same eval (VIAMD: clear_data, re-evaluate - src/main.cpp:990-996), frames handed out from the far end
+            ev.clear_data()
+            assert all(pooled(ev, 0, F, grain, order=list(range(0, F, grain))[::-1]))
+            same(ev, full, f"pool of {nthreads}, grain {grain}, descending")
+            ev.close()
+        # ---- a sub-range that starts and ends inside blocks (VIAMD's filtered evaluation, src/main.cpp:1014-1039): nothing beyond it is counted
+        ev = V.ScriptEval(F, ir)
+        assert all(pooled(ev, 7, 29, 1))
+        same(ev, part, "sub-range [7, 29), grain 1")
+        st = ev.readahead_stats()
+        assert st["direct_frames"] >= 2 and st["region_frames"] >= 22, st     # frames 7 and 28 sit in blocks nobody else asked for
+        # ... the rest of the trajectory afterwards, in one large call: 0..6 and 29..39 once each
+        assert ev.frame_range(sysm, traj, 0, 7) and ev.frame_range(sysm, traj, 29, F)
+        same(ev, full, "sub-range, then the rest in two direct calls")
+        ev.close()
+        # ---- interrupted half way, restarted (src/main.cpp:984-990)
+        ev = V.ScriptEval(F, ir)
+        pooled(ev, 0, F, 1, stop_at=F // 2)
+        assert ev.frames_done() <= F
+        ev.clear_data()
+        assert all(pooled(ev, 0, F, 1))
+        same(ev, full, "after interrupt + clear_data")
+        ev.close()
+        # ---- one caller, frame by frame: every call is the last one, read-ahead must stay out of the way
+        lib.vmd_set_option(b"readahead_company_us", 50)
+        ev = V.ScriptEval(F, ir)
+        for f in range(7, 29):
+            assert ev.frame_range(sysm, traj, f, f + 1)
+            assert ev.frames_done() == f + 1 - 7                      # final after EVERY call
+        same(ev, part, "single caller, grain 1")
+        assert ev.readahead_stats()["regions"] == 0
+        ev.close()
+        lib.vmd_set_option(b"readahead_company_us", 200000)
+        # ---- small calls first, then a large range over evaluated-ahead but never requested blocks
+        ev = V.ScriptEval(F, ir)
+        assert all(pooled(ev, 0, 10, 1))
+        assert ev.frames_done() == 10
+        assert ev.frame_range(sysm, traj, 10, F)
+        same(ev, full, "pool over [0, 10), one call over [10, F)")
+        ev.close()
+        # ---- the caller's own frame blocks (filtered evaluation): read-ahead evaluates into THOSE, and a filtered eval reuses them
+        ev = V.ScriptEval(F, ir)
+        ev.set_block_frames(5)
+        assert all(pooled(ev, 0, F, 1))
+        same(ev, full, "caller-set blocks of 5")
+        assert ev.readahead_stats()["block_frames"] == 5
+        filt = V.ScriptEval(F, ir)
+        filt.set_source(ev)
+        assert filt.frame_range(sysm, traj, 7, 29)
+        same(filt, part, "filtered eval served from blocks that read-ahead computed")
+        assert filt.frame_stats()[1] >= 15                         # blocks [10, 25) at least came from the partials
+        filt.close(); ev.close()
+    finally:
+        for k, v in old:
+            lib.vmd_set_option(k, v)
+
+
 def resource_cache_case(lib, O, device=False, n_water=1500, box=38.0):
     """VIAMD creates an eval per script edit and frees the old one: the blocks, streams and events an eval gives up are cached
     process-wide and reused by the next.  Many life cycles give the oracle's integers every time, the cache stops growing after the

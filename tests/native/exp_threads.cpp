@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <string>
 #include <thread>
 #include <vector>
@@ -46,6 +47,7 @@ int main(int argc, char** argv) {
     vmd_script_eval_t* eval = vmd_eval_create(F, ir);
     vmd_system_t sys = {};
     sys.atom_count = N;
+    std::vector<float> ref_values;
     auto one = [&]() {
         vmd_eval_clear_data(eval);
         const double t = now_ms();
@@ -68,9 +70,15 @@ int main(int argc, char** argv) {
         for (auto& th : pool) th.join();
         const double ms = now_ms() - t;
         if (vmd_eval_frames_done(eval) != F) { std::fprintf(stderr, "frames missing\n"); std::exit(1); }
+        // the integers of the pooled evaluation are the integers of the one call (RDF bins; an SDF volume is compared through its float view)
+        const vmd_script_property_data_t* pd = vmd_eval_property_data(eval, sdf ? "v" : "g");
+        if (ref_values.size() == pd->num_values && memcmp(ref_values.data(), pd->values, pd->num_values * sizeof(float)) != 0) {
+            std::fprintf(stderr, "pooled evaluation (%d threads, grain %u) differs from the one call\n", nthreads, grain); std::exit(1);
+        }
         return ms;
     };
     one();
+    { const vmd_script_property_data_t* pd = vmd_eval_property_data(eval, sdf ? "v" : "g"); ref_values.assign(pd->values, pd->values + pd->num_values); }
     double best = 1e30;
     for (int r = 0; r < 3; ++r) best = std::min(best, one());
     std::printf("%s atoms %zu frames %zu: one call %.2f ms", sdf ? "sdf" : "rdf", N, F, best);
@@ -81,6 +89,11 @@ int main(int argc, char** argv) {
         std::printf(" | %d threads grain %d: %.2f ms", c[0], c[1], b);
     }
     std::printf("\n");
+    vmd_readahead_stats_t st;
+    vmd_eval_readahead_stats(eval, &st);
+    std::printf("  read-ahead over all pooled runs: engaged %u, blocks of %u frames, %llu regions (%llu frames), %llu calls marked only, %llu waited, %llu settles, %llu frames evaluated directly, %llu blocks committed\n",
+                st.engaged, st.block_frames, (unsigned long long)st.regions, (unsigned long long)st.region_frames, (unsigned long long)st.fast_calls, (unsigned long long)st.slow_calls,
+                (unsigned long long)st.settles, (unsigned long long)st.direct_frames, (unsigned long long)st.committed_blocks);
     vmd_eval_free(eval); vmd_ir_free(ir); vmd_devtraj_free(dt);
     return 0;
 }

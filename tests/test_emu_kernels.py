@@ -55,6 +55,10 @@ def test_pool_threads_with_small_ranges_leave_the_views_of_one_call(emu_lib, ora
     cases.pool_threads_case(emu_lib, oracle)
 
 
+def test_pool_calls_are_served_by_read_ahead(emu_lib, oracle):
+    cases.readahead_case(emu_lib, oracle)
+
+
 def test_eval_life_cycles_reuse_cached_blocks_streams_and_events(emu_lib, oracle):
     cases.resource_cache_case(emu_lib, oracle)
 

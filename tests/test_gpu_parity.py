@@ -48,6 +48,10 @@ def test_batch_of_frame_blocks_overflow_is_all_or_nothing(gpu_lib, oracle):
     cases.blocks_overflow_case(gpu_lib, oracle, device=True, n=30000, box=80.0)
 
 
+def test_pool_calls_are_served_by_read_ahead(gpu_lib, oracle):
+    cases.readahead_case(gpu_lib, oracle, device=True, n_water=6000, box=58.0, F=160, nthreads=12)
+
+
 def test_pool_threads_with_small_ranges_leave_the_views_of_one_call(gpu_lib, oracle):
     cases.pool_threads_case(gpu_lib, oracle, device=True, n_water=9000, box=66.0, F=96, nthreads=12,
                             combos=((150, 1, 1), (150, 1, 3), (0, 1, 1), (0, 0, 2), (150, 0, 1)))

@@ -112,6 +112,12 @@ class ReduceStats(C.Structure):          # vmd_reduce_stats_t
     _fields_ = [("bytes", C.c_uint64), ("calls", C.c_uint32), ("grouped", C.c_uint32), ("volumes_as_u32", C.c_uint32), ("ms", C.c_double)]
 
 
+class ReadAheadStats(C.Structure):      # vmd_readahead_stats_t
+    _fields_ = [("engaged", C.c_uint32), ("block_frames", C.c_uint32), ("regions", C.c_uint64), ("region_frames", C.c_uint64),
+                ("fast_calls", C.c_uint64), ("slow_calls", C.c_uint64), ("settles", C.c_uint64), ("direct_frames", C.c_uint64),
+                ("committed_blocks", C.c_uint64)]
+
+
 COMM_ID_BYTES = 128
 
 
@@ -175,6 +181,7 @@ SIGNATURES = [
     ("vmd_eval_set_block_frames", C.c_bool, [_vp, C.c_size_t]),
     ("vmd_eval_set_source", C.c_bool, [_vp, _vp]),
     ("vmd_eval_frame_stats", None, [_vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    ("vmd_eval_readahead_stats", None, [_vp, C.POINTER(ReadAheadStats)]),
     ("vmd_eval_frames_device_decoded", C.c_size_t, [_vp]),
     ("vmd_eval_frames_section_decoded", C.c_size_t, [_vp]),
     ("vmd_eval_frames_mapped", C.c_size_t, [_vp]),

@@ -121,6 +121,15 @@ struct Options {
     std::atomic<int> sdf_dense{0};       // dense-target SDF scatter (stream whole frames, select by tag): measured slower, off
     std::atomic<int> sdf_arith{1};       // SDF target lists that are arithmetic progressions are generated on the device (0 = always load the index list)
     std::atomic<int> rdf_classes{1};     // co-evaluated RDFs of one range share pair passes through disjoint atom classes (0 = one pass per property)
+    // read-ahead under VIAMD's call pattern (many pool threads, ranges of a frame or a few): the first small call that finds
+    // company evaluates a whole REGION of frame blocks ahead into block partials, later calls for those frames only mark them requested
+    std::atomic<int> readahead{1};           // 0 = every call is evaluated when it arrives (the combining queue of round 3)
+    std::atomic<int> readahead_frames{128};  // frames of the first region of an evaluation (rounded to whole blocks) ...
+    std::atomic<int> readahead_growth{4};    // ... every further region is this many times larger (up to one kernel batch)
+    std::atomic<int> readahead_small{64};    // calls of at most this many frames take part; larger ranges are evaluated directly
+    std::atomic<int> readahead_block{0};     // frames per block partial (0 = by script: 256 without pair passes, 16 - 128 by selection size with)
+    std::atomic<int> readahead_linger_us{60};// a call that leaves alone waits this long for another call before it settles the eval (commit + views)
+    std::atomic<int> readahead_company_us{80};// the FIRST call of an evaluation waits this long for a second caller before it decides it is alone
 };
 static Options g_opt;
 
@@ -177,6 +186,13 @@ extern "C" int vmd_set_option(const char* key, int value) {
     else if (!strcmp(key, "spec_dist_geometric_com")) o = &g_opt.spec_dist_geometric_com;
     else if (!strcmp(key, "rdf_blocks_decode")) o = &g_opt.rdf_blocks_decode;
     else if (!strcmp(key, "rdf_classes")) o = &g_opt.rdf_classes;
+    else if (!strcmp(key, "readahead")) o = &g_opt.readahead;
+    else if (!strcmp(key, "readahead_frames")) o = &g_opt.readahead_frames;
+    else if (!strcmp(key, "readahead_growth")) o = &g_opt.readahead_growth;
+    else if (!strcmp(key, "readahead_small")) o = &g_opt.readahead_small;
+    else if (!strcmp(key, "readahead_block")) o = &g_opt.readahead_block;
+    else if (!strcmp(key, "readahead_linger_us")) o = &g_opt.readahead_linger_us;
+    else if (!strcmp(key, "readahead_company_us")) o = &g_opt.readahead_company_us;
     else if (!strcmp(key, "sdf_arith")) o = &g_opt.sdf_arith;
     else if (!strcmp(key, "sdf_ilp")) return vmd_hip_set_sdf_ilp(value);
     else if (!strcmp(key, "sdf_rows")) return vmd_hip_set_sdf_rows(value);
@@ -658,6 +674,7 @@ struct PropState {
     vmd_script_property_data_t data;
     vmd_script_aggregate_t aggregate;
     HostBuf<float> values;              // what data.values points at
+    std::vector<float> ahead_values;    // DIST: temporal rows of frames evaluated ahead, copied into `values` when their block is committed (read-ahead)
     std::vector<float> weights, agg_mean, agg_var, agg_ext;
     HostBuf<uint64_t> counts;           // host mirror of d_counts
     std::vector<double> weights64;
@@ -1016,6 +1033,32 @@ struct vmd_script_eval_t {
     size_t num_blocks = 0;
     vmd_script_eval_t* source = nullptr;
     std::atomic<size_t> frames_computed{0}, frames_reused{0}, frames_device_decoded{0};
+    // ---- read-ahead.  Block states move NONE -> PENDING -> READY under queue_mtx (the region leader), READY -> COMMITTED /
+    // DIRECT and NONE -> DIRECT under queue_mtx + mtx (settle / the direct path); the fast path of a call only READS a state and sets
+    // frame_req of its frames (compare-exchange: a frame is requested once).
+    enum : uint8_t { RA_NONE = 0, RA_PENDING = 1, RA_READY = 2, RA_COMMITTED = 3, RA_DIRECT = 4 };
+    struct ReadAhead {
+        std::atomic<bool> on{false};                 // states allocated, block partials exist: small calls take the read-ahead path
+        bool own_blocks = false;                     // block_frames was set by read-ahead itself (not by vmd_eval_set_block_frames)
+        std::unique_ptr<std::atomic<uint8_t>[]> blk_state;
+        std::unique_ptr<std::atomic<uint8_t>[]> frame_req;      // [num_frames]: requested by a call (committed or not)
+        std::atomic<int> in_flight{0};               // calls inside vmd_eval_frame_range
+        std::atomic<uint64_t> arrivals{0};
+        std::atomic<size_t> uncommitted{0};          // frames requested and not yet in the accumulators
+        std::atomic<bool> views_dirty{false};
+        bool spec_active = false;                    // a region is being evaluated (queue_mtx)
+        bool concurrent = false, lonely = false;     // has this evaluation seen two calls at once / has a first call waited for company in vain (queue_mtx)
+        bool disabled = false;                       // two settles had to evaluate frames directly mid-stream: the callers do not arrive the way read-ahead assumes
+        int strikes = 0;
+        size_t next_region = 0;                      // frames of the next region
+        bool failed = false; std::string error;      // a region failed: every waiting call reports it
+        std::mutex settle_mtx;                       // one settle at a time
+        int combining = 0;                           // calls inside the combining queue that entered before the states existed (queue_mtx)
+        size_t bmax = 0;                             // frames of one kernel batch for this eval and trajectory
+        const void* traj_inst = nullptr;             // the trajectory the regions are evaluated from
+        // statistics (vmd_eval_readahead_stats)
+        std::atomic<uint64_t> regions{0}, region_frames{0}, fast_calls{0}, slow_calls{0}, settles{0}, direct_frames{0}, committed_blocks{0};
+    } ra;
     vmd_reduce_stats_t reduce_stats = {};
     struct Spec { bool rdf_closed = false, sdf_include_self = false, sdf_density = false, dist_geometric_com = false; } spec;   // fixed at creation
     size_t atoms_checked = (size_t)-1;       // trajectory atom count the properties' indices were validated against (under mtx)
@@ -1269,6 +1312,7 @@ extern "C" void vmd_eval_free(vmd_script_eval_t* eval) {
     (void)hipSetDevice(prev_dev);
 }
 
+static void ra_reset(vmd_script_eval_t* e);
 extern "C" void vmd_eval_clear_data(vmd_script_eval_t* eval) {
     VMD_STAGE("vmd_eval_clear_data");
     if (!eval) return;
@@ -1278,6 +1322,7 @@ extern "C" void vmd_eval_clear_data(vmd_script_eval_t* eval) {
     eval->frames_done = 0;
     eval->frames_computed = 0; eval->frames_reused = 0; eval->frames_device_decoded = 0; eval->frames_section_decoded = 0; eval->frames_mapped = 0;
     for (size_t b = 0; b < eval->num_blocks; ++b) eval->block_ready[b] = 0;
+    ra_reset(eval);
     for (auto& p : eval->props) {
         // the 8.4 MB float view of a volume is pinned: the copy engine zeroes it from a zero buffer in HBM, in the background -
         // the DMA overlaps the kernels of the evaluation that follows (VIAMD clears and immediately re-evaluates,
@@ -1464,6 +1509,7 @@ extern "C" bool vmd_eval_set_block_frames(vmd_script_eval_t* eval, size_t block_
     std::lock_guard<std::mutex> l(eval->mtx);
     HIP_OK(hipSetDevice(eval->device));
     if (eval->frames_done.load() != 0) return vmd_fail("vmd_eval_set_block_frames: call before the first frame_range or right after clear_data");
+    eval->ra.on = false; eval->ra.own_blocks = false; eval->ra.blk_state.reset(); eval->ra.frame_req.reset();     // read-ahead re-engages on the new blocks
     eval->block_frames = 0; eval->num_blocks = 0; eval->block_ready.reset();
     for (auto& p : eval->props) { p->d_blocks.release(); p->block_weights64.clear(); }
     if (block_frames == 0) return true;
@@ -2372,10 +2418,10 @@ static bool view_holds(bool have_view, const vmd_device_view_t& view, size_t fra
 // evaluates frames [frame_beg, frame_end) in large batches; returns false on interrupt (empty error) or failure
 // views: bring the host views (values / weights / volume / aggregates) up to date before returning; false = the caller does it later
 // (refresh_views), the device accumulators and the frame mask are complete either way
-static bool process_range(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_trajectory_i* traj, uint32_t frame_beg, uint32_t frame_end, bool views = true) {
-    g_last_error.clear();
-    if (eval->interrupt) return false;
-    std::lock_guard<std::mutex> lock(eval->mtx);
+// spec (read-ahead): [frame_beg, frame_end) is a run of whole frame blocks; every block is evaluated into its own partial and
+// NOTHING else changes - no add into the totals, no frame mask, no frames_done, no normalisation weights outside the block's own, no view
+// (temporal rows are written: a frame's row is the same whenever it is computed, and nobody reads it before its mask bit is set)
+static bool process_range_locked(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_trajectory_i* traj, uint32_t frame_beg, uint32_t frame_end, bool views, bool spec) {
     HIP_OK(hipSetDevice(eval->device));
     vmd_script_eval_t* e = eval;
     const size_t num_atoms = traj->num_atoms(traj->inst);
@@ -2465,6 +2511,7 @@ static bool process_range(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
     }
     std::vector<Batch> batches;
     for (auto& sg : segments) plan_batches(e, sg.first, sg.second, Bmax, &batches);
+    if (spec) for (auto& b : batches) if (b.blk < 0) return vmd_fail("read-ahead: region [%u, %u) is not made of whole frame blocks", frame_beg, frame_end);
     // From a file the first batch has to cross PCIe and be decompressed before any kernel can start, and nothing overlaps the last
     // batch's kernels (r03p timeline: 1.7 ms of a 12.3 ms c2 step before the first pair kernel, one DMA = 1.13 ms per 128 frames).
     // Option xtc_ramp: the run starts with an eighth and a quarter of a batch and ends with a quarter.  Measured (r03o): the shorter
@@ -2667,7 +2714,7 @@ static bool process_range(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
             HIP_OK(hipStreamSynchronize(e->stream));
             repeated = true;
         }
-        if (c.bt.blk >= 0)
+        if (c.bt.blk >= 0 && !spec)
             for (auto& su : c.subs)
                 for (auto& p : e->props) if (p->ncounts) KRN_OK(vmd_hip_add_u64(e->stream, p->d_counts.p, acc_of(p.get(), su), p->ncounts));
         e->prof.resolve();
@@ -2675,13 +2722,17 @@ static bool process_range(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
         size_t toff = 0;
         for (auto& p : e->props) {
             if (p->prop.kind != PROP_DIST) continue;
-            memcpy(&p->values[c.f0 * p->dim1], e->h_temporal_slot[c.slot].data() + toff, c.nb * p->dim1 * sizeof(float));
+            // evaluated ahead: the rows wait beside the view until their block is committed (a reader of the values array never sees a
+            // frame nobody asked for)
+            if (spec && p->ahead_values.size() != p->values.size()) p->ahead_values.assign(p->values.size(), 0.0f);
+            memcpy(spec ? &p->ahead_values[c.f0 * p->dim1] : &p->values[c.f0 * p->dim1], e->h_temporal_slot[c.slot].data() + toff, c.nb * p->dim1 * sizeof(float));
             toff += c.nb * p->dim1;
         }
-        for (size_t b = 0; b < c.nb; ++b) e->frame_mask[c.f0 + b] = 1;
-        e->frames_done += c.nb;
         e->frames_computed += c.nb;
         if (c.bt.blk >= 0) for (auto& su : c.subs) e->block_ready[su.blk] = 1;
+        if (spec) return true;
+        for (size_t b = 0; b < c.nb; ++b) e->frame_mask[c.f0 + b] = 1;
+        e->frames_done += c.nb;
         // cheap views are refreshed every batch so a polling GUI sees progress (src/main.cpp:1508-1524): from the device when nothing
         // is queued behind this batch, from the snapshot taken behind its commits otherwise
         size_t soff = (size_t)c.slot * rdf_counts;
@@ -2747,12 +2798,12 @@ static bool process_range(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
                             const double r0 = (double)d.rmin + w * (double)k;
                             const double r1 = (double)d.rmin + w * (double)(k + 1);
                             const double wk = rho * (4.0 / 3.0) * M_PI * (r1 * r1 * r1 - r0 * r0 * r0);
-                            p->weights64[k] += wk;
+                            if (!spec) p->weights64[k] += wk;
                             if (bw) bw[k] += wk;
                         }
                     }
                 }
-                p->dirty = true;
+                p->dirty = p->dirty || !spec;
             } else if (d.kind == PROP_SDF) {
                 if (!p->d_R32.ensure(c.nb * d.K * 9) || !p->d_c32.ensure(c.nb * d.K * 3) || !p->d_group.ensure(c.nb * 4)) return false;
                 VMD_STAGE("batch: sdf align + scatter");
@@ -2771,7 +2822,7 @@ static bool process_range(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
                                                (p->have_tag && p->tag_len == c.src->row_stride && !e->spec.sdf_include_self) ? p->d_tag.p : nullptr,
                                                p->tgt_first, p->tgt_stride, (p->unowned || e->spec.sdf_include_self) ? 1 : 0));
                 e->prof.end(e->stream);
-                p->dirty = true;
+                p->dirty = p->dirty || !spec;
             } else {
                 if (!p->d_out.ensure(c.nb * p->dim1)) return false;
                 e->prof.begin("distance", e->stream);
@@ -2781,7 +2832,7 @@ static bool process_range(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
                 e->prof.end(e->stream);
                 HIP_OK(hipMemcpyAsync(e->h_temporal_slot[c.slot].data() + toff, p->d_out.p, c.nb * p->dim1 * sizeof(float), hipMemcpyDeviceToHost, e->stream));
                 toff += c.nb * p->dim1;
-                p->dirty = true;
+                p->dirty = p->dirty || !spec;
             }
         }
         if (defer) {
@@ -2831,10 +2882,16 @@ static bool process_range(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
     return completed;
 }
 
+static bool process_range(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_trajectory_i* traj, uint32_t frame_beg, uint32_t frame_end, bool views = true) {
+    g_last_error.clear();
+    if (eval->interrupt) return false;
+    std::lock_guard<std::mutex> lock(eval->mtx);
+    return process_range_locked(eval, sys, traj, frame_beg, frame_end, views, false);
+}
+
 // the host views of every property whose accumulators changed since its last refresh (the combining queue calls this when no call
 // is waiting, process_range(views = true) does the same at its end)
-static bool refresh_views(vmd_script_eval_t* e) {
-    std::lock_guard<std::mutex> lock(e->mtx);
+static bool refresh_views_locked(vmd_script_eval_t* e) {
     HIP_OK(hipSetDevice(e->device));
     for (auto& p : e->props) {
         if (!p->dirty) continue;
@@ -2845,20 +2902,16 @@ static bool refresh_views(vmd_script_eval_t* e) {
     e->views_at = std::chrono::steady_clock::now();
     return true;
 }
+static bool refresh_views(vmd_script_eval_t* e) {
+    std::lock_guard<std::mutex> lock(e->mtx);
+    return refresh_views_locked(e);
+}
 
 // The hot call.  VIAMD invokes it from N pool threads with small disjoint ranges (grain 1, src/main.cpp:993-997,
 // src/task_system.cpp:73-81).  Launching kernels per call would drown the GPU in tiny batches, so calls COMBINE: the first
 // caller becomes the leader, later callers queue their range and sleep; the leader repeatedly takes everything queued so far,
 // merges adjacent ranges into long runs and evaluates those in large frame batches, then wakes the owners.
-extern "C" bool vmd_eval_frame_range(vmd_script_eval_t* eval, const vmd_script_ir_t* ir, const vmd_system_t* sys,
-                                     vmd_trajectory_i* traj, uint32_t frame_beg, uint32_t frame_end) {
-    g_last_error.clear();   // a false return with an empty message means "interrupted"
-    if (!eval || !traj) return vmd_fail("vmd_eval_frame_range: NULL argument");
-    if (ir && vmd_ir_fingerprint(ir) != eval->ir_fingerprint) return vmd_fail("vmd_eval_frame_range: eval was created from a different ir");
-    if (frame_end > eval->num_frames) frame_end = (uint32_t)eval->num_frames;
-    if (frame_beg >= frame_end) return true;
-    if (eval->interrupt) return false;
-
+static bool combine_call(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_trajectory_i* traj, uint32_t frame_beg, uint32_t frame_end) {
     RangeRequest me;
     me.beg = frame_beg; me.end = frame_end; me.sys = sys; me.traj = traj;
     std::unique_lock<std::mutex> ql(eval->queue_mtx);
@@ -2946,6 +2999,368 @@ extern "C" bool vmd_eval_frame_range(vmd_script_eval_t* eval, const vmd_script_i
     ql.unlock();
     if (!me.ok) g_last_error = me.error;
     return me.ok;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Read-ahead: VIAMD's own call pattern at the one-call rate, without editing VIAMD.
+//
+// VIAMD evaluates a script as a pool task over [0, num_frames) with grain 1 (src/main.cpp:993-997, src/task_system.cpp:73-81): every pool
+// thread calls md_script_eval_frame_range with a frame or a few and blocks until they are evaluated, and the results must be final when
+// the last call returns - which no call knows to be.  A round of the combining queue above can therefore never hold more than
+// threads x grain frames (27 ms instead of 8 for the 100k-atom RDF, 130 instead of 7 for the 10 000-frame SDF).
+//
+// Here the first small call that needs a frame nobody has evaluated becomes the leader of a REGION: a run of whole frame blocks starting
+// at its frame (128 frames at first, four times as many each time, up to one kernel batch), evaluated in one go into the blocks' partial
+// accumulators (the filtered-evaluation machinery: process_range(spec)).  Nothing of a region is visible in the results.  A call whose
+// frames lie in an evaluated region only marks them REQUESTED (a compare-exchange per frame, no lock, no device work) and returns.  A block
+// joins the totals when every one of its frames has been requested - one k_add_u64 per accumulator, by the next region's leader or by the
+// settle below - so frames nobody asked for are never counted: a filtered range that ends inside a block, or an interrupt, leaves
+// the rest of the region unused.
+//
+// "Final when the last call returns": a call that leaves while no other call is inside the function waits a moment (readahead_linger_us)
+// for the next one to arrive - the pool threads of a running task come back within a microsecond - and if nobody comes it SETTLES the
+// eval before it returns: whole requested blocks are committed, requested frames of partly requested blocks are evaluated directly
+// (those blocks stay direct from then on), the host views are brought up to date.  Whoever returns last has either settled or handed
+// that duty to a call that arrived later.
+//
+// Callers that do not arrive like a pool (one thread calling frame by frame: every call is "the last") are recognised - the first call of
+// an evaluation waits readahead_company_us for a second caller - and served by the combining queue as before; so are large ranges, evals
+// with a source (filtered evaluation out of another eval's blocks) and evals whose settles keep finding partly requested blocks.
+typedef vmd_script_eval_t::ReadAhead ReadAhead;
+
+static void ra_reset(vmd_script_eval_t* e) {          // clear_data (mtx held): a new evaluation starts
+    ReadAhead& ra = e->ra;
+    if (ra.blk_state) for (size_t b = 0; b < e->num_blocks; ++b) ra.blk_state[b] = vmd_script_eval_t::RA_NONE;
+    if (ra.frame_req) for (size_t f = 0; f < e->num_frames; ++f) ra.frame_req[f] = 0;
+    ra.uncommitted = 0; ra.views_dirty = false;
+    ra.concurrent = false; ra.lonely = false; ra.disabled = false; ra.strikes = 0; ra.next_region = 0; ra.failed = false; ra.error.clear();
+}
+
+static size_t ra_block_frames(const vmd_script_eval_t* e, size_t Bmax) {
+    size_t G = (size_t)std::max(0, g_opt.readahead_block.load());
+    if (!G) {
+        if (e->rdf_groups.empty()) G = 256;           // streaming scripts: 16.8 MB of memset + add per volume and block - few, large blocks
+        else {
+            // pair passes: one pair launch per block; it needs ~4M selected atoms to fill the chip (50-frame launches of the
+            // 100k-atom box cost +12 %, 125-frame launches +5 %), and a block is also the most a ragged range end evaluates directly
+            size_t sel = 1;
+            for (auto& g : e->rdf_groups) for (auto& ps : g.passes) sel = std::max(sel, std::max(e->sels[ps.sel_a]->idx.size(), e->sels[ps.sel_b]->idx.size()));
+            G = 16;
+            while (G < 128 && G * sel < 4000000) G *= 2;
+        }
+    }
+    return std::max<size_t>(1, std::min(G, Bmax));
+}
+
+// queue_mtx held by the caller (and no combining call in flight): allocate the block partials and the states
+static bool ra_engage(vmd_script_eval_t* e, vmd_trajectory_i* traj) {
+    ReadAhead& ra = e->ra;
+    std::lock_guard<std::mutex> lock(e->mtx);
+    HIP_OK(hipSetDevice(e->device));
+    const size_t num_atoms = traj->num_atoms(traj->inst);
+    vmd_device_view_t view;
+    memset(&view, 0, sizeof(view));
+    const bool have_view = traj->device_view && traj->device_view(traj->inst, &view) && view.device == e->device;
+    const size_t Bmax = auto_batch(e, num_atoms, !have_view);
+    if (e->block_frames == 0) {
+        const size_t S = ra_block_frames(e, Bmax);
+        const size_t nblocks = (e->num_frames + S - 1) / S;
+        size_t bytes = 0;
+        for (auto& p : e->props) bytes += nblocks * p->ncounts * sizeof(uint64_t);
+        if (bytes > ((size_t)32 << 30)) { ra.disabled = true; return true; }        // not worth a ninth of the HBM: the combining queue serves this eval
+        for (auto& p : e->props) {
+            if (!p->ncounts) continue;
+            if (!p->d_blocks.ensure(nblocks * p->ncounts)) return false;
+            if (p->prop.kind == PROP_RDF) p->block_weights64.assign(nblocks * p->ncounts, 0.0);
+        }
+        e->block_ready.reset(new std::atomic<uint8_t>[nblocks]);
+        for (size_t b = 0; b < nblocks; ++b) e->block_ready[b] = 0;
+        e->num_blocks = nblocks;
+        e->block_frames = S;
+        ra.own_blocks = true;
+    }
+    const size_t S = e->block_frames;
+    ra.blk_state.reset(new std::atomic<uint8_t>[e->num_blocks]);
+    ra.frame_req.reset(new std::atomic<uint8_t>[std::max<size_t>(e->num_frames, 1)]);
+    // a rank's shard of a device trajectory: only blocks that lie inside it can be evaluated ahead
+    size_t lo = 0, hi = e->num_frames;
+    if (have_view && view_sharded(view)) { lo = view.resident_beg; hi = view.resident_end; }
+    for (size_t b = 0; b < e->num_blocks; ++b) {
+        const size_t f0 = b * S, f1 = std::min(f0 + S, e->num_frames);
+        bool done = false;
+        for (size_t f = f0; f < f1; ++f) { ra.frame_req[f] = e->frame_mask[f] ? 1 : 0; done = done || e->frame_mask[f]; }
+        ra.blk_state[b] = (done || f0 < lo || f1 > hi || f1 - f0 > Bmax) ? vmd_script_eval_t::RA_DIRECT : vmd_script_eval_t::RA_NONE;
+    }
+    ra.bmax = Bmax;
+    ra.traj_inst = traj->inst;
+    ra.on.store(true, std::memory_order_release);
+    return true;
+}
+
+// mtx held, device set: the block's partial joins the totals
+static bool ra_commit_block(vmd_script_eval_t* e, size_t blk) {
+    const size_t S = e->block_frames, f0 = blk * S, f1 = std::min(f0 + S, e->num_frames);
+    for (auto& p : e->props) {
+        if (p->ncounts) {
+            KRN_OK(vmd_hip_add_u64(e->stream, p->d_counts.p, p->d_blocks.p + blk * p->ncounts, p->ncounts));
+            if (p->prop.kind == PROP_RDF) for (size_t k = 0; k < p->ncounts; ++k) p->weights64[k] += p->block_weights64[blk * p->ncounts + k];
+        } else if (p->ahead_values.size() == p->values.size()) {
+            memcpy(&p->values[f0 * p->dim1], &p->ahead_values[f0 * p->dim1], (f1 - f0) * p->dim1 * sizeof(float));
+        }
+        p->dirty = true;
+    }
+    for (size_t f = f0; f < f1; ++f) e->frame_mask[f] = 1;
+    e->frames_done += f1 - f0;
+    e->ra.blk_state[blk].store(vmd_script_eval_t::RA_COMMITTED, std::memory_order_release);
+    e->ra.uncommitted -= f1 - f0;
+    e->ra.committed_blocks += 1;
+    e->ra.views_dirty = true;
+    return true;
+}
+
+// Brings the accumulators up to what has been requested.  full = false (a region leader, before its region): whole requested blocks are
+// committed, requested frames of direct blocks evaluated.  full = true (a call that leaves alone): also the requested frames of partly
+// requested blocks - evaluated directly, the block is direct from then on - and the host views.
+static bool ra_settle(vmd_script_eval_t* e, const vmd_system_t* sys, vmd_trajectory_i* traj, bool full) {
+    ReadAhead& ra = e->ra;
+    std::lock_guard<std::mutex> sl(ra.settle_mtx);
+    std::lock_guard<std::mutex> lock(e->mtx);
+    HIP_OK(hipSetDevice(e->device));
+    const size_t S = e->block_frames;
+    std::vector<std::pair<uint32_t, uint32_t>> runs;          // frames to evaluate directly
+    bool tainted = false;
+    for (size_t b = 0; b < e->num_blocks; ++b) {
+        const uint8_t st = ra.blk_state[b].load(std::memory_order_acquire);
+        if (st != vmd_script_eval_t::RA_READY && st != vmd_script_eval_t::RA_DIRECT) continue;
+        const size_t f0 = b * S, f1 = std::min(f0 + S, e->num_frames);
+        if (st == vmd_script_eval_t::RA_READY) {
+            size_t req = 0;
+            for (size_t f = f0; f < f1; ++f) req += ra.frame_req[f].load(std::memory_order_acquire) ? 1 : 0;
+            if (req == f1 - f0) { if (!ra_commit_block(e, b)) return false; continue; }
+            if (req == 0 || !full) continue;
+            ra.blk_state[b].store(vmd_script_eval_t::RA_DIRECT, std::memory_order_release);       // partly requested: its frames are evaluated one by one from now on
+            tainted = true;
+        }
+        for (size_t f = f0; f < f1; ++f) {
+            if (!ra.frame_req[f].load(std::memory_order_acquire) || e->frame_mask[f]) continue;
+            if (!runs.empty() && runs.back().second == f) runs.back().second = (uint32_t)f + 1;
+            else runs.push_back({(uint32_t)f, (uint32_t)f + 1});
+        }
+    }
+    for (auto& r : runs) {
+        g_last_error.clear();
+        if (e->interrupt) return false;
+        if (!process_range_locked(e, sys, traj, r.first, r.second, false, false)) return false;
+        ra.uncommitted -= r.second - r.first;
+        ra.direct_frames += r.second - r.first;
+        ra.views_dirty = true;
+    }
+    if (tainted && ++ra.strikes >= 3) ra.disabled = true;     // (settle_mtx) callers that keep leaving blocks half requested are not a pool walking a range
+    const bool overdue = std::chrono::steady_clock::now() - e->views_at > std::chrono::milliseconds(std::max(1, g_opt.lazy_views_ms.load()));
+    if ((full || overdue) && ra.views_dirty.exchange(false)) { if (!refresh_views_locked(e)) return false; }
+    ra.settles += full ? 1 : 0;
+    return true;
+}
+
+// no lock: 1 = every frame of [beg, end) lies in an evaluated (or direct) block and is now marked requested
+static bool ra_fast(vmd_script_eval_t* e, uint32_t beg, uint32_t end) {
+    ReadAhead& ra = e->ra;
+    const size_t S = e->block_frames;
+    for (size_t b = beg / S; b <= (size_t)(end - 1) / S; ++b) {
+        const uint8_t st = ra.blk_state[b].load(std::memory_order_acquire);
+        if (st != vmd_script_eval_t::RA_READY && st != vmd_script_eval_t::RA_DIRECT) return false;
+    }
+    for (uint32_t f = beg; f < end; ++f) if (ra.frame_req[f].load(std::memory_order_relaxed)) return false;      // asked for twice: the slow path sorts that out
+    ra.uncommitted += end - beg;                               // before the marks: a settle that sees a mark has this count to take it from
+    uint32_t dup = 0;
+    for (uint32_t f = beg; f < end; ++f) { uint8_t z = 0; if (!ra.frame_req[f].compare_exchange_strong(z, 1, std::memory_order_acq_rel)) ++dup; }
+    if (dup) ra.uncommitted -= dup;                            // lost a race against another call for the same frame: that call owns it
+    return true;
+}
+
+// the eval is not evaluating ahead for this call (a large range, a lone caller, read-ahead given up): the combining queue evaluates it when
+// it arrives.  With block states in place the blocks it touches become direct FIRST, so that no partial of theirs is committed later.
+static bool ra_direct_call(vmd_script_eval_t* e, const vmd_system_t* sys, vmd_trajectory_i* traj, uint32_t beg, uint32_t end) {
+    ReadAhead& ra = e->ra;
+    if (!ra.on.load(std::memory_order_acquire)) {
+        { std::lock_guard<std::mutex> ql(e->queue_mtx); ra.combining += 1; }
+        const bool ok = combine_call(e, sys, traj, beg, end);
+        { std::lock_guard<std::mutex> ql(e->queue_mtx); ra.combining -= 1; }
+        e->queue_cv.notify_all();
+        return ok;
+    }
+    const size_t S = e->block_frames;
+    const size_t b0 = beg / S, b1 = (size_t)(end - 1) / S;
+    for (;;) {
+        {
+            std::unique_lock<std::mutex> ql(e->queue_mtx);
+            e->queue_cv.wait(ql, [&] {
+                if (e->interrupt) return true;
+                for (size_t b = b0; b <= b1; ++b) if (ra.blk_state[b].load() == vmd_script_eval_t::RA_PENDING) return false;
+                return true; });
+        }
+        if (e->interrupt) { g_last_error.clear(); return false; }
+        // whatever has been requested in those blocks so far is settled first (committed whole, or evaluated), then they are direct
+        bool ready = false;
+        for (size_t b = b0; b <= b1; ++b) ready = ready || ra.blk_state[b].load() == vmd_script_eval_t::RA_READY;
+        if (ready && !ra_settle(e, sys, traj, true)) return false;
+        std::lock_guard<std::mutex> sl(ra.settle_mtx);
+        std::lock_guard<std::mutex> ql(e->queue_mtx);
+        bool pending = false;          // a region leader took one of them in the meantime: wait for it, or its partial would count these frames again
+        for (size_t b = b0; b <= b1; ++b) pending = pending || ra.blk_state[b].load() == vmd_script_eval_t::RA_PENDING;
+        if (pending) continue;
+        for (size_t b = b0; b <= b1; ++b) {
+            const uint8_t st = ra.blk_state[b].load();
+            if (st == vmd_script_eval_t::RA_READY || st == vmd_script_eval_t::RA_NONE) ra.blk_state[b].store(vmd_script_eval_t::RA_DIRECT, std::memory_order_release);
+        }
+        break;
+    }
+    const bool ok = combine_call(e, sys, traj, beg, end);
+    if (ok) for (uint32_t f = beg; f < end; ++f) ra.frame_req[f].store(1, std::memory_order_release);
+    return ok;
+}
+
+static bool ra_call(vmd_script_eval_t* e, const vmd_system_t* sys, vmd_trajectory_i* traj, uint32_t beg, uint32_t end) {
+    ReadAhead& ra = e->ra;
+    const bool small = (int)(end - beg) <= g_opt.readahead_small.load();
+    if (small && !ra.disabled && ra.on.load(std::memory_order_acquire) && ra.traj_inst == traj->inst && ra_fast(e, beg, end)) { ra.fast_calls += 1; return true; }
+    std::unique_lock<std::mutex> ql(e->queue_mtx);
+    if (ra.in_flight.load() >= 2 && !ra.concurrent) { ra.concurrent = true; e->queue_cv.notify_all(); }
+    if (small && !ra.disabled && !ra.on.load()) {
+        if (!ra.concurrent && !ra.lonely) {
+            // the first call of an evaluation: is this a pool?  Its other threads are microseconds behind
+            e->queue_cv.wait_for(ql, std::chrono::microseconds(std::max(0, g_opt.readahead_company_us.load())), [&] { return ra.concurrent || e->interrupt.load(); });
+            if (!ra.concurrent) ra.lonely = true;
+        }
+        if (ra.concurrent && !ra.on.load()) {
+            e->queue_cv.wait(ql, [&] { return ra.combining == 0 || ra.on.load(); });      // calls that went to the combining queue before anyone knew
+            if (!ra.on.load() && !ra_engage(e, traj)) return false;
+        }
+    }
+    if (!(small && !ra.disabled && ra.on.load() && ra.traj_inst == traj->inst)) {
+        ql.unlock();
+        return ra_direct_call(e, sys, traj, beg, end);
+    }
+    ra.slow_calls += 1;
+    const size_t S = e->block_frames;
+    const size_t b0 = beg / S, b1 = (size_t)(end - 1) / S;
+    for (;;) {
+        if (e->interrupt) { g_last_error.clear(); return false; }
+        if (ra.failed) { g_last_error = ra.error; return false; }
+        size_t need = (size_t)-1;
+        bool pending = false;
+        for (size_t b = b0; b <= b1; ++b) {
+            const uint8_t st = ra.blk_state[b].load(std::memory_order_acquire);
+            if (st == vmd_script_eval_t::RA_NONE) { need = b; break; }
+            pending = pending || st == vmd_script_eval_t::RA_PENDING;
+        }
+        if (need == (size_t)-1 && !pending) break;
+        if (need != (size_t)-1 && !ra.spec_active) {
+            // this call leads a region: whole blocks from `need` on, as far as nobody has touched them
+            size_t want = ra.next_region ? ra.next_region : (size_t)std::max(1, g_opt.readahead_frames.load());
+            want = std::min(std::max(want, S), std::max(ra.bmax, S));
+            size_t e1 = need, frames = 0;
+            while (e1 < e->num_blocks && ra.blk_state[e1].load() == vmd_script_eval_t::RA_NONE && frames < want) {
+                frames += std::min((e1 + 1) * S, e->num_frames) - e1 * S;
+                ++e1;
+            }
+            ra.next_region = std::min(std::max(ra.bmax, S), want * (size_t)std::max(1, g_opt.readahead_growth.load()));
+            for (size_t b = need; b < e1; ++b) ra.blk_state[b].store(vmd_script_eval_t::RA_PENDING, std::memory_order_release);
+            ra.spec_active = true;
+            ql.unlock();
+            const uint32_t f_lo = (uint32_t)(need * S), f_hi = (uint32_t)std::min(e1 * S, e->num_frames);
+            bool ok = ra_settle(e, sys, traj, false);         // what the callers have asked for so far joins the totals: progress for a polling GUI
+            if (ok) {
+                g_last_error.clear();
+                std::lock_guard<std::mutex> lock(e->mtx);
+                ok = !e->interrupt && process_range_locked(e, sys, traj, f_lo, f_hi, false, true);
+            }
+            const std::string err = ok ? std::string() : g_last_error;
+            ql.lock();
+            ra.spec_active = false;
+            for (size_t b = need; b < e1; ++b) ra.blk_state[b].store(ok ? vmd_script_eval_t::RA_READY : vmd_script_eval_t::RA_NONE, std::memory_order_release);
+            if (ok) { ra.regions += 1; ra.region_frames += f_hi - f_lo; }
+            else if (!e->interrupt) { ra.failed = true; ra.error = err; }
+            e->queue_cv.notify_all();
+            if (!ok) { g_last_error = err; return false; }
+            continue;
+        }
+        e->queue_cv.wait(ql);
+    }
+    ql.unlock();
+    // every block is evaluated (READY), direct or already committed: mark what can be marked, evaluate the rest now (frames asked for
+    // twice - the combining queue counts them twice, as it always has)
+    std::vector<std::pair<uint32_t, uint32_t>> again;
+    ra.uncommitted += end - beg;
+    uint32_t not_marked = 0;
+    for (uint32_t f = beg; f < end; ++f) {
+        uint8_t z = 0;
+        const bool committed = ra.blk_state[f / S].load(std::memory_order_acquire) == vmd_script_eval_t::RA_COMMITTED;
+        if (!committed && ra.frame_req[f].compare_exchange_strong(z, 1, std::memory_order_acq_rel)) continue;
+        ++not_marked;
+        if (!again.empty() && again.back().second == f) again.back().second = f + 1;
+        else again.push_back({f, f + 1});
+    }
+    if (not_marked) ra.uncommitted -= not_marked;
+    for (auto& r : again) if (!combine_call(e, sys, traj, r.first, r.second)) return false;
+    return true;
+}
+
+// the end of every call: whoever leaves last settles (or hands the duty to a call that has arrived since)
+static bool ra_leave(vmd_script_eval_t* e, const vmd_system_t* sys, vmd_trajectory_i* traj) {
+    ReadAhead& ra = e->ra;
+    for (;;) {
+        if (ra.in_flight.fetch_sub(1, std::memory_order_acq_rel) != 1) return true;
+        if (!ra.on.load(std::memory_order_acquire) || (ra.uncommitted.load() == 0 && !ra.views_dirty.load())) return true;
+        if (e->interrupt) return true;
+        const uint64_t a0 = ra.arrivals.load(std::memory_order_acquire);
+        const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(std::max(0, g_opt.readahead_linger_us.load()));
+        while (std::chrono::steady_clock::now() < deadline) {
+            if (ra.arrivals.load(std::memory_order_acquire) != a0) return true;
+            std::this_thread::yield();
+        }
+        if (ra.arrivals.load(std::memory_order_acquire) != a0) return true;
+        ra.in_flight.fetch_add(1, std::memory_order_acq_rel);
+        if (!ra_settle(e, sys, traj, true)) { ra.in_flight.fetch_sub(1, std::memory_order_acq_rel); return false; }
+    }
+}
+
+extern "C" bool vmd_eval_frame_range(vmd_script_eval_t* eval, const vmd_script_ir_t* ir, const vmd_system_t* sys,
+                                     vmd_trajectory_i* traj, uint32_t frame_beg, uint32_t frame_end) {
+    g_last_error.clear();   // a false return with an empty message means "interrupted"
+    if (!eval || !traj) return vmd_fail("vmd_eval_frame_range: NULL argument");
+    if (ir && vmd_ir_fingerprint(ir) != eval->ir_fingerprint) return vmd_fail("vmd_eval_frame_range: eval was created from a different ir");
+    if (frame_end > eval->num_frames) frame_end = (uint32_t)eval->num_frames;
+    if (frame_beg >= frame_end) return true;
+    if (eval->interrupt) return false;
+    if (!g_opt.readahead.load() || eval->source) {
+        if (!eval->ra.on.load()) return combine_call(eval, sys, traj, frame_beg, frame_end);
+        eval->ra.in_flight.fetch_add(1); eval->ra.arrivals.fetch_add(1);
+        const bool ok = ra_direct_call(eval, sys, traj, frame_beg, frame_end);
+        const std::string err = ok ? std::string() : g_last_error;
+        const bool lok = ra_leave(eval, sys, traj);
+        if (!ok) g_last_error = err;
+        return ok && lok;
+    }
+    eval->ra.in_flight.fetch_add(1, std::memory_order_acq_rel);
+    eval->ra.arrivals.fetch_add(1, std::memory_order_acq_rel);
+    const bool ok = ra_call(eval, sys, traj, frame_beg, frame_end);
+    const std::string err = ok ? std::string() : g_last_error;
+    const bool lok = ra_leave(eval, sys, traj);
+    if (!ok) g_last_error = err;
+    return ok && lok;
+}
+
+extern "C" void vmd_eval_readahead_stats(const vmd_script_eval_t* eval, vmd_readahead_stats_t* out) {
+    if (!out) return;
+    memset(out, 0, sizeof(*out));
+    if (!eval) return;
+    const ReadAhead& ra = eval->ra;
+    out->engaged = ra.on.load() ? 1 : 0;
+    out->block_frames = ra.on.load() ? (uint32_t)eval->block_frames : 0;
+    out->regions = ra.regions.load(); out->region_frames = ra.region_frames.load();
+    out->fast_calls = ra.fast_calls.load(); out->slow_calls = ra.slow_calls.load();
+    out->settles = ra.settles.load(); out->direct_frames = ra.direct_frames.load(); out->committed_blocks = ra.committed_blocks.load();
 }
 
 extern "C" const int32_t* vmd_eval_sdf_structures(const vmd_script_eval_t* eval, const char* name, size_t* num_structures, size_t* atoms_per_structure) {

@@ -281,6 +281,12 @@ class ScriptEval:
         self.lib.vmd_eval_frame_stats(self.h, C.byref(a), C.byref(b))
         return int(a.value), int(b.value)
 
+    def readahead_stats(self):
+        """What read-ahead did for this eval (vmd_eval_readahead_stats): a dict of the counters."""
+        st = L.ReadAheadStats()
+        self.lib.vmd_eval_readahead_stats(self.h, C.byref(st))
+        return {k: int(getattr(st, k)) for k, _ in L.ReadAheadStats._fields_}
+
     def frames_device_decoded(self):
         """Frames whose coordinates were decompressed on the device (load_raw + k_xtc_decode) since the last clear_data."""
         return int(self.lib.vmd_eval_frames_device_decoded(self.h))
