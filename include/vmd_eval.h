@@ -406,13 +406,13 @@ bool   vmd_eval_set_source(vmd_script_eval_t* eval, vmd_script_eval_t* source);
 void   vmd_eval_frame_stats(const vmd_script_eval_t* eval, size_t* frames_computed, size_t* frames_reused);
 /* Read-ahead under VIAMD's call pattern (pool threads, a frame or a few per call: /root/reference/src/main.cpp:993-997,
  * src/task_system.cpp:73-81): what this eval did since it was created.  engaged = small concurrent calls were recognised and regions of
- * frame blocks evaluated ahead; fast_calls = calls that only marked their frames requested; regions / region_frames = what was evaluated
- * ahead; committed_blocks = block partials that joined the totals; direct_frames = frames a settle evaluated one by one (ragged ends of a
+ * frame blocks evaluated ahead; slow_calls = calls that led or waited for a region (all others only marked their frames requested);
+ * regions / region_frames = what was evaluated ahead; committed_blocks = block partials that joined the totals; direct_frames = frames a settle evaluated one by one (ragged ends of a
  * range); settles = calls that left alone and brought accumulators and views up to date.  Options: readahead (0 = off), readahead_frames,
  * readahead_growth, readahead_small, readahead_block, readahead_linger_us, readahead_company_us (vmd_set_option). */
 typedef struct vmd_readahead_stats_t {
     uint32_t engaged, block_frames;
-    uint64_t regions, region_frames, fast_calls, slow_calls, settles, direct_frames, committed_blocks;
+    uint64_t regions, region_frames, slow_calls, settles, direct_frames, committed_blocks;
 } vmd_readahead_stats_t;
 void   vmd_eval_readahead_stats(const vmd_script_eval_t* eval, vmd_readahead_stats_t* out);
 /* frames whose coordinates were decompressed on the device (load_raw + k_xtc_wave) since the last clear_data, and how many of them

@@ -363,7 +363,7 @@ def readahead_case(lib, O, device=False, n_water=600, box=28.0, F=40, nthreads=6
             st = ev.readahead_stats()
             assert st["engaged"] == 1 and st["block_frames"] == 4 and st["regions"] >= 2 and st["committed_blocks"] + st["direct_frames"] // 4 >= 1, st
             assert st["committed_blocks"] * 4 + st["direct_frames"] == F, st            # every frame counted exactly once, one way or the other
-            assert st["fast_calls"] + st["slow_calls"] > 0 and st["settles"] >= 1, st
+            assert st["slow_calls"] > 0 and st["settles"] >= 1, st
             # again on the same eval (VIAMD: clear_data, re-evaluate - src/main.cpp:990-996), frames handed out from the far end
             ev.clear_data()
             assert all(pooled(ev, 0, F, grain, order=list(range(0, F, grain))[::-1]))

@@ -91,8 +91,8 @@ int main(int argc, char** argv) {
     std::printf("\n");
     vmd_readahead_stats_t st;
     vmd_eval_readahead_stats(eval, &st);
-    std::printf("  read-ahead over all pooled runs: engaged %u, blocks of %u frames, %llu regions (%llu frames), %llu calls marked only, %llu waited, %llu settles, %llu frames evaluated directly, %llu blocks committed\n",
-                st.engaged, st.block_frames, (unsigned long long)st.regions, (unsigned long long)st.region_frames, (unsigned long long)st.fast_calls, (unsigned long long)st.slow_calls,
+    std::printf("  read-ahead over all pooled runs: engaged %u, blocks of %u frames, %llu regions (%llu frames), %llu calls led or waited (the others only marked), %llu settles, %llu frames evaluated directly, %llu blocks committed\n",
+                st.engaged, st.block_frames, (unsigned long long)st.regions, (unsigned long long)st.region_frames, (unsigned long long)st.slow_calls,
                 (unsigned long long)st.settles, (unsigned long long)st.direct_frames, (unsigned long long)st.committed_blocks);
     vmd_eval_free(eval); vmd_ir_free(ir); vmd_devtraj_free(dt);
     return 0;

@@ -114,7 +114,7 @@ class ReduceStats(C.Structure):          # vmd_reduce_stats_t
 
 class ReadAheadStats(C.Structure):      # vmd_readahead_stats_t
     _fields_ = [("engaged", C.c_uint32), ("block_frames", C.c_uint32), ("regions", C.c_uint64), ("region_frames", C.c_uint64),
-                ("fast_calls", C.c_uint64), ("slow_calls", C.c_uint64), ("settles", C.c_uint64), ("direct_frames", C.c_uint64),
+                ("slow_calls", C.c_uint64), ("settles", C.c_uint64), ("direct_frames", C.c_uint64),
                 ("committed_blocks", C.c_uint64)]
 
 

@@ -1041,13 +1041,20 @@ struct vmd_script_eval_t {
         std::atomic<bool> on{false};                 // states allocated, block partials exist: small calls take the read-ahead path
         bool own_blocks = false;                     // block_frames was set by read-ahead itself (not by vmd_eval_set_block_frames)
         std::unique_ptr<std::atomic<uint8_t>[]> blk_state;
-        std::unique_ptr<std::atomic<uint8_t>[]> frame_req;      // [num_frames]: requested by a call (committed or not)
-        std::atomic<int> in_flight{0};               // calls inside vmd_eval_frame_range
-        std::atomic<uint64_t> arrivals{0};
-        std::atomic<size_t> uncommitted{0};          // frames requested and not yet in the accumulators
+        // requested by a call (committed or not).  Sixteen pool threads mark sixteen consecutive frames at the same instant: frame f lives
+        // at slot (f % 64) * req_stride + f / 64, so neighbours in time are at least a cache line apart
+        std::unique_ptr<std::atomic<uint8_t>[]> frame_req;
+        size_t req_stride = 64;
+        std::atomic<uint8_t>& req(size_t f) const { return frame_req[(f & 63) * req_stride + (f >> 6)]; }
+        // calls inside vmd_eval_frame_range (low half) and calls that ever arrived (high half) in ONE word: a call costs this line one
+        // read-modify-write when it enters and one when it leaves - with 16 threads and 10 000 one-frame calls every further shared
+        // counter on the path showed up in the total (r04b: 12.4 ms for the 10 000-frame SDF, 9.4 at grain 64)
+        alignas(64) std::atomic<uint64_t> flight{0};
+        alignas(64) std::atomic<bool> marks_pending{false};   // frames were marked since the last full settle began
         std::atomic<bool> views_dirty{false};
+        std::atomic<bool> concurrent{false};         // this evaluation (since clear_data) has seen two calls at once: it is a pool
         bool spec_active = false;                    // a region is being evaluated (queue_mtx)
-        bool concurrent = false, lonely = false;     // has this evaluation seen two calls at once / has a first call waited for company in vain (queue_mtx)
+        bool lonely = false;                         // a first call has waited for company in vain (queue_mtx)
         bool disabled = false;                       // two settles had to evaluate frames directly mid-stream: the callers do not arrive the way read-ahead assumes
         int strikes = 0;
         size_t next_region = 0;                      // frames of the next region
@@ -1057,7 +1064,7 @@ struct vmd_script_eval_t {
         size_t bmax = 0;                             // frames of one kernel batch for this eval and trajectory
         const void* traj_inst = nullptr;             // the trajectory the regions are evaluated from
         // statistics (vmd_eval_readahead_stats)
-        std::atomic<uint64_t> regions{0}, region_frames{0}, fast_calls{0}, slow_calls{0}, settles{0}, direct_frames{0}, committed_blocks{0};
+        std::atomic<uint64_t> regions{0}, region_frames{0}, slow_calls{0}, settles{0}, direct_frames{0}, committed_blocks{0};
     } ra;
     vmd_reduce_stats_t reduce_stats = {};
     struct Spec { bool rdf_closed = false, sdf_include_self = false, sdf_density = false, dist_geometric_com = false; } spec;   // fixed at creation
@@ -3031,15 +3038,15 @@ typedef vmd_script_eval_t::ReadAhead ReadAhead;
 static void ra_reset(vmd_script_eval_t* e) {          // clear_data (mtx held): a new evaluation starts
     ReadAhead& ra = e->ra;
     if (ra.blk_state) for (size_t b = 0; b < e->num_blocks; ++b) ra.blk_state[b] = vmd_script_eval_t::RA_NONE;
-    if (ra.frame_req) for (size_t f = 0; f < e->num_frames; ++f) ra.frame_req[f] = 0;
-    ra.uncommitted = 0; ra.views_dirty = false;
+    if (ra.frame_req) for (size_t i = 0; i < 64 * ra.req_stride; ++i) ra.frame_req[i] = 0;
+    ra.marks_pending = false; ra.views_dirty = false;
     ra.concurrent = false; ra.lonely = false; ra.disabled = false; ra.strikes = 0; ra.next_region = 0; ra.failed = false; ra.error.clear();
 }
 
 static size_t ra_block_frames(const vmd_script_eval_t* e, size_t Bmax) {
     size_t G = (size_t)std::max(0, g_opt.readahead_block.load());
     if (!G) {
-        if (e->rdf_groups.empty()) G = 256;           // streaming scripts: 16.8 MB of memset + add per volume and block - few, large blocks
+        if (e->rdf_groups.empty()) G = 1024;          // streaming scripts: 16.8 MB of memset + add per volume and block - few, large blocks (r04c, 10 000-frame SDF at grain 1: 10.8 ms with 256, 9.7 with 512, 9.2 with 1 024; one call 7.0)
         else {
             // pair passes: one pair launch per block; it needs ~4M selected atoms to fill the chip (50-frame launches of the
             // 100k-atom box cost +12 %, 125-frame launches +5 %), and a block is also the most a ragged range end evaluates directly
@@ -3081,14 +3088,16 @@ static bool ra_engage(vmd_script_eval_t* e, vmd_trajectory_i* traj) {
     }
     const size_t S = e->block_frames;
     ra.blk_state.reset(new std::atomic<uint8_t>[e->num_blocks]);
-    ra.frame_req.reset(new std::atomic<uint8_t>[std::max<size_t>(e->num_frames, 1)]);
+    ra.req_stride = std::max<size_t>(64, (e->num_frames + 63) / 64);
+    ra.frame_req.reset(new std::atomic<uint8_t>[64 * ra.req_stride]);
+    for (size_t i = 0; i < 64 * ra.req_stride; ++i) ra.frame_req[i] = 0;
     // a rank's shard of a device trajectory: only blocks that lie inside it can be evaluated ahead
     size_t lo = 0, hi = e->num_frames;
     if (have_view && view_sharded(view)) { lo = view.resident_beg; hi = view.resident_end; }
     for (size_t b = 0; b < e->num_blocks; ++b) {
         const size_t f0 = b * S, f1 = std::min(f0 + S, e->num_frames);
         bool done = false;
-        for (size_t f = f0; f < f1; ++f) { ra.frame_req[f] = e->frame_mask[f] ? 1 : 0; done = done || e->frame_mask[f]; }
+        for (size_t f = f0; f < f1; ++f) { ra.req(f) = e->frame_mask[f] ? 1 : 0; done = done || e->frame_mask[f]; }
         ra.blk_state[b] = (done || f0 < lo || f1 > hi || f1 - f0 > Bmax) ? vmd_script_eval_t::RA_DIRECT : vmd_script_eval_t::RA_NONE;
     }
     ra.bmax = Bmax;
@@ -3112,7 +3121,6 @@ static bool ra_commit_block(vmd_script_eval_t* e, size_t blk) {
     for (size_t f = f0; f < f1; ++f) e->frame_mask[f] = 1;
     e->frames_done += f1 - f0;
     e->ra.blk_state[blk].store(vmd_script_eval_t::RA_COMMITTED, std::memory_order_release);
-    e->ra.uncommitted -= f1 - f0;
     e->ra.committed_blocks += 1;
     e->ra.views_dirty = true;
     return true;
@@ -3127,6 +3135,7 @@ static bool ra_settle(vmd_script_eval_t* e, const vmd_system_t* sys, vmd_traject
     std::lock_guard<std::mutex> lock(e->mtx);
     HIP_OK(hipSetDevice(e->device));
     const size_t S = e->block_frames;
+    if (full) ra.marks_pending.store(false, std::memory_order_release);    // before the scan: whoever marks after this point sets it again
     std::vector<std::pair<uint32_t, uint32_t>> runs;          // frames to evaluate directly
     bool tainted = false;
     for (size_t b = 0; b < e->num_blocks; ++b) {
@@ -3135,14 +3144,14 @@ static bool ra_settle(vmd_script_eval_t* e, const vmd_system_t* sys, vmd_traject
         const size_t f0 = b * S, f1 = std::min(f0 + S, e->num_frames);
         if (st == vmd_script_eval_t::RA_READY) {
             size_t req = 0;
-            for (size_t f = f0; f < f1; ++f) req += ra.frame_req[f].load(std::memory_order_acquire) ? 1 : 0;
+            for (size_t f = f0; f < f1; ++f) req += ra.req(f).load(std::memory_order_acquire) ? 1 : 0;
             if (req == f1 - f0) { if (!ra_commit_block(e, b)) return false; continue; }
             if (req == 0 || !full) continue;
             ra.blk_state[b].store(vmd_script_eval_t::RA_DIRECT, std::memory_order_release);       // partly requested: its frames are evaluated one by one from now on
             tainted = true;
         }
         for (size_t f = f0; f < f1; ++f) {
-            if (!ra.frame_req[f].load(std::memory_order_acquire) || e->frame_mask[f]) continue;
+            if (!ra.req(f).load(std::memory_order_acquire) || e->frame_mask[f]) continue;
             if (!runs.empty() && runs.back().second == f) runs.back().second = (uint32_t)f + 1;
             else runs.push_back({(uint32_t)f, (uint32_t)f + 1});
         }
@@ -3151,7 +3160,6 @@ static bool ra_settle(vmd_script_eval_t* e, const vmd_system_t* sys, vmd_traject
         g_last_error.clear();
         if (e->interrupt) return false;
         if (!process_range_locked(e, sys, traj, r.first, r.second, false, false)) return false;
-        ra.uncommitted -= r.second - r.first;
         ra.direct_frames += r.second - r.first;
         ra.views_dirty = true;
     }
@@ -3170,11 +3178,10 @@ static bool ra_fast(vmd_script_eval_t* e, uint32_t beg, uint32_t end) {
         const uint8_t st = ra.blk_state[b].load(std::memory_order_acquire);
         if (st != vmd_script_eval_t::RA_READY && st != vmd_script_eval_t::RA_DIRECT) return false;
     }
-    for (uint32_t f = beg; f < end; ++f) if (ra.frame_req[f].load(std::memory_order_relaxed)) return false;      // asked for twice: the slow path sorts that out
-    ra.uncommitted += end - beg;                               // before the marks: a settle that sees a mark has this count to take it from
-    uint32_t dup = 0;
-    for (uint32_t f = beg; f < end; ++f) { uint8_t z = 0; if (!ra.frame_req[f].compare_exchange_strong(z, 1, std::memory_order_acq_rel)) ++dup; }
-    if (dup) ra.uncommitted -= dup;                            // lost a race against another call for the same frame: that call owns it
+    for (uint32_t f = beg; f < end; ++f) if (ra.req(f).load(std::memory_order_relaxed)) return false;      // asked for twice: the slow path sorts that out
+    // the flag before the marks: a settle that clears it and then misses a mark leaves it set for the next one
+    if (!ra.marks_pending.load(std::memory_order_relaxed)) ra.marks_pending.store(true, std::memory_order_release);
+    for (uint32_t f = beg; f < end; ++f) { uint8_t z = 0; (void)ra.req(f).compare_exchange_strong(z, 1, std::memory_order_acq_rel); }   // a lost race = another call for the same frame owns it
     return true;
 }
 
@@ -3216,17 +3223,18 @@ static bool ra_direct_call(vmd_script_eval_t* e, const vmd_system_t* sys, vmd_tr
         break;
     }
     const bool ok = combine_call(e, sys, traj, beg, end);
-    if (ok) for (uint32_t f = beg; f < end; ++f) ra.frame_req[f].store(1, std::memory_order_release);
+    if (ok) for (uint32_t f = beg; f < end; ++f) ra.req(f).store(1, std::memory_order_release);
     return ok;
 }
 
 static bool ra_call(vmd_script_eval_t* e, const vmd_system_t* sys, vmd_trajectory_i* traj, uint32_t beg, uint32_t end) {
     ReadAhead& ra = e->ra;
     const bool small = (int)(end - beg) <= g_opt.readahead_small.load();
-    if (small && !ra.disabled && ra.on.load(std::memory_order_acquire) && ra.traj_inst == traj->inst && ra_fast(e, beg, end)) { ra.fast_calls += 1; return true; }
+    if (small && !ra.disabled && ra.on.load(std::memory_order_acquire) && ra.concurrent.load(std::memory_order_relaxed) && ra.traj_inst == traj->inst && ra_fast(e, beg, end)) return true;
     std::unique_lock<std::mutex> ql(e->queue_mtx);
-    if (ra.in_flight.load() >= 2 && !ra.concurrent) { ra.concurrent = true; e->queue_cv.notify_all(); }
-    if (small && !ra.disabled && !ra.on.load()) {
+    if ((uint32_t)ra.flight.load() >= 2 && !ra.concurrent) { ra.concurrent = true; e->queue_cv.notify_all(); }
+    if (small && !ra.disabled) {
+        // (also on an eval whose blocks exist from an earlier evaluation: whether THIS evaluation is driven by a pool is found out anew)
         if (!ra.concurrent && !ra.lonely) {
             // the first call of an evaluation: is this a pool?  Its other threads are microseconds behind
             e->queue_cv.wait_for(ql, std::chrono::microseconds(std::max(0, g_opt.readahead_company_us.load())), [&] { return ra.concurrent || e->interrupt.load(); });
@@ -3237,7 +3245,7 @@ static bool ra_call(vmd_script_eval_t* e, const vmd_system_t* sys, vmd_trajector
             if (!ra.on.load() && !ra_engage(e, traj)) return false;
         }
     }
-    if (!(small && !ra.disabled && ra.on.load() && ra.traj_inst == traj->inst)) {
+    if (!(small && !ra.disabled && ra.concurrent && ra.on.load() && ra.traj_inst == traj->inst)) {
         ql.unlock();
         return ra_direct_call(e, sys, traj, beg, end);
     }
@@ -3291,17 +3299,14 @@ static bool ra_call(vmd_script_eval_t* e, const vmd_system_t* sys, vmd_trajector
     // every block is evaluated (READY), direct or already committed: mark what can be marked, evaluate the rest now (frames asked for
     // twice - the combining queue counts them twice, as it always has)
     std::vector<std::pair<uint32_t, uint32_t>> again;
-    ra.uncommitted += end - beg;
-    uint32_t not_marked = 0;
+    ra.marks_pending.store(true, std::memory_order_release);
     for (uint32_t f = beg; f < end; ++f) {
         uint8_t z = 0;
         const bool committed = ra.blk_state[f / S].load(std::memory_order_acquire) == vmd_script_eval_t::RA_COMMITTED;
-        if (!committed && ra.frame_req[f].compare_exchange_strong(z, 1, std::memory_order_acq_rel)) continue;
-        ++not_marked;
+        if (!committed && ra.req(f).compare_exchange_strong(z, 1, std::memory_order_acq_rel)) continue;
         if (!again.empty() && again.back().second == f) again.back().second = f + 1;
         else again.push_back({f, f + 1});
     }
-    if (not_marked) ra.uncommitted -= not_marked;
     for (auto& r : again) if (!combine_call(e, sys, traj, r.first, r.second)) return false;
     return true;
 }
@@ -3310,18 +3315,19 @@ static bool ra_call(vmd_script_eval_t* e, const vmd_system_t* sys, vmd_trajector
 static bool ra_leave(vmd_script_eval_t* e, const vmd_system_t* sys, vmd_trajectory_i* traj) {
     ReadAhead& ra = e->ra;
     for (;;) {
-        if (ra.in_flight.fetch_sub(1, std::memory_order_acq_rel) != 1) return true;
-        if (!ra.on.load(std::memory_order_acquire) || (ra.uncommitted.load() == 0 && !ra.views_dirty.load())) return true;
+        const uint64_t w = ra.flight.fetch_sub(1, std::memory_order_acq_rel);
+        if ((uint32_t)w != 1) return true;
+        if (!ra.on.load(std::memory_order_acquire) || (!ra.marks_pending.load() && !ra.views_dirty.load())) return true;
         if (e->interrupt) return true;
-        const uint64_t a0 = ra.arrivals.load(std::memory_order_acquire);
+        const uint64_t a0 = w >> 32;
         const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(std::max(0, g_opt.readahead_linger_us.load()));
         while (std::chrono::steady_clock::now() < deadline) {
-            if (ra.arrivals.load(std::memory_order_acquire) != a0) return true;
+            if ((ra.flight.load(std::memory_order_acquire) >> 32) != a0) return true;
             std::this_thread::yield();
         }
-        if (ra.arrivals.load(std::memory_order_acquire) != a0) return true;
-        ra.in_flight.fetch_add(1, std::memory_order_acq_rel);
-        if (!ra_settle(e, sys, traj, true)) { ra.in_flight.fetch_sub(1, std::memory_order_acq_rel); return false; }
+        if ((ra.flight.load(std::memory_order_acquire) >> 32) != a0) return true;
+        ra.flight.fetch_add(1, std::memory_order_acq_rel);
+        if (!ra_settle(e, sys, traj, true)) { ra.flight.fetch_sub(1, std::memory_order_acq_rel); return false; }
     }
 }
 
@@ -3335,15 +3341,14 @@ extern "C" bool vmd_eval_frame_range(vmd_script_eval_t* eval, const vmd_script_i
     if (eval->interrupt) return false;
     if (!g_opt.readahead.load() || eval->source) {
         if (!eval->ra.on.load()) return combine_call(eval, sys, traj, frame_beg, frame_end);
-        eval->ra.in_flight.fetch_add(1); eval->ra.arrivals.fetch_add(1);
+        eval->ra.flight.fetch_add(((uint64_t)1 << 32) | 1, std::memory_order_acq_rel);
         const bool ok = ra_direct_call(eval, sys, traj, frame_beg, frame_end);
         const std::string err = ok ? std::string() : g_last_error;
         const bool lok = ra_leave(eval, sys, traj);
         if (!ok) g_last_error = err;
         return ok && lok;
     }
-    eval->ra.in_flight.fetch_add(1, std::memory_order_acq_rel);
-    eval->ra.arrivals.fetch_add(1, std::memory_order_acq_rel);
+    eval->ra.flight.fetch_add(((uint64_t)1 << 32) | 1, std::memory_order_acq_rel);
     const bool ok = ra_call(eval, sys, traj, frame_beg, frame_end);
     const std::string err = ok ? std::string() : g_last_error;
     const bool lok = ra_leave(eval, sys, traj);
@@ -3359,7 +3364,7 @@ extern "C" void vmd_eval_readahead_stats(const vmd_script_eval_t* eval, vmd_read
     out->engaged = ra.on.load() ? 1 : 0;
     out->block_frames = ra.on.load() ? (uint32_t)eval->block_frames : 0;
     out->regions = ra.regions.load(); out->region_frames = ra.region_frames.load();
-    out->fast_calls = ra.fast_calls.load(); out->slow_calls = ra.slow_calls.load();
+    out->slow_calls = ra.slow_calls.load();
     out->settles = ra.settles.load(); out->direct_frames = ra.direct_frames.load(); out->committed_blocks = ra.committed_blocks.load();
 }
 
