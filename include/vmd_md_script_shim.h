@@ -7,10 +7,19 @@
  *     md_script_eval_create / _free / _clear_data / _interrupt / _ir_fingerprint      /root/reference/src/main.cpp:971,960,990,829,987
  *     md_script_eval_frame_range                                                      /root/reference/src/main.cpp:996,1032
  *     md_script_eval_property_data / md_script_eval_frame_mask                        /root/reference/src/main.cpp:1286,1513
+ *     md_script_ir_property_vis_payload                                               /root/reference/src/main.cpp:1304
+ *     md_script_vis_eval_payload (MD_SCRIPT_VISUALIZE_SDF / _ATOMS on an sdf property)
+ *                                          /root/reference/src/components/density_volume/density_volume.cpp:183-204, 263-269;
+ *                                          /root/reference/src/main.cpp:5751-5803 (export_cube); src/viamd.cpp:3197-3210
  *
  * With VMD_SHIM_PREFIX undefined the functions are emitted under those very names (a VIAMD build that drops mdlib's
  * md_script_eval.c from the link); define VMD_SHIM_PREFIX(name) to put them elsewhere (the compile test uses vmdshim_##name
  * next to a mock of mdlib's declarations).
+ *
+ * Hooks (define before including; the defaults name mdlib's own functions): VMD_SHIM_BONDS(sys, vsys) hands md_system_t::bond over;
+ * VMD_SHIM_UNIT(dst, str) turns the backend's printed unit ("\xC3\x85" or "") into an md_unit_t (default: md_unit_angstrom() /
+ * md_unit_none()); VMD_SHIM_BITFIELD_INIT / _SET build the md_bitfield_t of a reference structure (default: md_bitfield_init /
+ * md_bitfield_set_bit); md_array_resize / md_array_size are mdlib's stretchy-buffer macros.
  *
  * What the shim needs from the host besides the types: the property DESCRIPTORS.  mdlib's IR is opaque, so the host registers,
  * once per compiled script, the vmd_script_ir_t that carries its rdf / sdf / distance properties (INTEGRATION.md section 3 shows how
@@ -22,10 +31,12 @@
 
 #include <string.h>
 
+#include <iterator>
 #include <map>
 #include <memory>
 #include <mutex>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "vmd_eval.h"
@@ -34,11 +45,30 @@
 #define VMD_SHIM_PREFIX(name) name
 #endif
 
+/* the opaque payload VIAMD keeps per display property (src/viamd.h:350): here, which property of which script */
+struct md_script_vis_payload_o { const md_script_ir_t* ir; std::string name; };
+
+#ifndef VMD_SHIM_UNIT
+#define VMD_SHIM_UNIT(dst, str) do { (dst) = ((str) && (str)[0]) ? md_unit_angstrom() : md_unit_none(); } while (0)
+#endif
+#ifndef VMD_SHIM_BITFIELD_INIT
+#define VMD_SHIM_BITFIELD_INIT(bf, alloc) md_bitfield_init((bf), (alloc))
+#endif
+#ifndef VMD_SHIM_BITFIELD_SET
+#define VMD_SHIM_BITFIELD_SET(bf, idx) md_bitfield_set_bit((bf), (uint64_t)(idx))
+#endif
+
 /* ---- IR registry: md_script_ir_t* -> the descriptors of its properties ------------------------------------------------------ */
 namespace vmd_shim {
+struct PayloadEval { vmd_script_eval_t* eval = nullptr; size_t num_frames = 0; };
 struct Registry {
     std::mutex mtx;
     std::map<const void*, const vmd_script_ir_t*> ir;
+    /* vis payloads handed to VIAMD (one per (ir, property), stable addresses) and one small evaluator per ir that serves them:
+     * md_script_vis_eval_payload has no eval argument (density_volume.cpp:188), the reference pose and the per-frame alignment
+     * of an sdf() live behind vmd_eval_sdf_payload */
+    std::map<std::pair<const void*, std::string>, std::unique_ptr<md_script_vis_payload_o>> payloads;
+    std::map<const void*, PayloadEval> payload_evals;
 };
 inline Registry& registry() { static Registry r; return r; }
 inline const vmd_script_ir_t* find_ir(const void* md_ir) {
@@ -96,7 +126,11 @@ inline vmd_system_t wrap_system(const md_system_t* sys) {
 inline void vmd_shim_bind_ir(const md_script_ir_t* md_ir, const vmd_script_ir_t* vmd_ir) {
     vmd_shim::Registry& r = vmd_shim::registry();
     std::lock_guard<std::mutex> l(r.mtx);
-    if (vmd_ir) r.ir[md_ir] = vmd_ir; else r.ir.erase(md_ir);
+    if (vmd_ir) { r.ir[md_ir] = vmd_ir; return; }
+    r.ir.erase(md_ir);
+    auto pe = r.payload_evals.find(md_ir);
+    if (pe != r.payload_evals.end()) { vmd_eval_free(pe->second.eval); r.payload_evals.erase(pe); }
+    for (auto it = r.payloads.begin(); it != r.payloads.end();) it = it->first.first == md_ir ? r.payloads.erase(it) : std::next(it);
 }
 
 /* ---- md_script_eval_t ------------------------------------------------------------------------------------------------------ */
@@ -149,8 +183,10 @@ inline md_script_eval_t* VMD_SHIM_PREFIX(md_script_eval_create)(size_t num_frame
         p->src = vmd_eval_property_data(e->eval, p->name.c_str());
         memset(&p->dst, 0, sizeof(p->dst));
         memset(&p->agg, 0, sizeof(p->agg));
-        /* unit[2]: mdlib's md_unit_t is not visible here; the backend carries the printed form (unit_str), which is what VIAMD
-         * shows (src/main.cpp:1314-1315) - a host with the real md_unit.h maps "\xC3\x85" to md_unit_angstrom() */
+        /* unit[2] (src/main.cpp:1300-1301, printed at :1314-1315): the backend carries the printed form, VMD_SHIM_UNIT makes the
+         * md_unit_t of it */
+        VMD_SHIM_UNIT(p->dst.unit[0], p->src->unit_str[0]);
+        VMD_SHIM_UNIT(p->dst.unit[1], p->src->unit_str[1]);
         e->props.push_back(std::move(p));
     }
     e->mask_words.assign((num_frames + 63) / 64 + 1, 0);
@@ -208,6 +244,65 @@ inline const md_bitfield_t* VMD_SHIM_PREFIX(md_script_eval_frame_mask)(const md_
     std::lock_guard<std::mutex> l(e->mtx);
     vmd_eval_frame_mask_bits(e->eval, e->mask_words.data(), e->mask_words.size());
     return &e->mask;
+}
+
+/* ---- vis payloads ----------------------------------------------------------------------------------------------------------- */
+/* md_script_ir_property_vis_payload(ir, name), src/main.cpp:1304: NULL for an unknown ir / property */
+inline const md_script_vis_payload_o* VMD_SHIM_PREFIX(md_script_ir_property_vis_payload)(const md_script_ir_t* ir, str_t name) {
+    const vmd_script_ir_t* vir = vmd_shim::find_ir(ir);
+    if (!vir) return nullptr;
+    const std::string nm(name.ptr, (size_t)name.len);
+    bool known = false;
+    for (size_t i = 0; i < vmd_ir_property_count(vir); ++i) known = known || nm == vmd_ir_property_names(vir)[i];
+    if (!known) return nullptr;
+    vmd_shim::Registry& r = vmd_shim::registry();
+    std::lock_guard<std::mutex> l(r.mtx);
+    std::unique_ptr<md_script_vis_payload_o>& p = r.payloads[std::make_pair((const void*)ir, nm)];
+    if (!p) { p.reset(new md_script_vis_payload_o()); p->ir = ir; p->name = nm; }
+    return p.get();
+}
+
+/* md_script_vis_eval_payload(&vis, payload, subidx, &ctx, flags).  Served for sdf() properties - the one payload on the evaluation
+ * path: MD_SCRIPT_VISUALIZE_SDF fills vis->sdf.{extent, matrices, structures} for trajectory frame 0 of ctx->traj (the reference pose
+ * VIAMD draws the volume in: density_volume.cpp:190-204, 263-269; export_cube, src/main.cpp:5751-5803), MD_SCRIPT_VISUALIZE_ATOMS adds
+ * the atoms of the reference structures to vis->atom_mask (src/viamd.cpp:3205-3207).  subidx >= 0 selects one structure.  Payloads of
+ * other property kinds return false (their highlighting is mdlib's own). */
+inline bool VMD_SHIM_PREFIX(md_script_vis_eval_payload)(md_script_vis_t* vis, const md_script_vis_payload_o* payload, int subidx,
+                                                        const md_script_vis_ctx_t* ctx, md_script_vis_flags_t flags) {
+    if (!vis || !payload || !ctx || !ctx->mol || !ctx->traj) return false;
+    const vmd_script_ir_t* vir = vmd_shim::find_ir(payload->ir);
+    if (!vir || !(vmd_ir_property_flags(vir, payload->name.c_str()) & VMD_PROPERTY_FLAG_VOLUME)) return false;
+    vmd_shim::Registry& r = vmd_shim::registry();
+    vmd_script_eval_t* ev = nullptr;
+    const size_t F = (size_t)md_trajectory_num_frames(ctx->traj);
+    {
+        std::lock_guard<std::mutex> l(r.mtx);
+        vmd_shim::PayloadEval& pe = r.payload_evals[payload->ir];
+        if (!pe.eval || pe.num_frames != F) { vmd_eval_free(pe.eval); pe.eval = vmd_eval_create(F, vir); pe.num_frames = F; }
+        ev = pe.eval;
+    }
+    if (!ev) return false;
+    const vmd_system_t vsys = vmd_shim::wrap_system(ctx->mol);
+    vmd_trajectory_i vtraj = vmd_shim::wrap_trajectory(ctx->traj);
+    vmd_sdf_payload_t out;
+    if (!vmd_eval_sdf_payload(ev, payload->name.c_str(), &vsys, &vtraj, 0, &out)) return false;
+    const size_t k0 = subidx >= 0 ? (size_t)subidx : 0, k1 = subidx >= 0 ? (size_t)subidx + 1 : out.num_structures;
+    if (k1 > out.num_structures) return false;
+    if (flags & MD_SCRIPT_VISUALIZE_SDF) {
+        vis->sdf.extent = out.extent;
+        md_array_resize(vis->sdf.matrices, k1 - k0, vis->alloc);
+        md_array_resize(vis->sdf.structures, k1 - k0, vis->alloc);
+        for (size_t k = k0; k < k1; ++k) {
+            memcpy(&vis->sdf.matrices[k - k0], out.matrices + 16 * k, 16 * sizeof(float));        /* mat4_t: 16 floats, column-major */
+            md_bitfield_t* bf = &vis->sdf.structures[k - k0];
+            VMD_SHIM_BITFIELD_INIT(bf, vis->alloc);
+            for (size_t a = 0; a < out.atoms_per_structure; ++a) VMD_SHIM_BITFIELD_SET(bf, out.structures[k * out.atoms_per_structure + a]);
+        }
+    }
+    if (flags & MD_SCRIPT_VISUALIZE_ATOMS)
+        for (size_t k = k0; k < k1; ++k)
+            for (size_t a = 0; a < out.atoms_per_structure; ++a) VMD_SHIM_BITFIELD_SET(&vis->atom_mask, out.structures[k * out.atoms_per_structure + a]);
+    return true;
 }
 
 #endif /* VMD_MD_SCRIPT_SHIM_H */

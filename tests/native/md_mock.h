@@ -6,6 +6,10 @@
 //   md_trajectory_load_frame(traj, idx, &header, x, y, z)                  src/viamd.cpp:465-467
 //   md_script_property_data_t: dim, unit, values, weights, aggregate, ranges, fingerprint     src/main.cpp:1286-1524
 //   md_bitfield_t + iterator                                               src/main.cpp:194-210
+//   md_script_vis_t {alloc, atom_mask, sdf.{extent, matrices, structures}}, md_script_vis_ctx_t {ir, mol, traj}, flags
+//                                                                          src/components/density_volume/density_volume.cpp:179-204, 263-269; src/main.cpp:5746-5757
+//   md_array_size / md_array_resize, mat4_t, md_bitfield_scan / _popcount  src/main.cpp:5768-5793
+//   md_unit_t + md_unit_print / _none / _equal                             src/main.cpp:1300-1324, 4395-4401
 #pragma once
 #include <stddef.h>
 #include <stdint.h>
@@ -15,8 +19,51 @@ struct str_t { const char* ptr; size_t len; };
 #define STR_LIT(s) (str_t{(s), sizeof(s) - 1})
 static inline bool str_empty(str_t s) { return s.len == 0; }
 
+#include <stdio.h>
+#include <stdlib.h>
 struct md_allocator_i { void* inst; };
+// md_unit_t: the mock keeps one code per unit (0 = none, 1 = Angstrom); mdlib's has base dimensions and a multiplier
 struct md_unit_t { uint32_t base; float mult; };
+static inline md_unit_t md_unit_none(void) { return md_unit_t{0u, 1.0f}; }
+static inline md_unit_t md_unit_angstrom(void) { return md_unit_t{1u, 1e-10f}; }
+static inline bool md_unit_is_none(md_unit_t u) { return u.base == 0u; }
+static inline bool md_unit_equal(md_unit_t a, md_unit_t b) { return a.base == b.base && a.mult == b.mult; }
+static inline size_t md_unit_print(char* buf, size_t cap, md_unit_t u) { return (size_t)snprintf(buf, cap, "%s", u.base == 1u ? "\xC3\x85" : ""); }
+
+// md_array: mdlib's stretchy buffer (a header in front of the elements); the mock's grows with realloc and ignores the allocator
+struct md_mock_array_header_t { size_t size, capacity; };
+#define md_array(T) T*
+static inline size_t md_mock_array_size(const void* a) { return a ? ((const md_mock_array_header_t*)a)[-1].size : 0; }
+static inline void* md_mock_array_resize(void* a, size_t n, size_t elem) {
+    md_mock_array_header_t* h = a ? (md_mock_array_header_t*)a - 1 : nullptr;
+    const size_t old = h ? h->size : 0;
+    if (!h || h->capacity < n) {
+        h = (md_mock_array_header_t*)realloc(h, sizeof(md_mock_array_header_t) + (n ? n : 1) * elem);
+        h->capacity = n ? n : 1;
+    }
+    h->size = n;
+    if (n > old) memset((char*)(h + 1) + old * elem, 0, (n - old) * elem);
+    return h + 1;
+}
+#define md_array_size(a) md_mock_array_size(a)
+#define md_array_resize(a, n, alloc) ((void)(alloc), *(void**)&(a) = md_mock_array_resize((a), (n), sizeof(*(a))))
+#define md_array_free(a, alloc) ((void)(alloc), (a) ? free((md_mock_array_header_t*)(a) - 1) : (void)0, *(void**)&(a) = nullptr)
+
+struct vec3_t { float x, y, z; };
+struct vec4_t { float x, y, z, w; };
+struct mat4_t { vec4_t col[4]; };          // column-major, as VIAMD multiplies it (mat4_mul_vec3(M, coord, 1.0f), src/main.cpp:5790)
+static inline vec3_t mat4_mul_vec3(mat4_t M, vec3_t v, float w) {
+    return vec3_t{M.col[0].x * v.x + M.col[1].x * v.y + M.col[2].x * v.z + M.col[3].x * w,
+                  M.col[0].y * v.x + M.col[1].y * v.y + M.col[2].y * v.z + M.col[3].y * w,
+                  M.col[0].z * v.x + M.col[1].z * v.y + M.col[2].z * v.z + M.col[3].z * w};
+}
+static inline mat4_t mat4_scale(float x, float y, float z) { mat4_t M = {}; M.col[0].x = x; M.col[1].y = y; M.col[2].z = z; M.col[3].w = 1.0f; return M; }
+static inline mat4_t mat4_mul(mat4_t A, mat4_t B) {
+    mat4_t C;
+    const float* a = &A.col[0].x; const float* b = &B.col[0].x; float* c = &C.col[0].x;
+    for (int j = 0; j < 4; ++j) for (int i = 0; i < 4; ++i) { float s = 0.0f; for (int k = 0; k < 4; ++k) s += a[k * 4 + i] * b[j * 4 + k]; c[j * 4 + i] = s; }
+    return C;
+}
 
 struct md_unitcell_t {
     float x, y, z, xy, xz, yz;
@@ -66,6 +113,23 @@ static inline bool md_bitfield_iter_next(md_bitfield_iter_t* it) {
     return false;
 }
 static inline uint64_t md_bitfield_iter_idx(const md_bitfield_iter_t* it) { return (uint64_t)it->idx; }
+// growable: the mock owns `bits` (heap), enough for the vis payload's atom sets
+static inline void md_bitfield_init(md_bitfield_t* bf, md_allocator_i* alloc) { (void)alloc; bf->bits = nullptr; bf->beg_bit = 0; bf->end_bit = 0; }
+static inline void md_bitfield_free(md_bitfield_t* bf) { free(bf->bits); bf->bits = nullptr; bf->beg_bit = bf->end_bit = 0; }
+static inline void md_bitfield_set_bit(md_bitfield_t* bf, uint64_t i) {
+    if (i >= bf->end_bit) {
+        const size_t old_words = ((size_t)bf->end_bit + 63) / 64, new_words = (size_t)(i + 64) / 64;
+        if (new_words > old_words) { bf->bits = (uint64_t*)realloc(bf->bits, new_words * 8); memset(bf->bits + old_words, 0, (new_words - old_words) * 8); }
+        bf->end_bit = (uint32_t)(i + 1);
+    }
+    bf->bits[i >> 6] |= 1ull << (i & 63);
+}
+static inline bool md_bitfield_empty(const md_bitfield_t* bf) { return md_bitfield_popcount(bf) == 0; }
+// 1-based index of the first set bit in [beg, end), 0 when there is none (src/main.cpp:5786-5788)
+static inline size_t md_bitfield_scan(const md_bitfield_t* bf, size_t beg, size_t end) {
+    for (size_t i = beg; i < end; ++i) if (md_bitfield_test_bit(bf, i)) return i + 1;
+    return 0;
+}
 
 typedef uint32_t md_script_property_flags_t;
 enum { MD_SCRIPT_PROPERTY_FLAG_TEMPORAL = 1, MD_SCRIPT_PROPERTY_FLAG_DISTRIBUTION = 2, MD_SCRIPT_PROPERTY_FLAG_VOLUME = 4 };
@@ -90,4 +154,28 @@ struct md_script_property_data_t {
 };
 
 struct md_script_ir_t;      // opaque: the script compiler's product
+struct md_script_vis_payload_o;   // opaque: what md_script_ir_property_vis_payload hands out (src/main.cpp:1304)
+typedef uint32_t md_script_vis_flags_t;
+enum { MD_SCRIPT_VISUALIZE_DEFAULT = 0, MD_SCRIPT_VISUALIZE_GEOMETRY = 1, MD_SCRIPT_VISUALIZE_ATOMS = 2, MD_SCRIPT_VISUALIZE_SDF = 4 };
+struct md_script_vis_ctx_t {
+    const md_script_ir_t* ir;
+    const md_system_t* mol;
+    md_trajectory_i* traj;
+};
+struct md_script_vis_t {
+    md_allocator_i* alloc;
+    md_bitfield_t atom_mask;
+    md_array(md_bitfield_t) structure;
+    struct {
+        md_array(mat4_t) matrices;
+        md_array(md_bitfield_t) structures;
+        float extent;
+    } sdf;
+};
+static inline void md_script_vis_init(md_script_vis_t* vis, md_allocator_i* alloc) { memset(vis, 0, sizeof(*vis)); vis->alloc = alloc; md_bitfield_init(&vis->atom_mask, alloc); }
+static inline void md_script_vis_free(md_script_vis_t* vis) {
+    for (size_t i = 0; i < md_array_size(vis->sdf.structures); ++i) md_bitfield_free(&vis->sdf.structures[i]);
+    md_array_free(vis->sdf.structures, vis->alloc); md_array_free(vis->sdf.matrices, vis->alloc);
+    md_bitfield_free(&vis->atom_mask);
+}
 struct md_script_eval_t;    // defined by whoever implements the evaluator (mdlib, or include/vmd_md_script_shim.h)

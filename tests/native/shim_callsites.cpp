@@ -8,8 +8,12 @@
 //   :1014-1039 "Eval Filt": the same on a sub-range of the timeline with the second eval
 //   :1508-1524 update_display_properties: fingerprint compare -> compute_histogram_masked(frame_mask) / downsample_histogram
 //   :952-953   interrupt while tasks run; :960-964 free
+//   :1300-1315 unit[2] copied and printed; :1304 vis_payload fetched per display property
+//   density_volume.cpp:175-204, 263-269  md_script_vis_eval_payload(SDF): extent, one matrix + one atom bitfield per reference structure
+//   :5718-5830 export_cube re-typed with md_* names only; the file must equal vmd_export_cube's byte for byte
 //
 // Prints "OK ..." and exits 0 when the shimmed sequence returns, bit for bit, what direct vmd_* calls return.
+#include <algorithm>
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>
@@ -49,6 +53,9 @@ struct DisplayProperty {
     char label[64];
     md_script_property_flags_t prop_flags;
     const md_script_property_data_t* prop_data;
+    const md_script_vis_payload_o* vis_payload;
+    md_unit_t unit[2];
+    char unit_str[2][32];
     const md_script_eval_t* eval;
     uint64_t prop_fingerprint;
     int num_bins;
@@ -87,6 +94,11 @@ int main(int argc, char** argv) {
     const int32_t a = 0, b = 300;
     if (!vmd_ir_add_rdf(vir, "r", oxy.data(), oxy.size(), oxy.data(), oxy.size(), 0.0f, 10.0f)) fail("add_rdf");
     if (!vmd_ir_add_distance(vir, "d", VMD_DISTANCE_COM, &a, 1, &b, 1)) fail("add_distance");
+    // v = sdf(first three waters, every other water oxygen, 8): K = 3 reference structures of m = 3 atoms
+    std::vector<int32_t> sdf_structs;
+    for (int32_t i = 0; i < 9; ++i) sdf_structs.push_back(i);
+    std::vector<int32_t> sdf_targets(oxy.begin() + 3, oxy.end());
+    if (!vmd_ir_add_sdf(vir, "v", sdf_structs.data(), 3, 3, sdf_targets.data(), sdf_targets.size(), 8.0f)) fail("add_sdf");
     const md_script_ir_t* eval_ir = (const md_script_ir_t*)0x1234;      // whatever md_script_ir_compile_from_source returned
     vmd_shim_bind_ir(eval_ir, vir);
     md_allocator_i persistent{nullptr};
@@ -110,6 +122,12 @@ int main(int argc, char** argv) {
             DisplayProperty item{};
             snprintf(item.label, sizeof(item.label), "%.*s%s", (int)prop_name.len, prop_name.ptr, eval_idx ? " filt" : "");
             item.prop_flags = prop_flags; item.prop_data = prop_data; item.eval = evals[eval_idx]; item.prop_fingerprint = 0; item.num_bins = 128;
+            item.unit[0] = prop_data->unit[0];                                                     // :1300-1301
+            item.unit[1] = prop_data->unit[1];
+            item.vis_payload = md_script_ir_property_vis_payload(eval_ir, prop_name);              // :1304
+            md_unit_print(item.unit_str[0], sizeof(item.unit_str[0]), item.unit[0]);               // :1314-1315
+            md_unit_print(item.unit_str[1], sizeof(item.unit_str[1]), item.unit[1]);
+            if (!item.vis_payload) fail("md_script_ir_property_vis_payload");
             display_properties.push_back(item);
         }
     }
@@ -159,7 +177,115 @@ int main(int argc, char** argv) {
             ++refreshed;
         }
     }
-    if (refreshed != 4) fail("every property's fingerprint must have moved");
+    if (refreshed != 6) fail("every property's fingerprint must have moved");
+    // :1314-1315 what the property windows print: an rdf's x axis and a distance's y axis are lengths, an sdf has no unit
+    for (const DisplayProperty& dp : display_properties) {
+        const bool rdf = dp.label[0] == 'r', dist = dp.label[0] == 'd';
+        if (strcmp(dp.unit_str[0], rdf ? "\xC3\x85" : "") != 0 || strcmp(dp.unit_str[1], dist ? "\xC3\x85" : "") != 0) fail("unit strings");
+        if (md_unit_is_none(dp.unit[0]) == rdf) fail("unit[0]");
+    }
+
+    // ---- density_volume.cpp:134-150, 175-204, 263-269: the SDF window asks for the reference structures of the selected volume property
+    const DisplayProperty* vol_dp = nullptr;
+    for (const DisplayProperty& dp : display_properties) if ((dp.prop_flags & MD_SCRIPT_PROPERTY_FLAG_VOLUME) && dp.eval == full_eval) vol_dp = &dp;
+    if (!vol_dp) fail("no volume property among the display properties");
+    md_allocator_i frame_alloc{nullptr};
+    float sdf_extent = 0.0f;
+    std::vector<mat4_t> rep_model_mats;
+    std::vector<std::vector<int32_t>> rep_atom_indices;
+    {
+        const md_script_property_data_t* prop_data = vol_dp->prop_data;
+        const md_script_vis_payload_o* vis_payload = vol_dp->vis_payload;
+        size_t num_reps = 0;
+        bool result = false;
+        md_script_vis_t vis = {};
+        md_script_vis_init(&vis, &frame_alloc);
+        md_script_vis_ctx_t ctx = {eval_ir, &sys, sys.trajectory};
+        result = md_script_vis_eval_payload(&vis, vis_payload, 0, &ctx, MD_SCRIPT_VISUALIZE_SDF);
+        if (!result) fail("md_script_vis_eval_payload(SDF)");
+        if (vis.sdf.extent) {
+            sdf_extent = vis.sdf.extent;
+            const float voxel_spacing = 2 * sdf_extent / prop_data->dim[1];
+            if (!(voxel_spacing > 0.0f)) fail("voxel spacing");
+        }
+        num_reps = md_array_size(vis.sdf.structures);
+        if (num_reps != 1 || md_array_size(vis.sdf.matrices) != 1) fail("subidx 0 must select ONE reference structure");
+        md_script_vis_free(&vis);
+        // all of them (subidx -1: script_visualize_payload(state, dp.vis_payload, -1, ...), density_volume.cpp:318) + the atoms to highlight
+        md_script_vis_init(&vis, &frame_alloc);
+        if (!md_script_vis_eval_payload(&vis, vis_payload, -1, &ctx, MD_SCRIPT_VISUALIZE_SDF | MD_SCRIPT_VISUALIZE_ATOMS)) fail("md_script_vis_eval_payload(SDF | ATOMS)");
+        num_reps = md_array_size(vis.sdf.structures);
+        for (size_t i = 0; i < num_reps; ++i) {                                                    // :263-269
+            rep_model_mats.push_back(vis.sdf.matrices[i]);
+            size_t popcount = md_bitfield_popcount(&vis.sdf.structures[i]);
+            std::vector<int32_t> idx;
+            md_bitfield_iter_t it = md_bitfield_iter_create(&vis.sdf.structures[i]);
+            while (md_bitfield_iter_next(&it)) idx.push_back((int32_t)md_bitfield_iter_idx(&it));
+            if (idx.size() != popcount) fail("bitfield iteration");
+            rep_atom_indices.push_back(idx);
+        }
+        if (md_bitfield_empty(&vis.atom_mask) || md_bitfield_popcount(&vis.atom_mask) != 9) fail("atom_mask of the reference structures");   // src/viamd.cpp:3205-3207
+        md_script_vis_free(&vis);
+    }
+    if (rep_atom_indices.size() != 3 || !(sdf_extent == 8.0f)) fail("three reference structures, extent = cutoff");
+
+    // ---- export_cube, src/main.cpp:5718-5830, with the md_* names it uses (md_file_printf -> fprintf)
+    const char* cube_md = "/tmp/viamd_shim_callsites_md.cube";
+    const char* cube_vmd = "/tmp/viamd_shim_callsites_vmd.cube";
+    {
+        const md_script_property_data_t* prop_data = vol_dp->prop_data;
+        const md_script_vis_payload_o* vis_payload = vol_dp->vis_payload;
+        md_system_t mol = sys;
+        std::vector<float> coords(3 * N);
+        mol.atom.x = coords.data(); mol.atom.y = coords.data() + N; mol.atom.z = coords.data() + 2 * N;
+        if (!md_trajectory_load_frame(sys.trajectory, 0, NULL, mol.atom.x, mol.atom.y, mol.atom.z)) fail("load frame 0");
+        md_script_vis_t vis = {};
+        md_script_vis_init(&vis, &frame_alloc);
+        md_script_vis_ctx_t ctx = {eval_ir, &sys, sys.trajectory};
+        if (!md_script_vis_eval_payload(&vis, vis_payload, 0, &ctx, MD_SCRIPT_VISUALIZE_ATOMS | MD_SCRIPT_VISUALIZE_SDF)) fail("Failed to visualize volume for export.");
+        FILE* file = fopen(cube_md, "w");
+        if (!file) fail("open cube");
+        fprintf(file, "EXPORTED DENSITY VOLUME FROM VIAMD, UNITS IN BOHR\n");
+        fprintf(file, "OUTER LOOP: X, MIDDLE LOOP: Y, INNER LOOP: Z\n");
+        if (md_array_size(vis.sdf.structures) > 0) {
+            const float angstrom_to_bohr = (float)(1.0 / 0.529177210903);
+            mat4_t M = vis.sdf.matrices[0];
+            const md_bitfield_t* bf = &vis.sdf.structures[0];
+            const int num_atoms = (int)md_bitfield_popcount(bf);
+            const int vol_dim[3] = {prop_data->dim[1], prop_data->dim[2], prop_data->dim[3]};
+            const double extent = vis.sdf.extent * 2.0 * angstrom_to_bohr;
+            const double voxel_ext[3] = {(double)extent / (double)vol_dim[0], (double)extent / (double)vol_dim[1], (double)extent / (double)vol_dim[2]};
+            const double half_ext = extent * 0.5;
+            fprintf(file, "%5i %12.6f %12.6f %12.6f\n", -num_atoms, -half_ext, -half_ext, -half_ext);
+            fprintf(file, "%5i %12.6f %12.6f %12.6f\n", vol_dim[0], voxel_ext[0], 0.0, 0.0);
+            fprintf(file, "%5i %12.6f %12.6f %12.6f\n", vol_dim[1], 0.0, voxel_ext[1], 0.0);
+            fprintf(file, "%5i %12.6f %12.6f %12.6f\n", vol_dim[2], 0.0, 0.0, voxel_ext[2]);
+            const float scl = angstrom_to_bohr;
+            M = mat4_mul(mat4_scale(scl, scl, scl), M);
+            size_t beg_bit = bf->beg_bit;
+            size_t end_bit = bf->end_bit;
+            while ((beg_bit = md_bitfield_scan(bf, beg_bit, end_bit)) != 0) {
+                size_t i = beg_bit - 1;
+                vec3_t coord = vec3_t{mol.atom.x[i], mol.atom.y[i], mol.atom.z[i]};             // md_atom_coord(&mol.atom, i)
+                coord = mat4_mul_vec3(M, coord, 1.0f);
+                int anum = 0;                                                                   // md_atom_atomic_number: the mock molecule has no elements
+                float charge = (float)anum;
+                fprintf(file, "%5i %12.6f %12.6f %12.6f %12.6f\n", anum, charge, coord.x, coord.y, coord.z);
+            }
+            fprintf(file, "%5i %5i\n", 1, 1);
+            int count = 0;
+            for (int x = 0; x < vol_dim[0]; ++x)
+                for (int y = 0; y < vol_dim[1]; ++y)
+                    for (int z = 0; z < vol_dim[2]; ++z) {
+                        int idx = z * vol_dim[0] * vol_dim[1] + y * vol_dim[0] + x;
+                        float val = prop_data->values[idx];
+                        fprintf(file, " %12.6E", val);
+                        if (++count % 6 == 0) fprintf(file, "\n");
+                    }
+        }
+        fclose(file);
+        md_script_vis_free(&vis);
+    }
 
     // ---- the same two evaluations through the ABI directly: the shim must not change a bit
     auto direct = [&](uint32_t fb, uint32_t fe, std::vector<float>* r_values, std::vector<float>* d_values, std::vector<uint8_t>* mask) {
@@ -172,6 +298,23 @@ int main(int argc, char** argv) {
         r_values->assign(r->values, r->values + r->dim[2]);
         d_values->assign(d->values, d->values + (size_t)d->dim[0] * (size_t)d->dim[1]);
         mask->assign(vmd_eval_frame_mask(e), vmd_eval_frame_mask(e) + F);
+        if (fb == 0 && fe == F) {
+            // the volume, its payload and its cube file through the ABI: what the md_* sequence above must reproduce byte for byte
+            const vmd_script_property_data_t* v = vmd_eval_property_data(e, "v");
+            const md_script_property_data_t* sv = vol_dp->prop_data;
+            if (v->num_values != sv->num_values || memcmp(v->values, sv->values, v->num_values * sizeof(float)) != 0) fail("sdf volume differs from the direct call");
+            if (v->max_value != sv->max_value || !(v->max_value > 0.0f)) fail("sdf max_value");
+            vmd_sdf_payload_t pl;
+            if (!vmd_eval_sdf_payload(e, "v", &vsys, &vt, 0, &pl)) fail("vmd_eval_sdf_payload");
+            if (pl.num_structures != rep_model_mats.size() || pl.extent != sdf_extent) fail("payload shape");
+            for (size_t k = 0; k < pl.num_structures; ++k) {
+                if (memcmp(&rep_model_mats[k], pl.matrices + 16 * k, 16 * sizeof(float)) != 0) fail("vis.sdf.matrices differ from vmd_eval_sdf_payload");
+                std::vector<int32_t> want(pl.structures + k * pl.atoms_per_structure, pl.structures + (k + 1) * pl.atoms_per_structure);
+                std::sort(want.begin(), want.end());
+                if (want != rep_atom_indices[k]) fail("vis.sdf.structures differ from vmd_eval_sdf_payload");
+            }
+            if (!vmd_export_cube(cube_vmd, e, "v", &vsys, &vt, 0, nullptr)) fail("vmd_export_cube");
+        }
         vmd_eval_free(e);
     };
     double hits[2] = {0, 0};
@@ -179,8 +322,8 @@ int main(int argc, char** argv) {
         std::vector<float> rv, dv;
         std::vector<uint8_t> mk;
         direct(which ? beg_frame : 0, which ? end_frame : (uint32_t)F, &rv, &dv, &mk);
-        const md_script_property_data_t* r = display_properties[(size_t)which * 2 + 0].prop_data;
-        const md_script_property_data_t* d = display_properties[(size_t)which * 2 + 1].prop_data;
+        const md_script_property_data_t* r = display_properties[(size_t)which * 3 + 0].prop_data;
+        const md_script_property_data_t* d = display_properties[(size_t)which * 3 + 1].prop_data;
         if (r->dim[2] != (int)rv.size() || memcmp(r->values, rv.data(), rv.size() * sizeof(float)) != 0) fail("rdf values differ from the direct call");
         if (memcmp(d->values, dv.data(), dv.size() * sizeof(float)) != 0) fail("distance values differ from the direct call");
         const md_bitfield_t* mask = md_script_eval_frame_mask(evals[which]);
@@ -188,6 +331,12 @@ int main(int argc, char** argv) {
         for (float v : rv) hits[which] += v;
     }
     if (!(hits[0] > 0 && hits[1] > 0 && hits[1] < hits[0])) fail("hit counts");
+    {
+        auto slurp = [&](const char* path) { std::vector<char> b; FILE* f = fopen(path, "rb"); if (!f) fail(path); int c; while ((c = fgetc(f)) != EOF) b.push_back((char)c); fclose(f); return b; };
+        const std::vector<char> a_md = slurp(cube_md), a_vmd = slurp(cube_vmd);
+        if (a_md.size() < 1000 || a_md != a_vmd) fail("cube written through md_* names differs from vmd_export_cube");
+        remove(cube_md); remove(cube_vmd);
+    }
 
     // :952-953 interrupt while a task runs, then :960-964 free
     std::thread late([&] { md_script_eval_clear_data(full_eval); pool_task(full_eval, 0, (uint32_t)F, 2); });
