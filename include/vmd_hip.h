@@ -169,6 +169,7 @@ uint64_t vmd_hip_rdf_columns(int reset);
 int vmd_hip_bump_u64(void* stream, uint64_t* p, uint64_t value);
 /* DECISION(D-RDF-OPEN) as a switch: 1 = hit iff r_min <= d <= r_max in the pair kernels launched from now on; returns the old value */
 int vmd_hip_set_rdf_closed(int on);
+int vmd_hip_set_rdf_raw(int on);        /* vmd_hip_rdf_brute: positions enter the pair computation unwrapped, minimum image by rounding (oracle/SPEC.md D-WRAP flipped); per host thread; returns the previous value */
 
 /* XTC coordinate blocks decompressed on the device (the compressed bytes cross PCIe, not the floats): one
  * thread per frame walks its bit stream (frames are independent, a stream is strictly sequential).

@@ -317,7 +317,7 @@ class unwrap_tree:
 
 
 def set_spec(key, value):
-    """DECISION switch of SPEC.md ("rdf_closed", "sdf_include_self"); returns the previous value."""
+    """DECISION switch of SPEC.md ("rdf_closed", "sdf_include_self", "rdf_raw", "rdf_norm" = 0 / 1 / 2); returns the previous value."""
     L = lib()
     L.vo_set_spec.restype = C.c_int
     L.vo_set_spec.argtypes = [C.c_char_p, C.c_int]

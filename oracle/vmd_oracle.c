@@ -138,13 +138,21 @@ static vo_bin_t vo_bin_setup(float rmin, float rmax, int nbins) {
  * vmd_set_option("spec_...")): 0 = the default written in SPEC.md, 1 = the alternative mdlib may turn out to use. */
 static int g_spec_rdf_closed = 0;        /* D-RDF-OPEN: 1 = closed interval r_min <= d <= r_max (self pairs at d = 0 count when r_min = 0) */
 static int g_spec_sdf_include_self = 0;  /* D-SDF-EXCL: 1 = target atoms that belong to structure k are NOT skipped */
+static int g_spec_rdf_raw = 0;           /* D-WRAP: 1 = positions enter the pair computation as they are (no wrap into the cell); the minimum
+                                            image is taken by rounding, d = fmaf(-rintf(fl(d * fl(1/L))), L, d) per periodic axis (S3t for
+                                            triclinic cells takes unwrapped positions as it stands) */
+static int g_spec_rdf_norm = 0;          /* D-RDF-NORM: 0 = cell volume when fully periodic, else the cutoff sphere; 1 = always the cutoff
+                                            sphere; 2 = per reference atom (rho = N_tgt / V: the weights do not carry N_ref) */
 int vo_set_spec(const char* key, int value) {
     int* o = NULL;
+    int multi = 0;
     if (!strcmp(key, "rdf_closed")) o = &g_spec_rdf_closed;
     else if (!strcmp(key, "sdf_include_self")) o = &g_spec_sdf_include_self;
+    else if (!strcmp(key, "rdf_raw")) o = &g_spec_rdf_raw;
+    else if (!strcmp(key, "rdf_norm")) { o = &g_spec_rdf_norm; multi = 1; }
     if (!o) return -1;
     const int old = *o;
-    *o = value ? 1 : 0;
+    *o = multi ? value : (value ? 1 : 0);
     return old;
 }
 
@@ -182,8 +190,13 @@ uint64_t vo_rdf_frame_brute(const float* x, const float* y, const float* z, cons
     const vo_bin_t bn = vo_bin_setup(rmin, rmax, nbins);
     float* buf = (float*)malloc(sizeof(float) * 3 * (nref + ntgt) + 64);
     float *rx = buf, *ry = rx + nref, *rz = ry + nref, *tx = rz + nref, *ty = tx + ntgt, *tz = ty + ntgt;
-    vo_gather_wrapped(x, y, z, &bx, ref_idx, nref, rx, ry, rz);
-    vo_gather_wrapped(x, y, z, &bx, tgt_idx, ntgt, tx, ty, tz);
+    if (g_spec_rdf_raw) {
+        for (size_t i = 0; i < nref; ++i) { const int32_t a = ref_idx ? ref_idx[i] : (int32_t)i; rx[i] = x[a]; ry[i] = y[a]; rz[i] = z[a]; }
+        for (size_t i = 0; i < ntgt; ++i) { const int32_t a = tgt_idx ? tgt_idx[i] : (int32_t)i; tx[i] = x[a]; ty[i] = y[a]; tz[i] = z[a]; }
+    } else {
+        vo_gather_wrapped(x, y, z, &bx, ref_idx, nref, rx, ry, rz);
+        vo_gather_wrapped(x, y, z, &bx, tgt_idx, ntgt, tx, ty, tz);
+    }
     uint64_t hits = 0;
     for (size_t i = 0; i < nref; ++i) {
         const float xi = rx[i], yi = ry[i], zi = rz[i];
@@ -192,6 +205,10 @@ uint64_t vo_rdf_frame_brute(const float* x, const float* y, const float* z, cons
             if (bx.tri) {
                 const float si[3] = {xi, yi, zi}, sj[3] = {tx[j], ty[j], tz[j]};
                 d2 = vo_pair_d2_tri(&bx, si, sj);
+            } else if (g_spec_rdf_raw) {
+                float d[3] = {xi - tx[j], yi - ty[j], zi - tz[j]};
+                for (int a = 0; a < 3; ++a) if (bx.pbc[a]) d[a] = fmaf(-rintf(d[a] * bx.iL[a]), bx.L[a], d[a]);
+                d2 = vo_d2(d[0], d[1], d[2]);
             } else {
                 const float dx = vo_mi(xi - tx[j], bx.L[0], bx.hL[0], bx.pbc[0]);
                 const float dy = vo_mi(yi - ty[j], bx.L[1], bx.hL[1], bx.pbc[1]);
@@ -223,7 +240,7 @@ static inline int vo_cell_coord(float v, float org, float inv, int n) {
 uint64_t vo_rdf_frame_cells(const float* x, const float* y, const float* z, const vo_cell_t* cell,
                             const int32_t* ref_idx, size_t nref, const int32_t* tgt_idx, size_t ntgt,
                             float rmin, float rmax, int nbins, uint64_t* counts) {
-    if (vo_triclinic(cell)) return UINT64_MAX;       /* the grid is orthorhombic only: callers fall back to brute */
+    if (vo_triclinic(cell) || g_spec_rdf_raw) return UINT64_MAX;       /* the grid is orthorhombic, on wrapped positions only: callers fall back to brute */
     const vo_box_t bx = vo_box(cell);
     const vo_bin_t bn = vo_bin_setup(rmin, rmax, nbins);
     if (nref == 0 || ntgt == 0) return 0;
@@ -321,9 +338,9 @@ void vo_rdf_weights_frame(const vo_cell_t* cell, size_t nref, size_t ntgt, float
                           double* weights) {
     const vo_box_t bx = vo_box(cell);
     double V;
-    if (bx.pbc[0] && bx.pbc[1] && bx.pbc[2]) V = (double)bx.L[0] * (double)bx.L[1] * (double)bx.L[2];
+    if (bx.pbc[0] && bx.pbc[1] && bx.pbc[2] && g_spec_rdf_norm != 1) V = (double)bx.L[0] * (double)bx.L[1] * (double)bx.L[2];
     else V = (4.0 / 3.0) * VO_PI * (double)rmax * (double)rmax * (double)rmax;
-    const double rho = (double)nref * (double)ntgt / V;
+    const double rho = (g_spec_rdf_norm == 2 ? 1.0 : (double)nref) * (double)ntgt / V;
     const double w = ((double)rmax - (double)rmin) / (double)nbins;
     for (int b = 0; b < nbins; ++b) {
         const double r0 = (double)rmin + w * b;

@@ -1126,9 +1126,15 @@ def spec_switch_check(lib, oracle):
     members = structures.reshape(-1)
     tgt = np.unique(np.concatenate([o, members[::2]])).astype(np.int32)        # targets that ARE structure atoms: the exclusion rule matters
     F = coords.shape[0]
+    coords_default = coords
 
-    def product(**opts):
+    # the same system moved out of the cell: whole box lengths plus a fraction, a different shift per atom
+    rng = np.random.default_rng(17)
+    shifted = (coords + (rng.integers(-2, 3, size=(1, 3, N)) * np.float32(30.0) + rng.random((1, 3, N)).astype(np.float32) * np.float32(1e-3))).astype(np.float32)
+
+    def product(coords_override=None, **opts):
         old = {k: lib.vmd_set_option(("spec_" + k).encode(), v) for k, v in opts.items()}
+        coords = coords_override if coords_override is not None else coords_default
         try:
             ir = V.ScriptIR(lib)
             ir.add_rdf("g", o, o, 6.0)                                   # same set: half-shell pass
@@ -1137,7 +1143,9 @@ def spec_switch_check(lib, oracle):
             ir.add_distance("d", structures[0], structures[1], L.DIST_COM)
             ev = V.ScriptEval(F, ir)
             assert ev.frame_range(V.MolSystem(N, mass=mass, unitcell=cell), V.HostTrajectory(coords, cell), 0, F)
-            return {k: (ev.property_data(k).counts.copy() if k != "d" else None, np.array(ev.property_data(k).values)) for k in "ghvd"}
+            out = {k: (ev.property_data(k).counts.copy() if k != "d" else None, np.array(ev.property_data(k).values)) for k in "ghvd"}
+            out["hw"] = np.array(ev.property_data("h").weights64)
+            return out
         finally:
             for k, v in old.items():
                 lib.vmd_set_option(("spec_" + k).encode(), v)
@@ -1172,6 +1180,31 @@ def spec_switch_check(lib, oracle):
     scale = np.float32(1.0 / (F * edge ** 3))
     np.testing.assert_array_equal(got["v"][1], base["v"][0].astype(np.float32) * scale)
     assert got["v"][1].max() > 0 and not np.array_equal(got["v"][1], base["v"][1])
+    # --- D-RDF-NORM: the normalisation weights follow the setting, the counts never do
+    for mode in (1, 2):
+        got = product(rdf_norm=mode)
+        old = oracle.set_spec("rdf_norm", mode)
+        try:
+            _, want_w = oracle_rdf(oracle, coords, ocell, o[: o.size // 2], o, 0.0, 6.0)
+        finally:
+            oracle.set_spec("rdf_norm", old)
+        np.testing.assert_array_equal(got["h"][0], base["h"][0])
+        np.testing.assert_allclose(got["hw"], want_w, rtol=1e-12)
+        assert not np.allclose(got["hw"], base["hw"], rtol=1e-3)
+    # --- D-WRAP: positions as they are (here: shifted out of the cell by whole and fractional box lengths), minimum image by rounding
+    got = product(rdf_raw=1, coords_override=shifted)
+    old = oracle.set_spec("rdf_raw", 1)
+    try:
+        want_g, _ = oracle_rdf(oracle, shifted, ocell, o, o, 0.0, 6.0)
+        want_h, _ = oracle_rdf(oracle, shifted, ocell, o[: o.size // 2], o, 0.0, 6.0)
+    finally:
+        oracle.set_spec("rdf_raw", old)
+    np.testing.assert_array_equal(got["g"][0], want_g)
+    np.testing.assert_array_equal(got["h"][0], want_h)
+    wrapped_g = product(coords_override=shifted)["g"][0]
+    np.testing.assert_array_equal(wrapped_g, oracle_rdf(oracle, shifted, ocell, o, o, 0.0, 6.0)[0])
+    assert abs(int(got["g"][0].sum()) - int(wrapped_g.sum())) < 1e-4 * wrapped_g.sum()      # the same physics ...
+    assert not np.array_equal(got["g"][0], wrapped_g)                                       # ... in different roundings: some pair changes its bin
     # --- D-DIST-COM: geometric centres = the oracle's centre of mass with unit masses
     got = product(dist_geometric_com=1)
     want_d = oracle_distance(oracle, coords, ocell, np.ones_like(mass), structures[0], structures[1], L.DIST_COM)

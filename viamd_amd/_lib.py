@@ -287,6 +287,7 @@ SIGNATURES = [
     ("vmd_hip_rdf_columns", C.c_uint64, [C.c_int]),
     ("vmd_hip_set_sdf_nt", C.c_int, [C.c_int]),
     ("vmd_hip_set_rdf_closed", C.c_int, [C.c_int]),
+    ("vmd_hip_set_rdf_raw", C.c_int, [C.c_int]),
     ("vmd_hip_synth_frames", C.c_int, [_vp, _vp, C.c_size_t, C.c_size_t, C.c_int, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32,
                                        C.c_float, C.c_float]),
 ]

@@ -113,6 +113,10 @@ struct Options {
     std::atomic<int> spec_sdf_include_self{0};    // D-SDF-EXCL: targets that are atoms of structure k are scattered like any other
     std::atomic<int> spec_sdf_density{0};         // D-SDF-NORM: values = counts / (frames evaluated x voxel volume) instead of raw counts
     std::atomic<int> spec_dist_geometric_com{0};  // D-DIST-COM: distance(a, b) between geometric centres, not centres of mass
+    std::atomic<int> spec_rdf_raw{0};             // D-WRAP: positions enter rdf() as they are, minimum image by rounding - evaluated by k_rdf_brute (all pairs: a
+                                                  // setting for matching an mdlib that does it this way, not a fast path)
+    std::atomic<int> spec_rdf_norm{0};            // D-RDF-NORM: 0 = cell volume when fully periodic, else the cutoff sphere; 1 = always the cutoff sphere;
+                                                  // 2 = per reference atom (the weights do not carry N_ref)
     std::atomic<int> sdf_direct_view{1};          // k_counts_to_float writes the volume's float view into its pinned host pages itself
     std::atomic<int> stage_frames{128};      // frames per staged batch of a host / file trajectory (batch_frames <= 0)
     std::atomic<int> rdf_blocks_decode{1536};   // pair-kernel grid while batches are decompressed on the device: 6 blocks per CU leave every
@@ -184,6 +188,8 @@ extern "C" int vmd_set_option(const char* key, int value) {
     else if (!strcmp(key, "spec_sdf_include_self")) o = &g_opt.spec_sdf_include_self;
     else if (!strcmp(key, "spec_sdf_density")) o = &g_opt.spec_sdf_density;
     else if (!strcmp(key, "spec_dist_geometric_com")) o = &g_opt.spec_dist_geometric_com;
+    else if (!strcmp(key, "spec_rdf_raw")) o = &g_opt.spec_rdf_raw;
+    else if (!strcmp(key, "spec_rdf_norm")) o = &g_opt.spec_rdf_norm;
     else if (!strcmp(key, "rdf_blocks_decode")) o = &g_opt.rdf_blocks_decode;
     else if (!strcmp(key, "rdf_classes")) o = &g_opt.rdf_classes;
     else if (!strcmp(key, "readahead")) o = &g_opt.readahead;
@@ -1067,7 +1073,7 @@ struct vmd_script_eval_t {
         std::atomic<uint64_t> regions{0}, region_frames{0}, slow_calls{0}, settles{0}, direct_frames{0}, committed_blocks{0};
     } ra;
     vmd_reduce_stats_t reduce_stats = {};
-    struct Spec { bool rdf_closed = false, sdf_include_self = false, sdf_density = false, dist_geometric_com = false; } spec;   // fixed at creation
+    struct Spec { bool rdf_closed = false, sdf_include_self = false, sdf_density = false, dist_geometric_com = false, rdf_raw = false; int rdf_norm = 0; } spec;   // fixed at creation
     size_t atoms_checked = (size_t)-1;       // trajectory atom count the properties' indices were validated against (under mtx)
 };
 typedef vmd_script_eval_t::Stage Stage;
@@ -1195,6 +1201,8 @@ extern "C" vmd_script_eval_t* vmd_eval_create(size_t num_frames, const vmd_scrip
     e->spec.rdf_closed = g_opt.spec_rdf_closed.load() != 0;
     e->spec.sdf_include_self = g_opt.spec_sdf_include_self.load() != 0;
     e->spec.sdf_density = g_opt.spec_sdf_density.load() != 0;
+    e->spec.rdf_raw = g_opt.spec_rdf_raw.load() != 0;
+    e->spec.rdf_norm = g_opt.spec_rdf_norm.load();
     e->spec.dist_geometric_com = g_opt.spec_dist_geometric_com.load() != 0;
     e->frame_mask.assign(num_frames, 0);
     for (auto& p : ir->props) {
@@ -2601,6 +2609,7 @@ static bool process_range_locked(vmd_script_eval_t* eval, const vmd_system_t* sy
     auto launch_rdf = [&](BatchCtx& c) -> bool {
         VMD_STAGE("batch: cell build + pair kernels");
         vmd_hip_set_rdf_closed(e->spec.rdf_closed ? 1 : 0);
+        vmd_hip_set_rdf_raw(e->spec.rdf_raw ? 1 : 0);
         size_t scratch_rows = 0;
         for (auto& g : e->rdf_groups) scratch_rows += std::max(g.passes.size(), g.props.size());
         scratch_rows *= c.subs.size();
@@ -2617,7 +2626,7 @@ static bool process_range_locked(vmd_script_eval_t* eval, const vmd_system_t* sy
             if (open_axes && !g_opt.force_brute && !prepare_open_boxes(e, *c.src, c.nb, c.pbc, num_atoms)) return false;
             const std::vector<float>& gb = (open_axes && c.src->gboxes_ready) ? c.src->h_gboxes : c.src->h_boxes;
             const float* d_gb = (open_axes && c.src->gboxes_ready) ? c.src->d_gboxes.p : c.src->d_boxes.p;
-            if (!choose_grid(gb, c.pbc, c.nb, g.rmax, &grid)) {
+            if (e->spec.rdf_raw || !choose_grid(gb, c.pbc, c.nb, g.rmax, &grid)) {
                 // no grid for this batch (cutoff >= half the cell width, ...): all pairs, per property
                 for (int pi : g.props) {
                     PropState* p = e->props[pi].get();
@@ -2797,9 +2806,9 @@ static bool process_range_locked(vmd_script_eval_t* eval, const vmd_system_t* sy
                     for (size_t b = su.off; b < su.off + su.nb; ++b) {
                         const float* L = &c.src->h_boxes[9 * b];
                         double V;
-                        if ((c.pbc & VMD_UNITCELL_PBC_ALL) == VMD_UNITCELL_PBC_ALL) V = (double)L[0] * (double)L[1] * (double)L[2];   // also the triclinic volume
+                        if ((c.pbc & VMD_UNITCELL_PBC_ALL) == VMD_UNITCELL_PBC_ALL && e->spec.rdf_norm != 1) V = (double)L[0] * (double)L[1] * (double)L[2];   // also the triclinic volume
                         else V = (4.0 / 3.0) * M_PI * (double)d.rmax * (double)d.rmax * (double)d.rmax;
-                        const double rho = (double)d.a.size() * (double)d.b.size() / V;
+                        const double rho = (e->spec.rdf_norm == 2 ? 1.0 : (double)d.a.size()) * (double)d.b.size() / V;
                         const double w = ((double)d.rmax - (double)d.rmin) / (double)p->ncounts;
                         for (size_t k = 0; k < p->ncounts; ++k) {
                             const double r0 = (double)d.rmin + w * (double)k;

@@ -238,6 +238,8 @@ struct vmd_binning_t {
 };
 static thread_local int g_rdf_closed = 0;       // per host thread: set from the eval's spec right before that thread's launches (two evals with different specs on two threads must not race)
 extern "C" int vmd_hip_set_rdf_closed(int on) { const int old = g_rdf_closed; g_rdf_closed = on ? 1 : 0; return old; }
+static thread_local int g_rdf_raw = 0;          // k_rdf_brute: positions unwrapped, minimum image by rounding (DECISION D-WRAP flipped); per host thread like g_rdf_closed
+extern "C" int vmd_hip_set_rdf_raw(int on) { const int old = g_rdf_raw; g_rdf_raw = on ? 1 : 0; return old; }
 __host__ __device__ inline vmd_binning_t vmd_make_binning(float rmin, float rmax, int nbins, int closed = 0) {
     vmd_binning_t b;
     b.closed = closed;
@@ -1760,6 +1762,7 @@ struct vmd_brute_params_t {
     const int32_t* ref; int nref; const int32_t* tgt; int ntgt;
     vmd_binning_t bin;
     uint64_t* counts;
+    int raw;            // DECISION(D-WRAP) flipped: positions as they are, minimum image by rounding (oracle: vo_set_spec("rdf_raw", 1))
 };
 
 __global__ __launch_bounds__(256) void k_rdf_brute(vmd_brute_params_t p) {
@@ -1776,20 +1779,28 @@ __global__ __launch_bounds__(256) void k_rdf_brute(vmd_brute_params_t p) {
     const bool valid = t < p.nref;
     if (valid) {
         const int a = p.ref ? p.ref[t] : t;
-        vmd_pair_coords(bx, fx[a], fy[a], fz[a], xi, yi, zi);
+        if (p.raw) { xi = fx[a]; yi = fy[a]; zi = fz[a]; }
+        else vmd_pair_coords(bx, fx[a], fy[a], fz[a], xi, yi, zi);
     }
     for (int j0 = 0; j0 < p.ntgt; j0 += 256) {
         __syncthreads();
         const int j = j0 + threadIdx.x;
         if (j < p.ntgt) {
             const int a = p.tgt ? p.tgt[j] : j;
-            vmd_pair_coords(bx, fx[a], fy[a], fz[a], s_t[0][threadIdx.x], s_t[1][threadIdx.x], s_t[2][threadIdx.x]);
+            if (p.raw) { s_t[0][threadIdx.x] = fx[a]; s_t[1][threadIdx.x] = fy[a]; s_t[2][threadIdx.x] = fz[a]; }
+            else vmd_pair_coords(bx, fx[a], fy[a], fz[a], s_t[0][threadIdx.x], s_t[1][threadIdx.x], s_t[2][threadIdx.x]);
         }
         __syncthreads();
         const int nj = p.ntgt - j0 < 256 ? p.ntgt - j0 : 256;
         if (valid) {
             for (int jj = 0; jj < nj; ++jj) {
-                const int bin = vmd_bin_of(p.bin, vmd_pair_d2_general(bx, xi, yi, zi, s_t[0][jj], s_t[1][jj], s_t[2][jj]));
+                float d2;
+                if (p.raw && !bx.tri) {
+                    float dx = xi - s_t[0][jj], dy = yi - s_t[1][jj], dz = zi - s_t[2][jj];
+                    dx = vmd_mi_rintf(dx, bx.Lx, bx.iLx, bx.px); dy = vmd_mi_rintf(dy, bx.Ly, bx.iLy, bx.py); dz = vmd_mi_rintf(dz, bx.Lz, bx.iLz, bx.pz);
+                    d2 = vmd_d2(dx, dy, dz);
+                } else d2 = vmd_pair_d2_general(bx, xi, yi, zi, s_t[0][jj], s_t[1][jj], s_t[2][jj]);      // S3t takes positions as they come
+                const int bin = vmd_bin_of(p.bin, d2);
                 if (bin >= 0) atomicAdd(&s_hist[bin], 1u);
             }
         }
@@ -2741,7 +2752,7 @@ extern "C" int vmd_hip_rdf_brute(void* stream, const float* xyz, size_t frame_st
     hipStream_t s = (hipStream_t)stream;
     if (nbins <= 0 || nbins > VMD_MAX_BINS) return (int)hipErrorInvalidValue;
     if (B <= 0 || nref <= 0 || ntgt <= 0) return 0;
-    vmd_brute_params_t p{xyz, frame_stride, row_stride, boxes, pbc_flags, B, ref, nref, tgt, ntgt, {}, counts};
+    vmd_brute_params_t p{xyz, frame_stride, row_stride, boxes, pbc_flags, B, ref, nref, tgt, ntgt, {}, counts, g_rdf_raw};
     p.bin = vmd_make_binning(rmin, rmax, nbins, g_rdf_closed);
     hipLaunchKernelGGL(k_rdf_brute, dim3((nref + 255) / 256, B), dim3(256), 0, s, p);
     VMD_LAUNCH_CHECK();
