@@ -21,48 +21,62 @@ static bool exp_fail(const std::string& msg) {
     return false;
 }
 
-// src/main.cpp:5640-5683
-extern "C" bool vmd_export_xvg(const char* path, const float* const* columns, const char* const* labels, size_t num_columns, size_t num_rows) {
-    if (!path || !columns || !labels) return exp_fail("vmd_export_xvg: NULL argument");
-    FILE* f = fopen(path, "w");
-    if (!f) return exp_fail(std::string("Failed to open file '") + path + "' to write data.");
-    time_t t;
-    time(&t);
-    struct tm tmv;
-    char tbuf[64];
-    localtime_r(&t, &tmv);
-    fprintf(f, "# This file was created %s", asctime_r(&tmv, tbuf));
-    fprintf(f, "# Created by:\n");
-    fprintf(f, "# VIAMD \n");
-    fprintf(f, "@    title \"VIAMD Properties\"\n");
-    fprintf(f, "@    xaxis  label \"Time\"\n");
-    fprintf(f, "@ TYPE xy\n");
-    fprintf(f, "@ view 0.15, 0.15, 0.75, 0.85\n");
-    fprintf(f, "@ legend on\n");
-    fprintf(f, "@ legend box on\n");
-    fprintf(f, "@ legend loctype view\n");
-    fprintf(f, "@ legend 0.78, 0.8\n");
-    fprintf(f, "@ legend length %i\n", (int)num_columns);
-    for (size_t j = 0; j < num_columns; ++j) fprintf(f, "@ s%zu legend \"%s\"\n", j, labels[j]);
-    for (size_t i = 0; i < num_rows; ++i) {
-        for (size_t j = 0; j < num_columns; ++j) fprintf(f, "%12.6f ", columns[j][i]);
-        fprintf(f, "\n");
-    }
-    return fclose(f) == 0 ? true : exp_fail(std::string("writing '") + path + "' failed");
-}
+// ---- text tables.  XVG and CSV differ in a preamble, a cell format and nothing else: one emitter, two dialects.  The byte layout of
+// each dialect is the reference's (src/main.cpp:5640-5683 xvg, :5685-5716 csv) so that exported files diff clean against VIAMD's.
+namespace {
+struct OutFile {
+    FILE* f = nullptr;
+    std::string path;
+    explicit OutFile(const char* p) : f(fopen(p, "w")), path(p) {}
+    ~OutFile() { if (f) fclose(f); }
+    bool finish() { const bool ok = f && fclose(f) == 0; f = nullptr; return ok ? true : exp_fail("writing '" + path + "' failed"); }
+};
+struct TableDialect {
+    const char* cell;                 // one value
+    const char* label_cell;           // one label of the heading row (NULL: labels go into the preamble instead)
+    const char* const* preamble;      // fixed lines in front of the labels, NULL-terminated
+    const char* legend_count;         // "... %i" line announcing the number of columns (NULL: none)
+    const char* legend_entry;         // per column: index + label (NULL: none)
+    bool stamp;                       // first line carries the creation time
+};
+const char* const kXvgPreamble[] = {"# Created by:\n", "# VIAMD \n", "@    title \"VIAMD Properties\"\n", "@    xaxis  label \"Time\"\n", "@ TYPE xy\n",
+                                    "@ view 0.15, 0.15, 0.75, 0.85\n", "@ legend on\n", "@ legend box on\n", "@ legend loctype view\n", "@ legend 0.78, 0.8\n", nullptr};
+const char* const kNoPreamble[] = {nullptr};
+const TableDialect kXvg = {"%12.6f ", nullptr, kXvgPreamble, "@ legend length %i\n", "@ s%zu legend \"%s\"\n", true};
+const TableDialect kCsv = {"%.6g,", "%s,", kNoPreamble, nullptr, nullptr, false};
 
-// src/main.cpp:5685-5716
-extern "C" bool vmd_export_csv(const char* path, const float* const* columns, const char* const* labels, size_t num_columns, size_t num_rows) {
-    if (!path || !columns || !labels) return exp_fail("vmd_export_csv: NULL argument");
-    FILE* f = fopen(path, "w");
-    if (!f) return exp_fail(std::string("Failed to open file '") + path + "' to write data.");
-    for (size_t i = 0; i < num_columns; ++i) fprintf(f, "%s,", labels[i]);
-    fprintf(f, "\n");
-    for (size_t i = 0; i < num_rows; ++i) {
-        for (size_t j = 0; j < num_columns; ++j) fprintf(f, "%.6g,", columns[j][i]);
-        fprintf(f, "\n");
+bool write_table(const char* who, const TableDialect& d, const char* path, const float* const* columns, const char* const* labels, size_t ncol, size_t nrow) {
+    if (!path || !columns || !labels) return exp_fail(std::string(who) + ": NULL argument");
+    OutFile out(path);
+    if (!out.f) return exp_fail(std::string("Failed to open file '") + path + "' to write data.");
+    if (d.stamp) {
+        time_t now;
+        time(&now);
+        struct tm parts;
+        char text[64];
+        localtime_r(&now, &parts);
+        fprintf(out.f, "# This file was created %s", asctime_r(&parts, text));
     }
-    return fclose(f) == 0 ? true : exp_fail(std::string("writing '") + path + "' failed");
+    for (const char* const* line = d.preamble; *line; ++line) fputs(*line, out.f);
+    if (d.legend_count) fprintf(out.f, d.legend_count, (int)ncol);
+    for (size_t c = 0; c < ncol; ++c) {
+        if (d.legend_entry) fprintf(out.f, d.legend_entry, c, labels[c]);
+        if (d.label_cell) fprintf(out.f, d.label_cell, labels[c]);
+    }
+    if (d.label_cell) fputc('\n', out.f);
+    for (size_t r = 0; r < nrow; ++r) {
+        for (size_t c = 0; c < ncol; ++c) fprintf(out.f, d.cell, columns[c][r]);
+        fputc('\n', out.f);
+    }
+    return out.finish();
+}
+}  // namespace
+
+extern "C" bool vmd_export_xvg(const char* path, const float* const* columns, const char* const* labels, size_t num_columns, size_t num_rows) {
+    return write_table("vmd_export_xvg", kXvg, path, columns, labels, num_columns, num_rows);
+}
+extern "C" bool vmd_export_csv(const char* path, const float* const* columns, const char* const* labels, size_t num_columns, size_t num_rows) {
+    return write_table("vmd_export_csv", kCsv, path, columns, labels, num_columns, num_rows);
 }
 
 // the table draw_property_export_window builds for one property (src/main.cpp:5953-6040): temporal -> time column + one column
@@ -127,7 +141,26 @@ extern "C" bool vmd_eval_sdf_payload(vmd_script_eval_t* eval, const char* name, 
     return true;
 }
 
-// export_cube, src/main.cpp:5718-5830
+// Gaussian cube file of a volume (the format of export_cube, src/main.cpp:5718-5830: two comment lines, an atom count and origin line, one
+// line per axis, the atoms of reference structure 0 in the volume's frame, a density-count line, then the voxels x-outermost / z-innermost,
+// six per line).  Everything spatial is in Bohr.  Built as: a geometry record -> header rows from a table -> atoms -> a strided walk.
+namespace {
+constexpr double kBohrPerAngstrom = 1.0 / 0.529177210903;
+struct CubeGeometry {
+    int n[3];                 // voxels per axis
+    double step[3];           // voxel edge per axis, Bohr
+    double corner;            // -half edge of the cube, Bohr (the same on all axes)
+};
+CubeGeometry cube_geometry(const vmd_script_property_data_t* pd, float half_extent_angstrom) {
+    CubeGeometry g;
+    const float to_bohr = (float)kBohrPerAngstrom;                          // the reference scales in fp32 first (vis.sdf.extent * 2.0 * angstrom_to_bohr)
+    const double edge = half_extent_angstrom * 2.0 * to_bohr;
+    for (int a = 0; a < 3; ++a) { g.n[a] = pd->dim[1 + a]; g.step[a] = edge / (double)g.n[a]; }
+    g.corner = -(edge * 0.5);
+    return g;
+}
+}  // namespace
+
 extern "C" bool vmd_export_cube(const char* path, vmd_script_eval_t* eval, const char* name, const vmd_system_t* sys, vmd_trajectory_i* traj,
                                 uint32_t frame, const uint8_t* atomic_numbers) {
     if (!path || !eval || !name || !traj) return exp_fail("vmd_export_cube: NULL argument");
@@ -136,54 +169,57 @@ extern "C" bool vmd_export_cube(const char* path, vmd_script_eval_t* eval, const
     vmd_sdf_payload_t vis;
     if (!vmd_eval_sdf_payload(eval, name, sys, traj, frame, &vis)) return exp_fail(std::string("Failed to visualize volume for export. ") + vmd_last_error());
     if (!vmd_eval_finalize(eval)) return false;         // the float view VIAMD reads (prop_data->values) is current
-    // the atoms block is written from the coordinates of trajectory frame 0 (src/main.cpp:5741-5748)
+    // the atoms are placed from the coordinates of trajectory frame 0 (src/main.cpp:5741-5748)
     const size_t N = traj->num_atoms(traj->inst);
     std::vector<float> xyz(3 * N);
     vmd_frame_header_t hdr;
     memset(&hdr, 0, sizeof(hdr));
     if (!traj->load_frame(traj->inst, 0, &hdr, xyz.data(), xyz.data() + N, xyz.data() + 2 * N)) return exp_fail("Export Cube: loading frame 0 failed");
-    FILE* f = fopen(path, "w");
-    if (!f) return exp_fail(std::string("Failed to open file '") + path + "' in order to write to it.");
-    fprintf(f, "EXPORTED DENSITY VOLUME FROM VIAMD, UNITS IN BOHR\n");
-    fprintf(f, "OUTER LOOP: X, MIDDLE LOOP: Y, INNER LOOP: Z\n");
+    // a structure is a bitfield in VIAMD: its atoms come out once each, in ascending index order
+    std::vector<int32_t> members;
     if (vis.num_structures > 0) {
-        const float angstrom_to_bohr = (float)(1.0 / 0.529177210903);
-        // a structure is a bitfield in VIAMD: its atoms come out in ascending index order
-        std::vector<int32_t> atoms(vis.structures, vis.structures + vis.atoms_per_structure);
-        std::sort(atoms.begin(), atoms.end());
-        atoms.erase(std::unique(atoms.begin(), atoms.end()), atoms.end());
-        if (!atoms.empty() && (atoms.front() < 0 || (size_t)atoms.back() >= N)) {
-            fclose(f);
+        members.assign(vis.structures, vis.structures + vis.atoms_per_structure);
+        std::sort(members.begin(), members.end());
+        members.erase(std::unique(members.begin(), members.end()), members.end());
+        if (!members.empty() && (members.front() < 0 || (size_t)members.back() >= N))
             return exp_fail("Export Cube: a reference structure refers to atoms the trajectory does not have");
-        }
-        const int num_atoms = (int)atoms.size();
-        const int vol_dim[3] = {pd->dim[1], pd->dim[2], pd->dim[3]};
-        const double extent = vis.extent * 2.0 * angstrom_to_bohr;
-        const double voxel_ext[3] = {extent / (double)vol_dim[0], extent / (double)vol_dim[1], extent / (double)vol_dim[2]};
-        const double half_ext = extent * 0.5;
-        fprintf(f, "%5i %12.6f %12.6f %12.6f\n", -num_atoms, -half_ext, -half_ext, -half_ext);
-        fprintf(f, "%5i %12.6f %12.6f %12.6f\n", vol_dim[0], voxel_ext[0], 0.0, 0.0);
-        fprintf(f, "%5i %12.6f %12.6f %12.6f\n", vol_dim[1], 0.0, voxel_ext[1], 0.0);
-        fprintf(f, "%5i %12.6f %12.6f %12.6f\n", vol_dim[2], 0.0, 0.0, voxel_ext[2]);
-        // M = scale(angstrom_to_bohr) * matrices[0]; column-major mat4
-        const float* M = vis.matrices;
-        for (int32_t i : atoms) {
-            const float x = xyz[i], y = xyz[N + i], z = xyz[2 * N + i];
-            float c[3];
-            for (int r = 0; r < 3; ++r)
-                c[r] = (angstrom_to_bohr * M[0 + r]) * x + (angstrom_to_bohr * M[4 + r]) * y + (angstrom_to_bohr * M[8 + r]) * z + (angstrom_to_bohr * M[12 + r]);
-            const int anum = atomic_numbers ? (int)atomic_numbers[i] : 0;
-            fprintf(f, "%5i %12.6f %12.6f %12.6f %12.6f\n", anum, (float)anum, c[0], c[1], c[2]);
-        }
-        fprintf(f, "%5i %5i\n", 1, 1);
-        int count = 0;
-        for (int x = 0; x < vol_dim[0]; ++x)
-            for (int y = 0; y < vol_dim[1]; ++y)
-                for (int z = 0; z < vol_dim[2]; ++z) {
-                    const size_t idx = (size_t)z * vol_dim[0] * vol_dim[1] + (size_t)y * vol_dim[0] + x;
-                    fprintf(f, " %12.6E", pd->values[idx]);
-                    if (++count % 6 == 0) fprintf(f, "\n");
-                }
     }
-    return fclose(f) == 0 ? true : exp_fail(std::string("writing '") + path + "' failed");
+    OutFile out(path);
+    if (!out.f) return exp_fail(std::string("Failed to open file '") + path + "' in order to write to it.");
+    fputs("EXPORTED DENSITY VOLUME FROM VIAMD, UNITS IN BOHR\n", out.f);
+    fputs("OUTER LOOP: X, MIDDLE LOOP: Y, INNER LOOP: Z\n", out.f);
+    if (vis.num_structures == 0) return out.finish();
+    const CubeGeometry g = cube_geometry(pd, vis.extent);
+    // header: {count, three reals} per row - the origin row (minus the atom count: "the file holds one density per voxel"), then one row
+    // per axis with that axis' voxel edge on the diagonal
+    const struct { int count; double v[3]; } rows[4] = {
+        {-(int)members.size(), {g.corner, g.corner, g.corner}},
+        {g.n[0], {g.step[0], 0.0, 0.0}},
+        {g.n[1], {0.0, g.step[1], 0.0}},
+        {g.n[2], {0.0, 0.0, g.step[2]}},
+    };
+    for (const auto& r : rows) fprintf(out.f, "%5i %12.6f %12.6f %12.6f\n", r.count, r.v[0], r.v[1], r.v[2]);
+    // atoms: world -> reference frame of structure 0 (column-major mat4), every matrix element scaled to Bohr in fp32 before it is used
+    const float s = (float)kBohrPerAngstrom;
+    const float* M = vis.matrices;
+    for (int32_t atom : members) {
+        const float p[3] = {xyz[atom], xyz[N + atom], xyz[2 * N + atom]};
+        float q[3];
+        for (int r = 0; r < 3; ++r) q[r] = (s * M[0 + r]) * p[0] + (s * M[4 + r]) * p[1] + (s * M[8 + r]) * p[2] + (s * M[12 + r]);
+        const int z = atomic_numbers ? (int)atomic_numbers[atom] : 0;
+        fprintf(out.f, "%5i %12.6f %12.6f %12.6f %12.6f\n", z, (float)z, q[0], q[1], q[2]);
+    }
+    fprintf(out.f, "%5i %5i\n", 1, 1);
+    // voxels: the array is x-fastest, the file z-fastest: walk the array with strides (1, nx, nx * ny) in file order
+    const size_t stride[3] = {1, (size_t)g.n[0], (size_t)g.n[0] * (size_t)g.n[1]};
+    size_t written = 0;
+    for (int ix = 0; ix < g.n[0]; ++ix)
+        for (int iy = 0; iy < g.n[1]; ++iy) {
+            const float* row = pd->values + ix * stride[0] + iy * stride[1];
+            for (int iz = 0; iz < g.n[2]; ++iz) {
+                fprintf(out.f, " %12.6E", row[iz * stride[2]]);
+                if (++written % 6 == 0) fputc('\n', out.f);
+            }
+        }
+    return out.finish();
 }
