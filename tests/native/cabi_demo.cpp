@@ -59,6 +59,10 @@ int main(int argc, char** argv) {
                     const uint32_t beg = next.fetch_add(4);
                     if (beg >= F) break;
                     const uint32_t end = beg + 4 < F ? beg + 4 : (uint32_t)F;
+                    // the interrupt arrives while the task is half way through its ranges (VIAMD: a script edit, src/main.cpp:984).  Raised from
+                    // the thread that pulls the middle range, not from a poll of frames_done: with read-ahead the frames of a short trajectory are
+                    // evaluated in one region and committed together, so progress is not a clock any more
+                    if (interrupt_midway && beg == (uint32_t)(F / 2) / 4 * 4) vmd_eval_interrupt(eval);
                     if (!vmd_eval_frame_range(eval, ir, &sys, traj, beg, end)) break;      // false: interrupted
                 }
                 running -= 1;
@@ -67,7 +71,6 @@ int main(int argc, char** argv) {
         uint64_t fp = pd->fingerprint;
         while (running.load() > 0) {                         // the GUI thread: poll fingerprints, read (possibly torn) values
             if (pd->fingerprint != fp) { fp = pd->fingerprint; changes += 1; volatile float v = pd->values[100]; (void)v; }
-            if (interrupt_midway && vmd_eval_frames_done(eval) >= F / 4) vmd_eval_interrupt(eval);
             polls += 1;
             std::this_thread::sleep_for(std::chrono::microseconds(200));
         }

@@ -1,0 +1,148 @@
+// tests/native/stress_readahead.cpp - read-ahead under real thread concurrency: C++ pool threads with random thread counts,
+// grains, sub-ranges, hand-out orders, block sizes and region sizes, an occasional large direct call in the middle of the small ones, an
+// occasional interrupt + restart.  After every evaluation the eval must hold - bit for bit - what ONE call over the same frames leaves on a
+// fresh eval with read-ahead switched off: the RDF bins (u64), the normalisation weights, the temporal rows of the evaluated frames, the
+// frame mask and frames_done.  Python threads (tests/cases.py: readahead_case) take turns on the GIL; these do not.
+// usage: stress_readahead [iterations = 60] [frames = 96] [atoms = 1500] [seed = 1];  prints "OK iterations=<n> ..." and exits 0.
+#include <algorithm>
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <thread>
+#include <vector>
+
+#include "vmd_eval.h"
+
+static int g_iter = 0;
+static void fail(const char* what) {
+    std::fprintf(stderr, "FAIL in iteration %d: %s (%s)\n", g_iter, what, vmd_last_error());
+    std::exit(1);
+}
+
+struct Snapshot {
+    std::vector<uint64_t> counts;
+    std::vector<double> weights;
+    std::vector<float> temporal;
+    std::vector<uint8_t> mask;
+    size_t done = 0;
+};
+
+static Snapshot snapshot(vmd_script_eval_t* e, size_t F) {
+    Snapshot s;
+    const vmd_script_property_data_t* g = vmd_eval_property_data(e, "g");
+    const vmd_script_property_data_t* d = vmd_eval_property_data(e, "d");
+    s.counts.assign(g->counts, g->counts + g->dim[2]);
+    s.weights.assign(g->weights64, g->weights64 + g->dim[2]);
+    s.mask.assign(vmd_eval_frame_mask(e), vmd_eval_frame_mask(e) + F);
+    s.temporal.assign(d->values, d->values + (size_t)d->dim[0] * (size_t)d->dim[1]);
+    for (size_t f = 0; f < F; ++f) if (!s.mask[f]) for (int i = 0; i < d->dim[1]; ++i) s.temporal[f * (size_t)d->dim[1] + (size_t)i] = 0.0f;   // rows nobody asked for: whatever
+    s.done = vmd_eval_frames_done(e);
+    // the float views follow from the integers: check them where they are cheap to predict
+    for (int b = 0; b < g->dim[2]; ++b) if (g->values[b] != (float)g->counts[b]) fail("values[] is not (float)counts[]");
+    return s;
+}
+
+int main(int argc, char** argv) {
+    const int iterations = argc > 1 ? std::atoi(argv[1]) : 60;
+    const size_t F = argc > 2 ? (size_t)std::atoi(argv[2]) : 96;
+    const size_t N = argc > 3 ? (size_t)std::atoi(argv[3]) : 1500;
+    std::mt19937 rng(argc > 4 ? (unsigned)std::atoi(argv[4]) : 1u);
+    const float L = 30.0f * std::cbrt((float)N / 1500.0f);
+    if (vmd_device_count() <= 0) fail("no HIP device");
+    vmd_devtraj_t* dt = vmd_devtraj_create(F, N);
+    if (!dt || !vmd_devtraj_synth(dt, 3, L, 0.05f, 0, 0, F)) fail("synthetic trajectory");
+    vmd_trajectory_i* traj = vmd_devtraj_interface(dt);
+    std::vector<int32_t> oxy;
+    for (size_t i = 0; i < N; i += 3) oxy.push_back((int32_t)i);
+    vmd_script_ir_t* ir = vmd_ir_create();
+    const int32_t a[3] = {0, 1, 2}, b[3] = {30, 31, 32};
+    if (!vmd_ir_add_rdf(ir, "g", oxy.data(), oxy.size(), oxy.data(), oxy.size(), 0.0f, 9.0f)) fail("add_rdf");
+    if (!vmd_ir_add_distance(ir, "d", VMD_DISTANCE_MIN, a, 3, b, 3)) fail("add_distance");
+    vmd_system_t sys = {};
+    sys.atom_count = N;
+    vmd_set_option("readahead_company_us", 20000);
+
+    auto reference = [&](uint32_t lo, uint32_t hi) {
+        const int old = vmd_set_option("readahead", 0);
+        vmd_script_eval_t* e = vmd_eval_create(F, ir);
+        if (!e || !vmd_eval_frame_range(e, ir, &sys, traj, lo, hi)) fail("reference evaluation");
+        Snapshot s = snapshot(e, F);
+        vmd_eval_free(e);
+        vmd_set_option("readahead", old);
+        return s;
+    };
+    auto same = [&](const Snapshot& got, const Snapshot& want, const char* what) {
+        if (got.done != want.done || got.mask != want.mask) { std::fprintf(stderr, "frames_done %zu, wanted %zu\n", got.done, want.done); fail(what); }
+        if (got.counts != want.counts) fail(what);
+        if (got.temporal != want.temporal) fail(what);
+        for (size_t k = 0; k < got.weights.size(); ++k) {
+            const double d = got.weights[k] - want.weights[k];
+            if (std::abs(d) > 1e-12 * std::abs(want.weights[k])) fail(what);
+        }
+    };
+    // calls of `grain` frames over [lo, hi) handed to nthreads threads in the order of `starts`; stop_after >= 0: interrupt once that many calls were handed out
+    auto pooled = [&](vmd_script_eval_t* e, const std::vector<uint32_t>& starts, uint32_t grain, uint32_t hi, int nthreads, long stop_after) {
+        std::atomic<size_t> next{0};
+        std::atomic<int> failures{0};
+        std::vector<std::thread> pool;
+        for (int t = 0; t < nthreads; ++t)
+            pool.emplace_back([&] {
+                for (;;) {
+                    const size_t k = next.fetch_add(1);
+                    if (k >= starts.size()) break;
+                    if (stop_after >= 0 && (long)k == stop_after) vmd_eval_interrupt(e);
+                    const uint32_t fb = starts[k], fe = std::min(hi, fb + grain);
+                    if (!vmd_eval_frame_range(e, ir, &sys, traj, fb, fe)) { if (vmd_last_error()[0]) failures += 1; if (stop_after < 0) failures += 1; }
+                }
+            });
+        for (auto& th : pool) th.join();
+        return failures.load();
+    };
+
+    uint64_t regions = 0, direct = 0, blocks = 0, settles = 0;
+    vmd_script_eval_t* eval = vmd_eval_create(F, ir);       // reused across iterations like VIAMD reuses an eval across re-evaluations
+    for (g_iter = 0; g_iter < iterations; ++g_iter) {
+        const int nthreads = 2 + (int)(rng() % 15);
+        const uint32_t grain = (uint32_t[]){1, 1, 1, 2, 3, 5}[rng() % 6];
+        uint32_t lo = 0, hi = (uint32_t)F;
+        if (rng() % 3 == 0) { lo = (uint32_t)(rng() % (F / 2)); hi = lo + 1 + (uint32_t)(rng() % (F - lo)); }
+        const int order = (int)(rng() % 3);
+        const bool fresh = rng() % 4 == 0;                   // a new eval (new block size) now and then
+        if (fresh) {
+            vmd_eval_free(eval);
+            vmd_set_option("readahead_block", (int[]){0, 4, 8, 16}[rng() % 4]);
+            vmd_set_option("readahead_frames", (int[]){8, 16, 128}[rng() % 3]);
+            vmd_set_option("readahead_growth", (int[]){1, 2, 4}[rng() % 3]);
+            eval = vmd_eval_create(F, ir);
+            if (!eval) fail("vmd_eval_create");
+        }
+        std::vector<uint32_t> starts;
+        for (uint32_t f = lo; f < hi; f += grain) starts.push_back(f);
+        if (order == 1) std::reverse(starts.begin(), starts.end());
+        if (order == 2) std::shuffle(starts.begin(), starts.end(), rng);
+        vmd_eval_clear_data(eval);
+        if (rng() % 5 == 0) {                                 // interrupted somewhere, then restarted from scratch (src/main.cpp:984-990)
+            if (pooled(eval, starts, grain, hi, nthreads, (long)(rng() % starts.size())) != 0) fail("an interrupted evaluation reported an error");
+            if (vmd_eval_frames_done(eval) > (size_t)(hi - lo)) fail("an interrupted evaluation counted frames nobody asked for");
+            vmd_eval_clear_data(eval);
+        }
+        const bool split = rng() % 4 == 0 && hi - lo > 8;     // the second half of the range arrives as ONE large call while the pool works on the first
+        const uint32_t mid = split ? lo + (hi - lo) / 2 / grain * grain : hi;
+        if (split) starts.erase(std::remove_if(starts.begin(), starts.end(), [&](uint32_t f) { return f >= mid; }), starts.end());
+        std::thread big;
+        std::atomic<int> big_ok{1};
+        if (split) big = std::thread([&] { if (!vmd_eval_frame_range(eval, ir, &sys, traj, mid, hi)) big_ok = 0; });
+        if (pooled(eval, starts, grain, mid, nthreads, -1) != 0) fail("a call failed");
+        if (split) { big.join(); if (!big_ok) fail("the large call failed"); }
+        same(snapshot(eval, F), reference(lo, hi), "pooled evaluation differs from one call over the same range");
+        vmd_readahead_stats_t st;
+        vmd_eval_readahead_stats(eval, &st);
+        regions = st.regions; direct = st.direct_frames; blocks = st.committed_blocks; settles = st.settles;
+    }
+    vmd_eval_free(eval); vmd_ir_free(ir); vmd_devtraj_free(dt);
+    std::printf("OK iterations=%d frames=%zu (last eval: %llu regions, %llu blocks committed, %llu frames evaluated directly, %llu settles)\n", iterations, F,
+                (unsigned long long)regions, (unsigned long long)blocks, (unsigned long long)direct, (unsigned long long)settles);
+    return 0;
+}

@@ -179,3 +179,28 @@ def test_evaluator_life_cycle_stress(gpu_lib, tmp_path):
     out = subprocess.run([exe, "200", "48"], capture_output=True, text=True, timeout=900, env=dict(os.environ, AMD_LOG_LEVEL="1"))
     assert out.returncode == 0, (out.stdout[-500:], out.stderr[-3000:])
     assert out.stdout.strip().split("\n")[-1].startswith("OK iterations=200"), out.stdout[-500:]
+
+
+RA_STRESS_SRC = os.path.join(ROOT, "tests", "native", "stress_readahead.cpp")
+
+
+def test_read_ahead_stress_on_the_emulator(tmp_path, emu_lib):
+    """tests/native/stress_readahead.cpp: C++ pool threads (2 - 16 of them, no GIL) with random grains, sub-ranges, hand-out orders, block and
+    region sizes, a large direct call amid the small ones, interrupts + restarts - after every evaluation the eval holds bit for bit what
+    one call over the same frames leaves with read-ahead off.  A few iterations here; the long runs are `-m gpu`."""
+    import conftest
+    exe = _build_against(conftest.build_emu(), RA_STRESS_SRC, str(tmp_path / "stress_ra_emu"), "-O1")
+    out = subprocess.run([exe, "8", "40", "900", "7"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.startswith("OK iterations=8"), out.stdout
+
+
+@pytest.mark.gpu
+def test_read_ahead_stress(gpu_lib, tmp_path):
+    """400 randomised pool evaluations of a 30 000-atom box (240 frames) on the MI355X, three seeds"""
+    from viamd_amd import build
+    exe = _build_against(build.build(), RA_STRESS_SRC, str(tmp_path / "stress_ra"))
+    for seed in ("1", "2", "3"):
+        out = subprocess.run([exe, "400", "240", "30000", seed], capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, (out.stdout[-500:], out.stderr[-3000:])
+        assert out.stdout.strip().split("\n")[-1].startswith("OK iterations=400"), out.stdout[-500:]
