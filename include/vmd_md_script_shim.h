@@ -69,6 +69,8 @@ struct Registry {
      * of an sdf() live behind vmd_eval_sdf_payload */
     std::map<std::pair<const void*, std::string>, std::unique_ptr<md_script_vis_payload_o>> payloads;
     std::map<const void*, PayloadEval> payload_evals;
+    /* md_trajectory_i* -> the backend's own interface for the same frames (vmd_shim_bind_trajectory) */
+    std::map<const void*, vmd_trajectory_i*> native_traj;
 };
 inline Registry& registry() { static Registry r; return r; }
 inline const vmd_script_ir_t* find_ir(const void* md_ir) {
@@ -102,6 +104,14 @@ inline size_t num_frames_adapter(void* inst) { return (size_t)md_trajectory_num_
 inline size_t num_atoms_adapter(void* inst) { return (size_t)md_trajectory_num_atoms((md_trajectory_i*)inst); }
 inline vmd_trajectory_i wrap_trajectory(md_trajectory_i* traj) {
     vmd_trajectory_i t;
+    {
+        /* a trajectory the host opened through the backend's readers (or uploaded to HBM): hand the evaluator THAT interface, with its
+         * device view / raw frames / mapped file - behind load_frame alone every frame would be decoded on the host and staged over PCIe */
+        Registry& r = registry();
+        std::lock_guard<std::mutex> l(r.mtx);
+        auto it = r.native_traj.find(traj);
+        if (it != r.native_traj.end()) return *it->second;
+    }
     memset(&t, 0, sizeof(t));
     t.inst = traj; t.num_frames = num_frames_adapter; t.num_atoms = num_atoms_adapter; t.load_frame = load_frame_adapter;
     return t;
@@ -131,6 +141,17 @@ inline void vmd_shim_bind_ir(const md_script_ir_t* md_ir, const vmd_script_ir_t*
     auto pe = r.payload_evals.find(md_ir);
     if (pe != r.payload_evals.end()) { vmd_eval_free(pe->second.eval); r.payload_evals.erase(pe); }
     for (auto it = r.payloads.begin(); it != r.payloads.end();) it = it->first.first == md_ir ? r.payloads.erase(it) : std::next(it);
+}
+
+/* Optional: the frames behind `md_traj` are also available through `native` - a vmd_xdrtraj / vmd_dcdtraj / vmd_rawtraj / vmd_devtraj
+ * interface of the same file or of a copy in HBM (a loader shim registers the pair where VIAMD attaches the trajectory,
+ * src/loader.cpp:111-159).  md_script_eval_frame_range then evaluates from `native` - frames decompressed on the GPU, DMA'd out of the
+ * mapped file, or read in place from HBM - while VIAMD keeps using md_traj for display.  native = NULL unbinds; the native interface
+ * must outlive the binding. */
+inline void vmd_shim_bind_trajectory(const md_trajectory_i* md_traj, vmd_trajectory_i* native) {
+    vmd_shim::Registry& r = vmd_shim::registry();
+    std::lock_guard<std::mutex> l(r.mtx);
+    if (native) r.native_traj[md_traj] = native; else r.native_traj.erase(md_traj);
 }
 
 /* ---- md_script_eval_t ------------------------------------------------------------------------------------------------------ */

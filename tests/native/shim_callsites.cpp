@@ -338,6 +338,38 @@ int main(int argc, char** argv) {
         remove(cube_md); remove(cube_vmd);
     }
 
+    // ---- a trajectory the host also holds in HBM (VIAMD's frame cache, src/loader.cpp:111-159, as a vmd_devtraj): bound once, the same
+    // md_script_eval_frame_range calls evaluate from the device copy - no load_frame, no staging - and return the same bits
+    {
+        vmd_devtraj_t* dt = vmd_devtraj_create(F, N);
+        if (!dt) fail("devtraj");
+        vmd_unitcell_t cell{L, L, L, 0, 0, 0, 7u};
+        for (size_t f = 0; f < F; ++f) {
+            const float* p = mt.xyz.data() + f * 3 * N;
+            if (!vmd_devtraj_upload_frame(dt, f, &cell, p, p + N, p + 2 * N)) fail("upload_frame");
+        }
+        static std::atomic<long> loads{0};
+        static bool (*inner)(void*, int64_t, md_trajectory_frame_header_t*, float*, float*, float*) = mock_load_frame;
+        md_trajectory_i counted{&mt, mock_get_header, [](void* inst, int64_t idx, md_trajectory_frame_header_t* h, float* x, float* y, float* z) { loads += 1; return inner(inst, idx, h, x, y, z); }};
+        md_system_t sys2 = sys;
+        sys2.trajectory = &counted;
+        vmd_shim_bind_trajectory(&counted, vmd_devtraj_interface(dt));
+        md_script_eval_t* dev_eval = md_script_eval_create(F, eval_ir, &persistent);
+        if (!dev_eval) fail("md_script_eval_create (bound trajectory)");
+        md_script_eval_clear_data(dev_eval);
+        loads = 0;
+        for (uint32_t fb = 0; fb < F; fb += 4) if (!md_script_eval_frame_range(dev_eval, eval_ir, &sys2, sys2.trajectory, fb, fb + 4 < F ? fb + 4 : (uint32_t)F)) fail("frame_range (bound trajectory)");
+        if (loads.load() != 0) fail("a bound trajectory must not be staged through md_trajectory_load_frame");
+        for (const char* nm : {"r", "d", "v"}) {
+            const md_script_property_data_t* a = md_script_eval_property_data(dev_eval, str_t{nm, 1});
+            const md_script_property_data_t* b = md_script_eval_property_data(full_eval, str_t{nm, 1});
+            if (a->num_values != b->num_values || memcmp(a->values, b->values, a->num_values * sizeof(float)) != 0) fail("bound trajectory: results differ from the staged evaluation");
+        }
+        md_script_eval_free(dev_eval);
+        vmd_shim_bind_trajectory(&counted, nullptr);
+        vmd_devtraj_free(dt);
+    }
+
     // :952-953 interrupt while a task runs, then :960-964 free
     std::thread late([&] { md_script_eval_clear_data(full_eval); pool_task(full_eval, 0, (uint32_t)F, 2); });
     md_script_eval_interrupt(full_eval);
