@@ -404,6 +404,9 @@ bool   vmd_eval_set_block_frames(vmd_script_eval_t* eval, size_t block_frames);
 bool   vmd_eval_set_source(vmd_script_eval_t* eval, vmd_script_eval_t* source);
 /* frames evaluated by kernels / frames served from block partials since the last clear_data */
 void   vmd_eval_frame_stats(const vmd_script_eval_t* eval, size_t* frames_computed, size_t* frames_reused);
+/* the two-level cell build of this eval's selections: how often a pencil bucket overflowed (each time the batch's pair passes were repeated
+ * with wider buckets for THAT selection) and how many selections have given the buckets up for the single-level builds (three overflows) */
+void   vmd_eval_cell_build_stats(const vmd_script_eval_t* eval, size_t* bucket_overflows, size_t* selections_off_buckets);
 /* Read-ahead under VIAMD's call pattern (pool threads, a frame or a few per call: /root/reference/src/main.cpp:993-997,
  * src/task_system.cpp:73-81): what this eval did since it was created.  engaged = small concurrent calls were recognised and regions of
  * frame blocks evaluated ahead; slow_calls = calls that led or waited for a region (all others only marked their frames requested);

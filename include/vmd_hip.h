@@ -67,6 +67,9 @@ int vmd_hip_cells_build(void* stream, const float* xyz, size_t frame_stride, siz
  *   pen_count  u32[B][npen] scratch (zeroed by the call), pen_start u32[B][npen + 1] scratch, bucket f32[B][total_cap][4] scratch
  *   overflow   u32[1]: set to 1 when an atom found its bucket full (never cleared here).  The sorted copy is then incomplete;
  *              vmd_hip_rdf_pencil / vmd_hip_axpy_u64 given the same flag do nothing, the caller enlarges the buckets and repeats */
+/* the bit a bucket overflow of the NEXT vmd_hip_cells_build_pencil calls of this host thread ORs into *overflow (default 1): the evaluator
+ * gives every selection its own, so that only the selection that overflowed gets wider buckets; returns the previous value */
+uint32_t vmd_hip_set_cells_overflow_bit(uint32_t bit);
 int vmd_hip_cells_pencil_ok(vmd_grid_t grid);
 int vmd_hip_set_cells_pencil(int on);  /* A-B switch (0 = the single-level builds below), returns the previous value */
 int vmd_hip_cells_pencil_cap_max(void);

@@ -55,6 +55,10 @@ def test_pool_threads_with_small_ranges_leave_the_views_of_one_call(emu_lib, ora
     cases.pool_threads_case(emu_lib, oracle)
 
 
+def test_a_wandering_solute_does_not_cost_the_solvent_its_cell_build(emu_lib, oracle):
+    cases.wandering_solute_case(emu_lib, oracle)
+
+
 def test_pool_calls_are_served_by_read_ahead(emu_lib, oracle):
     cases.readahead_case(emu_lib, oracle)
 

@@ -48,6 +48,10 @@ def test_batch_of_frame_blocks_overflow_is_all_or_nothing(gpu_lib, oracle):
     cases.blocks_overflow_case(gpu_lib, oracle, device=True, n=30000, box=80.0)
 
 
+def test_a_wandering_solute_does_not_cost_the_solvent_its_cell_build(gpu_lib, oracle):
+    cases.wandering_solute_case(gpu_lib, oracle, device=True, n=30000, box=80.0, F=24, batch=4)
+
+
 def test_pool_calls_are_served_by_read_ahead(gpu_lib, oracle):
     cases.readahead_case(gpu_lib, oracle, device=True, n_water=6000, box=58.0, F=160, nthreads=12)
 

@@ -182,6 +182,7 @@ SIGNATURES = [
     ("vmd_eval_set_source", C.c_bool, [_vp, _vp]),
     ("vmd_eval_frame_stats", None, [_vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     ("vmd_eval_readahead_stats", None, [_vp, C.POINTER(ReadAheadStats)]),
+    ("vmd_eval_cell_build_stats", None, [_vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     ("vmd_eval_frames_device_decoded", C.c_size_t, [_vp]),
     ("vmd_eval_frames_section_decoded", C.c_size_t, [_vp]),
     ("vmd_eval_frames_mapped", C.c_size_t, [_vp]),
@@ -288,6 +289,7 @@ SIGNATURES = [
     ("vmd_hip_set_sdf_nt", C.c_int, [C.c_int]),
     ("vmd_hip_set_rdf_closed", C.c_int, [C.c_int]),
     ("vmd_hip_set_rdf_raw", C.c_int, [C.c_int]),
+    ("vmd_hip_set_cells_overflow_bit", C.c_uint32, [C.c_uint32]),
     ("vmd_hip_synth_frames", C.c_int, [_vp, _vp, C.c_size_t, C.c_size_t, C.c_int, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32,
                                        C.c_float, C.c_float]),
 ]

@@ -124,6 +124,7 @@ struct Options {
                                                 // kernel of batch k; costs the pair kernel ~4 % (0 = leave the grid alone)
     std::atomic<int> sdf_dense{0};       // dense-target SDF scatter (stream whole frames, select by tag): measured slower, off
     std::atomic<int> sdf_arith{1};       // SDF target lists that are arithmetic progressions are generated on the device (0 = always load the index list)
+    std::atomic<int> cells_small{8192};  // selections of at most this many atoms are sorted by one block per frame (k_cells_fused), never through pencil buckets (0: buckets for everyone)
     std::atomic<int> rdf_classes{1};     // co-evaluated RDFs of one range share pair passes through disjoint atom classes (0 = one pass per property)
     // read-ahead under VIAMD's call pattern (many pool threads, ranges of a frame or a few): the first small call that finds
     // company evaluates a whole REGION of frame blocks ahead into block partials, later calls for those frames only mark them requested
@@ -192,6 +193,7 @@ extern "C" int vmd_set_option(const char* key, int value) {
     else if (!strcmp(key, "spec_rdf_norm")) o = &g_opt.spec_rdf_norm;
     else if (!strcmp(key, "rdf_blocks_decode")) o = &g_opt.rdf_blocks_decode;
     else if (!strcmp(key, "rdf_classes")) o = &g_opt.rdf_classes;
+    else if (!strcmp(key, "cells_small")) o = &g_opt.cells_small;
     else if (!strcmp(key, "readahead")) o = &g_opt.readahead;
     else if (!strcmp(key, "readahead_frames")) o = &g_opt.readahead_frames;
     else if (!strcmp(key, "readahead_growth")) o = &g_opt.readahead_growth;
@@ -650,6 +652,7 @@ struct Selection {
     float cap_margin = 1.25f;
     int overflows = 0;                  // times a bucket overflowed; after 3 the selection stays on the single-level builds
     bool used_pencil = false;           // the current batch was built through the buckets
+    uint32_t overflow_bit = 1u;         // this selection's bit in the device overflow flag (1 << (index % 32))
     DevBuf<uint32_t> d_pen_off, pen_count, pen_start;
     DevBuf<float> bucket;
     // capacities measured for other pencil layouts: two RDF groups with different cutoffs on one selection alternate between two
@@ -1089,6 +1092,7 @@ static int intern_selection(vmd_script_eval_t* e, const std::vector<int32_t>& id
     for (size_t i = 0; i < e->sels.size(); ++i) if (e->sels[i]->idx == idx) return (int)i;
     auto s = std::make_unique<Selection>();
     s->idx = idx;
+    s->overflow_bit = 1u << (e->sels.size() % 32);
     e->sels.push_back(std::move(s));
     return (int)e->sels.size() - 1;
 }
@@ -1553,7 +1557,8 @@ extern "C" bool vmd_eval_set_source(vmd_script_eval_t* eval, vmd_script_eval_t* 
     if (source->ir_fingerprint != eval->ir_fingerprint || source->num_frames != eval->num_frames || source->props.size() != eval->props.size())
         return vmd_fail("vmd_eval_set_source: source was created from a different script or frame count");
     if (source->device != eval->device) return vmd_fail("vmd_eval_set_source: source lives on another device");
-    if (source->block_frames == 0) return vmd_fail("vmd_eval_set_source: source keeps no block partials (vmd_eval_set_block_frames)");
+    // (a source without block partials is accepted since round 4: read-ahead gives an eval driven by pool threads block partials of its own
+    // accord, and whether the source has any is looked up, under its mutex, whenever a range is served)
     eval->source = source;
     return true;
 }
@@ -1561,6 +1566,13 @@ extern "C" bool vmd_eval_set_source(vmd_script_eval_t* eval, vmd_script_eval_t* 
 extern "C" size_t vmd_eval_frames_device_decoded(const vmd_script_eval_t* eval) { return eval ? eval->frames_device_decoded.load() : 0; }
 extern "C" size_t vmd_eval_frames_section_decoded(const vmd_script_eval_t* eval) { return eval ? eval->frames_section_decoded.load() : 0; }
 extern "C" size_t vmd_eval_frames_mapped(const vmd_script_eval_t* eval) { return eval ? eval->frames_mapped.load() : 0; }
+
+extern "C" void vmd_eval_cell_build_stats(const vmd_script_eval_t* eval, size_t* bucket_overflows, size_t* selections_off_buckets) {
+    size_t ov = 0, off = 0;
+    if (eval) for (auto& s : eval->sels) { ov += (size_t)std::min(s->overflows, 98); off += s->overflows >= 3 ? 1 : 0; }
+    if (bucket_overflows) *bucket_overflows = ov;
+    if (selections_off_buckets) *selections_off_buckets = off;
+}
 
 extern "C" void vmd_eval_frame_stats(const vmd_script_eval_t* eval, size_t* frames_computed, size_t* frames_reused) {
     if (frames_computed) *frames_computed = eval ? eval->frames_computed.load() : 0;
@@ -2298,12 +2310,17 @@ static bool build_selection(vmd_script_eval_t* e, Selection* s, const Stage& src
     if (!s->cell_start.ensure(nb * (size_t)(g.ncell + 1)) || !s->sorted.ensure(nb * 3 * (size_t)s->nsel_pad + 64)) return false;   // +64: the pair kernel prefetches past a segment
     s->used_pencil = false;
     // two-level build through per-pencil buckets (one read of the frame, coalesced sorted rows); single-level builds otherwise
-    if (vmd_hip_cells_pencil_ok(g) && s->overflows < 3) {
+    // A small selection (a solute: the 2 000-atom blob of config 5) is not spread evenly over the pencils and wanders through them as the
+    // trajectory goes on: capacities measured on one batch overflow in the next, and every overflow repeats the batch's pair passes.  It is
+    // sorted by ONE block per frame in LDS instead (k_cells_fused: no buckets, nothing to overflow), which costs such a selection nothing.
+    const bool small = nsel <= g_opt.cells_small.load() && vmd_hip_cells_fused_ok(g, nsel);
+    if (vmd_hip_cells_pencil_ok(g) && s->overflows < 3 && !small) {
         if (!ensure_pencil_caps(e, s, src, d_boxes, pbc, nb, g)) return false;
         if (!s->pen_off.empty() && s->cap_max <= vmd_hip_cells_pencil_cap_max()) {
             const size_t npen = (size_t)g.ny * g.nz;
             if (!s->pen_count.ensure(nb * npen) || !s->pen_start.ensure(nb * (npen + 1)) || !s->bucket.ensure(nb * (size_t)s->total_cap * 4)) return false;
             e->prof.begin("cells_build", e->stream);
+            vmd_hip_set_cells_overflow_bit(s->overflow_bit);
             KRN_OK(vmd_hip_cells_build_pencil(e->stream, src.base, src.frame_stride, src.row_stride, d_boxes, pbc, (int)nb, s->d_idx.p, nsel, s->nsel_pad, g,
                                               s->d_pen_off.p, s->total_cap, s->cap_max, s->pen_count.p, s->pen_start.p, s->bucket.p, e->d_overflow.p,
                                               s->cell_start.p, s->sorted.p));
@@ -2382,8 +2399,9 @@ static void plan_batches(const vmd_script_eval_t* e, size_t beg, size_t end, siz
 // and return the sub-ranges that still have to be computed
 static bool reuse_blocks(vmd_script_eval_t* e, size_t beg, size_t end, std::vector<std::pair<size_t, size_t>>* todo) {
     vmd_script_eval_t* src = e->source;
-    if (!src || src->block_frames == 0) { todo->push_back({beg, end}); return true; }
+    if (!src) { todo->push_back({beg, end}); return true; }
     std::lock_guard<std::mutex> lock(src->mtx);   // order: own mutex, then the source's (a source never locks its users)
+    if (src->block_frames == 0) { todo->push_back({beg, end}); return true; }      // (looked up under its mutex: read-ahead may be giving it blocks right now)
     const size_t S = src->block_frames;
     size_t run = beg, reused = 0;
     for (size_t f = beg; f < end;) {
@@ -2463,7 +2481,8 @@ static bool process_range_locked(vmd_script_eval_t* eval, const vmd_system_t* sy
 
     // frames served from the block partials of the source eval (filtered evaluation), the rest is computed
     std::vector<std::pair<size_t, size_t>> segments;
-    if (!reuse_blocks(e, frame_beg, frame_end, &segments)) return false;
+    if (spec) segments.push_back({frame_beg, frame_end});         // a region's blocks are adopted from the source by the region leader, or evaluated here
+    else if (!reuse_blocks(e, frame_beg, frame_end, &segments)) return false;
 
     // compressed frames for the device decoder travel two batches ahead through a ring of three slots (RawSlot)
     vmd_host_view_t hv_probe;
@@ -2716,9 +2735,10 @@ static bool process_range_locked(vmd_script_eval_t* eval, const vmd_system_t* sy
                 later->poisoned = true;
             }
             const bool own = !(c.poisoned && attempt == 0);      // a poisoned batch did not overflow itself (as far as anyone knows)
+            const uint32_t who = e->h_overflow[c.slot];           // one bit per selection (Selection::overflow_bit; selections beyond 32 share)
             for (auto& sl : e->sels) {
                 sl->built = false;
-                if (!own || !sl->used_pencil) continue;
+                if (!own || !sl->used_pencil || !(who & sl->overflow_bit)) continue;       // only the selection whose buckets were too small gets wider ones
                 sl->pen_off.clear();
                 sl->caps_cache.clear();
                 sl->cap_margin *= 1.6f;
@@ -3079,7 +3099,8 @@ static bool ra_engage(vmd_script_eval_t* e, vmd_trajectory_i* traj) {
     const bool have_view = traj->device_view && traj->device_view(traj->inst, &view) && view.device == e->device;
     const size_t Bmax = auto_batch(e, num_atoms, !have_view);
     if (e->block_frames == 0) {
-        const size_t S = ra_block_frames(e, Bmax);
+        // a filtered eval (src/main.cpp:1014-1039) adopts whole blocks from its source's partials: same blocks as the source
+        const size_t S = (e->source && e->source->block_frames) ? std::min(e->source->block_frames, std::max<size_t>(Bmax, 1)) : ra_block_frames(e, Bmax);
         const size_t nblocks = (e->num_frames + S - 1) / S;
         size_t bytes = 0;
         for (auto& p : e->props) bytes += nblocks * p->ncounts * sizeof(uint64_t);
@@ -3112,6 +3133,42 @@ static bool ra_engage(vmd_script_eval_t* e, vmd_trajectory_i* traj) {
     ra.bmax = Bmax;
     ra.traj_inst = traj->inst;
     ra.on.store(true, std::memory_order_release);
+    return true;
+}
+
+// The filtered evaluation under VIAMD's call pattern: blocks of a region that the source eval has finished are not evaluated again - their
+// partials (and temporal rows) are copied from the source into this eval's own block partials, where they wait to be requested like any
+// block evaluated ahead.  mtx held, device set.  adopted[b - b0] = 1 for the blocks taken.
+static bool ra_adopt_blocks(vmd_script_eval_t* e, size_t b0, size_t b1, std::vector<char>* adopted) {
+    adopted->assign(b1 - b0, 0);
+    vmd_script_eval_t* src = e->source;
+    if (!src || src->props.size() != e->props.size()) return true;
+    std::lock_guard<std::mutex> lock(src->mtx);       // order: own mutex, then the source's (as reuse_blocks)
+    if (src->block_frames != e->block_frames) return true;
+    const size_t S = e->block_frames;
+    size_t taken = 0;
+    for (size_t b = b0; b < b1; ++b) {
+        if (b >= src->num_blocks || !src->block_ready[b]) continue;
+        const size_t f0 = b * S, f1 = std::min(f0 + S, e->num_frames);
+        for (size_t i = 0; i < e->props.size(); ++i) {
+            PropState* p = e->props[i].get();
+            const PropState* q = src->props[i].get();
+            if (p->ncounts) {
+                HIP_OK(hipMemcpyAsync(p->d_blocks.p + b * p->ncounts, q->d_blocks.p + b * p->ncounts, p->ncounts * sizeof(uint64_t), hipMemcpyDeviceToDevice, e->stream));
+                if (p->prop.kind == PROP_RDF) memcpy(&p->block_weights64[b * p->ncounts], &q->block_weights64[b * p->ncounts], p->ncounts * sizeof(double));
+            } else {
+                if (p->ahead_values.size() != p->values.size()) p->ahead_values.assign(p->values.size(), 0.0f);
+                memcpy(&p->ahead_values[f0 * p->dim1], &q->values[f0 * p->dim1], (f1 - f0) * p->dim1 * sizeof(float));
+            }
+        }
+        e->block_ready[b] = 1;
+        (*adopted)[b - b0] = 1;
+        taken += f1 - f0;
+    }
+    if (taken) {
+        HIP_OK(hipStreamSynchronize(e->stream));          // the source's partials are read before its mutex is released
+        e->frames_reused += taken;
+    }
     return true;
 }
 
@@ -3290,7 +3347,15 @@ static bool ra_call(vmd_script_eval_t* e, const vmd_system_t* sys, vmd_trajector
             if (ok) {
                 g_last_error.clear();
                 std::lock_guard<std::mutex> lock(e->mtx);
-                ok = !e->interrupt && process_range_locked(e, sys, traj, f_lo, f_hi, false, true);
+                std::vector<char> adopted;
+                ok = hipSetDevice(e->device) == hipSuccess && ra_adopt_blocks(e, need, e1, &adopted);
+                for (size_t b = need; b < e1 && ok;) {           // what the source could not supply: evaluated, in runs of blocks
+                    if (adopted[b - need]) { ++b; continue; }
+                    size_t r1 = b;
+                    while (r1 < e1 && !adopted[r1 - need]) ++r1;
+                    ok = !e->interrupt && process_range_locked(e, sys, traj, (uint32_t)(b * S), (uint32_t)std::min(r1 * S, e->num_frames), false, true);
+                    b = r1;
+                }
             }
             const std::string err = ok ? std::string() : g_last_error;
             ql.lock();
@@ -3348,7 +3413,7 @@ extern "C" bool vmd_eval_frame_range(vmd_script_eval_t* eval, const vmd_script_i
     if (frame_end > eval->num_frames) frame_end = (uint32_t)eval->num_frames;
     if (frame_beg >= frame_end) return true;
     if (eval->interrupt) return false;
-    if (!g_opt.readahead.load() || eval->source) {
+    if (!g_opt.readahead.load()) {
         if (!eval->ra.on.load()) return combine_call(eval, sys, traj, frame_beg, frame_end);
         eval->ra.flight.fetch_add(((uint64_t)1 << 32) | 1, std::memory_order_acq_rel);
         const bool ok = ra_direct_call(eval, sys, traj, frame_beg, frame_end);

@@ -524,6 +524,9 @@ struct vmd_bin_params_t {
     uint32_t* pen_count;             // [B][npen], zeroed before the launch: atoms per pencil
     float* bucket;                   // [B][pen_off[npen]][4], NULL in counting mode
     uint32_t* overflow;              // [1]
+    uint32_t overflow_bit;           // what an overflowing build ORs into it: one bit per selection, so that the host widens the buckets of THAT
+                                     // selection only (c5, 1 000 frames: the wandering blob overflowed three times and took the water selections'
+                                     // margins - and with them the two-level build - down with it: 49 ms of cell build per step instead of 21)
     int npen; int total_cap;
     int rec3;                        // 1: 12-byte records {x, y, z} (the fine cell follows from x alone: x-periodic, non-triclinic cells)
 };
@@ -572,7 +575,7 @@ __global__ __launch_bounds__(1024) void k_cells_bin(vmd_bin_params_t q) {
                 *(vmd_f4a*)(bk + 4 * (size_t)(off + slot)) = v;
             }
         } else {
-            *q.overflow = 1u;
+            atomicOr(q.overflow, q.overflow_bit);
         }
     }
 }
@@ -671,7 +674,7 @@ __global__ __launch_bounds__(1024) void k_cells_bin_sorted(vmd_bin_params_t q) {
             over = true;
         }
     }
-    if (over) *q.overflow = 1u;
+    if (over) atomicOr(q.overflow, q.overflow_bit);
 }
 
 // per frame: exclusive prefix of the (capacity-clamped) pencil populations = first sorted slot of every pencil
@@ -2915,7 +2918,7 @@ extern "C" int vmd_hip_cells_pencil_count(void* stream, const float* xyz, size_t
     hipError_t e = hipMemsetAsync(counts, 0, sizeof(uint32_t) * (size_t)S * npen, s);
     if (e != hipSuccess) return (int)e;
     vmd_bin_params_t q{{xyz, frame_stride, row_stride, boxes, pbc_flags, sel, nsel, 0, grid, nullptr, nullptr, nullptr, nullptr, nullptr},
-                       nullptr, counts, nullptr, nullptr, npen, 0};
+                       nullptr, counts, nullptr, nullptr, 1u, npen, 0, 0};
     hipLaunchKernelGGL(k_cells_bin, dim3((nsel + 1024 * VMD_BIN_ILP - 1) / (1024 * VMD_BIN_ILP), S), dim3(1024), sizeof(uint32_t) * npen, s, q);
     VMD_LAUNCH_CHECK();
     return 0;
@@ -2923,6 +2926,8 @@ extern "C" int vmd_hip_cells_pencil_count(void* stream, const float* xyz, size_t
 
 static int g_cells_bin_lds = 1;   // level 1 orders a block's records by pencil in LDS before writing them (A/B switch)
 extern "C" int vmd_hip_set_cells_bin_lds(int on) { const int old = g_cells_bin_lds; g_cells_bin_lds = on ? 1 : 0; return old; }
+static thread_local uint32_t g_cells_overflow_bit = 1u;    // per host thread, set by the evaluator before each selection's build (vmd_hip_set_cells_overflow_bit)
+extern "C" uint32_t vmd_hip_set_cells_overflow_bit(uint32_t bit) { const uint32_t old = g_cells_overflow_bit; g_cells_overflow_bit = bit ? bit : 1u; return old; }
 static int g_cells_rec3 = 1;      // 12-byte bucket records where the cell kind allows it (A/B switch)
 extern "C" int vmd_hip_set_cells_rec3(int on) { const int old = g_cells_rec3; g_cells_rec3 = on ? 1 : 0; return old; }
 extern "C" int vmd_hip_cells_build_pencil(void* stream, const float* xyz, size_t frame_stride, size_t row_stride, const float* boxes,
@@ -2938,7 +2943,7 @@ extern "C" int vmd_hip_cells_build_pencil(void* stream, const float* xyz, size_t
     // x-periodic, non-triclinic cells: the grid bins the wrapped x itself, so the record need not carry the fine cell
     const int rec3 = (g_cells_rec3 && (pbc_flags & 1u) && !(pbc_flags & VMD_PBC_TRICLINIC)) ? 1 : 0;
     vmd_bin_params_t q{{xyz, frame_stride, row_stride, boxes, pbc_flags, sel, nsel, nsel_pad, grid, nullptr, nullptr, nullptr, nullptr, nullptr},
-                       pen_off, pen_count, bucket, overflow, npen, total_cap, rec3};
+                       pen_off, pen_count, bucket, overflow, g_cells_overflow_bit ? g_cells_overflow_bit : 1u, npen, total_cap, rec3};
     const size_t shm_sorted = sizeof(uint32_t) * (3 * (size_t)npen + 1040 + (size_t)1024 * VMD_BIN_ILP * (rec3 ? 4 : 5));
     if (g_cells_bin_lds && shm_sorted <= 160 * 1024 - 64) {
         int eb = vmd_lds_opt_in((const void*)k_cells_bin_sorted);

@@ -287,6 +287,12 @@ class ScriptEval:
         self.lib.vmd_eval_readahead_stats(self.h, C.byref(st))
         return {k: int(getattr(st, k)) for k, _ in L.ReadAheadStats._fields_}
 
+    def cell_build_stats(self):
+        """(bucket overflows of the two-level cell build, selections that left it for the single-level builds)"""
+        a, b = C.c_size_t(0), C.c_size_t(0)
+        self.lib.vmd_eval_cell_build_stats(self.h, C.byref(a), C.byref(b))
+        return int(a.value), int(b.value)
+
     def frames_device_decoded(self):
         """Frames whose coordinates were decompressed on the device (load_raw + k_xtc_decode) since the last clear_data."""
         return int(self.lib.vmd_eval_frames_device_decoded(self.h))
