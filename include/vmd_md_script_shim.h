@@ -71,6 +71,9 @@ struct Registry {
     std::map<const void*, PayloadEval> payload_evals;
     /* md_trajectory_i* -> the backend's own interface for the same frames (vmd_shim_bind_trajectory) */
     std::map<const void*, vmd_trajectory_i*> native_traj;
+    /* live evals per script: VIAMD creates the full and the filtered eval from one ir, in that order (src/main.cpp:971-972); the later
+     * ones take the first as their SOURCE, so that a timeline sub-range is served from the block partials the full evaluation left */
+    std::map<const void*, std::vector<vmd_script_eval_t*>> evals;
 };
 inline Registry& registry() { static Registry r; return r; }
 inline const vmd_script_ir_t* find_ir(const void* md_ir) {
@@ -158,6 +161,7 @@ inline void vmd_shim_bind_trajectory(const md_trajectory_i* md_traj, vmd_traject
 struct md_script_eval_t {
     vmd_script_eval_t* eval = nullptr;
     const vmd_script_ir_t* vir = nullptr;
+    const md_script_ir_t* md_ir = nullptr;
     /* md_script_property_data_t records handed to VIAMD: fetched once and cached by the GUI (src/main.cpp:1286,1303), so their
      * addresses are stable for the eval's lifetime; the arrays they point at are the backend's own (equally stable), the scalar
      * fields (fingerprint, ranges, max_value) are refreshed from the backend whenever data may have changed */
@@ -216,10 +220,31 @@ inline md_script_eval_t* VMD_SHIM_PREFIX(md_script_eval_create)(size_t num_frame
     e->mask.beg_bit = 0;
     e->mask.end_bit = (uint32_t)num_frames;
     e->refresh();
+    {
+        vmd_shim::Registry& r = vmd_shim::registry();
+        std::lock_guard<std::mutex> l(r.mtx);
+        std::vector<vmd_script_eval_t*>& live = r.evals[ir];
+        if (!live.empty() && vmd_eval_num_frames(live.front()) == num_frames) vmd_eval_set_source(e->eval, live.front());
+        live.push_back(e->eval);
+        e->md_ir = ir;
+    }
     return e.release();
 }
 inline void VMD_SHIM_PREFIX(md_script_eval_free)(md_script_eval_t* e) {
     if (!e) return;
+    {
+        /* VIAMD frees the full eval before the filtered one (src/main.cpp:959-964): nobody may keep it as a source */
+        vmd_shim::Registry& r = vmd_shim::registry();
+        std::lock_guard<std::mutex> l(r.mtx);
+        auto it = r.evals.find(e->md_ir);
+        if (it != r.evals.end()) {
+            std::vector<vmd_script_eval_t*>& live = it->second;
+            const bool was_source = !live.empty() && live.front() == e->eval;
+            for (size_t i = 0; i < live.size(); ++i) if (live[i] == e->eval) { live.erase(live.begin() + (long)i); break; }
+            if (was_source) for (vmd_script_eval_t* o : live) vmd_eval_set_source(o, nullptr);
+            if (live.empty()) r.evals.erase(it);
+        }
+    }
     vmd_eval_free(e->eval);
     delete e;
 }

@@ -472,6 +472,23 @@ def readahead_case(lib, O, device=False, n_water=600, box=28.0, F=40, nthreads=6
         assert filt.frame_range(sysm, traj, 7, 29)
         same(filt, part, "filtered eval served from blocks that read-ahead computed")
         assert filt.frame_stats()[1] >= 15                         # blocks [10, 25) at least came from the partials
+        # ... and the filtered eval itself driven by the pool, frame by frame (src/main.cpp:1014-1039 under :993's grain): the blocks of its
+        # regions that the source has finished are adopted from the source's partials, not evaluated again
+        filt.clear_data()
+        assert all(pooled(filt, 7, 29, 1))
+        same(filt, part, "filtered eval, pool of threads, blocks adopted from the source")
+        computed, reused = filt.frame_stats()
+        assert reused >= 15 and computed <= 10, (computed, reused)     # [10, 25) adopted; only the ragged ends 7..9 and 25..28 (and their blocks) are work
+        filt.close(); ev.close()
+        # ---- VIAMD unedited: nobody calls set_block_frames; the full eval's own read-ahead blocks serve the filtered eval
+        ev = V.ScriptEval(F, ir)
+        assert all(pooled(ev, 0, F, 1))
+        same(ev, full, "full eval, pool")
+        filt = V.ScriptEval(F, ir)
+        filt.set_source(ev)                                        # (the shim links evals of one ir like this)
+        assert all(pooled(filt, 7, 29, 1))
+        same(filt, part, "filtered eval adopting the full eval's read-ahead blocks")
+        assert filt.frame_stats()[1] >= 16, filt.frame_stats()      # blocks of 4: [8, 28) are whole blocks of the source
         filt.close(); ev.close()
     finally:
         for k, v in old:
