@@ -1064,7 +1064,7 @@ struct vmd_script_eval_t {
         std::atomic<bool> concurrent{false};         // this evaluation (since clear_data) has seen two calls at once: it is a pool
         bool spec_active = false;                    // a region is being evaluated (queue_mtx)
         bool lonely = false;                         // a first call has waited for company in vain (queue_mtx)
-        bool disabled = false;                       // two settles had to evaluate frames directly mid-stream: the callers do not arrive the way read-ahead assumes
+        std::atomic<bool> disabled{false};           // settles keep finding partly requested blocks (three strikes): the callers do not arrive the way read-ahead assumes
         int strikes = 0;
         size_t next_region = 0;                      // frames of the next region
         bool failed = false; std::string error;      // a region failed: every waiting call reports it
