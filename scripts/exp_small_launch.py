@@ -6,8 +6,24 @@ import torch
 import viamd_amd as V
 from viamd_amd import script, synth
 lib = V.default_lib()
+busy = False
 for kv in sys.argv[1:]:
-    k, v = kv.split("="); lib.vmd_set_option(k.encode(), int(v))
+    k, v = kv.split("=")
+    if k == "busy":
+        busy = bool(int(v))        # keep the device busy from another stream while the small launches are timed: is it the clock?
+    else:
+        lib.vmd_set_option(k.encode(), int(v))
+if busy:
+    import threading
+    stop = [False]
+    def hog():
+        # ONE spinning block on a side stream (torch.cuda._sleep): the device is never idle, 255 CUs stay free for the launches under test
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            while not stop[0]:
+                torch.cuda._sleep(int(2.0e8))
+                st.synchronize()
+    th = threading.Thread(target=hog, daemon=True); th.start(); time.sleep(0.5)
 N, box, F = 100002, 100.0, 200
 traj = synth.make_device_trajectory(V, 2, N, box, F, 0)
 topo = synth.water_box_topology(N, 0)
@@ -30,3 +46,5 @@ for name, text, variant in (("O-O same set (variant 0)", "g = rdf(element('O'), 
         print(f"{name}: {g} frame(s) per call: pair launch {1e3 * ms / n.value:.0f} us", flush=True)
     ev.close()
 lib.vmd_set_option(b"rdf_variant", 0)
+if busy:
+    stop[0] = True; th.join()
