@@ -466,6 +466,17 @@ vmd_dcdtraj_t*    vmd_dcdtraj_open(const char* path);
 void              vmd_dcdtraj_close(vmd_dcdtraj_t* t);
 vmd_trajectory_i* vmd_dcdtraj_interface(vmd_dcdtraj_t* t);
 
+/* Text trajectories as a vmd_trajectory_i: multi-MODEL PDB (BASELINE configs[0] is one), XYZ / XMOL (incl. extended-XYZ Lattice="..."),
+ * LAMMPS dump files - the remaining LoaderFlag_Trajectory types of VIAMD's loader table (src/loader.cpp:22-77; attached through mdlib,
+ * :111-159).  The file is mapped, one pass indexes the frames (byte range, atom count, unit cell per frame), load_frame parses frame f into
+ * the rows it is handed: re-entrant, so the evaluator decodes a staged batch on its load threads.  format: "pdb" | "xyz" | "xmol" | "arc" |
+ * "lammpstrj", or NULL = by the file name's extension.  Numbers are converted like (float)strtod(text), without the locale.
+ * NULL + vmd_last_error on failure (unknown type, no frames, a frame whose atom count differs from the first). */
+typedef struct vmd_texttraj_t vmd_texttraj_t;
+vmd_texttraj_t*   vmd_texttraj_open(const char* path, const char* format);
+void              vmd_texttraj_close(vmd_texttraj_t* t);
+vmd_trajectory_i* vmd_texttraj_interface(vmd_texttraj_t* t);
+
 /* GROMACS XTC (compressed) / TRR trajectory file as a vmd_trajectory_i - VIAMD attaches these through md_xtc_attach_from_file /
  * md_trr_attach_from_file (src/loader.cpp:147-150).  The file type is taken from the magic number; a frame-offset index is
  * built on open; nm -> Angstrom; box rows -> {x,y,z,xy,xz,yz}; TRR frames without positions are skipped.  load_frame is

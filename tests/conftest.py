@@ -33,6 +33,7 @@ EMU_SOURCES = [os.path.join(ROOT, "viamd_amd", "csrc", "vmd_kernels.hip"),
                os.path.join(ROOT, "viamd_amd", "csrc", "vmd_script.cpp"),
                os.path.join(ROOT, "viamd_amd", "csrc", "vmd_reduce.cpp"),
                os.path.join(ROOT, "viamd_amd", "csrc", "vmd_export.cpp"),
+               os.path.join(ROOT, "viamd_amd", "csrc", "vmd_text.cpp"),
                os.path.join(EMU_DIR, "emu.cpp")]
 EMU_DEPS = EMU_SOURCES + [os.path.join(EMU_DIR, "hip", "hip_runtime.h"),
                           os.path.join(ROOT, "include", "vmd_eval.h"), os.path.join(ROOT, "include", "vmd_hip.h")]

@@ -1,7 +1,7 @@
 // A C++ host that goes from files and script text to results through the C ABI alone: DCD / XTC / TRR trajectory chosen by
-// the file extension like VIAMD's loader does (vmd_dcdtraj_open, vmd_xdrtraj_open; src/loader.cpp:40-56, 79-84),
+// the file extension like VIAMD's loader does (vmd_dcdtraj_open, vmd_xdrtraj_open, vmd_texttraj_open; src/loader.cpp:40-56, 79-84),
 // script front-end (vmd_ir_compile_from_source), evaluator (vmd_eval_*), consumer post-processing (vmd_downsample_histogram).
-// usage: cabi_script_demo <trajectory.dcd|.xtc|.trr> <n_blob_atoms> "<script>"
+// usage: cabi_script_demo <trajectory.dcd|.xtc|.trr|.pdb|.xyz|.lammpstrj> <n_blob_atoms> "<script>"
 // Topology: the synthetic system of viamd_amd/synth.py ([ALA-like residues of 10 atoms][O,H,H waters]).
 // Prints one line per property: name, flags, dim, sum of the integer accumulators (or of the temporal values).
 // tests/test_native.py links it against the SIMT-emulator build (CPU) and compares with the Python host.
@@ -18,11 +18,13 @@ int main(int argc, char** argv) {
     const char* ext = strrchr(argv[1], '.');
     vmd_dcdtraj_t* dcd = nullptr;
     vmd_xdrtraj_t* xdr = nullptr;
+    vmd_texttraj_t* txt = nullptr;
     if (ext && !strcmp(ext, ".dcd")) dcd = vmd_dcdtraj_open(argv[1]);
     else if (ext && (!strcmp(ext, ".xtc") || !strcmp(ext, ".trr"))) xdr = vmd_xdrtraj_open(argv[1]);
+    else if (ext && (!strcmp(ext, ".pdb") || !strcmp(ext, ".xyz") || !strcmp(ext, ".xmol") || !strcmp(ext, ".lammpstrj"))) txt = vmd_texttraj_open(argv[1], nullptr);
     else { fprintf(stderr, "could not determine loader type from file extension\n"); return 2; }
-    if (!dcd && !xdr) { fprintf(stderr, "open failed: %s\n", vmd_last_error()); return 1; }
-    vmd_trajectory_i* traj = dcd ? vmd_dcdtraj_interface(dcd) : vmd_xdrtraj_interface(xdr);
+    if (!dcd && !xdr && !txt) { fprintf(stderr, "open failed: %s\n", vmd_last_error()); return 1; }
+    vmd_trajectory_i* traj = dcd ? vmd_dcdtraj_interface(dcd) : (xdr ? vmd_xdrtraj_interface(xdr) : vmd_texttraj_interface(txt));
     const size_t n = traj->num_atoms(traj->inst), frames = traj->num_frames(traj->inst);
     const size_t n_blob = (size_t)atol(argv[2]);
 
@@ -76,5 +78,6 @@ int main(int argc, char** argv) {
     vmd_ir_free(ir);
     vmd_dcdtraj_close(dcd);
     vmd_xdrtraj_close(xdr);
+    vmd_texttraj_close(txt);
     return 0;
 }

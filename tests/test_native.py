@@ -63,7 +63,7 @@ def test_native_host_runs_like_viamd():
     assert out.stdout.startswith("OK frames=96"), out.stdout
 
 
-@pytest.mark.parametrize("fmt", ["dcd", "xtc"])
+@pytest.mark.parametrize("fmt", ["dcd", "xtc", "pdb"])
 def test_native_host_from_dcd_and_script_text_on_the_emulator(tmp_path, emu_lib, oracle, fmt):
     """No Python on the hot path: a C++ program links the C ABI (here the SIMT-emulator build of the same sources, so it runs
     without a GPU), reads a DCD or XTC file (chosen by extension), compiles the script text with vmd_ir_compile_from_source and evaluates it; its output
@@ -80,6 +80,9 @@ def test_native_host_from_dcd_and_script_text_on_the_emulator(tmp_path, emu_lib,
     dcd = tmp_path / f"t.{fmt}"
     if fmt == "dcd":
         V.write_dcd(dcd, coords, cell)
+    elif fmt == "pdb":
+        from viamd_amd import pdb
+        pdb.write_pdb(dcd, coords, topo, box=box)                  # a multi-MODEL PDB (BASELINE configs[0]'s format): three decimals survive
     else:
         V.write_xtc(dcd, coords, cell, lib=emu_lib)
     text = ("s = residue(2:4); v = sdf(s, element('O') and water, 7.0); g = rdf(element('O') and water, not element('H'), 8.0);"
@@ -94,7 +97,7 @@ def test_native_host_from_dcd_and_script_text_on_the_emulator(tmp_path, emu_lib,
     lines = dict(l.split(" ", 1) for l in out.stdout.strip().split("\n"))
     ir, info = script.compile_script(text, topo, lib=emu_lib)
     ev = V.ScriptEval(F, ir)
-    assert ev.frame_range(V.MolSystem(n_atoms, mass=topo.mass, unitcell=cell), (V.DcdTrajectory if fmt == "dcd" else V.XdrTrajectory)(dcd, lib=emu_lib), 0, F)
+    assert ev.frame_range(V.MolSystem(n_atoms, mass=topo.mass, unitcell=cell), {"dcd": V.DcdTrajectory, "xtc": V.XdrTrajectory, "pdb": V.TextTrajectory}[fmt](dcd, lib=emu_lib), 0, F)
     for name in ("v", "g"):
         want = float(ev.property_data(name).counts.sum())
         got = float(lines[name].split("sum=")[1].split()[0])

@@ -1,0 +1,166 @@
+"""Native text trajectory readers (viamd_amd/csrc/vmd_text.cpp: multi-MODEL PDB, XYZ / XMOL, LAMMPS dump) against the independent Python
+readers of the same formats (viamd_amd/pdb.py, viamd_amd/textio.py): every frame bit for bit, cells, errors, and an evaluation straight from
+the file.  Pure host code: runs on the emulator build and on the product library (which loads without a GPU)."""
+import numpy as np
+import pytest
+
+import viamd_amd as V
+from viamd_amd import loader, pdb, textio
+from viamd_amd.script import Topology
+
+
+def _topo(n):
+    elems = (["O", "H", "H"] * ((n + 2) // 3))[:n]
+    return Topology(elems, ["SOL"] * n, [i // 3 for i in range(n)], [e + "W" for e in elems])
+
+
+def _coords(F, n, seed=3, scale=40.0):
+    rng = np.random.default_rng(seed)
+    c = (rng.random((F, 3, n)) * scale - 5.0).astype(np.float32)
+    c[0, :, 0] = (0.0, -0.0004, 9999.999)          # zero, a value that prints as -0.000, the widest field of %8.3f
+    return c
+
+
+def _frames(t):
+    return np.stack([t.load_frame(f)[0] for f in range(t.num_frames())])
+
+
+def _cell_tuple(c):
+    return (c.x, c.y, c.z, c.xy, c.xz, c.yz, c.flags)
+
+
+def test_multi_model_pdb(tmp_path, host_lib):
+    F, n = 7, 50
+    coords, topo = _coords(F, n), _topo(n)
+    p = tmp_path / "traj.pdb"
+    pdb.write_pdb(p, coords, topo, box=(30.0, 28.0, 26.0), tilt=(6.0, -4.0, 5.0))
+    want, _, cell = pdb.read_pdb(p)
+    t = V.TextTrajectory(p, lib=host_lib)
+    assert (t.num_frames(), t.num_atoms()) == (F, n)
+    np.testing.assert_array_equal(_frames(t), want)                   # the text holds %8.3f: both readers must round it the same way
+    for f in (0, F - 1):
+        assert _cell_tuple(t.load_frame(f)[1]) == _cell_tuple(cell)
+    assert loader.open_trajectory(p, lib=host_lib).num_frames() == F
+    # no MODEL records, HETATM, a TER line between chains, CRLF line ends, no CRYST1: one frame, no cell
+    lines = ["REMARK single model\r\n"]
+    for i in range(5):
+        rec = "HETATM" if i == 3 else "ATOM  "
+        lines.append("%s%5d  CA  ALA A%4d    %8.3f%8.3f%8.3f  1.00  0.00           C\r\n" % (rec, i + 1, i + 1, -1.5 * i, 2.25 * i, 1000.125 + i))
+        if i == 2:
+            lines.append("TER\r\n")
+    lines.append("END\r\n")
+    q = tmp_path / "single.pdb"
+    q.write_bytes("".join(lines).encode())
+    t1 = V.TextTrajectory(q, lib=host_lib)
+    assert (t1.num_frames(), t1.num_atoms()) == (1, 5)
+    xyz, c1, _ = t1.load_frame(0)
+    np.testing.assert_array_equal(xyz, pdb.read_pdb(q)[0][0])
+    assert c1.flags == 0 and xyz[2, 4] == np.float32(1004.125)
+    # a MODEL with a different atom count is refused when the file is opened
+    bad = tmp_path / "bad.pdb"
+    text = p.read_text().split("\n")
+    k = max(i for i, l in enumerate(text) if l.startswith("ATOM"))
+    bad.write_text("\n".join(text[:k] + text[k + 1:]))
+    with pytest.raises(V.VmdError, match="atoms"):
+        V.TextTrajectory(bad, lib=host_lib)
+
+
+def test_xyz_and_extended_xyz(tmp_path, host_lib):
+    F, n = 5, 33
+    coords = _coords(F, n, seed=5, scale=12.0)
+    elements = np.array((["C", "N", "O"] * n)[:n])
+    cells = [V.make_unitcell((20.0 + f, 21.0, 22.0), tilt=(1.5, -0.5, 0.25 * f)) for f in range(F)]
+    p = tmp_path / "t.xyz"
+    textio.write_xyz(p, coords, elements, cells)
+    want, _, wcells = textio.read_xyz(p)
+    t = V.TextTrajectory(p, lib=host_lib)
+    assert (t.num_frames(), t.num_atoms()) == (F, n)
+    np.testing.assert_array_equal(_frames(t), want)
+    for f in range(F):
+        assert _cell_tuple(t.load_frame(f)[1]) == _cell_tuple(wcells[f])
+    # numbers the fast path does not take (17+ significant digits, exponents) and blank lines between frames
+    q = tmp_path / "odd.xmol"
+    q.write_text("2\nframe 0\nAr 1.2345678901234567890 -2.5e-3 3E+2\nAr 0.1 1e-30 123456789012345678\n\n2\nframe 1\nAr 1 2 3\nAr -0 +7.25 .5\n")
+    t2 = V.TextTrajectory(q, lib=host_lib)
+    got, want2 = _frames(t2), textio.read_xyz(q)[0]
+    np.testing.assert_array_equal(got, want2)
+    assert got[0, 0, 0] == np.float32(1.2345678901234567890) and got[0, 2, 1] == np.float32(123456789012345678.0) and t2.load_frame(0)[1].flags == 0
+    with pytest.raises(V.VmdError, match="lower triangular"):
+        r = tmp_path / "r.xyz"
+        r.write_text('1\nLattice="10 1 0 0 10 0 0 0 10"\nAr 0 0 0\n')
+        V.TextTrajectory(r, lib=host_lib)
+    with pytest.raises(V.VmdError, match="incomplete|missing"):
+        r = tmp_path / "s.xyz"
+        r.write_text("2\nc\nAr 0 0 0\nAr 1 1\n")
+        V.TextTrajectory(r, lib=host_lib).load_frame(0)
+
+
+def _write_dump(path, coords, ids_per_frame, scaled, tri, steps):
+    F, _, n = coords.shape
+    with open(path, "w") as f:
+        for m in range(F):
+            xlo, ylo, zlo, lx, ly, lz = -3.0, 1.0, 0.5, 30.0 + m, 28.0, 26.0
+            xy, xz, yz = (4.0, -2.0, 3.0) if tri else (0.0, 0.0, 0.0)
+            f.write(f"ITEM: TIMESTEP\n{steps[m]}\nITEM: NUMBER OF ATOMS\n{n}\n")
+            if tri:
+                bx = (xlo + min(0.0, xy, xz, xy + xz), xlo + lx + max(0.0, xy, xz, xy + xz))
+                by = (ylo + min(0.0, yz), ylo + ly + max(0.0, yz))
+                f.write(f"ITEM: BOX BOUNDS xy xz yz pp pp ff\n{bx[0]!r} {bx[1]!r} {xy!r}\n{by[0]!r} {by[1]!r} {xz!r}\n{zlo!r} {zlo + lz!r} {yz!r}\n")
+            else:
+                f.write(f"ITEM: BOX BOUNDS pp pp pp\n{xlo!r} {xlo + lx!r}\n{ylo!r} {ylo + ly!r}\n{zlo!r} {zlo + lz!r}\n")
+            cols = "id type xs ys zs vx" if scaled else "type x y z id"
+            f.write(f"ITEM: ATOMS {cols}\n")
+            for k in ids_per_frame[m]:                       # atoms in a different order in every frame: the id column sorts them
+                x, y, z = (float(v) for v in coords[m, :, k])
+                if scaled:
+                    sz = (z - zlo) / lz; sy = (y - ylo - sz * yz) / ly; sx = (x - xlo - sy * xy - sz * xz) / lx
+                    f.write(f"{k + 1} {1 + k % 2} {sx!r} {sy!r} {sz!r} 0.0\n")
+                else:
+                    f.write(f"{1 + k % 2} {x!r} {y!r} {z!r} {k + 1}\n")
+
+
+@pytest.mark.parametrize("scaled,tri", [(False, False), (True, False), (True, True)])
+def test_lammps_dump(tmp_path, host_lib, scaled, tri):
+    F, n = 4, 41
+    coords = _coords(F, n, seed=9, scale=20.0)
+    rng = np.random.default_rng(1)
+    order = [rng.permutation(n) for _ in range(F)]
+    steps = [0, 500, 1000, 2500]
+    p = tmp_path / "d.lammpstrj"
+    _write_dump(p, coords, order, scaled, tri, steps)
+    want, _, wcells, wsteps = textio.read_lammps_dump(p)
+    t = V.TextTrajectory(p, lib=host_lib)
+    assert (t.num_frames(), t.num_atoms()) == (F, n)
+    np.testing.assert_array_equal(_frames(t), want)
+    if not scaled:
+        np.testing.assert_array_equal(want, coords)                 # repr() round-trips a float32 through its double
+    for f in range(F):
+        _, cell, ts = t.load_frame(f)
+        assert _cell_tuple(cell) == _cell_tuple(wcells[f]) and ts == float(wsteps[f])
+    assert t.load_frame(0)[1].flags == (3 if tri else 7)
+
+
+def test_evaluation_straight_from_a_pdb_trajectory(tmp_path, emu_lib, oracle):
+    """BASELINE configs[0] in small: a multi-MODEL PDB, `rdf(element('O'), element('O'), 10.0)`, evaluated through the native reader (frames
+    parsed on the staging threads) - the oracle's integers on the coordinates the file holds."""
+    import cases
+    from viamd_amd import script
+    F, n, box = 6, 600, 24.0
+    coords = cases.water_box(oracle, 4, n, box, F)
+    topo = _topo(n)
+    p = tmp_path / "water.pdb"
+    pdb.write_pdb(p, coords, topo, box=box)
+    held = pdb.read_pdb(p)[0]                                        # three decimals survive the file
+    traj = loader.open_trajectory(p, lib=emu_lib)
+    assert isinstance(traj, V.TextTrajectory) and traj.num_frames() == F
+    ir, info = script.compile_script("g = rdf(element('O'), element('O'), 10.0);", topo, lib=emu_lib)
+    ev = V.ScriptEval(F, ir)
+    old = emu_lib.vmd_set_option(b"load_threads", 3)
+    try:
+        assert ev.frame_range(V.MolSystem(n, mass=topo.mass, unitcell=traj.load_frame(0)[1]), traj, 0, F)
+    finally:
+        emu_lib.vmd_set_option(b"load_threads", old)
+    o = np.arange(0, n, 3, dtype=np.int32)
+    counts, _ = cases.oracle_rdf(oracle, held, oracle.make_cell(box), o, o, 0.0, 10.0)
+    np.testing.assert_array_equal(ev.property_data("g").counts, counts)
+    assert counts.sum() > 0

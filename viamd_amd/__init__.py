@@ -9,10 +9,11 @@ from ._lib import (DIST_COM, DIST_MAX, DIST_MIN, DIST_PAIR, FLAG_DISTRIBUTION, F
 from .eval import (MolSystem, PropertyDataView, ScriptEval, ScriptIR, VmdError, compute_histogram_masked,
                    downsample_histogram, make_unitcell)
 from .dcd import DcdTrajectory, write_dcd
+from .texttraj import TextTrajectory
 from .xdr import CompressedDeviceTrajectory, XdrTrajectory, write_trr, write_xtc
 from .trajectory import DeviceTrajectory, HostTrajectory, PinnedHostTrajectory
 
-__all__ = ["ScriptIR", "ScriptEval", "MolSystem", "HostTrajectory", "DeviceTrajectory", "PinnedHostTrajectory", "DcdTrajectory", "write_dcd",
+__all__ = ["ScriptIR", "ScriptEval", "MolSystem", "HostTrajectory", "DeviceTrajectory", "PinnedHostTrajectory", "DcdTrajectory", "write_dcd", "TextTrajectory",
            "XdrTrajectory", "CompressedDeviceTrajectory", "write_xtc", "write_trr",
            "PropertyDataView", "VmdError",
            "make_unitcell", "downsample_histogram", "compute_histogram_masked", "VmdLib", "default_lib"]

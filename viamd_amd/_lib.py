@@ -210,6 +210,9 @@ SIGNATURES = [
     ("vmd_dcdtraj_open", _vp, [C.c_char_p]),
     ("vmd_dcdtraj_close", None, [_vp]),
     ("vmd_dcdtraj_interface", C.POINTER(TrajectoryI), [_vp]),
+    ("vmd_texttraj_open", _vp, [C.c_char_p, C.c_char_p]),
+    ("vmd_texttraj_close", None, [_vp]),
+    ("vmd_texttraj_interface", C.POINTER(TrajectoryI), [_vp]),
     ("vmd_xdrtraj_open", _vp, [C.c_char_p]),
     ("vmd_xdrtraj_close", None, [_vp]),
     ("vmd_xdrtraj_interface", C.POINTER(TrajectoryI), [_vp]),

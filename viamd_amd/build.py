@@ -9,7 +9,7 @@ SOURCES = [os.path.join(_HERE, "csrc", "vmd_kernels.hip"), os.path.join(_HERE, "
            os.path.join(_HERE, "csrc", "vmd_eval.cpp"),
            os.path.join(_HERE, "csrc", "vmd_dcd.cpp"), os.path.join(_HERE, "csrc", "vmd_xdr.cpp"),
            os.path.join(_HERE, "csrc", "vmd_script.cpp"), os.path.join(_HERE, "csrc", "vmd_reduce.cpp"),
-           os.path.join(_HERE, "csrc", "vmd_export.cpp")]
+           os.path.join(_HERE, "csrc", "vmd_export.cpp"), os.path.join(_HERE, "csrc", "vmd_text.cpp")]
 HEADERS = [os.path.join(ROOT, "include", "vmd_eval.h"), os.path.join(ROOT, "include", "vmd_hip.h")]
 OUT = os.path.join(_HERE, "libviamd_amd.so")
 

@@ -6,8 +6,8 @@ mdlib reader, :111-159).
     traj = loader.open_trajectory("run.xtc")                        # LoaderFlag_Trajectory: md_trajectory_i stand-in
     ev.frame_range(MolSystem(traj.num_atoms(), mass=topo.mass, unitcell=cell), traj, 0, traj.num_frames())
 
-Binary trajectories (DCD, XTC, TRR) go through the native readers (random access, decoded on the evaluator's staging
-threads); text formats are parsed once and held as a HostTrajectory.
+Trajectories go through the native readers (random access, decoded on the evaluator's staging threads): DCD, XTC, TRR and - since
+round 4 - the text formats (multi-MODEL PDB, XYZ / XMOL, LAMMPS dump: csrc/vmd_text.cpp).  Systems (topologies) are read in Python.
 """
 import os
 
@@ -105,7 +105,6 @@ def open_trajectory(path, lib=None):
     """-> an object with interface() / num_frames() / num_atoms() for ScriptEval.frame_range, for every type with
     LoaderFlag_Trajectory (md_*_attach_from_file / the multi-frame text readers)."""
     from .dcd import DcdTrajectory
-    from .trajectory import HostTrajectory
     from .xdr import XdrTrajectory
     kind, flags = loader_type(path)
     if not flags & FLAG_TRAJECTORY:
@@ -114,11 +113,6 @@ def open_trajectory(path, lib=None):
         return DcdTrajectory(path, lib=lib)
     if kind in ("xtc", "trr"):
         return XdrTrajectory(path, lib=lib)
-    if kind == "pdb":
-        coords, _, cell = pdb.read_pdb(path)
-        return HostTrajectory(coords, cell)
-    if kind == "xyz":
-        coords, _, cells = textio.read_xyz(path)
-        return HostTrajectory(coords, cells)
-    coords, _, cells, _ = textio.read_lammps_dump(path)
-    return HostTrajectory(coords, cells)
+    # multi-MODEL PDB, XYZ / XMOL, LAMMPS dump: the native text reader (mapped file, frame index, parsed on the staging threads)
+    from .texttraj import TextTrajectory
+    return TextTrajectory(path, format={"pdb": "pdb", "xyz": "xyz"}.get(kind, "lammpstrj"), lib=lib)
