@@ -476,6 +476,16 @@ typedef struct vmd_texttraj_t vmd_texttraj_t;
 vmd_texttraj_t*   vmd_texttraj_open(const char* path, const char* format);
 void              vmd_texttraj_close(vmd_texttraj_t* t);
 vmd_trajectory_i* vmd_texttraj_interface(vmd_texttraj_t* t);
+/* The SYSTEM of a PDB file (LoaderFlag_System, md_pdb_system_init_from_file, src/loader.cpp:113-128) as far as this path reads it: the
+ * topology the script front-end resolves selections against (element, atom name, residue name, residue index, resSeq of the first model's
+ * atoms), masses from the elements, the first model's coordinates ([3][num_atoms]: x row, y row, z row) and the CRYST1 cell.  With it a host
+ * without mdlib runs BASELINE configs[0] from the file alone: vmd_textsys_open + vmd_texttraj_open + vmd_ir_compile_from_source. */
+typedef struct vmd_textsys_t vmd_textsys_t;
+vmd_textsys_t*        vmd_textsys_open(const char* path);
+void                  vmd_textsys_close(vmd_textsys_t* s);
+const vmd_topology_t* vmd_textsys_topology(const vmd_textsys_t* s);
+const float*          vmd_textsys_mass(const vmd_textsys_t* s);
+const float*          vmd_textsys_coords(const vmd_textsys_t* s, vmd_unitcell_t* cell);
 
 /* GROMACS XTC (compressed) / TRR trajectory file as a vmd_trajectory_i - VIAMD attaches these through md_xtc_attach_from_file /
  * md_trr_attach_from_file (src/loader.cpp:147-150).  The file type is taken from the magic number; a frame-offset index is

@@ -164,3 +164,59 @@ def test_evaluation_straight_from_a_pdb_trajectory(tmp_path, emu_lib, oracle):
     counts, _ = cases.oracle_rdf(oracle, held, oracle.make_cell(box), o, o, 0.0, 10.0)
     np.testing.assert_array_equal(ev.property_data("g").counts, counts)
     assert counts.sum() > 0
+
+
+def test_pdb_system_and_a_cpp_host_running_config_1_from_the_file_alone(tmp_path, emu_lib, oracle):
+    """BASELINE configs[0] (`datasets/1ALA-500.pdb`, `rdf(element('O'),element('O'),10.0)`: the blob is missing from the reference, so a
+    stand-in of the same kind - a capped alanine in water, multi-MODEL PDB): the native PDB SYSTEM reader equals the Python one (elements,
+    names, residues, resSeq, masses, first-frame coordinates, cell), and a C++ program that is given nothing but the file and the script
+    string (tests/native/cabi_pdb_demo.cpp) prints the sums the Python host gets through its own readers."""
+    import ctypes as C
+    import os
+    import subprocess
+    import cases
+    import conftest
+    from viamd_amd import _lib as L, script
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    F, n_w, box = 5, 150, 22.0
+    names = ["N", "CA", "C", "O", "CB", "H", "HA", "HB1", "HB2", "HB3"]
+    elems = ["N", "C", "C", "O", "C", "H", "H", "H", "H", "H"]
+    n = 10 + 3 * n_w
+    topo = Topology(elems + ["O", "H", "H"] * n_w, ["ALA"] * 10 + ["HOH"] * (3 * n_w), [0] * 10 + [1 + i // 3 for i in range(3 * n_w)],
+                    names + ["OW", "HW1", "HW2"] * n_w)
+    coords = cases.water_box(oracle, 8, n, box, F)
+    p = tmp_path / "ala.pdb"
+    pdb.write_pdb(p, coords, topo, box=box)
+    want_c, want_t, want_cell = pdb.read_pdb(p)
+    h = emu_lib.vmd_textsys_open(str(p).encode())
+    assert h, emu_lib.last_error()
+    t = emu_lib.vmd_textsys_topology(h).contents
+    assert t.num_atoms == n
+    assert [t.elements[i].decode() for i in range(n)] == list(want_t.elements)
+    assert [t.names[i].decode() for i in range(n)] == list(want_t.names) and [t.resnames[i].decode() for i in range(n)] == list(want_t.resnames)
+    np.testing.assert_array_equal(np.ctypeslib.as_array(t.residue_index, (n,)), np.asarray(want_t.residue_index))
+    np.testing.assert_array_equal(np.ctypeslib.as_array(t.residue_seq_id, (n,)), np.asarray(want_t.residue_seq_id))
+    np.testing.assert_array_equal(np.ctypeslib.as_array(emu_lib.vmd_textsys_mass(h), (n,)), want_t.mass)
+    cell = L.Unitcell()
+    xyz = np.ctypeslib.as_array(emu_lib.vmd_textsys_coords(h, C.byref(cell)), (3, n)).copy()
+    np.testing.assert_array_equal(xyz, want_c[0])
+    assert _cell_tuple(cell) == _cell_tuple(want_cell)
+    emu_lib.vmd_textsys_close(h)
+    # the C++ host
+    text = "g = rdf(element('O'), element('O'), 10.0); d = distance(resname('ALA'), residue(5));"
+    exe = str(tmp_path / "cabi_pdb_demo")
+    emu = conftest.build_emu()
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", os.path.join(ROOT, "tests", "native", "cabi_pdb_demo.cpp"), "-I" + os.path.join(ROOT, "include"), emu,
+                           "-Wl,-rpath," + os.path.dirname(emu), "-lpthread", "-o", exe])
+    out = subprocess.run([exe, str(p), text], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = out.stdout.strip().split("\n")
+    assert lines[0].startswith(f"atoms={n} frames={F} residues={1 + n_w} first=N/N/ALA last_mass=1.008 cell=22.000,22.000,22.000"), lines[0]
+    got = dict(l.split(" ", 1) for l in lines[1:])
+    ir, info = script.compile_script(text, want_t, lib=emu_lib)
+    ev = V.ScriptEval(F, ir)
+    assert ev.frame_range(V.MolSystem(n, mass=want_t.mass, unitcell=want_cell), V.HostTrajectory(want_c, want_cell), 0, F)
+    assert float(got["g"].split("sum=")[1]) == float(ev.property_data("g").counts.sum()) > 0
+    o = np.array([i for i in range(n) if want_t.elements[i] == "O"], np.int32)
+    np.testing.assert_array_equal(ev.property_data("g").counts, cases.oracle_rdf(oracle, want_c, oracle.make_cell(box), o, o, 0.0, 10.0)[0])
+    assert abs(float(got["d"].split("sum=")[1]) - float(ev.property_data("d").values.astype(np.float64).sum())) < 1e-5

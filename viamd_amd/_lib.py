@@ -213,6 +213,11 @@ SIGNATURES = [
     ("vmd_texttraj_open", _vp, [C.c_char_p, C.c_char_p]),
     ("vmd_texttraj_close", None, [_vp]),
     ("vmd_texttraj_interface", C.POINTER(TrajectoryI), [_vp]),
+    ("vmd_textsys_open", _vp, [C.c_char_p]),
+    ("vmd_textsys_close", None, [_vp]),
+    ("vmd_textsys_topology", C.POINTER(TopologyC), [_vp]),
+    ("vmd_textsys_mass", c_float_p, [_vp]),
+    ("vmd_textsys_coords", c_float_p, [_vp, _vp]),
     ("vmd_xdrtraj_open", _vp, [C.c_char_p]),
     ("vmd_xdrtraj_close", None, [_vp]),
     ("vmd_xdrtraj_interface", C.POINTER(TrajectoryI), [_vp]),

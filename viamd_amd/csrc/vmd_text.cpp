@@ -454,3 +454,85 @@ extern "C" vmd_texttraj_t* vmd_texttraj_open(const char* path, const char* forma
 }
 
 extern "C" vmd_trajectory_i* vmd_texttraj_interface(vmd_texttraj_t* h) { return h ? &h->t.iface : nullptr; }
+
+// ---- the system (md_system_t as far as the script front-end and the evaluator read it) out of a PDB file: what
+// md_pdb_system_init_from_file gives VIAMD for LoaderFlag_System (src/loader.cpp:113-128).  Columns as in viamd_amd/pdb.py: element = 77-78,
+// else the first letter of the atom name; name 13-16; residue name 18-20; chain 22; resSeq 23-26.  A new residue starts whenever
+// (chain, resSeq) changes.  Only the atoms of the FIRST model are read.
+namespace {
+struct ElementMass { const char* sym; float mass; };
+const ElementMass kMass[] = {{"H", 1.008f}, {"He", 4.0026f}, {"Li", 6.94f}, {"Be", 9.0122f}, {"B", 10.81f}, {"C", 12.011f}, {"N", 14.007f}, {"O", 15.999f},
+    {"F", 18.998f}, {"Ne", 20.180f}, {"Na", 22.990f}, {"Mg", 24.305f}, {"Al", 26.982f}, {"Si", 28.085f}, {"P", 30.974f}, {"S", 32.06f}, {"Cl", 35.45f},
+    {"Ar", 39.948f}, {"K", 39.098f}, {"Ca", 40.078f}, {"Ti", 47.867f}, {"Cr", 51.996f}, {"Mn", 54.938f}, {"Fe", 55.845f}, {"Co", 58.933f}, {"Ni", 58.693f},
+    {"Cu", 63.546f}, {"Zn", 65.38f}, {"Se", 78.971f}, {"Br", 79.904f}, {"Rb", 85.468f}, {"Sr", 87.62f}, {"Mo", 95.95f}, {"Ag", 107.87f}, {"Cd", 112.41f},
+    {"I", 126.90f}, {"Cs", 132.91f}, {"Ba", 137.33f}, {"Pt", 195.08f}, {"Au", 196.97f}, {"Hg", 200.59f}, {"Pb", 207.2f}};
+float element_mass(const std::string& e) {
+    for (const ElementMass& m : kMass) if (e == m.sym) return m.mass;
+    return 12.0f;
+}
+std::string strip(const char* b, const char* e) {
+    while (b < e && (*b == ' ' || *b == '\t')) ++b;
+    while (e > b && (e[-1] == ' ' || e[-1] == '\t')) --e;
+    return std::string(b, e);
+}
+}  // namespace
+
+struct vmd_textsys_t {
+    std::vector<std::string> elements, names, resnames;
+    std::vector<const char*> p_elements, p_names, p_resnames;
+    std::vector<int32_t> residue_index, residue_seq_id;
+    std::vector<float> mass, xyz;
+    vmd_unitcell_t cell;
+    vmd_topology_t topo;
+};
+
+extern "C" void vmd_textsys_close(vmd_textsys_t* s) { delete s; }
+
+extern "C" vmd_textsys_t* vmd_textsys_open(const char* path) {
+    vmd_texttraj_t* h = vmd_texttraj_open(path, "pdb");
+    if (!h) return nullptr;
+    const TextTraj* t = &h->t;
+    vmd_textsys_t* s = new vmd_textsys_t();
+    const Frame& f = t->frames[0];
+    const size_t n = t->num_atoms;
+    s->cell = f.cell;
+    s->xyz.resize(3 * n);
+    bool ok = load_pdb(t, f, s->xyz.data(), s->xyz.data() + n, s->xyz.data() + 2 * n);
+    const char* p = t->data + f.beg;
+    const char* end = t->data + f.end;
+    Line l;
+    char last_chain = 0;
+    long last_seq = 0;
+    int32_t res = -1;
+    while (ok && next_line(p, end, &l)) {
+        if (!is_atom_record(l)) continue;
+        const size_t len = (size_t)(l.e - l.b);
+        std::string name = strip(l.b + 12, l.b + std::min<size_t>(16, len));
+        std::string el = len >= 78 ? strip(l.b + 76, l.b + 78) : std::string();
+        if (el.empty()) el = name.substr(0, 1);
+        if (!el.empty()) { el[0] = (char)toupper((unsigned char)el[0]); for (size_t k = 1; k < el.size(); ++k) el[k] = (char)tolower((unsigned char)el[k]); }
+        const char chain = len > 21 ? l.b[21] : ' ';
+        bool okn = false;
+        const long seq = len >= 26 ? (long)parse_double(l.b + 22, l.b + 26, &okn) : 0;
+        if (!okn) { ok = fail(t->path + ": unreadable residue number in atom record " + std::to_string(s->elements.size() + 1)); break; }
+        if (res < 0 || chain != last_chain || seq != last_seq) { ++res; last_chain = chain; last_seq = seq; }
+        s->elements.push_back(el); s->names.push_back(name); s->resnames.push_back(strip(l.b + 17, l.b + std::min<size_t>(20, len)));
+        s->residue_index.push_back(res); s->residue_seq_id.push_back((int32_t)seq);
+        s->mass.push_back(element_mass(el));
+    }
+    vmd_texttraj_close(h);
+    if (!ok) { delete s; return nullptr; }
+    for (size_t i = 0; i < n; ++i) { s->p_elements.push_back(s->elements[i].c_str()); s->p_names.push_back(s->names[i].c_str()); s->p_resnames.push_back(s->resnames[i].c_str()); }
+    s->topo.num_atoms = n;
+    s->topo.elements = s->p_elements.data(); s->topo.names = s->p_names.data(); s->topo.resnames = s->p_resnames.data();
+    s->topo.residue_index = s->residue_index.data(); s->topo.residue_seq_id = s->residue_seq_id.data();
+    return s;
+}
+
+extern "C" const vmd_topology_t* vmd_textsys_topology(const vmd_textsys_t* s) { return s ? &s->topo : nullptr; }
+extern "C" const float* vmd_textsys_mass(const vmd_textsys_t* s) { return s ? s->mass.data() : nullptr; }
+extern "C" const float* vmd_textsys_coords(const vmd_textsys_t* s, vmd_unitcell_t* cell) {
+    if (!s) return nullptr;
+    if (cell) *cell = s->cell;
+    return s->xyz.data();
+}
