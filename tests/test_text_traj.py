@@ -167,6 +167,17 @@ def test_evaluation_straight_from_a_pdb_trajectory(tmp_path, emu_lib, oracle):
 
 
 def test_pdb_system_and_a_cpp_host_running_config_1_from_the_file_alone(tmp_path, emu_lib, oracle):
+    import conftest
+    _pdb_host_case(tmp_path, emu_lib, conftest.build_emu(), oracle)
+
+
+@pytest.mark.gpu
+def test_cpp_host_runs_config_1_from_a_pdb_file_on_the_gpu(tmp_path, gpu_lib, oracle):
+    from viamd_amd import build
+    _pdb_host_case(tmp_path, gpu_lib, build.build(), oracle, n_w=3000, box=46.0, F=12)
+
+
+def _pdb_host_case(tmp_path, emu_lib, emu, oracle, n_w=150, box=22.0, F=5):
     """BASELINE configs[0] (`datasets/1ALA-500.pdb`, `rdf(element('O'),element('O'),10.0)`: the blob is missing from the reference, so a
     stand-in of the same kind - a capped alanine in water, multi-MODEL PDB): the native PDB SYSTEM reader equals the Python one (elements,
     names, residues, resSeq, masses, first-frame coordinates, cell), and a C++ program that is given nothing but the file and the script
@@ -175,10 +186,8 @@ def test_pdb_system_and_a_cpp_host_running_config_1_from_the_file_alone(tmp_path
     import os
     import subprocess
     import cases
-    import conftest
     from viamd_amd import _lib as L, script
     ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    F, n_w, box = 5, 150, 22.0
     names = ["N", "CA", "C", "O", "CB", "H", "HA", "HB1", "HB2", "HB3"]
     elems = ["N", "C", "C", "O", "C", "H", "H", "H", "H", "H"]
     n = 10 + 3 * n_w
@@ -205,13 +214,12 @@ def test_pdb_system_and_a_cpp_host_running_config_1_from_the_file_alone(tmp_path
     # the C++ host
     text = "g = rdf(element('O'), element('O'), 10.0); d = distance(resname('ALA'), residue(5));"
     exe = str(tmp_path / "cabi_pdb_demo")
-    emu = conftest.build_emu()
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", os.path.join(ROOT, "tests", "native", "cabi_pdb_demo.cpp"), "-I" + os.path.join(ROOT, "include"), emu,
-                           "-Wl,-rpath," + os.path.dirname(emu), "-lpthread", "-o", exe])
+                           "-Wl,-rpath," + os.path.dirname(emu), "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", "-Wl,-rpath-link,/opt/rocm/lib", "-lpthread", "-o", exe])
     out = subprocess.run([exe, str(p), text], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = out.stdout.strip().split("\n")
-    assert lines[0].startswith(f"atoms={n} frames={F} residues={1 + n_w} first=N/N/ALA last_mass=1.008 cell=22.000,22.000,22.000"), lines[0]
+    assert lines[0].startswith(f"atoms={n} frames={F} residues={1 + n_w} first=N/N/ALA last_mass=1.008 cell={box:.3f},{box:.3f},{box:.3f}"), lines[0]
     got = dict(l.split(" ", 1) for l in lines[1:])
     ir, info = script.compile_script(text, want_t, lib=emu_lib)
     ev = V.ScriptEval(F, ir)
