@@ -129,3 +129,73 @@ def test_plain_float_files_leave_the_mapped_file_by_dma_on_the_gpu(gpu_lib, orac
             assert res[0].sum() > 0
     finally:
         gpu_lib.vmd_set_option(b"batch_frames", old_b)
+
+
+def _pool_from_files(lib, oracle, tmp_path, box, F, N, nthreads):
+    """VIAMD's call pattern on trajectories that come out of FILES: pool threads ask for one frame each, read-ahead evaluates regions of
+    frame blocks - whose frames are staged / decompressed on the device / parsed by the native readers - and every file type must leave what
+    one call over the same file leaves, bit for bit (XTC: the device decoder and its checkpoints under regions of changing size)."""
+    import threading
+    from viamd_amd import pdb
+    from viamd_amd.script import Topology
+    coords = cases.water_box(oracle, 37, N, box, F)
+    cell = V.make_unitcell(box)
+    o = cases.oxygen(N)
+    ir = V.ScriptIR(lib); ir.add_rdf("g", o, o, 9.0); ir.add_distance("d", np.arange(3, dtype=np.int32), np.arange(30, 33, dtype=np.int32), 1)
+    sysm = V.MolSystem(N, unitcell=cell)
+    topo = Topology((["O", "H", "H"] * N)[:N])
+    files = {}
+    for fmt, write in (("xtc", V.write_xtc), ("trr", V.write_trr), ("dcd", None), ("pdb", None)):
+        p = tmp_path / f"pool.{fmt}"
+        if fmt == "dcd":
+            V.write_dcd(p, coords, cell)
+        elif fmt == "pdb":
+            pdb.write_pdb(p, coords, topo, box=box)
+        else:
+            write(p, coords, cell, lib=lib)
+        files[fmt] = p
+    opts = [(b"readahead_block", 4), (b"readahead_frames", 8), (b"readahead_growth", 2), (b"readahead_company_us", 200000)]
+    old = [(k, lib.vmd_set_option(k, v)) for k, v in opts]
+    try:
+        for fmt, p in files.items():
+            opener = {"xtc": V.XdrTrajectory, "trr": V.XdrTrajectory, "dcd": V.DcdTrajectory, "pdb": V.TextTrajectory}[fmt]
+            one = V.ScriptEval(F, ir)
+            old_ra = lib.vmd_set_option(b"readahead", 0)
+            try:
+                assert one.frame_range(sysm, opener(p, lib=lib), 0, F)
+            finally:
+                lib.vmd_set_option(b"readahead", old_ra)
+            traj = opener(p, lib=lib)
+            ev = V.ScriptEval(F, ir)
+            nxt = [0]; lock = threading.Lock(); res = []
+            gate = threading.Barrier(nthreads)
+            def work():
+                gate.wait()
+                while True:
+                    with lock:
+                        f = nxt[0]; nxt[0] += 1
+                    if f >= F:
+                        return
+                    res.append(ev.frame_range(sysm, traj, f, f + 1))
+            ths = [threading.Thread(target=work) for _ in range(nthreads)]
+            [t.start() for t in ths]; [t.join() for t in ths]
+            assert all(res) and ev.frames_done() == F and ev.frame_mask().all(), fmt
+            st = ev.readahead_stats()
+            assert st["engaged"] == 1 and st["regions"] >= 2, (fmt, st)
+            np.testing.assert_array_equal(ev.property_data("g").counts, one.property_data("g").counts, err_msg=fmt)
+            np.testing.assert_array_equal(ev.property_data("d").values, one.property_data("d").values, err_msg=fmt)
+            np.testing.assert_array_equal(ev.property_data("g").weights, one.property_data("g").weights, err_msg=fmt)
+            assert one.property_data("g").counts.sum() > 0
+            ev.close(); one.close()
+    finally:
+        for k, v in old:
+            lib.vmd_set_option(k, v)
+
+
+def test_pool_pattern_on_file_trajectories_on_emulator(emu_lib, oracle, tmp_path):
+    _pool_from_files(emu_lib, oracle, tmp_path, 30.0, 24, 600, 5)
+
+
+@pytest.mark.gpu
+def test_pool_pattern_on_file_trajectories(gpu_lib, oracle, tmp_path):
+    _pool_from_files(gpu_lib, oracle, tmp_path, 70.0, 96, 30000, 12)
