@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -77,6 +78,31 @@ int main(int argc, char** argv) {
         }
         return ms;
     };
+    // the order enkiTS really produces (TaskScheduler::AddTaskSetToPipe): the set is cut into threads x (threads - 1) partitions of at least one
+    // grain; the thread that added the set pops partitions off the END of its pipe, every other thread steals from the FRONT
+    auto pooled_enki = [&](int nthreads) {
+        vmd_eval_clear_data(eval);
+        const uint32_t parts = (uint32_t)std::max(1, nthreads * (nthreads - 1));
+        const uint32_t per = std::max<uint32_t>(1, (uint32_t)F / parts);
+        int64_t front = 0, back = (int64_t)((F + per - 1) / per) - 1;
+        std::mutex pipe;
+        std::vector<std::thread> pool;
+        const double t = now_ms();
+        for (int k = 0; k < nthreads; ++k)
+            pool.emplace_back([&, k] {
+                for (;;) {
+                    int64_t i;
+                    { std::lock_guard<std::mutex> l(pipe); if (front > back) break; i = k == 0 ? back-- : front++; }
+                    const uint32_t beg = (uint32_t)i * per, end = std::min<uint32_t>((uint32_t)F, beg + per);
+                    if (!vmd_eval_frame_range(eval, ir, &sys, traj, beg, end)) break;
+                }
+            });
+        for (auto& th : pool) th.join();
+        const double ms = now_ms() - t;
+        const vmd_script_property_data_t* pd = vmd_eval_property_data(eval, sdf ? "v" : "g");
+        const bool same = ref_values.size() == pd->num_values && memcmp(ref_values.data(), pd->values, pd->num_values * sizeof(float)) == 0;
+        return std::make_pair(ms, same && vmd_eval_frames_done(eval) == F);
+    };
     one();
     { const vmd_script_property_data_t* pd = vmd_eval_property_data(eval, sdf ? "v" : "g"); ref_values.assign(pd->values, pd->values + pd->num_values); }
     double best = 1e30;
@@ -87,6 +113,11 @@ int main(int argc, char** argv) {
         double b = 1e30;
         for (int r = 0; r < 3; ++r) b = std::min(b, pooled(c[0], (uint32_t)c[1]));
         std::printf(" | %d threads grain %d: %.2f ms", c[0], c[1], b);
+    }
+    {
+        double b = 1e30; int clean = 0;
+        for (int r = 0; r < 5; ++r) { auto pr = pooled_enki(16); if (pr.second) { b = std::min(b, pr.first); ++clean; } }
+        std::printf(" | 16 threads, enkiTS order (threads x (threads - 1) partitions, owner from the end, thieves from the front; %d of 5 runs identical to the one call): %.2f ms", clean, b);
     }
     std::printf("\n");
     vmd_readahead_stats_t st;

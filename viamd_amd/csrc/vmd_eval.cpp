@@ -3338,6 +3338,13 @@ static bool ra_call(vmd_script_eval_t* e, const vmd_system_t* sys, vmd_trajector
                 frames += std::min((e1 + 1) * S, e->num_frames) - e1 * S;
                 ++e1;
             }
+            // a caller that walks the range downwards (enkiTS: the thread that owns the task set pops its partitions from the far end while
+            // the others steal from the near end) finds everything above its block taken: the region grows towards lower frames instead
+            // (only when the way up is blocked - by evaluated blocks or the end of the trajectory - and never across blocks that are not free)
+            while (frames < want && need > 0 && ra.blk_state[need - 1].load() == vmd_script_eval_t::RA_NONE) {
+                --need;
+                frames += S;
+            }
             ra.next_region = std::min(std::max(ra.bmax, S), want * (size_t)std::max(1, g_opt.readahead_growth.load()));
             for (size_t b = need; b < e1; ++b) ra.blk_state[b].store(vmd_script_eval_t::RA_PENDING, std::memory_order_release);
             ra.spec_active = true;
