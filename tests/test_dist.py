@@ -47,6 +47,12 @@ def _worker(rank, world, port, tmpdir, mode="host", on_gpu=False):
     ev = V.ScriptEval(F, ir)
     vcell = V.make_unitcell(36.0)
     beg, end = shard_frames(F, rank, world)
+    F = 11 if mode == "shard_pool" else 5
+    if mode == "shard_pool":
+        coords, structures, mass = cases.sdf_system(O, 21, 900, 36.0, F)
+        ev.close()
+        ev = V.ScriptEval(F, ir)
+        beg, end = shard_frames(F, rank, world)
     if mode == "host":
         traj = V.HostTrajectory(coords, vcell)
     else:
@@ -56,12 +62,32 @@ def _worker(rank, world, port, tmpdir, mode="host", on_gpu=False):
         assert not on_gpu or bool(traj.device_ptr()[0])
         for f in sorted(set(range(beg, end)) | {0}):
             traj.upload_frame(f, vcell, coords[f, 0], coords[f, 1], coords[f, 2])
-        if rank == world - 1:       # world 4: the EMPTY shard [5, 5) - nothing is resident there, it is not "the whole trajectory"
+        if rank == world - 1 and mode == "shard":       # world 4: the EMPTY shard [5, 5) - nothing is resident there, it is not "the whole trajectory"
             import pytest
             with pytest.raises(V.VmdError, match="not resident"):
                 ev.frame_range(V.MolSystem(N, mass=mass, unitcell=vcell), traj, 0, F)
             ev.clear_data()
-    assert ev.frame_range(V.MolSystem(N, mass=mass, unitcell=vcell), traj, beg, end)
+    if mode == "shard_pool":
+        # the rank's pool threads walk its shard one frame per call (VIAMD's pattern on every GPU of the node): read-ahead evaluates regions of
+        # whole blocks INSIDE the shard, the blocks that straddle its ends are evaluated frame by frame
+        import threading
+        old = [(k, lib.vmd_set_option(k, v)) for k, v in ((b"readahead_block", 2), (b"readahead_frames", 2), (b"readahead_company_us", 200000))]
+        sysm = V.MolSystem(N, mass=mass, unitcell=vcell)
+        nxt = [beg]; lock = threading.Lock(); res = []
+        def work():
+            while True:
+                with lock:
+                    f = nxt[0]; nxt[0] += 1
+                if f >= end:
+                    return
+                res.append(ev.frame_range(sysm, traj, f, f + 1))
+        ths = [threading.Thread(target=work) for _ in range(3)]
+        [t.start() for t in ths]; [t.join() for t in ths]
+        for k, v in old:
+            lib.vmd_set_option(k, v)
+        assert all(res)
+    else:
+        assert ev.frame_range(V.MolSystem(N, mass=mass, unitcell=vcell), traj, beg, end)
     assert ev.frames_done() == end - beg
     reduce_eval(ev)
     assert ev.frame_mask().all() and ev.frames_done() == F
@@ -85,17 +111,17 @@ def test_shard_frames_covers_everything():
 import pytest
 
 
-@pytest.mark.parametrize("mode,world", [("host", 2), ("shard", 2), ("host", 4), ("shard", 4)])
+@pytest.mark.parametrize("mode,world", [("host", 2), ("shard", 2), ("host", 4), ("shard", 4), ("shard_pool", 2)])
 def test_two_rank_gloo_merge_matches_oracle(oracle, emu_lib, tmp_path, mode, world):
     """every rank evaluates its block of frames, ONE vmd_eval_reduce (C++, behind the ABI) merges; `shard`: each rank holds
     only its block of a device trajectory; 4 ranks on 5 frames: blocks of 2, 2, 1 and an EMPTY block (a rank without frames still
     takes part in the merge)"""
     import cases
     from viamd_amd import _lib as L
-    port = 29500 + (os.getpid() % 2000) + (7 if mode == "shard" else 0) + 13 * (world - 2)
+    port = 29500 + (os.getpid() % 2000) + (7 if mode == "shard" else 0) + (11 if mode == "shard_pool" else 0) + 13 * (world - 2)
     # ("shard", 4): rank 3 owns no frame; its device view must refuse every range (ADVICE r02: it used to read as "unsharded")
     mp.spawn(_worker, args=(world, port, str(tmp_path), mode), nprocs=world, join=True)
-    F = 5
+    F = 11 if mode == "shard_pool" else 5
     coords, structures, mass = cases.sdf_system(oracle, 21, 900, 36.0, F)
     N = coords.shape[2]
     o = np.arange(structures.size, N, 3, dtype=np.int32)
