@@ -15,6 +15,7 @@
 // to float - but without the locale: up to 15 significant digits and a decimal exponent within +-22 are exact in double arithmetic (one
 // correctly rounded multiply or divide by an exact power of ten); anything longer goes through strtod on a copy.
 #include <algorithm>
+#include <cctype>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -69,12 +70,11 @@ double parse_double(const char* b, const char* e, bool* ok) {
     bool neg = false;
     if (p < e && (*p == '+' || *p == '-')) { neg = *p == '-'; ++p; }
     uint64_t m = 0;
-    int digits = 0, sig = 0, exp10 = 0;
+    int sig = 0, exp10 = 0;
     bool any = false, exact = true;
     for (; p < e && *p >= '0' && *p <= '9'; ++p) {
         any = true;
         if (sig < 19) { m = m * 10 + (uint64_t)(*p - '0'); if (m) ++sig; } else { exact = false; ++exp10; }
-        ++digits;
     }
     if (p < e && *p == '.') {
         ++p;
