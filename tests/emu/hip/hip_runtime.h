@@ -105,6 +105,7 @@ template <typename T>
 static inline T atomicExch(T* p, T v) { T old = *p; *p = v; return old; }
 static inline unsigned atomicMax(unsigned* p, unsigned v) { unsigned old = *p; if (v > old) *p = v; return old; }
 static inline unsigned atomicOr(unsigned* p, unsigned v) { unsigned old = *p; *p = old | v; return old; }
+static inline unsigned long long atomicMax(unsigned long long* p, unsigned long long v) { unsigned long long old = *p; if (v > old) *p = v; return old; }
 
 // ---- host runtime -------------------------------------------------------------------------------------------------
 typedef int hipError_t;

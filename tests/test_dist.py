@@ -23,6 +23,11 @@ def _worker(rank, world, port, tmpdir, mode="host", on_gpu=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    if mode.endswith("+measure"):
+        # the path config 4 takes at N >= 2: the static bound cannot prove the 32-bit sum, the ranks measure their largest voxel, the sums of
+        # the maxima travel in the packed all-reduce FIRST and decide (here: forced, on a system of test size)
+        os.environ["VIAMD_AMD_REDUCE_MEASURE"] = "1"
+        mode = mode[: -len("+measure")]
     if on_gpu:
         # real device memory, real kernels, every process on GPU 0; the merge's all-reduces are staged through host memory (gloo)
         # because RCCL refuses two ranks on one device.  torch first: its HIP runtime must be the one that finds the GPU (conftest.gpu_lib)
@@ -90,6 +95,10 @@ def _worker(rank, world, port, tmpdir, mode="host", on_gpu=False):
         assert ev.frame_range(V.MolSystem(N, mass=mass, unitcell=vcell), traj, beg, end)
     assert ev.frames_done() == end - beg
     reduce_eval(ev)
+    from viamd_amd.dist import reduce_stats
+    st = reduce_stats(ev)
+    if os.environ.get("VIAMD_AMD_REDUCE_MEASURE") == "1":
+        assert st["volumes_as_u32"] == 1 and st["allreduce_calls"] >= 3, st      # measured: a few hundred hits per voxel at most - the volume travelled as u32
     assert ev.frame_mask().all() and ev.frames_done() == F
     np.savez(os.path.join(tmpdir, f"rank{rank}.npz"), goo=ev.property_data("goo").counts, w=ev.property_data("goo").weights64,
              v=ev.property_data("v").counts, d=ev.property_data("d").values, dp=ev.property_data("dp").values,
@@ -111,14 +120,14 @@ def test_shard_frames_covers_everything():
 import pytest
 
 
-@pytest.mark.parametrize("mode,world", [("host", 2), ("shard", 2), ("host", 4), ("shard", 4), ("shard_pool", 2)])
+@pytest.mark.parametrize("mode,world", [("host", 2), ("shard", 2), ("host", 4), ("shard", 4), ("shard_pool", 2), ("shard+measure", 2), ("host+measure", 3)])
 def test_two_rank_gloo_merge_matches_oracle(oracle, emu_lib, tmp_path, mode, world):
     """every rank evaluates its block of frames, ONE vmd_eval_reduce (C++, behind the ABI) merges; `shard`: each rank holds
     only its block of a device trajectory; 4 ranks on 5 frames: blocks of 2, 2, 1 and an EMPTY block (a rank without frames still
     takes part in the merge)"""
     import cases
     from viamd_amd import _lib as L
-    port = 29500 + (os.getpid() % 2000) + (7 if mode == "shard" else 0) + (11 if mode == "shard_pool" else 0) + 13 * (world - 2)
+    port = 29500 + (os.getpid() % 2000) + (7 if mode.startswith("shard") else 0) + (11 if mode == "shard_pool" else 0) + (17 if mode.endswith("measure") else 0) + 13 * (world - 2)
     # ("shard", 4): rank 3 owns no frame; its device view must refuse every range (ADVICE r02: it used to read as "unsharded")
     mp.spawn(_worker, args=(world, port, str(tmp_path), mode), nprocs=world, join=True)
     F = 11 if mode == "shard_pool" else 5
@@ -141,8 +150,8 @@ def test_two_rank_gloo_merge_matches_oracle(oracle, emu_lib, tmp_path, mode, wor
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world", [2, 3])
-def test_processes_sharing_one_gpu_merge_matches_oracle(oracle, gpu_lib, tmp_path, world):
+@pytest.mark.parametrize("world,mode", [(2, "shard"), (3, "shard"), (2, "shard+measure")])
+def test_processes_sharing_one_gpu_merge_matches_oracle(oracle, gpu_lib, tmp_path, world, mode):
     """VERDICT r03 #5 / SURVEY 8e on the hardware there is: `world` PROCESSES on GPU 0, each holding only its shard of a device
     trajectory (vmd_devtraj_create_shard) and running the real kernels on it, ONE vmd_eval_reduce per rank whose collective is a
     host-staged vmd_collective_i (D2H, gloo all-reduce, H2D).  Covers shard residency, per-process device state and the merge's
@@ -150,7 +159,7 @@ def test_processes_sharing_one_gpu_merge_matches_oracle(oracle, gpu_lib, tmp_pat
     import cases
     from viamd_amd import _lib as L
     port = 31500 + (os.getpid() % 2000) + world
-    mp.spawn(_worker, args=(world, port, str(tmp_path), "shard", True), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port + (5 if mode != "shard" else 0), str(tmp_path), mode, True), nprocs=world, join=True)
     F = 5
     coords, structures, mass = cases.sdf_system(oracle, 21, 900, 36.0, F)
     N = coords.shape[2]

@@ -16,6 +16,8 @@
 #include <dlfcn.h>
 
 #include <cstdio>
+#include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -181,6 +183,19 @@ __global__ void k_widen_u32(const uint32_t* __restrict__ src, uint64_t* __restri
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dst[i] = (uint64_t)src[i];
 }
+// the largest count of a volume on THIS rank (block maximum through LDS, one atomicMax per block): what the measured bound of the narrowing is made of
+__global__ void k_max_u64(const uint64_t* __restrict__ src, size_t n, unsigned long long* __restrict__ out) {
+    __shared__ unsigned long long part[256];
+    unsigned long long m = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) m = src[i] > m ? src[i] : m;
+    part[threadIdx.x] = m;
+    __syncthreads();
+    for (unsigned o = blockDim.x / 2; o > 0; o >>= 1) {
+        if (threadIdx.x < o && part[threadIdx.x + o] > part[threadIdx.x]) part[threadIdx.x] = part[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && part[0]) atomicMax(out, part[0]);
+}
 // staging of what travels: one buffer per device for the whole process (a merge per evaluation: no allocation in the steady state);
 // merges on one device take turns (the buffer used to be thread_local - leaked per thread - and lived on whatever
 // device the caller had current)
@@ -227,20 +242,28 @@ extern "C" bool vmd_eval_reduce(vmd_script_eval_t* eval, const vmd_collective_i*
     //  * everything that lives on the host as ONE fp64 buffer: normalisation weights, temporal rows (zero on the ranks that did not
     //    evaluate the frame; a float survives the trip through fp64 unchanged) and the frame mask (a frame is evaluated by one rank,
     //    so the sum is 0/1; > 0 also covers ranks that evaluated the same frame)
+    // VIAMD_AMD_REDUCE_MEASURE=1 (tests): never trust the static bound, always measure - the path config 4 takes, on systems of test size
+    const char* fm = getenv("VIAMD_AMD_REDUCE_MEASURE");
+    const bool force_measure = fm && fm[0] == '1';
     size_t n_f64 = F, n_u32 = 0;
-    std::vector<char> narrow(nviews, 0);
+    std::vector<char> narrow(nviews, 0);          // 1 = the bound proves it, 2 = to be decided from the measured maxima (below)
+    size_t n_measured = 0;
     for (size_t i = 0; i < nviews; ++i) {
         const vmd_accum_view_t& v = views[i];
         n_f64 += (v.weights64 ? v.num_weights : 0) + (v.temporal ? v.num_temporal : 0);
-        // count_bound assumes every frame is merged once; the frame mask also tolerates ranks that evaluated the same frames, which can
-        // multiply a voxel by up to the rank count: the narrowed path must hold that too.  Every rank computes the same bound from the
-        // same script and frame count, so all ranks decide alike.
-        if (coll->allreduce_sum_u32 && v.counts_dev && v.num_counts >= 65536 && v.count_bound != 0 && world > 0 &&
-            v.count_bound <= 0xffffffffull / (uint64_t)world) {
-            narrow[i] = 1;
-            n_u32 += (v.num_counts + 1) & ~(size_t)1;               // keep the fp64 part behind it 8-byte aligned
-        }
+        if (!(coll->allreduce_sum_u32 && v.counts_dev && v.num_counts >= 65536 && world > 0)) continue;
+        // count_bound assumes every frame index is merged once; ranks that evaluated the same indices (the bench's weak scaling does: every
+        // rank its own trajectory) multiply a voxel by up to the rank count, so the STATIC proof needs bound x ranks < 2^32.  Every rank
+        // computes the same bound from the same script and frame count, so all ranks decide alike.
+        if (!force_measure && v.count_bound != 0 && v.count_bound <= 0xffffffffull / (uint64_t)world) narrow[i] = 1;
+        // Where that fails (config 4: 10 000 frames x 7 structures x 33 000 targets = 2.3e9 - while no voxel of it ever holds more than a
+        // few hundred hits) the ranks MEASURE: the sum over the ranks of each rank's largest voxel bounds every merged voxel whatever
+        // the ranks evaluated.  The maxima ride in the packed fp64 all-reduce (a u64 below 2^53 survives it), which then has to leave
+        // BEFORE the volumes: two collective launches instead of one, 8.4 instead of 16.8 MB per volume on the links.
+        else { narrow[i] = 2; n_measured += 1; }
+        n_u32 += (v.num_counts + 1) & ~(size_t)1;               // keep the fp64 part behind it 8-byte aligned (reserved also for undecided volumes)
     }
+    n_f64 += n_measured;
     std::vector<double> packed(n_f64);
     {
         EvalLock lock(eval);                                         // the host-side arrays belong to the evaluator
@@ -252,6 +275,7 @@ extern "C" bool vmd_eval_reduce(vmd_script_eval_t* eval, const vmd_collective_i*
         const uint8_t* mask = vmd_eval_frame_mask(eval);
         for (size_t f = 0; f < F; ++f) packed[off + f] = mask[f] ? 1.0 : 0.0;
     }
+    const size_t off_measured = n_f64 - n_measured;      // the last n_measured slots: this rank's largest count per undecided volume
     std::lock_guard<std::mutex> scratch_lock(g_scratch_mtx[dev]);
     Scratch& sc = g_scratch[dev];
     const size_t need = n_u32 * sizeof(uint32_t) + n_f64 * sizeof(double);
@@ -263,11 +287,49 @@ extern "C" bool vmd_eval_reduce(vmd_script_eval_t* eval, const vmd_collective_i*
     }
     uint32_t* d_u32 = (uint32_t*)sc.p;
     double* d_packed = (double*)((char*)sc.p + n_u32 * sizeof(uint32_t));
-    bool ok = hipMemcpyAsync(d_packed, packed.data(), n_f64 * sizeof(double), hipMemcpyHostToDevice, s) == hipSuccess;
+    vmd_reduce_stats_t st;
+    memset(&st, 0, sizeof(st));
+    const bool grouped = coll->group_begin && coll->group_end;
+    bool ok = true;
+    bool packed_done = false;                    // the packed fp64 part has already travelled (measured bounds)
+    if (n_measured) {
+        // ---- first launch: this rank's largest count per undecided volume (block maxima, one u64 per volume, behind the u32 scratch is
+        // not needed: they go through 8 bytes each at the end of the packed buffer), then the packed all-reduce, then the decision
+        unsigned long long* d_max = (unsigned long long*)(d_packed + off_measured);         // the slots are overwritten with doubles below
+        ok = hipMemsetAsync(d_max, 0, n_measured * sizeof(unsigned long long), s) == hipSuccess;
+        size_t k = 0;
+        for (size_t i = 0; i < nviews && ok; ++i) {
+            if (narrow[i] != 2) continue;
+            const size_t n = views[i].num_counts;
+            hipLaunchKernelGGL(k_max_u64, dim3((unsigned)std::min<size_t>((n + 255) / 256, 2048)), dim3(256), 0, s, (const uint64_t*)views[i].counts_dev, n, d_max + k);
+            ok = hipGetLastError() == hipSuccess;
+            ++k;
+        }
+        std::vector<unsigned long long> h_max(n_measured, 0);
+        ok = ok && hipMemcpyAsync(h_max.data(), d_max, n_measured * sizeof(unsigned long long), hipMemcpyDeviceToHost, s) == hipSuccess;
+        ok = ok && hipStreamSynchronize(s) == hipSuccess;
+        if (!ok) return red_fail("vmd_eval_reduce: measuring the volumes failed");
+        for (size_t j = 0; j < n_measured; ++j) packed[off_measured + j] = h_max[j] < (1ull << 53) ? (double)h_max[j] : 1.0e19;      // beyond 2^53: never narrow
+        ok = hipMemcpyAsync(d_packed, packed.data(), n_f64 * sizeof(double), hipMemcpyHostToDevice, s) == hipSuccess;
+        ok = ok && coll->allreduce_sum_f64(coll->inst, d_packed, n_f64, s);
+        st.bytes += n_f64 * sizeof(double); st.calls += 1;
+        ok = ok && hipMemcpyAsync(packed.data(), d_packed, n_f64 * sizeof(double), hipMemcpyDeviceToHost, s) == hipSuccess;
+        ok = ok && hipStreamSynchronize(s) == hipSuccess;
+        if (!ok) return red_fail("vmd_eval_reduce: the first all-reduce failed");
+        packed_done = true;
+        k = 0;
+        for (size_t i = 0; i < nviews; ++i) {
+            if (narrow[i] != 2) continue;
+            narrow[i] = packed[off_measured + k] <= 4294967295.0 ? 1 : 0;       // the same sum on every rank: the same decision on every rank
+            ++k;
+        }
+    } else {
+        ok = hipMemcpyAsync(d_packed, packed.data(), n_f64 * sizeof(double), hipMemcpyHostToDevice, s) == hipSuccess;
+    }
     {
         size_t o = 0;
         for (size_t i = 0; i < nviews && ok; ++i) {
-            if (!narrow[i]) continue;
+            if (!narrow[i]) { if (coll->allreduce_sum_u32 && views[i].counts_dev && views[i].num_counts >= 65536 && world > 0) o += (views[i].num_counts + 1) & ~(size_t)1; continue; }
             const size_t n = views[i].num_counts;
             hipLaunchKernelGGL(k_narrow_u64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const uint64_t*)views[i].counts_dev, d_u32 + o, n);
             ok = hipGetLastError() == hipSuccess;
@@ -275,28 +337,29 @@ extern "C" bool vmd_eval_reduce(vmd_script_eval_t* eval, const vmd_collective_i*
         }
     }
     if (!ok) return red_fail("vmd_eval_reduce: staging the merge failed");
-    // ---- ONE collective launch: every all-reduce of this merge inside one group (north_star: "a single RCCL reduce")
-    vmd_reduce_stats_t st;
-    memset(&st, 0, sizeof(st));
-    const bool grouped = coll->group_begin && coll->group_end;
+    // ---- ONE collective launch for the accumulators: every all-reduce inside one group (north_star: "a single RCCL reduce"; the packed
+    // fp64 part rides in it unless it had to go first with the measured bounds)
     if (grouped && !coll->group_begin(coll->inst)) return false;
     {
         size_t o = 0;
         for (size_t i = 0; i < nviews && ok; ++i) {
             const vmd_accum_view_t& v = views[i];
             if (!v.counts_dev || !v.num_counts) continue;
+            const bool slot = coll->allreduce_sum_u32 && v.num_counts >= 65536 && world > 0;       // a stretch of the u32 scratch is reserved for it
             if (narrow[i]) {
                 ok = coll->allreduce_sum_u32(coll->inst, d_u32 + o, v.num_counts, s);
-                o += (v.num_counts + 1) & ~(size_t)1;
                 st.bytes += v.num_counts * sizeof(uint32_t); st.volumes_as_u32 += 1;
             } else {
                 ok = coll->allreduce_sum_u64(coll->inst, v.counts_dev, v.num_counts, s);      // in place on the evaluator's accumulators
                 st.bytes += v.num_counts * sizeof(uint64_t);
             }
+            if (slot) o += (v.num_counts + 1) & ~(size_t)1;
             st.calls += 1;
         }
-        ok = ok && coll->allreduce_sum_f64(coll->inst, d_packed, n_f64, s);
-        st.bytes += n_f64 * sizeof(double); st.calls += 1;
+        if (!packed_done) {
+            ok = ok && coll->allreduce_sum_f64(coll->inst, d_packed, n_f64, s);
+            st.bytes += n_f64 * sizeof(double); st.calls += 1;
+        }
     }
     if (grouped && !coll->group_end(coll->inst)) return false;
     st.grouped = grouped ? 1 : 0;
@@ -304,14 +367,14 @@ extern "C" bool vmd_eval_reduce(vmd_script_eval_t* eval, const vmd_collective_i*
     {
         size_t o = 0;
         for (size_t i = 0; i < nviews && ok; ++i) {
-            if (!narrow[i]) continue;
+            if (!narrow[i]) { if (coll->allreduce_sum_u32 && views[i].counts_dev && views[i].num_counts >= 65536 && world > 0) o += (views[i].num_counts + 1) & ~(size_t)1; continue; }
             const size_t n = views[i].num_counts;
             hipLaunchKernelGGL(k_widen_u32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const uint32_t*)(d_u32 + o), views[i].counts_dev, n);
             ok = hipGetLastError() == hipSuccess;
             o += (n + 1) & ~(size_t)1;
         }
     }
-    ok = ok && hipMemcpyAsync(packed.data(), d_packed, n_f64 * sizeof(double), hipMemcpyDeviceToHost, s) == hipSuccess;
+    if (!packed_done) ok = ok && hipMemcpyAsync(packed.data(), d_packed, n_f64 * sizeof(double), hipMemcpyDeviceToHost, s) == hipSuccess;
     if (t1) (void)hipEventRecord(t1, s);
     ok = ok && hipStreamSynchronize(s) == hipSuccess;       // also: the in-place counts are final before finalize reads them
     if (!ok) return red_fail("vmd_eval_reduce: the merge failed on the device");
