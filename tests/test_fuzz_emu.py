@@ -192,3 +192,17 @@ def test_random_sdf_and_distance_scenarios(emu_lib, oracle, chunk):
         finally:
             for k, v in old.items():
                 emu_lib.vmd_set_option(k.encode(), v)
+
+
+def test_seed_8941_of_the_round_4_gpu_campaign(emu_lib, oracle):
+    """Found by scripts/fuzz_gpu.py on the MI355X (profiles/r04n): three co-evaluated RDFs with different cutoffs on selections of ~1 000 atoms, a
+    cell that changes from frame to frame, one frame per batch.  On one group's grid the selection is sorted by the single-block build, on
+    another's (too many fine cells for LDS) through pencil buckets - which overflowed in the second frame; the evaluator widened the buckets of
+    selections by `used_pencil`, which only remembers the LAST build of a batch, found nobody to widen and gave up after four attempts."""
+    coords, box, flags, props, opts, kind = scenario(8941, scale=20)
+    old = {k: emu_lib.vmd_set_option(k.encode(), v) for k, v in opts.items()}
+    try:
+        cases.check_rdf(emu_lib, oracle, coords, box, props, flags=flags, oracle_method="brute")
+    finally:
+        for k, v in old.items():
+            emu_lib.vmd_set_option(k.encode(), v)

@@ -2738,7 +2738,10 @@ static bool process_range_locked(vmd_script_eval_t* eval, const vmd_system_t* sy
             const uint32_t who = e->h_overflow[c.slot];           // one bit per selection (Selection::overflow_bit; selections beyond 32 share)
             for (auto& sl : e->sels) {
                 sl->built = false;
-                if (!own || !sl->used_pencil || !(who & sl->overflow_bit)) continue;       // only the selection whose buckets were too small gets wider ones
+                // only the selection whose buckets were too small gets wider ones.  (Its bit, not used_pencil, says so: a selection can be
+                // sorted through buckets on one group's grid and by the single-block build on another's within ONE batch - co-evaluated RDFs
+                // with different cutoffs - and used_pencil only remembers the last of them; fuzz seed 8941, round 4.)
+                if (!own || !(who & sl->overflow_bit)) continue;
                 sl->pen_off.clear();
                 sl->caps_cache.clear();
                 sl->cap_margin *= 1.6f;
