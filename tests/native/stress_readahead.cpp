@@ -3,7 +3,9 @@
 // occasional interrupt + restart.  After every evaluation the eval must hold - bit for bit - what ONE call over the same frames leaves on a
 // fresh eval with read-ahead switched off: the RDF bins (u64), the normalisation weights, the temporal rows of the evaluated frames, the
 // frame mask and frames_done.  Python threads (tests/cases.py: readahead_case) take turns on the GIL; these do not.
-// usage: stress_readahead [iterations = 60] [frames = 96] [atoms = 1500] [seed = 1];  prints "OK iterations=<n> ..." and exits 0.
+// With "sdf" as fifth argument the script also holds an sdf() volume (block partials of 16.8 MB each); every third iteration a second eval with
+// the first as its SOURCE walks a sub-range from the pool (VIAMD's filtered evaluation): its regions adopt the source's finished blocks.
+// usage: stress_readahead [iterations = 60] [frames = 96] [atoms = 1500] [seed = 1] [sdf];  prints "OK iterations=<n> ..." and exits 0.
 #include <algorithm>
 #include <atomic>
 #include <cstdio>
@@ -21,7 +23,10 @@ static void fail(const char* what) {
     std::exit(1);
 }
 
+static bool g_sdf = false;
 struct Snapshot {
+    std::vector<float> volume;
+    float volume_max = 0.0f;
     std::vector<uint64_t> counts;
     std::vector<double> weights;
     std::vector<float> temporal;
@@ -39,6 +44,11 @@ static Snapshot snapshot(vmd_script_eval_t* e, size_t F) {
     s.temporal.assign(d->values, d->values + (size_t)d->dim[0] * (size_t)d->dim[1]);
     for (size_t f = 0; f < F; ++f) if (!s.mask[f]) for (int i = 0; i < d->dim[1]; ++i) s.temporal[f * (size_t)d->dim[1] + (size_t)i] = 0.0f;   // rows nobody asked for: whatever
     s.done = vmd_eval_frames_done(e);
+    if (g_sdf) {
+        const vmd_script_property_data_t* v = vmd_eval_property_data(e, "v");
+        s.volume.assign(v->values, v->values + v->num_values);
+        s.volume_max = v->max_value;
+    }
     // the float views follow from the integers: check them where they are cheap to predict
     for (int b = 0; b < g->dim[2]; ++b) if (g->values[b] != (float)g->counts[b]) fail("values[] is not (float)counts[]");
     return s;
@@ -49,6 +59,7 @@ int main(int argc, char** argv) {
     const size_t F = argc > 2 ? (size_t)std::atoi(argv[2]) : 96;
     const size_t N = argc > 3 ? (size_t)std::atoi(argv[3]) : 1500;
     std::mt19937 rng(argc > 4 ? (unsigned)std::atoi(argv[4]) : 1u);
+    g_sdf = argc > 5 && !strcmp(argv[5], "sdf");
     const float L = 30.0f * std::cbrt((float)N / 1500.0f);
     if (vmd_device_count() <= 0) fail("no HIP device");
     vmd_devtraj_t* dt = vmd_devtraj_create(F, N);
@@ -60,6 +71,12 @@ int main(int argc, char** argv) {
     const int32_t a[3] = {0, 1, 2}, b[3] = {30, 31, 32};
     if (!vmd_ir_add_rdf(ir, "g", oxy.data(), oxy.size(), oxy.data(), oxy.size(), 0.0f, 9.0f)) fail("add_rdf");
     if (!vmd_ir_add_distance(ir, "d", VMD_DISTANCE_MIN, a, 3, b, 3)) fail("add_distance");
+    if (g_sdf) {
+        std::vector<int32_t> st;                                  // 3 reference structures of 3 atoms: the first three waters
+        for (int32_t i = 0; i < 9; ++i) st.push_back(i);
+        std::vector<int32_t> tgt(oxy.begin() + 3, oxy.end());
+        if (!vmd_ir_add_sdf(ir, "v", st.data(), 3, 3, tgt.data(), tgt.size(), 7.0f)) fail("add_sdf");
+    }
     vmd_system_t sys = {};
     sys.atom_count = N;
     vmd_set_option("readahead_company_us", 20000);
@@ -76,6 +93,7 @@ int main(int argc, char** argv) {
     auto same = [&](const Snapshot& got, const Snapshot& want, const char* what) {
         if (got.done != want.done || got.mask != want.mask) { std::fprintf(stderr, "frames_done %zu, wanted %zu\n", got.done, want.done); fail(what); }
         if (got.counts != want.counts) fail(what);
+        if (got.volume != want.volume || got.volume_max != want.volume_max) fail(what);
         if (got.temporal != want.temporal) fail(what);
         for (size_t k = 0; k < got.weights.size(); ++k) {
             const double d = got.weights[k] - want.weights[k];
@@ -101,7 +119,7 @@ int main(int argc, char** argv) {
         return failures.load();
     };
 
-    uint64_t regions = 0, direct = 0, blocks = 0, settles = 0;
+    uint64_t regions = 0, direct = 0, blocks = 0, settles = 0, adopted = 0;
     vmd_script_eval_t* eval = vmd_eval_create(F, ir);       // reused across iterations like VIAMD reuses an eval across re-evaluations
     for (g_iter = 0; g_iter < iterations; ++g_iter) {
         const int nthreads = 2 + (int)(rng() % 15);
@@ -137,12 +155,27 @@ int main(int argc, char** argv) {
         if (pooled(eval, starts, grain, mid, nthreads, -1) != 0) fail("a call failed");
         if (split) { big.join(); if (!big_ok) fail("the large call failed"); }
         same(snapshot(eval, F), reference(lo, hi), "pooled evaluation differs from one call over the same range");
+        if (g_iter % 3 == 2 && hi - lo > 6) {
+            // the timeline slider: a second eval over a sub-range, the full one (just evaluated over [lo, hi)) as its source
+            const uint32_t flo = lo + (uint32_t)(rng() % ((hi - lo) / 2)), fhi = flo + 1 + (uint32_t)(rng() % (hi - flo));
+            vmd_script_eval_t* filt = vmd_eval_create(F, ir);
+            if (!filt || !vmd_eval_set_source(filt, eval)) fail("filtered eval");
+            std::vector<uint32_t> fstarts;
+            for (uint32_t f = flo; f < fhi; f += grain) fstarts.push_back(f);
+            if (rng() % 2) std::reverse(fstarts.begin(), fstarts.end());
+            if (pooled(filt, fstarts, grain, fhi, nthreads, -1) != 0) fail("a call of the filtered evaluation failed");
+            same(snapshot(filt, F), reference(flo, fhi), "filtered evaluation (source = the full eval) differs from one call over its range");
+            size_t computed = 0, reused = 0;
+            vmd_eval_frame_stats(filt, &computed, &reused);
+            adopted += reused;
+            vmd_eval_free(filt);
+        }
         vmd_readahead_stats_t st;
         vmd_eval_readahead_stats(eval, &st);
         regions = st.regions; direct = st.direct_frames; blocks = st.committed_blocks; settles = st.settles;
     }
     vmd_eval_free(eval); vmd_ir_free(ir); vmd_devtraj_free(dt);
-    std::printf("OK iterations=%d frames=%zu (last eval: %llu regions, %llu blocks committed, %llu frames evaluated directly, %llu settles)\n", iterations, F,
-                (unsigned long long)regions, (unsigned long long)blocks, (unsigned long long)direct, (unsigned long long)settles);
+    std::printf("OK iterations=%d frames=%zu%s (last eval: %llu regions, %llu blocks committed, %llu frames evaluated directly, %llu settles; filtered evals adopted %llu frames from their source)\n",
+                iterations, F, g_sdf ? " +sdf" : "", (unsigned long long)regions, (unsigned long long)blocks, (unsigned long long)direct, (unsigned long long)settles, (unsigned long long)adopted);
     return 0;
 }
