@@ -243,7 +243,11 @@ typedef struct vmd_script_aggregate_t {
 } vmd_script_aggregate_t;
 
 /* md_script_property_data_t — the fields VIAMD reads.  The struct address and the arrays
- * stay valid and fixed for the lifetime of the eval, across vmd_eval_clear_data (src/main.cpp:1286,1303). */
+ * stay valid and fixed for the lifetime of the eval, across vmd_eval_clear_data (src/main.cpp:1286,1303).
+ * Concurrent readers (VIAMD's GUI thread reads while pool threads are inside frame_range, src/main.cpp:1508-1524): the scalar
+ * fields below change through relaxed atomic stores - a reader sees each of them whole, possibly old next to new; fingerprint
+ * moves after the others.  The arrays are written by DMA and plain copies while a call runs: a reader may see a mix of old and
+ * new elements (the reference's own contract), never a dangling pointer. */
 typedef struct vmd_script_property_data_t {
     int32_t dim[4];                 /* [0] frames (temporal) | [2] bins (distribution) | [1..3] volume dims */
     float*  values;                 /* temporal: values[frame*dim[1]+i]; distribution: values[bin]; volume: x fastest */

@@ -171,24 +171,29 @@ struct md_script_eval_t {
     md_bitfield_t mask;
     std::mutex mtx;
 
+    /* The backend changes the scalar fields while other pool threads are inside frame_range, and VIAMD's GUI thread reads the records
+     * below at any time (src/main.cpp:1508-1524: old and new fields side by side are tolerated).  Both directions go through relaxed
+     * atomic loads / stores - plain moves on x86-64 - so the hand-over is defined behaviour, and ThreadSanitizer-clean. */
+    template <class T> static T peek(const T& v) { T r; __atomic_load(const_cast<T*>(&v), &r, __ATOMIC_RELAXED); return r; }
+    template <class T, class U> static void pub(T& d, U v) { T t = (T)v; __atomic_store(&d, &t, __ATOMIC_RELAXED); }
     void refresh() {
         for (auto& p : props) {
             const vmd_script_property_data_t* s = p->src;
             md_script_property_data_t& d = p->dst;
-            for (int k = 0; k < 4; ++k) d.dim[k] = s->dim[k];
-            d.values = s->values; d.weights = s->weights; d.num_values = s->num_values;
-            d.min_value = s->min_value; d.max_value = s->max_value;
-            for (int k = 0; k < 2; ++k) { d.min_range[k] = s->min_range[k]; d.max_range[k] = s->max_range[k]; }
+            for (int k = 0; k < 4; ++k) pub(d.dim[k], s->dim[k]);
+            pub(d.values, s->values); pub(d.weights, s->weights); pub(d.num_values, s->num_values);
+            pub(d.min_value, peek(s->min_value)); pub(d.max_value, peek(s->max_value));
+            for (int k = 0; k < 2; ++k) { pub(d.min_range[k], peek(s->min_range[k])); pub(d.max_range[k], peek(s->max_range[k])); }
             if (s->aggregate) {
-                p->agg.num_values = s->aggregate->num_values;
-                p->agg.population_mean = s->aggregate->population_mean;
-                p->agg.population_var = s->aggregate->population_var;
-                p->agg.population_ext = (decltype(p->agg.population_ext))s->aggregate->population_ext;
-                d.aggregate = &p->agg;
+                pub(p->agg.num_values, s->aggregate->num_values);
+                pub(p->agg.population_mean, s->aggregate->population_mean);
+                pub(p->agg.population_var, s->aggregate->population_var);
+                pub(p->agg.population_ext, (decltype(p->agg.population_ext))s->aggregate->population_ext);
+                pub(d.aggregate, &p->agg);
             } else {
-                d.aggregate = nullptr;
+                pub(d.aggregate, (decltype(d.aggregate))nullptr);
             }
-            d.fingerprint = s->fingerprint;      /* last: the GUI compares it to decide whether to re-read (src/main.cpp:1508-1509) */
+            pub(d.fingerprint, peek(s->fingerprint));      /* last: the GUI compares it to decide whether to re-read (src/main.cpp:1508-1509) */
         }
     }
 };

@@ -1,0 +1,35 @@
+#!/bin/bash
+# Host-side data-race check: the emulator build (same .hip/.cpp sources, g++) and the C++ pool-thread programs of tests/native
+# under ThreadSanitizer.  The emulator's fibers are announced to TSan (tests/emu/emu.cpp: __tsan_create_fiber /
+# __tsan_switch_to_fiber), so what is checked is the host code around the launches: the read-ahead's lock-free request marks and
+# flight word, the combining queue, the block commits, interrupt / clear / free against running calls, the shim's registry.
+# usage: bash scripts/tsan_emu.sh [out_dir]      (about 35 minutes of CPU: TSan costs 10 - 20 x)
+set -e
+cd "$(dirname "$0")/.."
+R=$(pwd)
+OUT=${1:-/tmp/viamd_tsan}; mkdir -p $OUT
+LIB=$(VIAMD_EMU_SANITIZE=thread python -c "import sys; sys.path.insert(0, 'tests'); import conftest; print(conftest.build_emu())" 2>/dev/null | tail -1)
+export TSAN_OPTIONS="halt_on_error=0:report_signal_unsafe=0:history_size=4"
+build() {   # src exe [extra include]
+  g++ -std=c++17 -O1 -g -fsanitize=thread "$1" -I$R/include ${3:+-I$3} $LIB -Wl,-rpath,$(dirname $LIB) -lpthread -o "$2"
+}
+build tests/native/stress_readahead.cpp $OUT/stress_ra
+build tests/native/stress_eval.cpp $OUT/stress_eval
+build tests/native/shim_callsites.cpp $OUT/shim_callsites $R/tests/native
+build tests/native/exp_threads.cpp $OUT/exp_threads
+cd $OUT
+rc=0
+run() {   # name args...
+  local name=$1; shift
+  local t0=$(date +%s)
+  timeout 3600 "$@" > $OUT/$name.log 2>&1 || rc=1
+  local n=$(grep -c "WARNING: ThreadSanitizer" $OUT/$name.log || true)
+  echo "$name: $(($(date +%s) - t0)) s, ThreadSanitizer warnings: $n, last line: $(grep -v '^$' $OUT/$name.log | tail -1 | cut -c1-200)"
+  [ "$n" = "0" ] || { rc=1; grep "SUMMARY" $OUT/$name.log | sort | uniq -c; }
+}
+run shim_callsites $OUT/shim_callsites 12
+run stress_eval $OUT/stress_eval 2 6
+run exp_threads_rdf $OUT/exp_threads ${TSAN_EXP_ARGS:-900 64}
+run stress_ra_sdf $OUT/stress_ra 3 16 600 9 sdf
+run stress_ra $OUT/stress_ra ${TSAN_RA_ARGS:-8 40 900 7}
+exit $rc

@@ -17,6 +17,10 @@ enum State { RUNNABLE = 0, WAIT_BLOCK = 1, WAIT_WAVE = 2, DONE = 3 };
 // one collective per few instructions switches millions of times (the serial CPU suite spent 6 of its 16 minutes in the kernel).
 // On x86-64 without a sanitizer the fibers therefore switch with twenty lines of assembly (callee-saved registers + stack pointer;
 // nothing here touches the signal mask, MXCSR or the x87 control word); sanitizer builds keep ucontext, which ASan knows about.
+// ThreadSanitizer has to be told: every emulator fiber is a TSan fiber (__tsan_create_fiber), announced before each swapcontext,
+// with flags 0 = "the switch synchronises" - the fibers of a launch are one logical thread of the host thread that holds
+// g_launch_mtx.  In the ucontext build a fiber lives for the whole process and loops over the kernels it is given, so that the
+// call stack TSan shadows stays balanced (a fiber re-made per block would leak a few shadow frames per block and overflow).
 #if defined(__x86_64__) && !defined(__SANITIZE_ADDRESS__) && !defined(__SANITIZE_THREAD__)
 #define EMU_ASM_SWITCH 1
 struct EmuCtx { void* rsp = nullptr; };
@@ -46,12 +50,24 @@ emu_switch:
 #else
 #define EMU_ASM_SWITCH 0
 #endif
+#if defined(__SANITIZE_THREAD__)
+#define EMU_TSAN 1
+extern "C" void* __tsan_get_current_fiber(void);
+extern "C" void* __tsan_create_fiber(unsigned flags);
+extern "C" void __tsan_switch_to_fiber(void* fiber, unsigned flags);
+#else
+#define EMU_TSAN 0
+#endif
 
 struct Fiber {
 #if EMU_ASM_SWITCH
     EmuCtx ctx;
 #else
     ucontext_t ctx;
+    bool made = false;          // the context exists and is parked at the end of fiber_entry's loop
+#endif
+#if EMU_TSAN
+    void* tsan = nullptr;
 #endif
     char* stack = nullptr;
     int state = DONE;
@@ -71,11 +87,17 @@ static EmuCtx g_sched;
 #else
 static ucontext_t g_sched;
 #endif
+#if EMU_TSAN
+static void* g_sched_tsan = nullptr;        // the launching host thread, as TSan sees it
+#endif
 // fiber -> scheduler and scheduler -> fiber
 static inline void to_sched(Fiber* f) {
 #if EMU_ASM_SWITCH
     emu_switch(&f->ctx, &g_sched);
 #else
+#if EMU_TSAN
+    __tsan_switch_to_fiber(g_sched_tsan, 0);
+#endif
     swapcontext(&f->ctx, &g_sched);
 #endif
 }
@@ -83,6 +105,9 @@ static inline void to_fiber(Fiber& f) {
 #if EMU_ASM_SWITCH
     emu_switch(&g_sched, &f.ctx);
 #else
+#if EMU_TSAN
+    __tsan_switch_to_fiber(f.tsan, 0);
+#endif
     swapcontext(&g_sched, &f.ctx);
 #endif
 }
@@ -94,6 +119,14 @@ emu_uint3 cur_tid() { return g_cur->tid; }
 int cur_lane() { return g_cur->linear & 63; }
 
 static void fiber_entry() {
+#if !EMU_ASM_SWITCH
+    for (;;) {              // ucontext build: the fiber is parked in to_sched() below and resumed with the next block's body
+        (*g_body)();
+        Fiber* f = g_cur;
+        f->state = DONE;    // (see the note on finished lanes below)
+        to_sched(f);
+    }
+#endif
     (*g_body)();
     Fiber* f = g_cur;
     // A lane that leaves the kernel must read as "not there" in every later collective of its wave - but NOT yet in the one its
@@ -161,6 +194,7 @@ static void run_block(int nthreads) {
     const int nwaves = (nthreads + 63) / 64;
     g_xbuf.assign((size_t)nwaves * 2 * 64, 0);
     if ((int)g_fibers.size() < nthreads) {
+        g_fibers.reserve(1024);         // the launch limit: a parked ucontext must never move (it points into itself)
         const size_t old = g_fibers.size();
         g_fibers.resize(nthreads);
         for (size_t i = old; i < g_fibers.size(); ++i) {
@@ -186,11 +220,17 @@ static void run_block(int nthreads) {
         for (int r = 0; r < 6; ++r) *--sp = nullptr;
         f.ctx.rsp = sp;
 #else
-        getcontext(&f.ctx);
-        f.ctx.uc_stack.ss_sp = f.stack;
-        f.ctx.uc_stack.ss_size = kStack;
-        f.ctx.uc_link = &g_sched;
-        makecontext(&f.ctx, fiber_entry, 0);
+        if (!f.made) {
+            getcontext(&f.ctx);
+            f.ctx.uc_stack.ss_sp = f.stack;
+            f.ctx.uc_stack.ss_size = kStack;
+            f.ctx.uc_link = &g_sched;
+            makecontext(&f.ctx, fiber_entry, 0);
+            f.made = true;
+#if EMU_TSAN
+            f.tsan = __tsan_create_fiber(0);
+#endif
+        }
 #endif
     }
     for (;;) {
@@ -252,6 +292,9 @@ void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& bo
         abort();
     }
     g_dynshm.assign(shmem / 8 + 2, 0);
+#if EMU_TSAN
+    g_sched_tsan = __tsan_get_current_fiber();
+#endif
     g_body = &body;
     g_gridDim = grid;
     g_blockDim = block;

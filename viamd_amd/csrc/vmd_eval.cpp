@@ -1331,6 +1331,14 @@ extern "C" void vmd_eval_free(vmd_script_eval_t* eval) {
     (void)hipSetDevice(prev_dev);
 }
 
+// Published scalars.  VIAMD's GUI thread reads a property's record while pool threads are inside frame_range (src/main.cpp:1508-1524):
+// by the reference's contract a reader may see old and new fields side by side, never a crash.  The scalar fields are therefore
+// written with relaxed atomic stores - plain moves on x86-64 - so that the contract is also what the C++ memory model and
+// ThreadSanitizer (scripts/tsan_emu.sh) see; the shim's refresh() loads them the same way.  The arrays behind `values` / `weights`
+// are written by DMA, memcpy and fills: a reader of those runs under the reference's "torn data is tolerated" rule only.
+template <class T> static inline void pub(T& dst, T v) { __atomic_store(&dst, &v, __ATOMIC_RELAXED); }
+static inline void pub_touch(uint64_t& fingerprint) { uint64_t v; __atomic_load(&fingerprint, &v, __ATOMIC_RELAXED); v += 1; __atomic_store(&fingerprint, &v, __ATOMIC_RELAXED); }
+
 static void ra_reset(vmd_script_eval_t* e);
 extern "C" void vmd_eval_clear_data(vmd_script_eval_t* eval) {
     VMD_STAGE("vmd_eval_clear_data");
@@ -1367,11 +1375,11 @@ extern "C" void vmd_eval_clear_data(vmd_script_eval_t* eval) {
         std::fill(p->agg_var.begin(), p->agg_var.end(), 0.0f);
         std::fill(p->agg_ext.begin(), p->agg_ext.end(), 0.0f);
         if (p->ncounts) (void)hipMemsetAsync(p->d_counts.p, 0, p->ncounts * sizeof(uint64_t), eval->stream);
-        p->data.max_value = 0.0f; p->data.min_value = 0.0f;
-        p->data.max_range[1] = 0.0f;
+        pub(p->data.max_value, 0.0f); pub(p->data.min_value, 0.0f);
+        pub(p->data.max_range[1], 0.0f);
         p->dirty = false;
         if (p->prop.kind != PROP_SDF) p->counts_stale = false;
-        p->data.fingerprint += 1;
+        pub_touch(p->data.fingerprint);
     }
     (void)hipStreamSynchronize(eval->stream);
 }
@@ -1399,6 +1407,7 @@ extern "C" size_t vmd_eval_frames_done(const vmd_script_eval_t* eval) { return e
 
 // ---- host views -------------------------------------------------------------------------------------------------
 
+
 // the float views of a distribution from integer counts and fp64 weights (the device accumulators, or a snapshot of them)
 static void refresh_distribution_from(PropState* p, const uint64_t* counts, const double* weights64) {
     float ymax = 0.0f, vmax = 0.0f;
@@ -1410,9 +1419,9 @@ static void refresh_distribution_from(PropState* p, const uint64_t* counts, cons
         vmax = std::max(vmax, v);
         if (w > 0.0f) ymax = std::max(ymax, v / w);
     }
-    p->data.min_value = 0.0f; p->data.max_value = vmax;
-    p->data.min_range[1] = 0.0f; p->data.max_range[1] = ymax;
-    p->data.fingerprint += 1;
+    pub(p->data.min_value, 0.0f); pub(p->data.max_value, vmax);
+    pub(p->data.min_range[1], 0.0f); pub(p->data.max_range[1], ymax);
+    pub_touch(p->data.fingerprint);
 }
 
 static bool refresh_distribution(vmd_script_eval_t* e, PropState* p) {
@@ -1426,9 +1435,9 @@ static bool refresh_distribution(vmd_script_eval_t* e, PropState* p) {
         vmax = std::max(vmax, v);
         if (w > 0.0f) ymax = std::max(ymax, v / w);
     }
-    p->data.min_value = 0.0f; p->data.max_value = vmax;
-    p->data.min_range[1] = 0.0f; p->data.max_range[1] = ymax;
-    p->data.fingerprint += 1;
+    pub(p->data.min_value, 0.0f); pub(p->data.max_value, vmax);
+    pub(p->data.min_range[1], 0.0f); pub(p->data.max_range[1], ymax);
+    pub_touch(p->data.fingerprint);
     p->dirty = false;
     return true;
 }
@@ -1464,8 +1473,8 @@ static bool refresh_volume(vmd_script_eval_t* e, PropState* p) {
     p->counts_stale = true;
     HIP_OK(hipMemcpyAsync(&vmax, p->d_max.p, sizeof(float), hipMemcpyDeviceToHost, e->stream));
     HIP_OK(hipStreamSynchronize(e->stream));
-    p->data.min_value = 0.0f; p->data.max_value = vmax;
-    p->data.fingerprint += 1;
+    pub(p->data.min_value, 0.0f); pub(p->data.max_value, vmax);
+    pub_touch(p->data.fingerprint);
     p->dirty = false;
     return true;
 }
@@ -1491,9 +1500,9 @@ static void refresh_temporal_stats(vmd_script_eval_t* e, PropState* p) {
         any = true;
     }
     if (!any) { lo = hi = 0.0f; }
-    p->data.min_value = lo; p->data.max_value = hi;
-    p->data.min_range[0] = lo; p->data.max_range[0] = hi;
-    p->data.fingerprint += 1;
+    pub(p->data.min_value, lo); pub(p->data.max_value, hi);
+    pub(p->data.min_range[0], lo); pub(p->data.max_range[0], hi);
+    pub_touch(p->data.fingerprint);
     p->dirty = false;
 }
 
@@ -3296,6 +3305,18 @@ static bool ra_direct_call(vmd_script_eval_t* e, const vmd_system_t* sys, vmd_tr
     return ok;
 }
 
+// A bounded wait on a condition variable.  libstdc++ waits on the steady clock through pthread_cond_clockwait, which the
+// ThreadSanitizer runtime of this toolchain does not intercept (it then believes the waiter kept the mutex): instrumented
+// builds wait on the system clock (pthread_cond_timedwait) so that the TSan runs of scripts/tsan_emu.sh see every hand-over.
+template <class Pred>
+static bool cv_wait_us(std::condition_variable& cv, std::unique_lock<std::mutex>& lk, int us, Pred pred) {
+#if defined(__SANITIZE_THREAD__)
+    return cv.wait_until(lk, std::chrono::system_clock::now() + std::chrono::microseconds(us), pred);
+#else
+    return cv.wait_for(lk, std::chrono::microseconds(us), pred);
+#endif
+}
+
 static bool ra_call(vmd_script_eval_t* e, const vmd_system_t* sys, vmd_trajectory_i* traj, uint32_t beg, uint32_t end) {
     ReadAhead& ra = e->ra;
     const bool small = (int)(end - beg) <= g_opt.readahead_small.load();
@@ -3306,7 +3327,7 @@ static bool ra_call(vmd_script_eval_t* e, const vmd_system_t* sys, vmd_trajector
         // (also on an eval whose blocks exist from an earlier evaluation: whether THIS evaluation is driven by a pool is found out anew)
         if (!ra.concurrent && !ra.lonely) {
             // the first call of an evaluation: is this a pool?  Its other threads are microseconds behind
-            e->queue_cv.wait_for(ql, std::chrono::microseconds(std::max(0, g_opt.readahead_company_us.load())), [&] { return ra.concurrent || e->interrupt.load(); });
+            cv_wait_us(e->queue_cv, ql, std::max(0, g_opt.readahead_company_us.load()), [&] { return ra.concurrent || e->interrupt.load(); });
             if (!ra.concurrent) ra.lonely = true;
         }
         if (ra.concurrent && !ra.on.load()) {
