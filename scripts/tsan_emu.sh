@@ -2,7 +2,7 @@
 # Host-side data-race check: the emulator build (same .hip/.cpp sources, g++) and the C++ pool-thread programs of tests/native
 # under ThreadSanitizer.  The emulator's fibers are announced to TSan (tests/emu/emu.cpp: __tsan_create_fiber /
 # __tsan_switch_to_fiber), so what is checked is the host code around the launches: the read-ahead's lock-free request marks and
-# flight word, the combining queue, the block commits, interrupt / clear / free against running calls, the shim's registry.
+# flight word, the combining queue, the block commits, interrupt / clear / free against running calls, the shim's registry, merges of several ranks driven from threads of one process.
 # usage: bash scripts/tsan_emu.sh [out_dir]      (about 35 minutes of CPU: TSan costs 10 - 20 x)
 set -e
 cd "$(dirname "$0")/.."
@@ -17,6 +17,8 @@ build tests/native/stress_readahead.cpp $OUT/stress_ra
 build tests/native/stress_eval.cpp $OUT/stress_eval
 build tests/native/shim_callsites.cpp $OUT/shim_callsites $R/tests/native
 build tests/native/exp_threads.cpp $OUT/exp_threads
+build tests/native/reduce_threads.cpp $OUT/reduce_threads
+build tests/native/concurrent_evals.cpp $OUT/concurrent_evals
 cd $OUT
 rc=0
 run() {   # name args...
@@ -27,6 +29,8 @@ run() {   # name args...
   echo "$name: $(($(date +%s) - t0)) s, ThreadSanitizer warnings: $n, last line: $(grep -v '^$' $OUT/$name.log | tail -1 | cut -c1-200)"
   [ "$n" = "0" ] || { rc=1; grep "SUMMARY" $OUT/$name.log | sort | uniq -c; }
 }
+run reduce_threads $OUT/reduce_threads 3 12 600
+run concurrent_evals $OUT/concurrent_evals 2 10 600 $OUT
 run shim_callsites $OUT/shim_callsites 12
 run stress_eval $OUT/stress_eval 2 6
 run exp_threads_rdf $OUT/exp_threads ${TSAN_EXP_ARGS:-900 64}

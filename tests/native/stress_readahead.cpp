@@ -92,9 +92,9 @@ int main(int argc, char** argv) {
     };
     auto same = [&](const Snapshot& got, const Snapshot& want, const char* what) {
         if (got.done != want.done || got.mask != want.mask) { std::fprintf(stderr, "frames_done %zu, wanted %zu\n", got.done, want.done); fail(what); }
-        if (got.counts != want.counts) fail(what);
-        if (got.volume != want.volume || got.volume_max != want.volume_max) fail(what);
-        if (got.temporal != want.temporal) fail(what);
+        if (got.counts != want.counts) { std::fprintf(stderr, "RDF bins differ\n"); fail(what); }
+        if (got.volume != want.volume || got.volume_max != want.volume_max) { std::fprintf(stderr, "voxels differ\n"); fail(what); }
+        if (got.temporal != want.temporal) { std::fprintf(stderr, "temporal rows differ\n"); fail(what); }
         for (size_t k = 0; k < got.weights.size(); ++k) {
             const double d = got.weights[k] - want.weights[k];
             if (std::abs(d) > 1e-12 * std::abs(want.weights[k])) fail(what);
@@ -152,8 +152,34 @@ int main(int argc, char** argv) {
         std::thread big;
         std::atomic<int> big_ok{1};
         if (split) big = std::thread([&] { if (!vmd_eval_frame_range(eval, ir, &sys, traj, mid, hi)) big_ok = 0; });
+        // "Eval Full" and "Eval Filt" side by side (src/main.cpp:982-1039 enqueues them as two pool tasks): a second eval with the full one as
+        // its source walks a sub-range WHILE the full one is being evaluated - it may adopt whatever blocks the source has finished by then
+        // and evaluates the rest itself
+        const bool beside = g_iter % 3 == 1 && hi - lo > 6;
+        vmd_script_eval_t* side = nullptr;
+        std::thread side_pool;
+        std::atomic<int> side_failures{0};
+        uint32_t slo = 0, shi = 0;
+        std::vector<uint32_t> sstarts;
+        if (beside) {
+            slo = lo + (uint32_t)(rng() % ((hi - lo) / 2)); shi = slo + 1 + (uint32_t)(rng() % (hi - slo));
+            side = vmd_eval_create(F, ir);
+            if (!side || !vmd_eval_set_source(side, eval)) fail("side-by-side filtered eval");
+            for (uint32_t f = slo; f < shi; f += grain) sstarts.push_back(f);
+            const int sthreads = 1 + (int)(rng() % 4);
+            side_pool = std::thread([&, sthreads] { side_failures = pooled(side, sstarts, grain, shi, sthreads, -1); });
+        }
         if (pooled(eval, starts, grain, mid, nthreads, -1) != 0) fail("a call failed");
         if (split) { big.join(); if (!big_ok) fail("the large call failed"); }
+        if (beside) {
+            side_pool.join();
+            if (side_failures.load()) fail("a call of the side-by-side filtered evaluation failed");
+            same(snapshot(side, F), reference(slo, shi), "filtered evaluation running beside its source differs from one call over its range");
+            size_t computed = 0, reused = 0;
+            vmd_eval_frame_stats(side, &computed, &reused);
+            adopted += reused;
+            vmd_eval_free(side);
+        }
         same(snapshot(eval, F), reference(lo, hi), "pooled evaluation differs from one call over the same range");
         if (g_iter % 3 == 2 && hi - lo > 6) {
             // the timeline slider: a second eval over a sub-range, the full one (just evaluated over [lo, hi)) as its source

@@ -213,3 +213,43 @@ def test_read_ahead_stress(gpu_lib, tmp_path):
     out = subprocess.run([exe, "150", "240", "30000", "4", "sdf"], capture_output=True, text=True, timeout=900)     # volumes: 16.8 MB block partials, adopted by filtered evals
     assert out.returncode == 0, (out.stdout[-500:], out.stderr[-3000:])
     assert out.stdout.strip().split("\n")[-1].startswith("OK iterations=150 frames=240 +sdf"), out.stdout[-500:]
+
+REDUCE_THREADS_SRC = os.path.join(ROOT, "tests", "native", "reduce_threads.cpp")
+
+
+def test_ranks_as_threads_of_one_process_merge_on_the_emulator(tmp_path, emu_lib):
+    """tests/native/reduce_threads.cpp: three ranks as THREADS of one process, all on one device, merged with vmd_eval_reduce through a
+    host-supplied vmd_collective_i (an in-process rendezvous) - both u32 narrowing paths.  With one staging buffer per device behind a
+    mutex this dead-locked (rank A in the collective, rank B waiting for A's buffer: ADVICE r03); the merge now leases its buffer from a
+    pool.  Every rank must end with the integers of one eval over all frames."""
+    import conftest
+    exe = _build_against(conftest.build_emu(), REDUCE_THREADS_SRC, str(tmp_path / "reduce_threads"), "-O1")
+    out = subprocess.run([exe, "3", "12", "600"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.startswith("OK ranks=3"), out.stdout
+    out = subprocess.run([exe, "5", "7", "450"], capture_output=True, text=True, timeout=300)        # more ranks than some have frames for
+    assert out.returncode == 0, out.stderr[-2000:]
+
+CONCURRENT_SRC = os.path.join(ROOT, "tests", "native", "concurrent_evals.cpp")
+
+
+def test_independent_evaluations_side_by_side_on_the_emulator(tmp_path, emu_lib):
+    """tests/native/concurrent_evals.cpp: four threads, each with its own eval, script (pencil walk / two-set RDF / all-pairs kernel + SDF /
+    distances + SDF) and kind of trajectory (HBM, pinned host, XTC file, XTC compressed in HBM), all at once - the process-wide state behind
+    the evals (per-launch parameters, resource cache, checkpoint cache, staging pools) must not leak from one into another: every result
+    equals the lone evaluation's integers.  The same program runs under ThreadSanitizer in scripts/tsan_emu.sh."""
+    import conftest
+    exe = _build_against(conftest.build_emu(), CONCURRENT_SRC, str(tmp_path / "concurrent_emu"), "-O1")
+    out = subprocess.run([exe, "2", "10", "600", str(tmp_path)], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.startswith("OK iterations=2"), out.stdout
+
+
+@pytest.mark.gpu
+def test_independent_evaluations_side_by_side(gpu_lib, tmp_path):
+    """the same on the MI355X: 25 rounds of 16 concurrent evaluations over 48 frames of 6 000 atoms"""
+    from viamd_amd import build
+    exe = _build_against(build.build(), CONCURRENT_SRC, str(tmp_path / "concurrent"))
+    out = subprocess.run([exe, "25", "48", "6000", str(tmp_path)], capture_output=True, text=True, timeout=900, env=dict(os.environ, AMD_LOG_LEVEL="1"))
+    assert out.returncode == 0, (out.stdout[-500:], out.stderr[-3000:])
+    assert out.stdout.startswith("OK iterations=25"), out.stdout

@@ -728,6 +728,14 @@ struct PropState {
     bool counts_stale = false;          // volume: host u64 mirror older than the device accumulators
 };
 
+// Flags several evals share (checkpoint tables of one compressed trajectory, evaluated by "Eval Full" and "Eval Filt" side by side,
+// src/main.cpp:982-1039): "this frame's checkpoints are valid", a frame's signature, "the group records lie".  A flag is raised after the
+// stream that wrote the table has been synchronised and is looked at before a launch that reads the table: release / acquire, so that
+// the hand-over is defined (and ThreadSanitizer-clean: tests/native/concurrent_evals.cpp).  Two evals that decode the same frame at the
+// same time write the same bytes into the table.
+template <class T> static inline T flag_get(const T* p) { T v; __atomic_load(const_cast<T*>(p), &v, __ATOMIC_ACQUIRE); return v; }
+template <class T> static inline void flag_set(T* p, T v) { __atomic_store(p, &v, __ATOMIC_RELEASE); }
+
 // Decoder checkpoints of file-backed trajectories (k_xtc_wave), kept per TRAJECTORY for the whole process: VIAMD creates
 // a fresh md_script_eval_t for every script edit (src/main.cpp:966-972), so a cache inside the eval would never be hit by the
 // re-evaluations it exists for.  Keyed by the trajectory's instance pointer; a frame's checkpoints are only used while the frame's
@@ -1789,10 +1797,10 @@ static int launch_raw_decode(vmd_script_eval_t* e, Stage& st, const unsigned cha
         rc = vmd_hip_xtc_decode(stream, d_raw, d_info, (int)nb, (int)num_atoms, st.d.p, 3 * npad, npad, st.d_raw_status.p);
     } else if (ck && nck && ck_have && g_opt.xtc_checkpoints.load()) {
         bool all = true;
-        for (size_t b = 0; b < nb; ++b) all = all && ck_have[b] != 0;
+        for (size_t b = 0; b < nb; ++b) all = all && flag_get(&ck_have[b]) != 0;
         // every frame of the batch has been decoded before: sections from its checkpoints; otherwise decode and leave checkpoints.
         // With group records next to the checkpoints (the first pass writes both) a later pass walks nothing at all.
-        const bool recs = rec && nrec && rec_stride >= num_atoms && rec_failed && !*rec_failed && g_opt.xtc_records.load();
+        const bool recs = rec && nrec && rec_stride >= num_atoms && rec_failed && !flag_get(rec_failed) && g_opt.xtc_records.load();
         if (recs) {
             rc = vmd_hip_xtc_decode_wave_rec(stream, d_raw, d_info, (int)nb, (int)num_atoms, st.d.p, 3 * npad, npad, st.d_raw_status.p, all ? 1 : 0, ck, nck, rec, nrec, rec_stride);
             if (all) st.rec_failed = rec_failed;
@@ -2049,7 +2057,7 @@ static bool fetch_stage(vmd_script_eval_t* e, Stage& st, vmd_trajectory_i* traj,
                     // a frame's checkpoints count only for the very bytes they were written for
                     for (size_t b = 0; b < nb; ++b) {
                         const uint64_t sg = frame_signature(rs->info[b], rs->h_streams + rs->info[b].offset);
-                        if (cc->sig[f0 + b] != sg) { cc->sig[f0 + b] = sg; cc->have[f0 + b] = 0; }
+                        if (flag_get(&cc->sig[f0 + b]) != sg) { flag_set(&cc->sig[f0 + b], sg); flag_set(&cc->have[f0 + b], (uint8_t)0); }
                     }
                     raw = launch_raw_decode(e, st, rs->d_streams(), rs->d_info(), num_atoms, nb, npad, ss, cc->ck.p + f0 * VMD_XTC_CK_MAX, cc->nck.p + f0, cc->have.data() + f0,
                                             cc->rec_stride ? cc->rec.p + f0 * cc->rec_stride : nullptr, cc->rec_stride ? cc->nrec.p + f0 : nullptr, cc->rec_stride, &cc->rec_failed);
@@ -2146,7 +2154,7 @@ static bool settle_stage(vmd_script_eval_t* e, Stage& st, vmd_trajectory_i* traj
     bool good = true;
     for (size_t b = 0; b < st.nb; ++b) if (st.h_raw_status[b] != 0) good = false;
     if (good) {
-        if (st.ck_mark) for (size_t b = 0; b < st.nb; ++b) st.ck_mark[b] = 1;
+        if (st.ck_mark) for (size_t b = 0; b < st.nb; ++b) flag_set(&st.ck_mark[b], (uint8_t)1);
         st.ck_mark = nullptr;
         st.ck_clear = nullptr;
         st.rec_failed = nullptr;
@@ -2157,9 +2165,9 @@ static bool settle_stage(vmd_script_eval_t* e, Stage& st, vmd_trajectory_i* traj
     st.ck_mark = nullptr;
     // checkpoints that did not describe these streams (a sidecar table that passed the signature test and still lies): the frames
     // walk from bit 0 again next time
-    if (st.ck_clear) for (size_t b = 0; b < st.nb; ++b) st.ck_clear[b] = 0;
+    if (st.ck_clear) for (size_t b = 0; b < st.nb; ++b) flag_set(&st.ck_clear[b], (uint8_t)0);
     st.ck_clear = nullptr;
-    if (st.rec_failed) *st.rec_failed = true;          // the records did not describe these streams: never again for this trajectory
+    if (st.rec_failed) flag_set(st.rec_failed, true);          // the records did not describe these streams: never again for this trajectory
     st.rec_failed = nullptr;
     return fetch_stage(e, st, traj, nullptr, num_atoms, st.f0, st.nb, true);
 }
@@ -2406,6 +2414,17 @@ static void plan_batches(const vmd_script_eval_t* e, size_t beg, size_t end, siz
 
 // filtered evaluation: merge every ready block of the source eval that lies inside [beg, end) into this eval's accumulators
 // and return the sub-ranges that still have to be computed
+// block_ready[b] != 0: block b's partial (d_blocks, block_weights64, temporal rows) is complete.  Where its temporal rows are: a block
+// evaluated by a plain call has them in `values`; a block evaluated AHEAD (read-ahead, spec) or adopted from a source has them in the side
+// buffer `ahead_values` until it is committed - `values` only ever shows frames somebody asked for.  An eval that takes blocks from a source
+// (reuse_blocks, ra_adopt_blocks) must read the rows where they are: a filtered evaluation running BESIDE its source (src/main.cpp:982-1039
+// enqueues both) used to copy rows of blocks the source had evaluated ahead but not yet committed out of `values` - zeros
+// (tests/native/stress_readahead.cpp, "beside").
+enum : uint8_t { BLOCK_ROWS_IN_PLACE = 1, BLOCK_ROWS_AHEAD = 2 };
+static const float* block_rows(const vmd_script_eval_t* src, const PropState* q, size_t blk) {
+    return src->block_ready[blk].load() == BLOCK_ROWS_AHEAD && q->ahead_values.size() == q->values.size() ? q->ahead_values.data() : q->values.data();
+}
+
 static bool reuse_blocks(vmd_script_eval_t* e, size_t beg, size_t end, std::vector<std::pair<size_t, size_t>>* todo) {
     vmd_script_eval_t* src = e->source;
     if (!src) { todo->push_back({beg, end}); return true; }
@@ -2426,7 +2445,7 @@ static bool reuse_blocks(vmd_script_eval_t* e, size_t beg, size_t end, std::vect
                     if (p->prop.kind == PROP_RDF)
                         for (size_t k = 0; k < p->ncounts; ++k) p->weights64[k] += q->block_weights64[blk * p->ncounts + k];
                 } else {
-                    memcpy(&p->values[f * p->dim1], &q->values[f * p->dim1], (bend - f) * p->dim1 * sizeof(float));
+                    memcpy(&p->values[f * p->dim1], block_rows(src, q, blk) + f * p->dim1, (bend - f) * p->dim1 * sizeof(float));
                 }
                 p->dirty = true;
             }
@@ -2541,9 +2560,9 @@ static bool process_range_locked(vmd_script_eval_t* eval, const vmd_system_t* sy
                 std::lock_guard<std::mutex> l(g_ck_mtx);
                 auto it = g_ck_store.find(CkKey(traj->inst, e->device));
                 warm = it != g_ck_store.end() && it->second && it->second->frames == traj->num_frames(traj->inst) && it->second->atoms == num_atoms &&
-                       it->second->device == e->device && it->second->have.size() > frame_beg && it->second->have[frame_beg];
+                       it->second->device == e->device && it->second->have.size() > frame_beg && flag_get(&it->second->have[frame_beg]);
             }
-            else warm = rv_probe.ck_have && rv_probe.ck_have[frame_beg];
+            else warm = rv_probe.ck_have && flag_get(&rv_probe.ck_have[frame_beg]);
         }
         // a first pass out of a mapped file keeps four walks in flight (stage_ahead below): half-size batches, twice as many
         cold_walk = raw_ring && !f32_ring && !warm && have_map && g_opt.xtc_device_decode.load() == 3 && g_opt.xtc_cold_streams.load() != 0;
@@ -2777,7 +2796,7 @@ static bool process_range_locked(vmd_script_eval_t* eval, const vmd_system_t* sy
             toff += c.nb * p->dim1;
         }
         e->frames_computed += c.nb;
-        if (c.bt.blk >= 0) for (auto& su : c.subs) e->block_ready[su.blk] = 1;
+        if (c.bt.blk >= 0) for (auto& su : c.subs) e->block_ready[su.blk] = spec ? BLOCK_ROWS_AHEAD : BLOCK_ROWS_IN_PLACE;
         if (spec) return true;
         for (size_t b = 0; b < c.nb; ++b) e->frame_mask[c.f0 + b] = 1;
         e->frames_done += c.nb;
@@ -3170,10 +3189,10 @@ static bool ra_adopt_blocks(vmd_script_eval_t* e, size_t b0, size_t b1, std::vec
                 if (p->prop.kind == PROP_RDF) memcpy(&p->block_weights64[b * p->ncounts], &q->block_weights64[b * p->ncounts], p->ncounts * sizeof(double));
             } else {
                 if (p->ahead_values.size() != p->values.size()) p->ahead_values.assign(p->values.size(), 0.0f);
-                memcpy(&p->ahead_values[f0 * p->dim1], &q->values[f0 * p->dim1], (f1 - f0) * p->dim1 * sizeof(float));
+                memcpy(&p->ahead_values[f0 * p->dim1], block_rows(src, q, b) + f0 * p->dim1, (f1 - f0) * p->dim1 * sizeof(float));
             }
         }
-        e->block_ready[b] = 1;
+        e->block_ready[b] = BLOCK_ROWS_AHEAD;           // (the rows went into the side buffer above)
         (*adopted)[b - b0] = 1;
         taken += f1 - f0;
     }
@@ -3198,6 +3217,7 @@ static bool ra_commit_block(vmd_script_eval_t* e, size_t blk) {
     }
     for (size_t f = f0; f < f1; ++f) e->frame_mask[f] = 1;
     e->frames_done += f1 - f0;
+    if (e->block_ready[blk]) e->block_ready[blk] = BLOCK_ROWS_IN_PLACE;
     e->ra.blk_state[blk].store(vmd_script_eval_t::RA_COMMITTED, std::memory_order_release);
     e->ra.committed_blocks += 1;
     e->ra.views_dirty = true;

@@ -2647,7 +2647,7 @@ static int g_rdf_nsub_pct = 100;   // automatic nsub = mean chunks per pencil x 
 extern "C" int vmd_hip_set_rdf_nsub_pct(int n) { const int old = g_rdf_nsub_pct; if (n >= 25 && n <= 800) g_rdf_nsub_pct = n; return old; }
 static int g_rdf_shist = 0;       // one LDS histogram per block instead of one per wave (8 instead of 7 waves per SIMD)
 extern "C" int vmd_hip_set_rdf_shared_hist(int on) { const int old = g_rdf_shist; g_rdf_shist = on ? 1 : 0; return old; }
-static int g_pen_ry = 1, g_pen_rz = 1;   // neighbour reach of the pencil walk; the grid handed to the build and to the walk must be cut to match
+static thread_local int g_pen_ry = 1, g_pen_rz = 1;   // neighbour reach of the pencil walk; the grid handed to the build and to the walk must be cut to match.  Per host thread like g_rdf_closed: the evaluator sets it (choose_grid) right before that thread's launches, two evals on two threads must not race (TSan: profiles/r04r_tsan.txt)
 extern "C" void vmd_hip_set_pencil_reach(int ry, int rz) { g_pen_ry = ry < 1 ? 1 : (ry > 4 ? 4 : ry); g_pen_rz = rz < 1 ? 1 : (rz > 4 ? 4 : rz); }
 // candidate columns walked by k_rdf_pencil (all launches of this process on the current device) since the last reset
 static unsigned long long* g_cols_dev[64] = {};

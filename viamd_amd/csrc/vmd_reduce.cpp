@@ -196,12 +196,48 @@ __global__ void k_max_u64(const uint64_t* __restrict__ src, size_t n, unsigned l
     }
     if (threadIdx.x == 0 && part[0]) atomicMax(out, part[0]);
 }
-// staging of what travels: one buffer per device for the whole process (a merge per evaluation: no allocation in the steady state);
-// merges on one device take turns (the buffer used to be thread_local - leaked per thread - and lived on whatever
-// device the caller had current)
+// staging of what travels: a small pool of buffers per device for the whole process (a merge per evaluation: no allocation in the steady
+// state).  A merge LEASES a buffer for its duration and never waits for another merge: a host that drives several ranks from threads
+// of one process - one GPU each, or several ranks on one GPU - would otherwise have rank A waiting in the collective for a rank B that
+// waits for A's buffer (tests/native/reduce_threads.cpp runs exactly that).  (the buffer used to be thread_local -
+// leaked per thread - and lived on whatever device the caller had current.)
 struct Scratch { void* p = nullptr; size_t cap = 0; };
-std::mutex g_scratch_mtx[64];                   // per DEVICE: a host that drives several ranks from threads of one process (one GPU each)
-Scratch g_scratch[64];                          // must not serialise them - rank A would wait in the collective for a rank B that waits for A's lock
+struct ScratchPool { std::mutex mtx; std::vector<Scratch> idle; };
+ScratchPool g_scratch_pool[64];
+struct ScratchLease {                            // declared after DeviceScope: returned (or freed) while the eval's device is still current
+    int dev;
+    Scratch sc;
+    explicit ScratchLease(int d) : dev(d) {}
+    bool take(size_t need) {
+        {
+            std::lock_guard<std::mutex> l(g_scratch_pool[dev].mtx);
+            std::vector<Scratch>& idle = g_scratch_pool[dev].idle;
+            // the smallest idle buffer that is large enough, else the largest one (it is regrown below)
+            auto better = [need](const Scratch& a, const Scratch& b) {
+                const bool fa = a.cap >= need, fb = b.cap >= need;
+                if (fa != fb) return fa;
+                return fa ? a.cap < b.cap : a.cap > b.cap;
+            };
+            size_t best = idle.size();
+            for (size_t i = 0; i < idle.size(); ++i) if (best == idle.size() || better(idle[i], idle[best])) best = i;
+            if (best < idle.size()) { sc = idle[best]; idle.erase(idle.begin() + (long)best); }
+        }
+        if (sc.cap >= need) return true;
+        if (sc.p) (void)hipFree(sc.p);
+        sc.p = nullptr; sc.cap = 0;
+        if (hipMalloc(&sc.p, need) != hipSuccess) { (void)hipGetLastError(); sc.p = nullptr; return false; }
+        sc.cap = need;
+        return true;
+    }
+    ~ScratchLease() {
+        if (!sc.p) return;
+        {
+            std::lock_guard<std::mutex> l(g_scratch_pool[dev].mtx);
+            if (g_scratch_pool[dev].idle.size() < 4) { g_scratch_pool[dev].idle.push_back(sc); return; }
+        }
+        (void)hipFree(sc.p);
+    }
+};
 // the caller's current device comes back on every exit path; the timing events are destroyed on every exit path
 struct DeviceScope {
     int prev = -1;
@@ -276,15 +312,10 @@ extern "C" bool vmd_eval_reduce(vmd_script_eval_t* eval, const vmd_collective_i*
         for (size_t f = 0; f < F; ++f) packed[off + f] = mask[f] ? 1.0 : 0.0;
     }
     const size_t off_measured = n_f64 - n_measured;      // the last n_measured slots: this rank's largest count per undecided volume
-    std::lock_guard<std::mutex> scratch_lock(g_scratch_mtx[dev]);
-    Scratch& sc = g_scratch[dev];
+    ScratchLease lease(dev);
     const size_t need = n_u32 * sizeof(uint32_t) + n_f64 * sizeof(double);
-    if (sc.cap < need) {
-        if (sc.p) (void)hipFree(sc.p);
-        sc.p = nullptr; sc.cap = 0;
-        if (hipMalloc(&sc.p, need) != hipSuccess) return red_fail("vmd_eval_reduce: hipMalloc failed");
-        sc.cap = need;
-    }
+    if (!lease.take(need)) return red_fail("vmd_eval_reduce: hipMalloc failed");
+    Scratch& sc = lease.sc;
     uint32_t* d_u32 = (uint32_t*)sc.p;
     double* d_packed = (double*)((char*)sc.p + n_u32 * sizeof(uint32_t));
     vmd_reduce_stats_t st;
