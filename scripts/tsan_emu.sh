@@ -3,7 +3,7 @@
 # under ThreadSanitizer.  The emulator's fibers are announced to TSan (tests/emu/emu.cpp: __tsan_create_fiber /
 # __tsan_switch_to_fiber), so what is checked is the host code around the launches: the read-ahead's lock-free request marks and
 # flight word, the combining queue, the block commits, interrupt / clear / free against running calls, the shim's registry, merges of several ranks driven from threads of one process.
-# usage: bash scripts/tsan_emu.sh [out_dir]      (about 35 minutes of CPU: TSan costs 10 - 20 x)
+# usage: bash scripts/tsan_emu.sh [out_dir]      (about 45 minutes on 8 cores: TSan costs 10 - 20 x)
 set -e
 cd "$(dirname "$0")/.."
 R=$(pwd)
@@ -20,14 +20,14 @@ build tests/native/exp_threads.cpp $OUT/exp_threads
 build tests/native/reduce_threads.cpp $OUT/reduce_threads
 build tests/native/concurrent_evals.cpp $OUT/concurrent_evals
 cd $OUT
-rc=0
+# the programs run side by side (the emulator executes one launch at a time per process, so each is about one core)
 run() {   # name args...
   local name=$1; shift
-  local t0=$(date +%s)
-  timeout 3600 "$@" > $OUT/$name.log 2>&1 || rc=1
-  local n=$(grep -c "WARNING: ThreadSanitizer" $OUT/$name.log || true)
-  echo "$name: $(($(date +%s) - t0)) s, ThreadSanitizer warnings: $n, last line: $(grep -v '^$' $OUT/$name.log | tail -1 | cut -c1-200)"
-  [ "$n" = "0" ] || { rc=1; grep "SUMMARY" $OUT/$name.log | sort | uniq -c; }
+  ( t0=$(date +%s)
+    timeout 5400 "$@" > $OUT/$name.log 2>&1; prc=$?
+    n=$(grep -c "WARNING: ThreadSanitizer" $OUT/$name.log || true)
+    echo "$name: rc $prc, $(($(date +%s) - t0)) s, ThreadSanitizer warnings: $n, last line: $(grep -v '^$' $OUT/$name.log | tail -1 | cut -c1-200)" > $OUT/$name.result
+    [ "$n" = "0" ] || grep "SUMMARY" $OUT/$name.log | sort | uniq -c >> $OUT/$name.result ) &
 }
 run reduce_threads $OUT/reduce_threads 3 12 600
 run concurrent_evals $OUT/concurrent_evals 2 10 600 $OUT
@@ -36,4 +36,6 @@ run stress_eval $OUT/stress_eval 2 6
 run exp_threads_rdf $OUT/exp_threads ${TSAN_EXP_ARGS:-900 64}
 run stress_ra_sdf $OUT/stress_ra 3 16 600 9 sdf
 run stress_ra $OUT/stress_ra ${TSAN_RA_ARGS:-8 40 900 7}
-exit $rc
+wait
+cat $OUT/*.result
+! grep -q "warnings: [1-9]\|rc [1-9]" $OUT/*.result

@@ -250,6 +250,6 @@ def test_independent_evaluations_side_by_side(gpu_lib, tmp_path):
     """the same on the MI355X: 25 rounds of 16 concurrent evaluations over 48 frames of 6 000 atoms"""
     from viamd_amd import build
     exe = _build_against(build.build(), CONCURRENT_SRC, str(tmp_path / "concurrent"))
-    out = subprocess.run([exe, "25", "48", "6000", str(tmp_path)], capture_output=True, text=True, timeout=900, env=dict(os.environ, AMD_LOG_LEVEL="1"))
+    out = subprocess.run([exe, "25", "48", "6000", str(tmp_path)], capture_output=True, text=True, timeout=180, env=dict(os.environ, AMD_LOG_LEVEL="1"))
     assert out.returncode == 0, (out.stdout[-500:], out.stderr[-3000:])
     assert out.stdout.startswith("OK iterations=25"), out.stdout
