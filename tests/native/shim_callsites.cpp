@@ -178,6 +178,43 @@ int main(int argc, char** argv) {
         }
     }
     if (refreshed != 6) fail("every property's fingerprint must have moved");
+
+    // ---- the same two tasks SIDE BY SIDE: VIAMD enqueues "Eval Full" and "Eval Filt" as two pool tasks (:982-1039) and nothing orders them -
+    // the filtered eval walks its sub-range while the full one, its source behind the shim, is still being evaluated.  Same numbers as above.
+    {
+        std::vector<std::vector<float>> want;
+        for (const DisplayProperty& dp : display_properties) want.emplace_back(dp.prop_data->values, dp.prop_data->values + dp.prop_data->num_values);
+        std::vector<uint8_t> want_mask[2];
+        for (int which = 0; which < 2; ++which) {
+            const md_bitfield_t* mask = md_script_eval_frame_mask(which ? filt_eval : full_eval);
+            want_mask[which].assign(F, 0);
+            md_bitfield_iter_t it = md_bitfield_iter_create(mask);
+            while (md_bitfield_iter_next(&it)) want_mask[which][md_bitfield_iter_idx(&it)] = 1;
+        }
+        md_script_eval_clear_data(full_eval);
+        md_script_eval_clear_data(filt_eval);
+        std::thread full_task([&] { pool_task(full_eval, 0, (uint32_t)F, 4); });
+        std::thread filt_task([&] { pool_task(filt_eval, beg_frame, end_frame, 3); });
+        full_task.join(); filt_task.join();
+        size_t k = 0;
+        for (const DisplayProperty& dp : display_properties) {
+            const bool temporal = (dp.prop_flags & MD_SCRIPT_PROPERTY_FLAG_TEMPORAL) != 0;
+            const std::vector<uint8_t>& m = want_mask[dp.eval == filt_eval ? 1 : 0];
+            const size_t width = temporal ? (size_t)dp.prop_data->dim[1] : 0;
+            for (size_t i = 0; i < want[k].size(); ++i) {
+                if (temporal && !m[i / width]) continue;                         // rows of frames nobody asked for: whatever
+                if (dp.prop_data->values[i] != want[k][i]) { std::fprintf(stderr, "%s (%s eval), value %zu: %g, one after the other %g\n", dp.label, dp.eval == filt_eval ? "filt" : "full", i, dp.prop_data->values[i], want[k][i]); fail("side-by-side evaluation differs"); }
+            }
+            ++k;
+        }
+        for (int which = 0; which < 2; ++which) {
+            const md_bitfield_t* mask = md_script_eval_frame_mask(which ? filt_eval : full_eval);
+            std::vector<uint8_t> got(F, 0);
+            md_bitfield_iter_t it = md_bitfield_iter_create(mask);
+            while (md_bitfield_iter_next(&it)) got[md_bitfield_iter_idx(&it)] = 1;
+            if (got != want_mask[which]) fail("side-by-side evaluation: frame mask differs");
+        }
+    }
     // :1314-1315 what the property windows print: an rdf's x axis and a distance's y axis are lengths, an sdf has no unit
     for (const DisplayProperty& dp : display_properties) {
         const bool rdf = dp.label[0] == 'r', dist = dp.label[0] == 'd';
