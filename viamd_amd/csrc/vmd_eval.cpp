@@ -3131,7 +3131,11 @@ static bool ra_engage(vmd_script_eval_t* e, vmd_trajectory_i* traj) {
     const size_t Bmax = auto_batch(e, num_atoms, !have_view);
     if (e->block_frames == 0) {
         // a filtered eval (src/main.cpp:1014-1039) adopts whole blocks from its source's partials: same blocks as the source
-        const size_t S = (e->source && e->source->block_frames) ? std::min(e->source->block_frames, std::max<size_t>(Bmax, 1)) : ra_block_frames(e, Bmax);
+        // (the source may be engaging at this very moment - "Eval Full" and "Eval Filt" side by side: its block size is read under its mutex;
+        // order: own mutex, then the source's, as everywhere)
+        size_t src_S = 0;
+        if (e->source) { std::lock_guard<std::mutex> sl(e->source->mtx); src_S = e->source->block_frames; }
+        const size_t S = src_S ? std::min(src_S, std::max<size_t>(Bmax, 1)) : ra_block_frames(e, Bmax);
         const size_t nblocks = (e->num_frames + S - 1) / S;
         size_t bytes = 0;
         for (auto& p : e->props) bytes += nblocks * p->ncounts * sizeof(uint64_t);
