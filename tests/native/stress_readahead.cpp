@@ -159,6 +159,7 @@ int main(int argc, char** argv) {
         vmd_script_eval_t* side = nullptr;
         std::thread side_pool;
         std::atomic<int> side_failures{0};
+        bool side_interrupted = false;
         uint32_t slo = 0, shi = 0;
         std::vector<uint32_t> sstarts;
         if (beside) {
@@ -167,13 +168,28 @@ int main(int argc, char** argv) {
             if (!side || !vmd_eval_set_source(side, eval)) fail("side-by-side filtered eval");
             for (uint32_t f = slo; f < shi; f += grain) sstarts.push_back(f);
             const int sthreads = 1 + (int)(rng() % 4);
-            side_pool = std::thread([&, sthreads] { side_failures = pooled(side, sstarts, grain, shi, sthreads, -1); });
+            // now and then the slider moves on before the filtered evaluation is through: interrupted midway, restarted once the full one is done
+            const long side_stop = rng() % 3 == 0 ? (long)(rng() % sstarts.size()) : -1;
+            side_pool = std::thread([&, sthreads, side_stop] { side_failures = pooled(side, sstarts, grain, shi, sthreads, side_stop); });
+            side_interrupted = side_stop >= 0;
+        }
+        // ... or the script is edited while both run: the full evaluation is interrupted and started over, the filtered one carries on beside it
+        const bool full_restart = beside && !split && rng() % 3 == 0;
+        if (full_restart) {
+            if (pooled(eval, starts, grain, mid, nthreads, (long)(rng() % starts.size())) != 0) fail("an interrupted evaluation (beside a filtered one) reported an error");
+            // (VIAMD waits for the interrupted task before it clears; the filtered eval must cope with its source's blocks vanishing)
+            vmd_eval_clear_data(eval);
         }
         if (pooled(eval, starts, grain, mid, nthreads, -1) != 0) fail("a call failed");
         if (split) { big.join(); if (!big_ok) fail("the large call failed"); }
         if (beside) {
             side_pool.join();
             if (side_failures.load()) fail("a call of the side-by-side filtered evaluation failed");
+            if (side_interrupted) {
+                if (vmd_eval_frames_done(side) > (size_t)(shi - slo)) fail("an interrupted filtered evaluation counted frames nobody asked for");
+                vmd_eval_clear_data(side);
+                if (pooled(side, sstarts, grain, shi, 1 + (int)(rng() % 4), -1) != 0) fail("a call of the restarted filtered evaluation failed");
+            }
             same(snapshot(side, F), reference(slo, shi), "filtered evaluation running beside its source differs from one call over its range");
             size_t computed = 0, reused = 0;
             vmd_eval_frame_stats(side, &computed, &reused);
