@@ -224,6 +224,24 @@ typedef struct vmd_topology_t {
     const int32_t* residue_seq_id;
 } vmd_topology_t;
 bool     vmd_ir_compile_from_source(vmd_script_ir_t* ir, const char* source, const vmd_topology_t* topology);
+/* The same, statement by statement: what the front-end understands is compiled, every other statement is REPORTED instead of failing the
+ * script - VIAMD's own default script (src/main.cpp:528) carries `a1 = angle(2,1,3) in resname("ALA");` and
+ * `{lin,plan,iso} = shape_weights(all);` next to its distance / rdf / sdf statements.  The report lists, per skipped statement, its
+ * left-hand names ("a1", "lin,plan,iso"), its byte range in `source` (without the ';') and the reason; a statement that uses an identifier
+ * of a skipped one is skipped with it.  vmd_script_report_fallback_source is `source` with the COMPILED property statements blanked out
+ * (offsets unchanged, selections kept): the text the evaluator behind include/vmd_md_script_shim.h's fallback hooks compiles, so that no
+ * property is evaluated twice.  Returns false only for NULL arguments or a malformed topology. */
+typedef struct vmd_script_skipped_t {
+    const char* names;       /* left-hand side as written, tuple members joined by ',' */
+    size_t      beg, end;    /* [beg, end) in `source` */
+    const char* reason;
+} vmd_script_skipped_t;
+typedef struct vmd_script_report_t vmd_script_report_t;
+bool     vmd_ir_compile_from_source_partial(vmd_script_ir_t* ir, const char* source, const vmd_topology_t* topology, vmd_script_report_t** report);
+size_t   vmd_script_report_skipped_count(const vmd_script_report_t* report);
+const vmd_script_skipped_t* vmd_script_report_skipped(const vmd_script_report_t* report);
+const char* vmd_script_report_fallback_source(const vmd_script_report_t* report);
+void     vmd_script_report_free(vmd_script_report_t* report);
 bool     vmd_ir_valid(const vmd_script_ir_t* ir);                       /* md_script_ir_valid, src/main.cpp:936 */
 uint64_t vmd_ir_fingerprint(const vmd_script_ir_t* ir);                 /* md_script_ir_fingerprint, src/main.cpp:937 */
 size_t   vmd_ir_property_count(const vmd_script_ir_t* ir);              /* md_script_ir_property_count, src/main.cpp:992,1277 */

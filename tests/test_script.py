@@ -156,3 +156,63 @@ def test_native_front_end_matches_the_python_one(host_lib, topo):
             script.compile_script_native(text, topo, lib=emu_lib)
         with pytest.raises((script.ScriptError, V.VmdError, ValueError)):
             script.compile_script(text, topo, lib=emu_lib)
+
+
+# the literal string VIAMD's editor starts with (/root/reference/src/main.cpp:528)
+VIAMD_DEFAULT_SCRIPT = ("s1 = resname(\"ALA\")[2:8];\nd1 = distance(10,30);\na1 = angle(2,1,3) in resname(\"ALA\");\n"
+                        "r = rdf(element('C'), element('H'), 10.0);\nv = sdf(s1, element('H'), 10.0);\n{lin,plan,iso} = shape_weights(all);")
+
+
+def test_partial_compile_skips_what_is_outside_the_path(host_lib, topo):
+    """one statement outside the subset must not cost the script its rdf / sdf / distance properties.
+    VIAMD's default script yields d1, r, v; a1 and {lin,plan,iso} come back as the list the shim's fallback evaluates; C++ and
+    Python agree on names, ranges and the fallback text."""
+    text = VIAMD_DEFAULT_SCRIPT
+    with pytest.raises((script.ScriptError, V.VmdError)):
+        script.compile_script_native(text, topo, lib=host_lib)                   # the strict mode still refuses the script as a whole
+    ir_py, info, rep_py = script.compile_script(text, topo, lib=host_lib, partial=True)
+    ir_c, rep_c = script.compile_script_native(text, topo, lib=host_lib, partial=True)
+    assert ir_py.property_names() == ir_c.property_names() == ["d1", "r", "v"]
+    assert ir_py.fingerprint() == ir_c.fingerprint()
+    strict = script.compile_script("s1 = resname(\"ALA\")[2:8]; d1 = distance(10,30); r = rdf(element('C'), element('H'), 10.0); v = sdf(s1, element('H'), 10.0);",
+                                   topo, lib=host_lib)[0]
+    assert strict.fingerprint() == ir_c.fingerprint()                            # the same descriptors as the script without the two statements
+    assert info["v"]["structures"].shape == (7, 10)
+    for rep in (rep_py, rep_c):
+        assert [k["names"] for k in rep["skipped"]] == ["a1", "lin,plan,iso"]
+        assert [text[k["beg"]:k["end"]] for k in rep["skipped"]] == ["a1 = angle(2,1,3) in resname(\"ALA\")", "{lin,plan,iso} = shape_weights(all)"]
+        assert "angle" in rep["skipped"][0]["reason"] and "shape_weights" in rep["skipped"][1]["reason"]
+        fb = rep["fallback_source"]
+        assert len(fb) == len(text) and fb.count("\n") == text.count("\n")       # offsets unchanged: mdlib's diagnostics still point into the editor's text
+        assert "distance" not in fb and "rdf" not in fb and "sdf" not in fb      # no property is evaluated twice
+        assert "s1 = resname(\"ALA\")[2:8];" in fb and "a1 = angle(2,1,3) in resname(\"ALA\");" in fb and "{lin,plan,iso} = shape_weights(all);" in fb
+    assert rep_py["fallback_source"] == rep_c["fallback_source"]
+    assert [(k["names"], k["beg"], k["end"]) for k in rep_py["skipped"]] == [(k["names"], k["beg"], k["end"]) for k in rep_c["skipped"]]
+
+
+def test_partial_compile_edge_cases(host_lib, topo):
+    cases_ = [
+        # a statement that uses an identifier of a skipped one goes with it; the next one still compiles
+        ("w = within(5.0, protein); g = rdf(w, all, 5.0); h = rdf(water and element('O'), all, 4.0);", ["h"], ["w", "g"]),
+        # characters outside the subset, a malformed number, trailing garbage after a complete call, an empty selection
+        ("x = 3 * 4 + 2; d = distance(1, 2) ; e = distance(1, 2) + 1; f = rdf(element('X'), all, 5.0); k = distance_max(1:3, 7);", ["d", "k"], ["x", "e", "f"]),
+        # a property name that is taken: the second statement is skipped with the library's message
+        ("d = distance(1, 2); d = distance(3, 4);", ["d"], ["d"]),
+        # nothing understood, nothing lost
+        ("{a,b} = shape_weights(all)", [], ["a,b"]),
+        ("", [], []),
+        # an unbalanced statement swallows the rest of the text: reported as one
+        ("g = rdf(all, all, 5.0; h = rdf(all, all, 4.0);", [], ["g"]),
+    ]
+    for text, compiled, skipped in cases_:
+        ir_py, _, rep_py = script.compile_script(text, topo, lib=host_lib, partial=True)
+        ir_c, rep_c = script.compile_script_native(text, topo, lib=host_lib, partial=True)
+        assert ir_py.property_names() == ir_c.property_names() == compiled, text
+        assert [k["names"] for k in rep_py["skipped"]] == [k["names"] for k in rep_c["skipped"]] == skipped, text
+        assert [(k["beg"], k["end"]) for k in rep_py["skipped"]] == [(k["beg"], k["end"]) for k in rep_c["skipped"]], text
+        assert rep_py["fallback_source"] == rep_c["fallback_source"], text
+        assert ir_py.fingerprint() == ir_c.fingerprint(), text
+    # every script the strict mode accepts compiles identically in the partial mode, with nothing skipped
+    for text in GOOD_SCRIPTS:
+        ir_c, rep = script.compile_script_native(text, topo, lib=host_lib, partial=True)
+        assert rep["skipped"] == [] and ir_c.fingerprint() == script.compile_script_native(text, topo, lib=host_lib).fingerprint(), text

@@ -57,6 +57,10 @@ class HostView(C.Structure):
 HOST_VIEW_FN = C.CFUNCTYPE(C.c_bool, C.c_void_p, C.POINTER(HostView))
 
 
+class ScriptSkippedC(C.Structure):
+    _fields_ = [("names", C.c_char_p), ("beg", C.c_size_t), ("end", C.c_size_t), ("reason", C.c_char_p)]
+
+
 class TopologyC(C.Structure):
     _fields_ = [("num_atoms", C.c_size_t), ("elements", C.POINTER(C.c_char_p)), ("names", C.POINTER(C.c_char_p)),
                 ("resnames", C.POINTER(C.c_char_p)), ("residue_index", c_int32_p), ("residue_seq_id", c_int32_p)]
@@ -141,6 +145,11 @@ SIGNATURES = [
     ("vmd_ir_add_distance", C.c_bool, [_vp, C.c_char_p, C.c_int, c_int32_p, C.c_size_t, c_int32_p, C.c_size_t]),
     ("vmd_ir_add_distance_population", C.c_bool, [_vp, C.c_char_p, C.c_int, C.c_size_t, c_int32_p, c_int32_p, c_int32_p, c_int32_p]),
     ("vmd_ir_compile_from_source", C.c_bool, [_vp, C.c_char_p, C.POINTER(TopologyC)]),
+    ("vmd_ir_compile_from_source_partial", C.c_bool, [_vp, C.c_char_p, C.POINTER(TopologyC), C.POINTER(_vp)]),
+    ("vmd_script_report_skipped_count", C.c_size_t, [_vp]),
+    ("vmd_script_report_skipped", C.POINTER(ScriptSkippedC), [_vp]),
+    ("vmd_script_report_fallback_source", C.c_char_p, [_vp]),
+    ("vmd_script_report_free", None, [_vp]),
     ("vmd_ir_valid", C.c_bool, [_vp]),
     ("vmd_ir_fingerprint", C.c_uint64, [_vp]),
     ("vmd_ir_property_count", C.c_size_t, [_vp]),

@@ -19,6 +19,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <memory>
 #include <set>
@@ -44,9 +45,11 @@ struct ScriptError : std::runtime_error { using std::runtime_error::runtime_erro
 }
 
 enum TokKind { T_END, T_NUM, T_STR, T_ID, T_OP };
-struct Token { TokKind kind; std::string text; };
+struct Token { TokKind kind; std::string text; size_t beg = 0, end = 0; };     // [beg, end): byte range in the source
 
-std::vector<Token> tokenize(const char* src) {
+// tolerant: a character outside the subset becomes a one-character T_OP token instead of an error (partial compilation: the statement
+// it belongs to is then reported as skipped, the others still compile)
+std::vector<Token> tokenize(const char* src, bool tolerant = false) {
     std::string text(src);
     // strip comments
     for (size_t i = 0; i < text.size(); ++i)
@@ -69,20 +72,25 @@ std::vector<Token> tokenize(const char* src) {
                     if (r < n && isdigit((unsigned char)text[r])) { while (r < n && isdigit((unsigned char)text[r])) ++r; q = r; }
                 }
             }
-            out.push_back({T_NUM, text.substr(p, q - p)});
+            out.push_back({T_NUM, text.substr(p, q - p), p, q});
             p = q;
         } else if (c == '\'' || c == '"') {
             const size_t q = text.find(c, p + 1);
-            if (q == std::string::npos) fail("unexpected character '%c' at offset %zu", c, p);
-            out.push_back({T_STR, text.substr(p + 1, q - p - 1)});
+            if (q == std::string::npos) {
+                if (!tolerant) fail("unexpected character '%c' at offset %zu", c, p);
+                out.push_back({T_OP, std::string(1, c), p, p + 1});
+                ++p;
+                continue;
+            }
+            out.push_back({T_STR, text.substr(p + 1, q - p - 1), p, q + 1});
             p = q + 1;
         } else if (isalpha((unsigned char)c) || c == '_') {
             size_t q = p;
             while (q < n && (isalnum((unsigned char)text[q]) || text[q] == '_')) ++q;
-            out.push_back({T_ID, text.substr(p, q - p)});
+            out.push_back({T_ID, text.substr(p, q - p), p, q});
             p = q;
-        } else if (strchr("=(),;:[]{}", c)) {
-            out.push_back({T_OP, std::string(1, c)});
+        } else if (strchr("=(),;:[]{}", c) || tolerant) {
+            out.push_back({T_OP, std::string(1, c), p, p + 1});
             ++p;
         } else {
             fail("unexpected character '%c' at offset %zu", c, p);
@@ -303,6 +311,7 @@ struct Parser {
             if ((size_t)b > topo.nres) fail("%s(%ld) out of range (system has %zu residues)", v.c_str(), b, topo.nres);
             return residues([&](size_t r) { return (size_t)a <= r && r < (size_t)b; });
         }
+        if (is_word("(")) fail("unsupported function '%s' (outside the rdf / sdf / distance path)", v.c_str());
         fail("unknown identifier '%s'", v.c_str());
     }
 };
@@ -314,93 +323,158 @@ vmd_distance_kind_t dist_kind(const std::string& f) {
     return VMD_DISTANCE_PAIR;
 }
 
-void compile(vmd_script_ir_t* ir, const char* source, const vmd_topology_t* t) {
+struct Skipped { std::string names; size_t beg, end; std::string reason; };
+struct Report {
+    std::vector<Skipped> skipped;
+    std::vector<vmd_script_skipped_t> view;
+    std::string fallback_source;
+};
+
+// One statement at a time.  A statement is parsed completely - up to its ';' - before its descriptor is appended, so a statement that
+// fails leaves neither a property nor an identifier behind.  report == nullptr: the first error ends the compilation (the strict
+// mode).  Otherwise the failing statement is recorded {left-hand names, source range, reason} and the next one is compiled: what a host
+// hands to the evaluator it falls back on (include/vmd_md_script_shim.h), e.g. `a1 = angle(2,1,3) in resname("ALA");` and
+// `{lin,plan,iso} = shape_weights(all);` of VIAMD's default script (src/main.cpp:528).  A later statement that uses an identifier of a
+// skipped one is skipped with it ("unknown identifier").
+void compile(vmd_script_ir_t* ir, const char* source, const vmd_topology_t* t, Report* report) {
     const Topo topo(t);
-    const std::vector<Token> toks = tokenize(source);
+    const std::vector<Token> toks = tokenize(source, report != nullptr);
     std::map<std::string, Sel> env;
     Parser p(toks, topo, env);
     auto check = [](bool ok) { if (!ok) throw ScriptError(vmd_last_error()); };
+    std::string fallback(source);
     while (p.peek().kind != T_END) {
         if (p.accept(";")) continue;
-        const std::string name = p.take(nullptr, T_ID);
-        p.take("=");
-        const Token k = p.peek();
-        const bool is_func = k.kind == T_ID && (k.text == "rdf" || k.text == "sdf" || k.text == "distance" || k.text == "distance_min" ||
-                                                k.text == "distance_max" || k.text == "distance_pair");
-        if (is_func) {
-            const std::string v = k.text;
-            ++p.i;
-            p.take("(");
-            if (v == "rdf") {
-                const Sel ref = p.sel_or(); p.take(",");
-                const Sel tgt = p.sel_or(); p.take(",");
-                double rmin = 0.0, rmax;
-                if (p.accept("{")) { rmin = p.number(); p.take(","); rmax = p.number(); p.take("}"); }
-                else {
-                    rmax = p.number();
-                    if (p.accept(":")) { rmin = rmax; rmax = p.number(); }
-                }
-                p.take(")");
-                const auto a = ref.indices(), b = tgt.indices();
-                if (a.empty() || b.empty()) fail("%s: empty selection", name.c_str());
-                check(vmd_ir_add_rdf(ir, name.c_str(), a.data(), a.size(), b.data(), b.size(), (float)rmin, (float)rmax));
-            } else if (v == "sdf") {
-                const Sel ref = p.sel_or(); p.take(",");
-                const Sel tgt = p.sel_or(); p.take(",");
-                const double cutoff = p.number();
-                p.take(")");
-                std::vector<std::vector<int32_t>> structs = ref.has_structs ? ref.structs : std::vector<std::vector<int32_t>>{ref.indices()};
-                if (structs.empty()) fail("%s: sdf reference structures must be non-empty and of equal size", name.c_str());
-                const size_t m = structs[0].size();
-                std::vector<int32_t> flat;
-                for (auto& s : structs) {
-                    if (s.size() != m || m == 0) fail("%s: sdf reference structures must be non-empty and of equal size", name.c_str());
-                    flat.insert(flat.end(), s.begin(), s.end());
-                }
-                const auto tg = tgt.indices();
-                check(vmd_ir_add_sdf(ir, name.c_str(), flat.data(), structs.size(), m, tg.data(), tg.size(), (float)cutoff));
-            } else {
-                // the arguments may be followed by `in <contexts>`: find the closing parenthesis first
-                const size_t start = p.i;
-                size_t j = p.i;
-                int depth = 1;
-                while (depth) {
-                    if (j >= toks.size()) fail("%s: missing ')'", name.c_str());
-                    if (toks[j].kind == T_OP && toks[j].text == "(") depth += 1;
-                    if (toks[j].kind == T_OP && toks[j].text == ")") depth -= 1;
-                    ++j;
-                }
-                if (j < toks.size() && toks[j].kind == T_ID && toks[j].text == "in") {
-                    Parser q(toks, topo, env);
-                    q.i = j + 1;
-                    const Sel ctx = q.sel_or();
-                    if (!ctx.has_structs || ctx.structs.empty()) fail("%s: `in` needs an array of structures (residue(...), resname(...))", name.c_str());
-                    std::vector<int32_t> a_all, b_all, a_off{0}, b_off{0};
-                    for (auto& st : ctx.structs) {
-                        Parser r(toks, topo, env, &st);
-                        r.i = start;
-                        const Sel a = r.sel_or(); r.take(","); const Sel b = r.sel_or(); r.take(")");
-                        const auto ai = a.indices(), bi = b.indices();
-                        if (ai.empty() || bi.empty()) fail("%s: empty selection inside a context", name.c_str());
-                        a_all.insert(a_all.end(), ai.begin(), ai.end()); a_off.push_back((int32_t)a_all.size());
-                        b_all.insert(b_all.end(), bi.begin(), bi.end()); b_off.push_back((int32_t)b_all.size());
-                    }
-                    p.i = q.i;
-                    check(vmd_ir_add_distance_population(ir, name.c_str(), dist_kind(v), ctx.structs.size(), a_all.data(), a_off.data(),
-                                                         b_all.data(), b_off.data()));
-                } else {
-                    const Sel a = p.sel_or(); p.take(",");
-                    const Sel b = p.sel_or();
-                    p.take(")");
-                    const auto ai = a.indices(), bi = b.indices();
-                    check(vmd_ir_add_distance(ir, name.c_str(), dist_kind(v), ai.data(), ai.size(), bi.data(), bi.size()));
-                }
+        const size_t first = p.i;
+        // the statement's extent: up to the next ';' outside brackets (or the end of the text)
+        size_t last = first;
+        {
+            int depth = 0;
+            for (; last < toks.size(); ++last) {
+                const Token& k = toks[last];
+                if (k.kind != T_OP) continue;
+                if (k.text == "(" || k.text == "[" || k.text == "{") depth += 1;
+                else if (k.text == ")" || k.text == "]" || k.text == "}") depth -= 1;
+                else if (k.text == ";" && depth <= 0) break;
             }
-        } else {
-            env[name] = p.sel_or();
         }
-        if (p.peek().kind != T_END) p.take(";");
+        std::string names;
+        std::function<void()> commit;
+        bool is_property = false;
+        try {
+            if (p.is_word("{")) {
+                // tuple assignment `{a, b, c} = f(...)`: no hot-path function returns a tuple
+                p.take("{");
+                names = p.take(nullptr, T_ID);
+                while (p.accept(",")) names += "," + p.take(nullptr, T_ID);
+                p.take("}");
+                p.take("=");
+                const Token& f = p.peek();
+                fail("unsupported %s '%s' (outside the rdf / sdf / distance path)", f.kind == T_ID ? "function" : "expression", f.text.c_str());
+            }
+            const std::string name = p.take(nullptr, T_ID);
+            names = name;
+            p.take("=");
+            const Token k = p.peek();
+            const bool is_func = k.kind == T_ID && (k.text == "rdf" || k.text == "sdf" || k.text == "distance" || k.text == "distance_min" ||
+                                                    k.text == "distance_max" || k.text == "distance_pair");
+            if (is_func) {
+                is_property = true;
+                const std::string v = k.text;
+                ++p.i;
+                p.take("(");
+                if (v == "rdf") {
+                    const Sel ref = p.sel_or(); p.take(",");
+                    const Sel tgt = p.sel_or(); p.take(",");
+                    double rmin = 0.0, rmax;
+                    if (p.accept("{")) { rmin = p.number(); p.take(","); rmax = p.number(); p.take("}"); }
+                    else {
+                        rmax = p.number();
+                        if (p.accept(":")) { rmin = rmax; rmax = p.number(); }
+                    }
+                    p.take(")");
+                    const auto a = ref.indices(), b = tgt.indices();
+                    if (a.empty() || b.empty()) fail("%s: empty selection", name.c_str());
+                    commit = [=]() { if (!vmd_ir_add_rdf(ir, name.c_str(), a.data(), a.size(), b.data(), b.size(), (float)rmin, (float)rmax)) throw ScriptError(vmd_last_error()); };
+                } else if (v == "sdf") {
+                    const Sel ref = p.sel_or(); p.take(",");
+                    const Sel tgt = p.sel_or(); p.take(",");
+                    const double cutoff = p.number();
+                    p.take(")");
+                    std::vector<std::vector<int32_t>> structs = ref.has_structs ? ref.structs : std::vector<std::vector<int32_t>>{ref.indices()};
+                    if (structs.empty()) fail("%s: sdf reference structures must be non-empty and of equal size", name.c_str());
+                    const size_t m = structs[0].size();
+                    std::vector<int32_t> flat;
+                    for (auto& st : structs) {
+                        if (st.size() != m || m == 0) fail("%s: sdf reference structures must be non-empty and of equal size", name.c_str());
+                        flat.insert(flat.end(), st.begin(), st.end());
+                    }
+                    const auto tg = tgt.indices();
+                    const size_t K = structs.size();
+                    commit = [=]() { if (!vmd_ir_add_sdf(ir, name.c_str(), flat.data(), K, m, tg.data(), tg.size(), (float)cutoff)) throw ScriptError(vmd_last_error()); };
+                } else {
+                    // the arguments may be followed by `in <contexts>`: find the closing parenthesis first
+                    const size_t start = p.i;
+                    size_t j = p.i;
+                    int depth = 1;
+                    while (depth) {
+                        if (j >= toks.size()) fail("%s: missing ')'", name.c_str());
+                        if (toks[j].kind == T_OP && toks[j].text == "(") depth += 1;
+                        if (toks[j].kind == T_OP && toks[j].text == ")") depth -= 1;
+                        ++j;
+                    }
+                    if (j < toks.size() && toks[j].kind == T_ID && toks[j].text == "in") {
+                        Parser q(toks, topo, env);
+                        q.i = j + 1;
+                        const Sel ctx = q.sel_or();
+                        if (!ctx.has_structs || ctx.structs.empty()) fail("%s: `in` needs an array of structures (residue(...), resname(...))", name.c_str());
+                        std::vector<int32_t> a_all, b_all, a_off{0}, b_off{0};
+                        for (auto& st : ctx.structs) {
+                            Parser r(toks, topo, env, &st);
+                            r.i = start;
+                            const Sel a = r.sel_or(); r.take(","); const Sel b = r.sel_or(); r.take(")");
+                            const auto ai = a.indices(), bi = b.indices();
+                            if (ai.empty() || bi.empty()) fail("%s: empty selection inside a context", name.c_str());
+                            a_all.insert(a_all.end(), ai.begin(), ai.end()); a_off.push_back((int32_t)a_all.size());
+                            b_all.insert(b_all.end(), bi.begin(), bi.end()); b_off.push_back((int32_t)b_all.size());
+                        }
+                        p.i = q.i;
+                        const size_t P = ctx.structs.size();
+                        const vmd_distance_kind_t kind = dist_kind(v);
+                        commit = [=]() {
+                            if (!vmd_ir_add_distance_population(ir, name.c_str(), kind, P, a_all.data(), a_off.data(), b_all.data(), b_off.data())) throw ScriptError(vmd_last_error());
+                        };
+                    } else {
+                        const Sel a = p.sel_or(); p.take(",");
+                        const Sel b = p.sel_or();
+                        p.take(")");
+                        const auto ai = a.indices(), bi = b.indices();
+                        const vmd_distance_kind_t kind = dist_kind(v);
+                        commit = [=]() { if (!vmd_ir_add_distance(ir, name.c_str(), kind, ai.data(), ai.size(), bi.data(), bi.size())) throw ScriptError(vmd_last_error()); };
+                    }
+                }
+            } else {
+                const Sel sel = p.sel_or();
+                commit = [&env, name, sel]() { env[name] = sel; };
+            }
+            if (p.peek().kind != T_END && !p.is_word(";")) fail("expected ;, found '%s'", p.peek().text.c_str());
+            commit();
+            if (p.peek().kind != T_END) p.take(";");
+            if (is_property && report) {
+                // the fallback evaluates the text WITHOUT this statement: blanked in place, so that every other offset stays what the editor shows
+                const size_t e = last < toks.size() ? toks[last].end : toks[last - 1].end;
+                for (size_t c = toks[first].beg; c < e && c < fallback.size(); ++c) if (fallback[c] != '\n') fallback[c] = ' ';
+            }
+        } catch (const ScriptError& e) {
+            if (!report) throw;
+            (void)check;
+            if (names.empty()) names = toks[first].text;
+            const size_t send = last > first ? toks[last - 1].end : toks[first].end;
+            report->skipped.push_back({names, toks[first].beg, send, e.what()});
+            p.i = last < toks.size() ? last + 1 : last;
+        }
     }
+    if (report) report->fallback_source = fallback;
 }
 
 }  // namespace
@@ -408,10 +482,31 @@ void compile(vmd_script_ir_t* ir, const char* source, const vmd_topology_t* t) {
 extern "C" bool vmd_ir_compile_from_source(vmd_script_ir_t* ir, const char* source, const vmd_topology_t* topology) {
     if (!ir || !source || !topology) { vmd_set_last_error("vmd_ir_compile_from_source: NULL argument"); return false; }
     try {
-        compile(ir, source, topology);
+        compile(ir, source, topology, nullptr);
     } catch (const std::exception& e) {
         vmd_set_last_error(e.what());
         return false;
     }
     return true;
 }
+
+struct vmd_script_report_t { Report r; };
+
+extern "C" bool vmd_ir_compile_from_source_partial(vmd_script_ir_t* ir, const char* source, const vmd_topology_t* topology, vmd_script_report_t** report) {
+    if (report) *report = nullptr;
+    if (!ir || !source || !topology || !report) { vmd_set_last_error("vmd_ir_compile_from_source_partial: NULL argument"); return false; }
+    std::unique_ptr<vmd_script_report_t> rep(new vmd_script_report_t());
+    try {
+        compile(ir, source, topology, &rep->r);
+    } catch (const std::exception& e) {          // the topology itself is malformed: nothing a fallback could take over
+        vmd_set_last_error(e.what());
+        return false;
+    }
+    for (const Skipped& k : rep->r.skipped) rep->r.view.push_back(vmd_script_skipped_t{k.names.c_str(), k.beg, k.end, k.reason.c_str()});
+    *report = rep.release();
+    return true;
+}
+extern "C" size_t vmd_script_report_skipped_count(const vmd_script_report_t* r) { return r ? r->r.view.size() : 0; }
+extern "C" const vmd_script_skipped_t* vmd_script_report_skipped(const vmd_script_report_t* r) { return r && !r->r.view.empty() ? r->r.view.data() : nullptr; }
+extern "C" const char* vmd_script_report_fallback_source(const vmd_script_report_t* r) { return r ? r->r.fallback_source.c_str() : ""; }
+extern "C" void vmd_script_report_free(vmd_script_report_t* r) { delete r; }

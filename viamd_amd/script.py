@@ -18,7 +18,7 @@ import re
 import numpy as np
 
 from . import _lib as L
-from .eval import ScriptIR
+from .eval import ScriptIR, VmdError
 
 WATER_RESNAMES = {"HOH", "WAT", "SOL", "TIP3", "TIP4", "SPC", "H2O"}
 PROTEIN_RESNAMES = {"ALA", "ARG", "ASN", "ASP", "CYS", "GLN", "GLU", "GLY", "HIS", "ILE", "LEU", "LYS", "MET", "PHE", "PRO",
@@ -69,18 +69,29 @@ class Sel:
 _TOKEN = re.compile(r"""\s*(?:(?P<num>\d+\.\d*(?:[eE][-+]?\d+)?|\.\d+|\d+)|(?P<str>'[^']*'|"[^"]*")|(?P<id>[A-Za-z_]\w*)|(?P<op>[=(),;:\[\]{}]))""")
 
 
-def _tokenize(text):
-    text = re.sub(r"#[^\n]*", "", text)
+def _tokenize(text, tolerant=False, spans=None):
+    """tokens as (kind, text); `spans` (a list) receives the [beg, end) byte range of each.  tolerant: a character outside the subset
+    becomes a one-character op token instead of an error (partial compilation)."""
+    text = re.sub(r"#[^\n]*", lambda m: " " * len(m.group()), text)       # comments -> blanks: offsets stay those of the source
     pos, out = 0, []
     while pos < len(text):
         m = _TOKEN.match(text, pos)
         if not m:
             if text[pos:].strip() == "":
                 break
-            raise ScriptError(f"unexpected character {text[pos:].strip()[0]!r} at offset {pos}")
+            bad = pos + len(text[pos:]) - len(text[pos:].lstrip())
+            if not tolerant:
+                raise ScriptError(f"unexpected character {text[bad]!r} at offset {pos}")
+            out.append(("op", text[bad]))
+            if spans is not None:
+                spans.append((bad, bad + 1))
+            pos = bad + 1
+            continue
         pos = m.end()
         kind = m.lastgroup
         out.append((kind, m.group(kind)))
+        if spans is not None:
+            spans.append((m.start(kind), m.end(kind)))
     return out
 
 
@@ -243,6 +254,8 @@ class _Parser:
             if b > topo.num_residues:
                 raise ScriptError(f"{v}({b}) out of range (system has {topo.num_residues} residues)")
             return self._residues(lambda r: a <= r < b)
+        if self.peek()[1] == "(":
+            raise ScriptError(f"unsupported function {v!r} (outside the rdf / sdf / distance path)")
         raise ScriptError(f"unknown identifier {v!r}")
 
     def number(self):
@@ -253,86 +266,149 @@ _FUNCS = {"rdf", "sdf", "distance", "distance_min", "distance_max", "distance_pa
 _DIST_KIND = {"distance": L.DIST_COM, "distance_min": L.DIST_MIN, "distance_max": L.DIST_MAX, "distance_pair": L.DIST_PAIR}
 
 
-def compile_script(text, topo, lib=None):
-    """Returns (ScriptIR, info) where info[name] = dict(kind=..., plus the resolved index arrays)."""
+def compile_script(text, topo, lib=None, partial=False):
+    """Returns (ScriptIR, info) where info[name] = dict(kind=..., plus the resolved index arrays).
+
+    partial=True (vmd_ir_compile_from_source_partial): statements outside the subset are reported instead of failing the script;
+    returns (ScriptIR, info, report) with report = dict(skipped=[dict(names, beg, end, reason)], fallback_source=text with the compiled
+    property statements blanked out).  VIAMD's default script (src/main.cpp:528) then yields d1, r, v and reports a1 and lin,plan,iso."""
     ir = ScriptIR(lib)
     env, info = {}, {}
-    p = _Parser(_tokenize(text), topo, env)
+    spans = []
+    toks = _tokenize(text, tolerant=partial, spans=spans)
+    p = _Parser(toks, topo, env)
+    skipped = []
+    fallback = list(text)
     while p.peek()[0] is not None:
         if p.accept(";"):
             continue
-        name = p.take(kind="id")
-        p.take("=")
-        k, v = p.peek()
-        if k == "id" and v in _FUNCS:
-            p.i += 1
-            p.take("(")
-            if v == "rdf":
-                ref = p.sel_or(); p.take(",")
-                tgt = p.sel_or(); p.take(",")
-                if p.accept("{"):
-                    rmin = p.number(); p.take(","); rmax = p.number(); p.take("}")
-                else:
-                    rmin, rmax = 0.0, p.number()
-                    if p.accept(":"):
-                        rmin, rmax = rmax, p.number()
-                p.take(")")
-                a, b = ref.indices(), tgt.indices()
-                if a.size == 0 or b.size == 0:
-                    raise ScriptError(f"{name}: empty selection")
-                ir.add_rdf(name, a, b, (rmin, rmax))
-                info[name] = dict(kind="rdf", ref=a, target=b, rmin=rmin, rmax=rmax)
-            elif v == "sdf":
-                ref = p.sel_or(); p.take(",")
-                tgt = p.sel_or(); p.take(",")
-                cutoff = p.number()
-                p.take(")")
-                structs = ref.structures if ref.structures is not None else [ref.indices()]
-                sizes = {len(s) for s in structs}
-                if len(sizes) != 1 or 0 in sizes:
-                    raise ScriptError(f"{name}: sdf reference structures must be non-empty and of equal size, got sizes {sorted(sizes)}")
-                st = np.stack([np.asarray(s, np.int32) for s in structs])
-                ir.add_sdf(name, st, tgt.indices(), cutoff)
-                info[name] = dict(kind="sdf", structures=st, target=tgt.indices(), cutoff=cutoff)
-            else:
-                # the arguments may be followed by `in <contexts>`: find the closing parenthesis first
-                start, depth, j = p.i, 1, p.i
-                while depth:
-                    if j >= len(p.t):
-                        raise ScriptError(f"{name}: missing ')'")
-                    depth += {"(": 1, ")": -1}.get(p.t[j][1], 0)
-                    j += 1
-                if j < len(p.t) and p.t[j][1] == "in":
-                    q = _Parser(p.t, topo, env)
-                    q.i = j + 1
-                    ctx = q.sel_or()
-                    if ctx.structures is None or not ctx.structures:
-                        raise ScriptError(f"{name}: `in` needs an array of structures (residue(...), resname(...))")
-                    a_sets, b_sets = [], []
-                    for st in ctx.structures:
-                        r = _Parser(p.t, topo, env, ctx=np.asarray(st))
-                        r.i = start
-                        a = r.sel_or(); r.take(","); b = r.sel_or(); r.take(")")
-                        if a.indices().size == 0 or b.indices().size == 0:
-                            raise ScriptError(f"{name}: empty selection inside a context")
-                        a_sets.append(a.indices()); b_sets.append(b.indices())
-                    p.i = q.i
-                    ir.add_distance_population(name, a_sets, b_sets, _DIST_KIND[v])
-                    info[name] = dict(kind=v, a_sets=a_sets, b_sets=b_sets)
-                else:
-                    a = p.sel_or(); p.take(",")
-                    b = p.sel_or()
-                    p.take(")")
-                    ir.add_distance(name, a.indices(), b.indices(), _DIST_KIND[v])
-                    info[name] = dict(kind=v, a=a.indices(), b=b.indices())
-        else:
-            env[name] = p.sel_or()
-        if p.peek()[0] is not None:
-            p.take(";")
+        first = p.i
+        last, depth = first, 0
+        while last < len(toks):
+            v = toks[last][1] if toks[last][0] == "op" else None
+            if v in ("(", "[", "{"):
+                depth += 1
+            elif v in (")", "]", "}"):
+                depth -= 1
+            elif v == ";" and depth <= 0:
+                break
+            last += 1
+        names = ""
+        try:
+            if p.peek()[1] == "{" and p.peek()[0] == "op":
+                p.take("{")
+                names = p.take(kind="id")
+                while p.accept(","):
+                    names += "," + p.take(kind="id")
+                p.take("}")
+                p.take("=")
+                k, v = p.peek()
+                raise ScriptError(f"unsupported {'function' if k == 'id' else 'expression'} {v!r} (outside the rdf / sdf / distance path)")
+            name = p.take(kind="id")
+            names = name
+            p.take("=")
+            commit, is_property = _statement(p, name, topo, env, ir, info)
+            if p.peek()[0] is not None and p.peek()[1] != ";":
+                raise ScriptError(f"expected ;, found {p.peek()[1]!r}")
+            commit()
+            if p.peek()[0] is not None:
+                p.take(";")
+            if is_property and partial:
+                e = spans[last][1] if last < len(toks) else spans[last - 1][1]
+                for c in range(spans[first][0], min(e, len(fallback))):
+                    if fallback[c] != "\n":
+                        fallback[c] = " "
+        except (ValueError, VmdError) as e:   # ScriptError, int() / float() on a malformed number, a descriptor the library refuses
+            if not partial:
+                raise
+            send = spans[last - 1][1] if last > first else spans[first][1]
+            skipped.append(dict(names=names or toks[first][1], beg=spans[first][0], end=send, reason=str(e)))
+            p.i = last + 1 if last < len(toks) else last
+    if partial:
+        return ir, info, dict(skipped=skipped, fallback_source="".join(fallback))
     return ir, info
 
 
-def compile_script_native(text, topo, lib=None):
+def _statement(p, name, topo, env, ir, info):
+    """parses the right-hand side of `name = ...` up to (not including) the ';'.  Returns (commit, is_property): nothing is added to the
+    IR or to the identifiers before commit() runs, so a statement that fails half way leaves nothing behind."""
+    k, v = p.peek()
+    if not (k == "id" and v in _FUNCS):
+        sel = p.sel_or()
+        return (lambda: env.__setitem__(name, sel)), False
+    p.i += 1
+    p.take("(")
+    if v == "rdf":
+        ref = p.sel_or(); p.take(",")
+        tgt = p.sel_or(); p.take(",")
+        if p.accept("{"):
+            rmin = p.number(); p.take(","); rmax = p.number(); p.take("}")
+        else:
+            rmin, rmax = 0.0, p.number()
+            if p.accept(":"):
+                rmin, rmax = rmax, p.number()
+        p.take(")")
+        a, b = ref.indices(), tgt.indices()
+        if a.size == 0 or b.size == 0:
+            raise ScriptError(f"{name}: empty selection")
+
+        def commit():
+            ir.add_rdf(name, a, b, (rmin, rmax))
+            info[name] = dict(kind="rdf", ref=a, target=b, rmin=rmin, rmax=rmax)
+        return commit, True
+    if v == "sdf":
+        ref = p.sel_or(); p.take(",")
+        tgt = p.sel_or(); p.take(",")
+        cutoff = p.number()
+        p.take(")")
+        structs = ref.structures if ref.structures is not None else [ref.indices()]
+        sizes = {len(s) for s in structs}
+        if len(sizes) != 1 or 0 in sizes:
+            raise ScriptError(f"{name}: sdf reference structures must be non-empty and of equal size, got sizes {sorted(sizes)}")
+        st = np.stack([np.asarray(s, np.int32) for s in structs])
+
+        def commit():
+            ir.add_sdf(name, st, tgt.indices(), cutoff)
+            info[name] = dict(kind="sdf", structures=st, target=tgt.indices(), cutoff=cutoff)
+        return commit, True
+    # the arguments may be followed by `in <contexts>`: find the closing parenthesis first
+    start, depth, j = p.i, 1, p.i
+    while depth:
+        if j >= len(p.t):
+            raise ScriptError(f"{name}: missing ')'")
+        depth += {"(": 1, ")": -1}.get(p.t[j][1], 0) if p.t[j][0] == "op" else 0
+        j += 1
+    if j < len(p.t) and p.t[j] == ("id", "in"):
+        q = _Parser(p.t, topo, env)
+        q.i = j + 1
+        ctx = q.sel_or()
+        if ctx.structures is None or not ctx.structures:
+            raise ScriptError(f"{name}: `in` needs an array of structures (residue(...), resname(...))")
+        a_sets, b_sets = [], []
+        for st in ctx.structures:
+            r = _Parser(p.t, topo, env, ctx=np.asarray(st))
+            r.i = start
+            a = r.sel_or(); r.take(","); b = r.sel_or(); r.take(")")
+            if a.indices().size == 0 or b.indices().size == 0:
+                raise ScriptError(f"{name}: empty selection inside a context")
+            a_sets.append(a.indices()); b_sets.append(b.indices())
+        p.i = q.i
+
+        def commit():
+            ir.add_distance_population(name, a_sets, b_sets, _DIST_KIND[v])
+            info[name] = dict(kind=v, a_sets=a_sets, b_sets=b_sets)
+        return commit, True
+    a = p.sel_or(); p.take(",")
+    b = p.sel_or()
+    p.take(")")
+
+    def commit():
+        ir.add_distance(name, a.indices(), b.indices(), _DIST_KIND[v])
+        info[name] = dict(kind=v, a=a.indices(), b=b.indices())
+    return commit, True
+
+
+def compile_script_native(text, topo, lib=None, partial=False):
     """The same front-end in C++ (vmd_ir_compile_from_source, viamd_amd/csrc/vmd_script.cpp): what a C / C++ host calls.
     Returns a ScriptIR; raises ScriptError with the library's message."""
     import ctypes as C
@@ -346,6 +422,18 @@ def compile_script_native(text, topo, lib=None):
     ri = np.ascontiguousarray(topo.residue_index, np.int32)
     sq = None if topo.residue_seq_id is None else np.ascontiguousarray(topo.residue_seq_id, np.int32)
     tc = L.TopologyC(n, el, nm, rn, ri.ctypes.data_as(L.c_int32_p), sq.ctypes.data_as(L.c_int32_p) if sq is not None else None)
-    if not ir.lib.vmd_ir_compile_from_source(ir.h, text.encode(), C.byref(tc)):
+    if not partial:
+        if not ir.lib.vmd_ir_compile_from_source(ir.h, text.encode(), C.byref(tc)):
+            raise ScriptError(ir.lib.last_error())
+        return ir
+    rep = C.c_void_p()
+    if not ir.lib.vmd_ir_compile_from_source_partial(ir.h, text.encode(), C.byref(tc), C.byref(rep)):
         raise ScriptError(ir.lib.last_error())
-    return ir
+    try:
+        n = ir.lib.vmd_script_report_skipped_count(rep)
+        items = ir.lib.vmd_script_report_skipped(rep)
+        skipped = [dict(names=items[k].names.decode(), beg=items[k].beg, end=items[k].end, reason=items[k].reason.decode()) for k in range(n)]
+        report = dict(skipped=skipped, fallback_source=ir.lib.vmd_script_report_fallback_source(rep).decode())
+    finally:
+        ir.lib.vmd_script_report_free(rep)
+    return ir, report
