@@ -565,6 +565,7 @@ void vmd_scale_histogram(float* bins, const float* weights, int num_bins);
 int         vmd_device_count(void);                 /* 0 when no HIP device is usable */
 bool        vmd_set_device(int device);
 const char* vmd_last_error(void);                   /* thread-local message of the last failure */
+void        vmd_clear_last_error(void);             /* a caller that handled a failure itself leaves no stale message behind */
 /* md_log_register analogue (VIAMD turns mdlib's log messages into toasts, src/main.cpp:384-420): evaluator failures are
  * delivered to `fn` (from whichever thread hit them) instead of stderr; NULL restores stderr. */
 #define VMD_LOG_INFO  1

@@ -21,6 +21,26 @@
  * md_unit_none()); VMD_SHIM_BITFIELD_INIT / _SET build the md_bitfield_t of a reference structure (default: md_bitfield_init /
  * md_bitfield_set_bit); md_array_resize / md_array_size are mdlib's stretchy-buffer macros.
  *
+ * A DECORATOR, not a replacement (round 5).  mdlib evaluates EVERY property of the IR in one md_script_eval_frame_range
+ * (/root/reference/src/main.cpp:993-997) and VIAMD asks md_script_eval_property_data for every name of md_script_ir_property_names
+ * (:1277-1291) - its own default script (:528) carries `a1 = angle(...)` and `{lin,plan,iso} = shape_weights(all)` next to d1 / r / v.
+ * The shim therefore keeps mdlib's evaluator BEHIND it: the rdf / sdf / distance properties bound with vmd_shim_bind_ir are evaluated
+ * on the GPU, everything else is forwarded to the fallback hooks
+ *
+ *     VMD_SHIM_FALLBACK(md_script_eval_create | _free | _clear_data | _interrupt | _ir_fingerprint | _frame_range | _property_data |
+ *                       _frame_mask)  and  VMD_SHIM_FALLBACK(md_script_ir_property_vis_payload | md_script_vis_eval_payload)
+ *
+ * whose default names are mdlib's originals under a rename: compile mdlib's md_script.c with
+ * -Dmd_script_eval_create=mdlib_md_script_eval_create ... (INTEGRATION.md section 2 lists the ten defines), or define
+ * VMD_SHIM_FALLBACK(name) yourself (dlsym(RTLD_NEXT, #name) wrappers, a test double).  Per call: create / free / clear_data / interrupt
+ * go to both evaluators; frame_range runs the GPU part, then the fallback on the same range; property_data answers bound names from the
+ * GPU eval and every other name from the fallback; frame_mask is the AND of the two masks (a frame counts once both have it);
+ * ir_fingerprint is the fallback's - what src/main.cpp:987 compares with md_script_ir_fingerprint(ir) - perturbed while the GPU
+ * binding of the ir is not the one the eval was created with (VIAMD then re-creates the evals).  The fallback evaluates the IR it is
+ * given: the whole script (the bound properties are then computed twice, their CPU copies ignored), or - vmd_shim_bind_fallback_ir - an
+ * IR mdlib compiled from vmd_script_report_fallback_source(), the script text without the statements the GPU took (include/vmd_eval.h).
+ * VMD_SHIM_NO_FALLBACK removes all of this: unbound names are then NULL, as in rounds 1 - 4.
+ *
  * What the shim needs from the host besides the types: the property DESCRIPTORS.  mdlib's IR is opaque, so the host registers,
  * once per compiled script, the vmd_script_ir_t that carries its rdf / sdf / distance properties (INTEGRATION.md section 3 shows how
  * VIAMD derives them from the evaluated argument bitfields):      vmd_shim_bind_ir(md_ir, vmd_ir);
@@ -58,12 +78,48 @@ struct md_script_vis_payload_o { const md_script_ir_t* ir; std::string name; };
 #define VMD_SHIM_BITFIELD_SET(bf, idx) md_bitfield_set_bit((bf), (uint64_t)(idx))
 #endif
 
+#ifndef VMD_SHIM_BITFIELD_TEST
+#define VMD_SHIM_BITFIELD_TEST(bf, idx) md_bitfield_test_bit((bf), (uint64_t)(idx))
+#endif
+
+/* ---- the evaluator behind the shim (mdlib's own, renamed) -------------------------------------------------------------------- */
+#ifndef VMD_SHIM_NO_FALLBACK
+#ifndef VMD_SHIM_FALLBACK
+#define VMD_SHIM_FALLBACK(name) mdlib_##name
+#endif
+#ifndef VMD_SHIM_FALLBACK_DECLARED
+/* mdlib's md_script_eval_t and md_script_vis_payload_o are opaque to their callers; behind the rename they are these two names */
+struct vmd_shim_fallback_eval_t;
+struct vmd_shim_fallback_payload_t;
+extern "C" {
+vmd_shim_fallback_eval_t* VMD_SHIM_FALLBACK(md_script_eval_create)(size_t num_frames, const md_script_ir_t* ir, md_allocator_i* alloc);
+void     VMD_SHIM_FALLBACK(md_script_eval_free)(vmd_shim_fallback_eval_t* eval);
+void     VMD_SHIM_FALLBACK(md_script_eval_clear_data)(vmd_shim_fallback_eval_t* eval);
+void     VMD_SHIM_FALLBACK(md_script_eval_interrupt)(vmd_shim_fallback_eval_t* eval);
+uint64_t VMD_SHIM_FALLBACK(md_script_eval_ir_fingerprint)(const vmd_shim_fallback_eval_t* eval);
+bool     VMD_SHIM_FALLBACK(md_script_eval_frame_range)(vmd_shim_fallback_eval_t* eval, const md_script_ir_t* ir, const md_system_t* sys,
+                                                       md_trajectory_i* traj, uint32_t frame_beg, uint32_t frame_end);
+const md_script_property_data_t* VMD_SHIM_FALLBACK(md_script_eval_property_data)(const vmd_shim_fallback_eval_t* eval, str_t name);
+const md_bitfield_t* VMD_SHIM_FALLBACK(md_script_eval_frame_mask)(const vmd_shim_fallback_eval_t* eval);
+const vmd_shim_fallback_payload_t* VMD_SHIM_FALLBACK(md_script_ir_property_vis_payload)(const md_script_ir_t* ir, str_t name);
+bool     VMD_SHIM_FALLBACK(md_script_vis_eval_payload)(md_script_vis_t* vis, const vmd_shim_fallback_payload_t* payload, int subidx,
+                                                       const md_script_vis_ctx_t* ctx, md_script_vis_flags_t flags);
+}
+#endif
+#define VMD_SHIM_HAVE_FALLBACK 1
+#else
+struct vmd_shim_fallback_eval_t;
+struct vmd_shim_fallback_payload_t;
+#define VMD_SHIM_HAVE_FALLBACK 0
+#endif
+
 /* ---- IR registry: md_script_ir_t* -> the descriptors of its properties ------------------------------------------------------ */
 namespace vmd_shim {
 struct PayloadEval { vmd_script_eval_t* eval = nullptr; size_t num_frames = 0; };
 struct Registry {
     std::mutex mtx;
     std::map<const void*, const vmd_script_ir_t*> ir;
+    std::map<const void*, const md_script_ir_t*> fallback_ir;        /* md_ir -> the IR the fallback evaluates for it (default: md_ir itself) */
     /* vis payloads handed to VIAMD (one per (ir, property), stable addresses) and one small evaluator per ir that serves them:
      * md_script_vis_eval_payload has no eval argument (density_volume.cpp:188), the reference pose and the per-frame alignment
      * of an sdf() live behind vmd_eval_sdf_payload */
@@ -81,6 +137,21 @@ inline const vmd_script_ir_t* find_ir(const void* md_ir) {
     std::lock_guard<std::mutex> l(r.mtx);
     auto it = r.ir.find(md_ir);
     return it == r.ir.end() ? nullptr : it->second;
+}
+inline const md_script_ir_t* fallback_ir_of(const md_script_ir_t* md_ir) {
+    Registry& r = registry();
+    std::lock_guard<std::mutex> l(r.mtx);
+    auto it = r.fallback_ir.find(md_ir);
+    return it == r.fallback_ir.end() ? md_ir : it->second;
+}
+inline bool name_is(const std::string& a, str_t b) { return a.size() == (size_t)b.len && memcmp(a.data(), b.ptr, (size_t)b.len) == 0; }
+/* is `name` one of the properties the GPU evaluates for this ir? */
+inline bool bound_name(const vmd_script_ir_t* vir, str_t name) {
+    if (!vir) return false;
+    const size_t n = vmd_ir_property_count(vir);
+    const char* const* names = vmd_ir_property_names(vir);
+    for (size_t i = 0; i < n; ++i) if (strlen(names[i]) == (size_t)name.len && memcmp(names[i], name.ptr, (size_t)name.len) == 0) return true;
+    return false;
 }
 
 /* md_unitcell_t -> vmd_unitcell_t: the six basis parameters VIAMD itself reads (src/viamd.cpp:1837-1842) + the periodicity bits */
@@ -146,6 +217,15 @@ inline void vmd_shim_bind_ir(const md_script_ir_t* md_ir, const vmd_script_ir_t*
     for (auto it = r.payloads.begin(); it != r.payloads.end();) it = it->first.first == md_ir ? r.payloads.erase(it) : std::next(it);
 }
 
+/* Optional: the IR the fallback evaluator runs for `md_ir` - one mdlib compiled from vmd_script_report_fallback_source() (the script
+ * without the statements the GPU evaluates), so that nothing is computed twice.  Default (and fallback_ir = NULL): md_ir itself.  The
+ * reduced IR must outlive the evals created from md_ir, like md_ir. */
+inline void vmd_shim_bind_fallback_ir(const md_script_ir_t* md_ir, const md_script_ir_t* fallback_ir) {
+    vmd_shim::Registry& r = vmd_shim::registry();
+    std::lock_guard<std::mutex> l(r.mtx);
+    if (fallback_ir) r.fallback_ir[md_ir] = fallback_ir; else r.fallback_ir.erase(md_ir);
+}
+
 /* Optional: the frames behind `md_traj` are also available through `native` - a vmd_xdrtraj / vmd_dcdtraj / vmd_rawtraj / vmd_devtraj
  * interface of the same file or of a copy in HBM (a loader shim registers the pair where VIAMD attaches the trajectory,
  * src/loader.cpp:111-159).  md_script_eval_frame_range then evaluates from `native` - frames decompressed on the GPU, DMA'd out of the
@@ -159,9 +239,12 @@ inline void vmd_shim_bind_trajectory(const md_trajectory_i* md_traj, vmd_traject
 
 /* ---- md_script_eval_t ------------------------------------------------------------------------------------------------------ */
 struct md_script_eval_t {
-    vmd_script_eval_t* eval = nullptr;
+    vmd_script_eval_t* eval = nullptr;           /* the GPU evaluator of the bound properties; NULL for a script without any */
     const vmd_script_ir_t* vir = nullptr;
     const md_script_ir_t* md_ir = nullptr;
+    vmd_shim_fallback_eval_t* fb = nullptr;      /* mdlib's evaluator of everything else; NULL without fallback hooks */
+    const md_script_ir_t* fb_ir = nullptr;       /* the IR `fb` was created from (md_ir, or the reduced one of vmd_shim_bind_fallback_ir) */
+    size_t num_frames = 0;
     /* md_script_property_data_t records handed to VIAMD: fetched once and cached by the GUI (src/main.cpp:1286,1303), so their
      * addresses are stable for the eval's lifetime; the arrays they point at are the backend's own (equally stable), the scalar
      * fields (fingerprint, ranges, max_value) are refreshed from the backend whenever data may have changed */
@@ -199,25 +282,40 @@ struct md_script_eval_t {
 };
 
 inline md_script_eval_t* VMD_SHIM_PREFIX(md_script_eval_create)(size_t num_frames, const md_script_ir_t* ir, md_allocator_i* alloc) {
-    (void)alloc;                                 /* host allocations are the library's own (DESIGN.md section 8) */
     const vmd_script_ir_t* vir = vmd_shim::find_ir(ir);
-    if (!vir) return nullptr;
     std::unique_ptr<md_script_eval_t> e(new md_script_eval_t());
     e->vir = vir;
-    e->eval = vmd_eval_create(num_frames, vir);
-    if (!e->eval) return nullptr;
-    const size_t n = vmd_ir_property_count(vir);
-    for (size_t i = 0; i < n; ++i) {
-        std::unique_ptr<md_script_eval_t::Prop> p(new md_script_eval_t::Prop());
-        p->name = vmd_ir_property_names(vir)[i];
-        p->src = vmd_eval_property_data(e->eval, p->name.c_str());
-        memset(&p->dst, 0, sizeof(p->dst));
-        memset(&p->agg, 0, sizeof(p->agg));
-        /* unit[2] (src/main.cpp:1300-1301, printed at :1314-1315): the backend carries the printed form, VMD_SHIM_UNIT makes the
-         * md_unit_t of it */
-        VMD_SHIM_UNIT(p->dst.unit[0], p->src->unit_str[0]);
-        VMD_SHIM_UNIT(p->dst.unit[1], p->src->unit_str[1]);
-        e->props.push_back(std::move(p));
+    e->md_ir = ir;
+    e->num_frames = num_frames;
+#if VMD_SHIM_HAVE_FALLBACK
+    /* mdlib's evaluator of the same script (or of the reduced one): every property the GPU does not evaluate lives there */
+    e->fb_ir = vmd_shim::fallback_ir_of(ir);
+    e->fb = VMD_SHIM_FALLBACK(md_script_eval_create)(num_frames, e->fb_ir, alloc);
+#else
+    (void)alloc;                                 /* host allocations are the library's own (DESIGN.md section 7) */
+#endif
+    if (!vir && !e->fb) return nullptr;          /* nothing bound and nobody to fall back on: as mdlib for an invalid ir */
+    if (vir) {
+        e->eval = vmd_eval_create(num_frames, vir);
+        if (!e->eval) {
+#if VMD_SHIM_HAVE_FALLBACK
+            if (e->fb) VMD_SHIM_FALLBACK(md_script_eval_free)(e->fb);
+#endif
+            return nullptr;
+        }
+        const size_t n = vmd_ir_property_count(vir);
+        for (size_t i = 0; i < n; ++i) {
+            std::unique_ptr<md_script_eval_t::Prop> p(new md_script_eval_t::Prop());
+            p->name = vmd_ir_property_names(vir)[i];
+            p->src = vmd_eval_property_data(e->eval, p->name.c_str());
+            memset(&p->dst, 0, sizeof(p->dst));
+            memset(&p->agg, 0, sizeof(p->agg));
+            /* unit[2] (src/main.cpp:1300-1301, printed at :1314-1315): the backend carries the printed form, VMD_SHIM_UNIT makes the
+             * md_unit_t of it */
+            VMD_SHIM_UNIT(p->dst.unit[0], p->src->unit_str[0]);
+            VMD_SHIM_UNIT(p->dst.unit[1], p->src->unit_str[1]);
+            e->props.push_back(std::move(p));
+        }
     }
     e->mask_words.assign((num_frames + 63) / 64 + 1, 0);
     memset(&e->mask, 0, sizeof(e->mask));
@@ -225,19 +323,23 @@ inline md_script_eval_t* VMD_SHIM_PREFIX(md_script_eval_create)(size_t num_frame
     e->mask.beg_bit = 0;
     e->mask.end_bit = (uint32_t)num_frames;
     e->refresh();
-    {
+    if (e->eval) {
         vmd_shim::Registry& r = vmd_shim::registry();
         std::lock_guard<std::mutex> l(r.mtx);
         std::vector<vmd_script_eval_t*>& live = r.evals[ir];
-        if (!live.empty() && vmd_eval_num_frames(live.front()) == num_frames) vmd_eval_set_source(e->eval, live.front());
+#ifndef VMD_SHIM_NO_AUTO_SOURCE
+        /* VIAMD's filtered eval takes the full one as its SOURCE (block partials instead of a second evaluation).  The backend hands
+         * blocks over only between evals that are evaluating the same trajectory instance, so a host that runs two evals of one ir over
+         * different trajectories of equal length gets two evaluations; a refusal (another device) is not an error of this call */
+        if (!live.empty() && vmd_eval_num_frames(live.front()) == num_frames && !vmd_eval_set_source(e->eval, live.front())) vmd_clear_last_error();
+#endif
         live.push_back(e->eval);
-        e->md_ir = ir;
     }
     return e.release();
 }
 inline void VMD_SHIM_PREFIX(md_script_eval_free)(md_script_eval_t* e) {
     if (!e) return;
-    {
+    if (e->eval) {
         /* VIAMD frees the full eval before the filtered one (src/main.cpp:959-964): nobody may keep it as a source */
         vmd_shim::Registry& r = vmd_shim::registry();
         std::lock_guard<std::mutex> l(r.mtx);
@@ -251,49 +353,109 @@ inline void VMD_SHIM_PREFIX(md_script_eval_free)(md_script_eval_t* e) {
         }
     }
     vmd_eval_free(e->eval);
+#if VMD_SHIM_HAVE_FALLBACK
+    if (e->fb) VMD_SHIM_FALLBACK(md_script_eval_free)(e->fb);
+#endif
     delete e;
 }
 inline void VMD_SHIM_PREFIX(md_script_eval_clear_data)(md_script_eval_t* e) {
     if (!e) return;
-    vmd_eval_clear_data(e->eval);
+    if (e->eval) vmd_eval_clear_data(e->eval);
+#if VMD_SHIM_HAVE_FALLBACK
+    if (e->fb) VMD_SHIM_FALLBACK(md_script_eval_clear_data)(e->fb);
+#endif
     std::lock_guard<std::mutex> l(e->mtx);
     e->refresh();
 }
-inline void VMD_SHIM_PREFIX(md_script_eval_interrupt)(md_script_eval_t* e) { if (e) vmd_eval_interrupt(e->eval); }
-inline uint64_t VMD_SHIM_PREFIX(md_script_eval_ir_fingerprint)(const md_script_eval_t* e) { return e ? vmd_eval_ir_fingerprint(e->eval) : 0; }
-/* md_script_ir_fingerprint of the bound IR: what src/main.cpp:987 compares the eval's fingerprint with */
+inline void VMD_SHIM_PREFIX(md_script_eval_interrupt)(md_script_eval_t* e) {
+    if (!e) return;
+    if (e->eval) vmd_eval_interrupt(e->eval);
+#if VMD_SHIM_HAVE_FALLBACK
+    if (e->fb) VMD_SHIM_FALLBACK(md_script_eval_interrupt)(e->fb);
+#endif
+}
+/* md_script_ir_fingerprint of the bound IR: what a host WITHOUT mdlib behind the shim compares the eval's fingerprint with */
 inline uint64_t vmd_shim_ir_fingerprint(const md_script_ir_t* ir) {
     const vmd_script_ir_t* vir = vmd_shim::find_ir(ir);
     return vir ? vmd_ir_fingerprint(vir) : 0;
 }
+/* src/main.cpp:987: md_script_eval_ir_fingerprint(eval) == md_script_ir_fingerprint(ir).  With mdlib behind the shim the right-hand side
+ * is mdlib's, so the answer is mdlib's fingerprint of the IR the eval was created from: the fallback eval's own when it evaluates that
+ * very IR, VMD_SHIM_IR_FINGERPRINT(md_ir) (default md_script_ir_fingerprint) when it evaluates the reduced one.  While the GPU binding of
+ * the ir is no longer the one this eval was created with, the value is perturbed: VIAMD sees a mismatch and re-creates its evals. */
+#ifndef VMD_SHIM_IR_FINGERPRINT
+#define VMD_SHIM_IR_FINGERPRINT(ir) md_script_ir_fingerprint(ir)
+#endif
+inline uint64_t VMD_SHIM_PREFIX(md_script_eval_ir_fingerprint)(const md_script_eval_t* e) {
+    if (!e) return 0;
+#if VMD_SHIM_HAVE_FALLBACK
+    if (e->fb) {
+        uint64_t fp = e->fb_ir == e->md_ir ? VMD_SHIM_FALLBACK(md_script_eval_ir_fingerprint)(e->fb) : (uint64_t)VMD_SHIM_IR_FINGERPRINT(e->md_ir);
+        if (vmd_shim::find_ir(e->md_ir) != e->vir) fp ^= 0x9E3779B97F4A7C15ull;
+        return fp;
+    }
+#endif
+    return e->eval ? vmd_eval_ir_fingerprint(e->eval) : 0;
+}
 
-/* the hot call: pool threads, disjoint ranges, one eval (src/main.cpp:993-997) */
+/* the hot call: pool threads, disjoint ranges, one eval (src/main.cpp:993-997).  The GPU part first (the calls of a pool arrive together
+ * and are combined / evaluated ahead), then mdlib's evaluator for the same range on the calling thread - the pool's other
+ * threads are inside their own ranges meanwhile, exactly as without the shim. */
 inline bool VMD_SHIM_PREFIX(md_script_eval_frame_range)(md_script_eval_t* e, const md_script_ir_t* ir, const md_system_t* sys,
                                                         md_trajectory_i* traj, uint32_t frame_beg, uint32_t frame_end) {
     if (!e || !sys || !traj) return false;
-    const vmd_script_ir_t* vir = vmd_shim::find_ir(ir);
-    if (vir != e->vir) return false;             /* mdlib compares fingerprints the same way */
-    const vmd_system_t vsys = vmd_shim::wrap_system(sys);
-    vmd_trajectory_i vtraj = vmd_shim::wrap_trajectory(traj);
-    const bool ok = vmd_eval_frame_range(e->eval, vir, &vsys, &vtraj, frame_beg, frame_end);
-    std::lock_guard<std::mutex> l(e->mtx);
-    e->refresh();
+    if (ir != e->md_ir) return false;            /* mdlib compares fingerprints the same way */
+    bool ok = true;
+    if (e->eval) {
+        const vmd_script_ir_t* vir = vmd_shim::find_ir(ir);
+        if (vir != e->vir) return false;
+        const vmd_system_t vsys = vmd_shim::wrap_system(sys);
+        vmd_trajectory_i vtraj = vmd_shim::wrap_trajectory(traj);
+        ok = vmd_eval_frame_range(e->eval, vir, &vsys, &vtraj, frame_beg, frame_end);
+        std::lock_guard<std::mutex> l(e->mtx);
+        e->refresh();
+    }
+#if VMD_SHIM_HAVE_FALLBACK
+    if (e->fb && ok) ok = VMD_SHIM_FALLBACK(md_script_eval_frame_range)(e->fb, e->fb_ir, sys, traj, frame_beg, frame_end);
+#endif
     return ok;
 }
 
+/* src/main.cpp:1286, once per name of md_script_ir_property_names: the GPU's record for a bound name, mdlib's for every other one
+ * (`a1`, `lin`, `plan`, `iso` of the default script) - NULL only where mdlib says NULL */
 inline const md_script_property_data_t* VMD_SHIM_PREFIX(md_script_eval_property_data)(const md_script_eval_t* e, str_t name) {
     if (!e) return nullptr;
-    for (auto& p : e->props)
-        if (p->name.size() == (size_t)name.len && memcmp(p->name.data(), name.ptr, (size_t)name.len) == 0) return &p->dst;
+    for (auto& p : e->props) if (vmd_shim::name_is(p->name, name)) return &p->dst;
+#if VMD_SHIM_HAVE_FALLBACK
+    if (e->fb) return VMD_SHIM_FALLBACK(md_script_eval_property_data)(e->fb, name);
+#endif
     return nullptr;
 }
 
-/* frames evaluated so far as the bitfield VIAMD iterates (src/main.cpp:194-210, 1513); refreshed by every call */
+/* frames evaluated so far as the bitfield VIAMD iterates (src/main.cpp:194-210, 1513); refreshed by every call.  With two evaluators a
+ * frame is done once BOTH have it: a histogram built over the mask never reads a temporal row one of them has not written yet. */
 inline const md_bitfield_t* VMD_SHIM_PREFIX(md_script_eval_frame_mask)(const md_script_eval_t* ce) {
     md_script_eval_t* e = const_cast<md_script_eval_t*>(ce);
     if (!e) return nullptr;
+#if VMD_SHIM_HAVE_FALLBACK
+    if (e->fb && !e->eval) return VMD_SHIM_FALLBACK(md_script_eval_frame_mask)(e->fb);
+#endif
     std::lock_guard<std::mutex> l(e->mtx);
     vmd_eval_frame_mask_bits(e->eval, e->mask_words.data(), e->mask_words.size());
+#if VMD_SHIM_HAVE_FALLBACK
+    if (e->fb) {
+        const md_bitfield_t* fm = VMD_SHIM_FALLBACK(md_script_eval_frame_mask)(e->fb);
+        for (size_t w = 0; w < e->mask_words.size(); ++w) {
+            uint64_t word = e->mask_words[w];
+            if (!word) continue;
+            for (uint64_t bits = word; bits; bits &= bits - 1) {
+                const size_t f = w * 64 + (size_t)__builtin_ctzll(bits);
+                if (!fm || !VMD_SHIM_BITFIELD_TEST(fm, f)) word &= ~(1ull << (f & 63));
+            }
+            e->mask_words[w] = word;
+        }
+    }
+#endif
     return &e->mask;
 }
 
@@ -301,11 +463,15 @@ inline const md_bitfield_t* VMD_SHIM_PREFIX(md_script_eval_frame_mask)(const md_
 /* md_script_ir_property_vis_payload(ir, name), src/main.cpp:1304: NULL for an unknown ir / property */
 inline const md_script_vis_payload_o* VMD_SHIM_PREFIX(md_script_ir_property_vis_payload)(const md_script_ir_t* ir, str_t name) {
     const vmd_script_ir_t* vir = vmd_shim::find_ir(ir);
-    if (!vir) return nullptr;
+    if (!vmd_shim::bound_name(vir, name)) {
+#if VMD_SHIM_HAVE_FALLBACK
+        /* mdlib's own payload of a property the GPU does not evaluate: an opaque pointer VIAMD only hands back (src/main.cpp:1304) */
+        return (const md_script_vis_payload_o*)VMD_SHIM_FALLBACK(md_script_ir_property_vis_payload)(ir, name);
+#else
+        return nullptr;
+#endif
+    }
     const std::string nm(name.ptr, (size_t)name.len);
-    bool known = false;
-    for (size_t i = 0; i < vmd_ir_property_count(vir); ++i) known = known || nm == vmd_ir_property_names(vir)[i];
-    if (!known) return nullptr;
     vmd_shim::Registry& r = vmd_shim::registry();
     std::lock_guard<std::mutex> l(r.mtx);
     std::unique_ptr<md_script_vis_payload_o>& p = r.payloads[std::make_pair((const void*)ir, nm)];
@@ -320,7 +486,24 @@ inline const md_script_vis_payload_o* VMD_SHIM_PREFIX(md_script_ir_property_vis_
  * other property kinds return false (their highlighting is mdlib's own). */
 inline bool VMD_SHIM_PREFIX(md_script_vis_eval_payload)(md_script_vis_t* vis, const md_script_vis_payload_o* payload, int subidx,
                                                         const md_script_vis_ctx_t* ctx, md_script_vis_flags_t flags) {
-    if (!vis || !payload || !ctx || !ctx->mol || !ctx->traj) return false;
+    if (!vis || !payload || !ctx) return false;
+    {
+        /* a payload this shim did not hand out is mdlib's: its evaluator draws it (angles, planes, selections ...) */
+        vmd_shim::Registry& r = vmd_shim::registry();
+        bool ours = false;
+        {
+            std::lock_guard<std::mutex> l(r.mtx);
+            for (auto& kv : r.payloads) ours = ours || kv.second.get() == payload;
+        }
+        if (!ours) {
+#if VMD_SHIM_HAVE_FALLBACK
+            return VMD_SHIM_FALLBACK(md_script_vis_eval_payload)(vis, (const vmd_shim_fallback_payload_t*)payload, subidx, ctx, flags);
+#else
+            return false;
+#endif
+        }
+    }
+    if (!ctx->mol || !ctx->traj) return false;
     const vmd_script_ir_t* vir = vmd_shim::find_ir(payload->ir);
     if (!vir || !(vmd_ir_property_flags(vir, payload->name.c_str()) & VMD_PROPERTY_FLAG_VOLUME)) return false;
     vmd_shim::Registry& r = vmd_shim::registry();

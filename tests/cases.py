@@ -359,6 +359,7 @@ def readahead_case(lib, O, device=False, n_water=600, box=28.0, F=40, nthreads=6
     ir = V.ScriptIR(lib)
     ir.add_rdf("g", ox, ox, (0.0, 9.0)); ir.add_sdf("v", structures, ox, 7.0); ir.add_distance("d", structures[0], structures[1], L.DIST_MIN)
     traj = make_traj(lib, coords, vcell, device)
+    traj0 = traj
     sysm = V.MolSystem(N, mass=mass, unitcell=vcell)
     names = ("g", "v", "d")
 
@@ -386,7 +387,11 @@ def readahead_case(lib, O, device=False, n_water=600, box=28.0, F=40, nthreads=6
         np.testing.assert_array_equal(ev.property_data("g").counts, want["g"].counts, err_msg=what)
         np.testing.assert_array_equal(ev.property_data("v").counts, want["v"].counts, err_msg=what)
 
-    def pooled(ev, beg, end, grain, nth=nthreads, stop_at=None, order=None):
+    def pooled_on(ev, traj_, beg, end, grain):
+        return pooled(ev, beg, end, grain, use_traj=traj_)
+
+    def pooled(ev, beg, end, grain, nth=nthreads, stop_at=None, order=None, use_traj=None):
+        traj = use_traj if use_traj is not None else traj0
         starts = list(range(beg, end, grain)) if order is None else order
         nxt = [0]; lock = threading.Lock(); res = []
         gate = threading.Barrier(nth)
@@ -490,6 +495,35 @@ def readahead_case(lib, O, device=False, n_water=600, box=28.0, F=40, nthreads=6
         same(filt, part, "filtered eval adopting the full eval's read-ahead blocks")
         assert filt.frame_stats()[1] >= 16, filt.frame_stats()      # blocks of 4: [8, 28) are whole blocks of the source
         filt.close(); ev.close()
+        # ---- block partials that cannot be allocated (a large volume script beside an HBM-resident trajectory) must not fail
+        # the evaluation: read-ahead steps aside, the combining queue serves the same calls, the results are the same
+        lib.vmd_set_option(b"readahead_fail_alloc", 1)
+        try:
+            ev = V.ScriptEval(F, ir)
+            assert all(pooled(ev, 0, F, 1)), lib.last_error()
+            same(ev, full, "read-ahead whose block allocation failed: served by the combining queue")
+            st = ev.readahead_stats()
+            assert st["engaged"] == 0 and st["regions"] == 0, st
+            ev.close()
+        finally:
+            lib.vmd_set_option(b"readahead_fail_alloc", 0)
+        # ---- a source that was evaluated from ANOTHER trajectory (same script, same frame count) hands over nothing
+        other = make_traj(lib, coords[::-1].copy(), vcell, device)      # the same frames in reverse order: a different trajectory instance
+        ev = V.ScriptEval(F, ir)
+        ev.set_block_frames(5)
+        assert all(pooled(ev, 0, F, 1))
+        for driver in ("one call", "pool"):
+            filt = V.ScriptEval(F, ir)
+            filt.set_source(ev)
+            if driver == "one call":
+                assert filt.frame_range(sysm, other, 0, F)
+            else:
+                assert all(pooled_on(filt, other, 0, F, 1))
+            assert filt.frame_stats()[1] == 0, (driver, filt.frame_stats())            # nothing adopted ...
+            np.testing.assert_array_equal(filt.property_data("g").counts, full["g"].counts)   # ... and a histogram does not care about frame order
+            np.testing.assert_array_equal(filt.property_data("d").values[::-1], full["d"].values, err_msg=driver)     # rows follow the OTHER trajectory
+            filt.close()
+        ev.close()
     finally:
         for k, v in old:
             lib.vmd_set_option(k, v)

@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "md_mock.h"
+#define VMD_SHIM_NO_FALLBACK                // this program binds every property of its script: no mdlib behind the shim (shim_default_script.cpp has one)
 #define VMD_SHIM_PREFIX(name) name          // emit the md_script_eval_* names themselves
 #include "vmd_md_script_shim.h"
 

@@ -245,6 +245,7 @@ SIGNATURES = [
     ("vmd_device_count", C.c_int, []),
     ("vmd_set_device", C.c_bool, [C.c_int]),
     ("vmd_last_error", C.c_char_p, []),
+    ("vmd_clear_last_error", None, []),
     ("vmd_last_stage", C.c_char_p, []),
     ("vmd_log_register", None, [LOG_FN, _vp]),
     ("vmd_version", C.c_char_p, []),

@@ -135,6 +135,7 @@ struct Options {
     std::atomic<int> readahead_block{0};     // frames per block partial (0 = by script: 256 without pair passes, 16 - 128 by selection size with)
     std::atomic<int> readahead_linger_us{60};// a call that leaves alone waits this long for another call before it settles the eval (commit + views)
     std::atomic<int> readahead_company_us{80};// the FIRST call of an evaluation waits this long for a second caller before it decides it is alone
+    std::atomic<int> readahead_fail_alloc{0}; // test hook: the block partials' allocation "fails" (the eval must fall back to the combining queue)
 };
 static Options g_opt;
 
@@ -201,6 +202,7 @@ extern "C" int vmd_set_option(const char* key, int value) {
     else if (!strcmp(key, "readahead_block")) o = &g_opt.readahead_block;
     else if (!strcmp(key, "readahead_linger_us")) o = &g_opt.readahead_linger_us;
     else if (!strcmp(key, "readahead_company_us")) o = &g_opt.readahead_company_us;
+    else if (!strcmp(key, "readahead_fail_alloc")) o = &g_opt.readahead_fail_alloc;
     else if (!strcmp(key, "sdf_arith")) o = &g_opt.sdf_arith;
     else if (!strcmp(key, "sdf_ilp")) return vmd_hip_set_sdf_ilp(value);
     else if (!strcmp(key, "sdf_rows")) return vmd_hip_set_sdf_rows(value);
@@ -228,6 +230,7 @@ static std::atomic<const char*> g_stage{"idle"};
 extern "C" const char* vmd_last_stage(void) { return g_stage.load(std::memory_order_relaxed); }
 // for the other translation units of the library (not part of the public headers)
 extern "C" void vmd_set_last_error(const char* msg) { g_last_error = msg ? msg : ""; }
+extern "C" void vmd_clear_last_error(void) { g_last_error.clear(); }
 extern "C" const char* vmd_version(void) { return "viamd_amd 0.1 (gfx950)"; }
 
 extern "C" int vmd_device_count(void) {
@@ -948,6 +951,20 @@ struct RangeRequest {
     std::string error;
 };
 
+// Which trajectory an interface stands for: its instance pointer AND its frame source.  Hosts whose callbacks close over their state
+// (ctypes, lambdas, file-static readers) pass inst = NULL for every trajectory; their callbacks differ.
+struct TrajId {
+    const void* inst = nullptr;
+    const void* fn = nullptr;
+    bool operator==(const TrajId& o) const { return inst == o.inst && fn == o.fn; }
+    bool operator!=(const TrajId& o) const { return !(*this == o); }
+};
+static TrajId traj_id(const vmd_trajectory_i* t) {
+    TrajId id;
+    if (t) { id.inst = t->inst; id.fn = t->load_frame ? reinterpret_cast<const void*>(t->load_frame) : reinterpret_cast<const void*>(t->device_view); }
+    return id;
+}
+
 struct vmd_script_eval_t {
     uint64_t ir_fingerprint = 0;
     size_t num_frames = 0;
@@ -1049,6 +1066,9 @@ struct vmd_script_eval_t {
     std::unique_ptr<std::atomic<uint8_t>[]> block_ready;
     size_t num_blocks = 0;
     vmd_script_eval_t* source = nullptr;
+    // the trajectory instance this eval's block partials were evaluated from: a user of this eval as a SOURCE takes blocks only while it is
+    // itself evaluating the same instance (two evals of one script over different trajectories of equal length must not trade blocks)
+    TrajId blocks_inst;
     std::atomic<size_t> frames_computed{0}, frames_reused{0}, frames_device_decoded{0};
     // ---- read-ahead.  Block states move NONE -> PENDING -> READY under queue_mtx (the region leader), READY -> COMMITTED /
     // DIRECT and NONE -> DIRECT under queue_mtx + mtx (settle / the direct path); the fast path of a call only READS a state and sets
@@ -1079,7 +1099,7 @@ struct vmd_script_eval_t {
         std::mutex settle_mtx;                       // one settle at a time
         int combining = 0;                           // calls inside the combining queue that entered before the states existed (queue_mtx)
         size_t bmax = 0;                             // frames of one kernel batch for this eval and trajectory
-        const void* traj_inst = nullptr;             // the trajectory the regions are evaluated from
+        TrajId traj_inst;                            // the trajectory the regions are evaluated from
         // statistics (vmd_eval_readahead_stats)
         std::atomic<uint64_t> regions{0}, region_frames{0}, slow_calls{0}, settles{0}, direct_frames{0}, committed_blocks{0};
     } ra;
@@ -1357,6 +1377,7 @@ extern "C" void vmd_eval_clear_data(vmd_script_eval_t* eval) {
     eval->frames_done = 0;
     eval->frames_computed = 0; eval->frames_reused = 0; eval->frames_device_decoded = 0; eval->frames_section_decoded = 0; eval->frames_mapped = 0;
     for (size_t b = 0; b < eval->num_blocks; ++b) eval->block_ready[b] = 0;
+    eval->blocks_inst = TrajId();
     ra_reset(eval);
     for (auto& p : eval->props) {
         // the 8.4 MB float view of a volume is pinned: the copy engine zeroes it from a zero buffer in HBM, in the background -
@@ -2425,11 +2446,11 @@ static const float* block_rows(const vmd_script_eval_t* src, const PropState* q,
     return src->block_ready[blk].load() == BLOCK_ROWS_AHEAD && q->ahead_values.size() == q->values.size() ? q->ahead_values.data() : q->values.data();
 }
 
-static bool reuse_blocks(vmd_script_eval_t* e, size_t beg, size_t end, std::vector<std::pair<size_t, size_t>>* todo) {
+static bool reuse_blocks(vmd_script_eval_t* e, const TrajId& traj_inst, size_t beg, size_t end, std::vector<std::pair<size_t, size_t>>* todo) {
     vmd_script_eval_t* src = e->source;
     if (!src) { todo->push_back({beg, end}); return true; }
     std::lock_guard<std::mutex> lock(src->mtx);   // order: own mutex, then the source's (a source never locks its users)
-    if (src->block_frames == 0) { todo->push_back({beg, end}); return true; }      // (looked up under its mutex: read-ahead may be giving it blocks right now)
+    if (src->block_frames == 0 || src->blocks_inst != traj_inst) { todo->push_back({beg, end}); return true; }      // (looked up under its mutex: read-ahead may be giving it blocks right now)
     const size_t S = src->block_frames;
     size_t run = beg, reused = 0;
     for (size_t f = beg; f < end;) {
@@ -2510,7 +2531,8 @@ static bool process_range_locked(vmd_script_eval_t* eval, const vmd_system_t* sy
     // frames served from the block partials of the source eval (filtered evaluation), the rest is computed
     std::vector<std::pair<size_t, size_t>> segments;
     if (spec) segments.push_back({frame_beg, frame_end});         // a region's blocks are adopted from the source by the region leader, or evaluated here
-    else if (!reuse_blocks(e, frame_beg, frame_end, &segments)) return false;
+    else if (!reuse_blocks(e, traj_id(traj), frame_beg, frame_end, &segments)) return false;
+    if (e->block_frames) e->blocks_inst = traj_id(traj);
 
     // compressed frames for the device decoder travel two batches ahead through a ring of three slots (RawSlot)
     vmd_host_view_t hv_probe;
@@ -3139,10 +3161,21 @@ static bool ra_engage(vmd_script_eval_t* e, vmd_trajectory_i* traj) {
         const size_t nblocks = (e->num_frames + S - 1) / S;
         size_t bytes = 0;
         for (auto& p : e->props) bytes += nblocks * p->ncounts * sizeof(uint64_t);
-        if (bytes > ((size_t)32 << 30)) { ra.disabled = true; return true; }        // not worth a ninth of the HBM: the combining queue serves this eval
+        // not worth a ninth of the HBM, nor more than half of what is free right now (a trajectory resident in HBM may have taken most of
+        // it): the combining queue serves this eval, as it did before read-ahead existed
+        size_t cap_bytes = (size_t)32 << 30, free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) cap_bytes = std::min(cap_bytes, free_b / 2);
+        if (bytes > cap_bytes) { ra.disabled = true; return true; }
         for (auto& p : e->props) {
             if (!p->ncounts) continue;
-            if (!p->d_blocks.ensure(nblocks * p->ncounts)) return false;
+            if (!p->d_blocks.ensure(nblocks * p->ncounts) || g_opt.readahead_fail_alloc.load()) {
+                // an allocation that fails here must not fail the evaluation (and every later call with it) - read-ahead is an
+                // optimisation; give back what was taken and let the combining queue serve the calls
+                for (auto& q : e->props) { q->d_blocks.release(); q->block_weights64.clear(); q->block_weights64.shrink_to_fit(); }
+                g_last_error.clear();
+                ra.disabled = true;
+                return true;
+            }
             if (p->prop.kind == PROP_RDF) p->block_weights64.assign(nblocks * p->ncounts, 0.0);
         }
         e->block_ready.reset(new std::atomic<uint8_t>[nblocks]);
@@ -3166,7 +3199,7 @@ static bool ra_engage(vmd_script_eval_t* e, vmd_trajectory_i* traj) {
         ra.blk_state[b] = (done || f0 < lo || f1 > hi || f1 - f0 > Bmax) ? vmd_script_eval_t::RA_DIRECT : vmd_script_eval_t::RA_NONE;
     }
     ra.bmax = Bmax;
-    ra.traj_inst = traj->inst;
+    ra.traj_inst = traj_id(traj);
     ra.on.store(true, std::memory_order_release);
     return true;
 }
@@ -3174,12 +3207,12 @@ static bool ra_engage(vmd_script_eval_t* e, vmd_trajectory_i* traj) {
 // The filtered evaluation under VIAMD's call pattern: blocks of a region that the source eval has finished are not evaluated again - their
 // partials (and temporal rows) are copied from the source into this eval's own block partials, where they wait to be requested like any
 // block evaluated ahead.  mtx held, device set.  adopted[b - b0] = 1 for the blocks taken.
-static bool ra_adopt_blocks(vmd_script_eval_t* e, size_t b0, size_t b1, std::vector<char>* adopted) {
+static bool ra_adopt_blocks(vmd_script_eval_t* e, const TrajId& traj_inst, size_t b0, size_t b1, std::vector<char>* adopted) {
     adopted->assign(b1 - b0, 0);
     vmd_script_eval_t* src = e->source;
     if (!src || src->props.size() != e->props.size()) return true;
     std::lock_guard<std::mutex> lock(src->mtx);       // order: own mutex, then the source's (as reuse_blocks)
-    if (src->block_frames != e->block_frames) return true;
+    if (src->block_frames != e->block_frames || src->blocks_inst != traj_inst) return true;
     const size_t S = e->block_frames;
     size_t taken = 0;
     for (size_t b = b0; b < b1; ++b) {
@@ -3237,7 +3270,7 @@ static bool ra_settle(vmd_script_eval_t* e, const vmd_system_t* sys, vmd_traject
     std::lock_guard<std::mutex> lock(e->mtx);
     HIP_OK(hipSetDevice(e->device));
     const size_t S = e->block_frames;
-    if (full) ra.marks_pending.store(false, std::memory_order_release);    // before the scan: whoever marks after this point sets it again
+    if (full) (void)ra.marks_pending.exchange(false, std::memory_order_seq_cst);    // before the scan: whoever marks after this point sets it again (ra_fast)
     std::vector<std::pair<uint32_t, uint32_t>> runs;          // frames to evaluate directly
     bool tainted = false;
     for (size_t b = 0; b < e->num_blocks; ++b) {
@@ -3246,14 +3279,14 @@ static bool ra_settle(vmd_script_eval_t* e, const vmd_system_t* sys, vmd_traject
         const size_t f0 = b * S, f1 = std::min(f0 + S, e->num_frames);
         if (st == vmd_script_eval_t::RA_READY) {
             size_t req = 0;
-            for (size_t f = f0; f < f1; ++f) req += ra.req(f).load(std::memory_order_acquire) ? 1 : 0;
+            for (size_t f = f0; f < f1; ++f) req += ra.req(f).load(std::memory_order_seq_cst) ? 1 : 0;     // seq_cst: ordered after the exchange of marks_pending above
             if (req == f1 - f0) { if (!ra_commit_block(e, b)) return false; continue; }
             if (req == 0 || !full) continue;
             ra.blk_state[b].store(vmd_script_eval_t::RA_DIRECT, std::memory_order_release);       // partly requested: its frames are evaluated one by one from now on
             tainted = true;
         }
         for (size_t f = f0; f < f1; ++f) {
-            if (!ra.req(f).load(std::memory_order_acquire) || e->frame_mask[f]) continue;
+            if (!ra.req(f).load(std::memory_order_seq_cst) || e->frame_mask[f]) continue;
             if (!runs.empty() && runs.back().second == f) runs.back().second = (uint32_t)f + 1;
             else runs.push_back({(uint32_t)f, (uint32_t)f + 1});
         }
@@ -3281,9 +3314,12 @@ static bool ra_fast(vmd_script_eval_t* e, uint32_t beg, uint32_t end) {
         if (st != vmd_script_eval_t::RA_READY && st != vmd_script_eval_t::RA_DIRECT) return false;
     }
     for (uint32_t f = beg; f < end; ++f) if (ra.req(f).load(std::memory_order_relaxed)) return false;      // asked for twice: the slow path sorts that out
-    // the flag before the marks: a settle that clears it and then misses a mark leaves it set for the next one
-    if (!ra.marks_pending.load(std::memory_order_relaxed)) ra.marks_pending.store(true, std::memory_order_release);
-    for (uint32_t f = beg; f < end; ++f) { uint8_t z = 0; (void)ra.req(f).compare_exchange_strong(z, 1, std::memory_order_acq_rel); }   // a lost race = another call for the same frame owns it
+    // the marks FIRST, then the flag, both sequentially consistent (the other order lost marks - B sees or sets the flag, the
+    // settling A clears it and scans B's block before B's CAS lands, B marks, and B's ra_leave finds the flag clear: requested frames that
+    // nobody commits).  A settle clears the flag with a seq_cst exchange and scans after it: a mark that the scan misses is followed by a
+    // store of the flag that the exchange did not clear, so the marker's own ra_leave (or a later caller's) settles again.
+    for (uint32_t f = beg; f < end; ++f) { uint8_t z = 0; (void)ra.req(f).compare_exchange_strong(z, 1, std::memory_order_seq_cst); }   // a lost race = another call for the same frame owns it
+    ra.marks_pending.store(true, std::memory_order_seq_cst);
     return true;
 }
 
@@ -3344,7 +3380,7 @@ static bool cv_wait_us(std::condition_variable& cv, std::unique_lock<std::mutex>
 static bool ra_call(vmd_script_eval_t* e, const vmd_system_t* sys, vmd_trajectory_i* traj, uint32_t beg, uint32_t end) {
     ReadAhead& ra = e->ra;
     const bool small = (int)(end - beg) <= g_opt.readahead_small.load();
-    if (small && !ra.disabled && ra.on.load(std::memory_order_acquire) && ra.concurrent.load(std::memory_order_relaxed) && ra.traj_inst == traj->inst && ra_fast(e, beg, end)) return true;
+    if (small && !ra.disabled && ra.on.load(std::memory_order_acquire) && ra.concurrent.load(std::memory_order_relaxed) && ra.traj_inst == traj_id(traj) && ra_fast(e, beg, end)) return true;
     std::unique_lock<std::mutex> ql(e->queue_mtx);
     if ((uint32_t)ra.flight.load() >= 2 && !ra.concurrent) { ra.concurrent = true; e->queue_cv.notify_all(); }
     if (small && !ra.disabled) {
@@ -3359,7 +3395,7 @@ static bool ra_call(vmd_script_eval_t* e, const vmd_system_t* sys, vmd_trajector
             if (!ra.on.load() && !ra_engage(e, traj)) return false;
         }
     }
-    if (!(small && !ra.disabled && ra.concurrent && ra.on.load() && ra.traj_inst == traj->inst)) {
+    if (!(small && !ra.disabled && ra.concurrent && ra.on.load() && ra.traj_inst == traj_id(traj))) {
         ql.unlock();
         return ra_direct_call(e, sys, traj, beg, end);
     }
@@ -3403,7 +3439,7 @@ static bool ra_call(vmd_script_eval_t* e, const vmd_system_t* sys, vmd_trajector
                 g_last_error.clear();
                 std::lock_guard<std::mutex> lock(e->mtx);
                 std::vector<char> adopted;
-                ok = hipSetDevice(e->device) == hipSuccess && ra_adopt_blocks(e, need, e1, &adopted);
+                ok = hipSetDevice(e->device) == hipSuccess && ra_adopt_blocks(e, traj_id(traj), need, e1, &adopted);
                 for (size_t b = need; b < e1 && ok;) {           // what the source could not supply: evaluated, in runs of blocks
                     if (adopted[b - need]) { ++b; continue; }
                     size_t r1 = b;
@@ -3428,14 +3464,14 @@ static bool ra_call(vmd_script_eval_t* e, const vmd_system_t* sys, vmd_trajector
     // every block is evaluated (READY), direct or already committed: mark what can be marked, evaluate the rest now (frames asked for
     // twice - the combining queue counts them twice, as it always has)
     std::vector<std::pair<uint32_t, uint32_t>> again;
-    ra.marks_pending.store(true, std::memory_order_release);
     for (uint32_t f = beg; f < end; ++f) {
         uint8_t z = 0;
         const bool committed = ra.blk_state[f / S].load(std::memory_order_acquire) == vmd_script_eval_t::RA_COMMITTED;
-        if (!committed && ra.req(f).compare_exchange_strong(z, 1, std::memory_order_acq_rel)) continue;
+        if (!committed && ra.req(f).compare_exchange_strong(z, 1, std::memory_order_seq_cst)) continue;
         if (!again.empty() && again.back().second == f) again.back().second = f + 1;
         else again.push_back({f, f + 1});
     }
+    ra.marks_pending.store(true, std::memory_order_seq_cst);      // after the marks, as in ra_fast
     for (auto& r : again) if (!combine_call(e, sys, traj, r.first, r.second)) return false;
     return true;
 }
