@@ -360,6 +360,10 @@ size_t vmd_eval_accum_views(vmd_script_eval_t* eval, vmd_accum_view_t* out, size
 bool   vmd_eval_refresh_counts(vmd_script_eval_t* eval, const char* name);
 /* re-derive values/weights/aggregates from the accumulators (after an external reduce) */
 bool   vmd_eval_finalize(vmd_script_eval_t* eval);
+/* A rank of a multi-GPU evaluation: do not materialise the float view of a VOLUME after every frame_range (8.4 MB over PCIe per call, for a
+ * partial result nobody reads) - vmd_eval_finalize / vmd_eval_reduce derive it once, from the merged counts.  Distribution and temporal views
+ * (a few KB) are kept current as ever.  Off by default: VIAMD reads `values` of a running evaluation (src/main.cpp:1508-1524). */
+bool   vmd_eval_defer_volume_views(vmd_script_eval_t* eval, bool defer);
 /* mark frames as evaluated elsewhere (after a mask all-reduce) */
 void   vmd_eval_set_frame_mask(vmd_script_eval_t* eval, const uint8_t* mask, size_t n);
 

@@ -28,6 +28,9 @@ def _worker(rank, world, port, tmpdir, mode="host", on_gpu=False):
         # the maxima travel in the packed all-reduce FIRST and decide (here: forced, on a system of test size)
         os.environ["VIAMD_AMD_REDUCE_MEASURE"] = "1"
         mode = mode[: -len("+measure")]
+    defer = mode.endswith("+defer")
+    if defer:
+        mode = mode[: -len("+defer")]
     if on_gpu:
         # real device memory, real kernels, every process on GPU 0; the merge's all-reduces are staged through host memory (gloo)
         # because RCCL refuses two ranks on one device.  torch first: its HIP runtime must be the one that finds the GPU (conftest.gpu_lib)
@@ -50,6 +53,8 @@ def _worker(rank, world, port, tmpdir, mode="host", on_gpu=False):
     ir.add_distance("d", structures[0], structures[1], L.DIST_COM)
     ir.add_distance("dp", structures[0][:2], structures[2][:3], L.DIST_PAIR)
     ev = V.ScriptEval(F, ir)
+    if defer:
+        ev.defer_volume_views(True)          # what bench.py does at N > 1: a rank's partial volume gets no float view of its own
     vcell = V.make_unitcell(36.0)
     beg, end = shard_frames(F, rank, world)
     F = 11 if mode == "shard_pool" else 5
@@ -94,7 +99,13 @@ def _worker(rank, world, port, tmpdir, mode="host", on_gpu=False):
     else:
         assert ev.frame_range(V.MolSystem(N, mass=mass, unitcell=vcell), traj, beg, end)
     assert ev.frames_done() == end - beg
+    if defer:
+        # nothing travelled for the volume, everything else is current
+        assert not ev.property_data("v").values.any() and (end == beg or ev.property_data("goo").values.sum() > 0)
     reduce_eval(ev)
+    if defer:
+        pv = ev.property_data("v")
+        assert pv.values.sum() > 0 and np.array_equal(pv.values, pv.counts.astype(np.float32)) and pv.max_value == pv.values.max()
     from viamd_amd.dist import reduce_stats
     st = reduce_stats(ev)
     if os.environ.get("VIAMD_AMD_REDUCE_MEASURE") == "1":
@@ -120,14 +131,14 @@ def test_shard_frames_covers_everything():
 import pytest
 
 
-@pytest.mark.parametrize("mode,world", [("host", 2), ("shard", 2), ("host", 4), ("shard", 4), ("shard_pool", 2), ("shard+measure", 2), ("host+measure", 3)])
+@pytest.mark.parametrize("mode,world", [("host", 2), ("shard", 2), ("host", 4), ("shard", 4), ("shard_pool", 2), ("shard+measure", 2), ("host+measure", 3), ("shard+defer", 2)])
 def test_two_rank_gloo_merge_matches_oracle(oracle, emu_lib, tmp_path, mode, world):
     """every rank evaluates its block of frames, ONE vmd_eval_reduce (C++, behind the ABI) merges; `shard`: each rank holds
     only its block of a device trajectory; 4 ranks on 5 frames: blocks of 2, 2, 1 and an EMPTY block (a rank without frames still
     takes part in the merge)"""
     import cases
     from viamd_amd import _lib as L
-    port = 29500 + (os.getpid() % 2000) + (7 if mode.startswith("shard") else 0) + (11 if mode == "shard_pool" else 0) + (17 if mode.endswith("measure") else 0) + 13 * (world - 2)
+    port = 29500 + (os.getpid() % 2000) + (7 if mode.startswith("shard") else 0) + (11 if mode == "shard_pool" else 0) + (17 if mode.endswith("measure") else 0) + (23 if mode.endswith("defer") else 0) + 13 * (world - 2)
     # ("shard", 4): rank 3 owns no frame; its device view must refuse every range (ADVICE r02: it used to read as "unsharded")
     mp.spawn(_worker, args=(world, port, str(tmp_path), mode), nprocs=world, join=True)
     F = 11 if mode == "shard_pool" else 5

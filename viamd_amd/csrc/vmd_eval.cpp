@@ -1069,6 +1069,7 @@ struct vmd_script_eval_t {
     // the trajectory instance this eval's block partials were evaluated from: a user of this eval as a SOURCE takes blocks only while it is
     // itself evaluating the same instance (two evals of one script over different trajectories of equal length must not trade blocks)
     TrajId blocks_inst;
+    std::atomic<bool> defer_volume_views{false};   // vmd_eval_defer_volume_views
     std::atomic<size_t> frames_computed{0}, frames_reused{0}, frames_device_decoded{0};
     // ---- read-ahead.  Block states move NONE -> PENDING -> READY under queue_mtx (the region leader), READY -> COMMITTED /
     // DIRECT and NONE -> DIRECT under queue_mtx + mtx (settle / the direct path); the fast path of a call only READS a state and sets
@@ -1533,6 +1534,12 @@ static void refresh_temporal_stats(vmd_script_eval_t* e, PropState* p) {
     pub(p->data.min_range[0], lo); pub(p->data.max_range[0], hi);
     pub_touch(p->data.fingerprint);
     p->dirty = false;
+}
+
+extern "C" bool vmd_eval_defer_volume_views(vmd_script_eval_t* eval, bool defer) {
+    if (!eval) return vmd_fail("eval is NULL");
+    eval->defer_volume_views.store(defer, std::memory_order_relaxed);
+    return true;
 }
 
 extern "C" bool vmd_eval_finalize(vmd_script_eval_t* eval) {
@@ -2985,7 +2992,13 @@ static bool refresh_views_locked(vmd_script_eval_t* e) {
     for (auto& p : e->props) {
         if (!p->dirty) continue;
         if (p->prop.kind == PROP_RDF) { if (!refresh_distribution(e, p.get())) return false; }
-        else if (p->prop.kind == PROP_SDF) { if (!refresh_volume(e, p.get())) return false; }
+        else if (p->prop.kind == PROP_SDF) {
+            // vmd_eval_defer_volume_views: a rank of a multi-GPU evaluation does not materialise ITS partial volume's float view (8.4 MB over
+            // PCIe after every range) - the merge re-derives the view of the merged counts (vmd_eval_reduce -> vmd_eval_finalize); the volume
+            // stays dirty until then
+            if (e->defer_volume_views.load(std::memory_order_relaxed)) continue;
+            if (!refresh_volume(e, p.get())) return false;
+        }
         else refresh_temporal_stats(e, p.get());
     }
     e->views_at = std::chrono::steady_clock::now();

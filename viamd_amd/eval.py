@@ -328,6 +328,11 @@ class ScriptEval:
         m = np.ascontiguousarray(mask, dtype=np.uint8)
         self.lib.vmd_eval_set_frame_mask(self.h, m.ctypes.data_as(L.c_uint8_p), m.size)
 
+    def defer_volume_views(self, defer=True):
+        """a rank of a multi-GPU evaluation: the float view of a volume is derived once, by finalize() / the merge, not after every range"""
+        if not self.lib.vmd_eval_defer_volume_views(self.h, bool(defer)):
+            raise VmdError(self.lib.last_error())
+
     def finalize(self):
         if not self.lib.vmd_eval_finalize(self.h):
             raise VmdError(self.lib.last_error())
