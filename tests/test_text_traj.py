@@ -95,6 +95,57 @@ def test_xyz_and_extended_xyz(tmp_path, host_lib):
         V.TextTrajectory(r, lib=host_lib).load_frame(0)
 
 
+def test_tinker_arc(tmp_path, host_lib):
+    """a Tinker archive has NO comment line and its atom lines start with an index (`idx sym x y z type bonds...`); a periodic
+    one carries a box line (a b c alpha beta gamma) after the count.  Both flavours, a Tinker-format .xyz, a file that changes flavour half
+    way, and counts that must be refused before they are cast."""
+    F, n = 4, 7
+    coords = _coords(F, n, seed=9, scale=15.0)
+    sym = ["O", "H", "H", "C", "N", "Cl", "Na+"]
+
+    def write(path, box, first_title="water box"):
+        with open(path, "w") as f:
+            for m in range(F):
+                f.write(f"{n:6d}  {first_title if m == 0 else ''}\n")
+                if box:
+                    f.write(f"{30.0 + m:12.6f}{31.0:12.6f}{32.0:12.6f}{90.0:12.6f}{90.0:12.6f}{90.0 if box == 'ortho' else 75.0:12.6f}\n")
+                for k in range(n):
+                    x, y, z = (float(v) for v in coords[m, :, k])
+                    f.write(f"{k + 1:6d}  {sym[k]:3s}{x:12.6f}{y:12.6f}{z:12.6f}{1 + k % 3:6d}{(k % n) + 1:6d}{((k + 1) % n) + 1:6d}\n")
+
+    want = np.asarray([[[np.float32(f"{float(coords[m, a, k]):.6f}") for k in range(n)] for a in range(3)] for m in range(F)], np.float32)
+    for name, box in (("plain.arc", None), ("ortho.arc", "ortho"), ("tri.arc", "tri"), ("tinker.xyz", "ortho")):
+        p = tmp_path / name
+        write(p, box)
+        t = V.TextTrajectory(p, lib=host_lib)
+        assert (t.num_frames(), t.num_atoms()) == (F, n), name
+        np.testing.assert_array_equal(_frames(t), want, err_msg=name)
+        cell = t.load_frame(2)[1]
+        if box is None:
+            assert cell.flags == 0, name
+        else:
+            assert cell.flags == 7 and cell.x == np.float32(32.0) and cell.z == np.float32(32.0), name
+            assert (cell.xy == 0.0) == (box == "ortho") and (box == "ortho" or abs(cell.xy - 31.0 * np.cos(np.deg2rad(75.0))) < 1e-4), name
+    # a plain XYZ frame after Tinker frames: refused, not misread
+    mixed = tmp_path / "mixed.arc"
+    write(mixed, None)
+    with open(mixed, "a") as f:
+        f.write(f"{n}\ncomment\n" + "".join(f"{sym[k]} 0 0 {k}\n" for k in range(n)))
+    with pytest.raises(V.VmdError, match="layout"):
+        V.TextTrajectory(mixed, lib=host_lib)
+    # counts: not integral, absurd (would overflow the cast), and the same for a LAMMPS dump
+    for bad, pat in (("2.5\nc\nAr 0 0 0\n", "atom count"), ("1e300\nc\nAr 0 0 0\n", "atom count"), ("99999999999\nc\nAr 0 0 0\n", "atom count")):
+        q = tmp_path / "bad.xyz"
+        q.write_text(bad)
+        with pytest.raises(V.VmdError, match=pat):
+            V.TextTrajectory(q, lib=host_lib)
+    for cnt in ("2.5", "1e300"):
+        q = tmp_path / "bad.lammpstrj"
+        q.write_text(f"ITEM: TIMESTEP\n0\nITEM: NUMBER OF ATOMS\n{cnt}\nITEM: BOX BOUNDS pp pp pp\n0 1\n0 1\n0 1\nITEM: ATOMS id x y z\n1 0 0 0\n")
+        with pytest.raises(V.VmdError, match="atom count"):
+            V.TextTrajectory(q, lib=host_lib)
+
+
 def _write_dump(path, coords, ids_per_frame, scaled, tri, steps):
     F, _, n = coords.shape
     with open(path, "w") as f:

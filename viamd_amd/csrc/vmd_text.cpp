@@ -56,6 +56,7 @@ struct TextTraj {
     std::vector<Frame> frames;
     vmd_trajectory_i iface;
     std::string path;
+    bool tinker = false;      // FMT_XYZ, Tinker flavour (.arc / Tinker .xyz): no comment line, atom lines `index symbol x y z type bonds...`
 };
 
 bool fail(const std::string& msg) { vmd_set_last_error(msg.c_str()); return false; }
@@ -245,6 +246,24 @@ bool lattice_cell(const Line& comment, vmd_unitcell_t* out, const std::string& p
     return true;
 }
 
+// a Tinker atom line: `<index> <symbol> x y z <type> [bonded atoms]` - first token an integer, second one not a number
+bool tinker_atom_line(const Line& l, long expect_index) {
+    Line tok[5];
+    if (split(l, tok, 5) < 5) return false;
+    bool ok;
+    const double idx = parse_double(tok[0].b, tok[0].e, &ok);
+    if (!ok || idx != (double)expect_index) return false;
+    (void)parse_double(tok[1].b, tok[1].e, &ok);
+    if (ok) return false;                                         // XYZ's own "element x y z" never has a number in the second column... of an index
+    bool okx, oky, okz;
+    (void)parse_double(tok[2].b, tok[2].e, &okx); (void)parse_double(tok[3].b, tok[3].e, &oky); (void)parse_double(tok[4].b, tok[4].e, &okz);
+    return okx && oky && okz;
+}
+
+// XYZ / XMOL: [natoms] [comment, optionally Lattice="..."] natoms x "element x y z ...".
+// Tinker (.arc archives, Tinker's own .xyz): [natoms title] [optional box line: a b c alpha beta gamma] natoms x
+// "index symbol x y z type bonds..." - there is NO comment line; the flavour is recognised on the first frame by its first atom line
+// (index 1, a symbol, three numbers) and must then hold for every frame.
 bool index_xyz(TextTraj* t) {
     const char* p = t->data;
     const char* end = t->data + t->bytes;
@@ -252,20 +271,40 @@ bool index_xyz(TextTraj* t) {
     while (next_line(p, end, &l)) {
         Line tok[2];
         if (split(l, tok, 2) == 0) continue;                      // blank lines between frames
+        const std::string where = t->path + ": frame " + std::to_string(t->frames.size());
         bool ok;
         const double nd = parse_double(tok[0].b, tok[0].e, &ok);
-        if (!ok || nd < 1 || nd != std::floor(nd)) return fail(t->path + ": frame " + std::to_string(t->frames.size()) + ": the atom count line is not a number");
+        // bounded BEFORE the cast: an atom line has at least two characters, so no frame of this file holds more than bytes / 2 atoms
+        if (!ok || nd < 1 || nd != std::floor(nd) || nd > (double)(t->bytes / 2 + 1)) return fail(where + ": the atom count line is not a number");
         const size_t n = (size_t)nd;
-        Line comment;
-        if (!next_line(p, end, &comment)) return fail(t->path + ": frame " + std::to_string(t->frames.size()) + " ends after its atom count");
         Frame f;
-        if (!lattice_cell(comment, &f.cell, t->path)) return false;
+        f.cell = no_cell();
+        const char* after_count = p;
+        Line second;
+        if (!next_line(p, end, &second)) return fail(where + " ends after its atom count");
+        bool tinker = false;
+        if (tinker_atom_line(second, 1)) { tinker = true; p = after_count; }                  // no comment line at all
+        else {
+            Line b6[7];
+            Line third;
+            const char* after_second = p;
+            if (split(second, b6, 7) == 6 && next_line(p, end, &third) && tinker_atom_line(third, 1)) {
+                double v[6];
+                bool okb = true;
+                for (int i = 0; i < 6 && okb; ++i) v[i] = parse_double(b6[i].b, b6[i].e, &okb);
+                if (okb && v[0] > 0 && v[1] > 0 && v[2] > 0) { tinker = true; f.cell = cell_from_parameters(v[0], v[1], v[2], v[3], v[4], v[5]); }
+            }
+            p = after_second;
+        }
+        if (t->frames.empty()) t->tinker = tinker;
+        else if (tinker != t->tinker) return fail(where + ": atom lines change their layout inside the file (Tinker `index symbol x y z` / plain `symbol x y z`)");
+        if (!tinker && !lattice_cell(second, &f.cell, t->path)) return false;
         f.beg = (size_t)(p - t->data);
-        for (size_t i = 0; i < n; ++i) if (!next_line(p, end, &l)) return fail(t->path + ": frame " + std::to_string(t->frames.size()) + ": atom line " + std::to_string(i) + " is missing");
+        for (size_t i = 0; i < n; ++i) if (!next_line(p, end, &l)) return fail(where + ": atom line " + std::to_string(i) + " is missing");
         f.end = (size_t)(p - t->data);
         f.timestamp = (double)t->frames.size();
         if (t->frames.empty()) t->num_atoms = n;
-        else if (n != t->num_atoms) return fail(t->path + ": frame " + std::to_string(t->frames.size()) + " has " + std::to_string(n) + " atoms, the first frame " + std::to_string(t->num_atoms));
+        else if (n != t->num_atoms) return fail(where + " has " + std::to_string(n) + " atoms, the first frame " + std::to_string(t->num_atoms));
         t->frames.push_back(f);
     }
     return true;
@@ -274,11 +313,12 @@ bool index_xyz(TextTraj* t) {
 bool load_xyz(const TextTraj* t, const Frame& f, float* x, float* y, float* z) {
     const char* p = t->data + f.beg;
     const char* end = t->data + f.end;
-    Line l, tok[4];
+    Line l, tok[5];
+    const int c0 = t->tinker ? 2 : 1;                              // first coordinate column
     for (size_t i = 0; i < t->num_atoms; ++i) {
-        if (!next_line(p, end, &l) || split(l, tok, 4) < 4) return fail(t->path + ": atom line " + std::to_string(i) + " is incomplete");
+        if (!next_line(p, end, &l) || split(l, tok, 5) < c0 + 3) return fail(t->path + ": atom line " + std::to_string(i) + " is incomplete");
         bool okx, oky, okz;
-        const float vx = (float)parse_double(tok[1].b, tok[1].e, &okx), vy = (float)parse_double(tok[2].b, tok[2].e, &oky), vz = (float)parse_double(tok[3].b, tok[3].e, &okz);
+        const float vx = (float)parse_double(tok[c0].b, tok[c0].e, &okx), vy = (float)parse_double(tok[c0 + 1].b, tok[c0 + 1].e, &oky), vz = (float)parse_double(tok[c0 + 2].b, tok[c0 + 2].e, &okz);
         if (!okx || !oky || !okz) return fail(t->path + ": unreadable coordinate in atom line " + std::to_string(i));
         if (x) x[i] = vx;
         if (y) y[i] = vy;
@@ -302,7 +342,7 @@ bool index_lammps(TextTraj* t) {
         if (!ok) return fail(where + ": unreadable time step");
         if (!next_line(p, end, &l) || !starts(l, "ITEM: NUMBER OF ATOMS") || !next_line(p, end, &l)) return fail(where + ": ITEM: NUMBER OF ATOMS expected");
         const double nd = parse_double(l.b, l.e, &ok);
-        if (!ok || nd < 1) return fail(where + ": unreadable atom count");
+        if (!ok || nd < 1 || nd != std::floor(nd) || nd > (double)(t->bytes / 2 + 1)) return fail(where + ": unreadable atom count");     // integral, and bounded before the cast
         const size_t n = (size_t)nd;
         if (!next_line(p, end, &l) || !starts(l, "ITEM: BOX BOUNDS")) return fail(where + ": ITEM: BOX BOUNDS expected");
         int nt = split(l, tok, 64);
