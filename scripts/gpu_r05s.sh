@@ -1,0 +1,39 @@
+#!/bin/bash
+# round 5 evidence call on the FINAL tree: the whole -m gpu suite, smoke, PMC passes at the bench's own frames per step (they run BEFORE the
+# default line, so that the line replays counters of the kernel source it runs), the driver-style default line, rocprofv3 kernel stats of the
+# same command, VIAMD's call pattern from C++ pool threads, the 2-rank line on one shared GPU
+T=${1:-r05s}; R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/$T; mkdir -p $O
+export HSA_ENABLE_IPC_MODE_LEGACY=0 TMPDIR=/tmp
+cd $R
+{ rocm-smi --showproductname 2>/dev/null | head -8; nproc; lscpu | grep -E "Model name|^CPU\(s\)|Thread|Core|Socket"; } > $O/device.txt
+timeout 900 python -m pytest tests -m gpu -x -q -p no:cacheprovider > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -4 $O/pytest_gpu.log | cut -c1-250
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?"; tail -1 $O/smoke.log
+for w in c3 c2 c4 c5; do
+  extra="--workload $w"; [ $w = c3 ] && extra="--no-secondary"
+  bash $R/scripts/gpu_pmc.sh ${T}_pmc_$w $extra > $O/pmc_$w.log 2>&1
+  fps=1000; [ $w = c4 ] && fps=10000
+  # steps in the profiled run: --steps 1 --warmup 1 = 2; frames per step = the workload's own
+  python $R/scripts/pmc_traffic.py $R/gpurun_out/${T}_pmc_$w $w $fps $O/pmc_traffic.json 2 $fps > /dev/null
+  cp $R/gpurun_out/${T}_pmc_$w/summary.txt $O/pmc_summary_$w.txt 2>/dev/null
+  rm -rf $R/gpurun_out/${T}_pmc_$w
+done
+cp $O/pmc_traffic.json $R/profiles/pmc_traffic.json
+timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_default.json 2> $O/bench_default.err; echo "bench rc=$?"
+cd /tmp
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_c3 -o c3 -- python $R/bench.py --no-cpu-baseline --no-secondary --steps 5 --warmup 2 > $O/prof_c3.log 2>&1
+find $O/prof_c3 -name "*kernel_trace.csv" -delete
+find $O/prof_c3 -name "*agent_info.csv" -delete
+cd $R
+python - <<PY
+import json
+d = json.load(open("$O/bench_default.json"))
+print("c3", round(d["value"]), "frames/s", round(d["ms_per_step"], 2), "ms/step frac", round(d["roofline"]["frac"], 4), "valu", {k: round(v, 3) for k, v in d["roofline"]["valu"].items() if k in ("frac", "busy")}, "cpu", round(d["cpu_baseline"]["value"], 1), "gpu/cpu", round(d["gpu_over_cpu"], 1), "fractions ok", d["fractions_within_0_1"], "counters current", d["roofline"]["traffic_counters_match_kernel_source"])
+for k, v in d.get("secondary", {}).items(): print(k, round(v["value"]), round(v["ms_per_step"], 3), {a: (round(b["frac"], 4), round(b["step_level"]["frac"], 4)) for a, b in v.items() if a == "roofline"}, v.get("strong_scaling_bound_8_gpus"))
+PY
+g++ -std=c++17 -O2 tests/native/exp_threads.cpp -Iinclude viamd_amd/libviamd_amd.so -Wl,-rpath,$R/viamd_amd -L/opt/rocm/lib -Wl,-rpath,/opt/rocm/lib -Wl,-rpath-link,/opt/rocm/lib -lpthread -o /tmp/exp_threads && { /tmp/exp_threads 100002 1000; VMD_SDF=1 /tmp/exp_threads 100002 10000; } > $O/readahead_call_pattern.txt 2>&1; cat $O/readahead_call_pattern.txt | cut -c1-400
+VIAMD_BENCH_SHARE_GPU=1 timeout 900 python3 bench.py --gpus 2 --steps 3 --warmup 1 2> $O/bench_share2.err | grep "^{" > $O/bench_share2.json; echo "share2 rc=$?"
+python - <<PY
+import json
+d = json.load(open("$O/bench_share2.json")); print("share2: n_gpus", d["n_gpus"], "ranks", d.get("ranks"), round(d["value"]), "frames/s", d["config"]["parallelism"][:60])
+PY
+du -sh $R/gpurun_out/$T

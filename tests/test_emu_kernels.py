@@ -114,6 +114,32 @@ def test_rdf_split_pencils(emu_lib, oracle, box3k, sy, sz):
         emu_lib.vmd_set_option(b"pencil_split_y", oy); emu_lib.vmd_set_option(b"pencil_split_z", oz)
 
 
+def test_dense_lane_selections_walk_half_width_pencils_by_default(emu_lib, oracle):
+    """Round 5: with `pencil_split_y` at its default (0 = by density) a group whose passes all put >= 0.08 atoms / A^3 in the lanes - every
+    atom of a liquid, SURVEY 8d's C3-dense - is walked on half-width pencils in y; sparser scripts keep the r_max pencils.  Either way the
+    oracle's integers; which grid was walked shows in the candidate-column count."""
+    assert emu_lib.vmd_set_option(b"pencil_split_y", 0) == 0          # the default
+    c = cases.water_box(oracle, 17, 3000, 30.0, 2)                      # 3 000 atoms in 27 000 A^3: 0.11 / A^3
+    everything = np.arange(3000, dtype=np.int32)
+
+    def columns(split, props):
+        old = emu_lib.vmd_set_option(b"pencil_split_y", split)
+        try:
+            emu_lib.vmd_hip_rdf_columns(1)
+            cases.check_rdf(emu_lib, oracle, c, 30.0, props)
+            return int(emu_lib.vmd_hip_rdf_columns(1))
+        finally:
+            emu_lib.vmd_set_option(b"pencil_split_y", old)
+
+    dense = [("gaa", everything, everything, 0.0, 7.0)]
+    auto, fixed1, fixed2 = columns(0, dense), columns(1, dense), columns(2, dense)
+    assert auto == fixed2 and fixed2 != fixed1, (auto, fixed1, fixed2)       # (which of the two walks fewer columns depends on the size: 5 % fewer for 10^6 atoms on the MI355X)
+    sparse = [("goo", cases.oxygen(3000), cases.oxygen(3000), 0.0, 7.0)]       # 0.037 / A^3 in the lanes
+    assert columns(0, sparse) == columns(1, sparse)
+    mixed = dense + [("goh", cases.oxygen(3000), cases.hydrogen(3000), 0.0, 7.0)]   # one sparse pass in the group keeps the r_max pencils for all
+    assert columns(0, mixed) == columns(1, mixed)
+
+
 def test_rdf_two_pencils_per_axis(emu_lib, oracle):
     # L = 26, rc = 12 -> ny = nz = 2: both neighbour offsets map to the same pencil with different images
     c = cases.water_box(oracle, 11, 1500, 26.0, 2)

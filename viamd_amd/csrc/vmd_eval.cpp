@@ -81,7 +81,11 @@ struct Options {
     std::atomic<int> batch_frames{0};    // 0 = auto
     std::atomic<int> force_brute{0};
     std::atomic<int> load_threads{0};    // host threads decoding one staged batch through load_frame; 0 = auto (see load_threads())
-    std::atomic<int> pencil_split_y{1}, pencil_split_z{1};   // A/B: pencils of cross-section rmax/split (walk reach = split); 1 x 1 measured best (profiles/r02m_ab_tile_shape.txt)
+    // pencils of cross-section rmax/split (walk reach = split).  z: explicit (A/B).  y: 0 = by density - selections of >= 0.08 atoms / A^3 in the
+    // lanes of every pass of a group (all heavy atoms of a liquid; SURVEY 8d's C3-dense) walk half-width pencils in y: a 64-atom chunk of such
+    // a selection is only ~4 A long, so the x windows are dominated by the 2 r_max of padding and thinner pencils pay (c3d 2 028 -> 2 131
+    // frames/s, profiles/r05d_pencil_split_by_density.txt; at c3's 0.033 / A^3 the same split costs 10 %, at c5's mix 6 %); 1 / 2 / .. = fixed
+    std::atomic<int> pencil_split_y{0}, pencil_split_z{1};
     std::atomic<int> nxf_divisor{16};    // fine x cell = rmax / nxf_divisor (8 / 12 / 16 / 24 / 32 measured: 16 is +0.8 % on c3, profiles/r02l_ab_fine_cells.txt)
     std::atomic<int> cells_aos{1};       // sort through 16-byte records + repack
     std::atomic<int> xtc_device_decode{3};   // frames offered raw (load_raw) are decompressed on the device (0 = on the host threads): 1 = one thread per
@@ -2250,7 +2254,7 @@ static bool prepare_open_boxes(vmd_script_eval_t* e, Stage& st, size_t nb, uint3
 
 // pencil grid for a batch and cutoff; false when the batch cannot use the grid kernel.  `boxes` = st.h_boxes, or
 // st.h_gboxes when some axes are open (pbc bits clear): those carry the bounding-box extent instead of a cell edge.
-static bool choose_grid(const std::vector<float>& boxes, uint32_t pbc, size_t nb, float rmax, vmd_grid_t* g) {
+static bool choose_grid(const std::vector<float>& boxes, uint32_t pbc, size_t nb, float rmax, vmd_grid_t* g, bool dense_lanes = false) {
     if (g_opt.force_brute) return false;
     const bool tri = (pbc & 8u) != 0;
     if (tri && (pbc & VMD_UNITCELL_PBC_ALL) != VMD_UNITCELL_PBC_ALL) return false;
@@ -2269,7 +2273,8 @@ static bool choose_grid(const std::vector<float>& boxes, uint32_t pbc, size_t nb
     // periodic axes: the minimum image must be unique for every hit (rmax < w/2 with margin); open axes: no restriction
     for (int a = 0; a < 3; ++a) if ((pbc & (1u << a)) && !(rmax * 2.0f * 1.001f < wmin[a])) return false;
     int n[3];
-    const int split[3] = {1, std::max(1, std::min(4, g_opt.pencil_split_y.load())), std::max(1, std::min(4, g_opt.pencil_split_z.load()))};
+    const int sy = g_opt.pencil_split_y.load();
+    const int split[3] = {1, sy <= 0 ? (dense_lanes ? 2 : 1) : std::min(4, sy), std::max(1, std::min(4, g_opt.pencil_split_z.load()))};
     vmd_hip_set_pencil_reach(split[1], split[2]);
     for (int a = 1; a < 3; ++a) {
         const float redge = rmax / (float)split[a];
@@ -2702,7 +2707,17 @@ static bool process_range_locked(vmd_script_eval_t* eval, const vmd_system_t* sy
             if (open_axes && !g_opt.force_brute && !prepare_open_boxes(e, *c.src, c.nb, c.pbc, num_atoms)) return false;
             const std::vector<float>& gb = (open_axes && c.src->gboxes_ready) ? c.src->h_gboxes : c.src->h_boxes;
             const float* d_gb = (open_axes && c.src->gboxes_ready) ? c.src->d_gboxes.p : c.src->d_boxes.p;
-            if (e->spec.rdf_raw || !choose_grid(gb, c.pbc, c.nb, g.rmax, &grid)) {
+            // density of the sparsest selection any pass of this group puts in the lanes (the denser of its two), against the first frame's cell
+            bool dense_lanes = !open_axes && !g.passes.empty();
+            if (dense_lanes) {
+                const float* q = gb.data();
+                const double vol = (double)q[0] * q[1] * q[2];
+                for (auto& ps : g.passes) {
+                    const size_t lanes = std::max(e->sels[ps.sel_a]->idx.size(), e->sels[ps.sel_b]->idx.size());
+                    dense_lanes = dense_lanes && vol > 0.0 && (double)lanes / vol >= 0.08;
+                }
+            }
+            if (e->spec.rdf_raw || !choose_grid(gb, c.pbc, c.nb, g.rmax, &grid, dense_lanes)) {
                 // no grid for this batch (cutoff >= half the cell width, ...): all pairs, per property
                 for (int pi : g.props) {
                     PropState* p = e->props[pi].get();
