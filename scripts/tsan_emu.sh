@@ -16,6 +16,7 @@ build() {   # src exe [extra include]
 build tests/native/stress_readahead.cpp $OUT/stress_ra
 build tests/native/stress_eval.cpp $OUT/stress_eval
 build tests/native/shim_callsites.cpp $OUT/shim_callsites $R/tests/native
+build tests/native/shim_default_script.cpp $OUT/shim_default_script $R/tests/native
 build tests/native/exp_threads.cpp $OUT/exp_threads
 build tests/native/reduce_threads.cpp $OUT/reduce_threads
 build tests/native/concurrent_evals.cpp $OUT/concurrent_evals
@@ -32,6 +33,7 @@ run() {   # name args...
 run reduce_threads $OUT/reduce_threads 3 12 600
 run concurrent_evals $OUT/concurrent_evals 2 10 600 $OUT
 run shim_callsites $OUT/shim_callsites 12
+run shim_default_script $OUT/shim_default_script 12
 run stress_eval $OUT/stress_eval 2 6
 run exp_threads_rdf $OUT/exp_threads ${TSAN_EXP_ARGS:-900 64}
 run stress_ra_sdf $OUT/stress_ra 3 16 600 9 sdf
