@@ -360,6 +360,15 @@ size_t vmd_eval_accum_views(vmd_script_eval_t* eval, vmd_accum_view_t* out, size
 bool   vmd_eval_refresh_counts(vmd_script_eval_t* eval, const char* name);
 /* re-derive values/weights/aggregates from the accumulators (after an external reduce) */
 bool   vmd_eval_finalize(vmd_script_eval_t* eval);
+/* Deferred-settle mode (vmd_set_option("readahead_lone", 1); off by default).  mdlib's contract - and this library's default - is that
+ * results are final when the last md_script_eval_frame_range call returns; since no call knows it is the last, a host that walks a range
+ * frame by frame from ONE thread pays a full small evaluation per call (~0.25 ms).  With the option on, small calls are served by read-ahead
+ * whoever makes them (evaluated ahead in regions, marked, committed by block) and the final settle - committing what was requested, the
+ * ragged ends, the host views - runs on a helper thread once the eval has been quiet for readahead_lone_settle_us (300): results trail the
+ * last call by that much, which a polling reader (VIAMD's GUI, src/main.cpp:1508-1524) does not notice.  vmd_eval_wait_settled performs
+ * that settle at once on the calling thread (vmd_eval_finalize, vmd_eval_reduce and the exporters call it); `sys` and the trajectory of
+ * the calls must stay valid until it has returned, or until clear_data / free.  A no-op for evals that are not in that mode. */
+bool   vmd_eval_wait_settled(vmd_script_eval_t* eval);
 /* A rank of a multi-GPU evaluation: do not materialise the float view of a VOLUME after every frame_range (8.4 MB over PCIe per call, for a
  * partial result nobody reads) - vmd_eval_finalize / vmd_eval_reduce derive it once, from the merged counts.  Distribution and temporal views
  * (a few KB) are kept current as ever.  Off by default: VIAMD reads `values` of a running evaluation (src/main.cpp:1508-1524). */

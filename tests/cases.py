@@ -1,5 +1,7 @@
 """Shared parity scenarios: the same checks run against the SIMT emulator build (CPU, small sizes, `-m "not gpu"`)
 and against the hipcc-built product library on a real MI355X (`-m gpu`).  The checker is always the oracle."""
+import time
+
 import numpy as np
 
 import viamd_amd as V
@@ -495,6 +497,63 @@ def readahead_case(lib, O, device=False, n_water=600, box=28.0, F=40, nthreads=6
         same(filt, part, "filtered eval adopting the full eval's read-ahead blocks")
         assert filt.frame_stats()[1] >= 16, filt.frame_stats()      # blocks of 4: [8, 28) are whole blocks of the source
         filt.close(); ev.close()
+        # ---- opt-in deferred settle (round 5): ONE caller walking frame by frame is served by read-ahead like a pool, the
+        # final settle runs on the eval's helper thread after a quiet period - or at once in wait_settled / finalize
+        lib.vmd_set_option(b"readahead_lone", 1)
+        try:
+            ev = V.ScriptEval(F, ir)
+            for f in range(F):
+                assert ev.frame_range(sysm, traj, f, f + 1)
+                assert ev.frames_done() <= f + 1                    # never ahead of what was asked for
+            ev.wait_settled()
+            same(ev, full, "lone caller, deferred settle, wait_settled")
+            ev.wait_settled()                                          # nothing owed: a no-op
+            st = ev.readahead_stats()
+            assert st["engaged"] == 1 and st["regions"] >= 2 and st["committed_blocks"] >= F // 4 - 1, st
+            # the same walk again on the same eval, no explicit wait: the helper settles by itself once the caller has been quiet
+            ev.clear_data()
+            for f in range(F):
+                assert ev.frame_range(sysm, traj, f, f + 1)
+            deadline = time.time() + 60.0
+            while True:                                                # commits first, the views at the end of the same settle: poll the whole state
+                try:
+                    same(ev, full, "lone caller, deferred settle, helper thread")
+                    break
+                except AssertionError:
+                    if time.time() > deadline:
+                        raise
+                    time.sleep(0.005)
+            # a sub-range that starts and ends inside blocks; finalize() settles
+            ev.clear_data()
+            for f in range(7, 29):
+                assert ev.frame_range(sysm, traj, f, f + 1)
+            ev.finalize()
+            same(ev, part, "lone caller over [7, 29), finalize")
+            # interrupted half way: whatever was committed is a prefix-free subset; clear_data cancels the owed settle; the rerun is exact
+            ev.clear_data()
+            for f in range(F // 2):
+                assert ev.frame_range(sysm, traj, f, f + 1)
+            ev.interrupt()
+            assert not ev.frame_range(sysm, traj, F // 2, F // 2 + 1)
+            ev.clear_data()
+            for f in range(0, F, 2):                                   # grain 2 this time
+                assert ev.frame_range(sysm, traj, f, min(F, f + 2))
+            ev.wait_settled()
+            same(ev, full, "lone caller after interrupt + clear_data")
+            ev.close()
+            # freed right after the last call returned, the settle still owed: the helper ends with the eval
+            ev = V.ScriptEval(F, ir)
+            for f in range(9):
+                assert ev.frame_range(sysm, traj, f, f + 1)
+            ev.close()
+            # a pool with the option on: the last leaver arms the helper instead of settling
+            ev = V.ScriptEval(F, ir)
+            assert all(pooled(ev, 0, F, 1))
+            ev.wait_settled()
+            same(ev, full, "pool of threads, deferred settle")
+            ev.close()
+        finally:
+            lib.vmd_set_option(b"readahead_lone", 0)
         # ---- block partials that cannot be allocated (a large volume script beside an HBM-resident trajectory) must not fail
         # the evaluation: read-ahead steps aside, the combining queue serves the same calls, the results are the same
         lib.vmd_set_option(b"readahead_fail_alloc", 1)

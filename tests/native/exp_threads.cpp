@@ -119,6 +119,26 @@ int main(int argc, char** argv) {
         for (int r = 0; r < 5; ++r) { auto pr = pooled_enki(16); if (pr.second) { b = std::min(b, pr.first); ++clean; } }
         std::printf(" | 16 threads, enkiTS order (threads x (threads - 1) partitions, owner from the end, thieves from the front; %d of 5 runs identical to the one call): %.2f ms", clean, b);
     }
+    {
+        // the lone caller once more, with the deferred settle switched on (vmd_set_option("readahead_lone", 1)): the time includes
+        // vmd_eval_wait_settled, i.e. it ends when totals and views are final, as the other columns' do
+        vmd_set_option("readahead_lone", 1);
+        double b = 1e30;
+        for (int r = 0; r < 3; ++r) {
+            vmd_eval_clear_data(eval);
+            const double t = now_ms();
+            for (uint32_t f = 0; f < F; ++f) if (!vmd_eval_frame_range(eval, ir, &sys, traj, f, f + 1)) { std::fprintf(stderr, "%s\n", vmd_last_error()); std::exit(1); }
+            const double t_calls = now_ms() - t;
+            if (!vmd_eval_wait_settled(eval)) { std::fprintf(stderr, "%s\n", vmd_last_error()); std::exit(1); }
+            const double ms = now_ms() - t;
+            const vmd_script_property_data_t* pd = vmd_eval_property_data(eval, sdf ? "v" : "g");
+            if (vmd_eval_frames_done(eval) != F || ref_values.size() != pd->num_values || memcmp(ref_values.data(), pd->values, pd->num_values * sizeof(float)) != 0) {
+                std::fprintf(stderr, "lone caller with deferred settle differs from the one call\n"); std::exit(1);
+            }
+            if (ms < b) { b = ms; std::printf(" | 1 thread grain 1, readahead_lone (calls %.2f ms + settle): %.2f ms", t_calls, ms); }
+        }
+        vmd_set_option("readahead_lone", 0);
+    }
     std::printf("\n");
     vmd_readahead_stats_t st;
     vmd_eval_readahead_stats(eval, &st);

@@ -5,9 +5,13 @@
 // frame mask and frames_done.  Python threads (tests/cases.py: readahead_case) take turns on the GIL; these do not.
 // With "sdf" as fifth argument the script also holds an sdf() volume (block partials of 16.8 MB each); every third iteration a second eval with
 // the first as its SOURCE walks a sub-range from the pool (VIAMD's filtered evaluation): its regions adopt the source's finished blocks.
+// Every fourth iteration runs in DEFERRED-SETTLE mode (vmd_set_option("readahead_lone", 1), round 5): half of those with ONE caller thread (the
+// lone sequential walker the mode is for), the settle owed to the eval's helper thread - awaited with vmd_eval_wait_settled, sometimes after a
+// pause in which the helper may have run on its own - and interrupts / clear_data / free racing that thread.
 // usage: stress_readahead [iterations = 60] [frames = 96] [atoms = 1500] [seed = 1] [sdf];  prints "OK iterations=<n> ..." and exits 0.
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -121,8 +125,19 @@ int main(int argc, char** argv) {
 
     uint64_t regions = 0, direct = 0, blocks = 0, settles = 0, adopted = 0;
     vmd_script_eval_t* eval = vmd_eval_create(F, ir);       // reused across iterations like VIAMD reuses an eval across re-evaluations
+    uint64_t lone_iterations = 0;
     for (g_iter = 0; g_iter < iterations; ++g_iter) {
-        const int nthreads = 2 + (int)(rng() % 15);
+        const bool lone = g_iter % 4 == 3;
+        vmd_set_option("readahead_lone", lone ? 1 : 0);
+        vmd_set_option("readahead_lone_settle_us", lone ? (int[]){50, 300, 2000}[rng() % 3] : 300);
+        lone_iterations += lone ? 1 : 0;
+        // deferred mode: what the calls asked for is final after wait_settled (now and then the helper thread gets a head start)
+        auto settled = [&](vmd_script_eval_t* e) {
+            if (!lone) return;
+            if (rng() % 2) std::this_thread::sleep_for(std::chrono::microseconds((int[]){30, 400, 3000}[rng() % 3]));
+            if (!vmd_eval_wait_settled(e)) fail("vmd_eval_wait_settled");
+        };
+        const int nthreads = lone && rng() % 2 ? 1 : 2 + (int)(rng() % 15);
         const uint32_t grain = (uint32_t[]){1, 1, 1, 2, 3, 5}[rng() % 6];
         uint32_t lo = 0, hi = (uint32_t)F;
         if (rng() % 3 == 0) { lo = (uint32_t)(rng() % (F / 2)); hi = lo + 1 + (uint32_t)(rng() % (F - lo)); }
@@ -190,12 +205,14 @@ int main(int argc, char** argv) {
                 vmd_eval_clear_data(side);
                 if (pooled(side, sstarts, grain, shi, 1 + (int)(rng() % 4), -1) != 0) fail("a call of the restarted filtered evaluation failed");
             }
+            settled(side);
             same(snapshot(side, F), reference(slo, shi), "filtered evaluation running beside its source differs from one call over its range");
             size_t computed = 0, reused = 0;
             vmd_eval_frame_stats(side, &computed, &reused);
             adopted += reused;
             vmd_eval_free(side);
         }
+        settled(eval);
         same(snapshot(eval, F), reference(lo, hi), "pooled evaluation differs from one call over the same range");
         if (g_iter % 3 == 2 && hi - lo > 6) {
             // the timeline slider: a second eval over a sub-range, the full one (just evaluated over [lo, hi)) as its source
@@ -206,6 +223,7 @@ int main(int argc, char** argv) {
             for (uint32_t f = flo; f < fhi; f += grain) fstarts.push_back(f);
             if (rng() % 2) std::reverse(fstarts.begin(), fstarts.end());
             if (pooled(filt, fstarts, grain, fhi, nthreads, -1) != 0) fail("a call of the filtered evaluation failed");
+            settled(filt);
             same(snapshot(filt, F), reference(flo, fhi), "filtered evaluation (source = the full eval) differs from one call over its range");
             size_t computed = 0, reused = 0;
             vmd_eval_frame_stats(filt, &computed, &reused);
@@ -216,8 +234,9 @@ int main(int argc, char** argv) {
         vmd_eval_readahead_stats(eval, &st);
         regions = st.regions; direct = st.direct_frames; blocks = st.committed_blocks; settles = st.settles;
     }
+    vmd_set_option("readahead_lone", 0);
     vmd_eval_free(eval); vmd_ir_free(ir); vmd_devtraj_free(dt);
-    std::printf("OK iterations=%d frames=%zu%s (last eval: %llu regions, %llu blocks committed, %llu frames evaluated directly, %llu settles; filtered evals adopted %llu frames from their source)\n",
-                iterations, F, g_sdf ? " +sdf" : "", (unsigned long long)regions, (unsigned long long)blocks, (unsigned long long)direct, (unsigned long long)settles, (unsigned long long)adopted);
+    std::printf("OK iterations=%d (%llu in deferred-settle mode) frames=%zu%s (last eval: %llu regions, %llu blocks committed, %llu frames evaluated directly, %llu settles; filtered evals adopted %llu frames from their source)\n",
+                iterations, (unsigned long long)lone_iterations, F, g_sdf ? " +sdf" : "", (unsigned long long)regions, (unsigned long long)blocks, (unsigned long long)direct, (unsigned long long)settles, (unsigned long long)adopted);
     return 0;
 }

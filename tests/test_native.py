@@ -237,10 +237,10 @@ def test_read_ahead_stress_on_the_emulator(tmp_path, emu_lib):
     exe = _build_against(conftest.build_emu(), RA_STRESS_SRC, str(tmp_path / "stress_ra_emu"), "-O1")
     out = subprocess.run([exe, "8", "40", "900", "7"], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
-    assert out.stdout.startswith("OK iterations=8"), out.stdout
+    assert out.stdout.startswith("OK iterations=8 (2 in deferred-settle mode)"), out.stdout       # every fourth iteration: option readahead_lone, helper-thread settle
     out = subprocess.run([exe, "3", "16", "600", "9", "sdf"], capture_output=True, text=True, timeout=900)      # + an sdf() volume, + a filtered eval with a source
     assert out.returncode == 0, out.stderr[-2000:]
-    assert out.stdout.startswith("OK iterations=3 frames=16 +sdf"), out.stdout
+    assert out.stdout.startswith("OK iterations=3 (0 in deferred-settle mode) frames=16 +sdf"), out.stdout
 
 
 @pytest.mark.gpu
@@ -254,7 +254,7 @@ def test_read_ahead_stress(gpu_lib, tmp_path):
         assert out.stdout.strip().split("\n")[-1].startswith("OK iterations=400"), out.stdout[-500:]
     out = subprocess.run([exe, "150", "240", "30000", "4", "sdf"], capture_output=True, text=True, timeout=900)     # volumes: 16.8 MB block partials, adopted by filtered evals
     assert out.returncode == 0, (out.stdout[-500:], out.stderr[-3000:])
-    assert out.stdout.strip().split("\n")[-1].startswith("OK iterations=150 frames=240 +sdf"), out.stdout[-500:]
+    assert out.stdout.strip().split("\n")[-1].startswith("OK iterations=150 (37 in deferred-settle mode) frames=240 +sdf"), out.stdout[-500:]
 
 REDUCE_THREADS_SRC = os.path.join(ROOT, "tests", "native", "reduce_threads.cpp")
 

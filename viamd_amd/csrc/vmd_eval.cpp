@@ -140,6 +140,12 @@ struct Options {
     std::atomic<int> readahead_linger_us{60};// a call that leaves alone waits this long for another call before it settles the eval (commit + views)
     std::atomic<int> readahead_company_us{80};// the FIRST call of an evaluation waits this long for a second caller before it decides it is alone
     std::atomic<int> readahead_fail_alloc{0}; // test hook: the block partials' allocation "fails" (the eval must fall back to the combining queue)
+    // Opt-in: small calls are served by read-ahead even when they come from ONE thread (a host that walks a range frame by frame), and the
+    // settle a pool's last leaver performs is DEFERRED to a helper thread that runs once the eval has been quiet for readahead_lone_settle_us.
+    // The price is the contract: results then trail the last call by that long (a polling reader like VIAMD's GUI does not notice;
+    // vmd_eval_wait_settled / finalize / reduce / the exporters wait for them), and system + trajectory must stay valid until then.
+    std::atomic<int> readahead_lone{0};
+    std::atomic<int> readahead_lone_settle_us{300};
 };
 static Options g_opt;
 
@@ -207,6 +213,8 @@ extern "C" int vmd_set_option(const char* key, int value) {
     else if (!strcmp(key, "readahead_linger_us")) o = &g_opt.readahead_linger_us;
     else if (!strcmp(key, "readahead_company_us")) o = &g_opt.readahead_company_us;
     else if (!strcmp(key, "readahead_fail_alloc")) o = &g_opt.readahead_fail_alloc;
+    else if (!strcmp(key, "readahead_lone")) o = &g_opt.readahead_lone;
+    else if (!strcmp(key, "readahead_lone_settle_us")) o = &g_opt.readahead_lone_settle_us;
     else if (!strcmp(key, "sdf_arith")) o = &g_opt.sdf_arith;
     else if (!strcmp(key, "sdf_ilp")) return vmd_hip_set_sdf_ilp(value);
     else if (!strcmp(key, "sdf_rows")) return vmd_hip_set_sdf_rows(value);
@@ -1107,6 +1115,18 @@ struct vmd_script_eval_t {
         TrajId traj_inst;                            // the trajectory the regions are evaluated from
         // statistics (vmd_eval_readahead_stats)
         std::atomic<uint64_t> regions{0}, region_frames{0}, slow_calls{0}, settles{0}, direct_frames{0}, committed_blocks{0};
+        // deferred settle (option readahead_lone): decided per evaluation at its first small call
+        std::atomic<bool> lone{false};
+        struct Helper {
+            std::thread th;
+            std::mutex mtx;
+            std::condition_variable cv, idle_cv;
+            bool started = false, quit = false, busy = false, have = false;      // (mtx)
+            std::atomic<bool> armed{false};                 // a settle is owed once the eval has been quiet long enough
+            std::atomic<int64_t> last_leave_ns{0};          // when the last call left (steady clock)
+            std::atomic<uint64_t> settles{0};
+            vmd_system_t sys; vmd_trajectory_i traj;        // (mtx) copies of the caller's records: what the deferred settle evaluates from
+        } helper;
     } ra;
     vmd_reduce_stats_t reduce_stats = {};
     struct Spec { bool rdf_closed = false, sdf_include_self = false, sdf_density = false, dist_geometric_com = false, rdf_raw = false; int rdf_norm = 0; } spec;   // fixed at creation
@@ -1305,9 +1325,11 @@ extern "C" vmd_script_eval_t* vmd_eval_create(size_t num_frames, const vmd_scrip
     return e.release();
 }
 
+static void lone_stop(vmd_script_eval_t* e);
 extern "C" void vmd_eval_free(vmd_script_eval_t* eval) {
     if (!eval) return;
     VMD_STAGE("vmd_eval_free");
+    lone_stop(eval);                     // the helper thread of a deferred-settle eval finishes what it is doing and ends
     int prev_dev = 0;
     (void)hipGetDevice(&prev_dev);
     (void)hipSetDevice(eval->device);
@@ -1373,9 +1395,11 @@ template <class T> static inline void pub(T& dst, T v) { __atomic_store(&dst, &v
 static inline void pub_touch(uint64_t& fingerprint) { uint64_t v; __atomic_load(&fingerprint, &v, __ATOMIC_RELAXED); v += 1; __atomic_store(&fingerprint, &v, __ATOMIC_RELAXED); }
 
 static void ra_reset(vmd_script_eval_t* e);
+static void lone_cancel(vmd_script_eval_t* e);
 extern "C" void vmd_eval_clear_data(vmd_script_eval_t* eval) {
     VMD_STAGE("vmd_eval_clear_data");
     if (!eval) return;
+    lone_cancel(eval);                   // a deferred settle of the evaluation that ends here must neither start nor be running
     std::lock_guard<std::mutex> l(eval->mtx);
     eval->interrupt = false;
     std::fill(eval->frame_mask.begin(), eval->frame_mask.end(), (uint8_t)0);
@@ -1546,8 +1570,10 @@ extern "C" bool vmd_eval_defer_volume_views(vmd_script_eval_t* eval, bool defer)
     return true;
 }
 
+extern "C" bool vmd_eval_wait_settled(vmd_script_eval_t* eval);
 extern "C" bool vmd_eval_finalize(vmd_script_eval_t* eval) {
     if (!eval) return vmd_fail("eval is NULL");
+    if (!vmd_eval_wait_settled(eval)) return false;       // deferred-settle evals: the totals first
     std::lock_guard<std::mutex> l(eval->mtx);
     HIP_OK(hipSetDevice(eval->device));
     for (auto& p : eval->props) {
@@ -3151,6 +3177,7 @@ static void ra_reset(vmd_script_eval_t* e) {          // clear_data (mtx held): 
     if (ra.frame_req) for (size_t i = 0; i < 64 * ra.req_stride; ++i) ra.frame_req[i] = 0;
     ra.marks_pending = false; ra.views_dirty = false;
     ra.concurrent = false; ra.lonely = false; ra.disabled = false; ra.strikes = 0; ra.next_region = 0; ra.failed = false; ra.error.clear();
+    ra.lone.store(false);
 }
 
 static size_t ra_block_frames(const vmd_script_eval_t* e, size_t Bmax) {
@@ -3414,9 +3441,15 @@ static bool ra_call(vmd_script_eval_t* e, const vmd_system_t* sys, vmd_trajector
     if (small && !ra.disabled) {
         // (also on an eval whose blocks exist from an earlier evaluation: whether THIS evaluation is driven by a pool is found out anew)
         if (!ra.concurrent && !ra.lonely) {
-            // the first call of an evaluation: is this a pool?  Its other threads are microseconds behind
-            cv_wait_us(e->queue_cv, ql, std::max(0, g_opt.readahead_company_us.load()), [&] { return ra.concurrent || e->interrupt.load(); });
-            if (!ra.concurrent) ra.lonely = true;
+            if (g_opt.readahead_lone.load() > 0) {
+                // opted in: every small call is part of a walk, whoever makes it - served like a pool's, settled by the helper thread
+                ra.lone.store(true);
+                ra.concurrent = true;
+            } else {
+                // the first call of an evaluation: is this a pool?  Its other threads are microseconds behind
+                cv_wait_us(e->queue_cv, ql, std::max(0, g_opt.readahead_company_us.load()), [&] { return ra.concurrent || e->interrupt.load(); });
+                if (!ra.concurrent) ra.lonely = true;
+            }
         }
         if (ra.concurrent && !ra.on.load()) {
             e->queue_cv.wait(ql, [&] { return ra.combining == 0 || ra.on.load(); });      // calls that went to the combining queue before anyone knew
@@ -3504,14 +3537,100 @@ static bool ra_call(vmd_script_eval_t* e, const vmd_system_t* sys, vmd_trajector
     return true;
 }
 
+// ---- deferred settle (option readahead_lone) ----------------------------------------------------------------------------------
+static int64_t steady_ns() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// The helper thread of an eval in deferred-settle mode: sleeps until a settle is owed (armed) and the eval has been quiet for
+// readahead_lone_settle_us since the last call left, then does what a pool's last leaver does - as a call of its own (flight + 1), so every
+// hand-over rule of ra_settle / ra_leave holds unchanged.  Marks that arrive while it settles keep it armed.
+static void lone_helper_main(vmd_script_eval_t* e) {
+    ReadAhead& ra = e->ra;
+    ReadAhead::Helper& h = ra.helper;
+    std::unique_lock<std::mutex> lk(h.mtx);
+    for (;;) {
+        h.cv.wait(lk, [&] { return h.quit || h.armed.load(); });
+        if (h.quit) break;
+        for (;;) {
+            const int64_t due = h.last_leave_ns.load() + (int64_t)std::max(1, g_opt.readahead_lone_settle_us.load()) * 1000;
+            const int64_t now = steady_ns();
+            if (h.quit || !h.armed.load() || now >= due) break;
+            cv_wait_us(h.cv, lk, (int)((due - now) / 1000 + 1), [&] { return h.quit || !h.armed.load(); });
+        }
+        if (h.quit) break;
+        if (!h.armed.load() || !h.have) continue;        // cancelled (clear_data, wait_settled)
+        if (e->interrupt.load()) { h.armed.store(false); h.idle_cv.notify_all(); continue; }     // an interrupted evaluation is not completed behind the host's back
+        h.busy = true;
+        vmd_system_t sys = h.sys;
+        vmd_trajectory_i traj = h.traj;
+        lk.unlock();
+        bool retry = false;
+        {
+            const uint64_t w = ra.flight.fetch_add(1, std::memory_order_acq_rel);
+            if ((uint32_t)w == 0) {
+                g_last_error.clear();
+                const bool ok = ra_settle(e, &sys, &traj, true);
+                if (!ok && !e->interrupt && !g_last_error.empty()) {
+                    std::lock_guard<std::mutex> ql(e->queue_mtx);
+                    ra.failed = true; ra.error = g_last_error;                 // the next call reports it
+                }
+                h.settles += 1;
+            } else {
+                retry = true;                                                     // a call is inside: it stamps last_leave when it goes
+            }
+            ra.flight.fetch_sub(1, std::memory_order_acq_rel);
+        }
+        lk.lock();
+        h.busy = false;
+        if (!retry && !ra.marks_pending.load() && !ra.views_dirty.load()) h.armed.store(false);
+        else if (retry) h.last_leave_ns.store(std::max(h.last_leave_ns.load(), steady_ns()));
+        h.idle_cv.notify_all();
+    }
+}
+
+// a call that leaves last in deferred-settle mode: stamp the time, make sure the helper knows a settle is owed
+static void lone_arm(vmd_script_eval_t* e, const vmd_system_t* sys, vmd_trajectory_i* traj) {
+    ReadAhead::Helper& h = e->ra.helper;
+    h.last_leave_ns.store(steady_ns(), std::memory_order_relaxed);
+    if (h.armed.load(std::memory_order_acquire)) return;
+    std::lock_guard<std::mutex> l(h.mtx);
+    if (sys) h.sys = *sys; else memset(&h.sys, 0, sizeof(h.sys));
+    h.traj = *traj;
+    h.have = true;
+    if (!h.started) { h.started = true; h.th = std::thread(lone_helper_main, e); }
+    h.armed.store(true, std::memory_order_release);
+    h.cv.notify_one();
+}
+// clear_data / wait_settled: no settle may start from now on, and none is running when this returns (call WITHOUT e->mtx held)
+static void lone_cancel(vmd_script_eval_t* e) {
+    ReadAhead::Helper& h = e->ra.helper;
+    std::unique_lock<std::mutex> lk(h.mtx);
+    if (!h.started) return;
+    h.armed.store(false);
+    h.cv.notify_one();
+    h.idle_cv.wait(lk, [&] { return !h.busy; });
+}
+static void lone_stop(vmd_script_eval_t* e) {           // vmd_eval_free
+    ReadAhead::Helper& h = e->ra.helper;
+    {
+        std::lock_guard<std::mutex> l(h.mtx);
+        if (!h.started) return;
+        h.quit = true;
+        h.cv.notify_one();
+    }
+    h.th.join();
+}
+
 // the end of every call: whoever leaves last settles (or hands the duty to a call that has arrived since)
 static bool ra_leave(vmd_script_eval_t* e, const vmd_system_t* sys, vmd_trajectory_i* traj) {
     ReadAhead& ra = e->ra;
+    const bool lone = ra.lone.load(std::memory_order_relaxed);
+    if (lone) ra.helper.last_leave_ns.store(steady_ns(), std::memory_order_relaxed);
     for (;;) {
         const uint64_t w = ra.flight.fetch_sub(1, std::memory_order_acq_rel);
         if ((uint32_t)w != 1) return true;
         if (!ra.on.load(std::memory_order_acquire) || (!ra.marks_pending.load() && !ra.views_dirty.load())) return true;
         if (e->interrupt) return true;
+        if (lone) { lone_arm(e, sys, traj); return true; }      // deferred: the helper settles once the eval has been quiet
         const uint64_t a0 = w >> 32;
         const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(std::max(0, g_opt.readahead_linger_us.load()));
         while (std::chrono::steady_clock::now() < deadline) {
@@ -3547,6 +3666,30 @@ extern "C" bool vmd_eval_frame_range(vmd_script_eval_t* eval, const vmd_script_i
     const bool lok = ra_leave(eval, sys, traj);
     if (!ok) g_last_error = err;
     return ok && lok;
+}
+
+// Deferred-settle mode (option readahead_lone): everything the calls so far have asked for joins the totals and the views NOW, on the
+// calling thread, instead of when the helper's quiet period is over.  Call after the last vmd_eval_frame_range has returned; a no-op for
+// every other eval (their last call has settled before it returned).
+extern "C" bool vmd_eval_wait_settled(vmd_script_eval_t* eval) {
+    if (!eval) return vmd_fail("eval is NULL");
+    ReadAhead& ra = eval->ra;
+    if (!ra.lone.load()) return true;
+    lone_cancel(eval);
+    ReadAhead::Helper& h = ra.helper;
+    vmd_system_t sys; vmd_trajectory_i traj;
+    {
+        std::lock_guard<std::mutex> l(h.mtx);
+        if (!h.have) return true;
+        sys = h.sys; traj = h.traj;
+    }
+    g_last_error.clear();
+    bool ok = true;
+    ra.flight.fetch_add(1, std::memory_order_acq_rel);
+    if (ra.on.load(std::memory_order_acquire) && (ra.marks_pending.load() || ra.views_dirty.load())) ok = ra_settle(eval, &sys, &traj, true);
+    ra.flight.fetch_sub(1, std::memory_order_acq_rel);
+    if (ok) { std::lock_guard<std::mutex> ql(eval->queue_mtx); if (ra.failed) { g_last_error = ra.error; ok = false; } }
+    return ok;
 }
 
 extern "C" void vmd_eval_readahead_stats(const vmd_script_eval_t* eval, vmd_readahead_stats_t* out) {

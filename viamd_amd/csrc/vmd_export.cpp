@@ -84,6 +84,7 @@ extern "C" bool vmd_export_csv(const char* path, const float* const* columns, co
 extern "C" bool vmd_export_property_table(const char* path, vmd_script_eval_t* eval, const char* name, const char* format,
                                           const double* frame_times, int num_bins) {
     if (!path || !eval || !name || !format) return exp_fail("vmd_export_property_table: NULL argument");
+    if (!vmd_eval_wait_settled(eval)) return false;
     const vmd_script_property_data_t* pd = vmd_eval_property_data(eval, name);
     if (!pd) return exp_fail(std::string("Export: the property '") + name + "' does not exist");
     const bool xvg = !strcmp(format, "xvg");
@@ -164,6 +165,7 @@ CubeGeometry cube_geometry(const vmd_script_property_data_t* pd, float half_exte
 extern "C" bool vmd_export_cube(const char* path, vmd_script_eval_t* eval, const char* name, const vmd_system_t* sys, vmd_trajectory_i* traj,
                                 uint32_t frame, const uint8_t* atomic_numbers) {
     if (!path || !eval || !name || !traj) return exp_fail("vmd_export_cube: NULL argument");
+    if (!vmd_eval_wait_settled(eval)) return false;
     const vmd_script_property_data_t* pd = vmd_eval_property_data(eval, name);
     if (!pd) return exp_fail("Export Cube: The property to be exported did not exist");
     vmd_sdf_payload_t vis;

@@ -259,6 +259,7 @@ struct EvalLock {
 extern "C" bool vmd_eval_reduce(vmd_script_eval_t* eval, const vmd_collective_i* coll, void* stream) {
     if (!eval) return red_fail("vmd_eval_reduce: eval is NULL");
     if (!coll || !coll->allreduce_sum_u64 || !coll->allreduce_sum_f64) return red_fail("vmd_eval_reduce: incomplete collective interface");
+    if (!vmd_eval_wait_settled(eval)) return false;       // a deferred-settle eval (option readahead_lone): this rank's totals first
     DeviceScope scope;
     hipEvent_t& t0 = scope.t0;
     hipEvent_t& t1 = scope.t1;

@@ -328,6 +328,11 @@ class ScriptEval:
         m = np.ascontiguousarray(mask, dtype=np.uint8)
         self.lib.vmd_eval_set_frame_mask(self.h, m.ctypes.data_as(L.c_uint8_p), m.size)
 
+    def wait_settled(self):
+        """deferred-settle mode (option readahead_lone): bring totals and views up to what the calls so far asked for, now"""
+        if not self.lib.vmd_eval_wait_settled(self.h):
+            raise VmdError(self.lib.last_error())
+
     def defer_volume_views(self, defer=True):
         """a rank of a multi-GPU evaluation: the float view of a volume is derived once, by finalize() / the merge, not after every range"""
         if not self.lib.vmd_eval_defer_volume_views(self.h, bool(defer)):
