@@ -1442,7 +1442,13 @@ extern "C" void vmd_eval_clear_data(vmd_script_eval_t* eval) {
     (void)hipStreamSynchronize(eval->stream);
 }
 
-extern "C" void vmd_eval_interrupt(vmd_script_eval_t* eval) { if (eval) eval->interrupt = true; }
+extern "C" void vmd_eval_interrupt(vmd_script_eval_t* eval) {
+    if (!eval) return;
+    eval->interrupt = true;
+    // deferred-settle mode: a settle that is owed is dropped, one that is running ends at its next batch boundary - and has ended when this
+    // returns: VIAMD resets the arena that holds molecule and trajectory right after interrupt_async_tasks (src/viamd.cpp:234-241, 624-630)
+    if (eval->ra.lone.load()) lone_cancel(eval);
+}
 extern "C" uint64_t vmd_eval_ir_fingerprint(const vmd_script_eval_t* eval) { return eval ? eval->ir_fingerprint : 0; }
 extern "C" const vmd_script_property_data_t* vmd_eval_property_data(const vmd_script_eval_t* eval, const char* name) {
     PropState* p = find_prop(eval, name);
@@ -3581,8 +3587,14 @@ static void lone_helper_main(vmd_script_eval_t* e) {
         }
         lk.lock();
         h.busy = false;
-        if (!retry && !ra.marks_pending.load() && !ra.views_dirty.load()) h.armed.store(false);
-        else if (retry) h.last_leave_ns.store(std::max(h.last_leave_ns.load(), steady_ns()));
+        if (retry) {
+            h.last_leave_ns.store(std::max(h.last_leave_ns.load(), steady_ns()));
+        } else {
+            // Disarm, THEN look at the marks (both seq_cst) - the mirror image of a leaving call, which marks and then looks at `armed`
+            // (lone_arm): at least one of the two sees the other, so a mark made while this settle ran is never left without an owner
+            h.armed.store(false, std::memory_order_seq_cst);
+            if (ra.marks_pending.load(std::memory_order_seq_cst) || ra.views_dirty.load(std::memory_order_seq_cst)) h.armed.store(true, std::memory_order_seq_cst);
+        }
         h.idle_cv.notify_all();
     }
 }
@@ -3591,7 +3603,7 @@ static void lone_helper_main(vmd_script_eval_t* e) {
 static void lone_arm(vmd_script_eval_t* e, const vmd_system_t* sys, vmd_trajectory_i* traj) {
     ReadAhead::Helper& h = e->ra.helper;
     h.last_leave_ns.store(steady_ns(), std::memory_order_relaxed);
-    if (h.armed.load(std::memory_order_acquire)) return;
+    if (h.armed.load(std::memory_order_seq_cst)) return;          // (the caller's marks are seq_cst stores before this load: see lone_helper_main)
     std::lock_guard<std::mutex> l(h.mtx);
     if (sys) h.sys = *sys; else memset(&h.sys, 0, sizeof(h.sys));
     h.traj = *traj;
