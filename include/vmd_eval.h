@@ -367,7 +367,8 @@ bool   vmd_eval_finalize(vmd_script_eval_t* eval);
  * ragged ends, the host views - runs on a helper thread once the eval has been quiet for readahead_lone_settle_us (300): results trail the
  * last call by that much, which a polling reader (VIAMD's GUI, src/main.cpp:1508-1524) does not notice.  vmd_eval_wait_settled performs
  * that settle at once on the calling thread (vmd_eval_finalize, vmd_eval_reduce and the exporters call it); `sys` and the trajectory of
- * the calls must stay valid until it has returned, or until clear_data / free.  A no-op for evals that are not in that mode. */
+ * the calls must stay valid until it has returned, or until interrupt / clear_data / free (all three drop a settle that is owed and wait for
+ * one that is running).  A no-op for evals that are not in that mode. */
 bool   vmd_eval_wait_settled(vmd_script_eval_t* eval);
 /* A rank of a multi-GPU evaluation: do not materialise the float view of a VOLUME after every frame_range (8.4 MB over PCIe per call, for a
  * partial result nobody reads) - vmd_eval_finalize / vmd_eval_reduce derive it once, from the merged counts.  Distribution and temporal views
