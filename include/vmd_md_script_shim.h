@@ -295,6 +295,13 @@ inline md_script_eval_t* VMD_SHIM_PREFIX(md_script_eval_create)(size_t num_frame
     (void)alloc;                                 /* host allocations are the library's own */
 #endif
     if (!vir && !e->fb) return nullptr;          /* nothing bound and nobody to fall back on: as mdlib for an invalid ir */
+#ifdef VMD_SHIM_DEFERRED_SETTLE
+    /* A VIAMD build whose task pool may have a single worker (src/main.cpp:494-495 clamps to >= 2 today): small calls are evaluated ahead
+     * whoever makes them, the final settle trails the last call by a fraction of a millisecond (include/vmd_eval.h, vmd_eval_wait_settled).
+     * Safe under VIAMD's teardown order - interrupt_async_tasks interrupts both evals before the system's arena is reset
+     * (src/viamd.cpp:234-241, 624-630) and vmd_eval_interrupt drops / awaits the owed settle - but not part of mdlib's contract: opt-in. */
+    vmd_set_option("readahead_lone", 1);
+#endif
     if (vir) {
         e->eval = vmd_eval_create(num_frames, vir);
         if (!e->eval) {

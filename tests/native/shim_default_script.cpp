@@ -141,11 +141,22 @@ int main(int argc, char** argv) {
         return failed.load() == 0;
     };
     if (!md_script_ir_valid(eval_ir) || md_script_eval_ir_fingerprint(full_eval) != md_script_ir_fingerprint(eval_ir)) fail("src/main.cpp:986-987: eval and ir fingerprints must match");
+    // built with -DVMD_SHIM_DEFERRED_SETTLE the GPU part's results trail the last call by the quiet period (include/vmd_eval.h): VIAMD polls, this
+    // program compares at once - so it waits where VIAMD would simply look again a frame later
+    auto settled = [&](md_script_eval_t* e) {
+#ifdef VMD_SHIM_DEFERRED_SETTLE
+        if (e->eval && !vmd_eval_wait_settled(e->eval)) fail("vmd_eval_wait_settled");
+#else
+        (void)e;
+#endif
+    };
     md_script_eval_clear_data(full_eval);
     if (!pool_task(full_eval, 0, (uint32_t)F, 4)) fail("Eval Full");
+    settled(full_eval);
     const uint32_t beg_frame = (uint32_t)(F / 4), end_frame = (uint32_t)(F - F / 4);
     md_script_eval_clear_data(filt_eval);
     if (!pool_task(filt_eval, beg_frame, end_frame, 3)) fail("Eval Filt");
+    settled(filt_eval);
 
     // ---- what VIAMD then reads: the hot-path properties = direct vmd_* calls, bit for bit; the others = mdlib's (the mock's) own values
     auto prop = [&](const md_script_eval_t* e, const char* nm) { return md_script_eval_property_data(e, str_t{nm, strlen(nm)}); };
@@ -154,6 +165,7 @@ int main(int argc, char** argv) {
         vmd_system_t vsys = vmd_shim::wrap_system(&sys);
         vmd_trajectory_i vt = vmd_shim::wrap_trajectory(&traj_i);
         if (!e || !vmd_eval_frame_range(e, vir, &vsys, &vt, 0, (uint32_t)F)) fail("direct evaluation");
+        if (!vmd_eval_wait_settled(e)) fail("direct evaluation: settle");       // (a no-op unless the process runs in deferred-settle mode)
         for (const char* nm : {"d1", "r", "v"}) {
             const vmd_script_property_data_t* want = vmd_eval_property_data(e, nm);
             const md_script_property_data_t* got = prop(full_eval, nm);
@@ -194,6 +206,7 @@ int main(int argc, char** argv) {
         md_script_eval_clear_data(e);
         const uint32_t half = (uint32_t)(F / 2);
         if (!md_script_eval_frame_range(e, eval_ir, &sys, sys.trajectory, 0, half)) fail("frame_range (first half)");
+        settled(e);
         if (!mockmd_md_script_eval_frame_range(e->fb, eval_ir, &sys, sys.trajectory, half, (uint32_t)F)) fail("fallback ahead");
         const md_bitfield_t* mask = md_script_eval_frame_mask(e);
         for (size_t f = 0; f < F; ++f) if (md_bitfield_test_bit(mask, f) != (f < half)) fail("frame mask must be the AND of the GPU's and the fallback's");
@@ -218,6 +231,7 @@ int main(int argc, char** argv) {
         if (md_script_eval_ir_fingerprint(e) != md_script_ir_fingerprint(eval_ir)) fail("fingerprint with a reduced fallback ir: still the editor's script (src/main.cpp:987)");
         md_script_eval_clear_data(e);
         for (uint32_t f = 0; f < F; f += 4) if (!md_script_eval_frame_range(e, eval_ir, &sys, sys.trajectory, f, std::min<uint32_t>(f + 4, (uint32_t)F))) fail("frame_range (reduced)");
+        settled(e);
         for (size_t i = 0; i < md_script_ir_property_count(eval_ir); ++i) {
             const str_t nm = md_script_ir_property_names(eval_ir)[i];
             const md_script_property_data_t* a = md_script_eval_property_data(e, nm);

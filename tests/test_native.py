@@ -185,6 +185,13 @@ def test_md_script_shim_keeps_viamds_default_script_whole_on_the_emulator(tmp_pa
     out = subprocess.run([exe, "12"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     assert out.stdout.startswith("OK frames=12 properties=7"), out.stdout
+    # the same program with the shim's opt-in deferred settle (-DVMD_SHIM_DEFERRED_SETTLE: vmd_set_option("readahead_lone", 1) at create)
+    exe2 = str(tmp_path / "shim_default_script_emu_deferred")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-DVMD_SHIM_DEFERRED_SETTLE", SHIM_DEFAULT_SRC, "-I" + os.path.join(ROOT, "include"),
+                           "-I" + os.path.join(ROOT, "tests", "native"), emu, "-Wl,-rpath," + os.path.dirname(emu), "-lpthread", "-o", exe2])
+    out = subprocess.run([exe2, "12"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.startswith("OK frames=12 properties=7"), out.stdout
 
 
 @pytest.mark.gpu
