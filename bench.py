@@ -11,7 +11,8 @@ merges the integer accumulators.
 
 Default (no flags): N = 1, workload c3 = BASELINE.json configs[2], the configuration the metric and north_star are quoted on
 (1M-atom box, 1k frames, all-heavy-atom RDF r_cut 12 A; 12 GB resident).  At N = 1 the same JSON line carries a `secondary`
-block with short runs of the other single-GPU configurations (c2 = configs[1], c4 = configs[3], c5 = configs[4]): value,
+block with short runs of the other single-GPU configurations (c2 = configs[1], c4 = configs[3], c5 = configs[4], c3d = SURVEY 8d's dense
+variant of configs[2], c4_1250 = one rank's share of configs[3] at 8 GPUs): value,
 ms_per_step, dominant-kernel time, kernel-level and step-level HBM fraction each.
 --scaling strong: the workload's frames are block-sharded over the ranks (configs[3]: 10 000 frames / N) instead of every
 rank owning its own frames; either way ONE vmd_eval_reduce (RCCL, C++ behind the ABI) merges per step.
@@ -196,7 +197,7 @@ def cpu_baseline(name, w, topo, info):
             "host": {"logical_cpus": logical, "physical_cores": physical, "cgroup_quota_cores": quota}}
 
 
-def run_workload(name, args, ctx, steps, warmup, frames=None, with_cpu=False, opts=()):
+def run_workload(name, args, ctx, steps, warmup, frames=None, with_cpu=False, opts=(), defer_views=False):
     """One workload end to end: synthesise the (rank's) trajectory in HBM, compile the script, W untimed + K timed steps
     bracketed by barrier + device sync, max over ranks.  Returns the result dict (rank 0: complete)."""
     import torch
@@ -288,7 +289,7 @@ def run_workload(name, args, ctx, steps, warmup, frames=None, with_cpu=False, op
     ir, info = script.compile_script(w["script"], topo)
     ev = V.ScriptEval(F, ir)
     sysm = V.MolSystem(w["atoms"], mass=topo.mass, unitcell=cell)
-    if world > 1:
+    if world > 1 or defer_views:
         # a rank's partial volume is nobody's result: its float view (8.4 MB over PCIe per range) is derived once, from the merged counts,
         # by the finalize inside vmd_eval_reduce.  At N = 1 the view is part of the step, as VIAMD reads it.
         ev.defer_volume_views(True)
@@ -619,8 +620,8 @@ def main():
     # the other single-GPU configurations of BASELINE.json, short runs in the same line (N = 1, default invocation only)
     if world == 1 and not args.no_secondary and args.workload == "c3" and args.traj == "device" and not args.frames:
         sec = {}
-        for nm in ("c2", "c4", "c5"):
-            r = run_workload(nm, args, ctx, WORKLOADS[nm]["sec_steps"], 1, opts=args.opt)
+        for nm in ("c2", "c4", "c5", "c3d"):       # c3d: SURVEY 8d's C3-dense variant (every atom counted as heavy), 200 frames
+            r = run_workload(nm, args, ctx, WORKLOADS[nm].get("sec_steps", 2), 1, opts=args.opt)
             rf = r["roofline"]
             sec[nm] = {"workload": r["config"]["workload"], "value": r["value"], "unit": "frames/s", "steps": r["steps"], "warmup": r["warmup"],
                        "ms_per_step": r["ms_per_step"], "frames_per_step": r["config"]["frames_per_step"],
@@ -632,13 +633,18 @@ def main():
         # configs[3] is quoted on 8 GPUs, strong scaling: 10 000 frames / 8 = 1 250 per rank.  One GPU can measure what bounds that curve - the
         # step over a rank's share against the step over the whole trajectory (kernels shrink 8x, the per-step fixed part does not; the merge,
         # which only N > 1 has, comes on top)
-        r = run_workload("c4", args, ctx, 10, 2, frames=1250, opts=args.opt)
+        r = run_workload("c4", args, ctx, 100, 10, frames=1250, opts=args.opt)        # 100 steps of ~0.6 ms: a 10-step sample moved by 20 % from call to call
+        # ... and what a RANK does before the merge: the same steps with the volume's float view deferred (vmd_eval_defer_volume_views: no zeroing
+        # of the view, no 8.4 MB over PCIe per step) - the merge and the one view of the merged counts come on top at N > 1
+        rank_part = run_workload("c4", args, ctx, 100, 10, frames=1250, opts=args.opt, defer_views=True)
         sec["c4_1250"] = {"workload": r["config"]["workload"] + " - ONE rank's share at 8 GPUs (1 250 frames)", "value": r["value"], "unit": "frames/s",
                           "steps": r["steps"], "warmup": r["warmup"], "ms_per_step": r["ms_per_step"], "frames_per_step": r["config"]["frames_per_step"],
                           "kernel_ms": r["kernel_ms"],
                           "strong_scaling_bound_8_gpus": sec["c4"]["ms_per_step"] / r["ms_per_step"],
+                          "rank_part_ms": rank_part["ms_per_step"],
                           "note": "ms_per_step(10 000 frames) / ms_per_step(1 250 frames) on one GPU: the upper bound of configs[3]'s 8-GPU strong scaling "
-                                  "(the float view of the volume, 8.4 MB over PCIe, is inside both steps; at N > 1 a rank defers it to the merge)"}
+                                  "(the float view of the volume, 8.4 MB over PCIe, is inside both steps; at N > 1 a rank defers it to the merge: rank_part_ms is that "
+                                  "step without the view - clear_data + frame_range only, NOT a complete evaluation)"}
         out["secondary"] = sec
     if world > 1 and not args.no_secondary and args.workload == "c3" and args.traj == "device" and not args.frames and args.scaling == "weak":
         # the two configurations BASELINE.json quotes on 8 GPUs, STRONG scaling (the named trajectory block-sharded over the ranks,

@@ -59,7 +59,7 @@ def test_default_line_has_the_contract_fields(tmp_path, emu_lib):
     assert d["n_gpus"] == 1 and d["config"]["name"] == "c3" and d["vs_baseline"] is None and d["dtype"] == "f32"
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in d["roofline"], k
-    assert set(d["secondary"]) == {"c2", "c4", "c5", "c4_1250"} and d["secondary"]["c4"]["roofline"]["kernel"] == "k_sdf_scatter"
+    assert set(d["secondary"]) == {"c2", "c4", "c5", "c3d", "c4_1250"} and d["secondary"]["c4"]["roofline"]["kernel"] == "k_sdf_scatter"
     assert d["secondary"]["c4_1250"]["strong_scaling_bound_8_gpus"] > 0
     assert d["secondary"]["c4"]["voxel_hits_per_s"] > 0 and d["pairs_per_s"] > 0
     assert 0.0 <= d["cell_build"]["frac_of_step"] < 1.0             # the sorted copies behind the pair kernel: share of the step (event times are 0 on the emulator)

@@ -1414,7 +1414,11 @@ extern "C" void vmd_eval_clear_data(vmd_script_eval_t* eval) {
         // src/main.cpp:990-996) and is awaited before the view is written again; a host memset here cost 10 % of a
         // 10 000-frame SDF evaluation.  Until it lands (~0.2 ms) a reader may still see the previous volume.
         bool dma = false;
-        if (p->prop.kind == PROP_SDF && p->pinned) {
+        // (an eval whose volume views are deferred - a rank of a multi-GPU evaluation - has no current view between clear_data and finalize by
+        // its own choice, and finalize rewrites every voxel: nothing to zero, 8.4 MB of PCIe traffic per evaluation saved)
+        const bool deferred_view = p->prop.kind == PROP_SDF && eval->defer_volume_views.load(std::memory_order_relaxed);
+        if (deferred_view) dma = true;
+        else if (p->prop.kind == PROP_SDF && p->pinned) {
             // on its own stream: the staging copies of the next frame_range must not queue behind 8 MB of PCIe traffic
             if (!p->d_zero.p && p->d_zero.ensure(p->ncounts)) (void)hipMemsetAsync(p->d_zero.p, 0, p->ncounts * sizeof(float), eval->aux_stream);
             if (!p->zero_done) p->zero_done = pool_event(false);
