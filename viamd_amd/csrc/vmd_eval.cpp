@@ -1122,6 +1122,7 @@ struct vmd_script_eval_t {
             std::mutex mtx;
             std::condition_variable cv, idle_cv;
             bool started = false, quit = false, busy = false, have = false;      // (mtx)
+            uint64_t cancel_seq = 0;                        // (mtx) bumped by every cancel: a settle that was running then does not re-arm itself
             std::atomic<bool> armed{false};                 // a settle is owed once the eval has been quiet long enough
             std::atomic<int64_t> last_leave_ns{0};          // when the last call left (steady clock)
             std::atomic<uint64_t> settles{0};
@@ -3570,6 +3571,7 @@ static void lone_helper_main(vmd_script_eval_t* e) {
         if (!h.armed.load() || !h.have) continue;        // cancelled (clear_data, wait_settled)
         if (e->interrupt.load()) { h.armed.store(false); h.idle_cv.notify_all(); continue; }     // an interrupted evaluation is not completed behind the host's back
         h.busy = true;
+        const uint64_t seq = h.cancel_seq;
         vmd_system_t sys = h.sys;
         vmd_trajectory_i traj = h.traj;
         lk.unlock();
@@ -3591,7 +3593,11 @@ static void lone_helper_main(vmd_script_eval_t* e) {
         }
         lk.lock();
         h.busy = false;
-        if (retry) {
+        if (h.cancel_seq != seq) {
+            // cancelled while it ran (interrupt, clear_data, wait_settled): whatever is marked from now on belongs to calls that arm afresh -
+            // with THEIR system and trajectory (lone_arm copies them only when it arms)
+            h.armed.store(false, std::memory_order_seq_cst);
+        } else if (retry) {
             h.last_leave_ns.store(std::max(h.last_leave_ns.load(), steady_ns()));
         } else {
             // Disarm, THEN look at the marks (both seq_cst) - the mirror image of a leaving call, which marks and then looks at `armed`
@@ -3621,6 +3627,7 @@ static void lone_cancel(vmd_script_eval_t* e) {
     ReadAhead::Helper& h = e->ra.helper;
     std::unique_lock<std::mutex> lk(h.mtx);
     if (!h.started) return;
+    h.cancel_seq += 1;
     h.armed.store(false);
     h.cv.notify_one();
     h.idle_cv.wait(lk, [&] { return !h.busy; });
