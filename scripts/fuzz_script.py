@@ -1,5 +1,8 @@
 """Random scripts through both front-ends (viamd_amd/script.py and the C++ vmd_ir_compile_from_source): both must accept and
-produce the same IR fingerprint, or both must reject.  usage: python scripts/fuzz_script.py [cases] [seed]"""
+produce the same IR fingerprint, or both must reject.  Every script also goes through the PARTIAL mode of both (round 5), salted with statements
+outside the subset (angle, shape_weights, arithmetic, stray characters): same compiled properties, same skipped names and source ranges, same
+fallback text; whatever the strict mode accepts the partial mode compiles identically with nothing skipped.
+usage: python scripts/fuzz_script.py [cases] [seed]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -50,7 +53,12 @@ def statement(i):
     return f"d{i} = {fn}({atom_sel()}, {atom_sel()}){ctx}"
 
 
-agree_ok = agree_err = 0
+def foreign(i):
+    return rng.choice([f"a{i} = angle(2,1,3) in resname(\"ALA\")", "{lin,plan,iso} = shape_weights(all)", f"x{i} = 3 * 4 + 2", f"w{i} = within(5.0, protein)",
+                       f"q{i} = rdf(w{max(i - 1, 0)}, all, 5.0)", f"z{i} = rmsd(protein) @ 2", f"y{i} = distance(1, 2) + 1", f"{{a,b}} = plane(resname('ALA'))", f"u{i} = 'unterminated"])
+
+
+agree_ok = agree_err = partial_ok = 0
 for it in range(ncases):
     text = "s0 = residue(2:6); " + "; ".join(statement(i) for i in range(rint(1, 4))) + rng.choice([";", "", " ;  # tail comment"])
     res = []
@@ -66,4 +74,22 @@ for it in range(ncases):
         agree_ok += 1
     else:
         agree_err += 1
-print(f"{ncases} scripts: {agree_ok} accepted identically, {agree_err} rejected by both")
+    # partial mode: the same statements with a few foreign ones mixed in
+    parts = ["s0 = residue(2:6)"] + [statement(i) if rng.random() < 0.7 else foreign(i) for i in range(rint(1, 5))]
+    ptext = "; ".join(parts) + rng.choice([";", ""])
+    try:
+        ir_py, _, rep_py = script.compile_script(ptext, topo, lib=lib, partial=True)
+        ir_c, rep_c = script.compile_script_native(ptext, topo, lib=lib, partial=True)
+        same = (ir_py.fingerprint() == ir_c.fingerprint() and ir_py.property_names() == ir_c.property_names() and
+                [(k["names"], k["beg"], k["end"]) for k in rep_py["skipped"]] == [(k["names"], k["beg"], k["end"]) for k in rep_c["skipped"]] and
+                rep_py["fallback_source"] == rep_c["fallback_source"] and len(rep_c["fallback_source"]) == len(ptext))
+        if res[0][0] == "ok":      # the strict text above: partial mode must agree with strict mode, nothing skipped
+            ir_s, rep_s = script.compile_script_native(text, topo, lib=lib, partial=True)
+            same = same and rep_s["skipped"] == [] and ir_s.fingerprint() == res[1][1]
+        if not same:
+            print("PARTIAL DISAGREE:", ptext, rep_py["skipped"], rep_c["skipped"])
+        else:
+            partial_ok += 1
+    except Exception as e:          # noqa: BLE001
+        print("PARTIAL ERROR:", ptext, repr(e)[:200])
+print(f"{ncases} scripts: {agree_ok} accepted identically, {agree_err} rejected by both; partial mode: {partial_ok} of {ncases} agree (properties, skipped names and ranges, fallback text)")
