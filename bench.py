@@ -633,10 +633,11 @@ def main():
         # configs[3] is quoted on 8 GPUs, strong scaling: 10 000 frames / 8 = 1 250 per rank.  One GPU can measure what bounds that curve - the
         # step over a rank's share against the step over the whole trajectory (kernels shrink 8x, the per-step fixed part does not; the merge,
         # which only N > 1 has, comes on top)
-        r = run_workload("c4", args, ctx, 100, 10, frames=1250, opts=args.opt)        # 100 steps of ~0.6 ms: a 10-step sample moved by 20 % from call to call
+        n1250, w1250 = (3, 1) if dry else (100, 10)
+        r = run_workload("c4", args, ctx, n1250, w1250, frames=1250, opts=args.opt)   # 100 steps of ~0.6 ms: a 10-step sample moved by 20 % from call to call
         # ... and what a RANK does before the merge: the same steps with the volume's float view deferred (vmd_eval_defer_volume_views: no zeroing
         # of the view, no 8.4 MB over PCIe per step) - the merge and the one view of the merged counts come on top at N > 1
-        rank_part = run_workload("c4", args, ctx, 100, 10, frames=1250, opts=args.opt, defer_views=True)
+        rank_part = run_workload("c4", args, ctx, n1250, w1250, frames=1250, opts=args.opt, defer_views=True)
         sec["c4_1250"] = {"workload": r["config"]["workload"] + " - ONE rank's share at 8 GPUs (1 250 frames)", "value": r["value"], "unit": "frames/s",
                           "steps": r["steps"], "warmup": r["warmup"], "ms_per_step": r["ms_per_step"], "frames_per_step": r["config"]["frames_per_step"],
                           "kernel_ms": r["kernel_ms"],

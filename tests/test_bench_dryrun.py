@@ -51,8 +51,14 @@ def test_under_the_launcher(tmp_path, emu_lib):
     assert d["n_gpus"] == 2 and d["merge"]["rccl_ranks"] == 2 and "secondary" not in d
 
 
-def test_default_line_has_the_contract_fields(tmp_path, emu_lib):
-    d = _run(tmp_path, emu_lib.path, 1, ["--steps", "1", "--warmup", "1"])
+@pytest.fixture(scope="module")
+def default_line(tmp_path_factory, emu_lib):
+    """ONE dry run of the default command, shared by the tests that read its line"""
+    return _run(tmp_path_factory.mktemp("default_line"), emu_lib.path, 1, ["--steps", "1", "--warmup", "1"])
+
+
+def test_default_line_has_the_contract_fields(default_line):
+    d = default_line
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
               "config", "roofline", "cpu_baseline", "secondary"):
         assert k in d, k
@@ -102,12 +108,12 @@ def _fractions(node, path=""):
             yield from _fractions(v, f"{path}{i}.")
 
 
-def test_no_fraction_exceeds_one(tmp_path, emu_lib):
+def test_no_fraction_exceeds_one(default_line):
     """`secondary.c5.roofline.valu.frac` was 1.026 (a self-calibrated ceiling) and c5's kernel-level HBM fraction
     divided one launch's time into the bytes of fourteen.  Every fraction of the line - dry run here, and the latest default line measured on
     the MI355X and committed under profiles/ - lies in [0, 1]; the VALU figure is priced against the guide's 2-cycle rate only and carries
     the counter-derived `busy`; a multi-pass workload's launch time is the sum of its passes."""
-    d = _run(tmp_path, emu_lib.path, 1, ["--steps", "1", "--warmup", "1"])
+    d = default_line
     assert d["fractions_within_0_1"] is True
     fr = dict(_fractions(d))
     assert fr and all(0.0 <= v <= 1.0 for v in fr.values()), {k: v for k, v in fr.items() if not 0.0 <= v <= 1.0}
