@@ -12,9 +12,9 @@
  *                                          /root/reference/src/components/density_volume/density_volume.cpp:183-204, 263-269;
  *                                          /root/reference/src/main.cpp:5751-5803 (export_cube); src/viamd.cpp:3197-3210
  *
- * With VMD_SHIM_PREFIX undefined the functions are emitted under those very names (a VIAMD build that drops mdlib's
- * md_script_eval.c from the link); define VMD_SHIM_PREFIX(name) to put them elsewhere (the compile test uses vmdshim_##name
- * next to a mock of mdlib's declarations).
+ * With VMD_SHIM_PREFIX undefined the functions are emitted under those very names (a VIAMD build whose mdlib has its own ten entry points
+ * renamed out of the way - see "A DECORATOR" below - or, with VMD_SHIM_NO_FALLBACK, dropped from the link); define VMD_SHIM_PREFIX(name) to
+ * put them elsewhere.
  *
  * Hooks (define before including; the defaults name mdlib's own functions): VMD_SHIM_BONDS(sys, vsys) hands md_system_t::bond over;
  * VMD_SHIM_UNIT(dst, str) turns the backend's printed unit ("\xC3\x85" or "") into an md_unit_t (default: md_unit_angstrom() /
