@@ -8,10 +8,10 @@ cd $R
 { rocm-smi --showproductname 2>/dev/null | head -8; nproc; lscpu | grep -E "Model name|^CPU\(s\)|Thread|Core|Socket"; } > $O/device.txt
 timeout 900 python -m pytest tests -m gpu -x -q -p no:cacheprovider > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -4 $O/pytest_gpu.log | cut -c1-250
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?"; tail -1 $O/smoke.log
-for w in c3 c2 c4 c5; do
+for w in c3 c2 c4 c5 c3d; do
   extra="--workload $w"; [ $w = c3 ] && extra="--no-secondary"
   bash $R/scripts/gpu_pmc.sh ${T}_pmc_$w $extra > $O/pmc_$w.log 2>&1
-  fps=1000; [ $w = c4 ] && fps=10000
+  fps=1000; [ $w = c4 ] && fps=10000; [ $w = c3d ] && fps=200
   # steps in the profiled run: --steps 1 --warmup 1 = 2; frames per step = the workload's own
   python $R/scripts/pmc_traffic.py $R/gpurun_out/${T}_pmc_$w $w $fps $O/pmc_traffic.json 2 $fps > /dev/null
   cp $R/gpurun_out/${T}_pmc_$w/summary.txt $O/pmc_summary_$w.txt 2>/dev/null
