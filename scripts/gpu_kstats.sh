@@ -1,13 +1,8 @@
 #!/bin/bash
-# rocprofv3 kernel stats of one bench command.  usage: gpurun -- 'bash scripts/gpu_kstats.sh <tag> <bench args...>'
-TAG=$1; shift
-R=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$R/gpurun_out/$TAG
-mkdir -p $OUT
-export TMPDIR=/tmp
-cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o k -- python $R/bench.py --no-cpu-baseline "$@" > $OUT/log.txt 2>&1
-echo "rc=$?"
-for f in $(find $OUT -name "*kernel_stats.csv"); do cut -d, -f1-4 $f; done
-find $OUT -name "*kernel_trace.csv" -size +5M -delete
-tail -1 $OUT/log.txt | cut -c1-300
+# rocprofv3 kernel stats of the secondary workloads (c3's are part of scripts/gpu_r05s.sh); usage: gpurun -- 'bash scripts/gpu_kstats.sh [tag]'
+T=${1:-r05z}; R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/${T}_kstats; mkdir -p $O; export TMPDIR=/tmp; cd /tmp
+for w in c2 c4 c5 c3d; do
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$w -o $w -- python $R/bench.py --workload $w --no-cpu-baseline --no-secondary --steps 5 --warmup 2 > $O/prof_$w.log 2>&1
+  find $O/prof_$w -name "*kernel_trace.csv" -delete; find $O/prof_$w -name "*agent_info.csv" -delete
+  f=$(find $O/prof_$w -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/kernel_stats_$w.csv && echo "== $w" && head -6 $O/kernel_stats_$w.csv | cut -c1-160
+done
