@@ -370,6 +370,9 @@ bool   vmd_eval_finalize(vmd_script_eval_t* eval);
  * the calls must stay valid until it has returned, or until interrupt / clear_data / free (all three drop a settle that is owed and wait for
  * one that is running).  A no-op for evals that are not in that mode. */
 bool   vmd_eval_wait_settled(vmd_script_eval_t* eval);
+/* the same choice per eval instead of per process: 1 = on, 0 = off, -1 = follow vmd_set_option("readahead_lone") (the default); read when an
+ * evaluation makes its first small call, i.e. set it before the calls or before clear_data */
+bool   vmd_eval_set_deferred_settle(vmd_script_eval_t* eval, int mode);
 /* A rank of a multi-GPU evaluation: do not materialise the float view of a VOLUME after every frame_range (8.4 MB over PCIe per call, for a
  * partial result nobody reads) - vmd_eval_finalize / vmd_eval_reduce derive it once, from the merged counts.  Distribution and temporal views
  * (a few KB) are kept current as ever.  Off by default: VIAMD reads `values` of a running evaluation (src/main.cpp:1508-1524). */

@@ -299,11 +299,14 @@ inline md_script_eval_t* VMD_SHIM_PREFIX(md_script_eval_create)(size_t num_frame
     /* A VIAMD build whose task pool may have a single worker (src/main.cpp:494-495 clamps to >= 2 today): small calls are evaluated ahead
      * whoever makes them, the final settle trails the last call by a fraction of a millisecond (include/vmd_eval.h, vmd_eval_wait_settled).
      * Safe under VIAMD's teardown order - interrupt_async_tasks interrupts both evals before the system's arena is reset
-     * (src/viamd.cpp:234-241, 624-630) and vmd_eval_interrupt drops / awaits the owed settle - but not part of mdlib's contract: opt-in. */
-    vmd_set_option("readahead_lone", 1);
+     * (src/viamd.cpp:234-241, 624-630) and vmd_eval_interrupt drops / awaits the owed settle - but not part of mdlib's contract: opt-in
+     * (set per eval right after vmd_eval_create below). */
 #endif
     if (vir) {
         e->eval = vmd_eval_create(num_frames, vir);
+#ifdef VMD_SHIM_DEFERRED_SETTLE
+        if (e->eval) vmd_eval_set_deferred_settle(e->eval, 1);      /* this eval only: nothing process-wide changes */
+#endif
         if (!e->eval) {
 #if VMD_SHIM_HAVE_FALLBACK
             if (e->fb) VMD_SHIM_FALLBACK(md_script_eval_free)(e->fb);

@@ -554,6 +554,22 @@ def readahead_case(lib, O, device=False, n_water=600, box=28.0, F=40, nthreads=6
             ev.close()
         finally:
             lib.vmd_set_option(b"readahead_lone", 0)
+        # ... and chosen per eval (vmd_eval_set_deferred_settle: what the shim's VMD_SHIM_DEFERRED_SETTLE does), the process-wide option off:
+        # this eval trails and is settled on demand, a second eval walked the same way beside it keeps the strict contract
+        ev, strict = V.ScriptEval(F, ir), V.ScriptEval(F, ir)
+        ev.set_deferred_settle(1)
+        for f in range(7, 29):
+            assert ev.frame_range(sysm, traj, f, f + 1) and strict.frame_range(sysm, traj, f, f + 1)
+            assert strict.frames_done() == f + 1 - 7 and ev.frames_done() <= f + 1 - 7
+        same(strict, part, "strict eval beside a deferred one")
+        assert ev.readahead_stats()["regions"] >= 1 and strict.readahead_stats()["regions"] == 0
+        ev.wait_settled()
+        same(ev, part, "per-eval deferred settle")
+        ev.set_deferred_settle(-1)                                      # back to the process-wide option (off): strict again after clear_data
+        ev.clear_data()
+        for f in range(7, 12):
+            assert ev.frame_range(sysm, traj, f, f + 1) and ev.frames_done() == f + 1 - 7
+        ev.close(); strict.close()
         # ---- block partials that cannot be allocated (a large volume script beside an HBM-resident trajectory) must not fail
         # the evaluation: read-ahead steps aside, the combining queue serves the same calls, the results are the same
         lib.vmd_set_option(b"readahead_fail_alloc", 1)

@@ -173,6 +173,7 @@ SIGNATURES = [
     ("vmd_eval_finalize", C.c_bool, [_vp]),
     ("vmd_eval_defer_volume_views", C.c_bool, [_vp, C.c_bool]),
     ("vmd_eval_wait_settled", C.c_bool, [_vp]),
+    ("vmd_eval_set_deferred_settle", C.c_bool, [_vp, C.c_int]),
     ("vmd_eval_set_frame_mask", None, [_vp, c_uint8_p, C.c_size_t]),
     ("vmd_eval_sdf_structures", c_int32_p, [_vp, C.c_char_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     ("vmd_eval_sdf_payload", C.c_bool, [_vp, C.c_char_p, C.POINTER(System), C.POINTER(TrajectoryI), C.c_uint32, C.POINTER(SdfPayload)]),

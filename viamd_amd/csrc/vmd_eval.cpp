@@ -1117,6 +1117,7 @@ struct vmd_script_eval_t {
         std::atomic<uint64_t> regions{0}, region_frames{0}, slow_calls{0}, settles{0}, direct_frames{0}, committed_blocks{0};
         // deferred settle (option readahead_lone): decided per evaluation at its first small call
         std::atomic<bool> lone{false};
+        std::atomic<int> lone_pref{-1};              // vmd_eval_set_deferred_settle: -1 = the process-wide option readahead_lone, 0 / 1 = this eval's own choice
         struct Helper {
             std::thread th;
             std::mutex mtx;
@@ -3452,7 +3453,8 @@ static bool ra_call(vmd_script_eval_t* e, const vmd_system_t* sys, vmd_trajector
     if (small && !ra.disabled) {
         // (also on an eval whose blocks exist from an earlier evaluation: whether THIS evaluation is driven by a pool is found out anew)
         if (!ra.concurrent && !ra.lonely) {
-            if (g_opt.readahead_lone.load() > 0) {
+            const int pref = ra.lone_pref.load(std::memory_order_relaxed);
+            if (pref < 0 ? g_opt.readahead_lone.load() > 0 : pref > 0) {
                 // opted in: every small call is part of a walk, whoever makes it - served like a pool's, settled by the helper thread
                 ra.lone.store(true);
                 ra.concurrent = true;
@@ -3689,6 +3691,12 @@ extern "C" bool vmd_eval_frame_range(vmd_script_eval_t* eval, const vmd_script_i
     const bool lok = ra_leave(eval, sys, traj);
     if (!ok) g_last_error = err;
     return ok && lok;
+}
+
+extern "C" bool vmd_eval_set_deferred_settle(vmd_script_eval_t* eval, int mode) {
+    if (!eval) return vmd_fail("eval is NULL");
+    eval->ra.lone_pref.store(mode < 0 ? -1 : (mode ? 1 : 0), std::memory_order_relaxed);       // takes effect at the next clear_data / first small call of an evaluation
+    return true;
 }
 
 // Deferred-settle mode (option readahead_lone): everything the calls so far have asked for joins the totals and the views NOW, on the

@@ -328,6 +328,11 @@ class ScriptEval:
         m = np.ascontiguousarray(mask, dtype=np.uint8)
         self.lib.vmd_eval_set_frame_mask(self.h, m.ctypes.data_as(L.c_uint8_p), m.size)
 
+    def set_deferred_settle(self, mode=1):
+        """this eval's own choice of the deferred-settle mode: 1 on, 0 off, -1 follow the process-wide option readahead_lone"""
+        if not self.lib.vmd_eval_set_deferred_settle(self.h, int(mode)):
+            raise VmdError(self.lib.last_error())
+
     def wait_settled(self):
         """deferred-settle mode (option readahead_lone): bring totals and views up to what the calls so far asked for, now"""
         if not self.lib.vmd_eval_wait_settled(self.h):
