@@ -330,11 +330,12 @@ bool vmd_eval_sdf_payload(vmd_script_eval_t* eval, const char* name, const vmd_s
  * export_xvg / export_csv (src/main.cpp:5640-5716): columns[j][i], one label per column */
 bool vmd_export_xvg(const char* path, const float* const* columns, const char* const* labels, size_t num_columns, size_t num_rows);
 bool vmd_export_csv(const char* path, const float* const* columns, const char* const* labels, size_t num_columns, size_t num_rows);
-/* the table the property-export window assembles for one property (src/main.cpp:5953-6040): temporal -> time (frame_times, or the
- * frame index when NULL) + one column per population member; distribution -> num_bins (0 = 128) display bins over
- * [min_range[0], max_range[0]].  format: "xvg" or "csv" */
+/* the table the property-export window assembles for one property (src/main.cpp:5953-6040), labels included: temporal -> time
+ * (frame_times, or the frame index when NULL; labelled "Frame", or "Time (<time_unit>)" when time_unit is a non-empty string) + the
+ * values ("name", "name (<unit>)" when the property has a y unit, "name[i]" per population member); distribution -> num_bins
+ * (0 = 128) display bins over [min_range[0], max_range[0]] labelled with the x unit + the downsampled histogram.  format: "xvg" or "csv" */
 bool vmd_export_property_table(const char* path, vmd_script_eval_t* eval, const char* name, const char* format,
-                               const double* frame_times, int num_bins);
+                               const double* frame_times, const char* time_unit, int num_bins);
 /* export_cube (src/main.cpp:5718-5830): Gaussian cube file of volume property `name` in Bohr, x outermost / z innermost over the
  * x-fastest array, preceded by the atoms of reference structure 0 (coordinates of trajectory frame 0 through the
  * world->reference matrix of `frame` - VIAMD passes the displayed frame).  atomic_numbers: per atom, or NULL (written as 0) */
@@ -373,6 +374,12 @@ bool   vmd_eval_wait_settled(vmd_script_eval_t* eval);
 /* the same choice per eval instead of per process: 1 = on, 0 = off, -1 = follow vmd_set_option("readahead_lone") (the default); read when an
  * evaluation makes its first small call, i.e. set it before the calls or before clear_data */
 bool   vmd_eval_set_deferred_settle(vmd_script_eval_t* eval, int mode);
+/* Deferred-settle mode: `fn(user)` is called after every settle the helper thread - or vmd_eval_wait_settled - has performed, on that
+ * thread, with no lock of the eval held; clear_data / interrupt / free wait for a call that is running, none starts after they return.  A
+ * host that caches scalar fields of the property records (include/vmd_md_script_shim.h re-publishes fingerprint / ranges / max_value to
+ * VIAMD, which re-reads a property only when prop_data->fingerprint moves, src/main.cpp:1508-1509) refreshes its copies here.  fn must not
+ * call clear_data / interrupt / free / wait_settled of the same eval.  Set before the evaluation's calls; NULL removes it. */
+bool   vmd_eval_set_settled_callback(vmd_script_eval_t* eval, void (*fn)(void*), void* user);
 /* A rank of a multi-GPU evaluation: do not materialise the float view of a VOLUME after every frame_range (8.4 MB over PCIe per call, for a
  * partial result nobody reads) - vmd_eval_finalize / vmd_eval_reduce derive it once, from the merged counts.  Distribution and temporal views
  * (a few KB) are kept current as ever.  Off by default: VIAMD reads `values` of a running evaluation (src/main.cpp:1508-1524). */
@@ -589,6 +596,7 @@ void        vmd_clear_last_error(void);             /* a caller that handled a f
 #define VMD_LOG_ERROR 2
 typedef void (*vmd_log_fn)(int level, const char* message, void* user);
 void        vmd_log_register(vmd_log_fn fn, void* user);
+void        vmd_log_message(int level, const char* message);      /* a layer above the ABI (the shim) reports through the same channel */
 const char* vmd_version(void);
 /* tuning knobs (kernel variant, frames per batch); returns previous value, -1 for unknown key */
 int         vmd_set_option(const char* key, int value);

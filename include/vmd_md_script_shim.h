@@ -18,8 +18,10 @@
  *
  * Hooks (define before including; the defaults name mdlib's own functions): VMD_SHIM_BONDS(sys, vsys) hands md_system_t::bond over;
  * VMD_SHIM_UNIT(dst, str) turns the backend's printed unit ("\xC3\x85" or "") into an md_unit_t (default: md_unit_angstrom() /
- * md_unit_none()); VMD_SHIM_BITFIELD_INIT / _SET build the md_bitfield_t of a reference structure (default: md_bitfield_init /
- * md_bitfield_set_bit); md_array_resize / md_array_size are mdlib's stretchy-buffer macros.
+ * md_unit_none()); VMD_SHIM_BITFIELD_INIT / _SET / _TEST / _CLEAR / _FREE are how the shim touches ANY md_bitfield_t - the reference
+ * structures of a vis payload and the frame mask it hands out (defaults: md_bitfield_init / _set_bit / _test_bit / _clear / _free); md_array_resize
+ * / md_array_size are mdlib's stretchy-buffer macros.  The block "what this header requires of mdlib" below lists, and checks at compile time,
+ * every name and field used directly, each with the line of the reference where it is observable.
  *
  * A DECORATOR, not a replacement (round 5).  mdlib evaluates EVERY property of the IR in one md_script_eval_frame_range
  * (/root/reference/src/main.cpp:993-997) and VIAMD asks md_script_eval_property_data for every name of md_script_ir_property_names
@@ -51,6 +53,7 @@
 
 #include <string.h>
 
+#include <atomic>
 #include <iterator>
 #include <map>
 #include <memory>
@@ -81,6 +84,74 @@ struct md_script_vis_payload_o { const md_script_ir_t* ir; std::string name; };
 #ifndef VMD_SHIM_BITFIELD_TEST
 #define VMD_SHIM_BITFIELD_TEST(bf, idx) md_bitfield_test_bit((bf), (uint64_t)(idx))
 #endif
+/* the frame mask the shim hands out (md_script_eval_frame_mask) is an md_bitfield_t the shim OWNS: initialised, emptied, filled and freed
+ * through mdlib's own functions only - its storage layout is mdlib's business */
+#ifndef VMD_SHIM_BITFIELD_CLEAR
+#define VMD_SHIM_BITFIELD_CLEAR(bf) md_bitfield_clear((bf))
+#endif
+#ifndef VMD_SHIM_BITFIELD_FREE
+#define VMD_SHIM_BITFIELD_FREE(bf) md_bitfield_free((bf))
+#endif
+/* Optional, for speed only: VMD_SHIM_BITFIELD_ASSIGN_WORDS(bf, words, num_bits) - make *bf hold exactly the set bits of the little-endian
+ * 64-bit words (bit i of the mask = frame i).  Undefined by default: the mask is rebuilt with CLEAR + one SET per evaluated frame, on the
+ * GUI thread, only when a fingerprint moved (src/main.cpp:1508-1513) */
+
+/* ---- what this header requires of mdlib: NAMES, FIELDS and CALL SHAPES, checked at compile time -------------------------------
+ * Every line is observable at the cited call site of /root/reference/src (the evaluator's own headers are an empty submodule there);
+ * nothing else of mdlib's declarations is touched - storage that is not observable (md_bitfield_t's words, md_unit_t's members, md_array's
+ * header) is only ever reached through the hooks above.  A real mdlib that differs fails HERE, with the field's name, not at run time. */
+#define VMD_SHIM_REQUIRE_FIELD(T, f) static_assert(sizeof(((T*)nullptr)->f) > 0, #T "::" #f " is required by vmd_md_script_shim.h")
+#define VMD_SHIM_REQUIRE_EXPR(expr) static_assert(sizeof(decltype(expr)) > 0, #expr " must be a valid expression for vmd_md_script_shim.h")
+namespace vmd_shim_requires {
+VMD_SHIM_REQUIRE_FIELD(str_t, ptr); VMD_SHIM_REQUIRE_FIELD(str_t, len);                                   /* src/main.cpp:1295 (STR_ARG), :5682 */
+VMD_SHIM_REQUIRE_FIELD(md_system_t, atom.count); VMD_SHIM_REQUIRE_FIELD(md_system_t, atom.x);             /* src/main.cpp:5737-5741 */
+VMD_SHIM_REQUIRE_FIELD(md_system_t, atom.y); VMD_SHIM_REQUIRE_FIELD(md_system_t, atom.z);
+VMD_SHIM_REQUIRE_FIELD(md_system_t, atom.mass);                                                           /* src/viamd.cpp:2253 */
+VMD_SHIM_REQUIRE_FIELD(md_system_t, unitcell); VMD_SHIM_REQUIRE_FIELD(md_system_t, trajectory);           /* src/viamd.cpp:1837; src/main.cpp:995 */
+VMD_SHIM_REQUIRE_FIELD(md_unitcell_t, x); VMD_SHIM_REQUIRE_FIELD(md_unitcell_t, y); VMD_SHIM_REQUIRE_FIELD(md_unitcell_t, z);      /* src/viamd.cpp:1837-1842 */
+VMD_SHIM_REQUIRE_FIELD(md_unitcell_t, xy); VMD_SHIM_REQUIRE_FIELD(md_unitcell_t, xz); VMD_SHIM_REQUIRE_FIELD(md_unitcell_t, yz);
+VMD_SHIM_REQUIRE_FIELD(md_unitcell_t, flags);                                                             /* src/main.cpp:6255 */
+VMD_SHIM_REQUIRE_FIELD(md_trajectory_frame_header_t, unitcell);                                            /* src/viamd.cpp:465-467 */
+VMD_SHIM_REQUIRE_EXPR(md_trajectory_load_frame((md_trajectory_i*)nullptr, (int64_t)0, (md_trajectory_frame_header_t*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr));   /* src/viamd.cpp:465-467 */
+VMD_SHIM_REQUIRE_EXPR(md_trajectory_num_frames((md_trajectory_i*)nullptr));                               /* src/main.cpp:1022 */
+VMD_SHIM_REQUIRE_EXPR(md_trajectory_num_atoms((md_trajectory_i*)nullptr));                                /* src/viamd.cpp:455 */
+VMD_SHIM_REQUIRE_FIELD(md_script_property_data_t, dim[3]); VMD_SHIM_REQUIRE_FIELD(md_script_property_data_t, unit[1]);             /* src/main.cpp:1300-1301, 1353, 5773 */
+VMD_SHIM_REQUIRE_FIELD(md_script_property_data_t, values); VMD_SHIM_REQUIRE_FIELD(md_script_property_data_t, weights);             /* :1513, 1524 */
+VMD_SHIM_REQUIRE_FIELD(md_script_property_data_t, aggregate);                                             /* :1378 */
+VMD_SHIM_REQUIRE_FIELD(md_script_property_data_t, max_value);                                             /* density_volume.cpp:281 */
+VMD_SHIM_REQUIRE_FIELD(md_script_property_data_t, min_range[1]); VMD_SHIM_REQUIRE_FIELD(md_script_property_data_t, max_range[1]);  /* :1513, 1519-1522 */
+VMD_SHIM_REQUIRE_FIELD(md_script_property_data_t, fingerprint);                                           /* :1508-1509 */
+VMD_SHIM_REQUIRE_FIELD(md_script_aggregate_t, population_mean);                                           /* :1383-1440 */
+VMD_SHIM_REQUIRE_FIELD(md_script_aggregate_t, population_var); VMD_SHIM_REQUIRE_FIELD(md_script_aggregate_t, population_ext);
+VMD_SHIM_REQUIRE_FIELD(md_script_vis_t, atom_mask);                                                       /* src/viamd.cpp:3205-3207 */
+VMD_SHIM_REQUIRE_FIELD(md_script_vis_t, sdf.extent); VMD_SHIM_REQUIRE_FIELD(md_script_vis_t, sdf.matrices);                        /* density_volume.cpp:190-204, 263-269 */
+VMD_SHIM_REQUIRE_FIELD(md_script_vis_t, sdf.structures);
+VMD_SHIM_REQUIRE_FIELD(md_script_vis_ctx_t, ir); VMD_SHIM_REQUIRE_FIELD(md_script_vis_ctx_t, mol); VMD_SHIM_REQUIRE_FIELD(md_script_vis_ctx_t, traj);   /* src/main.cpp:5751-5755 */
+static_assert(sizeof(mat4_t) == 16 * sizeof(float), "mat4_t is 16 floats (column-major: mat4_mul_vec3(M, coord, 1.0f), src/main.cpp:5790)");
+static_assert(sizeof(md_script_vis_flags_t(MD_SCRIPT_VISUALIZE_ATOMS)) > 0 && sizeof(md_script_vis_flags_t(MD_SCRIPT_VISUALIZE_SDF)) > 0, "MD_SCRIPT_VISUALIZE_ATOMS / _SDF (src/main.cpp:5757)");
+}  // namespace vmd_shim_requires
+/* Fields this header remembers of mdlib but NO line of the reference shows ([RECOLLECTION]): md_script_property_data_t::num_values and
+ * ::min_value, md_script_aggregate_t::num_values, md_trajectory_frame_header_t::{num_atoms, index, timestamp}.  They are written / read
+ * IF the host's mdlib has them (detected at compile time) and skipped otherwise - nothing VIAMD reads depends on them.  The allocator
+ * mdlib's stretchy buffers of a md_script_vis_t grow with is `vis->alloc` by default ([RECOLLECTION]; md_script_vis_init(&vis, alloc),
+ * src/main.cpp:5747, is all the reference shows): define VMD_SHIM_VIS_ALLOC(vis) if it lives elsewhere. */
+#ifndef VMD_SHIM_VIS_ALLOC
+#define VMD_SHIM_VIS_ALLOC(vis) ((vis)->alloc)
+#endif
+namespace vmd_shim {
+template <class T> inline T peek(const T& v) { T r; __atomic_load(const_cast<T*>(&v), &r, __ATOMIC_RELAXED); return r; }
+template <class T, class U> inline void pub(T& d, U v) { T t = (T)v; __atomic_store(&d, &t, __ATOMIC_RELAXED); }
+#define VMD_SHIM_OPTIONAL_FIELD(field)                                                                                                  \
+    template <class T, class V> inline auto set_if_##field(T& t, V v, int) -> decltype((void)(t.field), void()) { pub(t.field, v); }       \
+    template <class T, class V> inline void set_if_##field(T&, V, long) {}                                                                \
+    template <class T, class V> inline auto get_if_##field(const T& t, V, int) -> decltype((void)(t.field), V()) { return (V)peek(t.field); } \
+    template <class T, class V> inline V get_if_##field(const T&, V fallback, long) { return fallback; }
+VMD_SHIM_OPTIONAL_FIELD(num_values)
+VMD_SHIM_OPTIONAL_FIELD(min_value)
+VMD_SHIM_OPTIONAL_FIELD(num_atoms)
+VMD_SHIM_OPTIONAL_FIELD(index)
+VMD_SHIM_OPTIONAL_FIELD(timestamp)
+}  // namespace vmd_shim
 
 /* ---- the evaluator behind the shim (mdlib's own, renamed) -------------------------------------------------------------------- */
 #ifndef VMD_SHIM_NO_FALLBACK
@@ -169,7 +240,9 @@ inline bool load_frame_adapter(void* inst, int64_t idx, vmd_frame_header_t* h, f
     md_trajectory_frame_header_t hdr = {};
     if (!md_trajectory_load_frame(traj, idx, &hdr, x, y, z)) return false;
     if (h) {
-        h->num_atoms = (size_t)hdr.num_atoms; h->index = (int64_t)hdr.index; h->timestamp = (double)hdr.timestamp;
+        h->num_atoms = get_if_num_atoms(hdr, (size_t)md_trajectory_num_atoms(traj), 0);
+        h->index = get_if_index(hdr, (int64_t)idx, 0);
+        h->timestamp = get_if_timestamp(hdr, (double)idx, 0);
         h->unitcell = unitcell(hdr.unitcell);
     }
     return true;
@@ -210,8 +283,16 @@ inline vmd_system_t wrap_system(const md_system_t* sys) {
 inline void vmd_shim_bind_ir(const md_script_ir_t* md_ir, const vmd_script_ir_t* vmd_ir) {
     vmd_shim::Registry& r = vmd_shim::registry();
     std::lock_guard<std::mutex> l(r.mtx);
-    if (vmd_ir) { r.ir[md_ir] = vmd_ir; return; }
-    r.ir.erase(md_ir);
+    if (vmd_ir) {
+        auto cur = r.ir.find(md_ir);
+        const bool same = cur != r.ir.end() && cur->second == vmd_ir;
+        r.ir[md_ir] = vmd_ir;
+        if (same) return;
+        /* a NEW binding under an address that was bound before (mdlib recycles the ir's memory after md_script_ir_free): the payload
+         * evaluator and the payloads of the old script must not outlive it */
+    } else {
+        r.ir.erase(md_ir);
+    }
     auto pe = r.payload_evals.find(md_ir);
     if (pe != r.payload_evals.end()) { vmd_eval_free(pe->second.eval); r.payload_evals.erase(pe); }
     for (auto it = r.payloads.begin(); it != r.payloads.end();) it = it->first.first == md_ir ? r.payloads.erase(it) : std::next(it);
@@ -246,39 +327,70 @@ struct md_script_eval_t {
     const md_script_ir_t* fb_ir = nullptr;       /* the IR `fb` was created from (md_ir, or the reduced one of vmd_shim_bind_fallback_ir) */
     size_t num_frames = 0;
     /* md_script_property_data_t records handed to VIAMD: fetched once and cached by the GUI (src/main.cpp:1286,1303), so their
-     * addresses are stable for the eval's lifetime; the arrays they point at are the backend's own (equally stable), the scalar
-     * fields (fingerprint, ranges, max_value) are refreshed from the backend whenever data may have changed */
-    struct Prop { std::string name; const vmd_script_property_data_t* src; md_script_property_data_t dst; md_script_aggregate_t agg; };
+     * addresses are stable for the eval's lifetime; the arrays they point at are the owning evaluator's (equally stable), the scalar
+     * fields (fingerprint, ranges, max_value) are refreshed from it whenever data may have changed.  EVERY record VIAMD gets is one of
+     * these - the GPU's (src) and, with an evaluator behind the shim, mdlib's (fb_src) - because the shim must be able to move a
+     * record's fingerprint: VIAMD re-reads a property (and md_script_eval_frame_mask with it) only when prop_data->fingerprint changes
+     * (:1508-1513), and behind the shim the mask is the AND of two evaluators' masks - it can grow after the owning evaluator's last
+     * fingerprint change (the other evaluator finishes the frame later; a deferred settle lands later still).  So the fingerprint handed
+     * out is the owner's mixed with `epoch`, which moves whenever either evaluator has finished something. */
+    struct Prop {
+        std::string name;
+        const vmd_script_property_data_t* src = nullptr;        /* the GPU's record ... */
+        const md_script_property_data_t* fb_src = nullptr;      /* ... or mdlib's */
+        md_script_property_data_t dst;
+        md_script_aggregate_t agg;
+    };
     std::vector<std::unique_ptr<Prop>> props;
+    std::atomic<uint64_t> epoch{0};
     std::vector<uint64_t> mask_words;
-    md_bitfield_t mask;
+    md_bitfield_t mask[2];                           /* double-buffered: the one handed out last stays untouched while the next is built */
+    int mask_cur = 0;
     std::mutex mtx;
 
-    /* The backend changes the scalar fields while other pool threads are inside frame_range, and VIAMD's GUI thread reads the records
+    /* The evaluators change the scalar fields while other pool threads are inside frame_range, and VIAMD's GUI thread reads the records
      * below at any time (src/main.cpp:1508-1524: old and new fields side by side are tolerated).  Both directions go through relaxed
      * atomic loads / stores - plain moves on x86-64 - so the hand-over is defined behaviour, and ThreadSanitizer-clean. */
-    template <class T> static T peek(const T& v) { T r; __atomic_load(const_cast<T*>(&v), &r, __ATOMIC_RELAXED); return r; }
-    template <class T, class U> static void pub(T& d, U v) { T t = (T)v; __atomic_store(&d, &t, __ATOMIC_RELAXED); }
-    void refresh() {
+    static uint64_t mix(uint64_t fp, uint64_t epoch) { return fp ^ (epoch * 0x9E3779B97F4A7C15ull); }
+    void refresh() {                                 /* (mtx) */
+        using namespace vmd_shim;
+        const uint64_t ep = epoch.load(std::memory_order_acquire);
         for (auto& p : props) {
-            const vmd_script_property_data_t* s = p->src;
             md_script_property_data_t& d = p->dst;
-            for (int k = 0; k < 4; ++k) pub(d.dim[k], s->dim[k]);
-            pub(d.values, s->values); pub(d.weights, s->weights); pub(d.num_values, s->num_values);
-            pub(d.min_value, peek(s->min_value)); pub(d.max_value, peek(s->max_value));
-            for (int k = 0; k < 2; ++k) { pub(d.min_range[k], peek(s->min_range[k])); pub(d.max_range[k], peek(s->max_range[k])); }
-            if (s->aggregate) {
-                pub(p->agg.num_values, s->aggregate->num_values);
-                pub(p->agg.population_mean, s->aggregate->population_mean);
-                pub(p->agg.population_var, s->aggregate->population_var);
-                pub(p->agg.population_ext, (decltype(p->agg.population_ext))s->aggregate->population_ext);
-                pub(d.aggregate, &p->agg);
+            if (p->src) {
+                const vmd_script_property_data_t* s = p->src;
+                for (int k = 0; k < 4; ++k) pub(d.dim[k], s->dim[k]);
+                pub(d.values, s->values); pub(d.weights, s->weights); set_if_num_values(d, s->num_values, 0);
+                set_if_min_value(d, peek(s->min_value), 0); pub(d.max_value, peek(s->max_value));
+                for (int k = 0; k < 2; ++k) { pub(d.min_range[k], peek(s->min_range[k])); pub(d.max_range[k], peek(s->max_range[k])); }
+                if (s->aggregate) {
+                    set_if_num_values(p->agg, s->aggregate->num_values, 0);
+                    pub(p->agg.population_mean, s->aggregate->population_mean);
+                    pub(p->agg.population_var, s->aggregate->population_var);
+                    pub(p->agg.population_ext, (decltype(p->agg.population_ext))s->aggregate->population_ext);
+                    pub(d.aggregate, &p->agg);
+                } else {
+                    pub(d.aggregate, (decltype(d.aggregate))nullptr);
+                }
+                pub(d.fingerprint, mix(peek(s->fingerprint), ep));      /* last: the GUI compares it to decide whether to re-read (src/main.cpp:1508-1509) */
             } else {
-                pub(d.aggregate, (decltype(d.aggregate))nullptr);
+                const md_script_property_data_t* s = p->fb_src;         /* mdlib's record, read the way VIAMD itself reads it */
+                for (int k = 0; k < 4; ++k) pub(d.dim[k], peek(s->dim[k]));
+                pub(d.values, peek(s->values)); pub(d.weights, peek(s->weights));
+                pub(d.aggregate, peek(s->aggregate));
+                pub(d.max_value, peek(s->max_value));      /* (fields the shim does not know by name keep the value of the copy made at the first request) */
+                for (int k = 0; k < 2; ++k) { pub(d.min_range[k], peek(s->min_range[k])); pub(d.max_range[k], peek(s->max_range[k])); }
+                pub(d.fingerprint, mix(peek(s->fingerprint), ep));
             }
-            pub(d.fingerprint, peek(s->fingerprint));      /* last: the GUI compares it to decide whether to re-read (src/main.cpp:1508-1509) */
         }
     }
+    /* either evaluator has finished something (a range, a deferred settle): every record's fingerprint moves, so a polling GUI looks again */
+    void advance() {
+        epoch.fetch_add(1, std::memory_order_acq_rel);
+        std::lock_guard<std::mutex> l(mtx);
+        refresh();
+    }
+    static void on_settled(void* self) { ((md_script_eval_t*)self)->advance(); }       /* vmd_eval_set_settled_callback (deferred-settle mode) */
 };
 
 inline md_script_eval_t* VMD_SHIM_PREFIX(md_script_eval_create)(size_t num_frames, const md_script_ir_t* ir, md_allocator_i* alloc) {
@@ -295,6 +407,7 @@ inline md_script_eval_t* VMD_SHIM_PREFIX(md_script_eval_create)(size_t num_frame
     (void)alloc;                                 /* host allocations are the library's own */
 #endif
     if (!vir && !e->fb) return nullptr;          /* nothing bound and nobody to fall back on: as mdlib for an invalid ir */
+    (void)alloc;
 #ifdef VMD_SHIM_DEFERRED_SETTLE
     /* A VIAMD build whose task pool may have a single worker (src/main.cpp:494-495 clamps to >= 2 today): small calls are evaluated ahead
      * whoever makes them, the final settle trails the last call by a fraction of a millisecond (include/vmd_eval.h, vmd_eval_wait_settled).
@@ -307,6 +420,19 @@ inline md_script_eval_t* VMD_SHIM_PREFIX(md_script_eval_create)(size_t num_frame
 #ifdef VMD_SHIM_DEFERRED_SETTLE
         if (e->eval) vmd_eval_set_deferred_settle(e->eval, 1);      /* this eval only: nothing process-wide changes */
 #endif
+        /* whoever settles late (the helper thread of the deferred mode - also when the PROCESS opted in with readahead_lone) tells the shim,
+         * which moves the fingerprints VIAMD polls (without this the GUI kept the pre-settle histogram for good) */
+        if (e->eval) vmd_eval_set_settled_callback(e->eval, &md_script_eval_t::on_settled, e.get());
+#if VMD_SHIM_HAVE_FALLBACK
+        if (e->fb && e->fb_ir == ir) {
+            /* the fallback evaluates the WHOLE script: rdf / sdf / distance are then computed on the CPU as well, after the GPU part of
+             * every call - correct, but no faster than mdlib alone.  Said once per process. */
+            static std::atomic<bool> told{false};
+            if (!told.exchange(true))
+                vmd_log_message(VMD_LOG_INFO, "vmd_md_script_shim: no reduced fallback IR is bound (vmd_shim_bind_fallback_ir): mdlib evaluates the whole script "
+                                              "behind the GPU part, hot-path properties included; compile vmd_script_report_fallback_source() and bind it");
+        }
+#endif
         if (!e->eval) {
 #if VMD_SHIM_HAVE_FALLBACK
             if (e->fb) VMD_SHIM_FALLBACK(md_script_eval_free)(e->fb);
@@ -318,8 +444,8 @@ inline md_script_eval_t* VMD_SHIM_PREFIX(md_script_eval_create)(size_t num_frame
             std::unique_ptr<md_script_eval_t::Prop> p(new md_script_eval_t::Prop());
             p->name = vmd_ir_property_names(vir)[i];
             p->src = vmd_eval_property_data(e->eval, p->name.c_str());
-            memset(&p->dst, 0, sizeof(p->dst));
-            memset(&p->agg, 0, sizeof(p->agg));
+            p->dst = md_script_property_data_t();
+            p->agg = md_script_aggregate_t();
             /* unit[2] (src/main.cpp:1300-1301, printed at :1314-1315): the backend carries the printed form, VMD_SHIM_UNIT makes the
              * md_unit_t of it */
             VMD_SHIM_UNIT(p->dst.unit[0], p->src->unit_str[0]);
@@ -328,10 +454,7 @@ inline md_script_eval_t* VMD_SHIM_PREFIX(md_script_eval_create)(size_t num_frame
         }
     }
     e->mask_words.assign((num_frames + 63) / 64 + 1, 0);
-    memset(&e->mask, 0, sizeof(e->mask));
-    e->mask.bits = e->mask_words.data();
-    e->mask.beg_bit = 0;
-    e->mask.end_bit = (uint32_t)num_frames;
+    for (md_bitfield_t& m : e->mask) VMD_SHIM_BITFIELD_INIT(&m, alloc);      /* mdlib's own storage, reached through mdlib's own functions only */
     e->refresh();
     if (e->eval) {
         vmd_shim::Registry& r = vmd_shim::registry();
@@ -362,10 +485,11 @@ inline void VMD_SHIM_PREFIX(md_script_eval_free)(md_script_eval_t* e) {
             if (live.empty()) r.evals.erase(it);
         }
     }
-    vmd_eval_free(e->eval);
+    vmd_eval_free(e->eval);                      /* waits for a deferred settle (and its callback into *e) that is running */
 #if VMD_SHIM_HAVE_FALLBACK
     if (e->fb) VMD_SHIM_FALLBACK(md_script_eval_free)(e->fb);
 #endif
+    for (md_bitfield_t& m : e->mask) VMD_SHIM_BITFIELD_FREE(&m);
     delete e;
 }
 inline void VMD_SHIM_PREFIX(md_script_eval_clear_data)(md_script_eval_t* e) {
@@ -374,8 +498,7 @@ inline void VMD_SHIM_PREFIX(md_script_eval_clear_data)(md_script_eval_t* e) {
 #if VMD_SHIM_HAVE_FALLBACK
     if (e->fb) VMD_SHIM_FALLBACK(md_script_eval_clear_data)(e->fb);
 #endif
-    std::lock_guard<std::mutex> l(e->mtx);
-    e->refresh();
+    e->advance();
 }
 inline void VMD_SHIM_PREFIX(md_script_eval_interrupt)(md_script_eval_t* e) {
     if (!e) return;
@@ -422,11 +545,15 @@ inline bool VMD_SHIM_PREFIX(md_script_eval_frame_range)(md_script_eval_t* e, con
         const vmd_system_t vsys = vmd_shim::wrap_system(sys);
         vmd_trajectory_i vtraj = vmd_shim::wrap_trajectory(traj);
         ok = vmd_eval_frame_range(e->eval, vir, &vsys, &vtraj, frame_beg, frame_end);
-        std::lock_guard<std::mutex> l(e->mtx);
-        e->refresh();
+        e->advance();
     }
 #if VMD_SHIM_HAVE_FALLBACK
-    if (e->fb && ok) ok = VMD_SHIM_FALLBACK(md_script_eval_frame_range)(e->fb, e->fb_ir, sys, traj, frame_beg, frame_end);
+    if (e->fb && ok) {
+        ok = VMD_SHIM_FALLBACK(md_script_eval_frame_range)(e->fb, e->fb_ir, sys, traj, frame_beg, frame_end);
+        /* the AND of the masks has grown by this range only now: the records' fingerprints move once more, or a GUI that built a
+         * histogram between the two parts would keep it (found by the reference's own update_display_properties, tests/native/ref_callsites.cpp) */
+        e->advance();
+    }
 #endif
     return ok;
 }
@@ -435,9 +562,23 @@ inline bool VMD_SHIM_PREFIX(md_script_eval_frame_range)(md_script_eval_t* e, con
  * (`a1`, `lin`, `plan`, `iso` of the default script) - NULL only where mdlib says NULL */
 inline const md_script_property_data_t* VMD_SHIM_PREFIX(md_script_eval_property_data)(const md_script_eval_t* e, str_t name) {
     if (!e) return nullptr;
-    for (auto& p : e->props) if (vmd_shim::name_is(p->name, name)) return &p->dst;
+    md_script_eval_t* me = const_cast<md_script_eval_t*>(e);
+    std::lock_guard<std::mutex> l(me->mtx);
+    for (auto& p : me->props) if (vmd_shim::name_is(p->name, name)) return &p->dst;
 #if VMD_SHIM_HAVE_FALLBACK
-    if (e->fb) return VMD_SHIM_FALLBACK(md_script_eval_property_data)(e->fb, name);
+    if (e->fb) {
+        /* mdlib's record, handed out as a copy whose fingerprint the shim can move (see md_script_eval_t::Prop); made at the first request */
+        const md_script_property_data_t* rec = VMD_SHIM_FALLBACK(md_script_eval_property_data)(e->fb, name);
+        if (!rec) return nullptr;
+        std::unique_ptr<md_script_eval_t::Prop> p(new md_script_eval_t::Prop());
+        p->name.assign(name.ptr, (size_t)name.len);
+        p->fb_src = rec;
+        p->dst = *rec;                               /* unit[2] and whatever else mdlib keeps in the record */
+        p->agg = md_script_aggregate_t();
+        me->props.push_back(std::move(p));
+        me->refresh();
+        return &me->props.back()->dst;
+    }
 #endif
     return nullptr;
 }
@@ -466,7 +607,16 @@ inline const md_bitfield_t* VMD_SHIM_PREFIX(md_script_eval_frame_mask)(const md_
         }
     }
 #endif
-    return &e->mask;
+    /* into the buffer that was NOT handed out last: a reader still iterating the previous answer keeps a consistent bitfield */
+    md_bitfield_t* out = &e->mask[e->mask_cur ^= 1];
+#ifdef VMD_SHIM_BITFIELD_ASSIGN_WORDS
+    VMD_SHIM_BITFIELD_ASSIGN_WORDS(out, e->mask_words.data(), e->num_frames);
+#else
+    VMD_SHIM_BITFIELD_CLEAR(out);
+    for (size_t w = 0; w < e->mask_words.size(); ++w)
+        for (uint64_t bits = e->mask_words[w]; bits; bits &= bits - 1) VMD_SHIM_BITFIELD_SET(out, w * 64 + (size_t)__builtin_ctzll(bits));
+#endif
+    return out;
 }
 
 /* ---- vis payloads ----------------------------------------------------------------------------------------------------------- */
@@ -534,12 +684,12 @@ inline bool VMD_SHIM_PREFIX(md_script_vis_eval_payload)(md_script_vis_t* vis, co
     if (k1 > out.num_structures) return false;
     if (flags & MD_SCRIPT_VISUALIZE_SDF) {
         vis->sdf.extent = out.extent;
-        md_array_resize(vis->sdf.matrices, k1 - k0, vis->alloc);
-        md_array_resize(vis->sdf.structures, k1 - k0, vis->alloc);
+        md_array_resize(vis->sdf.matrices, k1 - k0, VMD_SHIM_VIS_ALLOC(vis));
+        md_array_resize(vis->sdf.structures, k1 - k0, VMD_SHIM_VIS_ALLOC(vis));
         for (size_t k = k0; k < k1; ++k) {
             memcpy(&vis->sdf.matrices[k - k0], out.matrices + 16 * k, 16 * sizeof(float));        /* mat4_t: 16 floats, column-major */
             md_bitfield_t* bf = &vis->sdf.structures[k - k0];
-            VMD_SHIM_BITFIELD_INIT(bf, vis->alloc);
+            VMD_SHIM_BITFIELD_INIT(bf, VMD_SHIM_VIS_ALLOC(vis));
             for (size_t a = 0; a < out.atoms_per_structure; ++a) VMD_SHIM_BITFIELD_SET(bf, out.structures[k * out.atoms_per_structure + a]);
         }
     }

@@ -1190,7 +1190,10 @@ def export_cases(lib, O, tmp_path, device=False, n_water=1500, box=34.0):
     d = ev.property_data("d").values
     assert len(rows) == F and [float(r.split()[0]) for r in rows] == [0.0, 1.0, 2.0]
     np.testing.assert_allclose([float(r.split()[1]) for r in rows], d, atol=6e-7)
-    assert '@ s1 legend "d"' in (tmp_path / "d.xvg").read_text()
+    assert '@ s1 legend "d (\u00c5)"' in (tmp_path / "d.xvg").read_text()       # "label (unit)": src/main.cpp:5965-5967
+    assert (tmp_path / "g.csv").read_text().split("\n")[0] == "\u00c5,g,"         # x label = the x unit string, :5999
+    ev.export_table(tmp_path / "d_ps.csv", "d", "csv", frame_times=np.arange(F) * 2.0, time_unit="ps")
+    assert (tmp_path / "d_ps.csv").read_text().split("\n")[:2] == ["Time (ps),d (\u00c5),", "0,%.6g," % d[0]]       # :5969-5974
     csv = (tmp_path / "p.csv").read_text().split("\n")
     assert csv[0] == "Frame,p[1],p[2],p[3],"                                      # trailing comma as export_csv writes it
     p = ev.property_data("p").values.reshape(F, 3)

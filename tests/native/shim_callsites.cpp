@@ -10,7 +10,9 @@
 //   :952-953   interrupt while tasks run; :960-964 free
 //   :1300-1315 unit[2] copied and printed; :1304 vis_payload fetched per display property
 //   density_volume.cpp:175-204, 263-269  md_script_vis_eval_payload(SDF): extent, one matrix + one atom bitfield per reference structure
-//   :5718-5830 export_cube re-typed with md_* names only; the file must equal vmd_export_cube's byte for byte
+//   :5718-5830 export_cube: the reference's own function (sliced verbatim, oracle/_ref/viamd_export_slices.inc); its file must equal
+//              vmd_export_cube's byte for byte.  (tests/native/ref_callsites.cpp runs ALL of these call sites verbatim; this program keeps
+//              the no-fallback build of the shim - every property bound, no mdlib behind it - covered without ImGui headers)
 //
 // Prints "OK ..." and exits 0 when the shimmed sequence returns, bit for bit, what direct vmd_* calls return.
 #include <algorithm>
@@ -25,6 +27,10 @@
 #define VMD_SHIM_NO_FALLBACK                // this program binds every property of its script: no mdlib behind the shim (shim_default_script.cpp has one)
 #define VMD_SHIM_PREFIX(name) name          // emit the md_script_eval_* names themselves
 #include "vmd_md_script_shim.h"
+static inline bool md_script_ir_valid(const md_script_ir_t* ir) { return ir != nullptr; }      // src/main.cpp:5750 (this program's ir is an opaque token)
+#define VIAMD_HOST_DOUBLE_EXPORT_ONLY
+#include "viamd_host_double.h"
+#include "_ref/viamd_export_slices.inc"      // export_xvg, export_csv, export_cube, sample_range - VERBATIM from /root/reference/src/main.cpp
 
 static void fail(const char* what) {
     std::fprintf(stderr, "FAIL: %s (%s)\n", what, vmd_last_error());
@@ -267,62 +273,17 @@ int main(int argc, char** argv) {
     }
     if (rep_atom_indices.size() != 3 || !(sdf_extent == 8.0f)) fail("three reference structures, extent = cutoff");
 
-    // ---- export_cube, src/main.cpp:5718-5830, with the md_* names it uses (md_file_printf -> fprintf)
+    // ---- export_cube, src/main.cpp:5718-5830: the REFERENCE's own function, cut verbatim into oracle/_ref/viamd_export_slices.inc by
+    // oracle/make_ref.py (this block used to be a re-typed copy) - it calls md_trajectory_load_frame, md_script_vis_init,
+    // md_script_vis_eval_payload(ATOMS | SDF) through the shim, walks structure 0 with md_bitfield_scan and reads prop_data->dim / ->values
     const char* cube_md = "/tmp/viamd_shim_callsites_md.cube";
     const char* cube_vmd = "/tmp/viamd_shim_callsites_vmd.cube";
     {
-        const md_script_property_data_t* prop_data = vol_dp->prop_data;
-        const md_script_vis_payload_o* vis_payload = vol_dp->vis_payload;
-        md_system_t mol = sys;
-        std::vector<float> coords(3 * N);
-        mol.atom.x = coords.data(); mol.atom.y = coords.data() + N; mol.atom.z = coords.data() + 2 * N;
-        if (!md_trajectory_load_frame(sys.trajectory, 0, NULL, mol.atom.x, mol.atom.y, mol.atom.z)) fail("load frame 0");
-        md_script_vis_t vis = {};
-        md_script_vis_init(&vis, &frame_alloc);
-        md_script_vis_ctx_t ctx = {eval_ir, &sys, sys.trajectory};
-        if (!md_script_vis_eval_payload(&vis, vis_payload, 0, &ctx, MD_SCRIPT_VISUALIZE_ATOMS | MD_SCRIPT_VISUALIZE_SDF)) fail("Failed to visualize volume for export.");
-        FILE* file = fopen(cube_md, "w");
-        if (!file) fail("open cube");
-        fprintf(file, "EXPORTED DENSITY VOLUME FROM VIAMD, UNITS IN BOHR\n");
-        fprintf(file, "OUTER LOOP: X, MIDDLE LOOP: Y, INNER LOOP: Z\n");
-        if (md_array_size(vis.sdf.structures) > 0) {
-            const float angstrom_to_bohr = (float)(1.0 / 0.529177210903);
-            mat4_t M = vis.sdf.matrices[0];
-            const md_bitfield_t* bf = &vis.sdf.structures[0];
-            const int num_atoms = (int)md_bitfield_popcount(bf);
-            const int vol_dim[3] = {prop_data->dim[1], prop_data->dim[2], prop_data->dim[3]};
-            const double extent = vis.sdf.extent * 2.0 * angstrom_to_bohr;
-            const double voxel_ext[3] = {(double)extent / (double)vol_dim[0], (double)extent / (double)vol_dim[1], (double)extent / (double)vol_dim[2]};
-            const double half_ext = extent * 0.5;
-            fprintf(file, "%5i %12.6f %12.6f %12.6f\n", -num_atoms, -half_ext, -half_ext, -half_ext);
-            fprintf(file, "%5i %12.6f %12.6f %12.6f\n", vol_dim[0], voxel_ext[0], 0.0, 0.0);
-            fprintf(file, "%5i %12.6f %12.6f %12.6f\n", vol_dim[1], 0.0, voxel_ext[1], 0.0);
-            fprintf(file, "%5i %12.6f %12.6f %12.6f\n", vol_dim[2], 0.0, 0.0, voxel_ext[2]);
-            const float scl = angstrom_to_bohr;
-            M = mat4_mul(mat4_scale(scl, scl, scl), M);
-            size_t beg_bit = bf->beg_bit;
-            size_t end_bit = bf->end_bit;
-            while ((beg_bit = md_bitfield_scan(bf, beg_bit, end_bit)) != 0) {
-                size_t i = beg_bit - 1;
-                vec3_t coord = vec3_t{mol.atom.x[i], mol.atom.y[i], mol.atom.z[i]};             // md_atom_coord(&mol.atom, i)
-                coord = mat4_mul_vec3(M, coord, 1.0f);
-                int anum = 0;                                                                   // md_atom_atomic_number: the mock molecule has no elements
-                float charge = (float)anum;
-                fprintf(file, "%5i %12.6f %12.6f %12.6f %12.6f\n", anum, charge, coord.x, coord.y, coord.z);
-            }
-            fprintf(file, "%5i %5i\n", 1, 1);
-            int count = 0;
-            for (int x = 0; x < vol_dim[0]; ++x)
-                for (int y = 0; y < vol_dim[1]; ++y)
-                    for (int z = 0; z < vol_dim[2]; ++z) {
-                        int idx = z * vol_dim[0] * vol_dim[1] + y * vol_dim[0] + x;
-                        float val = prop_data->values[idx];
-                        fprintf(file, " %12.6E", val);
-                        if (++count % 6 == 0) fprintf(file, "\n");
-                    }
-        }
-        fclose(file);
-        md_script_vis_free(&vis);
+        static ApplicationState data;
+        data.mold.sys = sys;
+        data.script.eval_ir = const_cast<md_script_ir_t*>(eval_ir);
+        if (!export_cube(data, vol_dp->prop_data, vol_dp->vis_payload, str_t{cube_md, strlen(cube_md)})) fail("the reference's export_cube returned false");
+        host_frame_reset();
     }
 
     // ---- the same two evaluations through the ABI directly: the shim must not change a bit

@@ -15,6 +15,7 @@
 // Prints "OK ..." and exits 0.
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -143,20 +144,34 @@ int main(int argc, char** argv) {
     if (!md_script_ir_valid(eval_ir) || md_script_eval_ir_fingerprint(full_eval) != md_script_ir_fingerprint(eval_ir)) fail("src/main.cpp:986-987: eval and ir fingerprints must match");
     // built with -DVMD_SHIM_DEFERRED_SETTLE the GPU part's results trail the last call by the quiet period (include/vmd_eval.h): VIAMD polls, this
     // program compares at once - so it waits where VIAMD would simply look again a frame later
-    auto settled = [&](md_script_eval_t* e) {
+    auto settled = [&](md_script_eval_t* e, size_t frames_expected = 0) {
 #ifdef VMD_SHIM_DEFERRED_SETTLE
+        // nobody calls into the shim any more - the helper thread settles on its own, and the records VIAMD polls
+        // (fingerprint, max_value: src/main.cpp:1508-1509, density_volume.cpp:281) must follow by themselves (vmd_eval_set_settled_callback)
+        if (e->eval && frames_expected) {
+            const auto t0 = std::chrono::steady_clock::now();
+            for (;;) {
+                bool follows = vmd_eval_frames_done(e->eval) == frames_expected;
+                for (auto& p : e->props)
+                    if (p->src) follows = follows && vmd_shim::peek(p->dst.fingerprint) == md_script_eval_t::mix(vmd_shim::peek(p->src->fingerprint), e->epoch.load()) &&
+                                          vmd_shim::peek(p->dst.max_value) == vmd_shim::peek(p->src->max_value);
+                if (follows) break;
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) fail("deferred settle: the records handed to VIAMD did not follow the helper's settle");
+                std::this_thread::sleep_for(std::chrono::microseconds(200));
+            }
+        }
         if (e->eval && !vmd_eval_wait_settled(e->eval)) fail("vmd_eval_wait_settled");
 #else
-        (void)e;
+        (void)e; (void)frames_expected;
 #endif
     };
     md_script_eval_clear_data(full_eval);
     if (!pool_task(full_eval, 0, (uint32_t)F, 4)) fail("Eval Full");
-    settled(full_eval);
+    settled(full_eval, F);
     const uint32_t beg_frame = (uint32_t)(F / 4), end_frame = (uint32_t)(F - F / 4);
     md_script_eval_clear_data(filt_eval);
     if (!pool_task(filt_eval, beg_frame, end_frame, 3)) fail("Eval Filt");
-    settled(filt_eval);
+    settled(filt_eval, end_frame - beg_frame);
 
     // ---- what VIAMD then reads: the hot-path properties = direct vmd_* calls, bit for bit; the others = mdlib's (the mock's) own values
     auto prop = [&](const md_script_eval_t* e, const char* nm) { return md_script_eval_property_data(e, str_t{nm, strlen(nm)}); };

@@ -114,19 +114,29 @@ def test_native_host_from_dcd_and_script_text_on_the_emulator(tmp_path, emu_lib,
 
 SHIM_SRC = os.path.join(ROOT, "tests", "native", "shim_callsites.cpp")
 SHIM_EXE = os.path.join(ROOT, "tests", "native", "shim_callsites")
+# C++20: the reference's export_cube uses designated initialisers (src/main.cpp:5751-5755); -Wno-format: it prints a size_t with %i (:5671)
+SHIM_FLAGS = ["-std=c++20", "-Wall", "-Wno-format", "-Wno-unused-function", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "tests", "native"),
+              "-I" + os.path.join(ROOT, "oracle")]
 
 
 def build_shim_callsites():
     """VIAMD's call sequence re-typed against a mock of mdlib's declarations, bound to libviamd_amd.so through
     include/vmd_md_script_shim.h (compiled by __graft_entry__.build() too: a boundary that stops compiling is caught without a GPU)."""
     from viamd_amd import build
+    from oracle import make_ref
     lib = build.build()
-    deps = [SHIM_SRC, lib, os.path.join(ROOT, "include", "vmd_md_script_shim.h"), os.path.join(ROOT, "tests", "native", "md_mock.h")]
+    # the program includes the reference's export_cube VERBATIM (oracle/_ref/viamd_export_slices.inc: generated here from /root/reference,
+    # travels to the GPU box in the git-ignored oracle/_ref/)
+    if not make_ref.slices_available():
+        if os.path.exists(SHIM_EXE):
+            return SHIM_EXE
+        pytest.skip("neither /root/reference nor oracle/_ref/viamd_export_slices.inc nor a prebuilt tests/native/shim_callsites is present")
+    deps = [SHIM_SRC, lib, make_ref.INC_EXPORT] + [os.path.join(ROOT, "tests", "native", h) for h in ("md_mock.h", "viamd_host_double.h")] + \
+           [os.path.join(ROOT, "include", "vmd_md_script_shim.h")]
     if os.path.exists(SHIM_EXE) and os.path.getmtime(SHIM_EXE) >= max(os.path.getmtime(d) for d in deps):
         return SHIM_EXE
-    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", SHIM_SRC, "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "tests", "native"),
-                           "-L" + os.path.join(ROOT, "viamd_amd"), "-lviamd_amd", "-L/opt/rocm/lib", "-Wl,-rpath,$ORIGIN/../../viamd_amd",
-                           "-Wl,-rpath,/opt/rocm/lib", "-Wl,-rpath-link,/opt/rocm/lib", "-lpthread", "-o", SHIM_EXE])
+    subprocess.check_call(["g++"] + SHIM_FLAGS + ["-O2", SHIM_SRC, "-L" + os.path.join(ROOT, "viamd_amd"), "-lviamd_amd", "-L/opt/rocm/lib",
+                           "-Wl,-rpath,$ORIGIN/../../viamd_amd", "-Wl,-rpath,/opt/rocm/lib", "-Wl,-rpath-link,/opt/rocm/lib", "-lpthread", "-o", SHIM_EXE])
     return SHIM_EXE
 
 
@@ -138,8 +148,7 @@ def test_md_script_shim_call_sites_on_the_emulator(tmp_path, emu_lib):
     assert os.access(build_shim_callsites(), os.X_OK)                  # links against the product library
     emu = conftest.build_emu()
     exe = str(tmp_path / "shim_callsites_emu")
-    subprocess.check_call(["g++", "-std=c++17", "-O1", SHIM_SRC, "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "tests", "native"), emu,
-                           "-Wl,-rpath," + os.path.dirname(emu), "-lpthread", "-o", exe])
+    subprocess.check_call(["g++"] + SHIM_FLAGS + ["-O1", SHIM_SRC, emu, "-Wl,-rpath," + os.path.dirname(emu), "-lpthread", "-o", exe])
     out = subprocess.run([exe, "12"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     assert out.stdout.startswith("OK frames=12"), out.stdout
@@ -150,6 +159,48 @@ def test_md_script_shim_call_sites(gpu_lib):
     out = subprocess.run([build_shim_callsites(), "48"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     assert out.stdout.startswith("OK frames=48"), out.stdout
+
+
+def build_ref_callsites():
+    """oracle/_ref/ref_callsites: VIAMD's OWN call sites (cut verbatim out of /root/reference/src by oracle/make_ref.py) as a host of the
+    shim, linked against the product library.  Needs /root/reference to compile (ImGui headers, the slices): built in this container
+    (also by __graft_entry__.build()), travels prebuilt to the GPU box."""
+    from viamd_amd import build
+    from oracle import make_ref
+    build.build()
+    return make_ref.build_callsites()
+
+
+def test_viamds_own_call_sites_on_the_emulator(tmp_path, emu_lib):
+    """VERDICT r05 next #1.  tests/native/ref_callsites.cpp: the reference's init_display_properties, its main-loop evaluation block (eval_init
+    -> md_script_eval_free / _create x 2 -> fingerprint check -> _clear_data -> pool tasks calling md_script_eval_frame_range), its
+    update_display_properties (compute_histogram_masked over md_script_eval_frame_mask / downsample_histogram) and its export_cube /
+    export_csv / export_xvg / sample_range - VERBATIM line ranges of src/main.cpp, src/viamd.h, src/task_system.h - run VIAMD's default
+    script through include/vmd_md_script_shim.h with a CPU mock of mdlib behind it: every array the reference's DisplayProperty reads is
+    bit-identical to direct vmd_* calls, its display histograms equal vmd_downsample_histogram / vmd_compute_histogram_masked bit for bit,
+    its cube / csv / xvg files equal vmd_export_cube / vmd_export_property_table byte for byte.  Here against the emulator build."""
+    import conftest
+    from oracle import make_ref
+    if not make_ref.available():
+        pytest.skip("/root/reference is not present: the program cannot be compiled here (the GPU suite runs the prebuilt oracle/_ref/ref_callsites)")
+    assert os.access(build_ref_callsites(), os.X_OK)                   # the GPU box's copy, linked against the product library
+    emu = conftest.build_emu()
+    make_ref.write_callsite_slices()
+    for name, extra in (("ref_callsites_emu", []), ("ref_callsites_emu_deferred", ["-DVMD_SHIM_DEFERRED_SETTLE"])):
+        exe = str(tmp_path / name)
+        subprocess.check_call(make_ref.callsites_compile_cmd(exe, extra + [emu, "-Wl,-rpath," + os.path.dirname(emu)], opt="-O1"))
+        out = subprocess.run([exe, "12", str(tmp_path)], capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stderr[-3000:]
+        assert out.stdout.startswith("OK frames=12 display_properties=21 (temporal 5, distribution 14, volume 2)") and "log_errors=0" in out.stdout, out.stdout
+
+
+@pytest.mark.gpu
+def test_viamds_own_call_sites(gpu_lib, tmp_path):
+    exe = build_ref_callsites()
+    assert exe is not None and os.access(exe, os.X_OK), "oracle/_ref/ref_callsites must travel prebuilt to the GPU box (python oracle/make_ref.py)"
+    out = subprocess.run([exe, "64", str(tmp_path)], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert out.stdout.startswith("OK frames=64 display_properties=21") and "log_errors=0" in out.stdout, out.stdout
 
 
 SHIM_DEFAULT_SRC = os.path.join(ROOT, "tests", "native", "shim_default_script.cpp")

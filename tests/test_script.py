@@ -204,6 +204,19 @@ def test_partial_compile_edge_cases(host_lib, topo):
         # an unbalanced statement swallows the rest of the text: reported as one
         ("g = rdf(all, all, 5.0; h = rdf(all, all, 4.0);", [], ["g"]),
     ]
+    # a compiled property a SKIPPED statement uses stays in the fallback's text (mdlib could not compile `x = d * 2` without
+    # `d`), transitively; one nobody uses is blanked as before; offsets never move
+    text = "d = distance(1, 2); e = distance(2, 3); x = d * 2; g = rdf(all, all, 5.0); {a,b} = f(x, g);"
+    for compile_ in (lambda t: script.compile_script(t, topo, lib=host_lib, partial=True)[::2], lambda t: script.compile_script_native(t, topo, lib=host_lib, partial=True)):
+        ir_, rep = compile_(text)
+        assert ir_.property_names() == ["d", "e", "g"] and [k["names"] for k in rep["skipped"]] == ["x", "a,b"]
+        fb = rep["fallback_source"]
+        assert len(fb) == len(text)
+        assert fb == "d = distance(1, 2);                     x = d * 2; g = rdf(all, all, 5.0); {a,b} = f(x, g);"
+    # ... transitively: y is skipped and uses h; h is compiled and (as a selection argument would) mentions nothing else; k uses nothing skipped
+    text = "s = residue(1); h = distance(s, 5); k = distance(1, 2); y = h + 1;"
+    ir_, rep = script.compile_script_native(text, topo, lib=host_lib, partial=True)
+    assert ir_.property_names() == ["h", "k"] and rep["fallback_source"] == "s = residue(1); h = distance(s, 5);                     y = h + 1;"
     for text, compiled, skipped in cases_:
         ir_py, _, rep_py = script.compile_script(text, topo, lib=host_lib, partial=True)
         ir_c, rep_c = script.compile_script_native(text, topo, lib=host_lib, partial=True)

@@ -18,6 +18,7 @@ VOLUME_DIM = 128
 
 c_float_p = C.POINTER(C.c_float)
 LOG_FN = C.CFUNCTYPE(None, C.c_int, C.c_char_p, C.c_void_p)      # vmd_log_fn
+SETTLED_FN = C.CFUNCTYPE(None, C.c_void_p)                        # vmd_eval_set_settled_callback
 c_int32_p = C.POINTER(C.c_int32)
 c_uint8_p = C.POINTER(C.c_uint8)
 c_uint64_p = C.POINTER(C.c_uint64)
@@ -174,12 +175,13 @@ SIGNATURES = [
     ("vmd_eval_defer_volume_views", C.c_bool, [_vp, C.c_bool]),
     ("vmd_eval_wait_settled", C.c_bool, [_vp]),
     ("vmd_eval_set_deferred_settle", C.c_bool, [_vp, C.c_int]),
+    ("vmd_eval_set_settled_callback", C.c_bool, [_vp, SETTLED_FN, C.c_void_p]),
     ("vmd_eval_set_frame_mask", None, [_vp, c_uint8_p, C.c_size_t]),
     ("vmd_eval_sdf_structures", c_int32_p, [_vp, C.c_char_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     ("vmd_eval_sdf_payload", C.c_bool, [_vp, C.c_char_p, C.POINTER(System), C.POINTER(TrajectoryI), C.c_uint32, C.POINTER(SdfPayload)]),
     ("vmd_export_xvg", C.c_bool, [C.c_char_p, C.POINTER(c_float_p), C.POINTER(C.c_char_p), C.c_size_t, C.c_size_t]),
     ("vmd_export_csv", C.c_bool, [C.c_char_p, C.POINTER(c_float_p), C.POINTER(C.c_char_p), C.c_size_t, C.c_size_t]),
-    ("vmd_export_property_table", C.c_bool, [C.c_char_p, _vp, C.c_char_p, C.c_char_p, c_double_p, C.c_int]),
+    ("vmd_export_property_table", C.c_bool, [C.c_char_p, _vp, C.c_char_p, C.c_char_p, c_double_p, C.c_char_p, C.c_int]),
     ("vmd_export_cube", C.c_bool, [C.c_char_p, _vp, C.c_char_p, C.POINTER(System), C.POINTER(TrajectoryI), C.c_uint32, c_uint8_p]),
     ("vmd_eval_reduce", C.c_bool, [_vp, C.POINTER(CollectiveI), _vp]),
     ("vmd_eval_reduce_stats", None, [_vp, C.POINTER(ReduceStats)]),
@@ -251,6 +253,7 @@ SIGNATURES = [
     ("vmd_clear_last_error", None, []),
     ("vmd_last_stage", C.c_char_p, []),
     ("vmd_log_register", None, [LOG_FN, _vp]),
+    ("vmd_log_message", None, [C.c_int, C.c_char_p]),
     ("vmd_version", C.c_char_p, []),
     ("vmd_set_option", C.c_int, [C.c_char_p, C.c_int]),
     ("vmd_profile_reset", None, []),

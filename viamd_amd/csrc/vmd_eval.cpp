@@ -54,6 +54,9 @@ static void vmd_log(int level, const char* msg) {
     else fprintf(stderr, "[viamd_amd] %s: %s\n", level >= VMD_LOG_ERROR ? "error" : "info", msg);
 }
 
+// a host-side layer (include/vmd_md_script_shim.h) reports through the same channel as the library
+extern "C" void vmd_log_message(int level, const char* message) { if (message) vmd_log(level, message); }
+
 static bool vmd_fail(const char* fmt, ...) {
     char buf[512];
     va_list ap;
@@ -1128,6 +1131,10 @@ struct vmd_script_eval_t {
             std::atomic<int64_t> last_leave_ns{0};          // when the last call left (steady clock)
             std::atomic<uint64_t> settles{0};
             vmd_system_t sys; vmd_trajectory_i traj;        // (mtx) copies of the caller's records: what the deferred settle evaluates from
+            // vmd_eval_set_settled_callback: told after every settle the helper (or vmd_eval_wait_settled) has performed, without any lock of
+            // the eval held.  Written before the evaluation's calls (like lone_pref), read by the helper: atomics, not a lock
+            std::atomic<void (*)(void*)> on_settled{nullptr};
+            std::atomic<void*> on_settled_user{nullptr};
         } helper;
     } ra;
     vmd_reduce_stats_t reduce_stats = {};
@@ -3592,6 +3599,9 @@ static void lone_helper_main(vmd_script_eval_t* e) {
                 retry = true;                                                     // a call is inside: it stamps last_leave when it goes
             }
             ra.flight.fetch_sub(1, std::memory_order_acq_rel);
+            // the host's records of this eval follow NOW (the shim re-publishes fingerprint / ranges / max_value: ADVICE r05 #1) - after the
+            // settle, before `busy` drops: clear_data / interrupt / free wait for the callback too, it never runs on a freed host object
+            if (!retry) if (auto cb = h.on_settled.load(std::memory_order_acquire)) cb(h.on_settled_user.load(std::memory_order_acquire));
         }
         lk.lock();
         h.busy = false;
@@ -3639,6 +3649,7 @@ static void lone_stop(vmd_script_eval_t* e) {           // vmd_eval_free
     {
         std::lock_guard<std::mutex> l(h.mtx);
         if (!h.started) return;
+        e->interrupt = true;                            // a settle that is running ends at its next batch boundary: nobody will read its results
         h.quit = true;
         h.cv.notify_one();
     }
@@ -3693,6 +3704,12 @@ extern "C" bool vmd_eval_frame_range(vmd_script_eval_t* eval, const vmd_script_i
     return ok && lok;
 }
 
+extern "C" bool vmd_eval_set_settled_callback(vmd_script_eval_t* eval, void (*fn)(void*), void* user) {
+    if (!eval) return vmd_fail("eval is NULL");
+    eval->ra.helper.on_settled_user.store(user, std::memory_order_release);
+    eval->ra.helper.on_settled.store(fn, std::memory_order_release);
+    return true;
+}
 extern "C" bool vmd_eval_set_deferred_settle(vmd_script_eval_t* eval, int mode) {
     if (!eval) return vmd_fail("eval is NULL");
     eval->ra.lone_pref.store(mode < 0 ? -1 : (mode ? 1 : 0), std::memory_order_relaxed);       // takes effect at the next clear_data / first small call of an evaluation
@@ -3720,6 +3737,7 @@ extern "C" bool vmd_eval_wait_settled(vmd_script_eval_t* eval) {
     if (ra.on.load(std::memory_order_acquire) && (ra.marks_pending.load() || ra.views_dirty.load())) ok = ra_settle(eval, &sys, &traj, true);
     ra.flight.fetch_sub(1, std::memory_order_acq_rel);
     if (ok) { std::lock_guard<std::mutex> ql(eval->queue_mtx); if (ra.failed) { g_last_error = ra.error; ok = false; } }
+    if (auto cb = h.on_settled.load(std::memory_order_acquire)) cb(h.on_settled_user.load(std::memory_order_acquire));
     return ok;
 }
 

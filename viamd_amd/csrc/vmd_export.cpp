@@ -79,10 +79,17 @@ extern "C" bool vmd_export_csv(const char* path, const float* const* columns, co
     return write_table("vmd_export_csv", kCsv, path, columns, labels, num_columns, num_rows);
 }
 
-// the table draw_property_export_window builds for one property (src/main.cpp:5953-6040): temporal -> time column + one column
-// per population member ("label[i]", 1-based); distribution -> sample_range(x_min, x_max, num_bins) + the display histogram
+// the table draw_property_export_window builds for one property (src/main.cpp:5953-6040), labels included:
+//   temporal (:5953-5990)      time column - trajectory times (frame_times) or, without them, the frame index - labelled "Frame", or
+//                              "Time (<unit>)" when the trajectory has a time unit (:5969-5974); then y_values, labelled `name`, or
+//                              "name (<unit>)" when unit[1] is set (:5965-5967; a temporal item's unit_str[0] holds the y unit, :1327); a
+//                              population gets one column per member, "name[i]" 1-based (:5979-5988)
+//   distribution (:5998-6020)  x = sample_range(hist.x_min, hist.x_max, num_bins) labelled with the x unit string (unit_str[0]); y = the
+//                              display histogram labelled `name`, or "name (<unit_str[0]>)" when unit_str[1] is not empty - the reference
+//                              prints `dp.unit_str`, which decays to unit_str[0] (:6003); kept as it is
+// pinned to the reference's own export_csv / export_xvg / sample_range by tests/native/ref_callsites.cpp
 extern "C" bool vmd_export_property_table(const char* path, vmd_script_eval_t* eval, const char* name, const char* format,
-                                          const double* frame_times, int num_bins) {
+                                          const double* frame_times, const char* time_unit, int num_bins) {
     if (!path || !eval || !name || !format) return exp_fail("vmd_export_property_table: NULL argument");
     if (!vmd_eval_wait_settled(eval)) return false;
     const vmd_script_property_data_t* pd = vmd_eval_property_data(eval, name);
@@ -92,27 +99,30 @@ extern "C" bool vmd_export_property_table(const char* path, vmd_script_eval_t* e
     std::vector<std::vector<float>> cols;
     std::vector<std::string> labels;
     size_t rows = 0;
+    const char* const unit_x = pd->unit_str[0] ? pd->unit_str[0] : "";
+    const char* const unit_y = pd->unit_str[1] ? pd->unit_str[1] : "";
     if (pd->weights) {                                   // distribution
         const int nb = num_bins > 0 ? num_bins : 128;    // display bins (src/viamd.h:341)
         rows = (size_t)nb;
         std::vector<float> x(nb), g(nb);
-        const double beg = pd->min_range[0], end = pd->max_range[0];
-        const double step = nb > 1 ? (end - beg) / (double)(nb - 1) : 0.0;       // sample_range, src/main.cpp:5832-5840
-        for (int i = 0; i < nb; ++i) x[i] = (float)(beg + step * (double)i);
+        const float beg = (float)(double)pd->min_range[0], end = (float)(double)pd->max_range[0];      // Histogram::x_min / x_max are doubles handed to float parameters
+        const double step = (end - beg) / (double)(nb - 1);                      // sample_range, src/main.cpp:5834-5841 (one bin: inf, like the reference)
+        for (int i = 0; i < nb; ++i) x[i] = (float)((double)beg + step * (double)i);
         vmd_downsample_histogram(g.data(), nb, pd->values, pd->weights, pd->dim[2]);
-        cols.push_back(std::move(x)); labels.push_back("");
-        cols.push_back(std::move(g)); labels.push_back(name);
+        cols.push_back(std::move(x)); labels.push_back(unit_x);
+        cols.push_back(std::move(g)); labels.push_back(unit_y[0] ? std::string(name) + " (" + unit_x + ")" : std::string(name));
     } else if (pd->dim[3] == 0 || pd->dim[2] == 0) {    // temporal: values[frame * dim[1] + i]
         const size_t F = (size_t)pd->dim[0], D = (size_t)std::max(1, pd->dim[1]);
         rows = F;
         std::vector<float> t(F);
         for (size_t f = 0; f < F; ++f) t[f] = frame_times ? (float)frame_times[f] : (float)f;
-        cols.push_back(std::move(t)); labels.push_back(frame_times ? "Time" : "Frame");
+        cols.push_back(std::move(t));
+        labels.push_back(time_unit && time_unit[0] ? std::string("Time (") + time_unit + ")" : std::string("Frame"));
         for (size_t i = 0; i < D; ++i) {
             std::vector<float> c(F);
             for (size_t f = 0; f < F; ++f) c[f] = pd->values[f * D + i];
             cols.push_back(std::move(c));
-            labels.push_back(D > 1 ? std::string(name) + "[" + std::to_string(i + 1) + "]" : std::string(name));
+            labels.push_back(D > 1 ? std::string(name) + "[" + std::to_string(i + 1) + "]" : unit_y[0] ? std::string(name) + " (" + unit_y + ")" : std::string(name));
         }
     } else {
         return exp_fail(std::string("Export: '") + name + "' is a volume; use vmd_export_cube");

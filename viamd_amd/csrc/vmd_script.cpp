@@ -343,6 +343,12 @@ void compile(vmd_script_ir_t* ir, const char* source, const vmd_topology_t* t, R
     Parser p(toks, topo, env);
     auto check = [](bool ok) { if (!ok) throw ScriptError(vmd_last_error()); };
     std::string fallback(source);
+    // a compiled property that a SKIPPED statement uses (`d = distance(1,2); x = d * 2;`) must stay in the fallback's text, or
+    // mdlib cannot compile the reduced script.  Blanked statements {left-hand name, token range, byte range} and the token ranges of the
+    // skipped ones are recorded; after the pass every blanked statement whose name a kept statement mentions is restored, transitively
+    struct Blanked { std::string name; size_t tok_first, tok_end, beg, end; bool kept; };
+    std::vector<Blanked> blanked;
+    std::vector<std::pair<size_t, size_t>> skipped_toks;
     while (p.peek().kind != T_END) {
         if (p.accept(";")) continue;
         const size_t first = p.i;
@@ -464,6 +470,7 @@ void compile(vmd_script_ir_t* ir, const char* source, const vmd_topology_t* t, R
                 // the fallback evaluates the text WITHOUT this statement: blanked in place, so that every other offset stays what the editor shows
                 const size_t e = last < toks.size() ? toks[last].end : toks[last - 1].end;
                 for (size_t c = toks[first].beg; c < e && c < fallback.size(); ++c) if (fallback[c] != '\n') fallback[c] = ' ';
+                blanked.push_back(Blanked{names, first, last, toks[first].beg, std::min(e, fallback.size()), false});
             }
         } catch (const ScriptError& e) {
             if (!report) throw;
@@ -471,10 +478,30 @@ void compile(vmd_script_ir_t* ir, const char* source, const vmd_topology_t* t, R
             if (names.empty()) names = toks[first].text;
             const size_t send = last > first ? toks[last - 1].end : toks[first].end;
             report->skipped.push_back({names, toks[first].beg, send, e.what()});
+            skipped_toks.emplace_back(first, last);
             p.i = last < toks.size() ? last + 1 : last;
         }
     }
-    if (report) report->fallback_source = fallback;
+    if (report) {
+        std::set<std::string> used;
+        // identifiers on the right-hand side of a statement (everything after its first `=`; the whole statement when it has none)
+        auto collect = [&](size_t a, size_t b) {
+            size_t k = a;
+            for (size_t q = a; q < b && q < toks.size(); ++q) if (toks[q].kind == T_OP && toks[q].text == "=") { k = q + 1; break; }
+            for (; k < b && k < toks.size(); ++k) if (toks[k].kind == T_ID) used.insert(toks[k].text);
+        };
+        for (const auto& r : skipped_toks) collect(r.first, r.second);
+        for (bool changed = true; changed;) {
+            changed = false;
+            for (Blanked& b : blanked) {
+                if (b.kept || !used.count(b.name)) continue;
+                b.kept = changed = true;
+                for (size_t c = b.beg; c < b.end; ++c) fallback[c] = source[c];        // the GPU still evaluates it; mdlib evaluates it too, for its users
+                collect(b.tok_first, b.tok_end);
+            }
+        }
+        report->fallback_source = fallback;
+    }
 }
 
 }  // namespace

@@ -246,6 +246,9 @@ class ScriptEval:
     def frame_range(self, sys, traj, frame_beg, frame_end):
         """md_script_eval_frame_range(eval, ir, &sys, traj, beg, end); False on interrupt; raises on error."""
         sysp = C.byref(sys.c) if sys is not None else None
+        # deferred-settle mode: the helper thread evaluates from copies of these records after the call has returned (ADVICE r05): the
+        # objects behind them - coordinate arrays, ctypes callbacks - stay referenced until the next call, wait_settled, clear_data or free
+        self._last_inputs = (sys, traj)
         ok = self.lib.vmd_eval_frame_range(self.h, self.ir.h, sysp, traj.interface(), int(frame_beg), int(frame_end))
         if not ok:
             if self.lib.vmd_eval_frames_done(self.h) < self.num_frames() and self._interrupted():
@@ -390,11 +393,12 @@ def _export_cube(self, path, name, sys, traj, frame=0, atomic_numbers=None):
         raise VmdError(self.lib.last_error())
 
 
-def _export_table(self, path, name, fmt="xvg", frame_times=None, num_bins=0):
+def _export_table(self, path, name, fmt="xvg", frame_times=None, num_bins=0, time_unit=None):
     """the XVG / CSV table VIAMD's export window writes for a temporal or distribution property (src/main.cpp:5953-6040)"""
     ft = None if frame_times is None else np.ascontiguousarray(frame_times, np.float64)
     if not self.lib.vmd_export_property_table(str(path).encode(), self.h, name.encode(), fmt.encode(),
-                                              ft.ctypes.data_as(L.c_double_p) if ft is not None else None, int(num_bins)):
+                                              ft.ctypes.data_as(L.c_double_p) if ft is not None else None,
+                                              time_unit.encode() if time_unit else None, int(num_bins)):
         raise VmdError(self.lib.last_error())
 
 

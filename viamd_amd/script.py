@@ -279,6 +279,7 @@ def compile_script(text, topo, lib=None, partial=False):
     p = _Parser(toks, topo, env)
     skipped = []
     fallback = list(text)
+    blanked, skipped_toks = [], []      # compiled property statements [name, tok_first, tok_end, beg, end, kept]; token ranges of the skipped ones
     while p.peek()[0] is not None:
         if p.accept(";"):
             continue
@@ -318,13 +319,37 @@ def compile_script(text, topo, lib=None, partial=False):
                 for c in range(spans[first][0], min(e, len(fallback))):
                     if fallback[c] != "\n":
                         fallback[c] = " "
+                blanked.append([names, first, last, spans[first][0], min(e, len(fallback)), False])
         except (ValueError, VmdError) as e:   # ScriptError, int() / float() on a malformed number, a descriptor the library refuses
             if not partial:
                 raise
             send = spans[last - 1][1] if last > first else spans[first][1]
             skipped.append(dict(names=names or toks[first][1], beg=spans[first][0], end=send, reason=str(e)))
+            skipped_toks.append((first, last))
             p.i = last + 1 if last < len(toks) else last
     if partial:
+        # a compiled property that a skipped statement uses stays in the fallback's text (the twin of vmd_script.cpp)
+        used = set()
+
+        def collect(a, b):
+            k = a
+            for q in range(a, min(b, len(toks))):
+                if toks[q][0] == "op" and toks[q][1] == "=":
+                    k = q + 1
+                    break
+            used.update(toks[q][1] for q in range(k, min(b, len(toks))) if toks[q][0] == "id")
+
+        for a, b in skipped_toks:
+            collect(a, b)
+        changed = True
+        while changed:
+            changed = False
+            for item in blanked:
+                if item[5] or item[0] not in used:
+                    continue
+                item[5] = changed = True
+                fallback[item[3]:item[4]] = text[item[3]:item[4]]
+                collect(item[1], item[2])
         return ir, info, dict(skipped=skipped, fallback_source="".join(fallback))
     return ir, info
 
