@@ -183,8 +183,21 @@ def cpu_baseline(name, w, topo, info):
     if simd is not None:
         simd["avx512"] = bool(O.have_avx512())
     best = simd if (simd is not None and simd["value"] > scalar["value"]) else scalar
+    # VERDICT r05 next #4c: the CPU leg moves by +-2 % from run to run (16 cores of a shared 128-core node) while the GPU side moves by 0.2 %: the
+    # reported value is the MEDIAN of three samples of the winning leg on the same frames, the spread is printed
+    fast = best is simd
+    traj3 = frames_for(best["frames"])
+    samples = [best["value"]]
+    for _ in range(2):
+        t = time.perf_counter()
+        run(traj3, cores, fast)
+        samples.append(best["frames"] / (time.perf_counter() - t))
+    del traj3
+    median = sorted(samples)[1]
+    best = dict(best, value=median, seconds=best["frames"] / median, pairs_per_s=best["pairs_per_s"] * median / samples[0])
     node = node_physical_cores()
     return {"value": best["value"], "unit": "frames/s", "cores": cores, "kind": "port",
+            "samples": samples, "spread": (max(samples) - min(samples)) / median, "statistic": "median of three samples of the same frames",
             "sample": f"{best['frames']} frames of {name} ({w['atoms']} atoms), {'tuned CPU code (half shell, AVX-512; oracle for SDF)' if best is simd else 'oracle (cell-list RDF / SDF align+scatter)'}, "
                       f"{cores} OpenMP threads, dynamic grain 1 over frames, {best['seconds']:.1f} s",
             "pairs_per_s": best["pairs_per_s"],
@@ -195,6 +208,106 @@ def cpu_baseline(name, w, topo, info):
             "extrapolated_to_node": {"physical_cores": node, "value": best["value"] * node / cores if node else None, "unit": "frames/s",
                                      "note": "value x node cores / cores used: the lease grants a slice of the node's CPUs"},
             "host": {"logical_cpus": logical, "physical_cores": physical, "cgroup_quota_cores": quota}}
+
+
+def c1_system():
+    """SURVEY 8d's C1 stand-in (datasets/1ALA-500.pdb is a missing blob): a 112-atom capped deca-alanine-like chain - ACE (6 atoms), 10 x ALA
+    (N H CA HA CB HB1 HB2 HB3 C O), NME (6 atoms) - no periodic cell, 500 frames of a helix-like frame 0 + Gaussian jitter (sigma 0.3 A, seed 1).
+    -> (elements, resnames, residue_index, coords [F][3][N])"""
+    rng = np.random.default_rng(1)
+    ala = ["N", "H", "C", "H", "C", "H", "H", "H", "C", "O"]
+    elements = ["C", "H", "H", "H", "C", "O"] + ala * 10 + ["N", "H", "C", "H", "H", "H"]
+    resnames = ["ACE"] * 6 + ["ALA"] * 100 + ["NME"] * 6
+    residue_index = [0] * 6 + [1 + i // 10 for i in range(100)] + [11] * 6
+    n = len(elements)
+    assert n == 112
+    base = np.zeros((3, n), np.float32)
+    for i in range(n):
+        r = residue_index[i]
+        ang = 1.745 * r                                    # 100 degrees per residue, 1.5 A rise: an alpha helix's backbone trace
+        centre = np.array([2.3 * np.cos(ang), 2.3 * np.sin(ang), 1.5 * r])
+        base[:, i] = centre + rng.normal(0.0, 0.9, 3)
+    F = 500
+    coords = (base[None] + rng.normal(0.0, 0.3, (F, 3, n))).astype(np.float32)
+    return elements, resnames, np.asarray(residue_index, np.int32), coords
+
+
+C1_SCRIPT = "s1 = resname(\"ALA\")[2:8]; d1 = distance(10,30); r = rdf(element('C'), element('H'), 10.0); v = sdf(s1, element('H'), 10.0);"
+
+
+def run_c1(ctx, dry):
+    """secondary.c1: the size class of VIAMD's default dataset with the hot-path statements of VIAMD's default script
+    (src/main.cpp:528: d1, r, v), once through the boundary the way VIAMD calls it - clear_data, then 16 pool threads pulling ranges of ONE frame
+    off [0, 500) (src/main.cpp:990-997) - from a host-memory trajectory (VIAMD's frame cache), and once through the oracle on the same host
+    cores with the same dynamic grain-1 hand-out.  The ratio is what include/vmd_md_script_shim.h's work threshold is set from."""
+    import torch
+    from oracle import oracle as O
+    from viamd_amd import _lib as L
+    V, lib, script = ctx["V"], ctx["lib"], ctx["script"]
+    elements, resnames, residue_index, coords = c1_system()
+    F, _, N = coords.shape
+    if dry:
+        F = 16
+        coords = coords[:F]
+    from viamd_amd import synth
+    topo = script.Topology(elements=elements, resnames=resnames, residue_index=residue_index,
+                           mass=np.array([synth.MASS.get(e, 12.0) for e in elements], np.float32))
+    ir, info = script.compile_script(C1_SCRIPT, topo)
+    cell = V.make_unitcell(None)                               # no periodic cell
+    traj = V.PinnedHostTrajectory(F, N)
+    traj.upload(coords, cell)
+    sysm = V.MolSystem(N, mass=topo.mass, unitcell=cell)
+    ev = V.ScriptEval(F, ir)
+    threads = 16
+
+    def gpu_once(pooled):
+        ev.clear_data()
+        t = time.perf_counter()
+        ok = ev.frame_range_pooled(sysm, traj, 0, F, threads, 1) if pooled else ev.frame_range(sysm, traj, 0, F)
+        assert ok
+        return time.perf_counter() - t
+
+    for _ in range(3):
+        gpu_once(True)
+    n = 3 if dry else 30
+    pooled = sorted(gpu_once(True) for _ in range(n))[n // 2]
+    one_call = sorted(gpu_once(False) for _ in range(n))[n // 2]
+    hits_r = int(ev.property_data("r").counts.sum())
+    vox_v = int(ev.property_data("v").counts.sum())
+    # the same three statements on the CPU: one thread per core this process is granted, frames handed out dynamically (grain 1)
+    logical, physical, quota = host_cpus()
+    cores = max(1, min(physical, int(np.ceil(quota))) if quota else physical)
+    ocell = O.make_cell(None)
+    cells = [ocell] * F
+    mass = topo.mass
+
+    def cpu_once(nthreads):
+        t = time.perf_counter()
+        for nm, d in info.items():
+            if d["kind"] == "rdf":
+                O.rdf_run(coords, cells, d["ref"], d["target"], d["rmin"], d["rmax"], nthreads=nthreads)
+            elif d["kind"] == "sdf":
+                O.sdf_run(coords, cells, d["structures"], mass[d["structures"]], d["target"], d["cutoff"], nthreads=nthreads)
+        return time.perf_counter() - t
+
+    cpu_once(cores)
+    m = 3 if dry else 9
+    cpu_pool = sorted(cpu_once(cores) for _ in range(m))[m // 2]
+    cpu_single = sorted(cpu_once(1) for _ in range(3))[1]
+    work = int(lib.vmd_ir_work_per_frame(ir.h)) * F
+    ev.close(); traj.close()
+    return {"workload": f"SURVEY 8d C1 stand-in: {N}-atom capped deca-alanine chain, no cell, {F} frames, host-memory trajectory; hot-path statements of "
+                        f"VIAMD's default script (src/main.cpp:528): d1 = distance, r = rdf(C, H, 10), v = sdf(7 residues, H, 10)",
+            "script": C1_SCRIPT, "frames_per_step": F,
+            "gpu_ms": {"pool_threads_16_grain_1": pooled * 1e3, "one_call": one_call * 1e3,
+                       "note": "clear_data excluded, vmd_eval_frame_range[_pooled] over [0, F) incl. the 8.4 MB float view of v; median of 30"},
+            "cpu_ms": {"cores": cores, "pool": cpu_pool * 1e3, "single_thread": cpu_single * 1e3,
+                       "note": "oracle (scalar restatement; kind port) rdf + sdf over the same frames, dynamic grain 1; median of 9 / 3"},
+            "gpu_over_cpu": cpu_pool / pooled, "rdf_hits": hits_r, "voxel_hits": vox_v,
+            "work_pairs_times_frames": work,
+            "shim_min_work_default": 4000000,
+            "note": "work = vmd_ir_work_per_frame x frames, the quantity include/vmd_md_script_shim.h compares with vmd_shim_set_min_work: below the "
+                    "threshold md_script_eval_create leaves the whole script with the evaluator behind the shim"}
 
 
 def run_workload(name, args, ctx, steps, warmup, frames=None, with_cpu=False, opts=(), defer_views=False):
@@ -298,20 +411,9 @@ def run_workload(name, args, ctx, steps, warmup, frames=None, with_cpu=False, op
 
     def ranged():
         # --pool-threads N --grain G: the way VIAMD drives the boundary (src/main.cpp:993-997): N pool threads pull ranges of G frames
-        # and all call frame_range on the SAME eval; every thread blocks until its frames are evaluated
-        import threading
-        nxt = [beg]; lock = threading.Lock(); ok = [True]
-        def work():
-            while ok[0]:
-                with lock:
-                    b = nxt[0]; nxt[0] += args.grain
-                if b >= end:
-                    return
-                if not ev.frame_range(sysm, traj, b, min(end, b + args.grain)):
-                    ok[0] = False
-        ths = [threading.Thread(target=work) for _ in range(args.pool_threads)]
-        [t.start() for t in ths]; [t.join() for t in ths]
-        return ok[0]
+        # and all call frame_range on the SAME eval; every thread blocks until its frames are evaluated.  Native threads
+        # (vmd_eval_frame_range_pooled): a Python thread per call costs more than a small call does
+        return ev.frame_range_pooled(sysm, traj, beg, end, args.pool_threads, args.grain)
 
     def step():
         ev.clear_data()
@@ -457,6 +559,18 @@ def run_workload(name, args, ctx, steps, warmup, frames=None, with_cpu=False, op
         "kernel_ms": dict(kernel_ms, timed_region=elapsed * 1e3),
         "synth_s": gen_s,
     }
+    # what ONE vmd_eval_reduce of this script moves per rank: the integer accumulators on the device (volumes as u32 where the
+    # merged counts provably fit: count_bound x 8 ranks < 2^32) + everything host-side packed as fp64 (weights, temporal rows, the frame mask)
+    try:
+        dev_b = host_b = 0
+        for v in ev.accum_views():
+            narrow = v.num_counts >= 1 << 20 and v.count_bound and v.count_bound * 8 < 1 << 32
+            dev_b += int(v.num_counts) * (4 if narrow else 8)
+            host_b += 8 * (int(v.num_weights) + int(v.num_temporal))
+        host_b += 8 * F
+        out["merge_payload_bytes"] = {"device_counts": dev_b, "host_packed_f64": host_b, "total": dev_b + host_b}
+    except Exception:
+        pass
     if "cells_build" in kernel_ms:
         # the sorted copies behind the pair kernel: share of the step and (where a PMC pass exists) HBM-side traffic against
         # 12*N (the frame, read once) + 12*N_sel (the sorted rows, written once) per frame
@@ -638,6 +752,7 @@ def main():
         # ... and what a RANK does before the merge: the same steps with the volume's float view deferred (vmd_eval_defer_volume_views: no zeroing
         # of the view, no 8.4 MB over PCIe per step) - the merge and the one view of the merged counts come on top at N > 1
         rank_part = run_workload("c4", args, ctx, n1250, w1250, frames=1250, opts=args.opt, defer_views=True)
+        r_c4_payload = r.get("merge_payload_bytes")
         sec["c4_1250"] = {"workload": r["config"]["workload"] + " - ONE rank's share at 8 GPUs (1 250 frames)", "value": r["value"], "unit": "frames/s",
                           "steps": r["steps"], "warmup": r["warmup"], "ms_per_step": r["ms_per_step"], "frames_per_step": r["config"]["frames_per_step"],
                           "kernel_ms": r["kernel_ms"],
@@ -646,6 +761,24 @@ def main():
                           "note": "ms_per_step(10 000 frames) / ms_per_step(1 250 frames) on one GPU: the upper bound of configs[3]'s 8-GPU strong scaling "
                                   "(the float view of the volume, 8.4 MB over PCIe, is inside both steps; at N > 1 a rank defers it to the merge: rank_part_ms is that "
                                   "step without the view - clear_data + frame_range only, NOT a complete evaluation)"}
+        # ... and the same one-GPU bound for the other two configurations BASELINE.json quotes on 8 GPUs (configs[2] = the metric's workload,
+        # configs[4]): a rank's share of their 1 000 frames is 125
+        for nm in ("c3", "c5"):
+            whole = out if nm == "c3" else sec[nm]
+            n125, w125 = (2, 1) if dry else ((20, 3) if nm == "c3" else (8, 2))
+            r = run_workload(nm, args, ctx, n125, w125, frames=125, opts=args.opt)
+            rp = run_workload(nm, args, ctx, n125, w125, frames=125, opts=args.opt, defer_views=True) if nm == "c5" else r
+            sec[nm + "_125"] = {"workload": r["config"]["workload"] + " - ONE rank's share at 8 GPUs (125 frames)", "value": r["value"], "unit": "frames/s",
+                                "steps": r["steps"], "warmup": r["warmup"], "ms_per_step": r["ms_per_step"], "frames_per_step": r["config"]["frames_per_step"],
+                                "kernel_ms": r["kernel_ms"], "strong_scaling_bound_8_gpus": whole["ms_per_step"] / r["ms_per_step"],
+                                "rank_part_ms": rp["ms_per_step"], "merge_payload_bytes": r.get("merge_payload_bytes"),
+                                "note": "ms_per_step(1 000 frames) / ms_per_step(125 frames) on one GPU: the upper bound of this configuration's 8-GPU STRONG "
+                                        "scaling (the weak-scaling curve of the metric keeps 1 000 frames per rank and does not see this bound)"}
+        sec["c4_1250"]["merge_payload_bytes"] = r_c4_payload
+        # SURVEY 8d's C1 stand-in - the size class of VIAMD's default dataset (datasets/1ALA-500.pdb: 112 atoms, 500 frames) with the literal
+        # default script's hot-path statements (src/main.cpp:528) - timed the way VIAMD drives the boundary (16 pool threads, grain 1) AND on the
+        # same host cores through the oracle: what include/vmd_md_script_shim.h's work threshold (vmd_shim_set_min_work) is set from
+        sec["c1"] = run_c1(ctx, dry)
         out["secondary"] = sec
     if world > 1 and not args.no_secondary and args.workload == "c3" and args.traj == "device" and not args.frames and args.scaling == "weak":
         # the two configurations BASELINE.json quotes on 8 GPUs, STRONG scaling (the named trajectory block-sharded over the ranks,

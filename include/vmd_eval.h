@@ -247,6 +247,9 @@ uint64_t vmd_ir_fingerprint(const vmd_script_ir_t* ir);                 /* md_sc
 size_t   vmd_ir_property_count(const vmd_script_ir_t* ir);              /* md_script_ir_property_count, src/main.cpp:992,1277 */
 const char* const* vmd_ir_property_names(const vmd_script_ir_t* ir);    /* md_script_ir_property_names, src/main.cpp:1278 */
 vmd_property_flags_t vmd_ir_property_flags(const vmd_script_ir_t* ir, const char* name); /* src/main.cpp:1285 */
+/* atom pairs ONE frame of the script asks for (rdf |ref| x |target|, sdf K x (|target| + m), distance |a| x |b| per context): the size a host
+ * compares with a threshold before it sends a small script to the GPU (vmd_shim_set_min_work; VIAMD's default dataset, src/main.cpp:522-528) */
+uint64_t vmd_ir_work_per_frame(const vmd_script_ir_t* ir);
 
 /* ---- evaluation (md_script_eval_t stand-in) ------------------------------------------------------ */
 
@@ -374,6 +377,11 @@ bool   vmd_eval_wait_settled(vmd_script_eval_t* eval);
 /* the same choice per eval instead of per process: 1 = on, 0 = off, -1 = follow vmd_set_option("readahead_lone") (the default); read when an
  * evaluation makes its first small call, i.e. set it before the calls or before clear_data */
 bool   vmd_eval_set_deferred_settle(vmd_script_eval_t* eval, int mode);
+/* VIAMD's call pattern as a utility (src/main.cpp:993-997, src/task_system.cpp:73-81): num_threads threads (the caller is one of them) pull
+ * ranges of `grain` frames off [frame_beg, frame_end) and call vmd_eval_frame_range on the one eval, each blocking until its frames are
+ * evaluated.  bench.py times VIAMD's pattern with it; false + vmd_last_error() if a call failed, false + "" if it was interrupted. */
+bool   vmd_eval_frame_range_pooled(vmd_script_eval_t* eval, const vmd_script_ir_t* ir, const vmd_system_t* sys, vmd_trajectory_i* traj,
+                                   uint32_t frame_beg, uint32_t frame_end, int num_threads, uint32_t grain);
 /* Deferred-settle mode: `fn(user)` is called after every settle the helper thread - or vmd_eval_wait_settled - has performed, on that
  * thread, with no lock of the eval held; clear_data / interrupt / free wait for a call that is running, none starts after they return.  A
  * host that caches scalar fields of the property records (include/vmd_md_script_shim.h re-publishes fingerprint / ranges / max_value to

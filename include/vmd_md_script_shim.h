@@ -279,6 +279,20 @@ inline vmd_system_t wrap_system(const md_system_t* sys) {
 }
 }  // namespace vmd_shim
 
+/* Work threshold: VIAMD opens datasets/1ALA-500.pdb - ~1e2 atoms x 500 frames - with the script of src/main.cpp:528,
+ * and wants to stay interactive (TODO.md:36).  An evaluation that small costs more to hand to the GPU (batch planning, a dozen launches, the
+ * views over PCIe: ~1 ms) than mdlib needs to evaluate it on the pool threads that are calling anyway.  md_script_eval_create therefore leaves
+ * a bound ir with the evaluator behind the shim when   vmd_ir_work_per_frame(vmd_ir) x num_frames < min_work   (atom pairs x frames): no GPU
+ * eval is created, the fallback evaluates the WHOLE script (not the reduced one), every record is mdlib's.  Default: VMD_SHIM_MIN_WORK_DEFAULT,
+ * from bench.py's `secondary.c1`; 0 sends everything that is bound to the GPU.  Without an evaluator behind the shim
+ * (VMD_SHIM_NO_FALLBACK) there is nobody to leave it with: the threshold is ignored. */
+#ifndef VMD_SHIM_MIN_WORK_DEFAULT
+#define VMD_SHIM_MIN_WORK_DEFAULT 4000000ull
+#endif
+namespace vmd_shim { inline std::atomic<uint64_t>& min_work() { static std::atomic<uint64_t> v{VMD_SHIM_MIN_WORK_DEFAULT}; return v; } }
+inline void vmd_shim_set_min_work(uint64_t pairs_times_frames) { vmd_shim::min_work().store(pairs_times_frames, std::memory_order_relaxed); }
+inline uint64_t vmd_shim_min_work() { return vmd_shim::min_work().load(std::memory_order_relaxed); }
+
 /* the host's one extra call: which descriptors belong to this compiled script (NULL unbinds; call before md_script_eval_create) */
 inline void vmd_shim_bind_ir(const md_script_ir_t* md_ir, const vmd_script_ir_t* vmd_ir) {
     vmd_shim::Registry& r = vmd_shim::registry();
@@ -321,7 +335,8 @@ inline void vmd_shim_bind_trajectory(const md_trajectory_i* md_traj, vmd_traject
 /* ---- md_script_eval_t ------------------------------------------------------------------------------------------------------ */
 struct md_script_eval_t {
     vmd_script_eval_t* eval = nullptr;           /* the GPU evaluator of the bound properties; NULL for a script without any */
-    const vmd_script_ir_t* vir = nullptr;
+    const vmd_script_ir_t* vir = nullptr;        /* what `eval` evaluates: the binding of md_ir at creation, or NULL when the script was too small (vmd_shim_set_min_work) */
+    const vmd_script_ir_t* bound_vir = nullptr;  /* the binding of md_ir at creation, whoever evaluates it (a later re-binding makes the eval stale) */
     const md_script_ir_t* md_ir = nullptr;
     vmd_shim_fallback_eval_t* fb = nullptr;      /* mdlib's evaluator of everything else; NULL without fallback hooks */
     const md_script_ir_t* fb_ir = nullptr;       /* the IR `fb` was created from (md_ir, or the reduced one of vmd_shim_bind_fallback_ir) */
@@ -360,7 +375,7 @@ struct md_script_eval_t {
             if (p->src) {
                 const vmd_script_property_data_t* s = p->src;
                 for (int k = 0; k < 4; ++k) pub(d.dim[k], s->dim[k]);
-                pub(d.values, s->values); pub(d.weights, s->weights); set_if_num_values(d, s->num_values, 0);
+                pub(d.values, peek(s->values)); pub(d.weights, s->weights); set_if_num_values(d, s->num_values, 0);      /* (a volume's `values` moves between the shared zeros and its view: clear_data / first view) */
                 set_if_min_value(d, peek(s->min_value), 0); pub(d.max_value, peek(s->max_value));
                 for (int k = 0; k < 2; ++k) { pub(d.min_range[k], peek(s->min_range[k])); pub(d.max_range[k], peek(s->max_range[k])); }
                 if (s->aggregate) {
@@ -396,18 +411,22 @@ struct md_script_eval_t {
 inline md_script_eval_t* VMD_SHIM_PREFIX(md_script_eval_create)(size_t num_frames, const md_script_ir_t* ir, md_allocator_i* alloc) {
     const vmd_script_ir_t* vir = vmd_shim::find_ir(ir);
     std::unique_ptr<md_script_eval_t> e(new md_script_eval_t());
-    e->vir = vir;
+    e->bound_vir = vir;
     e->md_ir = ir;
     e->num_frames = num_frames;
 #if VMD_SHIM_HAVE_FALLBACK
+    /* too small to be worth a trip to the GPU (vmd_shim_set_min_work): this eval is mdlib's alone, whole script */
+    const bool too_small = vir && vmd_ir_work_per_frame(vir) * (uint64_t)num_frames < vmd_shim_min_work();
+    if (too_small) vir = nullptr;
+    e->vir = vir;
     /* mdlib's evaluator of the same script (or of the reduced one): every property the GPU does not evaluate lives there */
-    e->fb_ir = vmd_shim::fallback_ir_of(ir);
+    e->fb_ir = too_small ? ir : vmd_shim::fallback_ir_of(ir);
     e->fb = VMD_SHIM_FALLBACK(md_script_eval_create)(num_frames, e->fb_ir, alloc);
 #else
-    (void)alloc;                                 /* host allocations are the library's own */
+    e->vir = vir;                                /* nobody to leave a small script with: the threshold does not apply */
 #endif
+    (void)alloc;                                 /* host allocations of the GPU part are the library's own */
     if (!vir && !e->fb) return nullptr;          /* nothing bound and nobody to fall back on: as mdlib for an invalid ir */
-    (void)alloc;
 #ifdef VMD_SHIM_DEFERRED_SETTLE
     /* A VIAMD build whose task pool may have a single worker (src/main.cpp:494-495 clamps to >= 2 today): small calls are evaluated ahead
      * whoever makes them, the final settle trails the last call by a fraction of a millisecond (include/vmd_eval.h, vmd_eval_wait_settled).
@@ -524,7 +543,7 @@ inline uint64_t VMD_SHIM_PREFIX(md_script_eval_ir_fingerprint)(const md_script_e
 #if VMD_SHIM_HAVE_FALLBACK
     if (e->fb) {
         uint64_t fp = e->fb_ir == e->md_ir ? VMD_SHIM_FALLBACK(md_script_eval_ir_fingerprint)(e->fb) : (uint64_t)VMD_SHIM_IR_FINGERPRINT(e->md_ir);
-        if (vmd_shim::find_ir(e->md_ir) != e->vir) fp ^= 0x9E3779B97F4A7C15ull;
+        if (vmd_shim::find_ir(e->md_ir) != e->bound_vir) fp ^= 0x9E3779B97F4A7C15ull;
         return fp;
     }
 #endif

@@ -2,6 +2,8 @@
 and against the hipcc-built product library on a real MI355X (`-m gpu`).  The checker is always the oracle."""
 import time
 
+import ctypes as C
+
 import numpy as np
 
 import viamd_amd as V
@@ -758,6 +760,19 @@ def check_sdf(lib, O, coords, box, structures, mass, tgt, cutoff, flags=L.PBC_AL
     M4, ext = ev.sdf_matrices("v", sysm, traj, f)
     assert ext == np.float32(cutoff)
     np.testing.assert_allclose(M4[:, :3, :], mats[f].astype(np.float32), rtol=0, atol=0)
+    if not ranges:
+        # clear_data (src/main.cpp:990): a reader polling the record sees a NEW fingerprint over ZEROS at once - never the previous run's voxels -
+        # although the 8.4 MB view itself is not touched (round 6: `values` points at shared zero pages until the next view has been written);
+        # the re-evaluation that follows immediately (:993-997) brings the same volume back, in the view's own memory
+        fp0, addr0 = pd.fingerprint, pd.c.values and C.cast(pd.c.values, C.c_void_p).value
+        ev.clear_data()
+        pd = ev.property_data("v")
+        assert pd.fingerprint != fp0 and pd.max_value == 0.0
+        assert not pd.values.any(), "clear_data must leave a zero volume under the new fingerprint"
+        assert ev.frame_range(sysm, traj, 0, F)
+        pd = ev.property_data("v")
+        np.testing.assert_array_equal(pd.values, vol.astype(np.float32))
+        assert C.cast(pd.c.values, C.c_void_p).value == addr0 and pd.max_value == float(vol.max())
     return ev, vol
 
 

@@ -95,6 +95,7 @@ int main(int argc, char** argv) {
     const size_t n_res = 20, n_blob = n_res * 10, N = n_blob + 933 * 3;
     const float L = 40.0f;
     if (vmd_device_count() <= 0) fail("no HIP device");
+    vmd_shim_set_min_work(0);                      // a test-sized system: below the default work threshold, send what is bound to the GPU anyway
 
     MockTraj mt{F, N, L, std::vector<float>(F * 3 * N)};
     {

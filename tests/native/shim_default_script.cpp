@@ -56,6 +56,8 @@ int main(int argc, char** argv) {
     const size_t n_res = 20, n_blob = n_res * 10, N = n_blob + 933 * 3;
     const float L = 40.0f;
     if (vmd_device_count() <= 0) fail("no HIP device");
+    if (vmd_shim_min_work() != VMD_SHIM_MIN_WORK_DEFAULT) fail("default work threshold");
+    vmd_shim_set_min_work(0);                     // this test system is far below the default threshold: send what is bound to the GPU (both sides: below)
 
     MockTraj mt{F, N, L, std::vector<float>(F * 3 * N)};
     {
@@ -285,6 +287,34 @@ int main(int argc, char** argv) {
         vmd_shim_bind_ir(eval_ir, vir);
         if (md_script_eval_ir_fingerprint(full_eval) != md_script_ir_fingerprint(eval_ir)) fail("fingerprint after re-binding");
         vmd_ir_free(other);
+    }
+
+    // ---- the work threshold (include/vmd_md_script_shim.h, vmd_shim_set_min_work): an evaluation below it stays with the
+    // evaluator behind the shim - whole script, no GPU eval - and one at or above it goes to the GPU as before
+    {
+        const uint64_t work = vmd_ir_work_per_frame(vir) * (uint64_t)F;
+        // d1: 1 pair; r: |C| x |H|; v: 7 structures (residues 2..8 of ALA, 10 atoms each) x (|H| + 10)
+        size_t nC = 0, nH = 0;
+        for (size_t i = 0; i < N; ++i) { nC += elements[i][0] == 'C'; nH += elements[i][0] == 'H'; }
+        if (work != (1 + (uint64_t)nC * nH + 7 * ((uint64_t)nH + 10)) * F) fail("vmd_ir_work_per_frame of the default script");
+        vmd_shim_set_min_work(work + 1);                                   // just too small
+        md_script_eval_t* small = md_script_eval_create(F, eval_ir, &persistent);
+        if (!small || small->eval || !small->fb || small->fb->ir != eval_ir) fail("below the threshold: no GPU eval, the fallback gets the WHOLE script");
+        if (md_script_eval_ir_fingerprint(small) != md_script_ir_fingerprint(eval_ir)) fail("below the threshold: fingerprint (src/main.cpp:987) must still match");
+        md_script_eval_clear_data(small);
+        if (!md_script_eval_frame_range(small, eval_ir, &sys, sys.trajectory, 0, (uint32_t)F)) fail("below the threshold: frame_range");
+        for (const char* nm : {"d1", "r", "v"}) {
+            const md_script_property_data_t* rec = prop(small, nm);
+            if (!rec || rec->values[0] != MOCK_CPU_COPY) fail("below the threshold: d1 / r / v are the fallback evaluator's own");
+        }
+        if (memcmp(prop(small, "a1")->values, prop(full_eval, "a1")->values, prop(small, "a1")->num_values * sizeof(float)) != 0) fail("below the threshold: a1");
+        if (md_bitfield_popcount(md_script_eval_frame_mask(small)) != F) fail("below the threshold: frame mask");
+        md_script_eval_free(small);
+        vmd_shim_set_min_work(work);                                       // exactly enough
+        md_script_eval_t* big = md_script_eval_create(F, eval_ir, &persistent);
+        if (!big || !big->eval) fail("at the threshold: the GPU evaluates the bound properties");
+        md_script_eval_free(big);
+        vmd_shim_set_min_work(0);
     }
 
     // ---- a script without any hot-path statement: nothing is bound, the fallback evaluates it alone

@@ -156,6 +156,7 @@ SIGNATURES = [
     ("vmd_ir_property_count", C.c_size_t, [_vp]),
     ("vmd_ir_property_names", C.POINTER(C.c_char_p), [_vp]),
     ("vmd_ir_property_flags", C.c_uint32, [_vp, C.c_char_p]),
+    ("vmd_ir_work_per_frame", C.c_uint64, [_vp]),
     ("vmd_eval_create", _vp, [C.c_size_t, _vp]),
     ("vmd_eval_free", None, [_vp]),
     ("vmd_eval_clear_data", None, [_vp]),
@@ -174,6 +175,7 @@ SIGNATURES = [
     ("vmd_eval_finalize", C.c_bool, [_vp]),
     ("vmd_eval_defer_volume_views", C.c_bool, [_vp, C.c_bool]),
     ("vmd_eval_wait_settled", C.c_bool, [_vp]),
+    ("vmd_eval_frame_range_pooled", C.c_bool, [_vp, _vp, C.POINTER(System), C.POINTER(TrajectoryI), C.c_uint32, C.c_uint32, C.c_int, C.c_uint32]),
     ("vmd_eval_set_deferred_settle", C.c_bool, [_vp, C.c_int]),
     ("vmd_eval_set_settled_callback", C.c_bool, [_vp, SETTLED_FN, C.c_void_p]),
     ("vmd_eval_set_frame_mask", None, [_vp, c_uint8_p, C.c_size_t]),

@@ -9,6 +9,8 @@
 #include <float.h>
 
 #include <algorithm>
+#include <sys/mman.h>
+
 #include <atomic>
 #include <climits>
 #include <chrono>
@@ -548,6 +550,20 @@ static uint64_t fnv1a(uint64_t h, const void* data, size_t n) {
 }
 
 extern "C" vmd_script_ir_t* vmd_ir_create(void) { return new vmd_script_ir_t(); }
+// atom pairs one frame of this script asks for (rdf: |ref| x |target|; sdf: K x |target| + K m for the alignment; distance: |a| x |b| of every
+// context): what a host compares with its threshold before it sends a SMALL script to the GPU at all (include/vmd_md_script_shim.h,
+// vmd_shim_set_min_work; VIAMD's default dataset is ~1e2 atoms, src/main.cpp:522-528)
+extern "C" uint64_t vmd_ir_work_per_frame(const vmd_script_ir_t* ir) {
+    if (!ir) return 0;
+    uint64_t w = 0;
+    for (const Property& p : ir->props) {
+        if (p.kind == PROP_RDF) w += (uint64_t)p.a.size() * (uint64_t)p.b.size();
+        else if (p.kind == PROP_SDF) w += (uint64_t)p.K * ((uint64_t)p.b.size() + (uint64_t)p.m);
+        else if (p.aoff.size() > 1) { for (size_t c = 0; c + 1 < p.aoff.size(); ++c) w += (uint64_t)(p.aoff[c + 1] - p.aoff[c]) * (uint64_t)(p.boff[c + 1] - p.boff[c]); }
+        else w += (uint64_t)p.a.size() * (uint64_t)p.b.size();
+    }
+    return w;
+}
 extern "C" void vmd_ir_free(vmd_script_ir_t* ir) { delete ir; }
 
 static bool ir_name_ok(vmd_script_ir_t* ir, const char* name) {
@@ -696,6 +712,22 @@ struct RdfGroup {
     bool classes = false;                               // passes come from the class decomposition
 };
 
+// what `values` of a volume points at between clear_data and the evaluation's first view: zero pages shared by every volume of the process,
+// mapped read-only (a write through the pointer is a bug and faults loudly) and never backed by memory of their own (anonymous pages that
+// are only ever read all alias the kernel's zero page)
+static float* zero_volume_view(size_t nfloats) {
+    static std::mutex mtx;
+    static float* view = nullptr;
+    static size_t cap = 0;
+    std::lock_guard<std::mutex> l(mtx);
+    if (nfloats > cap) {
+        void* m = mmap(nullptr, nfloats * sizeof(float), PROT_READ, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        if (m == MAP_FAILED) return nullptr;
+        view = (float*)m; cap = nfloats;        // (an earlier, smaller mapping stays: readers may still hold it)
+    }
+    return view;
+}
+
 struct PropState {
     Property prop;                      // private copy of the descriptor
     vmd_script_property_data_t data;
@@ -712,9 +744,6 @@ struct PropState {
     DevBuf<uint64_t> d_blocks;          // [nblocks][ncounts]: per-frame-block partial accumulators (filtered evaluation)
     std::vector<double> block_weights64; // [nblocks][ncounts], distributions only
     DevBuf<float> d_values;             // volume float view (device)
-    DevBuf<float> d_zero;               // volume: zeros, the source of the host view's clearing DMA
-    hipEvent_t zero_done = nullptr;     // volume: that DMA has landed (awaited before the view is written again)
-    bool zero_pending = false;
     DevBuf<float> d_max;
     int sel_a = -1, sel_b = -1;         // RDF: indices into eval->sels
     bool same_set = false;
@@ -739,9 +768,6 @@ struct PropState {
     DevBuf<float> d_ma, d_mb, d_out;
     bool uploaded = false;
     bool pinned = false;
-    ~PropState() {
-        if (zero_done) { (void)hipEventSynchronize(zero_done); pool_event_give(zero_done, false); }
-    }
     bool dirty = false;                 // device accumulators changed since the last host refresh
     bool counts_stale = false;          // volume: host u64 mirror older than the device accumulators
 };
@@ -1418,25 +1444,14 @@ extern "C" void vmd_eval_clear_data(vmd_script_eval_t* eval) {
     eval->blocks_inst = TrajId();
     ra_reset(eval);
     for (auto& p : eval->props) {
-        // the 8.4 MB float view of a volume is pinned: the copy engine zeroes it from a zero buffer in HBM, in the background -
-        // the DMA overlaps the kernels of the evaluation that follows (VIAMD clears and immediately re-evaluates,
-        // src/main.cpp:990-996) and is awaited before the view is written again; a host memset here cost 10 % of a
-        // 10 000-frame SDF evaluation.  Until it lands (~0.2 ms) a reader may still see the previous volume.
-        bool dma = false;
-        // (an eval whose volume views are deferred - a rank of a multi-GPU evaluation - has no current view between clear_data and finalize by
-        // its own choice, and finalize rewrites every voxel: nothing to zero, 8.4 MB of PCIe traffic per evaluation saved)
-        const bool deferred_view = p->prop.kind == PROP_SDF && eval->defer_volume_views.load(std::memory_order_relaxed);
-        if (deferred_view) dma = true;
-        else if (p->prop.kind == PROP_SDF && p->pinned) {
-            // on its own stream: the staging copies of the next frame_range must not queue behind 8 MB of PCIe traffic
-            if (!p->d_zero.p && p->d_zero.ensure(p->ncounts)) (void)hipMemsetAsync(p->d_zero.p, 0, p->ncounts * sizeof(float), eval->aux_stream);
-            if (!p->zero_done) p->zero_done = pool_event(false);
-            dma = p->d_zero.p && p->zero_done &&
-                  hipMemcpyAsync(p->values.data(), p->d_zero.p, p->ncounts * sizeof(float), hipMemcpyDeviceToHost, eval->aux_stream) == hipSuccess &&
-                  hipEventRecord(p->zero_done, eval->aux_stream) == hipSuccess;
-            p->zero_pending = dma;
-        }
-        if (!dma) std::fill(p->values.begin(), p->values.end(), 0.0f);
+        // The float view of a volume (8.4 MB, pinned) is NOT zeroed: `data.values` is pointed at a shared, read-only page range of zeros until
+        // the next view of this evaluation has been written - k_counts_to_float rewrites every voxel of the real view, then the pointer
+        // flips back (refresh_volume).  Round 6: the zeroing was a second 8.4 MB pass over PCIe per evaluation - 0.15 ms
+        // that the kernel trace showed IN FRONT of the evaluation's kernels, not under them (profiles/r06a_c4_1250_timeline.txt) - a fifth of
+        // a rank's 1 250-frame share of configs[3].  A reader polling `fingerprint` (src/main.cpp:1508; density_volume.cpp:159-163, 279-283) sees
+        // zeros under the new fingerprint at once, never the previous run's voxels; VIAMD dereferences prop_data->values when it uploads.
+        if (p->prop.kind == PROP_SDF) pub(p->data.values, zero_volume_view(p->ncounts));
+        else std::fill(p->values.begin(), p->values.end(), 0.0f);
         std::fill(p->weights.begin(), p->weights.end(), 0.0f);
         // the 17 MB u64 mirror of a volume is only ever read after vmd_eval_refresh_counts: mark it stale instead of zeroing it
         if (p->prop.kind == PROP_SDF) p->counts_stale = true;
@@ -1530,7 +1545,6 @@ static bool refresh_volume(vmd_script_eval_t* e, PropState* p) {
         scale = nf ? (float)(1.0 / ((double)nf * edge * edge * edge)) : 0.0f;
     }
     float vmax = 0.0f;
-    if (p->zero_pending) { HIP_OK(hipStreamWaitEvent(e->stream, p->zero_done, 0)); p->zero_pending = false; }
     float* host_view_dev = nullptr;
     if (g_opt.sdf_direct_view.load() && p->values.pinned && hipHostGetDevicePointer((void**)&host_view_dev, p->values.data(), 0) != hipSuccess) {
         (void)hipGetLastError();
@@ -1550,6 +1564,7 @@ static bool refresh_volume(vmd_script_eval_t* e, PropState* p) {
     p->counts_stale = true;
     HIP_OK(hipMemcpyAsync(&vmax, p->d_max.p, sizeof(float), hipMemcpyDeviceToHost, e->stream));
     HIP_OK(hipStreamSynchronize(e->stream));
+    pub(p->data.values, p->values.data());       // every voxel of the real view has just been rewritten: readers leave the shared zeros (clear_data)
     pub(p->data.min_value, 0.0f); pub(p->data.max_value, vmax);
     pub_touch(p->data.fingerprint);
     p->dirty = false;
@@ -3702,6 +3717,40 @@ extern "C" bool vmd_eval_frame_range(vmd_script_eval_t* eval, const vmd_script_i
     const bool lok = ra_leave(eval, sys, traj);
     if (!ok) g_last_error = err;
     return ok && lok;
+}
+
+// VIAMD's call pattern as a utility (src/main.cpp:993-997, src/task_system.cpp:73-81): `num_threads` pool threads pull ranges of `grain`
+// frames off [frame_beg, frame_end) and call vmd_eval_frame_range on the ONE eval, each blocking until its frames are evaluated.  What
+// bench.py times VIAMD's pattern with (native threads: a Python thread per call costs more than a small call does), and what a host
+// without a task system of its own can use as is.  Returns false if any call failed or was interrupted.
+extern "C" bool vmd_eval_frame_range_pooled(vmd_script_eval_t* eval, const vmd_script_ir_t* ir, const vmd_system_t* sys, vmd_trajectory_i* traj,
+                                            uint32_t frame_beg, uint32_t frame_end, int num_threads, uint32_t grain) {
+    if (!eval || !traj) return vmd_fail("vmd_eval_frame_range_pooled: NULL argument");
+    if (num_threads < 1) num_threads = 1;
+    if (grain < 1) grain = 1;
+    std::atomic<uint32_t> next{frame_beg};
+    std::atomic<bool> ok{true};
+    std::mutex err_mtx;
+    std::string err;
+    auto work = [&] {
+        for (;;) {
+            const uint32_t b = next.fetch_add(grain, std::memory_order_relaxed);
+            if (b >= frame_end || b < frame_beg) break;           // (b < frame_beg: the counter wrapped)
+            const uint32_t e = frame_end - b < grain ? frame_end : b + grain;
+            if (!vmd_eval_frame_range(eval, ir, sys, traj, b, e)) {
+                std::lock_guard<std::mutex> l(err_mtx);
+                if (err.empty()) err = g_last_error;               // thread-local in the worker: carried to the caller below
+                ok.store(false);
+                break;
+            }
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < num_threads; ++t) pool.emplace_back(work);
+    work();
+    for (auto& t : pool) t.join();
+    if (!ok.load()) g_last_error = err;
+    return ok.load();
 }
 
 extern "C" bool vmd_eval_set_settled_callback(vmd_script_eval_t* eval, void (*fn)(void*), void* user) {

@@ -331,6 +331,17 @@ class ScriptEval:
         m = np.ascontiguousarray(mask, dtype=np.uint8)
         self.lib.vmd_eval_set_frame_mask(self.h, m.ctypes.data_as(L.c_uint8_p), m.size)
 
+    def frame_range_pooled(self, sys, traj, frame_beg, frame_end, num_threads=16, grain=1):
+        """VIAMD's call pattern (src/main.cpp:993-997): native pool threads pulling ranges of `grain` frames, all calling frame_range on this eval"""
+        sysp = C.byref(sys.c) if sys is not None else None
+        self._last_inputs = (sys, traj)
+        ok = self.lib.vmd_eval_frame_range_pooled(self.h, self.ir.h, sysp, traj.interface(), int(frame_beg), int(frame_end), int(num_threads), int(grain))
+        if not ok:
+            if self.lib.vmd_eval_frames_done(self.h) < self.num_frames() and self._interrupted():
+                return False
+            raise VmdError(self.lib.last_error())
+        return True
+
     def set_deferred_settle(self, mode=1):
         """this eval's own choice of the deferred-settle mode: 1 on, 0 off, -1 follow the process-wide option readahead_lone"""
         if not self.lib.vmd_eval_set_deferred_settle(self.h, int(mode)):
