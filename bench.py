@@ -435,6 +435,7 @@ def run_workload(name, args, ctx, steps, warmup, frames=None, with_cpu=False, op
     merge_s[0] = 0.0
     if dist:
         dist.barrier()
+    lib.vmd_hip_marker(None)                 # an empty kernel: a counter collection of this command keeps what is dispatched after it
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -557,6 +558,7 @@ def run_workload(name, args, ctx, steps, warmup, frames=None, with_cpu=False, op
                      "note": ("k_rdf_pencil is VALU-issue bound, not HBM bound (DESIGN.md 3.1/5): achieved is the brief's "
                               "12*N*frames/launch-time figure" if dom == "rdf_pencil" else "HBM stream kernel")},
         "kernel_ms": dict(kernel_ms, timed_region=elapsed * 1e3),
+        "kernel_launches_per_step": {k_: v_ / steps for k_, v_ in kernel_launches.items() if not k_.startswith("host_")},
         "synth_s": gen_s,
     }
     # what ONE vmd_eval_reduce of this script moves per rank: the integer accumulators on the device (volumes as u32 where the

@@ -170,6 +170,8 @@ int vmd_hip_set_sdf_nt(int on);
 uint64_t vmd_hip_rdf_columns(int reset);
 /* counts[0] += value on the device (closed-interval RDF: the self pairs a half-shell pass never visits) */
 int vmd_hip_bump_u64(void* stream, uint64_t* p, uint64_t value);
+/* an empty kernel named k_marker_timed_region: a profiled command marks where its timed region begins (bench.py, scripts/pmc_traffic.py) */
+int vmd_hip_marker(void* stream);
 /* DECISION(D-RDF-OPEN) as a switch: 1 = hit iff r_min <= d <= r_max in the pair kernels launched from now on; returns the old value */
 int vmd_hip_set_rdf_closed(int on);
 int vmd_hip_set_rdf_raw(int on);        /* vmd_hip_rdf_brute: positions enter the pair computation unwrapped, minimum image by rounding (oracle/SPEC.md D-WRAP flipped); per host thread; returns the previous value */

@@ -8,7 +8,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
 rocprofv3 -L > $OUT/counters_list.txt 2>&1
-BENCH="python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline ${FRAMES:+--frames $FRAMES} $*"
+BENCH="python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline ${FRAMES:+--frames $FRAMES} $*"
 i=0
 while read -r line; do
   [ -z "$line" ] && continue

@@ -25,18 +25,9 @@ def oracle():
 
 EMU_DIR = os.path.join(ROOT, "tests", "emu")
 EMU_LIB = os.path.join(EMU_DIR, "libviamd_emu.so")
-EMU_SOURCES = [os.path.join(ROOT, "viamd_amd", "csrc", "vmd_kernels.hip"),
-               os.path.join(ROOT, "viamd_amd", "csrc", "vmd_xtc_device.hip"),
-               os.path.join(ROOT, "viamd_amd", "csrc", "vmd_eval.cpp"),
-               os.path.join(ROOT, "viamd_amd", "csrc", "vmd_dcd.cpp"),
-               os.path.join(ROOT, "viamd_amd", "csrc", "vmd_xdr.cpp"),
-               os.path.join(ROOT, "viamd_amd", "csrc", "vmd_script.cpp"),
-               os.path.join(ROOT, "viamd_amd", "csrc", "vmd_reduce.cpp"),
-               os.path.join(ROOT, "viamd_amd", "csrc", "vmd_export.cpp"),
-               os.path.join(ROOT, "viamd_amd", "csrc", "vmd_text.cpp"),
-               os.path.join(EMU_DIR, "emu.cpp")]
-EMU_DEPS = EMU_SOURCES + [os.path.join(EMU_DIR, "hip", "hip_runtime.h"),
-                          os.path.join(ROOT, "include", "vmd_eval.h"), os.path.join(ROOT, "include", "vmd_hip.h")]
+from viamd_amd import build as _vb          # the ONE list of product sources (viamd_amd/build.py): the emulator compiles exactly those
+EMU_SOURCES = list(_vb.SOURCES) + [os.path.join(EMU_DIR, "emu.cpp")]
+EMU_DEPS = EMU_SOURCES + [os.path.join(EMU_DIR, "hip", "hip_runtime.h")] + list(_vb.HEADERS)
 
 
 def build_emu():
@@ -47,16 +38,28 @@ def build_emu():
     out = EMU_LIB if not san else os.path.join("/tmp", "libviamd_emu_" + san.replace(",", "_") + ".so")   # never into the tree: in-tree .so files travel to the GPU box
     if os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(s) for s in EMU_DEPS):
         return out
-    # several pytest-xdist workers may find the library missing at once: each builds into its own file and renames it into place
+    # several pytest-xdist workers may find the library missing at once: each builds into its own files and renames the library into place
+    from concurrent.futures import ThreadPoolExecutor
     tmp = f"{out}.{os.getpid()}.tmp"
-    cmd = ["g++", "-O2", "-g", "-shared", "-fPIC", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-mavx2", "-mfma",
-           "-I" + EMU_DIR, "-I" + os.path.join(ROOT, "include"), "-x", "c++"] + EMU_SOURCES + ["-ldl", "-o", tmp]
+    objdir = os.path.join("/tmp", f"viamd_emu_obj_{san.replace(',', '_') or 'plain'}_{os.getpid()}")
+    os.makedirs(objdir, exist_ok=True)
+    cflags = ["-O2", "-g", "-fPIC", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-mavx2", "-mfma", "-I" + EMU_DIR, "-I" + os.path.join(ROOT, "include")]
     if san:
-        cmd[1:1] = ["-fsanitize=" + san, "-fno-omit-frame-pointer", "-fno-sanitize-recover=undefined"]
+        cflags = ["-fsanitize=" + san, "-fno-omit-frame-pointer", "-fno-sanitize-recover=undefined"] + cflags
+
+    def compile_one(src):
+        obj = os.path.join(objdir, os.path.basename(src) + ".o")
+        subprocess.check_call(["g++"] + cflags + ["-x", "c++", "-c", src, "-o", obj])
+        return obj
+
     try:
-        subprocess.check_call(cmd)
+        with ThreadPoolExecutor(min(8, os.cpu_count() or 1)) as ex:
+            objs = list(ex.map(compile_one, EMU_SOURCES))
+        subprocess.check_call(["g++", "-shared"] + (["-fsanitize=" + san] if san else []) + objs + ["-ldl", "-o", tmp])
         os.replace(tmp, out)
     finally:
+        import shutil
+        shutil.rmtree(objdir, ignore_errors=True)
         if os.path.exists(tmp):
             os.remove(tmp)
     return out
@@ -74,9 +77,7 @@ def build_twin():
     deps = vb.SOURCES + vb.HEADERS
     if os.path.exists(TWIN_LIB) and all(os.path.getmtime(TWIN_LIB) >= os.path.getmtime(s) for s in deps):
         return TWIN_LIB
-    cmd = [vb.hipcc()] + vb.FLAGS + ["-DVMD_NO_INLINE_ASM", "-I", os.path.join(ROOT, "include"), "-x", "hip"] + vb.SOURCES + ["-ldl", "-o", TWIN_LIB]
-    subprocess.check_call(cmd)
-    return TWIN_LIB
+    return vb.build(force=False, extra_flags=("-DVMD_NO_INLINE_ASM",), out=TWIN_LIB)
 
 
 @pytest.fixture(scope="session")

@@ -280,7 +280,7 @@ extern "C" vmd_dcdtraj_t* vmd_dcdtraj_open(const char* path) {
     return t;
 }
 
-extern "C" void vmd_mapreg_drop(const void* base);       // vmd_eval.cpp: the pinned windows of this mapping
+extern "C" void vmd_mapreg_drop(const void* base);       // vmd_eval_traj.cpp: the pinned windows of this mapping
 extern "C" void vmd_dcdtraj_close(vmd_dcdtraj_t* t) {
     if (!t) return;
     if (const unsigned char* m = t->d.map.load()) {

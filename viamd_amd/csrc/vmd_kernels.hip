@@ -2993,6 +2993,14 @@ extern "C" int vmd_hip_add_u64(void* stream, uint64_t* dst, const uint64_t* src,
 }
 
 // counts[index] += value: the self pairs (d = 0) a half-shell pass never visits, when the closed interval counts them
+// An empty kernel with a name of its own: bench.py launches it where its timed region begins, so that a counter collection of the same
+// command (scripts/pmc_traffic.py) can tell the steady-state dispatches from the warm-up's (capacity sampling, first-touch, overflow repeats)
+__global__ void k_marker_timed_region() {}
+extern "C" int vmd_hip_marker(void* stream) {
+    hipLaunchKernelGGL(k_marker_timed_region, dim3(1), dim3(64), 0, (hipStream_t)stream);
+    VMD_LAUNCH_CHECK();
+    return 0;
+}
 __global__ void k_bump_u64(uint64_t* p, uint64_t v) { if (threadIdx.x == 0 && blockIdx.x == 0) *p += v; }
 extern "C" int vmd_hip_bump_u64(void* stream, uint64_t* p, uint64_t v) {
     hipLaunchKernelGGL(k_bump_u64, dim3(1), dim3(64), 0, (hipStream_t)stream, p, v);

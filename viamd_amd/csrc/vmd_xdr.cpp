@@ -832,8 +832,8 @@ extern "C" vmd_xdrtraj_t* vmd_xdrtraj_open(const char* path) {
     return t;
 }
 
-extern "C" void vmd_ckcache_drop(const void* inst);      // vmd_eval.cpp: the decoder checkpoints kept for this trajectory
-extern "C" void vmd_mapreg_drop(const void* base);       // vmd_eval.cpp: the pinned windows of this mapping
+extern "C" void vmd_ckcache_drop(const void* inst);      // vmd_eval_traj.cpp: the decoder checkpoints kept for this trajectory
+extern "C" void vmd_mapreg_drop(const void* base);       // vmd_eval_traj.cpp: the pinned windows of this mapping
 extern "C" void vmd_xdrtraj_close(vmd_xdrtraj_t* t) {
     if (!t) return;
     vmd_ckcache_drop(&t->d);
