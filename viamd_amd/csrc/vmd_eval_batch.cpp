@@ -1,9 +1,14 @@
+// viamd_amd/csrc/vmd_eval_batch.cpp - one call's worth of evaluation: the pencil grid of a batch, the two-level cell build per
+// selection (md_spatial_hash's role), batch planning, reuse of another eval's block partials (filtered evaluation,
+// /root/reference/src/main.cpp:1014-1039) and process_range - the loop that queues the kernels of batch k + 1 before it waits for
+// batch k, repeats a batch whose buckets overflowed and books frames, temporal rows and the frame mask.
 #include "vmd_eval_internal.h"
 
 // Bucket capacities of the two-level build for selection `s` on the pencils of grid `g`: per-pencil maximum over the first and
 // last (up to) 4 frames of the batch x margin + a few standard deviations.  One small readback, then kept for the eval's
 // lifetime (frames of one trajectory look alike; a bucket that overflows later is caught by the device flag and re-measured).
-bool ensure_pencil_caps(vmd_script_eval_t* e, Selection* s, const Stage& src, const float* d_boxes, uint32_t pbc, size_t nb, const vmd_grid_t& g) {
+bool ensure_pencil_caps(vmd_script_eval_t* e, Selection* s, const Stage& src, const float* d_boxes, uint32_t pbc, size_t nb,
+        const vmd_grid_t& g) {
     if (!s->pen_off.empty() && s->pen_ny == g.ny && s->pen_nz == g.nz) return true;
     if (!s->pen_off.empty()) {                 // keep what was measured for the layout we are leaving
         bool known = false;
@@ -16,7 +21,8 @@ bool ensure_pencil_caps(vmd_script_eval_t* e, Selection* s, const Stage& src, co
     for (auto& c : s->caps_cache) {
         if (c.ny != g.ny || c.nz != g.nz) continue;
         s->pen_off = c.pen_off; s->cap_max = c.cap_max; s->total_cap = c.total_cap; s->pen_ny = c.ny; s->pen_nz = c.nz;
-        return s->d_pen_off.upload(s->pen_off.data(), s->pen_off.size(), e->stream);      // pageable source: the copy is staged before the call returns
+        // pageable source: the copy is staged before the call returns
+        return s->d_pen_off.upload(s->pen_off.data(), s->pen_off.size(), e->stream);
     }
     const int npen = g.ny * g.nz, nsel = (int)s->idx.size();
     // after an overflow: every frame of the batch (exact populations), otherwise the first and last 4
@@ -24,10 +30,12 @@ bool ensure_pencil_caps(vmd_script_eval_t* e, Selection* s, const Stage& src, co
     const size_t S = exhaustive ? nb : 4, rows = exhaustive ? nb : 8;
     if (!e->d_pen_sample.ensure(rows * (size_t)npen)) return false;
     std::vector<uint32_t> h(rows * (size_t)npen);
-    KRN_OK(vmd_hip_cells_pencil_count(e->stream, src.base, src.frame_stride, src.row_stride, d_boxes, pbc, (int)S, s->d_idx.p, nsel, g, e->d_pen_sample.p));
+    KRN_OK(vmd_hip_cells_pencil_count(e->stream, src.base, src.frame_stride, src.row_stride, d_boxes, pbc, (int)S, s->d_idx.p, nsel, g,
+            e->d_pen_sample.p));
     if (!exhaustive) {
         const size_t tail = nb - S;
-        KRN_OK(vmd_hip_cells_pencil_count(e->stream, src.base + tail * src.frame_stride, src.frame_stride, src.row_stride, d_boxes + 9 * tail, pbc, (int)S,
+        KRN_OK(vmd_hip_cells_pencil_count(e->stream, src.base + tail * src.frame_stride, src.frame_stride, src.row_stride, d_boxes + 9
+                * tail, pbc, (int)S,
                                           s->d_idx.p, nsel, g, e->d_pen_sample.p + S * (size_t)npen));
     }
     HIP_OK(hipMemcpyAsync(h.data(), e->d_pen_sample.p, h.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
@@ -51,11 +59,13 @@ bool ensure_pencil_caps(vmd_script_eval_t* e, Selection* s, const Stage& src, co
     return s->d_pen_off.upload(s->pen_off.data(), s->pen_off.size(), e->stream);
 }
 
-bool build_selection(vmd_script_eval_t* e, Selection* s, const Stage& src, const float* d_boxes, uint32_t pbc, size_t nb, const vmd_grid_t& g) {
+bool build_selection(vmd_script_eval_t* e, Selection* s, const Stage& src, const float* d_boxes, uint32_t pbc, size_t nb,
+        const vmd_grid_t& g) {
     if (s->built && s->built_grid.nxf == g.nxf && s->built_grid.ny == g.ny && s->built_grid.nz == g.nz) return true;
     const int nsel = (int)s->idx.size();
     s->nsel_pad = (nsel + 63) & ~63;
-    if (!s->cell_start.ensure(nb * (size_t)(g.ncell + 1)) || !s->sorted.ensure(nb * 3 * (size_t)s->nsel_pad + 64)) return false;   // +64: the pair kernel prefetches past a segment
+    // +64: the pair kernel prefetches past a segment
+    if (!s->cell_start.ensure(nb * (size_t)(g.ncell + 1)) || !s->sorted.ensure(nb * 3 * (size_t)s->nsel_pad + 64)) return false;
     s->used_pencil = false;
     // two-level build through per-pencil buckets (one read of the frame, coalesced sorted rows); single-level builds otherwise
     // A small selection (a solute: the 2 000-atom blob of config 5) is not spread evenly over the pencils and wanders through them as the
@@ -66,11 +76,14 @@ bool build_selection(vmd_script_eval_t* e, Selection* s, const Stage& src, const
         if (!ensure_pencil_caps(e, s, src, d_boxes, pbc, nb, g)) return false;
         if (!s->pen_off.empty() && s->cap_max <= vmd_hip_cells_pencil_cap_max()) {
             const size_t npen = (size_t)g.ny * g.nz;
-            if (!s->pen_count.ensure(nb * npen) || !s->pen_start.ensure(nb * (npen + 1)) || !s->bucket.ensure(nb * (size_t)s->total_cap * 4)) return false;
+            if (!s->pen_count.ensure(nb * npen) || !s->pen_start.ensure(nb * (npen + 1)) || !s->bucket.ensure(nb * (size_t)s->total_cap
+                    * 4)) return false;
             e->prof.begin("cells_build", e->stream);
             vmd_hip_set_cells_overflow_bit(s->overflow_bit);
-            KRN_OK(vmd_hip_cells_build_pencil(e->stream, src.base, src.frame_stride, src.row_stride, d_boxes, pbc, (int)nb, s->d_idx.p, nsel, s->nsel_pad, g,
-                                              s->d_pen_off.p, s->total_cap, s->cap_max, s->pen_count.p, s->pen_start.p, s->bucket.p, e->d_overflow.p,
+            KRN_OK(vmd_hip_cells_build_pencil(e->stream, src.base, src.frame_stride, src.row_stride, d_boxes, pbc, (int)nb, s->d_idx.p,
+                    nsel, s->nsel_pad, g,
+                                              s->d_pen_off.p, s->total_cap, s->cap_max, s->pen_count.p, s->pen_start.p, s->bucket.p,
+                                                      e->d_overflow.p,
                                               s->cell_start.p, s->sorted.p));
             e->prof.end(e->stream);
             s->built = true; s->built_grid = g; s->used_pencil = true;
@@ -129,7 +142,8 @@ void plan_batches(const vmd_script_eval_t* e, size_t beg, size_t end, size_t Bma
         if (f == blk * S && bend <= end && bend - f <= Bmax) {
             even(run, f);
             Batch* last = out->empty() ? nullptr : &out->back();
-            if (super && last && last->blk >= 0 && last->f0 + last->nb == f && last->nb + (bend - f) <= Bmax) { last->nb += bend - f; last->nblk += 1; }
+            if (super && last && last->blk >= 0 && last->f0 + last->nb == f && last->nb + (bend - f) <= Bmax) { last->nb += bend - f;
+                    last->nblk += 1; }
             else out->push_back({f, bend - f, (long)blk, 1});
             f = bend; run = f;
         } else {
@@ -140,14 +154,16 @@ void plan_batches(const vmd_script_eval_t* e, size_t beg, size_t end, size_t Bma
 }
 
 const float* block_rows(const vmd_script_eval_t* src, const PropState* q, size_t blk) {
-    return src->block_ready[blk].load() == BLOCK_ROWS_AHEAD && q->ahead_values.size() == q->values.size() ? q->ahead_values.data() : q->values.data();
+    return src->block_ready[blk].load() == BLOCK_ROWS_AHEAD && q->ahead_values.size() == q->values.size()
+            ? q->ahead_values.data() : q->values.data();
 }
 
 bool reuse_blocks(vmd_script_eval_t* e, const TrajId& traj_inst, size_t beg, size_t end, std::vector<std::pair<size_t, size_t>>* todo) {
     vmd_script_eval_t* src = e->source;
     if (!src) { todo->push_back({beg, end}); return true; }
     std::lock_guard<std::mutex> lock(src->mtx);   // order: own mutex, then the source's (a source never locks its users)
-    if (src->block_frames == 0 || src->blocks_inst != traj_inst) { todo->push_back({beg, end}); return true; }      // (looked up under its mutex: read-ahead may be giving it blocks right now)
+    // (looked up under its mutex: read-ahead may be giving it blocks right now)
+    if (src->block_frames == 0 || src->blocks_inst != traj_inst) { todo->push_back({beg, end}); return true; }
     const size_t S = src->block_frames;
     size_t run = beg, reused = 0;
     for (size_t f = beg; f < end;) {
@@ -201,7 +217,8 @@ bool view_holds(bool have_view, const vmd_device_view_t& view, size_t frame) {
 // spec (read-ahead): [frame_beg, frame_end) is a run of whole frame blocks; every block is evaluated into its own partial and
 // NOTHING else changes - no add into the totals, no frame mask, no frames_done, no normalisation weights outside the block's own, no view
 // (temporal rows are written: a frame's row is the same whenever it is computed, and nobody reads it before its mask bit is set)
-bool process_range_locked(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_trajectory_i* traj, uint32_t frame_beg, uint32_t frame_end, bool views, bool spec) {
+bool process_range_locked(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_trajectory_i* traj, uint32_t frame_beg, uint32_t frame_end,
+        bool views, bool spec) {
     HIP_OK(hipSetDevice(eval->device));
     vmd_script_eval_t* e = eval;
     const size_t num_atoms = traj->num_atoms(traj->inst);
@@ -213,22 +230,26 @@ bool process_range_locked(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
     memset(&view, 0, sizeof(view));
     const bool have_view = traj->device_view && traj->device_view(traj->inst, &view) && view.device == e->device;
     if (have_view && view_sharded(view) && frame_beg < frame_end && (frame_beg < view.resident_beg || frame_end > view.resident_end))
-        return vmd_fail("frames [%u, %u) are not resident on this rank (its shard holds [%zu, %zu))", frame_beg, frame_end, view.resident_beg, view.resident_end);
+        return vmd_fail("frames [%u, %u) are not resident on this rank (its shard holds [%zu, %zu))", frame_beg, frame_end,
+                view.resident_beg, view.resident_end);
 
     // SDF reference pose: structure 0 at trajectory frame 0 (SPEC S5)
     for (auto& p : e->props) {
         if (p->prop.kind != PROP_SDF || p->ref_pose_ready) continue;
         BatchSrc src;
         if (!fetch_batch(e, traj, view_holds(have_view, view, 0) ? &view : nullptr, num_atoms, 0, 1, &src)) return false;
-        KRN_OK(vmd_hip_sdf_ref_pose(e->stream, src.base, src.row_stride, e->stages[0].d_boxes.p, batch_pbc(e->stages[0]), p->d_structs.p, p->d_mass.p,
-                                    (int)p->prop.m, p->d_ref_pose.p, p->have_tree ? p->d_tree_order.p : nullptr, p->have_tree ? p->d_tree_parent.p : nullptr));
+        KRN_OK(vmd_hip_sdf_ref_pose(e->stream, src.base, src.row_stride, e->stages[0].d_boxes.p, batch_pbc(e->stages[0]), p->d_structs.p,
+                p->d_mass.p,
+                                    (int)p->prop.m, p->d_ref_pose.p, p->have_tree ? p->d_tree_order.p : nullptr, p->have_tree
+                                            ? p->d_tree_parent.p : nullptr));
         HIP_OK(hipStreamSynchronize(e->stream));
         p->ref_pose_ready = true;
     }
 
     // frames served from the block partials of the source eval (filtered evaluation), the rest is computed
     std::vector<std::pair<size_t, size_t>> segments;
-    if (spec) segments.push_back({frame_beg, frame_end});         // a region's blocks are adopted from the source by the region leader, or evaluated here
+    // a region's blocks are adopted from the source by the region leader, or evaluated here
+    if (spec) segments.push_back({frame_beg, frame_end});
     else if (!reuse_blocks(e, traj_id(traj), frame_beg, frame_end, &segments)) return false;
     if (e->block_frames) e->blocks_inst = traj_id(traj);
 
@@ -247,13 +268,17 @@ bool process_range_locked(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
         vmd_raw_frame_t probe;
         memset(&probe, 0, sizeof(probe));
         if (!traj->load_raw(traj->inst, (int64_t)frame_beg, nullptr, &probe, nullptr, 0)) raw_ring = false;
-        else if (probe.codec == VMD_RAW_CODEC_F32) { f32_ring = have_map && mv_probe.codec == VMD_RAW_CODEC_F32 && g_opt.raw_f32_device.load(); raw_ring = f32_ring; }
+        else if (probe.codec == VMD_RAW_CODEC_F32) { f32_ring = have_map && mv_probe.codec == VMD_RAW_CODEC_F32
+                && g_opt.raw_f32_device.load(); raw_ring = f32_ring; }
     }
     e->raw_skip = traj->load_raw && !raw_ring;              // fetch_stage: do not ask this trajectory for raw frames batch by batch
     // how many batches the bit streams run ahead of the kernels (one more than the decoder, which runs two ahead).  Copied through
-    // pinned blocks (host threads read them, this thread waits): 3.  Taken out of the mapped file by the copy engine alone: as many as the ring holds minus the one being decoded - the
+    // pinned blocks (host threads read them, this thread waits): 3.  Taken out of the mapped file by the copy engine alone: as many as the
+    // ring holds minus the one being decoded - the
     // DMAs then queue back to back and PCIe never waits for this thread (r03n: 12.4 ms per c2 step against 9.4 ms of transfers).
-    const size_t raw_ahead = (raw_ring && have_map && (f32_ring || g_opt.xtc_device_decode.load() == 3)) ? vmd_script_eval_t::kRawSlots - 1 : 3;      // always > stage_ahead
+    // always > stage_ahead
+    const size_t raw_ahead = (raw_ring && have_map && (f32_ring || g_opt.xtc_device_decode.load() == 3)) ? vmd_script_eval_t::kRawSlots
+            - 1 : 3;
     auto slot_of = [&](size_t bi) -> RawSlot* { return raw_ring ? &e->raw_slots[bi % vmd_script_eval_t::kRawSlots] : nullptr; };
     // batches decompressed on the device while the previous batch is in the pair kernel: the persistent pair grid leaves room for them
     const bool device_decode = raw_ring || (!have_view && traj->raw_device_view && traj->raw_device_view(traj->inst, &rv_probe));
@@ -274,12 +299,14 @@ bool process_range_locked(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
         const size_t npad_s = (num_atoms + 63) & ~(size_t)63;
         const size_t S0 = (size_t)std::max(1, g_opt.stage_frames.load());
         const size_t S = std::max<size_t>(1, std::min<size_t>(S0, S0 * 100032 / std::max<size_t>(npad_s, 1)));
-        bool warm = f32_ring;                               // does the first frame of the range have checkpoints already?  (plain floats need none)
+        // does the first frame of the range have checkpoints already?  (plain floats need none)
+        bool warm = f32_ring;
         if (!f32_ring && device_decode && g_opt.xtc_checkpoints.load() && frame_beg < frame_end) {
             if (raw_ring) {
                 std::lock_guard<std::mutex> l(g_ck_mtx);
                 auto it = g_ck_store.find(CkKey(traj->inst, e->device));
-                warm = it != g_ck_store.end() && it->second && it->second->frames == traj->num_frames(traj->inst) && it->second->atoms == num_atoms &&
+                warm = it != g_ck_store.end() && it->second && it->second->frames == traj->num_frames(traj->inst)
+                        && it->second->atoms == num_atoms &&
                        it->second->device == e->device && it->second->have.size() > frame_beg && flag_get(&it->second->have[frame_beg]);
             }
             else warm = rv_probe.ck_have && flag_get(&rv_probe.ck_have[frame_beg]);
@@ -288,12 +315,14 @@ bool process_range_locked(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
         cold_walk = raw_ring && !f32_ring && !warm && have_map && g_opt.xtc_device_decode.load() == 3 && g_opt.xtc_cold_streams.load() != 0;
         // (a walk takes as long for one frame as for a thousand - 7 ms for a c2 frame, 70 ms for 1M atoms -: never more launches than
         // decode streams for a short range)
-        const size_t cold_b = std::max<size_t>(2 * S, (frame_end - frame_beg + vmd_script_eval_t::kDecodeStreams - 1) / vmd_script_eval_t::kDecodeStreams);
+        const size_t cold_b = std::max<size_t>(2 * S, (frame_end - frame_beg + vmd_script_eval_t::kDecodeStreams
+                - 1) / vmd_script_eval_t::kDecodeStreams);
         Bmax = std::min<size_t>(Bmax, !device_decode ? S : (raw_ring ? (warm ? S : (cold_walk ? cold_b : 4 * S)) : (warm ? 8 * S : 4 * S)));
     }
     std::vector<Batch> batches;
     for (auto& sg : segments) plan_batches(e, sg.first, sg.second, Bmax, &batches);
-    if (spec) for (auto& b : batches) if (b.blk < 0) return vmd_fail("read-ahead: region [%u, %u) is not made of whole frame blocks", frame_beg, frame_end);
+    if (spec) for (auto& b : batches) if (b.blk < 0) return vmd_fail("read-ahead: region [%u, %u) is not made of whole frame blocks",
+            frame_beg, frame_end);
     // From a file the first batch has to cross PCIe and be decompressed before any kernel can start, and nothing overlaps the last
     // batch's kernels (r03p timeline: 1.7 ms of a 12.3 ms c2 step before the first pair kernel, one DMA = 1.13 ms per 128 frames).
     // Option xtc_ramp: the run starts with an eighth and a quarter of a batch and ends with a quarter.  Measured (r03o): the shorter
@@ -305,7 +334,8 @@ bool process_range_locked(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
         if (first.blk < 0 && first.nb >= 64) { carve_front(first, first.nb / 8); carve_front(first, first.nb / 3); }
         ramped.push_back(first);
         for (size_t i = 1; i + 1 < batches.size(); ++i) ramped.push_back(batches[i]);
-        if (last.blk < 0 && last.nb >= 64) { const size_t tail = last.nb / 4; ramped.push_back({last.f0, last.nb - tail, -1, 0}); ramped.push_back({last.f0 + last.nb - tail, tail, -1, 0}); }
+        if (last.blk < 0 && last.nb >= 64) { const size_t tail = last.nb / 4; ramped.push_back({last.f0, last.nb - tail, -1, 0});
+                ramped.push_back({last.f0 + last.nb - tail, tail, -1, 0}); }
         else ramped.push_back(last);
         batches.swap(ramped);
     }
@@ -324,7 +354,8 @@ bool process_range_locked(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
     } blocks_guard;
     if (device_decode && batches.size() > 1 && g_opt.rdf_blocks_decode.load() >= 8) {
         blocks_guard.old = vmd_hip_set_rdf_blocks(g_opt.rdf_blocks_decode.load());
-        if (blocks_guard.old < g_opt.rdf_blocks_decode.load()) vmd_hip_set_rdf_blocks(blocks_guard.old);      // never raise a smaller setting
+        // never raise a smaller setting
+        if (blocks_guard.old < g_opt.rdf_blocks_decode.load()) vmd_hip_set_rdf_blocks(blocks_guard.old);
     }
     if (raw_ring) {
         for (auto& rs : e->raw_slots) rs.state = 0;
@@ -393,7 +424,8 @@ bool process_range_locked(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
             if (open_axes && !g_opt.force_brute && !prepare_open_boxes(e, *c.src, c.nb, c.pbc, num_atoms)) return false;
             const std::vector<float>& gb = (open_axes && c.src->gboxes_ready) ? c.src->h_gboxes : c.src->h_boxes;
             const float* d_gb = (open_axes && c.src->gboxes_ready) ? c.src->d_gboxes.p : c.src->d_boxes.p;
-            // density of the sparsest selection any pass of this group puts in the lanes (the denser of its two), against the first frame's cell
+            // density of the sparsest selection any pass of this group puts in the lanes (the denser of its two), against the first frame's
+            // cell
             bool dense_lanes = !open_axes && !g.passes.empty();
             if (dense_lanes) {
                 const float* q = gb.data();
@@ -412,7 +444,8 @@ bool process_range_locked(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
                     for (auto& su : c.subs) {
                         uint64_t* dst = e->d_pass.p + (row++) * VMD_RDF_NUM_BINS;
                         e->prof.begin("rdf_brute", e->stream);
-                        KRN_OK(vmd_hip_rdf_brute(e->stream, c.src->base + su.off * c.src->frame_stride, c.src->frame_stride, c.src->row_stride, c.src->d_boxes.p + 9 * su.off, c.pbc, (int)su.nb,
+                        KRN_OK(vmd_hip_rdf_brute(e->stream, c.src->base + su.off * c.src->frame_stride, c.src->frame_stride,
+                                c.src->row_stride, c.src->d_boxes.p + 9 * su.off, c.pbc, (int)su.nb,
                                                  sa->d_idx.p, (int)sa->idx.size(), sb->d_idx.p, (int)sb->idx.size(),
                                                  g.rmin, g.rmax, VMD_RDF_NUM_BINS, dst));
                         e->prof.end(e->stream);
@@ -448,10 +481,13 @@ bool process_range_locked(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
                     const bool second = c.two_streams && (si++ & 1);
                     hipStream_t ks = second ? e->pair_stream : e->stream;
                     if (!second) e->prof.begin("rdf_pencil", ks);
-                    KRN_OK(vmd_hip_rdf_pencil(ks, sa->sorted.p + su.off * 3 * (size_t)sa->nsel_pad, sa->cell_start.p + su.off * (size_t)(grid.ncell + 1), (int)sa->idx.size(), sa->nsel_pad,
-                                              sb->sorted.p + su.off * 3 * (size_t)sb->nsel_pad, sb->cell_start.p + su.off * (size_t)(grid.ncell + 1), (int)sb->idx.size(), sb->nsel_pad,
+                    KRN_OK(vmd_hip_rdf_pencil(ks, sa->sorted.p + su.off * 3 * (size_t)sa->nsel_pad, sa->cell_start.p + su.off
+                            * (size_t)(grid.ncell + 1), (int)sa->idx.size(), sa->nsel_pad,
+                                              sb->sorted.p + su.off * 3 * (size_t)sb->nsel_pad, sb->cell_start.p + su.off
+                                                      * (size_t)(grid.ncell + 1), (int)sb->idx.size(), sb->nsel_pad,
                                               d_gb + 9 * su.off, (int)su.nb, grid, g.rmin, g.rmax, VMD_RDF_NUM_BINS,
-                                              ps.same ? 1 : 0, g_opt.rdf_variant, c.pbc, second ? e->d_partial2.p : e->d_partial.p, dst, e->d_overflow.p));
+                                              ps.same ? 1 : 0, g_opt.rdf_variant, c.pbc, second ? e->d_partial2.p : e->d_partial.p, dst,
+                                                      e->d_overflow.p));
                     if (!second) e->prof.end(ks);
                     if (e->spec.rdf_closed && ps.same && g.rmin <= 0.0f && 0.0f <= g.rmax) {
                         // closed interval: d = 0 is a hit, but a same-set pass walks the half shell (j > i, every hit twice) and never
@@ -473,7 +509,8 @@ bool process_range_locked(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
         return true;
     };
 
-    // waits for a queued batch (`later`: the batch already queued behind it, if any), repeats its RDF part when a bucket overflowed, books its frames
+    // waits for a queued batch (`later`: the batch already queued behind it, if any), repeats its RDF part when a bucket overflowed, books
+    // its frames
     auto complete_batch = [&](BatchCtx& c, BatchCtx* later) -> bool {
         if (!c.active) return true;
         c.active = false;
@@ -488,16 +525,19 @@ bool process_range_locked(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
         bool repeated = false;
         for (int attempt = 0; e->h_overflow[c.slot] != 0; ++attempt) {
             if (attempt >= 4) return vmd_fail("cell build: pencil buckets keep overflowing");
-            if (behind) {          // the batch behind this one saw the flag too: let it drain, it repeats its RDF part at its own completion
+            // the batch behind this one saw the flag too: let it drain, it repeats its RDF part at its own completion
+            if (behind) {
                 HIP_OK(hipStreamSynchronize(e->stream));
                 later->poisoned = true;
             }
             const bool own = !(c.poisoned && attempt == 0);      // a poisoned batch did not overflow itself (as far as anyone knows)
-            const uint32_t who = e->h_overflow[c.slot];           // one bit per selection (Selection::overflow_bit; selections beyond 32 share)
+            // one bit per selection (Selection::overflow_bit; selections beyond 32 share)
+            const uint32_t who = e->h_overflow[c.slot];
             for (auto& sl : e->sels) {
                 sl->built = false;
                 // only the selection whose buckets were too small gets wider ones.  (Its bit, not used_pencil, says so: a selection can be
-                // sorted through buckets on one group's grid and by the single-block build on another's within ONE batch - co-evaluated RDFs
+                // sorted through buckets on one group's grid and by the single-block build on another's within ONE batch - co-evaluated
+                // RDFs
                 // with different cutoffs - and used_pencil only remembers the last of them; fuzz seed 8941, round 4.)
                 if (!own || !(who & sl->overflow_bit)) continue;
                 sl->pen_off.clear();
@@ -522,7 +562,8 @@ bool process_range_locked(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
             // evaluated ahead: the rows wait beside the view until their block is committed (a reader of the values array never sees a
             // frame nobody asked for)
             if (spec && p->ahead_values.size() != p->values.size()) p->ahead_values.assign(p->values.size(), 0.0f);
-            memcpy(spec ? &p->ahead_values[c.f0 * p->dim1] : &p->values[c.f0 * p->dim1], e->h_temporal_slot[c.slot].data() + toff, c.nb * p->dim1 * sizeof(float));
+            memcpy(spec ? &p->ahead_values[c.f0 * p->dim1] : &p->values[c.f0 * p->dim1], e->h_temporal_slot[c.slot].data() + toff, c.nb
+                    * p->dim1 * sizeof(float));
             toff += c.nb * p->dim1;
         }
         e->frames_computed += c.nb;
@@ -535,7 +576,8 @@ bool process_range_locked(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
         size_t soff = (size_t)c.slot * rdf_counts;
         for (auto& p : e->props) {
             if (p->prop.kind != PROP_RDF) continue;
-            if (behind && c.snapshot && !repeated && !(later && later->poisoned)) refresh_distribution_from(p.get(), e->h_snap + soff, e->w_snap.data() + soff);
+            if (behind && c.snapshot && !repeated && !(later && later->poisoned)) refresh_distribution_from(p.get(), e->h_snap + soff,
+                    e->w_snap.data() + soff);
             else if (!behind && views) { if (!refresh_distribution(e, p.get())) return false; }
             soff += p->ncounts;
         }
@@ -569,7 +611,8 @@ bool process_range_locked(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
         } else c.subs.push_back({0, c.nb, c.bt.blk});
         if (c.bt.blk >= 0)
             for (auto& sb : c.subs)
-                for (auto& p : e->props) if (p->ncounts) HIP_OK(hipMemsetAsync(acc_of(p.get(), sb), 0, p->ncounts * sizeof(uint64_t), e->stream));
+                for (auto& p : e->props) if (p->ncounts) HIP_OK(hipMemsetAsync(acc_of(p.get(), sb), 0, p->ncounts * sizeof(uint64_t),
+                        e->stream));
         // the blocks' pair launches alternate between the eval's stream and a second one (own partial rows): a 50-frame launch of a
         // 100k-atom system is ~3 work items per resident wave, and the tail of one launch then runs under the head of the next
         c.two_streams = c.subs.size() > 1 && g_opt.block_two_streams.load() != 0;
@@ -587,7 +630,9 @@ bool process_range_locked(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
                     for (size_t b = su.off; b < su.off + su.nb; ++b) {
                         const float* L = &c.src->h_boxes[9 * b];
                         double V;
-                        if ((c.pbc & VMD_UNITCELL_PBC_ALL) == VMD_UNITCELL_PBC_ALL && e->spec.rdf_norm != 1) V = (double)L[0] * (double)L[1] * (double)L[2];   // also the triclinic volume
+                        // also the triclinic volume
+                        if ((c.pbc & VMD_UNITCELL_PBC_ALL) == VMD_UNITCELL_PBC_ALL && e->spec.rdf_norm != 1) V = (double)L[0]
+                                * (double)L[1] * (double)L[2];
                         else V = (4.0 / 3.0) * M_PI * (double)d.rmax * (double)d.rmax * (double)d.rmax;
                         const double rho = (e->spec.rdf_norm == 2 ? 1.0 : (double)d.a.size()) * (double)d.b.size() / V;
                         const double w = ((double)d.rmax - (double)d.rmin) / (double)p->ncounts;
@@ -607,27 +652,35 @@ bool process_range_locked(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
                 e->prof.begin("sdf_align", e->stream);
                 if (p->have_tree && !p->d_tree_pos.ensure(c.nb * d.K * d.m * 3)) return false;
                 KRN_OK(vmd_hip_sdf_align(e->stream, c.src->base, c.src->frame_stride, c.src->row_stride, c.src->d_boxes.p, c.pbc, (int)c.nb,
-                                         p->d_structs.p, p->d_mass.p, (int)d.K, (int)d.m, p->d_ref_pose.p, p->d_R32.p, p->d_c32.p, nullptr, p->d_group.p,
-                                         p->have_tree ? p->d_tree_order.p : nullptr, p->have_tree ? p->d_tree_parent.p : nullptr, p->have_tree ? p->d_tree_pos.p : nullptr));
+                                         p->d_structs.p, p->d_mass.p, (int)d.K, (int)d.m, p->d_ref_pose.p, p->d_R32.p, p->d_c32.p, nullptr,
+                                                 p->d_group.p,
+                                         p->have_tree ? p->d_tree_order.p : nullptr, p->have_tree ? p->d_tree_parent.p : nullptr,
+                                                 p->have_tree ? p->d_tree_pos.p : nullptr));
                 e->prof.end(e->stream);
                 e->prof.begin("sdf_scatter", e->stream);
                 for (auto& su : c.subs)
-                    KRN_OK(vmd_hip_sdf_scatter(e->stream, c.src->base + su.off * c.src->frame_stride, c.src->frame_stride, c.src->row_stride, c.src->d_boxes.p + 9 * su.off, c.pbc, (int)su.nb,
-                                               p->d_structs.p, (int)d.K, (int)d.m, p->d_R32.p + su.off * d.K * 9, p->d_c32.p + su.off * d.K * 3, p->d_tgt.p,
+                    KRN_OK(vmd_hip_sdf_scatter(e->stream, c.src->base + su.off * c.src->frame_stride, c.src->frame_stride,
+                            c.src->row_stride, c.src->d_boxes.p + 9 * su.off, c.pbc, (int)su.nb,
+                                               p->d_structs.p, (int)d.K, (int)d.m, p->d_R32.p + su.off * d.K * 9, p->d_c32.p + su.off * d.K
+                                                       * 3, p->d_tgt.p,
                                                (p->have_owner && !e->spec.sdf_include_self) ? p->d_owner.p : nullptr, (int)d.b.size(),
                                                d.rmax, VMD_VOLUME_DIM, acc_of(p.get(), su), p->d_group.p + 4 * su.off,
-                                               (p->have_tag && p->tag_len == c.src->row_stride && !e->spec.sdf_include_self) ? p->d_tag.p : nullptr,
+                                               (p->have_tag && p->tag_len == c.src->row_stride && !e->spec.sdf_include_self)
+                                                       ? p->d_tag.p : nullptr,
                                                p->tgt_first, p->tgt_stride, (p->unowned || e->spec.sdf_include_self) ? 1 : 0));
                 e->prof.end(e->stream);
                 p->dirty = p->dirty || !spec;
             } else {
                 if (!p->d_out.ensure(c.nb * p->dim1)) return false;
                 e->prof.begin("distance", e->stream);
-                KRN_OK(vmd_hip_distance(e->stream, c.src->base, c.src->frame_stride, c.src->row_stride, c.src->d_boxes.p, c.pbc, (int)c.nb, d.dist_kind,
-                                        (int)p->dist_P, (int)p->dist_per, p->d_a.p, p->d_ma.p, p->d_aoff.p, p->d_b.p, p->d_mb.p, p->d_boff.p,
+                KRN_OK(vmd_hip_distance(e->stream, c.src->base, c.src->frame_stride, c.src->row_stride, c.src->d_boxes.p, c.pbc, (int)c.nb,
+                        d.dist_kind,
+                                        (int)p->dist_P, (int)p->dist_per, p->d_a.p, p->d_ma.p, p->d_aoff.p, p->d_b.p, p->d_mb.p,
+                                                p->d_boff.p,
                                         p->d_out.p));
                 e->prof.end(e->stream);
-                HIP_OK(hipMemcpyAsync(e->h_temporal_slot[c.slot].data() + toff, p->d_out.p, c.nb * p->dim1 * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+                HIP_OK(hipMemcpyAsync(e->h_temporal_slot[c.slot].data() + toff, p->d_out.p, c.nb * p->dim1 * sizeof(float),
+                        hipMemcpyDeviceToHost, e->stream));
                 toff += c.nb * p->dim1;
                 p->dirty = p->dirty || !spec;
             }
@@ -659,7 +712,8 @@ bool process_range_locked(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
             }
             // ... and send the bit streams of the batch after that on their way (its slot held batch bi - 1: decoded long ago)
             if (raw_ring && bi + raw_ahead < batches.size() &&
-                raw_upload(e, *slot_of(bi + raw_ahead), traj, num_atoms, batches[bi + raw_ahead].f0, batches[bi + raw_ahead].nb) < 0) return false;
+                raw_upload(e, *slot_of(bi + raw_ahead), traj, num_atoms, batches[bi + raw_ahead].f0, batches[bi
+                        + raw_ahead].nb) < 0) return false;
         }
         if (!defer && !complete_batch(c, nullptr)) return false;
     }
@@ -679,7 +733,8 @@ bool process_range_locked(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
     return completed;
 }
 
-bool process_range(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_trajectory_i* traj, uint32_t frame_beg, uint32_t frame_end, bool views) {
+bool process_range(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_trajectory_i* traj, uint32_t frame_beg, uint32_t frame_end,
+        bool views) {
     g_last_error.clear();
     if (eval->interrupt) return false;
     std::lock_guard<std::mutex> lock(eval->mtx);
@@ -694,8 +749,10 @@ bool refresh_views_locked(vmd_script_eval_t* e) {
         if (!p->dirty) continue;
         if (p->prop.kind == PROP_RDF) { if (!refresh_distribution(e, p.get())) return false; }
         else if (p->prop.kind == PROP_SDF) {
-            // vmd_eval_defer_volume_views: a rank of a multi-GPU evaluation does not materialise ITS partial volume's float view (8.4 MB over
-            // PCIe after every range) - the merge re-derives the view of the merged counts (vmd_eval_reduce -> vmd_eval_finalize); the volume
+            // vmd_eval_defer_volume_views: a rank of a multi-GPU evaluation does not materialise ITS partial volume's float view (8.4 MB
+            // over
+            // PCIe after every range) - the merge re-derives the view of the merged counts (vmd_eval_reduce -> vmd_eval_finalize); the
+            // volume
             // stays dirty until then
             if (e->defer_volume_views.load(std::memory_order_relaxed)) continue;
             if (!refresh_volume(e, p.get())) return false;
@@ -769,7 +826,8 @@ bool combine_call(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_trajecto
         // trajectory type per call (include/vmd_md_script_shim.h did, from every pool thread) presents a different address each time
         // (such ranges never fused)
         auto same_traj = [](const vmd_trajectory_i* a, const vmd_trajectory_i* b) {
-            return a == b || (a->inst == b->inst && a->load_frame == b->load_frame && a->device_view == b->device_view && a->load_raw == b->load_raw);
+            return a == b || (a->inst == b->inst && a->load_frame == b->load_frame && a->device_view == b->device_view
+                    && a->load_raw == b->load_raw);
         };
         std::sort(taken.begin(), taken.end(), [](const RangeRequest* a, const RangeRequest* b) {
             return a->traj->inst != b->traj->inst ? a->traj->inst < b->traj->inst : a->beg < b->beg; });
@@ -777,22 +835,26 @@ bool combine_call(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_trajecto
         while (i < taken.size()) {
             size_t j = i + 1;
             uint32_t run_end = taken[i]->end;
-            while (j < taken.size() && same_traj(taken[j]->traj, taken[i]->traj) && taken[j]->beg == run_end) { run_end = taken[j]->end; ++j; }
+            while (j < taken.size() && same_traj(taken[j]->traj, taken[i]->traj) && taken[j]->beg == run_end) { run_end = taken[j]->end;
+                    ++j; }
             const bool ok = process_range(eval, taken[i]->sys, taken[i]->traj, taken[i]->beg, run_end, !lazy);
             const std::string err = ok ? std::string() : g_last_error;
             for (size_t k = i; k < j; ++k) { taken[k]->ok = ok; taken[k]->error = err; }
             all_ok = all_ok && ok;
             i = j;
         }
-        const long round_us = (long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - round_t0).count();
+        const long round_us = (long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now()
+                - round_t0).count();
         ql.lock();
         eval->last_round_us = round_us;
         if (lazy) {
-            const bool overdue = std::chrono::steady_clock::now() - eval->views_at > std::chrono::milliseconds(std::max(1, g_opt.lazy_views_ms.load()));
+            const bool overdue = std::chrono::steady_clock::now() - eval->views_at > std::chrono::milliseconds(std::max(1,
+                    g_opt.lazy_views_ms.load()));
             if (eval->queue.empty() || overdue) {
                 ql.unlock();
                 const bool vok = refresh_views(eval);
-                if (!vok && all_ok) { const std::string err = g_last_error; for (RangeRequest* r : taken) { r->ok = false; r->error = err; } }
+                if (!vok && all_ok) { const std::string err = g_last_error; for (RangeRequest* r : taken) { r->ok = false; r->error = err;
+                        } }
                 ql.lock();
             }
         }

@@ -1,3 +1,7 @@
+// viamd_amd/csrc/vmd_eval_calls.cpp - how calls ARRIVE.  VIAMD does not call md_script_eval_frame_range once: a pool
+// task hands single frames to many threads that all block in it (/root/reference/src/main.cpp:993-997, src/task_system.cpp:73-81).
+// Combining queue (the first caller leads, later ones queue), read-ahead (regions evaluated ahead into block partials, calls only mark
+// their frames, whoever leaves last settles), the opt-in deferred settle on a helper thread, and vmd_eval_frame_range itself.
 #include "vmd_eval_internal.h"
 
 void ra_reset(vmd_script_eval_t* e) {          // clear_data (mtx held): a new evaluation starts
@@ -12,12 +16,15 @@ void ra_reset(vmd_script_eval_t* e) {          // clear_data (mtx held): a new e
 size_t ra_block_frames(const vmd_script_eval_t* e, size_t Bmax) {
     size_t G = (size_t)std::max(0, g_opt.readahead_block.load());
     if (!G) {
-        if (e->rdf_groups.empty()) G = 1024;          // streaming scripts: 16.8 MB of memset + add per volume and block - few, large blocks (r04c, 10 000-frame SDF at grain 1: 10.8 ms with 256, 9.7 with 512, 9.2 with 1 024; one call 7.0)
+        // streaming scripts: 16.8 MB of memset + add per volume and block - few, large blocks (r04c, 10 000-frame SDF at grain 1: 10.8 ms
+        // with 256, 9.7 with 512, 9.2 with 1 024; one call 7.0)
+        if (e->rdf_groups.empty()) G = 1024;
         else {
             // pair passes: one pair launch per block; it needs ~4M selected atoms to fill the chip (50-frame launches of the
             // 100k-atom box cost +12 %, 125-frame launches +5 %), and a block is also the most a ragged range end evaluates directly
             size_t sel = 1;
-            for (auto& g : e->rdf_groups) for (auto& ps : g.passes) sel = std::max(sel, std::max(e->sels[ps.sel_a]->idx.size(), e->sels[ps.sel_b]->idx.size()));
+            for (auto& g : e->rdf_groups) for (auto& ps : g.passes) sel = std::max(sel, std::max(e->sels[ps.sel_a]->idx.size(),
+                    e->sels[ps.sel_b]->idx.size()));
             G = 16;
             while (G < 128 && G * sel < 4000000) G *= 2;
         }
@@ -37,7 +44,8 @@ bool ra_engage(vmd_script_eval_t* e, vmd_trajectory_i* traj) {
     const size_t Bmax = auto_batch(e, num_atoms, !have_view);
     if (e->block_frames == 0) {
         // a filtered eval (src/main.cpp:1014-1039) adopts whole blocks from its source's partials: same blocks as the source
-        // (the source may be engaging at this very moment - "Eval Full" and "Eval Filt" side by side: its block size is read under its mutex;
+        // (the source may be engaging at this very moment - "Eval Full" and "Eval Filt" side by side: its block size is read under its
+        // mutex;
         // order: own mutex, then the source's, as everywhere)
         size_t src_S = 0;
         if (e->source) { std::lock_guard<std::mutex> sl(e->source->mtx); src_S = e->source->block_frames; }
@@ -106,8 +114,10 @@ bool ra_adopt_blocks(vmd_script_eval_t* e, const TrajId& traj_inst, size_t b0, s
             PropState* p = e->props[i].get();
             const PropState* q = src->props[i].get();
             if (p->ncounts) {
-                HIP_OK(hipMemcpyAsync(p->d_blocks.p + b * p->ncounts, q->d_blocks.p + b * p->ncounts, p->ncounts * sizeof(uint64_t), hipMemcpyDeviceToDevice, e->stream));
-                if (p->prop.kind == PROP_RDF) memcpy(&p->block_weights64[b * p->ncounts], &q->block_weights64[b * p->ncounts], p->ncounts * sizeof(double));
+                HIP_OK(hipMemcpyAsync(p->d_blocks.p + b * p->ncounts, q->d_blocks.p + b * p->ncounts, p->ncounts * sizeof(uint64_t),
+                        hipMemcpyDeviceToDevice, e->stream));
+                if (p->prop.kind == PROP_RDF) memcpy(&p->block_weights64[b * p->ncounts], &q->block_weights64[b * p->ncounts], p->ncounts
+                        * sizeof(double));
             } else {
                 if (p->ahead_values.size() != p->values.size()) p->ahead_values.assign(p->values.size(), 0.0f);
                 memcpy(&p->ahead_values[f0 * p->dim1], block_rows(src, q, b) + f0 * p->dim1, (f1 - f0) * p->dim1 * sizeof(float));
@@ -130,7 +140,8 @@ bool ra_commit_block(vmd_script_eval_t* e, size_t blk) {
     for (auto& p : e->props) {
         if (p->ncounts) {
             KRN_OK(vmd_hip_add_u64(e->stream, p->d_counts.p, p->d_blocks.p + blk * p->ncounts, p->ncounts));
-            if (p->prop.kind == PROP_RDF) for (size_t k = 0; k < p->ncounts; ++k) p->weights64[k] += p->block_weights64[blk * p->ncounts + k];
+            if (p->prop.kind == PROP_RDF) for (size_t k = 0; k < p->ncounts; ++k) p->weights64[k] += p->block_weights64[blk * p->ncounts
+                    + k];
         } else if (p->ahead_values.size() == p->values.size()) {
             memcpy(&p->values[f0 * p->dim1], &p->ahead_values[f0 * p->dim1], (f1 - f0) * p->dim1 * sizeof(float));
         }
@@ -154,7 +165,8 @@ bool ra_settle(vmd_script_eval_t* e, const vmd_system_t* sys, vmd_trajectory_i* 
     std::lock_guard<std::mutex> lock(e->mtx);
     HIP_OK(hipSetDevice(e->device));
     const size_t S = e->block_frames;
-    if (full) (void)ra.marks_pending.exchange(false, std::memory_order_seq_cst);    // before the scan: whoever marks after this point sets it again (ra_fast)
+    // before the scan: whoever marks after this point sets it again (ra_fast)
+    if (full) (void)ra.marks_pending.exchange(false, std::memory_order_seq_cst);
     std::vector<std::pair<uint32_t, uint32_t>> runs;          // frames to evaluate directly
     bool tainted = false;
     for (size_t b = 0; b < e->num_blocks; ++b) {
@@ -163,10 +175,12 @@ bool ra_settle(vmd_script_eval_t* e, const vmd_system_t* sys, vmd_trajectory_i* 
         const size_t f0 = b * S, f1 = std::min(f0 + S, e->num_frames);
         if (st == vmd_script_eval_t::RA_READY) {
             size_t req = 0;
-            for (size_t f = f0; f < f1; ++f) req += ra.req(f).load(std::memory_order_seq_cst) ? 1 : 0;     // seq_cst: ordered after the exchange of marks_pending above
+            // seq_cst: ordered after the exchange of marks_pending above
+            for (size_t f = f0; f < f1; ++f) req += ra.req(f).load(std::memory_order_seq_cst) ? 1 : 0;
             if (req == f1 - f0) { if (!ra_commit_block(e, b)) return false; continue; }
             if (req == 0 || !full) continue;
-            ra.blk_state[b].store(vmd_script_eval_t::RA_DIRECT, std::memory_order_release);       // partly requested: its frames are evaluated one by one from now on
+            // partly requested: its frames are evaluated one by one from now on
+            ra.blk_state[b].store(vmd_script_eval_t::RA_DIRECT, std::memory_order_release);
             tainted = true;
         }
         for (size_t f = f0; f < f1; ++f) {
@@ -182,8 +196,10 @@ bool ra_settle(vmd_script_eval_t* e, const vmd_system_t* sys, vmd_trajectory_i* 
         ra.direct_frames += r.second - r.first;
         ra.views_dirty = true;
     }
-    if (tainted && ++ra.strikes >= 3) ra.disabled = true;     // (settle_mtx) callers that keep leaving blocks half requested are not a pool walking a range
-    const bool overdue = std::chrono::steady_clock::now() - e->views_at > std::chrono::milliseconds(std::max(1, g_opt.lazy_views_ms.load()));
+    // (settle_mtx) callers that keep leaving blocks half requested are not a pool walking a range
+    if (tainted && ++ra.strikes >= 3) ra.disabled = true;
+    const bool overdue = std::chrono::steady_clock::now() - e->views_at > std::chrono::milliseconds(std::max(1,
+            g_opt.lazy_views_ms.load()));
     if ((full || overdue) && ra.views_dirty.exchange(false)) { if (!refresh_views_locked(e)) return false; }
     ra.settles += full ? 1 : 0;
     return true;
@@ -197,12 +213,14 @@ bool ra_fast(vmd_script_eval_t* e, uint32_t beg, uint32_t end) {
         const uint8_t st = ra.blk_state[b].load(std::memory_order_acquire);
         if (st != vmd_script_eval_t::RA_READY && st != vmd_script_eval_t::RA_DIRECT) return false;
     }
-    for (uint32_t f = beg; f < end; ++f) if (ra.req(f).load(std::memory_order_relaxed)) return false;      // asked for twice: the slow path sorts that out
+    // asked for twice: the slow path sorts that out
+    for (uint32_t f = beg; f < end; ++f) if (ra.req(f).load(std::memory_order_relaxed)) return false;
     // the marks FIRST, then the flag, both sequentially consistent (the other order lost marks - B sees or sets the flag, the
     // settling A clears it and scans B's block before B's CAS lands, B marks, and B's ra_leave finds the flag clear: requested frames that
     // nobody commits).  A settle clears the flag with a seq_cst exchange and scans after it: a mark that the scan misses is followed by a
     // store of the flag that the exchange did not clear, so the marker's own ra_leave (or a later caller's) settles again.
-    for (uint32_t f = beg; f < end; ++f) { uint8_t z = 0; (void)ra.req(f).compare_exchange_strong(z, 1, std::memory_order_seq_cst); }   // a lost race = another call for the same frame owns it
+    // a lost race = another call for the same frame owns it
+    for (uint32_t f = beg; f < end; ++f) { uint8_t z = 0; (void)ra.req(f).compare_exchange_strong(z, 1, std::memory_order_seq_cst); }
     ra.marks_pending.store(true, std::memory_order_seq_cst);
     return true;
 }
@@ -235,12 +253,14 @@ bool ra_direct_call(vmd_script_eval_t* e, const vmd_system_t* sys, vmd_trajector
         if (ready && !ra_settle(e, sys, traj, true)) return false;
         std::lock_guard<std::mutex> sl(ra.settle_mtx);
         std::lock_guard<std::mutex> ql(e->queue_mtx);
-        bool pending = false;          // a region leader took one of them in the meantime: wait for it, or its partial would count these frames again
+        // a region leader took one of them in the meantime: wait for it, or its partial would count these frames again
+        bool pending = false;
         for (size_t b = b0; b <= b1; ++b) pending = pending || ra.blk_state[b].load() == vmd_script_eval_t::RA_PENDING;
         if (pending) continue;
         for (size_t b = b0; b <= b1; ++b) {
             const uint8_t st = ra.blk_state[b].load();
-            if (st == vmd_script_eval_t::RA_READY || st == vmd_script_eval_t::RA_NONE) ra.blk_state[b].store(vmd_script_eval_t::RA_DIRECT, std::memory_order_release);
+            if (st == vmd_script_eval_t::RA_READY || st == vmd_script_eval_t::RA_NONE) ra.blk_state[b].store(vmd_script_eval_t::RA_DIRECT,
+                    std::memory_order_release);
         }
         break;
     }
@@ -252,7 +272,8 @@ bool ra_direct_call(vmd_script_eval_t* e, const vmd_system_t* sys, vmd_trajector
 bool ra_call(vmd_script_eval_t* e, const vmd_system_t* sys, vmd_trajectory_i* traj, uint32_t beg, uint32_t end) {
     ReadAhead& ra = e->ra;
     const bool small = (int)(end - beg) <= g_opt.readahead_small.load();
-    if (small && !ra.disabled && ra.on.load(std::memory_order_acquire) && ra.concurrent.load(std::memory_order_relaxed) && ra.traj_inst == traj_id(traj) && ra_fast(e, beg, end)) return true;
+    if (small && !ra.disabled && ra.on.load(std::memory_order_acquire) && ra.concurrent.load(std::memory_order_relaxed)
+            && ra.traj_inst == traj_id(traj) && ra_fast(e, beg, end)) return true;
     std::unique_lock<std::mutex> ql(e->queue_mtx);
     if ((uint32_t)ra.flight.load() >= 2 && !ra.concurrent) { ra.concurrent = true; e->queue_cv.notify_all(); }
     if (small && !ra.disabled) {
@@ -265,12 +286,14 @@ bool ra_call(vmd_script_eval_t* e, const vmd_system_t* sys, vmd_trajectory_i* tr
                 ra.concurrent = true;
             } else {
                 // the first call of an evaluation: is this a pool?  Its other threads are microseconds behind
-                cv_wait_us(e->queue_cv, ql, std::max(0, g_opt.readahead_company_us.load()), [&] { return ra.concurrent || e->interrupt.load(); });
+                cv_wait_us(e->queue_cv, ql, std::max(0, g_opt.readahead_company_us.load()), [&] { return ra.concurrent
+                        || e->interrupt.load(); });
                 if (!ra.concurrent) ra.lonely = true;
             }
         }
         if (ra.concurrent && !ra.on.load()) {
-            e->queue_cv.wait(ql, [&] { return ra.combining == 0 || ra.on.load(); });      // calls that went to the combining queue before anyone knew
+            // calls that went to the combining queue before anyone knew
+            e->queue_cv.wait(ql, [&] { return ra.combining == 0 || ra.on.load(); });
             if (!ra.on.load() && !ra_engage(e, traj)) return false;
         }
     }
@@ -303,7 +326,8 @@ bool ra_call(vmd_script_eval_t* e, const vmd_system_t* sys, vmd_trajectory_i* tr
             }
             // a caller that walks the range downwards (enkiTS: the thread that owns the task set pops its partitions from the far end while
             // the others steal from the near end) finds everything above its block taken: the region grows towards lower frames instead
-            // (only when the way up is blocked - by evaluated blocks or the end of the trajectory - and never across blocks that are not free)
+            // (only when the way up is blocked - by evaluated blocks or the end of the trajectory - and never across blocks that are not
+            // free)
             while (frames < want && need > 0 && ra.blk_state[need - 1].load() == vmd_script_eval_t::RA_NONE) {
                 --need;
                 frames += S;
@@ -313,7 +337,8 @@ bool ra_call(vmd_script_eval_t* e, const vmd_system_t* sys, vmd_trajectory_i* tr
             ra.spec_active = true;
             ql.unlock();
             const uint32_t f_lo = (uint32_t)(need * S), f_hi = (uint32_t)std::min(e1 * S, e->num_frames);
-            bool ok = ra_settle(e, sys, traj, false);         // what the callers have asked for so far joins the totals: progress for a polling GUI
+            // what the callers have asked for so far joins the totals: progress for a polling GUI
+            bool ok = ra_settle(e, sys, traj, false);
             if (ok) {
                 g_last_error.clear();
                 std::lock_guard<std::mutex> lock(e->mtx);
@@ -323,14 +348,16 @@ bool ra_call(vmd_script_eval_t* e, const vmd_system_t* sys, vmd_trajectory_i* tr
                     if (adopted[b - need]) { ++b; continue; }
                     size_t r1 = b;
                     while (r1 < e1 && !adopted[r1 - need]) ++r1;
-                    ok = !e->interrupt && process_range_locked(e, sys, traj, (uint32_t)(b * S), (uint32_t)std::min(r1 * S, e->num_frames), false, true);
+                    ok = !e->interrupt && process_range_locked(e, sys, traj, (uint32_t)(b * S), (uint32_t)std::min(r1 * S, e->num_frames),
+                            false, true);
                     b = r1;
                 }
             }
             const std::string err = ok ? std::string() : g_last_error;
             ql.lock();
             ra.spec_active = false;
-            for (size_t b = need; b < e1; ++b) ra.blk_state[b].store(ok ? vmd_script_eval_t::RA_READY : vmd_script_eval_t::RA_NONE, std::memory_order_release);
+            for (size_t b = need; b < e1; ++b) ra.blk_state[b].store(ok ? vmd_script_eval_t::RA_READY : vmd_script_eval_t::RA_NONE,
+                    std::memory_order_release);
             if (ok) { ra.regions += 1; ra.region_frames += f_hi - f_lo; }
             else if (!e->interrupt) { ra.failed = true; ra.error = err; }
             e->queue_cv.notify_all();
@@ -356,7 +383,9 @@ bool ra_call(vmd_script_eval_t* e, const vmd_system_t* sys, vmd_trajectory_i* tr
 }
 
 // ---- deferred settle (option readahead_lone) ----------------------------------------------------------------------------------
-int64_t steady_ns() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+int64_t steady_ns() {
+    return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
 
 // The helper thread of an eval in deferred-settle mode: sleeps until a settle is owed (armed) and the eval has been quiet for
 // readahead_lone_settle_us since the last call left, then does what a pool's last leaver does - as a call of its own (flight + 1), so every
@@ -376,7 +405,8 @@ void lone_helper_main(vmd_script_eval_t* e) {
         }
         if (h.quit) break;
         if (!h.armed.load() || !h.have) continue;        // cancelled (clear_data, wait_settled)
-        if (e->interrupt.load()) { h.armed.store(false); h.idle_cv.notify_all(); continue; }     // an interrupted evaluation is not completed behind the host's back
+        // an interrupted evaluation is not completed behind the host's back
+        if (e->interrupt.load()) { h.armed.store(false); h.idle_cv.notify_all(); continue; }
         h.busy = true;
         const uint64_t seq = h.cancel_seq;
         vmd_system_t sys = h.sys;
@@ -397,14 +427,16 @@ void lone_helper_main(vmd_script_eval_t* e) {
                 retry = true;                                                     // a call is inside: it stamps last_leave when it goes
             }
             ra.flight.fetch_sub(1, std::memory_order_acq_rel);
-            // the host's records of this eval follow NOW (the shim re-publishes fingerprint / ranges / max_value: ADVICE r05 #1) - after the
+            // the host's records of this eval follow NOW (the shim re-publishes fingerprint / ranges / max_value: ADVICE r05 #1) - after
+            // the
             // settle, before `busy` drops: clear_data / interrupt / free wait for the callback too, it never runs on a freed host object
             if (!retry) if (auto cb = h.on_settled.load(std::memory_order_acquire)) cb(h.on_settled_user.load(std::memory_order_acquire));
         }
         lk.lock();
         h.busy = false;
         if (h.cancel_seq != seq) {
-            // cancelled while it ran (interrupt, clear_data, wait_settled): whatever is marked from now on belongs to calls that arm afresh -
+            // cancelled while it ran (interrupt, clear_data, wait_settled): whatever is marked from now on belongs to calls that arm afresh
+            // -
             // with THEIR system and trajectory (lone_arm copies them only when it arms)
             h.armed.store(false, std::memory_order_seq_cst);
         } else if (retry) {
@@ -413,7 +445,8 @@ void lone_helper_main(vmd_script_eval_t* e) {
             // Disarm, THEN look at the marks (both seq_cst) - the mirror image of a leaving call, which marks and then looks at `armed`
             // (lone_arm): at least one of the two sees the other, so a mark made while this settle ran is never left without an owner
             h.armed.store(false, std::memory_order_seq_cst);
-            if (ra.marks_pending.load(std::memory_order_seq_cst) || ra.views_dirty.load(std::memory_order_seq_cst)) h.armed.store(true, std::memory_order_seq_cst);
+            if (ra.marks_pending.load(std::memory_order_seq_cst) || ra.views_dirty.load(std::memory_order_seq_cst)) h.armed.store(true,
+                    std::memory_order_seq_cst);
         }
         h.idle_cv.notify_all();
     }
@@ -423,7 +456,8 @@ void lone_helper_main(vmd_script_eval_t* e) {
 void lone_arm(vmd_script_eval_t* e, const vmd_system_t* sys, vmd_trajectory_i* traj) {
     ReadAhead::Helper& h = e->ra.helper;
     h.last_leave_ns.store(steady_ns(), std::memory_order_relaxed);
-    if (h.armed.load(std::memory_order_seq_cst)) return;          // (the caller's marks are seq_cst stores before this load: see lone_helper_main)
+    // (the caller's marks are seq_cst stores before this load: see lone_helper_main)
+    if (h.armed.load(std::memory_order_seq_cst)) return;
     std::lock_guard<std::mutex> l(h.mtx);
     if (sys) h.sys = *sys; else memset(&h.sys, 0, sizeof(h.sys));
     h.traj = *traj;
@@ -449,7 +483,8 @@ void lone_stop(vmd_script_eval_t* e) {           // vmd_eval_free
     {
         std::lock_guard<std::mutex> l(h.mtx);
         if (!h.started) return;
-        e->interrupt = true;                            // a settle that is running ends at its next batch boundary: nobody will read its results
+        // a settle that is running ends at its next batch boundary: nobody will read its results
+        e->interrupt = true;
         h.quit = true;
         h.cv.notify_one();
     }
@@ -508,7 +543,8 @@ extern "C" bool vmd_eval_frame_range(vmd_script_eval_t* eval, const vmd_script_i
 // frames off [frame_beg, frame_end) and call vmd_eval_frame_range on the ONE eval, each blocking until its frames are evaluated.  What
 // bench.py times VIAMD's pattern with (native threads: a Python thread per call costs more than a small call does), and what a host
 // without a task system of its own can use as is.  Returns false if any call failed or was interrupted.
-extern "C" bool vmd_eval_frame_range_pooled(vmd_script_eval_t* eval, const vmd_script_ir_t* ir, const vmd_system_t* sys, vmd_trajectory_i* traj,
+extern "C" bool vmd_eval_frame_range_pooled(vmd_script_eval_t* eval, const vmd_script_ir_t* ir, const vmd_system_t* sys,
+        vmd_trajectory_i* traj,
                                             uint32_t frame_beg, uint32_t frame_end, int num_threads, uint32_t grain) {
     if (!eval || !traj) return vmd_fail("vmd_eval_frame_range_pooled: NULL argument");
     if (num_threads < 1) num_threads = 1;
@@ -547,7 +583,8 @@ extern "C" bool vmd_eval_set_settled_callback(vmd_script_eval_t* eval, void (*fn
 
 extern "C" bool vmd_eval_set_deferred_settle(vmd_script_eval_t* eval, int mode) {
     if (!eval) return vmd_fail("eval is NULL");
-    eval->ra.lone_pref.store(mode < 0 ? -1 : (mode ? 1 : 0), std::memory_order_relaxed);       // takes effect at the next clear_data / first small call of an evaluation
+    // takes effect at the next clear_data / first small call of an evaluation
+    eval->ra.lone_pref.store(mode < 0 ? -1 : (mode ? 1 : 0), std::memory_order_relaxed);
     return true;
 }
 
@@ -569,7 +606,8 @@ extern "C" bool vmd_eval_wait_settled(vmd_script_eval_t* eval) {
     g_last_error.clear();
     bool ok = true;
     ra.flight.fetch_add(1, std::memory_order_acq_rel);
-    if (ra.on.load(std::memory_order_acquire) && (ra.marks_pending.load() || ra.views_dirty.load())) ok = ra_settle(eval, &sys, &traj, true);
+    if (ra.on.load(std::memory_order_acquire) && (ra.marks_pending.load() || ra.views_dirty.load())) ok = ra_settle(eval, &sys, &traj,
+            true);
     ra.flight.fetch_sub(1, std::memory_order_acq_rel);
     if (ok) { std::lock_guard<std::mutex> ql(eval->queue_mtx); if (ra.failed) { g_last_error = ra.error; ok = false; } }
     if (auto cb = h.on_settled.load(std::memory_order_acquire)) cb(h.on_settled_user.load(std::memory_order_acquire));

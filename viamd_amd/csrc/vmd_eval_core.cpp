@@ -1,3 +1,7 @@
+// viamd_amd/csrc/vmd_eval_core.cpp - the evaluator object: vmd_eval_create / _free / _clear_data / _interrupt (md_script_eval_create
+// ..., /root/reference/src/main.cpp:960-990), the plan of pair passes for co-evaluated RDFs, the host views VIAMD polls
+// (md_script_property_data_t: values / weights / aggregate / ranges / fingerprint, :1286-1524), accessors, block / source settings of
+// the filtered evaluation, and the sdf() vis payload (reference pose + per-frame matrices, density_volume.cpp:183-204).
 #include "vmd_eval_internal.h"
 
 // what `values` of a volume points at between clear_data and the evaluation's first view: zero pages shared by every volume of the process,
@@ -18,7 +22,8 @@ float* zero_volume_view(size_t nfloats) {
 
 TrajId traj_id(const vmd_trajectory_i* t) {
     TrajId id;
-    if (t) { id.inst = t->inst; id.fn = t->load_frame ? reinterpret_cast<const void*>(t->load_frame) : reinterpret_cast<const void*>(t->device_view); }
+    if (t) { id.inst = t->inst; id.fn = t->load_frame ? reinterpret_cast<const void*>(t->load_frame)
+            : reinterpret_cast<const void*>(t->device_view); }
     return id;
 }
 
@@ -46,7 +51,8 @@ void build_rdf_plan(vmd_script_eval_t* e) {
         const Property& d = e->props[i]->prop;
         if (d.kind != PROP_RDF) continue;
         RdfGroup* g = nullptr;
-        for (auto& q : e->rdf_groups) if (memcmp(&q.rmin, &d.rmin, sizeof(float)) == 0 && memcmp(&q.rmax, &d.rmax, sizeof(float)) == 0) g = &q;
+        for (auto& q : e->rdf_groups) if (memcmp(&q.rmin, &d.rmin, sizeof(float)) == 0 && memcmp(&q.rmax, &d.rmax, sizeof(float)) == 0) g =
+                &q;
         if (!g) { e->rdf_groups.emplace_back(); g = &e->rdf_groups.back(); g->rmin = d.rmin; g->rmax = d.rmax; }
         g->props.push_back((int)i);
     }
@@ -73,7 +79,8 @@ void build_rdf_plan(vmd_script_eval_t* e) {
         if (np < 2 || np > 30 || !g_opt.rdf_classes) { direct(); continue; }
         // signature of every atom: bit 2k = in the reference set of the group's k-th property, bit 2k + 1 = in its target set
         int32_t amax = 0;
-        for (int pi : g.props) { for (int32_t a : e->props[pi]->prop.a) amax = std::max(amax, a); for (int32_t b : e->props[pi]->prop.b) amax = std::max(amax, b); }
+        for (int pi : g.props) { for (int32_t a : e->props[pi]->prop.a) amax = std::max(amax, a); for (int32_t b
+                : e->props[pi]->prop.b) amax = std::max(amax, b); }
         std::vector<uint64_t> sig((size_t)amax + 1, 0);
         bool dup = false;
         for (size_t k = 0; k < np && !dup; ++k) {
@@ -199,13 +206,15 @@ extern "C" vmd_script_eval_t* vmd_eval_create(size_t num_frames, const vmd_scrip
         st->data.fingerprint = 1;
         if (st->ncounts) {
             if (!st->d_counts.ensure(st->ncounts)) return nullptr;
-            if (hipMemsetAsync(st->d_counts.p, 0, st->ncounts * sizeof(uint64_t), e->stream) != hipSuccess) { vmd_fail("hipMemset failed"); return nullptr; }
+            if (hipMemsetAsync(st->d_counts.p, 0, st->ncounts * sizeof(uint64_t), e->stream) != hipSuccess) { vmd_fail("hipMemset failed");
+                    return nullptr; }
         }
         e->props.push_back(std::move(st));
     }
     build_rdf_plan(e.get());
     if (!e->d_overflow.ensure(1) || hipMemsetAsync(e->d_overflow.p, 0, sizeof(uint32_t), e->stream) != hipSuccess ||
-        pool_take(kPinned, (void**)&e->h_overflow, 2 * sizeof(uint32_t)) != hipSuccess) { vmd_fail("allocating the overflow flag failed"); return nullptr; }
+        pool_take(kPinned, (void**)&e->h_overflow, 2 * sizeof(uint32_t)) != hipSuccess) { vmd_fail("allocating the overflow flag failed");
+                return nullptr; }
     e->h_overflow[0] = e->h_overflow[1] = 0;
     for (auto& ev : e->batch_done) if (!(ev = pool_event(false))) { vmd_fail("hipEventCreate failed"); return nullptr; }
     if (hipStreamSynchronize(e->stream) != hipSuccess) { vmd_fail("hipStreamSynchronize failed"); return nullptr; }
@@ -261,7 +270,8 @@ extern "C" void vmd_eval_free(vmd_script_eval_t* eval) {
         if (eval->h_snap) pool_give(eval->h_snap);
         eval->h_snap = nullptr;
         for (auto& ev : eval->batch_done) { pool_event_give(ev, false); ev = nullptr; }
-        eval->d_partial.release(); eval->d_partial2.release(); eval->d_pass.release(); eval->d_overflow.release(); eval->d_pen_sample.release();
+        eval->d_partial.release(); eval->d_partial2.release(); eval->d_pass.release(); eval->d_overflow.release();
+                eval->d_pen_sample.release();
         pool_stream_give(eval->stream, false);
         eval->stream = nullptr;
     }
@@ -280,16 +290,21 @@ extern "C" void vmd_eval_clear_data(vmd_script_eval_t* eval) {
     eval->interrupt = false;
     std::fill(eval->frame_mask.begin(), eval->frame_mask.end(), (uint8_t)0);
     eval->frames_done = 0;
-    eval->frames_computed = 0; eval->frames_reused = 0; eval->frames_device_decoded = 0; eval->frames_section_decoded = 0; eval->frames_mapped = 0;
+    eval->frames_computed = 0; eval->frames_reused = 0; eval->frames_device_decoded = 0; eval->frames_section_decoded = 0;
+            eval->frames_mapped = 0;
     for (size_t b = 0; b < eval->num_blocks; ++b) eval->block_ready[b] = 0;
     eval->blocks_inst = TrajId();
     ra_reset(eval);
     for (auto& p : eval->props) {
-        // The float view of a volume (8.4 MB, pinned) is NOT zeroed: `data.values` is pointed at a shared, read-only page range of zeros until
+        // The float view of a volume (8.4 MB, pinned) is NOT zeroed: `data.values` is pointed at a shared, read-only page range of zeros
+        // until
         // the next view of this evaluation has been written - k_counts_to_float rewrites every voxel of the real view, then the pointer
-        // flips back (refresh_volume).  Round 6: the zeroing was a second 8.4 MB pass over PCIe per evaluation - 0.15 ms
-        // that the kernel trace showed IN FRONT of the evaluation's kernels, not under them (profiles/r06a_c4_1250_timeline.txt) - a fifth of
-        // a rank's 1 250-frame share of configs[3].  A reader polling `fingerprint` (src/main.cpp:1508; density_volume.cpp:159-163, 279-283) sees
+        // flips back (refresh_volume).  Round 6: the zeroing was a second 8.4 MB pass over PCIe per evaluation - 0.15
+        // ms
+        // that the kernel trace showed IN FRONT of the evaluation's kernels, not under them (profiles/r06a_c4_1250_timeline.txt) - a fifth
+        // of
+        // a rank's 1 250-frame share of configs[3].  A reader polling `fingerprint` (src/main.cpp:1508; density_volume.cpp:159-163,
+        // 279-283) sees
         // zeros under the new fingerprint at once, never the previous run's voxels; VIAMD dereferences prop_data->values when it uploads.
         if (p->prop.kind == PROP_SDF) pub(p->data.values, zero_volume_view(p->ncounts));
         else std::fill(p->values.begin(), p->values.end(), 0.0f);
@@ -391,7 +406,8 @@ bool refresh_volume(vmd_script_eval_t* e, PropState* p) {
     }
     float vmax = 0.0f;
     float* host_view_dev = nullptr;
-    if (g_opt.sdf_direct_view.load() && p->values.pinned && hipHostGetDevicePointer((void**)&host_view_dev, p->values.data(), 0) != hipSuccess) {
+    if (g_opt.sdf_direct_view.load() && p->values.pinned && hipHostGetDevicePointer((void**)&host_view_dev, p->values.data(),
+            0) != hipSuccess) {
         (void)hipGetLastError();
         host_view_dev = nullptr;
     }
@@ -409,7 +425,8 @@ bool refresh_volume(vmd_script_eval_t* e, PropState* p) {
     p->counts_stale = true;
     HIP_OK(hipMemcpyAsync(&vmax, p->d_max.p, sizeof(float), hipMemcpyDeviceToHost, e->stream));
     HIP_OK(hipStreamSynchronize(e->stream));
-    pub(p->data.values, p->values.data());       // every voxel of the real view has just been rewritten: readers leave the shared zeros (clear_data)
+    // every voxel of the real view has just been rewritten: readers leave the shared zeros (clear_data)
+    pub(p->data.values, p->values.data());
     pub(p->data.min_value, 0.0f); pub(p->data.max_value, vmax);
     pub_touch(p->data.fingerprint);
     p->dirty = false;
@@ -480,8 +497,10 @@ extern "C" bool vmd_eval_set_block_frames(vmd_script_eval_t* eval, size_t block_
     if (!eval) return vmd_fail("eval is NULL");
     std::lock_guard<std::mutex> l(eval->mtx);
     HIP_OK(hipSetDevice(eval->device));
-    if (eval->frames_done.load() != 0) return vmd_fail("vmd_eval_set_block_frames: call before the first frame_range or right after clear_data");
-    eval->ra.on = false; eval->ra.own_blocks = false; eval->ra.blk_state.reset(); eval->ra.frame_req.reset();     // read-ahead re-engages on the new blocks
+    if (eval->frames_done.load() != 0)
+        return vmd_fail("vmd_eval_set_block_frames: call before the first frame_range or right after clear_data");
+    // read-ahead re-engages on the new blocks
+    eval->ra.on = false; eval->ra.own_blocks = false; eval->ra.blk_state.reset(); eval->ra.frame_req.reset();
     eval->block_frames = 0; eval->num_blocks = 0; eval->block_ready.reset();
     for (auto& p : eval->props) { p->d_blocks.release(); p->block_weights64.clear(); }
     if (block_frames == 0) return true;
@@ -489,7 +508,8 @@ extern "C" bool vmd_eval_set_block_frames(vmd_script_eval_t* eval, size_t block_
     size_t bytes = 0;
     for (auto& p : eval->props) bytes += nblocks * p->ncounts * sizeof(uint64_t);
     if (bytes > ((size_t)96 << 30))
-        return vmd_fail("vmd_eval_set_block_frames: %zu blocks need %.1f GB of block partials; use larger blocks", nblocks, (double)bytes / 1073741824.0);
+        return vmd_fail("vmd_eval_set_block_frames: %zu blocks need %.1f GB of block partials; use larger blocks", nblocks,
+                (double)bytes / 1073741824.0);
     for (auto& p : eval->props) {
         if (!p->ncounts) continue;
         if (!p->d_blocks.ensure(nblocks * p->ncounts)) return false;
@@ -507,7 +527,8 @@ extern "C" bool vmd_eval_set_source(vmd_script_eval_t* eval, vmd_script_eval_t* 
     std::lock_guard<std::mutex> l(eval->mtx);
     if (!source) { eval->source = nullptr; return true; }
     if (source == eval) return vmd_fail("vmd_eval_set_source: an eval cannot be its own source");
-    if (source->ir_fingerprint != eval->ir_fingerprint || source->num_frames != eval->num_frames || source->props.size() != eval->props.size())
+    if (source->ir_fingerprint != eval->ir_fingerprint || source->num_frames != eval->num_frames
+            || source->props.size() != eval->props.size())
         return vmd_fail("vmd_eval_set_source: source was created from a different script or frame count");
     if (source->device != eval->device) return vmd_fail("vmd_eval_set_source: source lives on another device");
     // (a source without block partials is accepted since round 4: read-ahead gives an eval driven by pool threads block partials of its own
@@ -572,7 +593,8 @@ extern "C" size_t vmd_eval_accum_views(vmd_script_eval_t* eval, vmd_accum_view_t
 // hooks for vmd_reduce.cpp (same library, not part of the public headers)
 extern "C" int vmd_eval_internal_device(const vmd_script_eval_t* eval) { return eval ? eval->device : 0; }
 
-extern "C" void vmd_eval_internal_lock(vmd_script_eval_t* eval, int lock) { if (eval) { if (lock) eval->mtx.lock(); else eval->mtx.unlock(); } }
+extern "C" void vmd_eval_internal_lock(vmd_script_eval_t* eval, int lock) { if (eval) { if (lock) eval->mtx.lock();
+        else eval->mtx.unlock(); } }
 
 extern "C" vmd_reduce_stats_t* vmd_eval_internal_reduce_stats(vmd_script_eval_t* eval) { return eval ? &eval->reduce_stats : nullptr; }
 
@@ -627,13 +649,15 @@ bool upload_static(vmd_script_eval_t* e, const vmd_system_t* sys, size_t traj_at
                         const int32_t a = ord[head++];
                         std::vector<int32_t> nb;
                         auto it = adj.find(idx[a]);
-                        if (it != adj.end()) for (int32_t g : it->second) { auto l = local.find(g); if (l != local.end()) nb.push_back(l->second); }
+                        if (it != adj.end()) for (int32_t g : it->second) { auto l = local.find(g);
+                                if (l != local.end()) nb.push_back(l->second); }
                         std::sort(nb.begin(), nb.end());
                         for (int32_t c : nb) if (!seen[c]) { seen[c] = 1; par[c] = a; ord[tail++] = c; }
                     }
                     for (size_t a = 1; a < d.m; ++a) if (!seen[a]) { par[a] = (int32_t)a - 1; ord[tail++] = (int32_t)a; }
                 }
-                if (!p->d_tree_order.upload(order.data(), order.size(), e->stream) || !p->d_tree_parent.upload(parent.data(), parent.size(), e->stream)) return false;
+                if (!p->d_tree_order.upload(order.data(), order.size(), e->stream) || !p->d_tree_parent.upload(parent.data(),
+                        parent.size(), e->stream)) return false;
                 HIP_OK(hipStreamSynchronize(e->stream));                 // the vectors go out of scope
                 p->have_tree = true;
             }
@@ -648,7 +672,8 @@ bool upload_static(vmd_script_eval_t* e, const vmd_system_t* sys, size_t traj_at
                         if (it != where.end() && it->second != (int)k) { unique = false; break; }
                         where[d.a[k * d.m + a]] = (int)k;
                     }
-                if (unique) for (size_t t = 0; t < d.b.size(); ++t) { auto it = where.find(d.b[t]); if (it != where.end()) owner[t] = (int8_t)it->second; }
+                if (unique) for (size_t t = 0; t < d.b.size(); ++t) { auto it = where.find(d.b[t]);
+                        if (it != where.end()) owner[t] = (int8_t)it->second; }
             }
             p->have_owner = unique;
             if (unique && !p->d_owner.upload(owner.data(), owner.size(), e->stream)) return false;
@@ -690,7 +715,8 @@ bool upload_static(vmd_script_eval_t* e, const vmd_system_t* sys, size_t traj_at
     return true;
 }
 
-extern "C" const int32_t* vmd_eval_sdf_structures(const vmd_script_eval_t* eval, const char* name, size_t* num_structures, size_t* atoms_per_structure) {
+extern "C" const int32_t* vmd_eval_sdf_structures(const vmd_script_eval_t* eval, const char* name, size_t* num_structures,
+        size_t* atoms_per_structure) {
     PropState* p = find_prop(eval, name);
     if (!p || p->prop.kind != PROP_SDF) { vmd_fail("'%s' is not an sdf property", name ? name : "(null)"); return nullptr; }
     if (num_structures) *num_structures = p->prop.K;
@@ -714,8 +740,10 @@ extern "C" bool vmd_eval_sdf_matrices(vmd_script_eval_t* eval, const char* name,
     BatchSrc src;
     if (!p->ref_pose_ready) {
         if (!fetch_batch(e, traj, view_holds(have_view, view, 0) ? &view : nullptr, num_atoms, 0, 1, &src)) return false;
-        KRN_OK(vmd_hip_sdf_ref_pose(e->stream, src.base, src.row_stride, e->stages[0].d_boxes.p, batch_pbc(e->stages[0]), p->d_structs.p, p->d_mass.p,
-                                    (int)p->prop.m, p->d_ref_pose.p, p->have_tree ? p->d_tree_order.p : nullptr, p->have_tree ? p->d_tree_parent.p : nullptr));
+        KRN_OK(vmd_hip_sdf_ref_pose(e->stream, src.base, src.row_stride, e->stages[0].d_boxes.p, batch_pbc(e->stages[0]), p->d_structs.p,
+                p->d_mass.p,
+                                    (int)p->prop.m, p->d_ref_pose.p, p->have_tree ? p->d_tree_order.p : nullptr, p->have_tree
+                                            ? p->d_tree_parent.p : nullptr));
         HIP_OK(hipStreamSynchronize(e->stream));
         p->ref_pose_ready = true;
     }
@@ -726,7 +754,8 @@ extern "C" bool vmd_eval_sdf_matrices(vmd_script_eval_t* eval, const char* name,
     if (p->have_tree && !p->d_tree_pos.ensure(K * p->prop.m * 3)) return false;
     KRN_OK(vmd_hip_sdf_align(e->stream, src.base, src.frame_stride, src.row_stride, e->stages[0].d_boxes.p, batch_pbc(e->stages[0]), 1,
                              p->d_structs.p, p->d_mass.p, (int)K, (int)p->prop.m, p->d_ref_pose.p, p->d_R32.p, p->d_c32.p, dM.p, nullptr,
-                             p->have_tree ? p->d_tree_order.p : nullptr, p->have_tree ? p->d_tree_parent.p : nullptr, p->have_tree ? p->d_tree_pos.p : nullptr));
+                             p->have_tree ? p->d_tree_order.p : nullptr, p->have_tree ? p->d_tree_parent.p : nullptr, p->have_tree
+                                     ? p->d_tree_pos.p : nullptr));
     std::vector<double> M(K * 12);
     HIP_OK(hipMemcpyAsync(M.data(), dM.p, K * 12 * sizeof(double), hipMemcpyDeviceToHost, e->stream));
     HIP_OK(hipStreamSynchronize(e->stream));

@@ -1,10 +1,16 @@
 #pragma once
-// viamd_amd/csrc/vmd_eval.cpp — C++ host side of the drop-in boundary (include/vmd_eval.h).
+// viamd_amd/csrc/vmd_eval_internal.h - the evaluator's shared declarations: C++ host side of the drop-in boundary (include/vmd_eval.h).
 //
-// Mirrors the md_script_eval_* lifecycle VIAMD drives (/root/reference/src/main.cpp:951-1039): create ->
-// clear_data -> frame_range from pool threads -> property_data / frame_mask polled by the GUI thread.
-// All arithmetic happens in the HIP kernels of vmd_kernels.hip; this file only batches frames, owns the
-// device buffers and keeps the md_script_property_data_t views up to date.  There is no CPU compute path.
+// Mirrors the md_script_eval_* lifecycle VIAMD drives (/root/reference/src/main.cpp:951-1039): create -> clear_data -> frame_range from
+// pool threads -> property_data / frame_mask polled by the GUI thread.  All arithmetic happens in the HIP kernels of vmd_kernels.hip;
+// the host code only batches frames, owns the device buffers and keeps the md_script_property_data_t views up to date.  There is no
+// CPU compute path.  Round 6: the one translation unit this used to be (4 300 lines) is eight files by concern -
+//     vmd_eval_runtime.cpp  errors, options, profiling, resource pool        vmd_eval_ir.cpp     property descriptors
+//     vmd_eval_core.cpp     the eval object, host views, accessors           vmd_eval_stage.cpp  static uploads, trajectory staging
+//     vmd_eval_batch.cpp    grids, cell builds, batches, process_range       vmd_eval_calls.cpp  combining queue, read-ahead, deferred settle
+//     vmd_eval_traj.cpp     trajectory kinds, checkpoint / mapping caches    vmd_eval_post.cpp   histogram post-processing
+// - and this header holds every struct they share, in the order the single file declared them, with each function's prototype where
+// its definition used to stand.  Nothing here is part of the ABI.
 #include <hip/hip_runtime.h>
 
 #include <float.h>
@@ -63,29 +69,45 @@ struct Options {
     std::atomic<int> batch_frames{0};    // 0 = auto
     std::atomic<int> force_brute{0};
     std::atomic<int> load_threads{0};    // host threads decoding one staged batch through load_frame; 0 = auto (see load_threads())
-    // pencils of cross-section rmax/split (walk reach = split).  z: explicit (A/B).  y: 0 = by density - selections of >= 0.08 atoms / A^3 in the
-    // lanes of every pass of a group (all heavy atoms of a liquid; SURVEY 8d's C3-dense) walk half-width pencils in y: a 64-atom chunk of such
+    // pencils of cross-section rmax/split (walk reach = split).  z: explicit (A/B).  y: 0 = by density - selections of >= 0.08 atoms / A^3
+    // in the
+    // lanes of every pass of a group (all heavy atoms of a liquid; SURVEY 8d's C3-dense) walk half-width pencils in y: a 64-atom chunk of
+    // such
     // a selection is only ~4 A long, so the x windows are dominated by the 2 r_max of padding and thinner pencils pay (c3d 2 028 -> 2 131
-    // frames/s, profiles/r05d_pencil_split_by_density.txt; at c3's 0.033 / A^3 the same split costs 10 %, at c5's mix 6 %); 1 / 2 / .. = fixed
+    // frames/s, profiles/r05d_pencil_split_by_density.txt; at c3's 0.033 / A^3 the same split costs 10 %, at c5's mix 6 %); 1 / 2 / .. =
+    // fixed
     std::atomic<int> pencil_split_y{0}, pencil_split_z{1};
-    std::atomic<int> nxf_divisor{16};    // fine x cell = rmax / nxf_divisor (8 / 12 / 16 / 24 / 32 measured: 16 is +0.8 % on c3, profiles/r02l_ab_fine_cells.txt)
+    // fine x cell = rmax / nxf_divisor (8 / 12 / 16 / 24 / 32 measured: 16 is +0.8 % on c3, profiles/r02l_ab_fine_cells.txt)
+    std::atomic<int> nxf_divisor{16};
     std::atomic<int> cells_aos{1};       // sort through 16-byte records + repack
-    std::atomic<int> xtc_device_decode{3};   // frames offered raw (load_raw) are decompressed on the device (0 = on the host threads): 1 = one thread per
+    // frames offered raw (load_raw) are decompressed on the device (0 = on the host threads): 1 = one thread per
+    std::atomic<int> xtc_device_decode{3};
                                              // frame (k_xtc_decode), 2 = index pass + one thread per chunk (k_xtc_index / k_xtc_chunks),
                                              // 3 = one wave per frame (k_xtc_wave)
     std::atomic<int> xtc_chunk{256};         // atoms per chunk of variant 2
-    std::atomic<int> pool_mb{16384};         // process-wide cache of device blocks freed by evals (MB; pinned host blocks: a quarter of it); 0 = off
-    std::atomic<int> gather_us{150};         // combining queue: how long the leader waits for the other pool threads of the previous round to come back with their next ranges (0 = take what is there)
-    std::atomic<int> lazy_views{1};          // combining queue: the host views are refreshed when no call is waiting (and every lazy_views_ms at the latest), not after every batch
+    // process-wide cache of device blocks freed by evals (MB; pinned host blocks: a quarter of it); 0 = off
+    std::atomic<int> pool_mb{16384};
+    // combining queue: how long the leader waits for the other pool threads of the previous round to come back with their next ranges (0 =
+    // take what is there)
+    std::atomic<int> gather_us{150};
+    // combining queue: the host views are refreshed when no call is waiting (and every lazy_views_ms at the latest), not after every batch
+    std::atomic<int> lazy_views{1};
     std::atomic<int> lazy_views_ms{20};
-    std::atomic<int> defer_sync{0};          // the next batch is queued before the host waits for the current one (evals without block partials); measured r03ad: no gain (the per-batch host gap is ~0.06 ms; the next decode then lands on the cell build), off
-    std::atomic<int> block_superbatch{1};    // filtered evaluation: consecutive frame blocks share ONE batch (one cell build, one synchronisation; a pair launch per block)
-    std::atomic<int> block_two_streams{1};   // ... and the blocks' pair launches alternate between two streams, so that the tail of one runs under the head of the next
-    std::atomic<int> xtc_ramp{0};            // file-backed device decode: small first and last batches (pipeline fill / drain); r03o: no gain, off
+    // the next batch is queued before the host waits for the current one (evals without block partials); measured r03ad: no gain (the
+    // per-batch host gap is ~0.06 ms; the next decode then lands on the cell build), off
+    std::atomic<int> defer_sync{0};
+    // filtered evaluation: consecutive frame blocks share ONE batch (one cell build, one synchronisation; a pair launch per block)
+    std::atomic<int> block_superbatch{1};
+    // ... and the blocks' pair launches alternate between two streams, so that the tail of one runs under the head of the next
+    std::atomic<int> block_two_streams{1};
+    // file-backed device decode: small first and last batches (pipeline fill / drain); r03o: no gain, off
+    std::atomic<int> xtc_ramp{0};
     std::atomic<int> xtc_decode_ahead{1};    // batches the device decoder runs ahead of the kernels (1 or 2); r03n: 2 changes nothing
-    std::atomic<int> raw_f32_device{1};      // TRR / DCD: frames DMA'd out of the mapped file, swapped / scaled / transposed by k_raw_f32 (0: host threads)
+    // TRR / DCD: frames DMA'd out of the mapped file, swapped / scaled / transposed by k_raw_f32 (0: host threads)
+    std::atomic<int> raw_f32_device{1};
     std::atomic<int> xtc_cold_streams{1};    // first pass out of a mapped file: up to four batches walked side by side on their own streams
-    std::atomic<int> xtc_mapped{1};          // variant 3: DMA the compressed frames straight out of the mapped file (raw_mapped_view), no host copy
+    // variant 3: DMA the compressed frames straight out of the mapped file (raw_mapped_view), no host copy
+    std::atomic<int> xtc_mapped{1};
     std::atomic<int> xtc_map_limit_mb{0};    // pinned bytes of mapped files, all trajectories together (0 = half of the physical memory)
     // variant 3: the first decode also leaves a 16-bit record per group; later decodes place every group from them, no walk.  Measured
     // (r03t2, c2): +2 % from a file, +3 % compressed-resident - the walk was a fifth of a re-decode, the per-group arithmetic is the rest.
@@ -99,31 +121,44 @@ struct Options {
     std::atomic<int> spec_sdf_include_self{0};    // D-SDF-EXCL: targets that are atoms of structure k are scattered like any other
     std::atomic<int> spec_sdf_density{0};         // D-SDF-NORM: values = counts / (frames evaluated x voxel volume) instead of raw counts
     std::atomic<int> spec_dist_geometric_com{0};  // D-DIST-COM: distance(a, b) between geometric centres, not centres of mass
-    std::atomic<int> spec_rdf_raw{0};             // D-WRAP: positions enter rdf() as they are, minimum image by rounding - evaluated by k_rdf_brute (all pairs: a
+    // D-WRAP: positions enter rdf() as they are, minimum image by rounding - evaluated by k_rdf_brute (all pairs: a
+    std::atomic<int> spec_rdf_raw{0};
                                                   // setting for matching an mdlib that does it this way, not a fast path)
-    std::atomic<int> spec_rdf_norm{0};            // D-RDF-NORM: 0 = cell volume when fully periodic, else the cutoff sphere; 1 = always the cutoff sphere;
+    // D-RDF-NORM: 0 = cell volume when fully periodic, else the cutoff sphere; 1 = always the cutoff sphere;
+    std::atomic<int> spec_rdf_norm{0};
                                                   // 2 = per reference atom (the weights do not carry N_ref)
     std::atomic<int> sdf_direct_view{1};          // k_counts_to_float writes the volume's float view into its pinned host pages itself
     std::atomic<int> stage_frames{128};      // frames per staged batch of a host / file trajectory (batch_frames <= 0)
-    std::atomic<int> rdf_blocks_decode{1536};   // pair-kernel grid while batches are decompressed on the device: 6 blocks per CU leave every
-                                                // SIMD a wave slot and 80 VGPRs, so k_xtc_wave of batch k + 1 (wave priority 3) runs under the pair
+    // pair-kernel grid while batches are decompressed on the device: 6 blocks per CU leave every
+    std::atomic<int> rdf_blocks_decode{1536};
+                                                // SIMD a wave slot and 80 VGPRs, so k_xtc_wave of batch k + 1 (wave priority 3) runs under
+                                                // the pair
                                                 // kernel of batch k; costs the pair kernel ~4 % (0 = leave the grid alone)
     std::atomic<int> sdf_dense{0};       // dense-target SDF scatter (stream whole frames, select by tag): measured slower, off
-    std::atomic<int> sdf_arith{1};       // SDF target lists that are arithmetic progressions are generated on the device (0 = always load the index list)
-    std::atomic<int> cells_small{8192};  // selections of at most this many atoms are sorted by one block per frame (k_cells_fused), never through pencil buckets (0: buckets for everyone)
-    std::atomic<int> rdf_classes{1};     // co-evaluated RDFs of one range share pair passes through disjoint atom classes (0 = one pass per property)
+    // SDF target lists that are arithmetic progressions are generated on the device (0 = always load the index list)
+    std::atomic<int> sdf_arith{1};
+    // selections of at most this many atoms are sorted by one block per frame (k_cells_fused), never through pencil buckets (0: buckets for
+    // everyone)
+    std::atomic<int> cells_small{8192};
+    // co-evaluated RDFs of one range share pair passes through disjoint atom classes (0 = one pass per property)
+    std::atomic<int> rdf_classes{1};
     // read-ahead under VIAMD's call pattern (many pool threads, ranges of a frame or a few): the first small call that finds
     // company evaluates a whole REGION of frame blocks ahead into block partials, later calls for those frames only mark them requested
     std::atomic<int> readahead{1};           // 0 = every call is evaluated when it arrives (the combining queue of round 3)
     std::atomic<int> readahead_frames{128};  // frames of the first region of an evaluation (rounded to whole blocks) ...
     std::atomic<int> readahead_growth{4};    // ... every further region is this many times larger (up to one kernel batch)
     std::atomic<int> readahead_small{64};    // calls of at most this many frames take part; larger ranges are evaluated directly
-    std::atomic<int> readahead_block{0};     // frames per block partial (0 = by script: 256 without pair passes, 16 - 128 by selection size with)
-    std::atomic<int> readahead_linger_us{60};// a call that leaves alone waits this long for another call before it settles the eval (commit + views)
-    std::atomic<int> readahead_company_us{80};// the FIRST call of an evaluation waits this long for a second caller before it decides it is alone
-    std::atomic<int> readahead_fail_alloc{0}; // test hook: the block partials' allocation "fails" (the eval must fall back to the combining queue)
+    // frames per block partial (0 = by script: 256 without pair passes, 16 - 128 by selection size with)
+    std::atomic<int> readahead_block{0};
+    // a call that leaves alone waits this long for another call before it settles the eval (commit + views)
+    std::atomic<int> readahead_linger_us{60};
+    // the FIRST call of an evaluation waits this long for a second caller before it decides it is alone
+    std::atomic<int> readahead_company_us{80};
+    // test hook: the block partials' allocation "fails" (the eval must fall back to the combining queue)
+    std::atomic<int> readahead_fail_alloc{0};
     // Opt-in: small calls are served by read-ahead even when they come from ONE thread (a host that walks a range frame by frame), and the
-    // settle a pool's last leaver performs is DEFERRED to a helper thread that runs once the eval has been quiet for readahead_lone_settle_us.
+    // settle a pool's last leaver performs is DEFERRED to a helper thread that runs once the eval has been quiet for
+    // readahead_lone_settle_us.
     // The price is the contract: results then trail the last call by that long (a polling reader like VIAMD's GUI does not notice;
     // vmd_eval_wait_settled / finalize / reduce / the exporters wait for them), and system + trajectory must stay valid until then.
     std::atomic<int> readahead_lone{0};
@@ -236,13 +271,15 @@ struct Profiler {
         for (auto& p : pending) {
             float ms = 0.0f;
             const hipError_t rc = hipEventElapsedTime(&ms, p.a, p.b);
-            if (rc == hipErrorNotReady) { (void)hipGetLastError(); later.push_back(p); continue; }     // queued on another stream, still running
+            // queued on another stream, still running
+            if (rc == hipErrorNotReady) { (void)hipGetLastError(); later.push_back(p); continue; }
             if (rc == hipSuccess) { g_prof[p.name].ms += ms; g_prof[p.name].launches += 1; }
             pool.push_back(p.a); pool.push_back(p.b);
         }
         pending.swap(later);
     }
-    ~Profiler() { for (auto e : pool) pool_event_give(e, true); for (auto& p : pending) { (void)hipEventSynchronize(p.b); pool_event_give(p.a, true); pool_event_give(p.b, true); } }
+    ~Profiler() { for (auto e : pool) pool_event_give(e, true); for (auto& p : pending) { (void)hipEventSynchronize(p.b);
+            pool_event_give(p.a, true); pool_event_give(p.b, true); } }
 };
 
 // ------------------------------------------------------------------------------------------------ device buffer helper
@@ -382,7 +419,8 @@ struct PropState {
     vmd_script_property_data_t data;
     vmd_script_aggregate_t aggregate;
     HostBuf<float> values;              // what data.values points at
-    std::vector<float> ahead_values;    // DIST: temporal rows of frames evaluated ahead, copied into `values` when their block is committed (read-ahead)
+    // DIST: temporal rows of frames evaluated ahead, copied into `values` when their block is committed (read-ahead)
+    std::vector<float> ahead_values;
     std::vector<float> weights, agg_mean, agg_var, agg_ext;
     HostBuf<uint64_t> counts;           // host mirror of d_counts
     std::vector<double> weights64;
@@ -553,8 +591,10 @@ struct vmd_script_eval_t {
         bool raw_pending = false;                // a device decode is queued behind `ready`: its status words are checked before use
         bool sectioned = false;                  // that decode ran from checkpoints (sections), not from bit 0
         bool* rec_failed = nullptr;              // that decode placed its groups from records: where to note that they were rejected
-        uint8_t* ck_mark = nullptr;              // that decode also writes the frames' checkpoints: mark them valid (ck_mark[0 .. nb)) when it succeeded
-        uint8_t* ck_clear = nullptr;             // that decode entered the frames at their checkpoints: forget them (ck_clear[0 .. nb)) when it was rejected
+        // that decode also writes the frames' checkpoints: mark them valid (ck_mark[0 .. nb)) when it succeeded
+        uint8_t* ck_mark = nullptr;
+        // that decode entered the frames at their checkpoints: forget them (ck_clear[0 .. nb)) when it was rejected
+        uint8_t* ck_clear = nullptr;
         std::shared_ptr<CkCache> ck_hold;        // the table those three point into, for as long as the decode is pending
         DevBuf<float> d_boxes;
         std::vector<float> h_boxes;              // [nb][6]: L, 1/L
@@ -605,7 +645,8 @@ struct vmd_script_eval_t {
     hipStream_t pair_stream = nullptr;       // every other block of a batch of frame blocks runs its pair kernel here
     hipEvent_t pair_fork = nullptr, pair_join = nullptr;
     std::vector<RdfGroup> rdf_groups;
-    DevBuf<uint64_t> d_pass;                 // [passes of the batch][bins]: scratch histogram of every pair pass, committed at the batch's end
+    // [passes of the batch][bins]: scratch histogram of every pair pass, committed at the batch's end
+    DevBuf<uint64_t> d_pass;
     DevBuf<uint32_t> d_overflow;             // device flag raised by the two-level cell build when a pencil bucket is full
     uint32_t* h_overflow = nullptr;          // pinned host copies (one per batch in flight), read where a batch is completed
     hipEvent_t batch_done[2] = {nullptr, nullptr};   // end of a queued batch (deferred completion: process_range)
@@ -619,7 +660,8 @@ struct vmd_script_eval_t {
     size_t num_blocks = 0;
     vmd_script_eval_t* source = nullptr;
     // the trajectory instance this eval's block partials were evaluated from: a user of this eval as a SOURCE takes blocks only while it is
-    // itself evaluating the same instance (two evals of one script over different trajectories of equal length must not trade blocks)
+    // itself evaluating the same instance (two evals of one script over different trajectories of equal length must not trade
+    // blocks)
     TrajId blocks_inst;
     std::atomic<bool> defer_volume_views{false};   // vmd_eval_defer_volume_views
     std::atomic<size_t> frames_computed{0}, frames_reused{0}, frames_device_decoded{0};
@@ -645,7 +687,8 @@ struct vmd_script_eval_t {
         std::atomic<bool> concurrent{false};         // this evaluation (since clear_data) has seen two calls at once: it is a pool
         bool spec_active = false;                    // a region is being evaluated (queue_mtx)
         bool lonely = false;                         // a first call has waited for company in vain (queue_mtx)
-        std::atomic<bool> disabled{false};           // settles keep finding partly requested blocks (three strikes): the callers do not arrive the way read-ahead assumes
+        // settles keep finding partly requested blocks (three strikes): the callers do not arrive the way read-ahead assumes
+        std::atomic<bool> disabled{false};
         int strikes = 0;
         size_t next_region = 0;                      // frames of the next region
         bool failed = false; std::string error;      // a region failed: every waiting call reports it
@@ -657,25 +700,30 @@ struct vmd_script_eval_t {
         std::atomic<uint64_t> regions{0}, region_frames{0}, slow_calls{0}, settles{0}, direct_frames{0}, committed_blocks{0};
         // deferred settle (option readahead_lone): decided per evaluation at its first small call
         std::atomic<bool> lone{false};
-        std::atomic<int> lone_pref{-1};              // vmd_eval_set_deferred_settle: -1 = the process-wide option readahead_lone, 0 / 1 = this eval's own choice
+        // vmd_eval_set_deferred_settle: -1 = the process-wide option readahead_lone, 0 / 1 = this eval's own choice
+        std::atomic<int> lone_pref{-1};
         struct Helper {
             std::thread th;
             std::mutex mtx;
             std::condition_variable cv, idle_cv;
             bool started = false, quit = false, busy = false, have = false;      // (mtx)
-            uint64_t cancel_seq = 0;                        // (mtx) bumped by every cancel: a settle that was running then does not re-arm itself
+            // (mtx) bumped by every cancel: a settle that was running then does not re-arm itself
+            uint64_t cancel_seq = 0;
             std::atomic<bool> armed{false};                 // a settle is owed once the eval has been quiet long enough
             std::atomic<int64_t> last_leave_ns{0};          // when the last call left (steady clock)
             std::atomic<uint64_t> settles{0};
             vmd_system_t sys; vmd_trajectory_i traj;        // (mtx) copies of the caller's records: what the deferred settle evaluates from
-            // vmd_eval_set_settled_callback: told after every settle the helper (or vmd_eval_wait_settled) has performed, without any lock of
+            // vmd_eval_set_settled_callback: told after every settle the helper (or vmd_eval_wait_settled) has performed, without any lock
+            // of
             // the eval held.  Written before the evaluation's calls (like lone_pref), read by the helper: atomics, not a lock
             std::atomic<void (*)(void*)> on_settled{nullptr};
             std::atomic<void*> on_settled_user{nullptr};
         } helper;
     } ra;
     vmd_reduce_stats_t reduce_stats = {};
-    struct Spec { bool rdf_closed = false, sdf_include_self = false, sdf_density = false, dist_geometric_com = false, rdf_raw = false; int rdf_norm = 0; } spec;   // fixed at creation
+    // fixed at creation
+    struct Spec { bool rdf_closed = false, sdf_include_self = false, sdf_density = false, dist_geometric_com = false, rdf_raw = false;
+            int rdf_norm = 0; } spec;
     size_t atoms_checked = (size_t)-1;       // trajectory atom count the properties' indices were validated against (under mtx)
 };
 
@@ -698,7 +746,8 @@ void lone_stop(vmd_script_eval_t* e);
 // are written by DMA, memcpy and fills: a reader of those runs under the reference's "torn data is tolerated" rule only.
 template <class T> static inline void pub(T& dst, T v) { __atomic_store(&dst, &v, __ATOMIC_RELAXED); }
 
-static inline void pub_touch(uint64_t& fingerprint) { uint64_t v; __atomic_load(&fingerprint, &v, __ATOMIC_RELAXED); v += 1; __atomic_store(&fingerprint, &v, __ATOMIC_RELAXED); }
+static inline void pub_touch(uint64_t& fingerprint) { uint64_t v; __atomic_load(&fingerprint, &v, __ATOMIC_RELAXED); v += 1;
+        __atomic_store(&fingerprint, &v, __ATOMIC_RELAXED); }
 
 void ra_reset(vmd_script_eval_t* e);
 
@@ -747,9 +796,11 @@ bool prepare_open_boxes(vmd_script_eval_t* e, Stage& st, size_t nb, uint32_t pbc
 
 bool choose_grid(const std::vector<float>& boxes, uint32_t pbc, size_t nb, float rmax, vmd_grid_t* g, bool dense_lanes = false);
 
-bool ensure_pencil_caps(vmd_script_eval_t* e, Selection* s, const Stage& src, const float* d_boxes, uint32_t pbc, size_t nb, const vmd_grid_t& g);
+bool ensure_pencil_caps(vmd_script_eval_t* e, Selection* s, const Stage& src, const float* d_boxes, uint32_t pbc, size_t nb,
+        const vmd_grid_t& g);
 
-bool build_selection(vmd_script_eval_t* e, Selection* s, const Stage& src, const float* d_boxes, uint32_t pbc, size_t nb, const vmd_grid_t& g);
+bool build_selection(vmd_script_eval_t* e, Selection* s, const Stage& src, const float* d_boxes, uint32_t pbc, size_t nb,
+        const vmd_grid_t& g);
 
 size_t auto_batch(const vmd_script_eval_t* e, size_t num_atoms, bool staged);
 
@@ -763,7 +814,8 @@ void plan_batches(const vmd_script_eval_t* e, size_t beg, size_t end, size_t Bma
 // and return the sub-ranges that still have to be computed
 // block_ready[b] != 0: block b's partial (d_blocks, block_weights64, temporal rows) is complete.  Where its temporal rows are: a block
 // evaluated by a plain call has them in `values`; a block evaluated AHEAD (read-ahead, spec) or adopted from a source has them in the side
-// buffer `ahead_values` until it is committed - `values` only ever shows frames somebody asked for.  An eval that takes blocks from a source
+// buffer `ahead_values` until it is committed - `values` only ever shows frames somebody asked for.  An eval that takes blocks from a
+// source
 // (reuse_blocks, ra_adopt_blocks) must read the rows where they are: a filtered evaluation running BESIDE its source (src/main.cpp:982-1039
 // enqueues both) used to copy rows of blocks the source had evaluated ahead but not yet committed out of `values` - zeros
 // (tests/native/stress_readahead.cpp, "beside").
@@ -777,9 +829,11 @@ bool view_sharded(const vmd_device_view_t& view);
 
 bool view_holds(bool have_view, const vmd_device_view_t& view, size_t frame);
 
-bool process_range_locked(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_trajectory_i* traj, uint32_t frame_beg, uint32_t frame_end, bool views, bool spec);
+bool process_range_locked(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_trajectory_i* traj, uint32_t frame_beg, uint32_t frame_end,
+        bool views, bool spec);
 
-bool process_range(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_trajectory_i* traj, uint32_t frame_beg, uint32_t frame_end, bool views = true);
+bool process_range(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_trajectory_i* traj, uint32_t frame_beg, uint32_t frame_end,
+        bool views = true);
 
 bool refresh_views_locked(vmd_script_eval_t* e);
 
@@ -862,13 +916,16 @@ struct vmd_devtraj_t {
     size_t num_frames = 0, num_atoms = 0, npad = 0;
     size_t first = 0, resident = 0;     // frames [first, first + resident) are in HBM (a rank's shard; the whole trajectory otherwise)
     float* d = nullptr;                 // frame `first`
-    float* d0 = nullptr;                // shards that do not start at frame 0 keep a copy of it: the SDF reference pose is taken there (SPEC S5)
-    bool has(size_t beg, size_t end) const { return (beg >= first && end <= first + resident && beg <= end) || (d0 && beg == 0 && end == 1); }
+    // shards that do not start at frame 0 keep a copy of it: the SDF reference pose is taken there (SPEC S5)
+    float* d0 = nullptr;
+    bool has(size_t beg, size_t end) const { return (beg >= first && end <= first + resident && beg <= end) || (d0 && beg == 0
+            && end == 1); }
     float* frame(size_t f) const { return (d0 && f == 0) ? d0 : d + (f - first) * 3 * npad; }
     int device = 0;
     std::vector<vmd_unitcell_t> cells;
     uint64_t cells_version = next_cells_version();   // a new process-wide number for every change of `cells` or of the coordinates: two
-                                                     // trajectories (one freed, one created at the same address) never share one
+                                                     // trajectories (one freed, one created at the same address) never share one (ADVICE
+                                                     // r02)
     vmd_trajectory_i iface;
 };
 

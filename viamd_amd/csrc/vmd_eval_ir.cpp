@@ -1,3 +1,6 @@
+// viamd_amd/csrc/vmd_eval_ir.cpp - the property descriptors behind vmd_ir_*: what md_script_ir_t carries for the hot-path properties
+// (rdf / sdf / distance family; /root/reference/src/main.cpp:528, 2817-2858), their fingerprint and the work estimate a host compares
+// with its threshold (include/vmd_md_script_shim.h).
 #include "vmd_eval_internal.h"
 
 uint64_t fnv1a(uint64_t h, const void* data, size_t n) {
@@ -8,7 +11,8 @@ uint64_t fnv1a(uint64_t h, const void* data, size_t n) {
 
 extern "C" vmd_script_ir_t* vmd_ir_create(void) { return new vmd_script_ir_t(); }
 
-// atom pairs one frame of this script asks for (rdf: |ref| x |target|; sdf: K x |target| + K m for the alignment; distance: |a| x |b| of every
+// atom pairs one frame of this script asks for (rdf: |ref| x |target|; sdf: K x |target| + K m for the alignment; distance: |a| x |b| of
+// every
 // context): what a host compares with its threshold before it sends a SMALL script to the GPU at all (include/vmd_md_script_shim.h,
 // vmd_shim_set_min_work; VIAMD's default dataset is ~1e2 atoms, src/main.cpp:522-528)
 extern "C" uint64_t vmd_ir_work_per_frame(const vmd_script_ir_t* ir) {
@@ -17,7 +21,8 @@ extern "C" uint64_t vmd_ir_work_per_frame(const vmd_script_ir_t* ir) {
     for (const Property& p : ir->props) {
         if (p.kind == PROP_RDF) w += (uint64_t)p.a.size() * (uint64_t)p.b.size();
         else if (p.kind == PROP_SDF) w += (uint64_t)p.K * ((uint64_t)p.b.size() + (uint64_t)p.m);
-        else if (p.aoff.size() > 1) { for (size_t c = 0; c + 1 < p.aoff.size(); ++c) w += (uint64_t)(p.aoff[c + 1] - p.aoff[c]) * (uint64_t)(p.boff[c + 1] - p.boff[c]); }
+        else if (p.aoff.size() > 1) { for (size_t c = 0; c + 1 < p.aoff.size(); ++c) w += (uint64_t)(p.aoff[c + 1] - p.aoff[c])
+                * (uint64_t)(p.boff[c + 1] - p.boff[c]); }
         else w += (uint64_t)p.a.size() * (uint64_t)p.b.size();
     }
     return w;
@@ -53,7 +58,8 @@ extern "C" bool vmd_ir_add_rdf(vmd_script_ir_t* ir, const char* name, const int3
 
 extern "C" bool vmd_ir_add_sdf(vmd_script_ir_t* ir, const char* name, const int32_t* structures, size_t K, size_t m,
                                const int32_t* target, size_t ntarget, float cutoff) {
-    if (!ir_name_ok(ir, name) || !idx_ok(structures, K * m, "sdf reference structures") || !idx_ok(target, ntarget, "sdf target set")) return false;
+    if (!ir_name_ok(ir, name) || !idx_ok(structures, K * m, "sdf reference structures") || !idx_ok(target, ntarget,
+            "sdf target set")) return false;
     if (!(cutoff > 0.0f)) return vmd_fail("sdf cutoff must be positive");
     Property p;
     p.name = name; p.kind = PROP_SDF; p.flags = VMD_PROPERTY_FLAG_VOLUME;
@@ -85,8 +91,10 @@ extern "C" bool vmd_ir_add_distance_population(vmd_script_ir_t* ir, const char* 
     if ((int)kind < 0 || (int)kind > 3) return vmd_fail("unknown distance kind %d", (int)kind);
     if (a_offsets[0] != 0 || b_offsets[0] != 0) return vmd_fail("context offsets must start at 0");
     for (size_t c = 0; c < P; ++c) {
-        if (a_offsets[c + 1] <= a_offsets[c] || b_offsets[c + 1] <= b_offsets[c]) return vmd_fail("distance context %zu has an empty set", c);
-        if (kind == VMD_DISTANCE_PAIR && ((a_offsets[c + 1] - a_offsets[c]) != a_offsets[1] || (b_offsets[c + 1] - b_offsets[c]) != b_offsets[1]))
+        if (a_offsets[c + 1] <= a_offsets[c] || b_offsets[c + 1] <= b_offsets[c]) return vmd_fail("distance context %zu has an empty set",
+                c);
+        if (kind == VMD_DISTANCE_PAIR && ((a_offsets[c + 1] - a_offsets[c]) != a_offsets[1] || (b_offsets[c + 1]
+                - b_offsets[c]) != b_offsets[1]))
             return vmd_fail("distance_pair needs contexts of equal size");
     }
     if (!idx_ok(a, (size_t)a_offsets[P], "distance set a") || !idx_ok(b, (size_t)b_offsets[P], "distance set b")) return false;

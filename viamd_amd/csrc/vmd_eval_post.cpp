@@ -1,3 +1,6 @@
+// viamd_amd/csrc/vmd_eval_post.cpp - VIAMD's consumer-side post-processing of evaluated properties, behind the C ABI: compute_histogram,
+// compute_histogram_masked, downsample_histogram, scale_histogram (/root/reference/src/main.cpp:139-261).  Pinned to the reference's own
+// code bit for bit (tests/test_ref_pin.py, tests/native/ref_callsites.cpp): this is the formula the 1e-5 tolerance of g(r) goes through.
 #include "vmd_eval_internal.h"
 
 // ------------------------------------------------------------------------------------------------ consumer post-processing

@@ -1,3 +1,7 @@
+// viamd_amd/csrc/vmd_eval_runtime.cpp - what every part of the evaluator stands on: the thread-local error string and the log hook
+// (md_log_register analogue, /root/reference/src/main.cpp:384-420), the tuning knobs behind vmd_set_option, hipEvent profiling, and the
+// process-wide resource pool - device blocks, pinned blocks, streams and events an eval gives up are handed to the next one (VIAMD
+// creates a fresh eval per script edit, src/main.cpp:960-972).  Shared declarations: vmd_eval_internal.h.
 #include "vmd_eval_internal.h"
 
 // ------------------------------------------------------------------------------------------------ errors / options
@@ -188,7 +192,8 @@ extern "C" void vmd_pool_trim(void) {
     ResourcePool& P = pool();
     std::vector<std::pair<int, void*>> victims;
     { std::lock_guard<std::mutex> l(P.mtx);
-      for (int k = 0; k <= kPinned; ++k) { for (auto& b : P.blocks[k]) { victims.push_back({k, b.second}); P.owner.erase(b.second); } P.blocks[k].clear(); }
+      for (int k = 0; k <= kPinned; ++k) { for (auto& b : P.blocks[k]) { victims.push_back({k, b.second}); P.owner.erase(b.second);
+              } P.blocks[k].clear(); }
       P.pooled[0] = P.pooled[1] = 0; }
     if (victims.empty()) return;
     int prev = pool_device();

@@ -1,10 +1,18 @@
+// viamd_amd/csrc/vmd_eval_stage.cpp - getting a batch of frames to where the kernels read it: the static per-eval uploads (index lists,
+// masses, bond trees), frames read in place from HBM (device views), frames staged through pinned memory behind the copy engine, and
+// compressed XTC frames uploaded raw and decoded on the device next to the pair kernel (/root/reference/src/loader.cpp:111-159 is the
+// CPU-side counterpart: md_trajectory_load_frame behind a frame cache).
 #include "vmd_eval_internal.h"
 
 bool check_atoms(vmd_script_eval_t* e, size_t num_atoms) {
     if (e->atoms_checked == num_atoms) return true;          // the index lists never change: one pass per trajectory size
     for (auto& p : e->props) {
-        for (int32_t i : p->prop.a) if ((size_t)i >= num_atoms) return vmd_fail("property '%s' references atom %d but the trajectory has %zu atoms", p->prop.name.c_str(), i, num_atoms);
-        for (int32_t i : p->prop.b) if ((size_t)i >= num_atoms) return vmd_fail("property '%s' references atom %d but the trajectory has %zu atoms", p->prop.name.c_str(), i, num_atoms);
+        for (int32_t i : p->prop.a)
+            if ((size_t)i >= num_atoms)
+                return vmd_fail("property '%s' references atom %d but the trajectory has %zu atoms", p->prop.name.c_str(), i, num_atoms);
+        for (int32_t i : p->prop.b)
+            if ((size_t)i >= num_atoms)
+                return vmd_fail("property '%s' references atom %d but the trajectory has %zu atoms", p->prop.name.c_str(), i, num_atoms);
     }
     e->atoms_checked = num_atoms;
     return true;
@@ -26,7 +34,8 @@ int launch_raw_decode(vmd_script_eval_t* e, Stage& st, const unsigned char* d_ra
     if (nb > st.h_raw_status_cap) {
         if (st.h_raw_status) pool_give(st.h_raw_status);
         st.h_raw_status = nullptr; st.h_raw_status_cap = 0;
-        if (pool_take(kPinned, (void**)&st.h_raw_status, nb * sizeof(uint32_t)) != hipSuccess) { vmd_fail("hipHostMalloc failed"); return -1; }
+        if (pool_take(kPinned, (void**)&st.h_raw_status, nb * sizeof(uint32_t)) != hipSuccess) { vmd_fail("hipHostMalloc failed");
+                return -1; }
         st.h_raw_status_cap = nb;
     }
     if (!st.d.ensure(nb * 3 * npad) || !st.d_raw_status.ensure(nb)) return -1;
@@ -47,10 +56,12 @@ int launch_raw_decode(vmd_script_eval_t* e, Stage& st, const unsigned char* d_ra
         // With group records next to the checkpoints (the first pass writes both) a later pass walks nothing at all.
         const bool recs = rec && nrec && rec_stride >= num_atoms && rec_failed && !flag_get(rec_failed) && g_opt.xtc_records.load();
         if (recs) {
-            rc = vmd_hip_xtc_decode_wave_rec(stream, d_raw, d_info, (int)nb, (int)num_atoms, st.d.p, 3 * npad, npad, st.d_raw_status.p, all ? 1 : 0, ck, nck, rec, nrec, rec_stride);
+            rc = vmd_hip_xtc_decode_wave_rec(stream, d_raw, d_info, (int)nb, (int)num_atoms, st.d.p, 3 * npad, npad, st.d_raw_status.p, all
+                    ? 1 : 0, ck, nck, rec, nrec, rec_stride);
             if (all) st.rec_failed = rec_failed;
         } else
-        rc = vmd_hip_xtc_decode_wave_ck(stream, d_raw, d_info, (int)nb, (int)num_atoms, st.d.p, 3 * npad, npad, st.d_raw_status.p, all ? 1 : 0, ck, nck);
+        rc = vmd_hip_xtc_decode_wave_ck(stream, d_raw, d_info, (int)nb, (int)num_atoms, st.d.p, 3 * npad, npad, st.d_raw_status.p, all ? 1
+                : 0, ck, nck);
         if (!all) st.ck_mark = ck_have;
         else st.ck_clear = ck_have;
         st.sectioned = all;
@@ -60,7 +71,8 @@ int launch_raw_decode(vmd_script_eval_t* e, Stage& st, const unsigned char* d_ra
     e->prof_copy.end(stream);
     if (rc != 0) { vmd_fail("XTC decode kernel launch failed"); return -1; }
     for (size_t b = 0; b < nb; ++b) st.h_raw_status[b] = 99u;
-    if (hipMemcpyAsync(st.h_raw_status, st.d_raw_status.p, nb * sizeof(uint32_t), hipMemcpyDeviceToHost, stream) != hipSuccess) { vmd_fail("device XTC decode failed"); return -1; }
+    if (hipMemcpyAsync(st.h_raw_status, st.d_raw_status.p, nb * sizeof(uint32_t), hipMemcpyDeviceToHost,
+            stream) != hipSuccess) { vmd_fail("device XTC decode failed"); return -1; }
     st.raw_pending = true;
     return 1;
 }
@@ -96,17 +108,20 @@ int raw_upload_f32(vmd_script_eval_t* e, vmd_script_eval_t::RawSlot& rs, vmd_tra
     if (rs.info_bytes > rs.hcap) {
         if (rs.h) pool_give(rs.h);
         rs.h = nullptr; rs.hcap = 0;
-        if (pool_take(kPinned, (void**)&rs.h, 2 * rs.info_bytes) != hipSuccess) { vmd_fail("hipHostMalloc(%zu bytes) failed", 2 * rs.info_bytes); return -1; }
+        if (pool_take(kPinned, (void**)&rs.h, 2 * rs.info_bytes) != hipSuccess) { vmd_fail("hipHostMalloc(%zu bytes) failed", 2
+                * rs.info_bytes); return -1; }
         rs.hcap = 2 * rs.info_bytes;
     }
     memcpy(rs.h, rs.f32.data(), nb * sizeof(vmd_f32_frame_t));
     rs.h_streams = mv.base + lo;
     const size_t span = hi - lo;
     if (!rs.d.ensure(rs.info_bytes + span + span / 8 + 64)) return -1;
-    if (hipMemcpyAsync(rs.d.p, rs.h, nb * sizeof(vmd_f32_frame_t), hipMemcpyHostToDevice, e->copy_stream) != hipSuccess) { vmd_fail("hipMemcpyAsync of the frame table failed"); return -1; }
+    if (hipMemcpyAsync(rs.d.p, rs.h, nb * sizeof(vmd_f32_frame_t), hipMemcpyHostToDevice,
+            e->copy_stream) != hipSuccess) { vmd_fail("hipMemcpyAsync of the frame table failed"); return -1; }
     for (size_t a = lo; a < hi;) {                          // one copy per pinned window the span touches
         const size_t stop = std::min(hi, (a / kMapWindow + 1) * kMapWindow);
-        if (hipMemcpyAsync(rs.d.p + rs.info_bytes + (a - lo), mv.base + a, stop - a, hipMemcpyHostToDevice, e->copy_stream) != hipSuccess) { vmd_fail("hipMemcpyAsync from the mapped trajectory file failed"); return -1; }
+        if (hipMemcpyAsync(rs.d.p + rs.info_bytes + (a - lo), mv.base + a, stop - a, hipMemcpyHostToDevice,
+                e->copy_stream) != hipSuccess) { vmd_fail("hipMemcpyAsync from the mapped trajectory file failed"); return -1; }
         a = stop;
     }
     if (hipEventRecord(rs.uploaded, e->copy_stream) != hipSuccess) { vmd_fail("hipEventRecord failed"); return -1; }
@@ -126,7 +141,8 @@ int raw_upload(vmd_script_eval_t* e, RawSlot& rs, vmd_trajectory_i* traj, size_t
     size_t total = 0;
     for (size_t b = 0; b < nb; ++b) {                      // sizes first (no payload), then one pinned block for the batch
         vmd_frame_header_t hdr;
-        if (!traj->load_raw(traj->inst, (int64_t)(f0 + b), &hdr, &infos[b], nullptr, 0) || hdr.num_atoms != num_atoms || infos[b].codec != infos[0].codec ||
+        if (!traj->load_raw(traj->inst, (int64_t)(f0 + b), &hdr, &infos[b], nullptr, 0) || hdr.num_atoms != num_atoms
+                || infos[b].codec != infos[0].codec ||
             (infos[b].codec != VMD_RAW_CODEC_XTC && infos[b].codec != VMD_RAW_CODEC_F32)) { rs.state = -1; return 0; }
         rs.cells[b] = hdr.unitcell;
         vmd_xtc_frame_t& fi = rs.info[b];
@@ -166,17 +182,21 @@ int raw_upload(vmd_script_eval_t* e, RawSlot& rs, vmd_trajectory_i* traj, size_t
             if (rs.info_bytes > rs.hcap) {
                 if (rs.h) pool_give(rs.h);
                 rs.h = nullptr; rs.hcap = 0;
-                if (pool_take(kPinned, (void**)&rs.h, 2 * rs.info_bytes) != hipSuccess) { vmd_fail("hipHostMalloc(%zu bytes) failed", 2 * rs.info_bytes); return -1; }
+                if (pool_take(kPinned, (void**)&rs.h, 2 * rs.info_bytes) != hipSuccess) { vmd_fail("hipHostMalloc(%zu bytes) failed", 2
+                        * rs.info_bytes); return -1; }
                 rs.hcap = 2 * rs.info_bytes;
             }
             memcpy(rs.h, rs.info.data(), nb * sizeof(vmd_xtc_frame_t));
             rs.h_streams = mv.base + lo;
             const size_t span = hi - lo;
-            if (!rs.d.ensure(rs.info_bytes + span + span / 8 + 64)) return -1;        // >= 32 readable bytes behind the last stream even at the file's end
-            if (hipMemcpyAsync(rs.d.p, rs.h, nb * sizeof(vmd_xtc_frame_t), hipMemcpyHostToDevice, e->copy_stream) != hipSuccess) { vmd_fail("hipMemcpyAsync of the frame table failed"); return -1; }
+            // >= 32 readable bytes behind the last stream even at the file's end
+            if (!rs.d.ensure(rs.info_bytes + span + span / 8 + 64)) return -1;
+            if (hipMemcpyAsync(rs.d.p, rs.h, nb * sizeof(vmd_xtc_frame_t), hipMemcpyHostToDevice,
+                    e->copy_stream) != hipSuccess) { vmd_fail("hipMemcpyAsync of the frame table failed"); return -1; }
             for (size_t a = lo; a < hi;) {                  // one copy per pinned window the span touches
                 const size_t stop = std::min(hi, (a / kMapWindow + 1) * kMapWindow);
-                if (hipMemcpyAsync(rs.d.p + rs.info_bytes + (a - lo), mv.base + a, stop - a, hipMemcpyHostToDevice, e->copy_stream) != hipSuccess) { vmd_fail("hipMemcpyAsync from the mapped trajectory file failed"); return -1; }
+                if (hipMemcpyAsync(rs.d.p + rs.info_bytes + (a - lo), mv.base + a, stop - a, hipMemcpyHostToDevice,
+                        e->copy_stream) != hipSuccess) { vmd_fail("hipMemcpyAsync from the mapped trajectory file failed"); return -1; }
                 a = stop;
             }
             if (hipEventRecord(rs.uploaded, e->copy_stream) != hipSuccess) { vmd_fail("hipEventRecord failed"); return -1; }
@@ -205,7 +225,8 @@ int raw_upload(vmd_script_eval_t* e, RawSlot& rs, vmd_trajectory_i* traj, size_t
             const vmd_xtc_frame_t& fi = rs.info[b];
             vmd_raw_frame_t info;
             unsigned char* dst = rs.h + rs.info_bytes + fi.offset;
-            if (!traj->load_raw(traj->inst, (int64_t)(f0 + b), nullptr, &info, dst, (size_t)fi.nbytes) || info.nbytes != fi.nbytes) { ok = false; break; }
+            if (!traj->load_raw(traj->inst, (int64_t)(f0 + b), nullptr, &info, dst, (size_t)fi.nbytes)
+                    || info.nbytes != fi.nbytes) { ok = false; break; }
             memset(dst + fi.nbytes, 0, (((size_t)fi.nbytes + 32 + 63) & ~(size_t)63) - (size_t)fi.nbytes);
         }
     };
@@ -223,7 +244,8 @@ int raw_upload(vmd_script_eval_t* e, RawSlot& rs, vmd_trajectory_i* traj, size_t
     if (!ok.load()) { rs.state = -1; return 0; }           // let load_frame produce the real error message
     rs.h_streams = rs.h + rs.info_bytes;
     if (!rs.d.ensure(total + total / 8)) return -1;
-    if (hipMemcpyAsync(rs.d.p, rs.h, total, hipMemcpyHostToDevice, e->copy_stream) != hipSuccess) { vmd_fail("hipMemcpyAsync of the compressed batch failed"); return -1; }
+    if (hipMemcpyAsync(rs.d.p, rs.h, total, hipMemcpyHostToDevice,
+            e->copy_stream) != hipSuccess) { vmd_fail("hipMemcpyAsync of the compressed batch failed"); return -1; }
     if (hipEventRecord(rs.uploaded, e->copy_stream) != hipSuccess) { vmd_fail("hipEventRecord failed"); return -1; }
     rs.state = 1;
     return 1;
@@ -272,12 +294,15 @@ bool fetch_stage(vmd_script_eval_t* e, Stage& st, vmd_trajectory_i* traj, const 
         int raw = 0;
         vmd_raw_device_view_t rv;
         memset(&rv, 0, sizeof(rv));
-        if (!force_host && traj->raw_device_view && traj->raw_device_view(traj->inst, &rv) && rv.codec == VMD_RAW_CODEC_XTC && rv.device == e->device) {
+        if (!force_host && traj->raw_device_view && traj->raw_device_view(traj->inst, &rv) && rv.codec == VMD_RAW_CODEC_XTC
+                && rv.device == e->device) {
             // the compressed trajectory is resident in HBM: no host work, no PCIe - decode the batch where it lies
             for (size_t b = 0; b < nb; ++b) st.cells[b] = rv.cells[f0 + b];
             raw = launch_raw_decode(e, st, rv.base, (const vmd_xtc_frame_t*)rv.info + f0, num_atoms, nb, npad, ss,
-                                    rv.ck ? (vmd_xtc_ck_t*)rv.ck + f0 * VMD_XTC_CK_MAX : nullptr, rv.nck ? rv.nck + f0 : nullptr, rv.ck_have ? rv.ck_have + f0 : nullptr,
-                                    (rv.rec && rv.rec_stride) ? rv.rec + f0 * rv.rec_stride : nullptr, (rv.rec && rv.rec_stride) ? rv.nrec + f0 : nullptr, rv.rec_stride, rv.rec_failed);
+                                    rv.ck ? (vmd_xtc_ck_t*)rv.ck + f0 * VMD_XTC_CK_MAX : nullptr, rv.nck ? rv.nck + f0 : nullptr,
+                                            rv.ck_have ? rv.ck_have + f0 : nullptr,
+                                    (rv.rec && rv.rec_stride) ? rv.rec + f0 * rv.rec_stride : nullptr, (rv.rec && rv.rec_stride) ? rv.nrec
+                                            + f0 : nullptr, rv.rec_stride, rv.rec_failed);
             if (raw < 0) return false;
         } else if (!force_host && g_opt.xtc_device_decode.load() && traj->load_raw && !(e->raw_skip && !pre)) {
             // the bit streams were (or are now) sent ahead through a slot of the ring; decompression runs on its own stream
@@ -290,7 +315,8 @@ bool fetch_stage(vmd_script_eval_t* e, Stage& st, vmd_trajectory_i* traj, const 
                 if (rs->codec == VMD_RAW_CODEC_F32) {
                     if (!st.d.ensure(nb * 3 * npad)) return false;
                     e->prof_copy.begin("raw_f32", ss);
-                    KRN_OK(vmd_hip_raw_f32_decode(ss, rs->d_streams(), (const vmd_f32_frame_t*)rs->d.p, (int)nb, (int)num_atoms, st.d.p, 3 * npad, npad));
+                    KRN_OK(vmd_hip_raw_f32_decode(ss, rs->d_streams(), (const vmd_f32_frame_t*)rs->d.p, (int)nb, (int)num_atoms, st.d.p, 3
+                            * npad, npad));
                     e->prof_copy.end(ss);
                     e->frames_device_decoded += nb;
                     raw = 1;
@@ -304,8 +330,10 @@ bool fetch_stage(vmd_script_eval_t* e, Stage& st, vmd_trajectory_i* traj, const 
                         const uint64_t sg = frame_signature(rs->info[b], rs->h_streams + rs->info[b].offset);
                         if (flag_get(&cc->sig[f0 + b]) != sg) { flag_set(&cc->sig[f0 + b], sg); flag_set(&cc->have[f0 + b], (uint8_t)0); }
                     }
-                    raw = launch_raw_decode(e, st, rs->d_streams(), rs->d_info(), num_atoms, nb, npad, ss, cc->ck.p + f0 * VMD_XTC_CK_MAX, cc->nck.p + f0, cc->have.data() + f0,
-                                            cc->rec_stride ? cc->rec.p + f0 * cc->rec_stride : nullptr, cc->rec_stride ? cc->nrec.p + f0 : nullptr, cc->rec_stride, &cc->rec_failed);
+                    raw = launch_raw_decode(e, st, rs->d_streams(), rs->d_info(), num_atoms, nb, npad, ss, cc->ck.p + f0 * VMD_XTC_CK_MAX,
+                            cc->nck.p + f0, cc->have.data() + f0,
+                                            cc->rec_stride ? cc->rec.p + f0 * cc->rec_stride : nullptr, cc->rec_stride ? cc->nrec.p
+                                                    + f0 : nullptr, cc->rec_stride, &cc->rec_failed);
                 } else {
                     raw = launch_raw_decode(e, st, rs->d_streams(), rs->d_info(), num_atoms, nb, npad, ss);
                 }
@@ -383,7 +411,8 @@ bool fetch_stage(vmd_script_eval_t* e, Stage& st, vmd_trajectory_i* traj, const 
     }
     if (!st.d_boxes.upload(st.h_boxes.data(), nb * 9, ss)) return false;
     HIP_OK(hipEventRecord(st.ready, ss));
-    if (view && view->cells_version != 0) { st.boxes_cells = view->cells; st.boxes_f0 = f0; st.boxes_nb = nb; st.boxes_version = view->cells_version; }
+    if (view && view->cells_version != 0) { st.boxes_cells = view->cells; st.boxes_f0 = f0; st.boxes_nb = nb;
+            st.boxes_version = view->cells_version; }
     return true;
 }
 
@@ -412,7 +441,8 @@ bool settle_stage(vmd_script_eval_t* e, Stage& st, vmd_trajectory_i* traj, size_
     // walk from bit 0 again next time
     if (st.ck_clear) for (size_t b = 0; b < st.nb; ++b) flag_set(&st.ck_clear[b], (uint8_t)0);
     st.ck_clear = nullptr;
-    if (st.rec_failed) flag_set(st.rec_failed, true);          // the records did not describe these streams: never again for this trajectory
+    // the records did not describe these streams: never again for this trajectory
+    if (st.rec_failed) flag_set(st.rec_failed, true);
     st.rec_failed = nullptr;
     return fetch_stage(e, st, traj, nullptr, num_atoms, st.f0, st.nb, true);
 }
@@ -478,7 +508,8 @@ bool choose_grid(const std::vector<float>& boxes, uint32_t pbc, size_t nb, float
         const float* q = &boxes[9 * b];
         const double Lx = q[0], Ly = q[1], Lz = q[2];
         const double xy = tri ? q[6] : 0.0, xz = tri ? q[7] : 0.0, yz = tri ? q[8] : 0.0;
-        const double wx = Lx / std::sqrt(1.0 + (xy / Ly) * (xy / Ly) + ((xy * yz - Ly * xz) / (Ly * Lz)) * ((xy * yz - Ly * xz) / (Ly * Lz)));
+        const double wx = Lx / std::sqrt(1.0 + (xy / Ly) * (xy / Ly) + ((xy * yz - Ly * xz) / (Ly * Lz)) * ((xy * yz - Ly * xz) / (Ly
+                * Lz)));
         const double wy = Ly / std::sqrt(1.0 + (yz / Lz) * (yz / Lz));
         wmin[0] = std::min(wmin[0], (float)wx); wmin[1] = std::min(wmin[1], (float)wy); wmin[2] = std::min(wmin[2], (float)Lz);
         Lxmin = std::min(Lxmin, q[0]);

@@ -1,3 +1,6 @@
+// viamd_amd/csrc/vmd_eval_traj.cpp - trajectories the library itself holds: resident in HBM (vmd_devtraj), compressed-resident
+// XTC streams (vmd_rawtraj), pinned host frames (vmd_hosttraj); plus two process-wide caches the staging code uses - decoder
+// checkpoints of XTC streams (with their sidecar file) and pinned windows of mapped trajectory files.
 #include "vmd_eval_internal.h"
 
 size_t record_stride_for(size_t frames, size_t atoms, int level) {
@@ -20,9 +23,11 @@ std::shared_ptr<CkCache> ckcache_for(const void* inst_, size_t frames, size_t at
         c->frames = frames; c->atoms = atoms; c->device = device;
         c->have.assign(frames, 0);
         c->sig.assign(frames, 0);
-        if (!c->ck.ensure(std::max<size_t>(frames, 1) * VMD_XTC_CK_MAX) || !c->nck.ensure(std::max<size_t>(frames, 1))) { g_ck_store.erase(inst); return nullptr; }
+        if (!c->ck.ensure(std::max<size_t>(frames, 1) * VMD_XTC_CK_MAX) || !c->nck.ensure(std::max<size_t>(frames,
+                1))) { g_ck_store.erase(inst); return nullptr; }
         c->rec_stride = record_stride_for(frames, atoms);
-        if (c->rec_stride && (!c->rec.ensure(frames * c->rec_stride) || !c->nrec.ensure(frames))) { (void)hipGetLastError(); c->rec.release(); c->nrec.release(); c->rec_stride = 0; }
+        if (c->rec_stride && (!c->rec.ensure(frames * c->rec_stride) || !c->nrec.ensure(frames))) { (void)hipGetLastError();
+                c->rec.release(); c->nrec.release(); c->rec_stride = 0; }
         if (g_ck_store.size() > 16) {                       // a handful of open trajectories at most: forget the others
             for (auto it = g_ck_store.begin(); it != g_ck_store.end();) it = it->first == inst ? std::next(it) : g_ck_store.erase(it);
         }
@@ -32,7 +37,8 @@ std::shared_ptr<CkCache> ckcache_for(const void* inst_, size_t frames, size_t at
 
 extern "C" void vmd_ckcache_drop(const void* inst) {
     std::lock_guard<std::mutex> l(g_ck_mtx);
-    for (auto it = g_ck_store.lower_bound(CkKey(inst, INT_MIN)); it != g_ck_store.end() && it->first.first == inst;) it = g_ck_store.erase(it);
+    for (auto it = g_ck_store.lower_bound(CkKey(inst, INT_MIN)); it != g_ck_store.end() && it->first.first == inst;) it =
+            g_ck_store.erase(it);
 }
 
 extern "C" bool vmd_ckcache_save(const vmd_trajectory_i* traj, const char* path) {
@@ -42,7 +48,8 @@ extern "C" bool vmd_ckcache_save(const vmd_trajectory_i* traj, const char* path)
     { std::lock_guard<std::mutex> l(g_ck_mtx);
       auto it = g_ck_store.lower_bound(CkKey(traj->inst, INT_MIN));       // whichever device decoded it: the table describes the file
       if (it != g_ck_store.end() && it->first.first == traj->inst) c = it->second; }
-    if (!c || c->frames == 0) return vmd_fail("vmd_ckcache_save: no decoder checkpoints exist for this trajectory (nothing of it was decoded on the device yet)");
+    if (!c || c->frames == 0)
+        return vmd_fail("vmd_ckcache_save: no decoder checkpoints exist for this trajectory (nothing of it was decoded on the device yet)");
     int prev = 0;
     HIP_OK(hipGetDevice(&prev));
     HIP_OK(hipSetDevice(c->device));
@@ -60,7 +67,8 @@ extern "C" bool vmd_ckcache_save(const vmd_trajectory_i* traj, const char* path)
     FILE* f = fopen(tmp.c_str(), "wb");
     if (!f) return vmd_fail("vmd_ckcache_save: cannot create %s", tmp.c_str());
     bool ok = fwrite(&h, sizeof(h), 1, f) == 1 && fwrite(c->have.data(), 1, c->frames, f) == c->frames &&
-              fwrite(c->sig.data(), sizeof(uint64_t), c->frames, f) == c->frames && fwrite(nck.data(), sizeof(uint32_t), nck.size(), f) == nck.size() &&
+              fwrite(c->sig.data(), sizeof(uint64_t), c->frames, f) == c->frames && fwrite(nck.data(), sizeof(uint32_t), nck.size(),
+                      f) == nck.size() &&
               fwrite(ck.data(), sizeof(vmd_xtc_ck_t), ck.size(), f) == ck.size();
     ok = (fclose(f) == 0) && ok;
     if (!ok || rename(tmp.c_str(), path) != 0) { remove(tmp.c_str()); return vmd_fail("vmd_ckcache_save: writing %s failed", path); }
@@ -75,14 +83,16 @@ extern "C" long vmd_ckcache_load(const vmd_trajectory_i* traj, const char* path,
     if (!f) { vmd_fail("vmd_ckcache_load: cannot open %s", path); return -1; }
     CkFileHeader h;
     const size_t frames = traj->num_frames(traj->inst), atoms = traj->num_atoms(traj->inst);
-    if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, kCkMagic, 8) != 0 || h.version != 1) { fclose(f); vmd_fail("vmd_ckcache_load: %s is not a checkpoint file", path); return -1; }
+    if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, kCkMagic, 8) != 0 || h.version != 1) { fclose(f);
+            vmd_fail("vmd_ckcache_load: %s is not a checkpoint file", path); return -1; }
     if (h.ck_max != VMD_XTC_CK_MAX || h.frames != frames || h.atoms != atoms || frames == 0) { fclose(f); return 0; }
     std::vector<uint8_t> have(frames);
     std::vector<uint64_t> sig(frames);
     std::vector<uint32_t> nck(frames);
     std::vector<vmd_xtc_ck_t> ck(frames * VMD_XTC_CK_MAX);
     const bool ok = fread(have.data(), 1, frames, f) == frames && fread(sig.data(), sizeof(uint64_t), frames, f) == frames &&
-                    fread(nck.data(), sizeof(uint32_t), frames, f) == frames && fread(ck.data(), sizeof(vmd_xtc_ck_t), ck.size(), f) == ck.size();
+                    fread(nck.data(), sizeof(uint32_t), frames, f) == frames && fread(ck.data(), sizeof(vmd_xtc_ck_t), ck.size(),
+                            f) == ck.size();
     fclose(f);
     if (!ok) { vmd_fail("vmd_ckcache_load: %s is truncated", path); return -1; }
     long n = 0;
@@ -91,7 +101,8 @@ extern "C" long vmd_ckcache_load(const vmd_trajectory_i* traj, const char* path,
         n += have[i] ? 1 : 0;
     }
     int prev = 0;
-    if (hipGetDevice(&prev) != hipSuccess || hipSetDevice(device) != hipSuccess) { vmd_fail("vmd_ckcache_load: no such device"); return -1; }
+    if (hipGetDevice(&prev) != hipSuccess || hipSetDevice(device) != hipSuccess) { vmd_fail("vmd_ckcache_load: no such device"); return -1;
+            }
     std::shared_ptr<CkCache> c = ckcache_for(traj->inst, frames, atoms, device);
     bool up = c != nullptr;
     if (up) {
@@ -183,7 +194,8 @@ size_t dt_num_atoms(void* inst) { return ((vmd_devtraj_t*)inst)->num_atoms; }
 
 bool dt_load_frame(void* inst, int64_t idx, vmd_frame_header_t* hdr, float* x, float* y, float* z) {
     vmd_devtraj_t* t = (vmd_devtraj_t*)inst;
-    if (idx < 0 || !t->has((size_t)idx, (size_t)idx + 1)) return vmd_fail("devtraj: frame %lld is not resident on this rank", (long long)idx);
+    if (idx < 0 || !t->has((size_t)idx, (size_t)idx + 1)) return vmd_fail("devtraj: frame %lld is not resident on this rank",
+            (long long)idx);
     const float* f = t->frame((size_t)idx);
     if (x) HIP_OK(hipMemcpy(x, f, t->num_atoms * sizeof(float), hipMemcpyDeviceToHost));
     if (y) HIP_OK(hipMemcpy(y, f + t->npad, t->num_atoms * sizeof(float), hipMemcpyDeviceToHost));
@@ -196,7 +208,8 @@ bool dt_device_view(void* inst, vmd_device_view_t* out) {
     vmd_devtraj_t* t = (vmd_devtraj_t*)inst;
     // frame f sits at base + f * frame_stride: for a shard the base lies `first` frames before the allocation and is only ever
     // used with resident frame indices (the evaluator is handed ranges inside the shard)
-    out->base = t->d - t->first * 3 * t->npad; out->frame_stride = 3 * t->npad; out->row_stride = t->npad; out->cells = t->cells.data(); out->device = t->device;
+    out->base = t->d - t->first * 3 * t->npad; out->frame_stride = 3 * t->npad; out->row_stride = t->npad; out->cells = t->cells.data();
+            out->device = t->device;
     out->resident_beg = t->first; out->resident_end = t->first + t->resident;
     out->cells_version = t->cells_version;
     return true;
@@ -225,7 +238,8 @@ extern "C" vmd_devtraj_t* vmd_devtraj_create_shard(size_t num_frames, size_t fra
     return t.release();
 }
 
-extern "C" vmd_devtraj_t* vmd_devtraj_create(size_t num_frames, size_t num_atoms) { return vmd_devtraj_create_shard(num_frames, 0, num_frames, num_atoms); }
+extern "C" vmd_devtraj_t* vmd_devtraj_create(size_t num_frames, size_t num_atoms) { return vmd_devtraj_create_shard(num_frames, 0,
+        num_frames, num_atoms); }
 
 extern "C" void vmd_devtraj_free(vmd_devtraj_t* t) {
     if (!t) return;
@@ -250,7 +264,8 @@ extern "C" bool vmd_devtraj_upload_frame(vmd_devtraj_t* t, size_t frame, const v
 
 extern "C" bool vmd_devtraj_upload_atoms(vmd_devtraj_t* t, size_t frame_beg, size_t frame_count, size_t first_atom, size_t atom_count,
                                         const float* xyz /* [frame_count][3][atom_count] */) {
-    if (!t || !t->has(frame_beg, frame_beg + frame_count) || first_atom + atom_count > t->num_atoms) return vmd_fail("vmd_devtraj_upload_atoms: bad range");
+    if (!t || !t->has(frame_beg, frame_beg + frame_count) || first_atom
+            + atom_count > t->num_atoms) return vmd_fail("vmd_devtraj_upload_atoms: bad range");
     for (size_t f = 0; f < frame_count; ++f)
         for (int c = 0; c < 3; ++c)
             HIP_OK(hipMemcpyAsync(t->frame(frame_beg + f) + (size_t)c * t->npad + first_atom,
@@ -329,7 +344,8 @@ extern "C" void vmd_rawtraj_free(vmd_rawtraj_t* t) {
 }
 
 extern "C" vmd_rawtraj_t* vmd_rawtraj_create(vmd_trajectory_i* src) {
-    if (!src || !src->load_raw) { vmd_fail("vmd_rawtraj_create: the trajectory does not offer its frames compressed (load_raw)"); return nullptr; }
+    if (!src || !src->load_raw) { vmd_fail("vmd_rawtraj_create: the trajectory does not offer its frames compressed (load_raw)");
+            return nullptr; }
     if (vmd_device_count() <= 0) { vmd_fail("vmd_rawtraj_create: no usable HIP device"); return nullptr; }
     std::unique_ptr<vmd_rawtraj_t, void (*)(vmd_rawtraj_t*)> t(new vmd_rawtraj_t(), vmd_rawtraj_free);
     t->src = src;
@@ -343,7 +359,8 @@ extern "C" vmd_rawtraj_t* vmd_rawtraj_create(vmd_trajectory_i* src) {
     for (size_t f = 0; f < F; ++f) {
         vmd_frame_header_t hdr;
         vmd_raw_frame_t ri;
-        if (!src->load_raw(src->inst, (int64_t)f, &hdr, &ri, nullptr, 0) || ri.codec != VMD_RAW_CODEC_XTC || hdr.num_atoms != t->num_atoms) {
+        if (!src->load_raw(src->inst, (int64_t)f, &hdr, &ri, nullptr, 0) || ri.codec != VMD_RAW_CODEC_XTC
+                || hdr.num_atoms != t->num_atoms) {
             vmd_fail("vmd_rawtraj_create: frame %zu is not available compressed", f);
             return nullptr;
         }
@@ -363,12 +380,14 @@ extern "C" vmd_rawtraj_t* vmd_rawtraj_create(vmd_trajectory_i* src) {
     t->ck_have.assign(F, 0);
     if (err != hipSuccess) { vmd_fail("vmd_rawtraj_create: hipMalloc(%zu) failed: %s", total, hipGetErrorString(err)); return nullptr; }
     t->rec_stride = record_stride_for(F, t->num_atoms, 2);
-    if (t->rec_stride && (hipMalloc((void**)&t->d_rec, F * t->rec_stride * sizeof(uint16_t)) != hipSuccess || hipMalloc((void**)&t->d_nrec, F * sizeof(uint32_t)) != hipSuccess)) {
+    if (t->rec_stride && (hipMalloc((void**)&t->d_rec, F * t->rec_stride * sizeof(uint16_t)) != hipSuccess || hipMalloc((void**)&t->d_nrec,
+            F * sizeof(uint32_t)) != hipSuccess)) {
         (void)hipGetLastError();                   // no room for the records: the sections are walked from their checkpoints as before
         if (t->d_rec) (void)hipFree(t->d_rec);
         t->d_rec = nullptr; t->rec_stride = 0;
     }
-    if (F && hipMemcpy(t->d_info, info.data(), F * sizeof(vmd_xtc_frame_t), hipMemcpyHostToDevice) != hipSuccess) { vmd_fail("vmd_rawtraj_create: upload failed"); return nullptr; }
+    if (F && hipMemcpy(t->d_info, info.data(), F * sizeof(vmd_xtc_frame_t),
+            hipMemcpyHostToDevice) != hipSuccess) { vmd_fail("vmd_rawtraj_create: upload failed"); return nullptr; }
     // upload in pinned pieces of <= 256 MB, each filled by the load threads
     const size_t piece_cap = std::min<size_t>(std::max<size_t>(total, 64), (size_t)256 << 20);
     unsigned char* pin = nullptr;
@@ -384,7 +403,8 @@ extern "C" vmd_rawtraj_t* vmd_rawtraj_create(vmd_trajectory_i* src) {
     bool good = true;
     for (size_t f0 = 0; f0 < F && good;) {
         size_t f1 = f0, piece = 0;
-        while (f1 < F && (f1 == f0 || piece + (info[f1].offset + (((size_t)info[f1].nbytes + 32 + 63) & ~(size_t)63) - info[f1].offset) <= piece_cap)) {
+        while (f1 < F && (f1 == f0 || piece + (info[f1].offset + (((size_t)info[f1].nbytes + 32 + 63) & ~(size_t)63)
+                - info[f1].offset) <= piece_cap)) {
             piece = info[f1].offset + (((size_t)info[f1].nbytes + 32 + 63) & ~(size_t)63) - info[f0].offset;
             ++f1;
         }
@@ -398,7 +418,8 @@ extern "C" vmd_rawtraj_t* vmd_rawtraj_create(vmd_trajectory_i* src) {
                 if (f >= f1 || !ok.load()) break;
                 unsigned char* dst = pin + (info[f].offset - info[f0].offset);
                 vmd_raw_frame_t ri;
-                if (!src->load_raw(src->inst, (int64_t)f, nullptr, &ri, dst, (size_t)info[f].nbytes) || ri.nbytes != info[f].nbytes) { ok = false; break; }
+                if (!src->load_raw(src->inst, (int64_t)f, nullptr, &ri, dst, (size_t)info[f].nbytes)
+                        || ri.nbytes != info[f].nbytes) { ok = false; break; }
                 memset(dst + info[f].nbytes, 0, (((size_t)info[f].nbytes + 32 + 63) & ~(size_t)63) - (size_t)info[f].nbytes);
             }
         };
@@ -409,8 +430,10 @@ extern "C" vmd_rawtraj_t* vmd_rawtraj_create(vmd_trajectory_i* src) {
             work();
             for (auto& th : pool) th.join();
         }
-        if (!ok.load()) { if (g_last_error.empty()) vmd_fail("vmd_rawtraj_create: reading the compressed frames failed"); good = false; break; }
-        if (hipMemcpy(t->d_raw + info[f0].offset, pin, piece, hipMemcpyHostToDevice) != hipSuccess) { vmd_fail("vmd_rawtraj_create: upload failed"); good = false; break; }
+        if (!ok.load()) { if (g_last_error.empty()) vmd_fail("vmd_rawtraj_create: reading the compressed frames failed"); good = false;
+                break; }
+        if (hipMemcpy(t->d_raw + info[f0].offset, pin, piece,
+                hipMemcpyHostToDevice) != hipSuccess) { vmd_fail("vmd_rawtraj_create: upload failed"); good = false; break; }
         f0 = f1;
     }
     if (pin) (void)hipHostFree(pin);
@@ -457,7 +480,8 @@ extern "C" vmd_hosttraj_t* vmd_hosttraj_create(size_t num_frames, size_t num_ato
     auto t = std::make_unique<vmd_hosttraj_t>();
     t->num_frames = num_frames; t->num_atoms = num_atoms; t->npad = (num_atoms + 63) & ~(size_t)63;
     const size_t bytes = std::max<size_t>(num_frames * 3 * t->npad, 1) * sizeof(float);
-    if (hipHostMalloc((void**)&t->h, bytes, hipHostMallocDefault) != hipSuccess) { vmd_fail("vmd_hosttraj_create: hipHostMalloc(%zu) failed", bytes); return nullptr; }
+    if (hipHostMalloc((void**)&t->h, bytes,
+            hipHostMallocDefault) != hipSuccess) { vmd_fail("vmd_hosttraj_create: hipHostMalloc(%zu) failed", bytes); return nullptr; }
     vmd_unitcell_t none;
     memset(&none, 0, sizeof(none));
     t->cells.assign(num_frames, none);
@@ -487,10 +511,12 @@ extern "C" bool vmd_hosttraj_set_cell(vmd_hosttraj_t* t, size_t frame, const vmd
 }
 
 extern "C" bool vmd_hosttraj_copy_from_device(vmd_hosttraj_t* t, vmd_devtraj_t* src, size_t frame_beg, size_t frame_end) {
-    if (!t || !src || frame_end > t->num_frames || frame_end > src->num_frames || src->num_atoms != t->num_atoms) return vmd_fail("vmd_hosttraj_copy_from_device: shape mismatch");
+    if (!t || !src || frame_end > t->num_frames || frame_end > src->num_frames
+            || src->num_atoms != t->num_atoms) return vmd_fail("vmd_hosttraj_copy_from_device: shape mismatch");
     if (frame_beg >= frame_end) return true;
     if (!src->has(frame_beg, frame_end)) return vmd_fail("vmd_hosttraj_copy_from_device: frames are not resident on this rank");
-    HIP_OK(hipMemcpy(t->h + frame_beg * 3 * t->npad, src->frame(frame_beg), (frame_end - frame_beg) * 3 * t->npad * sizeof(float), hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(t->h + frame_beg * 3 * t->npad, src->frame(frame_beg), (frame_end - frame_beg) * 3 * t->npad * sizeof(float),
+            hipMemcpyDeviceToHost));
     for (size_t f = frame_beg; f < frame_end; ++f) t->cells[f] = src->cells[f];
     return true;
 }
