@@ -305,7 +305,7 @@ def run_c1(ctx, dry):
                        "note": "oracle (scalar restatement; kind port) rdf + sdf over the same frames, dynamic grain 1; median of 9 / 3"},
             "gpu_over_cpu": cpu_pool / pooled, "rdf_hits": hits_r, "voxel_hits": vox_v,
             "work_pairs_times_frames": work,
-            "shim_min_work_default": 4000000,
+            "shim_min_work_default": 1000000,
             "note": "work = vmd_ir_work_per_frame x frames, the quantity include/vmd_md_script_shim.h compares with vmd_shim_set_min_work: below the "
                     "threshold md_script_eval_create leaves the whole script with the evaluator behind the shim"}
 
@@ -594,6 +594,11 @@ def run_workload(name, args, ctx, steps, warmup, frames=None, with_cpu=False, op
                        "traffic_source": f"profiles/pmc_traffic.json ({pt['source']}), kernels k_cells_*"})
         except Exception:
             pass
+        try:
+            ov, off = ev.cell_build_stats()
+            cb.update({"launches_per_step": kernel_launches.get("cells_build", 0) / steps, "bucket_overflows_since_creation": ov, "selections_off_buckets": off})
+        except Exception:
+            pass
         out["cell_build"] = cb
     if share:
         out["ranks"], out["shared_gpu"] = world, True
@@ -742,6 +747,7 @@ def main():
             sec[nm] = {"workload": r["config"]["workload"], "value": r["value"], "unit": "frames/s", "steps": r["steps"], "warmup": r["warmup"],
                        "ms_per_step": r["ms_per_step"], "frames_per_step": r["config"]["frames_per_step"],
                        "pairs_per_s": r["pairs_per_s"], "voxel_hits_per_s": r["voxel_hits_per_s"], "kernel_ms": r["kernel_ms"],
+                       "kernel_launches_per_step": r.get("kernel_launches_per_step"), "cell_build": r.get("cell_build"),
                        "roofline": {"bound": "hbm", "kernel": rf["kernel"], "avg_launch_ms": rf["avg_launch_ms"], "launches": rf["launches"], "dispatches": rf["dispatches"],
                                     "achieved": rf["achieved"], "peak": rf["peak"], "unit": rf["unit"], "frac": rf["frac"],
                                     "frames_per_launch": rf["frames_per_launch"], "traffic": rf["traffic"],

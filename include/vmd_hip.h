@@ -170,6 +170,9 @@ int vmd_hip_set_sdf_nt(int on);
 uint64_t vmd_hip_rdf_columns(int reset);
 /* counts[0] += value on the device (closed-interval RDF: the self pairs a half-shell pass never visits) */
 int vmd_hip_bump_u64(void* stream, uint64_t* p, uint64_t value);
+/* the selection the NEXT vmd_hip_cells_* calls of this host thread sort is periodic: atom(t) = first + (t / m) * period + off[t % m], 1 <= m <= 4
+ * (the O of every water: m = 1, period 3) - the kernels compute it instead of reading sel[t].  m = 0: read the list (the default). */
+void vmd_hip_set_cells_sel_pattern(int m, int first, int period, const int* off);
 /* an empty kernel named k_marker_timed_region: a profiled command marks where its timed region begins (bench.py, scripts/pmc_traffic.py) */
 int vmd_hip_marker(void* stream);
 /* DECISION(D-RDF-OPEN) as a switch: 1 = hit iff r_min <= d <= r_max in the pair kernels launched from now on; returns the old value */

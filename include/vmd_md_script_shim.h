@@ -287,7 +287,7 @@ inline vmd_system_t wrap_system(const md_system_t* sys) {
  * from bench.py's `secondary.c1`; 0 sends everything that is bound to the GPU.  Without an evaluator behind the shim
  * (VMD_SHIM_NO_FALLBACK) there is nobody to leave it with: the threshold is ignored. */
 #ifndef VMD_SHIM_MIN_WORK_DEFAULT
-#define VMD_SHIM_MIN_WORK_DEFAULT 4000000ull
+#define VMD_SHIM_MIN_WORK_DEFAULT 1000000ull
 #endif
 namespace vmd_shim { inline std::atomic<uint64_t>& min_work() { static std::atomic<uint64_t> v{VMD_SHIM_MIN_WORK_DEFAULT}; return v; } }
 inline void vmd_shim_set_min_work(uint64_t pairs_times_frames) { vmd_shim::min_work().store(pairs_times_frames, std::memory_order_relaxed); }

@@ -11,8 +11,19 @@ OUT=${1:-/tmp/viamd_tsan}; mkdir -p $OUT
 LIB=$(VIAMD_EMU_SANITIZE=thread python -c "import sys; sys.path.insert(0, 'tests'); import conftest; print(conftest.build_emu())" 2>/dev/null | tail -1)
 export TSAN_OPTIONS="halt_on_error=0:report_signal_unsafe=0:history_size=4"
 build() {   # src exe [extra include]
-  g++ -std=c++17 -O1 -g -fsanitize=thread "$1" -I$R/include ${3:+-I$3} $LIB -Wl,-rpath,$(dirname $LIB) -lpthread -o "$2"
+  g++ -std=c++20 -O1 -g -fsanitize=thread -Wno-format "$1" -I$R/include -I$R/oracle ${3:+-I$3} $LIB -Wl,-rpath,$(dirname $LIB) -lpthread -o "$2"
 }
+# VIAMD's own call sites (verbatim slices of /root/reference/src, tests/native/ref_callsites.cpp): the reference's main-loop block polls and
+# re-creates evals while its pool tasks run inside md_script_eval_frame_range - the shim's epoch / record refresh / settle callback under TSan
+python - <<PY
+import subprocess, sys
+sys.path.insert(0, "$R")
+from oracle import make_ref
+if make_ref.available():
+    make_ref.write_callsite_slices()
+    for exe, extra in (("$OUT/ref_callsites", []), ("$OUT/ref_callsites_deferred", ["-DVMD_SHIM_DEFERRED_SETTLE"])):
+        subprocess.check_call(make_ref.callsites_compile_cmd(exe, ["-g", "-fsanitize=thread"] + extra + ["$LIB", "-Wl,-rpath,$(dirname $LIB)"], opt="-O1"))
+PY
 build tests/native/stress_readahead.cpp $OUT/stress_ra
 build tests/native/stress_eval.cpp $OUT/stress_eval
 build tests/native/shim_callsites.cpp $OUT/shim_callsites $R/tests/native
@@ -34,6 +45,8 @@ run reduce_threads $OUT/reduce_threads 3 12 600
 run concurrent_evals $OUT/concurrent_evals 2 10 600 $OUT
 run shim_callsites $OUT/shim_callsites 12
 run shim_default_script $OUT/shim_default_script 12
+[ -x $OUT/ref_callsites ] && run ref_callsites $OUT/ref_callsites 12 $OUT
+[ -x $OUT/ref_callsites_deferred ] && run ref_callsites_deferred $OUT/ref_callsites_deferred 12 $OUT
 run stress_eval $OUT/stress_eval 2 6
 run exp_threads_rdf $OUT/exp_threads ${TSAN_EXP_ARGS:-900 64}
 run stress_ra_sdf $OUT/stress_ra 3 16 600 9 sdf

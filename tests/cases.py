@@ -145,6 +145,26 @@ def cell_build_cases(lib, O, coords, box, device=False):
             lib.vmd_set_option(b"cells_small", old_small)
             lib.vmd_set_option(b"cells_pencil", old[0]); lib.vmd_set_option(b"cells_fused", old[1]); lib.vmd_set_option(b"cells_split", old[2])
             lib.vmd_set_option(b"cells_rec3", old[3]); lib.vmd_set_option(b"cells_bin_lds", old_lds)
+    # round 6: a periodic index list is computed by the build kernels, not read (cells_sel_pattern): the O of every water (m = 1, period 3),
+    # the two H (m = 2), every atom (period 1), a periodic list that starts late, one that is NOT periodic, one that is periodic but for its
+    # last entry - with the switch on and off, through the bucket build and the single-level ones
+    rng = np.random.default_rng(11)
+    ragged = np.sort(rng.choice(n, n // 3, replace=False)).astype(np.int32)
+    late = o[37:]
+    almost = np.concatenate([o[:-1], [o[-1] + 1]]).astype(np.int32)
+    every = np.arange(n, dtype=np.int32)
+    old_small = lib.vmd_set_option(b"cells_small", 0)
+    try:
+        for pattern in (1, 0):
+            for pencil in (1, 0):
+                old = (lib.vmd_set_option(b"cells_sel_pattern", pattern), lib.vmd_set_option(b"cells_pencil", pencil))
+                try:
+                    check_rdf(lib, O, coords[:2], box, [("a", every, o, 0.0, 7.0), ("b", late, h, 0.0, 9.0), ("c", ragged, ragged, 0.0, 8.0),
+                                                        ("d", almost, almost, 0.0, 8.0)], device=device)
+                finally:
+                    lib.vmd_set_option(b"cells_sel_pattern", old[0]); lib.vmd_set_option(b"cells_pencil", old[1])
+    finally:
+        lib.vmd_set_option(b"cells_small", old_small)
 
 
 def cell_build_overflow_case(lib, O, device=False, n=3000, box=60.0):

@@ -313,6 +313,7 @@ SIGNATURES = [
     ("vmd_hip_bump_u64", C.c_int, [_vp, _vp, C.c_uint64]),
     ("vmd_hip_rdf_columns", C.c_uint64, [C.c_int]),
     ("vmd_hip_marker", C.c_int, [C.c_void_p]),
+    ("vmd_hip_set_cells_sel_pattern", None, [C.c_int, C.c_int, C.c_int, c_int32_p]),
     ("vmd_hip_set_sdf_nt", C.c_int, [C.c_int]),
     ("vmd_hip_set_rdf_closed", C.c_int, [C.c_int]),
     ("vmd_hip_set_rdf_raw", C.c_int, [C.c_int]),

@@ -35,8 +35,7 @@ bool ensure_pencil_caps(vmd_script_eval_t* e, Selection* s, const Stage& src, co
     if (!exhaustive) {
         const size_t tail = nb - S;
         KRN_OK(vmd_hip_cells_pencil_count(e->stream, src.base + tail * src.frame_stride, src.frame_stride, src.row_stride, d_boxes + 9
-                * tail, pbc, (int)S,
-                                          s->d_idx.p, nsel, g, e->d_pen_sample.p + S * (size_t)npen));
+                * tail, pbc, (int)S, s->d_idx.p, nsel, g, e->d_pen_sample.p + S * (size_t)npen));
     }
     HIP_OK(hipMemcpyAsync(h.data(), e->d_pen_sample.p, h.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
     HIP_OK(hipStreamSynchronize(e->stream));
@@ -59,9 +58,19 @@ bool ensure_pencil_caps(vmd_script_eval_t* e, Selection* s, const Stage& src, co
     return s->d_pen_off.upload(s->pen_off.data(), s->pen_off.size(), e->stream);
 }
 
+// the kernels of this selection's builds compute a periodic index list instead of reading it: set for the calls below, cleared on every way
+// out
+struct SelPatternScope {
+    explicit SelPatternScope(const Selection* s) {
+        if (s->pat_m) vmd_hip_set_cells_sel_pattern(s->pat_m, s->pat_first, s->pat_period, s->pat_off);
+    }
+    ~SelPatternScope() { vmd_hip_set_cells_sel_pattern(0, 0, 0, nullptr); }
+};
+
 bool build_selection(vmd_script_eval_t* e, Selection* s, const Stage& src, const float* d_boxes, uint32_t pbc, size_t nb,
         const vmd_grid_t& g) {
     if (s->built && s->built_grid.nxf == g.nxf && s->built_grid.ny == g.ny && s->built_grid.nz == g.nz) return true;
+    const SelPatternScope pattern(s);
     const int nsel = (int)s->idx.size();
     s->nsel_pad = (nsel + 63) & ~63;
     // +64: the pair kernel prefetches past a segment
@@ -81,10 +90,8 @@ bool build_selection(vmd_script_eval_t* e, Selection* s, const Stage& src, const
             e->prof.begin("cells_build", e->stream);
             vmd_hip_set_cells_overflow_bit(s->overflow_bit);
             KRN_OK(vmd_hip_cells_build_pencil(e->stream, src.base, src.frame_stride, src.row_stride, d_boxes, pbc, (int)nb, s->d_idx.p,
-                    nsel, s->nsel_pad, g,
-                                              s->d_pen_off.p, s->total_cap, s->cap_max, s->pen_count.p, s->pen_start.p, s->bucket.p,
-                                                      e->d_overflow.p,
-                                              s->cell_start.p, s->sorted.p));
+                    nsel, s->nsel_pad, g, s->d_pen_off.p, s->total_cap, s->cap_max, s->pen_count.p, s->pen_start.p, s->bucket.p,
+                    e->d_overflow.p, s->cell_start.p, s->sorted.p));
             e->prof.end(e->stream);
             s->built = true; s->built_grid = g; s->used_pencil = true;
             return true;
@@ -239,9 +246,8 @@ bool process_range_locked(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
         BatchSrc src;
         if (!fetch_batch(e, traj, view_holds(have_view, view, 0) ? &view : nullptr, num_atoms, 0, 1, &src)) return false;
         KRN_OK(vmd_hip_sdf_ref_pose(e->stream, src.base, src.row_stride, e->stages[0].d_boxes.p, batch_pbc(e->stages[0]), p->d_structs.p,
-                p->d_mass.p,
-                                    (int)p->prop.m, p->d_ref_pose.p, p->have_tree ? p->d_tree_order.p : nullptr, p->have_tree
-                                            ? p->d_tree_parent.p : nullptr));
+                p->d_mass.p, (int)p->prop.m, p->d_ref_pose.p, p->have_tree ? p->d_tree_order.p : nullptr, p->have_tree
+                ? p->d_tree_parent.p : nullptr));
         HIP_OK(hipStreamSynchronize(e->stream));
         p->ref_pose_ready = true;
     }
@@ -251,7 +257,15 @@ bool process_range_locked(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
     // a region's blocks are adopted from the source by the region leader, or evaluated here
     if (spec) segments.push_back({frame_beg, frame_end});
     else if (!reuse_blocks(e, traj_id(traj), frame_beg, frame_end, &segments)) return false;
-    if (e->block_frames) e->blocks_inst = traj_id(traj);
+    if (e->block_frames) {
+        // a source evaluated over trajectory A and then, WITHOUT clear_data, over another trajectory of the same length must
+        // not
+        // hand A's block partials to users that evaluate B - the blocks kept from now on belong to B, the ones kept so far are forgotten
+        const TrajId now = traj_id(traj);
+        if (e->blocks_inst.inst && e->blocks_inst != now)
+            for (size_t b = 0; b < e->num_blocks; ++b) e->block_ready[b] = 0;
+        e->blocks_inst = now;
+    }
 
     // compressed frames for the device decoder travel two batches ahead through a ring of three slots (RawSlot)
     vmd_host_view_t hv_probe;
@@ -445,9 +459,8 @@ bool process_range_locked(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
                         uint64_t* dst = e->d_pass.p + (row++) * VMD_RDF_NUM_BINS;
                         e->prof.begin("rdf_brute", e->stream);
                         KRN_OK(vmd_hip_rdf_brute(e->stream, c.src->base + su.off * c.src->frame_stride, c.src->frame_stride,
-                                c.src->row_stride, c.src->d_boxes.p + 9 * su.off, c.pbc, (int)su.nb,
-                                                 sa->d_idx.p, (int)sa->idx.size(), sb->d_idx.p, (int)sb->idx.size(),
-                                                 g.rmin, g.rmax, VMD_RDF_NUM_BINS, dst));
+                                c.src->row_stride, c.src->d_boxes.p + 9 * su.off, c.pbc, (int)su.nb, sa->d_idx.p, (int)sa->idx.size(),
+                                sb->d_idx.p, (int)sb->idx.size(), g.rmin, g.rmax, VMD_RDF_NUM_BINS, dst));
                         e->prof.end(e->stream);
                         commits.push_back({acc_of(p, su), dst, 1});
                     }
@@ -482,12 +495,10 @@ bool process_range_locked(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
                     hipStream_t ks = second ? e->pair_stream : e->stream;
                     if (!second) e->prof.begin("rdf_pencil", ks);
                     KRN_OK(vmd_hip_rdf_pencil(ks, sa->sorted.p + su.off * 3 * (size_t)sa->nsel_pad, sa->cell_start.p + su.off
-                            * (size_t)(grid.ncell + 1), (int)sa->idx.size(), sa->nsel_pad,
-                                              sb->sorted.p + su.off * 3 * (size_t)sb->nsel_pad, sb->cell_start.p + su.off
-                                                      * (size_t)(grid.ncell + 1), (int)sb->idx.size(), sb->nsel_pad,
-                                              d_gb + 9 * su.off, (int)su.nb, grid, g.rmin, g.rmax, VMD_RDF_NUM_BINS,
-                                              ps.same ? 1 : 0, g_opt.rdf_variant, c.pbc, second ? e->d_partial2.p : e->d_partial.p, dst,
-                                                      e->d_overflow.p));
+                            * (size_t)(grid.ncell + 1), (int)sa->idx.size(), sa->nsel_pad, sb->sorted.p + su.off * 3
+                            * (size_t)sb->nsel_pad, sb->cell_start.p + su.off * (size_t)(grid.ncell + 1), (int)sb->idx.size(),
+                            sb->nsel_pad, d_gb + 9 * su.off, (int)su.nb, grid, g.rmin, g.rmax, VMD_RDF_NUM_BINS, ps.same ? 1 : 0,
+                            g_opt.rdf_variant, c.pbc, second ? e->d_partial2.p : e->d_partial.p, dst, e->d_overflow.p));
                     if (!second) e->prof.end(ks);
                     if (e->spec.rdf_closed && ps.same && g.rmin <= 0.0f && 0.0f <= g.rmax) {
                         // closed interval: d = 0 is a hit, but a same-set pass walks the half shell (j > i, every hit twice) and never
@@ -651,33 +662,26 @@ bool process_range_locked(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
                 VMD_STAGE("batch: sdf align + scatter");
                 e->prof.begin("sdf_align", e->stream);
                 if (p->have_tree && !p->d_tree_pos.ensure(c.nb * d.K * d.m * 3)) return false;
-                KRN_OK(vmd_hip_sdf_align(e->stream, c.src->base, c.src->frame_stride, c.src->row_stride, c.src->d_boxes.p, c.pbc, (int)c.nb,
-                                         p->d_structs.p, p->d_mass.p, (int)d.K, (int)d.m, p->d_ref_pose.p, p->d_R32.p, p->d_c32.p, nullptr,
-                                                 p->d_group.p,
-                                         p->have_tree ? p->d_tree_order.p : nullptr, p->have_tree ? p->d_tree_parent.p : nullptr,
-                                                 p->have_tree ? p->d_tree_pos.p : nullptr));
+                KRN_OK(vmd_hip_sdf_align(e->stream, c.src->base, c.src->frame_stride, c.src->row_stride, c.src->d_boxes.p, c.pbc,
+                        (int)c.nb, p->d_structs.p, p->d_mass.p, (int)d.K, (int)d.m, p->d_ref_pose.p, p->d_R32.p, p->d_c32.p, nullptr,
+                        p->d_group.p, p->have_tree ? p->d_tree_order.p : nullptr, p->have_tree ? p->d_tree_parent.p : nullptr, p->have_tree
+                        ? p->d_tree_pos.p : nullptr));
                 e->prof.end(e->stream);
                 e->prof.begin("sdf_scatter", e->stream);
-                for (auto& su : c.subs)
-                    KRN_OK(vmd_hip_sdf_scatter(e->stream, c.src->base + su.off * c.src->frame_stride, c.src->frame_stride,
-                            c.src->row_stride, c.src->d_boxes.p + 9 * su.off, c.pbc, (int)su.nb,
-                                               p->d_structs.p, (int)d.K, (int)d.m, p->d_R32.p + su.off * d.K * 9, p->d_c32.p + su.off * d.K
-                                                       * 3, p->d_tgt.p,
-                                               (p->have_owner && !e->spec.sdf_include_self) ? p->d_owner.p : nullptr, (int)d.b.size(),
-                                               d.rmax, VMD_VOLUME_DIM, acc_of(p.get(), su), p->d_group.p + 4 * su.off,
-                                               (p->have_tag && p->tag_len == c.src->row_stride && !e->spec.sdf_include_self)
-                                                       ? p->d_tag.p : nullptr,
-                                               p->tgt_first, p->tgt_stride, (p->unowned || e->spec.sdf_include_self) ? 1 : 0));
+                for (auto& su : c.subs) KRN_OK(vmd_hip_sdf_scatter(e->stream, c.src->base + su.off * c.src->frame_stride,
+                        c.src->frame_stride, c.src->row_stride, c.src->d_boxes.p + 9 * su.off, c.pbc, (int)su.nb, p->d_structs.p, (int)d.K,
+                        (int)d.m, p->d_R32.p + su.off * d.K * 9, p->d_c32.p + su.off * d.K * 3, p->d_tgt.p, (p->have_owner
+                        && !e->spec.sdf_include_self) ? p->d_owner.p : nullptr, (int)d.b.size(), d.rmax, VMD_VOLUME_DIM, acc_of(p.get(),
+                        su), p->d_group.p + 4 * su.off, (p->have_tag && p->tag_len == c.src->row_stride && !e->spec.sdf_include_self)
+                        ? p->d_tag.p : nullptr, p->tgt_first, p->tgt_stride, (p->unowned || e->spec.sdf_include_self) ? 1 : 0));
                 e->prof.end(e->stream);
                 p->dirty = p->dirty || !spec;
             } else {
                 if (!p->d_out.ensure(c.nb * p->dim1)) return false;
                 e->prof.begin("distance", e->stream);
                 KRN_OK(vmd_hip_distance(e->stream, c.src->base, c.src->frame_stride, c.src->row_stride, c.src->d_boxes.p, c.pbc, (int)c.nb,
-                        d.dist_kind,
-                                        (int)p->dist_P, (int)p->dist_per, p->d_a.p, p->d_ma.p, p->d_aoff.p, p->d_b.p, p->d_mb.p,
-                                                p->d_boff.p,
-                                        p->d_out.p));
+                        d.dist_kind, (int)p->dist_P, (int)p->dist_per, p->d_a.p, p->d_ma.p, p->d_aoff.p, p->d_b.p, p->d_mb.p, p->d_boff.p,
+                        p->d_out.p));
                 e->prof.end(e->stream);
                 HIP_OK(hipMemcpyAsync(e->h_temporal_slot[c.slot].data() + toff, p->d_out.p, c.nb * p->dim1 * sizeof(float),
                         hipMemcpyDeviceToHost, e->stream));

@@ -544,8 +544,7 @@ extern "C" bool vmd_eval_frame_range(vmd_script_eval_t* eval, const vmd_script_i
 // bench.py times VIAMD's pattern with (native threads: a Python thread per call costs more than a small call does), and what a host
 // without a task system of its own can use as is.  Returns false if any call failed or was interrupted.
 extern "C" bool vmd_eval_frame_range_pooled(vmd_script_eval_t* eval, const vmd_script_ir_t* ir, const vmd_system_t* sys,
-        vmd_trajectory_i* traj,
-                                            uint32_t frame_beg, uint32_t frame_end, int num_threads, uint32_t grain) {
+        vmd_trajectory_i* traj, uint32_t frame_beg, uint32_t frame_end, int num_threads, uint32_t grain) {
     if (!eval || !traj) return vmd_fail("vmd_eval_frame_range_pooled: NULL argument");
     if (num_threads < 1) num_threads = 1;
     if (grain < 1) grain = 1;

@@ -37,6 +37,18 @@ int intern_selection(vmd_script_eval_t* e, const std::vector<int32_t>& idx) {
     for (size_t i = 0; i < e->sels.size(); ++i) if (e->sels[i]->idx == idx) return (int)i;
     auto s = std::make_unique<Selection>();
     s->idx = idx;
+    // periodic? the smallest m <= 4 with idx[t + m] - idx[t] the same for every t ("every third atom", "the two H of every water")
+    if (g_opt.cells_sel_pattern.load() && idx.size() >= 8) {
+        for (int m = 1; m <= 4 && !s->pat_m; ++m) {
+            const int64_t period = (int64_t)idx[(size_t)m] - (int64_t)idx[0];
+            if (period <= 0 || period > (1 << 20)) continue;
+            bool ok = true;
+            for (size_t t = 0; t + (size_t)m < idx.size() && ok; ++t) ok = (int64_t)idx[t + (size_t)m] - (int64_t)idx[t] == period;
+            if (!ok) continue;
+            s->pat_m = m; s->pat_first = idx[0]; s->pat_period = (int)period;
+            for (int k = 0; k < m; ++k) s->pat_off[k] = idx[(size_t)k] - idx[0];
+        }
+    }
     s->overflow_bit = 1u << (e->sels.size() % 32);
     e->sels.push_back(std::move(s));
     return (int)e->sels.size() - 1;
@@ -741,9 +753,8 @@ extern "C" bool vmd_eval_sdf_matrices(vmd_script_eval_t* eval, const char* name,
     if (!p->ref_pose_ready) {
         if (!fetch_batch(e, traj, view_holds(have_view, view, 0) ? &view : nullptr, num_atoms, 0, 1, &src)) return false;
         KRN_OK(vmd_hip_sdf_ref_pose(e->stream, src.base, src.row_stride, e->stages[0].d_boxes.p, batch_pbc(e->stages[0]), p->d_structs.p,
-                p->d_mass.p,
-                                    (int)p->prop.m, p->d_ref_pose.p, p->have_tree ? p->d_tree_order.p : nullptr, p->have_tree
-                                            ? p->d_tree_parent.p : nullptr));
+                p->d_mass.p, (int)p->prop.m, p->d_ref_pose.p, p->have_tree ? p->d_tree_order.p : nullptr, p->have_tree
+                ? p->d_tree_parent.p : nullptr));
         HIP_OK(hipStreamSynchronize(e->stream));
         p->ref_pose_ready = true;
     }
@@ -753,9 +764,8 @@ extern "C" bool vmd_eval_sdf_matrices(vmd_script_eval_t* eval, const char* name,
     if (!dM.ensure(K * 12) || !p->d_R32.ensure(K * 9) || !p->d_c32.ensure(K * 3)) return false;
     if (p->have_tree && !p->d_tree_pos.ensure(K * p->prop.m * 3)) return false;
     KRN_OK(vmd_hip_sdf_align(e->stream, src.base, src.frame_stride, src.row_stride, e->stages[0].d_boxes.p, batch_pbc(e->stages[0]), 1,
-                             p->d_structs.p, p->d_mass.p, (int)K, (int)p->prop.m, p->d_ref_pose.p, p->d_R32.p, p->d_c32.p, dM.p, nullptr,
-                             p->have_tree ? p->d_tree_order.p : nullptr, p->have_tree ? p->d_tree_parent.p : nullptr, p->have_tree
-                                     ? p->d_tree_pos.p : nullptr));
+            p->d_structs.p, p->d_mass.p, (int)K, (int)p->prop.m, p->d_ref_pose.p, p->d_R32.p, p->d_c32.p, dM.p, nullptr, p->have_tree
+            ? p->d_tree_order.p : nullptr, p->have_tree ? p->d_tree_parent.p : nullptr, p->have_tree ? p->d_tree_pos.p : nullptr));
     std::vector<double> M(K * 12);
     HIP_OK(hipMemcpyAsync(M.data(), dM.p, K * 12 * sizeof(double), hipMemcpyDeviceToHost, e->stream));
     HIP_OK(hipStreamSynchronize(e->stream));

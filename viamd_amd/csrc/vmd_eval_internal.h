@@ -163,6 +163,8 @@ struct Options {
     // vmd_eval_wait_settled / finalize / reduce / the exporters wait for them), and system + trajectory must stay valid until then.
     std::atomic<int> readahead_lone{0};
     std::atomic<int> readahead_lone_settle_us{300};
+    // the cell build computes the atom index of a periodic selection instead of reading its index list (round 6; A/B switch, read at creation)
+    std::atomic<int> cells_sel_pattern{1};
 };
 
 extern Options g_opt;
@@ -373,6 +375,9 @@ bool idx_ok(const int32_t* idx, size_t n, const char* what);
 struct Selection {
     std::vector<int32_t> idx;
     DevBuf<int32_t> d_idx;
+    // the periodic form of idx - atom(t) = first + (t / m) * period + off[t % m] - found once at creation (intern_selection); m = 0: none.
+    // The cell-build kernels then compute the index instead of reading the list (vmd_hip_set_cells_sel_pattern)
+    int pat_m = 0, pat_first = 0, pat_period = 0, pat_off[4] = {0, 0, 0, 0};
     DevBuf<uint32_t> cell_count, rank, cell_start;
     DevBuf<float> sorted, aos;
     int nsel_pad = 0;

@@ -298,11 +298,10 @@ bool fetch_stage(vmd_script_eval_t* e, Stage& st, vmd_trajectory_i* traj, const 
                 && rv.device == e->device) {
             // the compressed trajectory is resident in HBM: no host work, no PCIe - decode the batch where it lies
             for (size_t b = 0; b < nb; ++b) st.cells[b] = rv.cells[f0 + b];
-            raw = launch_raw_decode(e, st, rv.base, (const vmd_xtc_frame_t*)rv.info + f0, num_atoms, nb, npad, ss,
-                                    rv.ck ? (vmd_xtc_ck_t*)rv.ck + f0 * VMD_XTC_CK_MAX : nullptr, rv.nck ? rv.nck + f0 : nullptr,
-                                            rv.ck_have ? rv.ck_have + f0 : nullptr,
-                                    (rv.rec && rv.rec_stride) ? rv.rec + f0 * rv.rec_stride : nullptr, (rv.rec && rv.rec_stride) ? rv.nrec
-                                            + f0 : nullptr, rv.rec_stride, rv.rec_failed);
+            raw = launch_raw_decode(e, st, rv.base, (const vmd_xtc_frame_t*)rv.info + f0, num_atoms, nb, npad, ss, rv.ck
+                    ? (vmd_xtc_ck_t*)rv.ck + f0 * VMD_XTC_CK_MAX : nullptr, rv.nck ? rv.nck + f0 : nullptr, rv.ck_have ? rv.ck_have
+                    + f0 : nullptr, (rv.rec && rv.rec_stride) ? rv.rec + f0 * rv.rec_stride : nullptr, (rv.rec && rv.rec_stride) ? rv.nrec
+                    + f0 : nullptr, rv.rec_stride, rv.rec_failed);
             if (raw < 0) return false;
         } else if (!force_host && g_opt.xtc_device_decode.load() && traj->load_raw && !(e->raw_skip && !pre)) {
             // the bit streams were (or are now) sent ahead through a slot of the ring; decompression runs on its own stream
@@ -331,9 +330,8 @@ bool fetch_stage(vmd_script_eval_t* e, Stage& st, vmd_trajectory_i* traj, const 
                         if (flag_get(&cc->sig[f0 + b]) != sg) { flag_set(&cc->sig[f0 + b], sg); flag_set(&cc->have[f0 + b], (uint8_t)0); }
                     }
                     raw = launch_raw_decode(e, st, rs->d_streams(), rs->d_info(), num_atoms, nb, npad, ss, cc->ck.p + f0 * VMD_XTC_CK_MAX,
-                            cc->nck.p + f0, cc->have.data() + f0,
-                                            cc->rec_stride ? cc->rec.p + f0 * cc->rec_stride : nullptr, cc->rec_stride ? cc->nrec.p
-                                                    + f0 : nullptr, cc->rec_stride, &cc->rec_failed);
+                            cc->nck.p + f0, cc->have.data() + f0, cc->rec_stride ? cc->rec.p + f0 * cc->rec_stride : nullptr,
+                            cc->rec_stride ? cc->nrec.p + f0 : nullptr, cc->rec_stride, &cc->rec_failed);
                 } else {
                     raw = launch_raw_decode(e, st, rs->d_streams(), rs->d_info(), num_atoms, nb, npad, ss);
                 }
