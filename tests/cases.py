@@ -169,11 +169,13 @@ def cell_build_cases(lib, O, coords, box, device=False):
 
 def cell_build_overflow_case(lib, O, device=False, n=3000, box=60.0):
     """(small selections are normally sorted by one block per frame, without buckets: the case asks for buckets - cells_small = 0)"""
-    old = lib.vmd_set_option(b"cells_small", 0)
+    # cells_cap_sample = 2: capacities from the batch's beginning and end only - the middle frames of these cases are what overflows (the
+    # default also looks at the middle of a batch, round 6)
+    old = lib.vmd_set_option(b"cells_small", 0), lib.vmd_set_option(b"cells_cap_sample", 2)
     try:
         _cell_build_overflow_case(lib, O, device, n, box)
     finally:
-        lib.vmd_set_option(b"cells_small", old)
+        lib.vmd_set_option(b"cells_small", old[0]); lib.vmd_set_option(b"cells_cap_sample", old[1])
 
 
 def _cell_build_overflow_case(lib, O, device=False, n=3000, box=60.0):
@@ -262,11 +264,11 @@ def wandering_solute_case(lib, O, device=False, n=3000, box=60.0, F=12, batch=3)
 
 
 def blocks_overflow_case(lib, O, device=False, n=3000, box=60.0):
-    old = lib.vmd_set_option(b"cells_small", 0)
+    old = lib.vmd_set_option(b"cells_small", 0), lib.vmd_set_option(b"cells_cap_sample", 2)
     try:
         _blocks_overflow_case(lib, O, device, n, box)
     finally:
-        lib.vmd_set_option(b"cells_small", old)
+        lib.vmd_set_option(b"cells_small", old[0]); lib.vmd_set_option(b"cells_cap_sample", old[1])
 
 
 def _blocks_overflow_case(lib, O, device=False, n=3000, box=60.0):

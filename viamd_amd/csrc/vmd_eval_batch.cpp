@@ -25,18 +25,18 @@ bool ensure_pencil_caps(vmd_script_eval_t* e, Selection* s, const Stage& src, co
         return s->d_pen_off.upload(s->pen_off.data(), s->pen_off.size(), e->stream);
     }
     const int npen = g.ny * g.nz, nsel = (int)s->idx.size();
-    // after an overflow: every frame of the batch (exact populations), otherwise the first and last 4
+    // after an overflow: every frame of the batch (exact populations), otherwise 4 frames each from its beginning, middle and end (round 6:
+    // the middle was not looked at, and a solute that wanders through the batch - config 5 - overflowed the solvent's buckets there)
+    // (cells_cap_sample = 2: beginning and end only, as before - the overflow tests ask for it)
     const bool exhaustive = s->overflows > 0 || nb <= 8;
-    const size_t S = exhaustive ? nb : 4, rows = exhaustive ? nb : 8;
+    const size_t nsamp = exhaustive ? 1 : (g_opt.cells_cap_sample.load() >= 3 ? 3 : 2);
+    const size_t S = exhaustive ? nb : 4, rows = exhaustive ? nb : 4 * nsamp;
     if (!e->d_pen_sample.ensure(rows * (size_t)npen)) return false;
     std::vector<uint32_t> h(rows * (size_t)npen);
-    KRN_OK(vmd_hip_cells_pencil_count(e->stream, src.base, src.frame_stride, src.row_stride, d_boxes, pbc, (int)S, s->d_idx.p, nsel, g,
-            e->d_pen_sample.p));
-    if (!exhaustive) {
-        const size_t tail = nb - S;
-        KRN_OK(vmd_hip_cells_pencil_count(e->stream, src.base + tail * src.frame_stride, src.frame_stride, src.row_stride, d_boxes + 9
-                * tail, pbc, (int)S, s->d_idx.p, nsel, g, e->d_pen_sample.p + S * (size_t)npen));
-    }
+    const size_t starts[3] = {0, nsamp == 3 ? (nb - S) / 2 : nb - S, nb - S};
+    for (size_t k = 0; k < nsamp; ++k)
+        KRN_OK(vmd_hip_cells_pencil_count(e->stream, src.base + starts[k] * src.frame_stride, src.frame_stride, src.row_stride,
+                d_boxes + 9 * starts[k], pbc, (int)S, s->d_idx.p, nsel, g, e->d_pen_sample.p + k * S * (size_t)npen));
     HIP_OK(hipMemcpyAsync(h.data(), e->d_pen_sample.p, h.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
     HIP_OK(hipStreamSynchronize(e->stream));
     s->pen_off.assign((size_t)npen + 1, 0);
@@ -550,7 +550,14 @@ bool process_range_locked(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
                 // sorted through buckets on one group's grid and by the single-block build on another's within ONE batch - co-evaluated
                 // RDFs
                 // with different cutoffs - and used_pencil only remembers the last of them; fuzz seed 8941, round 4.)
-                if (!own || !(who & sl->overflow_bit)) continue;
+                if (!own) continue;
+                if (!(who & sl->overflow_bit)) {
+                    // round 6: the others are re-measured with more head room too, without a strike against them - what crowded one
+                    // selection's
+                    // pencils (a solute pushing solvent around) crowds the next one's a batch later, and every overflow repeats a batch
+                    if (sl->used_pencil && sl->cap_margin < 2.0f) { sl->pen_off.clear(); sl->caps_cache.clear(); sl->cap_margin = 2.0f; }
+                    continue;
+                }
                 sl->pen_off.clear();
                 sl->caps_cache.clear();
                 sl->cap_margin *= 1.6f;

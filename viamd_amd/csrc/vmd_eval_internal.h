@@ -165,6 +165,9 @@ struct Options {
     std::atomic<int> readahead_lone_settle_us{300};
     // the cell build computes the atom index of a periodic selection instead of reading its index list (round 6; A/B switch, read at creation)
     std::atomic<int> cells_sel_pattern{1};
+    // bucket capacities of the two-level cell build are measured on 4 frames each from the beginning, middle and end of a batch (3, round 6)
+    // or from its beginning and end only (2)
+    std::atomic<int> cells_cap_sample{3};
 };
 
 extern Options g_opt;
