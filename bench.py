@@ -579,13 +579,21 @@ def run_workload(name, args, ctx, steps, warmup, frames=None, with_cpu=False, op
         cb = {"ms_per_step": kernel_ms["cells_build"] / steps, "frac_of_step": kernel_ms["cells_build"] / (elapsed * 1e3)}
         try:
             pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))[name]
-            per_frame = sum(k["hbm_bytes_per_launch_read_x2"] for kn, k in pt["kernels"].items() if kn.startswith("k_cells")) / pt["frames_per_launch"]
-            sel = {}
-            for d in info.values():
-                if d["kind"] == "rdf":
+            # every dispatch of every k_cells_* kernel in one step of the profiled run (a co-evaluated script sorts several selections per batch)
+            per_frame = sum(k.get("hbm_bytes_per_step_read_x2") or k["hbm_bytes_per_launch_read_x2"] for kn, k in pt["kernels"].items()
+                            if kn.startswith("k_cells")) / (pt.get("frames_per_step") or pt["frames_per_launch"])
+            # sorted rows written once per frame: co-evaluated RDFs are split into DISJOINT atom classes, each sorted once, so the
+            # selected atoms are the union of the sets; a lone RDF over two different sets sorts both
+            rdfs = [d for d in info.values() if d["kind"] == "rdf"]
+            if len(rdfs) > 1:
+                nsel = len(np.unique(np.concatenate([np.asarray(a) for d in rdfs for a in (d["ref"], d["target"])])))
+            else:
+                sel = {}
+                for d in rdfs:
                     for arr in (d["ref"], d["target"]):
                         sel[(len(arr), int(arr[0]), int(arr[-1]))] = len(arr)
-            alg = 12.0 * w["atoms"] + 12.0 * sum(sel.values())
+                nsel = sum(sel.values())
+            alg = 12.0 * w["atoms"] + 12.0 * nsel
             # the build's floor is 1.5 x (the records between its two levels are written once and read once: DESIGN 3.0); what the traffic above
             # that floor costs the step, at the rate the build moves its bytes
             floor = 1.5 * alg
