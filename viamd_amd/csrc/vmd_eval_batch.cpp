@@ -42,10 +42,16 @@ bool ensure_pencil_caps(vmd_script_eval_t* e, Selection* s, const Stage& src, co
     s->pen_off.assign((size_t)npen + 1, 0);
     s->cap_max = 0;
     uint64_t total = 0;
+    const double mean_pop = g_opt.cells_cap_floor.load() ? (double)nsel / (double)npen : 0.0;
     for (int p = 0; p < npen; ++p) {
         uint32_t m = 0;
         for (size_t k = 0; k < rows; ++k) m = std::max(m, h[k * npen + p]);
         uint32_t cap = (uint32_t)std::ceil((double)m * s->cap_margin + 6.0 * std::sqrt((double)m)) + 16;
+        // ... but never below what a pencil holds at the selection's MEAN density (round 6).  A solute that sits in a pencil for the whole
+        // of
+        // the batch the capacities were measured on (config 5's wandering blob) leaves that pencil's bucket too small for the batches in
+        // which it has moved on: two overflows, i.e. two repeated batches, per evaluation of c5.  Costs at most 1.15 x nsel records.
+        cap = std::max(cap, (uint32_t)std::ceil(mean_pop * 1.15 + 6.0 * std::sqrt(mean_pop)) + 16);
         cap = (cap + 3u) & ~3u;
         s->pen_off[p] = (uint32_t)total;
         total += cap;

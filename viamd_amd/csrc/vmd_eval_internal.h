@@ -7,7 +7,7 @@
 // CPU compute path.  Round 6: the one translation unit this used to be (4 300 lines) is eight files by concern -
 //     vmd_eval_runtime.cpp  errors, options, profiling, resource pool        vmd_eval_ir.cpp     property descriptors
 //     vmd_eval_core.cpp     the eval object, host views, accessors           vmd_eval_stage.cpp  static uploads, trajectory staging
-//     vmd_eval_batch.cpp    grids, cell builds, batches, process_range       vmd_eval_calls.cpp  combining queue, read-ahead, deferred settle
+//     vmd_eval_batch.cpp    grids, cell builds, batches, process_range       vmd_eval_calls.cpp  queue, read-ahead, deferred settle
 //     vmd_eval_traj.cpp     trajectory kinds, checkpoint / mapping caches    vmd_eval_post.cpp   histogram post-processing
 // - and this header holds every struct they share, in the order the single file declared them, with each function's prototype where
 // its definition used to stand.  Nothing here is part of the ABI.
@@ -163,11 +163,13 @@ struct Options {
     // vmd_eval_wait_settled / finalize / reduce / the exporters wait for them), and system + trajectory must stay valid until then.
     std::atomic<int> readahead_lone{0};
     std::atomic<int> readahead_lone_settle_us{300};
-    // the cell build computes the atom index of a periodic selection instead of reading its index list (round 6; A/B switch, read at creation)
+    // the cell build computes the atom index of a periodic selection instead of reading its index list (round 6; A/B, read at creation)
     std::atomic<int> cells_sel_pattern{1};
-    // bucket capacities of the two-level cell build are measured on 4 frames each from the beginning, middle and end of a batch (3, round 6)
-    // or from its beginning and end only (2)
+    // bucket capacities of the two-level cell build are measured on 4 frames each from the beginning, middle and end of a batch (3,
+    // round 6) or from its beginning and end only (2)
     std::atomic<int> cells_cap_sample{3};
+    // ... and never below the selection's mean population per pencil x 1.15 (0: measured populations only)
+    std::atomic<int> cells_cap_floor{1};
 };
 
 extern Options g_opt;

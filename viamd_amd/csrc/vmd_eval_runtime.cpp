@@ -111,6 +111,7 @@ extern "C" int vmd_set_option(const char* key, int value) {
     else if (!strcmp(key, "readahead_lone_settle_us")) o = &g_opt.readahead_lone_settle_us;
     else if (!strcmp(key, "cells_sel_pattern")) o = &g_opt.cells_sel_pattern;
     else if (!strcmp(key, "cells_cap_sample")) o = &g_opt.cells_cap_sample;
+    else if (!strcmp(key, "cells_cap_floor")) o = &g_opt.cells_cap_floor;
     else if (!strcmp(key, "sdf_arith")) o = &g_opt.sdf_arith;
     else if (!strcmp(key, "sdf_ilp")) return vmd_hip_set_sdf_ilp(value);
     else if (!strcmp(key, "sdf_rows")) return vmd_hip_set_sdf_rows(value);
