@@ -133,7 +133,7 @@ def test_no_fraction_exceeds_one(default_line):
     rf5 = d["secondary"]["c5"]["roofline"]
     assert rf5["launches"] <= rf5["dispatches"]                      # batches, not dispatches: the passes of one batch share its bytes
     import glob
-    lines = sorted(glob.glob(os.path.join(ROOT, "profiles", "r05*_bench_default.json")))
+    lines = sorted(glob.glob(os.path.join(ROOT, "profiles", "r06z*_bench_default.json")))
     for path in lines[-1:]:
         g = json.load(open(path))
         bad = {k: v for k, v in _fractions(g) if not 0.0 <= v <= 1.0}
@@ -141,3 +141,8 @@ def test_no_fraction_exceeds_one(default_line):
         v = g["roofline"]["valu"]
         assert v["peak"] == 256 * 4 * 2.4e9 / 2.0 and 0.0 < v["busy"] <= 1.0 and "cycles_per_inst_assumed" not in v
         assert g["secondary"]["c5"]["roofline"]["frac"] < 0.01 and g["fractions_within_0_1"] is True
+        # round 6: the CPU column is the median of three samples with its spread; every 8-GPU configuration has its one-GPU bound; c1 is there
+        cb = g["cpu_baseline"]
+        assert len(cb["samples"]) == 3 and sorted(cb["samples"])[1] == cb["value"] and 0.0 <= cb["spread"] < 0.2
+        assert all(g["secondary"][k]["strong_scaling_bound_8_gpus"] > 1.0 for k in ("c3_125", "c5_125", "c4_1250"))
+        assert g["secondary"]["c1"]["gpu_ms"]["pool_threads_16_grain_1"] > 0 and g["roofline"]["traffic_counters_match_kernel_source"] is True

@@ -86,7 +86,11 @@ bool build_selection(vmd_script_eval_t* e, Selection* s, const Stage& src, const
     // A small selection (a solute: the 2 000-atom blob of config 5) is not spread evenly over the pencils and wanders through them as the
     // trajectory goes on: capacities measured on one batch overflow in the next, and every overflow repeats the batch's pair passes.  It is
     // sorted by ONE block per frame in LDS instead (k_cells_fused: no buckets, nothing to overflow), which costs such a selection nothing.
-    const bool small = nsel <= g_opt.cells_small.load() && vmd_hip_cells_fused_ok(g, nsel);
+    // (round 6: whether or not the grid's cell table fits the fused kernel's LDS - c5's 30 000 cells do not, and its 1 200-atom solute
+    // class went
+    // through the buckets after all: one overflow, i.e. one repeated batch, in each of an evaluation's first two passes.  The single-level
+    // builds behind vmd_hip_cells_build pick the fused, the split or the atomic three-kernel variant themselves.)
+    const bool small = nsel <= g_opt.cells_small.load();
     if (vmd_hip_cells_pencil_ok(g) && s->overflows < 3 && !small) {
         if (!ensure_pencil_caps(e, s, src, d_boxes, pbc, nb, g)) return false;
         if (!s->pen_off.empty() && s->cap_max <= vmd_hip_cells_pencil_cap_max()) {
@@ -550,20 +554,28 @@ bool process_range_locked(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
             const bool own = !(c.poisoned && attempt == 0);      // a poisoned batch did not overflow itself (as far as anyone knows)
             // one bit per selection (Selection::overflow_bit; selections beyond 32 share)
             const uint32_t who = e->h_overflow[c.slot];
-            for (auto& sl : e->sels) {
+            for (size_t si = 0; si < e->sels.size(); ++si) {
+                Selection* sl = e->sels[si].get();
                 sl->built = false;
-                // only the selection whose buckets were too small gets wider ones.  (Its bit, not used_pencil, says so: a selection can be
-                // sorted through buckets on one group's grid and by the single-block build on another's within ONE batch - co-evaluated
-                // RDFs
-                // with different cutoffs - and used_pencil only remembers the last of them; fuzz seed 8941, round 4.)
+                // only the selection whose buckets were too small gets wider ones.  (Its bit, not used_pencil, says so: a selection can
+                // be sorted through buckets on one group's grid and by the single-block build on another's within ONE batch - co-evaluated
+                // RDFs with different cutoffs - and used_pencil only remembers the last of them; fuzz seed 8941, round 4.)
                 if (!own) continue;
                 if (!(who & sl->overflow_bit)) {
                     // round 6: the others are re-measured with more head room too, without a strike against them - what crowded one
-                    // selection's
-                    // pencils (a solute pushing solvent around) crowds the next one's a batch later, and every overflow repeats a batch
+                    // selection's pencils crowds the next one's a batch later, and every overflow repeats a batch
                     if (sl->used_pencil && sl->cap_margin < 2.0f) { sl->pen_off.clear(); sl->caps_cache.clear(); sl->cap_margin = 2.0f; }
                     continue;
                 }
+                // a rare event worth a line in the host's log: it costs the batch a second cell build, and after three of them the
+                // selection
+                // leaves the two-level build for good
+                char msg[256];
+                snprintf(msg, sizeof(msg),
+                        "cell build: a pencil bucket of selection %zu (%zu atoms, %d x %d pencils, capacity margin %.2f, "
+                         "largest bucket %d) overflowed in frames [%zu, %zu): re-measured on every frame of the batch, margin x 1.6",
+                         si, sl->idx.size(), sl->pen_ny, sl->pen_nz, (double)sl->cap_margin, sl->cap_max, c.f0, c.f0 + c.nb);
+                vmd_log(VMD_LOG_INFO, msg);
                 sl->pen_off.clear();
                 sl->caps_cache.clear();
                 sl->cap_margin *= 1.6f;
