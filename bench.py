@@ -198,7 +198,7 @@ def cpu_baseline(name, w, topo, info):
     node = node_physical_cores()
     return {"value": best["value"], "unit": "frames/s", "cores": cores, "kind": "port",
             "samples": samples, "spread": (max(samples) - min(samples)) / median, "statistic": "median of three samples of the same frames",
-            "sample": f"{best['frames']} frames of {name} ({w['atoms']} atoms), {'tuned CPU code (half shell, AVX-512; oracle for SDF)' if best is simd else 'oracle (cell-list RDF / SDF align+scatter)'}, "
+            "sample": f"{best['frames']} frames of {name} ({w['atoms']} atoms), {'tuned CPU code (half shell, AVX-512; oracle for SDF)' if fast else 'oracle (cell-list RDF / SDF align+scatter)'}, "
                       f"{cores} OpenMP threads, dynamic grain 1 over frames, {best['seconds']:.1f} s",
             "pairs_per_s": best["pairs_per_s"],
             "scalar": scalar, "simd": simd,

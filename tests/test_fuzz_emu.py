@@ -81,6 +81,15 @@ def scenario(seed, scale=1):
     if seed % 4 == 1:
         opts["defer_sync"] = 1                      # the next batch queued before the host waits for the current one (several batches
         opts.setdefault("batch_frames", 2)          # needed; no draw from rng)
+    # round 6 (no draws from rng: the scenarios stay what they were): the base sets above are mostly PERIODIC index lists (all, every 2nd,
+    # every 3rd from 1, a prefix), which the cell build computes instead of reading - every 6th scenario reads the lists as before; every
+    # 4th sends small selections through the pencil buckets as well (cells_small = 0), every 9th measures capacities at batch ends only
+    if seed % 6 == 2:
+        opts["cells_sel_pattern"] = 0
+    if seed % 4 == 3:
+        opts["cells_small"] = 0
+    if seed % 9 == 4:
+        opts["cells_cap_sample"] = 2
     return coords, box, flags, props, opts, kind
 
 

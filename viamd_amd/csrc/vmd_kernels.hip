@@ -347,29 +347,38 @@ __global__ __launch_bounds__(256) void k_cells_count(vmd_cells_params_t p) {
     }
 }
 
-// one 1024-thread block per frame: exclusive prefix over the cell populations
+// one 1024-thread block per frame: exclusive prefix over the cell populations.  Round 6: chunks of 4 096 cells, four CONSECUTIVE cells per
+// thread - the previous version gave every thread its own contiguous stretch of ncell / 1024 cells, i.e. 64 lanes reading 64 different cache
+// lines per load: 0.80 ms per dispatch for the 30 000 cells x 334 frames of config 5's solute class (profiles/r06z3_*), 2.4 ms of its step
 __global__ __launch_bounds__(1024) void k_cells_scan(const uint32_t* __restrict__ cell_count, uint32_t* __restrict__ cell_start,
                                                      int ncell) {
     __shared__ uint32_t part[1024];
-    const int b = blockIdx.x;
+    const int b = blockIdx.x, tid = threadIdx.x;
     const uint32_t* cnt = cell_count + (size_t)b * (ncell + 1);
     uint32_t* out = cell_start + (size_t)b * (ncell + 1);
-    const int per = (ncell + 1023) / 1024;
-    const int beg = threadIdx.x * per;
-    const int end = beg + per < ncell ? beg + per : ncell;
-    uint32_t s = 0;
-    for (int c = beg; c < end; ++c) s += cnt[c];
-    part[threadIdx.x] = s;
-    __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {
-        const uint32_t v = threadIdx.x >= (unsigned)o ? part[threadIdx.x - o] : 0u;
+    uint32_t carry = 0;
+    for (int base = 0; base < ncell; base += 4096) {
+        const int c0 = base + 4 * tid;
+        uint32_t v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = c0 + k < ncell ? cnt[c0 + k] : 0u;
+        const uint32_t s = v[0] + v[1] + v[2] + v[3];
+        part[tid] = s;
         __syncthreads();
-        part[threadIdx.x] += v;
-        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {
+            const uint32_t u = tid >= o ? part[tid - o] : 0u;
+            __syncthreads();
+            part[tid] += u;
+            __syncthreads();
+        }
+        uint32_t run = carry + part[tid] - s;   // exclusive
+        const uint32_t total = part[1023];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { if (c0 + k < ncell) out[c0 + k] = run; run += v[k]; }
+        carry += total;
+        __syncthreads();                         // part[] is rewritten by the next chunk
     }
-    uint32_t run = part[threadIdx.x] - s;   // exclusive
-    for (int c = beg; c < end; ++c) { out[c] = run; run += cnt[c]; }
-    if (threadIdx.x == 1023) out[ncell] = part[1023];
+    if (tid == 0) out[ncell] = carry;
 }
 
 __global__ __launch_bounds__(256) void k_cells_scatter(vmd_cells_params_t p) {
