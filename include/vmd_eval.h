@@ -271,7 +271,10 @@ typedef struct vmd_script_aggregate_t {
  * new elements (the reference's own contract), never a dangling pointer. */
 typedef struct vmd_script_property_data_t {
     int32_t dim[4];                 /* [0] frames (temporal) | [2] bins (distribution) | [1..3] volume dims */
-    float*  values;                 /* temporal: values[frame*dim[1]+i]; distribution: values[bin]; volume: x fastest */
+    float*  values;                 /* temporal: values[frame*dim[1]+i]; distribution: values[bin]; volume: x fastest.  READ THE FIELD WHEN YOU
+                                     * READ THE DATA (VIAMD does: density_volume.cpp:279-283, src/main.cpp:5817): a volume's pointer is one of two
+                                     * stable addresses - shared read-only zeros between clear_data and the evaluation's first view, the view's own
+                                     * pinned pages otherwise (round 6: the 8.4 MB view is never zeroed) - changed by a relaxed atomic store */
     float*  weights;                /* distribution only */
     size_t  num_values;
     vmd_script_aggregate_t* aggregate;
@@ -302,9 +305,9 @@ bool vmd_eval_frame_range(vmd_script_eval_t* eval, const vmd_script_ir_t* ir, co
 const vmd_script_property_data_t* vmd_eval_property_data(const vmd_script_eval_t* eval, const char* name);
 /* md_script_eval_frame_mask (src/main.cpp:1513): one byte per frame here, non-zero = evaluated */
 const uint8_t* vmd_eval_frame_mask(const vmd_script_eval_t* eval);
-/* the same mask in the shape of an md_bitfield_t's storage (VIAMD tests it bit by bit, src/main.cpp:194-210): bit (f & 63) of word
- * f / 64 is set when frame f is evaluated.  Writes min(cap, words) words and returns words = ceil(num_frames / 64); a shim fills its
- * md_bitfield_t {bits, beg_bit = 0, end_bit = num_frames} from it. */
+/* the same mask as little-endian 64-bit words (VIAMD tests the bitfield bit by bit, src/main.cpp:194-210): bit (f & 63) of word f / 64 is
+ * set when frame f is evaluated.  Writes min(cap, words) words and returns words = ceil(num_frames / 64); the shim turns them into an
+ * md_bitfield_t through mdlib's own md_bitfield_clear / _set_bit (its storage layout is mdlib's business). */
 size_t   vmd_eval_frame_mask_bits(const vmd_script_eval_t* eval, uint64_t* words, size_t cap);
 size_t   vmd_eval_num_frames(const vmd_script_eval_t* eval);
 size_t   vmd_eval_frames_done(const vmd_script_eval_t* eval);

@@ -47,7 +47,9 @@
  * once per compiled script, the vmd_script_ir_t that carries its rdf / sdf / distance properties (INTEGRATION.md section 3 shows how
  * VIAMD derives them from the evaluated argument bitfields):      vmd_shim_bind_ir(md_ir, vmd_ir);
  *
- * tests/native/shim_callsites.cpp re-types VIAMD's call sequence against tests/native/md_mock.h and runs it. */
+ * tests/native/ref_callsites.cpp runs VIAMD's OWN call sites - cut verbatim out of /root/reference/src by oracle/make_ref.py - against this
+ * header with a test double of mdlib (tests/native/md_mock.h, md_mock_eval.h); shim_default_script.cpp and shim_callsites.cpp cover the
+ * fallback / no-fallback builds with re-typed sequences. */
 #ifndef VMD_MD_SCRIPT_SHIM_H
 #define VMD_MD_SCRIPT_SHIM_H
 

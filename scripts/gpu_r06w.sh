@@ -6,14 +6,14 @@ TAG=${1:-r06w}; S0=${2:-31}; R=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$R/gpurun_out/$TA
 {
 echo "Round 6 campaign on the MI355X, final tree (scripts/gpu_r06w.sh $TAG $S0):"
 echo "== fuzz_gpu.py: RDF + SDF + distance scenarios vs the oracle"
-timeout 1200 python scripts/fuzz_gpu.py $((S0 * 100)) $((S0 * 100 + 240)) 20 2>&1 | tail -3
+timeout 2400 python scripts/fuzz_gpu.py $((S0 * 100)) $((S0 * 100 + ${FUZZ_N:-240})) 20 2>&1 | tail -3
 echo "== fuzz_pool.py: pool patterns (plain, then deferred settle)"
-timeout 900 python scripts/fuzz_pool.py $((S0 * 1000)) $((S0 * 1000 + 1200)) gpu 2>&1 | tail -2
-timeout 900 python scripts/fuzz_pool.py $((S0 * 1000 + 5000)) $((S0 * 1000 + 5600)) gpu lone 2>&1 | tail -2
+timeout 1800 python scripts/fuzz_pool.py $((S0 * 1000)) $((S0 * 1000 + ${POOL_N:-1200})) gpu 2>&1 | tail -2
+timeout 1800 python scripts/fuzz_pool.py $((S0 * 1000 + 50000)) $((S0 * 1000 + 50000 + ${POOL_N:-1200} / 2)) gpu lone 2>&1 | tail -2
 echo "== stress_readahead.cpp"
 g++ -std=c++17 -O2 tests/native/stress_readahead.cpp -Iinclude viamd_amd/libviamd_amd.so -Wl,-rpath,$R/viamd_amd -L/opt/rocm/lib -Wl,-rpath,/opt/rocm/lib -Wl,-rpath-link,/opt/rocm/lib -lpthread -o /tmp/stress_ra
-for k in 0 1 2 3; do timeout 600 /tmp/stress_ra 600 240 30000 $((S0 + k)) 2>&1 | tail -1; done
-for k in 4 5; do timeout 600 /tmp/stress_ra 200 240 30000 $((S0 + k)) sdf 2>&1 | tail -1; done
+for k in $(seq 0 $((${STRESS_N:-4} - 1))); do timeout 600 /tmp/stress_ra 600 240 30000 $((S0 + k)) 2>&1 | tail -1; done
+for k in 104 105; do timeout 600 /tmp/stress_ra 200 240 30000 $((S0 + k)) sdf 2>&1 | tail -1; done
 echo "== the reference's own call sites through the shim (oracle/_ref/ref_callsites F tmpdir)"
 for F in 16 33 64 100 257; do mkdir -p /tmp/rc$F; timeout 600 oracle/_ref/ref_callsites $F /tmp/rc$F 2>/dev/null | tail -1; done
 echo "== shim_default_script / shim_callsites at other lengths"

@@ -365,6 +365,20 @@ def pool_threads_case(lib, O, device=False, n_water=900, box=32.0, F=12, nthread
             assert all(pooled(ev, grain)) and ev.frames_done() == F
             for n in ("g", "v", "d"):
                 np.testing.assert_array_equal(ev.property_data(n).values, want[n].values, err_msg=f"{n} after interrupt + restart")
+            # the same pattern from NATIVE threads (vmd_eval_frame_range_pooled, round 6: what bench.py --pool-threads and secondary.c1 time):
+            # whole range, a ragged sub-range, one thread, more threads than frames
+            for beg, end, threads in ((0, F, nthreads), (1, F - 2, 3), (0, F, 1), (0, F, 2 * F)):
+                ev.clear_data()
+                assert ev.frame_range_pooled(sysm, traj, beg, end, threads, grain) and ev.frames_done() == end - beg
+                if (beg, end) == (0, F):
+                    for n in ("g", "v", "d"):
+                        np.testing.assert_array_equal(ev.property_data(n).values, want[n].values, err_msg=f"{n} from native pool threads")
+                else:
+                    sub = V.ScriptEval(F, ir)
+                    assert sub.frame_range(sysm, traj, beg, end)
+                    np.testing.assert_array_equal(ev.property_data("g").counts, sub.property_data("g").counts)
+                    np.testing.assert_array_equal(ev.property_data("v").values, sub.property_data("v").values)
+                    sub.close()
             ev.close()
         finally:
             lib.vmd_set_option(b"gather_us", old[0]); lib.vmd_set_option(b"lazy_views", old[1])

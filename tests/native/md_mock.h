@@ -108,7 +108,10 @@ struct md_bitfield_t {
     uint32_t beg_bit, end_bit;             // [src/main.cpp:2511-2512, 5795-5796 bf->beg_bit / bf->end_bit]; width [RECOLLECTION]
 };
 struct md_bitfield_iter_t { const md_bitfield_t* bf; int64_t idx; };      // name [src/main.cpp:194]; members [RECOLLECTION]
-/* [components/ramachandran/ramachandran.cpp:947] */ static inline bool md_bitfield_test_bit(const md_bitfield_t* bf, uint64_t i) { return i >= bf->beg_bit && i < bf->end_bit && ((bf->bits[i >> 6] >> (i & 63)) & 1ull); }
+/* [components/ramachandran/ramachandran.cpp:947] */ static inline bool md_bitfield_test_bit(const md_bitfield_t* bf, uint64_t i) {
+    // (relaxed atomic word reads: the mock's evaluator sets bits of its frame mask while VIAMD's GUI thread iterates it, as mdlib's does)
+    return i >= bf->beg_bit && i < bf->end_bit && ((__atomic_load_n(&bf->bits[i >> 6], __ATOMIC_RELAXED) >> (i & 63)) & 1ull);
+}
 /* [src/main.cpp:185] */ static inline size_t md_bitfield_popcount(const md_bitfield_t* bf) { size_t c = 0; for (uint64_t i = bf->beg_bit; i < bf->end_bit; ++i) c += md_bitfield_test_bit(bf, i); return c; }
 /* [src/main.cpp:194-196: create / next / idx] */ static inline md_bitfield_iter_t md_bitfield_iter_create(const md_bitfield_t* bf) { return md_bitfield_iter_t{bf, (int64_t)bf->beg_bit - 1}; }
 static inline bool md_bitfield_iter_next(md_bitfield_iter_t* it) {

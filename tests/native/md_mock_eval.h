@@ -153,8 +153,8 @@ static inline void mockmd_md_script_eval_free(vmd_shim_fallback_eval_t* e) { if 
 static inline void mockmd_md_script_eval_clear_data(vmd_shim_fallback_eval_t* e) {
     std::lock_guard<std::mutex> l(e->mtx);
     e->interrupt = false; e->clears += 1; e->frames_evaluated = 0;
-    std::fill(e->mask_words.begin(), e->mask_words.end(), 0ull);
-    for (auto& d : e->data) { std::fill(d.values.begin(), d.values.end(), 0.0f); d.rec.fingerprint += 1; }
+    for (auto& w : e->mask_words) __atomic_store_n(&w, 0ull, __ATOMIC_RELAXED);
+    for (auto& d : e->data) { std::fill(d.values.begin(), d.values.end(), 0.0f); __atomic_fetch_add(&d.rec.fingerprint, 1, __ATOMIC_RELAXED); }
 }
 static inline void mockmd_md_script_eval_interrupt(vmd_shim_fallback_eval_t* e) { e->interrupt = true; e->interrupts += 1; }
 static inline uint64_t mockmd_md_script_eval_ir_fingerprint(const vmd_shim_fallback_eval_t* e) { return e->ir->fingerprint; }
@@ -171,8 +171,8 @@ static inline bool mockmd_md_script_eval_frame_range(vmd_shim_fallback_eval_t* e
             mock_eval_row(p, x.data(), y.data(), z.data(), n, &e->data[i].values[(size_t)f * p.width()]);
         }
         std::lock_guard<std::mutex> l(e->mtx);
-        e->mask_words[f >> 6] |= 1ull << (f & 63);
-        for (auto& d : e->data) d.rec.fingerprint += 1;
+        __atomic_fetch_or(&e->mask_words[f >> 6], 1ull << (f & 63), __ATOMIC_RELAXED);      // read by the GUI thread meanwhile (md_bitfield_test_bit)
+        for (auto& d : e->data) __atomic_fetch_add(&d.rec.fingerprint, 1, __ATOMIC_RELAXED);
         e->frames_evaluated += 1;
     }
     return true;

@@ -165,7 +165,8 @@ int main(int argc, char** argv) {
 
     // ---- VIAMD's main loop, as far as evaluation goes: the block, then update_display_properties (src/main.cpp:1064), once per GUI frame
     auto gui_frames_until_idle = [&](const char* what) {
-        for (int frame = 0; frame < 200000; ++frame) {
+        const auto t_begin = std::chrono::steady_clock::now();
+        for (int frame = 0; std::chrono::steady_clock::now() - t_begin < std::chrono::seconds(1800); ++frame) {      // (ThreadSanitizer builds are 20 x slower)
             viamd_main_loop_evaluation_block(state, F);
             update_display_properties(&state);
             host_frame_reset();

@@ -20,8 +20,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <string>
 #include <thread>
 #include <vector>
+
+#include <unistd.h>
 
 #include "md_mock.h"
 #define VMD_SHIM_NO_FALLBACK                // this program binds every property of its script: no mdlib behind the shim (shim_default_script.cpp has one)
@@ -276,8 +279,11 @@ int main(int argc, char** argv) {
     // ---- export_cube, src/main.cpp:5718-5830: the REFERENCE's own function, cut verbatim into oracle/_ref/viamd_export_slices.inc by
     // oracle/make_ref.py (this block used to be a re-typed copy) - it calls md_trajectory_load_frame, md_script_vis_init,
     // md_script_vis_eval_payload(ATOMS | SDF) through the shim, walks structure 0 with md_bitfield_scan and reads prop_data->dim / ->values
-    const char* cube_md = "/tmp/viamd_shim_callsites_md.cube";
-    const char* cube_vmd = "/tmp/viamd_shim_callsites_vmd.cube";
+    // (one pair of files per process: the test suite, the sanitizer scripts and the GPU campaign run this program side by side)
+    const std::string cube_md_s = "/tmp/viamd_shim_callsites_md." + std::to_string((long)getpid()) + ".cube";
+    const std::string cube_vmd_s = "/tmp/viamd_shim_callsites_vmd." + std::to_string((long)getpid()) + ".cube";
+    const char* cube_md = cube_md_s.c_str();
+    const char* cube_vmd = cube_vmd_s.c_str();
     {
         static ApplicationState data;
         data.mold.sys = sys;

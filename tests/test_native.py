@@ -128,9 +128,8 @@ def build_shim_callsites():
     # the program includes the reference's export_cube VERBATIM (oracle/_ref/viamd_export_slices.inc: generated here from /root/reference,
     # travels to the GPU box in the git-ignored oracle/_ref/)
     if not make_ref.slices_available():
-        if os.path.exists(SHIM_EXE):
-            return SHIM_EXE
-        pytest.skip("neither /root/reference nor oracle/_ref/viamd_export_slices.inc nor a prebuilt tests/native/shim_callsites is present")
+        # neither /root/reference nor oracle/_ref/viamd_export_slices.inc: a prebuilt program, or nothing (callers skip)
+        return SHIM_EXE if os.path.exists(SHIM_EXE) else None
     deps = [SHIM_SRC, lib, make_ref.INC_EXPORT] + [os.path.join(ROOT, "tests", "native", h) for h in ("md_mock.h", "viamd_host_double.h")] + \
            [os.path.join(ROOT, "include", "vmd_md_script_shim.h")]
     if os.path.exists(SHIM_EXE) and os.path.getmtime(SHIM_EXE) >= max(os.path.getmtime(d) for d in deps):
@@ -145,6 +144,9 @@ def test_md_script_shim_call_sites_on_the_emulator(tmp_path, emu_lib):
     _interrupt / _free with mdlib's signatures, driven by a re-typed copy of /root/reference/src/main.cpp:951-1039, 1275-1316, 1508-1524
     (here against the SIMT-emulator build of the library, so it runs without a GPU): same bits as direct vmd_* calls."""
     import conftest
+    from oracle import make_ref
+    if not make_ref.slices_available():
+        pytest.skip("the program includes the reference's export_cube (oracle/_ref/viamd_export_slices.inc): neither /root/reference nor the slices are here")
     assert os.access(build_shim_callsites(), os.X_OK)                  # links against the product library
     emu = conftest.build_emu()
     exe = str(tmp_path / "shim_callsites_emu")
@@ -156,7 +158,9 @@ def test_md_script_shim_call_sites_on_the_emulator(tmp_path, emu_lib):
 
 @pytest.mark.gpu
 def test_md_script_shim_call_sites(gpu_lib):
-    out = subprocess.run([build_shim_callsites(), "48"], capture_output=True, text=True, timeout=300)
+    exe = build_shim_callsites()
+    assert exe, "tests/native/shim_callsites (or oracle/_ref/viamd_export_slices.inc to build it from) must travel to the GPU box"
+    out = subprocess.run([exe, "48"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     assert out.stdout.startswith("OK frames=48"), out.stdout
 

@@ -200,7 +200,7 @@ bool reuse_blocks(vmd_script_eval_t* e, const TrajId& traj_inst, size_t beg, siz
                 }
                 p->dirty = true;
             }
-            for (size_t g = f; g < bend; ++g) e->frame_mask[g] = 1;
+            for (size_t g = f; g < bend; ++g) mask_set(e->frame_mask, g);
             reused += bend - f;
             f = bend; run = f;
         } else {
@@ -605,7 +605,7 @@ bool process_range_locked(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
         e->frames_computed += c.nb;
         if (c.bt.blk >= 0) for (auto& su : c.subs) e->block_ready[su.blk] = spec ? BLOCK_ROWS_AHEAD : BLOCK_ROWS_IN_PLACE;
         if (spec) return true;
-        for (size_t b = 0; b < c.nb; ++b) e->frame_mask[c.f0 + b] = 1;
+        for (size_t b = 0; b < c.nb; ++b) mask_set(e->frame_mask, c.f0 + b);
         e->frames_done += c.nb;
         // cheap views are refreshed every batch so a polling GUI sees progress (src/main.cpp:1508-1524): from the device when nothing
         // is queued behind this batch, from the snapshot taken behind its commits otherwise

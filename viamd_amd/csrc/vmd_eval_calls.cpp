@@ -147,7 +147,7 @@ bool ra_commit_block(vmd_script_eval_t* e, size_t blk) {
         }
         p->dirty = true;
     }
-    for (size_t f = f0; f < f1; ++f) e->frame_mask[f] = 1;
+    for (size_t f = f0; f < f1; ++f) mask_set(e->frame_mask, f);
     e->frames_done += f1 - f0;
     if (e->block_ready[blk]) e->block_ready[blk] = BLOCK_ROWS_IN_PLACE;
     e->ra.blk_state[blk].store(vmd_script_eval_t::RA_COMMITTED, std::memory_order_release);

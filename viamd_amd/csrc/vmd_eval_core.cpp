@@ -300,7 +300,7 @@ extern "C" void vmd_eval_clear_data(vmd_script_eval_t* eval) {
     lone_cancel(eval);                   // a deferred settle of the evaluation that ends here must neither start nor be running
     std::lock_guard<std::mutex> l(eval->mtx);
     eval->interrupt = false;
-    std::fill(eval->frame_mask.begin(), eval->frame_mask.end(), (uint8_t)0);
+    for (size_t f = 0; f < eval->frame_mask.size(); ++f) mask_set(eval->frame_mask, f, 0);
     eval->frames_done = 0;
     eval->frames_computed = 0; eval->frames_reused = 0; eval->frames_device_decoded = 0; eval->frames_section_decoded = 0;
             eval->frames_mapped = 0;
@@ -361,7 +361,7 @@ extern "C" size_t vmd_eval_frame_mask_bits(const vmd_script_eval_t* eval, uint64
     for (size_t w = 0; w < nw && w < cap && words; ++w) {
         uint64_t v = 0;
         const size_t f1 = std::min(eval->num_frames, (w + 1) * 64);
-        for (size_t f = w * 64; f < f1; ++f) if (eval->frame_mask[f]) v |= 1ull << (f & 63);
+        for (size_t f = w * 64; f < f1; ++f) if (mask_get(eval->frame_mask, f)) v |= 1ull << (f & 63);
         words[w] = v;
     }
     return nw;
@@ -572,7 +572,7 @@ extern "C" void vmd_eval_set_frame_mask(vmd_script_eval_t* eval, const uint8_t* 
     std::lock_guard<std::mutex> l(eval->mtx);
     size_t done = 0;
     for (size_t f = 0; f < eval->num_frames; ++f) {
-        if (f < n) eval->frame_mask[f] = mask[f] ? 1 : 0;
+        if (f < n) mask_set(eval->frame_mask, f, mask[f] ? 1 : 0);
         done += eval->frame_mask[f] ? 1 : 0;
     }
     eval->frames_done = done;

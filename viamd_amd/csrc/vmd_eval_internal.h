@@ -478,6 +478,12 @@ template <class T> static inline T flag_get(const T* p) { T v; __atomic_load(con
 
 template <class T> static inline void flag_set(T* p, T v) { __atomic_store(p, &v, __ATOMIC_RELEASE); }
 
+// the frame mask is read by the host's GUI thread (vmd_eval_frame_mask_bits, one byte per frame) while pool threads complete frames: bytes go
+// through relaxed atomic accesses - plain moves on x86-64 -, so the hand-over is defined behaviour (found by ThreadSanitizer once the
+// reference's own polling loop ran against the shim, round 6)
+static inline void mask_set(std::vector<uint8_t>& m, size_t f, uint8_t v = 1) { __atomic_store_n(&m[f], v, __ATOMIC_RELAXED); }
+static inline uint8_t mask_get(const std::vector<uint8_t>& m, size_t f) { return __atomic_load_n(&m[f], __ATOMIC_RELAXED); }
+
 // Decoder checkpoints of file-backed trajectories (k_xtc_wave), kept per TRAJECTORY for the whole process: VIAMD creates
 // a fresh md_script_eval_t for every script edit (src/main.cpp:966-972), so a cache inside the eval would never be hit by the
 // re-evaluations it exists for.  Keyed by the trajectory's instance pointer; a frame's checkpoints are only used while the frame's
