@@ -91,6 +91,7 @@ int vmd_hip_cells_build_pencil(void* stream, const float* xyz, size_t frame_stri
  *             carry tilt factors, cells live in the unsheared coordinates s_k * L_k (SPEC S3t) and the grid edge must be
  *             >= rmax measured perpendicular to the cell faces.  Open axes: no images, neighbours end at the bounding box. */
 int vmd_hip_rdf_num_blocks(void);
+int vmd_hip_set_rdf_pop(int mode);    /* how k_rdf_pencil drains its hit stack when r_min == 0: 0 = the 9-instruction pop, 1 (default) = margin folded into the constant, spare bin, stack read with ds_read_addtid_b32 (6); returns the previous value */
 int vmd_hip_set_rdf_nsub(int n);       /* tuning knob: work items per pencil (1..64, 0 = automatic), returns the previous value */
 int vmd_hip_set_rdf_nsub_pct(int pct);  /* tuning knob: the automatic number of work items per pencil as a percentage of the mean number of i-chunks per pencil */
 int vmd_hip_set_rdf_shared_hist(int on); /* A-B switch: one LDS histogram per block instead of one per wave, returns the previous value */

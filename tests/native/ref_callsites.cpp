@@ -24,6 +24,7 @@
 // container, runs prebuilt on the GPU box.
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -49,6 +50,14 @@ static void viamd_main_loop_evaluation_block(ApplicationState& state, const size
 #include "_ref/viamd_eval_block.inc"
 }
 // ===========================================================================================
+
+// how long the deferred-settle helper may take before the run counts as hung: seconds on the product and the plain emulator build, far longer
+// under ThreadSanitizer (the emulator is ~20 x slower there and scripts/tsan_emu.sh runs ten programs side by side)
+#if defined(__SANITIZE_THREAD__) || defined(__SANITIZE_ADDRESS__)
+static const std::chrono::seconds kSettleLimit(1800);
+#else
+static const std::chrono::seconds kSettleLimit(60);
+#endif
 
 static void fail(const char* what) {
     std::fprintf(stderr, "FAIL: %s (%s)\n", what, vmd_last_error());
@@ -188,7 +197,7 @@ int main(int argc, char** argv) {
         while (vmd_eval_frames_done(state.script.full_eval->eval) != F || vmd_eval_frames_done(state.script.filt_eval->eval) != F - 2 * (F / 4)) {
             update_display_properties(&state);
             host_frame_reset();
-            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30)) fail("deferred settle: the helper thread never settled");
+            if (std::chrono::steady_clock::now() - t0 > kSettleLimit) fail("deferred settle: the helper thread never settled");
             std::this_thread::sleep_for(std::chrono::microseconds(300));
         }
         // the helper may still be inside its callback into the shim (the fingerprints move once more there): wait for it, then compare
@@ -351,8 +360,8 @@ int main(int argc, char** argv) {
         vmd_script_eval_t* e = vmd_eval_create(F, vir);
         if (!e || !vmd_eval_frame_range(e, vir, &vsys, &vt, 0, (uint32_t)F) || !vmd_eval_wait_settled(e)) fail("direct evaluation (edited script)");
 #ifdef VMD_SHIM_DEFERRED_SETTLE
-        for (int spin = 0; vmd_eval_frames_done(state.script.full_eval->eval) != F; ++spin) {
-            if (spin > 100000) fail("deferred settle (edited script): the helper thread never settled");
+        for (const auto t0 = std::chrono::steady_clock::now(); vmd_eval_frames_done(state.script.full_eval->eval) != F;) {
+            if (std::chrono::steady_clock::now() - t0 > kSettleLimit) fail("deferred settle (edited script): the helper thread never settled");
             std::this_thread::sleep_for(std::chrono::microseconds(300));
         }
         if (!vmd_eval_wait_settled(state.script.full_eval->eval)) fail("vmd_eval_wait_settled");

@@ -98,6 +98,31 @@ def test_rdf_hit_compaction_variants(gpu_lib, oracle, box30k, variant, shist):
         gpu_lib.vmd_set_option(b"rdf_shared_hist", old_sh)
 
 
+@pytest.mark.parametrize("pop", [0, 1])
+def test_rdf_pop_variants(gpu_lib, oracle, box30k, pop):
+    """how k_rdf_pencil drains its hit stack when r_min == 0: 0 = the 9-instruction pop, 1 = margin folded into the constant + spare bin, the
+    stack read with ds_read_addtid_b32 (M0 + 4 * lane; the default) - bit-identical counts, incl. BASELINE config 2's shape.  The exact path
+    behind both is the out-of-line vmd_slow_flush_call (the thin shell and the edge cases put most hits on it)"""
+    o, h = cases.oxygen(30000), cases.hydrogen(30000)
+    old = gpu_lib.vmd_set_option(b"rdf_pop", pop)
+    try:
+        cases.check_rdf(gpu_lib, oracle, box30k[:3], 80.0, [("goo", o, o, 0.0, 12.0), ("goh", o, h, 0.0, 10.0), ("ring", h, o, 2.5, 9.0),
+                                                          ("shell", o, o, 11.5, 12.0)], device=True)
+        cases.rdf_edge_cases(gpu_lib, oracle, device=True)
+        N, F = 100002, 3
+        t = V.DeviceTrajectory(F, N)
+        t.synth(2, 100.0, 0.05)
+        oo = cases.oxygen(N)
+        ir = V.ScriptIR(); ir.add_rdf("g", oo, oo, 12.0)
+        ev = V.ScriptEval(F, ir)
+        assert ev.frame_range(V.MolSystem(N), t, 0, F)
+        coords = np.stack([oracle.synth_frame(2, N, 100.0, 0.05, f) for f in range(F)])
+        counts, _ = cases.oracle_rdf(oracle, coords, oracle.make_cell(100.0), oo, oo, 0.0, 12.0)
+        np.testing.assert_array_equal(ev.property_data("g").counts, counts)
+    finally:
+        gpu_lib.vmd_set_option(b"rdf_pop", old)
+
+
 def test_rdf_inline_variant_and_host_staging(gpu_lib, oracle, box30k):
     o = cases.oxygen(30000)
     cases.check_rdf(gpu_lib, oracle, box30k[:2], 80.0, [("goo", o, o, 0.0, 12.0)], variant=1, device=False)

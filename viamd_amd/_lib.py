@@ -283,6 +283,7 @@ SIGNATURES = [
     ("vmd_hip_set_cells_bin_lds", C.c_int, [C.c_int]),
     ("vmd_hip_set_sdf_wave", C.c_int, [C.c_int]),
     ("vmd_hip_set_rdf_nsplit", C.c_int, [C.c_int]),
+    ("vmd_hip_set_rdf_pop", C.c_int, [C.c_int]),
     ("vmd_hip_set_rdf_nsub", C.c_int, [C.c_int]),
     ("vmd_hip_cells_split_blocks", C.c_int, [Grid, C.c_int]),
     ("vmd_hip_set_cells_split", C.c_int, [C.c_int]),

@@ -48,8 +48,7 @@ bool ensure_pencil_caps(vmd_script_eval_t* e, Selection* s, const Stage& src, co
         for (size_t k = 0; k < rows; ++k) m = std::max(m, h[k * npen + p]);
         uint32_t cap = (uint32_t)std::ceil((double)m * s->cap_margin + 6.0 * std::sqrt((double)m)) + 16;
         // ... but never below what a pencil holds at the selection's MEAN density (round 6).  A solute that sits in a pencil for the whole
-        // of
-        // the batch the capacities were measured on (config 5's wandering blob) leaves that pencil's bucket too small for the batches in
+        // of the batch the capacities were measured on (config 5's wandering blob) leaves that pencil's bucket too small for the batches in
         // which it has moved on: two overflows, i.e. two repeated batches, per evaluation of c5.  Costs at most 1.15 x nsel records.
         cap = std::max(cap, (uint32_t)std::ceil(mean_pop * 1.15 + 6.0 * std::sqrt(mean_pop)) + 16);
         cap = (cap + 3u) & ~3u;
@@ -82,14 +81,13 @@ bool build_selection(vmd_script_eval_t* e, Selection* s, const Stage& src, const
     // +64: the pair kernel prefetches past a segment
     if (!s->cell_start.ensure(nb * (size_t)(g.ncell + 1)) || !s->sorted.ensure(nb * 3 * (size_t)s->nsel_pad + 64)) return false;
     s->used_pencil = false;
-    // two-level build through per-pencil buckets (one read of the frame, coalesced sorted rows); single-level builds otherwise
-    // A small selection (a solute: the 2 000-atom blob of config 5) is not spread evenly over the pencils and wanders through them as the
+    // two-level build through per-pencil buckets (one read of the frame, coalesced sorted rows); single-level builds otherwise A small
+    // selection (a solute: the 2 000-atom blob of config 5) is not spread evenly over the pencils and wanders through them as the
     // trajectory goes on: capacities measured on one batch overflow in the next, and every overflow repeats the batch's pair passes.  It is
     // sorted by ONE block per frame in LDS instead (k_cells_fused: no buckets, nothing to overflow), which costs such a selection nothing.
     // (round 6: whether or not the grid's cell table fits the fused kernel's LDS - c5's 30 000 cells do not, and its 1 200-atom solute
-    // class went
-    // through the buckets after all: one overflow, i.e. one repeated batch, in each of an evaluation's first two passes.  The single-level
-    // builds behind vmd_hip_cells_build pick the fused, the split or the atomic three-kernel variant themselves.)
+    // class went through the buckets after all: one overflow, i.e. one repeated batch, in each of an evaluation's first two passes.  The
+    // single-level builds behind vmd_hip_cells_build pick the fused, the split or the atomic three-kernel variant themselves.)
     const bool small = nsel <= g_opt.cells_small.load();
     if (vmd_hip_cells_pencil_ok(g) && s->overflows < 3 && !small) {
         if (!ensure_pencil_caps(e, s, src, d_boxes, pbc, nb, g)) return false;
@@ -269,8 +267,8 @@ bool process_range_locked(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
     else if (!reuse_blocks(e, traj_id(traj), frame_beg, frame_end, &segments)) return false;
     if (e->block_frames) {
         // a source evaluated over trajectory A and then, WITHOUT clear_data, over another trajectory of the same length must
-        // not
-        // hand A's block partials to users that evaluate B - the blocks kept from now on belong to B, the ones kept so far are forgotten
+        // not hand A's block partials to users that evaluate B - the blocks kept from now on belong to B, the ones kept so far are
+        // forgotten
         const TrajId now = traj_id(traj);
         if (e->blocks_inst.inst && e->blocks_inst != now)
             for (size_t b = 0; b < e->num_blocks; ++b) e->block_ready[b] = 0;
@@ -296,11 +294,10 @@ bool process_range_locked(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
                 && g_opt.raw_f32_device.load(); raw_ring = f32_ring; }
     }
     e->raw_skip = traj->load_raw && !raw_ring;              // fetch_stage: do not ask this trajectory for raw frames batch by batch
-    // how many batches the bit streams run ahead of the kernels (one more than the decoder, which runs two ahead).  Copied through
-    // pinned blocks (host threads read them, this thread waits): 3.  Taken out of the mapped file by the copy engine alone: as many as the
-    // ring holds minus the one being decoded - the
-    // DMAs then queue back to back and PCIe never waits for this thread (r03n: 12.4 ms per c2 step against 9.4 ms of transfers).
-    // always > stage_ahead
+    // how many batches the bit streams run ahead of the kernels (one more than the decoder, which runs two ahead).  Copied through pinned
+    // blocks (host threads read them, this thread waits): 3.  Taken out of the mapped file by the copy engine alone: as many as the ring
+    // holds minus the one being decoded - the DMAs then queue back to back and PCIe never waits for this thread (r03n: 12.4 ms per c2 step
+    // against 9.4 ms of transfers). always > stage_ahead
     const size_t raw_ahead = (raw_ring && have_map && (f32_ring || g_opt.xtc_device_decode.load() == 3)) ? vmd_script_eval_t::kRawSlots
             - 1 : 3;
     auto slot_of = [&](size_t bi) -> RawSlot* { return raw_ring ? &e->raw_slots[bi % vmd_script_eval_t::kRawSlots] : nullptr; };
@@ -568,8 +565,7 @@ bool process_range_locked(vmd_script_eval_t* eval, const vmd_system_t* sys, vmd_
                     continue;
                 }
                 // a rare event worth a line in the host's log: it costs the batch a second cell build, and after three of them the
-                // selection
-                // leaves the two-level build for good
+                // selection leaves the two-level build for good
                 char msg[256];
                 snprintf(msg, sizeof(msg),
                         "cell build: a pencil bucket of selection %zu (%zu atoms, %d x %d pencils, capacity margin %.2f, "
@@ -779,10 +775,8 @@ bool refresh_views_locked(vmd_script_eval_t* e) {
         if (p->prop.kind == PROP_RDF) { if (!refresh_distribution(e, p.get())) return false; }
         else if (p->prop.kind == PROP_SDF) {
             // vmd_eval_defer_volume_views: a rank of a multi-GPU evaluation does not materialise ITS partial volume's float view (8.4 MB
-            // over
-            // PCIe after every range) - the merge re-derives the view of the merged counts (vmd_eval_reduce -> vmd_eval_finalize); the
-            // volume
-            // stays dirty until then
+            // over PCIe after every range) - the merge re-derives the view of the merged counts (vmd_eval_reduce -> vmd_eval_finalize); the
+            // volume stays dirty until then
             if (e->defer_volume_views.load(std::memory_order_relaxed)) continue;
             if (!refresh_volume(e, p.get())) return false;
         }

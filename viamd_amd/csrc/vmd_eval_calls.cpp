@@ -43,10 +43,9 @@ bool ra_engage(vmd_script_eval_t* e, vmd_trajectory_i* traj) {
     const bool have_view = traj->device_view && traj->device_view(traj->inst, &view) && view.device == e->device;
     const size_t Bmax = auto_batch(e, num_atoms, !have_view);
     if (e->block_frames == 0) {
-        // a filtered eval (src/main.cpp:1014-1039) adopts whole blocks from its source's partials: same blocks as the source
-        // (the source may be engaging at this very moment - "Eval Full" and "Eval Filt" side by side: its block size is read under its
-        // mutex;
-        // order: own mutex, then the source's, as everywhere)
+        // a filtered eval (src/main.cpp:1014-1039) adopts whole blocks from its source's partials: same blocks as the source (the source
+        // may be engaging at this very moment - "Eval Full" and "Eval Filt" side by side: its block size is read under its mutex; order:
+        // own mutex, then the source's, as everywhere)
         size_t src_S = 0;
         if (e->source) { std::lock_guard<std::mutex> sl(e->source->mtx); src_S = e->source->block_frames; }
         const size_t S = src_S ? std::min(src_S, std::max<size_t>(Bmax, 1)) : ra_block_frames(e, Bmax);
@@ -428,8 +427,8 @@ void lone_helper_main(vmd_script_eval_t* e) {
             }
             ra.flight.fetch_sub(1, std::memory_order_acq_rel);
             // the host's records of this eval follow NOW (the shim re-publishes fingerprint / ranges / max_value: ADVICE r05 #1) - after
-            // the
-            // settle, before `busy` drops: clear_data / interrupt / free wait for the callback too, it never runs on a freed host object
+            // the settle, before `busy` drops: clear_data / interrupt / free wait for the callback too, it never runs on a freed host
+            // object
             if (!retry) if (auto cb = h.on_settled.load(std::memory_order_acquire)) cb(h.on_settled_user.load(std::memory_order_acquire));
         }
         lk.lock();

@@ -309,16 +309,20 @@ extern "C" void vmd_eval_clear_data(vmd_script_eval_t* eval) {
     ra_reset(eval);
     for (auto& p : eval->props) {
         // The float view of a volume (8.4 MB, pinned) is NOT zeroed: `data.values` is pointed at a shared, read-only page range of zeros
-        // until
-        // the next view of this evaluation has been written - k_counts_to_float rewrites every voxel of the real view, then the pointer
-        // flips back (refresh_volume).  Round 6: the zeroing was a second 8.4 MB pass over PCIe per evaluation - 0.15
-        // ms
-        // that the kernel trace showed IN FRONT of the evaluation's kernels, not under them (profiles/r06a_c4_1250_timeline.txt) - a fifth
-        // of
-        // a rank's 1 250-frame share of configs[3].  A reader polling `fingerprint` (src/main.cpp:1508; density_volume.cpp:159-163,
-        // 279-283) sees
-        // zeros under the new fingerprint at once, never the previous run's voxels; VIAMD dereferences prop_data->values when it uploads.
-        if (p->prop.kind == PROP_SDF) pub(p->data.values, zero_volume_view(p->ncounts));
+        // until the next view of this evaluation has been written - k_counts_to_float rewrites every voxel of the real view, then the
+        // pointer flips back (refresh_volume).  Round 6: the zeroing was a second 8.4 MB pass over PCIe per
+        // evaluation - 0.15 ms that the kernel trace showed IN FRONT of the evaluation's kernels, not under them
+        // (profiles/r06a_c4_1250_timeline.txt) - a fifth of a rank's 1 250-frame share of configs[3].  A reader polling `fingerprint`
+        // (src/main.cpp:1508; density_volume.cpp:159-163, 279-283) sees zeros under the new fingerprint at once, never the previous run's
+        // voxels; VIAMD dereferences prop_data->values when it uploads.
+        if (p->prop.kind == PROP_SDF) {
+            float* zeros = zero_volume_view(p->ncounts);
+            if (zeros) pub(p->data.values, zeros);
+            else {      // no address space for the shared zeros: zero the view itself, as before round 6 (never a NULL `values`)
+                std::fill(p->values.begin(), p->values.end(), 0.0f);
+                pub(p->data.values, p->values.data());
+            }
+        }
         else std::fill(p->values.begin(), p->values.end(), 0.0f);
         std::fill(p->weights.begin(), p->weights.end(), 0.0f);
         // the 17 MB u64 mirror of a volume is only ever read after vmd_eval_refresh_counts: mark it stale instead of zeroing it

@@ -70,12 +70,10 @@ struct Options {
     std::atomic<int> force_brute{0};
     std::atomic<int> load_threads{0};    // host threads decoding one staged batch through load_frame; 0 = auto (see load_threads())
     // pencils of cross-section rmax/split (walk reach = split).  z: explicit (A/B).  y: 0 = by density - selections of >= 0.08 atoms / A^3
-    // in the
-    // lanes of every pass of a group (all heavy atoms of a liquid; SURVEY 8d's C3-dense) walk half-width pencils in y: a 64-atom chunk of
-    // such
-    // a selection is only ~4 A long, so the x windows are dominated by the 2 r_max of padding and thinner pencils pay (c3d 2 028 -> 2 131
-    // frames/s, profiles/r05d_pencil_split_by_density.txt; at c3's 0.033 / A^3 the same split costs 10 %, at c5's mix 6 %); 1 / 2 / .. =
-    // fixed
+    // in the lanes of every pass of a group (all heavy atoms of a liquid; SURVEY 8d's C3-dense) walk half-width pencils in y: a 64-atom
+    // chunk of such a selection is only ~4 A long, so the x windows are dominated by the 2 r_max of padding and thinner pencils pay
+    // (c3d 2 028 -> 2 131 frames/s, profiles/r05d_pencil_split_by_density.txt; at c3's 0.033 / A^3 the same split costs 10 %, at c5's mix
+    // 6 %); 1 / 2 / .. = fixed
     std::atomic<int> pencil_split_y{0}, pencil_split_z{1};
     // fine x cell = rmax / nxf_divisor (8 / 12 / 16 / 24 / 32 measured: 16 is +0.8 % on c3, profiles/r02l_ab_fine_cells.txt)
     std::atomic<int> nxf_divisor{16};
@@ -132,8 +130,7 @@ struct Options {
     // pair-kernel grid while batches are decompressed on the device: 6 blocks per CU leave every
     std::atomic<int> rdf_blocks_decode{1536};
                                                 // SIMD a wave slot and 80 VGPRs, so k_xtc_wave of batch k + 1 (wave priority 3) runs under
-                                                // the pair
-                                                // kernel of batch k; costs the pair kernel ~4 % (0 = leave the grid alone)
+                                                // the pair kernel of batch k; costs the pair kernel ~4 % (0 = leave the grid alone)
     std::atomic<int> sdf_dense{0};       // dense-target SDF scatter (stream whole frames, select by tag): measured slower, off
     // SDF target lists that are arithmetic progressions are generated on the device (0 = always load the index list)
     std::atomic<int> sdf_arith{1};
@@ -158,9 +155,9 @@ struct Options {
     std::atomic<int> readahead_fail_alloc{0};
     // Opt-in: small calls are served by read-ahead even when they come from ONE thread (a host that walks a range frame by frame), and the
     // settle a pool's last leaver performs is DEFERRED to a helper thread that runs once the eval has been quiet for
-    // readahead_lone_settle_us.
-    // The price is the contract: results then trail the last call by that long (a polling reader like VIAMD's GUI does not notice;
-    // vmd_eval_wait_settled / finalize / reduce / the exporters wait for them), and system + trajectory must stay valid until then.
+    // readahead_lone_settle_us. The price is the contract: results then trail the last call by that long (a polling reader like VIAMD's GUI
+    // does not notice; vmd_eval_wait_settled / finalize / reduce / the exporters wait for them), and system + trajectory must stay valid
+    // until then.
     std::atomic<int> readahead_lone{0};
     std::atomic<int> readahead_lone_settle_us{300};
     // the cell build computes the atom index of a periodic selection instead of reading its index list (round 6; A/B, read at creation)
@@ -730,8 +727,7 @@ struct vmd_script_eval_t {
             std::atomic<uint64_t> settles{0};
             vmd_system_t sys; vmd_trajectory_i traj;        // (mtx) copies of the caller's records: what the deferred settle evaluates from
             // vmd_eval_set_settled_callback: told after every settle the helper (or vmd_eval_wait_settled) has performed, without any lock
-            // of
-            // the eval held.  Written before the evaluation's calls (like lone_pref), read by the helper: atomics, not a lock
+            // of the eval held.  Written before the evaluation's calls (like lone_pref), read by the helper: atomics, not a lock
             std::atomic<void (*)(void*)> on_settled{nullptr};
             std::atomic<void*> on_settled_user{nullptr};
         } helper;
@@ -826,15 +822,14 @@ struct Batch { size_t f0, nb; long blk; size_t nblk; };
 
 void plan_batches(const vmd_script_eval_t* e, size_t beg, size_t end, size_t Bmax, std::vector<Batch>* out);
 
-// filtered evaluation: merge every ready block of the source eval that lies inside [beg, end) into this eval's accumulators
-// and return the sub-ranges that still have to be computed
-// block_ready[b] != 0: block b's partial (d_blocks, block_weights64, temporal rows) is complete.  Where its temporal rows are: a block
-// evaluated by a plain call has them in `values`; a block evaluated AHEAD (read-ahead, spec) or adopted from a source has them in the side
-// buffer `ahead_values` until it is committed - `values` only ever shows frames somebody asked for.  An eval that takes blocks from a
-// source
-// (reuse_blocks, ra_adopt_blocks) must read the rows where they are: a filtered evaluation running BESIDE its source (src/main.cpp:982-1039
-// enqueues both) used to copy rows of blocks the source had evaluated ahead but not yet committed out of `values` - zeros
-// (tests/native/stress_readahead.cpp, "beside").
+// filtered evaluation: merge every ready block of the source eval that lies inside [beg, end) into this eval's accumulators and return the
+// sub-ranges that still have to be computed.
+// block_ready[b] != 0: block b's partial (d_blocks, block_weights64, temporal rows) is complete.
+// Where its temporal rows are: a block evaluated by a plain call has them in `values`; a block evaluated AHEAD (read-ahead, spec) or
+// adopted from a source has them in the side buffer `ahead_values` until it is committed - `values` only ever shows frames somebody asked
+// for.  An eval that takes blocks from a source (reuse_blocks, ra_adopt_blocks) must read the rows where they are: a filtered evaluation
+// running BESIDE its source (src/main.cpp:982-1039 enqueues both) used to copy rows of blocks the source had evaluated ahead but not yet
+// committed out of `values` - zeros (tests/native/stress_readahead.cpp, "beside").
 enum : uint8_t { BLOCK_ROWS_IN_PLACE = 1, BLOCK_ROWS_AHEAD = 2 };
 
 const float* block_rows(const vmd_script_eval_t* src, const PropState* q, size_t blk);

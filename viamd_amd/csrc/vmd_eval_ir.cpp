@@ -12,8 +12,7 @@ uint64_t fnv1a(uint64_t h, const void* data, size_t n) {
 extern "C" vmd_script_ir_t* vmd_ir_create(void) { return new vmd_script_ir_t(); }
 
 // atom pairs one frame of this script asks for (rdf: |ref| x |target|; sdf: K x |target| + K m for the alignment; distance: |a| x |b| of
-// every
-// context): what a host compares with its threshold before it sends a SMALL script to the GPU at all (include/vmd_md_script_shim.h,
+// every context): what a host compares with its threshold before it sends a SMALL script to the GPU at all (include/vmd_md_script_shim.h,
 // vmd_shim_set_min_work; VIAMD's default dataset is ~1e2 atoms, src/main.cpp:522-528)
 extern "C" uint64_t vmd_ir_work_per_frame(const vmd_script_ir_t* ir) {
     if (!ir) return 0;

@@ -124,6 +124,7 @@ extern "C" int vmd_set_option(const char* key, int value) {
     else if (!strcmp(key, "cells_split")) return vmd_hip_set_cells_split(value);
     else if (!strcmp(key, "rdf_blocks")) return vmd_hip_set_rdf_blocks(value);
     else if (!strcmp(key, "rdf_shared_hist")) return vmd_hip_set_rdf_shared_hist(value);
+    else if (!strcmp(key, "rdf_pop")) return vmd_hip_set_rdf_pop(value);
     else if (!strcmp(key, "rdf_nsub")) return vmd_hip_set_rdf_nsub(value);
     else if (!strcmp(key, "rdf_nsub_pct")) return vmd_hip_set_rdf_nsub_pct(value);
     if (!o) return -1;

@@ -233,6 +233,10 @@ struct vmd_binning_t {
     // nbins-1 also from r_min / r_max); everything else takes the exact path
     float fast_k, fast_c, fast_half;   // fast_half = 0.5 - fast_delta
     float fast_far;                    // t' >= fast_far: beyond r_max by a whole bin, i.e. certainly not a hit (pair entries carry such partners)
+    // the same test with fast_delta folded into the constant (r_min = 0 only, vmd_pop_hot0): t2 = fma(v_sqrt_f32(d2), fast_k, fast_delta) is
+    // t' + delta, so "t' at least delta away from every integer" reads  fract(t2) > 2 delta  and floor(t2) is the bin - one compare instead of
+    // add + compare, and no range test: t2 > 0 always, and t2 >= nbins (d > r_max, still below the padded cutoff) lands in a spare bin
+    float fast_c2, fast_2d;            // fast_delta, 2 * fast_delta; fast_2d >= 1 (nothing is ever sure) when the fold does not apply
     int closed;                        // DECISION(D-RDF-OPEN) flipped: hit iff r_min <= d <= r_max.  Only vmd_bin_of looks at it: the fast path is
                                        // never trusted within delta of a bin edge, and d = r_min / r_max sit exactly on one
 };
@@ -253,7 +257,9 @@ __host__ __device__ inline vmd_binning_t vmd_make_binning(float rmin, float rmax
     b.fast_c = -rmin * b.fast_k;
     b.fast_half = 0.5f - delta;
     b.fast_far = b.fnbins + 1.0f;                   // |t' - t| <= delta / 4 << 1: t' >= nbins + 1 implies d > r_max
+    b.fast_c2 = delta; b.fast_2d = 2.0f * delta;
     if (!(delta < 0.25f)) { b.fast_half = -1.0f; b.fast_far = 3.0e38f; }      // degenerate range: nothing is ever "sure", exact path only
+    if (!(delta < 0.25f) || rmin != 0.0f) b.fast_2d = 2.0f;                   // (v_fract_f32 < 1)
     return b;
 }
 __device__ __forceinline__ int vmd_bin_of(const vmd_binning_t& b, float d2) {
@@ -832,20 +838,26 @@ struct vmd_pair_params_t {
     int ry, rz;              // neighbour reach in pencils per axis: 1 (cross-section >= rmax), 2 = split pencils (cross-section >= rmax/2)
     int nsplit;              // > 1 (small launches): a chunk's neighbour pencils are dealt to nsplit work items instead of one - a lone
                              // item is a dependent chain of cold scalar loads (170 us for a one-frame launch, profiles/r03aq)
+    int pop;                 // host side only: variant 0 is launched with the folded pop (instantiation POP = 2); 0 unless r_min == 0 and the fast path is usable at all
     unsigned long long* cols_total;   // device counter or NULL: candidate columns of every launch since the host last reset it (one atomic per
                                       // wave at kernel end): bench.py's "candidate lanes per counted hit" is measured, not modelled
 };
 #define VMD_COUNTER_STRIDE 32    // one 128-byte line per queue counter
 
-// per-wave state of the hit machinery
-struct vmd_wave_acc_t {
+// per-wave state of the hit machinery.  POP is part of the TYPE (the helpers below deduce it): a run-time choice between the pops - three
+// inlined at every drain site, +6 KB of code, 72 instead of 68 VGPRs - cost the kernel 8 % (profiles/r06q_pop_compile_time_ab.txt).
+// 0 = vmd_pop_hot, 1 = vmd_pop_hot0 (folded delta) with a plain ds_read_b32, 2 = vmd_pop_hot0 reading the stack with ds_read_addtid_b32
+template <int POP>
+struct vmd_wave_acc_tt {
+    static constexpr int pop = POP;
     unsigned* hist;       // LDS, nbins
     float* queue;         // LDS, VMD_QUEUE_CAP floats: the wave's hit stack
     unsigned qbase;       // LDS byte address of queue[0] (0 in the emulator build, where qtop is a plain offset)
     unsigned hbase;       // LDS byte address of hist[0] (product build only)
     unsigned qtop;        // wave-uniform: LDS byte address of the top of the stack
     float fast_c;         // bn.fast_c held in a VGPR
-    float fast_k, fast_far;   // variant 2: bn.fast_k / bn.fast_far in VGPRs (an SGPR operand halves the issue rate of v_fma_f32)
+    float fast_k, fast_far;   // bn.fast_k / bn.fast_far in VGPRs (an SGPR operand halves the issue rate of v_fma_f32)
+    float fast_c2;            // bn.fast_c2 in a VGPR (vmd_pop_hot0)
     float* slow;          // LDS, 64 floats behind the stack: hits whose fast binning was not provably exact, waiting for
     unsigned nslow;       // (wave-uniform count) a full wave of them to go through the exact path together
     unsigned ncols;       // wave-uniform: candidate columns (<= 64 hits each) since the last flush
@@ -874,8 +886,10 @@ __device__ __forceinline__ void vmd_bin_add(const vmd_binning_t& bn, unsigned* h
 // The exact path of vmd_bin_add costs ~25 VALU instructions and used to run for 1-2 lanes at a time in every fifth pop.
 // The drain therefore parks uncertain hits on a second, 64-entry LDS stack and sends them through vmd_bin_of a full wave at
 // a time.  Both functions must be called by all lanes of the wave.
-template <unsigned INC>
-__device__ __forceinline__ void vmd_slow_flush(const vmd_binning_t& bn, vmd_wave_acc_t& w, int lane) {
+// (Round 6: an out-of-line version - one copy behind a three-register call instead of one per drain site, 24 -> 17 KB of code - measured
+// 0.7 % SLOWER on c3, profiles/r06s_pop_ab.txt; the copies stay.)
+template <unsigned INC, class W>
+__device__ __forceinline__ void vmd_slow_flush(const vmd_binning_t& bn, W& w, int lane) {
     __builtin_amdgcn_wave_barrier();
     const float v = w.slow[lane];
     __builtin_amdgcn_wave_barrier();
@@ -886,16 +900,16 @@ __device__ __forceinline__ void vmd_slow_flush(const vmd_binning_t& bn, vmd_wave
     w.nslow = 0;
 }
 // parks the lanes of mask `m` (hits whose fast binning was not provably exact) on the slow stack
-template <unsigned INC>
-__device__ __forceinline__ void vmd_slow_park(const vmd_binning_t& bn, vmd_wave_acc_t& w, float d2, unsigned long long m, bool unsure, int lane) {
+template <unsigned INC, class W>
+__device__ __forceinline__ void vmd_slow_park(const vmd_binning_t& bn, W& w, float d2, unsigned long long m, bool unsure, int lane) {
     const unsigned cnt = (unsigned)__popcll(m);
     if (w.nslow + cnt > VMD_WAVE) vmd_slow_flush<INC>(bn, w, lane);
     const unsigned pre = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
     if (unsure) w.slow[w.nslow + pre] = d2;
     w.nslow += cnt;
 }
-template <unsigned INC>
-__device__ __forceinline__ void vmd_bin_add_deferred(const vmd_binning_t& bn, vmd_wave_acc_t& w, float d2, bool active, int lane) {
+template <unsigned INC, class W>
+__device__ __forceinline__ void vmd_bin_add_deferred(const vmd_binning_t& bn, W& w, float d2, bool active, int lane) {
     const float t = fmaf(__builtin_amdgcn_sqrtf(d2), bn.fast_k, w.fast_c);
     const int bin = vmd_floor_to_int(t);                // floor: a negative t (d < rmin) can never pass the range test below
     const float fr = vmd_fract(t);                      // t - floor(t), exact
@@ -905,14 +919,79 @@ __device__ __forceinline__ void vmd_bin_add_deferred(const vmd_binning_t& bn, vm
     const unsigned long long m = VMD_BALLOT(unsure);
     if (m) vmd_slow_park<INC>(bn, w, d2, m, unsure, lane);
 }
+// r_min = 0, delta folded into the constant (vmd_binning_t::fast_c2 / fast_2d): t2 = t' + delta.  sure <=> fract(t2) > 2 delta, i.e. t' lies
+// in (n + delta, n + 1 - delta) with n = floor(t2): the spec's scaled distance, at most delta / 2 away from t', is strictly inside bin n - the
+// argument of vmd_bin_add, one rounding (the fma's) as there.  No range test: t2 >= delta > 0, and a "sure" t2 >= nbins is a distance beyond
+// r_max that the padded cutoff let through (t2 < nbins * sqrt(1.0001) + delta < nbins + 1): it lands in the spare bin nbins, which nobody reads.
+template <unsigned INC, class W>
+__device__ __forceinline__ void vmd_bin_add_deferred0(const vmd_binning_t& bn, W& w, float d2, bool active, int lane) {
+    const float t2 = fmaf(__builtin_amdgcn_sqrtf(d2), w.fast_k, w.fast_c2);
+    const int bin = vmd_floor_to_int(t2);
+    const bool sure = vmd_fract(t2) > bn.fast_2d;
+    if (active && sure) atomicAdd(&w.hist[bin], INC);
+    const bool unsure = active && !sure;
+    const unsigned long long m = VMD_BALLOT(unsure);
+    if (m) vmd_slow_park<INC>(bn, w, d2, m, unsure, lane);
+}
 #ifndef VMD_NO_INLINE_ASM
+// vmd_pop_hot for r_min = 0 (every rdf() VIAMD's scripts write): 7 VALU instructions instead of 9 - v_add_f32 -0.5 and the |t| compare become
+// one compare against 2 delta, the bin range compare goes (spare bin).  (k stays an SGPR operand of the fma: a VGPR would issue faster, and
+// be the 73rd of a kernel that needs 72 for its seventh wave per SIMD.)
+// ADDTID: the stack is read with ds_read_addtid_b32 (address = M0 + 4 * lane): the address add goes too, 6 VALU.
+template <unsigned INC, bool ADDTID, class W>
+__device__ __forceinline__ unsigned long long vmd_pop_hot0(const vmd_binning_t& bn, W& w, unsigned lane4, unsigned inc, float& d2) {
+    unsigned long long m;
+    float t;
+    int b;
+    if (ADDTID) {
+        asm volatile(
+            "s_mov_b32 m0, %[q]\n\t"
+            "s_nop 0\n\t"                                   // SALU write of M0 -> LDS add-TID instruction: one wait state
+            "ds_read_addtid_b32 %[d2]\n\t"
+            "s_waitcnt lgkmcnt(0)\n\t"
+            "v_sqrt_f32 %[t], %[d2]\n\t"
+            "s_nop 0\n\t"
+            "v_fma_f32 %[t], %[k], %[t], %[c]\n\t"
+            "v_cvt_flr_i32_f32 %[b], %[t]\n\t"
+            "v_fract_f32 %[t], %[t]\n\t"
+            "v_cmp_lt_f32 vcc, %[dd], %[t]\n\t"
+            "v_lshl_add_u32 %[b], %[b], 2, %[hb]\n\t"
+            "s_mov_b64 exec, vcc\n\t"
+            "ds_add_u32 %[b], %[inc]\n\t"
+            "s_mov_b64 exec, -1\n\t"
+            "s_not_b64 %[m], vcc\n\t"
+            : [m] "=&s"(m), [t] "=&v"(t), [b] "=&v"(b), [d2] "=&v"(d2)
+            : [q] "s"(w.qtop), [k] "s"(bn.fast_k), [c] "v"(w.fast_c2), [dd] "s"(bn.fast_2d), [hb] "s"(w.hbase), [inc] "v"(inc)
+            : "vcc", "scc", "m0", "memory");
+    } else {
+        asm volatile(
+            "v_add_u32 %[b], %[q], %[l4]\n\t"
+            "ds_read_b32 %[d2], %[b]\n\t"
+            "s_waitcnt lgkmcnt(0)\n\t"
+            "v_sqrt_f32 %[t], %[d2]\n\t"
+            "s_nop 0\n\t"
+            "v_fma_f32 %[t], %[k], %[t], %[c]\n\t"
+            "v_cvt_flr_i32_f32 %[b], %[t]\n\t"
+            "v_fract_f32 %[t], %[t]\n\t"
+            "v_cmp_lt_f32 vcc, %[dd], %[t]\n\t"
+            "v_lshl_add_u32 %[b], %[b], 2, %[hb]\n\t"
+            "s_mov_b64 exec, vcc\n\t"
+            "ds_add_u32 %[b], %[inc]\n\t"
+            "s_mov_b64 exec, -1\n\t"
+            "s_not_b64 %[m], vcc\n\t"
+            : [m] "=&s"(m), [t] "=&v"(t), [b] "=&v"(b), [d2] "=&v"(d2)
+            : [q] "s"(w.qtop), [l4] "v"(lane4), [k] "s"(bn.fast_k), [c] "v"(w.fast_c2), [dd] "s"(bn.fast_2d), [hb] "s"(w.hbase), [inc] "v"(inc)
+            : "vcc", "scc", "memory");
+    }
+    return m;
+}
 // The pop of the hot loop, hand-scheduled: read one full wave of hits from the top of the stack (w.qtop already lowered),
 // fast-bin them (same arithmetic as vmd_bin_add_deferred) and ds_add under EXEC = sure mask; returns the mask of the lanes
 // that must take the exact path.  9 VALU instructions; hipcc needs 14 for the same C++ (two address adds, a v_mov for the
 // second uniform operand of the fma, trunc + sub instead of fract, and a v_cndmask + v_cmp round trip for the ballot).
 // Requires EXEC = all lanes.
-template <unsigned INC>
-__device__ __forceinline__ unsigned long long vmd_pop_hot(const vmd_binning_t& bn, vmd_wave_acc_t& w, unsigned lane4, unsigned inc, float& d2) {
+template <unsigned INC, class W>
+__device__ __forceinline__ unsigned long long vmd_pop_hot(const vmd_binning_t& bn, W& w, unsigned lane4, unsigned inc, float& d2) {
     unsigned long long m;
     float t;
     int b;
@@ -943,8 +1022,8 @@ __device__ __forceinline__ unsigned long long vmd_pop_hot(const vmd_binning_t& b
 #endif
 
 // variant 2: the same with the "certainly outside" test in front of the parking (a pair entry's partner is usually no hit)
-template <unsigned INC>
-__device__ __forceinline__ void vmd_bin_add_deferred_far(const vmd_binning_t& bn, vmd_wave_acc_t& w, float d2, bool active, int lane) {
+template <unsigned INC, class W>
+__device__ __forceinline__ void vmd_bin_add_deferred_far(const vmd_binning_t& bn, W& w, float d2, bool active, int lane) {
     const float t = fmaf(__builtin_amdgcn_sqrtf(d2), bn.fast_k, w.fast_c);
     const int bin = vmd_floor_to_int(t);
     const float fr = vmd_fract(t);
@@ -956,8 +1035,8 @@ __device__ __forceinline__ void vmd_bin_add_deferred_far(const vmd_binning_t& bn
 }
 #ifndef VMD_NO_INLINE_ASM
 // variant 2 pop: 64 pair entries = 128 values, two interleaved binning chains; returns the two park masks.  19 VALU.
-template <unsigned INC>
-__device__ __forceinline__ void vmd_pop_hot2(const vmd_binning_t& bn, vmd_wave_acc_t& w, unsigned lane8 /* 4 * lane: entries are slots of 4 bytes */, unsigned inc, float& a, float& b,
+template <unsigned INC, class W>
+__device__ __forceinline__ void vmd_pop_hot2(const vmd_binning_t& bn, W& w, unsigned lane8 /* 4 * lane: entries are slots of 4 bytes */, unsigned inc, float& a, float& b,
                                              unsigned long long& ma, unsigned long long& mb) {
     unsigned long long sa;
     float ta, tb;
@@ -1009,7 +1088,8 @@ __device__ __forceinline__ void vmd_pop_hot2(const vmd_binning_t& bn, vmd_wave_a
 // partner that is no hit with one compare.  Per pair of columns: v_min + v_cmp + 2 v_mbcnt + v_lshl_add + one ds_write_b64 instead of
 // 2 x (v_cmp + 2 v_mbcnt + v_lshl_add + ds_write_b32): the integer ops of the prefix issue at 4 cycles per wave whatever their
 // operands are (profiles/r02_valu_calibration.txt), so halving them is what counts; the pop handles ~1.85 values per hit.
-__device__ __forceinline__ void vmd_push2(vmd_wave_acc_t& w, bool hit, float a, float b) {
+template <class W>
+__device__ __forceinline__ void vmd_push2(W& w, bool hit, float a, float b) {
     const unsigned long long mask = VMD_BALLOT(hit);
     if (mask) {
         const unsigned pre = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
@@ -1025,8 +1105,8 @@ __device__ __forceinline__ void vmd_push2(vmd_wave_acc_t& w, bool hit, float a, 
 // histogram, so LIFO: no head pointer, no wrap-around); vmd_drain_full pops full waves of 64 so that
 // sqrt + binning + ds_add always run with every lane busy.
 // VARIANT 1: bin the hits in place under the divergent mask (same arithmetic; A/B baseline and cross-check).
-template <int VARIANT, unsigned INC>
-__device__ __forceinline__ void vmd_push(const vmd_binning_t& bn, vmd_wave_acc_t& w, bool hit, float d2) {
+template <int VARIANT, unsigned INC, class W>
+__device__ __forceinline__ void vmd_push(const vmd_binning_t& bn, W& w, bool hit, float d2) {
     if (VARIANT == 1) {
         vmd_bin_add<INC>(bn, w.hist, d2, hit);
         return;
@@ -1040,8 +1120,8 @@ __device__ __forceinline__ void vmd_push(const vmd_binning_t& bn, vmd_wave_acc_t
     }
 }
 
-template <int VARIANT, unsigned INC>
-__device__ __forceinline__ void vmd_drain_full(const vmd_binning_t& bn, vmd_wave_acc_t& w, int lane) {
+template <int VARIANT, unsigned INC, class W>
+__device__ __forceinline__ void vmd_drain_full(const vmd_binning_t& bn, W& w, int lane) {
     if (VARIANT == 1) return;
     if (VARIANT == 2) {
         while (w.qtop - w.qbase >= 4u * VMD_WAVE) {
@@ -1067,19 +1147,22 @@ __device__ __forceinline__ void vmd_drain_full(const vmd_binning_t& bn, vmd_wave
         w.qtop -= 4u * VMD_WAVE;
 #ifndef VMD_NO_INLINE_ASM
         float v;
-        const unsigned long long m = vmd_pop_hot<INC>(bn, w, 4u * (unsigned)lane, INC, v);
+        const unsigned long long m = W::pop == 2 ? vmd_pop_hot0<INC, true>(bn, w, 4u * (unsigned)lane, INC, v)
+                                   : W::pop == 1 ? vmd_pop_hot0<INC, false>(bn, w, 4u * (unsigned)lane, INC, v)
+                                                 : vmd_pop_hot<INC>(bn, w, 4u * (unsigned)lane, INC, v);
         if (m) vmd_slow_park<INC>(bn, w, v, m, (m >> lane) & 1ull, lane);
 #else
         __builtin_amdgcn_wave_barrier();
         const float v = *(const float*)((const char*)w.queue + ((w.qtop - w.qbase) + 4u * (unsigned)lane));
         __builtin_amdgcn_wave_barrier();
-        vmd_bin_add_deferred<INC>(bn, w, v, true, lane);
+        if (W::pop) vmd_bin_add_deferred0<INC>(bn, w, v, true, lane);
+        else vmd_bin_add_deferred<INC>(bn, w, v, true, lane);
 #endif
     }
 }
 
-template <int VARIANT, unsigned INC>
-__device__ __forceinline__ void vmd_drain(const vmd_binning_t& bn, vmd_wave_acc_t& w, int lane) {
+template <int VARIANT, unsigned INC, class W>
+__device__ __forceinline__ void vmd_drain(const vmd_binning_t& bn, W& w, int lane) {
     if (VARIANT == 1) return;
     vmd_drain_full<VARIANT, INC>(bn, w, lane);
     if (VARIANT == 2) {
@@ -1098,7 +1181,8 @@ __device__ __forceinline__ void vmd_drain(const vmd_binning_t& bn, vmd_wave_acc_
     const float v = w.queue[lane];
     __builtin_amdgcn_wave_barrier();
     w.qtop = w.qbase;
-    vmd_bin_add_deferred<INC>(bn, w, v, (unsigned)lane < rem, lane);
+    if (W::pop) vmd_bin_add_deferred0<INC>(bn, w, v, (unsigned)lane < rem, lane);
+    else vmd_bin_add_deferred<INC>(bn, w, v, (unsigned)lane < rem, lane);
     vmd_slow_flush<INC>(bn, w, lane);
 }
 
@@ -1108,7 +1192,8 @@ __device__ __forceinline__ void vmd_drain(const vmd_binning_t& bn, vmd_wave_acc_
 // being masked off).  The SIMT emulator build (tests/emu) has no inline asm and takes the plain C++ vmd_push instead.
 #ifndef VMD_NO_INLINE_ASM
 #define VMD_LDS_ADDRESS(p) ((unsigned)(size_t)(__attribute__((address_space(3))) void*)(p))
-__device__ __forceinline__ void vmd_push_hot(vmd_wave_acc_t& w, float d2, float r2) {
+template <class W>
+__device__ __forceinline__ void vmd_push_hot(W& w, float d2, float r2) {
     unsigned t, n;
     // s_nop: d2 usually comes straight out of a v_pk_fma_f32; the hazard recogniser cannot see into this block and the
     // VOP3P result needs one wait state before a dependent VALU read on gfx940-class parts
@@ -1130,7 +1215,8 @@ __device__ __forceinline__ void vmd_push_hot(vmd_wave_acc_t& w, float d2, float 
         : "vcc", "scc", "memory");
 }
 // same with the own-pencil condition j > i folded in (j wave-uniform, i per lane)
-__device__ __forceinline__ void vmd_push_hot_masked(vmd_wave_acc_t& w, float d2, float r2, unsigned j, unsigned i) {
+template <class W>
+__device__ __forceinline__ void vmd_push_hot_masked(W& w, float d2, float r2, unsigned j, unsigned i) {
     unsigned t, n;
     unsigned long long m;
     asm volatile(
@@ -1155,7 +1241,8 @@ __device__ __forceinline__ void vmd_push_hot_masked(vmd_wave_acc_t& w, float d2,
 // Four columns per asm block: consecutive blocks each drew a hazard nop from the compiler (which cannot see inside) on top
 // of their own, and pinned the order of the packed chains around them; one block per s_load group needs a single wait
 // state and lets hipcc interleave the two packed d2 chains in front of it.
-__device__ __forceinline__ void vmd_push_hot4(vmd_wave_acc_t& w, float d0, float d1, float d2, float d3, float r2) {
+template <class W>
+__device__ __forceinline__ void vmd_push_hot4(W& w, float d0, float d1, float d2, float d3, float r2) {
     unsigned t, n;
     asm volatile(
         "s_nop 0\n\t"
@@ -1209,7 +1296,8 @@ __device__ __forceinline__ void vmd_push_hot4(vmd_wave_acc_t& w, float d0, float
 }
 // own pencil: column k counts only j + k > i.  ik = i - k as signed integers (indices stay far below 2^31), so the four
 // conditions are v_cmp_gt_i32 j, ik with ONE uniform j.
-__device__ __forceinline__ void vmd_push_hot4_masked(vmd_wave_acc_t& w, float d0, float d1, float d2, float d3, float r2,
+template <class W>
+__device__ __forceinline__ void vmd_push_hot4_masked(W& w, float d0, float d1, float d2, float d3, float r2,
                                                      int j, int i0, int i1, int i2, int i3) {
     unsigned t, n;
     unsigned long long m;
@@ -1273,7 +1361,8 @@ __device__ __forceinline__ void vmd_push_hot4_masked(vmd_wave_acc_t& w, float d0
 }
 // variant 2: one pair-column (two candidate columns), a / b = its two d2 values.  The stack is drained after every pair-column, so it
 // never holds more than 64 + 64 entries.
-__device__ __forceinline__ void vmd_push_hot2p(vmd_wave_acc_t& w, float a, float b, float r2) {
+template <class W>
+__device__ __forceinline__ void vmd_push_hot2p(W& w, float a, float b, float r2) {
     unsigned t, n;
     float m;
     asm volatile(
@@ -1298,7 +1387,8 @@ __device__ __forceinline__ void vmd_push_hot2p(vmd_wave_acc_t& w, float a, float
 // own pencil: the chunk against itself.  Lane L holds atom cbeg + L; the pair-column (j, j + 1) counts for the lanes L <= j - cbeg
 // only (unordered pairs once; on lane L == j - cbeg the first value is the atom's distance to itself: the caller replaces it by
 // VMD_JUNK).  lm: that lane mask, wave-uniform.
-__device__ __forceinline__ void vmd_push_hot2p_masked(vmd_wave_acc_t& w, float a, float b, float r2, unsigned long long lm) {
+template <class W>
+__device__ __forceinline__ void vmd_push_hot2p_masked(W& w, float a, float b, float r2, unsigned long long lm) {
     unsigned t, n;
     float m;
     asm volatile(
@@ -1327,8 +1417,8 @@ __device__ __forceinline__ void vmd_push_hot2p_masked(vmd_wave_acc_t& w, float a
 
 // one uniform j segment [ja, jb) against the wave's 64 i atoms.  MASKED: count only j > i (own pencil, same set).
 // SHIFT: the segment is a periodic image, displaced by (sx,sy,sz) (SPEC S3: dx = fl(fl(xi-xj) - sx)).
-template <int VARIANT, unsigned INC, bool MASKED, bool SHIFT>
-__device__ __forceinline__ void vmd_segment_loop(const vmd_pair_params_t& p, vmd_wave_acc_t& w, vmd_cf32* tx, vmd_cf32* ty, vmd_cf32* tz,
+template <int VARIANT, unsigned INC, bool MASKED, bool SHIFT, class W>
+__device__ __forceinline__ void vmd_segment_loop(const vmd_pair_params_t& p, W& w, vmd_cf32* tx, vmd_cf32* ty, vmd_cf32* tz,
                                                  unsigned ja, unsigned jb, float sx, float sy, float sz,
                                                  float xi, float yi, float zi, unsigned i, int lane) {
     const float r2 = p.r2_up;
@@ -1399,25 +1489,30 @@ __device__ __forceinline__ void vmd_segment_loop(const vmd_pair_params_t& p, vmd
     };
     // software pipeline: the scalar loads of the next group are issued before the current group is processed (two register
     // sets, no copies).  Loads may run up to 16 bytes past the segment: the sorted rows carry that much slack.
+    // The ragged end (n mod 8 columns) goes through the same packed group, its columns beyond the segment moved out of every cutoff
+    // (x = -VMD_FAR: never a hit, for valid and padding lanes alike) - until round 6 a one-column loop with the plain C++ push and a
+    // drain of its own: ~1 % of the columns at twice the price (c3: 71.9 -> 71.3 ms per 1 000 frames, profiles/r06r_tail_ab.txt).
+    if (n == 0) return;
     unsigned k = 0;
-    if (n >= 4) {
-        vmd_f4 xa = vmd_uniform_load4(px, 0), ya = vmd_uniform_load4(py, 0), za = vmd_uniform_load4(pz, 0);
-        for (; k + 8 <= n; k += 8) {
-            const vmd_f4 xb = vmd_uniform_load4(px, 4u * k + 16u), yb = vmd_uniform_load4(py, 4u * k + 16u), zb = vmd_uniform_load4(pz, 4u * k + 16u);
-            group(xa, ya, za, k);
-            xa = vmd_uniform_load4(px, 4u * k + 32u); ya = vmd_uniform_load4(py, 4u * k + 32u); za = vmd_uniform_load4(pz, 4u * k + 32u);
-            group(xb, yb, zb, k + 4);
-        }
-        if (k + 4 <= n) { group(xa, ya, za, k); k += 4; }
+    vmd_f4 xa = vmd_uniform_load4(px, 0), ya = vmd_uniform_load4(py, 0), za = vmd_uniform_load4(pz, 0);
+    for (; k + 8 <= n; k += 8) {
+        const vmd_f4 xb = vmd_uniform_load4(px, 4u * k + 16u), yb = vmd_uniform_load4(py, 4u * k + 16u), zb = vmd_uniform_load4(pz, 4u * k + 16u);
+        group(xa, ya, za, k);
+        xa = vmd_uniform_load4(px, 4u * k + 32u); ya = vmd_uniform_load4(py, 4u * k + 32u); za = vmd_uniform_load4(pz, 4u * k + 32u);
+        group(xb, yb, zb, k + 4);
     }
-    for (; k < n; ++k) {
-        float dx = xi - px[k], dy = yi - py[k], dz = zi - pz[k];
-        if (SHIFT) { dx = dx - sx; dy = dy - sy; dz = dz - sz; }
-        const float d2 = vmd_d2(dx, dy, dz);
-        bool hit = d2 < r2;
-        if (MASKED) hit = hit && (ja + k > i);
-        vmd_push<VARIANT, INC>(p.bin, w, hit, d2);
-        if (VARIANT == 2) vmd_drain_full<VARIANT, INC>(p.bin, w, lane);      // pair entries: room for one column beyond the 64 pending
+    while (k < n) {                                   // at most twice: xa / ya / za hold columns k .. k + 3
+        const unsigned r = n - k;
+        vmd_f4 xb = xa, yb = ya, zb = za;
+        if (r > 4) { xb = vmd_uniform_load4(px, 4u * k + 16u); yb = vmd_uniform_load4(py, 4u * k + 16u); zb = vmd_uniform_load4(pz, 4u * k + 16u); }
+        if (r < 4) {
+            xa[3] = -VMD_FAR;
+            if (r < 3) xa[2] = -VMD_FAR;
+            if (r < 2) xa[1] = -VMD_FAR;
+        }
+        group(xa, ya, za, k);
+        k += 4;
+        xa = xb; ya = yb; za = zb;
     }
     vmd_drain_full<VARIANT, INC>(p.bin, w, lane);
 }
@@ -1448,8 +1543,8 @@ __device__ __forceinline__ float vmd_uniform_load1(vmd_cf32* base, unsigned off)
     return *(VMD_UNIFORM_AS const float*)((VMD_UNIFORM_AS const char*)base + off);
 }
 
-template <int VARIANT, unsigned INC, bool SHIFT>
-__device__ __forceinline__ void vmd_segment_pruned(const vmd_pair_params_t& p, vmd_wave_acc_t& w, vmd_cf32* tx, vmd_cf32* ty, vmd_cf32* tz,
+template <int VARIANT, unsigned INC, bool SHIFT, class W>
+__device__ __forceinline__ void vmd_segment_pruned(const vmd_pair_params_t& p, W& w, vmd_cf32* tx, vmd_cf32* ty, vmd_cf32* tz,
                                                    unsigned ja, unsigned jb, float sx, float sy, float sz,
                                                    float xi, float yi, float zi, const vmd_bbox_t& bb, int lane) {
     const float r2 = p.r2_up;
@@ -1530,8 +1625,8 @@ __device__ __forceinline__ void vmd_segment_pruned(const vmd_pair_params_t& p, v
     }
 }
 
-template <int VARIANT, unsigned INC, bool MASKED>
-__device__ __forceinline__ void vmd_segment(const vmd_pair_params_t& p, vmd_wave_acc_t& w, vmd_cf32* st,
+template <int VARIANT, unsigned INC, bool MASKED, class W>
+__device__ __forceinline__ void vmd_segment(const vmd_pair_params_t& p, W& w, vmd_cf32* st,
                                             unsigned ja, unsigned jb, float sx, float sy, float sz,
                                             float xi, float yi, float zi, unsigned i, int lane) {
     vmd_cf32* tx = st;
@@ -1573,12 +1668,12 @@ __device__ __forceinline__ int vmd_next_item(unsigned* counters, int& q, int& tr
 // periodic orthorhombic cell and carries none of this.
 // SHIST: ONE LDS histogram per block (ds_add is atomic across its four waves) instead of one per wave: 10 KB of LDS per block
 // instead of 22.5, so 8 blocks = 8 waves per SIMD fit a CU instead of 7.
-template <int VARIANT_, bool SAME, int CELL, bool SHIST>
+template <int VARIANT_, bool SAME, int CELL, bool SHIST, int POP = 0>
 __global__ __launch_bounds__(256) VMD_SGPR_CAP(96) void k_rdf_pencil(vmd_pair_params_t p) {
     constexpr bool TRI = CELL == 1, OPEN = CELL == 2;
     constexpr bool PRUNE = VARIANT_ == 3;            // variant 3 = variant 0 + bounding-box pruning of the j windows
     constexpr int VARIANT = PRUNE ? 0 : VARIANT_;
-    __shared__ unsigned s_hist[SHIST ? 1 : 4][VMD_MAX_BINS];
+    __shared__ unsigned s_hist[SHIST ? 1 : 4][VMD_MAX_BINS + 2];       // + the spare bin of vmd_pop_hot0 (index nbins; never read)
     __shared__ float s_queue[4][VMD_QUEUE_CAP];
     constexpr unsigned INC = SAME ? 2u : 1u;
     if (p.skip && *p.skip) return;       // set before this launch by the cell build; the host repeats the batch with larger buckets
@@ -1587,7 +1682,7 @@ __global__ __launch_bounds__(256) VMD_SGPR_CAP(96) void k_rdf_pencil(vmd_pair_pa
     const int lane = threadIdx.x & 63;
     const int nbins = p.bin.nbins;
 
-    vmd_wave_acc_t w;
+    vmd_wave_acc_tt<POP> w;
     w.hist = s_hist[SHIST ? 0 : wave];
     w.queue = s_queue[wave];
     w.qbase = VMD_LDS_ADDRESS(s_queue[wave]);
@@ -1598,6 +1693,7 @@ __global__ __launch_bounds__(256) VMD_SGPR_CAP(96) void k_rdf_pencil(vmd_pair_pa
     w.fast_c = vmd_in_vgpr(p.bin.fast_c);
     w.fast_k = vmd_in_vgpr(p.bin.fast_k);
     w.fast_far = vmd_in_vgpr(p.bin.fast_far);
+    w.fast_c2 = vmd_in_vgpr(p.bin.fast_c2);
     w.ncols = 0;
     if (SHIST) {
         for (int b = threadIdx.x; b < nbins; b += 256) s_hist[0][b] = 0u;
@@ -2673,6 +2769,12 @@ extern "C" int vmd_hip_cells_build(void* stream, const float* xyz, size_t frame_
     return 0;
 }
 
+// which pop the hit stack of k_rdf_pencil (variant 0) is drained with when r_min == 0: 0 = vmd_pop_hot (9 VALU instructions), 1 = vmd_pop_hot0
+// (delta folded into the constant, a spare bin instead of the range compare, the stack read with ds_read_addtid_b32: 6).  A/B and cross-check
+// switch; measured on c3: 73.3 -> 71.9 ms per 1 000 frames (profiles/r06q_pop_compile_time_ab.txt; the variant with a plain ds_read, 7
+// instructions, sits between them: profiles/r06p_pop_ab.txt)
+static int g_rdf_pop = 1;
+extern "C" int vmd_hip_set_rdf_pop(int mode) { const int old = g_rdf_pop; if (mode >= 0 && mode <= 1) g_rdf_pop = mode; return old; }
 static int g_rdf_nsub = 0;   // 0 = automatic: about one i-chunk per item
 extern "C" int vmd_hip_set_rdf_nsub(int n) { const int old = g_rdf_nsub; if (n >= 0 && n <= 64) g_rdf_nsub = n; return old; }
 static int g_rdf_nsub_pct = 100;   // automatic nsub = mean chunks per pencil x this / 100
@@ -2730,6 +2832,7 @@ extern "C" int vmd_hip_rdf_pencil(void* stream, const float* sorted_ref, const u
     p.bin = vmd_make_binning(rmin, rmax, nbins, g_rdf_closed);
     p.r2_up = nextafterf(rmax * rmax, 3.0e38f) * 1.0001f;
     p.rpad = rmax * 1.0001f + 1.0e-4f;
+    p.pop = p.bin.fast_2d < 1.0f ? g_rdf_pop : 0;       // the folded test needs r_min == 0 and a usable fast path (vmd_make_binning)
     p.partial = partial;
     p.counts = (unsigned long long*)counts;
     // items per pencil: the mean number of 64-atom i-chunks in a pencil, so that an XCD's waves in flight cover as few frames
@@ -2758,9 +2861,14 @@ extern "C" int vmd_hip_rdf_pencil(void* stream, const float* sorted_ref, const u
     const int which = (variant == 1 ? 6 : variant == 2 ? 12 : variant == 3 ? 18 : 0) + (same_set ? 3 : 0) + cell;
 #define VMD_PENCIL_CASE(n, V, S, C) case n: if (g_rdf_shist) hipLaunchKernelGGL((k_rdf_pencil<V, S, C, true>), g, blk, 0, s, p); \
                                             else hipLaunchKernelGGL((k_rdf_pencil<V, S, C, false>), g, blk, 0, s, p); break;
+    // variant 0 (the default): the pop is part of the instantiation (vmd_wave_acc_tt)
+#define VMD_PENCIL_CASE0(n, S, C) case n: if (p.pop) { if (g_rdf_shist) hipLaunchKernelGGL((k_rdf_pencil<0, S, C, true, 2>), g, blk, 0, s, p); \
+                                                       else hipLaunchKernelGGL((k_rdf_pencil<0, S, C, false, 2>), g, blk, 0, s, p); } \
+                                          else if (g_rdf_shist) hipLaunchKernelGGL((k_rdf_pencil<0, S, C, true, 0>), g, blk, 0, s, p); \
+                                          else hipLaunchKernelGGL((k_rdf_pencil<0, S, C, false, 0>), g, blk, 0, s, p); break;
     switch (which) {
-    VMD_PENCIL_CASE(0, 0, false, 0) VMD_PENCIL_CASE(1, 0, false, 1) VMD_PENCIL_CASE(2, 0, false, 2)
-    VMD_PENCIL_CASE(3, 0, true, 0) VMD_PENCIL_CASE(4, 0, true, 1) VMD_PENCIL_CASE(5, 0, true, 2)
+    VMD_PENCIL_CASE0(0, false, 0) VMD_PENCIL_CASE0(1, false, 1) VMD_PENCIL_CASE0(2, false, 2)
+    VMD_PENCIL_CASE0(3, true, 0) VMD_PENCIL_CASE0(4, true, 1) VMD_PENCIL_CASE0(5, true, 2)
     VMD_PENCIL_CASE(6, 1, false, 0) VMD_PENCIL_CASE(7, 1, false, 1) VMD_PENCIL_CASE(8, 1, false, 2)
     VMD_PENCIL_CASE(9, 1, true, 0) VMD_PENCIL_CASE(10, 1, true, 1) VMD_PENCIL_CASE(11, 1, true, 2)
     VMD_PENCIL_CASE(12, 2, false, 0) VMD_PENCIL_CASE(13, 2, false, 1) VMD_PENCIL_CASE(14, 2, false, 2)
@@ -2774,6 +2882,7 @@ extern "C" int vmd_hip_rdf_pencil(void* stream, const float* sorted_ref, const u
     default: return (int)hipErrorInvalidValue;
     }
 #undef VMD_PENCIL_CASE
+#undef VMD_PENCIL_CASE0
     VMD_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_hist_reduce, dim3((nbins + 255) / 256, (nblocks + 31) / 32), dim3(256), 0, s, (const uint64_t*)partial, nblocks, nbins, counts, skip_flag);
     VMD_LAUNCH_CHECK();
