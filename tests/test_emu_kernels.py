@@ -96,19 +96,21 @@ def test_rdf_hit_compaction_variants(emu_lib, oracle, box3k, variant, shist):
         emu_lib.vmd_set_option(b"rdf_shared_hist", old_sh)
 
 
-@pytest.mark.parametrize("pop", [0, 1])
-def test_rdf_pop_variants(emu_lib, oracle, box3k, pop):
+@pytest.mark.parametrize("pop,shist", [(0, 0), (1, 0), (0, 1), (1, 1)])
+def test_rdf_pop_variants(emu_lib, oracle, box3k, pop, shist):
     """how the hit stack is drained when r_min == 0: the 9-instruction pop against the one with the margin folded into the constant and a
     spare bin instead of the range compare (the C++ twins here; asm against twins on the GPU).  A cutoff-sized last bin, a thin shell
     (r_min > 0 falls back to the old pop), few bins, edge cases"""
     o, h = cases.oxygen(3000), cases.hydrogen(3000)
     old = emu_lib.vmd_set_option(b"rdf_pop", pop)
+    old_sh = emu_lib.vmd_set_option(b"rdf_shared_hist", shist)      # 1 (default): one histogram per block, eight waves per SIMD
     try:
         cases.check_rdf(emu_lib, oracle, box3k[:2], 60.0, [("goo", o, o, 0.0, 12.0), ("goh", o, h, 0.0, 10.0), ("ring", h, o, 2.5, 9.0),
                                                           ("shell", o, o, 11.5, 12.0)])
         cases.rdf_edge_cases(emu_lib, oracle)
     finally:
         emu_lib.vmd_set_option(b"rdf_pop", old)
+        emu_lib.vmd_set_option(b"rdf_shared_hist", old_sh)
 
 
 @pytest.mark.parametrize("sy,sz", [(2, 1), (3, 2)])

@@ -84,6 +84,8 @@ def scenario(seed, scale=1):
     # round 6 (no draws from rng: the scenarios stay what they were): the base sets above are mostly PERIODIC index lists (all, every 2nd,
     # every 3rd from 1, a prefix), which the cell build computes instead of reading - every 6th scenario reads the lists as before; every
     # 4th sends small selections through the pencil buckets as well (cells_small = 0), every 9th measures capacities at batch ends only
+    if seed % 7 == 3:
+        opts["rdf_shared_hist"] = 0                 # wave-private LDS histograms (the default until round 6; seven waves per SIMD)
     if seed % 5 == 3:
         opts["rdf_pop"] = 0                         # the 9-instruction pop (default: margin folded into the constant, ds_read_addtid_b32)
     if seed % 6 == 2:

@@ -98,13 +98,14 @@ def test_rdf_hit_compaction_variants(gpu_lib, oracle, box30k, variant, shist):
         gpu_lib.vmd_set_option(b"rdf_shared_hist", old_sh)
 
 
-@pytest.mark.parametrize("pop", [0, 1])
-def test_rdf_pop_variants(gpu_lib, oracle, box30k, pop):
+@pytest.mark.parametrize("pop,shist", [(0, 0), (1, 0), (0, 1), (1, 1)])
+def test_rdf_pop_variants(gpu_lib, oracle, box30k, pop, shist):
     """how k_rdf_pencil drains its hit stack when r_min == 0: 0 = the 9-instruction pop, 1 = margin folded into the constant + spare bin, the
     stack read with ds_read_addtid_b32 (M0 + 4 * lane; the default) - bit-identical counts, incl. BASELINE config 2's shape.  The exact path
     behind both is the out-of-line vmd_slow_flush_call (the thin shell and the edge cases put most hits on it)"""
     o, h = cases.oxygen(30000), cases.hydrogen(30000)
     old = gpu_lib.vmd_set_option(b"rdf_pop", pop)
+    old_sh = gpu_lib.vmd_set_option(b"rdf_shared_hist", shist)      # 1 (default): one histogram per block, eight waves per SIMD
     try:
         cases.check_rdf(gpu_lib, oracle, box30k[:3], 80.0, [("goo", o, o, 0.0, 12.0), ("goh", o, h, 0.0, 10.0), ("ring", h, o, 2.5, 9.0),
                                                           ("shell", o, o, 11.5, 12.0)], device=True)
@@ -121,6 +122,7 @@ def test_rdf_pop_variants(gpu_lib, oracle, box30k, pop):
         np.testing.assert_array_equal(ev.property_data("g").counts, counts)
     finally:
         gpu_lib.vmd_set_option(b"rdf_pop", old)
+        gpu_lib.vmd_set_option(b"rdf_shared_hist", old_sh)
 
 
 def test_rdf_inline_variant_and_host_staging(gpu_lib, oracle, box30k):

@@ -1668,8 +1668,18 @@ __device__ __forceinline__ int vmd_next_item(unsigned* counters, int& q, int& tr
 // periodic orthorhombic cell and carries none of this.
 // SHIST: ONE LDS histogram per block (ds_add is atomic across its four waves) instead of one per wave: 10 KB of LDS per block
 // instead of 22.5, so 8 blocks = 8 waves per SIMD fit a CU instead of 7.
+// Occupancy (round 6): with ONE histogram per block (SHIST: 10 KB of LDS instead of 22.5) eight blocks fit a CU, and the compiler meets the
+// register budget of an eighth wave per SIMD (64 VGPRs, 80 SGPRs; 111 instead of 92 SGPRs spilled to VGPR lanes, nothing to scratch) when it
+// is told to: c3 71.7 -> 70.4 ms per 1 000 frames, c2 7.35 -> 7.23 (profiles/r06u_eight_waves_ab.txt).  Round 2 had measured the shared
+// histogram at seven waves (no gain) and an SGPR cap of 80 on the kernel of that time (no gain); the two together are the default now.
+// Wave-private histograms keep the budget of seven waves (96 SGPRs, as capped since round 1: LDS admits no more).
+#ifndef VMD_NO_INLINE_ASM
+#define VMD_PENCIL_OCC(SH) __attribute__((amdgpu_waves_per_eu((SH) ? 8 : 7, (SH) ? 8 : 7)))      /* (amdgpu_num_sgpr takes no template-dependent value; seven waves = the cap of 96 SGPRs of rounds 1 - 5) */
+#else
+#define VMD_PENCIL_OCC(SH)
+#endif
 template <int VARIANT_, bool SAME, int CELL, bool SHIST, int POP = 0>
-__global__ __launch_bounds__(256) VMD_SGPR_CAP(96) void k_rdf_pencil(vmd_pair_params_t p) {
+__global__ __launch_bounds__(256) VMD_PENCIL_OCC(SHIST) void k_rdf_pencil(vmd_pair_params_t p) {
     constexpr bool TRI = CELL == 1, OPEN = CELL == 2;
     constexpr bool PRUNE = VARIANT_ == 3;            // variant 3 = variant 0 + bounding-box pruning of the j windows
     constexpr int VARIANT = PRUNE ? 0 : VARIANT_;
@@ -2779,7 +2789,7 @@ static int g_rdf_nsub = 0;   // 0 = automatic: about one i-chunk per item
 extern "C" int vmd_hip_set_rdf_nsub(int n) { const int old = g_rdf_nsub; if (n >= 0 && n <= 64) g_rdf_nsub = n; return old; }
 static int g_rdf_nsub_pct = 100;   // automatic nsub = mean chunks per pencil x this / 100
 extern "C" int vmd_hip_set_rdf_nsub_pct(int n) { const int old = g_rdf_nsub_pct; if (n >= 25 && n <= 800) g_rdf_nsub_pct = n; return old; }
-static int g_rdf_shist = 0;       // one LDS histogram per block instead of one per wave (8 instead of 7 waves per SIMD)
+static int g_rdf_shist = 1;       // one LDS histogram per block instead of one per wave: 8 instead of 7 waves per SIMD (default since round 6, see VMD_PENCIL_OCC)
 extern "C" int vmd_hip_set_rdf_shared_hist(int on) { const int old = g_rdf_shist; g_rdf_shist = on ? 1 : 0; return old; }
 static thread_local int g_pen_ry = 1, g_pen_rz = 1;   // neighbour reach of the pencil walk; the grid handed to the build and to the walk must be cut to match.  Per host thread like g_rdf_closed: the evaluator sets it (choose_grid) right before that thread's launches, two evals on two threads must not race (TSan: profiles/r04r_tsan.txt)
 extern "C" void vmd_hip_set_pencil_reach(int ry, int rz) { g_pen_ry = ry < 1 ? 1 : (ry > 4 ? 4 : ry); g_pen_rz = rz < 1 ? 1 : (rz > 4 ? 4 : rz); }
@@ -2803,7 +2813,7 @@ extern "C" uint64_t vmd_hip_rdf_columns(int reset) {
 }
 static int g_rdf_nsplit = -1;     // small launches split a chunk's neighbour pencils over work items: -1 automatic (5 / 9), 0 never, n > 0 = n parts
 extern "C" int vmd_hip_set_rdf_nsplit(int n) { const int old = g_rdf_nsplit; g_rdf_nsplit = n < -1 ? -1 : (n > 25 ? 25 : n); return old; }
-static int g_rdf_blocks = 2048;   // 8 blocks x 4 waves per CU requested; 6 fit (SGPR budget)
+static int g_rdf_blocks = 2048;   // 8 blocks x 4 waves per CU: all resident with the shared histogram (7 per CU with wave-private ones)
 extern "C" int vmd_hip_rdf_num_blocks(void) { return 2048; }   // capacity of the partial-row scratch
 extern "C" int vmd_hip_set_rdf_blocks(int n) { const int old = g_rdf_blocks; if (n >= 8 && n <= 2048) g_rdf_blocks = n; return old; }
 extern "C" size_t vmd_hip_rdf_partial_words(void) {
