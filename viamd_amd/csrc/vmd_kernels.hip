@@ -853,6 +853,7 @@ struct vmd_wave_acc_tt {
     unsigned* hist;       // LDS, nbins
     float* queue;         // LDS, VMD_QUEUE_CAP floats: the wave's hit stack
     unsigned qbase;       // LDS byte address of queue[0] (0 in the emulator build, where qtop is a plain offset)
+    unsigned qlim;        // qbase + 4 * VMD_WAVE: the stack holds a full wave of hits when qtop reaches it
     unsigned hbase;       // LDS byte address of hist[0] (product build only)
     unsigned qtop;        // wave-uniform: LDS byte address of the top of the stack
     float fast_c;         // bn.fast_c held in a VGPR
@@ -1143,7 +1144,8 @@ __device__ __forceinline__ void vmd_drain_full(const vmd_binning_t& bn, W& w, in
         }
         return;
     }
-    while (w.qtop - w.qbase >= 4u * VMD_WAVE) {
+    while (w.qtop >= w.qlim) {      // (against a kept limit: s_cmp + branch; `qtop - qbase >= 256` is one SALU instruction more per group of four
+                                    // columns, and this loop feels every one of them - c3 -1.2 %, profiles/r06v_salu_ab.txt)
         w.qtop -= 4u * VMD_WAVE;
 #ifndef VMD_NO_INLINE_ASM
         float v;
@@ -1191,6 +1193,7 @@ __device__ __forceinline__ void vmd_drain(const vmd_binning_t& bn, W& w, int lan
 // Requires EXEC = all 64 lanes on entry (true in the segment loops: padding lanes carry far-away coordinates instead of
 // being masked off).  The SIMT emulator build (tests/emu) has no inline asm and takes the plain C++ vmd_push instead.
 #ifndef VMD_NO_INLINE_ASM
+#define VMD_PUSH_NOP "s_nop 0\n\t"      // (dropping it changes neither results nor speed on gfx950, profiles/r06v_salu_ab.txt; the VOP3P -> VALU wait state stays explicit)
 #define VMD_LDS_ADDRESS(p) ((unsigned)(size_t)(__attribute__((address_space(3))) void*)(p))
 template <class W>
 __device__ __forceinline__ void vmd_push_hot(W& w, float d2, float r2) {
@@ -1245,7 +1248,7 @@ template <class W>
 __device__ __forceinline__ void vmd_push_hot4(W& w, float d0, float d1, float d2, float d3, float r2) {
     unsigned t, n;
     asm volatile(
-        "s_nop 0\n\t"
+        VMD_PUSH_NOP
         "v_cmp_gt_f32 vcc, %[r2], %[d0]\n\t"
         "s_cbranch_vccz .Lvmd_p4_0_%=\n\t"
         "v_mbcnt_lo_u32_b32 %[t], vcc_lo, 0\n\t"
@@ -1302,7 +1305,7 @@ __device__ __forceinline__ void vmd_push_hot4_masked(W& w, float d0, float d1, f
     unsigned t, n;
     unsigned long long m;
     asm volatile(
-        "s_nop 0\n\t"
+        VMD_PUSH_NOP
         "v_cmp_gt_f32 vcc, %[r2], %[d0]\n\t"
         "v_cmp_gt_i32 %[m], %[j], %[i0]\n\t"
         "s_and_b64 vcc, vcc, %[m]\n\t"
@@ -1493,14 +1496,21 @@ __device__ __forceinline__ void vmd_segment_loop(const vmd_pair_params_t& p, W& 
     // (x = -VMD_FAR: never a hit, for valid and padding lanes alike) - until round 6 a one-column loop with the plain C++ push and a
     // drain of its own: ~1 % of the columns at twice the price (c3: 71.9 -> 71.3 ms per 1 000 frames, profiles/r06r_tail_ab.txt).
     if (n == 0) return;
-    unsigned k = 0;
     vmd_f4 xa = vmd_uniform_load4(px, 0), ya = vmd_uniform_load4(py, 0), za = vmd_uniform_load4(pz, 0);
-    for (; k + 8 <= n; k += 8) {
-        const vmd_f4 xb = vmd_uniform_load4(px, 4u * k + 16u), yb = vmd_uniform_load4(py, 4u * k + 16u), zb = vmd_uniform_load4(pz, 4u * k + 16u);
-        group(xa, ya, za, k);
-        xa = vmd_uniform_load4(px, 4u * k + 32u); ya = vmd_uniform_load4(py, 4u * k + 32u); za = vmd_uniform_load4(pz, 4u * k + 32u);
-        group(xb, yb, zb, k + 4);
+    // the loop counts BYTES of the j rows and runs against a kept last offset: add + compare + one backward branch per eight columns (counting
+    // columns it was add, compare, two branches, a register copy and a shift; every scalar instruction of this loop shows, profiles/r06v_salu_ab.txt)
+    unsigned off = 0;
+    if (n >= 8) {
+        const unsigned stop = 4u * n - 32u;
+        do {
+            const vmd_f4 xb = vmd_uniform_load4(px, off + 16u), yb = vmd_uniform_load4(py, off + 16u), zb = vmd_uniform_load4(pz, off + 16u);
+            group(xa, ya, za, off >> 2);
+            xa = vmd_uniform_load4(px, off + 32u); ya = vmd_uniform_load4(py, off + 32u); za = vmd_uniform_load4(pz, off + 32u);
+            group(xb, yb, zb, (off >> 2) + 4u);
+            off += 32u;
+        } while (off <= stop);
     }
+    unsigned k = off >> 2;
     while (k < n) {                                   // at most twice: xa / ya / za hold columns k .. k + 3
         const unsigned r = n - k;
         vmd_f4 xb = xa, yb = ya, zb = za;
@@ -1684,6 +1694,8 @@ __global__ __launch_bounds__(256) VMD_PENCIL_OCC(SHIST) void k_rdf_pencil(vmd_pa
     constexpr bool PRUNE = VARIANT_ == 3;            // variant 3 = variant 0 + bounding-box pruning of the j windows
     constexpr int VARIANT = PRUNE ? 0 : VARIANT_;
     __shared__ unsigned s_hist[SHIST ? 1 : 4][VMD_MAX_BINS + 2];       // + the spare bin of vmd_pop_hot0 (index nbins; never read)
+    // (looking at the stack once per EIGHT columns - a 640-float stack, which the one-histogram kernels have the LDS for - measured 1 % slower
+    // than once per four: profiles/r06v_salu_ab.txt)
     __shared__ float s_queue[4][VMD_QUEUE_CAP];
     constexpr unsigned INC = SAME ? 2u : 1u;
     if (p.skip && *p.skip) return;       // set before this launch by the cell build; the host repeats the batch with larger buckets
@@ -1698,6 +1710,7 @@ __global__ __launch_bounds__(256) VMD_PENCIL_OCC(SHIST) void k_rdf_pencil(vmd_pa
     w.qbase = VMD_LDS_ADDRESS(s_queue[wave]);
     w.hbase = VMD_LDS_ADDRESS(s_hist[SHIST ? 0 : wave]);
     w.qtop = w.qbase;
+    w.qlim = w.qbase + 4u * VMD_WAVE;
     w.slow = &s_queue[wave][VMD_QUEUE_CAP - VMD_WAVE];
     w.nslow = 0;
     w.fast_c = vmd_in_vgpr(p.bin.fast_c);
