@@ -36,9 +36,6 @@
 // Wave-uniform read-only data (j coordinates, cell offsets, boxes) is read through the constant address space so
 // that hipcc emits s_load (scalar cache, SGPR operands) instead of per-lane global_load.  Legal because those
 // arrays are only written by earlier kernels.  (The SIMT emulator under tests/emu defines this to nothing.)
-#ifndef VMD_SGPR_CAP
-#define VMD_SGPR_CAP(n) __attribute__((amdgpu_num_sgpr(n)))
-#endif
 // wave-wide predicate mask straight from the compare (HIP's __ballot goes through a 0/1 VGPR and a second v_cmp)
 #ifndef VMD_BALLOT
 #define VMD_BALLOT(pred) __builtin_amdgcn_ballot_w64(pred)
@@ -1668,8 +1665,8 @@ __device__ __forceinline__ int vmd_next_item(unsigned* counters, int& q, int& tr
     return -1;
 }
 
-// SGPR cap: the kernel wants 106 SGPRs (6 waves/SIMD); at 96 a 7th wave fits and the extra spills land in the outer
-// (per work item / per segment) loops.  Measured +1.7 % on c2 (profiles/r01s_ab.txt); a cap of 80 (8 waves) gives it back.
+// Register budget, rounds 1 - 5 (wave-private histograms): the kernel wants 106 SGPRs (6 waves/SIMD); at 96 a 7th wave fits and the extra
+// spills land in the outer (per work item / per segment) loops: +1.7 % on c2 (profiles/r01s_ab.txt).  Round 6: "Occupancy" below.
 // TRI: triclinic cell (SPEC S3t).  Pencils and fine cells live in the unsheared coordinates s_k * L_k; a neighbour pencil's
 // periodic image is displaced by the lattice vector (kx, nb, nc), and because the Cartesian x of its atoms is
 // s_x*Lx + xy*s_y + xz*s_z, the x window is widened by the range that offset takes over the pencil's cross-section.
